@@ -1,0 +1,334 @@
+"""ctypes binding of include/gtcrn_micro_hip.h (the C-ABI drop-in boundary).
+
+The product path is HIP only: if the shared library is missing, or no gfx950
+device is present, everything here raises -- there is no CPU fallback and
+nothing under oracle/ is ever imported from this package.
+"""
+import ctypes
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libgtcrn_micro_hip.so")
+NPARAM_FLOATS = 44938
+NBINS = 257
+
+_c_f32p = ctypes.POINTER(ctypes.c_float)
+_vp = ctypes.c_void_p
+_lib = None
+
+
+class GtcrnError(RuntimeError):
+    pass
+
+
+def lib():
+    """Loads libgtcrn_micro_hip.so (built in-tree by gtcrn_micro_amd.build / __graft_entry__.build)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise GtcrnError(
+            f"{LIB_PATH} not found: run `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(the HIP extension is mandatory, there is no CPU path)")
+    L = ctypes.CDLL(LIB_PATH)
+    ci, cl = ctypes.c_int, ctypes.c_long
+    L.gtcrn_abi_version.restype = ci
+    L.gtcrn_last_error.restype = ctypes.c_char_p
+    L.gtcrn_param_tensors.restype = cl
+    L.gtcrn_param_name.restype = ctypes.c_char_p
+    L.gtcrn_param_name.argtypes = [cl]
+    L.gtcrn_param_numel.restype = cl
+    L.gtcrn_param_numel.argtypes = [cl]
+    L.gtcrn_param_offset.restype = cl
+    L.gtcrn_param_offset.argtypes = [cl]
+    L.gtcrn_model_create.argtypes = [ctypes.POINTER(_vp), _c_f32p, cl, ci]
+    L.gtcrn_model_set_params.argtypes = [_vp, _c_f32p, cl]
+    L.gtcrn_model_destroy.argtypes = [_vp]
+    L.gtcrn_model_destroy.restype = None
+    L.gtcrn_model_reserve.argtypes = [_vp, ci, ci]
+    L.gtcrn_make_window.argtypes = [ci, _c_f32p]
+    L.gtcrn_num_frames.restype = cl
+    L.gtcrn_num_frames.argtypes = [cl]
+    L.gtcrn_stft.argtypes = [_vp, ci, cl, _vp, _vp, cl, cl, cl, _vp]
+    L.gtcrn_stft_frames.argtypes = [_vp, ci, cl, _vp, _vp, _vp]
+    L.gtcrn_istft.argtypes = [_vp, cl, cl, cl, ci, ci, _vp, _vp, _vp]
+    L.gtcrn_forward_spec.argtypes = [_vp, _vp, cl, cl, cl, _vp, cl, cl, cl, ci, ci, _vp]
+    L.gtcrn_forward_wave.argtypes = [_vp, _vp, _vp, ci, cl, _vp, _vp]
+    L.gtcrn_stream_state_bytes.restype = ctypes.c_size_t
+    L.gtcrn_stream_reset.argtypes = [_vp, _vp, ci, _vp]
+    L.gtcrn_stream_step.argtypes = [_vp, _vp, _vp, cl, cl, cl, _vp, cl, cl, cl, ci, ci, _vp]
+    L.gtcrn_stream_import.argtypes = [_vp, _vp, ci, _vp, _vp, ctypes.POINTER(_vp), _vp]
+    L.gtcrn_stream_export.argtypes = [_vp, _vp, ci, _vp, _vp, ctypes.POINTER(_vp), _vp]
+    L.gtcrn_pack_sizes.argtypes = [ctypes.POINTER(cl), ctypes.POINTER(cl)]
+    L.gtcrn_pack_sizes.restype = None
+    L.gtcrn_pack_params_host.argtypes = [_c_f32p, cl, _c_f32p, ctypes.POINTER(ci)]
+    L.gtcrn_debug_enable.argtypes = [_vp, ci]
+    L.gtcrn_debug_tap.restype = cl
+    L.gtcrn_debug_tap.argtypes = [_vp, ctypes.c_char_p, ci, _c_f32p, cl]
+    L.gtcrn_selftest_mfma.argtypes = [ci]
+    L.gtcrn_timing_enable.argtypes = [_vp, ci]
+    L.gtcrn_timing_read.argtypes = [_vp, ci, ctypes.c_char_p, ci, _c_f32p]
+    if L.gtcrn_abi_version() != 1:
+        raise GtcrnError("libgtcrn_micro_hip.so ABI version mismatch")
+    _lib = L
+    return L
+
+
+def _check(rc):
+    if rc < 0:
+        raise GtcrnError(lib().gtcrn_last_error().decode() or f"gtcrn error {rc}")
+    return rc
+
+
+def param_table():
+    """[(name, numel, offset)] of the canonical blob (reference state_dict order)."""
+    L = lib()
+    return [(L.gtcrn_param_name(i).decode(), L.gtcrn_param_numel(i), L.gtcrn_param_offset(i))
+            for i in range(L.gtcrn_param_tensors())]
+
+
+def make_window(kind=0):
+    w = np.empty(512, np.float32)
+    _check(lib().gtcrn_make_window(kind, w.ctypes.data_as(_c_f32p)))
+    return w
+
+
+def num_frames(L):
+    return int(lib().gtcrn_num_frames(int(L)))
+
+
+def pack_params_host(params):
+    """Host-only: the BN-folded slot-space buffers (floats, ints) the kernels consume."""
+    params = np.ascontiguousarray(params, np.float32).ravel()
+    nf, ni = ctypes.c_long(), ctypes.c_long()
+    lib().gtcrn_pack_sizes(ctypes.byref(nf), ctypes.byref(ni))
+    F = np.empty(nf.value, np.float32)
+    I = np.empty(ni.value, np.int32)
+    _check(lib().gtcrn_pack_params_host(params.ctypes.data_as(_c_f32p), params.size, F.ctypes.data_as(_c_f32p),
+                                        I.ctypes.data_as(ctypes.POINTER(ctypes.c_int))))
+    return F, I
+
+
+def _stream_ptr(stream=None):
+    import torch
+    s = stream if stream is not None else torch.cuda.current_stream()
+    return ctypes.c_void_p(s.cuda_stream)
+
+
+def _spec_strides(t):
+    """(sb, sf, st) in elements of a (B,257,T,2) float32 tensor whose last dim is contiguous."""
+    assert t.dim() == 4 and t.shape[1] == NBINS and t.shape[3] == 2
+    if t.stride(3) != 1:
+        raise GtcrnError("the re/im pair of a spectrogram must be contiguous")
+    return t.stride(0), t.stride(1), t.stride(2)
+
+
+def _require_cuda_f32(t, what):
+    import torch
+    if not isinstance(t, torch.Tensor) or not t.is_cuda:
+        raise GtcrnError(f"{what} must be a CUDA (ROCm) tensor: this implementation has no CPU path")
+    if t.dtype != torch.float32:
+        raise GtcrnError(f"{what} must be float32")
+
+
+def stft(wave, window, out=None):
+    """torch.stft(x,512,256,512,window,return_complex=False) on the GPU: (B,L) or (L,) -> (B,257,T,2)/(257,T,2)."""
+    import torch
+    _require_cuda_f32(wave, "wave")
+    squeeze = wave.dim() == 1
+    w2 = wave.reshape(1, -1) if squeeze else wave
+    w2 = w2.contiguous()
+    B, L = w2.shape
+    if L < 257:
+        raise GtcrnError("reflect padding needs more than 256 samples")
+    T = num_frames(L)
+    win = window.to(device=wave.device, dtype=torch.float32).contiguous()
+    spec = out if out is not None else torch.empty((B, NBINS, T, 2), device=wave.device, dtype=torch.float32)
+    sb, sf, st = _spec_strides(spec)
+    with torch.cuda.device(wave.device):
+        _check(lib().gtcrn_stft(w2.data_ptr(), B, L, win.data_ptr(), spec.data_ptr(), sb, sf, st, _stream_ptr()))
+    return spec[0] if squeeze else spec
+
+
+def stft_frames(wave, window):
+    import torch
+    _require_cuda_f32(wave, "wave")
+    w2 = (wave.reshape(1, -1) if wave.dim() == 1 else wave).contiguous()
+    B, L = w2.shape
+    T = num_frames(L)
+    win = window.to(device=wave.device, dtype=torch.float32).contiguous()
+    fr = torch.empty((B, T, 512), device=wave.device, dtype=torch.float32)
+    with torch.cuda.device(wave.device):
+        _check(lib().gtcrn_stft_frames(w2.data_ptr(), B, L, win.data_ptr(), fr.data_ptr(), _stream_ptr()))
+    return fr
+
+
+def istft(spec, window):
+    """torch.istft(view_as_complex(spec),512,256,512,window): (B,257,T,2)/(257,T,2) -> (B,256(T-1))/(256(T-1),)."""
+    import torch
+    _require_cuda_f32(spec, "spec")
+    squeeze = spec.dim() == 3
+    s4 = spec.unsqueeze(0) if squeeze else spec
+    if s4.stride(3) != 1:
+        s4 = s4.contiguous()
+    B, _, T, _ = s4.shape
+    if T < 2:
+        raise GtcrnError("iSTFT needs at least 2 frames")
+    win = window.to(device=spec.device, dtype=torch.float32).contiguous()
+    out = torch.empty((B, 256 * (T - 1)), device=spec.device, dtype=torch.float32)
+    sb, sf, st = _spec_strides(s4)
+    with torch.cuda.device(spec.device):
+        _check(lib().gtcrn_istft(s4.data_ptr(), sb, sf, st, B, T, win.data_ptr(), out.data_ptr(), _stream_ptr()))
+    return out[0] if squeeze else out
+
+
+class Engine:
+    """One model handle (gtcrn_model) on one device."""
+
+    def __init__(self, params, device=0):
+        params = np.ascontiguousarray(params, np.float32).ravel()
+        if params.size != NPARAM_FLOATS:
+            raise GtcrnError(f"parameter blob must hold {NPARAM_FLOATS} floats, got {params.size}")
+        self.device = int(device)
+        h = ctypes.c_void_p()
+        _check(lib().gtcrn_model_create(ctypes.byref(h), params.ctypes.data_as(_c_f32p), params.size, self.device))
+        self._h = h
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().gtcrn_model_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_params(self, params):
+        params = np.ascontiguousarray(params, np.float32).ravel()
+        _check(lib().gtcrn_model_set_params(self._h, params.ctypes.data_as(_c_f32p), params.size))
+
+    def reserve(self, B, T):
+        _check(lib().gtcrn_model_reserve(self._h, int(B), int(T)))
+
+    def _dev(self):
+        import torch
+        return torch.cuda.device(self.device)
+
+    def forward_spec(self, spec, out=None):
+        import torch
+        _require_cuda_f32(spec, "spec")
+        if spec.dim() != 4 or spec.shape[1] != NBINS or spec.shape[3] != 2:
+            raise GtcrnError(f"spec must be (B,257,T,2), got {tuple(spec.shape)}")
+        if spec.device.index != self.device:
+            raise GtcrnError("spec is on a different device than the model")
+        if spec.stride(3) != 1:
+            spec = spec.contiguous()
+        B, _, T, _ = spec.shape
+        if out is None:
+            out = torch.empty((B, NBINS, T, 2), device=spec.device, dtype=torch.float32)
+        isb, isf, ist = _spec_strides(spec)
+        osb, osf, ost = _spec_strides(out)
+        with self._dev():
+            _check(lib().gtcrn_forward_spec(self._h, spec.data_ptr(), isb, isf, ist, out.data_ptr(), osb, osf, ost,
+                                            B, T, _stream_ptr()))
+        return out
+
+    def forward_wave(self, wave, window, out=None):
+        import torch
+        _require_cuda_f32(wave, "wave")
+        w2 = (wave.reshape(1, -1) if wave.dim() == 1 else wave).contiguous()
+        B, L = w2.shape
+        T = num_frames(L)
+        win = window.to(device=wave.device, dtype=torch.float32).contiguous()
+        if out is None:
+            out = torch.empty((B, 256 * (T - 1)), device=wave.device, dtype=torch.float32)
+        with self._dev():
+            _check(lib().gtcrn_forward_wave(self._h, w2.data_ptr(), out.data_ptr(), B, L, win.data_ptr(),
+                                            _stream_ptr()))
+        return out[0] if wave.dim() == 1 else out
+
+    # ---- streaming -----------------------------------------------------------------------
+    @staticmethod
+    def state_bytes():
+        return int(lib().gtcrn_stream_state_bytes())
+
+    def new_state(self, nstreams):
+        import torch
+        st = torch.empty((nstreams, self.state_bytes() // 4), device=f"cuda:{self.device}", dtype=torch.float32)
+        with self._dev():
+            _check(lib().gtcrn_stream_reset(self._h, st.data_ptr(), nstreams, _stream_ptr()))
+        return st
+
+    def stream_step(self, state, spec_t, out=None):
+        import torch
+        _require_cuda_f32(spec_t, "spec")
+        if spec_t.stride(3) != 1:
+            spec_t = spec_t.contiguous()
+        N, _, nfr, _ = spec_t.shape
+        assert state.shape[0] == N
+        if out is None:
+            out = torch.empty((N, NBINS, nfr, 2), device=spec_t.device, dtype=torch.float32)
+        isb, isf, ist = _spec_strides(spec_t)
+        osb, osf, ost = _spec_strides(out)
+        with self._dev():
+            _check(lib().gtcrn_stream_step(self._h, state.data_ptr(), spec_t.data_ptr(), isb, isf, ist,
+                                           out.data_ptr(), osb, osf, ost, N, nfr, _stream_ptr()))
+        return out
+
+    def _cache_ptrs(self, tcn_cache):
+        flat = [tcn_cache[g][k] for g in range(2) for k in range(4)]
+        for g in range(2):
+            for k in range(4):
+                _require_cuda_f32(tcn_cache[g][k], "tcn_cache")
+                assert tcn_cache[g][k].is_contiguous()
+        arr = (ctypes.c_void_p * 8)(*[t.data_ptr() for t in flat])
+        return arr
+
+    def stream_import(self, state, conv_cache, tra_cache, tcn_cache):
+        N = state.shape[0]
+        assert conv_cache.is_contiguous() and tra_cache.is_contiguous()
+        with self._dev():
+            _check(lib().gtcrn_stream_import(self._h, state.data_ptr(), N, conv_cache.data_ptr(),
+                                             tra_cache.data_ptr(), self._cache_ptrs(tcn_cache), _stream_ptr()))
+
+    def stream_export(self, state, conv_cache, tra_cache, tcn_cache):
+        N = state.shape[0]
+        assert conv_cache.is_contiguous() and tra_cache.is_contiguous()
+        with self._dev():
+            _check(lib().gtcrn_stream_export(self._h, state.data_ptr(), N, conv_cache.data_ptr(),
+                                             tra_cache.data_ptr(), self._cache_ptrs(tcn_cache), _stream_ptr()))
+
+    # ---- test / measurement hooks ------------------------------------------------------------
+    def debug_enable(self, on=True):
+        _check(lib().gtcrn_debug_enable(self._h, int(bool(on))))
+
+    def tap(self, name, b, T):
+        F = {"en0": 65, "de3": 65}.get(name, 33)
+        shape = (2, T, 129) if name == "de4" else (16, T, F)
+        dst = np.empty(shape, np.float32)
+        n = lib().gtcrn_debug_tap(self._h, name.encode(), int(b), dst.ctypes.data_as(_c_f32p), dst.size)
+        _check(n)
+        assert n == dst.size, (n, dst.size)
+        return dst
+
+    def timing_enable(self, on=True):
+        _check(lib().gtcrn_timing_enable(self._h, int(bool(on))))
+
+    def timing_read(self):
+        """[(kernel name, ms)] of the kernels launched by the most recent call."""
+        out = []
+        buf = ctypes.create_string_buffer(64)
+        ms = ctypes.c_float()
+        i = 0
+        while lib().gtcrn_timing_read(self._h, i, buf, 64, ctypes.byref(ms)) == 0:
+            out.append((buf.value.decode(), float(ms.value)))
+            i += 1
+        return out
+
+
+def selftest_mfma(device=0):
+    _check(lib().gtcrn_selftest_mfma(int(device)))

@@ -1,0 +1,45 @@
+"""Builds the gfx950 shared library in-tree (gtcrn_micro_amd/libgtcrn_micro_hip.so).
+
+hipcc cross-compiles for gfx950 without a GPU; the .so travels with the repo
+snapshot to the GPU box.  No CPU fallback is built: the library is HIP only.
+"""
+import os
+import subprocess
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIB = os.path.join(HERE, "libgtcrn_micro_hip.so")
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+SOURCES = ["kernels.hip", "api.cpp", "pack.cpp"]
+HEADERS = ["kernels.h", "layout.h", "pack.h", os.path.join("..", "..", "include", "gtcrn_micro_hip.h")]
+
+
+def _stale(target, deps):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build_native(force=False, verbose=False):
+    deps = [os.path.join(CSRC, f) for f in SOURCES + HEADERS]
+    objs = []
+    common = ["-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-result"]
+    for src in SOURCES:
+        obj = os.path.join(CSRC, os.path.splitext(src)[0] + ".o")
+        objs.append(obj)
+        if force or _stale(obj, deps):
+            cmd = [HIPCC, "--offload-arch=gfx950"] + common + ["-c", os.path.join(CSRC, src), "-o", obj]
+            if verbose:
+                print(" ".join(cmd))
+            subprocess.check_call(cmd)
+    if force or _stale(LIB, objs):
+        cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build_native(verbose=True))

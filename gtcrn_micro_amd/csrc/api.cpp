@@ -1,0 +1,557 @@
+// api.cpp -- the C ABI of include/gtcrn_micro_hip.h: handle, workspace, launch sequencing.
+// Host code only; every arithmetic step runs in kernels.hip on the GPU.  There is no CPU fallback:
+// without a gfx950 device gtcrn_model_create fails.
+#include "../../include/gtcrn_micro_hip.h"
+
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "kernels.h"
+#include "layout.h"
+#include "pack.h"
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const std::string& msg) {
+    g_err = msg;
+    return code;
+}
+int hip_fail(hipError_t e, const char* what) {
+    return fail(GTCRN_ERR_HIP, std::string(what) + ": " + hipGetErrorString(e));
+}
+#define HIP_TRY(expr)                                         \
+    do {                                                      \
+        hipError_t e_ = (expr);                               \
+        if (e_ != hipSuccess) return hip_fail(e_, #expr);     \
+    } while (0)
+#define LAUNCH_TRY(expr)                                                         \
+    do {                                                                         \
+        int e_ = (expr);                                                         \
+        if (e_ != 0) return hip_fail(static_cast<hipError_t>(e_), #expr);        \
+    } while (0)
+
+struct Timing {
+    std::string name;
+    hipEvent_t a = nullptr, b = nullptr;
+};
+
+}  // namespace
+
+struct gtcrn_model {
+    int device = 0;
+    float* d_pf = nullptr;   // packed floats (gtl::P_FLOATS)
+    int* d_pi = nullptr;     // packed ints (gtl::P_INTS)
+    float* d_twid = nullptr; // 512 complex twiddles
+    std::vector<int> h_pi;   // host copy of the int tables (slot permutations for the debug taps)
+    // workspace for B x T
+    long cap_bt = 0;         // capacity in (batch * frames)
+    int last_B = 0, last_T = 0;
+    float* d_en0 = nullptr;  // (B,T,65,16)
+    float* d_en[4] = {nullptr, nullptr, nullptr, nullptr};  // en1..en4 (B,T,33,16)
+    float* d_g1 = nullptr;   // gtcn1 output
+    float* d_g2 = nullptr;   // gtcn2 output
+    float* d_spec_a = nullptr;  // frame-major spectrograms for forward_wave (B,T,257,2)
+    float* d_spec_b = nullptr;
+    bool debug = false;
+    float* d_dbg = nullptr;
+    long dbg_cap_bt = 0;
+    float** d_ptr8 = nullptr;  // device table of 8 tcn cache pointers
+    bool timing = false;
+    std::vector<Timing> timings;
+    size_t n_timed = 0;
+};
+
+namespace {
+
+void free_workspace(gtcrn_model* m) {
+    float** bufs[] = {&m->d_en0, &m->d_en[0], &m->d_en[1], &m->d_en[2], &m->d_en[3], &m->d_g1, &m->d_g2,
+                      &m->d_spec_a, &m->d_spec_b};
+    for (float** p : bufs) {
+        if (*p) (void)hipFree(*p);
+        *p = nullptr;
+    }
+    m->cap_bt = 0;
+}
+
+int ensure_workspace(gtcrn_model* m, int B, int T, hipStream_t s) {
+    const long bt = (long)B * T;
+    if (bt > m->cap_bt) {
+        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(s, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone)
+            return fail(GTCRN_ERR_STATE, "workspace too small during stream capture: call gtcrn_model_reserve first");
+        HIP_TRY(hipDeviceSynchronize());
+        free_workspace(m);
+        HIP_TRY(hipMalloc(&m->d_en0, sizeof(float) * bt * 65 * 16));
+        for (int i = 0; i < 4; ++i) HIP_TRY(hipMalloc(&m->d_en[i], sizeof(float) * bt * 528));
+        HIP_TRY(hipMalloc(&m->d_g1, sizeof(float) * bt * 528));
+        HIP_TRY(hipMalloc(&m->d_g2, sizeof(float) * bt * 528));
+        HIP_TRY(hipMalloc(&m->d_spec_a, sizeof(float) * bt * 514));
+        HIP_TRY(hipMalloc(&m->d_spec_b, sizeof(float) * bt * 514));
+        m->cap_bt = bt;
+    }
+    if (m->debug && bt > m->dbg_cap_bt) {
+        if (m->d_dbg) (void)hipFree(m->d_dbg);
+        m->d_dbg = nullptr;
+        HIP_TRY(hipMalloc(&m->d_dbg, sizeof(float) * bt * (3 * 528 + 65 * 16 + 2 * 129)));
+        m->dbg_cap_bt = bt;
+    }
+    return 0;
+}
+
+struct Timer {
+    gtcrn_model* m;
+    hipStream_t s;
+    Timer(gtcrn_model* m_, hipStream_t s_) : m(m_), s(s_) { m->n_timed = 0; }
+    void begin(const char* name) {
+        if (!m->timing) return;
+        if (m->n_timed == m->timings.size()) {
+            Timing t;
+            (void)hipEventCreate(&t.a);
+            (void)hipEventCreate(&t.b);
+            m->timings.push_back(t);
+        }
+        m->timings[m->n_timed].name = name;
+        (void)hipEventRecord(m->timings[m->n_timed].a, s);
+    }
+    void end() {
+        if (!m->timing) return;
+        (void)hipEventRecord(m->timings[m->n_timed].b, s);
+        ++m->n_timed;
+    }
+};
+
+// the five model kernels on one stream; state == nullptr for offline
+int run_model(gtcrn_model* m, const float* spec_in, long isb, long isf, long ist, float* spec_out, long osb, long osf,
+              long ost, int B, int T, float* state, hipStream_t s) {
+    Timer tm(m, s);
+    tm.begin("k_encoder");
+    LAUNCH_TRY(gtk::launch_encoder(spec_in, isb, isf, ist, B, T, m->d_pf, m->d_pi, m->d_en0, m->d_en[0], m->d_en[1],
+                                   m->d_en[2], m->d_en[3], state, s));
+    tm.end();
+    tm.begin("k_gtcn1");
+    LAUNCH_TRY(gtk::launch_gtcn(m->d_en[3], m->d_g1, m->d_pf + gtl::P_GTCN, B, T, state, gtk::ST_G1_H, s));
+    tm.end();
+    tm.begin("k_gtcn2");
+    LAUNCH_TRY(gtk::launch_gtcn(m->d_g1, m->d_g2, m->d_pf + gtl::P_GTCN + gtl::GTCN_SIZE, B, T, state, gtk::ST_G2_H, s));
+    tm.end();
+    tm.begin("k_decoder");
+    LAUNCH_TRY(gtk::launch_decoder(m->d_g2, m->d_en0, m->d_en[0], m->d_en[1], m->d_en[2], m->d_en[3], spec_in, isb, isf,
+                                   ist, spec_out, osb, osf, ost, B, T, m->d_pf, m->d_pi, state,
+                                   m->debug ? m->d_dbg : nullptr, s));
+    tm.end();
+    m->last_B = B;
+    m->last_T = T;
+    return 0;
+}
+
+int check_model(gtcrn_model* m) {
+    if (!m || !m->d_pf) return fail(GTCRN_ERR_STATE, "invalid model handle");
+    HIP_TRY(hipSetDevice(m->device));
+    return 0;
+}
+
+int upload_params(gtcrn_model* m, const float* h_params, long n) {
+    std::vector<float> F(gtl::P_FLOATS);
+    std::vector<int> I(gtl::P_INTS);
+    std::string err;
+    if (gtcrn::pack_params(h_params, n, F.data(), I.data(), err) != 0) return fail(GTCRN_ERR_ARG, err);
+    HIP_TRY(hipMemcpy(m->d_pf, F.data(), sizeof(float) * gtl::P_FLOATS, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(m->d_pi, I.data(), sizeof(int) * gtl::P_INTS, hipMemcpyHostToDevice));
+    m->h_pi = I;
+    return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int gtcrn_abi_version(void) { return GTCRN_ABI_VERSION; }
+const char* gtcrn_last_error(void) { return g_err.c_str(); }
+
+long gtcrn_param_tensors(void) { return (long)gtcrn::param_table().size(); }
+const char* gtcrn_param_name(long i) {
+    const auto& t = gtcrn::param_table();
+    return (i < 0 || i >= (long)t.size()) ? nullptr : t[i].name.c_str();
+}
+long gtcrn_param_numel(long i) {
+    const auto& t = gtcrn::param_table();
+    return (i < 0 || i >= (long)t.size()) ? -1 : t[i].numel;
+}
+long gtcrn_param_offset(long i) {
+    const auto& t = gtcrn::param_table();
+    return (i < 0 || i >= (long)t.size()) ? -1 : t[i].offset;
+}
+
+// Host-only view of the packer for the CPU test-suite (no device needed): fills the slot-space
+// buffers the kernels consume.  Sizes: gtcrn_pack_sizes().
+void gtcrn_pack_sizes(long* n_floats, long* n_ints) {
+    if (n_floats) *n_floats = gtl::P_FLOATS;
+    if (n_ints) *n_ints = gtl::P_INTS;
+}
+int gtcrn_pack_params_host(const float* h_params, long n, float* h_f, int* h_i) {
+    std::string err;
+    if (gtcrn::pack_params(h_params, n, h_f, h_i, err) != 0) return fail(GTCRN_ERR_ARG, err);
+    return 0;
+}
+
+int gtcrn_model_create(gtcrn_model** out, const float* h_params, long n_floats, int device) {
+    if (!out || !h_params) return fail(GTCRN_ERR_ARG, "null argument");
+    *out = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return fail(GTCRN_ERR_DEVICE, "no HIP device: this library has no CPU path");
+    if (device < 0 || device >= ndev) return fail(GTCRN_ERR_ARG, "device ordinal out of range");
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, device));
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(GTCRN_ERR_DEVICE, std::string("built for gfx950 only, device is ") + prop.gcnArchName);
+    HIP_TRY(hipSetDevice(device));
+    gtcrn_model* m = new gtcrn_model();
+    m->device = device;
+    hipError_t e = hipMalloc(&m->d_pf, sizeof(float) * gtl::P_FLOATS);
+    if (e == hipSuccess) e = hipMalloc(&m->d_pi, sizeof(int) * gtl::P_INTS);
+    if (e == hipSuccess) e = hipMalloc(&m->d_twid, sizeof(float) * 1024);
+    if (e == hipSuccess) e = hipMalloc(&m->d_ptr8, sizeof(float*) * 8);
+    if (e != hipSuccess) {
+        gtcrn_model_destroy(m);
+        return hip_fail(e, "hipMalloc(params)");
+    }
+    std::vector<float> tw(1024);
+    for (int k = 0; k < 256; ++k) {
+        tw[2 * k] = (float)std::cos(-2.0 * M_PI * k / 256.0);
+        tw[2 * k + 1] = (float)std::sin(-2.0 * M_PI * k / 256.0);
+        tw[512 + 2 * k] = (float)std::cos(-2.0 * M_PI * k / 512.0);
+        tw[512 + 2 * k + 1] = (float)std::sin(-2.0 * M_PI * k / 512.0);
+    }
+    e = hipMemcpy(m->d_twid, tw.data(), sizeof(float) * 1024, hipMemcpyHostToDevice);
+    if (e != hipSuccess) {
+        gtcrn_model_destroy(m);
+        return hip_fail(e, "hipMemcpy(twiddles)");
+    }
+    int rc = upload_params(m, h_params, n_floats);
+    if (rc == 0) {
+        int le = gtk::configure_kernels();
+        if (le != 0) rc = hip_fail(static_cast<hipError_t>(le), "hipFuncSetAttribute(dynamic LDS)");
+    }
+    if (rc != 0) {
+        gtcrn_model_destroy(m);
+        return rc;
+    }
+    *out = m;
+    return 0;
+}
+
+int gtcrn_model_set_params(gtcrn_model* m, const float* h_params, long n_floats) {
+    int rc = check_model(m);
+    if (rc) return rc;
+    HIP_TRY(hipDeviceSynchronize());
+    return upload_params(m, h_params, n_floats);
+}
+
+void gtcrn_model_destroy(gtcrn_model* m) {
+    if (!m) return;
+    (void)hipSetDevice(m->device);
+    (void)hipDeviceSynchronize();
+    free_workspace(m);
+    if (m->d_dbg) (void)hipFree(m->d_dbg);
+    if (m->d_pf) (void)hipFree(m->d_pf);
+    if (m->d_pi) (void)hipFree(m->d_pi);
+    if (m->d_twid) (void)hipFree(m->d_twid);
+    if (m->d_ptr8) (void)hipFree(m->d_ptr8);
+    for (auto& t : m->timings) {
+        if (t.a) (void)hipEventDestroy(t.a);
+        if (t.b) (void)hipEventDestroy(t.b);
+    }
+    delete m;
+}
+
+int gtcrn_model_reserve(gtcrn_model* m, int B, int T) {
+    int rc = check_model(m);
+    if (rc) return rc;
+    if (B < 1 || T < 1) return fail(GTCRN_ERR_ARG, "B and T must be >= 1");
+    return ensure_workspace(m, B, T, nullptr);
+}
+
+int gtcrn_make_window(int kind, float* h_w512) {
+    if (!h_w512 || (kind != 0 && kind != 1)) return fail(GTCRN_ERR_ARG, "window kind must be 0 (sqrt-Hann) or 1 (Hann)");
+    gtcrn::make_window(kind, h_w512);
+    return 0;
+}
+
+long gtcrn_num_frames(long L) { return 1 + L / 256; }
+
+// twiddles are per model; the standalone STFT entry points keep one table per device
+namespace {
+float* g_twid[16] = {nullptr};
+int device_twiddles(float** out) {
+    int dev = 0;
+    HIP_TRY(hipGetDevice(&dev));
+    if (dev < 0 || dev >= 16) return fail(GTCRN_ERR_DEVICE, "device ordinal >= 16");
+    if (!g_twid[dev]) {
+        std::vector<float> tw(1024);
+        for (int k = 0; k < 256; ++k) {
+            tw[2 * k] = (float)std::cos(-2.0 * M_PI * k / 256.0);
+            tw[2 * k + 1] = (float)std::sin(-2.0 * M_PI * k / 256.0);
+            tw[512 + 2 * k] = (float)std::cos(-2.0 * M_PI * k / 512.0);
+            tw[512 + 2 * k + 1] = (float)std::sin(-2.0 * M_PI * k / 512.0);
+        }
+        float* d = nullptr;
+        HIP_TRY(hipMalloc(&d, sizeof(float) * 1024));
+        HIP_TRY(hipMemcpy(d, tw.data(), sizeof(float) * 1024, hipMemcpyHostToDevice));
+        g_twid[dev] = d;
+    }
+    *out = g_twid[dev];
+    return 0;
+}
+}  // namespace
+
+int gtcrn_stft(const float* d_wave, int B, long L, const float* d_win, float* d_spec, long sb, long sf, long st,
+               void* stream) {
+    if (!d_wave || !d_win || !d_spec || B < 1) return fail(GTCRN_ERR_ARG, "null pointer or B < 1");
+    if (L < 257) return fail(GTCRN_ERR_ARG, "reflect padding needs L > 256 samples");
+    float* tw = nullptr;
+    int rc = device_twiddles(&tw);
+    if (rc) return rc;
+    LAUNCH_TRY(gtk::launch_stft(d_wave, B, L, (int)gtcrn_num_frames(L), d_win, tw, d_spec, sb, sf, st, nullptr,
+                                (hipStream_t)stream));
+    return 0;
+}
+
+int gtcrn_stft_frames(const float* d_wave, int B, long L, const float* d_win, float* d_frames, void* stream) {
+    if (!d_wave || !d_win || !d_frames || B < 1) return fail(GTCRN_ERR_ARG, "null pointer or B < 1");
+    if (L < 257) return fail(GTCRN_ERR_ARG, "reflect padding needs L > 256 samples");
+    float* tw = nullptr;
+    int rc = device_twiddles(&tw);
+    if (rc) return rc;
+    LAUNCH_TRY(gtk::launch_stft(d_wave, B, L, (int)gtcrn_num_frames(L), d_win, tw, nullptr, 0, 0, 0, d_frames,
+                                (hipStream_t)stream));
+    return 0;
+}
+
+int gtcrn_istft(const float* d_spec, long sb, long sf, long st, int B, int T, const float* d_win, float* d_wave,
+                void* stream) {
+    if (!d_spec || !d_win || !d_wave || B < 1) return fail(GTCRN_ERR_ARG, "null pointer or B < 1");
+    if (T < 2) return fail(GTCRN_ERR_ARG, "iSTFT needs T >= 2 frames");
+    float* tw = nullptr;
+    int rc = device_twiddles(&tw);
+    if (rc) return rc;
+    LAUNCH_TRY(gtk::launch_istft(d_spec, sb, sf, st, B, T, d_win, tw, d_wave, (hipStream_t)stream));
+    return 0;
+}
+
+int gtcrn_forward_spec(gtcrn_model* m, const float* d_spec_in, long isb, long isf, long ist, float* d_spec_out,
+                       long osb, long osf, long ost, int B, int T, void* stream) {
+    int rc = check_model(m);
+    if (rc) return rc;
+    if (!d_spec_in || !d_spec_out) return fail(GTCRN_ERR_ARG, "null spectrogram pointer");
+    if (B < 1 || T < 1) return fail(GTCRN_ERR_ARG, "B and T must be >= 1");
+    hipStream_t s = (hipStream_t)stream;
+    rc = ensure_workspace(m, B, T, s);
+    if (rc) return rc;
+    return run_model(m, d_spec_in, isb, isf, ist, d_spec_out, osb, osf, ost, B, T, nullptr, s);
+}
+
+int gtcrn_forward_wave(gtcrn_model* m, const float* d_wave, float* d_wave_out, int B, long L, const float* d_win,
+                       void* stream) {
+    int rc = check_model(m);
+    if (rc) return rc;
+    if (!d_wave || !d_wave_out || !d_win) return fail(GTCRN_ERR_ARG, "null pointer");
+    if (B < 1) return fail(GTCRN_ERR_ARG, "B must be >= 1");
+    if (L < 257) return fail(GTCRN_ERR_ARG, "reflect padding needs L > 256 samples");
+    hipStream_t s = (hipStream_t)stream;
+    const int T = (int)gtcrn_num_frames(L);
+    rc = ensure_workspace(m, B, T, s);
+    if (rc) return rc;
+    // internal spectrograms are frame-major (B,T,257,2): sb = T*514, sf = 2, st = 514
+    const long sb = (long)T * 514, sf = 2, st = 514;
+    const bool timing = m->timing;
+    hipEvent_t e0 = nullptr, e1 = nullptr, e2 = nullptr, e3 = nullptr;
+    if (timing) {
+        (void)hipEventCreate(&e0); (void)hipEventCreate(&e1); (void)hipEventCreate(&e2); (void)hipEventCreate(&e3);
+        (void)hipEventRecord(e0, s);
+    }
+    LAUNCH_TRY(gtk::launch_stft(d_wave, B, L, T, d_win, m->d_twid, m->d_spec_a, sb, sf, st, nullptr, s));
+    if (timing) (void)hipEventRecord(e1, s);
+    rc = run_model(m, m->d_spec_a, sb, sf, st, m->d_spec_b, sb, sf, st, B, T, nullptr, s);
+    if (rc) return rc;
+    if (timing) (void)hipEventRecord(e2, s);
+    LAUNCH_TRY(gtk::launch_istft(m->d_spec_b, sb, sf, st, B, T, d_win, m->d_twid, d_wave_out, s));
+    if (timing) {
+        (void)hipEventRecord(e3, s);
+        // append the two FFT kernels to the timing list (events owned by the list from here on)
+        Timing a; a.name = "k_stft"; a.a = e0; a.b = e1;
+        Timing b; b.name = "k_istft"; b.a = e2; b.b = e3;
+        if (m->timings.size() > m->n_timed) {
+            for (size_t i = m->n_timed; i < m->timings.size(); ++i) {
+                (void)hipEventDestroy(m->timings[i].a);
+                (void)hipEventDestroy(m->timings[i].b);
+            }
+            m->timings.resize(m->n_timed);
+        }
+        m->timings.push_back(a);
+        m->timings.push_back(b);
+        m->n_timed += 2;
+    }
+    return 0;
+}
+
+size_t gtcrn_stream_state_bytes(void) { return sizeof(float) * gtk::ST_FLOATS; }
+
+int gtcrn_stream_reset(gtcrn_model* m, void* d_state, int nstreams, void* stream) {
+    int rc = check_model(m);
+    if (rc) return rc;
+    if (!d_state || nstreams < 1) return fail(GTCRN_ERR_ARG, "null state or nstreams < 1");
+    HIP_TRY(hipMemsetAsync(d_state, 0, gtcrn_stream_state_bytes() * nstreams, (hipStream_t)stream));
+    return 0;
+}
+
+int gtcrn_stream_step(gtcrn_model* m, void* d_state, const float* d_spec_t, long isb, long isf, long ist,
+                      float* d_spec_out_t, long osb, long osf, long ost, int nstreams, int nframes, void* stream) {
+    int rc = check_model(m);
+    if (rc) return rc;
+    if (!d_state || !d_spec_t || !d_spec_out_t) return fail(GTCRN_ERR_ARG, "null pointer");
+    if (nstreams < 1 || nframes < 1) return fail(GTCRN_ERR_ARG, "nstreams and nframes must be >= 1");
+    hipStream_t s = (hipStream_t)stream;
+    rc = ensure_workspace(m, nstreams, nframes, s);
+    if (rc) return rc;
+    return run_model(m, d_spec_t, isb, isf, ist, d_spec_out_t, osb, osf, ost, nstreams, nframes, (float*)d_state, s);
+}
+
+static int state_convert(gtcrn_model* m, void* d_state, int nstreams, float* conv, float* tra,
+                         float* const* tcn8, int dir, void* stream) {
+    int rc = check_model(m);
+    if (rc) return rc;
+    if (!d_state || !conv || !tra || !tcn8 || nstreams < 1) return fail(GTCRN_ERR_ARG, "null pointer or nstreams < 1");
+    hipStream_t s = (hipStream_t)stream;
+    HIP_TRY(hipMemcpyAsync(m->d_ptr8, tcn8, sizeof(float*) * 8, hipMemcpyHostToDevice, s));
+    LAUNCH_TRY(gtk::launch_state_convert((float*)d_state, nstreams, conv, tra, m->d_ptr8, m->d_pi, dir, s));
+    return 0;
+}
+
+int gtcrn_stream_import(gtcrn_model* m, void* d_state, int nstreams, const float* d_conv_cache,
+                        const float* d_tra_cache, const float* const* d_tcn_cache8, void* stream) {
+    return state_convert(m, d_state, nstreams, const_cast<float*>(d_conv_cache), const_cast<float*>(d_tra_cache),
+                         const_cast<float* const*>(reinterpret_cast<const float* const*>(d_tcn_cache8)), 0, stream);
+}
+
+int gtcrn_stream_export(gtcrn_model* m, const void* d_state, int nstreams, float* d_conv_cache, float* d_tra_cache,
+                        float* const* d_tcn_cache8, void* stream) {
+    return state_convert(m, const_cast<void*>(d_state), nstreams, d_conv_cache, d_tra_cache, d_tcn_cache8, 1, stream);
+}
+
+int gtcrn_debug_enable(gtcrn_model* m, int on) {
+    int rc = check_model(m);
+    if (rc) return rc;
+    m->debug = on != 0;
+    return 0;
+}
+
+long gtcrn_debug_tap(gtcrn_model* m, const char* name, int b, float* h_dst, long cap) {
+    int rc = check_model(m);
+    if (rc) return rc;
+    if (!name || !h_dst) return fail(GTCRN_ERR_ARG, "null argument");
+    const int B = m->last_B, T = m->last_T;
+    if (B < 1 || b < 0 || b >= B) return fail(GTCRN_ERR_ARG, "no forward recorded or batch index out of range");
+    const std::string nm(name);
+    const long bt = (long)B * T;
+    const float* src = nullptr;
+    int F = 33, perm = -1;
+    if (nm == "en0") { src = m->d_en0; F = 65; perm = 0; }
+    else if (nm == "en1") { src = m->d_en[0]; perm = 1; }
+    else if (nm == "en2") { src = m->d_en[1]; perm = 2; }
+    else if (nm == "en3") { src = m->d_en[2]; perm = 3; }
+    else if (nm == "en4") { src = m->d_en[3]; perm = 4; }
+    else if (nm == "gtcn1") { src = m->d_g1; perm = 4; }
+    else if (nm == "gtcn2") { src = m->d_g2; perm = 4; }
+    else if (nm == "de0" || nm == "de1" || nm == "de2" || nm == "de3" || nm == "de4") {
+        if (!m->debug || !m->d_dbg || m->dbg_cap_bt < bt)
+            return fail(GTCRN_ERR_STATE, "decoder taps need gtcrn_debug_enable(m,1) before the forward");
+        const int j = nm[2] - '0';
+        if (j < 3) { src = m->d_dbg + (long)j * bt * 528; perm = 5 + j; }
+        else if (j == 3) { src = m->d_dbg + 3 * bt * 528; F = 65; perm = 8; }
+        else {
+            // de4 is stored as (B,2,T,129) already
+            const long nel = 2L * T * 129;
+            if (cap < nel) return fail(GTCRN_ERR_ARG, "destination too small");
+            HIP_TRY(hipDeviceSynchronize());
+            HIP_TRY(hipMemcpy(h_dst, m->d_dbg + 3 * bt * 528 + bt * 65 * 16 + (long)b * nel, sizeof(float) * nel,
+                              hipMemcpyDeviceToHost));
+            return nel;
+        }
+    } else {
+        return fail(GTCRN_ERR_ARG, "unknown tap name");
+    }
+    const long nel = 16L * T * F;
+    if (cap < nel) return fail(GTCRN_ERR_ARG, "destination too small");
+    std::vector<float> tmp(nel);
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(tmp.data(), src + (long)b * T * F * 16, sizeof(float) * nel, hipMemcpyDeviceToHost));
+    const int* pm = m->h_pi.data() + gtl::I_PERM + perm * 16;
+    for (int t = 0; t < T; ++t)
+        for (int f = 0; f < F; ++f)
+            for (int s = 0; s < 16; ++s) h_dst[((long)pm[s] * T + t) * F + f] = tmp[((long)t * F + f) * 16 + s];
+    return nel;
+}
+
+int gtcrn_selftest_mfma(int device) {
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(GTCRN_ERR_DEVICE, "no HIP device");
+    HIP_TRY(hipSetDevice(device));
+    float hA[64], hB[64], hC[256], hD[256], ref[256];
+    for (int i = 0; i < 16; ++i)
+        for (int k = 0; k < 4; ++k) hA[i * 4 + k] = (float)(1 + i * 5 + k * 3);       // asymmetric integers
+    for (int k = 0; k < 4; ++k)
+        for (int j = 0; j < 16; ++j) hB[k * 16 + j] = (float)(2 + k * 7 - j * 2 + (j * j) % 5);
+    for (int i = 0; i < 256; ++i) hC[i] = (float)((i * 37) % 101 - 50);
+    for (int i = 0; i < 16; ++i)
+        for (int j = 0; j < 16; ++j) {
+            float s = hC[i * 16 + j];
+            for (int k = 0; k < 4; ++k) s += hA[i * 4 + k] * hB[k * 16 + j];
+            ref[i * 16 + j] = s;
+        }
+    float *dA = nullptr, *dB = nullptr, *dC = nullptr, *dD = nullptr;
+    HIP_TRY(hipMalloc(&dA, sizeof(hA))); HIP_TRY(hipMalloc(&dB, sizeof(hB)));
+    HIP_TRY(hipMalloc(&dC, sizeof(hC))); HIP_TRY(hipMalloc(&dD, sizeof(hD)));
+    HIP_TRY(hipMemcpy(dA, hA, sizeof(hA), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(dB, hB, sizeof(hB), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(dC, hC, sizeof(hC), hipMemcpyHostToDevice));
+    LAUNCH_TRY(gtk::launch_selftest(dA, dB, dC, dD, nullptr));
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(hD, dD, sizeof(hD), hipMemcpyDeviceToHost));
+    (void)hipFree(dA); (void)hipFree(dB); (void)hipFree(dC); (void)hipFree(dD);
+    int bad = 0;
+    for (int i = 0; i < 256; ++i) bad += hD[i] != ref[i];
+    if (bad) return fail(GTCRN_ERR_DEVICE, "MFMA 16x16x4 f32 lane map differs from the assumed one (" +
+                                               std::to_string(bad) + " of 256 elements)");
+    return 0;
+}
+
+int gtcrn_timing_enable(gtcrn_model* m, int on) {
+    int rc = check_model(m);
+    if (rc) return rc;
+    m->timing = on != 0;
+    return 0;
+}
+
+int gtcrn_timing_read(gtcrn_model* m, int idx, char* name, int name_cap, float* ms) {
+    int rc = check_model(m);
+    if (rc) return rc;
+    if (idx < 0 || (size_t)idx >= m->n_timed || !ms) return fail(GTCRN_ERR_ARG, "timing index out of range");
+    Timing& t = m->timings[idx];
+    HIP_TRY(hipEventSynchronize(t.b));
+    HIP_TRY(hipEventElapsedTime(ms, t.a, t.b));
+    if (name && name_cap > 0) {
+        std::strncpy(name, t.name.c_str(), name_cap - 1);
+        name[name_cap - 1] = 0;
+    }
+    return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,47 @@
+// kernels.h -- launch interface between api.cpp (host) and kernels.hip (gfx950 device code).
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace gtk {
+
+// workgroup geometry: 8 waves per utterance/stream, time chunks of 16 frames.
+// 16 frames x 33 bins = 528 positions = exactly 33 MFMA tiles of 16 positions.
+constexpr int TC = 16;
+constexpr int NW = 8;
+constexpr int NTHR = NW * 64;
+constexpr int NT2 = TC * 33 / 16;
+constexpr int TPW = (NT2 + NW - 1) / NW;
+static_assert(TC * 33 % 16 == 0, "chunk must be a whole number of tiles");
+
+// STFT / iSTFT geometry
+constexpr int FRAMES_PER_WAVE = 4;   // frames each of the 4 waves of a k_stft workgroup transforms
+constexpr int ISTFT_BLOCKS = 15;     // hop blocks one k_istft workgroup emits (from 16 frames)
+
+// per-stream state (floats).  Rings are indexed by absolute frame number: the conv/TRA rings
+// hold 2 rows (row = frame & 1), TCN block k holds 2d rows (row = frame mod 2d, d = 2^k).
+constexpr int ST_POS = 0;                        // int frame counter (+3 pad)
+constexpr int ST_ENC_H = 4;                      // [3 blocks][2][33][16]
+constexpr int ST_ENC_E = ST_ENC_H + 3 * 2 * 33 * 16;   // [3][2][8]
+constexpr int ST_G1_H = ST_ENC_E + 48;           // [30 rows][33][16], block k at row 2*(2^k - 1)
+constexpr int ST_G2_H = ST_G1_H + 30 * 33 * 16;
+constexpr int ST_DEC_H = ST_G2_H + 30 * 33 * 16;
+constexpr int ST_DEC_E = ST_DEC_H + 3 * 2 * 33 * 16;
+constexpr int ST_FLOATS = ST_DEC_E + 48;         // 38116 floats = 152 464 B per stream
+
+int configure_kernels();
+int launch_stft(const float* wave, int B, long L, int T, const float* win, const float* twid, float* spec, long sb,
+                long sf, long st, float* frames, hipStream_t s);
+int launch_istft(const float* spec, long sb, long sf, long st, int B, int T, const float* win, const float* twid,
+                 float* wave, hipStream_t s);
+int launch_encoder(const float* spec, long sb, long sf, long st, int B, int T, const float* PF, const int* PI,
+                   float* en0, float* en1, float* en2, float* en3, float* en4, float* state, hipStream_t s);
+int launch_gtcn(const float* xin, float* xout, const float* P, int B, int T, float* state, int st_off,
+                hipStream_t s);
+int launch_decoder(const float* xg, const float* en0, const float* en1, const float* en2, const float* en3,
+                   const float* en4, const float* spec, long sb, long sf, long st, float* out, long osb, long osf,
+                   long ost, int B, int T, const float* PF, const int* PI, float* state, float* dbg, hipStream_t s);
+int launch_state_convert(float* state, int N, float* conv, float* tra, float* const* tcn8, const int* PI, int dir,
+                         hipStream_t s);
+int launch_selftest(const float* A, const float* Bm, const float* C, float* D, hipStream_t s);
+
+}  // namespace gtk

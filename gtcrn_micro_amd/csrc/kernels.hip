@@ -1,0 +1,1038 @@
+// kernels.hip -- gfx950 (MI355X / CDNA4) kernels of the GTCRN-Micro hot path.
+//
+// Design (DESIGN.md has the long form):
+//   * one workgroup (8 waves) owns one utterance / stream and walks it in time
+//     chunks of TC = 16 frames; causal history lives in LDS rings, so nothing is
+//     recomputed and chunked == offline == streaming by construction.
+//   * every 16-channel activation is a "slot-space" tile: 16 consecutive
+//     (frame, bin) positions x 16 slots = the C/D fragment of
+//     v_mfma_f32_16x16x4_f32 (weights are the A operand, activations the B
+//     operand), so chains of 1x1 convs run register to register and only the
+//     spatial taps go through LDS.  fp32 MFMA is exact fp32 (k-ordered fma).
+//   * elementwise work (bias via the C operand, PReLU, depthwise taps, gates)
+//     rides on the VALU next to the MFMA pipe.
+// Reference semantics are cited per function (paths relative to the reference repo).
+#include <hip/hip_runtime.h>
+
+#include "kernels.h"
+#include "layout.h"
+
+using namespace gtl;
+
+namespace gtk {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// ----------------------------------------------------------------------------- helpers
+__device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+__device__ __forceinline__ void st4(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
+__device__ __forceinline__ f32x4 splat(float v) { f32x4 r = {v, v, v, v}; return r; }
+
+// position-major LDS image: 16 floats per position, the 16-byte slot group g is XOR-swizzled by
+// the position so that the wave's ds_read_b128/ds_write_b128 of one tile are bank-conflict free
+// (lane groups of ds_read_b128: MI355X_MICROARCH.md LDS table).
+__device__ __forceinline__ int pl(int pos, int g) { return pos * 16 + (((g ^ (-(pos >> 2))) & 3) << 2); }
+__device__ __forceinline__ int pls(int pos, int slot) { return pl(pos, slot >> 2) + (slot & 3); }
+
+__device__ __forceinline__ f32x4 mfma(float a, float b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ f32x4 prelu4(f32x4 v, float a) {
+    f32x4 r;
+    r[0] = v[0] >= 0.f ? v[0] : a * v[0];
+    r[1] = v[1] >= 0.f ? v[1] : a * v[1];
+    r[2] = v[2] >= 0.f ? v[2] : a * v[2];
+    r[3] = v[3] >= 0.f ? v[3] : a * v[3];
+    return r;
+}
+
+// acc[i] += M * x[i] for the wave's tiles: 4 k-steps, tiles interleaved so the dependent
+// accumulator chains (40-cycle latency vs 32-cycle issue) overlap.
+template <int N>
+__device__ __forceinline__ void mm16(const f32x4 A, const f32x4 (&x)[N], f32x4 (&acc)[N], int ntl) {
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int i = 0; i < N; ++i)
+            if (i < ntl) acc[i] = mfma(A[s], x[i][s], acc[i]);
+}
+
+struct Lane {
+    int tid, lane, wave, n, g, ntl;
+};
+__device__ __forceinline__ Lane lane_info() {
+    Lane L;
+    L.tid = threadIdx.x;
+    L.lane = L.tid & 63;
+    L.wave = __builtin_amdgcn_readfirstlane(L.tid >> 6);
+    L.n = L.lane & 15;
+    L.g = L.lane >> 4;
+    L.ntl = (NT2 - L.wave + NW - 1) / NW;  // tiles of this wave in a full chunk (wave-uniform)
+    return L;
+}
+
+// =============================================================================== STFT
+// torch.stft(x,512,256,512,win,center=True,reflect,onesided) (infer.py:60-67): frame t =
+// reflect_pad(x,256)[256t : 256t+512] * win, unnormalised rFFT.  One wave per frame: the 512 real
+// samples are packed as 256 complex, radix-4 Stockham FFT in LDS, then the real-FFT split.
+__device__ __forceinline__ long reflect_idx(long i, long L) {
+    long j = i - 256;
+    j = j < 0 ? -j : j;
+    return j >= L ? 2 * (L - 1) - j : j;
+}
+
+__device__ __forceinline__ float2 cmul(float2 a, float2 b) {
+    return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
+}
+
+// 256-point complex FFT of one wave's buffer (ping-pong a -> b ...), DIR = -1 forward, +1 inverse
+// (unnormalised).  tw[k] = exp(-2 pi i k / 256).  Result ends in `a` (4 stages).
+template <int DIR>
+__device__ __forceinline__ void fft256(float2* a, float2* b, const float2* tw, int lane) {
+    float2* src = a;
+    float2* dst = b;
+#pragma unroll
+    for (int stage = 0; stage < 4; ++stage) {
+        const int Ns = 1 << (2 * stage);
+        const int k = lane & (Ns - 1);
+        const int tstep = k * (64 / Ns);
+        float2 v0 = src[lane], v1 = src[lane + 64], v2 = src[lane + 128], v3 = src[lane + 192];
+        if (stage > 0) {
+            float2 w1 = tw[tstep], w2 = tw[2 * tstep], w3 = tw[3 * tstep];
+            if (DIR > 0) { w1.y = -w1.y; w2.y = -w2.y; w3.y = -w3.y; }
+            v1 = cmul(v1, w1); v2 = cmul(v2, w2); v3 = cmul(v3, w3);
+        }
+        const float2 s0 = make_float2(v0.x + v2.x, v0.y + v2.y), s1 = make_float2(v0.x - v2.x, v0.y - v2.y);
+        const float2 s2 = make_float2(v1.x + v3.x, v1.y + v3.y);
+        const float2 dd = make_float2(v1.x - v3.x, v1.y - v3.y);
+        // (v1 - v3) * (i * DIR): forward multiplies by -i, inverse by +i
+        const float2 s3 = DIR < 0 ? make_float2(dd.y, -dd.x) : make_float2(-dd.y, dd.x);
+        const int j0 = ((lane - k) << 2) + k;
+        dst[j0] = make_float2(s0.x + s2.x, s0.y + s2.y);
+        dst[j0 + Ns] = make_float2(s1.x + s3.x, s1.y + s3.y);
+        dst[j0 + 2 * Ns] = make_float2(s0.x - s2.x, s0.y - s2.y);
+        dst[j0 + 3 * Ns] = make_float2(s1.x - s3.x, s1.y - s3.y);
+        __syncthreads();
+        float2* t = src; src = dst; dst = t;
+    }
+}
+
+constexpr int FFT_WAVES = 4;
+
+__global__ __launch_bounds__(FFT_WAVES * 64) void k_stft(const float* __restrict__ wave, int B, long L, int T,
+                                                        const float* __restrict__ win,
+                                                        const float2* __restrict__ twid, float* __restrict__ spec,
+                                                        long sb, long sf, long st, float* __restrict__ frames_out) {
+    __shared__ float2 s_tw[256];
+    __shared__ float2 s_tw512[256];
+    __shared__ float s_win[512];
+    __shared__ float2 s_buf[FFT_WAVES][2][256];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    for (int i = tid; i < 256; i += FFT_WAVES * 64) { s_tw[i] = twid[i]; s_tw512[i] = twid[256 + i]; }
+    for (int i = tid; i < 512; i += FFT_WAVES * 64) s_win[i] = win[i];
+    __syncthreads();
+    const long nframes = (long)B * T;
+    const long base = (long)blockIdx.x * (FFT_WAVES * FRAMES_PER_WAVE);
+    for (int it = 0; it < FRAMES_PER_WAVE; ++it) {
+        // all 4 waves run the same number of iterations (the FFT uses __syncthreads)
+        const long fr = base + (long)it * FFT_WAVES + wv;
+        const bool live = fr < nframes;
+        const int b = live ? (int)(fr / T) : 0;
+        const int t = live ? (int)(fr - (long)b * T) : 0;
+        float2* A = s_buf[wv][0];
+        float2* Bf = s_buf[wv][1];
+        const float* x = wave + (long)b * L;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int m = lane + 64 * q;
+            const long i0 = 256L * t + 2 * m;
+            float2 v;
+            // interior frames read contiguously; only the edge frames reflect
+            v.x = x[reflect_idx(i0, L)] * s_win[2 * m];
+            v.y = x[reflect_idx(i0 + 1, L)] * s_win[2 * m + 1];
+            A[m] = v;
+            if (frames_out && live) {
+                frames_out[fr * 512 + 2 * m] = v.x;
+                frames_out[fr * 512 + 2 * m + 1] = v.y;
+            }
+        }
+        __syncthreads();
+        fft256<-1>(A, Bf, s_tw, lane);
+        // real-FFT split: X[k] = Ze + exp(-2 pi i k/512) Zo, Ze = (Z[k]+conj(Z[256-k]))/2,
+        // Zo = (Z[k]-conj(Z[256-k]))/(2i)
+        if (live && spec) {
+            float* o = spec + (long)b * sb + (long)t * st;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int k = lane + 64 * q;
+                const float2 zk = A[k], zm = A[(256 - k) & 255];
+                const float2 ze = make_float2(0.5f * (zk.x + zm.x), 0.5f * (zk.y - zm.y));
+                const float2 zo = make_float2(0.5f * (zk.y + zm.y), -0.5f * (zk.x - zm.x));
+                const float2 r = cmul(s_tw512[k], zo);
+                o[(long)k * sf] = ze.x + r.x;
+                o[(long)k * sf + 1] = ze.y + r.y;
+                if (k == 0) {  // Nyquist bin: X[256] = Re Z[0] - Im Z[0]
+                    o[256L * sf] = zk.x - zk.y;
+                    o[256L * sf + 1] = 0.f;
+                }
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// torch.istft(view_as_complex(y),512,256,512,win) (infer.py:73-76): irfft (1/512), * win,
+// overlap-add, / sum(win^2), trim 256 samples at both ends -> 256*(T-1) samples.  The 512-point
+// c2r runs as a 256-point complex inverse FFT of the merged spectrum (scale 1/256).
+// One workgroup produces ISTFT_BLOCKS hop blocks of one utterance from ISTFT_BLOCKS+1 frames.
+__global__ __launch_bounds__(FFT_WAVES * 64) void k_istft(const float* __restrict__ spec, long sb, long sf, long st,
+                                                         int B, int T, const float* __restrict__ win,
+                                                         const float2* __restrict__ twid, float* __restrict__ wave) {
+    __shared__ float2 s_tw[256];
+    __shared__ float2 s_tw512[256];
+    __shared__ float s_win[512];
+    __shared__ float2 s_buf[FFT_WAVES][2][256];
+    __shared__ float s_fr[ISTFT_BLOCKS + 1][512];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    for (int i = tid; i < 256; i += FFT_WAVES * 64) { s_tw[i] = twid[i]; s_tw512[i] = twid[256 + i]; }
+    for (int i = tid; i < 512; i += FFT_WAVES * 64) s_win[i] = win[i];
+    __syncthreads();
+    const int nblk = T - 1;                                   // hop blocks of this utterance
+    const int groups = (nblk + ISTFT_BLOCKS - 1) / ISTFT_BLOCKS;
+    const int b = blockIdx.x / groups, grp = blockIdx.x - b * groups;
+    const int j0 = grp * ISTFT_BLOCKS;                        // first hop block == first frame needed
+    const int nfr = min(ISTFT_BLOCKS, nblk - j0) + 1;
+    constexpr int ROUNDS = (ISTFT_BLOCKS + 1 + FFT_WAVES - 1) / FFT_WAVES;
+    for (int it = 0; it < ROUNDS; ++it) {
+        const int fi = it * FFT_WAVES + wv;
+        const bool live = fi < nfr;
+        const int t = j0 + (live ? fi : 0);
+        float2* A = s_buf[wv][0];
+        float2* Bf = s_buf[wv][1];
+        const float* x = spec + (long)b * sb + (long)t * st;
+        // merge: Z[k] = Xe + i Xo, Xe = (X[k]+conj(X[256-k]))/2, Xo = (X[k]-conj(X[256-k]))/2 * exp(+2 pi i k/512);
+        // c2r semantics: the imaginary parts of DC and Nyquist are ignored.
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int k = lane + 64 * q;
+            float2 xk = make_float2(x[(long)k * sf], x[(long)k * sf + 1]);
+            float2 xm = make_float2(x[(long)(256 - k) * sf], -x[(long)(256 - k) * sf + 1]);
+            if (k == 0) { xk.y = 0.f; xm.y = 0.f; }
+            const float2 xe = make_float2(0.5f * (xk.x + xm.x), 0.5f * (xk.y + xm.y));
+            float2 w = s_tw512[k];
+            w.y = -w.y;
+            const float2 xo = cmul(make_float2(0.5f * (xk.x - xm.x), 0.5f * (xk.y - xm.y)), w);
+            A[k] = make_float2(xe.x - xo.y, xe.y + xo.x);
+        }
+        __syncthreads();
+        fft256<1>(A, Bf, s_tw, lane);
+        if (live) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int m = lane + 64 * q;
+                const float2 z = A[m];
+                s_fr[fi][2 * m] = (z.x * (1.0f / 256.0f)) * s_win[2 * m];
+                s_fr[fi][2 * m + 1] = (z.y * (1.0f / 256.0f)) * s_win[2 * m + 1];
+            }
+        }
+        __syncthreads();
+    }
+    // overlap-add: output block j = frame j second half + frame j+1 first half
+    float* o = wave + (long)b * 256 * nblk;
+    for (int idx = tid; idx < (nfr - 1) * 256; idx += FFT_WAVES * 64) {
+        const int jb = idx >> 8, i = idx & 255;
+        const float acc = s_fr[jb][256 + i] + s_fr[jb + 1][i];
+        const float env = s_win[256 + i] * s_win[256 + i] + s_win[i] * s_win[i];
+        o[(long)(j0 + jb) * 256 + i] = env > 1e-11f ? acc / env : acc;
+    }
+}
+
+// ===================================================================== GTConv block
+// GTConvBlock.forward (models/gtcrn_micro.py:229-253) and its streaming twin
+// (streaming/gtcrn_micro_stream.py:245-262), in slot space (layout.h / pack.cpp):
+//   h  = PReLU(BN(point_conv1(x1)))                     16x16 slot matrix, zero columns on x2 slots
+//   hd = PReLU(BN(depth_conv([hist | h])))              encoder: depthwise 3x3 (VALU);
+//                                                       decoder: dense transposed 3x3 = 9 slot matrices (MFMA)
+//   v  = BN(point_conv2(hd)) written over the x1 slots, x2 slots pass through the C operand
+//   TRALite (:122-139): e = mean_F(v^2) per h' channel, causal k=3 conv over [cache | e], 1x1, sigmoid
+//   out = v * gate  (gate = 1 on pass-through slots) -- this IS the channel shuffle (:222-227),
+//   because the packer renamed the slots instead of moving data.
+struct BlockCtx {
+    const float* pb;     // LDS: block parameters (GB_* offsets)
+    const float* gA;     // LDS: dense 3x3 slot matrices (decoder) or nullptr
+    const int* ib;       // LDS: slot_of_c[8], x2slots[8]
+    float* sW;           // LDS: h of this chunk, rows of 35 positions (zero pad columns 0 and 34)
+    float* sHk;          // LDS: 2-row history ring of h (row = frame & 1), rows of 35 positions
+    float* sS;           // LDS: v^2, 33 positions per frame
+    float* sG;           // LDS: gates [frame][16 slots]
+    float* sEHk;         // LDS: 2-entry ring of e: [frame & 1][8]
+    int nfr;             // frames in this chunk
+    int tabs;            // absolute frame index of the chunk's first frame
+};
+
+template <bool DENSE>
+__device__ __forceinline__ void gtconv_block(f32x4 (&x)[TPW], const int (&tl)[TPW], const int (&ff)[TPW],
+                                             const BlockCtx& c, const Lane& L) {
+    const int n = L.n, g = L.g, ntl = L.ntl;
+    const float a1 = c.pb[GB_SLOPE], a2 = c.pb[GB_SLOPE + 1];
+    f32x4 h[TPW];
+    // ---- point_conv1 + BN + PReLU (tiles interleaved: x and h are live across the phase anyway) ----
+    {
+        const f32x4 A = ld4(c.pb + GB_PC1_A + n * 16 + 4 * g), Bv = ld4(c.pb + GB_PC1_B + 4 * g);
+#pragma unroll
+        for (int i = 0; i < TPW; ++i) h[i] = Bv;
+        mm16<TPW>(A, x, h, ntl);
+#pragma unroll
+        for (int i = 0; i < TPW; ++i)
+            if (i < ntl) {
+                h[i] = prelu4(h[i], a1);
+                st4(c.sW + pl(tl[i] * 35 + 1 + ff[i], g), h[i]);
+            }
+    }
+    __syncthreads();
+    // ---- depth conv + BN + PReLU, then point_conv2 + BN in place over the x1 slots; one tile at a
+    //      time so that the tap registers die with the tile (the partner wave on the SIMD fills the
+    //      MFMA dependency gaps) --------------------------------------------------------------------
+    {
+        const f32x4 Bd = ld4(c.pb + GB_DW_B + 4 * g);
+        const f32x4 A2 = ld4(c.pb + GB_PC2_A + n * 16 + 4 * g), B2 = ld4(c.pb + GB_PC2_B + 4 * g);
+        const f32x4 keep = ld4(c.pb + GB_KEEP + 4 * g);
+        f32x4 wdw[DENSE ? 1 : 9];
+        if (!DENSE) {
+#pragma unroll
+            for (int q = 0; q < 9; ++q) wdw[q] = ld4(c.pb + GB_DW_W + q * 16 + 4 * g);
+        }
+#pragma unroll
+        for (int i = 0; i < TPW; ++i) {
+            if (i < ntl) {
+                f32x4 acc = Bd;
+#pragma unroll
+                for (int kt = 0; kt < 3; ++kt)
+#pragma unroll
+                    for (int kf = 0; kf < 3; ++kf) {
+                        // encoder: tap (t-2+kt, f-1+kf); decoder (transposed): tap (t-kt, f+1-kf)
+                        const int dt = DENSE ? -kt : kt - 2;
+                        const int df = DENSE ? 1 - kf : kf - 1;
+                        f32x4 tap;
+                        if (dt == 0 && df == 0) {
+                            tap = h[i];
+                        } else {
+                            const int tau = tl[i] + dt;
+                            const int col = 1 + ff[i] + df;
+                            const float* src = tau >= 0 ? c.sW + pl(tau * 35 + col, g)
+                                                        : c.sHk + pl(((c.tabs + tau) & 1) * 35 + col, g);
+                            tap = ld4(src);
+                        }
+                        if (DENSE) {
+                            const f32x4 A = ld4(c.gA + (kt * 3 + kf) * 256 + n * 16 + 4 * g);
+#pragma unroll
+                            for (int s = 0; s < 4; ++s) acc = mfma(A[s], tap[s], acc);
+                        } else {
+                            acc += wdw[kt * 3 + kf] * tap;
+                        }
+                    }
+                const f32x4 hd = prelu4(acc, a2);
+                f32x4 v = keep * x[i] + B2;
+#pragma unroll
+                for (int s = 0; s < 4; ++s) v = mfma(A2[s], hd[s], v);
+                st4(c.sS + pl(tl[i] * 33 + ff[i], g), v * v);
+                x[i] = v;
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    __syncthreads();
+    // ---- history ring of h (after every wave has read its taps) -----------------------------------
+#pragma unroll
+    for (int i = 0; i < TPW; ++i)
+        if (i < ntl && tl[i] < c.nfr && tl[i] >= c.nfr - 2)
+            st4(c.sHk + pl(((c.tabs + tl[i]) & 1) * 35 + 1 + ff[i], g), h[i]);
+    // ---- TRALite gate: 8 threads per frame (one per h' channel) -------------------------------------
+    float e_keep = 0.f;
+    const int rt = L.tid >> 3, rc = L.tid & 7;
+    const bool reducer = L.tid < c.nfr * 8;
+    if (reducer) {
+        const int slot = c.ib[rc];
+        float e[3];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {  // e[j] = energy of frame rt - 2 + j
+            const int tau = rt - 2 + j;
+            if (tau >= 0) {
+                float s = 0.f;
+                for (int f = 0; f < 33; ++f) s += c.sS[pls(tau * 33 + f, slot)];
+                e[j] = s / 33.0f;
+            } else {
+                e[j] = c.sEHk[((c.tabs + tau) & 1) * 8 + rc];
+            }
+        }
+        e_keep = e[2];
+        const float y = c.pb[GB_TRA_DB + rc] + c.pb[GB_TRA_DW + rc * 3] * e[0] + c.pb[GB_TRA_DW + rc * 3 + 1] * e[1] +
+                        c.pb[GB_TRA_DW + rc * 3 + 2] * e[2];
+        float z = c.pb[GB_TRA_PB + rc];
+#pragma unroll
+        for (int cc = 0; cc < 8; ++cc) z += c.pb[GB_TRA_PW + rc * 8 + cc] * __shfl(y, (L.lane & ~7) + cc);
+        const float gate = 1.0f / (1.0f + __expf(-z));
+        c.sG[rt * 16 + slot] = gate;
+        c.sG[rt * 16 + c.ib[8 + rc]] = 1.0f;
+    }
+    __syncthreads();
+    if (reducer && rt >= c.nfr - 2) c.sEHk[((c.tabs + rt) & 1) * 8 + rc] = e_keep;
+#pragma unroll
+    for (int i = 0; i < TPW; ++i)
+        if (i < ntl) x[i] = x[i] * ld4(c.sG + tl[i] * 16 + 4 * g);
+}
+
+// zero the two pad columns of the TC rows of a 35-position row image
+__device__ __forceinline__ void zero_row_pads(float* img, int tid) {
+    if (tid < TC * 2 * 4) {
+        const int r = tid >> 3, side = (tid >> 2) & 1, gg = tid & 3;
+        st4(img + pl(r * 35 + side * 34, gg), splat(0.f));
+    }
+}
+
+// load / store the 2-row h rings and e rings of 3 blocks from / to the stream state
+__device__ __forceinline__ void rings_load(float* sH, float* sEH, const float* st_h, const float* st_e, int tid) {
+    for (int i = tid; i < 3 * 2 * 35 * 4; i += NTHR) {
+        const int gg = i & 3, pos = i >> 2;           // pos over 3 blocks x 2 rows x 35 columns
+        const int col = pos % 35, br = pos / 35;      // br = block*2 + row
+        f32x4 v = splat(0.f);
+        if (st_h && col >= 1 && col <= 33) v = ld4(st_h + ((br * 33) + col - 1) * 16 + gg * 4);
+        st4(sH + (br / 2) * (2 * 35 * 16) + pl((br & 1) * 35 + col, gg), v);
+    }
+    if (tid < 48) sEH[tid] = st_e ? st_e[tid] : 0.f;
+}
+__device__ __forceinline__ void rings_store(const float* sH, const float* sEH, float* st_h, float* st_e, int tid) {
+    for (int i = tid; i < 3 * 2 * 33 * 4; i += NTHR) {
+        const int gg = i & 3, pos = i >> 2;
+        const int f = pos % 33, br = pos / 33;
+        st4(st_h + pos * 16 + gg * 4, ld4(sH + (br / 2) * (2 * 35 * 16) + pl((br & 1) * 35 + 1 + f, gg)));
+    }
+    if (tid < 48) st_e[tid] = sEH[tid];
+}
+
+// =============================================================================== encoder
+// spec -> [mag,re,im] (models/gtcrn_micro.py:510-515) -> ERB.bm (:63-67) -> SFE_Lite (:77-90)
+// -> en_convs.0/1 (ConvBlock :142-164, Conv2d (1,5) stride (1,2)) -> 3 x GTConvBlock (:365-393).
+// Writes the five skip tensors en0 (B,T,65,16) and en1..en4 (B,T,33,16), slot order.
+constexpr int ENC_LDS_P = 0;
+constexpr int ENC_LDS_I = ENC_LDS_P + ENC_SIZE;
+constexpr int ENC_LDS_H = ENC_LDS_I + P_INTS;
+constexpr int ENC_LDS_EH = ENC_LDS_H + 3 * 2 * 35 * 16;
+constexpr int ENC_LDS_G = ENC_LDS_EH + 48;
+constexpr int ENC_LDS_A = ENC_LDS_G + TC * 16;             // E0, later W + S
+constexpr int ENC_E0_ROW = 69;
+constexpr int ENC_LDS_B = ENC_LDS_A + TC * ENC_E0_ROW * 16;  // EB + F0
+constexpr int EB_ROW = 131, F0_ROW = 136;
+constexpr int ENC_LDS_FLOATS = ENC_LDS_B + 3 * TC * EB_ROW + 3 * TC * F0_ROW;
+static_assert(TC * 35 * 16 + TC * 33 * 16 <= TC * ENC_E0_ROW * 16, "W + S must fit in the E0 region");
+static_assert(ENC_LDS_FLOATS * 4 <= 160 * 1024, "encoder LDS budget");
+static_assert(ENC_LDS_I % 4 == 0 && ENC_LDS_H % 4 == 0 && ENC_LDS_G % 4 == 0 && ENC_LDS_A % 4 == 0, "16B carve");
+
+__global__ __launch_bounds__(NTHR) void k_encoder(const float* __restrict__ spec, long sb, long sf, long st, int T,
+                                                 const float* __restrict__ PF, const int* __restrict__ PI,
+                                                 float* __restrict__ en0, float* __restrict__ en1,
+                                                 float* __restrict__ en2, float* __restrict__ en3,
+                                                 float* __restrict__ en4, float* __restrict__ state) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* sP = smem + ENC_LDS_P;
+    int* sI = reinterpret_cast<int*>(smem + ENC_LDS_I);
+    float* sH = smem + ENC_LDS_H;
+    float* sEH = smem + ENC_LDS_EH;
+    float* sG = smem + ENC_LDS_G;
+    float* sE0 = smem + ENC_LDS_A;
+    float* sW = smem + ENC_LDS_A;
+    float* sS = sW + TC * 35 * 16;
+    float* sEB = smem + ENC_LDS_B;
+    float* sF0 = sEB + 3 * TC * EB_ROW;
+    const Lane L = lane_info();
+    const int tid = L.tid, n = L.n, g = L.g;
+    const int b = blockIdx.x;
+
+    for (int i = tid; i < ENC_SIZE; i += NTHR) sP[i] = PF[P_ENC + i];
+    for (int i = tid; i < P_INTS; i += NTHR) sI[i] = PI[i];
+    for (int i = tid; i < 3 * TC * EB_ROW + 3 * TC * F0_ROW; i += NTHR) sEB[i] = 0.f;  // zero pads once
+    float* stb = state ? state + (long)b * ST_FLOATS : nullptr;
+    const int tbase = stb ? reinterpret_cast<const int*>(stb)[0] : 0;
+    rings_load(sH, sEH, stb ? stb + ST_ENC_H : nullptr, stb ? stb + ST_ENC_E : nullptr, tid);
+    __syncthreads();
+
+    spec += (long)b * sb;
+    const long ob = (long)b * T;
+    const bool t_fast = st < sf;  // reference layout (B,257,T,2): consecutive frames are adjacent
+
+    for (int t0 = 0; t0 < T; t0 += TC) {
+        const int nfr = min(TC, T - t0);
+        // ---- A: features + ERB.bm straight from global: EB[c][tl][1 + j] ------------------------
+        for (int idx = tid; idx < nfr * F0; idx += NTHR) {
+            int tl, j;
+            if (t_fast) { tl = idx % nfr; j = idx / nfr; } else { j = idx % F0; tl = idx / F0; }
+            const float* sp = spec + (long)(t0 + tl) * st;
+            float v0, v1, v2;
+            if (j < ERB_LOW) {
+                const float re = sp[(long)j * sf], im = sp[(long)j * sf + 1];
+                v0 = sqrtf(re * re + im * im + 1e-12f); v1 = re; v2 = im;
+            } else {
+                const int band = j - ERB_LOW, lo = sI[I_ERB_LO + band], cnt = sI[I_ERB_N + band];
+                v0 = v1 = v2 = 0.f;
+                for (int i = 0; i < cnt; ++i) {
+                    const long bin = ERB_LOW + lo + i;
+                    const float re = sp[bin * sf], im = sp[bin * sf + 1];
+                    const float w = sP[E_ERB_W + band * ERB_MAXBW + i];
+                    v0 += w * sqrtf(re * re + im * im + 1e-12f); v1 += w * re; v2 += w * im;
+                }
+            }
+            sEB[(0 * TC + tl) * EB_ROW + 1 + j] = v0;
+            sEB[(1 * TC + tl) * EB_ROW + 1 + j] = v1;
+            sEB[(2 * TC + tl) * EB_ROW + 1 + j] = v2;
+        }
+        __syncthreads();
+        // ---- B: SFE_Lite depthwise (1,3): F0[c][tl][2 + f] ---------------------------------------
+        for (int idx = tid; idx < 3 * nfr * F0; idx += NTHR) {
+            const int f = idx % F0, ct = idx / F0, tl = ct % nfr, c = ct / nfr;
+            const float* e = sEB + (c * TC + tl) * EB_ROW + f;
+            sF0[(c * TC + tl) * F0_ROW + 2 + f] =
+                sP[E_SFE_W + c * 3] * e[0] + sP[E_SFE_W + c * 3 + 1] * e[1] + sP[E_SFE_W + c * 3 + 2] * e[2];
+        }
+        // zero the pad positions of E0 (columns 0,1,67,68 of each row): region A was W/S last chunk
+        if (tid < TC * 4 * 4) {
+            const int r = tid >> 4, cc = (tid >> 2) & 3, gg = tid & 3;
+            st4(sE0 + pl(r * ENC_E0_ROW + (cc < 2 ? cc : 65 + cc), gg), splat(0.f));
+        }
+        __syncthreads();
+        // ---- C: en_convs.0 = Conv2d(3,16,(1,5),stride (1,2),pad (0,2)) + BN + PReLU --------------
+        {
+            const f32x4 A = ld4(sP + E_EN0_A + n * 16 + 4 * g), Bv = ld4(sP + E_EN0_B + 4 * g);
+            const float a = sP[E_EN0_S];
+            int off[4];
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const int e = 4 * g + s, c = e < 15 ? e / 5 : 0, k = e < 15 ? e % 5 : 0;
+                off[s] = c * TC * F0_ROW + k;
+            }
+            constexpr int NT0 = TC * F1 / 16;  // 65 tiles
+            static_assert(TC * F1 % 16 == 0, "en0 tiling");
+            for (int tile = L.wave; tile < NT0; tile += NW) {
+                const int q = tile * 16 + n, tl = q / F1, fo = q - tl * F1;
+                f32x4 bv;
+#pragma unroll
+                for (int s = 0; s < 4; ++s) bv[s] = sF0[off[s] + tl * F0_ROW + 2 * fo];
+                f32x4 acc = Bv;
+#pragma unroll
+                for (int s = 0; s < 4; ++s) acc = mfma(A[s], bv[s], acc);
+                acc = prelu4(acc, a);
+                st4(sE0 + pl(tl * ENC_E0_ROW + 2 + fo, g), acc);
+                if (tl < nfr) st4(en0 + ((ob + t0 + tl) * F1 + fo) * 16 + 4 * g, acc);
+            }
+        }
+        __syncthreads();
+        // ---- D: en_convs.1 = Conv2d(16,16,(1,5),stride (1,2),pad (0,2)) + BN + PReLU -------------
+        f32x4 x[TPW];
+        int tl[TPW], ff[TPW];
+        {
+            const f32x4 Bv = ld4(sP + E_EN1_B + 4 * g);
+            const float a = sP[E_EN1_S];
+            f32x4 A[5];
+#pragma unroll
+            for (int k = 0; k < 5; ++k) A[k] = ld4(sP + E_EN1_A + k * 256 + n * 16 + 4 * g);
+#pragma unroll
+            for (int i = 0; i < TPW; ++i) {
+                const int p = (L.wave + i * NW) * 16 + n;
+                tl[i] = p / 33;
+                ff[i] = p - tl[i] * 33;
+                if (i < L.ntl) {
+                    f32x4 acc = Bv;
+#pragma unroll
+                    for (int k = 0; k < 5; ++k) {
+                        const f32x4 tap = ld4(sE0 + pl(tl[i] * ENC_E0_ROW + 2 * ff[i] + k, g));
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) acc = mfma(A[k][q], tap[q], acc);
+                    }
+                    x[i] = prelu4(acc, a);
+                    if (p < nfr * 33) st4(en1 + ((ob + t0) * 33 + p) * 16 + 4 * g, x[i]);
+                } else {
+                    x[i] = splat(0.f);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        __syncthreads();  // E0 is dead: its region becomes W + S
+        zero_row_pads(sW, tid);
+        // ---- E: 3 x GTConvBlock (depthwise) --------------------------------------------------------
+#pragma unroll 1
+        for (int k = 0; k < 3; ++k) {
+            BlockCtx c;
+            c.pb = sP + E_BLK + k * GB_SIZE;
+            c.gA = nullptr;
+            c.ib = sI + I_ENC_BLK + k * 16;
+            c.sW = sW; c.sHk = sH + k * (2 * 35 * 16); c.sS = sS; c.sG = sG; c.sEHk = sEH + k * 16;
+            c.nfr = nfr; c.tabs = tbase + t0;
+            gtconv_block<false>(x, tl, ff, c, L);
+            float* dst = k == 0 ? en2 : (k == 1 ? en3 : en4);
+#pragma unroll
+            for (int i = 0; i < TPW; ++i)
+                if (i < L.ntl) {
+                    const int p = (L.wave + i * NW) * 16 + n;
+                    if (p < nfr * 33) st4(dst + ((ob + t0) * 33 + p) * 16 + 4 * g, x[i]);
+                }
+        }
+        __syncthreads();  // region A is rewritten as E0 by the next chunk
+    }
+    if (stb) {
+        __syncthreads();
+        rings_store(sH, sEH, stb + ST_ENC_H, stb + ST_ENC_E, tid);
+    }
+}
+
+// ================================================================================== GTCN
+// GTCN.forward = 4 x TCN (models/gtcrn_micro.py:290-336): y1 = PReLU(BN(conv1 x)); y2 =
+// PReLU(BN(depthwise (3,1) dilated d over [hist(2d) | y1])); out = PReLU(BN(conv3 y2) + x).
+// x stays in registers across the four blocks; only y1 goes through LDS (chunk image sW plus a
+// 2d-row ring per block, row = frame mod 2d).
+constexpr int GT_LDS_P = 0;
+constexpr int GT_LDS_W = GT_LDS_P + GTCN_SIZE;
+constexpr int GT_LDS_H = GT_LDS_W + TC * 33 * 16;
+constexpr int GT_LDS_FLOATS = GT_LDS_H + 30 * 33 * 16;
+static_assert(GT_LDS_W % 4 == 0, "16B carve");
+
+__global__ __launch_bounds__(NTHR) void k_gtcn(const float* __restrict__ xin, float* __restrict__ xout,
+                                              const float* __restrict__ P, int T, float* __restrict__ state,
+                                              int st_off) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* sP = smem + GT_LDS_P;
+    float* sW = smem + GT_LDS_W;
+    float* sH = smem + GT_LDS_H;
+    const Lane L = lane_info();
+    const int tid = L.tid, n = L.n, g = L.g, ntl = L.ntl;
+    const int b = blockIdx.x;
+    for (int i = tid; i < GTCN_SIZE; i += NTHR) sP[i] = P[i];
+    float* stb = state ? state + (long)b * ST_FLOATS : nullptr;
+    const int tbase = stb ? reinterpret_cast<const int*>(stb)[0] : 0;
+    // ring image of block k starts at row 2*(2^k - 1); the swizzle is relative to the block's base
+    for (int i = tid; i < 30 * 33 * 4; i += NTHR) {
+        const int gg = i & 3, pos = i >> 2, row = pos / 33;
+        const int r0 = row < 2 ? 0 : (row < 6 ? 2 : (row < 14 ? 6 : 14));
+        st4(sH + r0 * 528 + pl(pos - r0 * 33, gg), stb ? ld4(stb + st_off + pos * 16 + gg * 4) : splat(0.f));
+    }
+    __syncthreads();
+    xin += (long)b * T * 528;
+    xout += (long)b * T * 528;
+
+    for (int t0 = 0; t0 < T; t0 += TC) {
+        const int nfr = min(TC, T - t0), npos = nfr * 33;
+        f32x4 x[TPW], y1[TPW], acc[TPW];
+        int pp[TPW], tl[TPW], ff[TPW];
+#pragma unroll
+        for (int i = 0; i < TPW; ++i) {
+            pp[i] = (L.wave + i * NW) * 16 + n;
+            tl[i] = pp[i] / 33;
+            ff[i] = pp[i] - tl[i] * 33;
+            x[i] = (i < ntl && pp[i] < npos) ? ld4(xin + ((long)t0 * 33 + pp[i]) * 16 + 4 * g) : splat(0.f);
+        }
+#pragma unroll 1
+        for (int k = 0; k < 4; ++k) {
+            const int d = 1 << k, m2d = 2 * d - 1;
+            const float* pk = sP + k * TCN_SIZE;
+            float* sHk = sH + 2 * (d - 1) * 33 * 16;
+            const float a1 = pk[TCN_SLOPE], a2 = pk[TCN_SLOPE + 1], a3 = pk[TCN_SLOPE + 2];
+            {
+                const f32x4 A = ld4(pk + TCN_A1 + n * 16 + 4 * g), Bv = ld4(pk + TCN_B1 + 4 * g);
+#pragma unroll
+                for (int i = 0; i < TPW; ++i) acc[i] = Bv;
+                mm16<TPW>(A, x, acc, ntl);
+#pragma unroll
+                for (int i = 0; i < TPW; ++i)
+                    if (i < ntl) {
+                        y1[i] = prelu4(acc[i], a1);
+                        st4(sW + pl(pp[i], g), y1[i]);
+                    }
+            }
+            __syncthreads();
+            {
+                const f32x4 w0 = ld4(pk + TCN_DW + 4 * g), w1 = ld4(pk + TCN_DW + 16 + 4 * g),
+                            w2 = ld4(pk + TCN_DW + 32 + 4 * g), B2 = ld4(pk + TCN_B2 + 4 * g);
+                const f32x4 A = ld4(pk + TCN_A3 + n * 16 + 4 * g), B3 = ld4(pk + TCN_B3 + 4 * g);
+                f32x4 y2[TPW];
+#pragma unroll
+                for (int i = 0; i < TPW; ++i)
+                    if (i < ntl) {
+                        const int t = tbase + t0 + tl[i];
+                        const float* s1 = tl[i] >= d ? sW + pl(pp[i] - 33 * d, g)
+                                                     : sHk + pl(((t + d) & m2d) * 33 + ff[i], g);
+                        const float* s2 = tl[i] >= 2 * d ? sW + pl(pp[i] - 66 * d, g)
+                                                         : sHk + pl((t & m2d) * 33 + ff[i], g);
+                        const f32x4 tp1 = ld4(s1), tp2 = ld4(s2);
+                        y2[i] = prelu4(B2 + w0 * tp2 + w1 * tp1 + w2 * y1[i], a2);
+                        acc[i] = B3;
+                    }
+                mm16<TPW>(A, y2, acc, ntl);
+#pragma unroll
+                for (int i = 0; i < TPW; ++i)
+                    if (i < ntl) x[i] = prelu4(acc[i] + x[i], a3);
+            }
+            __syncthreads();
+#pragma unroll
+            for (int i = 0; i < TPW; ++i)
+                if (i < ntl && pp[i] < npos && tl[i] >= nfr - 2 * d)
+                    st4(sHk + pl(((tbase + t0 + tl[i]) & m2d) * 33 + ff[i], g), y1[i]);
+        }
+#pragma unroll
+        for (int i = 0; i < TPW; ++i)
+            if (i < ntl && pp[i] < npos) st4(xout + ((long)t0 * 33 + pp[i]) * 16 + 4 * g, x[i]);
+    }
+    if (stb) {
+        __syncthreads();
+        for (int i = tid; i < 30 * 33 * 4; i += NTHR) {
+            const int gg = i & 3, pos = i >> 2, row = pos / 33;
+            const int r0 = row < 2 ? 0 : (row < 6 ? 2 : (row < 14 ? 6 : 14));
+            st4(stb + st_off + pos * 16 + gg * 4, ld4(sH + r0 * 528 + pl(pos - r0 * 33, gg)));
+        }
+    }
+}
+
+// =============================================================================== decoder
+// Decoder.forward (models/gtcrn_micro.py:464-469): x = de[i](x + en_outs[4-i]); three dense
+// GTConvBlocks, de_convs.3 (ConvTranspose2d (1,5) stride (1,2), 33 -> 65) in gather form,
+// de_convs.4 (16 -> 2, 65 -> 129, Tanh) in scatter form, then ERB.bs (:69-73), the complex
+// ratio mask (:478-482) and the output permute (:529-530).
+constexpr int DEC_LDS_P = 0;                                      // the whole decoder segment
+constexpr int DEC_LDS_I = DEC_LDS_P + DEC_SIZE;
+constexpr int DEC_LDS_H = DEC_LDS_I + P_INTS;
+constexpr int DEC_LDS_EH = DEC_LDS_H + 3 * 2 * 35 * 16;
+constexpr int DEC_LDS_G = DEC_LDS_EH + 48;
+constexpr int DEC_LDS_A = DEC_LDS_G + TC * 16;                    // W + S, later Z
+constexpr int DEC_LDS_M = DEC_LDS_A + TC * 35 * 16 + TC * 33 * 16;
+constexpr int DEC_LDS_FLOATS = DEC_LDS_M + 2 * TC * F0;
+static_assert(TC * F1 * 16 <= TC * 35 * 16 + TC * 33 * 16, "Z must fit in the W + S region");
+static_assert(DEC_LDS_FLOATS * 4 <= 160 * 1024, "decoder LDS budget");
+static_assert(DEC_SIZE % 4 == 0 && DEC_LDS_I % 4 == 0 && DEC_LDS_H % 4 == 0 && DEC_LDS_A % 4 == 0, "16B carve");
+
+__device__ __forceinline__ f32x4 ld_skip(const float* rec, const int* idx4) {
+    f32x4 v;
+    v[0] = rec[idx4[0]]; v[1] = rec[idx4[1]]; v[2] = rec[idx4[2]]; v[3] = rec[idx4[3]];
+    return v;
+}
+
+__global__ __launch_bounds__(NTHR) void k_decoder(const float* __restrict__ xg, const float* __restrict__ en0,
+                                                 const float* __restrict__ en1, const float* __restrict__ en2,
+                                                 const float* __restrict__ en3, const float* __restrict__ en4,
+                                                 const float* __restrict__ spec, long sb, long sf, long st,
+                                                 float* __restrict__ out, long osb, long osf, long ost, int T,
+                                                 const float* __restrict__ PF, const int* __restrict__ PI,
+                                                 float* __restrict__ state, float* __restrict__ dbg) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* sP = smem + DEC_LDS_P;
+    int* sI = reinterpret_cast<int*>(smem + DEC_LDS_I);
+    float* sH = smem + DEC_LDS_H;
+    float* sEH = smem + DEC_LDS_EH;
+    float* sG = smem + DEC_LDS_G;
+    float* sW = smem + DEC_LDS_A;
+    float* sS = sW + TC * 35 * 16;
+    float* sZ = smem + DEC_LDS_A;
+    float* sM = smem + DEC_LDS_M;
+    const Lane L = lane_info();
+    const int tid = L.tid, n = L.n, g = L.g, ntl = L.ntl;
+    const int b = blockIdx.x;
+    for (int i = tid; i < DEC_SIZE; i += NTHR) sP[i] = PF[P_DEC + i];
+    for (int i = tid; i < P_INTS; i += NTHR) sI[i] = PI[i];
+    float* stb = state ? state + (long)b * ST_FLOATS : nullptr;
+    const int tbase = stb ? reinterpret_cast<const int*>(stb)[0] : 0;
+    rings_load(sH, sEH, stb ? stb + ST_DEC_H : nullptr, stb ? stb + ST_DEC_E : nullptr, tid);
+    __syncthreads();
+
+    const long ob = (long)b * T;
+    const long nbt = (long)gridDim.x * T;
+    spec += (long)b * sb;
+    out += (long)b * osb;
+    const bool t_fast = st < sf;
+
+    for (int t0 = 0; t0 < T; t0 += TC) {
+        const int nfr = min(TC, T - t0), npos = nfr * 33;
+        f32x4 x[TPW];
+        int pp[TPW], tl[TPW], ff[TPW];
+        bool ok[TPW];
+#pragma unroll
+        for (int i = 0; i < TPW; ++i) {
+            pp[i] = (L.wave + i * NW) * 16 + n;
+            tl[i] = pp[i] / 33;
+            ff[i] = pp[i] - tl[i] * 33;
+            ok[i] = i < ntl && pp[i] < npos;
+            const long o = ((ob + t0) * 33 + pp[i]) * 16 + 4 * g;
+            x[i] = ok[i] ? ld4(xg + o) + ld4(en4 + o) : splat(0.f);
+        }
+        zero_row_pads(sW, tid);  // region A was Z in the previous chunk (a barrier follows in the block)
+        // ---- 3 x GTConvBlock (dense transposed 3x3) -----------------------------------------------
+#pragma unroll 1
+        for (int j = 0; j < 3; ++j) {
+            BlockCtx c;
+            c.pb = sP + D_BLK + j * GBD_SIZE;
+            c.gA = c.pb + GB_DN_A;
+            c.ib = sI + I_DEC_BLK + j * 16;
+            c.sW = sW; c.sHk = sH + j * (2 * 35 * 16); c.sS = sS; c.sG = sG; c.sEHk = sEH + j * 16;
+            c.nfr = nfr; c.tabs = tbase + t0;
+            gtconv_block<true>(x, tl, ff, c, L);
+            if (dbg)
+#pragma unroll
+                for (int i = 0; i < TPW; ++i)
+                    if (ok[i]) st4(dbg + ((long)j * nbt + ob + t0) * 528 + pp[i] * 16 + 4 * g, x[i]);
+            // skip added to this block's output: en3, en2, en1 (stored in their producer's slot order)
+            const float* sk = j == 0 ? en3 : (j == 1 ? en2 : en1);
+            const int* idx4 = sI + I_SKIP + j * 16 + 4 * g;
+#pragma unroll
+            for (int i = 0; i < TPW; ++i)
+                if (ok[i]) x[i] += ld_skip(sk + ((ob + t0) * 33 + pp[i]) * 16, idx4);
+        }
+        // ---- de_convs.3: gather form; input image in sW rows (pad columns are zero).  Every wave is
+        // past the last block's tap reads (they precede that block's 2nd barrier), so sW is free.
+#pragma unroll
+        for (int i = 0; i < TPW; ++i)
+            if (i < ntl) st4(sW + pl(tl[i] * 35 + 1 + ff[i], g), x[i]);
+        __syncthreads();
+        f32x4 ze[TPW], zo[TPW];
+        {
+            const f32x4 Bv = ld4(sP + D_DE3_B + 4 * g);
+            const float a = sP[D_DE3_S];
+            const f32x4 A4 = ld4(sP + D_DE4_A + n * 16 + 4 * g);
+            // even output 2m: k=0 <- x[m+1], k=2 <- x[m], k=4 <- x[m-1]; odd 2m+1: k=1 <- x[m+1], k=3 <- x[m]
+            const f32x4 Ae0 = ld4(sP + D_DE3_AE + 0 * 256 + n * 16 + 4 * g),
+                        Ae1 = ld4(sP + D_DE3_AE + 1 * 256 + n * 16 + 4 * g),
+                        Ae2 = ld4(sP + D_DE3_AE + 2 * 256 + n * 16 + 4 * g),
+                        Ao0 = ld4(sP + D_DE3_AO + 0 * 256 + n * 16 + 4 * g),
+                        Ao1 = ld4(sP + D_DE3_AO + 1 * 256 + n * 16 + 4 * g);
+#pragma unroll
+            for (int i = 0; i < TPW; ++i) {
+                if (i < ntl) {
+                    const f32x4 xp = ld4(sW + pl(tl[i] * 35 + 2 + ff[i], g));  // input bin f+1
+                    const f32x4 xm = ld4(sW + pl(tl[i] * 35 + ff[i], g));      // input bin f-1
+                    f32x4 ae = Bv, ao = Bv;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        ae = mfma(Ae0[q], xp[q], ae);
+                        ao = mfma(Ao0[q], xp[q], ao);
+                    }
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        ae = mfma(Ae1[q], x[i][q], ae);
+                        ao = mfma(Ao1[q], x[i][q], ao);
+                    }
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) ae = mfma(Ae2[q], xm[q], ae);
+                    ae = prelu4(ae, a);
+                    ao = prelu4(ao, a);
+                    if (dbg && ok[i]) {
+                        float* d3 = dbg + 3 * nbt * 528 + ((ob + t0 + tl[i]) * F1) * 16 + 4 * g;
+                        st4(d3 + (2 * ff[i]) * 16, ae);
+                        if (ff[i] < 32) st4(d3 + (2 * ff[i] + 1) * 16, ao);
+                    }
+                    // + en_outs[0] (identity slot order), then de_convs.4 in scatter form
+                    if (ok[i]) {
+                        const float* s0 = en0 + ((ob + t0 + tl[i]) * F1 + 2 * ff[i]) * 16 + 4 * g;
+                        ae += ld4(s0);
+                        if (ff[i] < 32) ao += ld4(s0 + 16);
+                    }
+                    f32x4 e = splat(0.f), o = splat(0.f);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        e = mfma(A4[q], ae[q], e);
+                        o = mfma(A4[q], ao[q], o);
+                    }
+                    ze[i] = e;
+                    zo[i] = o;
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        __syncthreads();  // all taps of sW read: region A becomes Z[tl][65][16]
+#pragma unroll
+        for (int i = 0; i < TPW; ++i)
+            if (i < ntl) {
+                st4(sZ + pl(tl[i] * F1 + 2 * ff[i], g), ze[i]);
+                if (ff[i] < 32) st4(sZ + pl(tl[i] * F1 + 2 * ff[i] + 1, g), zo[i]);
+            }
+        __syncthreads();
+        // de_convs.4 gather + BN + Tanh: m[o][f''] = tanh(b[o] + sum_k z[(f''+2-k)/2][o*5+k])
+        for (int idx = tid; idx < 2 * nfr * F0; idx += NTHR) {
+            const int fq = idx % F0, ot = idx / F0, tq = ot % nfr, o = ot / nfr;
+            float s = sP[D_DE4_B + o];
+#pragma unroll
+            for (int k = 0; k < 5; ++k) {
+                const int num = fq + 2 - k;
+                if ((num & 1) == 0 && num >= 0 && num < 2 * F1) s += sZ[pls(tq * F1 + (num >> 1), o * 5 + k)];
+            }
+            sM[(o * TC + tq) * F0 + fq] = tanhf(s);
+        }
+        __syncthreads();
+        if (dbg)
+            for (int idx = tid; idx < 2 * nfr * F0; idx += NTHR) {
+                const int fq = idx % F0, ot = idx / F0, tq = ot % nfr, o = ot / nfr;
+                dbg[3 * nbt * 528 + nbt * F1 * 16 + (((long)b * 2 + o) * T + t0 + tq) * F0 + fq] =
+                    sM[(o * TC + tq) * F0 + fq];
+            }
+        // ---- ERB.bs + complex ratio mask + output layout --------------------------------------------
+        for (int idx = tid; idx < nfr * NBINS; idx += NTHR) {
+            int tq, f;
+            if (t_fast) { tq = idx % nfr; f = idx / nfr; } else { f = idx % NBINS; tq = idx / NBINS; }
+            float mr, mi;
+            if (f < ERB_LOW) {
+                mr = sM[(0 * TC + tq) * F0 + f];
+                mi = sM[(1 * TC + tq) * F0 + f];
+            } else {
+                const int i = f - ERB_LOW, lo = sI[I_BS_LO + i], cnt = sI[I_BS_N + i];
+                mr = 0.f; mi = 0.f;
+                for (int q = 0; q < cnt; ++q) {
+                    const float w = sP[D_BS_W + i * ERB_MAXBS + q];
+                    mr += w * sM[(0 * TC + tq) * F0 + ERB_LOW + lo + q];
+                    mi += w * sM[(1 * TC + tq) * F0 + ERB_LOW + lo + q];
+                }
+            }
+            const float* sp = spec + (long)f * sf + (long)(t0 + tq) * st;
+            const float re = sp[0], im = sp[1];
+            float* op = out + (long)f * osf + (long)(t0 + tq) * ost;
+            op[0] = re * mr - im * mi;
+            op[1] = im * mr + re * mi;
+        }
+        __syncthreads();  // sM and region A are rewritten by the next chunk
+    }
+    if (stb) {
+        __syncthreads();
+        rings_store(sH, sEH, stb + ST_DEC_H, stb + ST_DEC_E, tid);
+        if (tid == 0) reinterpret_cast<int*>(stb)[0] = (tbase + T) & 0xFFFF;  // frame counter (rings use mod 16)
+    }
+}
+
+// ==================================================================== state conversion
+// library ring state <-> the reference's caches (gtcrn_micro_stream.py:618-623, slices :416-428
+// and :490-500).  dir 0: import (reference -> rings), 1: export.  One workgroup per stream.
+__global__ void k_state_convert(float* __restrict__ state, int N, float* __restrict__ conv, float* __restrict__ tra,
+                                float* const* __restrict__ tcn8, const int* __restrict__ PI, int dir) {
+    const int b = blockIdx.x, tid = threadIdx.x, nthr = blockDim.x;
+    float* st = state + (long)b * ST_FLOATS;
+    int pos = dir == 0 ? 0 : reinterpret_cast<const int*>(st)[0];
+    if (dir == 0 && tid == 0) reinterpret_cast<int*>(st)[0] = 0;
+    // conv_cache (2,N,16,6,33): encoder block k rows 2k..2k+1, decoder block j rows 4-2j..5-2j;
+    // the cached tensor is h (hidden channel order == slot order); cache row r holds frame pos-2+r.
+    for (int e = 0; e < 2; ++e)
+        for (int idx = tid; idx < 3 * 2 * 33 * 16; idx += nthr) {
+            const int s = idx & 15, f = (idx >> 4) % 33, r = ((idx >> 4) / 33) & 1, k = (idx >> 4) / 66;
+            const int row = (e == 0 ? 2 * k : 4 - 2 * k) + r;
+            float* c = conv + ((((long)e * N + b) * 16 + s) * 6 + row) * 33 + f;
+            float* rg = st + (e == 0 ? ST_ENC_H : ST_DEC_H) + ((k * 2 + ((pos - 2 + r) & 1)) * 33 + f) * 16 + s;
+            if (dir == 0) *rg = *c; else *c = *rg;
+        }
+    // tra_cache (2,3,N,8,2): last two energies, entry r holds frame pos-2+r
+    for (int idx = tid; idx < 2 * 3 * 8 * 2; idx += nthr) {
+        const int r = idx & 1, c8 = (idx >> 1) & 7, k = (idx >> 4) % 3, e = idx / 48;
+        float* c = tra + ((((long)e * 3 + k) * N + b) * 8 + c8) * 2 + r;
+        float* rg = st + (e == 0 ? ST_ENC_E : ST_DEC_E) + k * 16 + ((pos - 2 + r) & 1) * 8 + c8;
+        if (dir == 0) *rg = *c; else *c = *rg;
+    }
+    // tcn_cache[g][k] (N,16,2d,33): y1 (hidden order), row r holds frame pos-2d+r
+    for (int gk = 0; gk < 8; ++gk) {
+        const int gg = gk >> 2, k = gk & 3, d = 1 << k;
+        float* cache = tcn8[gk];
+        for (int idx = tid; idx < 2 * d * 33 * 16; idx += nthr) {
+            const int s = idx & 15, f = (idx >> 4) % 33, r = (idx >> 4) / 33;
+            float* c = cache + (((long)b * 16 + s) * 2 * d + r) * 33 + f;
+            float* rg = st + (gg == 0 ? ST_G1_H : ST_G2_H) + ((2 * (d - 1) + ((pos - 2 * d + r) & (2 * d - 1))) * 33 + f) * 16 + s;
+            if (dir == 0) *rg = *c; else *c = *rg;
+        }
+    }
+    (void)PI;
+}
+
+// ==================================================================================== self test
+// D = A(16x4) * B(4x16) + C with the lane maps the kernels rely on:
+// a = A[i = lane&15][k = lane>>4], b = B[k = lane>>4][j = lane&15], D reg r -> row 4*(lane>>4)+r, col lane&15.
+__global__ void k_selftest(const float* __restrict__ A, const float* __restrict__ Bm, const float* __restrict__ C,
+                           float* __restrict__ D) {
+    const int lane = threadIdx.x, n = lane & 15, g = lane >> 4;
+    f32x4 c;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) c[r] = C[(4 * g + r) * 16 + n];
+    c = mfma(A[n * 4 + g], Bm[g * 16 + n], c);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) D[(4 * g + r) * 16 + n] = c[r];
+}
+
+}  // namespace gtk
+
+// ============================================================================== launchers
+namespace gtk {
+
+#define GT_LAUNCH_CHECK()                       \
+    do {                                        \
+        hipError_t e_ = hipGetLastError();      \
+        if (e_ != hipSuccess) return (int)e_;   \
+    } while (0)
+
+int launch_stft(const float* wave, int B, long L, int T, const float* win, const float* twid, float* spec, long sb,
+                long sf, long st, float* frames, hipStream_t s) {
+    const long nframes = (long)B * T;
+    const int per = FFT_WAVES * FRAMES_PER_WAVE;
+    const int grid = (int)((nframes + per - 1) / per);
+    hipLaunchKernelGGL(k_stft, dim3(grid), dim3(FFT_WAVES * 64), 0, s, wave, B, L, T, win,
+                       reinterpret_cast<const float2*>(twid), spec, sb, sf, st, frames);
+    GT_LAUNCH_CHECK();
+    return 0;
+}
+
+int launch_istft(const float* spec, long sb, long sf, long st, int B, int T, const float* win, const float* twid,
+                 float* wave, hipStream_t s) {
+    const int groups = (T - 1 + ISTFT_BLOCKS - 1) / ISTFT_BLOCKS;
+    hipLaunchKernelGGL(k_istft, dim3(B * groups), dim3(FFT_WAVES * 64), 0, s, spec, sb, sf, st, B, T, win,
+                       reinterpret_cast<const float2*>(twid), wave);
+    GT_LAUNCH_CHECK();
+    return 0;
+}
+
+int configure_kernels() {
+    hipError_t e;
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_encoder), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            ENC_LDS_FLOATS * 4);
+    if (e != hipSuccess) return (int)e;
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_gtcn), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            GT_LDS_FLOATS * 4);
+    if (e != hipSuccess) return (int)e;
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_decoder), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            DEC_LDS_FLOATS * 4);
+    if (e != hipSuccess) return (int)e;
+    return 0;
+}
+
+int launch_encoder(const float* spec, long sb, long sf, long st, int B, int T, const float* PF, const int* PI,
+                   float* en0, float* en1, float* en2, float* en3, float* en4, float* state, hipStream_t s) {
+    hipLaunchKernelGGL(k_encoder, dim3(B), dim3(NTHR), ENC_LDS_FLOATS * 4, s, spec, sb, sf, st, T, PF, PI, en0, en1,
+                       en2, en3, en4, state);
+    GT_LAUNCH_CHECK();
+    return 0;
+}
+
+int launch_gtcn(const float* xin, float* xout, const float* P, int B, int T, float* state, int st_off,
+                hipStream_t s) {
+    hipLaunchKernelGGL(k_gtcn, dim3(B), dim3(NTHR), GT_LDS_FLOATS * 4, s, xin, xout, P, T, state, st_off);
+    GT_LAUNCH_CHECK();
+    return 0;
+}
+
+int launch_decoder(const float* xg, const float* en0, const float* en1, const float* en2, const float* en3,
+                   const float* en4, const float* spec, long sb, long sf, long st, float* out, long osb, long osf,
+                   long ost, int B, int T, const float* PF, const int* PI, float* state, float* dbg, hipStream_t s) {
+    hipLaunchKernelGGL(k_decoder, dim3(B), dim3(NTHR), DEC_LDS_FLOATS * 4, s, xg, en0, en1, en2, en3, en4, spec, sb,
+                       sf, st, out, osb, osf, ost, T, PF, PI, state, dbg);
+    GT_LAUNCH_CHECK();
+    return 0;
+}
+
+int launch_state_convert(float* state, int N, float* conv, float* tra, float* const* tcn8, const int* PI, int dir,
+                         hipStream_t s) {
+    hipLaunchKernelGGL(k_state_convert, dim3(N), dim3(256), 0, s, state, N, conv, tra, tcn8, PI, dir);
+    GT_LAUNCH_CHECK();
+    return 0;
+}
+
+int launch_selftest(const float* A, const float* Bm, const float* C, float* D, hipStream_t s) {
+    hipLaunchKernelGGL(k_selftest, dim3(1), dim3(64), 0, s, A, Bm, C, D);
+    GT_LAUNCH_CHECK();
+    return 0;
+}
+
+}  // namespace gtk

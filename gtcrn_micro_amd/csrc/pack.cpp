@@ -1,0 +1,325 @@
+// pack.cpp -- host side of the weight contract: the reference state_dict blob
+// (canonical order, see include/gtcrn_micro_hip.h) -> BatchNorm folded, slot-space
+// packed buffers the gfx950 kernels consume (layout.h).  Pure C++17, no HIP.
+//
+// Reference semantics restated here (paths relative to the reference repo):
+//   * eval-mode BatchNorm2d folding: y = (conv(x) - mean) * gamma / sqrt(var + 1e-5) + beta
+//     (ConvBlock.forward models/gtcrn_micro.py:163-164, GTConvBlock :233-243, TCN :296-310)
+//   * Conv2d weight (out,in,kt,kf); ConvTranspose2d weight (in,out,kt,kf)
+//     (streaming/conversion/convert.py:35-48)
+//   * GTConvBlock split/shuffle: x1 = channels 0..7, x2 = 8..15, out[2c] = h[c],
+//     out[2c+1] = x2[c] (models/gtcrn_micro.py:222-253)
+#include "pack.h"
+
+#include <cmath>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "layout.h"
+
+namespace gtcrn {
+using namespace gtl;
+
+// ------------------------------------------------------------ parameter table
+static void add(std::vector<ParamInfo>& v, const std::string& name, long numel) {
+    long off = v.empty() ? 0 : v.back().offset + v.back().numel;
+    v.push_back({name, numel, off});
+}
+static void add_bn(std::vector<ParamInfo>& v, const std::string& p, int C) {
+    add(v, p + ".weight", C); add(v, p + ".bias", C);
+    add(v, p + ".running_mean", C); add(v, p + ".running_var", C);
+}
+static void add_convblock(std::vector<ParamInfo>& v, const std::string& p, long wnumel, int Cout, bool act) {
+    add(v, p + ".conv.weight", wnumel); add(v, p + ".conv.bias", Cout);
+    add_bn(v, p + ".bn", Cout);
+    if (act) add(v, p + ".act.weight", 1);
+}
+static void add_gtconv(std::vector<ParamInfo>& v, const std::string& p, bool dense) {
+    add(v, p + ".point_conv1.weight", 128); add(v, p + ".point_conv1.bias", 16);
+    add_bn(v, p + ".point_bn1", 16); add(v, p + ".point_act.weight", 1);
+    add(v, p + ".depth_conv.weight", dense ? 2304 : 144); add(v, p + ".depth_conv.bias", 16);
+    add_bn(v, p + ".depth_bn", 16); add(v, p + ".depth_act.weight", 1);
+    add(v, p + ".point_conv2.weight", 128); add(v, p + ".point_conv2.bias", 8);
+    add_bn(v, p + ".point_bn2", 8);
+    add(v, p + ".tra.depth_conv.weight", 24); add(v, p + ".tra.depth_conv.bias", 8);
+    add(v, p + ".tra.point_conv.weight", 64); add(v, p + ".tra.point_conv.bias", 8);
+}
+
+const std::vector<ParamInfo>& param_table() {
+    static const std::vector<ParamInfo> table = [] {
+        std::vector<ParamInfo> v;
+        add(v, "erb.erb_fc.weight", 64 * 192);
+        add(v, "erb.ierb_fc.weight", 192 * 64);
+        add(v, "sfe.depth_conv.weight", 9);
+        add_convblock(v, "encoder.en_convs.0", 16 * 3 * 5, 16, true);
+        add_convblock(v, "encoder.en_convs.1", 16 * 16 * 5, 16, true);
+        for (int k = 2; k < 5; ++k) add_gtconv(v, "encoder.en_convs." + std::to_string(k), false);
+        for (int g = 1; g <= 2; ++g)
+            for (int k = 0; k < 4; ++k) {
+                std::string p = "gtcn" + std::to_string(g) + ".blocks." + std::to_string(k);
+                add(v, p + ".conv1.weight", 256); add(v, p + ".conv1.bias", 16);
+                add_bn(v, p + ".bn1", 16); add(v, p + ".act1.weight", 1);
+                add(v, p + ".conv2.weight", 48); add(v, p + ".conv2.bias", 16);
+                add_bn(v, p + ".bn2", 16); add(v, p + ".act2.weight", 1);
+                add(v, p + ".conv3.weight", 256); add(v, p + ".conv3.bias", 16);
+                add_bn(v, p + ".bn3", 16); add(v, p + ".act3.weight", 1);
+            }
+        for (int k = 0; k < 3; ++k) add_gtconv(v, "decoder.de_convs." + std::to_string(k), true);
+        add_convblock(v, "decoder.de_convs.3", 16 * 16 * 5, 16, true);
+        add_convblock(v, "decoder.de_convs.4", 16 * 2 * 5, 2, false);
+        return v;
+    }();
+    return table;
+}
+
+// ------------------------------------------------------------------- helpers
+namespace {
+
+struct Cursor {
+    const float* p;
+    const float* take(long n) { const float* r = p; p += n; return r; }
+};
+struct BN { const float *w, *b, *rm, *rv; };
+static BN take_bn(Cursor& c, int C) { BN b; b.w = c.take(C); b.b = c.take(C); b.rm = c.take(C); b.rv = c.take(C); return b; }
+
+// folded per-channel affine: y = conv_nobias(x) * scale + shift
+static void fold(const BN& bn, const float* conv_bias, int C, std::vector<double>& scale, std::vector<double>& shift) {
+    scale.resize(C); shift.resize(C);
+    for (int o = 0; o < C; ++o) {
+        double s = (double)bn.w[o] / std::sqrt((double)bn.rv[o] + 1e-5);
+        scale[o] = s;
+        shift[o] = ((double)(conv_bias ? conv_bias[o] : 0.f) - (double)bn.rm[o]) * s + (double)bn.b[o];
+    }
+}
+
+struct Perm {          // slot -> logical channel
+    int l[16];
+    int slot_of(int logical) const { for (int s = 0; s < 16; ++s) if (l[s] == logical) return s; return -1; }
+};
+static Perm identity() { Perm p; for (int s = 0; s < 16; ++s) p.l[s] = s; return p; }
+
+struct GTRaw {
+    const float *pc1_w, *pc1_b; BN bn1; float a1;
+    const float *dc_w, *dc_b; BN bn2; float a2;
+    const float *pc2_w, *pc2_b; BN bn3;
+    const float *tdw, *tdb, *tpw, *tpb;
+};
+static GTRaw take_gt(Cursor& c, bool dense) {
+    GTRaw g;
+    g.pc1_w = c.take(128); g.pc1_b = c.take(16); g.bn1 = take_bn(c, 16); g.a1 = *c.take(1);
+    g.dc_w = c.take(dense ? 2304 : 144); g.dc_b = c.take(16); g.bn2 = take_bn(c, 16); g.a2 = *c.take(1);
+    g.pc2_w = c.take(128); g.pc2_b = c.take(8); g.bn3 = take_bn(c, 8);
+    g.tdw = c.take(24); g.tdb = c.take(8); g.tpw = c.take(64); g.tpb = c.take(8);
+    return g;
+}
+
+// Packs one GTConv block in slot space; in = permutation of the block input, returns output permutation.
+// deconv: 1x1 weights are ConvTranspose2d (in,out); dense 3x3 transposed conv packed at GB_DN_A.
+static Perm pack_gtconv(const GTRaw& g, bool deconv, const Perm& in, float* F, int* I) {
+    std::vector<double> sc, sh;
+    // point_conv1 (8 -> 16) + point_bn1; hidden channels keep their own order
+    fold(g.bn1, g.pc1_b, 16, sc, sh);
+    for (int h = 0; h < 16; ++h) {
+        for (int s = 0; s < 16; ++s) {
+            int lc = in.l[s];
+            double w = 0.0;
+            if (lc < 8) w = deconv ? g.pc1_w[lc * 16 + h] : g.pc1_w[h * 8 + lc];
+            F[GB_PC1_A + h * 16 + s] = (float)(w * sc[h]);
+        }
+        F[GB_PC1_B + h] = (float)sh[h];
+    }
+    // depth conv + depth_bn
+    fold(g.bn2, g.dc_b, 16, sc, sh);
+    if (!deconv) {
+        // depthwise Conv2d (16,1,3,3): out[c,t,f] = sum w[c,kt,kf] * h[c, t-2+kt, f-1+kf]
+        for (int kt = 0; kt < 3; ++kt)
+            for (int kf = 0; kf < 3; ++kf)
+                for (int c = 0; c < 16; ++c)
+                    F[GB_DW_W + (kt * 3 + kf) * 16 + c] = (float)((double)g.dc_w[(c * 3 + kt) * 3 + kf] * sc[c]);
+    } else {
+        for (int i = 0; i < 144; ++i) F[GB_DW_W + i] = 0.f;
+        // dense ConvTranspose2d (in,out,3,3): y[o,t,f] = sum_i h[i, t-kt, f+1-kf] * W[i,o,kt,kf]
+        for (int kt = 0; kt < 3; ++kt)
+            for (int kf = 0; kf < 3; ++kf)
+                for (int o = 0; o < 16; ++o)
+                    for (int i = 0; i < 16; ++i)
+                        F[GB_DN_A + (kt * 3 + kf) * 256 + o * 16 + i] =
+                            (float)((double)g.dc_w[((i * 16 + o) * 3 + kt) * 3 + kf] * sc[o]);
+    }
+    for (int c = 0; c < 16; ++c) F[GB_DW_B + c] = (float)sh[c];
+    // point_conv2 (16 -> 8) + point_bn2, written in place over the x1 slots
+    fold(g.bn3, g.pc2_b, 8, sc, sh);
+    Perm out;
+    int c_next = 0;
+    for (int s = 0; s < 16; ++s) {
+        if (in.l[s] < 8) {  // x1 slot: receives h'[c]
+            int c = c_next++;
+            for (int h = 0; h < 16; ++h) {
+                double w = deconv ? g.pc2_w[h * 8 + c] : g.pc2_w[c * 16 + h];
+                F[GB_PC2_A + s * 16 + h] = (float)(w * sc[c]);
+            }
+            F[GB_PC2_B + s] = (float)sh[c];
+            F[GB_KEEP + s] = 0.f;
+            I[c] = s;                 // slot_of_c
+            out.l[s] = 2 * c;         // shuffle: out[2c] = h'[c]
+        } else {            // x2 slot: passes through
+            int c = in.l[s] - 8;
+            for (int h = 0; h < 16; ++h) F[GB_PC2_A + s * 16 + h] = 0.f;
+            F[GB_PC2_B + s] = 0.f;
+            F[GB_KEEP + s] = 1.f;
+            I[8 + c] = s;             // x2slots (indexed by x2 channel)
+            out.l[s] = 2 * c + 1;     // shuffle: out[2c+1] = x2[c]
+        }
+    }
+    std::memcpy(F + GB_TRA_DW, g.tdw, 24 * sizeof(float));
+    std::memcpy(F + GB_TRA_DB, g.tdb, 8 * sizeof(float));
+    std::memcpy(F + GB_TRA_PW, g.tpw, 64 * sizeof(float));
+    std::memcpy(F + GB_TRA_PB, g.tpb, 8 * sizeof(float));
+    F[GB_SLOPE + 0] = g.a1; F[GB_SLOPE + 1] = g.a2; F[GB_SLOPE + 2] = 0.f; F[GB_SLOPE + 3] = 0.f;
+    return out;
+}
+
+// skip[s] = index inside the stored record (order `stored`) of the logical channel held in slot s of `cur`
+static void skip_table(const Perm& cur, const Perm& stored, int* out) {
+    for (int s = 0; s < 16; ++s) out[s] = stored.slot_of(cur.l[s]);
+}
+
+}  // namespace
+
+int pack_params(const float* params, long n, float* F, int* I, std::string& err) {
+    if (!params || n != NPARAM) { err = "parameter blob must hold 44938 floats"; return -1; }
+    std::memset(F, 0, sizeof(float) * P_FLOATS);
+    std::memset(I, 0, sizeof(int) * P_INTS);
+    Cursor c{params};
+    std::vector<double> sc, sh;
+
+    // ---- ERB (fixed filterbank): contiguous supports -> banded tables ----------------
+    const float* erb = c.take(64 * 192);   // erb_fc.weight (64,192)
+    const float* ierb = c.take(192 * 64);  // ierb_fc.weight (192,64)
+    float* E = F + P_ENC;
+    float* D = F + P_DEC;
+    for (int j = 0; j < 64; ++j) {
+        int lo = -1, hi = -1;
+        for (int i = 0; i < 192; ++i) if (erb[j * 192 + i] != 0.f) { if (lo < 0) lo = i; hi = i; }
+        if (lo < 0) { lo = 0; hi = -1; }
+        if (hi - lo + 1 > ERB_MAXBW) { err = "erb_fc band wider than ERB_MAXBW"; return -1; }
+        I[I_ERB_LO + j] = lo; I[I_ERB_N + j] = hi - lo + 1;
+        for (int i = lo; i <= hi; ++i) E[E_ERB_W + j * ERB_MAXBW + (i - lo)] = erb[j * 192 + i];
+    }
+    for (int i = 0; i < 192; ++i) {
+        int lo = -1, hi = -1;
+        for (int j = 0; j < 64; ++j) if (ierb[i * 64 + j] != 0.f) { if (lo < 0) lo = j; hi = j; }
+        if (lo < 0) { lo = 0; hi = -1; }
+        if (hi - lo + 1 > ERB_MAXBS) { err = "ierb_fc row wider than ERB_MAXBS"; return -1; }
+        I[I_BS_LO + i] = lo; I[I_BS_N + i] = hi - lo + 1;
+        for (int j = lo; j <= hi; ++j) D[D_BS_W + i * ERB_MAXBS + (j - lo)] = ierb[i * 64 + j];
+    }
+    // ---- SFE_Lite ---------------------------------------------------------------------
+    std::memcpy(E + E_SFE_W, c.take(9), 9 * sizeof(float));
+    // ---- en_convs.0: Conv2d(3,16,(1,5)) + BN + PReLU; im2col column e = c*5 + k -----------
+    {
+        const float* w = c.take(240); const float* b = c.take(16); BN bn = take_bn(c, 16);
+        fold(bn, b, 16, sc, sh);
+        for (int o = 0; o < 16; ++o) {
+            for (int e = 0; e < 15; ++e) E[E_EN0_A + o * 16 + e] = (float)((double)w[o * 15 + e] * sc[o]);
+            E[E_EN0_A + o * 16 + 15] = 0.f;
+            E[E_EN0_B + o] = (float)sh[o];
+        }
+        E[E_EN0_S] = *c.take(1);
+    }
+    // ---- en_convs.1: Conv2d(16,16,(1,5)) + BN + PReLU; one slot matrix per tap -------------
+    {
+        const float* w = c.take(1280); const float* b = c.take(16); BN bn = take_bn(c, 16);
+        fold(bn, b, 16, sc, sh);
+        for (int k = 0; k < 5; ++k)
+            for (int o = 0; o < 16; ++o)
+                for (int i = 0; i < 16; ++i)
+                    E[E_EN1_A + k * 256 + o * 16 + i] = (float)((double)w[(o * 16 + i) * 5 + k] * sc[o]);
+        for (int o = 0; o < 16; ++o) E[E_EN1_B + o] = (float)sh[o];
+        E[E_EN1_S] = *c.take(1);
+    }
+    Perm perm[9];
+    perm[0] = identity();  // en0
+    perm[1] = identity();  // en1
+    for (int k = 0; k < 3; ++k) {
+        GTRaw g = take_gt(c, false);
+        perm[2 + k] = pack_gtconv(g, false, perm[1 + k], E + E_BLK + k * GB_SIZE, I + I_ENC_BLK + k * 16);
+    }
+    // ---- GTCN x2: residual blocks keep the slot order of en4 ---------------------------------
+    const Perm& pg = perm[4];
+    for (int g = 0; g < 2; ++g)
+        for (int k = 0; k < 4; ++k) {
+            float* T = F + P_GTCN + g * GTCN_SIZE + k * TCN_SIZE;
+            const float* w1 = c.take(256); const float* b1 = c.take(16); BN bn1 = take_bn(c, 16); float a1 = *c.take(1);
+            const float* w2 = c.take(48);  const float* b2 = c.take(16); BN bn2 = take_bn(c, 16); float a2 = *c.take(1);
+            const float* w3 = c.take(256); const float* b3 = c.take(16); BN bn3 = take_bn(c, 16); float a3 = *c.take(1);
+            fold(bn1, b1, 16, sc, sh);
+            for (int h = 0; h < 16; ++h) {
+                for (int s = 0; s < 16; ++s) T[TCN_A1 + h * 16 + s] = (float)((double)w1[h * 16 + pg.l[s]] * sc[h]);
+                T[TCN_B1 + h] = (float)sh[h];
+            }
+            fold(bn2, b2, 16, sc, sh);
+            for (int kk = 0; kk < 3; ++kk)
+                for (int h = 0; h < 16; ++h) T[TCN_DW + kk * 16 + h] = (float)((double)w2[h * 3 + kk] * sc[h]);
+            for (int h = 0; h < 16; ++h) T[TCN_B2 + h] = (float)sh[h];
+            fold(bn3, b3, 16, sc, sh);
+            for (int s = 0; s < 16; ++s) {
+                int o = pg.l[s];
+                for (int h = 0; h < 16; ++h) T[TCN_A3 + s * 16 + h] = (float)((double)w3[o * 16 + h] * sc[o]);
+                T[TCN_B3 + s] = (float)sh[o];
+            }
+            T[TCN_SLOPE + 0] = a1; T[TCN_SLOPE + 1] = a2; T[TCN_SLOPE + 2] = a3; T[TCN_SLOPE + 3] = 0.f;
+        }
+    // ---- decoder GTConv blocks (input of block j = x + en_outs[4-j]) -----------------------------
+    Perm cur = perm[4];
+    for (int j = 0; j < 3; ++j) {
+        GTRaw g = take_gt(c, true);
+        cur = pack_gtconv(g, true, cur, D + D_BLK + j * GBD_SIZE, I + I_DEC_BLK + j * 16);
+        perm[5 + j] = cur;
+        // the skip added to this block's OUTPUT: en3 (after de0), en2 (after de1), en1 (after de2)
+        skip_table(cur, perm[3 - j], I + I_SKIP + j * 16);
+    }
+    // ---- de_convs.3: ConvTranspose2d(16,16,(1,5),stride 2) + BN + PReLU, gather form -------------
+    {
+        const float* w = c.take(1280); const float* b = c.take(16); BN bn = take_bn(c, 16);
+        fold(bn, b, 16, sc, sh);
+        const int ke[3] = {0, 2, 4}, ko[2] = {1, 3};
+        for (int o = 0; o < 16; ++o) {
+            for (int s = 0; s < 16; ++s) {
+                int i = cur.l[s];
+                for (int a = 0; a < 3; ++a) D[D_DE3_AE + a * 256 + o * 16 + s] = (float)((double)w[(i * 16 + o) * 5 + ke[a]] * sc[o]);
+                for (int a = 0; a < 2; ++a) D[D_DE3_AO + a * 256 + o * 16 + s] = (float)((double)w[(i * 16 + o) * 5 + ko[a]] * sc[o]);
+            }
+            D[D_DE3_B + o] = (float)sh[o];
+        }
+        D[D_DE3_S] = *c.take(1);
+        perm[8] = identity();
+    }
+    // ---- de_convs.4: ConvTranspose2d(16,2,(1,5),stride 2) + BN (+Tanh), scatter form ----------------
+    {
+        const float* w = c.take(160); const float* b = c.take(2); BN bn = take_bn(c, 2);
+        fold(bn, b, 2, sc, sh);
+        for (int o = 0; o < 2; ++o) {
+            for (int k = 0; k < 5; ++k)
+                for (int i = 0; i < 16; ++i)
+                    D[D_DE4_A + (o * 5 + k) * 16 + i] = (float)((double)w[(i * 2 + o) * 5 + k] * sc[o]);
+            D[D_DE4_B + o] = (float)sh[o];
+        }
+    }
+    if (c.p - params != NPARAM) { err = "internal: parameter walk ended at the wrong offset"; return -1; }
+    for (int t = 0; t < 9; ++t)
+        for (int s = 0; s < 16; ++s) I[I_PERM + t * 16 + s] = perm[t].l[s];
+    return 0;
+}
+
+void make_window(int kind, float* w) {
+    // torch.hann_window(512) (periodic, fp32: cos(n * float(2pi/512)) * -0.5 + 0.5); kind 0 takes sqrt
+    for (int n = 0; n < 512; ++n) {
+        float ang = (float)n * (float)(2.0 * M_PI / 512.0);
+        float hann = std::cos(ang) * -0.5f + 0.5f;
+        w[n] = kind == 0 ? std::sqrt(hann) : hann;
+    }
+}
+
+}  // namespace gtcrn

@@ -1,0 +1,147 @@
+/*
+ * gtcrn_micro_hip.h -- C ABI of the MI355X (gfx950) GTCRN-Micro hot path.
+ *
+ * The reference (bglid/GTCRN-Micro) has no FFI layer: its seam is the Python
+ * class surface.  Each entry point below names the reference interface it
+ * replaces (paths relative to the reference repo).  All pointers are plain
+ * caller-owned pointers; "d_" = device memory (e.g. torch.Tensor.data_ptr()),
+ * "h_" = host memory.  No torch types cross this boundary.
+ *
+ * Every function returns 0 on success or a negative gtcrn_status; the message
+ * is available from gtcrn_last_error() (thread-local).  Launches are
+ * asynchronous on the given HIP stream (a hipStream_t passed as void*; NULL =
+ * the default stream).  A model handle is bound to one device and is not
+ * meant for concurrent calls from several threads (the reference's contract:
+ * single-threaded caller, one process per GPU -- train.py:461-471).
+ */
+#ifndef GTCRN_MICRO_HIP_H
+#define GTCRN_MICRO_HIP_H
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GTCRN_ABI_VERSION 1
+#define GTCRN_NFFT 512
+#define GTCRN_HOP 256
+#define GTCRN_NBINS 257
+#define GTCRN_NPARAM_FLOATS 44938 /* state_dict minus num_batches_tracked */
+
+typedef enum {
+    GTCRN_OK = 0,
+    GTCRN_ERR_ARG = -1,     /* bad argument (shape, null pointer, T < 1 ...) */
+    GTCRN_ERR_HIP = -2,     /* a HIP runtime call failed */
+    GTCRN_ERR_DEVICE = -3,  /* no gfx950 device / wrong architecture */
+    GTCRN_ERR_STATE = -4    /* handle used before/after its lifetime, workspace too small under capture */
+} gtcrn_status;
+
+typedef struct gtcrn_model gtcrn_model;
+
+int gtcrn_abi_version(void);
+const char *gtcrn_last_error(void);
+
+/* ---- parameter blob -----------------------------------------------------
+ * The flat fp32 blob is the reference state_dict in its own order without the
+ * int64 num_batches_tracked entries (ckpt["model"], train.py:200-216;
+ * models/gtcrn_micro.py:486-504).  These describe that order so a host can
+ * pack by name. */
+long gtcrn_param_tensors(void);             /* number of tensors (342) */
+const char *gtcrn_param_name(long i);       /* e.g. "encoder.en_convs.0.conv.weight" */
+long gtcrn_param_numel(long i);
+long gtcrn_param_offset(long i);            /* float offset into the blob */
+
+/* ---- model handle -------------------------------------------------------
+ * Replaces: GTCRNMicro(...).to(device) + load_state_dict(ckpt["model"]) + .eval()
+ * (infer.py:37-41).  BatchNorm is folded with its running statistics
+ * (eval mode).  device = HIP device ordinal. */
+int gtcrn_model_create(gtcrn_model **out, const float *h_params, long n_floats, int device);
+/* Re-fold after the host changed the weights (load_state_dict on a live module). */
+int gtcrn_model_set_params(gtcrn_model *m, const float *h_params, long n_floats);
+void gtcrn_model_destroy(gtcrn_model *m);
+
+/* Pre-size the library-owned workspace so that later calls with batch <= B and
+ * frames <= T do no allocation (required before HIP-graph capture). */
+int gtcrn_model_reserve(gtcrn_model *m, int B, int T);
+
+/* ---- windows ------------------------------------------------------------
+ * kind 0: torch.hann_window(512).pow(0.5) (infer.py:65, loss.py:50, tests);
+ * kind 1: torch.hann_window(512) (train.py:252).  Host helper; callers may
+ * pass any 512-tap window they computed themselves. */
+int gtcrn_make_window(int kind, float *h_w512);
+long gtcrn_num_frames(long L); /* 1 + L/256 (torch.stft center=True) */
+
+/* ---- STFT / iSTFT (the callers' torch.stft / torch.istft) ---------------
+ * Replaces torch.stft(x,512,256,512,win,return_complex=False) (infer.py:60-67,
+ * train.py:247-263): d_wave (B,L) -> d_spec.  The spectrogram is addressed as
+ *   spec[b,f,t,c] = d_spec[b*sb + f*sf + t*st + c]   (c = 0 re, 1 im)
+ * reference layout (B,257,T,2): sb = 257*T*2, sf = T*2, st = 2. */
+int gtcrn_stft(const float *d_wave, int B, long L, const float *d_win, float *d_spec,
+               long sb, long sf, long st, void *stream);
+/* Windowed frames only, (B,T,512): exposes the framing/indexing for the
+ * bit-exactness check (reflect pad 256, frame t = xp[256t:256t+512]). */
+int gtcrn_stft_frames(const float *d_wave, int B, long L, const float *d_win, float *d_frames, void *stream);
+/* Replaces torch.istft(view_as_complex(y),512,256,512,win) (infer.py:73-76):
+ * d_spec (strided as above) -> d_wave (B, 256*(T-1)). */
+int gtcrn_istft(const float *d_spec, long sb, long sf, long st, int B, int T, const float *d_win,
+                float *d_wave, void *stream);
+
+/* ---- offline forward ----------------------------------------------------
+ * Replaces GTCRNMicro.forward(spec) in eval mode (models/gtcrn_micro.py:506-532):
+ * (B,257,T,2) -> (B,257,T,2), both addressed with the strides given. */
+int gtcrn_forward_spec(gtcrn_model *m, const float *d_spec_in, long isb, long isf, long ist,
+                       float *d_spec_out, long osb, long osf, long ost, int B, int T, void *stream);
+/* Fused caller loop of infer.py:60-76 for B equal-length clips:
+ * STFT -> forward -> iSTFT; d_wave (B,L) -> d_wave_out (B, 256*(L/256)). */
+int gtcrn_forward_wave(gtcrn_model *m, const float *d_wave, float *d_wave_out, int B, long L,
+                       const float *d_win, void *stream);
+
+/* ---- streaming ----------------------------------------------------------
+ * Replaces StreamGTCRNMicro.forward(spec, conv_cache, tra_cache, tcn_cache)
+ * (gtcrn_micro_stream.py:541-574) for nstreams independent streams.  The
+ * per-stream state lives in device memory in the library's ring layout;
+ * import/export convert from/to the reference's three caches:
+ *   conv_cache (2,N,16,6,33)  tra_cache (2,3,N,8,2)
+ *   tcn_cache  2 x 4 tensors (N,16,2d,33), d = 1,2,4,8, passed as 8 pointers
+ *   in the order [g0 d1, g0 d2, g0 d4, g0 d8, g1 d1, ...]. */
+size_t gtcrn_stream_state_bytes(void); /* per stream */
+int gtcrn_stream_reset(gtcrn_model *m, void *d_state, int nstreams, void *stream);
+/* nframes >= 1 consecutive frames per call: d_spec_t / d_spec_out_t are
+ * (N,257,nframes,2) addressed with the strides given. */
+int gtcrn_stream_step(gtcrn_model *m, void *d_state, const float *d_spec_t, long isb, long isf, long ist,
+                      float *d_spec_out_t, long osb, long osf, long ost, int nstreams, int nframes,
+                      void *stream);
+int gtcrn_stream_import(gtcrn_model *m, void *d_state, int nstreams, const float *d_conv_cache,
+                        const float *d_tra_cache, const float *const *d_tcn_cache8, void *stream);
+int gtcrn_stream_export(gtcrn_model *m, const void *d_state, int nstreams, float *d_conv_cache,
+                        float *d_tra_cache, float *const *d_tcn_cache8, void *stream);
+
+/* ---- host-side packer view (no device needed) ---------------------------
+ * The BatchNorm-folded "slot space" buffers the kernels consume, as produced
+ * from a parameter blob; lets a CPU test check the weight contract
+ * (convert_to_stream's permute/flip, streaming/conversion/convert.py:35-48,
+ * and the shuffle renaming) without a GPU. */
+void gtcrn_pack_sizes(long *n_floats, long *n_ints);
+int gtcrn_pack_params_host(const float *h_params, long n_floats, float *h_f, int *h_i);
+
+/* ---- test hooks ---------------------------------------------------------
+ * Stage boundaries of the most recent gtcrn_forward_spec call, converted to
+ * the reference's (C,T,F) layout and logical channel order, for batch item b.
+ * Names: en0..en4, gtcn1, gtcn2, de0..de4 (de* need gtcn_debug_enable(m,1)
+ * before the forward).  Returns element count, or a negative status. */
+int gtcrn_debug_enable(gtcrn_model *m, int on);
+long gtcrn_debug_tap(gtcrn_model *m, const char *name, int b, float *h_dst, long cap);
+/* Checks the MFMA f32 16x16x4 lane maps the kernels rely on (exact integer
+ * data, asymmetric operands).  0 = as assumed. */
+int gtcrn_selftest_mfma(int device);
+/* Average device time in ms of the kernels launched by the last forward/stream
+ * call when timing was enabled (HIP events on the call's stream); fills up to
+ * cap entries of (name, ms).  Used by bench.py for the roofline line. */
+int gtcrn_timing_enable(gtcrn_model *m, int on);
+int gtcrn_timing_read(gtcrn_model *m, int idx, char *name, int name_cap, float *ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

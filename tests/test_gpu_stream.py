@@ -1,0 +1,93 @@
+"""Streaming parity (config 3 path): frame-by-frame == offline, caches == the reference's."""
+import numpy as np
+import pytest
+
+from conftest import golden, load_params, rel_err
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+torch = pytest.importorskip("torch")
+
+
+@pytest.fixture(scope="module")
+def dev():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import __graft_entry__ as graft
+    graft.build()
+    return torch.device("cuda:0")
+
+
+def cu(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+@pytest.mark.parametrize("tag", ["dns3", "rand"])
+def test_native_stream_steps_match_reference(dev, tag):
+    from gtcrn_micro_amd import Engine
+    g = golden(f"stream_{tag}_T17.npz")
+    eng = Engine(load_params(tag), 0)
+    spec = cu(g["spec"])
+    st = eng.new_state(1)
+    outs = []
+    for i in range(17):
+        outs.append(eng.stream_step(st, spec[:, :, i:i + 1]))
+        if i in (0, 1, 16):
+            conv = torch.zeros(2, 1, 16, 6, 33, device="cuda")
+            tra = torch.zeros(2, 3, 1, 8, 2, device="cuda")
+            tcn = [[torch.zeros(1, 16, 2 * d, 33, device="cuda") for d in (1, 2, 4, 8)] for _ in range(2)]
+            eng.stream_export(st, conv, tra, tcn)
+            assert rel_err(conv.cpu().numpy(), g[f"conv_cache_f{i}"]) < TOL, i
+            assert rel_err(tra.cpu().numpy(), g[f"tra_cache_f{i}"]) < TOL, i
+            for gi in range(2):
+                for k in range(4):
+                    assert rel_err(tcn[gi][k].cpu().numpy(), g[f"tcn_cache_f{i}_g{gi}_b{k}"]) < TOL, (i, gi, k)
+    ys = torch.cat(outs, dim=2).cpu().numpy()
+    assert rel_err(ys, g["spec_enh_stream"]) < TOL
+    assert rel_err(ys, g["spec_enh_offline"]) < TOL
+
+
+def test_stream_module_mirror_reference_call(dev):
+    """StreamGTCRNMicro.forward(spec, conv_cache, tra_cache, tcn_cache) with caller-owned caches."""
+    import json, os
+    from conftest import GOLDEN
+    from gtcrn_micro_amd.models.gtcrn_micro import GTCRNMicro
+    from gtcrn_micro_amd.streaming.gtcrn_micro_stream import StreamGTCRNMicro
+    from gtcrn_micro_amd.streaming.conversion.convert import convert_to_stream
+    g = golden("stream_rand_T17.npz")
+    p = load_params("rand")
+    man = json.load(open(os.path.join(GOLDEN, "params_manifest.json")))
+    model = GTCRNMicro().eval()
+    model.load_state_dict({n: torch.from_numpy(p[o:o + int(np.prod(s))].reshape(s).copy())
+                           for n, s, o in man["tensors"]}, strict=False)
+    sm = StreamGTCRNMicro().eval()
+    convert_to_stream(sm, model)
+    sm = sm.to("cuda")
+    conv_cache, tra_cache, tcn_cache = sm.init_caches(1, "cuda")
+    spec = cu(g["spec"])
+    ys = []
+    with torch.no_grad():
+        for i in range(17):
+            y, conv_cache, tra_cache, tcn_cache = sm(spec[:, :, i:i + 1], conv_cache, tra_cache, tcn_cache)
+            ys.append(y)
+    assert rel_err(torch.cat(ys, 2).cpu().numpy(), g["spec_enh_stream"]) < TOL
+    assert rel_err(conv_cache.cpu().numpy(), g["conv_cache_f16"]) < TOL
+    with pytest.raises(AssertionError):
+        sm(spec[:, :, :1], conv_cache[:, :, :, :4], tra_cache, tcn_cache)
+
+
+def test_chunked_equals_offline_many_streams(dev):
+    from gtcrn_micro_amd import Engine
+    eng = Engine(load_params("rand"), 0)
+    rng = np.random.default_rng(3)
+    N, T = 64, 50
+    spec = cu((rng.standard_normal((N, 257, T, 2)) * 0.3).astype(np.float32))
+    full = eng.forward_spec(spec)
+    for chunks in ([1] * 50, [7, 16, 16, 11], [33, 17], [3, 1, 2, 44]):
+        st = eng.new_state(N)
+        t0, outs = 0, []
+        for c in chunks:
+            outs.append(eng.stream_step(st, spec[:, :, t0:t0 + c]))
+            t0 += c
+        got = torch.cat(outs, 2)
+        assert rel_err(got.cpu().numpy(), full.cpu().numpy()) < 2e-5, chunks

@@ -1,0 +1,107 @@
+"""CPU-side checks of the product's host logic: the C ABI loads and exports every declared
+symbol, the parameter table matches the reference state_dict, and the packed slot-space
+buffers reproduce the oracle when run through a numpy emulation of the kernels' dataflow."""
+import ctypes
+import json
+import os
+import re
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, ROOT, golden, load_params, rel_err
+
+import __graft_entry__ as graft
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _built():
+    graft.build()
+
+
+def test_abi_exports_every_declared_symbol():
+    hdr = open(os.path.join(ROOT, "include", "gtcrn_micro_hip.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    names = set(re.findall(r"\b(gtcrn_\w+)\s*\(", hdr))
+    assert len(names) >= 28
+    L = ctypes.CDLL(os.path.join(ROOT, "gtcrn_micro_amd", "libgtcrn_micro_hip.so"))
+    missing = [n for n in sorted(names) if not hasattr(L, n)]
+    assert not missing, missing
+
+
+def test_param_table_matches_reference_state_dict():
+    from gtcrn_micro_amd import _lib
+    man = json.load(open(os.path.join(GOLDEN, "params_manifest.json")))
+    table = _lib.param_table()
+    assert len(table) == len(man["tensors"]) == 342
+    for (name, numel, off), (rname, rshape, roff) in zip(table, man["tensors"]):
+        assert name == rname and numel == int(np.prod(rshape)) and off == roff
+    assert table[-1][1] + table[-1][2] == man["n_floats"] == _lib.NPARAM_FLOATS
+
+
+def test_module_mirror_state_dict_and_errors():
+    import torch
+    from gtcrn_micro_amd.models.gtcrn_micro import GTCRNMicro, erb_filter_bank, state_dict_to_blob
+    from gtcrn_micro_amd import GtcrnError
+    p = load_params("dns3")
+    assert np.array_equal(erb_filter_bank().ravel(), p[:64 * 192])      # fixed ERB bank, bit for bit
+    m = GTCRNMicro(n_fft=512, hop_len=256, win_len=512)
+    man = json.load(open(os.path.join(GOLDEN, "params_manifest.json")))
+    sd = m.state_dict()
+    assert len(sd) == 388
+    # load the shipped checkpoint blob by name and get the same blob back
+    new = {}
+    for name, shape, off in man["tensors"]:
+        new[name] = torch.from_numpy(p[off:off + int(np.prod(shape))].reshape(shape).copy())
+    for k, v in sd.items():
+        if k.endswith("num_batches_tracked"):
+            new[k] = v
+    m.load_state_dict({"module." + k: v for k, v in new.items()})        # DDP prefix tolerated
+    assert np.array_equal(state_dict_to_blob(m.state_dict()), p)
+    m.eval()
+    with pytest.raises(GtcrnError):
+        m(torch.zeros(1, 257, 4, 2))                                      # CPU tensor: no CPU path
+    m.train()
+    with pytest.raises(NotImplementedError):
+        m(torch.zeros(1, 257, 4, 2))
+
+
+def test_no_gpu_means_loud_failure():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from gtcrn_micro_amd import Engine, GtcrnError
+    with pytest.raises(GtcrnError):
+        Engine(load_params("dns3"), 0)
+
+
+def test_product_does_not_import_oracle():
+    """Only tests/, smoke() and bench.py's cpu_baseline may touch oracle/."""
+    pkg = os.path.join(ROOT, "gtcrn_micro_amd")
+    pat = re.compile(r"^\s*(from|import)\s+oracle|#include\s+\".*oracle|libgtcrn_oracle|oracle\.py", re.M)
+    for dp, _, fs in os.walk(pkg):
+        for f in fs:
+            if f.endswith((".py", ".cpp", ".hip", ".h")):
+                txt = open(os.path.join(dp, f)).read()
+                assert not pat.search(txt), os.path.join(dp, f)
+
+
+@pytest.mark.parametrize("tag", ["dns3", "rand"])
+def test_packed_slot_space_reproduces_reference(tag):
+    from gtcrn_micro_amd import _lib
+    import slot_emulator as E
+    g = golden(f"offline_{tag}_T17.npz")
+    F, I = _lib.pack_params_host(load_params(tag))
+    rec = E.forward(F, I, g["spec"][0])
+    for name in ("en0", "en1", "en2", "en3", "en4", "de0", "de1", "de2", "de3"):
+        assert rel_err(E.to_logical(name, rec[name], I), g[name][0]) < 2e-5, name
+    assert rel_err(E.to_logical("gtcn1", rec["gtcn1"], I), g["gtcn1_b3"][0]) < 2e-5
+    assert rel_err(E.to_logical("gtcn2", rec["gtcn2"], I), g["gtcn2_b3"][0]) < 2e-5
+    assert rel_err(rec["de4"], g["de4"][0]) < 2e-5
+    assert rel_err(rec["out"], g["spec_enh"][0]) < 2e-5
+
+
+def test_make_window_close_to_torch():
+    from gtcrn_micro_amd import make_window
+    g = golden("offline_dns3_T17.npz")
+    assert np.abs(make_window(0) - g["window"]).max() < 2e-6
