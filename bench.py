@@ -1,0 +1,204 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the GTCRN-Micro hot path on MI355X.
+
+Metric (BASELINE.json): 16 kHz frames/s through STFT -> mask -> iSTFT.
+Workload (BASELINE.json configs[1]): batch of 256 four-second 16 kHz clips per GPU, fp32,
+offline forward, wave -> wave (the caller loop of infer.py:60-76), synthetic N(0, 0.1^2) input
+already resident in HBM, shipped checkpoint weights (tests/golden/params_dns3.f32).
+One "step" = one pass of the six kernels over the batch = 256 x 251 = 64 256 frames per GPU.
+
+    python bench.py --gpus 1 --steps 50 --warmup 10
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+Multi-GPU: utterances are independent, so every rank runs its own 256-clip shard on its own
+GPU with no data-path collective (weak scaling); torch.distributed (RCCL) is used only for the
+barrier and the max-over-ranks of the elapsed time.
+
+The JSON line also carries
+  roofline     for the dominant kernel (k_decoder): algorithmic fp32 FLOPs per launch / average
+               launch duration from HIP events recorded inside the timed region, against the
+               dense fp32 MFMA peak (157.3 TFLOP/s, MI355X_MICROARCH.md); `traffic` = HBM bytes per
+               launch from the committed rocprofv3 PMC run when profiles/ has it, else null
+  cpu_baseline the PyTorch-CPU port of the path (oracle/torch_port.py, the reference's own ATen
+               op sequence) timed on this box's host cores on a bounded sample.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+# algorithmic multiply-accumulates per frame, per kernel (SURVEY.md 2a with the
+# ERB filterbank counted sparse as it is computed): 1 MAC = 2 FLOP
+MAC_PER_FRAME = {
+    "k_encoder": 1146 + 1161 + 15600 + 42240 + 3 * 13288,
+    "k_gtcn1": 73920,
+    "k_gtcn2": 73920,
+    "k_decoder": 3 * 84602 + 42240 + 10400 + 764 + 1028,
+}
+FFT_FLOP_PER_FRAME = 2 * 11520 + 6000          # 512-point rFFT + irFFT (5 N log2 N / 2) + window/OLA
+FP32_MFMA_PEAK_TFLOPS = 157.3                   # MI355X_MICROARCH.md, dense, v_mfma_f32_16x16x4_f32
+HBM_PEAK_GBS = 8000.0
+
+
+def cpu_baseline(params, seconds_budget=12.0):
+    """The reference's CPU arithmetic (ATen) on a bounded sample of the same workload."""
+    import numpy as np
+    import torch
+    from oracle.torch_port import TorchPort
+    port = TorchPort(params)
+    threads = torch.get_num_threads()
+    win = torch.hann_window(512).pow(0.5)
+    g = torch.Generator().manual_seed(43)
+    B = 16
+    x = torch.randn(B, 64000, generator=g) * 0.1
+    port.enhance(x, win)                                   # warm-up
+    n, t0 = 0, time.perf_counter()
+    while True:
+        port.enhance(x, win)
+        n += 1
+        el = time.perf_counter() - t0
+        if el >= seconds_budget or n >= 200:
+            break
+    fps = n * B * 251 / el
+    # the infer.py shape too: one utterance at a time
+    x1 = x[:1]
+    port.enhance(x1, win)
+    m, t1 = 0, time.perf_counter()
+    while time.perf_counter() - t1 < 3.0:
+        port.enhance(x1, win)
+        m += 1
+    fps_b1 = m * 251 / (time.perf_counter() - t1)
+    return {
+        "value": round(max(fps, fps_b1), 1), "unit": "frames/s", "cores": int(threads), "kind": "port",
+        "sample": f"{n} passes of 16 four-second clips (B=16, {el:.1f} s) through oracle/torch_port.py "
+                  f"(PyTorch {torch.__version__} CPU, same ATen ops as the reference); B=1 loop: {fps_b1:.0f} frames/s",
+        "host_cpus": os.cpu_count(),
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--batch", type=int, default=256, help="clips per GPU (BASELINE config 2: 256)")
+    ap.add_argument("--seconds", type=float, default=4.0, help="clip length")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    import __graft_entry__ as graft
+    if rank == 0:
+        graft.build()
+    if world > 1:
+        dist.barrier()
+    from gtcrn_micro_amd import Engine
+
+    params = np.fromfile(os.path.join(ROOT, "tests", "golden", "params_dns3.f32"), dtype=np.float32)
+    eng = Engine(params, local_rank)
+    B, L = args.batch, int(args.seconds * 16000)
+    T = 1 + L // 256
+    frames_per_step = B * T
+    torch.manual_seed(43 + rank)                               # the reference's seed (train.py:27)
+    wave = (torch.randn(B, L, device="cuda") * 0.1).contiguous()
+    win = torch.hann_window(512).pow(0.5).cuda()               # infer.py:65
+    out = torch.empty((B, 256 * (T - 1)), device="cuda")
+    eng.reserve(B, T)
+
+    def sync_all():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        eng.forward_wave(wave, win, out=out)
+    sync_all()
+    eng.timing_enable(True)                                    # HIP events on the launch stream
+    sync_all()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        eng.forward_wave(wave, win, out=out)
+    sync_all()
+    elapsed = time.perf_counter() - t0
+    kern = eng.timing_read()
+    eng.timing_enable(False)
+    if world > 1:
+        t = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    assert bool(torch.isfinite(out).all())
+
+    if rank == 0:
+        ms_per_step = elapsed / args.steps * 1e3
+        value = world * frames_per_step * args.steps / elapsed
+        dom = max((k for k in kern if k in MAC_PER_FRAME), key=lambda k: kern[k][0])
+        dom_ms = kern[dom][0]
+        flops_launch = 2.0 * MAC_PER_FRAME[dom] * frames_per_step
+        achieved = flops_launch / (dom_ms * 1e-3) / 1e12
+        traffic = None
+        tf = os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")
+        if os.path.exists(tf):
+            try:
+                traffic = json.load(open(tf)).get(dom, {}).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        path_flop = (2.0 * sum(MAC_PER_FRAME.values()) + FFT_FLOP_PER_FRAME) * frames_per_step
+        sum_ms = sum(v[0] for v in kern.values())
+        line = {
+            "metric": "16 kHz frames/sec (STFT->mask->iSTFT)",
+            "value": round(value, 1),
+            "unit": "frames/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 4),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": f"offline wave->wave, B={B} clips/GPU x {args.seconds:g} s @16 kHz "
+                                   f"(T={T} frames), fp32, shipped checkpoint weights",
+                       "batch_per_gpu": B, "frames_per_step_per_gpu": frames_per_step,
+                       "parallelism": f"{world} independent utterance shards, no data-path collective"},
+            "rtf_per_stream": round((elapsed / args.steps) / (B * args.seconds) * 1.0, 9),
+            "roofline": {
+                "bound": "mfma", "kernel": dom, "achieved": round(achieved, 3), "peak": FP32_MFMA_PEAK_TFLOPS,
+                "unit": "TFLOP/s", "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
+                "flop_per_launch": flops_launch, "avg_launch_ms": round(dom_ms, 4), "launches": kern[dom][1],
+                "path_tflops": round(path_flop / (sum_ms * 1e-3) / 1e12, 3),
+                "path_frac": round(path_flop / (sum_ms * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4),
+                "hbm_frac_at_boundary": round(value / world * 2048 / 1e9 / HBM_PEAK_GBS, 6),
+            },
+            "kernel_ms": {k: round(v[0], 4) for k, v in kern.items()},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(params)
+            line["gpu_over_cpu"] = round(value / line["cpu_baseline"]["value"], 1)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

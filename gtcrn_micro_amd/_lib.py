@@ -69,7 +69,7 @@ def lib():
     L.gtcrn_debug_tap.argtypes = [_vp, ctypes.c_char_p, ci, _c_f32p, cl]
     L.gtcrn_selftest_mfma.argtypes = [ci]
     L.gtcrn_timing_enable.argtypes = [_vp, ci]
-    L.gtcrn_timing_read.argtypes = [_vp, ci, ctypes.c_char_p, ci, _c_f32p]
+    L.gtcrn_timing_read.argtypes = [_vp, ci, ctypes.c_char_p, ci, _c_f32p, ctypes.POINTER(ci)]
     if L.gtcrn_abi_version() != 1:
         raise GtcrnError("libgtcrn_micro_hip.so ABI version mismatch")
     _lib = L
@@ -319,14 +319,14 @@ class Engine:
         _check(lib().gtcrn_timing_enable(self._h, int(bool(on))))
 
     def timing_read(self):
-        """[(kernel name, ms)] of the kernels launched by the most recent call."""
-        out = []
+        """{kernel name: (average ms, launches)} over the launches recorded since timing_enable(True)."""
+        out = {}
         buf = ctypes.create_string_buffer(64)
-        ms = ctypes.c_float()
-        i = 0
-        while lib().gtcrn_timing_read(self._h, i, buf, 64, ctypes.byref(ms)) == 0:
-            out.append((buf.value.decode(), float(ms.value)))
-            i += 1
+        ms, n = ctypes.c_float(), ctypes.c_int()
+        for i in range(6):
+            _check(lib().gtcrn_timing_read(self._h, i, buf, 64, ctypes.byref(ms), ctypes.byref(n)))
+            if n.value:
+                out[buf.value.decode()] = (float(ms.value), int(n.value))
         return out
 
 

@@ -37,10 +37,14 @@ int hip_fail(hipError_t e, const char* what) {
         if (e_ != 0) return hip_fail(static_cast<hipError_t>(e_), #expr);        \
     } while (0)
 
+// HIP-event timing of every kernel launch, kept per call so that a whole timed region can be
+// averaged afterwards without synchronising inside it.
 struct Timing {
-    std::string name;
+    int kernel = 0;  // index into kKernelNames
     hipEvent_t a = nullptr, b = nullptr;
 };
+const char* const kKernelNames[] = {"k_stft", "k_encoder", "k_gtcn1", "k_gtcn2", "k_decoder", "k_istft"};
+constexpr int kNumKernels = 6;
 
 }  // namespace
 
@@ -64,8 +68,8 @@ struct gtcrn_model {
     long dbg_cap_bt = 0;
     float** d_ptr8 = nullptr;  // device table of 8 tcn cache pointers
     bool timing = false;
-    std::vector<Timing> timings;
-    size_t n_timed = 0;
+    std::vector<Timing> timings;   // one entry per timed launch since gtcrn_timing_enable(m, 1)
+    std::vector<Timing> ev_pool;   // recycled events
 };
 
 namespace {
@@ -108,22 +112,24 @@ int ensure_workspace(gtcrn_model* m, int B, int T, hipStream_t s) {
 struct Timer {
     gtcrn_model* m;
     hipStream_t s;
-    Timer(gtcrn_model* m_, hipStream_t s_) : m(m_), s(s_) { m->n_timed = 0; }
-    void begin(const char* name) {
+    Timer(gtcrn_model* m_, hipStream_t s_) : m(m_), s(s_) {}
+    void begin(int kernel) {
         if (!m->timing) return;
-        if (m->n_timed == m->timings.size()) {
-            Timing t;
+        Timing t;
+        if (!m->ev_pool.empty()) {
+            t = m->ev_pool.back();
+            m->ev_pool.pop_back();
+        } else {
             (void)hipEventCreate(&t.a);
             (void)hipEventCreate(&t.b);
-            m->timings.push_back(t);
         }
-        m->timings[m->n_timed].name = name;
-        (void)hipEventRecord(m->timings[m->n_timed].a, s);
+        t.kernel = kernel;
+        (void)hipEventRecord(t.a, s);
+        m->timings.push_back(t);
     }
     void end() {
         if (!m->timing) return;
-        (void)hipEventRecord(m->timings[m->n_timed].b, s);
-        ++m->n_timed;
+        (void)hipEventRecord(m->timings.back().b, s);
     }
 };
 
@@ -131,17 +137,17 @@ struct Timer {
 int run_model(gtcrn_model* m, const float* spec_in, long isb, long isf, long ist, float* spec_out, long osb, long osf,
               long ost, int B, int T, float* state, hipStream_t s) {
     Timer tm(m, s);
-    tm.begin("k_encoder");
+    tm.begin(1);
     LAUNCH_TRY(gtk::launch_encoder(spec_in, isb, isf, ist, B, T, m->d_pf, m->d_pi, m->d_en0, m->d_en[0], m->d_en[1],
                                    m->d_en[2], m->d_en[3], state, s));
     tm.end();
-    tm.begin("k_gtcn1");
+    tm.begin(2);
     LAUNCH_TRY(gtk::launch_gtcn(m->d_en[3], m->d_g1, m->d_pf + gtl::P_GTCN, B, T, state, gtk::ST_G1_H, s));
     tm.end();
-    tm.begin("k_gtcn2");
+    tm.begin(3);
     LAUNCH_TRY(gtk::launch_gtcn(m->d_g1, m->d_g2, m->d_pf + gtl::P_GTCN + gtl::GTCN_SIZE, B, T, state, gtk::ST_G2_H, s));
     tm.end();
-    tm.begin("k_decoder");
+    tm.begin(4);
     LAUNCH_TRY(gtk::launch_decoder(m->d_g2, m->d_en0, m->d_en[0], m->d_en[1], m->d_en[2], m->d_en[3], spec_in, isb, isf,
                                    ist, spec_out, osb, osf, ost, B, T, m->d_pf, m->d_pi, state,
                                    m->debug ? m->d_dbg : nullptr, s));
@@ -265,10 +271,11 @@ void gtcrn_model_destroy(gtcrn_model* m) {
     if (m->d_pi) (void)hipFree(m->d_pi);
     if (m->d_twid) (void)hipFree(m->d_twid);
     if (m->d_ptr8) (void)hipFree(m->d_ptr8);
-    for (auto& t : m->timings) {
-        if (t.a) (void)hipEventDestroy(t.a);
-        if (t.b) (void)hipEventDestroy(t.b);
-    }
+    for (auto* v : {&m->timings, &m->ev_pool})
+        for (auto& t : *v) {
+            if (t.a) (void)hipEventDestroy(t.a);
+            if (t.b) (void)hipEventDestroy(t.b);
+        }
     delete m;
 }
 
@@ -371,34 +378,15 @@ int gtcrn_forward_wave(gtcrn_model* m, const float* d_wave, float* d_wave_out, i
     if (rc) return rc;
     // internal spectrograms are frame-major (B,T,257,2): sb = T*514, sf = 2, st = 514
     const long sb = (long)T * 514, sf = 2, st = 514;
-    const bool timing = m->timing;
-    hipEvent_t e0 = nullptr, e1 = nullptr, e2 = nullptr, e3 = nullptr;
-    if (timing) {
-        (void)hipEventCreate(&e0); (void)hipEventCreate(&e1); (void)hipEventCreate(&e2); (void)hipEventCreate(&e3);
-        (void)hipEventRecord(e0, s);
-    }
+    Timer tm(m, s);
+    tm.begin(0);
     LAUNCH_TRY(gtk::launch_stft(d_wave, B, L, T, d_win, m->d_twid, m->d_spec_a, sb, sf, st, nullptr, s));
-    if (timing) (void)hipEventRecord(e1, s);
+    tm.end();
     rc = run_model(m, m->d_spec_a, sb, sf, st, m->d_spec_b, sb, sf, st, B, T, nullptr, s);
     if (rc) return rc;
-    if (timing) (void)hipEventRecord(e2, s);
+    tm.begin(5);
     LAUNCH_TRY(gtk::launch_istft(m->d_spec_b, sb, sf, st, B, T, d_win, m->d_twid, d_wave_out, s));
-    if (timing) {
-        (void)hipEventRecord(e3, s);
-        // append the two FFT kernels to the timing list (events owned by the list from here on)
-        Timing a; a.name = "k_stft"; a.a = e0; a.b = e1;
-        Timing b; b.name = "k_istft"; b.a = e2; b.b = e3;
-        if (m->timings.size() > m->n_timed) {
-            for (size_t i = m->n_timed; i < m->timings.size(); ++i) {
-                (void)hipEventDestroy(m->timings[i].a);
-                (void)hipEventDestroy(m->timings[i].b);
-            }
-            m->timings.resize(m->n_timed);
-        }
-        m->timings.push_back(a);
-        m->timings.push_back(b);
-        m->n_timed += 2;
-    }
+    tm.end();
     return 0;
 }
 
@@ -536,19 +524,31 @@ int gtcrn_selftest_mfma(int device) {
 int gtcrn_timing_enable(gtcrn_model* m, int on) {
     int rc = check_model(m);
     if (rc) return rc;
+    HIP_TRY(hipDeviceSynchronize());
+    for (auto& t : m->timings) m->ev_pool.push_back(t);
+    m->timings.clear();
     m->timing = on != 0;
     return 0;
 }
 
-int gtcrn_timing_read(gtcrn_model* m, int idx, char* name, int name_cap, float* ms) {
+int gtcrn_timing_read(gtcrn_model* m, int idx, char* name, int name_cap, float* ms, int* launches) {
     int rc = check_model(m);
     if (rc) return rc;
-    if (idx < 0 || (size_t)idx >= m->n_timed || !ms) return fail(GTCRN_ERR_ARG, "timing index out of range");
-    Timing& t = m->timings[idx];
-    HIP_TRY(hipEventSynchronize(t.b));
-    HIP_TRY(hipEventElapsedTime(ms, t.a, t.b));
+    if (idx < 0 || idx >= kNumKernels || !ms) return fail(GTCRN_ERR_ARG, "timing index out of range");
+    double sum = 0.0;
+    int n = 0;
+    for (auto& t : m->timings)
+        if (t.kernel == idx) {
+            float v = 0.f;
+            HIP_TRY(hipEventSynchronize(t.b));
+            HIP_TRY(hipEventElapsedTime(&v, t.a, t.b));
+            sum += v;
+            ++n;
+        }
+    *ms = n ? (float)(sum / n) : 0.f;
+    if (launches) *launches = n;
     if (name && name_cap > 0) {
-        std::strncpy(name, t.name.c_str(), name_cap - 1);
+        std::strncpy(name, kKernelNames[idx], name_cap - 1);
         name[name_cap - 1] = 0;
     }
     return 0;

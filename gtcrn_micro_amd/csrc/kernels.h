@@ -4,14 +4,16 @@
 
 namespace gtk {
 
-// workgroup geometry: 8 waves per utterance/stream, time chunks of 16 frames.
-// 16 frames x 33 bins = 528 positions = exactly 33 MFMA tiles of 16 positions.
+// workgroup geometry: 11 waves per utterance/stream, time chunks of 16 frames.
+// 16 frames x 33 bins = 528 positions = exactly 33 MFMA tiles of 16 positions = 11 waves x 3 tiles,
+// so every wave owns the same number of tiles and no MFMA sits behind a branch.
 constexpr int TC = 16;
-constexpr int NW = 8;
+constexpr int NW = 11;
 constexpr int NTHR = NW * 64;
 constexpr int NT2 = TC * 33 / 16;
-constexpr int TPW = (NT2 + NW - 1) / NW;
+constexpr int TPW = NT2 / NW;
 static_assert(TC * 33 % 16 == 0, "chunk must be a whole number of tiles");
+static_assert(NT2 % NW == 0, "tiles must divide evenly over the waves");
 
 // STFT / iSTFT geometry
 constexpr int FRAMES_PER_WAVE = 4;   // frames each of the 4 waves of a k_stft workgroup transforms

@@ -49,16 +49,15 @@ __device__ __forceinline__ f32x4 prelu4(f32x4 v, float a) {
 // acc[i] += M * x[i] for the wave's tiles: 4 k-steps, tiles interleaved so the dependent
 // accumulator chains (40-cycle latency vs 32-cycle issue) overlap.
 template <int N>
-__device__ __forceinline__ void mm16(const f32x4 A, const f32x4 (&x)[N], f32x4 (&acc)[N], int ntl) {
+__device__ __forceinline__ void mm16(const f32x4 A, const f32x4 (&x)[N], f32x4 (&acc)[N]) {
 #pragma unroll
     for (int s = 0; s < 4; ++s)
 #pragma unroll
-        for (int i = 0; i < N; ++i)
-            if (i < ntl) acc[i] = mfma(A[s], x[i][s], acc[i]);
+        for (int i = 0; i < N; ++i) acc[i] = mfma(A[s], x[i][s], acc[i]);
 }
 
 struct Lane {
-    int tid, lane, wave, n, g, ntl;
+    int tid, lane, wave, n, g;
 };
 __device__ __forceinline__ Lane lane_info() {
     Lane L;
@@ -67,7 +66,6 @@ __device__ __forceinline__ Lane lane_info() {
     L.wave = __builtin_amdgcn_readfirstlane(L.tid >> 6);
     L.n = L.lane & 15;
     L.g = L.lane >> 4;
-    L.ntl = (NT2 - L.wave + NW - 1) / NW;  // tiles of this wave in a full chunk (wave-uniform)
     return L;
 }
 
@@ -273,7 +271,7 @@ struct BlockCtx {
 template <bool DENSE>
 __device__ __forceinline__ void gtconv_block(f32x4 (&x)[TPW], const int (&tl)[TPW], const int (&ff)[TPW],
                                              const BlockCtx& c, const Lane& L) {
-    const int n = L.n, g = L.g, ntl = L.ntl;
+    const int n = L.n, g = L.g;
     const float a1 = c.pb[GB_SLOPE], a2 = c.pb[GB_SLOPE + 1];
     f32x4 h[TPW];
     // ---- point_conv1 + BN + PReLU (tiles interleaved: x and h are live across the phase anyway) ----
@@ -281,10 +279,10 @@ __device__ __forceinline__ void gtconv_block(f32x4 (&x)[TPW], const int (&tl)[TP
         const f32x4 A = ld4(c.pb + GB_PC1_A + n * 16 + 4 * g), Bv = ld4(c.pb + GB_PC1_B + 4 * g);
 #pragma unroll
         for (int i = 0; i < TPW; ++i) h[i] = Bv;
-        mm16<TPW>(A, x, h, ntl);
+        mm16<TPW>(A, x, h);
 #pragma unroll
         for (int i = 0; i < TPW; ++i)
-            if (i < ntl) {
+            {
                 h[i] = prelu4(h[i], a1);
                 st4(c.sW + pl(tl[i] * 35 + 1 + ff[i], g), h[i]);
             }
@@ -304,7 +302,7 @@ __device__ __forceinline__ void gtconv_block(f32x4 (&x)[TPW], const int (&tl)[TP
         }
 #pragma unroll
         for (int i = 0; i < TPW; ++i) {
-            if (i < ntl) {
+            {
                 f32x4 acc = Bd;
 #pragma unroll
                 for (int kt = 0; kt < 3; ++kt)
@@ -345,7 +343,7 @@ __device__ __forceinline__ void gtconv_block(f32x4 (&x)[TPW], const int (&tl)[TP
     // ---- history ring of h (after every wave has read its taps) -----------------------------------
 #pragma unroll
     for (int i = 0; i < TPW; ++i)
-        if (i < ntl && tl[i] < c.nfr && tl[i] >= c.nfr - 2)
+        if (tl[i] < c.nfr && tl[i] >= c.nfr - 2)
             st4(c.sHk + pl(((c.tabs + tl[i]) & 1) * 35 + 1 + ff[i], g), h[i]);
     // ---- TRALite gate: 8 threads per frame (one per h' channel) -------------------------------------
     float e_keep = 0.f;
@@ -379,7 +377,7 @@ __device__ __forceinline__ void gtconv_block(f32x4 (&x)[TPW], const int (&tl)[TP
     if (reducer && rt >= c.nfr - 2) c.sEHk[((c.tabs + rt) & 1) * 8 + rc] = e_keep;
 #pragma unroll
     for (int i = 0; i < TPW; ++i)
-        if (i < ntl) x[i] = x[i] * ld4(c.sG + tl[i] * 16 + 4 * g);
+        x[i] = x[i] * ld4(c.sG + tl[i] * 16 + 4 * g);
 }
 
 // zero the two pad columns of the TC rows of a 35-position row image
@@ -531,26 +529,22 @@ __global__ __launch_bounds__(NTHR) void k_encoder(const float* __restrict__ spec
         {
             const f32x4 Bv = ld4(sP + E_EN1_B + 4 * g);
             const float a = sP[E_EN1_S];
-            f32x4 A[5];
-#pragma unroll
-            for (int k = 0; k < 5; ++k) A[k] = ld4(sP + E_EN1_A + k * 256 + n * 16 + 4 * g);
 #pragma unroll
             for (int i = 0; i < TPW; ++i) {
                 const int p = (L.wave + i * NW) * 16 + n;
                 tl[i] = p / 33;
                 ff[i] = p - tl[i] * 33;
-                if (i < L.ntl) {
+                {
                     f32x4 acc = Bv;
 #pragma unroll
                     for (int k = 0; k < 5; ++k) {
                         const f32x4 tap = ld4(sE0 + pl(tl[i] * ENC_E0_ROW + 2 * ff[i] + k, g));
+                        const f32x4 A = ld4(sP + E_EN1_A + k * 256 + n * 16 + 4 * g);
 #pragma unroll
-                        for (int q = 0; q < 4; ++q) acc = mfma(A[k][q], tap[q], acc);
+                        for (int q = 0; q < 4; ++q) acc = mfma(A[q], tap[q], acc);
                     }
                     x[i] = prelu4(acc, a);
                     if (p < nfr * 33) st4(en1 + ((ob + t0) * 33 + p) * 16 + 4 * g, x[i]);
-                } else {
-                    x[i] = splat(0.f);
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
@@ -570,7 +564,7 @@ __global__ __launch_bounds__(NTHR) void k_encoder(const float* __restrict__ spec
             float* dst = k == 0 ? en2 : (k == 1 ? en3 : en4);
 #pragma unroll
             for (int i = 0; i < TPW; ++i)
-                if (i < L.ntl) {
+                {
                     const int p = (L.wave + i * NW) * 16 + n;
                     if (p < nfr * 33) st4(dst + ((ob + t0) * 33 + p) * 16 + 4 * g, x[i]);
                 }
@@ -602,7 +596,7 @@ __global__ __launch_bounds__(NTHR) void k_gtcn(const float* __restrict__ xin, fl
     float* sW = smem + GT_LDS_W;
     float* sH = smem + GT_LDS_H;
     const Lane L = lane_info();
-    const int tid = L.tid, n = L.n, g = L.g, ntl = L.ntl;
+    const int tid = L.tid, n = L.n, g = L.g;
     const int b = blockIdx.x;
     for (int i = tid; i < GTCN_SIZE; i += NTHR) sP[i] = P[i];
     float* stb = state ? state + (long)b * ST_FLOATS : nullptr;
@@ -626,7 +620,7 @@ __global__ __launch_bounds__(NTHR) void k_gtcn(const float* __restrict__ xin, fl
             pp[i] = (L.wave + i * NW) * 16 + n;
             tl[i] = pp[i] / 33;
             ff[i] = pp[i] - tl[i] * 33;
-            x[i] = (i < ntl && pp[i] < npos) ? ld4(xin + ((long)t0 * 33 + pp[i]) * 16 + 4 * g) : splat(0.f);
+            x[i] = pp[i] < npos ? ld4(xin + ((long)t0 * 33 + pp[i]) * 16 + 4 * g) : splat(0.f);
         }
 #pragma unroll 1
         for (int k = 0; k < 4; ++k) {
@@ -638,10 +632,10 @@ __global__ __launch_bounds__(NTHR) void k_gtcn(const float* __restrict__ xin, fl
                 const f32x4 A = ld4(pk + TCN_A1 + n * 16 + 4 * g), Bv = ld4(pk + TCN_B1 + 4 * g);
 #pragma unroll
                 for (int i = 0; i < TPW; ++i) acc[i] = Bv;
-                mm16<TPW>(A, x, acc, ntl);
+                mm16<TPW>(A, x, acc);
 #pragma unroll
                 for (int i = 0; i < TPW; ++i)
-                    if (i < ntl) {
+                    {
                         y1[i] = prelu4(acc[i], a1);
                         st4(sW + pl(pp[i], g), y1[i]);
                     }
@@ -654,7 +648,7 @@ __global__ __launch_bounds__(NTHR) void k_gtcn(const float* __restrict__ xin, fl
                 f32x4 y2[TPW];
 #pragma unroll
                 for (int i = 0; i < TPW; ++i)
-                    if (i < ntl) {
+                    {
                         const int t = tbase + t0 + tl[i];
                         const float* s1 = tl[i] >= d ? sW + pl(pp[i] - 33 * d, g)
                                                      : sHk + pl(((t + d) & m2d) * 33 + ff[i], g);
@@ -664,20 +658,20 @@ __global__ __launch_bounds__(NTHR) void k_gtcn(const float* __restrict__ xin, fl
                         y2[i] = prelu4(B2 + w0 * tp2 + w1 * tp1 + w2 * y1[i], a2);
                         acc[i] = B3;
                     }
-                mm16<TPW>(A, y2, acc, ntl);
+                mm16<TPW>(A, y2, acc);
 #pragma unroll
                 for (int i = 0; i < TPW; ++i)
-                    if (i < ntl) x[i] = prelu4(acc[i] + x[i], a3);
+                    x[i] = prelu4(acc[i] + x[i], a3);
             }
             __syncthreads();
 #pragma unroll
             for (int i = 0; i < TPW; ++i)
-                if (i < ntl && pp[i] < npos && tl[i] >= nfr - 2 * d)
+                if (pp[i] < npos && tl[i] >= nfr - 2 * d)
                     st4(sHk + pl(((tbase + t0 + tl[i]) & m2d) * 33 + ff[i], g), y1[i]);
         }
 #pragma unroll
         for (int i = 0; i < TPW; ++i)
-            if (i < ntl && pp[i] < npos) st4(xout + ((long)t0 * 33 + pp[i]) * 16 + 4 * g, x[i]);
+            if (pp[i] < npos) st4(xout + ((long)t0 * 33 + pp[i]) * 16 + 4 * g, x[i]);
     }
     if (stb) {
         __syncthreads();
@@ -730,7 +724,7 @@ __global__ __launch_bounds__(NTHR) void k_decoder(const float* __restrict__ xg, 
     float* sZ = smem + DEC_LDS_A;
     float* sM = smem + DEC_LDS_M;
     const Lane L = lane_info();
-    const int tid = L.tid, n = L.n, g = L.g, ntl = L.ntl;
+    const int tid = L.tid, n = L.n, g = L.g;
     const int b = blockIdx.x;
     for (int i = tid; i < DEC_SIZE; i += NTHR) sP[i] = PF[P_DEC + i];
     for (int i = tid; i < P_INTS; i += NTHR) sI[i] = PI[i];
@@ -755,7 +749,7 @@ __global__ __launch_bounds__(NTHR) void k_decoder(const float* __restrict__ xg, 
             pp[i] = (L.wave + i * NW) * 16 + n;
             tl[i] = pp[i] / 33;
             ff[i] = pp[i] - tl[i] * 33;
-            ok[i] = i < ntl && pp[i] < npos;
+            ok[i] = pp[i] < npos;
             const long o = ((ob + t0) * 33 + pp[i]) * 16 + 4 * g;
             x[i] = ok[i] ? ld4(xg + o) + ld4(en4 + o) : splat(0.f);
         }
@@ -785,7 +779,7 @@ __global__ __launch_bounds__(NTHR) void k_decoder(const float* __restrict__ xg, 
         // past the last block's tap reads (they precede that block's 2nd barrier), so sW is free.
 #pragma unroll
         for (int i = 0; i < TPW; ++i)
-            if (i < ntl) st4(sW + pl(tl[i] * 35 + 1 + ff[i], g), x[i]);
+            st4(sW + pl(tl[i] * 35 + 1 + ff[i], g), x[i]);
         __syncthreads();
         f32x4 ze[TPW], zo[TPW];
         {
@@ -800,7 +794,7 @@ __global__ __launch_bounds__(NTHR) void k_decoder(const float* __restrict__ xg, 
                         Ao1 = ld4(sP + D_DE3_AO + 1 * 256 + n * 16 + 4 * g);
 #pragma unroll
             for (int i = 0; i < TPW; ++i) {
-                if (i < ntl) {
+                {
                     const f32x4 xp = ld4(sW + pl(tl[i] * 35 + 2 + ff[i], g));  // input bin f+1
                     const f32x4 xm = ld4(sW + pl(tl[i] * 35 + ff[i], g));      // input bin f-1
                     f32x4 ae = Bv, ao = Bv;
@@ -844,7 +838,7 @@ __global__ __launch_bounds__(NTHR) void k_decoder(const float* __restrict__ xg, 
         __syncthreads();  // all taps of sW read: region A becomes Z[tl][65][16]
 #pragma unroll
         for (int i = 0; i < TPW; ++i)
-            if (i < ntl) {
+            {
                 st4(sZ + pl(tl[i] * F1 + 2 * ff[i], g), ze[i]);
                 if (ff[i] < 32) st4(sZ + pl(tl[i] * F1 + 2 * ff[i] + 1, g), zo[i]);
             }

@@ -135,11 +135,13 @@ long gtcrn_debug_tap(gtcrn_model *m, const char *name, int b, float *h_dst, long
 /* Checks the MFMA f32 16x16x4 lane maps the kernels rely on (exact integer
  * data, asymmetric operands).  0 = as assumed. */
 int gtcrn_selftest_mfma(int device);
-/* Average device time in ms of the kernels launched by the last forward/stream
- * call when timing was enabled (HIP events on the call's stream); fills up to
- * cap entries of (name, ms).  Used by bench.py for the roofline line. */
+/* HIP-event timing of every kernel launch (events recorded on the call's stream, no
+ * synchronisation inside the timed region).  gtcrn_timing_enable(m,1) clears the record;
+ * gtcrn_timing_read returns, for kernel idx (0 k_stft, 1 k_encoder, 2 k_gtcn1, 3 k_gtcn2,
+ * 4 k_decoder, 5 k_istft), the average device time in ms over the launches recorded since and
+ * their count.  Used by bench.py for the roofline line. */
 int gtcrn_timing_enable(gtcrn_model *m, int on);
-int gtcrn_timing_read(gtcrn_model *m, int idx, char *name, int name_cap, float *ms);
+int gtcrn_timing_read(gtcrn_model *m, int idx, char *name, int name_cap, float *ms, int *launches);
 
 #ifdef __cplusplus
 }

@@ -159,3 +159,13 @@ def test_conv_wrappers():
     for i in range(2):
         y = O.convT2d_causal(x[i], None, w, b, pf=1)
         assert np.abs(y - g["ct33_y"][i][:, :9]).max() < 2e-6
+
+
+@pytest.mark.parametrize("tag", ["dns3", "rand"])
+def test_torch_port_matches_reference(tag):
+    """The PyTorch-CPU port used as bench.py's cpu_baseline is pinned to the same goldens."""
+    from oracle.torch_port import TorchPort
+    g = golden(f"offline_{tag}_T17.npz")
+    port = TorchPort(load_params(tag))
+    assert rel_err(port.forward(g["spec"]).numpy(), g["spec_enh"]) < 2e-6
+    assert rel_err(port.enhance(g["wave"][None], g["window"]).numpy()[0], g["wave_out"]) < 2e-6
