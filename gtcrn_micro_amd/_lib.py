@@ -28,11 +28,14 @@ def lib():
     global _lib
     if _lib is not None:
         return _lib
-    if not os.path.exists(LIB_PATH):
+    path = LIB_PATH
+    if os.environ.get("GTCRN_LIB_VARIANT") == "stamps":      # diagnostic build, tools/phase_profile.py only
+        path = LIB_PATH.replace(".so", "_stamps.so")
+    if not os.path.exists(path):
         raise GtcrnError(
-            f"{LIB_PATH} not found: run `python -c 'import __graft_entry__ as g; g.build()'` "
+            f"{path} not found: run `python -c 'import __graft_entry__ as g; g.build()'` "
             "(the HIP extension is mandatory, there is no CPU path)")
-    L = ctypes.CDLL(LIB_PATH)
+    L = ctypes.CDLL(path)
     ci, cl = ctypes.c_int, ctypes.c_long
     L.gtcrn_abi_version.restype = ci
     L.gtcrn_last_error.restype = ctypes.c_char_p
@@ -67,6 +70,8 @@ def lib():
     L.gtcrn_debug_enable.argtypes = [_vp, ci]
     L.gtcrn_debug_tap.restype = cl
     L.gtcrn_debug_tap.argtypes = [_vp, ctypes.c_char_p, ci, _c_f32p, cl]
+    L.gtcrn_debug_stamps.restype = cl
+    L.gtcrn_debug_stamps.argtypes = [_vp, ci, ctypes.POINTER(ctypes.c_ulonglong), cl]
     L.gtcrn_selftest_mfma.argtypes = [ci]
     L.gtcrn_timing_enable.argtypes = [_vp, ci]
     L.gtcrn_timing_read.argtypes = [_vp, ci, ctypes.c_char_p, ci, _c_f32p, ctypes.POINTER(ci)]
@@ -313,6 +318,13 @@ class Engine:
         n = lib().gtcrn_debug_tap(self._h, name.encode(), int(b), dst.ctypes.data_as(_c_f32p), dst.size)
         _check(n)
         assert n == dst.size, (n, dst.size)
+        return dst
+
+    def stamps(self, kernel, B):
+        """Diagnostic build: (B,16) phase cycle sums of kernel 0 encoder, 1 gtcn1, 2 gtcn2, 3 decoder."""
+        dst = np.zeros((B, 16), np.uint64)
+        _check(lib().gtcrn_debug_stamps(self._h, int(kernel), dst.ctypes.data_as(ctypes.POINTER(ctypes.c_ulonglong)),
+                                        dst.size))
         return dst
 
     def timing_enable(self, on=True):

@@ -21,24 +21,32 @@ def _stale(target, deps):
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build_native(force=False, verbose=False):
+def build_native(force=False, verbose=False, stamps=False):
+    """stamps=True builds the diagnostic variant libgtcrn_micro_hip_stamps.so (-DGT_STAMPS: in-kernel
+    s_memtime phase stamps, used only by tools/phase_profile.py; never loaded by the product path)."""
     deps = [os.path.join(CSRC, f) for f in SOURCES + HEADERS]
     objs = []
     common = ["-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-result"]
+    suffix = ""
+    lib = LIB
+    if stamps:
+        common.append("-DGT_STAMPS")
+        suffix = ".stamps"
+        lib = LIB.replace(".so", "_stamps.so")
     for src in SOURCES:
-        obj = os.path.join(CSRC, os.path.splitext(src)[0] + ".o")
+        obj = os.path.join(CSRC, os.path.splitext(src)[0] + suffix + ".o")
         objs.append(obj)
         if force or _stale(obj, deps):
             cmd = [HIPCC, "--offload-arch=gfx950"] + common + ["-c", os.path.join(CSRC, src), "-o", obj]
             if verbose:
                 print(" ".join(cmd))
             subprocess.check_call(cmd)
-    if force or _stale(LIB, objs):
-        cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+    if force or _stale(lib, objs):
+        cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib] + objs
         if verbose:
             print(" ".join(cmd))
         subprocess.check_call(cmd)
-    return LIB
+    return lib
 
 
 if __name__ == "__main__":

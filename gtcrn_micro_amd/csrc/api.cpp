@@ -66,6 +66,8 @@ struct gtcrn_model {
     bool debug = false;
     float* d_dbg = nullptr;
     long dbg_cap_bt = 0;
+    unsigned long long* d_stamps = nullptr;  // [4 kernels][B][16] phase cycle sums (diagnostic build only)
+    int stamps_cap_b = 0;
     float** d_ptr8 = nullptr;  // device table of 8 tcn cache pointers
     bool timing = false;
     std::vector<Timing> timings;   // one entry per timed launch since gtcrn_timing_enable(m, 1)
@@ -106,6 +108,13 @@ int ensure_workspace(gtcrn_model* m, int B, int T, hipStream_t s) {
         HIP_TRY(hipMalloc(&m->d_dbg, sizeof(float) * bt * (3 * 528 + 65 * 16 + 2 * 129)));
         m->dbg_cap_bt = bt;
     }
+    if (m->debug && B > m->stamps_cap_b) {
+        if (m->d_stamps) (void)hipFree(m->d_stamps);
+        m->d_stamps = nullptr;
+        HIP_TRY(hipMalloc(&m->d_stamps, sizeof(unsigned long long) * 4 * B * 16));
+        HIP_TRY(hipMemset(m->d_stamps, 0, sizeof(unsigned long long) * 4 * B * 16));
+        m->stamps_cap_b = B;
+    }
     return 0;
 }
 
@@ -137,20 +146,24 @@ struct Timer {
 int run_model(gtcrn_model* m, const float* spec_in, long isb, long isf, long ist, float* spec_out, long osb, long osf,
               long ost, int B, int T, float* state, hipStream_t s) {
     Timer tm(m, s);
+    unsigned long long* stp = (m->debug && m->d_stamps) ? m->d_stamps : nullptr;
+    const long sst = (long)m->stamps_cap_b * 16;
     tm.begin(1);
     LAUNCH_TRY(gtk::launch_encoder(spec_in, isb, isf, ist, B, T, m->d_pf, m->d_pi, m->d_en0, m->d_en[0], m->d_en[1],
-                                   m->d_en[2], m->d_en[3], state, s));
+                                   m->d_en[2], m->d_en[3], state, stp ? stp : nullptr, s));
     tm.end();
     tm.begin(2);
-    LAUNCH_TRY(gtk::launch_gtcn(m->d_en[3], m->d_g1, m->d_pf + gtl::P_GTCN, B, T, state, gtk::ST_G1_H, s));
+    LAUNCH_TRY(gtk::launch_gtcn(m->d_en[3], m->d_g1, m->d_pf + gtl::P_GTCN, B, T, state, gtk::ST_G1_H,
+                                stp ? stp + sst : nullptr, s));
     tm.end();
     tm.begin(3);
-    LAUNCH_TRY(gtk::launch_gtcn(m->d_g1, m->d_g2, m->d_pf + gtl::P_GTCN + gtl::GTCN_SIZE, B, T, state, gtk::ST_G2_H, s));
+    LAUNCH_TRY(gtk::launch_gtcn(m->d_g1, m->d_g2, m->d_pf + gtl::P_GTCN + gtl::GTCN_SIZE, B, T, state, gtk::ST_G2_H,
+                                stp ? stp + 2 * sst : nullptr, s));
     tm.end();
     tm.begin(4);
     LAUNCH_TRY(gtk::launch_decoder(m->d_g2, m->d_en0, m->d_en[0], m->d_en[1], m->d_en[2], m->d_en[3], spec_in, isb, isf,
                                    ist, spec_out, osb, osf, ost, B, T, m->d_pf, m->d_pi, state,
-                                   m->debug ? m->d_dbg : nullptr, s));
+                                   m->debug ? m->d_dbg : nullptr, stp ? stp + 3 * sst : nullptr, s));
     tm.end();
     m->last_B = B;
     m->last_T = T;
@@ -267,6 +280,7 @@ void gtcrn_model_destroy(gtcrn_model* m) {
     (void)hipDeviceSynchronize();
     free_workspace(m);
     if (m->d_dbg) (void)hipFree(m->d_dbg);
+    if (m->d_stamps) (void)hipFree(m->d_stamps);
     if (m->d_pf) (void)hipFree(m->d_pf);
     if (m->d_pi) (void)hipFree(m->d_pi);
     if (m->d_twid) (void)hipFree(m->d_twid);
@@ -486,6 +500,19 @@ long gtcrn_debug_tap(gtcrn_model* m, const char* name, int b, float* h_dst, long
         for (int f = 0; f < F; ++f)
             for (int s = 0; s < 16; ++s) h_dst[((long)pm[s] * T + t) * F + f] = tmp[((long)t * F + f) * 16 + s];
     return nel;
+}
+
+long gtcrn_debug_stamps(gtcrn_model* m, int kernel, unsigned long long* h_dst, long cap) {
+    int rc = check_model(m);
+    if (rc) return rc;
+    if (kernel < 0 || kernel > 3 || !h_dst) return fail(GTCRN_ERR_ARG, "kernel index 0..3 (encoder, gtcn1, gtcn2, decoder)");
+    if (!m->d_stamps) return fail(GTCRN_ERR_STATE, "enable debug before the forward");
+    const long n = (long)m->last_B * 16;
+    if (cap < n) return fail(GTCRN_ERR_ARG, "destination too small");
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(h_dst, m->d_stamps + (long)kernel * m->stamps_cap_b * 16, sizeof(unsigned long long) * n,
+                      hipMemcpyDeviceToHost));
+    return n;
 }
 
 int gtcrn_selftest_mfma(int device) {

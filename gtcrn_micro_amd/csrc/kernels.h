@@ -36,12 +36,14 @@ int launch_stft(const float* wave, int B, long L, int T, const float* win, const
 int launch_istft(const float* spec, long sb, long sf, long st, int B, int T, const float* win, const float* twid,
                  float* wave, hipStream_t s);
 int launch_encoder(const float* spec, long sb, long sf, long st, int B, int T, const float* PF, const int* PI,
-                   float* en0, float* en1, float* en2, float* en3, float* en4, float* state, hipStream_t s);
+                   float* en0, float* en1, float* en2, float* en3, float* en4, float* state,
+                   unsigned long long* stamps, hipStream_t s);
 int launch_gtcn(const float* xin, float* xout, const float* P, int B, int T, float* state, int st_off,
-                hipStream_t s);
+                unsigned long long* stamps, hipStream_t s);
 int launch_decoder(const float* xg, const float* en0, const float* en1, const float* en2, const float* en3,
                    const float* en4, const float* spec, long sb, long sf, long st, float* out, long osb, long osf,
-                   long ost, int B, int T, const float* PF, const int* PI, float* state, float* dbg, hipStream_t s);
+                   long ost, int B, int T, const float* PF, const int* PI, float* state, float* dbg,
+                   unsigned long long* stamps, hipStream_t s);
 int launch_state_convert(float* state, int N, float* conv, float* tra, float* const* tcn8, const int* PI, int dir,
                          hipStream_t s);
 int launch_selftest(const float* A, const float* Bm, const float* C, float* D, hipStream_t s);

@@ -28,22 +28,42 @@ __device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<
 __device__ __forceinline__ void st4(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
 __device__ __forceinline__ f32x4 splat(float v) { f32x4 r = {v, v, v, v}; return r; }
 
-// position-major LDS image: 16 floats per position, the 16-byte slot group g is XOR-swizzled by
-// the position so that the wave's ds_read_b128/ds_write_b128 of one tile are bank-conflict free
-// (lane groups of ds_read_b128: MI355X_MICROARCH.md LDS table).
-__device__ __forceinline__ int pl(int pos, int g) { return pos * 16 + (((g ^ (-(pos >> 2))) & 3) << 2); }
-__device__ __forceinline__ int pls(int pos, int slot) { return pl(pos, slot >> 2) + (slot & 3); }
+// position-major LDS image: 16 floats (one 64-byte record) per position, slot group g at +16g bytes.
+// Unswizzled on purpose: tap addresses are then "own address + compile-time constant", which keeps
+// address arithmetic off the VALU (the kernels are VALU-issue bound around the MFMAs, not LDS bound);
+// the price is a 2-way bank conflict on the tile-wide ds_read_b128 (8 instead of 4 LDS cycles).
+__device__ __forceinline__ int pl(int pos, int g) { return pos * 16 + 4 * g; }
+__device__ __forceinline__ int pls(int pos, int slot) { return pos * 16 + slot; }
 
 __device__ __forceinline__ f32x4 mfma(float a, float b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
 }
-__device__ __forceinline__ f32x4 prelu4(f32x4 v, float a) {
+// PReLU with one shared slope a (nn.PReLU(), num_parameters = 1): x + (a-1) * min(x, 0); am1 = a - 1.
+__device__ __forceinline__ f32x4 prelu4(f32x4 v, float am1) {
     f32x4 r;
-    r[0] = v[0] >= 0.f ? v[0] : a * v[0];
-    r[1] = v[1] >= 0.f ? v[1] : a * v[1];
-    r[2] = v[2] >= 0.f ? v[2] : a * v[2];
-    r[3] = v[3] >= 0.f ? v[3] : a * v[3];
+    r[0] = fmaf(am1, fminf(v[0], 0.f), v[0]);
+    r[1] = fmaf(am1, fminf(v[1], 0.f), v[1]);
+    r[2] = fmaf(am1, fminf(v[2], 0.f), v[2]);
+    r[3] = fmaf(am1, fminf(v[3], 0.f), v[3]);
     return r;
+}
+// sum over the 16 lanes of a DPP row (= the 16 positions of a tile, same slot group), result in
+// every lane; fixed order, so results are reproducible run to run.
+template <int CTRL>
+__device__ __forceinline__ float dpp_ror(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float row_sum16(float v) {
+    v += dpp_ror<0x128>(v);  // row_ror:8
+    v += dpp_ror<0x124>(v);  // row_ror:4
+    v += dpp_ror<0x122>(v);  // row_ror:2
+    v += dpp_ror<0x121>(v);  // row_ror:1
+    return v;
+}
+__device__ __forceinline__ float fast_tanh(float x) {
+    // tanh(x) = 1 - 2 / (exp(2x) + 1); v_exp_f32 / v_rcp_f32 are ~1 ulp, far inside the 1e-4 budget
+    const float t = __expf(2.0f * x);
+    return 1.0f - 2.0f * __frcp_rn(t + 1.0f);
 }
 
 // acc[i] += M * x[i] for the wave's tiles: 4 k-steps, tiles interleaved so the dependent
@@ -55,6 +75,37 @@ __device__ __forceinline__ void mm16(const f32x4 A, const f32x4 (&x)[N], f32x4 (
 #pragma unroll
         for (int i = 0; i < N; ++i) acc[i] = mfma(A[s], x[i][s], acc[i]);
 }
+
+// Diagnostic build only (-DGT_STAMPS, libgtcrn_micro_hip_stamps.so): s_memtime stamps at the
+// barrier-delimited phases, summed per workgroup and written to a buffer nothing else reads.
+// In the product build these macros expand to nothing.
+#ifdef GT_STAMPS
+struct Stamps {
+    unsigned long long t, acc[16];
+};
+#define STAMP_INIT(S)                                   \
+    Stamps S;                                           \
+    _Pragma("unroll") for (int k_ = 0; k_ < 16; ++k_) S.acc[k_] = 0; \
+    S.t = __builtin_amdgcn_s_memtime();
+#define STAMP(S, k)                                                  \
+    {                                                                \
+        const unsigned long long now_ = __builtin_amdgcn_s_memtime(); \
+        S.acc[k] += now_ - S.t;                                      \
+        S.t = now_;                                                  \
+    }
+#define STAMP_OUT(S, ptr)                                                                       \
+    if (ptr && threadIdx.x == 0) {                                                              \
+        _Pragma("unroll") for (int k_ = 0; k_ < 16; ++k_) ptr[(long)blockIdx.x * 16 + k_] = S.acc[k_]; \
+    }
+#define STAMP_PARAM , Stamps& SS
+#define STAMP_ARG , SS
+#else
+#define STAMP_INIT(S)
+#define STAMP(S, k)
+#define STAMP_OUT(S, ptr)
+#define STAMP_PARAM
+#define STAMP_ARG
+#endif
 
 struct Lane {
     int tid, lane, wave, n, g;
@@ -255,13 +306,40 @@ __global__ __launch_bounds__(FFT_WAVES * 64) void k_istft(const float* __restric
 //   TRALite (:122-139): e = mean_F(v^2) per h' channel, causal k=3 conv over [cache | e], 1x1, sigmoid
 //   out = v * gate  (gate = 1 on pass-through slots) -- this IS the channel shuffle (:222-227),
 //   because the packer renamed the slots instead of moving data.
+
+// per-lane geometry of the wave's TPW tiles; constant for the whole kernel (chunks start at multiples
+// of 16 frames, so ring rows -- frame mod 2 / mod 2d -- do not depend on the chunk either)
+struct Tiles {
+    int pp[TPW];    // position inside the chunk: tile * 16 + n
+    int tl[TPW];    // frame inside the chunk
+    int ff[TPW];    // frequency bin
+    int o35[TPW];   // float offset of the record in a 35-column row image (zero pad columns 0 and 34)
+    int rb1[TPW];   // float offset inside a 2-row h ring of (frame-1, bin), for frames before the chunk
+    int rb2[TPW];   // same for frame-2
+};
+__device__ __forceinline__ Tiles make_tiles(const Lane& L, int tbase) {
+    Tiles t;
+#pragma unroll
+    for (int i = 0; i < TPW; ++i) {
+        t.pp[i] = (L.wave + i * NW) * 16 + L.n;
+        t.tl[i] = t.pp[i] / 33;
+        t.ff[i] = t.pp[i] - t.tl[i] * 33;
+        t.o35[i] = (t.tl[i] * 35 + 1 + t.ff[i]) * 16 + 4 * L.g;
+        t.rb1[i] = (((tbase + t.tl[i] + 1) & 1) * 35 + 1 + t.ff[i]) * 16 + 4 * L.g;
+        t.rb2[i] = (((tbase + t.tl[i]) & 1) * 35 + 1 + t.ff[i]) * 16 + 4 * L.g;
+    }
+    return t;
+}
+
+constexpr int PART_FLOATS = NT2 * 2 * 16;   // per tile: two frame segments x 16 slots of sum(v^2)
+
 struct BlockCtx {
     const float* pb;     // LDS: block parameters (GB_* offsets)
     const float* gA;     // LDS: dense 3x3 slot matrices (decoder) or nullptr
     const int* ib;       // LDS: slot_of_c[8], x2slots[8]
     float* sW;           // LDS: h of this chunk, rows of 35 positions (zero pad columns 0 and 34)
     float* sHk;          // LDS: 2-row history ring of h (row = frame & 1), rows of 35 positions
-    float* sS;           // LDS: v^2, 33 positions per frame
+    float* sPart;        // LDS: per-tile partial sums of v^2
     float* sG;           // LDS: gates [frame][16 slots]
     float* sEHk;         // LDS: 2-entry ring of e: [frame & 1][8]
     int nfr;             // frames in this chunk
@@ -269,10 +347,10 @@ struct BlockCtx {
 };
 
 template <bool DENSE>
-__device__ __forceinline__ void gtconv_block(f32x4 (&x)[TPW], const int (&tl)[TPW], const int (&ff)[TPW],
-                                             const BlockCtx& c, const Lane& L) {
+__device__ __forceinline__ void gtconv_block(f32x4 (&x)[TPW], const Tiles& tt, const BlockCtx& c,
+                                             const Lane& L STAMP_PARAM) {
     const int n = L.n, g = L.g;
-    const float a1 = c.pb[GB_SLOPE], a2 = c.pb[GB_SLOPE + 1];
+    const float a1 = c.pb[GB_SLOPE] - 1.0f, a2 = c.pb[GB_SLOPE + 1] - 1.0f;
     f32x4 h[TPW];
     // ---- point_conv1 + BN + PReLU (tiles interleaved: x and h are live across the phase anyway) ----
     {
@@ -281,20 +359,21 @@ __device__ __forceinline__ void gtconv_block(f32x4 (&x)[TPW], const int (&tl)[TP
         for (int i = 0; i < TPW; ++i) h[i] = Bv;
         mm16<TPW>(A, x, h);
 #pragma unroll
-        for (int i = 0; i < TPW; ++i)
-            {
-                h[i] = prelu4(h[i], a1);
-                st4(c.sW + pl(tl[i] * 35 + 1 + ff[i], g), h[i]);
-            }
+        for (int i = 0; i < TPW; ++i) {
+            h[i] = prelu4(h[i], a1);
+            st4(c.sW + tt.o35[i], h[i]);
+        }
     }
     __syncthreads();
+    STAMP(SS, 5)
     // ---- depth conv + BN + PReLU, then point_conv2 + BN in place over the x1 slots; one tile at a
-    //      time so that the tap registers die with the tile (the partner wave on the SIMD fills the
-    //      MFMA dependency gaps) --------------------------------------------------------------------
+    //      time so that the tap registers die with the tile (the partner waves on the SIMD fill the
+    //      MFMA dependency gaps); v^2 is reduced over the tile's 16 positions in registers -----------
     {
         const f32x4 Bd = ld4(c.pb + GB_DW_B + 4 * g);
         const f32x4 A2 = ld4(c.pb + GB_PC2_A + n * 16 + 4 * g), B2 = ld4(c.pb + GB_PC2_B + 4 * g);
         const f32x4 keep = ld4(c.pb + GB_KEEP + 4 * g);
+        const long ringoff = c.sHk - c.sW;   // both live in the same LDS array
         f32x4 wdw[DENSE ? 1 : 9];
         if (!DENSE) {
 #pragma unroll
@@ -302,50 +381,58 @@ __device__ __forceinline__ void gtconv_block(f32x4 (&x)[TPW], const int (&tl)[TP
         }
 #pragma unroll
         for (int i = 0; i < TPW; ++i) {
-            {
-                f32x4 acc = Bd;
+            // row bases for frames t, t-1, t-2: inside the chunk image, or the ring for earlier frames
+            const int b0 = tt.o35[i];
+            const int b1 = tt.tl[i] >= 1 ? b0 - 35 * 16 : (int)ringoff + tt.rb1[i];
+            const int b2 = tt.tl[i] >= 2 ? b0 - 70 * 16 : (int)ringoff + tt.rb2[i];
+            f32x4 acc = Bd;
 #pragma unroll
-                for (int kt = 0; kt < 3; ++kt)
+            for (int kt = 0; kt < 3; ++kt)
 #pragma unroll
-                    for (int kf = 0; kf < 3; ++kf) {
-                        // encoder: tap (t-2+kt, f-1+kf); decoder (transposed): tap (t-kt, f+1-kf)
-                        const int dt = DENSE ? -kt : kt - 2;
-                        const int df = DENSE ? 1 - kf : kf - 1;
-                        f32x4 tap;
-                        if (dt == 0 && df == 0) {
-                            tap = h[i];
-                        } else {
-                            const int tau = tl[i] + dt;
-                            const int col = 1 + ff[i] + df;
-                            const float* src = tau >= 0 ? c.sW + pl(tau * 35 + col, g)
-                                                        : c.sHk + pl(((c.tabs + tau) & 1) * 35 + col, g);
-                            tap = ld4(src);
-                        }
-                        if (DENSE) {
-                            const f32x4 A = ld4(c.gA + (kt * 3 + kf) * 256 + n * 16 + 4 * g);
+                for (int kf = 0; kf < 3; ++kf) {
+                    // encoder: tap (t-2+kt, f-1+kf); decoder (transposed): tap (t-kt, f+1-kf)
+                    const int back = DENSE ? kt : 2 - kt;          // frames back: 0, 1, 2
+                    const int df = DENSE ? 1 - kf : kf - 1;
+                    f32x4 tap;
+                    if (back == 0 && df == 0) tap = h[i];
+                    else tap = ld4(c.sW + (back == 0 ? b0 : (back == 1 ? b1 : b2)) + df * 16);
+                    if (DENSE) {
+                        const f32x4 A = ld4(c.gA + (kt * 3 + kf) * 256 + n * 16 + 4 * g);
 #pragma unroll
-                            for (int s = 0; s < 4; ++s) acc = mfma(A[s], tap[s], acc);
-                        } else {
-                            acc += wdw[kt * 3 + kf] * tap;
-                        }
+                        for (int s = 0; s < 4; ++s) acc = mfma(A[s], tap[s], acc);
+                    } else {
+                        acc += wdw[kt * 3 + kf] * tap;
                     }
-                const f32x4 hd = prelu4(acc, a2);
-                f32x4 v = keep * x[i] + B2;
+                }
+            const f32x4 hd = prelu4(acc, a2);
+            f32x4 v = keep * x[i] + B2;
 #pragma unroll
-                for (int s = 0; s < 4; ++s) v = mfma(A2[s], hd[s], v);
-                st4(c.sS + pl(tl[i] * 33 + ff[i], g), v * v);
-                x[i] = v;
+            for (int s = 0; s < 4; ++s) v = mfma(A2[s], hd[s], v);
+            x[i] = v;
+            // a tile spans at most two frames: sum v^2 over the tile's positions per frame segment
+            const int tile = L.wave + i * NW;
+            const bool seg1 = tt.tl[i] != (tile * 16) / 33;
+            f32x4 sa, sb;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float q = v[r] * v[r];
+                sa[r] = row_sum16(seg1 ? 0.f : q);
+                sb[r] = row_sum16(seg1 ? q : 0.f);
+            }
+            if (n == 0) {
+                st4(c.sPart + (tile * 2) * 16 + 4 * g, sa);
+                st4(c.sPart + (tile * 2 + 1) * 16 + 4 * g, sb);
             }
             __builtin_amdgcn_sched_barrier(0);
         }
     }
     __syncthreads();
+    STAMP(SS, 6)
     // ---- history ring of h (after every wave has read its taps) -----------------------------------
 #pragma unroll
     for (int i = 0; i < TPW; ++i)
-        if (tl[i] < c.nfr && tl[i] >= c.nfr - 2)
-            st4(c.sHk + pl(((c.tabs + tl[i]) & 1) * 35 + 1 + ff[i], g), h[i]);
-    // ---- TRALite gate: 8 threads per frame (one per h' channel) -------------------------------------
+        if (tt.tl[i] < c.nfr && tt.tl[i] >= c.nfr - 2) st4(c.sHk + tt.rb2[i], h[i]);
+    // ---- TRALite gate: 8 threads per frame (one per h' channel) combine the per-tile partial sums ----
     float e_keep = 0.f;
     const int rt = L.tid >> 3, rc = L.tid & 7;
     const bool reducer = L.tid < c.nfr * 8;
@@ -356,8 +443,9 @@ __device__ __forceinline__ void gtconv_block(f32x4 (&x)[TPW], const int (&tl)[TP
         for (int j = 0; j < 3; ++j) {  // e[j] = energy of frame rt - 2 + j
             const int tau = rt - 2 + j;
             if (tau >= 0) {
+                const int qa = (33 * tau) >> 4, qb = (33 * tau + 32) >> 4;
                 float s = 0.f;
-                for (int f = 0; f < 33; ++f) s += c.sS[pls(tau * 33 + f, slot)];
+                for (int q = qa; q <= qb; ++q) s += c.sPart[(q * 2 + (tau - (q * 16) / 33)) * 16 + slot];
                 e[j] = s / 33.0f;
             } else {
                 e[j] = c.sEHk[((c.tabs + tau) & 1) * 8 + rc];
@@ -374,10 +462,10 @@ __device__ __forceinline__ void gtconv_block(f32x4 (&x)[TPW], const int (&tl)[TP
         c.sG[rt * 16 + c.ib[8 + rc]] = 1.0f;
     }
     __syncthreads();
+    STAMP(SS, 7)
     if (reducer && rt >= c.nfr - 2) c.sEHk[((c.tabs + rt) & 1) * 8 + rc] = e_keep;
 #pragma unroll
-    for (int i = 0; i < TPW; ++i)
-        x[i] = x[i] * ld4(c.sG + tl[i] * 16 + 4 * g);
+    for (int i = 0; i < TPW; ++i) x[i] = x[i] * ld4(c.sG + tt.tl[i] * 16 + 4 * g);
 }
 
 // zero the two pad columns of the TC rows of a 35-position row image
@@ -395,7 +483,7 @@ __device__ __forceinline__ void rings_load(float* sH, float* sEH, const float* s
         const int col = pos % 35, br = pos / 35;      // br = block*2 + row
         f32x4 v = splat(0.f);
         if (st_h && col >= 1 && col <= 33) v = ld4(st_h + ((br * 33) + col - 1) * 16 + gg * 4);
-        st4(sH + (br / 2) * (2 * 35 * 16) + pl((br & 1) * 35 + col, gg), v);
+        st4(sH + pl(pos, gg), v);
     }
     if (tid < 48) sEH[tid] = st_e ? st_e[tid] : 0.f;
 }
@@ -403,43 +491,54 @@ __device__ __forceinline__ void rings_store(const float* sH, const float* sEH, f
     for (int i = tid; i < 3 * 2 * 33 * 4; i += NTHR) {
         const int gg = i & 3, pos = i >> 2;
         const int f = pos % 33, br = pos / 33;
-        st4(st_h + pos * 16 + gg * 4, ld4(sH + (br / 2) * (2 * 35 * 16) + pl((br & 1) * 35 + 1 + f, gg)));
+        st4(st_h + pos * 16 + gg * 4, ld4(sH + pl(br * 35 + 1 + f, gg)));
     }
     if (tid < 48) st_e[tid] = sEH[tid];
+}
+
+// scatter the 4 slots of a lane into a 16-float record (slot order of the consumer)
+__device__ __forceinline__ void st_perm(float* rec, const int* idx4, f32x4 v) {
+    rec[idx4[0]] = v[0]; rec[idx4[1]] = v[1]; rec[idx4[2]] = v[2]; rec[idx4[3]] = v[3];
 }
 
 // =============================================================================== encoder
 // spec -> [mag,re,im] (models/gtcrn_micro.py:510-515) -> ERB.bm (:63-67) -> SFE_Lite (:77-90)
 // -> en_convs.0/1 (ConvBlock :142-164, Conv2d (1,5) stride (1,2)) -> 3 x GTConvBlock (:365-393).
-// Writes the five skip tensors en0 (B,T,65,16) and en1..en4 (B,T,33,16), slot order.
+// Writes the five skip tensors en0 (B,T,65,16) and en1..en4 (B,T,33,16); en1..en3 are written in
+// the slot order of the decoder stage that consumes them (layout.h I_ENST), en4 in its own order.
 constexpr int ENC_LDS_P = 0;
 constexpr int ENC_LDS_I = ENC_LDS_P + ENC_SIZE;
 constexpr int ENC_LDS_H = ENC_LDS_I + P_INTS;
 constexpr int ENC_LDS_EH = ENC_LDS_H + 3 * 2 * 35 * 16;
 constexpr int ENC_LDS_G = ENC_LDS_EH + 48;
-constexpr int ENC_LDS_A = ENC_LDS_G + TC * 16;             // E0, later W + S
+constexpr int ENC_LDS_PART = ENC_LDS_G + TC * 16;
+constexpr int ENC_LDS_A = ENC_LDS_PART + PART_FLOATS;      // staged spec, then E0, then W
 constexpr int ENC_E0_ROW = 69;
 constexpr int ENC_LDS_B = ENC_LDS_A + TC * ENC_E0_ROW * 16;  // EB + F0
 constexpr int EB_ROW = 131, F0_ROW = 136;
 constexpr int ENC_LDS_FLOATS = ENC_LDS_B + 3 * TC * EB_ROW + 3 * TC * F0_ROW;
-static_assert(TC * 35 * 16 + TC * 33 * 16 <= TC * ENC_E0_ROW * 16, "W + S must fit in the E0 region");
+static_assert(TC * NBINS * 2 <= TC * ENC_E0_ROW * 16, "staged spec chunk must fit in the E0 region");
 static_assert(ENC_LDS_FLOATS * 4 <= 160 * 1024, "encoder LDS budget");
-static_assert(ENC_LDS_I % 4 == 0 && ENC_LDS_H % 4 == 0 && ENC_LDS_G % 4 == 0 && ENC_LDS_A % 4 == 0, "16B carve");
+static_assert(ENC_LDS_I % 4 == 0 && ENC_LDS_H % 4 == 0 && ENC_LDS_G % 4 == 0 && ENC_LDS_A % 4 == 0 &&
+              ENC_LDS_PART % 4 == 0, "16B carve");
 
 __global__ __launch_bounds__(NTHR) void k_encoder(const float* __restrict__ spec, long sb, long sf, long st, int T,
                                                  const float* __restrict__ PF, const int* __restrict__ PI,
                                                  float* __restrict__ en0, float* __restrict__ en1,
                                                  float* __restrict__ en2, float* __restrict__ en3,
-                                                 float* __restrict__ en4, float* __restrict__ state) {
+                                                 float* __restrict__ en4, float* __restrict__ state,
+                                                 unsigned long long* __restrict__ stamps) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
+    STAMP_INIT(SS)
     float* sP = smem + ENC_LDS_P;
     int* sI = reinterpret_cast<int*>(smem + ENC_LDS_I);
     float* sH = smem + ENC_LDS_H;
     float* sEH = smem + ENC_LDS_EH;
     float* sG = smem + ENC_LDS_G;
+    float* sPart = smem + ENC_LDS_PART;
+    float* sSpec = smem + ENC_LDS_A;     // [tl][257][2]
     float* sE0 = smem + ENC_LDS_A;
     float* sW = smem + ENC_LDS_A;
-    float* sS = sW + TC * 35 * 16;
     float* sEB = smem + ENC_LDS_B;
     float* sF0 = sEB + 3 * TC * EB_ROW;
     const Lane L = lane_info();
@@ -452,29 +551,40 @@ __global__ __launch_bounds__(NTHR) void k_encoder(const float* __restrict__ spec
     float* stb = state ? state + (long)b * ST_FLOATS : nullptr;
     const int tbase = stb ? reinterpret_cast<const int*>(stb)[0] : 0;
     rings_load(sH, sEH, stb ? stb + ST_ENC_H : nullptr, stb ? stb + ST_ENC_E : nullptr, tid);
+    const Tiles tt = make_tiles(L, tbase);
     __syncthreads();
 
     spec += (long)b * sb;
     const long ob = (long)b * T;
     const bool t_fast = st < sf;  // reference layout (B,257,T,2): consecutive frames are adjacent
+    STAMP(SS, 0)
 
     for (int t0 = 0; t0 < T; t0 += TC) {
         const int nfr = min(TC, T - t0);
-        // ---- A: features + ERB.bm straight from global: EB[c][tl][1 + j] ------------------------
+        // ---- A0: stage the spectrogram chunk in LDS with independent, coalesced 8-byte loads --------
+        for (int idx = tid; idx < nfr * NBINS; idx += NTHR) {
+            int tl, f;
+            if (t_fast) { tl = idx % nfr; f = idx / nfr; } else { f = idx % NBINS; tl = idx / NBINS; }
+            const float* sp = spec + (long)f * sf + (long)(t0 + tl) * st;
+            float2 v;
+            v.x = sp[0]; v.y = sp[1];
+            *reinterpret_cast<float2*>(sSpec + (tl * NBINS + f) * 2) = v;
+        }
+        __syncthreads();
+        // ---- A: features + ERB.bm: EB[c][tl][1 + j] ---------------------------------------------------
         for (int idx = tid; idx < nfr * F0; idx += NTHR) {
-            int tl, j;
-            if (t_fast) { tl = idx % nfr; j = idx / nfr; } else { j = idx % F0; tl = idx / F0; }
-            const float* sp = spec + (long)(t0 + tl) * st;
+            const int j = idx % F0, tl = idx / F0;
+            const float* sp = sSpec + tl * NBINS * 2;
             float v0, v1, v2;
             if (j < ERB_LOW) {
-                const float re = sp[(long)j * sf], im = sp[(long)j * sf + 1];
+                const float re = sp[2 * j], im = sp[2 * j + 1];
                 v0 = sqrtf(re * re + im * im + 1e-12f); v1 = re; v2 = im;
             } else {
                 const int band = j - ERB_LOW, lo = sI[I_ERB_LO + band], cnt = sI[I_ERB_N + band];
                 v0 = v1 = v2 = 0.f;
                 for (int i = 0; i < cnt; ++i) {
-                    const long bin = ERB_LOW + lo + i;
-                    const float re = sp[bin * sf], im = sp[bin * sf + 1];
+                    const int bin = ERB_LOW + lo + i;
+                    const float re = sp[2 * bin], im = sp[2 * bin + 1];
                     const float w = sP[E_ERB_W + band * ERB_MAXBW + i];
                     v0 += w * sqrtf(re * re + im * im + 1e-12f); v1 += w * re; v2 += w * im;
                 }
@@ -484,6 +594,7 @@ __global__ __launch_bounds__(NTHR) void k_encoder(const float* __restrict__ spec
             sEB[(2 * TC + tl) * EB_ROW + 1 + j] = v2;
         }
         __syncthreads();
+        STAMP(SS, 1)
         // ---- B: SFE_Lite depthwise (1,3): F0[c][tl][2 + f] ---------------------------------------
         for (int idx = tid; idx < 3 * nfr * F0; idx += NTHR) {
             const int f = idx % F0, ct = idx / F0, tl = ct % nfr, c = ct / nfr;
@@ -491,16 +602,17 @@ __global__ __launch_bounds__(NTHR) void k_encoder(const float* __restrict__ spec
             sF0[(c * TC + tl) * F0_ROW + 2 + f] =
                 sP[E_SFE_W + c * 3] * e[0] + sP[E_SFE_W + c * 3 + 1] * e[1] + sP[E_SFE_W + c * 3 + 2] * e[2];
         }
-        // zero the pad positions of E0 (columns 0,1,67,68 of each row): region A was W/S last chunk
+        // zero the pad positions of E0 (columns 0,1,67,68 of each row): region A held the spectrogram
         if (tid < TC * 4 * 4) {
             const int r = tid >> 4, cc = (tid >> 2) & 3, gg = tid & 3;
             st4(sE0 + pl(r * ENC_E0_ROW + (cc < 2 ? cc : 65 + cc), gg), splat(0.f));
         }
         __syncthreads();
+        STAMP(SS, 2)
         // ---- C: en_convs.0 = Conv2d(3,16,(1,5),stride (1,2),pad (0,2)) + BN + PReLU --------------
         {
             const f32x4 A = ld4(sP + E_EN0_A + n * 16 + 4 * g), Bv = ld4(sP + E_EN0_B + 4 * g);
-            const float a = sP[E_EN0_S];
+            const float a = sP[E_EN0_S] - 1.0f;
             int off[4];
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
@@ -523,33 +635,31 @@ __global__ __launch_bounds__(NTHR) void k_encoder(const float* __restrict__ spec
             }
         }
         __syncthreads();
+        STAMP(SS, 3)
         // ---- D: en_convs.1 = Conv2d(16,16,(1,5),stride (1,2),pad (0,2)) + BN + PReLU -------------
         f32x4 x[TPW];
-        int tl[TPW], ff[TPW];
         {
             const f32x4 Bv = ld4(sP + E_EN1_B + 4 * g);
-            const float a = sP[E_EN1_S];
+            const float a = sP[E_EN1_S] - 1.0f;
+            const int* ix = sI + I_ENST + 0 * 16 + 4 * g;
 #pragma unroll
             for (int i = 0; i < TPW; ++i) {
-                const int p = (L.wave + i * NW) * 16 + n;
-                tl[i] = p / 33;
-                ff[i] = p - tl[i] * 33;
-                {
-                    f32x4 acc = Bv;
+                f32x4 acc = Bv;
+                const int e0 = pl(tt.tl[i] * ENC_E0_ROW + 2 * tt.ff[i], g);
 #pragma unroll
-                    for (int k = 0; k < 5; ++k) {
-                        const f32x4 tap = ld4(sE0 + pl(tl[i] * ENC_E0_ROW + 2 * ff[i] + k, g));
-                        const f32x4 A = ld4(sP + E_EN1_A + k * 256 + n * 16 + 4 * g);
+                for (int k = 0; k < 5; ++k) {
+                    const f32x4 tap = ld4(sE0 + e0 + k * 16);
+                    const f32x4 A = ld4(sP + E_EN1_A + k * 256 + n * 16 + 4 * g);
 #pragma unroll
-                        for (int q = 0; q < 4; ++q) acc = mfma(A[q], tap[q], acc);
-                    }
-                    x[i] = prelu4(acc, a);
-                    if (p < nfr * 33) st4(en1 + ((ob + t0) * 33 + p) * 16 + 4 * g, x[i]);
+                    for (int q = 0; q < 4; ++q) acc = mfma(A[q], tap[q], acc);
                 }
+                x[i] = prelu4(acc, a);
+                if (tt.pp[i] < nfr * 33) st_perm(en1 + ((ob + t0) * 33 + tt.pp[i]) * 16, ix, x[i]);
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
-        __syncthreads();  // E0 is dead: its region becomes W + S
+        __syncthreads();  // E0 is dead: its region becomes W
+        STAMP(SS, 4)
         zero_row_pads(sW, tid);
         // ---- E: 3 x GTConvBlock (depthwise) --------------------------------------------------------
 #pragma unroll 1
@@ -558,23 +668,30 @@ __global__ __launch_bounds__(NTHR) void k_encoder(const float* __restrict__ spec
             c.pb = sP + E_BLK + k * GB_SIZE;
             c.gA = nullptr;
             c.ib = sI + I_ENC_BLK + k * 16;
-            c.sW = sW; c.sHk = sH + k * (2 * 35 * 16); c.sS = sS; c.sG = sG; c.sEHk = sEH + k * 16;
+            c.sW = sW; c.sHk = sH + k * (2 * 35 * 16); c.sPart = sPart; c.sG = sG; c.sEHk = sEH + k * 16;
             c.nfr = nfr; c.tabs = tbase + t0;
-            gtconv_block<false>(x, tl, ff, c, L);
-            float* dst = k == 0 ? en2 : (k == 1 ? en3 : en4);
+            gtconv_block<false>(x, tt, c, L STAMP_ARG);
+            if (k < 2) {
+                float* dst = k == 0 ? en2 : en3;
+                const int* ix = sI + I_ENST + (k + 1) * 16 + 4 * g;
 #pragma unroll
-            for (int i = 0; i < TPW; ++i)
-                {
-                    const int p = (L.wave + i * NW) * 16 + n;
-                    if (p < nfr * 33) st4(dst + ((ob + t0) * 33 + p) * 16 + 4 * g, x[i]);
-                }
+                for (int i = 0; i < TPW; ++i)
+                    if (tt.pp[i] < nfr * 33) st_perm(dst + ((ob + t0) * 33 + tt.pp[i]) * 16, ix, x[i]);
+            } else {
+#pragma unroll
+                for (int i = 0; i < TPW; ++i)
+                    if (tt.pp[i] < nfr * 33) st4(en4 + ((ob + t0) * 33 + tt.pp[i]) * 16 + 4 * g, x[i]);
+            }
+            STAMP(SS, 8)
         }
-        __syncthreads();  // region A is rewritten as E0 by the next chunk
+        __syncthreads();  // region A is rewritten (staged spectrogram) by the next chunk
+        STAMP(SS, 9)
     }
     if (stb) {
         __syncthreads();
         rings_store(sH, sEH, stb + ST_ENC_H, stb + ST_ENC_E, tid);
     }
+    STAMP_OUT(SS, stamps)
 }
 
 // ================================================================================== GTCN
@@ -588,10 +705,62 @@ constexpr int GT_LDS_H = GT_LDS_W + TC * 33 * 16;
 constexpr int GT_LDS_FLOATS = GT_LDS_H + 30 * 33 * 16;
 static_assert(GT_LDS_W % 4 == 0, "16B carve");
 
+// one TCN block, dilation D (compile time); own = float offset of the lane's record in sW
+template <int D>
+__device__ __forceinline__ void tcn_block(f32x4 (&x)[TPW], const float* pk, float* sW, float* sHk,
+                                          const int (&own)[TPW], const int (&tl)[TPW], const int (&ff)[TPW],
+                                          int tb16, int nfr, int npos, const int (&pp)[TPW], const Lane& L STAMP_PARAM) {
+    const int n = L.n, g = L.g;
+    constexpr int M2D = 2 * D - 1;
+    const float a1 = pk[TCN_SLOPE] - 1.0f, a2 = pk[TCN_SLOPE + 1] - 1.0f, a3 = pk[TCN_SLOPE + 2] - 1.0f;
+    f32x4 y1[TPW], acc[TPW];
+    {
+        const f32x4 A = ld4(pk + TCN_A1 + n * 16 + 4 * g), Bv = ld4(pk + TCN_B1 + 4 * g);
+#pragma unroll
+        for (int i = 0; i < TPW; ++i) acc[i] = Bv;
+        mm16<TPW>(A, x, acc);
+#pragma unroll
+        for (int i = 0; i < TPW; ++i) {
+            y1[i] = prelu4(acc[i], a1);
+            st4(sW + own[i], y1[i]);
+        }
+    }
+    __syncthreads();
+    STAMP(SS, 2)
+    int r2[TPW];
+    {
+        const f32x4 w0 = ld4(pk + TCN_DW + 4 * g), w1 = ld4(pk + TCN_DW + 16 + 4 * g),
+                    w2 = ld4(pk + TCN_DW + 32 + 4 * g), B2 = ld4(pk + TCN_B2 + 4 * g);
+        const f32x4 A = ld4(pk + TCN_A3 + n * 16 + 4 * g), B3 = ld4(pk + TCN_B3 + 4 * g);
+        const long ringoff = sHk - sW;
+        f32x4 y2[TPW];
+#pragma unroll
+        for (int i = 0; i < TPW; ++i) {
+            // ring row of frame t is t mod 2d; chunk starts are multiples of 16 >= 2d
+            const int r1 = (int)ringoff + (((tb16 + tl[i] + D) & M2D) * 33 + ff[i]) * 16 + 4 * g;
+            r2[i] = (int)ringoff + (((tb16 + tl[i]) & M2D) * 33 + ff[i]) * 16 + 4 * g;
+            const f32x4 tp1 = ld4(sW + (tl[i] >= D ? own[i] - 33 * D * 16 : r1));
+            const f32x4 tp2 = ld4(sW + (tl[i] >= 2 * D ? own[i] - 66 * D * 16 : r2[i]));
+            y2[i] = prelu4(B2 + w0 * tp2 + w1 * tp1 + w2 * y1[i], a2);
+            acc[i] = B3 + x[i];
+        }
+        mm16<TPW>(A, y2, acc);
+#pragma unroll
+        for (int i = 0; i < TPW; ++i) x[i] = prelu4(acc[i], a3);
+    }
+    __syncthreads();
+    STAMP(SS, 3)
+#pragma unroll
+    for (int i = 0; i < TPW; ++i)
+        if (pp[i] < npos && tl[i] >= nfr - 2 * D) st4(sW + r2[i], y1[i]);
+    STAMP(SS, 4)
+}
+
 __global__ __launch_bounds__(NTHR) void k_gtcn(const float* __restrict__ xin, float* __restrict__ xout,
                                               const float* __restrict__ P, int T, float* __restrict__ state,
-                                              int st_off) {
+                                              int st_off, unsigned long long* __restrict__ stamps) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
+    STAMP_INIT(SS)
     float* sP = smem + GT_LDS_P;
     float* sW = smem + GT_LDS_W;
     float* sH = smem + GT_LDS_H;
@@ -601,84 +770,46 @@ __global__ __launch_bounds__(NTHR) void k_gtcn(const float* __restrict__ xin, fl
     for (int i = tid; i < GTCN_SIZE; i += NTHR) sP[i] = P[i];
     float* stb = state ? state + (long)b * ST_FLOATS : nullptr;
     const int tbase = stb ? reinterpret_cast<const int*>(stb)[0] : 0;
-    // ring image of block k starts at row 2*(2^k - 1); the swizzle is relative to the block's base
     for (int i = tid; i < 30 * 33 * 4; i += NTHR) {
-        const int gg = i & 3, pos = i >> 2, row = pos / 33;
-        const int r0 = row < 2 ? 0 : (row < 6 ? 2 : (row < 14 ? 6 : 14));
-        st4(sH + r0 * 528 + pl(pos - r0 * 33, gg), stb ? ld4(stb + st_off + pos * 16 + gg * 4) : splat(0.f));
+        const int gg = i & 3, pos = i >> 2;
+        st4(sH + pl(pos, gg), stb ? ld4(stb + st_off + pos * 16 + gg * 4) : splat(0.f));
     }
     __syncthreads();
     xin += (long)b * T * 528;
     xout += (long)b * T * 528;
+    int pp[TPW], tl[TPW], ff[TPW], own[TPW];
+#pragma unroll
+    for (int i = 0; i < TPW; ++i) {
+        pp[i] = (L.wave + i * NW) * 16 + n;
+        tl[i] = pp[i] / 33;
+        ff[i] = pp[i] - tl[i] * 33;
+        own[i] = pp[i] * 16 + 4 * g;
+    }
+    const int tb16 = tbase & 15;
+    STAMP(SS, 0)
 
     for (int t0 = 0; t0 < T; t0 += TC) {
         const int nfr = min(TC, T - t0), npos = nfr * 33;
-        f32x4 x[TPW], y1[TPW], acc[TPW];
-        int pp[TPW], tl[TPW], ff[TPW];
-#pragma unroll
-        for (int i = 0; i < TPW; ++i) {
-            pp[i] = (L.wave + i * NW) * 16 + n;
-            tl[i] = pp[i] / 33;
-            ff[i] = pp[i] - tl[i] * 33;
-            x[i] = pp[i] < npos ? ld4(xin + ((long)t0 * 33 + pp[i]) * 16 + 4 * g) : splat(0.f);
-        }
-#pragma unroll 1
-        for (int k = 0; k < 4; ++k) {
-            const int d = 1 << k, m2d = 2 * d - 1;
-            const float* pk = sP + k * TCN_SIZE;
-            float* sHk = sH + 2 * (d - 1) * 33 * 16;
-            const float a1 = pk[TCN_SLOPE], a2 = pk[TCN_SLOPE + 1], a3 = pk[TCN_SLOPE + 2];
-            {
-                const f32x4 A = ld4(pk + TCN_A1 + n * 16 + 4 * g), Bv = ld4(pk + TCN_B1 + 4 * g);
-#pragma unroll
-                for (int i = 0; i < TPW; ++i) acc[i] = Bv;
-                mm16<TPW>(A, x, acc);
-#pragma unroll
-                for (int i = 0; i < TPW; ++i)
-                    {
-                        y1[i] = prelu4(acc[i], a1);
-                        st4(sW + pl(pp[i], g), y1[i]);
-                    }
-            }
-            __syncthreads();
-            {
-                const f32x4 w0 = ld4(pk + TCN_DW + 4 * g), w1 = ld4(pk + TCN_DW + 16 + 4 * g),
-                            w2 = ld4(pk + TCN_DW + 32 + 4 * g), B2 = ld4(pk + TCN_B2 + 4 * g);
-                const f32x4 A = ld4(pk + TCN_A3 + n * 16 + 4 * g), B3 = ld4(pk + TCN_B3 + 4 * g);
-                f32x4 y2[TPW];
-#pragma unroll
-                for (int i = 0; i < TPW; ++i)
-                    {
-                        const int t = tbase + t0 + tl[i];
-                        const float* s1 = tl[i] >= d ? sW + pl(pp[i] - 33 * d, g)
-                                                     : sHk + pl(((t + d) & m2d) * 33 + ff[i], g);
-                        const float* s2 = tl[i] >= 2 * d ? sW + pl(pp[i] - 66 * d, g)
-                                                         : sHk + pl((t & m2d) * 33 + ff[i], g);
-                        const f32x4 tp1 = ld4(s1), tp2 = ld4(s2);
-                        y2[i] = prelu4(B2 + w0 * tp2 + w1 * tp1 + w2 * y1[i], a2);
-                        acc[i] = B3;
-                    }
-                mm16<TPW>(A, y2, acc);
-#pragma unroll
-                for (int i = 0; i < TPW; ++i)
-                    x[i] = prelu4(acc[i] + x[i], a3);
-            }
-            __syncthreads();
-#pragma unroll
-            for (int i = 0; i < TPW; ++i)
-                if (pp[i] < npos && tl[i] >= nfr - 2 * d)
-                    st4(sHk + pl(((tbase + t0 + tl[i]) & m2d) * 33 + ff[i], g), y1[i]);
-        }
+        f32x4 x[TPW];
 #pragma unroll
         for (int i = 0; i < TPW; ++i)
-            if (pp[i] < npos) st4(xout + ((long)t0 * 33 + pp[i]) * 16 + 4 * g, x[i]);
+            x[i] = pp[i] < npos ? ld4(xin + (long)t0 * 528 + own[i]) : splat(0.f);
+        STAMP(SS, 1)
+        tcn_block<1>(x, sP + 0 * TCN_SIZE, sW, sH + 0 * 528, own, tl, ff, tb16, nfr, npos, pp, L STAMP_ARG);
+        tcn_block<2>(x, sP + 1 * TCN_SIZE, sW, sH + 2 * 528, own, tl, ff, tb16, nfr, npos, pp, L STAMP_ARG);
+        tcn_block<4>(x, sP + 2 * TCN_SIZE, sW, sH + 6 * 528, own, tl, ff, tb16, nfr, npos, pp, L STAMP_ARG);
+        tcn_block<8>(x, sP + 3 * TCN_SIZE, sW, sH + 14 * 528, own, tl, ff, tb16, nfr, npos, pp, L STAMP_ARG);
+#pragma unroll
+        for (int i = 0; i < TPW; ++i)
+            if (pp[i] < npos) st4(xout + (long)t0 * 528 + own[i], x[i]);
+        STAMP(SS, 5)
     }
+    STAMP_OUT(SS, stamps)
     if (stb) {
         __syncthreads();
         for (int i = tid; i < 30 * 33 * 4; i += NTHR) {
-            const int gg = i & 3, pos = i >> 2, row = pos / 33;
-            const int r0 = row < 2 ? 0 : (row < 6 ? 2 : (row < 14 ? 6 : 14));
-            st4(stb + st_off + pos * 16 + gg * 4, ld4(sH + r0 * 528 + pl(pos - r0 * 33, gg)));
+            const int gg = i & 3, pos = i >> 2;
+            st4(stb + st_off + pos * 16 + gg * 4, ld4(sH + pl(pos, gg)));
         }
     }
 }
@@ -693,18 +824,14 @@ constexpr int DEC_LDS_I = DEC_LDS_P + DEC_SIZE;
 constexpr int DEC_LDS_H = DEC_LDS_I + P_INTS;
 constexpr int DEC_LDS_EH = DEC_LDS_H + 3 * 2 * 35 * 16;
 constexpr int DEC_LDS_G = DEC_LDS_EH + 48;
-constexpr int DEC_LDS_A = DEC_LDS_G + TC * 16;                    // W + S, later Z
-constexpr int DEC_LDS_M = DEC_LDS_A + TC * 35 * 16 + TC * 33 * 16;
+constexpr int DEC_LDS_PART = DEC_LDS_G + TC * 16;
+constexpr int DEC_LDS_A = DEC_LDS_PART + PART_FLOATS;             // W, later Z
+constexpr int DEC_LDS_M = DEC_LDS_A + TC * F1 * 16;
 constexpr int DEC_LDS_FLOATS = DEC_LDS_M + 2 * TC * F0;
-static_assert(TC * F1 * 16 <= TC * 35 * 16 + TC * 33 * 16, "Z must fit in the W + S region");
+static_assert(TC * 35 * 16 <= TC * F1 * 16, "W must fit in the Z region");
 static_assert(DEC_LDS_FLOATS * 4 <= 160 * 1024, "decoder LDS budget");
-static_assert(DEC_SIZE % 4 == 0 && DEC_LDS_I % 4 == 0 && DEC_LDS_H % 4 == 0 && DEC_LDS_A % 4 == 0, "16B carve");
-
-__device__ __forceinline__ f32x4 ld_skip(const float* rec, const int* idx4) {
-    f32x4 v;
-    v[0] = rec[idx4[0]]; v[1] = rec[idx4[1]]; v[2] = rec[idx4[2]]; v[3] = rec[idx4[3]];
-    return v;
-}
+static_assert(DEC_SIZE % 4 == 0 && DEC_LDS_I % 4 == 0 && DEC_LDS_H % 4 == 0 && DEC_LDS_A % 4 == 0 &&
+              DEC_LDS_PART % 4 == 0, "16B carve");
 
 __global__ __launch_bounds__(NTHR) void k_decoder(const float* __restrict__ xg, const float* __restrict__ en0,
                                                  const float* __restrict__ en1, const float* __restrict__ en2,
@@ -712,15 +839,17 @@ __global__ __launch_bounds__(NTHR) void k_decoder(const float* __restrict__ xg, 
                                                  const float* __restrict__ spec, long sb, long sf, long st,
                                                  float* __restrict__ out, long osb, long osf, long ost, int T,
                                                  const float* __restrict__ PF, const int* __restrict__ PI,
-                                                 float* __restrict__ state, float* __restrict__ dbg) {
+                                                 float* __restrict__ state, float* __restrict__ dbg,
+                                                 unsigned long long* __restrict__ stamps) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
+    STAMP_INIT(SS)
     float* sP = smem + DEC_LDS_P;
     int* sI = reinterpret_cast<int*>(smem + DEC_LDS_I);
     float* sH = smem + DEC_LDS_H;
     float* sEH = smem + DEC_LDS_EH;
     float* sG = smem + DEC_LDS_G;
+    float* sPart = smem + DEC_LDS_PART;
     float* sW = smem + DEC_LDS_A;
-    float* sS = sW + TC * 35 * 16;
     float* sZ = smem + DEC_LDS_A;
     float* sM = smem + DEC_LDS_M;
     const Lane L = lane_info();
@@ -731,6 +860,7 @@ __global__ __launch_bounds__(NTHR) void k_decoder(const float* __restrict__ xg, 
     float* stb = state ? state + (long)b * ST_FLOATS : nullptr;
     const int tbase = stb ? reinterpret_cast<const int*>(stb)[0] : 0;
     rings_load(sH, sEH, stb ? stb + ST_DEC_H : nullptr, stb ? stb + ST_DEC_E : nullptr, tid);
+    const Tiles tt = make_tiles(L, tbase);
     __syncthreads();
 
     const long ob = (long)b * T;
@@ -738,53 +868,62 @@ __global__ __launch_bounds__(NTHR) void k_decoder(const float* __restrict__ xg, 
     spec += (long)b * sb;
     out += (long)b * osb;
     const bool t_fast = st < sf;
+    constexpr int MASK_ITEMS = (TC * NBINS + NTHR - 1) / NTHR;   // spectrogram bins per thread and chunk
+    STAMP(SS, 0)
 
     for (int t0 = 0; t0 < T; t0 += TC) {
         const int nfr = min(TC, T - t0), npos = nfr * 33;
         f32x4 x[TPW];
-        int pp[TPW], tl[TPW], ff[TPW];
         bool ok[TPW];
 #pragma unroll
         for (int i = 0; i < TPW; ++i) {
-            pp[i] = (L.wave + i * NW) * 16 + n;
-            tl[i] = pp[i] / 33;
-            ff[i] = pp[i] - tl[i] * 33;
-            ok[i] = pp[i] < npos;
-            const long o = ((ob + t0) * 33 + pp[i]) * 16 + 4 * g;
+            ok[i] = tt.pp[i] < npos;
+            const long o = ((ob + t0) * 33 + tt.pp[i]) * 16 + 4 * g;
             x[i] = ok[i] ? ld4(xg + o) + ld4(en4 + o) : splat(0.f);
         }
         zero_row_pads(sW, tid);  // region A was Z in the previous chunk (a barrier follows in the block)
+        STAMP(SS, 1)
         // ---- 3 x GTConvBlock (dense transposed 3x3) -----------------------------------------------
 #pragma unroll 1
         for (int j = 0; j < 3; ++j) {
+            // the skip added to this block's output (en3, en2, en1; already in this stage's slot
+            // order) is fetched up front so that its latency hides behind the block
+            const float* sk = j == 0 ? en3 : (j == 1 ? en2 : en1);
+            f32x4 skv[TPW];
+#pragma unroll
+            for (int i = 0; i < TPW; ++i)
+                skv[i] = ok[i] ? ld4(sk + ((ob + t0) * 33 + tt.pp[i]) * 16 + 4 * g) : splat(0.f);
             BlockCtx c;
             c.pb = sP + D_BLK + j * GBD_SIZE;
             c.gA = c.pb + GB_DN_A;
             c.ib = sI + I_DEC_BLK + j * 16;
-            c.sW = sW; c.sHk = sH + j * (2 * 35 * 16); c.sS = sS; c.sG = sG; c.sEHk = sEH + j * 16;
+            c.sW = sW; c.sHk = sH + j * (2 * 35 * 16); c.sPart = sPart; c.sG = sG; c.sEHk = sEH + j * 16;
             c.nfr = nfr; c.tabs = tbase + t0;
-            gtconv_block<true>(x, tl, ff, c, L);
+            gtconv_block<true>(x, tt, c, L STAMP_ARG);
             if (dbg)
 #pragma unroll
                 for (int i = 0; i < TPW; ++i)
-                    if (ok[i]) st4(dbg + ((long)j * nbt + ob + t0) * 528 + pp[i] * 16 + 4 * g, x[i]);
-            // skip added to this block's output: en3, en2, en1 (stored in their producer's slot order)
-            const float* sk = j == 0 ? en3 : (j == 1 ? en2 : en1);
-            const int* idx4 = sI + I_SKIP + j * 16 + 4 * g;
+                    if (ok[i]) st4(dbg + ((long)j * nbt + ob + t0) * 528 + tt.pp[i] * 16 + 4 * g, x[i]);
 #pragma unroll
-            for (int i = 0; i < TPW; ++i)
-                if (ok[i]) x[i] += ld_skip(sk + ((ob + t0) * 33 + pp[i]) * 16, idx4);
+            for (int i = 0; i < TPW; ++i) x[i] += skv[i];
+            STAMP(SS, 8)
         }
         // ---- de_convs.3: gather form; input image in sW rows (pad columns are zero).  Every wave is
         // past the last block's tap reads (they precede that block's 2nd barrier), so sW is free.
+        f32x4 s0e[TPW], s0o[TPW];   // en_outs[0] for the even / odd output bins, fetched early
 #pragma unroll
-        for (int i = 0; i < TPW; ++i)
-            st4(sW + pl(tl[i] * 35 + 1 + ff[i], g), x[i]);
+        for (int i = 0; i < TPW; ++i) {
+            st4(sW + tt.o35[i], x[i]);
+            const float* s0 = en0 + ((ob + t0 + tt.tl[i]) * F1 + 2 * tt.ff[i]) * 16 + 4 * g;
+            s0e[i] = ok[i] ? ld4(s0) : splat(0.f);
+            s0o[i] = (ok[i] && tt.ff[i] < 32) ? ld4(s0 + 16) : splat(0.f);
+        }
         __syncthreads();
+        STAMP(SS, 10)
         f32x4 ze[TPW], zo[TPW];
         {
             const f32x4 Bv = ld4(sP + D_DE3_B + 4 * g);
-            const float a = sP[D_DE3_S];
+            const float a = sP[D_DE3_S] - 1.0f;
             const f32x4 A4 = ld4(sP + D_DE4_A + n * 16 + 4 * g);
             // even output 2m: k=0 <- x[m+1], k=2 <- x[m], k=4 <- x[m-1]; odd 2m+1: k=1 <- x[m+1], k=3 <- x[m]
             const f32x4 Ae0 = ld4(sP + D_DE3_AE + 0 * 256 + n * 16 + 4 * g),
@@ -794,55 +933,66 @@ __global__ __launch_bounds__(NTHR) void k_decoder(const float* __restrict__ xg, 
                         Ao1 = ld4(sP + D_DE3_AO + 1 * 256 + n * 16 + 4 * g);
 #pragma unroll
             for (int i = 0; i < TPW; ++i) {
-                {
-                    const f32x4 xp = ld4(sW + pl(tl[i] * 35 + 2 + ff[i], g));  // input bin f+1
-                    const f32x4 xm = ld4(sW + pl(tl[i] * 35 + ff[i], g));      // input bin f-1
-                    f32x4 ae = Bv, ao = Bv;
+                const f32x4 xp = ld4(sW + tt.o35[i] + 16);   // input bin f+1
+                const f32x4 xm = ld4(sW + tt.o35[i] - 16);   // input bin f-1
+                f32x4 ae = Bv, ao = Bv;
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        ae = mfma(Ae0[q], xp[q], ae);
-                        ao = mfma(Ao0[q], xp[q], ao);
-                    }
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        ae = mfma(Ae1[q], x[i][q], ae);
-                        ao = mfma(Ao1[q], x[i][q], ao);
-                    }
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) ae = mfma(Ae2[q], xm[q], ae);
-                    ae = prelu4(ae, a);
-                    ao = prelu4(ao, a);
-                    if (dbg && ok[i]) {
-                        float* d3 = dbg + 3 * nbt * 528 + ((ob + t0 + tl[i]) * F1) * 16 + 4 * g;
-                        st4(d3 + (2 * ff[i]) * 16, ae);
-                        if (ff[i] < 32) st4(d3 + (2 * ff[i] + 1) * 16, ao);
-                    }
-                    // + en_outs[0] (identity slot order), then de_convs.4 in scatter form
-                    if (ok[i]) {
-                        const float* s0 = en0 + ((ob + t0 + tl[i]) * F1 + 2 * ff[i]) * 16 + 4 * g;
-                        ae += ld4(s0);
-                        if (ff[i] < 32) ao += ld4(s0 + 16);
-                    }
-                    f32x4 e = splat(0.f), o = splat(0.f);
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        e = mfma(A4[q], ae[q], e);
-                        o = mfma(A4[q], ao[q], o);
-                    }
-                    ze[i] = e;
-                    zo[i] = o;
+                for (int q = 0; q < 4; ++q) {
+                    ae = mfma(Ae0[q], xp[q], ae);
+                    ao = mfma(Ao0[q], xp[q], ao);
                 }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    ae = mfma(Ae1[q], x[i][q], ae);
+                    ao = mfma(Ao1[q], x[i][q], ao);
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) ae = mfma(Ae2[q], xm[q], ae);
+                ae = prelu4(ae, a);
+                ao = prelu4(ao, a);
+                if (dbg && ok[i]) {
+                    float* d3 = dbg + 3 * nbt * 528 + ((ob + t0 + tt.tl[i]) * F1) * 16 + 4 * g;
+                    st4(d3 + (2 * tt.ff[i]) * 16, ae);
+                    if (tt.ff[i] < 32) st4(d3 + (2 * tt.ff[i] + 1) * 16, ao);
+                }
+                // + en_outs[0] (identity slot order), then de_convs.4 in scatter form
+                ae += s0e[i];
+                ao += s0o[i];
+                f32x4 e = splat(0.f), o = splat(0.f);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    e = mfma(A4[q], ae[q], e);
+                    o = mfma(A4[q], ao[q], o);
+                }
+                ze[i] = e;
+                zo[i] = o;
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
         __syncthreads();  // all taps of sW read: region A becomes Z[tl][65][16]
+        STAMP(SS, 11)
 #pragma unroll
-        for (int i = 0; i < TPW; ++i)
-            {
-                st4(sZ + pl(tl[i] * F1 + 2 * ff[i], g), ze[i]);
-                if (ff[i] < 32) st4(sZ + pl(tl[i] * F1 + 2 * ff[i] + 1, g), zo[i]);
+        for (int i = 0; i < TPW; ++i) {
+            st4(sZ + pl(tt.tl[i] * F1 + 2 * tt.ff[i], g), ze[i]);
+            if (tt.ff[i] < 32) st4(sZ + pl(tt.tl[i] * F1 + 2 * tt.ff[i] + 1, g), zo[i]);
+        }
+        // the input spectrogram for the mask is fetched here so that its latency hides behind the
+        // de_convs.4 gather below
+        float2 spv[MASK_ITEMS];
+#pragma unroll
+        for (int q = 0; q < MASK_ITEMS; ++q) {
+            const int idx = tid + q * NTHR;
+            int tq, f;
+            if (t_fast) { tq = idx % nfr; f = idx / nfr; } else { f = idx % NBINS; tq = idx / NBINS; }
+            spv[q] = make_float2(0.f, 0.f);
+            if (idx < nfr * NBINS) {
+                const float* sp = spec + (long)f * sf + (long)(t0 + tq) * st;
+                spv[q].x = sp[0];
+                spv[q].y = sp[1];
             }
+        }
         __syncthreads();
+        STAMP(SS, 12)
         // de_convs.4 gather + BN + Tanh: m[o][f''] = tanh(b[o] + sum_k z[(f''+2-k)/2][o*5+k])
         for (int idx = tid; idx < 2 * nfr * F0; idx += NTHR) {
             const int fq = idx % F0, ot = idx / F0, tq = ot % nfr, o = ot / nfr;
@@ -852,9 +1002,10 @@ __global__ __launch_bounds__(NTHR) void k_decoder(const float* __restrict__ xg, 
                 const int num = fq + 2 - k;
                 if ((num & 1) == 0 && num >= 0 && num < 2 * F1) s += sZ[pls(tq * F1 + (num >> 1), o * 5 + k)];
             }
-            sM[(o * TC + tq) * F0 + fq] = tanhf(s);
+            sM[(o * TC + tq) * F0 + fq] = fast_tanh(s);
         }
         __syncthreads();
+        STAMP(SS, 13)
         if (dbg)
             for (int idx = tid; idx < 2 * nfr * F0; idx += NTHR) {
                 const int fq = idx % F0, ot = idx / F0, tq = ot % nfr, o = ot / nfr;
@@ -862,30 +1013,35 @@ __global__ __launch_bounds__(NTHR) void k_decoder(const float* __restrict__ xg, 
                     sM[(o * TC + tq) * F0 + fq];
             }
         // ---- ERB.bs + complex ratio mask + output layout --------------------------------------------
-        for (int idx = tid; idx < nfr * NBINS; idx += NTHR) {
-            int tq, f;
-            if (t_fast) { tq = idx % nfr; f = idx / nfr; } else { f = idx % NBINS; tq = idx / NBINS; }
-            float mr, mi;
-            if (f < ERB_LOW) {
-                mr = sM[(0 * TC + tq) * F0 + f];
-                mi = sM[(1 * TC + tq) * F0 + f];
-            } else {
-                const int i = f - ERB_LOW, lo = sI[I_BS_LO + i], cnt = sI[I_BS_N + i];
-                mr = 0.f; mi = 0.f;
-                for (int q = 0; q < cnt; ++q) {
-                    const float w = sP[D_BS_W + i * ERB_MAXBS + q];
-                    mr += w * sM[(0 * TC + tq) * F0 + ERB_LOW + lo + q];
-                    mi += w * sM[(1 * TC + tq) * F0 + ERB_LOW + lo + q];
+#pragma unroll
+        for (int q = 0; q < MASK_ITEMS; ++q) {
+            const int idx = tid + q * NTHR;
+            if (idx < nfr * NBINS) {
+                int tq, f;
+                if (t_fast) { tq = idx % nfr; f = idx / nfr; } else { f = idx % NBINS; tq = idx / NBINS; }
+                float mr, mi;
+                if (f < ERB_LOW) {
+                    mr = sM[(0 * TC + tq) * F0 + f];
+                    mi = sM[(1 * TC + tq) * F0 + f];
+                } else {
+                    const int i = f - ERB_LOW, lo = sI[I_BS_LO + i], cnt = sI[I_BS_N + i];
+                    mr = 0.f; mi = 0.f;
+                    for (int r = 0; r < cnt; ++r) {
+                        const float w = sP[D_BS_W + i * ERB_MAXBS + r];
+                        mr += w * sM[(0 * TC + tq) * F0 + ERB_LOW + lo + r];
+                        mi += w * sM[(1 * TC + tq) * F0 + ERB_LOW + lo + r];
+                    }
                 }
+                const float re = spv[q].x, im = spv[q].y;
+                float* op = out + (long)f * osf + (long)(t0 + tq) * ost;
+                op[0] = re * mr - im * mi;
+                op[1] = im * mr + re * mi;
             }
-            const float* sp = spec + (long)f * sf + (long)(t0 + tq) * st;
-            const float re = sp[0], im = sp[1];
-            float* op = out + (long)f * osf + (long)(t0 + tq) * ost;
-            op[0] = re * mr - im * mi;
-            op[1] = im * mr + re * mi;
         }
         __syncthreads();  // sM and region A are rewritten by the next chunk
+        STAMP(SS, 14)
     }
+    STAMP_OUT(SS, stamps)
     if (stb) {
         __syncthreads();
         rings_store(sH, sEH, stb + ST_DEC_H, stb + ST_DEC_E, tid);
@@ -993,25 +1149,27 @@ int configure_kernels() {
 }
 
 int launch_encoder(const float* spec, long sb, long sf, long st, int B, int T, const float* PF, const int* PI,
-                   float* en0, float* en1, float* en2, float* en3, float* en4, float* state, hipStream_t s) {
+                   float* en0, float* en1, float* en2, float* en3, float* en4, float* state,
+                   unsigned long long* stamps, hipStream_t s) {
     hipLaunchKernelGGL(k_encoder, dim3(B), dim3(NTHR), ENC_LDS_FLOATS * 4, s, spec, sb, sf, st, T, PF, PI, en0, en1,
-                       en2, en3, en4, state);
+                       en2, en3, en4, state, stamps);
     GT_LAUNCH_CHECK();
     return 0;
 }
 
 int launch_gtcn(const float* xin, float* xout, const float* P, int B, int T, float* state, int st_off,
-                hipStream_t s) {
-    hipLaunchKernelGGL(k_gtcn, dim3(B), dim3(NTHR), GT_LDS_FLOATS * 4, s, xin, xout, P, T, state, st_off);
+                unsigned long long* stamps, hipStream_t s) {
+    hipLaunchKernelGGL(k_gtcn, dim3(B), dim3(NTHR), GT_LDS_FLOATS * 4, s, xin, xout, P, T, state, st_off, stamps);
     GT_LAUNCH_CHECK();
     return 0;
 }
 
 int launch_decoder(const float* xg, const float* en0, const float* en1, const float* en2, const float* en3,
                    const float* en4, const float* spec, long sb, long sf, long st, float* out, long osb, long osf,
-                   long ost, int B, int T, const float* PF, const int* PI, float* state, float* dbg, hipStream_t s) {
+                   long ost, int B, int T, const float* PF, const int* PI, float* state, float* dbg,
+                   unsigned long long* stamps, hipStream_t s) {
     hipLaunchKernelGGL(k_decoder, dim3(B), dim3(NTHR), DEC_LDS_FLOATS * 4, s, xg, en0, en1, en2, en3, en4, spec, sb,
-                       sf, st, out, osb, osf, ost, T, PF, PI, state, dbg);
+                       sf, st, out, osb, osf, ost, T, PF, PI, state, dbg, stamps);
     GT_LAUNCH_CHECK();
     return 0;
 }

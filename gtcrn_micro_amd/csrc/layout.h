@@ -92,12 +92,13 @@ constexpr int I_BS_LO = 128;                       // [192] first band of bin i
 constexpr int I_BS_N = 320;                        // [192] bands of bin i
 constexpr int I_ENC_BLK = 512;                     // 3 x 16: slot_of_c[8], x2slots[8]
 constexpr int I_DEC_BLK = I_ENC_BLK + 48;          // 3 x 16
-// skip-add index tables (16 each): for the tensor x held in slot order, the
-// position inside the stored 16-float skip record that belongs to slot s.
-constexpr int I_SKIP = I_DEC_BLK + 48;             // [4][16]: dec1 (+en3), dec2 (+en2), de3 (+en1), spare
-// slot -> logical channel of each stored activation, for the debug taps:
+// encoder store tables (16 each): the skips en1, en2, en3 are stored in the slot order of the
+// decoder stage that adds them (so the decoder reads them with one 16-byte load per lane):
+// I_ENST[q][s] = index inside the stored 16-float record for the value in encoder slot s.
+constexpr int I_ENST = I_DEC_BLK + 48;             // [4][16]: en1, en2, en3, spare
+// slot -> logical channel of each STORED activation, for the debug taps:
 // 0:en0 1:en1 2:en2 3:en3 4:en4(=gtcn) 5:de0 6:de1 7:de2 8:de3
-constexpr int I_PERM = I_SKIP + 64;                // [9][16]
+constexpr int I_PERM = I_ENST + 64;                // [9][16]
 constexpr int P_INTS = I_PERM + 9 * 16;
 
 }  // namespace gtl

@@ -180,9 +180,9 @@ static Perm pack_gtconv(const GTRaw& g, bool deconv, const Perm& in, float* F, i
     return out;
 }
 
-// skip[s] = index inside the stored record (order `stored`) of the logical channel held in slot s of `cur`
-static void skip_table(const Perm& cur, const Perm& stored, int* out) {
-    for (int s = 0; s < 16; ++s) out[s] = stored.slot_of(cur.l[s]);
+// out[s] = index inside a record stored in `consumer` order for the value held in slot s of `producer`
+static void store_table(const Perm& producer, const Perm& consumer, int* out) {
+    for (int s = 0; s < 16; ++s) out[s] = consumer.slot_of(producer.l[s]);
 }
 
 }  // namespace
@@ -277,9 +277,11 @@ int pack_params(const float* params, long n, float* F, int* I, std::string& err)
         GTRaw g = take_gt(c, true);
         cur = pack_gtconv(g, true, cur, D + D_BLK + j * GBD_SIZE, I + I_DEC_BLK + j * 16);
         perm[5 + j] = cur;
-        // the skip added to this block's OUTPUT: en3 (after de0), en2 (after de1), en1 (after de2)
-        skip_table(cur, perm[3 - j], I + I_SKIP + j * 16);
     }
+    // the skip added to the OUTPUT of decoder block j is en_outs[3-j]: en3 after de0, en2 after de1,
+    // en1 after de2.  The encoder stores each of them in that consumer's slot order.
+    for (int q = 0; q < 3; ++q)             // q = 0: en1 -> de2 order, 1: en2 -> de1, 2: en3 -> de0
+        store_table(perm[1 + q], perm[7 - q], I + I_ENST + q * 16);
     // ---- de_convs.3: ConvTranspose2d(16,16,(1,5),stride 2) + BN + PReLU, gather form -------------
     {
         const float* w = c.take(1280); const float* b = c.take(16); BN bn = take_bn(c, 16);
@@ -308,8 +310,11 @@ int pack_params(const float* params, long n, float* F, int* I, std::string& err)
         }
     }
     if (c.p - params != NPARAM) { err = "internal: parameter walk ended at the wrong offset"; return -1; }
+    Perm stored[9];
+    for (int t = 0; t < 9; ++t) stored[t] = perm[t];
+    for (int q = 0; q < 3; ++q) stored[1 + q] = perm[7 - q];
     for (int t = 0; t < 9; ++t)
-        for (int s = 0; s < 16; ++s) I[I_PERM + t * 16 + s] = perm[t].l[s];
+        for (int s = 0; s < 16; ++s) I[I_PERM + t * 16 + s] = stored[t].l[s];
     return 0;
 }
 

@@ -132,6 +132,10 @@ int gtcrn_pack_params_host(const float *h_params, long n_floats, float *h_f, int
  * before the forward).  Returns element count, or a negative status. */
 int gtcrn_debug_enable(gtcrn_model *m, int on);
 long gtcrn_debug_tap(gtcrn_model *m, const char *name, int b, float *h_dst, long cap);
+/* Diagnostic build only (libgtcrn_micro_hip_stamps.so, -DGT_STAMPS): per-workgroup sums of shader
+ * cycles spent in each barrier-delimited phase of kernel 0 encoder, 1 gtcn1, 2 gtcn2, 3 decoder,
+ * (B,16) values.  The product library returns zeros. */
+long gtcrn_debug_stamps(gtcrn_model *m, int kernel, unsigned long long *h_dst, long cap);
 /* Checks the MFMA f32 16x16x4 lane maps the kernels rely on (exact integer
  * data, asymmetric operands).  0 = as assumed. */
 int gtcrn_selftest_mfma(int device);

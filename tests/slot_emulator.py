@@ -101,10 +101,16 @@ def forward(F, I, spec):
     for k in range(5):
         acc += x0p[:, k + 2 * np.arange(33)] @ _mat(E, K["E_EN1_A"] + k * 256).T
     x = prelu(acc, E[K["E_EN1_S"]])
-    rec["en1"] = x
+
+    def stored(q, v):   # en1..en3 are stored in their decoder consumer's slot order (I_ENST)
+        out = np.empty_like(v)
+        out[:, :, I[K["I_ENST"] + q * 16:K["I_ENST"] + q * 16 + 16]] = v
+        return out
+
+    rec["en1"] = stored(0, x)
     for k in range(3):
         x = gtconv(x, E[K["E_BLK"] + k * K["GB_SIZE"]:], I[K["I_ENC_BLK"] + k * 16:], False)
-        rec[f"en{2 + k}"] = x
+        rec[f"en{2 + k}"] = stored(k + 1, x) if k < 2 else x
     for g in range(2):
         for k in range(4):
             x = tcn(x, F[K["P_GTCN"] + g * K["GTCN_SIZE"] + k * K["TCN_SIZE"]:], 1 << k)
@@ -113,8 +119,7 @@ def forward(F, I, spec):
     for j in range(3):
         x = gtconv(x, D[K["D_BLK"] + j * K["GBD_SIZE"]:], I[K["I_DEC_BLK"] + j * 16:], True)
         rec[f"de{j}"] = x
-        skip = rec[f"en{3 - j}"]
-        x = x + skip[:, :, I[K["I_SKIP"] + j * 16:K["I_SKIP"] + j * 16 + 16]]
+        x = x + rec[f"en{3 - j}"]
     # de3 gather form
     xp = np.pad(x, ((0, 0), (1, 1), (0, 0)))           # index f+1
     b3 = D[K["D_DE3_B"]:K["D_DE3_B"] + 16]

@@ -1,0 +1,70 @@
+#!/usr/bin/env python3
+"""Phase anatomy of the model kernels from in-kernel s_memtime stamps (diagnostic build).
+
+    GTCRN_LIB_VARIANT=stamps python tools/phase_profile.py [--batch 256] [--seconds 4]
+
+Builds libgtcrn_micro_hip_stamps.so (-DGT_STAMPS), runs the bench workload once and prints, per
+kernel, the average shader cycles a workgroup spends in each barrier-delimited phase.  Read the
+SHARES, not the absolute run time: the stamps and their fences perturb the schedule.
+"""
+import argparse
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+os.environ["GTCRN_LIB_VARIANT"] = "stamps"
+
+PHASES = {
+    0: {0: "prologue", 1: "A erb(global)", 2: "B sfe", 3: "C en_conv0", 4: "D en_conv1", 5: "blk pc1", 6: "blk depth+pc2",
+        7: "blk tra reduce", 8: "blk apply+store", 9: "chunk end"},
+    1: {0: "prologue", 1: "load x", 2: "conv1", 3: "taps+conv3", 4: "ring", 5: "store"},
+    3: {0: "prologue", 1: "load x+en4", 5: "blk pc1", 6: "blk dense+pc2", 7: "blk tra reduce", 8: "blk apply+skip",
+        10: "de3 stage x", 11: "de3+de4 mfma", 12: "Z write", 13: "de4 gather+tanh", 14: "bs+mask+store"},
+}
+PHASES[2] = PHASES[1]
+NAMES = ["k_encoder", "k_gtcn1", "k_gtcn2", "k_decoder"]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--batch", type=int, default=256)
+    ap.add_argument("--seconds", type=float, default=4.0)
+    ap.add_argument("--json", default=None)
+    a = ap.parse_args()
+    import numpy as np
+    import torch
+    from gtcrn_micro_amd.build import build_native
+    build_native(stamps=True)
+    from gtcrn_micro_amd import Engine
+    params = np.fromfile(os.path.join(ROOT, "tests", "golden", "params_dns3.f32"), dtype=np.float32)
+    eng = Engine(params, 0)
+    B, L = a.batch, int(a.seconds * 16000)
+    torch.manual_seed(43)
+    wave = torch.randn(B, L, device="cuda") * 0.1
+    win = torch.hann_window(512).pow(0.5).cuda()
+    for _ in range(3):
+        eng.forward_wave(wave, win)
+    eng.debug_enable(True)
+    eng.timing_enable(True)
+    eng.forward_wave(wave, win)
+    torch.cuda.synchronize()
+    kern = eng.timing_read()
+    out = {}
+    for k in range(4):
+        st = eng.stamps(k, B).astype(np.float64)
+        avg = st.mean(axis=0)
+        tot = avg.sum()
+        print(f"\n{NAMES[k]}: {tot:,.0f} cycles per workgroup (launch {kern.get(NAMES[k], (0, 0))[0] * 1e3:.1f} us "
+              f"-> {tot / max(kern.get(NAMES[k], (1, 0))[0] * 1e3, 1e-9):.0f} cycles/us)")
+        out[NAMES[k]] = {}
+        for i, nm in PHASES[k].items():
+            print(f"   {nm:<18} {avg[i]:>12,.0f}  {100 * avg[i] / tot:5.1f} %")
+            out[NAMES[k]][nm] = avg[i]
+    if a.json:
+        json.dump(out, open(a.json, "w"), indent=1)
+
+
+if __name__ == "__main__":
+    main()
