@@ -153,12 +153,13 @@ int run_model(gtcrn_model* m, const float* spec_in, long isb, long isf, long ist
                                    m->d_en[2], m->d_en[3], state, stp ? stp : nullptr, s));
     tm.end();
     tm.begin(2);
-    LAUNCH_TRY(gtk::launch_gtcn(m->d_en[3], m->d_g1, m->d_pf + gtl::P_GTCN, B, T, state, gtk::ST_G1_H,
+    LAUNCH_TRY(gtk::launch_gtcn(m->d_en[3], m->d_g1, m->d_pf + gtl::P_GTCN, B, T, state, gtk::ST_G1_H, nullptr,
                                 stp ? stp + sst : nullptr, s));
     tm.end();
     tm.begin(3);
+    // the second stack stores gtcn2(x) + en_outs[4]: exactly the decoder's first input (Decoder.forward :467)
     LAUNCH_TRY(gtk::launch_gtcn(m->d_g1, m->d_g2, m->d_pf + gtl::P_GTCN + gtl::GTCN_SIZE, B, T, state, gtk::ST_G2_H,
-                                stp ? stp + 2 * sst : nullptr, s));
+                                m->d_en[3], stp ? stp + 2 * sst : nullptr, s));
     tm.end();
     tm.begin(4);
     LAUNCH_TRY(gtk::launch_decoder(m->d_g2, m->d_en0, m->d_en[0], m->d_en[1], m->d_en[2], m->d_en[3], spec_in, isb, isf,
@@ -495,6 +496,11 @@ long gtcrn_debug_tap(gtcrn_model* m, const char* name, int b, float* h_dst, long
     std::vector<float> tmp(nel);
     HIP_TRY(hipDeviceSynchronize());
     HIP_TRY(hipMemcpy(tmp.data(), src + (long)b * T * F * 16, sizeof(float) * nel, hipMemcpyDeviceToHost));
+    if (nm == "gtcn2") {  // stored as gtcn2(x) + en4: recover the stage output for the tap
+        std::vector<float> e4(nel);
+        HIP_TRY(hipMemcpy(e4.data(), m->d_en[3] + (long)b * T * F * 16, sizeof(float) * nel, hipMemcpyDeviceToHost));
+        for (long i = 0; i < nel; ++i) tmp[i] -= e4[i];
+    }
     const int* pm = m->h_pi.data() + gtl::I_PERM + perm * 16;
     for (int t = 0; t < T; ++t)
         for (int f = 0; f < F; ++f)

@@ -39,7 +39,7 @@ int launch_encoder(const float* spec, long sb, long sf, long st, int B, int T, c
                    float* en0, float* en1, float* en2, float* en3, float* en4, float* state,
                    unsigned long long* stamps, hipStream_t s);
 int launch_gtcn(const float* xin, float* xout, const float* P, int B, int T, float* state, int st_off,
-                unsigned long long* stamps, hipStream_t s);
+                const float* addend, unsigned long long* stamps, hipStream_t s);
 int launch_decoder(const float* xg, const float* en0, const float* en1, const float* en2, const float* en3,
                    const float* en4, const float* spec, long sb, long sf, long st, float* out, long osb, long osf,
                    long ost, int B, int T, const float* PF, const int* PI, float* state, float* dbg,

@@ -28,6 +28,14 @@ __device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<
 __device__ __forceinline__ void st4(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
 __device__ __forceinline__ f32x4 splat(float v) { f32x4 r = {v, v, v, v}; return r; }
 
+// Workgroup barrier for LDS hand-offs only.  __syncthreads() carries a workgroup-scope release
+// fence, which on gfx950 drains vmcnt: every barrier would then wait for all global loads and
+// stores in flight (prefetches, skip-tensor stores).  Waves of a workgroup exchange data only
+// through LDS here, so waiting for this wave's LDS operations (lgkmcnt) is sufficient.
+__device__ __forceinline__ void wg_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
 // position-major LDS image: 16 floats (one 64-byte record) per position, slot group g at +16g bytes.
 // Unswizzled on purpose: tap addresses are then "own address + compile-time constant", which keeps
 // address arithmetic off the VALU (the kernels are VALU-issue bound around the MFMAs, not LDS bound);
@@ -313,22 +321,22 @@ struct Tiles {
     int pp[TPW];    // position inside the chunk: tile * 16 + n
     int tl[TPW];    // frame inside the chunk
     int ff[TPW];    // frequency bin
-    int o35[TPW];   // float offset of the record in a 35-column row image (zero pad columns 0 and 34)
-    int rb1[TPW];   // float offset inside a 2-row h ring of (frame-1, bin), for frames before the chunk
-    int rb2[TPW];   // same for frame-2
 };
-__device__ __forceinline__ Tiles make_tiles(const Lane& L, int tbase) {
+__device__ __forceinline__ Tiles make_tiles(const Lane& L) {
     Tiles t;
 #pragma unroll
     for (int i = 0; i < TPW; ++i) {
         t.pp[i] = (L.wave + i * NW) * 16 + L.n;
         t.tl[i] = t.pp[i] / 33;
         t.ff[i] = t.pp[i] - t.tl[i] * 33;
-        t.o35[i] = (t.tl[i] * 35 + 1 + t.ff[i]) * 16 + 4 * L.g;
-        t.rb1[i] = (((tbase + t.tl[i] + 1) & 1) * 35 + 1 + t.ff[i]) * 16 + 4 * L.g;
-        t.rb2[i] = (((tbase + t.tl[i]) & 1) * 35 + 1 + t.ff[i]) * 16 + 4 * L.g;
     }
     return t;
+}
+// float offset of the lane's record in a 35-column row image (zero pad columns 0 and 34)
+__device__ __forceinline__ int o35(const Tiles& t, int i, int g) { return (t.tl[i] * 35 + 1 + t.ff[i]) * 16 + 4 * g; }
+// float offset inside a 2-row ring (row = frame & 1) of (frame tl - back, bin ff), back = 1 or 2
+__device__ __forceinline__ int ring35(const Tiles& t, int i, int g, int tbase, int back) {
+    return (((tbase + t.tl[i] + back) & 1) * 35 + 1 + t.ff[i]) * 16 + 4 * g;
 }
 
 constexpr int PART_FLOATS = NT2 * 2 * 16;   // per tile: two frame segments x 16 slots of sum(v^2)
@@ -361,10 +369,10 @@ __device__ __forceinline__ void gtconv_block(f32x4 (&x)[TPW], const Tiles& tt, c
 #pragma unroll
         for (int i = 0; i < TPW; ++i) {
             h[i] = prelu4(h[i], a1);
-            st4(c.sW + tt.o35[i], h[i]);
+            st4(c.sW + o35(tt, i, g), h[i]);
         }
     }
-    __syncthreads();
+    wg_barrier();
     STAMP(SS, 5)
     // ---- depth conv + BN + PReLU, then point_conv2 + BN in place over the x1 slots; one tile at a
     //      time so that the tap registers die with the tile (the partner waves on the SIMD fill the
@@ -382,12 +390,15 @@ __device__ __forceinline__ void gtconv_block(f32x4 (&x)[TPW], const Tiles& tt, c
 #pragma unroll
         for (int i = 0; i < TPW; ++i) {
             // row bases for frames t, t-1, t-2: inside the chunk image, or the ring for earlier frames
-            const int b0 = tt.o35[i];
-            const int b1 = tt.tl[i] >= 1 ? b0 - 35 * 16 : (int)ringoff + tt.rb1[i];
-            const int b2 = tt.tl[i] >= 2 ? b0 - 70 * 16 : (int)ringoff + tt.rb2[i];
-            f32x4 acc = Bd;
+            const int b0 = o35(tt, i, g);
+            const int b1 = tt.tl[i] >= 1 ? b0 - 35 * 16 : (int)ringoff + ring35(tt, i, g, c.tabs, 1);
+            const int b2 = tt.tl[i] >= 2 ? b0 - 70 * 16 : (int)ringoff + ring35(tt, i, g, c.tabs, 2);
+            f32x4 acc = Bd, acc1 = splat(0.f);   // two chains: the dense conv is 36 dependent MFMAs otherwise
 #pragma unroll
-            for (int kt = 0; kt < 3; ++kt)
+            for (int kt = 0; kt < 3; ++kt) {
+                // keep at most one kernel row (3 taps + 3 matrices) of LDS loads in flight: hoisting all
+                // nine ahead of the MFMAs costs 68 registers and pushes the kernel into scratch
+                if (DENSE && kt > 0) __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int kf = 0; kf < 3; ++kf) {
                     // encoder: tap (t-2+kt, f-1+kf); decoder (transposed): tap (t-kt, f+1-kf)
@@ -398,12 +409,19 @@ __device__ __forceinline__ void gtconv_block(f32x4 (&x)[TPW], const Tiles& tt, c
                     else tap = ld4(c.sW + (back == 0 ? b0 : (back == 1 ? b1 : b2)) + df * 16);
                     if (DENSE) {
                         const f32x4 A = ld4(c.gA + (kt * 3 + kf) * 256 + n * 16 + 4 * g);
+                        if ((kt * 3 + kf) & 1) {
 #pragma unroll
-                        for (int s = 0; s < 4; ++s) acc = mfma(A[s], tap[s], acc);
+                            for (int s = 0; s < 4; ++s) acc1 = mfma(A[s], tap[s], acc1);
+                        } else {
+#pragma unroll
+                            for (int s = 0; s < 4; ++s) acc = mfma(A[s], tap[s], acc);
+                        }
                     } else {
                         acc += wdw[kt * 3 + kf] * tap;
                     }
                 }
+            }
+            if (DENSE) acc += acc1;
             const f32x4 hd = prelu4(acc, a2);
             f32x4 v = keep * x[i] + B2;
 #pragma unroll
@@ -411,13 +429,15 @@ __device__ __forceinline__ void gtconv_block(f32x4 (&x)[TPW], const Tiles& tt, c
             x[i] = v;
             // a tile spans at most two frames: sum v^2 over the tile's positions per frame segment
             const int tile = L.wave + i * NW;
-            const bool seg1 = tt.tl[i] != (tile * 16) / 33;
-            f32x4 sa, sb;
+            const int f_lo = (tile * 16) / 33;
+            const bool two = (tile * 16 + 15) / 33 != f_lo;     // wave-uniform
+            const bool seg1 = tt.tl[i] != f_lo;
+            f32x4 sa, sb = splat(0.f);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float q = v[r] * v[r];
-                sa[r] = row_sum16(seg1 ? 0.f : q);
-                sb[r] = row_sum16(seg1 ? q : 0.f);
+            for (int r = 0; r < 4; ++r) sa[r] = row_sum16(seg1 ? 0.f : v[r] * v[r]);
+            if (two) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) sb[r] = row_sum16(seg1 ? v[r] * v[r] : 0.f);
             }
             if (n == 0) {
                 st4(c.sPart + (tile * 2) * 16 + 4 * g, sa);
@@ -426,12 +446,12 @@ __device__ __forceinline__ void gtconv_block(f32x4 (&x)[TPW], const Tiles& tt, c
             __builtin_amdgcn_sched_barrier(0);
         }
     }
-    __syncthreads();
+    wg_barrier();
     STAMP(SS, 6)
     // ---- history ring of h (after every wave has read its taps) -----------------------------------
 #pragma unroll
     for (int i = 0; i < TPW; ++i)
-        if (tt.tl[i] < c.nfr && tt.tl[i] >= c.nfr - 2) st4(c.sHk + tt.rb2[i], h[i]);
+        if (tt.tl[i] < c.nfr && tt.tl[i] >= c.nfr - 2) st4(c.sHk + ring35(tt, i, g, c.tabs, 2), h[i]);
     // ---- TRALite gate: 8 threads per frame (one per h' channel) combine the per-tile partial sums ----
     float e_keep = 0.f;
     const int rt = L.tid >> 3, rc = L.tid & 7;
@@ -461,18 +481,22 @@ __device__ __forceinline__ void gtconv_block(f32x4 (&x)[TPW], const Tiles& tt, c
         c.sG[rt * 16 + slot] = gate;
         c.sG[rt * 16 + c.ib[8 + rc]] = 1.0f;
     }
-    __syncthreads();
+    wg_barrier();
     STAMP(SS, 7)
     if (reducer && rt >= c.nfr - 2) c.sEHk[((c.tabs + rt) & 1) * 8 + rc] = e_keep;
 #pragma unroll
     for (int i = 0; i < TPW; ++i) x[i] = x[i] * ld4(c.sG + tt.tl[i] * 16 + 4 * g);
 }
 
-// zero the two pad columns of the TC rows of a 35-position row image
+// zero the two pad columns of the TC rows of a 35-position row image (tid and the zero are made
+// opaque so that neither is hoisted out of the chunk loop and kept live / spilled)
 __device__ __forceinline__ void zero_row_pads(float* img, int tid) {
+    asm volatile("" : "+v"(tid));
     if (tid < TC * 2 * 4) {
         const int r = tid >> 3, side = (tid >> 2) & 1, gg = tid & 3;
-        st4(img + pl(r * 35 + side * 34, gg), splat(0.f));
+        float z = 0.f;
+        asm volatile("" : "+v"(z));
+        st4(img + pl(r * 35 + side * 34, gg), splat(z));
     }
 }
 
@@ -551,72 +575,81 @@ __global__ __launch_bounds__(NTHR) void k_encoder(const float* __restrict__ spec
     float* stb = state ? state + (long)b * ST_FLOATS : nullptr;
     const int tbase = stb ? reinterpret_cast<const int*>(stb)[0] : 0;
     rings_load(sH, sEH, stb ? stb + ST_ENC_H : nullptr, stb ? stb + ST_ENC_E : nullptr, tid);
-    const Tiles tt = make_tiles(L, tbase);
-    __syncthreads();
+    const Tiles tt = make_tiles(L);
+    wg_barrier();
 
     spec += (long)b * sb;
     const long ob = (long)b * T;
+    // global addressing: wave-uniform base pointers (SGPR pairs) + 32-bit per-lane offsets
+    en0 += ob * (F1 * 16); en1 += ob * 528; en2 += ob * 528; en3 += ob * 528; en4 += ob * 528;
     const bool t_fast = st < sf;  // reference layout (B,257,T,2): consecutive frames are adjacent
     STAMP(SS, 0)
 
     for (int t0 = 0; t0 < T; t0 += TC) {
         const int nfr = min(TC, T - t0);
+        // the cooperative loops index from an opaque copy of tid so that their per-item offsets are
+        // recomputed per chunk instead of being hoisted, spilled and reloaded (scratch shares vmcnt)
+        int tv = tid;
+        asm volatile("" : "+v"(tv));
         // ---- A0: stage the spectrogram chunk in LDS with independent, coalesced 8-byte loads --------
-        for (int idx = tid; idx < nfr * NBINS; idx += NTHR) {
+        for (int idx = tv; idx < nfr * NBINS; idx += NTHR) {
             int tl, f;
             if (t_fast) { tl = idx % nfr; f = idx / nfr; } else { f = idx % NBINS; tl = idx / NBINS; }
-            const float* sp = spec + (long)f * sf + (long)(t0 + tl) * st;
-            float2 v;
-            v.x = sp[0]; v.y = sp[1];
-            *reinterpret_cast<float2*>(sSpec + (tl * NBINS + f) * 2) = v;
+            *reinterpret_cast<float2*>(sSpec + (tl * NBINS + f) * 2) =
+                *reinterpret_cast<const float2*>(spec + (long)f * sf + (long)(t0 + tl) * st);
         }
-        __syncthreads();
-        // ---- A: features + ERB.bm: EB[c][tl][1 + j] ---------------------------------------------------
-        for (int idx = tid; idx < nfr * F0; idx += NTHR) {
-            const int j = idx % F0, tl = idx / F0;
-            const float* sp = sSpec + tl * NBINS * 2;
-            float v0, v1, v2;
-            if (j < ERB_LOW) {
-                const float re = sp[2 * j], im = sp[2 * j + 1];
-                v0 = sqrtf(re * re + im * im + 1e-12f); v1 = re; v2 = im;
-            } else {
-                const int band = j - ERB_LOW, lo = sI[I_ERB_LO + band], cnt = sI[I_ERB_N + band];
-                v0 = v1 = v2 = 0.f;
-                for (int i = 0; i < cnt; ++i) {
-                    const int bin = ERB_LOW + lo + i;
-                    const float re = sp[2 * bin], im = sp[2 * bin + 1];
-                    const float w = sP[E_ERB_W + band * ERB_MAXBW + i];
-                    v0 += w * sqrtf(re * re + im * im + 1e-12f); v1 += w * re; v2 += w * im;
-                }
+        wg_barrier();
+        // ---- A: features + ERB.bm: EB[c][tl][1 + j]; pass-through bins and bands in separate loops so
+        //      that the lanes of a wave carry similar work ------------------------------------------
+        for (int idx = tv; idx < nfr * ERB_LOW; idx += NTHR) {
+            const int j = idx % ERB_LOW, tl = idx / ERB_LOW;
+            const float2 v = *reinterpret_cast<const float2*>(sSpec + (tl * NBINS + j) * 2);
+            sEB[(0 * TC + tl) * EB_ROW + 1 + j] = sqrtf(v.x * v.x + v.y * v.y + 1e-12f);
+            sEB[(1 * TC + tl) * EB_ROW + 1 + j] = v.x;
+            sEB[(2 * TC + tl) * EB_ROW + 1 + j] = v.y;
+        }
+        for (int idx = tv; idx < nfr * ERB_BANDS; idx += NTHR) {
+            const int band = idx % ERB_BANDS, tl = idx / ERB_BANDS;
+            const int lo = sI[I_ERB_LO + band], cnt = sI[I_ERB_N + band];
+            const float* sp = sSpec + (tl * NBINS + ERB_LOW + lo) * 2;
+            float v0 = 0.f, v1 = 0.f, v2 = 0.f;
+            for (int i = 0; i < cnt; ++i) {
+                const float2 v = *reinterpret_cast<const float2*>(sp + 2 * i);
+                const float w = sP[E_ERB_W + band * ERB_MAXBW + i];
+                v0 += w * sqrtf(v.x * v.x + v.y * v.y + 1e-12f); v1 += w * v.x; v2 += w * v.y;
             }
-            sEB[(0 * TC + tl) * EB_ROW + 1 + j] = v0;
-            sEB[(1 * TC + tl) * EB_ROW + 1 + j] = v1;
-            sEB[(2 * TC + tl) * EB_ROW + 1 + j] = v2;
+            sEB[(0 * TC + tl) * EB_ROW + 1 + ERB_LOW + band] = v0;
+            sEB[(1 * TC + tl) * EB_ROW + 1 + ERB_LOW + band] = v1;
+            sEB[(2 * TC + tl) * EB_ROW + 1 + ERB_LOW + band] = v2;
         }
-        __syncthreads();
+        wg_barrier();
         STAMP(SS, 1)
         // ---- B: SFE_Lite depthwise (1,3): F0[c][tl][2 + f] ---------------------------------------
-        for (int idx = tid; idx < 3 * nfr * F0; idx += NTHR) {
+        for (int idx = tv; idx < 3 * nfr * F0; idx += NTHR) {
             const int f = idx % F0, ct = idx / F0, tl = ct % nfr, c = ct / nfr;
             const float* e = sEB + (c * TC + tl) * EB_ROW + f;
             sF0[(c * TC + tl) * F0_ROW + 2 + f] =
                 sP[E_SFE_W + c * 3] * e[0] + sP[E_SFE_W + c * 3 + 1] * e[1] + sP[E_SFE_W + c * 3 + 2] * e[2];
         }
         // zero the pad positions of E0 (columns 0,1,67,68 of each row): region A held the spectrogram
-        if (tid < TC * 4 * 4) {
-            const int r = tid >> 4, cc = (tid >> 2) & 3, gg = tid & 3;
-            st4(sE0 + pl(r * ENC_E0_ROW + (cc < 2 ? cc : 65 + cc), gg), splat(0.f));
+        if (tv < TC * 4 * 4) {
+            const int r = tv >> 4, cc = (tv >> 2) & 3, gg = tv & 3;
+            float z = 0.f;
+            asm volatile("" : "+v"(z));
+            st4(sE0 + pl(r * ENC_E0_ROW + (cc < 2 ? cc : 65 + cc), gg), splat(z));
         }
-        __syncthreads();
+        wg_barrier();
         STAMP(SS, 2)
         // ---- C: en_convs.0 = Conv2d(3,16,(1,5),stride (1,2),pad (0,2)) + BN + PReLU --------------
         {
             const f32x4 A = ld4(sP + E_EN0_A + n * 16 + 4 * g), Bv = ld4(sP + E_EN0_B + 4 * g);
             const float a = sP[E_EN0_S] - 1.0f;
             int off[4];
+            int go = g;
+            asm volatile("" : "+v"(go));   // recompute the im2col offsets per chunk instead of spilling them
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
-                const int e = 4 * g + s, c = e < 15 ? e / 5 : 0, k = e < 15 ? e % 5 : 0;
+                const int e = 4 * go + s, c = e < 15 ? e / 5 : 0, k = e < 15 ? e % 5 : 0;
                 off[s] = c * TC * F0_ROW + k;
             }
             constexpr int NT0 = TC * F1 / 16;  // 65 tiles
@@ -631,10 +664,10 @@ __global__ __launch_bounds__(NTHR) void k_encoder(const float* __restrict__ spec
                 for (int s = 0; s < 4; ++s) acc = mfma(A[s], bv[s], acc);
                 acc = prelu4(acc, a);
                 st4(sE0 + pl(tl * ENC_E0_ROW + 2 + fo, g), acc);
-                if (tl < nfr) st4(en0 + ((ob + t0 + tl) * F1 + fo) * 16 + 4 * g, acc);
+                if (tl < nfr) st4(en0 + (long)t0 * (F1 * 16) + (unsigned)(q * 16 + 4 * g), acc);
             }
         }
-        __syncthreads();
+        wg_barrier();
         STAMP(SS, 3)
         // ---- D: en_convs.1 = Conv2d(16,16,(1,5),stride (1,2),pad (0,2)) + BN + PReLU -------------
         f32x4 x[TPW];
@@ -654,11 +687,11 @@ __global__ __launch_bounds__(NTHR) void k_encoder(const float* __restrict__ spec
                     for (int q = 0; q < 4; ++q) acc = mfma(A[q], tap[q], acc);
                 }
                 x[i] = prelu4(acc, a);
-                if (tt.pp[i] < nfr * 33) st_perm(en1 + ((ob + t0) * 33 + tt.pp[i]) * 16, ix, x[i]);
+                if (tt.pp[i] < nfr * 33) st_perm(en1 + (long)t0 * 528 + (unsigned)(tt.pp[i] * 16), ix, x[i]);
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
-        __syncthreads();  // E0 is dead: its region becomes W
+        wg_barrier();  // E0 is dead: its region becomes W
         STAMP(SS, 4)
         zero_row_pads(sW, tid);
         // ---- E: 3 x GTConvBlock (depthwise) --------------------------------------------------------
@@ -676,19 +709,19 @@ __global__ __launch_bounds__(NTHR) void k_encoder(const float* __restrict__ spec
                 const int* ix = sI + I_ENST + (k + 1) * 16 + 4 * g;
 #pragma unroll
                 for (int i = 0; i < TPW; ++i)
-                    if (tt.pp[i] < nfr * 33) st_perm(dst + ((ob + t0) * 33 + tt.pp[i]) * 16, ix, x[i]);
+                    if (tt.pp[i] < nfr * 33) st_perm(dst + (long)t0 * 528 + (unsigned)(tt.pp[i] * 16), ix, x[i]);
             } else {
 #pragma unroll
                 for (int i = 0; i < TPW; ++i)
-                    if (tt.pp[i] < nfr * 33) st4(en4 + ((ob + t0) * 33 + tt.pp[i]) * 16 + 4 * g, x[i]);
+                    if (tt.pp[i] < nfr * 33) st4(en4 + (long)t0 * 528 + (unsigned)(tt.pp[i] * 16 + 4 * g), x[i]);
             }
             STAMP(SS, 8)
         }
-        __syncthreads();  // region A is rewritten (staged spectrogram) by the next chunk
+        wg_barrier();  // region A is rewritten (staged spectrogram) by the next chunk
         STAMP(SS, 9)
     }
     if (stb) {
-        __syncthreads();
+        wg_barrier();
         rings_store(sH, sEH, stb + ST_ENC_H, stb + ST_ENC_E, tid);
     }
     STAMP_OUT(SS, stamps)
@@ -725,7 +758,7 @@ __device__ __forceinline__ void tcn_block(f32x4 (&x)[TPW], const float* pk, floa
             st4(sW + own[i], y1[i]);
         }
     }
-    __syncthreads();
+    wg_barrier();
     STAMP(SS, 2)
     int r2[TPW];
     {
@@ -748,7 +781,7 @@ __device__ __forceinline__ void tcn_block(f32x4 (&x)[TPW], const float* pk, floa
 #pragma unroll
         for (int i = 0; i < TPW; ++i) x[i] = prelu4(acc[i], a3);
     }
-    __syncthreads();
+    wg_barrier();
     STAMP(SS, 3)
 #pragma unroll
     for (int i = 0; i < TPW; ++i)
@@ -758,7 +791,8 @@ __device__ __forceinline__ void tcn_block(f32x4 (&x)[TPW], const float* pk, floa
 
 __global__ __launch_bounds__(NTHR) void k_gtcn(const float* __restrict__ xin, float* __restrict__ xout,
                                               const float* __restrict__ P, int T, float* __restrict__ state,
-                                              int st_off, unsigned long long* __restrict__ stamps) {
+                                              int st_off, const float* __restrict__ addend,
+                                              unsigned long long* __restrict__ stamps) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     STAMP_INIT(SS)
     float* sP = smem + GT_LDS_P;
@@ -774,9 +808,10 @@ __global__ __launch_bounds__(NTHR) void k_gtcn(const float* __restrict__ xin, fl
         const int gg = i & 3, pos = i >> 2;
         st4(sH + pl(pos, gg), stb ? ld4(stb + st_off + pos * 16 + gg * 4) : splat(0.f));
     }
-    __syncthreads();
+    wg_barrier();
     xin += (long)b * T * 528;
     xout += (long)b * T * 528;
+    if (addend) addend += (long)b * T * 528;
     int pp[TPW], tl[TPW], ff[TPW], own[TPW];
 #pragma unroll
     for (int i = 0; i < TPW; ++i) {
@@ -790,10 +825,15 @@ __global__ __launch_bounds__(NTHR) void k_gtcn(const float* __restrict__ xin, fl
 
     for (int t0 = 0; t0 < T; t0 += TC) {
         const int nfr = min(TC, T - t0), npos = nfr * 33;
-        f32x4 x[TPW];
+        // positions past the end of the utterance load a clamped (valid) record: no select, so the
+        // loads are not waited for until their first use; such lanes are never stored
+        f32x4 x[TPW], ad[TPW];
 #pragma unroll
-        for (int i = 0; i < TPW; ++i)
-            x[i] = pp[i] < npos ? ld4(xin + (long)t0 * 528 + own[i]) : splat(0.f);
+        for (int i = 0; i < TPW; ++i) {
+            const long o = (long)t0 * 528 + (pp[i] < npos ? own[i] : 4 * g);
+            x[i] = ld4(xin + o);
+            if (addend) ad[i] = ld4(addend + o);
+        }
         STAMP(SS, 1)
         tcn_block<1>(x, sP + 0 * TCN_SIZE, sW, sH + 0 * 528, own, tl, ff, tb16, nfr, npos, pp, L STAMP_ARG);
         tcn_block<2>(x, sP + 1 * TCN_SIZE, sW, sH + 2 * 528, own, tl, ff, tb16, nfr, npos, pp, L STAMP_ARG);
@@ -801,12 +841,12 @@ __global__ __launch_bounds__(NTHR) void k_gtcn(const float* __restrict__ xin, fl
         tcn_block<8>(x, sP + 3 * TCN_SIZE, sW, sH + 14 * 528, own, tl, ff, tb16, nfr, npos, pp, L STAMP_ARG);
 #pragma unroll
         for (int i = 0; i < TPW; ++i)
-            if (pp[i] < npos) st4(xout + (long)t0 * 528 + own[i], x[i]);
+            if (pp[i] < npos) st4(xout + (long)t0 * 528 + own[i], addend ? x[i] + ad[i] : x[i]);
         STAMP(SS, 5)
     }
     STAMP_OUT(SS, stamps)
     if (stb) {
-        __syncthreads();
+        wg_barrier();
         for (int i = tid; i < 30 * 33 * 4; i += NTHR) {
             const int gg = i & 3, pos = i >> 2;
             st4(stb + st_off + pos * 16 + gg * 4, ld4(sH + pl(pos, gg)));
@@ -833,6 +873,8 @@ static_assert(DEC_LDS_FLOATS * 4 <= 160 * 1024, "decoder LDS budget");
 static_assert(DEC_SIZE % 4 == 0 && DEC_LDS_I % 4 == 0 && DEC_LDS_H % 4 == 0 && DEC_LDS_A % 4 == 0 &&
               DEC_LDS_PART % 4 == 0, "16B carve");
 
+// DBG = true only for the stage-tap variant used by the parity tests (writes de0..de4 to `dbg`).
+template <bool DBG>
 __global__ __launch_bounds__(NTHR) void k_decoder(const float* __restrict__ xg, const float* __restrict__ en0,
                                                  const float* __restrict__ en1, const float* __restrict__ en2,
                                                  const float* __restrict__ en3, const float* __restrict__ en4,
@@ -860,8 +902,8 @@ __global__ __launch_bounds__(NTHR) void k_decoder(const float* __restrict__ xg, 
     float* stb = state ? state + (long)b * ST_FLOATS : nullptr;
     const int tbase = stb ? reinterpret_cast<const int*>(stb)[0] : 0;
     rings_load(sH, sEH, stb ? stb + ST_DEC_H : nullptr, stb ? stb + ST_DEC_E : nullptr, tid);
-    const Tiles tt = make_tiles(L, tbase);
-    __syncthreads();
+    const Tiles tt = make_tiles(L);
+    wg_barrier();
 
     const long ob = (long)b * T;
     const long nbt = (long)gridDim.x * T;
@@ -871,16 +913,23 @@ __global__ __launch_bounds__(NTHR) void k_decoder(const float* __restrict__ xg, 
     constexpr int MASK_ITEMS = (TC * NBINS + NTHR - 1) / NTHR;   // spectrogram bins per thread and chunk
     STAMP(SS, 0)
 
+    // xg already holds gtcn2(x) + en_outs[4] (k_gtcn adds it on store).  Lanes past the end of the
+    // utterance read a clamped, valid record (never stored), so no load sits behind a select and
+    // every load's latency runs until its first use.
+    // global addressing: wave-uniform chunk base pointers (SGPR pairs) + 32-bit per-lane offsets
+    xg += ob * 528; en0 += ob * (F1 * 16); en1 += ob * 528; en2 += ob * 528; en3 += ob * 528;
+    f32x4 xn[TPW];
+    {
+        const int np0 = min(TC, T) * 33;
+#pragma unroll
+        for (int i = 0; i < TPW; ++i) xn[i] = ld4(xg + (unsigned)((tt.pp[i] < np0 ? tt.pp[i] : 0) * 16 + 4 * g));
+    }
+    (void)en4;
     for (int t0 = 0; t0 < T; t0 += TC) {
         const int nfr = min(TC, T - t0), npos = nfr * 33;
         f32x4 x[TPW];
-        bool ok[TPW];
 #pragma unroll
-        for (int i = 0; i < TPW; ++i) {
-            ok[i] = tt.pp[i] < npos;
-            const long o = ((ob + t0) * 33 + tt.pp[i]) * 16 + 4 * g;
-            x[i] = ok[i] ? ld4(xg + o) + ld4(en4 + o) : splat(0.f);
-        }
+        for (int i = 0; i < TPW; ++i) x[i] = xn[i];
         zero_row_pads(sW, tid);  // region A was Z in the previous chunk (a barrier follows in the block)
         STAMP(SS, 1)
         // ---- 3 x GTConvBlock (dense transposed 3x3) -----------------------------------------------
@@ -890,9 +939,10 @@ __global__ __launch_bounds__(NTHR) void k_decoder(const float* __restrict__ xg, 
             // order) is fetched up front so that its latency hides behind the block
             const float* sk = j == 0 ? en3 : (j == 1 ? en2 : en1);
             f32x4 skv[TPW];
+            sk += (long)t0 * 528;
 #pragma unroll
             for (int i = 0; i < TPW; ++i)
-                skv[i] = ok[i] ? ld4(sk + ((ob + t0) * 33 + tt.pp[i]) * 16 + 4 * g) : splat(0.f);
+                skv[i] = ld4(sk + (unsigned)((tt.pp[i] < npos ? tt.pp[i] : 0) * 16 + 4 * g));
             BlockCtx c;
             c.pb = sP + D_BLK + j * GBD_SIZE;
             c.gA = c.pb + GB_DN_A;
@@ -900,10 +950,10 @@ __global__ __launch_bounds__(NTHR) void k_decoder(const float* __restrict__ xg, 
             c.sW = sW; c.sHk = sH + j * (2 * 35 * 16); c.sPart = sPart; c.sG = sG; c.sEHk = sEH + j * 16;
             c.nfr = nfr; c.tabs = tbase + t0;
             gtconv_block<true>(x, tt, c, L STAMP_ARG);
-            if (dbg)
+            if (DBG)
 #pragma unroll
                 for (int i = 0; i < TPW; ++i)
-                    if (ok[i]) st4(dbg + ((long)j * nbt + ob + t0) * 528 + tt.pp[i] * 16 + 4 * g, x[i]);
+                    if (tt.pp[i] < npos) st4(dbg + ((long)j * nbt + ob + t0) * 528 + tt.pp[i] * 16 + 4 * g, x[i]);
 #pragma unroll
             for (int i = 0; i < TPW; ++i) x[i] += skv[i];
             STAMP(SS, 8)
@@ -913,44 +963,59 @@ __global__ __launch_bounds__(NTHR) void k_decoder(const float* __restrict__ xg, 
         f32x4 s0e[TPW], s0o[TPW];   // en_outs[0] for the even / odd output bins, fetched early
 #pragma unroll
         for (int i = 0; i < TPW; ++i) {
-            st4(sW + tt.o35[i], x[i]);
-            const float* s0 = en0 + ((ob + t0 + tt.tl[i]) * F1 + 2 * tt.ff[i]) * 16 + 4 * g;
-            s0e[i] = ok[i] ? ld4(s0) : splat(0.f);
-            s0o[i] = (ok[i] && tt.ff[i] < 32) ? ld4(s0 + 16) : splat(0.f);
+            st4(sW + o35(tt, i, g), x[i]);
+            // en0 record of output bin 2f (even) and 2f+1 (odd; for f = 32 the clamped record is unused)
+            const float* en0c = en0 + (long)t0 * (F1 * 16);
+            const unsigned o0 = (unsigned)((tt.pp[i] < npos ? tt.tl[i] * F1 + 2 * tt.ff[i] : 0) * 16 + 4 * g);
+            s0e[i] = ld4(en0c + o0);
+            s0o[i] = ld4(en0c + o0 + (tt.ff[i] < 32 ? 16u : 0u));
         }
-        __syncthreads();
+        // next chunk's input: x is dead from here on, so its registers are reused for the prefetch
+        if (t0 + TC < T) {
+            const int npn = min(TC, T - t0 - TC) * 33;
+            const float* xgn = xg + (long)(t0 + TC) * 528;
+#pragma unroll
+            for (int i = 0; i < TPW; ++i) xn[i] = ld4(xgn + (unsigned)((tt.pp[i] < npn ? tt.pp[i] : 0) * 16 + 4 * g));
+        }
+        wg_barrier();
         STAMP(SS, 10)
         f32x4 ze[TPW], zo[TPW];
         {
             const f32x4 Bv = ld4(sP + D_DE3_B + 4 * g);
             const float a = sP[D_DE3_S] - 1.0f;
-            const f32x4 A4 = ld4(sP + D_DE4_A + n * 16 + 4 * g);
             // even output 2m: k=0 <- x[m+1], k=2 <- x[m], k=4 <- x[m-1]; odd 2m+1: k=1 <- x[m+1], k=3 <- x[m]
-            const f32x4 Ae0 = ld4(sP + D_DE3_AE + 0 * 256 + n * 16 + 4 * g),
-                        Ae1 = ld4(sP + D_DE3_AE + 1 * 256 + n * 16 + 4 * g),
-                        Ae2 = ld4(sP + D_DE3_AE + 2 * 256 + n * 16 + 4 * g),
-                        Ao0 = ld4(sP + D_DE3_AO + 0 * 256 + n * 16 + 4 * g),
-                        Ao1 = ld4(sP + D_DE3_AO + 1 * 256 + n * 16 + 4 * g);
+            const float* Ae = sP + D_DE3_AE + n * 16 + 4 * g;
+            const float* Ao = sP + D_DE3_AO + n * 16 + 4 * g;
 #pragma unroll
             for (int i = 0; i < TPW; ++i) {
-                const f32x4 xp = ld4(sW + tt.o35[i] + 16);   // input bin f+1
-                const f32x4 xm = ld4(sW + tt.o35[i] - 16);   // input bin f-1
+                const int b0 = o35(tt, i, g);
                 f32x4 ae = Bv, ao = Bv;
+                {
+                    const f32x4 xp = ld4(sW + b0 + 16);   // input bin f+1
+                    const f32x4 A0 = ld4(Ae), A1 = ld4(Ao);
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    ae = mfma(Ae0[q], xp[q], ae);
-                    ao = mfma(Ao0[q], xp[q], ao);
+                    for (int q = 0; q < 4; ++q) {
+                        ae = mfma(A0[q], xp[q], ae);
+                        ao = mfma(A1[q], xp[q], ao);
+                    }
                 }
+                {
+                    const f32x4 A0 = ld4(Ae + 256), A1 = ld4(Ao + 256);
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    ae = mfma(Ae1[q], x[i][q], ae);
-                    ao = mfma(Ao1[q], x[i][q], ao);
+                    for (int q = 0; q < 4; ++q) {
+                        ae = mfma(A0[q], x[i][q], ae);
+                        ao = mfma(A1[q], x[i][q], ao);
+                    }
                 }
+                {
+                    const f32x4 xm = ld4(sW + b0 - 16);   // input bin f-1
+                    const f32x4 A0 = ld4(Ae + 512);
 #pragma unroll
-                for (int q = 0; q < 4; ++q) ae = mfma(Ae2[q], xm[q], ae);
+                    for (int q = 0; q < 4; ++q) ae = mfma(A0[q], xm[q], ae);
+                }
                 ae = prelu4(ae, a);
                 ao = prelu4(ao, a);
-                if (dbg && ok[i]) {
+                if (DBG && tt.pp[i] < npos) {
                     float* d3 = dbg + 3 * nbt * 528 + ((ob + t0 + tt.tl[i]) * F1) * 16 + 4 * g;
                     st4(d3 + (2 * tt.ff[i]) * 16, ae);
                     if (tt.ff[i] < 32) st4(d3 + (2 * tt.ff[i] + 1) * 16, ao);
@@ -959,6 +1024,7 @@ __global__ __launch_bounds__(NTHR) void k_decoder(const float* __restrict__ xg, 
                 ae += s0e[i];
                 ao += s0o[i];
                 f32x4 e = splat(0.f), o = splat(0.f);
+                const f32x4 A4 = ld4(sP + D_DE4_A + n * 16 + 4 * g);
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     e = mfma(A4[q], ae[q], e);
@@ -969,7 +1035,7 @@ __global__ __launch_bounds__(NTHR) void k_decoder(const float* __restrict__ xg, 
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
-        __syncthreads();  // all taps of sW read: region A becomes Z[tl][65][16]
+        wg_barrier();  // all taps of sW read: region A becomes Z[tl][65][16]
         STAMP(SS, 11)
 #pragma unroll
         for (int i = 0; i < TPW; ++i) {
@@ -981,17 +1047,17 @@ __global__ __launch_bounds__(NTHR) void k_decoder(const float* __restrict__ xg, 
         float2 spv[MASK_ITEMS];
 #pragma unroll
         for (int q = 0; q < MASK_ITEMS; ++q) {
-            const int idx = tid + q * NTHR;
+            int idx = tid + q * NTHR;
+            // opaque per chunk: otherwise the per-item 64-bit addresses are hoisted out of the chunk
+            // loop, spilled, and every reload drains the loads in flight (scratch shares vmcnt)
+            asm volatile("" : "+v"(idx));
             int tq, f;
             if (t_fast) { tq = idx % nfr; f = idx / nfr; } else { f = idx % NBINS; tq = idx / NBINS; }
             spv[q] = make_float2(0.f, 0.f);
-            if (idx < nfr * NBINS) {
-                const float* sp = spec + (long)f * sf + (long)(t0 + tq) * st;
-                spv[q].x = sp[0];
-                spv[q].y = sp[1];
-            }
+            if (idx < nfr * NBINS)
+                spv[q] = *reinterpret_cast<const float2*>(spec + (long)f * sf + (long)(t0 + tq) * st);
         }
-        __syncthreads();
+        wg_barrier();
         STAMP(SS, 12)
         // de_convs.4 gather + BN + Tanh: m[o][f''] = tanh(b[o] + sum_k z[(f''+2-k)/2][o*5+k])
         for (int idx = tid; idx < 2 * nfr * F0; idx += NTHR) {
@@ -1004,9 +1070,9 @@ __global__ __launch_bounds__(NTHR) void k_decoder(const float* __restrict__ xg, 
             }
             sM[(o * TC + tq) * F0 + fq] = fast_tanh(s);
         }
-        __syncthreads();
+        wg_barrier();
         STAMP(SS, 13)
-        if (dbg)
+        if (DBG)
             for (int idx = tid; idx < 2 * nfr * F0; idx += NTHR) {
                 const int fq = idx % F0, ot = idx / F0, tq = ot % nfr, o = ot / nfr;
                 dbg[3 * nbt * 528 + nbt * F1 * 16 + (((long)b * 2 + o) * T + t0 + tq) * F0 + fq] =
@@ -1015,7 +1081,8 @@ __global__ __launch_bounds__(NTHR) void k_decoder(const float* __restrict__ xg, 
         // ---- ERB.bs + complex ratio mask + output layout --------------------------------------------
 #pragma unroll
         for (int q = 0; q < MASK_ITEMS; ++q) {
-            const int idx = tid + q * NTHR;
+            int idx = tid + q * NTHR;
+            asm volatile("" : "+v"(idx));
             if (idx < nfr * NBINS) {
                 int tq, f;
                 if (t_fast) { tq = idx % nfr; f = idx / nfr; } else { f = idx % NBINS; tq = idx / NBINS; }
@@ -1033,17 +1100,16 @@ __global__ __launch_bounds__(NTHR) void k_decoder(const float* __restrict__ xg, 
                     }
                 }
                 const float re = spv[q].x, im = spv[q].y;
-                float* op = out + (long)f * osf + (long)(t0 + tq) * ost;
-                op[0] = re * mr - im * mi;
-                op[1] = im * mr + re * mi;
+                *reinterpret_cast<float2*>(out + (long)f * osf + (long)(t0 + tq) * ost) =
+                    make_float2(re * mr - im * mi, im * mr + re * mi);
             }
         }
-        __syncthreads();  // sM and region A are rewritten by the next chunk
+        wg_barrier();  // sM and region A are rewritten by the next chunk
         STAMP(SS, 14)
     }
     STAMP_OUT(SS, stamps)
     if (stb) {
-        __syncthreads();
+        wg_barrier();
         rings_store(sH, sEH, stb + ST_DEC_H, stb + ST_DEC_E, tid);
         if (tid == 0) reinterpret_cast<int*>(stb)[0] = (tbase + T) & 0xFFFF;  // frame counter (rings use mod 16)
     }
@@ -1142,8 +1208,11 @@ int configure_kernels() {
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_gtcn), hipFuncAttributeMaxDynamicSharedMemorySize,
                             GT_LDS_FLOATS * 4);
     if (e != hipSuccess) return (int)e;
-    e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_decoder), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            DEC_LDS_FLOATS * 4);
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_decoder<false>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, DEC_LDS_FLOATS * 4);
+    if (e != hipSuccess) return (int)e;
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_decoder<true>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, DEC_LDS_FLOATS * 4);
     if (e != hipSuccess) return (int)e;
     return 0;
 }
@@ -1158,8 +1227,9 @@ int launch_encoder(const float* spec, long sb, long sf, long st, int B, int T, c
 }
 
 int launch_gtcn(const float* xin, float* xout, const float* P, int B, int T, float* state, int st_off,
-                unsigned long long* stamps, hipStream_t s) {
-    hipLaunchKernelGGL(k_gtcn, dim3(B), dim3(NTHR), GT_LDS_FLOATS * 4, s, xin, xout, P, T, state, st_off, stamps);
+                const float* addend, unsigned long long* stamps, hipStream_t s) {
+    hipLaunchKernelGGL(k_gtcn, dim3(B), dim3(NTHR), GT_LDS_FLOATS * 4, s, xin, xout, P, T, state, st_off, addend,
+                       stamps);
     GT_LAUNCH_CHECK();
     return 0;
 }
@@ -1168,8 +1238,12 @@ int launch_decoder(const float* xg, const float* en0, const float* en1, const fl
                    const float* en4, const float* spec, long sb, long sf, long st, float* out, long osb, long osf,
                    long ost, int B, int T, const float* PF, const int* PI, float* state, float* dbg,
                    unsigned long long* stamps, hipStream_t s) {
-    hipLaunchKernelGGL(k_decoder, dim3(B), dim3(NTHR), DEC_LDS_FLOATS * 4, s, xg, en0, en1, en2, en3, en4, spec, sb,
-                       sf, st, out, osb, osf, ost, T, PF, PI, state, dbg, stamps);
+    if (dbg)
+        hipLaunchKernelGGL(k_decoder<true>, dim3(B), dim3(NTHR), DEC_LDS_FLOATS * 4, s, xg, en0, en1, en2, en3, en4,
+                           spec, sb, sf, st, out, osb, osf, ost, T, PF, PI, state, dbg, stamps);
+    else
+        hipLaunchKernelGGL(k_decoder<false>, dim3(B), dim3(NTHR), DEC_LDS_FLOATS * 4, s, xg, en0, en1, en2, en3, en4,
+                           spec, sb, sf, st, out, osb, osf, ost, T, PF, PI, state, dbg, stamps);
     GT_LAUNCH_CHECK();
     return 0;
 }
