@@ -40,6 +40,7 @@ int launch_encoder(const float* spec, long sb, long sf, long st, int B, int T, c
                    unsigned long long* stamps, hipStream_t s);
 int launch_gtcn(const float* xin, float* xout, const float* P, int B, int T, float* state, int st_off,
                 const float* addend, unsigned long long* stamps, hipStream_t s);
+int launch_gtcn_band(const float* xin, float* xout, const float* P, int B, int T, const float* addend, hipStream_t s);
 int launch_decoder(const float* xg, const float* en0, const float* en1, const float* en2, const float* en3,
                    const float* en4, const float* spec, long sb, long sf, long st, float* out, long osb, long osf,
                    long ost, int B, int T, const float* PF, const int* PI, float* state, float* dbg,

@@ -733,20 +733,34 @@ __global__ __launch_bounds__(NTHR) void k_encoder(const float* __restrict__ spec
 // x stays in registers across the four blocks; only y1 goes through LDS (chunk image sW plus a
 // 2d-row ring per block, row = frame mod 2d).
 constexpr int GT_LDS_P = 0;
-constexpr int GT_LDS_W = GT_LDS_P + GTCN_SIZE;
-constexpr int GT_LDS_H = GT_LDS_W + TC * 33 * 16;
+constexpr int GT_LDS_W = GT_LDS_P + GTCN_SIZE;             // two chunk images, used alternately by the blocks
+constexpr int GT_LDS_H = GT_LDS_W + 2 * TC * 33 * 16;
 constexpr int GT_LDS_FLOATS = GT_LDS_H + 30 * 33 * 16;
 static_assert(GT_LDS_W % 4 == 0, "16B carve");
+static_assert(GT_LDS_FLOATS * 4 <= 160 * 1024, "GTCN LDS budget");
 
-// one TCN block, dilation D (compile time); own = float offset of the lane's record in sW
+// one TCN block, dilation D (compile time); own = float offset of the lane's record in a chunk image.
+// ONE barrier per block: taps older than the chunk come from the block's ring and are read BEFORE the
+// barrier (they do not depend on this block's y1, and their latency hides behind conv1); the ring is
+// rewritten after the barrier, when every wave is past its ring reads; the chunk image alternates
+// between two buffers so that the next block's y1 never overwrites taps a slower wave still reads.
 template <int D>
-__device__ __forceinline__ void tcn_block(f32x4 (&x)[TPW], const float* pk, float* sW, float* sHk,
+__device__ __forceinline__ void tcn_block(f32x4 (&x)[TPW], const float* pk, float* sWb, float* sHk,
                                           const int (&own)[TPW], const int (&tl)[TPW], const int (&ff)[TPW],
                                           int tb16, int nfr, int npos, const int (&pp)[TPW], const Lane& L STAMP_PARAM) {
     const int n = L.n, g = L.g;
     constexpr int M2D = 2 * D - 1;
     const float a1 = pk[TCN_SLOPE] - 1.0f, a2 = pk[TCN_SLOPE + 1] - 1.0f, a3 = pk[TCN_SLOPE + 2] - 1.0f;
-    f32x4 y1[TPW], acc[TPW];
+    f32x4 y1[TPW], acc[TPW], tp1[TPW], tp2[TPW];
+    int r2[TPW];
+    // ring row of frame t is t mod 2d; chunk starts are multiples of 16 >= 2d
+#pragma unroll
+    for (int i = 0; i < TPW; ++i) {
+        const int r1 = (((tb16 + tl[i] + D) & M2D) * 33 + ff[i]) * 16 + 4 * g;
+        r2[i] = (((tb16 + tl[i]) & M2D) * 33 + ff[i]) * 16 + 4 * g;
+        tp1[i] = ld4(sHk + r1);     // frame t-d  (used when t-d  lies before the chunk)
+        tp2[i] = ld4(sHk + r2[i]);  // frame t-2d (used when t-2d lies before the chunk)
+    }
     {
         const f32x4 A = ld4(pk + TCN_A1 + n * 16 + 4 * g), Bv = ld4(pk + TCN_B1 + 4 * g);
 #pragma unroll
@@ -755,37 +769,34 @@ __device__ __forceinline__ void tcn_block(f32x4 (&x)[TPW], const float* pk, floa
 #pragma unroll
         for (int i = 0; i < TPW; ++i) {
             y1[i] = prelu4(acc[i], a1);
-            st4(sW + own[i], y1[i]);
+            st4(sWb + own[i], y1[i]);
         }
     }
     wg_barrier();
     STAMP(SS, 2)
-    int r2[TPW];
     {
         const f32x4 w0 = ld4(pk + TCN_DW + 4 * g), w1 = ld4(pk + TCN_DW + 16 + 4 * g),
                     w2 = ld4(pk + TCN_DW + 32 + 4 * g), B2 = ld4(pk + TCN_B2 + 4 * g);
         const f32x4 A = ld4(pk + TCN_A3 + n * 16 + 4 * g), B3 = ld4(pk + TCN_B3 + 4 * g);
-        const long ringoff = sHk - sW;
         f32x4 y2[TPW];
 #pragma unroll
         for (int i = 0; i < TPW; ++i) {
-            // ring row of frame t is t mod 2d; chunk starts are multiples of 16 >= 2d
-            const int r1 = (int)ringoff + (((tb16 + tl[i] + D) & M2D) * 33 + ff[i]) * 16 + 4 * g;
-            r2[i] = (int)ringoff + (((tb16 + tl[i]) & M2D) * 33 + ff[i]) * 16 + 4 * g;
-            const f32x4 tp1 = ld4(sW + (tl[i] >= D ? own[i] - 33 * D * 16 : r1));
-            const f32x4 tp2 = ld4(sW + (tl[i] >= 2 * D ? own[i] - 66 * D * 16 : r2[i]));
-            y2[i] = prelu4(B2 + w0 * tp2 + w1 * tp1 + w2 * y1[i], a2);
+            // in-chunk taps: lanes whose tap lies before the chunk read their own record (discarded)
+            const f32x4 c1 = ld4(sWb + (tl[i] >= D ? own[i] - 33 * D * 16 : own[i]));
+            const f32x4 c2 = ld4(sWb + (tl[i] >= 2 * D ? own[i] - 66 * D * 16 : own[i]));
+            const f32x4 t1 = tl[i] >= D ? c1 : tp1[i];
+            const f32x4 t2 = tl[i] >= 2 * D ? c2 : tp2[i];
+            y2[i] = prelu4(B2 + w0 * t2 + w1 * t1 + w2 * y1[i], a2);
             acc[i] = B3 + x[i];
         }
         mm16<TPW>(A, y2, acc);
 #pragma unroll
         for (int i = 0; i < TPW; ++i) x[i] = prelu4(acc[i], a3);
     }
-    wg_barrier();
     STAMP(SS, 3)
 #pragma unroll
     for (int i = 0; i < TPW; ++i)
-        if (pp[i] < npos && tl[i] >= nfr - 2 * D) st4(sW + r2[i], y1[i]);
+        if (pp[i] < npos && tl[i] >= nfr - 2 * D) st4(sHk + r2[i], y1[i]);
     STAMP(SS, 4)
 }
 
@@ -835,10 +846,11 @@ __global__ __launch_bounds__(NTHR) void k_gtcn(const float* __restrict__ xin, fl
             if (addend) ad[i] = ld4(addend + o);
         }
         STAMP(SS, 1)
+        float* sW1 = sW + TC * 33 * 16;
         tcn_block<1>(x, sP + 0 * TCN_SIZE, sW, sH + 0 * 528, own, tl, ff, tb16, nfr, npos, pp, L STAMP_ARG);
-        tcn_block<2>(x, sP + 1 * TCN_SIZE, sW, sH + 2 * 528, own, tl, ff, tb16, nfr, npos, pp, L STAMP_ARG);
+        tcn_block<2>(x, sP + 1 * TCN_SIZE, sW1, sH + 2 * 528, own, tl, ff, tb16, nfr, npos, pp, L STAMP_ARG);
         tcn_block<4>(x, sP + 2 * TCN_SIZE, sW, sH + 6 * 528, own, tl, ff, tb16, nfr, npos, pp, L STAMP_ARG);
-        tcn_block<8>(x, sP + 3 * TCN_SIZE, sW, sH + 14 * 528, own, tl, ff, tb16, nfr, npos, pp, L STAMP_ARG);
+        tcn_block<8>(x, sP + 3 * TCN_SIZE, sW1, sH + 14 * 528, own, tl, ff, tb16, nfr, npos, pp, L STAMP_ARG);
 #pragma unroll
         for (int i = 0; i < TPW; ++i)
             if (pp[i] < npos) st4(xout + (long)t0 * 528 + own[i], addend ? x[i] + ad[i] : x[i]);
@@ -851,6 +863,99 @@ __global__ __launch_bounds__(NTHR) void k_gtcn(const float* __restrict__ xin, fl
             const int gg = i & 3, pos = i >> 2;
             st4(stb + st_off + pos * 16 + gg * 4, ld4(sH + pl(pos, gg)));
         }
+    }
+}
+
+// ---------------------------------------------------------------------------- GTCN, offline form
+// Same arithmetic, different ownership: wave w owns frequency bins 3w..3w+2 for ALL frames (11 waves x
+// 3 bins = 33), a tile = 16 consecutive frames of one bin (lane n <-> frame t0+n).  The TCN couples
+// positions only along time, so its taps are rotations inside the 16-lane DPP row of a tile:
+//   tap_s[n] = y1[n-s] for n >= s, else the previous chunk's y1[16+n-s]
+//            = row_ror:s of (n >= 16-s ? prev : cur)
+// The 2d frames of history live in registers (the previous chunk's y1 tile per block), so this form
+// uses no LDS for activations and NO barrier: waves run decoupled and overlap each other's MFMA and
+// VALU phases.  Used when there is no stream state (offline forward); the ring form above serves
+// streaming calls, where a chunk may hold a single frame.
+template <int S>
+__device__ __forceinline__ f32x4 tap_shift(const f32x4 cur, const f32x4 prev, int n) {
+    if (S == 16) return prev;
+    f32x4 r;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) r[q] = dpp_ror<0x120 + (S & 15)>(n >= 16 - S ? prev[q] : cur[q]);
+    return r;
+}
+
+template <int D>
+__device__ __forceinline__ void tcn_block_band(f32x4 (&x)[TPW], f32x4 (&prev)[TPW], const float* pk, const Lane& L) {
+    const int n = L.n, g = L.g;
+    const float a1 = pk[TCN_SLOPE] - 1.0f, a2 = pk[TCN_SLOPE + 1] - 1.0f, a3 = pk[TCN_SLOPE + 2] - 1.0f;
+    f32x4 y1[TPW], acc[TPW];
+    {
+        const f32x4 A = ld4(pk + TCN_A1 + n * 16 + 4 * g), Bv = ld4(pk + TCN_B1 + 4 * g);
+#pragma unroll
+        for (int i = 0; i < TPW; ++i) acc[i] = Bv;
+        mm16<TPW>(A, x, acc);
+#pragma unroll
+        for (int i = 0; i < TPW; ++i) y1[i] = prelu4(acc[i], a1);
+    }
+    {
+        const f32x4 w0 = ld4(pk + TCN_DW + 4 * g), w1 = ld4(pk + TCN_DW + 16 + 4 * g),
+                    w2 = ld4(pk + TCN_DW + 32 + 4 * g), B2 = ld4(pk + TCN_B2 + 4 * g);
+        const f32x4 A = ld4(pk + TCN_A3 + n * 16 + 4 * g), B3 = ld4(pk + TCN_B3 + 4 * g);
+        f32x4 y2[TPW];
+#pragma unroll
+        for (int i = 0; i < TPW; ++i) {
+            const f32x4 t1 = tap_shift<D>(y1[i], prev[i], n);
+            const f32x4 t2 = tap_shift<2 * D>(y1[i], prev[i], n);
+            y2[i] = prelu4(B2 + w0 * t2 + w1 * t1 + w2 * y1[i], a2);
+            acc[i] = B3 + x[i];
+            prev[i] = y1[i];
+        }
+        mm16<TPW>(A, y2, acc);
+#pragma unroll
+        for (int i = 0; i < TPW; ++i) x[i] = prelu4(acc[i], a3);
+    }
+}
+
+__global__ __launch_bounds__(NTHR) void k_gtcn_band(const float* __restrict__ xin, float* __restrict__ xout,
+                                                   const float* __restrict__ P, int T,
+                                                   const float* __restrict__ addend) {
+    __shared__ __attribute__((aligned(16))) float sP[GTCN_SIZE];
+    const Lane L = lane_info();
+    const int tid = L.tid, n = L.n, g = L.g;
+    const int b = blockIdx.x;
+    for (int i = tid; i < GTCN_SIZE; i += NTHR) sP[i] = P[i];
+    __syncthreads();
+    xin += (long)b * T * 528;
+    xout += (long)b * T * 528;
+    if (addend) addend += (long)b * T * 528;
+    f32x4 prev[4][TPW];
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+#pragma unroll
+        for (int i = 0; i < TPW; ++i) prev[k][i] = splat(0.f);
+    const int f0 = L.wave * TPW;                         // first bin of this wave
+    for (int t0 = 0; t0 < T; t0 += TC) {
+        const bool live = t0 + n < T;
+        const int tc = live ? t0 + n : T - 1;            // clamped frame: no select behind the loads
+        f32x4 x[TPW], ad[TPW];
+#pragma unroll
+        for (int i = 0; i < TPW; ++i) {
+            const unsigned o = (unsigned)((tc * 33 + f0 + i) * 16 + 4 * g);
+            x[i] = ld4(xin + o);
+            if (addend) ad[i] = ld4(addend + o);
+        }
+        // opaque offset: the block parameters are re-read from LDS every chunk; hoisting the four
+        // blocks' fragments out of the chunk loop would need 128 registers and spill
+        int po = 0;
+        asm volatile("" : "+v"(po));
+        tcn_block_band<1>(x, prev[0], sP + po + 0 * TCN_SIZE, L);
+        tcn_block_band<2>(x, prev[1], sP + po + 1 * TCN_SIZE, L);
+        tcn_block_band<4>(x, prev[2], sP + po + 2 * TCN_SIZE, L);
+        tcn_block_band<8>(x, prev[3], sP + po + 3 * TCN_SIZE, L);
+#pragma unroll
+        for (int i = 0; i < TPW; ++i)
+            if (live) st4(xout + (unsigned)((tc * 33 + f0 + i) * 16 + 4 * g), addend ? x[i] + ad[i] : x[i]);
     }
 }
 
@@ -1230,6 +1335,12 @@ int launch_gtcn(const float* xin, float* xout, const float* P, int B, int T, flo
                 const float* addend, unsigned long long* stamps, hipStream_t s) {
     hipLaunchKernelGGL(k_gtcn, dim3(B), dim3(NTHR), GT_LDS_FLOATS * 4, s, xin, xout, P, T, state, st_off, addend,
                        stamps);
+    GT_LAUNCH_CHECK();
+    return 0;
+}
+
+int launch_gtcn_band(const float* xin, float* xout, const float* P, int B, int T, const float* addend, hipStream_t s) {
+    hipLaunchKernelGGL(k_gtcn_band, dim3(B), dim3(NTHR), 0, s, xin, xout, P, T, addend);
     GT_LAUNCH_CHECK();
     return 0;
 }
