@@ -318,17 +318,18 @@ __global__ __launch_bounds__(FFT_WAVES * 64) void k_istft(const float* __restric
 // per-lane geometry of the wave's TPW tiles; constant for the whole kernel (chunks start at multiples
 // of 16 frames, so ring rows -- frame mod 2 / mod 2d -- do not depend on the chunk either)
 struct Tiles {
-    int pp[TPW];    // position inside the chunk: tile * 16 + n
     int tl[TPW];    // frame inside the chunk
     int ff[TPW];    // frequency bin
+    // position inside the chunk (= tile * 16 + n); one mad, cheaper than a third live register per tile
+    __device__ __forceinline__ int pp(int i) const { return tl[i] * 33 + ff[i]; }
 };
 __device__ __forceinline__ Tiles make_tiles(const Lane& L) {
     Tiles t;
 #pragma unroll
     for (int i = 0; i < TPW; ++i) {
-        t.pp[i] = (L.wave + i * NW) * 16 + L.n;
-        t.tl[i] = t.pp[i] / 33;
-        t.ff[i] = t.pp[i] - t.tl[i] * 33;
+        const int p = (L.wave + i * NW) * 16 + L.n;
+        t.tl[i] = p / 33;
+        t.ff[i] = p - t.tl[i] * 33;
     }
     return t;
 }
@@ -339,7 +340,6 @@ __device__ __forceinline__ int ring35(const Tiles& t, int i, int g, int tbase, i
     return (((tbase + t.tl[i] + back) & 1) * 35 + 1 + t.ff[i]) * 16 + 4 * g;
 }
 
-constexpr int PART_FLOATS = NT2 * 2 * 16;   // per tile: two frame segments x 16 slots of sum(v^2)
 
 struct BlockCtx {
     const float* pb;     // LDS: block parameters (GB_* offsets)
@@ -347,7 +347,7 @@ struct BlockCtx {
     const int* ib;       // LDS: slot_of_c[8], x2slots[8]
     float* sW;           // LDS: h of this chunk, rows of 35 positions (zero pad columns 0 and 34)
     float* sHk;          // LDS: 2-row history ring of h (row = frame & 1), rows of 35 positions
-    float* sPart;        // LDS: per-tile partial sums of v^2
+    float* sS;           // LDS: v^2, [position][16 slots], 33 positions per frame
     float* sG;           // LDS: gates [frame][16 slots]
     float* sEHk;         // LDS: 2-entry ring of e: [frame & 1][8]
     int nfr;             // frames in this chunk
@@ -359,18 +359,16 @@ __device__ __forceinline__ void gtconv_block(f32x4 (&x)[TPW], const Tiles& tt, c
                                              const Lane& L STAMP_PARAM) {
     const int n = L.n, g = L.g;
     const float a1 = c.pb[GB_SLOPE] - 1.0f, a2 = c.pb[GB_SLOPE + 1] - 1.0f;
-    f32x4 h[TPW];
-    // ---- point_conv1 + BN + PReLU (tiles interleaved: x and h are live across the phase anyway) ----
+    // ---- point_conv1 + BN + PReLU; h lives only in the LDS image from here on (its centre tap and the
+    //      ring update re-read it: one ds_read_b128 each instead of 12 registers held across the phase) ----
     {
+        f32x4 h[TPW];
         const f32x4 A = ld4(c.pb + GB_PC1_A + n * 16 + 4 * g), Bv = ld4(c.pb + GB_PC1_B + 4 * g);
 #pragma unroll
         for (int i = 0; i < TPW; ++i) h[i] = Bv;
         mm16<TPW>(A, x, h);
 #pragma unroll
-        for (int i = 0; i < TPW; ++i) {
-            h[i] = prelu4(h[i], a1);
-            st4(c.sW + o35(tt, i, g), h[i]);
-        }
+        for (int i = 0; i < TPW; ++i) st4(c.sW + o35(tt, i, g), prelu4(h[i], a1));
     }
     wg_barrier();
     STAMP(SS, 5)
@@ -404,9 +402,7 @@ __device__ __forceinline__ void gtconv_block(f32x4 (&x)[TPW], const Tiles& tt, c
                     // encoder: tap (t-2+kt, f-1+kf); decoder (transposed): tap (t-kt, f+1-kf)
                     const int back = DENSE ? kt : 2 - kt;          // frames back: 0, 1, 2
                     const int df = DENSE ? 1 - kf : kf - 1;
-                    f32x4 tap;
-                    if (back == 0 && df == 0) tap = h[i];
-                    else tap = ld4(c.sW + (back == 0 ? b0 : (back == 1 ? b1 : b2)) + df * 16);
+                    const f32x4 tap = ld4(c.sW + (back == 0 ? b0 : (back == 1 ? b1 : b2)) + df * 16);
                     if (DENSE) {
                         const f32x4 A = ld4(c.gA + (kt * 3 + kf) * 256 + n * 16 + 4 * g);
                         if ((kt * 3 + kf) & 1) {
@@ -427,22 +423,7 @@ __device__ __forceinline__ void gtconv_block(f32x4 (&x)[TPW], const Tiles& tt, c
 #pragma unroll
             for (int s = 0; s < 4; ++s) v = mfma(A2[s], hd[s], v);
             x[i] = v;
-            // a tile spans at most two frames: sum v^2 over the tile's positions per frame segment
-            const int tile = L.wave + i * NW;
-            const int f_lo = (tile * 16) / 33;
-            const bool two = (tile * 16 + 15) / 33 != f_lo;     // wave-uniform
-            const bool seg1 = tt.tl[i] != f_lo;
-            f32x4 sa, sb = splat(0.f);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) sa[r] = row_sum16(seg1 ? 0.f : v[r] * v[r]);
-            if (two) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) sb[r] = row_sum16(seg1 ? v[r] * v[r] : 0.f);
-            }
-            if (n == 0) {
-                st4(c.sPart + (tile * 2) * 16 + 4 * g, sa);
-                st4(c.sPart + (tile * 2 + 1) * 16 + 4 * g, sb);
-            }
+            st4(c.sS + tt.pp(i) * 16 + 4 * g, v * v);   // energies are reduced cooperatively after the barrier
             __builtin_amdgcn_sched_barrier(0);
         }
     }
@@ -451,39 +432,44 @@ __device__ __forceinline__ void gtconv_block(f32x4 (&x)[TPW], const Tiles& tt, c
     // ---- history ring of h (after every wave has read its taps) -----------------------------------
 #pragma unroll
     for (int i = 0; i < TPW; ++i)
-        if (tt.tl[i] < c.nfr && tt.tl[i] >= c.nfr - 2) st4(c.sHk + ring35(tt, i, g, c.tabs, 2), h[i]);
-    // ---- TRALite gate: 8 threads per frame (one per h' channel) combine the per-tile partial sums ----
+        if (tt.tl[i] < c.nfr && tt.tl[i] >= c.nfr - 2)
+            st4(c.sHk + ring35(tt, i, g, c.tabs, 2), ld4(c.sW + o35(tt, i, g)));
+    // ---- TRALite gate: 32 threads per frame = 8 h' channels x 4 bin ranges (9, 9, 9, 6 bins); the four
+    //      partial sums of a channel sit in one DPP quad and are combined there (fixed order, so the
+    //      result is reproducible); every quad also sums the two previous frames itself, which
+    //      costs 18 more LDS reads but saves a barrier -------------------------------------------------
     float e_keep = 0.f;
-    const int rt = L.tid >> 3, rc = L.tid & 7;
-    const bool reducer = L.tid < c.nfr * 8;
+    const int part = L.tid & 3, rc = (L.tid >> 2) & 7, rt = L.tid >> 5;
+    const bool reducer = L.tid < c.nfr * 32;
     if (reducer) {
         const int slot = c.ib[rc];
+        const int f0 = part * 9, cnt = part == 3 ? 6 : 9;
         float e[3];
 #pragma unroll
         for (int j = 0; j < 3; ++j) {  // e[j] = energy of frame rt - 2 + j
             const int tau = rt - 2 + j;
-            if (tau >= 0) {
-                const int qa = (33 * tau) >> 4, qb = (33 * tau + 32) >> 4;
-                float s = 0.f;
-                for (int q = qa; q <= qb; ++q) s += c.sPart[(q * 2 + (tau - (q * 16) / 33)) * 16 + slot];
-                e[j] = s / 33.0f;
-            } else {
-                e[j] = c.sEHk[((c.tabs + tau) & 1) * 8 + rc];
-            }
+            const float* sp = c.sS + ((tau >= 0 ? tau : 0) * 33 + f0) * 16 + slot;
+            float sum = 0.f;
+            for (int f = 0; f < cnt; ++f) sum += sp[f * 16];
+            sum += dpp_ror<0xB1>(sum);   // quad_perm [1,0,3,2]
+            sum += dpp_ror<0x4E>(sum);   // quad_perm [2,3,0,1]
+            e[j] = tau >= 0 ? sum / 33.0f : c.sEHk[((c.tabs + tau) & 1) * 8 + rc];
         }
         e_keep = e[2];
         const float y = c.pb[GB_TRA_DB + rc] + c.pb[GB_TRA_DW + rc * 3] * e[0] + c.pb[GB_TRA_DW + rc * 3 + 1] * e[1] +
                         c.pb[GB_TRA_DW + rc * 3 + 2] * e[2];
         float z = c.pb[GB_TRA_PB + rc];
 #pragma unroll
-        for (int cc = 0; cc < 8; ++cc) z += c.pb[GB_TRA_PW + rc * 8 + cc] * __shfl(y, (L.lane & ~7) + cc);
+        for (int cc = 0; cc < 8; ++cc) z += c.pb[GB_TRA_PW + rc * 8 + cc] * __shfl(y, (L.lane & 32) + cc * 4 + part);
         const float gate = 1.0f / (1.0f + __expf(-z));
-        c.sG[rt * 16 + slot] = gate;
-        c.sG[rt * 16 + c.ib[8 + rc]] = 1.0f;
+        if (part == 0) {
+            c.sG[rt * 16 + slot] = gate;
+            c.sG[rt * 16 + c.ib[8 + rc]] = 1.0f;
+        }
     }
     wg_barrier();
     STAMP(SS, 7)
-    if (reducer && rt >= c.nfr - 2) c.sEHk[((c.tabs + rt) & 1) * 8 + rc] = e_keep;
+    if (reducer && part == 0 && rt >= c.nfr - 2) c.sEHk[((c.tabs + rt) & 1) * 8 + rc] = e_keep;
 #pragma unroll
     for (int i = 0; i < TPW; ++i) x[i] = x[i] * ld4(c.sG + tt.tl[i] * 16 + 4 * g);
 }
@@ -520,9 +506,15 @@ __device__ __forceinline__ void rings_store(const float* sH, const float* sEH, f
     if (tid < 48) st_e[tid] = sEH[tid];
 }
 
-// scatter the 4 slots of a lane into a 16-float record (slot order of the consumer)
-__device__ __forceinline__ void st_perm(float* rec, const int* idx4, f32x4 v) {
-    rec[idx4[0]] = v[0]; rec[idx4[1]] = v[1]; rec[idx4[2]] = v[2]; rec[idx4[3]] = v[3];
+// scatter the 4 slots of a lane into a 16-float record (slot order of the consumer); base is
+// wave-uniform, the record offset is 32-bit and opaque (recomputed per use instead of being hoisted
+// out of the chunk loop as four 64-bit addresses and spilled)
+__device__ __forceinline__ void st_perm(float* base, unsigned rec_off, const int* idx4, f32x4 v) {
+    asm volatile("" : "+v"(rec_off));
+    base[rec_off + (unsigned)idx4[0]] = v[0];
+    base[rec_off + (unsigned)idx4[1]] = v[1];
+    base[rec_off + (unsigned)idx4[2]] = v[2];
+    base[rec_off + (unsigned)idx4[3]] = v[3];
 }
 
 // =============================================================================== encoder
@@ -535,16 +527,15 @@ constexpr int ENC_LDS_I = ENC_LDS_P + ENC_SIZE;
 constexpr int ENC_LDS_H = ENC_LDS_I + P_INTS;
 constexpr int ENC_LDS_EH = ENC_LDS_H + 3 * 2 * 35 * 16;
 constexpr int ENC_LDS_G = ENC_LDS_EH + 48;
-constexpr int ENC_LDS_PART = ENC_LDS_G + TC * 16;
-constexpr int ENC_LDS_A = ENC_LDS_PART + PART_FLOATS;      // staged spec, then E0, then W
+constexpr int ENC_LDS_A = ENC_LDS_G + TC * 16;             // staged spec, then E0, then W + S
 constexpr int ENC_E0_ROW = 69;
 constexpr int ENC_LDS_B = ENC_LDS_A + TC * ENC_E0_ROW * 16;  // EB + F0
 constexpr int EB_ROW = 131, F0_ROW = 136;
 constexpr int ENC_LDS_FLOATS = ENC_LDS_B + 3 * TC * EB_ROW + 3 * TC * F0_ROW;
 static_assert(TC * NBINS * 2 <= TC * ENC_E0_ROW * 16, "staged spec chunk must fit in the E0 region");
 static_assert(ENC_LDS_FLOATS * 4 <= 160 * 1024, "encoder LDS budget");
-static_assert(ENC_LDS_I % 4 == 0 && ENC_LDS_H % 4 == 0 && ENC_LDS_G % 4 == 0 && ENC_LDS_A % 4 == 0 &&
-              ENC_LDS_PART % 4 == 0, "16B carve");
+static_assert(TC * 35 * 16 + TC * 33 * 16 <= TC * ENC_E0_ROW * 16, "W + S must fit in the E0 region");
+static_assert(ENC_LDS_I % 4 == 0 && ENC_LDS_H % 4 == 0 && ENC_LDS_G % 4 == 0 && ENC_LDS_A % 4 == 0, "16B carve");
 
 __global__ __launch_bounds__(NTHR) void k_encoder(const float* __restrict__ spec, long sb, long sf, long st, int T,
                                                  const float* __restrict__ PF, const int* __restrict__ PI,
@@ -559,10 +550,10 @@ __global__ __launch_bounds__(NTHR) void k_encoder(const float* __restrict__ spec
     float* sH = smem + ENC_LDS_H;
     float* sEH = smem + ENC_LDS_EH;
     float* sG = smem + ENC_LDS_G;
-    float* sPart = smem + ENC_LDS_PART;
     float* sSpec = smem + ENC_LDS_A;     // [tl][257][2]
     float* sE0 = smem + ENC_LDS_A;
     float* sW = smem + ENC_LDS_A;
+    float* sS = sW + TC * 35 * 16;
     float* sEB = smem + ENC_LDS_B;
     float* sF0 = sEB + 3 * TC * EB_ROW;
     const Lane L = lane_info();
@@ -687,7 +678,7 @@ __global__ __launch_bounds__(NTHR) void k_encoder(const float* __restrict__ spec
                     for (int q = 0; q < 4; ++q) acc = mfma(A[q], tap[q], acc);
                 }
                 x[i] = prelu4(acc, a);
-                if (tt.pp[i] < nfr * 33) st_perm(en1 + (long)t0 * 528 + (unsigned)(tt.pp[i] * 16), ix, x[i]);
+                if (tt.pp(i) < nfr * 33) st_perm(en1 + (long)t0 * 528, (unsigned)(tt.pp(i) * 16), ix, x[i]);
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
@@ -701,7 +692,7 @@ __global__ __launch_bounds__(NTHR) void k_encoder(const float* __restrict__ spec
             c.pb = sP + E_BLK + k * GB_SIZE;
             c.gA = nullptr;
             c.ib = sI + I_ENC_BLK + k * 16;
-            c.sW = sW; c.sHk = sH + k * (2 * 35 * 16); c.sPart = sPart; c.sG = sG; c.sEHk = sEH + k * 16;
+            c.sW = sW; c.sHk = sH + k * (2 * 35 * 16); c.sS = sS; c.sG = sG; c.sEHk = sEH + k * 16;
             c.nfr = nfr; c.tabs = tbase + t0;
             gtconv_block<false>(x, tt, c, L STAMP_ARG);
             if (k < 2) {
@@ -709,11 +700,11 @@ __global__ __launch_bounds__(NTHR) void k_encoder(const float* __restrict__ spec
                 const int* ix = sI + I_ENST + (k + 1) * 16 + 4 * g;
 #pragma unroll
                 for (int i = 0; i < TPW; ++i)
-                    if (tt.pp[i] < nfr * 33) st_perm(dst + (long)t0 * 528 + (unsigned)(tt.pp[i] * 16), ix, x[i]);
+                    if (tt.pp(i) < nfr * 33) st_perm(dst + (long)t0 * 528, (unsigned)(tt.pp(i) * 16), ix, x[i]);
             } else {
 #pragma unroll
                 for (int i = 0; i < TPW; ++i)
-                    if (tt.pp[i] < nfr * 33) st4(en4 + (long)t0 * 528 + (unsigned)(tt.pp[i] * 16 + 4 * g), x[i]);
+                    if (tt.pp(i) < nfr * 33) st4(en4 + (long)t0 * 528 + (unsigned)(tt.pp(i) * 16 + 4 * g), x[i]);
             }
             STAMP(SS, 8)
         }
@@ -969,14 +960,13 @@ constexpr int DEC_LDS_I = DEC_LDS_P + DEC_SIZE;
 constexpr int DEC_LDS_H = DEC_LDS_I + P_INTS;
 constexpr int DEC_LDS_EH = DEC_LDS_H + 3 * 2 * 35 * 16;
 constexpr int DEC_LDS_G = DEC_LDS_EH + 48;
-constexpr int DEC_LDS_PART = DEC_LDS_G + TC * 16;
-constexpr int DEC_LDS_A = DEC_LDS_PART + PART_FLOATS;             // W, later Z
-constexpr int DEC_LDS_M = DEC_LDS_A + TC * F1 * 16;
+constexpr int DEC_LDS_A = DEC_LDS_G + TC * 16;                    // W + S, later Z
+constexpr int DEC_LDS_ASZ = TC * 35 * 16 + TC * 33 * 16;
+constexpr int DEC_LDS_M = DEC_LDS_A + DEC_LDS_ASZ;
 constexpr int DEC_LDS_FLOATS = DEC_LDS_M + 2 * TC * F0;
-static_assert(TC * 35 * 16 <= TC * F1 * 16, "W must fit in the Z region");
+static_assert(TC * F1 * 16 <= DEC_LDS_ASZ, "Z must fit in the W + S region");
 static_assert(DEC_LDS_FLOATS * 4 <= 160 * 1024, "decoder LDS budget");
-static_assert(DEC_SIZE % 4 == 0 && DEC_LDS_I % 4 == 0 && DEC_LDS_H % 4 == 0 && DEC_LDS_A % 4 == 0 &&
-              DEC_LDS_PART % 4 == 0, "16B carve");
+static_assert(DEC_SIZE % 4 == 0 && DEC_LDS_I % 4 == 0 && DEC_LDS_H % 4 == 0 && DEC_LDS_A % 4 == 0, "16B carve");
 
 // DBG = true only for the stage-tap variant used by the parity tests (writes de0..de4 to `dbg`).
 template <bool DBG>
@@ -995,8 +985,8 @@ __global__ __launch_bounds__(NTHR) void k_decoder(const float* __restrict__ xg, 
     float* sH = smem + DEC_LDS_H;
     float* sEH = smem + DEC_LDS_EH;
     float* sG = smem + DEC_LDS_G;
-    float* sPart = smem + DEC_LDS_PART;
     float* sW = smem + DEC_LDS_A;
+    float* sS = sW + TC * 35 * 16;
     float* sZ = smem + DEC_LDS_A;
     float* sM = smem + DEC_LDS_M;
     const Lane L = lane_info();
@@ -1027,7 +1017,7 @@ __global__ __launch_bounds__(NTHR) void k_decoder(const float* __restrict__ xg, 
     {
         const int np0 = min(TC, T) * 33;
 #pragma unroll
-        for (int i = 0; i < TPW; ++i) xn[i] = ld4(xg + (unsigned)((tt.pp[i] < np0 ? tt.pp[i] : 0) * 16 + 4 * g));
+        for (int i = 0; i < TPW; ++i) xn[i] = ld4(xg + (unsigned)((tt.pp(i) < np0 ? tt.pp(i) : 0) * 16 + 4 * g));
     }
     (void)en4;
     for (int t0 = 0; t0 < T; t0 += TC) {
@@ -1047,18 +1037,18 @@ __global__ __launch_bounds__(NTHR) void k_decoder(const float* __restrict__ xg, 
             sk += (long)t0 * 528;
 #pragma unroll
             for (int i = 0; i < TPW; ++i)
-                skv[i] = ld4(sk + (unsigned)((tt.pp[i] < npos ? tt.pp[i] : 0) * 16 + 4 * g));
+                skv[i] = ld4(sk + (unsigned)((tt.pp(i) < npos ? tt.pp(i) : 0) * 16 + 4 * g));
             BlockCtx c;
             c.pb = sP + D_BLK + j * GBD_SIZE;
             c.gA = c.pb + GB_DN_A;
             c.ib = sI + I_DEC_BLK + j * 16;
-            c.sW = sW; c.sHk = sH + j * (2 * 35 * 16); c.sPart = sPart; c.sG = sG; c.sEHk = sEH + j * 16;
+            c.sW = sW; c.sHk = sH + j * (2 * 35 * 16); c.sS = sS; c.sG = sG; c.sEHk = sEH + j * 16;
             c.nfr = nfr; c.tabs = tbase + t0;
             gtconv_block<true>(x, tt, c, L STAMP_ARG);
             if (DBG)
 #pragma unroll
                 for (int i = 0; i < TPW; ++i)
-                    if (tt.pp[i] < npos) st4(dbg + ((long)j * nbt + ob + t0) * 528 + tt.pp[i] * 16 + 4 * g, x[i]);
+                    if (tt.pp(i) < npos) st4(dbg + ((long)j * nbt + ob + t0) * 528 + tt.pp(i) * 16 + 4 * g, x[i]);
 #pragma unroll
             for (int i = 0; i < TPW; ++i) x[i] += skv[i];
             STAMP(SS, 8)
@@ -1071,7 +1061,7 @@ __global__ __launch_bounds__(NTHR) void k_decoder(const float* __restrict__ xg, 
             st4(sW + o35(tt, i, g), x[i]);
             // en0 record of output bin 2f (even) and 2f+1 (odd; for f = 32 the clamped record is unused)
             const float* en0c = en0 + (long)t0 * (F1 * 16);
-            const unsigned o0 = (unsigned)((tt.pp[i] < npos ? tt.tl[i] * F1 + 2 * tt.ff[i] : 0) * 16 + 4 * g);
+            const unsigned o0 = (unsigned)((tt.pp(i) < npos ? tt.tl[i] * F1 + 2 * tt.ff[i] : 0) * 16 + 4 * g);
             s0e[i] = ld4(en0c + o0);
             s0o[i] = ld4(en0c + o0 + (tt.ff[i] < 32 ? 16u : 0u));
         }
@@ -1080,7 +1070,7 @@ __global__ __launch_bounds__(NTHR) void k_decoder(const float* __restrict__ xg, 
             const int npn = min(TC, T - t0 - TC) * 33;
             const float* xgn = xg + (long)(t0 + TC) * 528;
 #pragma unroll
-            for (int i = 0; i < TPW; ++i) xn[i] = ld4(xgn + (unsigned)((tt.pp[i] < npn ? tt.pp[i] : 0) * 16 + 4 * g));
+            for (int i = 0; i < TPW; ++i) xn[i] = ld4(xgn + (unsigned)((tt.pp(i) < npn ? tt.pp(i) : 0) * 16 + 4 * g));
         }
         wg_barrier();
         STAMP(SS, 10)
@@ -1120,7 +1110,7 @@ __global__ __launch_bounds__(NTHR) void k_decoder(const float* __restrict__ xg, 
                 }
                 ae = prelu4(ae, a);
                 ao = prelu4(ao, a);
-                if (DBG && tt.pp[i] < npos) {
+                if (DBG && tt.pp(i) < npos) {
                     float* d3 = dbg + 3 * nbt * 528 + ((ob + t0 + tt.tl[i]) * F1) * 16 + 4 * g;
                     st4(d3 + (2 * tt.ff[i]) * 16, ae);
                     if (tt.ff[i] < 32) st4(d3 + (2 * tt.ff[i] + 1) * 16, ao);
