@@ -380,11 +380,6 @@ __device__ __forceinline__ void gtconv_block(f32x4 (&x)[TPW], const Tiles& tt, c
         const f32x4 A2 = ld4(c.pb + GB_PC2_A + n * 16 + 4 * g), B2 = ld4(c.pb + GB_PC2_B + 4 * g);
         const f32x4 keep = ld4(c.pb + GB_KEEP + 4 * g);
         const long ringoff = c.sHk - c.sW;   // both live in the same LDS array
-        f32x4 wdw[DENSE ? 1 : 9];
-        if (!DENSE) {
-#pragma unroll
-            for (int q = 0; q < 9; ++q) wdw[q] = ld4(c.pb + GB_DW_W + q * 16 + 4 * g);
-        }
 #pragma unroll
         for (int i = 0; i < TPW; ++i) {
             // row bases for frames t, t-1, t-2: inside the chunk image, or the ring for earlier frames
@@ -413,7 +408,8 @@ __device__ __forceinline__ void gtconv_block(f32x4 (&x)[TPW], const Tiles& tt, c
                             for (int s = 0; s < 4; ++s) acc = mfma(A[s], tap[s], acc);
                         }
                     } else {
-                        acc += wdw[kt * 3 + kf] * tap;
+                        // depthwise weights are re-read per tap (36 registers would be pinned otherwise)
+                        acc += ld4(c.pb + GB_DW_W + (kt * 3 + kf) * 16 + 4 * g) * tap;
                     }
                 }
             }
@@ -453,7 +449,7 @@ __device__ __forceinline__ void gtconv_block(f32x4 (&x)[TPW], const Tiles& tt, c
             for (int f = 0; f < cnt; ++f) sum += sp[f * 16];
             sum += dpp_ror<0xB1>(sum);   // quad_perm [1,0,3,2]
             sum += dpp_ror<0x4E>(sum);   // quad_perm [2,3,0,1]
-            e[j] = tau >= 0 ? sum / 33.0f : c.sEHk[((c.tabs + tau) & 1) * 8 + rc];
+            e[j] = tau >= 0 ? sum * (1.0f / 33.0f) : c.sEHk[((c.tabs + tau) & 1) * 8 + rc];
         }
         e_keep = e[2];
         const float y = c.pb[GB_TRA_DB + rc] + c.pb[GB_TRA_DW + rc * 3] * e[0] + c.pb[GB_TRA_DW + rc * 3 + 1] * e[1] +
@@ -461,7 +457,7 @@ __device__ __forceinline__ void gtconv_block(f32x4 (&x)[TPW], const Tiles& tt, c
         float z = c.pb[GB_TRA_PB + rc];
 #pragma unroll
         for (int cc = 0; cc < 8; ++cc) z += c.pb[GB_TRA_PW + rc * 8 + cc] * __shfl(y, (L.lane & 32) + cc * 4 + part);
-        const float gate = 1.0f / (1.0f + __expf(-z));
+        const float gate = __frcp_rn(1.0f + __expf(-z));
         if (part == 0) {
             c.sG[rt * 16 + slot] = gate;
             c.sG[rt * 16 + c.ib[8 + rc]] = 1.0f;
@@ -506,15 +502,21 @@ __device__ __forceinline__ void rings_store(const float* sH, const float* sEH, f
     if (tid < 48) st_e[tid] = sEH[tid];
 }
 
-// scatter the 4 slots of a lane into a 16-float record (slot order of the consumer); base is
-// wave-uniform, the record offset is 32-bit and opaque (recomputed per use instead of being hoisted
-// out of the chunk loop as four 64-bit addresses and spilled)
-__device__ __forceinline__ void st_perm(float* base, unsigned rec_off, const int* idx4, f32x4 v) {
-    asm volatile("" : "+v"(rec_off));
-    base[rec_off + (unsigned)idx4[0]] = v[0];
-    base[rec_off + (unsigned)idx4[1]] = v[1];
-    base[rec_off + (unsigned)idx4[2]] = v[2];
-    base[rec_off + (unsigned)idx4[3]] = v[3];
+// Store a tile in the slot order of its consumer.  The permutation crosses lane groups, so it goes
+// through LDS: each lane scatters its 4 slots into the position's 64-byte record of a wave-private
+// scratch image (LDS handles 4-byte scatters at full rate), reads the record back as its own 16-byte
+// quarter and issues ONE coalesced 16-byte global store.  (Scattering 4-byte global stores instead
+// writes 64 partial lines per instruction and was ~3 k cycles per block.)  The four lanes of a
+// position belong to one wave, LDS operations of a wave complete in order, so no barrier is needed.
+__device__ __forceinline__ f32x4 permute_via_lds(float* scratch_rec, const int* idx4, int g, f32x4 v) {
+    scratch_rec[idx4[0]] = v[0];
+    scratch_rec[idx4[1]] = v[1];
+    scratch_rec[idx4[2]] = v[2];
+    scratch_rec[idx4[3]] = v[3];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    return ld4(scratch_rec + 4 * g);
 }
 
 // =============================================================================== encoder
@@ -532,7 +534,7 @@ constexpr int ENC_E0_ROW = 69;
 constexpr int ENC_LDS_B = ENC_LDS_A + TC * ENC_E0_ROW * 16;  // EB + F0
 constexpr int EB_ROW = 131, F0_ROW = 136;
 constexpr int ENC_LDS_FLOATS = ENC_LDS_B + 3 * TC * EB_ROW + 3 * TC * F0_ROW;
-static_assert(TC * NBINS * 2 <= TC * ENC_E0_ROW * 16, "staged spec chunk must fit in the E0 region");
+static_assert(3 * TC * NBINS <= TC * ENC_E0_ROW * 16, "staged [mag,re,im] chunk must fit in the E0 region");
 static_assert(ENC_LDS_FLOATS * 4 <= 160 * 1024, "encoder LDS budget");
 static_assert(TC * 35 * 16 + TC * 33 * 16 <= TC * ENC_E0_ROW * 16, "W + S must fit in the E0 region");
 static_assert(ENC_LDS_I % 4 == 0 && ENC_LDS_H % 4 == 0 && ENC_LDS_G % 4 == 0 && ENC_LDS_A % 4 == 0, "16B carve");
@@ -550,7 +552,7 @@ __global__ __launch_bounds__(NTHR) void k_encoder(const float* __restrict__ spec
     float* sH = smem + ENC_LDS_H;
     float* sEH = smem + ENC_LDS_EH;
     float* sG = smem + ENC_LDS_G;
-    float* sSpec = smem + ENC_LDS_A;     // [tl][257][2]
+    float* sSpec = smem + ENC_LDS_A;     // [3: mag, re, im][tl][257]
     float* sE0 = smem + ENC_LDS_A;
     float* sW = smem + ENC_LDS_A;
     float* sS = sW + TC * 35 * 16;
@@ -576,42 +578,72 @@ __global__ __launch_bounds__(NTHR) void k_encoder(const float* __restrict__ spec
     const bool t_fast = st < sf;  // reference layout (B,257,T,2): consecutive frames are adjacent
     STAMP(SS, 0)
 
+    // Spectrogram items of this thread: item q is element idx = tid + q*NTHR of the chunk, idx -> (tl, f)
+    // with f fastest for the frame-major layout (consecutive bins adjacent) and tl fastest for the
+    // reference layout (consecutive frames adjacent).  The chunk is fetched one chunk ahead into
+    // registers, so its HBM latency is hidden behind the previous chunk's compute.
+    constexpr int SPEC_ITEMS = (TC * NBINS + NTHR - 1) / NTHR;
+    float2 spn[SPEC_ITEMS];
+    auto spec_fetch = [&](int t0f) {
+        const int nf = min(TC, T - t0f);
+#pragma unroll
+        for (int q = 0; q < SPEC_ITEMS; ++q) {
+            int idx = tid + q * NTHR;
+            asm volatile("" : "+v"(idx));
+            if (idx >= nf * NBINS) idx = 0;              // clamped: no select behind the load
+            int tl, f;
+            if (t_fast) { tl = idx % nf; f = idx / nf; } else { f = idx % NBINS; tl = idx / NBINS; }
+            spn[q] = *reinterpret_cast<const float2*>(spec + (long)f * sf + (long)(t0f + tl) * st);
+        }
+    };
+    spec_fetch(0);
+
     for (int t0 = 0; t0 < T; t0 += TC) {
         const int nfr = min(TC, T - t0);
         // the cooperative loops index from an opaque copy of tid so that their per-item offsets are
         // recomputed per chunk instead of being hoisted, spilled and reloaded (scratch shares vmcnt)
         int tv = tid;
         asm volatile("" : "+v"(tv));
-        // ---- A0: stage the spectrogram chunk in LDS with independent, coalesced 8-byte loads --------
-        for (int idx = tv; idx < nfr * NBINS; idx += NTHR) {
-            int tl, f;
-            if (t_fast) { tl = idx % nfr; f = idx / nfr; } else { f = idx % NBINS; tl = idx / NBINS; }
-            *reinterpret_cast<float2*>(sSpec + (tl * NBINS + f) * 2) =
-                *reinterpret_cast<const float2*>(spec + (long)f * sf + (long)(t0 + tl) * st);
+        // the EB/F0 region doubles as the scratch of the en1 store (phase D), so the zero pad entries
+        // (EB columns 0 and 130, F0 columns 0,1 and 131..135) are re-zeroed every chunk
+        if (tv < 3 * TC * 9) {
+            const int row = tv / 9, e = tv - row * 9;
+            float z = 0.f;
+            asm volatile("" : "+v"(z));
+            if (e < 2) sEB[row * EB_ROW + e * 130] = z;
+            else sF0[row * F0_ROW + (e < 4 ? e - 2 : 127 + e)] = z;
         }
-        wg_barrier();
-        // ---- A: features + ERB.bm: EB[c][tl][1 + j]; pass-through bins and bands in separate loops so
-        //      that the lanes of a wave carry similar work ------------------------------------------
-        for (int idx = tv; idx < nfr * ERB_LOW; idx += NTHR) {
-            const int j = idx % ERB_LOW, tl = idx / ERB_LOW;
-            const float2 v = *reinterpret_cast<const float2*>(sSpec + (tl * NBINS + j) * 2);
-            sEB[(0 * TC + tl) * EB_ROW + 1 + j] = sqrtf(v.x * v.x + v.y * v.y + 1e-12f);
-            sEB[(1 * TC + tl) * EB_ROW + 1 + j] = v.x;
-            sEB[(2 * TC + tl) * EB_ROW + 1 + j] = v.y;
-        }
-        for (int idx = tv; idx < nfr * ERB_BANDS; idx += NTHR) {
-            const int band = idx % ERB_BANDS, tl = idx / ERB_BANDS;
-            const int lo = sI[I_ERB_LO + band], cnt = sI[I_ERB_N + band];
-            const float* sp = sSpec + (tl * NBINS + ERB_LOW + lo) * 2;
-            float v0 = 0.f, v1 = 0.f, v2 = 0.f;
-            for (int i = 0; i < cnt; ++i) {
-                const float2 v = *reinterpret_cast<const float2*>(sp + 2 * i);
-                const float w = sP[E_ERB_W + band * ERB_MAXBW + i];
-                v0 += w * sqrtf(v.x * v.x + v.y * v.y + 1e-12f); v1 += w * v.x; v2 += w * v.y;
+        // ---- A0: stage [mag, re, im] of the chunk in LDS (structure of arrays, [c][tl][257]); the
+        //      magnitude (models/gtcrn_micro.py:514) is computed once per bin here -----------------------
+#pragma unroll
+        for (int q = 0; q < SPEC_ITEMS; ++q) {
+            int idx = tv + q * NTHR;
+            if (idx < nfr * NBINS) {
+                int tl, f;
+                if (t_fast) { tl = idx % nfr; f = idx / nfr; } else { f = idx % NBINS; tl = idx / NBINS; }
+                const float2 v = spn[q];
+                float* d = sSpec + tl * NBINS + f;
+                d[0] = __builtin_amdgcn_sqrtf(v.x * v.x + v.y * v.y + 1e-12f);
+                d[TC * NBINS] = v.x;
+                d[2 * TC * NBINS] = v.y;
             }
-            sEB[(0 * TC + tl) * EB_ROW + 1 + ERB_LOW + band] = v0;
-            sEB[(1 * TC + tl) * EB_ROW + 1 + ERB_LOW + band] = v1;
-            sEB[(2 * TC + tl) * EB_ROW + 1 + ERB_LOW + band] = v2;
+        }
+        if (t0 + TC < T) spec_fetch(t0 + TC);
+        wg_barrier();
+        // ---- A: ERB.bm: EB[c][tl][1 + j]; pass-through bins and bands in separate loops so that the
+        //      lanes of a wave carry similar work ------------------------------------------------------
+        for (int idx = tv; idx < 3 * nfr * ERB_LOW; idx += NTHR) {
+            const int j = idx % ERB_LOW, ct = idx / ERB_LOW, tl = ct % nfr, c = ct / nfr;
+            sEB[(c * TC + tl) * EB_ROW + 1 + j] = sSpec[(c * TC + tl) * NBINS + j];
+        }
+        for (int idx = tv; idx < 3 * nfr * ERB_BANDS; idx += NTHR) {
+            const int band = idx % ERB_BANDS, ct = idx / ERB_BANDS, tl = ct % nfr, c = ct / nfr;
+            const int lo = sI[I_ERB_LO + band], cnt = sI[I_ERB_N + band];
+            const float* sp = sSpec + (c * TC + tl) * NBINS + ERB_LOW + lo;
+            const float* w = sP + E_ERB_W + band * ERB_MAXBW;
+            float acc = 0.f;
+            for (int i = 0; i < cnt; ++i) acc += w[i] * sp[i];
+            sEB[(c * TC + tl) * EB_ROW + 1 + ERB_LOW + band] = acc;
         }
         wg_barrier();
         STAMP(SS, 1)
@@ -678,7 +710,10 @@ __global__ __launch_bounds__(NTHR) void k_encoder(const float* __restrict__ spec
                     for (int q = 0; q < 4; ++q) acc = mfma(A[q], tap[q], acc);
                 }
                 x[i] = prelu4(acc, a);
-                if (tt.pp(i) < nfr * 33) st_perm(en1 + (long)t0 * 528, (unsigned)(tt.pp(i) * 16), ix, x[i]);
+                {   // en1 in the slot order of its decoder consumer; scratch: this tile's records of F0/EB (dead)
+                    const f32x4 y = permute_via_lds(sEB + tt.pp(i) * 16, ix, g, x[i]);
+                    if (tt.pp(i) < nfr * 33) st4(en1 + (long)t0 * 528 + (unsigned)(tt.pp(i) * 16 + 4 * g), y);
+                }
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
@@ -699,8 +734,10 @@ __global__ __launch_bounds__(NTHR) void k_encoder(const float* __restrict__ spec
                 float* dst = k == 0 ? en2 : en3;
                 const int* ix = sI + I_ENST + (k + 1) * 16 + 4 * g;
 #pragma unroll
-                for (int i = 0; i < TPW; ++i)
-                    if (tt.pp(i) < nfr * 33) st_perm(dst + (long)t0 * 528, (unsigned)(tt.pp(i) * 16), ix, x[i]);
+                for (int i = 0; i < TPW; ++i) {   // scratch: the tile's own v^2 records (dead after the gate barrier)
+                    const f32x4 y = permute_via_lds(sS + tt.pp(i) * 16, ix, g, x[i]);
+                    if (tt.pp(i) < nfr * 33) st4(dst + (long)t0 * 528 + (unsigned)(tt.pp(i) * 16 + 4 * g), y);
+                }
             } else {
 #pragma unroll
                 for (int i = 0; i < TPW; ++i)
@@ -962,9 +999,12 @@ constexpr int DEC_LDS_EH = DEC_LDS_H + 3 * 2 * 35 * 16;
 constexpr int DEC_LDS_G = DEC_LDS_EH + 48;
 constexpr int DEC_LDS_A = DEC_LDS_G + TC * 16;                    // W + S, later Z
 constexpr int DEC_LDS_ASZ = TC * 35 * 16 + TC * 33 * 16;
-constexpr int DEC_LDS_M = DEC_LDS_A + DEC_LDS_ASZ;
-constexpr int DEC_LDS_FLOATS = DEC_LDS_M + 2 * TC * F0;
-static_assert(TC * F1 * 16 <= DEC_LDS_ASZ, "Z must fit in the W + S region");
+constexpr int DEC_Z_ROW = F1 + 2;                                 // Z rows carry a zero record at both ends
+constexpr int DEC_LDS_M = DEC_LDS_A + DEC_LDS_ASZ;                // mask m [2][TC][129] (+4: the 2-tap read of the last bin)
+constexpr int DEC_LDS_BS = DEC_LDS_M + 2 * TC * F0 + 4;           // per-bin ERB.bs table {first index, w0, w1, -}
+constexpr int DEC_LDS_FLOATS = DEC_LDS_BS + NBINS * 4;
+static_assert(TC * DEC_Z_ROW * 16 <= DEC_LDS_ASZ, "Z must fit in the W + S region");
+static_assert(DEC_LDS_M % 4 == 0 && DEC_LDS_BS % 4 == 0, "16B carve");
 static_assert(DEC_LDS_FLOATS * 4 <= 160 * 1024, "decoder LDS budget");
 static_assert(DEC_SIZE % 4 == 0 && DEC_LDS_I % 4 == 0 && DEC_LDS_H % 4 == 0 && DEC_LDS_A % 4 == 0, "16B carve");
 
@@ -989,11 +1029,27 @@ __global__ __launch_bounds__(NTHR) void k_decoder(const float* __restrict__ xg, 
     float* sS = sW + TC * 35 * 16;
     float* sZ = smem + DEC_LDS_A;
     float* sM = smem + DEC_LDS_M;
+    float* sBS = smem + DEC_LDS_BS;
     const Lane L = lane_info();
     const int tid = L.tid, n = L.n, g = L.g;
     const int b = blockIdx.x;
     for (int i = tid; i < DEC_SIZE; i += NTHR) sP[i] = PF[P_DEC + i];
     for (int i = tid; i < P_INTS; i += NTHR) sI[i] = PI[i];
+    // ERB.bs (models/gtcrn_micro.py:69-73) as a uniform 2-tap gather per output bin: the 65 low bins
+    // pass through (weight 1), the others combine at most two neighbouring ERB bands
+    for (int f = tid; f < NBINS; f += NTHR) {
+        f32x4 e = {0.f, 1.f, 0.f, 0.f};
+        int i0 = f;
+        if (f >= ERB_LOW) {
+            const int i = f - ERB_LOW, cnt = PI[I_BS_N + i];
+            i0 = ERB_LOW + PI[I_BS_LO + i];
+            e[1] = cnt > 0 ? PF[P_DEC + D_BS_W + i * ERB_MAXBS] : 0.f;
+            e[2] = cnt > 1 ? PF[P_DEC + D_BS_W + i * ERB_MAXBS + 1] : 0.f;
+        }
+        e[0] = __int_as_float(i0);
+        st4(sBS + f * 4, e);
+    }
+    if (tid < 4) sM[2 * TC * F0 + tid] = 0.f;
     float* stb = state ? state + (long)b * ST_FLOATS : nullptr;
     const int tbase = stb ? reinterpret_cast<const int*>(stb)[0] : 0;
     rings_load(sH, sEH, stb ? stb + ST_DEC_H : nullptr, stb ? stb + ST_DEC_E : nullptr, tid);
@@ -1134,8 +1190,17 @@ __global__ __launch_bounds__(NTHR) void k_decoder(const float* __restrict__ xg, 
         STAMP(SS, 11)
 #pragma unroll
         for (int i = 0; i < TPW; ++i) {
-            st4(sZ + pl(tt.tl[i] * F1 + 2 * tt.ff[i], g), ze[i]);
-            if (tt.ff[i] < 32) st4(sZ + pl(tt.tl[i] * F1 + 2 * tt.ff[i] + 1, g), zo[i]);
+            st4(sZ + pl(tt.tl[i] * DEC_Z_ROW + 1 + 2 * tt.ff[i], g), ze[i]);
+            if (tt.ff[i] < 32) st4(sZ + pl(tt.tl[i] * DEC_Z_ROW + 2 + 2 * tt.ff[i], g), zo[i]);
+        }
+        {   // zero records at both ends of every Z row (region A held W / S)
+            int tz = tid;
+            asm volatile("" : "+v"(tz));
+            if (tz < TC * 2 * 4) {
+                float z = 0.f;
+                asm volatile("" : "+v"(z));
+                st4(sZ + pl((tz >> 3) * DEC_Z_ROW + ((tz >> 2) & 1) * (DEC_Z_ROW - 1), tz & 3), splat(z));
+            }
         }
         // the input spectrogram for the mask is fetched here so that its latency hides behind the
         // de_convs.4 gather below
@@ -1154,16 +1219,16 @@ __global__ __launch_bounds__(NTHR) void k_decoder(const float* __restrict__ xg, 
         }
         wg_barrier();
         STAMP(SS, 12)
-        // de_convs.4 gather + BN + Tanh: m[o][f''] = tanh(b[o] + sum_k z[(f''+2-k)/2][o*5+k])
+        // de_convs.4 gather + BN + Tanh: m[o][f''] = tanh(b[o] + sum_k z[(f''+2-k)/2][o*5+k]).  Branch free:
+        // even f'' = 2m takes k = 0,2,4 from rows m+1, m, m-1; odd f'' = 2m+1 takes k = 1,3 from rows m+1, m
+        // and a zero slot (rows 10..15 of the de_conv4 slot matrix are zero); the end records are zero.
         for (int idx = tid; idx < 2 * nfr * F0; idx += NTHR) {
             const int fq = idx % F0, ot = idx / F0, tq = ot % nfr, o = ot / nfr;
-            float s = sP[D_DE4_B + o];
-#pragma unroll
-            for (int k = 0; k < 5; ++k) {
-                const int num = fq + 2 - k;
-                if ((num & 1) == 0 && num >= 0 && num < 2 * F1) s += sZ[pls(tq * F1 + (num >> 1), o * 5 + k)];
-            }
-            sM[(o * TC + tq) * F0 + fq] = fast_tanh(s);
+            const int par = fq & 1, m = fq >> 1;
+            const float* zr = sZ + (tq * DEC_Z_ROW + 1 + m) * 16;
+            const float sum = sP[D_DE4_B + o] + zr[16 + o * 5 + par] + zr[o * 5 + 2 + par] +
+                              zr[-16 + (par ? 10 : o * 5 + 4)];
+            sM[(o * TC + tq) * F0 + fq] = fast_tanh(sum);
         }
         wg_barrier();
         STAMP(SS, 13)
@@ -1181,19 +1246,10 @@ __global__ __launch_bounds__(NTHR) void k_decoder(const float* __restrict__ xg, 
             if (idx < nfr * NBINS) {
                 int tq, f;
                 if (t_fast) { tq = idx % nfr; f = idx / nfr; } else { f = idx % NBINS; tq = idx / NBINS; }
-                float mr, mi;
-                if (f < ERB_LOW) {
-                    mr = sM[(0 * TC + tq) * F0 + f];
-                    mi = sM[(1 * TC + tq) * F0 + f];
-                } else {
-                    const int i = f - ERB_LOW, lo = sI[I_BS_LO + i], cnt = sI[I_BS_N + i];
-                    mr = 0.f; mi = 0.f;
-                    for (int r = 0; r < cnt; ++r) {
-                        const float w = sP[D_BS_W + i * ERB_MAXBS + r];
-                        mr += w * sM[(0 * TC + tq) * F0 + ERB_LOW + lo + r];
-                        mi += w * sM[(1 * TC + tq) * F0 + ERB_LOW + lo + r];
-                    }
-                }
+                const f32x4 tb = ld4(sBS + f * 4);
+                const float* m0 = sM + tq * F0 + __float_as_int(tb[0]);
+                const float mr = tb[1] * m0[0] + tb[2] * m0[1];
+                const float mi = tb[1] * m0[TC * F0] + tb[2] * m0[TC * F0 + 1];
                 const float re = spv[q].x, im = spv[q].y;
                 *reinterpret_cast<float2*>(out + (long)f * osf + (long)(t0 + tq) * ost) =
                     make_float2(re * mr - im * mi, im * mr + re * mi);
