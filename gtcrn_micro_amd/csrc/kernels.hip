@@ -897,72 +897,98 @@ __global__ __launch_bounds__(NTHR) void k_gtcn(const float* __restrict__ xin, fl
 // ---------------------------------------------------------------------------- GTCN, offline form
 // Same arithmetic, different ownership: wave w owns frequency bins 3w..3w+2 for ALL frames (11 waves x
 // 3 bins = 33), a tile = 16 consecutive frames of one bin (lane n <-> frame t0+n).  The TCN couples
-// positions only along time, so its taps are rotations inside the 16-lane DPP row of a tile:
-//   tap_s[n] = y1[n-s] for n >= s, else the previous chunk's y1[16+n-s]
-//            = row_ror:s of (n >= 16-s ? prev : cur)
-// The 2d frames of history live in registers (the previous chunk's y1 tile per block), so this form
-// uses no LDS for activations and NO barrier: waves run decoupled and overlap each other's MFMA and
-// VALU phases.  Used when there is no stream state (offline forward); the ring form above serves
-// streaming calls, where a chunk may hold a single frame.
-template <int S>
-__device__ __forceinline__ f32x4 tap_shift(const f32x4 cur, const f32x4 prev, int n) {
-    if (S == 16) return prev;
-    f32x4 r;
-#pragma unroll
-    for (int q = 0; q < 4; ++q) r[q] = dpp_ror<0x120 + (S & 15)>(n >= 16 - S ? prev[q] : cur[q]);
-    return r;
-}
+// positions only along time, so every tap of a wave's tile lies in that same wave's data: the y1
+// history is a WAVE-PRIVATE LDS image per block and bin, [32 frame rows][16 slots], row = frame mod 32
+// (the current chunk's 16 rows next to the previous chunk's).  A tap is one ds_read_b128 at
+// "own row - d" (mod 32); nothing is shared between waves, so the chunk loop has NO barrier and the
+// waves run decoupled.  (A register-only variant with DPP row rotations measured slower: a DPP
+// rotate costs ~10 issue cycles on gfx950.)  Used when there is no stream state (offline forward);
+// the ring form above serves streaming calls, where a chunk may hold a single frame.
+constexpr int GB_LDS_P = 0;
+constexpr int GB_LDS_C = GB_LDS_P + GTCN_SIZE;                 // current chunk's y1: [33 bins][16 frames][16]
+constexpr int GB_LDS_H = GB_LDS_C + 33 * 16 * 16;              // history: block k: [33 bins][2d rows][16]
+constexpr int GB_LDS_FLOATS = GB_LDS_H + 33 * 30 * 16;
+static_assert(GB_LDS_C % 4 == 0, "16B carve");
+static_assert(GB_LDS_FLOATS * 4 <= 160 * 1024, "band GTCN LDS budget");
 
+// cw: this wave's 3 tiles of the current-chunk image; hw: this wave's 3 bins of block D's history ring
+// (row = frame mod 2d); n = lane's frame inside the chunk; t0 is a multiple of 16 >= 2d, so
+// (t0 + n) mod 2d == n mod 2d.
 template <int D>
-__device__ __forceinline__ void tcn_block_band(f32x4 (&x)[TPW], f32x4 (&prev)[TPW], const float* pk, const Lane& L) {
+__device__ __forceinline__ void tcn_block_band(f32x4 (&x)[TPW], const float* pk, float* cw, float* hw, bool live,
+                                               const Lane& L) {
     const int n = L.n, g = L.g;
+    constexpr int M2D = 2 * D - 1, HR = 2 * D * 16;           // ring mask, floats per bin of the ring
     const float a1 = pk[TCN_SLOPE] - 1.0f, a2 = pk[TCN_SLOPE + 1] - 1.0f, a3 = pk[TCN_SLOPE + 2] - 1.0f;
-    f32x4 y1[TPW], acc[TPW];
+    f32x4 y1[TPW], acc[TPW], t1[TPW], t2[TPW];
+    const long h_minus_c = hw - cw;
+    // taps that lie before the chunk come from the ring; they do not depend on this block's y1
+    const int r1 = ((n - D) & M2D) * 16 + 4 * g, r2 = (n & M2D) * 16 + 4 * g;
+#pragma unroll
+    for (int i = 0; i < TPW; ++i) {
+        t1[i] = ld4(hw + i * HR + r1);
+        t2[i] = ld4(hw + i * HR + r2);
+    }
     {
         const f32x4 A = ld4(pk + TCN_A1 + n * 16 + 4 * g), Bv = ld4(pk + TCN_B1 + 4 * g);
 #pragma unroll
         for (int i = 0; i < TPW; ++i) acc[i] = Bv;
         mm16<TPW>(A, x, acc);
 #pragma unroll
-        for (int i = 0; i < TPW; ++i) y1[i] = prelu4(acc[i], a1);
+        for (int i = 0; i < TPW; ++i) {
+            y1[i] = prelu4(acc[i], a1);
+            st4(cw + i * 256 + n * 16 + 4 * g, y1[i]);
+        }
     }
+    // the in-chunk taps were written by lanes of this wave: LDS operations of a wave complete in order,
+    // only the compiler has to be kept from hoisting the reads above the writes
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     {
         const f32x4 w0 = ld4(pk + TCN_DW + 4 * g), w1 = ld4(pk + TCN_DW + 16 + 4 * g),
                     w2 = ld4(pk + TCN_DW + 32 + 4 * g), B2 = ld4(pk + TCN_B2 + 4 * g);
         const f32x4 A = ld4(pk + TCN_A3 + n * 16 + 4 * g), B3 = ld4(pk + TCN_B3 + 4 * g);
         f32x4 y2[TPW];
+        const int c1 = (n >= D ? n - D : n) * 16 + 4 * g, c2 = (n >= 2 * D ? n - 2 * D : n) * 16 + 4 * g;
 #pragma unroll
         for (int i = 0; i < TPW; ++i) {
-            const f32x4 t1 = tap_shift<D>(y1[i], prev[i], n);
-            const f32x4 t2 = tap_shift<2 * D>(y1[i], prev[i], n);
-            y2[i] = prelu4(B2 + w0 * t2 + w1 * t1 + w2 * y1[i], a2);
+            const f32x4 u1 = ld4(cw + i * 256 + c1), u2 = ld4(cw + i * 256 + c2);
+            const f32x4 p1 = n >= D ? u1 : t1[i], p2 = n >= 2 * D ? u2 : t2[i];
+            y2[i] = prelu4(B2 + w0 * p2 + w1 * p1 + w2 * y1[i], a2);
             acc[i] = B3 + x[i];
-            prev[i] = y1[i];
         }
         mm16<TPW>(A, y2, acc);
 #pragma unroll
         for (int i = 0; i < TPW; ++i) x[i] = prelu4(acc[i], a3);
     }
+    // ring update: the last 2d frames of the chunk (every live lane for the final, partial chunk is fine:
+    // later frames overwrite earlier ones of the same row only in program order of a single lane set)
+    if (live && n >= 16 - 2 * D) {
+#pragma unroll
+        for (int i = 0; i < TPW; ++i) st4(hw + i * HR + r2, y1[i]);
+    }
+    (void)h_minus_c;
 }
 
 __global__ __launch_bounds__(NTHR) void k_gtcn_band(const float* __restrict__ xin, float* __restrict__ xout,
                                                    const float* __restrict__ P, int T,
                                                    const float* __restrict__ addend) {
-    __shared__ __attribute__((aligned(16))) float sP[GTCN_SIZE];
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* sP = smem + GB_LDS_P;
+    float* sC = smem + GB_LDS_C;
+    float* sHh = smem + GB_LDS_H;
     const Lane L = lane_info();
     const int tid = L.tid, n = L.n, g = L.g;
     const int b = blockIdx.x;
     for (int i = tid; i < GTCN_SIZE; i += NTHR) sP[i] = P[i];
+    for (int i = tid; i < 33 * 30 * 4; i += NTHR) st4(sHh + i * 4, splat(0.f));   // zero history (frames < 0)
     __syncthreads();
     xin += (long)b * T * 528;
     xout += (long)b * T * 528;
     if (addend) addend += (long)b * T * 528;
-    f32x4 prev[4][TPW];
-#pragma unroll
-    for (int k = 0; k < 4; ++k)
-#pragma unroll
-        for (int i = 0; i < TPW; ++i) prev[k][i] = splat(0.f);
     const int f0 = L.wave * TPW;                         // first bin of this wave
+    float* cw = sC + f0 * 256;
     for (int t0 = 0; t0 < T; t0 += TC) {
         const bool live = t0 + n < T;
         const int tc = live ? t0 + n : T - 1;            // clamped frame: no select behind the loads
@@ -977,10 +1003,11 @@ __global__ __launch_bounds__(NTHR) void k_gtcn_band(const float* __restrict__ xi
         // blocks' fragments out of the chunk loop would need 128 registers and spill
         int po = 0;
         asm volatile("" : "+v"(po));
-        tcn_block_band<1>(x, prev[0], sP + po + 0 * TCN_SIZE, L);
-        tcn_block_band<2>(x, prev[1], sP + po + 1 * TCN_SIZE, L);
-        tcn_block_band<4>(x, prev[2], sP + po + 2 * TCN_SIZE, L);
-        tcn_block_band<8>(x, prev[3], sP + po + 3 * TCN_SIZE, L);
+        // block k's ring: [33 bins][2d rows][16], blocks back to back (2, 4, 8, 16 rows per bin)
+        tcn_block_band<1>(x, sP + po + 0 * TCN_SIZE, cw, sHh + 33 * 0 * 16 + f0 * 2 * 16, live, L);
+        tcn_block_band<2>(x, sP + po + 1 * TCN_SIZE, cw, sHh + 33 * 2 * 16 + f0 * 4 * 16, live, L);
+        tcn_block_band<4>(x, sP + po + 2 * TCN_SIZE, cw, sHh + 33 * 6 * 16 + f0 * 8 * 16, live, L);
+        tcn_block_band<8>(x, sP + po + 3 * TCN_SIZE, cw, sHh + 33 * 14 * 16 + f0 * 16 * 16, live, L);
 #pragma unroll
         for (int i = 0; i < TPW; ++i)
             if (live) st4(xout + (unsigned)((tc * 33 + f0 + i) * 16 + 4 * g), addend ? x[i] + ad[i] : x[i]);
@@ -1359,6 +1386,9 @@ int configure_kernels() {
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_gtcn), hipFuncAttributeMaxDynamicSharedMemorySize,
                             GT_LDS_FLOATS * 4);
     if (e != hipSuccess) return (int)e;
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_gtcn_band), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            GB_LDS_FLOATS * 4);
+    if (e != hipSuccess) return (int)e;
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_decoder<false>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, DEC_LDS_FLOATS * 4);
     if (e != hipSuccess) return (int)e;
@@ -1386,7 +1416,7 @@ int launch_gtcn(const float* xin, float* xout, const float* P, int B, int T, flo
 }
 
 int launch_gtcn_band(const float* xin, float* xout, const float* P, int B, int T, const float* addend, hipStream_t s) {
-    hipLaunchKernelGGL(k_gtcn_band, dim3(B), dim3(NTHR), 0, s, xin, xout, P, T, addend);
+    hipLaunchKernelGGL(k_gtcn_band, dim3(B), dim3(NTHR), GB_LDS_FLOATS * 4, s, xin, xout, P, T, addend);
     GT_LAUNCH_CHECK();
     return 0;
 }
