@@ -64,6 +64,7 @@ def lib():
     L.gtcrn_stream_step.argtypes = [_vp, _vp, _vp, cl, cl, cl, _vp, cl, cl, cl, ci, ci, _vp]
     L.gtcrn_stream_import.argtypes = [_vp, _vp, ci, _vp, _vp, ctypes.POINTER(_vp), _vp]
     L.gtcrn_stream_export.argtypes = [_vp, _vp, ci, _vp, _vp, ctypes.POINTER(_vp), _vp]
+    L.gtcrn_stream_conv2d.argtypes = [_vp, _vp, _vp, _vp, _vp, _vp] + [ci] * 12 + [_vp]
     L.gtcrn_pack_sizes.argtypes = [ctypes.POINTER(cl), ctypes.POINTER(cl)]
     L.gtcrn_pack_sizes.restype = None
     L.gtcrn_pack_params_host.argtypes = [_c_f32p, cl, _c_f32p, ctypes.POINTER(ci)]
@@ -187,6 +188,32 @@ def istft(spec, window):
     with torch.cuda.device(spec.device):
         _check(lib().gtcrn_istft(s4.data_ptr(), sb, sf, st, B, T, win.data_ptr(), out.data_ptr(), _stream_ptr()))
     return out[0] if squeeze else out
+
+
+def stream_conv2d(x, cache, weight, bias, kt, kf, dt=1, df=1, pad_f=0, groups=1, transposed=False):
+    """Causal streaming conv step on the GPU (see gtcrn_stream_conv2d): returns (y, new_cache)."""
+    import torch
+    _require_cuda_f32(x, "x")
+    x = x.contiguous()
+    B, Cin, T, F = x.shape
+    Cout = weight.shape[1] if transposed else weight.shape[0]
+    H = (kt - 1) * dt
+    if cache is None:
+        cache = torch.zeros((B, Cin, H, F), device=x.device, dtype=torch.float32)
+    cache = cache.contiguous()
+    Fout = F - 2 * pad_f + df * (kf - 1) if transposed else F + 2 * pad_f - df * (kf - 1)
+    y = torch.empty((B, Cout, T, Fout), device=x.device, dtype=torch.float32)
+    new_cache = torch.empty_like(cache)
+    w = weight.detach().to(device=x.device, dtype=torch.float32).contiguous()
+    bptr = bias.detach().to(device=x.device, dtype=torch.float32).contiguous() if bias is not None else None
+    with torch.cuda.device(x.device):
+        rc = lib().gtcrn_stream_conv2d(x.data_ptr(), cache.data_ptr(), w.data_ptr(),
+                                       bptr.data_ptr() if bptr is not None else None, y.data_ptr(),
+                                       new_cache.data_ptr(), B, Cin, Cout, T, F, kt, kf, dt, df, pad_f, groups,
+                                       int(bool(transposed)), _stream_ptr())
+    _check(rc)
+    assert rc == Fout
+    return y, new_cache
 
 
 class Engine:

@@ -457,6 +457,24 @@ int gtcrn_stream_export(gtcrn_model* m, const void* d_state, int nstreams, float
     return state_convert(m, const_cast<void*>(d_state), nstreams, d_conv_cache, d_tra_cache, d_tcn_cache8, 1, stream);
 }
 
+int gtcrn_stream_conv2d(const float* d_x, const float* d_cache, const float* d_w, const float* d_bias, float* d_y,
+                        float* d_cache_out, int B, int Cin, int Cout, int T, int F, int kt, int kf, int dt, int df,
+                        int pad_f, int groups, int transposed, void* stream) {
+    if (!d_x || !d_w || !d_y) return fail(GTCRN_ERR_ARG, "null pointer");
+    // pad_f may be negative: the reference pads by (kF-1)*dF - F_pad, which crops when kF == 1 (convolution.py:243-250)
+    if (B < 1 || Cin < 1 || Cout < 1 || T < 1 || F < 1 || kt < 1 || kf < 1 || dt < 1 || df < 1)
+        return fail(GTCRN_ERR_ARG, "bad shape");
+    const int H = (kt - 1) * dt;
+    if (H > 0 && (!d_cache || !d_cache_out)) return fail(GTCRN_ERR_ARG, "a causal kernel taller than 1 needs a cache");
+    if (transposed && groups != 1) return fail(GTCRN_ERR_ARG, "transposed form supports groups == 1 only");
+    if (!transposed && (groups < 1 || Cin % groups || Cout % groups)) return fail(GTCRN_ERR_ARG, "bad groups");
+    const int Fout = transposed ? F - 2 * pad_f + df * (kf - 1) : F + 2 * pad_f - df * (kf - 1);
+    if (Fout < 1) return fail(GTCRN_ERR_ARG, "empty output");
+    LAUNCH_TRY(gtk::launch_conv2d_causal(d_x, d_cache, d_w, d_bias, d_y, d_cache_out, B, Cin, Cout, T, F, kt, kf, dt,
+                                         df, pad_f, groups, transposed, Fout, (hipStream_t)stream));
+    return Fout;
+}
+
 int gtcrn_debug_enable(gtcrn_model* m, int on) {
     int rc = check_model(m);
     if (rc) return rc;

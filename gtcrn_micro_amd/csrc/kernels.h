@@ -47,6 +47,9 @@ int launch_decoder(const float* xg, const float* en0, const float* en1, const fl
                    unsigned long long* stamps, hipStream_t s);
 int launch_state_convert(float* state, int N, float* conv, float* tra, float* const* tcn8, const int* PI, int dir,
                          hipStream_t s);
+int launch_conv2d_causal(const float* x, const float* cache, const float* w, const float* bias, float* y,
+                         float* cache_out, int B, int Cin, int Cout, int T, int F, int kt, int kf, int dt, int df,
+                         int pf, int groups, int transposed, int Fout, hipStream_t s);
 int launch_selftest(const float* A, const float* Bm, const float* C, float* D, hipStream_t s);
 
 }  // namespace gtk

@@ -1333,6 +1333,58 @@ __global__ void k_state_convert(float* __restrict__ state, int N, float* __restr
     (void)PI;
 }
 
+// ===================================================================== generic causal conv (wrappers)
+// StreamConv2d.forward / StreamConvTranspose2d.forward (streaming/conversion/convolution.py:107-119,
+// 201-253) for arbitrary small shapes: input = cat([cache, x]) along time, VALID convolution in time,
+// zero padding pf in frequency, stride 1, dilation (dt, df), groups; the new cache is the last
+// (kt-1)*dt rows of the input.  transposed = 1 computes ConvTranspose2d semantics directly from the
+// (in, out, kt, kf) weight: y[o,t,f] = b[o] + sum x[i, t - a*dt, f + pf - q*df] W[i,o,a,q], which is
+// what the reference obtains from Conv2d with permuted + flipped weights (convert.py:35-48).
+// One thread per output element; these wrappers are not on the fused hot path.
+__global__ void k_conv2d_causal(const float* __restrict__ x, const float* __restrict__ cache,
+                                const float* __restrict__ w, const float* __restrict__ bias,
+                                float* __restrict__ y, float* __restrict__ cache_out, int B, int Cin, int Cout, int T,
+                                int F, int kt, int kf, int dt, int df, int pf, int groups, int transposed, int Fout) {
+    const int H = (kt - 1) * dt;
+    const long total = (long)B * Cout * T * Fout;
+    const int cpg = Cin / groups, opg = Cout / groups;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const int f = (int)(idx % Fout);
+        const int t = (int)((idx / Fout) % T);
+        const int o = (int)((idx / ((long)Fout * T)) % Cout);
+        const int b = (int)(idx / ((long)Fout * T * Cout));
+        float acc = bias ? bias[o] : 0.f;
+        const int gq = transposed ? 0 : o / opg;
+        const int ci0 = transposed ? 0 : gq * cpg, nci = transposed ? Cin : cpg;
+        for (int ci = 0; ci < nci; ++ci) {
+            const int c = ci0 + ci;
+            for (int a = 0; a < kt; ++a) {
+                const int tau = transposed ? t - a * dt : t - H + a * dt;   // frame relative to the chunk start
+                const float* row = tau >= 0 ? x + (((long)b * Cin + c) * T + tau) * F
+                                            : cache + (((long)b * Cin + c) * H + (H + tau)) * F;
+                for (int q = 0; q < kf; ++q) {
+                    const int fi = transposed ? f + pf - q * df : f - pf + q * df;
+                    if (fi >= 0 && fi < F) {
+                        const float wv = transposed ? w[(((long)c * Cout + o) * kt + a) * kf + q]
+                                                    : w[(((long)o * cpg + ci) * kt + a) * kf + q];
+                        acc += wv * row[fi];
+                    }
+                }
+            }
+        }
+        y[idx] = acc;
+    }
+    // new cache = last H rows of [cache | x]
+    const long ctotal = (long)B * Cin * H * F;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < ctotal; idx += (long)gridDim.x * blockDim.x) {
+        const int f = (int)(idx % F);
+        const int r = (int)((idx / F) % H);
+        const long bc = idx / ((long)F * H);
+        const int tau = T - H + r;
+        cache_out[idx] = tau >= 0 ? x[(bc * T + tau) * F + f] : cache[(bc * H + (H + tau)) * F + f];
+    }
+}
+
 // ==================================================================================== self test
 // D = A(16x4) * B(4x16) + C with the lane maps the kernels rely on:
 // a = A[i = lane&15][k = lane>>4], b = B[k = lane>>4][j = lane&15], D reg r -> row 4*(lane>>4)+r, col lane&15.
@@ -1438,6 +1490,17 @@ int launch_decoder(const float* xg, const float* en0, const float* en1, const fl
 int launch_state_convert(float* state, int N, float* conv, float* tra, float* const* tcn8, const int* PI, int dir,
                          hipStream_t s) {
     hipLaunchKernelGGL(k_state_convert, dim3(N), dim3(256), 0, s, state, N, conv, tra, tcn8, PI, dir);
+    GT_LAUNCH_CHECK();
+    return 0;
+}
+
+int launch_conv2d_causal(const float* x, const float* cache, const float* w, const float* bias, float* y,
+                         float* cache_out, int B, int Cin, int Cout, int T, int F, int kt, int kf, int dt, int df,
+                         int pf, int groups, int transposed, int Fout, hipStream_t s) {
+    const long total = (long)B * Cout * T * Fout;
+    const int grid = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+    hipLaunchKernelGGL(k_conv2d_causal, dim3(grid > 0 ? grid : 1), dim3(256), 0, s, x, cache, w, bias, y, cache_out, B,
+                       Cin, Cout, T, F, kt, kf, dt, df, pf, groups, transposed, Fout);
     GT_LAUNCH_CHECK();
     return 0;
 }

@@ -117,6 +117,18 @@ int gtcrn_stream_import(gtcrn_model *m, void *d_state, int nstreams, const float
 int gtcrn_stream_export(gtcrn_model *m, const void *d_state, int nstreams, float *d_conv_cache,
                         float *d_tra_cache, float *const *d_tcn_cache8, void *stream);
 
+/* ---- standalone streaming conv wrappers -----------------------------------
+ * Replaces StreamConv2d.forward / StreamConvTranspose2d.forward
+ * (streaming/conversion/convolution.py:107-119, 201-253): out = conv(cat([cache, x], time)),
+ * cache_out = last (kt-1)*dt rows of the input.  x (B,Cin,T,F), cache (B,Cin,(kt-1)*dt,F),
+ * y (B,Cout,T,Fout); stride 1, time padding 0 (causal), frequency padding pad_f.
+ * transposed = 0: Conv2d weight (Cout, Cin/groups, kt, kf);
+ * transposed = 1: ConvTranspose2d weight (Cin, Cout, kt, kf) as stored by the OFFLINE module
+ * (the permute + flip of convert.py:35-48 is implied).  Returns Fout (> 0) or a negative status. */
+int gtcrn_stream_conv2d(const float *d_x, const float *d_cache, const float *d_w, const float *d_bias,
+                        float *d_y, float *d_cache_out, int B, int Cin, int Cout, int T, int F, int kt, int kf,
+                        int dt, int df, int pad_f, int groups, int transposed, void *stream);
+
 /* ---- host-side packer view (no device needed) ---------------------------
  * The BatchNorm-folded "slot space" buffers the kernels consume, as produced
  * from a parameter blob; lets a CPU test check the weight contract

@@ -91,3 +91,52 @@ def test_chunked_equals_offline_many_streams(dev):
             t0 += c
         got = torch.cat(outs, 2)
         assert rel_err(got.cpu().numpy(), full.cpu().numpy()) < 2e-5, chunks
+
+
+def test_conv_wrappers_like_reference_test(dev):
+    """tests/streaming/conversion/test_convolution.py of the reference, run against the HIP wrappers:
+    streaming == offline for StreamConv2d(1,1,3) and StreamConvTranspose2d(4,8,(3,1),dil(2,2),pad(0,1)),
+    including convert_to_stream's weight permute + flip.  Offline results come from the frozen goldens."""
+    import torch.nn as nn
+    from gtcrn_micro_amd.streaming.conversion.convert import convert_to_stream
+    from gtcrn_micro_amd.streaming.conversion.convolution import StreamConv2d, StreamConvTranspose2d
+    g = golden("conv_wrappers.npz")
+    # --- StreamConv2d(1, 1, 3)
+    conv = nn.Conv2d(1, 1, 3)
+    with torch.no_grad():
+        conv.weight.copy_(torch.from_numpy(g["c2d_w"])); conv.bias.copy_(torch.from_numpy(g["c2d_b"]))
+    sconv = StreamConv2d(1, 1, 3)
+    convert_to_stream(stream_model=sconv, model=conv)
+    sconv = sconv.cuda()
+    x = cu(g["c2d_x"])
+    cache = torch.zeros(1, 1, 2, 6, device="cuda")
+    outs = []
+    for i in range(10):
+        o, cache = sconv(x[:, :, i:i + 1], cache)
+        outs.append(o)
+    assert np.abs(torch.cat(outs, 2).cpu().numpy() - g["c2d_y"]).max() < 1e-6
+    o_all, _ = sconv(x, torch.zeros(1, 1, 2, 6, device="cuda"))                # whole clip in one call
+    assert np.abs(o_all.cpu().numpy() - g["c2d_y"]).max() < 1e-6
+    # --- StreamConvTranspose2d(4, 8, (3,1), stride (1,1), padding (0,1), dilation (2,2))
+    kt, dt = 3, 2
+    pt = (kt - 1) * dt
+    de = nn.ConvTranspose2d(4, 8, (kt, 1), stride=(1, 1), padding=(pt, 1), dilation=(dt, 2), groups=1)
+    with torch.no_grad():
+        de.weight.copy_(torch.from_numpy(g["ct2d_w"])); de.bias.copy_(torch.from_numpy(g["ct2d_b"]))
+    sde = StreamConvTranspose2d(4, 8, (kt, 1), stride=(1, 1), padding=(0, 1), dilation=(dt, 2), groups=1)
+    convert_to_stream(sde, de)
+    assert np.array_equal(sde.ConvTranspose2d.weight.detach().numpy(), g["ct2d_w_stream"])
+    sde = sde.cuda()
+    x = cu(g["ct2d_x"])
+    cache = torch.zeros(1, 4, pt, 6, device="cuda")
+    outs = []
+    for i in range(100):
+        o, cache = sde(x[:, :, i:i + 1], cache)
+        outs.append(o)
+    assert np.abs(torch.cat(outs, 2).cpu().numpy() - g["ct2d_y"]).max() < 1e-6
+    with pytest.raises(AssertionError):
+        StreamConv2d(1, 1, 3, padding=(1, 0))            # time padding must be 0 (convolution.py:94)
+    # the C ABI's transposed form on the OFFLINE weight layout equals the same thing
+    from gtcrn_micro_amd._lib import stream_conv2d
+    y, _ = stream_conv2d(cu(g["ct33_x"]), None, cu(g["ct33_w"]), cu(g["ct33_b"]), 3, 3, pad_f=1, transposed=True)
+    assert np.abs(y.cpu().numpy() - g["ct33_y"][:, :, :9]).max() < 2e-6
