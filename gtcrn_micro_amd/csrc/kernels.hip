@@ -32,6 +32,13 @@ __device__ __forceinline__ f32x4 splat(float v) { f32x4 r = {v, v, v, v}; return
 // fence, which on gfx950 drains vmcnt: every barrier would then wait for all global loads and
 // stores in flight (prefetches, skip-tensor stores).  Waves of a workgroup exchange data only
 // through LDS here, so waiting for this wave's LDS operations (lgkmcnt) is sufficient.
+// Ordering for LDS data that only the lanes of ONE wave exchange: LDS operations of a wave complete in
+// issue order, so it is enough to keep the compiler from reordering across this point.
+__device__ __forceinline__ void wave_lds_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
 __device__ __forceinline__ void wg_barrier() {
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
@@ -169,7 +176,7 @@ __device__ __forceinline__ void fft256(float2* a, float2* b, const float2* tw, i
         dst[j0 + Ns] = make_float2(s1.x + s3.x, s1.y + s3.y);
         dst[j0 + 2 * Ns] = make_float2(s0.x - s2.x, s0.y - s2.y);
         dst[j0 + 3 * Ns] = make_float2(s1.x - s3.x, s1.y - s3.y);
-        __syncthreads();
+        wave_lds_sync();   // each wave transforms its own frame in its own buffers
         float2* t = src; src = dst; dst = t;
     }
 }
@@ -213,7 +220,7 @@ __global__ __launch_bounds__(FFT_WAVES * 64) void k_stft(const float* __restrict
                 frames_out[fr * 512 + 2 * m + 1] = v.y;
             }
         }
-        __syncthreads();
+        wave_lds_sync();
         fft256<-1>(A, Bf, s_tw, lane);
         // real-FFT split: X[k] = Ze + exp(-2 pi i k/512) Zo, Ze = (Z[k]+conj(Z[256-k]))/2,
         // Zo = (Z[k]-conj(Z[256-k]))/(2i)
@@ -234,7 +241,7 @@ __global__ __launch_bounds__(FFT_WAVES * 64) void k_stft(const float* __restrict
                 }
             }
         }
-        __syncthreads();
+        wave_lds_sync();
     }
 }
 
@@ -281,7 +288,7 @@ __global__ __launch_bounds__(FFT_WAVES * 64) void k_istft(const float* __restric
             const float2 xo = cmul(make_float2(0.5f * (xk.x - xm.x), 0.5f * (xk.y - xm.y)), w);
             A[k] = make_float2(xe.x - xo.y, xe.y + xo.x);
         }
-        __syncthreads();
+        wave_lds_sync();
         fft256<1>(A, Bf, s_tw, lane);
         if (live) {
 #pragma unroll
@@ -292,8 +299,9 @@ __global__ __launch_bounds__(FFT_WAVES * 64) void k_istft(const float* __restric
                 s_fr[fi][2 * m + 1] = (z.y * (1.0f / 256.0f)) * s_win[2 * m + 1];
             }
         }
-        __syncthreads();
+        wave_lds_sync();
     }
+    __syncthreads();   // the windowed frames of all four waves are overlap-added below
     // overlap-add: output block j = frame j second half + frame j+1 first half
     float* o = wave + (long)b * 256 * nblk;
     for (int idx = tid; idx < (nfr - 1) * 256; idx += FFT_WAVES * 64) {
@@ -513,9 +521,7 @@ __device__ __forceinline__ f32x4 permute_via_lds(float* scratch_rec, const int* 
     scratch_rec[idx4[1]] = v[1];
     scratch_rec[idx4[2]] = v[2];
     scratch_rec[idx4[3]] = v[3];
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    wave_lds_sync();
     return ld4(scratch_rec + 4 * g);
 }
 
@@ -1155,6 +1161,7 @@ __global__ __launch_bounds__(NTHR) void k_decoder(const float* __restrict__ xg, 
 #pragma unroll
             for (int i = 0; i < TPW; ++i) xn[i] = ld4(xgn + (unsigned)((tt.pp(i) < npn ? tt.pp(i) : 0) * 16 + 4 * g));
         }
+        STAMP(SS, 9)
         wg_barrier();
         STAMP(SS, 10)
         f32x4 ze[TPW], zo[TPW];
@@ -1244,6 +1251,7 @@ __global__ __launch_bounds__(NTHR) void k_decoder(const float* __restrict__ xg, 
             if (idx < nfr * NBINS)
                 spv[q] = *reinterpret_cast<const float2*>(spec + (long)f * sf + (long)(t0 + tq) * st);
         }
+        STAMP(SS, 15)
         wg_barrier();
         STAMP(SS, 12)
         // de_convs.4 gather + BN + Tanh: m[o][f''] = tanh(b[o] + sum_k z[(f''+2-k)/2][o*5+k]).  Branch free:

@@ -21,7 +21,7 @@ PHASES = {
         7: "blk tra reduce", 8: "blk apply+store", 9: "chunk end"},
     1: {0: "prologue", 1: "load x", 2: "conv1", 3: "taps+conv3", 4: "ring", 5: "store"},
     3: {0: "prologue", 1: "load x+en4", 5: "blk pc1", 6: "blk dense+pc2", 7: "blk tra reduce", 8: "blk apply+skip",
-        10: "de3 stage x", 11: "de3+de4 mfma", 12: "Z write", 13: "de4 gather+tanh", 14: "bs+mask+store"},
+        9: "de3 stage x (issue)", 10: "de3 stage x (barrier)", 11: "de3+de4 mfma", 15: "Z write (issue)", 12: "Z write (barrier)", 13: "de4 gather+tanh", 14: "bs+mask+store"},
 }
 PHASES[2] = PHASES[1]
 NAMES = ["k_encoder", "k_gtcn1", "k_gtcn2", "k_decoder"]
