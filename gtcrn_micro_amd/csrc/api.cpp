@@ -6,6 +6,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cmath>
+#include <cstdint>
 #include <cstdio>
 #include <cstring>
 #include <string>
@@ -342,9 +343,17 @@ int device_twiddles(float** out) {
 }
 }  // namespace
 
+static int check_spec_layout(const void* p, long sb, long sf, long st) {
+    // the kernels move the (re, im) pair with 8-byte accesses
+    if ((reinterpret_cast<uintptr_t>(p) & 7) || (sb & 1) || (sf & 1) || (st & 1))
+        return fail(GTCRN_ERR_ARG, "spectrogram base must be 8-byte aligned and its strides even (re/im pairs)");
+    return 0;
+}
+
 int gtcrn_stft(const float* d_wave, int B, long L, const float* d_win, float* d_spec, long sb, long sf, long st,
                void* stream) {
     if (!d_wave || !d_win || !d_spec || B < 1) return fail(GTCRN_ERR_ARG, "null pointer or B < 1");
+    if (int rc0 = check_spec_layout(d_spec, sb, sf, st)) return rc0;
     if (L < 257) return fail(GTCRN_ERR_ARG, "reflect padding needs L > 256 samples");
     float* tw = nullptr;
     int rc = device_twiddles(&tw);
@@ -369,6 +378,7 @@ int gtcrn_istft(const float* d_spec, long sb, long sf, long st, int B, int T, co
                 void* stream) {
     if (!d_spec || !d_win || !d_wave || B < 1) return fail(GTCRN_ERR_ARG, "null pointer or B < 1");
     if (T < 2) return fail(GTCRN_ERR_ARG, "iSTFT needs T >= 2 frames");
+    if (int rc0 = check_spec_layout(d_spec, sb, sf, st)) return rc0;
     float* tw = nullptr;
     int rc = device_twiddles(&tw);
     if (rc) return rc;
@@ -382,6 +392,8 @@ int gtcrn_forward_spec(gtcrn_model* m, const float* d_spec_in, long isb, long is
     if (rc) return rc;
     if (!d_spec_in || !d_spec_out) return fail(GTCRN_ERR_ARG, "null spectrogram pointer");
     if (B < 1 || T < 1) return fail(GTCRN_ERR_ARG, "B and T must be >= 1");
+    if (int rc0 = check_spec_layout(d_spec_in, isb, isf, ist)) return rc0;
+    if (int rc0 = check_spec_layout(d_spec_out, osb, osf, ost)) return rc0;
     hipStream_t s = (hipStream_t)stream;
     rc = ensure_workspace(m, B, T, s);
     if (rc) return rc;
@@ -429,6 +441,8 @@ int gtcrn_stream_step(gtcrn_model* m, void* d_state, const float* d_spec_t, long
     if (rc) return rc;
     if (!d_state || !d_spec_t || !d_spec_out_t) return fail(GTCRN_ERR_ARG, "null pointer");
     if (nstreams < 1 || nframes < 1) return fail(GTCRN_ERR_ARG, "nstreams and nframes must be >= 1");
+    if (int rc0 = check_spec_layout(d_spec_t, isb, isf, ist)) return rc0;
+    if (int rc0 = check_spec_layout(d_spec_out_t, osb, osf, ost)) return rc0;
     hipStream_t s = (hipStream_t)stream;
     rc = ensure_workspace(m, nstreams, nframes, s);
     if (rc) return rc;

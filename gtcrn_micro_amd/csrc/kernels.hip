@@ -233,12 +233,10 @@ __global__ __launch_bounds__(FFT_WAVES * 64) void k_stft(const float* __restrict
                 const float2 ze = make_float2(0.5f * (zk.x + zm.x), 0.5f * (zk.y - zm.y));
                 const float2 zo = make_float2(0.5f * (zk.y + zm.y), -0.5f * (zk.x - zm.x));
                 const float2 r = cmul(s_tw512[k], zo);
-                o[(long)k * sf] = ze.x + r.x;
-                o[(long)k * sf + 1] = ze.y + r.y;
-                if (k == 0) {  // Nyquist bin: X[256] = Re Z[0] - Im Z[0]
-                    o[256L * sf] = zk.x - zk.y;
-                    o[256L * sf + 1] = 0.f;
-                }
+                // the re/im pair is contiguous and 8-byte aligned (even strides): one 8-byte store
+                *reinterpret_cast<float2*>(o + (long)k * sf) = make_float2(ze.x + r.x, ze.y + r.y);
+                if (k == 0)  // Nyquist bin: X[256] = Re Z[0] - Im Z[0]
+                    *reinterpret_cast<float2*>(o + 256L * sf) = make_float2(zk.x - zk.y, 0.f);
             }
         }
         wave_lds_sync();
@@ -279,8 +277,9 @@ __global__ __launch_bounds__(FFT_WAVES * 64) void k_istft(const float* __restric
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int k = lane + 64 * q;
-            float2 xk = make_float2(x[(long)k * sf], x[(long)k * sf + 1]);
-            float2 xm = make_float2(x[(long)(256 - k) * sf], -x[(long)(256 - k) * sf + 1]);
+            float2 xk = *reinterpret_cast<const float2*>(x + (long)k * sf);
+            float2 xm = *reinterpret_cast<const float2*>(x + (long)(256 - k) * sf);
+            xm.y = -xm.y;
             if (k == 0) { xk.y = 0.f; xm.y = 0.f; }
             const float2 xe = make_float2(0.5f * (xk.x + xm.x), 0.5f * (xk.y + xm.y));
             float2 w = s_tw512[k];
