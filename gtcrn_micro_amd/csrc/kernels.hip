@@ -642,22 +642,26 @@ __global__ __launch_bounds__(NTHR) void k_encoder(const float* __restrict__ spec
             sEB[(c * TC + tl) * EB_ROW + 1 + j] = sSpec[(c * TC + tl) * NBINS + j];
         }
         for (int idx = tv; idx < 3 * nfr * ERB_BANDS; idx += NTHR) {
-            const int band = idx % ERB_BANDS, ct = idx / ERB_BANDS, tl = ct % nfr, c = ct / nfr;
-            const int lo = sI[I_ERB_LO + band], cnt = sI[I_ERB_N + band];
-            const float* sp = sSpec + (c * TC + tl) * NBINS + ERB_LOW + lo;
+            const int band = idx & (ERB_BANDS - 1), ct = idx >> 6, tl = ct % nfr, c = ct / nfr;
+            const float* sp = sSpec + (c * TC + tl) * NBINS + ERB_LOW + sI[I_ERB_LO + band];
             const float* w = sP + E_ERB_W + band * ERB_MAXBW;
-            float acc = 0.f;
-            for (int i = 0; i < cnt; ++i) acc += w[i] * sp[i];
-            sEB[(c * TC + tl) * EB_ROW + 1 + ERB_LOW + band] = acc;
+            // fixed trip count: the packed band weights are zero beyond the band's width and the staged
+            // image is finite (a few floats of slack follow it), so all 12 taps can be issued at once
+            // instead of a data-dependent loop whose LDS reads serialise
+            float a0 = 0.f, a1 = 0.f;
+#pragma unroll
+            for (int i = 0; i < ERB_MAXBW; i += 2) { a0 += w[i] * sp[i]; a1 += w[i + 1] * sp[i + 1]; }
+            sEB[(c * TC + tl) * EB_ROW + 1 + ERB_LOW + band] = a0 + a1;
         }
         wg_barrier();
         STAMP(SS, 1)
         // ---- B: SFE_Lite depthwise (1,3): F0[c][tl][2 + f] ---------------------------------------
-        for (int idx = tv; idx < 3 * nfr * F0; idx += NTHR) {
-            const int f = idx % F0, ct = idx / F0, tl = ct % nfr, c = ct / nfr;
-            const float* e = sEB + (c * TC + tl) * EB_ROW + f;
-            sF0[(c * TC + tl) * F0_ROW + 2 + f] =
-                sP[E_SFE_W + c * 3] * e[0] + sP[E_SFE_W + c * 3 + 1] * e[1] + sP[E_SFE_W + c * 3 + 2] * e[2];
+        for (int row = tv >> 6; row < 3 * nfr; row += NW) {       // one (channel, frame) row per wave pass
+            const int tl = row % nfr, c = row / nfr;
+            const float w0 = sP[E_SFE_W + c * 3], w1 = sP[E_SFE_W + c * 3 + 1], w2 = sP[E_SFE_W + c * 3 + 2];
+            const float* e = sEB + (c * TC + tl) * EB_ROW;
+            float* d = sF0 + (c * TC + tl) * F0_ROW + 2;
+            for (int f = tv & 63; f < F0; f += 64) d[f] = w0 * e[f] + w1 * e[f + 1] + w2 * e[f + 2];
         }
         // zero the pad positions of E0 (columns 0,1,67,68 of each row): region A held the spectrogram
         if (tv < TC * 4 * 4) {
