@@ -357,6 +357,7 @@ struct BlockCtx {
     float* sS;           // LDS: v^2, [position][16 slots], 33 positions per frame
     float* sG;           // LDS: gates [frame][16 slots]
     float* sEHk;         // LDS: 2-entry ring of e: [frame & 1][8]
+    float* sE;           // LDS: energies of the chunk, [2 + TC][8] (rows 0,1: the two frames before it)
     int nfr;             // frames in this chunk
     int tabs;            // absolute frame index of the chunk's first frame
 };
@@ -437,42 +438,50 @@ __device__ __forceinline__ void gtconv_block(f32x4 (&x)[TPW], const Tiles& tt, c
     for (int i = 0; i < TPW; ++i)
         if (tt.tl[i] < c.nfr && tt.tl[i] >= c.nfr - 2)
             st4(c.sHk + ring35(tt, i, g, c.tabs, 2), ld4(c.sW + o35(tt, i, g)));
-    // ---- TRALite gate: 32 threads per frame = 8 h' channels x 4 bin ranges (9, 9, 9, 6 bins); the four
-    //      partial sums of a channel sit in one DPP quad and are combined there (fixed order, so the
-    //      result is reproducible); every quad also sums the two previous frames itself, which
-    //      costs 18 more LDS reads but saves a barrier -------------------------------------------------
-    float e_keep = 0.f;
-    const int part = L.tid & 3, rc = (L.tid >> 2) & 7, rt = L.tid >> 5;
-    const bool reducer = L.tid < c.nfr * 32;
-    if (reducer) {
-        const int slot = c.ib[rc];
-        const int f0 = part * 9, cnt = part == 3 ? 6 : 9;
-        float e[3];
-#pragma unroll
-        for (int j = 0; j < 3; ++j) {  // e[j] = energy of frame rt - 2 + j
-            const int tau = rt - 2 + j;
-            const float* sp = c.sS + ((tau >= 0 ? tau : 0) * 33 + f0) * 16 + slot;
+    // ---- TRALite, step 1: energies e[t][c] = mean_F(v^2): 32 threads per frame = 8 h' channels x 4 bin
+    //      ranges (9, 9, 9, 6 bins); the four partial sums of a channel sit in one DPP quad and are
+    //      combined there in a fixed order (bit-reproducible).  Written to sE[2 + t][c]; rows 0,1 of sE
+    //      hold the two frames before the chunk (the block's energy ring) ---------------------------------
+    {
+        const int part = L.tid & 3, rc = (L.tid >> 2) & 7, rt = L.tid >> 5;
+        if (L.tid < c.nfr * 32) {
+            const float* sp = c.sS + (rt * 33 + part * 9) * 16 + c.ib[rc];
+            const int cnt = part == 3 ? 6 : 9;
             float sum = 0.f;
             for (int f = 0; f < cnt; ++f) sum += sp[f * 16];
             sum += dpp_ror<0xB1>(sum);   // quad_perm [1,0,3,2]
             sum += dpp_ror<0x4E>(sum);   // quad_perm [2,3,0,1]
-            e[j] = tau >= 0 ? sum * (1.0f / 33.0f) : c.sEHk[((c.tabs + tau) & 1) * 8 + rc];
+            if (part == 0) c.sE[(2 + rt) * 8 + rc] = sum * (1.0f / 33.0f);
+        } else if (L.tid >= NTHR - 16) {          // an otherwise idle wave copies the ring into rows 0,1
+            const int q = L.tid - (NTHR - 16), r = q >> 3, cc = q & 7;
+            c.sE[r * 8 + cc] = c.sEHk[((c.tabs - 2 + r) & 1) * 8 + cc];
         }
-        e_keep = e[2];
-        const float y = c.pb[GB_TRA_DB + rc] + c.pb[GB_TRA_DW + rc * 3] * e[0] + c.pb[GB_TRA_DW + rc * 3 + 1] * e[1] +
-                        c.pb[GB_TRA_DW + rc * 3 + 2] * e[2];
-        float z = c.pb[GB_TRA_PB + rc];
+    }
+    wg_barrier();
+    // ---- step 2: one thread per (frame, output channel): causal depthwise conv1d (k=3) over the energies,
+    //      1x1 conv, sigmoid (models/gtcrn_micro.py:122-139) ------------------------------------------------
+    {
+        const int ro = L.tid & 7, rt = L.tid >> 3;
+        if (L.tid < c.nfr * 8) {
+            const float* e = c.sE + rt * 8 + ro;                 // rows rt, rt+1, rt+2 = frames t-2, t-1, t
+            const float y = c.pb[GB_TRA_DB + ro] + c.pb[GB_TRA_DW + ro * 3] * e[0] +
+                            c.pb[GB_TRA_DW + ro * 3 + 1] * e[8] + c.pb[GB_TRA_DW + ro * 3 + 2] * e[16];
+            // the 8 channels of a frame sit in 8 adjacent lanes of one wave: exchange y through the
+            // (now dead) first rows of sG with wave-local ordering, no workgroup barrier
+            float* sy = c.sG + TC * 16 + rt * 8;                 // scratch behind the gate table
+            sy[ro] = y;
+            wave_lds_sync();
+            float z = c.pb[GB_TRA_PB + ro];
 #pragma unroll
-        for (int cc = 0; cc < 8; ++cc) z += c.pb[GB_TRA_PW + rc * 8 + cc] * __shfl(y, (L.lane & 32) + cc * 4 + part);
-        const float gate = __frcp_rn(1.0f + __expf(-z));
-        if (part == 0) {
-            c.sG[rt * 16 + slot] = gate;
-            c.sG[rt * 16 + c.ib[8 + rc]] = 1.0f;
+            for (int cc = 0; cc < 8; ++cc) z += c.pb[GB_TRA_PW + ro * 8 + cc] * sy[cc];
+            c.sG[rt * 16 + c.ib[ro]] = __frcp_rn(1.0f + __expf(-z));
+            c.sG[rt * 16 + c.ib[8 + ro]] = 1.0f;
+            // the last two frames' energies become the ring for the next chunk (row = frame & 1)
+            if (rt >= c.nfr - 2) c.sEHk[((c.tabs + rt) & 1) * 8 + ro] = e[16];
         }
     }
     wg_barrier();
     STAMP(SS, 7)
-    if (reducer && part == 0 && rt >= c.nfr - 2) c.sEHk[((c.tabs + rt) & 1) * 8 + rc] = e_keep;
 #pragma unroll
     for (int i = 0; i < TPW; ++i) x[i] = x[i] * ld4(c.sG + tt.tl[i] * 16 + 4 * g);
 }
@@ -534,7 +543,8 @@ constexpr int ENC_LDS_I = ENC_LDS_P + ENC_SIZE;
 constexpr int ENC_LDS_H = ENC_LDS_I + P_INTS;
 constexpr int ENC_LDS_EH = ENC_LDS_H + 3 * 2 * 35 * 16;
 constexpr int ENC_LDS_G = ENC_LDS_EH + 48;
-constexpr int ENC_LDS_A = ENC_LDS_G + TC * 16;             // staged spec, then E0, then W + S
+constexpr int ENC_LDS_E = ENC_LDS_G + TC * 16 + TC * 8;    // (gates [TC][16] + y scratch [TC][8]); energies [2 + TC][8]
+constexpr int ENC_LDS_A = ENC_LDS_E + (TC + 2) * 8;        // staged spec, then E0, then W + S
 constexpr int ENC_E0_ROW = 69;
 constexpr int ENC_LDS_B = ENC_LDS_A + TC * ENC_E0_ROW * 16;  // EB + F0
 constexpr int EB_ROW = 131, F0_ROW = 136;
@@ -595,9 +605,9 @@ __global__ __launch_bounds__(NTHR) void k_encoder(const float* __restrict__ spec
         for (int q = 0; q < SPEC_ITEMS; ++q) {
             int idx = tid + q * NTHR;
             asm volatile("" : "+v"(idx));
-            if (idx >= nf * NBINS) idx = 0;              // clamped: no select behind the load
             int tl, f;
-            if (t_fast) { tl = idx % nf; f = idx / nf; } else { f = idx % NBINS; tl = idx / NBINS; }
+            if (t_fast) { tl = idx & (TC - 1); f = idx >> 4; } else { f = idx % NBINS; tl = idx / NBINS; }
+            if (tl >= nf || f >= NBINS) { tl = 0; f = 0; }   // clamped: no select behind the load
             spn[q] = *reinterpret_cast<const float2*>(spec + (long)f * sf + (long)(t0f + tl) * st);
         }
     };
@@ -623,9 +633,9 @@ __global__ __launch_bounds__(NTHR) void k_encoder(const float* __restrict__ spec
 #pragma unroll
         for (int q = 0; q < SPEC_ITEMS; ++q) {
             int idx = tv + q * NTHR;
-            if (idx < nfr * NBINS) {
-                int tl, f;
-                if (t_fast) { tl = idx % nfr; f = idx / nfr; } else { f = idx % NBINS; tl = idx / NBINS; }
+            int tl, f;
+            if (t_fast) { tl = idx & (TC - 1); f = idx >> 4; } else { f = idx % NBINS; tl = idx / NBINS; }
+            if (tl < nfr && f < NBINS) {
                 const float2 v = spn[q];
                 float* d = sSpec + tl * NBINS + f;
                 d[0] = __builtin_amdgcn_sqrtf(v.x * v.x + v.y * v.y + 1e-12f);
@@ -737,6 +747,7 @@ __global__ __launch_bounds__(NTHR) void k_encoder(const float* __restrict__ spec
             c.gA = nullptr;
             c.ib = sI + I_ENC_BLK + k * 16;
             c.sW = sW; c.sHk = sH + k * (2 * 35 * 16); c.sS = sS; c.sG = sG; c.sEHk = sEH + k * 16;
+            c.sE = smem + ENC_LDS_E;
             c.nfr = nfr; c.tabs = tbase + t0;
             gtconv_block<false>(x, tt, c, L STAMP_ARG);
             if (k < 2) {
@@ -1033,7 +1044,8 @@ constexpr int DEC_LDS_I = DEC_LDS_P + DEC_SIZE;
 constexpr int DEC_LDS_H = DEC_LDS_I + P_INTS;
 constexpr int DEC_LDS_EH = DEC_LDS_H + 3 * 2 * 35 * 16;
 constexpr int DEC_LDS_G = DEC_LDS_EH + 48;
-constexpr int DEC_LDS_A = DEC_LDS_G + TC * 16;                    // W + S, later Z
+constexpr int DEC_LDS_E = DEC_LDS_G + TC * 16 + TC * 8;           // (gates [TC][16] + y scratch [TC][8]); energies [2 + TC][8]
+constexpr int DEC_LDS_A = DEC_LDS_E + (TC + 2) * 8;               // W + S, later Z
 constexpr int DEC_LDS_ASZ = TC * 35 * 16 + TC * 33 * 16;
 constexpr int DEC_Z_ROW = F1 + 2;                                 // Z rows carry a zero record at both ends
 constexpr int DEC_LDS_M = DEC_LDS_A + DEC_LDS_ASZ;                // mask m [2][TC][129] (+4: the 2-tap read of the last bin)
@@ -1135,6 +1147,7 @@ __global__ __launch_bounds__(NTHR) void k_decoder(const float* __restrict__ xg, 
             c.gA = c.pb + GB_DN_A;
             c.ib = sI + I_DEC_BLK + j * 16;
             c.sW = sW; c.sHk = sH + j * (2 * 35 * 16); c.sS = sS; c.sG = sG; c.sEHk = sEH + j * 16;
+            c.sE = smem + DEC_LDS_E;
             c.nfr = nfr; c.tabs = tbase + t0;
             gtconv_block<true>(x, tt, c, L STAMP_ARG);
             if (DBG)
@@ -1249,9 +1262,9 @@ __global__ __launch_bounds__(NTHR) void k_decoder(const float* __restrict__ xg, 
             // loop, spilled, and every reload drains the loads in flight (scratch shares vmcnt)
             asm volatile("" : "+v"(idx));
             int tq, f;
-            if (t_fast) { tq = idx % nfr; f = idx / nfr; } else { f = idx % NBINS; tq = idx / NBINS; }
+            if (t_fast) { tq = idx & (TC - 1); f = idx >> 4; } else { f = idx % NBINS; tq = idx / NBINS; }
             spv[q] = make_float2(0.f, 0.f);
-            if (idx < nfr * NBINS)
+            if (tq < nfr && f < NBINS)
                 spv[q] = *reinterpret_cast<const float2*>(spec + (long)f * sf + (long)(t0 + tq) * st);
         }
         STAMP(SS, 15)
@@ -1261,7 +1274,7 @@ __global__ __launch_bounds__(NTHR) void k_decoder(const float* __restrict__ xg, 
         // even f'' = 2m takes k = 0,2,4 from rows m+1, m, m-1; odd f'' = 2m+1 takes k = 1,3 from rows m+1, m
         // and a zero slot (rows 10..15 of the de_conv4 slot matrix are zero); the end records are zero.
         for (int idx = tid; idx < 2 * nfr * F0; idx += NTHR) {
-            const int fq = idx % F0, ot = idx / F0, tq = ot % nfr, o = ot / nfr;
+            const int fq = idx % F0, ot = idx / F0, o = ot >= nfr ? 1 : 0, tq = ot - o * nfr;
             const int par = fq & 1, m = fq >> 1;
             const float* zr = sZ + (tq * DEC_Z_ROW + 1 + m) * 16;
             const float sum = sP[D_DE4_B + o] + zr[16 + o * 5 + par] + zr[o * 5 + 2 + par] +
@@ -1272,7 +1285,7 @@ __global__ __launch_bounds__(NTHR) void k_decoder(const float* __restrict__ xg, 
         STAMP(SS, 13)
         if (DBG)
             for (int idx = tid; idx < 2 * nfr * F0; idx += NTHR) {
-                const int fq = idx % F0, ot = idx / F0, tq = ot % nfr, o = ot / nfr;
+                const int fq = idx % F0, ot = idx / F0, o = ot >= nfr ? 1 : 0, tq = ot - o * nfr;
                 dbg[3 * nbt * 528 + nbt * F1 * 16 + (((long)b * 2 + o) * T + t0 + tq) * F0 + fq] =
                     sM[(o * TC + tq) * F0 + fq];
             }
@@ -1281,9 +1294,9 @@ __global__ __launch_bounds__(NTHR) void k_decoder(const float* __restrict__ xg, 
         for (int q = 0; q < MASK_ITEMS; ++q) {
             int idx = tid + q * NTHR;
             asm volatile("" : "+v"(idx));
-            if (idx < nfr * NBINS) {
-                int tq, f;
-                if (t_fast) { tq = idx % nfr; f = idx / nfr; } else { f = idx % NBINS; tq = idx / NBINS; }
+            int tq, f;
+            if (t_fast) { tq = idx & (TC - 1); f = idx >> 4; } else { f = idx % NBINS; tq = idx / NBINS; }
+            if (tq < nfr && f < NBINS) {
                 const f32x4 tb = ld4(sBS + f * 4);
                 const float* m0 = sM + tq * F0 + __float_as_int(tb[0]);
                 const float mr = tb[1] * m0[0] + tb[2] * m0[1];
