@@ -362,9 +362,11 @@ struct BlockCtx {
     int tabs;            // absolute frame index of the chunk's first frame
 };
 
-template <bool DENSE>
+// `hook` runs right after the depth-conv phase (register pressure is past its peak there, and two
+// barrier intervals of work follow): the decoder uses it to request inputs of later phases early.
+template <bool DENSE, class Hook>
 __device__ __forceinline__ void gtconv_block(f32x4 (&x)[TPW], const Tiles& tt, const BlockCtx& c,
-                                             const Lane& L STAMP_PARAM) {
+                                             const Lane& L, Hook&& hook STAMP_PARAM) {
     const int n = L.n, g = L.g;
     const float a1 = c.pb[GB_SLOPE] - 1.0f, a2 = c.pb[GB_SLOPE + 1] - 1.0f;
     // ---- point_conv1 + BN + PReLU; h lives only in the LDS image from here on (its centre tap and the
@@ -433,6 +435,7 @@ __device__ __forceinline__ void gtconv_block(f32x4 (&x)[TPW], const Tiles& tt, c
     }
     wg_barrier();
     STAMP(SS, 6)
+    hook();
     // ---- history ring of h (after every wave has read its taps) -----------------------------------
 #pragma unroll
     for (int i = 0; i < TPW; ++i)
@@ -655,12 +658,16 @@ __global__ __launch_bounds__(NTHR) void k_encoder(const float* __restrict__ spec
             const int band = idx & (ERB_BANDS - 1), ct = idx >> 6, tl = ct % nfr, c = ct / nfr;
             const float* sp = sSpec + (c * TC + tl) * NBINS + ERB_LOW + sI[I_ERB_LO + band];
             const float* w = sP + E_ERB_W + band * ERB_MAXBW;
-            // fixed trip count: the packed band weights are zero beyond the band's width and the staged
-            // image is finite (a few floats of slack follow it), so all 12 taps can be issued at once
-            // instead of a data-dependent loop whose LDS reads serialise
+            // fixed trip count so that all 12 taps are issued at once (a data-dependent loop serialises
+            // its LDS reads); taps beyond the band's width have zero weight but may read stale LDS past
+            // the row, which need not be finite, so they are selected away rather than multiplied by 0
+            const int cnt = sI[I_ERB_N + band];
             float a0 = 0.f, a1 = 0.f;
 #pragma unroll
-            for (int i = 0; i < ERB_MAXBW; i += 2) { a0 += w[i] * sp[i]; a1 += w[i + 1] * sp[i + 1]; }
+            for (int i = 0; i < ERB_MAXBW; i += 2) {
+                a0 += w[i] * (i < cnt ? sp[i] : 0.f);
+                a1 += w[i + 1] * (i + 1 < cnt ? sp[i + 1] : 0.f);
+            }
             sEB[(c * TC + tl) * EB_ROW + 1 + ERB_LOW + band] = a0 + a1;
         }
         wg_barrier();
@@ -749,7 +756,7 @@ __global__ __launch_bounds__(NTHR) void k_encoder(const float* __restrict__ spec
             c.sW = sW; c.sHk = sH + k * (2 * 35 * 16); c.sS = sS; c.sG = sG; c.sEHk = sEH + k * 16;
             c.sE = smem + ENC_LDS_E;
             c.nfr = nfr; c.tabs = tbase + t0;
-            gtconv_block<false>(x, tt, c, L STAMP_ARG);
+            gtconv_block<false>(x, tt, c, L, [] {} STAMP_ARG);
             if (k < 2) {
                 float* dst = k == 0 ? en2 : en3;
                 const int* ix = sI + I_ENST + (k + 1) * 16 + 4 * g;
@@ -1131,9 +1138,14 @@ __global__ __launch_bounds__(NTHR) void k_decoder(const float* __restrict__ xg, 
         for (int i = 0; i < TPW; ++i) x[i] = xn[i];
         zero_row_pads(sW, tid);  // region A was Z in the previous chunk (a barrier follows in the block)
         STAMP(SS, 1)
-        // ---- 3 x GTConvBlock (dense transposed 3x3) -----------------------------------------------
-#pragma unroll 1
-        for (int j = 0; j < 3; ++j) {
+        // All 256 workgroups run in lock step, so a load burst right before its use is a chip-wide HBM
+        // burst (25 MB at once costs ~10 k cycles).  The inputs of the tail are therefore requested
+        // early and spread out: en_outs[0] after the last block's dense conv (two barrier intervals before
+        // its use), the next chunk's x during the de_conv4 gather.
+        f32x4 s0e[TPW], s0o[TPW];   // en_outs[0] for the even / odd output bins
+        // ---- 3 x GTConvBlock (dense transposed 3x3); the last one is peeled so that s0e/s0o are live only
+        //      from its hook on, not across the loop --------------------------------------------------------
+        auto run_block = [&](int j, auto&& hook) {
             // the skip added to this block's output (en3, en2, en1; already in this stage's slot
             // order) is fetched up front so that its latency hides behind the block
             const float* sk = j == 0 ? en3 : (j == 1 ? en2 : en1);
@@ -1149,7 +1161,7 @@ __global__ __launch_bounds__(NTHR) void k_decoder(const float* __restrict__ xg, 
             c.sW = sW; c.sHk = sH + j * (2 * 35 * 16); c.sS = sS; c.sG = sG; c.sEHk = sEH + j * 16;
             c.sE = smem + DEC_LDS_E;
             c.nfr = nfr; c.tabs = tbase + t0;
-            gtconv_block<true>(x, tt, c, L STAMP_ARG);
+            gtconv_block<true>(x, tt, c, L, hook STAMP_ARG);
             if (DBG)
 #pragma unroll
                 for (int i = 0; i < TPW; ++i)
@@ -1157,26 +1169,23 @@ __global__ __launch_bounds__(NTHR) void k_decoder(const float* __restrict__ xg, 
 #pragma unroll
             for (int i = 0; i < TPW; ++i) x[i] += skv[i];
             STAMP(SS, 8)
-        }
+        };
+#pragma unroll 1
+        for (int j = 0; j < 2; ++j) run_block(j, [] {});
+        run_block(2, [&] {
+            const float* en0c = en0 + (long)t0 * (F1 * 16);
+#pragma unroll
+            for (int i = 0; i < TPW; ++i) {
+                // record of output bin 2f (even) and 2f+1 (odd; for f = 32 the clamped record is unused)
+                const unsigned o0 = (unsigned)((tt.pp(i) < npos ? tt.tl[i] * F1 + 2 * tt.ff[i] : 0) * 16 + 4 * g);
+                s0e[i] = ld4(en0c + o0);
+                s0o[i] = ld4(en0c + o0 + (tt.ff[i] < 32 ? 16u : 0u));
+            }
+        });
         // ---- de_convs.3: gather form; input image in sW rows (pad columns are zero).  Every wave is
         // past the last block's tap reads (they precede that block's 2nd barrier), so sW is free.
-        f32x4 s0e[TPW], s0o[TPW];   // en_outs[0] for the even / odd output bins, fetched early
 #pragma unroll
-        for (int i = 0; i < TPW; ++i) {
-            st4(sW + o35(tt, i, g), x[i]);
-            // en0 record of output bin 2f (even) and 2f+1 (odd; for f = 32 the clamped record is unused)
-            const float* en0c = en0 + (long)t0 * (F1 * 16);
-            const unsigned o0 = (unsigned)((tt.pp(i) < npos ? tt.tl[i] * F1 + 2 * tt.ff[i] : 0) * 16 + 4 * g);
-            s0e[i] = ld4(en0c + o0);
-            s0o[i] = ld4(en0c + o0 + (tt.ff[i] < 32 ? 16u : 0u));
-        }
-        // next chunk's input: x is dead from here on, so its registers are reused for the prefetch
-        if (t0 + TC < T) {
-            const int npn = min(TC, T - t0 - TC) * 33;
-            const float* xgn = xg + (long)(t0 + TC) * 528;
-#pragma unroll
-            for (int i = 0; i < TPW; ++i) xn[i] = ld4(xgn + (unsigned)((tt.pp(i) < npn ? tt.pp(i) : 0) * 16 + 4 * g));
-        }
+        for (int i = 0; i < TPW; ++i) st4(sW + o35(tt, i, g), x[i]);
         STAMP(SS, 9)
         wg_barrier();
         STAMP(SS, 10)
@@ -1270,6 +1279,13 @@ __global__ __launch_bounds__(NTHR) void k_decoder(const float* __restrict__ xg, 
         STAMP(SS, 15)
         wg_barrier();
         STAMP(SS, 12)
+        // next chunk's input: x is dead, so its registers are reused for the prefetch
+        if (t0 + TC < T) {
+            const int npn = min(TC, T - t0 - TC) * 33;
+            const float* xgn = xg + (long)(t0 + TC) * 528;
+#pragma unroll
+            for (int i = 0; i < TPW; ++i) xn[i] = ld4(xgn + (unsigned)((tt.pp(i) < npn ? tt.pp(i) : 0) * 16 + 4 * g));
+        }
         // de_convs.4 gather + BN + Tanh: m[o][f''] = tanh(b[o] + sum_k z[(f''+2-k)/2][o*5+k]).  Branch free:
         // even f'' = 2m takes k = 0,2,4 from rows m+1, m, m-1; odd f'' = 2m+1 takes k = 1,3 from rows m+1, m
         // and a zero slot (rows 10..15 of the de_conv4 slot matrix are zero); the end records are zero.
@@ -1299,8 +1315,11 @@ __global__ __launch_bounds__(NTHR) void k_decoder(const float* __restrict__ xg, 
             if (tq < nfr && f < NBINS) {
                 const f32x4 tb = ld4(sBS + f * 4);
                 const float* m0 = sM + tq * F0 + __float_as_int(tb[0]);
-                const float mr = tb[1] * m0[0] + tb[2] * m0[1];
-                const float mi = tb[1] * m0[TC * F0] + tb[2] * m0[TC * F0 + 1];
+                // second tap selected, not multiplied by a zero weight: for the last band it would read the
+                // first element of the next frame's row, which may be stale (0 * NaN)
+                const bool two = tb[2] != 0.f;
+                const float mr = tb[1] * m0[0] + (two ? tb[2] * m0[1] : 0.f);
+                const float mi = tb[1] * m0[TC * F0] + (two ? tb[2] * m0[TC * F0 + 1] : 0.f);
                 const float re = spv[q].x, im = spv[q].y;
                 *reinterpret_cast<float2*>(out + (long)f * osf + (long)(t0 + tq) * ost) =
                     make_float2(re * mr - im * mi, im * mr + re * mi);

@@ -187,3 +187,17 @@ def test_full_size_batch_invariance(dev, engines):
         y1 = eng.forward_wave(xg[b:b + 1].clone(), win)
         assert torch.equal(y1[0], y[b]), b
     assert bool(torch.isfinite(y).all())
+
+
+def test_no_dependence_on_stale_memory(dev, engines, oracles):
+    """Short, partial chunks after a poisoned large run: results must not depend on what earlier
+    launches left in the workspace or in LDS (0 * NaN hazards on out-of-range lanes)."""
+    eng = engines["rand"]
+    big = torch.full((64, 257, 40, 2), float("nan"), device="cuda")
+    eng.forward_spec(big)                                   # poisons workspace and LDS with NaN
+    rng = np.random.default_rng(5)
+    for T in (1, 3, 12, 15, 21):
+        spec = (rng.standard_normal((3, 257, T, 2)) * 0.5).astype(np.float32)
+        got = eng.forward_spec(cu(spec)).cpu().numpy()
+        assert np.isfinite(got).all(), T
+        assert rel_err(got, oracles["rand"].forward(spec)) < TOL, T
