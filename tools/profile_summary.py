@@ -29,7 +29,11 @@ def main():
     dst = os.path.join(ROOT, "profiles")
     os.makedirs(dst, exist_ok=True)
     # --- kernel stats
-    f = glob.glob(os.path.join(src, "trace", "**", "*kernel_stats.csv"), recursive=True)
+    # gpurun merges every call's output into the same directory: only the newest file of a pass counts
+    def newest(sub, pat):
+        f = glob.glob(os.path.join(src, sub, "**", pat), recursive=True)
+        return [max(f, key=os.path.getmtime)] if f else []
+    f = newest("trace", "*kernel_stats.csv")
     if f:
         rows = [r for r in csv.DictReader(open(f[0])) if short(r["Name"])]
         with open(os.path.join(dst, f"{tag}_kernel_stats.csv"), "w", newline="") as o:
@@ -42,7 +46,7 @@ def main():
     # --- PMC
     def pmc(sub):
         acc = defaultdict(lambda: defaultdict(list))
-        for f in glob.glob(os.path.join(src, sub, "**", "*counter_collection.csv"), recursive=True):
+        for f in newest(sub, "*counter_collection.csv"):
             for r in csv.DictReader(open(f)):
                 k = short(r["Kernel_Name"])
                 if k:
