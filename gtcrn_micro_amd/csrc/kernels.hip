@@ -1,7 +1,7 @@
 // kernels.hip -- gfx950 (MI355X / CDNA4) kernels of the GTCRN-Micro hot path.
 //
 // Design (DESIGN.md has the long form):
-//   * one workgroup (8 waves) owns one utterance / stream and walks it in time
+//   * one workgroup (11 waves) owns one utterance / stream and walks it in time
 //     chunks of TC = 16 frames; causal history lives in LDS rings, so nothing is
 //     recomputed and chunked == offline == streaming by construction.
 //   * every 16-channel activation is a "slot-space" tile: 16 consecutive
@@ -631,8 +631,9 @@ __global__ __launch_bounds__(NTHR) void k_encoder(const float* __restrict__ spec
             if (e < 2) sEB[row * EB_ROW + e * 130] = z;
             else sF0[row * F0_ROW + (e < 4 ? e - 2 : 127 + e)] = z;
         }
-        // ---- A0: stage [mag, re, im] of the chunk in LDS (structure of arrays, [c][tl][257]); the
-        //      magnitude (models/gtcrn_micro.py:514) is computed once per bin here -----------------------
+        // ---- A0: stage [mag, re, im] of the chunk in LDS; the magnitude (models/gtcrn_micro.py:514) is
+        //      computed once per bin here.  The 65 pass-through bins of ERB.bm (:63-67) go straight to
+        //      their place in EB; the 192 high bins are staged as [c][tl][257] for the band filters -------
 #pragma unroll
         for (int q = 0; q < SPEC_ITEMS; ++q) {
             int idx = tv + q * NTHR;
@@ -640,44 +641,56 @@ __global__ __launch_bounds__(NTHR) void k_encoder(const float* __restrict__ spec
             if (t_fast) { tl = idx & (TC - 1); f = idx >> 4; } else { f = idx % NBINS; tl = idx / NBINS; }
             if (tl < nfr && f < NBINS) {
                 const float2 v = spn[q];
-                float* d = sSpec + tl * NBINS + f;
+                const bool low = f < ERB_LOW;
+                float* d = low ? sEB + tl * EB_ROW + 1 + f : sSpec + tl * NBINS + f;
+                const int cs = low ? TC * EB_ROW : TC * NBINS;
                 d[0] = __builtin_amdgcn_sqrtf(v.x * v.x + v.y * v.y + 1e-12f);
-                d[TC * NBINS] = v.x;
-                d[2 * TC * NBINS] = v.y;
+                d[cs] = v.x;
+                d[2 * cs] = v.y;
             }
         }
+        STAMP(SS, 10)
         if (t0 + TC < T) spec_fetch(t0 + TC);
+        STAMP(SS, 11)
         wg_barrier();
-        // ---- A: ERB.bm: EB[c][tl][1 + j]; pass-through bins and bands in separate loops so that the
-        //      lanes of a wave carry similar work ------------------------------------------------------
-        for (int idx = tv; idx < 3 * nfr * ERB_LOW; idx += NTHR) {
-            const int j = idx % ERB_LOW, ct = idx / ERB_LOW, tl = ct % nfr, c = ct / nfr;
-            sEB[(c * TC + tl) * EB_ROW + 1 + j] = sSpec[(c * TC + tl) * NBINS + j];
-        }
-        for (int idx = tv; idx < 3 * nfr * ERB_BANDS; idx += NTHR) {
-            const int band = idx & (ERB_BANDS - 1), ct = idx >> 6, tl = ct % nfr, c = ct / nfr;
-            const float* sp = sSpec + (c * TC + tl) * NBINS + ERB_LOW + sI[I_ERB_LO + band];
-            const float* w = sP + E_ERB_W + band * ERB_MAXBW;
-            // fixed trip count so that all 12 taps are issued at once (a data-dependent loop serialises
-            // its LDS reads); taps beyond the band's width have zero weight but may read stale LDS past
-            // the row, which need not be finite, so they are selected away rather than multiplied by 0
-            const int cnt = sI[I_ERB_N + band];
-            float a0 = 0.f, a1 = 0.f;
+        STAMP(SS, 12)
+        // ---- A: ERB.bm bands: EB[c][tl][66 + band]; items run over all TC rows of the chunk image with
+        //      power-of-two index math (rows past a short last chunk are skipped).  NTHR is a multiple of
+        //      64, so a lane keeps its band for all its items: the band's weights are read once per chunk -----
+        {
+            static_assert(NTHR % ERB_BANDS == 0, "lane <-> band");
+            const int band = tv & (ERB_BANDS - 1);
+            const int lo = sI[I_ERB_LO + band], cnt = sI[I_ERB_N + band];
+            float w[ERB_MAXBW];
 #pragma unroll
-            for (int i = 0; i < ERB_MAXBW; i += 2) {
-                a0 += w[i] * (i < cnt ? sp[i] : 0.f);
-                a1 += w[i + 1] * (i + 1 < cnt ? sp[i + 1] : 0.f);
+            for (int i = 0; i < ERB_MAXBW; i += 4) {
+                const f32x4 t = ld4(sP + E_ERB_W + band * ERB_MAXBW + i);
+                // taps beyond the band's width may read stale LDS past the row, which need not be finite:
+                // they are selected away below rather than multiplied by their zero weight
+                w[i] = t[0]; w[i + 1] = t[1]; w[i + 2] = t[2]; w[i + 3] = t[3];
             }
-            sEB[(c * TC + tl) * EB_ROW + 1 + ERB_LOW + band] = a0 + a1;
+            for (int ct = tv >> 6; ct < 3 * TC; ct += NW) {
+                if ((ct & (TC - 1)) >= nfr) continue;
+                const float* sp = sSpec + ct * NBINS + ERB_LOW + lo;
+                float a0 = 0.f, a1 = 0.f;
+#pragma unroll
+                for (int i = 0; i < ERB_MAXBW; i += 2) {    // fixed trip count: all 12 LDS reads issue at once
+                    a0 += w[i] * (i < cnt ? sp[i] : 0.f);
+                    a1 += w[i + 1] * (i + 1 < cnt ? sp[i + 1] : 0.f);
+                }
+                sEB[ct * EB_ROW + 1 + ERB_LOW + band] = a0 + a1;
+            }
         }
+        STAMP(SS, 13)
         wg_barrier();
         STAMP(SS, 1)
-        // ---- B: SFE_Lite depthwise (1,3): F0[c][tl][2 + f] ---------------------------------------
-        for (int row = tv >> 6; row < 3 * nfr; row += NW) {       // one (channel, frame) row per wave pass
-            const int tl = row % nfr, c = row / nfr;
+        // ---- B: SFE_Lite depthwise (1,3): F0[c][tl][2 + f]; one (channel, frame) row per wave pass -------
+        for (int row = L.wave; row < 3 * TC; row += NW) {
+            const int tl = row & (TC - 1), c = row >> 4;
+            if (tl >= nfr) continue;
             const float w0 = sP[E_SFE_W + c * 3], w1 = sP[E_SFE_W + c * 3 + 1], w2 = sP[E_SFE_W + c * 3 + 2];
-            const float* e = sEB + (c * TC + tl) * EB_ROW;
-            float* d = sF0 + (c * TC + tl) * F0_ROW + 2;
+            const float* e = sEB + row * EB_ROW;
+            float* d = sF0 + row * F0_ROW + 2;
             for (int f = tv & 63; f < F0; f += 64) d[f] = w0 * e[f] + w1 * e[f + 1] + w2 * e[f + 2];
         }
         // zero the pad positions of E0 (columns 0,1,67,68 of each row): region A held the spectrogram

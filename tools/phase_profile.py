@@ -17,7 +17,7 @@ sys.path.insert(0, ROOT)
 os.environ["GTCRN_LIB_VARIANT"] = "stamps"
 
 PHASES = {
-    0: {0: "prologue", 1: "A erb(global)", 2: "B sfe", 3: "C en_conv0", 4: "D en_conv1", 5: "blk pc1", 6: "blk depth+pc2",
+    0: {0: "prologue", 10: "A0 stage spec", 11: "A0 fetch next (issue)", 12: "A0 barrier", 13: "A erb bands", 1: "A erb barrier", 2: "B sfe", 3: "C en_conv0", 4: "D en_conv1", 5: "blk pc1", 6: "blk depth+pc2",
         7: "blk tra reduce", 8: "blk apply+store", 9: "chunk end"},
     1: {0: "prologue", 1: "load x", 2: "conv1", 3: "taps+conv3", 4: "ring", 5: "store"},
     3: {0: "prologue", 1: "load x+en4", 5: "blk pc1", 6: "blk dense+pc2", 7: "blk tra reduce", 8: "blk apply+skip",
