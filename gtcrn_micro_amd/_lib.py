@@ -76,6 +76,14 @@ def lib():
     L.gtcrn_selftest_mfma.argtypes = [ci]
     L.gtcrn_timing_enable.argtypes = [_vp, ci]
     L.gtcrn_timing_read.argtypes = [_vp, ci, ctypes.c_char_p, ci, _c_f32p, ctypes.POINTER(ci)]
+    L.gtcrn_trainer_create.argtypes = [ctypes.POINTER(_vp), ci]
+    L.gtcrn_trainer_destroy.argtypes = [_vp]
+    L.gtcrn_trainer_destroy.restype = None
+    L.gtcrn_train_workspace_bytes.restype = cl
+    L.gtcrn_train_workspace_bytes.argtypes = [ci, ci]
+    L.gtcrn_train_forward.argtypes = [_vp, _vp, _vp, cl, cl, cl, _vp, cl, cl, cl, ci, ci, _vp]
+    L.gtcrn_train_backward.argtypes = [_vp, _vp, _vp, cl, cl, cl, _vp, cl, cl, cl, _vp, _vp]
+    L.gtcrn_train_tap.argtypes = [_vp, ctypes.c_char_p, _vp, ctypes.POINTER(cl), _vp]
     if L.gtcrn_abi_version() != 1:
         raise GtcrnError("libgtcrn_micro_hip.so ABI version mismatch")
     _lib = L
@@ -371,3 +379,82 @@ class Engine:
 
 def selftest_mfma(device=0):
     _check(lib().gtcrn_selftest_mfma(int(device)))
+
+
+class Trainer:
+    """Train-mode forward/backward of the model on one device (gtcrn_trainer): batch-statistics
+    BatchNorm, saved activations, gradients of the 248 trainable tensors in the canonical blob layout."""
+
+    def __init__(self, device=0):
+        self.device = int(device)
+        h = ctypes.c_void_p()
+        _check(lib().gtcrn_trainer_create(ctypes.byref(h), self.device))
+        self._h = h
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().gtcrn_trainer_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @staticmethod
+    def workspace_bytes(B, T):
+        return int(lib().gtcrn_train_workspace_bytes(int(B), int(T)))
+
+    def _check_blob(self, blob, what):
+        _require_cuda_f32(blob, what)
+        if blob.numel() != NPARAM_FLOATS or not blob.is_contiguous():
+            raise GtcrnError(f"{what} must be a contiguous tensor of {NPARAM_FLOATS} floats")
+
+    def forward(self, params, spec, out=None):
+        """params: canonical blob on the device (running statistics are updated in place); spec (B,257,T,2)."""
+        import torch
+        self._check_blob(params, "params")
+        _require_cuda_f32(spec, "spec")
+        if spec.dim() != 4 or spec.shape[1] != NBINS or spec.shape[3] != 2:
+            raise GtcrnError(f"spec must be (B,257,T,2), got {tuple(spec.shape)}")
+        if spec.stride(3) != 1:
+            spec = spec.contiguous()
+        B, _, T, _ = spec.shape
+        if out is None:
+            out = torch.empty((B, NBINS, T, 2), device=spec.device, dtype=torch.float32)
+        isb, isf, ist = _spec_strides(spec)
+        osb, osf, ost = _spec_strides(out)
+        with torch.cuda.device(self.device):
+            _check(lib().gtcrn_train_forward(self._h, params.data_ptr(), spec.data_ptr(), isb, isf, ist,
+                                             out.data_ptr(), osb, osf, ost, B, T, _stream_ptr()))
+        return out
+
+    def backward(self, params, spec, grad_out, grads=None):
+        """Gradients (canonical blob layout) of the most recent forward for the upstream gradient grad_out."""
+        import torch
+        self._check_blob(params, "params")
+        _require_cuda_f32(grad_out, "grad_out")
+        if spec.stride(3) != 1:
+            spec = spec.contiguous()
+        if grad_out.stride(3) != 1:
+            grad_out = grad_out.contiguous()
+        if grads is None:
+            grads = torch.empty(NPARAM_FLOATS, device=params.device, dtype=torch.float32)
+        self._check_blob(grads, "grads")
+        isb, isf, ist = _spec_strides(spec)
+        gsb, gsf, gst = _spec_strides(grad_out)
+        with torch.cuda.device(self.device):
+            _check(lib().gtcrn_train_backward(self._h, params.data_ptr(), spec.data_ptr(), isb, isf, ist,
+                                              grad_out.data_ptr(), gsb, gsf, gst, grads.data_ptr(), _stream_ptr()))
+        return grads
+
+    def tap(self, name):
+        """Train-mode activation of the most recent forward at a stage boundary, as (B,C,T,F)."""
+        import torch
+        sh = (ctypes.c_long * 4)()
+        _check(lib().gtcrn_train_tap(self._h, name.encode(), None, sh, None))
+        out = torch.empty(tuple(sh), device=f"cuda:{self.device}", dtype=torch.float32)
+        with torch.cuda.device(self.device):
+            _check(lib().gtcrn_train_tap(self._h, name.encode(), out.data_ptr(), sh, _stream_ptr()))
+        return out.permute(0, 3, 1, 2).contiguous()

@@ -10,8 +10,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libgtcrn_micro_hip.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-SOURCES = ["kernels.hip", "api.cpp", "pack.cpp"]
-HEADERS = ["kernels.h", "layout.h", "pack.h", os.path.join("..", "..", "include", "gtcrn_micro_hip.h")]
+SOURCES = ["kernels.hip", "api.cpp", "pack.cpp", "train_kernels.hip", "train.cpp"]
+HEADERS = ["kernels.h", "layout.h", "pack.h", "train_kernels.h", os.path.join("..", "..", "include", "gtcrn_micro_hip.h")]
 
 
 def _stale(target, deps):

@@ -49,6 +49,9 @@ constexpr int kNumKernels = 6;
 
 }  // namespace
 
+// train.cpp reports its errors through the same thread-local message
+extern "C" void gtcrn_set_error_(const char* msg) { g_err = msg ? msg : ""; }
+
 struct gtcrn_model {
     int device = 0;
     float* d_pf = nullptr;   // packed floats (gtl::P_FLOATS)

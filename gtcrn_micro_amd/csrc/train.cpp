@@ -1,0 +1,488 @@
+// train.cpp -- the train-mode forward/backward of GTCRN-Micro behind the C ABI (gtcrn_train_* in
+// include/gtcrn_micro_hip.h).  Host sequencing only; the arithmetic is in train_kernels.hip.
+//
+// Reference: GTCRNMicro.forward with every nn.BatchNorm2d in .train() mode (models/gtcrn_micro.py:
+// 506-532) and autograd's backward of it, as driven by train.py:239-288.  The model is a chain of
+// "units" conv -> BatchNorm(batch statistics) -> activation; the forward keeps, per unit, the conv
+// output y and the activation a (the next unit's input), which is all the backward needs
+// (z and xhat are recomputed from y and the saved statistics).
+#include "../../include/gtcrn_micro_hip.h"
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "pack.h"
+#include "train_kernels.h"
+
+extern "C" void gtcrn_set_error_(const char* msg);   // api.cpp: thread-local last error
+
+namespace {
+
+using gtt::ConvGeom;
+using gtt::DwGeom;
+
+int tfail(int code, const std::string& m) {
+    gtcrn_set_error_(m.c_str());
+    return code;
+}
+#define T_HIP(expr)                                                                                  \
+    do {                                                                                             \
+        hipError_t e_ = (expr);                                                                      \
+        if (e_ != hipSuccess) return tfail(GTCRN_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_)); \
+    } while (0)
+#define T_RUN(expr)                                                                                  \
+    do {                                                                                             \
+        int e_ = (expr);                                                                             \
+        if (e_ != 0) return tfail(GTCRN_ERR_HIP, std::string(#expr) + ": " +                         \
+                                  hipGetErrorString(static_cast<hipError_t>(e_)));                   \
+    } while (0)
+
+struct Unit {                 // conv (dense or depthwise) + BatchNorm + activation
+    bool dw = false;
+    ConvGeom cg{};
+    DwGeom dg{};
+    long o_w = -1, o_b = -1, o_bn = -1, o_slope = -1;   // float offsets into the canonical blob
+    int act = gtt::ACT_NONE;
+    int C = 16;               // channels of y
+    long n = 0;               // positions of y
+    const float* x = nullptr; // input tensor
+    float* y = nullptr;       // conv output (pre-BN)
+    float* a = nullptr;       // activation output
+    const float* res = nullptr;
+    float* stats = nullptr;   // mean[C], invstd[C]
+};
+
+struct GtBlock {              // GTConvBlock (models/gtcrn_micro.py:167-253)
+    Unit pc1, depth, pc2;
+    long o_tra = -1;          // tra.depth_conv.weight; then .bias, point_conv.weight, .bias
+    int Tt = 0;               // frames of the depth/pc2/TRA tensors (T, or T+2 for the transposed conv)
+    const float* xin = nullptr;  // block input (after the skip add in the decoder)
+    float* s = nullptr;       // decoder: x + skip
+    float *e = nullptr, *yt = nullptr, *g = nullptr, *out = nullptr;
+};
+
+struct TcnBlock {             // TCN (models/gtcrn_micro.py:256-310)
+    Unit c1, c2, c3;
+};
+
+}  // namespace
+
+struct gtcrn_trainer {
+    int device = 0;
+    int B = 0, T = 0;
+    bool planned = false, have_fwd = false;
+    float* arena = nullptr;
+    size_t arena_floats = 0;
+    float* fscratch = nullptr;    // wgrad / TRA partial sums
+    double* dscratch = nullptr;   // BatchNorm partial sums
+    std::map<std::string, long> off;   // parameter name -> blob offset
+    // plan
+    float *eb = nullptr, *f0 = nullptr;
+    Unit en0, en1, de3, de4;
+    GtBlock enc[3], dec[3];
+    TcnBlock tcn[8];
+    float *s3 = nullptr, *s4 = nullptr;
+    // backward buffers
+    float *dm = nullptr, *gs0 = nullptr, *gs[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    float *q1 = nullptr, *q2 = nullptr, *dy = nullptr, *dv = nullptr, *dhd = nullptr, *dh = nullptr, *tmp_tra = nullptr;
+    float *d65 = nullptr, *df0 = nullptr;
+    std::map<std::string, std::pair<const float*, std::vector<int>>> taps;  // name -> (ptr, {T', F, C})
+};
+
+namespace {
+
+struct Bump {
+    size_t used = 0;
+    float* base = nullptr;
+    float* take(size_t n) {
+        n = (n + 63) & ~size_t(63);
+        float* p = base ? base + used : nullptr;
+        used += n;
+        return p;
+    }
+};
+
+ConvGeom conv_geom(int B, int T, int Tout, int Fin, int Fout, int CinT, int cin_off, int Cin, int CoutT, int Cout,
+                   int nkt, int nkf, int t0, int t1, int t2, int f_mode, int sf, int pf, int w_co, int w_ci, int w_kt,
+                   int w_kf) {
+    ConvGeom g{};
+    g.B = B; g.Tin = T; g.Tout = Tout; g.Fin = Fin; g.Fout = Fout;
+    g.CinT = CinT; g.cin_off = cin_off; g.Cin = Cin; g.CoutT = CoutT; g.cout_off = 0; g.Cout = Cout;
+    g.nkt = nkt; g.nkf = nkf; g.t_off[0] = t0; g.t_off[1] = t1; g.t_off[2] = t2;
+    g.f_mode = f_mode; g.sf = sf; g.pf = pf; g.w_co = w_co; g.w_ci = w_ci; g.w_kt = w_kt; g.w_kf = w_kf;
+    g.accumulate = 0;
+    return g;
+}
+ConvGeom adjoint(const ConvGeom& g, int accumulate) {
+    ConvGeom a = g;
+    a.Tin = g.Tout; a.Tout = g.Tin; a.Fin = g.Fout; a.Fout = g.Fin;
+    a.CinT = g.CoutT; a.cin_off = g.cout_off; a.Cin = g.Cout;
+    a.CoutT = g.CinT; a.cout_off = g.cin_off; a.Cout = g.Cin;
+    for (int k = 0; k < 3; ++k) a.t_off[k] = -g.t_off[k];
+    a.f_mode = 1 - g.f_mode;
+    a.w_co = g.w_ci; a.w_ci = g.w_co;
+    a.accumulate = accumulate;
+    return a;
+}
+DwGeom adjoint(const DwGeom& g, int accumulate) {
+    DwGeom a = g;
+    a.Tin = g.Tout; a.Tout = g.Tin;
+    for (int k = 0; k < 3; ++k) { a.t_off[k] = -g.t_off[k]; a.f_off[k] = -g.f_off[k]; }
+    a.accumulate = accumulate;
+    return a;
+}
+
+long P(gtcrn_trainer* t, const std::string& name) {
+    auto it = t->off.find(name);
+    return it == t->off.end() ? -1 : it->second;
+}
+
+void unit_params(gtcrn_trainer* t, Unit& u, const std::string& conv, const std::string& bn, const std::string& act) {
+    u.o_w = P(t, conv + ".weight");
+    u.o_b = P(t, conv + ".bias");
+    u.o_bn = P(t, bn + ".weight");
+    u.o_slope = act.empty() ? -1 : P(t, act + ".weight");
+}
+
+void alloc_unit(Bump& b, Unit& u, long n, int C) {
+    u.n = n; u.C = C;
+    u.y = b.take((size_t)n * C);
+    u.a = b.take((size_t)n * C);
+    u.stats = b.take(32);
+}
+
+// lays out every tensor of one (B, T) problem in the arena; base == nullptr: size query
+size_t plan(gtcrn_trainer* t, int B, int T, float* base) {
+    Bump b;
+    b.base = base;
+    const long n129 = (long)B * T * 129, n65 = (long)B * T * 65, n33 = (long)B * T * 33;
+    const int T2 = T + 2;
+    const long n33x = (long)B * T2 * 33;
+    t->taps.clear();
+    t->eb = b.take(n129 * 3);
+    t->f0 = b.take(n129 * 3);
+    // encoder.en_convs.0/1: ConvBlock (models/gtcrn_micro.py:344-364)
+    t->en0.cg = conv_geom(B, T, T, 129, 65, 3, 0, 3, 16, 16, 1, 5, 0, 0, 0, 0, 2, 2, 15, 5, 5, 1);
+    unit_params(t, t->en0, "encoder.en_convs.0.conv", "encoder.en_convs.0.bn", "encoder.en_convs.0.act");
+    t->en0.act = gtt::ACT_PRELU; t->en0.x = t->f0;
+    alloc_unit(b, t->en0, n65, 16);
+    t->en1.cg = conv_geom(B, T, T, 65, 33, 16, 0, 16, 16, 16, 1, 5, 0, 0, 0, 0, 2, 2, 80, 5, 5, 1);
+    unit_params(t, t->en1, "encoder.en_convs.1.conv", "encoder.en_convs.1.bn", "encoder.en_convs.1.act");
+    t->en1.act = gtt::ACT_PRELU; t->en1.x = t->en0.a;
+    alloc_unit(b, t->en1, n33, 16);
+    t->taps["en0"] = {t->en0.a, {T, 65, 16}};
+    t->taps["en1"] = {t->en1.a, {T, 33, 16}};
+    const float* X = t->en1.a;
+    const float* skips[5] = {t->en0.a, t->en1.a, nullptr, nullptr, nullptr};
+    auto gt_block = [&](GtBlock& k, const std::string& p, bool deconv, const float* xin) {
+        const int Tt = deconv ? T2 : T;
+        const long nt = deconv ? n33x : n33;
+        k.Tt = Tt; k.xin = xin;
+        // point_conv1: Conv2d(8,16,1) weight [16][8] / ConvTranspose2d(8,16,1) weight [8][16]
+        k.pc1.cg = conv_geom(B, T, T, 33, 33, 16, 0, 8, 16, 16, 1, 1, 0, 0, 0, 0, 1, 0, deconv ? 1 : 8, deconv ? 16 : 1, 1, 1);
+        unit_params(t, k.pc1, p + ".point_conv1", p + ".point_bn1", p + ".point_act");
+        k.pc1.act = gtt::ACT_PRELU; k.pc1.x = xin;
+        alloc_unit(b, k.pc1, n33, 16);
+        if (deconv) {
+            // depth_conv: ConvTranspose2d(16,16,(3,3),padding=(0,1)), weight [in][out][kt][kf]; T+2 output frames
+            k.depth.cg = conv_geom(B, T, T2, 33, 33, 16, 0, 16, 16, 16, 3, 3, 0, -1, -2, 1, 1, 1, 9, 144, 3, 1);
+        } else {
+            // depth_conv: Conv2d(16,16,(3,3),padding=(0,1),groups=16) on the input padded by 2 frames in front
+            k.depth.dw = true;
+            DwGeom d{};
+            d.B = B; d.Tin = T; d.Tout = T; d.F = 33; d.C = 16; d.nkt = 3; d.nkf = 3;
+            d.t_off[0] = -2; d.t_off[1] = -1; d.t_off[2] = 0; d.f_off[0] = -1; d.f_off[1] = 0; d.f_off[2] = 1;
+            d.w_c = 9; d.w_kt = 3; d.w_kf = 1; d.accumulate = 0;
+            k.depth.dg = d;
+        }
+        unit_params(t, k.depth, p + ".depth_conv", p + ".depth_bn", p + ".depth_act");
+        k.depth.act = gtt::ACT_PRELU; k.depth.x = k.pc1.a;
+        alloc_unit(b, k.depth, nt, 16);
+        // point_conv2: Conv2d(16,8,1) weight [8][16] / ConvTranspose2d(16,8,1) weight [16][8]
+        k.pc2.cg = conv_geom(B, Tt, Tt, 33, 33, 16, 0, 16, 8, 8, 1, 1, 0, 0, 0, 0, 1, 0, deconv ? 1 : 16, deconv ? 8 : 1, 1, 1);
+        unit_params(t, k.pc2, p + ".point_conv2", p + ".point_bn2", "");
+        k.pc2.act = gtt::ACT_NONE; k.pc2.x = k.depth.a;
+        alloc_unit(b, k.pc2, nt, 8);
+        k.o_tra = P(t, p + ".tra.depth_conv.weight");
+        k.e = b.take((size_t)B * Tt * 8); k.yt = b.take((size_t)B * Tt * 8); k.g = b.take((size_t)B * Tt * 8);
+        k.out = b.take(n33 * 16);
+    };
+    for (int k = 0; k < 3; ++k) {
+        gt_block(t->enc[k], "encoder.en_convs." + std::to_string(k + 2), false, X);
+        X = t->enc[k].out;
+        skips[k + 2] = X;
+        t->taps["en" + std::to_string(k + 2)] = {X, {T, 33, 16}};
+    }
+    for (int i = 0; i < 8; ++i) {
+        TcnBlock& k = t->tcn[i];
+        const int d = 1 << (i & 3);
+        const std::string p = "gtcn" + std::to_string(i / 4 + 1) + ".blocks." + std::to_string(i & 3);
+        k.c1.cg = conv_geom(B, T, T, 33, 33, 16, 0, 16, 16, 16, 1, 1, 0, 0, 0, 0, 1, 0, 16, 1, 1, 1);
+        unit_params(t, k.c1, p + ".conv1", p + ".bn1", p + ".act1");
+        k.c1.act = gtt::ACT_PRELU; k.c1.x = X;
+        alloc_unit(b, k.c1, n33, 16);
+        k.c2.dw = true;
+        DwGeom g{};
+        g.B = B; g.Tin = T; g.Tout = T; g.F = 33; g.C = 16; g.nkt = 3; g.nkf = 1;
+        g.t_off[0] = -2 * d; g.t_off[1] = -d; g.t_off[2] = 0; g.f_off[0] = 0;
+        g.w_c = 3; g.w_kt = 1; g.w_kf = 1; g.accumulate = 0;
+        k.c2.dg = g;
+        unit_params(t, k.c2, p + ".conv2", p + ".bn2", p + ".act2");
+        k.c2.act = gtt::ACT_PRELU; k.c2.x = k.c1.a;
+        alloc_unit(b, k.c2, n33, 16);
+        k.c3.cg = k.c1.cg;
+        unit_params(t, k.c3, p + ".conv3", p + ".bn3", p + ".act3");
+        k.c3.act = gtt::ACT_PRELU; k.c3.x = k.c2.a; k.c3.res = X;
+        alloc_unit(b, k.c3, n33, 16);
+        X = k.c3.a;
+        if ((i & 3) == 3) t->taps["gtcn" + std::to_string(i / 4 + 1)] = {X, {T, 33, 16}};
+    }
+    for (int i = 0; i < 3; ++i) {
+        GtBlock& k = t->dec[i];
+        k.s = b.take(n33 * 16);
+        gt_block(k, "decoder.de_convs." + std::to_string(i), true, k.s);
+        k.pc1.x = k.s;
+        // the addends of s (previous output, skip) are needed by forward() only
+        (void)skips;
+        X = k.out;
+        t->taps["de" + std::to_string(i)] = {X, {T, 33, 16}};
+    }
+    t->s3 = b.take(n33 * 16);
+    // decoder.de_convs.3: ConvTranspose2d(16,16,(1,5),stride (1,2),padding (0,2)), weight [in][out][1][5]
+    t->de3.cg = conv_geom(B, T, T, 33, 65, 16, 0, 16, 16, 16, 1, 5, 0, 0, 0, 1, 2, 2, 5, 80, 5, 1);
+    unit_params(t, t->de3, "decoder.de_convs.3.conv", "decoder.de_convs.3.bn", "decoder.de_convs.3.act");
+    t->de3.act = gtt::ACT_PRELU; t->de3.x = t->s3;
+    alloc_unit(b, t->de3, n65, 16);
+    t->s4 = b.take(n65 * 16);
+    t->de4.cg = conv_geom(B, T, T, 65, 129, 16, 0, 16, 2, 2, 1, 5, 0, 0, 0, 1, 2, 2, 5, 10, 5, 1);
+    unit_params(t, t->de4, "decoder.de_convs.4.conv", "decoder.de_convs.4.bn", "");
+    t->de4.act = gtt::ACT_TANH; t->de4.x = t->s4;
+    alloc_unit(b, t->de4, n129, 2);
+    t->taps["de3"] = {t->de3.a, {T, 65, 16}};
+    t->taps["de4"] = {t->de4.a, {T, 129, 2}};
+    // ---- backward buffers
+    t->dm = b.take(n129 * 2);
+    t->gs0 = b.take(n65 * 16);
+    for (int i = 1; i < 5; ++i) t->gs[i] = b.take(n33 * 16);
+    t->q1 = b.take(n33 * 16); t->q2 = b.take(n33 * 16);
+    t->dy = b.take((size_t)std::max(std::max(n65 * 16, n33x * 16), n129 * 3));
+    t->dv = b.take(n33x * 8); t->dhd = b.take(n33x * 16); t->dh = b.take(n33 * 16);
+    t->tmp_tra = b.take((size_t)B * T2 * 8 * 3);
+    t->d65 = b.take(n65 * 16);
+    t->df0 = b.take(n129 * 3);
+    return b.used;
+}
+
+int ensure_plan(gtcrn_trainer* t, int B, int T) {
+    if (t->planned && t->B == B && t->T == T) return 0;
+    const size_t need = plan(t, B, T, nullptr);
+    if (need > t->arena_floats) {
+        T_HIP(hipDeviceSynchronize());
+        if (t->arena) (void)hipFree(t->arena);
+        t->arena = nullptr; t->arena_floats = 0;
+        T_HIP(hipMalloc(&t->arena, need * sizeof(float)));
+        t->arena_floats = need;
+    }
+    plan(t, B, T, t->arena);
+    t->B = B; t->T = T; t->planned = true; t->have_fwd = false;
+    return 0;
+}
+
+int unit_fwd(gtcrn_trainer* t, Unit& u, float* prm, hipStream_t s) {
+    if (u.dw) T_RUN(gtt::dw_fwd(u.dg, u.x, prm + u.o_w, prm + u.o_b, u.y, s));
+    else T_RUN(gtt::conv_fwd(u.cg, u.x, prm + u.o_w, prm + u.o_b, u.y, s));
+    float* bn = prm + u.o_bn;   // weight, bias, running_mean, running_var (consecutive in the blob)
+    T_RUN(gtt::bn_stats(u.y, u.n, u.C, u.stats, bn + 2 * u.C, bn + 3 * u.C, t->dscratch, s));
+    T_RUN(gtt::bn_act(u.y, u.n, u.C, u.stats, bn, bn + u.C, u.res, u.act, u.o_slope >= 0 ? prm + u.o_slope : nullptr,
+                      u.a, s));
+    return 0;
+}
+
+// da: gradient w.r.t. u.a (read only).  dx: where the data gradient goes (nullptr: not needed).
+int unit_bwd(gtcrn_trainer* t, Unit& u, const float* prm, float* grads, const float* da, float* dx, int dx_acc,
+             float* dres, int dres_acc, hipStream_t s) {
+    const float* bn = prm + u.o_bn;
+    float* gbn = grads + u.o_bn;
+    T_RUN(gtt::bn_act_bwd(da, u.y, u.n, u.C, u.stats, bn, bn + u.C, u.res, u.act,
+                          u.o_slope >= 0 ? prm + u.o_slope : nullptr, t->dy, dres, dres_acc, gbn, gbn + u.C,
+                          u.o_slope >= 0 ? grads + u.o_slope : nullptr, t->dscratch, s));
+    if (u.dw) {
+        T_RUN(gtt::dw_wgrad(u.dg, u.x, t->dy, grads + u.o_w, u.o_b >= 0 ? grads + u.o_b : nullptr, t->fscratch, s));
+        if (dx) T_RUN(gtt::dw_fwd(adjoint(u.dg, dx_acc), t->dy, prm + u.o_w, nullptr, dx, s));
+    } else {
+        T_RUN(gtt::conv_wgrad(u.cg, u.x, t->dy, grads + u.o_w, u.o_b >= 0 ? grads + u.o_b : nullptr, t->fscratch, s));
+        if (dx) T_RUN(gtt::conv_fwd(adjoint(u.cg, dx_acc), t->dy, prm + u.o_w, nullptr, dx, s));
+    }
+    return 0;
+}
+
+int gt_fwd(gtcrn_trainer* t, GtBlock& k, float* prm, hipStream_t s) {
+    int rc;
+    if ((rc = unit_fwd(t, k.pc1, prm, s))) return rc;
+    if ((rc = unit_fwd(t, k.depth, prm, s))) return rc;
+    if ((rc = unit_fwd(t, k.pc2, prm, s))) return rc;
+    const float* tr = prm + k.o_tra;   // depth_conv.weight[24], .bias[8], point_conv.weight[64], .bias[8]
+    T_RUN(gtt::tra_fwd(k.pc2.a, t->B, k.Tt, tr, tr + 24, tr + 32, tr + 96, k.e, k.yt, k.g, s));
+    T_RUN(gtt::gate_shuffle_fwd(k.pc2.a, k.g, k.xin, t->B, t->T, k.Tt, k.out, s));
+    return 0;
+}
+// dout: gradient of k.out; dxin: gradient of the block input (all 16 channels written)
+int gt_bwd(gtcrn_trainer* t, GtBlock& k, const float* prm, float* grads, const float* dout, float* dxin,
+           hipStream_t s) {
+    const float* tr = prm + k.o_tra;
+    float* gtr = grads + k.o_tra;
+    int rc;
+    T_RUN(gtt::tra_gate_shuffle_bwd(dout, k.pc2.a, k.g, k.e, k.yt, t->B, t->T, k.Tt, tr, tr + 32, t->dv, dxin, gtr,
+                                    gtr + 24, gtr + 32, gtr + 96, t->tmp_tra, t->fscratch, s));
+    if ((rc = unit_bwd(t, k.pc2, prm, grads, t->dv, t->dhd, 0, nullptr, 0, s))) return rc;
+    if ((rc = unit_bwd(t, k.depth, prm, grads, t->dhd, t->dh, 0, nullptr, 0, s))) return rc;
+    if ((rc = unit_bwd(t, k.pc1, prm, grads, t->dh, dxin, 0, nullptr, 0, s))) return rc;   // channels 0..7
+    return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int gtcrn_trainer_create(gtcrn_trainer** out, int device) {
+    if (!out) return tfail(GTCRN_ERR_ARG, "gtcrn_trainer_create: null out");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev)
+        return tfail(GTCRN_ERR_DEVICE, "gtcrn_trainer_create: no such HIP device (the training path has no CPU fallback)");
+    T_HIP(hipSetDevice(device));
+    gtcrn_trainer* t = new gtcrn_trainer();
+    t->device = device;
+    for (const auto& p : gtcrn::param_table()) t->off[p.name] = p.offset;
+    T_HIP(hipMalloc(&t->fscratch, sizeof(float) * gtt::MAX_PARTIALS * (9 * 256 + 16)));
+    T_HIP(hipMalloc(&t->dscratch, sizeof(double) * gtt::MAX_PARTIALS * 3 * 16 + 256));
+    *out = t;
+    return 0;
+}
+
+void gtcrn_trainer_destroy(gtcrn_trainer* t) {
+    if (!t) return;
+    if (t->arena) (void)hipFree(t->arena);
+    if (t->fscratch) (void)hipFree(t->fscratch);
+    if (t->dscratch) (void)hipFree(t->dscratch);
+    delete t;
+}
+
+long gtcrn_train_workspace_bytes(int B, int T) {
+    gtcrn_trainer tmp;
+    for (const auto& p : gtcrn::param_table()) tmp.off[p.name] = p.offset;
+    return (long)(plan(&tmp, B, T, nullptr) * sizeof(float));
+}
+
+int gtcrn_train_forward(gtcrn_trainer* t, float* d_params, const float* d_spec, long sb, long sf, long st,
+                        float* d_out, long ob, long of, long ot, int B, int T, void* stream) {
+    if (!t || !d_params || !d_spec || !d_out || B < 1 || T < 1)
+        return tfail(GTCRN_ERR_ARG, "gtcrn_train_forward: bad argument");
+    hipStream_t s = (hipStream_t)stream;
+    int rc = ensure_plan(t, B, T);
+    if (rc) return rc;
+    float* prm = d_params;
+    T_RUN(gtt::feat_fwd(d_spec, sb, sf, st, B, T, prm + P(t, "erb.erb_fc.weight"), t->eb, s));
+    {   // SFE_Lite: Conv2d(3,3,(1,3),padding (0,1),groups 3,bias=False), weight [3][1][1][3]
+        DwGeom g{};
+        g.B = B; g.Tin = T; g.Tout = T; g.F = 129; g.C = 3; g.nkt = 1; g.nkf = 3;
+        g.f_off[0] = -1; g.f_off[1] = 0; g.f_off[2] = 1; g.w_c = 3; g.w_kt = 3; g.w_kf = 1;
+        T_RUN(gtt::dw_fwd(g, t->eb, prm + P(t, "sfe.depth_conv.weight"), nullptr, t->f0, s));
+    }
+    if ((rc = unit_fwd(t, t->en0, prm, s))) return rc;
+    if ((rc = unit_fwd(t, t->en1, prm, s))) return rc;
+    for (int k = 0; k < 3; ++k)
+        if ((rc = gt_fwd(t, t->enc[k], prm, s))) return rc;
+    for (int i = 0; i < 8; ++i) {
+        if ((rc = unit_fwd(t, t->tcn[i].c1, prm, s))) return rc;
+        if ((rc = unit_fwd(t, t->tcn[i].c2, prm, s))) return rc;
+        if ((rc = unit_fwd(t, t->tcn[i].c3, prm, s))) return rc;
+    }
+    const long n33 = (long)B * T * 33 * 16, n65 = (long)B * T * 65 * 16;
+    const float* X = t->tcn[7].c3.a;
+    for (int i = 0; i < 3; ++i) {     // Decoder.forward: x = de_convs[i](x + en_outs[4 - i]) (models/gtcrn_micro.py:463-469)
+        T_RUN(gtt::add(X, t->enc[2 - i].out, t->dec[i].s, n33, s));
+        if ((rc = gt_fwd(t, t->dec[i], prm, s))) return rc;
+        X = t->dec[i].out;
+    }
+    T_RUN(gtt::add(X, t->en1.a, t->s3, n33, s));
+    if ((rc = unit_fwd(t, t->de3, prm, s))) return rc;
+    T_RUN(gtt::add(t->de3.a, t->en0.a, t->s4, n65, s));
+    if ((rc = unit_fwd(t, t->de4, prm, s))) return rc;
+    T_RUN(gtt::bs_mask_fwd(t->de4.a, d_spec, sb, sf, st, B, T, prm + P(t, "erb.ierb_fc.weight"), d_out, ob, of, ot, s));
+    t->have_fwd = true;
+    return 0;
+}
+
+int gtcrn_train_backward(gtcrn_trainer* t, const float* d_params, const float* d_spec, long sb, long sf, long st,
+                         const float* d_grad_out, long gb, long gf, long gt, float* d_grads, void* stream) {
+    if (!t || !d_params || !d_spec || !d_grad_out || !d_grads)
+        return tfail(GTCRN_ERR_ARG, "gtcrn_train_backward: bad argument");
+    if (!t->have_fwd) return tfail(GTCRN_ERR_STATE, "gtcrn_train_backward: no forward pass to differentiate");
+    hipStream_t s = (hipStream_t)stream;
+    const int B = t->B, T = t->T;
+    const float* prm = d_params;
+    float* G = d_grads;
+    int rc;
+    T_HIP(hipMemsetAsync(G, 0, sizeof(float) * GTCRN_NPARAM_FLOATS, s));
+    const long n33 = (long)B * T * 33 * 16, n65 = (long)B * T * 65 * 16;
+    T_RUN(gtt::bs_mask_bwd(d_grad_out, gb, gf, gt, d_spec, sb, sf, st, B, T, prm + P(t, "erb.ierb_fc.weight"), t->dm, s));
+    // de_convs.4 <- s4 = de3.a + en0.a : gs0 is the gradient of both addends
+    if ((rc = unit_bwd(t, t->de4, prm, G, t->dm, t->gs0, 0, nullptr, 0, s))) return rc;
+    if ((rc = unit_bwd(t, t->de3, prm, G, t->gs0, t->gs[1], 0, nullptr, 0, s))) return rc;   // gs[1]: d s3
+    // decoder blocks 2,1,0: d s_i is the gradient of the previous block's output and of the skip en_outs[4-i]
+    const float* dout = t->gs[1];
+    for (int i = 2; i >= 0; --i) {
+        float* ds = t->gs[4 - i];            // gs[2], gs[3], gs[4]
+        if ((rc = gt_bwd(t, t->dec[i], prm, G, dout, ds, s))) return rc;
+        dout = ds;
+    }
+    // GTCN: out = act3(bn3(conv3(..)) + x): dx = dz3 (residual) + conv1 data gradient
+    float* qa = t->q1;
+    float* qb = t->q2;
+    for (int i = 7; i >= 0; --i) {
+        TcnBlock& k = t->tcn[i];
+        if ((rc = unit_bwd(t, k.c3, prm, G, dout, t->dhd, 0, qa, 0, s))) return rc;     // dhd: d a2, qa: residual part
+        if ((rc = unit_bwd(t, k.c2, prm, G, t->dhd, t->dh, 0, nullptr, 0, s))) return rc;  // dh: d a1
+        if ((rc = unit_bwd(t, k.c1, prm, G, t->dh, qa, 1, nullptr, 0, s))) return rc;     // += conv1 data gradient
+        dout = qa;
+        float* tq = qa; qa = qb; qb = tq;
+    }
+    // encoder blocks 2,1,0: total gradient of en_outs[k+2] = main path + decoder skip
+    for (int k = 2; k >= 0; --k) {
+        T_RUN(gtt::add(dout, t->gs[k + 2], qa, n33, s));
+        if ((rc = gt_bwd(t, t->enc[k], prm, G, qa, qb, s))) return rc;
+        dout = qb;
+        float* tq = qa; qa = qb; qb = tq;
+    }
+    T_RUN(gtt::add(dout, t->gs[1], qa, n33, s));                    // d en1.a
+    if ((rc = unit_bwd(t, t->en1, prm, G, qa, t->d65, 0, nullptr, 0, s))) return rc;
+    T_RUN(gtt::add(t->d65, t->gs0, t->d65, n65, s));                // d en0.a
+    if ((rc = unit_bwd(t, t->en0, prm, G, t->d65, t->df0, 0, nullptr, 0, s))) return rc;
+    {   // SFE weight gradient (no bias); the ERB bank is frozen and the input is data: the chain ends here
+        DwGeom g{};
+        g.B = B; g.Tin = T; g.Tout = T; g.F = 129; g.C = 3; g.nkt = 1; g.nkf = 3;
+        g.f_off[0] = -1; g.f_off[1] = 0; g.f_off[2] = 1; g.w_c = 3; g.w_kt = 3; g.w_kf = 1;
+        T_RUN(gtt::dw_wgrad(g, t->eb, t->df0, G + P(t, "sfe.depth_conv.weight"), nullptr, t->fscratch, s));
+    }
+    return 0;
+}
+
+int gtcrn_train_tap(gtcrn_trainer* t, const char* name, float* d_out, long* shape4, void* stream) {
+    if (!t || !name) return tfail(GTCRN_ERR_ARG, "gtcrn_train_tap: bad argument");
+    if (!t->have_fwd) return tfail(GTCRN_ERR_STATE, "gtcrn_train_tap: no forward pass yet");
+    auto it = t->taps.find(name);
+    if (it == t->taps.end()) return tfail(GTCRN_ERR_ARG, std::string("gtcrn_train_tap: unknown stage ") + name);
+    const std::vector<int>& sh = it->second.second;   // T', F, C
+    if (shape4) { shape4[0] = t->B; shape4[1] = sh[0]; shape4[2] = sh[1]; shape4[3] = sh[2]; }
+    if (d_out)
+        T_HIP(hipMemcpyAsync(d_out, it->second.first, sizeof(float) * (size_t)t->B * sh[0] * sh[1] * sh[2],
+                             hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,90 @@
+// train_kernels.h -- launch interface between train.cpp (host) and train_kernels.hip (gfx950):
+// the train-mode forward/backward of the GTCRN-Micro model (reference: models/gtcrn_micro.py with
+// nn.BatchNorm2d in .train() mode, train.py:239-288).
+//
+// Unlike the inference kernels (kernels.hip), training is layer-at-a-time: train-mode BatchNorm
+// needs the statistics of a layer's output over the WHOLE batch before the next layer can run,
+// so every conv -> BN -> activation unit is a grid-wide pass over channels-last tensors
+// [B][T][F][C] (C = 2, 3, 8 or 16 floats per position), and the passes are HBM-streaming.
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace gtt {
+
+// A convolution over (time, frequency) on channels-last tensors, gather form:
+//   out[b, to, fo, cout_off + co] (+)= bias[co] + sum_{kt,kf,ci} W[co,ci,kt,kf] * in[b, to + t_off[kt], fi, cin_off + ci]
+//   f_mode 0 (Conv2d along F):           fi = fo * sf - pf + kf
+//   f_mode 1 (ConvTranspose2d along F):  fi = (fo + pf - kf) / sf   when divisible
+// Out-of-range taps read zero.  The adjoint (data gradient) of such a convolution is again one of
+// these with in/out swapped, t_off negated, f_mode flipped and the weight strides of ci/co swapped,
+// so one kernel serves Conv2d, ConvTranspose2d and both their data gradients.
+struct ConvGeom {
+    int B, Tin, Tout, Fin, Fout;
+    int CinT, cin_off, Cin;     // channels of the input tensor, first channel used, channels used
+    int CoutT, cout_off, Cout;
+    int nkt, nkf;
+    int t_off[3];
+    int f_mode, sf, pf;
+    int w_co, w_ci, w_kt, w_kf; // strides (floats) into the weight tensor in the reference's layout
+    int accumulate;             // 1: add to the existing output instead of overwriting it
+};
+
+// depthwise convolution (groups = channels), C channels:
+//   out[b,to,fo,c] (+)= bias[c] + sum_{kt,kf} W[c,kt,kf] * in[b, to + t_off[kt], fo + f_off[kf], c]
+struct DwGeom {
+    int B, Tin, Tout, F, C;
+    int nkt, nkf;
+    int t_off[3], f_off[3];
+    int w_c, w_kt, w_kf;
+    int accumulate;
+};
+
+enum Act { ACT_NONE = 0, ACT_PRELU = 1, ACT_TANH = 2 };
+
+constexpr int MAX_PARTIALS = 512;   // workgroups of a two-stage reduction
+
+int conv_fwd(const ConvGeom& g, const float* in, const float* w, const float* bias, float* out, hipStream_t s);
+// dW (and db when dbias != nullptr) of the convolution g: in = its input, dout = gradient of its output.
+// scratch: MAX_PARTIALS * (9*256 + 16) floats.
+int conv_wgrad(const ConvGeom& g, const float* in, const float* dout, float* dw, float* dbias, float* scratch,
+               hipStream_t s);
+int dw_fwd(const DwGeom& g, const float* in, const float* w, const float* bias, float* out, hipStream_t s);
+int dw_wgrad(const DwGeom& g, const float* in, const float* dout, float* dw, float* dbias, float* scratch,
+             hipStream_t s);
+
+// BatchNorm (train mode) of y [n][C]: batch statistics, running-statistics update (momentum 0.1, unbiased
+// variance), stats[0..C) = mean, stats[C..2C) = 1/sqrt(var + 1e-5).  scratch: MAX_PARTIALS * 2 * C doubles.
+int bn_stats(const float* y, long n, int C, float* stats, float* running_mean, float* running_var, double* scratch,
+             hipStream_t s);
+// a = act(gamma * (y - mean) * invstd + beta [+ res])
+int bn_act(const float* y, long n, int C, const float* stats, const float* gamma, const float* beta,
+           const float* res, int act, const float* slope, float* a, hipStream_t s);
+// backward of the same: given da, writes dy (may alias da); if dres != nullptr: dres (+)= dz (dres_acc: add);
+// dgamma/dbeta [C], dslope [1] (PReLU) are WRITTEN.  scratch: MAX_PARTIALS * 3 * C doubles + 2 * C floats.
+int bn_act_bwd(const float* da, const float* y, long n, int C, const float* stats, const float* gamma,
+               const float* beta, const float* res, int act, const float* slope, float* dy, float* dres,
+               int dres_acc, float* dgamma, float* dbeta, float* dslope, double* scratch, hipStream_t s);
+
+// features: spec (strided (b,f,t) + re/im) -> EB [B][T][129][3] = ERB.bm([mag,re,im]) (models/gtcrn_micro.py:510-516)
+int feat_fwd(const float* spec, long sb, long sf, long st, int B, int T, const float* erb_w, float* eb,
+             hipStream_t s);
+// mask: m [B][T][129][2] -> ERB.bs -> complex ratio mask applied to spec (:472-482, 526-530)
+int bs_mask_fwd(const float* m, const float* spec, long sb, long sf, long st, int B, int T, const float* ierb_w,
+                float* out, long ob, long of, long ot, hipStream_t s);
+int bs_mask_bwd(const float* dout, long ob, long of, long ot, const float* spec, long sb, long sf, long st, int B,
+                int T, const float* ierb_w, float* dm, hipStream_t s);
+
+// TRALite (:122-139) on v [B][Tt][33][8]: e = mean_F v^2; y = dw conv1d k=3 causal; g = sigmoid(1x1(y))
+int tra_fwd(const float* v, int B, int Tt, const float* dw_w, const float* dw_b, const float* pw_w,
+            const float* pw_b, float* e, float* y, float* g, hipStream_t s);
+// out[b,t,f,2c] = v[b,t,f,c] * g[b,t,c], out[b,t,f,2c+1] = x[b,t,f,8+c]   (shuffle, :222-227), t < T
+int gate_shuffle_fwd(const float* v, const float* g, const float* x, int B, int T, int Tt, float* out, hipStream_t s);
+// backward of tra + gate + shuffle: dout [B][T][33][16] -> dv [B][Tt][33][8] (written), dx channels 8..15 (written),
+// parameter gradients written.  tmp: 3 * B*Tt*8 floats; scratch: MAX_PARTIALS * 80 floats.
+int tra_gate_shuffle_bwd(const float* dout, const float* v, const float* g, const float* e, const float* y, int B,
+                         int T, int Tt, const float* dw_w, const float* pw_w, float* dv, float* dx, float* d_dw_w,
+                         float* d_dw_b, float* d_pw_w, float* d_pw_b, float* tmp, float* scratch, hipStream_t s);
+
+int add(const float* a, const float* b, float* out, long n, hipStream_t s);
+
+}  // namespace gtt

@@ -1,0 +1,788 @@
+// train_kernels.hip -- gfx950 kernels of the train-mode forward/backward (see train_kernels.h).
+//
+// First correct version of the training row: every pass streams
+// channels-last tensors through HBM once, one thread per output position, fp32 VALU arithmetic,
+// two-stage reductions with a fixed summation order (bit-reproducible gradients; no atomics).
+// Reference semantics are cited per kernel (paths relative to the reference repo).
+#include <hip/hip_runtime.h>
+
+#include "train_kernels.h"
+
+namespace gtt {
+
+namespace {
+
+constexpr int NT = 256;
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+inline int grid_for(long n, int cap = 4096) {
+    long g = (n + NT - 1) / NT;
+    if (g < 1) g = 1;
+    if (g > cap) g = cap;
+    return (int)g;
+}
+
+// frequency index of the input tap (ConvGeom); false when the tap falls outside / between samples
+__device__ __forceinline__ bool tap_fi(const ConvGeom& g, int fo, int kf, int& fi) {
+    if (g.f_mode == 0) {
+        fi = fo * g.sf - g.pf + kf;
+    } else {
+        const int num = fo + g.pf - kf;
+        if (num < 0 || (num % g.sf) != 0) return false;
+        fi = num / g.sf;
+    }
+    return fi >= 0 && fi < g.Fin;
+}
+
+template <int C>
+__device__ __forceinline__ void load_vec(const float* p, float (&v)[C]) {
+    if constexpr (C % 4 == 0) {
+#pragma unroll
+        for (int i = 0; i < C; i += 4) {
+            const f32x4 t = *reinterpret_cast<const f32x4*>(p + i);
+            v[i] = t[0]; v[i + 1] = t[1]; v[i + 2] = t[2]; v[i + 3] = t[3];
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < C; ++i) v[i] = p[i];
+    }
+}
+
+// ------------------------------------------------------------------------------ dense conv
+// nn.Conv2d / nn.ConvTranspose2d of ConvBlock (models/gtcrn_micro.py:142-164), GTConvBlock
+// (:167-253) and TCN conv1/conv3 (:268-287), and their data gradients.
+template <int CIN, int COUT>
+__global__ __launch_bounds__(NT) void k_conv(ConvGeom g, const float* __restrict__ in, const float* __restrict__ w,
+                                            const float* __restrict__ bias, float* __restrict__ out) {
+    __shared__ __attribute__((aligned(16))) float sW[9 * CIN * COUT];   // [tap][ci][co]
+    const int tid = threadIdx.x, ntap = g.nkt * g.nkf;
+    for (int i = tid; i < ntap * CIN * COUT; i += NT) {
+        const int tap = i / (CIN * COUT), r = i - tap * (CIN * COUT), ci = r / COUT, co = r - ci * COUT;
+        const int kt = tap / g.nkf, kf = tap - kt * g.nkf;
+        sW[i] = w[co * g.w_co + ci * g.w_ci + kt * g.w_kt + kf * g.w_kf];
+    }
+    __syncthreads();
+    const long npos = (long)g.B * g.Tout * g.Fout;
+    for (long p = (long)blockIdx.x * NT + tid; p < npos; p += (long)gridDim.x * NT) {
+        const int fo = (int)(p % g.Fout);
+        const long bt = p / g.Fout;
+        const int to = (int)(bt % g.Tout), b = (int)(bt / g.Tout);
+        float acc[COUT];
+#pragma unroll
+        for (int co = 0; co < COUT; ++co) acc[co] = bias ? bias[co] : 0.f;
+        for (int kt = 0; kt < g.nkt; ++kt) {
+            const int ti = to + g.t_off[kt];
+            if (ti < 0 || ti >= g.Tin) continue;
+            for (int kf = 0; kf < g.nkf; ++kf) {
+                int fi;
+                if (!tap_fi(g, fo, kf, fi)) continue;
+                float xv[CIN];
+                load_vec<CIN>(in + (((long)b * g.Tin + ti) * g.Fin + fi) * g.CinT + g.cin_off, xv);
+                const float* wt = sW + (kt * g.nkf + kf) * CIN * COUT;
+#pragma unroll
+                for (int ci = 0; ci < CIN; ++ci)
+#pragma unroll
+                    for (int co = 0; co < COUT; ++co) acc[co] = fmaf(wt[ci * COUT + co], xv[ci], acc[co]);
+            }
+        }
+        float* o = out + p * g.CoutT + g.cout_off;
+#pragma unroll
+        for (int co = 0; co < COUT; ++co) o[co] = g.accumulate ? o[co] + acc[co] : acc[co];
+    }
+}
+
+// weight / bias gradient: dW[co,ci,kt,kf] = sum_pos dout[pos,co] * in[tap(pos),ci]; one (ci,co) pair per
+// thread, rows (b,t) staged in LDS, per-workgroup partial sums, summed in a fixed order by k_wgrad_finish.
+template <int CIN, int COUT>
+__global__ __launch_bounds__(NT) void k_conv_wgrad(ConvGeom g, const float* __restrict__ in,
+                                                  const float* __restrict__ dout, float* __restrict__ partial) {
+    __shared__ float sD[1040];
+    __shared__ float sX[3][1040];
+    const int tid = threadIdx.x, ntap = g.nkt * g.nkf;
+    const bool active = tid < CIN * COUT;
+    const int ci = tid / COUT, co = tid - ci * COUT;
+    float acc[9], accb = 0.f;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) acc[k] = 0.f;
+    const long rows = (long)g.B * g.Tout;
+    for (long row = blockIdx.x; row < rows; row += gridDim.x) {
+        const int b = (int)(row / g.Tout), to = (int)(row - (long)b * g.Tout);
+        __syncthreads();
+        for (int i = tid; i < g.Fout * COUT; i += NT)
+            sD[i] = dout[(row * g.Fout + i / COUT) * g.CoutT + g.cout_off + i % COUT];
+        for (int kt = 0; kt < g.nkt; ++kt) {
+            const int ti = to + g.t_off[kt];
+            const bool ok = ti >= 0 && ti < g.Tin;
+            for (int i = tid; i < g.Fin * CIN; i += NT)
+                sX[kt][i] = ok ? in[(((long)b * g.Tin + ti) * g.Fin + i / CIN) * g.CinT + g.cin_off + i % CIN] : 0.f;
+        }
+        __syncthreads();
+        if (active) {
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) {
+                if (tap < ntap) {
+                    const int kt = tap / g.nkf, kf = tap - kt * g.nkf;
+                    float a = 0.f;
+                    for (int fo = 0; fo < g.Fout; ++fo) {
+                        int fi;
+                        if (tap_fi(g, fo, kf, fi)) a = fmaf(sD[fo * COUT + co], sX[kt][fi * CIN + ci], a);
+                    }
+                    acc[tap] += a;
+                }
+            }
+            if (ci == 0) {
+                float a = 0.f;
+                for (int fo = 0; fo < g.Fout; ++fo) a += sD[fo * COUT + co];
+                accb += a;
+            }
+        }
+    }
+    float* pp = partial + (long)blockIdx.x * (9 * CIN * COUT + COUT);
+    if (active) {
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) pp[tap * CIN * COUT + tid] = acc[tap];
+        if (ci == 0) pp[9 * CIN * COUT + co] = accb;
+    }
+}
+
+__global__ void k_conv_wgrad_finish(ConvGeom g, int CIN, int COUT, const float* __restrict__ partial, int nparts,
+                                    float* __restrict__ dw, float* __restrict__ dbias) {
+    const int K = 9 * CIN * COUT + COUT, ntap = g.nkt * g.nkf;
+    for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < K; k += gridDim.x * blockDim.x) {
+        double s = 0.0;
+        for (int w = 0; w < nparts; ++w) s += partial[(long)w * K + k];
+        if (k >= 9 * CIN * COUT) {
+            if (dbias) dbias[k - 9 * CIN * COUT] = (float)s;
+        } else {
+            const int tap = k / (CIN * COUT), r = k - tap * (CIN * COUT), ci = r / COUT, co = r - ci * COUT;
+            if (tap < ntap) {
+                const int kt = tap / g.nkf, kf = tap - kt * g.nkf;
+                dw[co * g.w_co + ci * g.w_ci + kt * g.w_kt + kf * g.w_kf] = (float)s;
+            }
+        }
+    }
+}
+
+// -------------------------------------------------------------------------- depthwise conv
+// SFE_Lite (:77-90), encoder depth_conv groups=16 (:206-216), TCN conv2 (:273-281), + data gradients
+template <int C>
+__global__ __launch_bounds__(NT) void k_dw(DwGeom g, const float* __restrict__ in, const float* __restrict__ w,
+                                          const float* __restrict__ bias, float* __restrict__ out) {
+    __shared__ float sW[9 * C];   // [tap][c]
+    const int tid = threadIdx.x, ntap = g.nkt * g.nkf;
+    for (int i = tid; i < ntap * C; i += NT) {
+        const int tap = i / C, c = i - tap * C, kt = tap / g.nkf, kf = tap - kt * g.nkf;
+        sW[i] = w[c * g.w_c + kt * g.w_kt + kf * g.w_kf];
+    }
+    __syncthreads();
+    const long npos = (long)g.B * g.Tout * g.F;
+    for (long p = (long)blockIdx.x * NT + tid; p < npos; p += (long)gridDim.x * NT) {
+        const int fo = (int)(p % g.F);
+        const long bt = p / g.F;
+        const int to = (int)(bt % g.Tout), b = (int)(bt / g.Tout);
+        float acc[C];
+#pragma unroll
+        for (int c = 0; c < C; ++c) acc[c] = bias ? bias[c] : 0.f;
+        for (int kt = 0; kt < g.nkt; ++kt) {
+            const int ti = to + g.t_off[kt];
+            if (ti < 0 || ti >= g.Tin) continue;
+            for (int kf = 0; kf < g.nkf; ++kf) {
+                const int fi = fo + g.f_off[kf];
+                if (fi < 0 || fi >= g.F) continue;
+                float xv[C];
+                load_vec<C>(in + (((long)b * g.Tin + ti) * g.F + fi) * C, xv);
+                const float* wt = sW + (kt * g.nkf + kf) * C;
+#pragma unroll
+                for (int c = 0; c < C; ++c) acc[c] = fmaf(wt[c], xv[c], acc[c]);
+            }
+        }
+        float* o = out + p * C;
+#pragma unroll
+        for (int c = 0; c < C; ++c) o[c] = g.accumulate ? o[c] + acc[c] : acc[c];
+    }
+}
+
+template <int C>
+__global__ __launch_bounds__(NT) void k_dw_wgrad(DwGeom g, const float* __restrict__ in,
+                                                const float* __restrict__ dout, float* __restrict__ partial) {
+    __shared__ float sD[129 * C];
+    __shared__ float sX[3][129 * C];
+    const int tid = threadIdx.x, ntap = g.nkt * g.nkf;
+    const int tap = tid / C, c = tid - tap * C;
+    const bool active = tap < ntap, bias_thread = tid >= 9 * C && tid < 10 * C;
+    float acc = 0.f;
+    const long rows = (long)g.B * g.Tout;
+    for (long row = blockIdx.x; row < rows; row += gridDim.x) {
+        const int b = (int)(row / g.Tout), to = (int)(row - (long)b * g.Tout);
+        __syncthreads();
+        for (int i = tid; i < g.F * C; i += NT) sD[i] = dout[row * g.F * C + i];
+        for (int kt = 0; kt < g.nkt; ++kt) {
+            const int ti = to + g.t_off[kt];
+            const bool ok = ti >= 0 && ti < g.Tin;
+            for (int i = tid; i < g.F * C; i += NT) sX[kt][i] = ok ? in[((long)b * g.Tin + ti) * g.F * C + i] : 0.f;
+        }
+        __syncthreads();
+        if (active) {
+            const int kt = tap / g.nkf, kf = tap - kt * g.nkf;
+            float a = 0.f;
+            for (int fo = 0; fo < g.F; ++fo) {
+                const int fi = fo + g.f_off[kf];
+                if (fi >= 0 && fi < g.F) a = fmaf(sD[fo * C + c], sX[kt][fi * C + c], a);
+            }
+            acc += a;
+        } else if (bias_thread) {
+            float a = 0.f;
+            for (int fo = 0; fo < g.F; ++fo) a += sD[fo * C + (tid - 9 * C)];
+            acc += a;
+        }
+    }
+    if (tid < 10 * C) partial[(long)blockIdx.x * (10 * C) + tid] = (active || bias_thread) ? acc : 0.f;
+}
+
+__global__ void k_dw_wgrad_finish(DwGeom g, const float* __restrict__ partial, int nparts, float* __restrict__ dw,
+                                  float* __restrict__ dbias) {
+    const int C = g.C, K = 10 * C, ntap = g.nkt * g.nkf;
+    for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < K; k += gridDim.x * blockDim.x) {
+        double s = 0.0;
+        for (int w = 0; w < nparts; ++w) s += partial[(long)w * K + k];
+        const int tap = k / C, c = k - tap * C;
+        if (tap == 9) {
+            if (dbias) dbias[c] = (float)s;
+        } else if (tap < ntap) {
+            const int kt = tap / g.nkf, kf = tap - kt * g.nkf;
+            dw[c * g.w_c + kt * g.w_kt + kf * g.w_kf] = (float)s;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------ BatchNorm
+// nn.BatchNorm2d in train mode (ConvBlock :159, GTConvBlock :190/:218/:222, TCN :269/:282/:286):
+// biased batch variance for the normalisation, unbiased for the running estimate, momentum 0.1, eps 1e-5.
+// The flat index of a thread advances by a multiple of C, so a thread sees one channel only.
+template <int NV>
+__device__ __forceinline__ void block_reduce_store(double (&v)[NV], int C, double* sh, double* dst) {
+    // threads with the same (tid % C) hold partial sums of one channel; NT % C == 0
+    const int tid = threadIdx.x;
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+        __syncthreads();
+        sh[tid] = v[k];
+        __syncthreads();
+        if (tid < C) {
+            double s = 0.0;
+            for (int i = tid; i < NT; i += C) s += sh[i];
+            dst[k * C + tid] = s;
+        }
+    }
+}
+
+__global__ __launch_bounds__(NT) void k_bn_stats(const float* __restrict__ y, long total, int C,
+                                                double* __restrict__ partial) {
+    __shared__ double sh[NT];
+    double v[2] = {0.0, 0.0};
+    for (long i = (long)blockIdx.x * NT + threadIdx.x; i < total; i += (long)gridDim.x * NT) {
+        const double x = y[i];
+        v[0] += x;
+        v[1] += x * x;
+    }
+    block_reduce_store<2>(v, C, sh, partial + (long)blockIdx.x * 2 * C);
+}
+
+__global__ void k_bn_stats_finish(const double* __restrict__ partial, int nparts, long n, int C,
+                                  float* __restrict__ stats, float* __restrict__ rmean, float* __restrict__ rvar) {
+    const int c = threadIdx.x;
+    if (c >= C) return;
+    double s = 0.0, q = 0.0;
+    for (int w = 0; w < nparts; ++w) {
+        s += partial[(long)w * 2 * C + c];
+        q += partial[(long)w * 2 * C + C + c];
+    }
+    const double mean = s / (double)n;
+    double var = q / (double)n - mean * mean;
+    if (var < 0.0) var = 0.0;
+    stats[c] = (float)mean;
+    stats[C + c] = (float)(1.0 / sqrt(var + 1e-5));
+    if (rmean) {
+        const double unb = n > 1 ? var * (double)n / (double)(n - 1) : var;
+        rmean[c] = (float)(0.9 * (double)rmean[c] + 0.1 * mean);
+        rvar[c] = (float)(0.9 * (double)rvar[c] + 0.1 * unb);
+    }
+}
+
+__device__ __forceinline__ float act_fwd(float z, int act, float slope) {
+    if (act == ACT_PRELU) return z > 0.f ? z : slope * z;     // nn.PReLU(), one shared slope
+    if (act == ACT_TANH) return tanhf(z);
+    return z;
+}
+
+__global__ __launch_bounds__(NT) void k_bn_act(const float* __restrict__ y, long total, int C,
+                                              const float* __restrict__ stats, const float* __restrict__ gamma,
+                                              const float* __restrict__ beta, const float* __restrict__ res, int act,
+                                              const float* __restrict__ slope, float* __restrict__ a) {
+    const float sl = slope ? slope[0] : 0.f;
+    for (long i = (long)blockIdx.x * NT + threadIdx.x; i < total; i += (long)gridDim.x * NT) {
+        const int c = (int)(i % C);
+        float z = gamma[c] * ((y[i] - stats[c]) * stats[C + c]) + beta[c];
+        if (res) z += res[i];
+        a[i] = act_fwd(z, act, sl);
+    }
+}
+
+// backward, pass 1: S1 = sum dz, S2 = sum dz * xhat, S3 = sum da * min(z, 0) (PReLU slope gradient)
+__global__ __launch_bounds__(NT) void k_bn_bwd_reduce(const float* __restrict__ da, const float* __restrict__ y,
+                                                     long total, int C, const float* __restrict__ stats,
+                                                     const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                     const float* __restrict__ res, int act,
+                                                     const float* __restrict__ slope, double* __restrict__ partial) {
+    __shared__ double sh[NT];
+    const float sl = slope ? slope[0] : 0.f;
+    double v[3] = {0.0, 0.0, 0.0};
+    for (long i = (long)blockIdx.x * NT + threadIdx.x; i < total; i += (long)gridDim.x * NT) {
+        const int c = (int)(i % C);
+        const float xh = (y[i] - stats[c]) * stats[C + c];
+        float z = gamma[c] * xh + beta[c];
+        if (res) z += res[i];
+        const float g = da[i];
+        float dz = g;
+        if (act == ACT_PRELU) {
+            dz = z > 0.f ? g : sl * g;
+            v[2] += z > 0.f ? 0.0 : (double)(g * z);
+        } else if (act == ACT_TANH) {
+            const float t = tanhf(z);
+            dz = g * (1.f - t * t);
+        }
+        v[0] += dz;
+        v[1] += (double)dz * xh;
+    }
+    block_reduce_store<3>(v, C, sh, partial + (long)blockIdx.x * 3 * C);
+}
+
+__global__ void k_bn_bwd_finish(const double* __restrict__ partial, int nparts, long n, int C,
+                                float* __restrict__ red, float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                float* __restrict__ dslope) {
+    __shared__ double s3[16];
+    const int c = threadIdx.x;
+    if (c < C) {
+        double s1 = 0.0, s2 = 0.0, t3 = 0.0;
+        for (int w = 0; w < nparts; ++w) {
+            s1 += partial[(long)w * 3 * C + c];
+            s2 += partial[(long)w * 3 * C + C + c];
+            t3 += partial[(long)w * 3 * C + 2 * C + c];
+        }
+        red[c] = (float)(s1 / (double)n);
+        red[C + c] = (float)(s2 / (double)n);
+        if (dgamma) dgamma[c] = (float)s2;
+        if (dbeta) dbeta[c] = (float)s1;
+        s3[c] = t3;
+    }
+    __syncthreads();
+    if (c == 0 && dslope) {
+        double t = 0.0;
+        for (int i = 0; i < C; ++i) t += s3[i];
+        dslope[0] = (float)t;
+    }
+}
+
+// pass 2: dy = gamma * invstd * (dz - mean(dz) - xhat * mean(dz * xhat)); dres (+)= dz
+__global__ __launch_bounds__(NT) void k_bn_bwd_apply(const float* __restrict__ da, const float* __restrict__ y,
+                                                    long total, int C, const float* __restrict__ stats,
+                                                    const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                    const float* __restrict__ res, int act,
+                                                    const float* __restrict__ slope, const float* __restrict__ red,
+                                                    float* __restrict__ dy, float* __restrict__ dres, int dres_acc) {
+    const float sl = slope ? slope[0] : 0.f;
+    for (long i = (long)blockIdx.x * NT + threadIdx.x; i < total; i += (long)gridDim.x * NT) {
+        const int c = (int)(i % C);
+        const float xh = (y[i] - stats[c]) * stats[C + c];
+        float z = gamma[c] * xh + beta[c];
+        if (res) z += res[i];
+        const float g = da[i];
+        float dz = g;
+        if (act == ACT_PRELU) dz = z > 0.f ? g : sl * g;
+        else if (act == ACT_TANH) { const float t = tanhf(z); dz = g * (1.f - t * t); }
+        if (dres) dres[i] = dres_acc ? dres[i] + dz : dz;
+        dy[i] = gamma[c] * stats[C + c] * (dz - red[c] - xh * red[C + c]);
+    }
+}
+
+// --------------------------------------------------------------------------- features, mask
+// GTCRNMicro.forward prologue + ERB.bm (models/gtcrn_micro.py:510-516, :63-67): one thread per (b,t,j)
+__global__ __launch_bounds__(NT) void k_feat(const float* __restrict__ spec, long sb, long sf, long st, int B, int T,
+                                            const float* __restrict__ erb_w, float* __restrict__ eb) {
+    const long total = (long)B * T * 129;
+    for (long p = (long)blockIdx.x * NT + threadIdx.x; p < total; p += (long)gridDim.x * NT) {
+        const int j = (int)(p % 129);
+        const long bt = p / 129;
+        const int t = (int)(bt % T), b = (int)(bt / T);
+        const float* x = spec + (long)b * sb + (long)t * st;
+        float m = 0.f, re = 0.f, im = 0.f;
+        if (j < 65) {
+            re = x[(long)j * sf]; im = x[(long)j * sf + 1];
+            m = sqrtf(re * re + im * im + 1e-12f);
+        } else {
+            const float* w = erb_w + (long)(j - 65) * 192;
+            for (int i = 0; i < 192; ++i) {
+                const float wi = w[i];
+                if (wi != 0.f) {
+                    const float r = x[(long)(65 + i) * sf], q = x[(long)(65 + i) * sf + 1];
+                    m = fmaf(wi, sqrtf(r * r + q * q + 1e-12f), m);
+                    re = fmaf(wi, r, re);
+                    im = fmaf(wi, q, im);
+                }
+            }
+        }
+        eb[p * 3] = m; eb[p * 3 + 1] = re; eb[p * 3 + 2] = im;
+    }
+}
+
+// ERB.bs (:69-73) + Mask (:472-482) + output permute (:529-530): one thread per (b,t,f)
+__global__ __launch_bounds__(NT) void k_bs_mask(const float* __restrict__ m, const float* __restrict__ spec, long sb,
+                                               long sf, long st, int B, int T, const float* __restrict__ ierb_w,
+                                               float* __restrict__ out, long ob, long of, long ot) {
+    const long total = (long)B * T * 257;
+    for (long p = (long)blockIdx.x * NT + threadIdx.x; p < total; p += (long)gridDim.x * NT) {
+        const int f = (int)(p % 257);
+        const long bt = p / 257;
+        const int t = (int)(bt % T), b = (int)(bt / T);
+        const float* mm = m + bt * 129 * 2;
+        float m0 = 0.f, m1 = 0.f;
+        if (f < 65) {
+            m0 = mm[f * 2]; m1 = mm[f * 2 + 1];
+        } else {
+            const float* w = ierb_w + (long)(f - 65) * 64;
+            for (int j = 0; j < 64; ++j) {
+                const float wj = w[j];
+                if (wj != 0.f) { m0 = fmaf(wj, mm[(65 + j) * 2], m0); m1 = fmaf(wj, mm[(65 + j) * 2 + 1], m1); }
+            }
+        }
+        const float* x = spec + (long)b * sb + (long)t * st + (long)f * sf;
+        float* o = out + (long)b * ob + (long)t * ot + (long)f * of;
+        o[0] = x[0] * m0 - x[1] * m1;
+        o[1] = x[1] * m0 + x[0] * m1;
+    }
+}
+
+__global__ __launch_bounds__(NT) void k_bs_mask_bwd(const float* __restrict__ dout, long ob, long of, long ot,
+                                                   const float* __restrict__ spec, long sb, long sf, long st, int B,
+                                                   int T, const float* __restrict__ ierb_w, float* __restrict__ dm) {
+    const long total = (long)B * T * 129;
+    for (long p = (long)blockIdx.x * NT + threadIdx.x; p < total; p += (long)gridDim.x * NT) {
+        const int j = (int)(p % 129);
+        const long bt = p / 129;
+        const int t = (int)(bt % T), b = (int)(bt / T);
+        const float* x = spec + (long)b * sb + (long)t * st;
+        const float* d = dout + (long)b * ob + (long)t * ot;
+        float g0 = 0.f, g1 = 0.f;
+        if (j < 65) {
+            const float re = x[(long)j * sf], im = x[(long)j * sf + 1], dr = d[(long)j * of], di = d[(long)j * of + 1];
+            g0 = dr * re + di * im;
+            g1 = di * re - dr * im;
+        } else {
+            for (int i = 0; i < 192; ++i) {
+                const float wi = ierb_w[(long)i * 64 + (j - 65)];
+                if (wi != 0.f) {
+                    const int f = 65 + i;
+                    const float re = x[(long)f * sf], im = x[(long)f * sf + 1], dr = d[(long)f * of], di = d[(long)f * of + 1];
+                    g0 = fmaf(wi, dr * re + di * im, g0);
+                    g1 = fmaf(wi, di * re - dr * im, g1);
+                }
+            }
+        }
+        dm[p * 2] = g0; dm[p * 2 + 1] = g1;
+    }
+}
+
+// ---------------------------------------------------------------------------------- TRALite
+// TRALite.forward (models/gtcrn_micro.py:122-139) with a zero cache: e = mean_F(v^2); y = causal depthwise
+// conv1d (k=3, bias) over [0,0 | e]; g = sigmoid(point_conv(y)).  v: [B][Tt][33][8].
+__global__ __launch_bounds__(NT) void k_tra_energy(const float* __restrict__ v, long rows, float* __restrict__ e) {
+    for (long i = (long)blockIdx.x * NT + threadIdx.x; i < rows * 8; i += (long)gridDim.x * NT) {
+        const int c = (int)(i & 7);
+        const float* p = v + (i >> 3) * 33 * 8 + c;
+        float s = 0.f;
+        for (int f = 0; f < 33; ++f) s = fmaf(p[f * 8], p[f * 8], s);
+        e[i] = s * (1.0f / 33.0f);
+    }
+}
+__global__ __launch_bounds__(NT) void k_tra_gate(const float* __restrict__ e, int B, int Tt,
+                                                const float* __restrict__ dw_w, const float* __restrict__ dw_b,
+                                                const float* __restrict__ pw_w, const float* __restrict__ pw_b,
+                                                float* __restrict__ y, float* __restrict__ g) {
+    const long total = (long)B * Tt * 8;
+    for (long i = (long)blockIdx.x * NT + threadIdx.x; i < total; i += (long)gridDim.x * NT) {
+        const int co = (int)(i & 7);
+        const long row = i >> 3;
+        const int t = (int)(row % Tt);
+        float z = pw_b[co];
+        for (int c = 0; c < 8; ++c) {
+            float yc = dw_b[c];
+            for (int k = 0; k < 3; ++k) {
+                const int tt = t - 2 + k;
+                if (tt >= 0) yc = fmaf(dw_w[c * 3 + k], e[(row - 2 + k) * 8 + c], yc);
+            }
+            if (c == co) y[i] = yc;
+            z = fmaf(pw_w[co * 8 + c], yc, z);
+        }
+        g[i] = 1.0f / (1.0f + expf(-z));
+    }
+}
+// TRA gate + channel shuffle (:222-227, :246-253): out[2c] = v[c] * g[c], out[2c+1] = x2[c] = x[8+c]
+__global__ __launch_bounds__(NT) void k_gate_shuffle(const float* __restrict__ v, const float* __restrict__ g,
+                                                    const float* __restrict__ x, int B, int T, int Tt,
+                                                    float* __restrict__ out) {
+    const long total = (long)B * T * 33 * 8;
+    for (long i = (long)blockIdx.x * NT + threadIdx.x; i < total; i += (long)gridDim.x * NT) {
+        const int c = (int)(i & 7);
+        const long pos = i >> 3;                      // (b, t, f) over T frames
+        const int f = (int)(pos % 33);
+        const long bt = pos / 33;
+        const int t = (int)(bt % T), b = (int)(bt / T);
+        const long rowv = (long)b * Tt + t;
+        out[pos * 16 + 2 * c] = v[(rowv * 33 + f) * 8 + c] * g[rowv * 8 + c];
+        out[pos * 16 + 2 * c + 1] = x[pos * 16 + 8 + c];
+    }
+}
+// backward, step 1: dv = dout[2c] * g (0 on the trimmed tail frames), dx[8+c] = dout[2c+1]
+__global__ __launch_bounds__(NT) void k_gate_shuffle_bwd(const float* __restrict__ dout, const float* __restrict__ g,
+                                                        int B, int T, int Tt, float* __restrict__ dv,
+                                                        float* __restrict__ dx) {
+    const long total = (long)B * Tt * 33 * 8;
+    for (long i = (long)blockIdx.x * NT + threadIdx.x; i < total; i += (long)gridDim.x * NT) {
+        const int c = (int)(i & 7);
+        const long posv = i >> 3;
+        const int f = (int)(posv % 33);
+        const long rowv = posv / 33;
+        const int t = (int)(rowv % Tt), b = (int)(rowv / Tt);
+        float r = 0.f;
+        if (t < T) {
+            const long pos = ((long)b * T + t) * 33 + f;
+            r = dout[pos * 16 + 2 * c] * g[rowv * 8 + c];
+            dx[pos * 16 + 8 + c] = dout[pos * 16 + 2 * c + 1];
+        }
+        dv[i] = r;
+    }
+}
+// step 2: dg = sum_F dout[2c] * v  ->  dzg = dg * g * (1 - g)
+__global__ __launch_bounds__(NT) void k_tra_dgate(const float* __restrict__ dout, const float* __restrict__ v,
+                                                 const float* __restrict__ g, int B, int T, int Tt,
+                                                 float* __restrict__ dzg) {
+    const long total = (long)B * Tt * 8;
+    for (long i = (long)blockIdx.x * NT + threadIdx.x; i < total; i += (long)gridDim.x * NT) {
+        const int c = (int)(i & 7);
+        const long rowv = i >> 3;
+        const int t = (int)(rowv % Tt), b = (int)(rowv / Tt);
+        float s = 0.f;
+        if (t < T) {
+            const float* d = dout + (((long)b * T + t) * 33) * 16 + 2 * c;
+            const float* vv = v + rowv * 33 * 8 + c;
+            for (int f = 0; f < 33; ++f) s = fmaf(d[f * 16], vv[f * 8], s);
+        }
+        const float gg = g[i];
+        dzg[i] = s * gg * (1.f - gg);
+    }
+}
+// step 3: dy[c] = sum_co pw[co][c] * dzg[co]
+__global__ __launch_bounds__(NT) void k_tra_dy(const float* __restrict__ dzg, long rows, const float* __restrict__ pw_w,
+                                              float* __restrict__ dy) {
+    for (long i = (long)blockIdx.x * NT + threadIdx.x; i < rows * 8; i += (long)gridDim.x * NT) {
+        const int c = (int)(i & 7);
+        const float* d = dzg + (i >> 3) * 8;
+        float s = 0.f;
+        for (int co = 0; co < 8; ++co) s = fmaf(pw_w[co * 8 + c], d[co], s);
+        dy[i] = s;
+    }
+}
+// step 4: de[t][c] = sum_k dw[c][k] * dy[t + 2 - k][c];  dv += de * (2/33) * v
+__global__ __launch_bounds__(NT) void k_tra_dv(const float* __restrict__ dy, const float* __restrict__ v, int B, int Tt,
+                                              const float* __restrict__ dw_w, float* __restrict__ dv) {
+    const long total = (long)B * Tt * 8;
+    for (long i = (long)blockIdx.x * NT + threadIdx.x; i < total; i += (long)gridDim.x * NT) {
+        const int c = (int)(i & 7);
+        const long rowv = i >> 3;
+        const int t = (int)(rowv % Tt);
+        float de = 0.f;
+        for (int k = 0; k < 3; ++k) {
+            const int tt = t + 2 - k;
+            if (tt < Tt) de = fmaf(dw_w[c * 3 + k], dy[(rowv + 2 - k) * 8 + c], de);
+        }
+        de *= 2.0f / 33.0f;
+        const float* vv = v + rowv * 33 * 8 + c;
+        float* d = dv + rowv * 33 * 8 + c;
+        for (int f = 0; f < 33; ++f) d[f * 8] = fmaf(de, vv[f * 8], d[f * 8]);
+    }
+}
+// parameter gradients of the two conv1d: 104 sums over the rows (b,t), per-workgroup partials
+//   [0,64)  d pw_w[co][c] = sum dzg[co] * y[c]     [64,72)  d pw_b[co] = sum dzg[co]
+//   [72,96) d dw_w[c][k]  = sum dy[t][c] * e[t-2+k][c]   [96,104) d dw_b[c] = sum dy[c]
+__global__ __launch_bounds__(128) void k_tra_pgrad(const float* __restrict__ dzg, const float* __restrict__ y,
+                                                  const float* __restrict__ dy, const float* __restrict__ e, int B,
+                                                  int Tt, float* __restrict__ partial) {
+    const int tid = threadIdx.x;
+    if (tid >= 104) return;
+    const long rows = (long)B * Tt;
+    const long per = (rows + gridDim.x - 1) / gridDim.x;
+    const long r0 = (long)blockIdx.x * per, r1 = r0 + per < rows ? r0 + per : rows;
+    float s = 0.f;
+    for (long r = r0; r < r1; ++r) {
+        if (tid < 64) s = fmaf(dzg[r * 8 + (tid >> 3)], y[r * 8 + (tid & 7)], s);
+        else if (tid < 72) s += dzg[r * 8 + tid - 64];
+        else if (tid < 96) {
+            const int c = (tid - 72) / 3, k = (tid - 72) % 3, t = (int)(r % Tt);
+            if (t - 2 + k >= 0) s = fmaf(dy[r * 8 + c], e[(r - 2 + k) * 8 + c], s);
+        } else s += dy[r * 8 + tid - 96];
+    }
+    partial[(long)blockIdx.x * 104 + tid] = s;
+}
+__global__ void k_tra_pgrad_finish(const float* __restrict__ partial, int nparts, float* __restrict__ d_dw_w,
+                                   float* __restrict__ d_dw_b, float* __restrict__ d_pw_w, float* __restrict__ d_pw_b) {
+    const int k = threadIdx.x;
+    if (k >= 104) return;
+    double s = 0.0;
+    for (int w = 0; w < nparts; ++w) s += partial[(long)w * 104 + k];
+    if (k < 64) d_pw_w[k] = (float)s;
+    else if (k < 72) d_pw_b[k - 64] = (float)s;
+    else if (k < 96) d_dw_w[k - 72] = (float)s;
+    else d_dw_b[k - 96] = (float)s;
+}
+
+__global__ __launch_bounds__(NT) void k_add(const float* __restrict__ a, const float* __restrict__ b,
+                                           float* __restrict__ out, long n) {
+    for (long i = (long)blockIdx.x * NT + threadIdx.x; i < n; i += (long)gridDim.x * NT) out[i] = a[i] + b[i];
+}
+
+int check() { return (int)hipGetLastError(); }
+
+}  // namespace
+
+// ====================================================================================== launchers
+int conv_fwd(const ConvGeom& g, const float* in, const float* w, const float* bias, float* out, hipStream_t s) {
+    const int grid = grid_for((long)g.B * g.Tout * g.Fout);
+#define GT_CONV_CASE(CI, CO)                                                                      \
+    if (g.Cin == CI && g.Cout == CO) {                                                            \
+        hipLaunchKernelGGL((k_conv<CI, CO>), dim3(grid), dim3(NT), 0, s, g, in, w, bias, out);    \
+        return check();                                                                           \
+    }
+    GT_CONV_CASE(3, 16) GT_CONV_CASE(16, 3) GT_CONV_CASE(16, 16) GT_CONV_CASE(8, 16) GT_CONV_CASE(16, 8)
+    GT_CONV_CASE(16, 2) GT_CONV_CASE(2, 16)
+#undef GT_CONV_CASE
+    return (int)hipErrorInvalidValue;
+}
+
+int conv_wgrad(const ConvGeom& g, const float* in, const float* dout, float* dw, float* dbias, float* scratch,
+               hipStream_t s) {
+    const long rows = (long)g.B * g.Tout;
+    const int grid = (int)(rows < MAX_PARTIALS ? rows : MAX_PARTIALS);
+    if (g.Fout * g.Cout > 1040 || g.Fin * g.Cin > 1040) return (int)hipErrorInvalidValue;
+#define GT_WG_CASE(CI, CO)                                                                              \
+    if (g.Cin == CI && g.Cout == CO) {                                                                  \
+        hipLaunchKernelGGL((k_conv_wgrad<CI, CO>), dim3(grid), dim3(NT), 0, s, g, in, dout, scratch);   \
+        hipLaunchKernelGGL(k_conv_wgrad_finish, dim3(10), dim3(NT), 0, s, g, CI, CO, scratch, grid, dw, dbias); \
+        return check();                                                                                 \
+    }
+    GT_WG_CASE(3, 16) GT_WG_CASE(16, 16) GT_WG_CASE(8, 16) GT_WG_CASE(16, 8) GT_WG_CASE(16, 2)
+#undef GT_WG_CASE
+    return (int)hipErrorInvalidValue;
+}
+
+int dw_fwd(const DwGeom& g, const float* in, const float* w, const float* bias, float* out, hipStream_t s) {
+    const int grid = grid_for((long)g.B * g.Tout * g.F);
+    if (g.C == 16) hipLaunchKernelGGL((k_dw<16>), dim3(grid), dim3(NT), 0, s, g, in, w, bias, out);
+    else if (g.C == 3) hipLaunchKernelGGL((k_dw<3>), dim3(grid), dim3(NT), 0, s, g, in, w, bias, out);
+    else return (int)hipErrorInvalidValue;
+    return check();
+}
+
+int dw_wgrad(const DwGeom& g, const float* in, const float* dout, float* dw, float* dbias, float* scratch,
+             hipStream_t s) {
+    const long rows = (long)g.B * g.Tout;
+    const int grid = (int)(rows < MAX_PARTIALS ? rows : MAX_PARTIALS);
+    if (g.F > 129) return (int)hipErrorInvalidValue;
+    if (g.C == 16 && g.F <= 33) hipLaunchKernelGGL((k_dw_wgrad<16>), dim3(grid), dim3(NT), 0, s, g, in, dout, scratch);
+    else if (g.C == 3) hipLaunchKernelGGL((k_dw_wgrad<3>), dim3(grid), dim3(NT), 0, s, g, in, dout, scratch);
+    else return (int)hipErrorInvalidValue;
+    hipLaunchKernelGGL(k_dw_wgrad_finish, dim3(1), dim3(NT), 0, s, g, scratch, grid, dw, dbias);
+    return check();
+}
+
+int bn_stats(const float* y, long n, int C, float* stats, float* running_mean, float* running_var, double* scratch,
+             hipStream_t s) {
+    const long total = n * C;
+    int grid = grid_for(total, MAX_PARTIALS);
+    hipLaunchKernelGGL(k_bn_stats, dim3(grid), dim3(NT), 0, s, y, total, C, scratch);
+    hipLaunchKernelGGL(k_bn_stats_finish, dim3(1), dim3(64), 0, s, scratch, grid, n, C, stats, running_mean, running_var);
+    return check();
+}
+
+int bn_act(const float* y, long n, int C, const float* stats, const float* gamma, const float* beta,
+           const float* res, int act, const float* slope, float* a, hipStream_t s) {
+    const long total = n * C;
+    hipLaunchKernelGGL(k_bn_act, dim3(grid_for(total)), dim3(NT), 0, s, y, total, C, stats, gamma, beta, res, act,
+                       slope, a);
+    return check();
+}
+
+int bn_act_bwd(const float* da, const float* y, long n, int C, const float* stats, const float* gamma,
+               const float* beta, const float* res, int act, const float* slope, float* dy, float* dres,
+               int dres_acc, float* dgamma, float* dbeta, float* dslope, double* scratch, hipStream_t s) {
+    const long total = n * C;
+    const int grid = grid_for(total, MAX_PARTIALS);
+    float* red = reinterpret_cast<float*>(scratch + (long)MAX_PARTIALS * 3 * C);
+    hipLaunchKernelGGL(k_bn_bwd_reduce, dim3(grid), dim3(NT), 0, s, da, y, total, C, stats, gamma, beta, res, act,
+                       slope, scratch);
+    hipLaunchKernelGGL(k_bn_bwd_finish, dim3(1), dim3(64), 0, s, scratch, grid, n, C, red, dgamma, dbeta, dslope);
+    hipLaunchKernelGGL(k_bn_bwd_apply, dim3(grid_for(total)), dim3(NT), 0, s, da, y, total, C, stats, gamma, beta, res,
+                       act, slope, red, dy, dres, dres_acc);
+    return check();
+}
+
+int feat_fwd(const float* spec, long sb, long sf, long st, int B, int T, const float* erb_w, float* eb,
+             hipStream_t s) {
+    hipLaunchKernelGGL(k_feat, dim3(grid_for((long)B * T * 129)), dim3(NT), 0, s, spec, sb, sf, st, B, T, erb_w, eb);
+    return check();
+}
+int bs_mask_fwd(const float* m, const float* spec, long sb, long sf, long st, int B, int T, const float* ierb_w,
+                float* out, long ob, long of, long ot, hipStream_t s) {
+    hipLaunchKernelGGL(k_bs_mask, dim3(grid_for((long)B * T * 257)), dim3(NT), 0, s, m, spec, sb, sf, st, B, T, ierb_w,
+                       out, ob, of, ot);
+    return check();
+}
+int bs_mask_bwd(const float* dout, long ob, long of, long ot, const float* spec, long sb, long sf, long st, int B,
+                int T, const float* ierb_w, float* dm, hipStream_t s) {
+    hipLaunchKernelGGL(k_bs_mask_bwd, dim3(grid_for((long)B * T * 129)), dim3(NT), 0, s, dout, ob, of, ot, spec, sb, sf,
+                       st, B, T, ierb_w, dm);
+    return check();
+}
+
+int tra_fwd(const float* v, int B, int Tt, const float* dw_w, const float* dw_b, const float* pw_w,
+            const float* pw_b, float* e, float* y, float* g, hipStream_t s) {
+    const long rows = (long)B * Tt;
+    hipLaunchKernelGGL(k_tra_energy, dim3(grid_for(rows * 8)), dim3(NT), 0, s, v, rows, e);
+    hipLaunchKernelGGL(k_tra_gate, dim3(grid_for(rows * 8)), dim3(NT), 0, s, e, B, Tt, dw_w, dw_b, pw_w, pw_b, y, g);
+    return check();
+}
+int gate_shuffle_fwd(const float* v, const float* g, const float* x, int B, int T, int Tt, float* out, hipStream_t s) {
+    hipLaunchKernelGGL(k_gate_shuffle, dim3(grid_for((long)B * T * 33 * 8)), dim3(NT), 0, s, v, g, x, B, T, Tt, out);
+    return check();
+}
+int tra_gate_shuffle_bwd(const float* dout, const float* v, const float* g, const float* e, const float* y, int B,
+                         int T, int Tt, const float* dw_w, const float* pw_w, float* dv, float* dx, float* d_dw_w,
+                         float* d_dw_b, float* d_pw_w, float* d_pw_b, float* tmp, float* scratch, hipStream_t s) {
+    const long rows = (long)B * Tt;
+    float* dzg = tmp;
+    float* dy = tmp + rows * 8;
+    hipLaunchKernelGGL(k_gate_shuffle_bwd, dim3(grid_for(rows * 33 * 8)), dim3(NT), 0, s, dout, g, B, T, Tt, dv, dx);
+    hipLaunchKernelGGL(k_tra_dgate, dim3(grid_for(rows * 8)), dim3(NT), 0, s, dout, v, g, B, T, Tt, dzg);
+    hipLaunchKernelGGL(k_tra_dy, dim3(grid_for(rows * 8)), dim3(NT), 0, s, dzg, rows, pw_w, dy);
+    hipLaunchKernelGGL(k_tra_dv, dim3(grid_for(rows * 8)), dim3(NT), 0, s, dy, v, B, Tt, dw_w, dv);
+    const int parts = (int)(rows < MAX_PARTIALS ? rows : MAX_PARTIALS);
+    hipLaunchKernelGGL(k_tra_pgrad, dim3(parts), dim3(128), 0, s, dzg, y, dy, e, B, Tt, scratch);
+    hipLaunchKernelGGL(k_tra_pgrad_finish, dim3(1), dim3(128), 0, s, scratch, parts, d_dw_w, d_dw_b, d_pw_w, d_pw_b);
+    return check();
+}
+
+int add(const float* a, const float* b, float* out, long n, hipStream_t s) {
+    hipLaunchKernelGGL(k_add, dim3(grid_for(n)), dim3(NT), 0, s, a, b, out, n);
+    return check();
+}
+
+}  // namespace gtt

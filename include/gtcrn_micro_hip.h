@@ -159,6 +159,36 @@ int gtcrn_selftest_mfma(int device);
 int gtcrn_timing_enable(gtcrn_model *m, int on);
 int gtcrn_timing_read(gtcrn_model *m, int idx, char *name, int name_cap, float *ms, int *launches);
 
+/* ---- train step (model forward/backward) ---------------------------------
+ * Replaces: `enhanced = self.model(noisy_spec)` with the module in .train() mode and the model part
+ * of `loss.backward()` (train.py:265, 280; models/gtcrn_micro.py:506-532).  Every nn.BatchNorm2d
+ * normalises with the statistics of the batch and updates its running estimates in place
+ * (momentum 0.1, unbiased variance), exactly as nn.BatchNorm2d.train() does; the transposed
+ * depth convs of the decoder produce T+2 frames whose tail takes part in the statistics
+ * (models/gtcrn_micro.py:238-251).  The loss, the optimiser and the scheduler stay with the caller
+ * (PyTorch; train.py:267-288).
+ *
+ * d_params: the canonical blob (GTCRN_NPARAM_FLOATS floats, raw, NOT folded) in device memory; the
+ *   forward writes the new running_mean/running_var into it.
+ * d_grads:  same layout; the backward writes d loss / d parameter for the 248 trainable tensors and
+ *   zeros in the slots of buffers (running statistics, ERB filterbank).
+ * Spectrograms are addressed by strides like gtcrn_forward_spec.  The backward differentiates the
+ * most recent forward of this trainer (same d_params, same d_spec).  One trainer per device,
+ * single caller thread (train.py:461-471); no CPU fallback. */
+typedef struct gtcrn_trainer gtcrn_trainer;
+int gtcrn_trainer_create(gtcrn_trainer **out, int device);
+void gtcrn_trainer_destroy(gtcrn_trainer *t);
+long gtcrn_train_workspace_bytes(int B, int T);   /* saved activations + gradient buffers */
+int gtcrn_train_forward(gtcrn_trainer *t, float *d_params, const float *d_spec, long sb, long sf, long st,
+                        float *d_out, long ob, long of, long ot, int B, int T, void *stream);
+int gtcrn_train_backward(gtcrn_trainer *t, const float *d_params, const float *d_spec, long sb, long sf,
+                         long st, const float *d_grad_out, long gb, long gf, long gt, float *d_grads,
+                         void *stream);
+/* Test hook: train-mode activation of the most recent forward at a stage boundary (en0..en4, gtcn1,
+ * gtcn2, de0..de4), channels-last (B, T, F, C) in the reference's channel order; shape4 receives
+ * the four extents; d_out may be NULL to query the shape. */
+int gtcrn_train_tap(gtcrn_trainer *t, const char *name, float *d_out, long *shape4, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -26,15 +26,28 @@ def blob_to_dict(blob):
     return {n: torch.from_numpy(blob[o:o + int(np.prod(s))].reshape(s).copy()) for n, s, o in man["tensors"]}
 
 
-class TorchPort:
-    def __init__(self, blob):
-        self.p = blob_to_dict(blob)
+def is_trainable(name):
+    """The 248 tensors train.py hands to Adam: everything except BatchNorm running statistics and the
+    frozen ERB filterbank (models/gtcrn_micro.py:27-33, requires_grad False)."""
+    return not (name.endswith("running_mean") or name.endswith("running_var") or name.startswith("erb."))
 
-    # conv + eval BatchNorm + activation (ConvBlock.forward, models/gtcrn_micro.py:163-164)
+
+class TorchPort:
+    def __init__(self, blob, train=False):
+        """train=True: BatchNorm uses batch statistics and updates the running ones in place
+        (nn.BatchNorm2d in .train() mode, momentum 0.1), and trainable tensors require grad."""
+        self.p = blob_to_dict(blob)
+        self.train = bool(train)
+        if self.train:
+            for k, v in self.p.items():
+                if is_trainable(k):
+                    v.requires_grad_(True)
+
+    # conv + BatchNorm + activation (ConvBlock.forward, models/gtcrn_micro.py:163-164)
     def _bn(self, x, pre):
         p = self.p
         return F.batch_norm(x, p[pre + ".running_mean"], p[pre + ".running_var"], p[pre + ".weight"],
-                            p[pre + ".bias"], False, 0.1, 1e-5)
+                            p[pre + ".bias"], self.train, 0.1, 1e-5)
 
     def _tra(self, x, pre):
         # TRALite.forward (models/gtcrn_micro.py:122-139), zero cache
@@ -72,10 +85,19 @@ class TorchPort:
         y = self._bn(F.conv2d(y, p[pre + ".conv3.weight"], p[pre + ".conv3.bias"]), pre + ".bn3")
         return F.prelu(y + x, p[pre + ".act3.weight"])
 
-    @torch.inference_mode()
-    def forward(self, spec):
+    def forward(self, spec, taps=None):
         """GTCRNMicro.forward (models/gtcrn_micro.py:506-532): (B,257,T,2) -> (B,257,T,2)."""
+        if self.train:
+            return self._forward(spec, taps)
+        with torch.inference_mode():
+            return self._forward(spec, taps)
+
+    def _forward(self, spec, taps=None):
         p = self.p
+
+        def tap(name, v):
+            if taps is not None:
+                taps[name] = v.detach().clone()
         spec = torch.as_tensor(spec, dtype=torch.float32)
         re, im = spec[..., 0].permute(0, 2, 1), spec[..., 1].permute(0, 2, 1)
         feat = torch.stack([torch.sqrt(re * re + im * im + 1e-12), re, im], dim=1)
@@ -87,24 +109,80 @@ class TorchPort:
             x = F.conv2d(x, p[pre + ".conv.weight"], p[pre + ".conv.bias"], stride=(1, 2), padding=(0, 2))
             x = F.prelu(self._bn(x, pre + ".bn"), p[pre + ".act.weight"])
             skips.append(x)
+            tap(f"en{i}", x)
         for i in range(2, 5):
             x = self._gtconv(x, f"encoder.en_convs.{i}", False)
             skips.append(x)
+            tap(f"en{i}", x)
         for g in (1, 2):
             for k in range(4):
                 x = self._tcn(x, f"gtcn{g}.blocks.{k}", 1 << k)
+            tap(f"gtcn{g}", x)
         for i in range(3):
             x = self._gtconv(x + skips[4 - i], f"decoder.de_convs.{i}", True)
+            tap(f"de{i}", x)
         pre = "decoder.de_convs.3"
         x = F.conv_transpose2d(x + skips[1], p[pre + ".conv.weight"], p[pre + ".conv.bias"], stride=(1, 2), padding=(0, 2))
         x = F.prelu(self._bn(x, pre + ".bn"), p[pre + ".act.weight"])
+        tap("de3", x)
         pre = "decoder.de_convs.4"
         x = F.conv_transpose2d(x + skips[0], p[pre + ".conv.weight"], p[pre + ".conv.bias"], stride=(1, 2), padding=(0, 2))
         m = torch.tanh(self._bn(x, pre + ".bn"))
+        tap("de4", m)
         m = torch.cat([m[..., :65], F.linear(m[..., 65:], p["erb.ierb_fc.weight"])], dim=-1)   # (B,2,T,257)
         out_re = re * m[:, 0] - im * m[:, 1]
         out_im = im * m[:, 0] + re * m[:, 1]
         return torch.stack([out_re, out_im], dim=-1).permute(0, 2, 1, 3)
+
+    # ---- train step (train.py:239-288): HybridLoss (loss.py:30-71) and the gradients ----------------
+    @staticmethod
+    def hybrid_loss(pred, true):
+        pr, pi, tr, ti = pred[..., 0], pred[..., 1], true[..., 0], true[..., 1]
+        pm = torch.sqrt(pr ** 2 + pi ** 2 + 1e-12)
+        tm = torch.sqrt(tr ** 2 + ti ** 2 + 1e-12)
+        mse = F.mse_loss
+        ri = mse(pr / pm ** 0.7, tr / tm ** 0.7) + mse(pi / pm ** 0.7, ti / tm ** 0.7)
+        mag = mse(pm ** 0.3, tm ** 0.3)
+        win = torch.hann_window(512).pow(0.5).to(pred.device)
+        yp = torch.istft(torch.complex(pr, pi), 512, 256, 512, window=win)
+        yt = torch.istft(torch.complex(tr, ti), 512, 256, 512, window=win)
+        yt = torch.sum(yt * yp, -1, keepdim=True) * yt / (torch.sum(yt ** 2, -1, keepdim=True) + 1e-8)
+        sisnr = -torch.log10(torch.norm(yt, dim=-1, keepdim=True) ** 2 /
+                             (torch.norm(yp - yt, dim=-1, keepdim=True) ** 2 + 1e-8) + 1e-8).mean()
+        return 30 * ri + 70 * mag + sisnr
+
+    def blob(self):
+        man = json.load(open(_MANIFEST))
+        return np.concatenate([self.p[n].detach().numpy().astype(np.float32).ravel() for n, _, _ in man["tensors"]])
+
+    def grads_blob(self):
+        """d loss / d parameter in the canonical blob layout (zeros in the slots of buffers)."""
+        man = json.load(open(_MANIFEST))
+        out = []
+        for n, s, _ in man["tensors"]:
+            g = self.p[n].grad
+            out.append((g if g is not None else torch.zeros(s)).detach().numpy().astype(np.float32).ravel())
+        return np.concatenate(out)
+
+    def train_step(self, noisy_spec, clean_spec):
+        """One forward/backward in train mode; returns (enh, loss, d loss/d enh, grads blob)."""
+        assert self.train
+        for v in self.p.values():
+            v.grad = None
+        enh = self.forward(torch.as_tensor(noisy_spec, dtype=torch.float32))
+        enh.retain_grad()
+        loss = self.hybrid_loss(enh, torch.as_tensor(clean_spec, dtype=torch.float32))
+        loss.backward()
+        return enh.detach().numpy(), float(loss), enh.grad.numpy(), self.grads_blob()
+
+    def backward_from(self, spec, grad_enh):
+        """Gradients for a given upstream gradient (the model's backward alone, without the loss)."""
+        assert self.train
+        for v in self.p.values():
+            v.grad = None
+        enh = self.forward(torch.as_tensor(spec, dtype=torch.float32))
+        enh.backward(torch.as_tensor(grad_enh, dtype=torch.float32))
+        return enh.detach().numpy(), self.grads_blob()
 
     @torch.inference_mode()
     def enhance(self, wave, window):
