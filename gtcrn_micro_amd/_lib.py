@@ -35,6 +35,9 @@ def lib():
         raise GtcrnError(
             f"{path} not found: run `python -c 'import __graft_entry__ as g; g.build()'` "
             "(the HIP extension is mandatory, there is no CPU path)")
+    # PyTorch ships its own libamdhip64; loading it first makes this library bind to the same runtime
+    # (two HIP runtimes in one process: the second one finds no GPU)
+    import torch  # noqa: F401
     L = ctypes.CDLL(path)
     ci, cl = ctypes.c_int, ctypes.c_long
     L.gtcrn_abi_version.restype = ci

@@ -162,8 +162,41 @@ def state_dict_to_blob(sd):
     return torch.cat(parts).numpy()
 
 
+def _is_trainable(name):
+    return not (name.endswith("running_mean") or name.endswith("running_var") or name.startswith("erb."))
+
+
+class _TrainStep(torch.autograd.Function):
+    """``model(spec)`` in train mode: the HIP train-mode forward (gtcrn_train_forward) and, for
+    ``loss.backward()``, the HIP backward (gtcrn_train_backward).  The trainable tensors are inputs of
+    this node, so autograd, ``clip_grad_norm_``, Adam and DistributedDataParallel see ordinary ``.grad``s
+    (train.py:280-286); the spectrogram is data and receives no gradient."""
+
+    @staticmethod
+    def forward(ctx, spec, model, *params):
+        tr = model._trainer(spec.device)
+        out = tr.forward(model._flat, spec)
+        model._nbt_flat += 1              # num_batches_tracked of every BatchNorm (nn.BatchNorm2d.forward)
+        model._stats_dirty = True         # the kernel updated the running statistics in the flat blob
+        model._fwd_serial += 1
+        ctx.model, ctx.serial = model, model._fwd_serial
+        ctx.save_for_backward(spec)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        model = ctx.model
+        if ctx.serial != model._fwd_serial:
+            raise RuntimeError("backward of a train-mode forward that is no longer the most recent one: the HIP "
+                               "trainer keeps the activations of one forward pass")
+        (spec,) = ctx.saved_tensors
+        grads = model._trainer(spec.device).backward(model._flat, spec, grad_out)
+        return (None, None) + tuple(grads[o:o + n].view(shape) for o, n, shape in model._train_slices)
+
+
 class GTCRNMicro(nn.Module):
-    """Drop-in for ``gtcrn_micro.models.gtcrn_micro.GTCRNMicro`` (eval-mode inference on MI355X)."""
+    """Drop-in for ``gtcrn_micro.models.gtcrn_micro.GTCRNMicro`` on MI355X: eval-mode inference through
+    the fused kernels, train-mode forward/backward through the layer-at-a-time training kernels."""
 
     def __init__(self, n_fft=512, hop_len=256, win_len=512):
         super().__init__()
@@ -176,10 +209,62 @@ class GTCRNMicro(nn.Module):
         self.decoder = Decoder()
         self.mask = Mask()
         self._engines = {}     # device index -> (Engine, version signature)
+        self._trainers = {}    # device index -> Trainer
+        self._flat = None      # canonical blob on the device; every parameter/buffer is a view into it
+        self._nbt_flat = None
+        self._stats_dirty = False
+        self._fwd_serial = 0
 
     # -- weight hand-over -------------------------------------------------------------------
     def _signature(self):
-        return sum(int(t._version) for t in self.state_dict(keep_vars=True).values())
+        return (sum(int(t._version) for t in self.state_dict(keep_vars=True).values()), self._fwd_serial)
+
+    # -- train mode: flat parameter storage ----------------------------------------------------
+    def _trainer(self, device):
+        idx = torch.device(device).index
+        if idx is None:
+            idx = torch.cuda.current_device()
+        if idx not in self._trainers:
+            self._trainers[idx] = _lib.Trainer(idx)
+        return self._trainers[idx]
+
+    def _flatten(self, device):
+        """Moves the storage of every parameter and buffer into ONE canonical blob on ``device`` (the layout
+        of the C ABI) and re-points the tensors at views of it: optimiser updates, ``load_state_dict`` and
+        the kernels' running-statistics updates then all act on the same memory, with no per-step packing."""
+        table = _lib.param_table()
+        sd = self.state_dict(keep_vars=True)
+        for name, _, _ in table:
+            if sd[name].device != device:
+                raise _lib.GtcrnError(f"parameter '{name}' lives on {sd[name].device}, the input on {device}: "
+                                      "move the model with .to(device) first (there is no CPU path)")
+        blob = torch.empty(_lib.NPARAM_FLOATS, device=device, dtype=torch.float32)
+        slices = []
+        with torch.no_grad():
+            for name, numel, off in table:
+                t = sd[name]
+                blob[off:off + numel].copy_(t.reshape(-1))
+                t.data = blob[off:off + numel].view(t.shape)
+                if _is_trainable(name):
+                    slices.append((off, numel, tuple(t.shape)))
+            nbt = [v for k, v in sd.items() if k.endswith("num_batches_tracked")]
+            flat_n = torch.stack([v.reshape(()) for v in nbt]).to(device)
+            for i, v in enumerate(nbt):
+                v.data = flat_n[i]
+        self._flat, self._nbt_flat, self._train_slices = blob, flat_n, slices
+        self._train_params = [sd[name] for name, _, _ in table if _is_trainable(name)]
+
+    def _flat_ok(self, device):
+        if self._flat is None or self._flat.device != device:
+            return False
+        base = self._flat.data_ptr()
+        sd = self.state_dict(keep_vars=True)
+        return all(sd[name].data_ptr() == base + 4 * off for name, _, off in _lib.param_table())
+
+    def _apply(self, fn, *args, **kwargs):
+        out = super()._apply(fn, *args, **kwargs)     # .to()/.cuda()/.float() re-create the storages
+        self._flat = None
+        return out
 
     def engine(self, device):
         """The HIP model handle for ``device``, re-folded whenever a parameter changed."""
@@ -208,9 +293,20 @@ class GTCRNMicro(nn.Module):
 
     def forward(self, spec):
         """spec: (B, 257, T, 2) float32 on the GPU -> enhanced (B, 257, T, 2)."""
-        if self.training:
-            raise NotImplementedError(
-                "train-mode forward/backward is not built yet (SURVEY.md section 8f row 2); call .eval()")
         if not spec.is_cuda:
             raise _lib.GtcrnError("GTCRNMicro.forward needs a CUDA (ROCm) tensor: there is no CPU path")
+        if self.training:
+            # nn.BatchNorm2d in .train() mode: batch statistics + running-statistics update (train.py:265)
+            if not self._flat_ok(spec.device):
+                self._flatten(spec.device)
+            if torch.is_grad_enabled():
+                return _TrainStep.apply(spec, self, *self._train_params)
+            return _TrainStep.forward(_NoCtx(), spec, self)
         return self.engine(spec.device).forward_spec(spec)
+
+
+class _NoCtx:
+    """Stand-in for the autograd context when a train-mode forward runs under torch.no_grad()."""
+
+    def save_for_backward(self, *a):
+        pass

@@ -1,0 +1,82 @@
+"""Counterpart of the reference's train step (train.py:239-288) on MI355X.
+
+The outer loop stays PyTorch-ROCm, exactly as north_star asks: Hann-window STFTs of the noisy/clean
+batch on the device (HIP kernel), ``model(noisy_spec)`` in train mode (HIP forward, saved
+activations), HybridLoss (torch ops), ``loss.backward()`` (HIP backward through the autograd node of
+models/gtcrn_micro.py), ``clip_grad_norm_(3.0)``, Adam, warm-up-cosine schedule.  Data parallel
+training shards independent utterances over the ranks; the ONE exchange step is the all-reduce of the
+19 014 gradient floats (train.py:87-88 wraps the model in DistributedDataParallel; here either do the
+same, or call ``allreduce_gradients`` which moves them as one contiguous buffer over RCCL)."""
+import math
+
+import torch
+
+from . import _lib
+from .loss import HybridLoss
+from .models.gtcrn_micro import GTCRNMicro
+from .utils.scheduler import LinearWarmupCosineAnnealingLR
+
+
+def synthetic_mix(batch, samples=64000, seed=43, device="cuda"):
+    """DNS-style synthetic mixes: speech-like harmonic ``clean`` (5 harmonics of a
+    100-300 Hz f0, 4 Hz amplitude modulation, peak 0.5) + low-passed Gaussian noise at an SNR drawn
+    from U(-5, 20) dB; returns (noisy, clean), both (batch, samples) fp32 in [-1, 1]."""
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    t = torch.arange(samples, dtype=torch.float32) / 16000.0
+    f0 = 100.0 + 200.0 * torch.rand(batch, 1, generator=g)
+    ph = 2 * math.pi * torch.rand(batch, 5, generator=g)
+    clean = sum(torch.sin(2 * math.pi * (h + 1) * f0 * t + ph[:, h:h + 1]) / (h + 1) for h in range(5))
+    clean = clean * (0.6 + 0.4 * torch.sin(2 * math.pi * 4.0 * t))
+    clean = 0.5 * clean / clean.abs().amax(dim=1, keepdim=True)
+    noise = torch.randn(batch, samples, generator=g)
+    noise = torch.nn.functional.avg_pool1d(noise[:, None], 5, 1, 2)[:, 0]          # crude low-pass
+    snr = -5.0 + 25.0 * torch.rand(batch, 1, generator=g)
+    scale = clean.pow(2).mean(1, keepdim=True).sqrt() / (noise.pow(2).mean(1, keepdim=True).sqrt() * 10 ** (snr / 20))
+    noisy = (clean + scale * noise).clamp(-1, 1)
+    return noisy.to(device), clean.to(device)
+
+
+def make_training(config=None, device="cuda"):
+    """Model, Adam, scheduler and loss with the reference's defaults (conf/cfg_train_DNS3.yaml)."""
+    cfg = {"lr": 1e-3, "warmup_steps": 25000, "decay_until_step": 250000, "max_lr": 1e-3, "min_lr": 1e-6}
+    cfg.update(config or {})
+    model = GTCRNMicro().to(device)
+    opt = torch.optim.Adam(model.parameters(), lr=cfg["lr"])
+    sched = LinearWarmupCosineAnnealingLR(opt, cfg["warmup_steps"], cfg["decay_until_step"], cfg["max_lr"],
+                                          cfg["min_lr"])
+    return model, opt, sched, HybridLoss().to(device)
+
+
+def allreduce_gradients(model, world_size):
+    """The one exchange step of data-parallel training: average the gradients of the 248 trainable tensors
+    over the ranks as ONE contiguous 19 014-float buffer (76 KB; latency-bound over xGMI)."""
+    import torch.distributed as dist
+    ps = [p for p in model.parameters() if p.grad is not None]
+    flat = torch.cat([p.grad.reshape(-1) for p in ps])
+    dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+    flat /= world_size
+    off = 0
+    for p in ps:
+        p.grad.copy_(flat[off:off + p.numel()].view_as(p.grad))
+        off += p.numel()
+    return flat.numel()
+
+
+def train_step(model, optimizer, scheduler, loss_func, noisy, clean, clip_grad_norm_value=3.0, world_size=1,
+               window=None):
+    """One iteration of Trainer._train_epoch (train.py:244-288); returns (loss, grad_norm) as floats."""
+    dev = noisy.device
+    win = window if window is not None else torch.hann_window(512, device=dev)      # train.py:252 (Hann, not sqrt)
+    noisy_spec = _lib.stft(noisy, win)
+    clean_spec = _lib.stft(clean, win)
+    enhanced = model(noisy_spec)
+    loss = loss_func(enhanced, clean_spec)
+    optimizer.zero_grad()
+    loss.backward()
+    if world_size > 1:
+        allreduce_gradients(model, world_size)
+    gn = torch.nn.utils.clip_grad_norm_(model.parameters(), clip_grad_norm_value)
+    optimizer.step()
+    if scheduler is not None:
+        scheduler.step()
+    return loss.detach(), gn

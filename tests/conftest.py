@@ -37,3 +37,15 @@ def params_dns3():
 @pytest.fixture(scope="session")
 def params_rand():
     return load_params("rand")
+
+
+@pytest.fixture(scope="session", autouse=True)
+def _bounded_cpu_threads():
+    """The checkers (oracle/torch_port.py) run ATen on the host: with the 128+ threads of a GPU box's CPU the
+    tiny convolutions of this model crawl (minutes instead of seconds), so the CPU side is capped."""
+    try:
+        import torch
+        torch.set_num_threads(min(8, torch.get_num_threads()))
+    except Exception:
+        pass
+    yield

@@ -62,8 +62,8 @@ def test_module_mirror_state_dict_and_errors():
     with pytest.raises(GtcrnError):
         m(torch.zeros(1, 257, 4, 2))                                      # CPU tensor: no CPU path
     m.train()
-    with pytest.raises(NotImplementedError):
-        m(torch.zeros(1, 257, 4, 2))
+    with pytest.raises(GtcrnError):
+        m(torch.zeros(1, 257, 4, 2))                                      # train mode has no CPU path either
 
 
 def test_no_gpu_means_loud_failure():
