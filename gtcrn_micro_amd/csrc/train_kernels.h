@@ -41,7 +41,7 @@ struct DwGeom {
 
 enum Act { ACT_NONE = 0, ACT_PRELU = 1, ACT_TANH = 2 };
 
-constexpr int MAX_PARTIALS = 512;   // workgroups of a two-stage reduction
+constexpr int MAX_PARTIALS = 1024;   // workgroups of a two-stage reduction
 
 int conv_fwd(const ConvGeom& g, const float* in, const float* w, const float* bias, float* out, hipStream_t s);
 // dW (and db when dbias != nullptr) of the convolution g: in = its input, dout = gradient of its output.

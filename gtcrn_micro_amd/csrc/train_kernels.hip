@@ -27,9 +27,9 @@ __device__ __forceinline__ bool tap_fi(const ConvGeom& g, int fo, int kf, int& f
     if (g.f_mode == 0) {
         fi = fo * g.sf - g.pf + kf;
     } else {
-        const int num = fo + g.pf - kf;
-        if (num < 0 || (num % g.sf) != 0) return false;
-        fi = num / g.sf;
+        const int num = fo + g.pf - kf;                 // sf is 1 or 2 in this model
+        if (num < 0 || (num & (g.sf - 1)) != 0) return false;
+        fi = num >> (g.sf - 1);
     }
     return fi >= 0 && fi < g.Fin;
 }
@@ -163,6 +163,178 @@ __global__ void k_conv_wgrad_finish(ConvGeom g, int CIN, int COUT, const float* 
     }
 }
 
+
+// ------------------------------------------------------------------ dense conv on the matrix cores
+// Same arithmetic as k_conv / k_conv_wgrad for channel counts that are multiples of 4 (all the
+// 16/8-channel layers), on v_mfma_f32_16x16x4_f32 (exact fp32 products, fp32 accumulation):
+//   forward / data gradient: a tile = 16 consecutive output positions; lane (n = lane&15, g = lane>>4)
+//     loads the 4 input channels 4g..4g+3 of position n for each tap (one coalesced 16-byte load), the
+//     weights sit in LDS as 16x16 matrices [tap][co][ci] read as A fragments; the D fragment is
+//     channels 4g..4g+3 of position n again: one 16-byte store per lane.
+//   weight gradient: the contraction runs over positions, so positions are the K index: lane (c, k)
+//     loads channel c of position 4*group + k of dout (A) and of the tap-shifted input (B); one MFMA per
+//     tap per 4 positions accumulates the full 16x16 dW of that tap in registers.
+__device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+// (b, t, f) of a flat position, advanced incrementally (rows have >= 16 positions)
+struct Pos {
+    int f, t, b;
+    __device__ __forceinline__ void init(long p, int F, int T) {
+        f = (int)(p % F);
+        const long bt = p / F;
+        t = (int)(bt % T);
+        b = (int)(bt / T);
+    }
+    __device__ __forceinline__ void advance(int step, int F, int T) {
+        f += step;
+        if (f >= F) { f -= F; if (++t >= T) { t = 0; ++b; } }
+    }
+};
+
+template <int NKT, int NKF>
+__global__ __launch_bounds__(NT) void k_conv_mfma(ConvGeom g, const float* __restrict__ in,
+                                                 const float* __restrict__ w, const float* __restrict__ bias,
+                                                 float* __restrict__ out, long tiles_per_wave) {
+    __shared__ __attribute__((aligned(16))) float sW[NKT * NKF * 256];   // [tap][co][ci], zero padded
+    const int tid = threadIdx.x;
+    for (int i = tid; i < NKT * NKF * 256; i += NT) {
+        const int tap = i >> 8, co = (i >> 4) & 15, ci = i & 15, kt = tap / NKF, kf = tap - kt * NKF;
+        sW[i] = (co < g.Cout && ci < g.Cin) ? w[co * g.w_co + ci * g.w_ci + kt * g.w_kt + kf * g.w_kf] : 0.f;
+    }
+    __syncthreads();
+    const int lane = tid & 63, n = lane & 15, q = lane >> 4;
+    const long npos = (long)g.B * g.Tout * g.Fout, ntiles = (npos + 15) >> 4;
+    const long wave = (long)blockIdx.x * (NT / 64) + (tid >> 6);
+    long tile = wave * tiles_per_wave;
+    const long tend = tile + tiles_per_wave < ntiles ? tile + tiles_per_wave : ntiles;
+    if (tile >= tend) return;
+    Pos P;
+    {
+        const long p0 = tile * 16 + n;
+        P.init(p0 < npos ? p0 : npos - 1, g.Fout, g.Tout);
+    }
+    f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+    if (bias && 4 * q < g.Cout) bv = *reinterpret_cast<const f32x4*>(bias + 4 * q);
+    const bool cin_ok = 4 * q < g.Cin, cout_ok = 4 * q < g.Cout;
+    for (; tile < tend; ++tile) {
+        const long p = tile * 16 + n;
+        const bool pv = p < npos;
+        f32x4 acc = bv;
+#pragma unroll
+        for (int kt = 0; kt < NKT; ++kt) {
+            const int ti = P.t + g.t_off[kt];
+            const bool okt = pv && cin_ok && ti >= 0 && ti < g.Tin;
+            const long rowbase = ((long)P.b * g.Tin + ti) * g.Fin;
+#pragma unroll
+            for (int kf = 0; kf < NKF; ++kf) {
+                int fi;
+                const bool ok = tap_fi(g, P.f, kf, fi) && okt;
+                f32x4 xv = {0.f, 0.f, 0.f, 0.f};
+                if (ok) xv = *reinterpret_cast<const f32x4*>(in + (rowbase + fi) * g.CinT + g.cin_off + 4 * q);
+                const f32x4 A = *reinterpret_cast<const f32x4*>(sW + (kt * NKF + kf) * 256 + n * 16 + 4 * q);
+#pragma unroll
+                for (int s = 0; s < 4; ++s) acc = mfma4(A[s], xv[s], acc);
+            }
+        }
+        if (pv && cout_ok) {
+            f32x4* o = reinterpret_cast<f32x4*>(out + p * g.CoutT + g.cout_off + 4 * q);
+            *o = g.accumulate ? *o + acc : acc;
+        }
+        P.advance(16, g.Fout, g.Tout);
+    }
+}
+
+constexpr int WG_WAVES = 4;   // waves per workgroup of the MFMA weight-gradient kernel
+template <int NKT, int NKF>
+__global__ __launch_bounds__(WG_WAVES * 64) void k_conv_wgrad_mfma(ConvGeom g, const float* __restrict__ in,
+                                                                  const float* __restrict__ dout,
+                                                                  float* __restrict__ partial,
+                                                                  long groups_per_wave) {
+    constexpr int NTAP = NKT * NKF;
+    __shared__ float sAcc[WG_WAVES][NTAP * 256 + 64];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, c = lane & 15, k = lane >> 4;
+    const long npos = (long)g.B * g.Tout * g.Fout, ngroups = (npos + 3) >> 2;
+    const long wave = (long)blockIdx.x * WG_WAVES + wv;
+    long grp = wave * groups_per_wave;
+    const long gend = grp + groups_per_wave < ngroups ? grp + groups_per_wave : ngroups;
+    f32x4 acc[NTAP];
+#pragma unroll
+    for (int i = 0; i < NTAP; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float bsum = 0.f;
+    if (grp < gend) {
+        Pos P;
+        {
+            const long p0 = grp * 4 + k;
+            P.init(p0 < npos ? p0 : npos - 1, g.Fout, g.Tout);
+        }
+        const bool co_ok = c < g.Cout, ci_ok = c < g.Cin;
+        for (; grp < gend; ++grp) {
+            const long p = grp * 4 + k;
+            const bool pv = p < npos;
+            const float a = (pv && co_ok) ? dout[p * g.CoutT + g.cout_off + c] : 0.f;
+            bsum += a;
+#pragma unroll
+            for (int kt = 0; kt < NKT; ++kt) {
+                const int ti = P.t + g.t_off[kt];
+                const bool okt = pv && ci_ok && ti >= 0 && ti < g.Tin;
+                const long rowbase = ((long)P.b * g.Tin + ti) * g.Fin;
+#pragma unroll
+                for (int kf = 0; kf < NKF; ++kf) {
+                    int fi;
+                    const bool ok = tap_fi(g, P.f, kf, fi) && okt;
+                    const float b = ok ? in[(rowbase + fi) * g.CinT + g.cin_off + c] : 0.f;
+                    acc[kt * NKF + kf] = mfma4(a, b, acc[kt * NKF + kf]);
+                }
+            }
+            P.advance(4, g.Fout, g.Tout);
+        }
+    }
+    // D fragment: lane (j = c, q = k) holds dW[co = 4q + r][ci = j] of each tap
+#pragma unroll
+    for (int tap = 0; tap < NTAP; ++tap)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) sAcc[wv][tap * 256 + (4 * k + r) * 16 + c] = acc[tap][r];
+    sAcc[wv][NTAP * 256 + lane] = bsum;
+    __syncthreads();
+    float* pp = partial + (long)blockIdx.x * (NTAP * 256 + 16);
+    for (int i = tid; i < NTAP * 256; i += WG_WAVES * 64) {
+        float s = 0.f;
+#pragma unroll
+        for (int w2 = 0; w2 < WG_WAVES; ++w2) s += sAcc[w2][i];
+        pp[i] = s;
+    }
+    if (tid < 16) {
+        float s = 0.f;
+        for (int w2 = 0; w2 < WG_WAVES; ++w2)
+            for (int kk = 0; kk < 4; ++kk) s += sAcc[w2][NTAP * 256 + kk * 16 + tid];
+        pp[NTAP * 256 + tid] = s;
+    }
+}
+
+// partial [nparts][ntap*256 + 16] -> dw (reference layout), dbias.  1024 threads = 64 outputs x 16 slices
+// of the partials; the slices are combined in a fixed order.
+__global__ __launch_bounds__(1024) void k_wgrad_mfma_finish(ConvGeom g, const float* __restrict__ partial, int nparts,
+                                                           float* __restrict__ dw, float* __restrict__ dbias) {
+    __shared__ double sh[16][64];
+    const int ntap = g.nkt * g.nkf, K = ntap * 256 + 16;
+    const int j = threadIdx.x & 63, slice = threadIdx.x >> 6, k = blockIdx.x * 64 + j;
+    double s = 0.0;
+    if (k < K)
+        for (int w = slice; w < nparts; w += 16) s += partial[(long)w * K + k];
+    sh[slice][j] = s;
+    __syncthreads();
+    if (slice != 0 || k >= K) return;
+    for (int q = 1; q < 16; ++q) s += sh[q][j];
+    if (k >= ntap * 256) {
+        const int co = k - ntap * 256;
+        if (dbias && co < g.Cout) dbias[co] = (float)s;
+    } else {
+        const int tap = k >> 8, co = (k >> 4) & 15, ci = k & 15, kt = tap / g.nkf, kf = tap - kt * g.nkf;
+        if (co < g.Cout && ci < g.Cin) dw[co * g.w_co + ci * g.w_ci + kt * g.w_kt + kf * g.w_kf] = (float)s;
+    }
+}
+
 // -------------------------------------------------------------------------- depthwise conv
 // SFE_Lite (:77-90), encoder depth_conv groups=16 (:206-216), TCN conv2 (:273-281), + data gradients
 template <int C>
@@ -258,47 +430,69 @@ __global__ void k_dw_wgrad_finish(DwGeom g, const float* __restrict__ partial, i
 // ------------------------------------------------------------------------------ BatchNorm
 // nn.BatchNorm2d in train mode (ConvBlock :159, GTConvBlock :190/:218/:222, TCN :269/:282/:286):
 // biased batch variance for the normalisation, unbiased for the running estimate, momentum 0.1, eps 1e-5.
-// The flat index of a thread advances by a multiple of C, so a thread sees one channel only.
-template <int NV>
-__device__ __forceinline__ void block_reduce_store(double (&v)[NV], int C, double* sh, double* dst) {
-    // threads with the same (tid % C) hold partial sums of one channel; NT % C == 0
-    const int tid = threadIdx.x;
+// Reductions: a thread walks the tensor with a stride that is a multiple of C, so it sees fixed
+// channels; it accumulates a bounded number of elements in fp32, the per-thread sums are combined in
+// double (workgroup, then across workgroups) in a fixed order.
+template <int NV, int V>   // NV sums per channel, V channels per thread (vector width)
+__device__ __forceinline__ void block_reduce_store(const float (&v)[NV][V], int C, double* sh, double* dst) {
+    const int tid = threadIdx.x, groups = C / V;      // threads with equal (tid % groups) share channels
 #pragma unroll
-    for (int k = 0; k < NV; ++k) {
-        __syncthreads();
-        sh[tid] = v[k];
-        __syncthreads();
-        if (tid < C) {
-            double s = 0.0;
-            for (int i = tid; i < NT; i += C) s += sh[i];
-            dst[k * C + tid] = s;
+    for (int k = 0; k < NV; ++k)
+#pragma unroll
+        for (int e = 0; e < V; ++e) {
+            __syncthreads();
+            sh[tid] = (double)v[k][e];
+            __syncthreads();
+            if (tid < groups) {
+                double s = 0.0;
+                for (int i = tid; i < NT; i += groups) s += sh[i];
+                dst[k * C + tid * V + e] = s;
+            }
         }
-    }
 }
 
+template <int V>
 __global__ __launch_bounds__(NT) void k_bn_stats(const float* __restrict__ y, long total, int C,
                                                 double* __restrict__ partial) {
     __shared__ double sh[NT];
-    double v[2] = {0.0, 0.0};
-    for (long i = (long)blockIdx.x * NT + threadIdx.x; i < total; i += (long)gridDim.x * NT) {
-        const double x = y[i];
-        v[0] += x;
-        v[1] += x * x;
+    float v[2][V];
+#pragma unroll
+    for (int e = 0; e < V; ++e) v[0][e] = v[1][e] = 0.f;
+    const long units = total / V;
+    for (long i = (long)blockIdx.x * NT + threadIdx.x; i < units; i += (long)gridDim.x * NT) {
+        float x[V];
+        load_vec<V>(y + i * V, x);
+#pragma unroll
+        for (int e = 0; e < V; ++e) { v[0][e] += x[e]; v[1][e] = fmaf(x[e], x[e], v[1][e]); }
     }
-    block_reduce_store<2>(v, C, sh, partial + (long)blockIdx.x * 2 * C);
+    block_reduce_store<2, V>(v, C, sh, partial + (long)blockIdx.x * 2 * C);
 }
 
-__global__ void k_bn_stats_finish(const double* __restrict__ partial, int nparts, long n, int C,
-                                  float* __restrict__ stats, float* __restrict__ rmean, float* __restrict__ rvar) {
+// sums the per-workgroup partials [nparts][K] (K <= 64 values) with 1024 threads: 64 values x 16 slices
+__device__ __forceinline__ double reduce_partials(const double* partial, int nparts, int K, double (*sh)[64]) {
+    const int j = threadIdx.x & 63, slice = threadIdx.x >> 6;
+    double s = 0.0;
+    if (j < K)
+        for (int w = slice; w < nparts; w += 16) s += partial[(long)w * K + j];
+    sh[slice][j] = s;
+    __syncthreads();
+    if (slice == 0)
+        for (int q = 1; q < 16; ++q) s += sh[q][j];
+    return s;    // valid in threads 0..K-1
+}
+
+__global__ __launch_bounds__(1024) void k_bn_stats_finish(const double* __restrict__ partial, int nparts, long n, int C,
+                                                         float* __restrict__ stats, float* __restrict__ rmean,
+                                                         float* __restrict__ rvar) {
+    __shared__ double sh[16][64];
+    __shared__ double tot[64];
+    const double s = reduce_partials(partial, nparts, 2 * C, sh);
+    if (threadIdx.x < 2 * C) tot[threadIdx.x] = s;
+    __syncthreads();
     const int c = threadIdx.x;
     if (c >= C) return;
-    double s = 0.0, q = 0.0;
-    for (int w = 0; w < nparts; ++w) {
-        s += partial[(long)w * 2 * C + c];
-        q += partial[(long)w * 2 * C + C + c];
-    }
-    const double mean = s / (double)n;
-    double var = q / (double)n - mean * mean;
+    const double mean = tot[c] / (double)n;
+    double var = tot[C + c] / (double)n - mean * mean;
     if (var < 0.0) var = 0.0;
     stats[c] = (float)mean;
     stats[C + c] = (float)(1.0 / sqrt(var + 1e-5));
@@ -315,20 +509,38 @@ __device__ __forceinline__ float act_fwd(float z, int act, float slope) {
     return z;
 }
 
+template <int V>
 __global__ __launch_bounds__(NT) void k_bn_act(const float* __restrict__ y, long total, int C,
                                               const float* __restrict__ stats, const float* __restrict__ gamma,
                                               const float* __restrict__ beta, const float* __restrict__ res, int act,
                                               const float* __restrict__ slope, float* __restrict__ a) {
     const float sl = slope ? slope[0] : 0.f;
-    for (long i = (long)blockIdx.x * NT + threadIdx.x; i < total; i += (long)gridDim.x * NT) {
-        const int c = (int)(i % C);
-        float z = gamma[c] * ((y[i] - stats[c]) * stats[C + c]) + beta[c];
-        if (res) z += res[i];
-        a[i] = act_fwd(z, act, sl);
+    const long units = total / V;
+    for (long i = (long)blockIdx.x * NT + threadIdx.x; i < units; i += (long)gridDim.x * NT) {
+        const int c0 = (int)((i * V) % C);
+        float x[V], r[V], o[V];
+        load_vec<V>(y + i * V, x);
+        if (res) load_vec<V>(res + i * V, r);
+#pragma unroll
+        for (int e = 0; e < V; ++e) {
+            float z = gamma[c0 + e] * ((x[e] - stats[c0 + e]) * stats[C + c0 + e]) + beta[c0 + e];
+            if (res) z += r[e];
+            o[e] = act_fwd(z, act, sl);
+        }
+        if constexpr (V == 4) *reinterpret_cast<f32x4*>(a + i * 4) = f32x4{o[0], o[1], o[2], o[3]};
+        else a[i] = o[0];
     }
 }
 
+__device__ __forceinline__ float act_bwd(float z, float g, int act, float sl, float& dsl) {
+    if (act == ACT_PRELU) { dsl = z > 0.f ? 0.f : g * z; return z > 0.f ? g : sl * g; }
+    dsl = 0.f;
+    if (act == ACT_TANH) { const float t = tanhf(z); return g * (1.f - t * t); }
+    return g;
+}
+
 // backward, pass 1: S1 = sum dz, S2 = sum dz * xhat, S3 = sum da * min(z, 0) (PReLU slope gradient)
+template <int V>
 __global__ __launch_bounds__(NT) void k_bn_bwd_reduce(const float* __restrict__ da, const float* __restrict__ y,
                                                      long total, int C, const float* __restrict__ stats,
                                                      const float* __restrict__ gamma, const float* __restrict__ beta,
@@ -336,54 +548,58 @@ __global__ __launch_bounds__(NT) void k_bn_bwd_reduce(const float* __restrict__ 
                                                      const float* __restrict__ slope, double* __restrict__ partial) {
     __shared__ double sh[NT];
     const float sl = slope ? slope[0] : 0.f;
-    double v[3] = {0.0, 0.0, 0.0};
-    for (long i = (long)blockIdx.x * NT + threadIdx.x; i < total; i += (long)gridDim.x * NT) {
-        const int c = (int)(i % C);
-        const float xh = (y[i] - stats[c]) * stats[C + c];
-        float z = gamma[c] * xh + beta[c];
-        if (res) z += res[i];
-        const float g = da[i];
-        float dz = g;
-        if (act == ACT_PRELU) {
-            dz = z > 0.f ? g : sl * g;
-            v[2] += z > 0.f ? 0.0 : (double)(g * z);
-        } else if (act == ACT_TANH) {
-            const float t = tanhf(z);
-            dz = g * (1.f - t * t);
+    float v[3][V];
+#pragma unroll
+    for (int e = 0; e < V; ++e) v[0][e] = v[1][e] = v[2][e] = 0.f;
+    const long units = total / V;
+    const int c0 = (int)((((long)blockIdx.x * NT + threadIdx.x) * V) % C);   // fixed per thread
+    float mean[V], istd[V], gm[V], bt[V];
+#pragma unroll
+    for (int e = 0; e < V; ++e) { mean[e] = stats[c0 + e]; istd[e] = stats[C + c0 + e]; gm[e] = gamma[c0 + e]; bt[e] = beta[c0 + e]; }
+    for (long i = (long)blockIdx.x * NT + threadIdx.x; i < units; i += (long)gridDim.x * NT) {
+        float x[V], g[V], r[V];
+        load_vec<V>(y + i * V, x);
+        load_vec<V>(da + i * V, g);
+        if (res) load_vec<V>(res + i * V, r);
+#pragma unroll
+        for (int e = 0; e < V; ++e) {
+            const float xh = (x[e] - mean[e]) * istd[e];
+            float z = gm[e] * xh + bt[e];
+            if (res) z += r[e];
+            float dsl;
+            const float dz = act_bwd(z, g[e], act, sl, dsl);
+            v[0][e] += dz;
+            v[1][e] = fmaf(dz, xh, v[1][e]);
+            v[2][e] += dsl;
         }
-        v[0] += dz;
-        v[1] += (double)dz * xh;
     }
-    block_reduce_store<3>(v, C, sh, partial + (long)blockIdx.x * 3 * C);
+    block_reduce_store<3, V>(v, C, sh, partial + (long)blockIdx.x * 3 * C);
 }
 
-__global__ void k_bn_bwd_finish(const double* __restrict__ partial, int nparts, long n, int C,
-                                float* __restrict__ red, float* __restrict__ dgamma, float* __restrict__ dbeta,
-                                float* __restrict__ dslope) {
-    __shared__ double s3[16];
+__global__ __launch_bounds__(1024) void k_bn_bwd_finish(const double* __restrict__ partial, int nparts, long n, int C,
+                                                       float* __restrict__ red, float* __restrict__ dgamma,
+                                                       float* __restrict__ dbeta, float* __restrict__ dslope) {
+    __shared__ double sh[16][64];
+    __shared__ double tot[64];
+    const double s = reduce_partials(partial, nparts, 3 * C, sh);
+    if (threadIdx.x < 3 * C) tot[threadIdx.x] = s;
+    __syncthreads();
     const int c = threadIdx.x;
     if (c < C) {
-        double s1 = 0.0, s2 = 0.0, t3 = 0.0;
-        for (int w = 0; w < nparts; ++w) {
-            s1 += partial[(long)w * 3 * C + c];
-            s2 += partial[(long)w * 3 * C + C + c];
-            t3 += partial[(long)w * 3 * C + 2 * C + c];
-        }
-        red[c] = (float)(s1 / (double)n);
-        red[C + c] = (float)(s2 / (double)n);
-        if (dgamma) dgamma[c] = (float)s2;
-        if (dbeta) dbeta[c] = (float)s1;
-        s3[c] = t3;
+        red[c] = (float)(tot[c] / (double)n);
+        red[C + c] = (float)(tot[C + c] / (double)n);
+        if (dgamma) dgamma[c] = (float)tot[C + c];
+        if (dbeta) dbeta[c] = (float)tot[c];
     }
-    __syncthreads();
     if (c == 0 && dslope) {
         double t = 0.0;
-        for (int i = 0; i < C; ++i) t += s3[i];
+        for (int i = 0; i < C; ++i) t += tot[2 * C + i];
         dslope[0] = (float)t;
     }
 }
 
 // pass 2: dy = gamma * invstd * (dz - mean(dz) - xhat * mean(dz * xhat)); dres (+)= dz
+template <int V>
 __global__ __launch_bounds__(NT) void k_bn_bwd_apply(const float* __restrict__ da, const float* __restrict__ y,
                                                     long total, int C, const float* __restrict__ stats,
                                                     const float* __restrict__ gamma, const float* __restrict__ beta,
@@ -391,18 +607,113 @@ __global__ __launch_bounds__(NT) void k_bn_bwd_apply(const float* __restrict__ d
                                                     const float* __restrict__ slope, const float* __restrict__ red,
                                                     float* __restrict__ dy, float* __restrict__ dres, int dres_acc) {
     const float sl = slope ? slope[0] : 0.f;
-    for (long i = (long)blockIdx.x * NT + threadIdx.x; i < total; i += (long)gridDim.x * NT) {
-        const int c = (int)(i % C);
-        const float xh = (y[i] - stats[c]) * stats[C + c];
-        float z = gamma[c] * xh + beta[c];
-        if (res) z += res[i];
-        const float g = da[i];
-        float dz = g;
-        if (act == ACT_PRELU) dz = z > 0.f ? g : sl * g;
-        else if (act == ACT_TANH) { const float t = tanhf(z); dz = g * (1.f - t * t); }
-        if (dres) dres[i] = dres_acc ? dres[i] + dz : dz;
-        dy[i] = gamma[c] * stats[C + c] * (dz - red[c] - xh * red[C + c]);
+    const long units = total / V;
+    const int c0 = (int)((((long)blockIdx.x * NT + threadIdx.x) * V) % C);
+    float mean[V], istd[V], gm[V], bt[V], m1[V], m2[V];
+#pragma unroll
+    for (int e = 0; e < V; ++e) {
+        mean[e] = stats[c0 + e]; istd[e] = stats[C + c0 + e]; gm[e] = gamma[c0 + e]; bt[e] = beta[c0 + e];
+        m1[e] = red[c0 + e]; m2[e] = red[C + c0 + e];
     }
+    for (long i = (long)blockIdx.x * NT + threadIdx.x; i < units; i += (long)gridDim.x * NT) {
+        float x[V], g[V], r[V], o[V], dzv[V];
+        load_vec<V>(y + i * V, x);
+        load_vec<V>(da + i * V, g);
+        if (res) load_vec<V>(res + i * V, r);
+        if (dres && dres_acc) load_vec<V>(dres + i * V, dzv);
+#pragma unroll
+        for (int e = 0; e < V; ++e) {
+            const float xh = (x[e] - mean[e]) * istd[e];
+            float z = gm[e] * xh + bt[e];
+            if (res) z += r[e];
+            float dsl;
+            const float dz = act_bwd(z, g[e], act, sl, dsl);
+            dzv[e] = (dres && dres_acc) ? dzv[e] + dz : dz;
+            o[e] = gm[e] * istd[e] * (dz - m1[e] - xh * m2[e]);
+        }
+        if constexpr (V == 4) {
+            *reinterpret_cast<f32x4*>(dy + i * 4) = f32x4{o[0], o[1], o[2], o[3]};
+            if (dres) *reinterpret_cast<f32x4*>(dres + i * 4) = f32x4{dzv[0], dzv[1], dzv[2], dzv[3]};
+        } else {
+            dy[i] = o[0];
+            if (dres) dres[i] = dzv[0];
+        }
+    }
+}
+
+// depthwise weight gradient, C = 16, streaming form: a thread owns 4 channels and walks the positions with a
+// stride that keeps them fixed; dW[c][tap] = sum_pos dout[pos][c] * in[pos + tap][c] and db = sum dout are
+// per-thread fp32 partial sums, combined in double in a fixed order (workgroup, then k_dw_wgrad_finish2).
+template <int NKT, int NKF>
+__global__ __launch_bounds__(NT) void k_dw_wgrad_stream(DwGeom g, const float* __restrict__ in,
+                                                       const float* __restrict__ dout, double* __restrict__ partial) {
+    constexpr int NTAP = NKT * NKF;
+    __shared__ double sh[NT];
+    float v[NTAP + 1][4];
+#pragma unroll
+    for (int k = 0; k <= NTAP; ++k)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[k][e] = 0.f;
+    const long units = (long)g.B * g.Tout * g.F * 4;
+    for (long i = (long)blockIdx.x * NT + threadIdx.x; i < units; i += (long)gridDim.x * NT) {
+        const int q = (int)(i & 3);
+        const long p = i >> 2;
+        const int fo = (int)(p % g.F);
+        const long bt = p / g.F;
+        const int to = (int)(bt % g.Tout), b = (int)(bt / g.Tout);
+        const f32x4 d = *reinterpret_cast<const f32x4*>(dout + p * 16 + 4 * q);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[NTAP][e] += d[e];
+#pragma unroll
+        for (int kt = 0; kt < NKT; ++kt) {
+            const int ti = to + g.t_off[kt];
+            if (ti < 0 || ti >= g.Tin) continue;
+#pragma unroll
+            for (int kf = 0; kf < NKF; ++kf) {
+                const int fi = fo + g.f_off[kf];
+                if (fi < 0 || fi >= g.F) continue;
+                const f32x4 x = *reinterpret_cast<const f32x4*>(in + (((long)b * g.Tin + ti) * g.F + fi) * 16 + 4 * q);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[kt * NKF + kf][e] = fmaf(d[e], x[e], v[kt * NKF + kf][e]);
+            }
+        }
+    }
+    block_reduce_store<NTAP + 1, 4>(v, 16, sh, partial + (long)blockIdx.x * (NTAP + 1) * 16);
+}
+// partial [nparts][(ntap+1)*16] (tap-major, bias last) -> dw, dbias; grid = ceil(K / 64) workgroups of 1024
+__global__ __launch_bounds__(1024) void k_dw_wgrad_finish2(DwGeom g, const double* __restrict__ partial, int nparts,
+                                                          float* __restrict__ dw, float* __restrict__ dbias) {
+    __shared__ double sh[16][64];
+    const int ntap = g.nkt * g.nkf, K = (ntap + 1) * 16;
+    const int j = threadIdx.x & 63, slice = threadIdx.x >> 6, k = blockIdx.x * 64 + j;
+    double s = 0.0;
+    if (k < K)
+        for (int w = slice; w < nparts; w += 16) s += partial[(long)w * K + k];
+    sh[slice][j] = s;
+    __syncthreads();
+    if (slice != 0 || k >= K) return;
+    for (int q = 1; q < 16; ++q) s += sh[q][j];
+    const int tap = k >> 4, c = k & 15;
+    if (tap == ntap) {
+        if (dbias) dbias[c] = (float)s;
+    } else {
+        const int kt = tap / g.nkf, kf = tap - kt * g.nkf;
+        dw[c * g.w_c + kt * g.w_kt + kf * g.w_kf] = (float)s;
+    }
+}
+// generic: out[k] = sum over workgroups of float partials [nparts][K]; grid = ceil(K / 64) x 1024 threads
+__global__ __launch_bounds__(1024) void k_reduce_partials_f(const float* __restrict__ partial, int nparts, int K,
+                                                           float* __restrict__ out) {
+    __shared__ double sh[16][64];
+    const int j = threadIdx.x & 63, slice = threadIdx.x >> 6, k = blockIdx.x * 64 + j;
+    double s = 0.0;
+    if (k < K)
+        for (int w = slice; w < nparts; w += 16) s += partial[(long)w * K + k];
+    sh[slice][j] = s;
+    __syncthreads();
+    if (slice != 0 || k >= K) return;
+    for (int q = 1; q < 16; ++q) s += sh[q][j];
+    out[k] = (float)s;
 }
 
 // --------------------------------------------------------------------------- features, mask
@@ -611,9 +922,9 @@ __global__ __launch_bounds__(NT) void k_tra_dv(const float* __restrict__ dy, con
         for (int f = 0; f < 33; ++f) d[f * 8] = fmaf(de, vv[f * 8], d[f * 8]);
     }
 }
-// parameter gradients of the two conv1d: 104 sums over the rows (b,t), per-workgroup partials
-//   [0,64)  d pw_w[co][c] = sum dzg[co] * y[c]     [64,72)  d pw_b[co] = sum dzg[co]
-//   [72,96) d dw_w[c][k]  = sum dy[t][c] * e[t-2+k][c]   [96,104) d dw_b[c] = sum dy[c]
+// parameter gradients of the two conv1d: 104 sums over the rows (b,t), per-workgroup partials, in the order
+// the blob stores them: [0,24) d dw_w[c][k] = sum dy[t][c] * e[t-2+k][c]   [24,32) d dw_b[c] = sum dy[c]
+//                       [32,96) d pw_w[co][c] = sum dzg[co] * y[c]         [96,104) d pw_b[co] = sum dzg[co]
 __global__ __launch_bounds__(128) void k_tra_pgrad(const float* __restrict__ dzg, const float* __restrict__ y,
                                                   const float* __restrict__ dy, const float* __restrict__ e, int B,
                                                   int Tt, float* __restrict__ partial) {
@@ -624,25 +935,14 @@ __global__ __launch_bounds__(128) void k_tra_pgrad(const float* __restrict__ dzg
     const long r0 = (long)blockIdx.x * per, r1 = r0 + per < rows ? r0 + per : rows;
     float s = 0.f;
     for (long r = r0; r < r1; ++r) {
-        if (tid < 64) s = fmaf(dzg[r * 8 + (tid >> 3)], y[r * 8 + (tid & 7)], s);
-        else if (tid < 72) s += dzg[r * 8 + tid - 64];
-        else if (tid < 96) {
-            const int c = (tid - 72) / 3, k = (tid - 72) % 3, t = (int)(r % Tt);
+        if (tid < 24) {
+            const int c = tid / 3, k = tid % 3, t = (int)(r % Tt);
             if (t - 2 + k >= 0) s = fmaf(dy[r * 8 + c], e[(r - 2 + k) * 8 + c], s);
-        } else s += dy[r * 8 + tid - 96];
+        } else if (tid < 32) s += dy[r * 8 + tid - 24];
+        else if (tid < 96) s = fmaf(dzg[r * 8 + ((tid - 32) >> 3)], y[r * 8 + ((tid - 32) & 7)], s);
+        else s += dzg[r * 8 + tid - 96];
     }
     partial[(long)blockIdx.x * 104 + tid] = s;
-}
-__global__ void k_tra_pgrad_finish(const float* __restrict__ partial, int nparts, float* __restrict__ d_dw_w,
-                                   float* __restrict__ d_dw_b, float* __restrict__ d_pw_w, float* __restrict__ d_pw_b) {
-    const int k = threadIdx.x;
-    if (k >= 104) return;
-    double s = 0.0;
-    for (int w = 0; w < nparts; ++w) s += partial[(long)w * 104 + k];
-    if (k < 64) d_pw_w[k] = (float)s;
-    else if (k < 72) d_pw_b[k - 64] = (float)s;
-    else if (k < 96) d_dw_w[k - 72] = (float)s;
-    else d_dw_b[k - 96] = (float)s;
 }
 
 __global__ __launch_bounds__(NT) void k_add(const float* __restrict__ a, const float* __restrict__ b,
@@ -655,7 +955,32 @@ int check() { return (int)hipGetLastError(); }
 }  // namespace
 
 // ====================================================================================== launchers
+// grid of a streaming reduction: a stride that is a multiple of C (NT is), at most MAX_PARTIALS workgroups
+static int red_grid(long units) {
+    long g = (units + NT * 8 - 1) / (NT * 8);       // >= 8 elements per thread
+    if (g < 1) g = 1;
+    if (g > MAX_PARTIALS) g = MAX_PARTIALS;
+    return (int)g;
+}
+
+static bool mfma_ok(const ConvGeom& g) {
+    return (g.Cin % 4) == 0 && (g.Cout % 4) == 0 && (g.CinT % 4) == 0 && (g.CoutT % 4) == 0 && (g.cin_off % 4) == 0 &&
+           (g.cout_off % 4) == 0 && g.Fout >= 16 && g.sf <= 2 &&
+           ((g.nkt == 1 && (g.nkf == 1 || g.nkf == 5)) || (g.nkt == 3 && g.nkf == 3));
+}
+
 int conv_fwd(const ConvGeom& g, const float* in, const float* w, const float* bias, float* out, hipStream_t s) {
+    if (mfma_ok(g)) {
+        const long ntiles = ((long)g.B * g.Tout * g.Fout + 15) / 16;
+        long waves = 256L * 4 * 4;                       // 4 workgroups of 4 waves per CU
+        if (waves > ntiles) waves = ntiles;
+        const long tpw = (ntiles + waves - 1) / waves;
+        const int grid = (int)((ntiles + tpw * 4 - 1) / (tpw * 4));
+        if (g.nkt == 3) hipLaunchKernelGGL((k_conv_mfma<3, 3>), dim3(grid), dim3(NT), 0, s, g, in, w, bias, out, tpw);
+        else if (g.nkf == 5) hipLaunchKernelGGL((k_conv_mfma<1, 5>), dim3(grid), dim3(NT), 0, s, g, in, w, bias, out, tpw);
+        else hipLaunchKernelGGL((k_conv_mfma<1, 1>), dim3(grid), dim3(NT), 0, s, g, in, w, bias, out, tpw);
+        return check();
+    }
     const int grid = grid_for((long)g.B * g.Tout * g.Fout);
 #define GT_CONV_CASE(CI, CO)                                                                      \
     if (g.Cin == CI && g.Cout == CO) {                                                            \
@@ -670,6 +995,19 @@ int conv_fwd(const ConvGeom& g, const float* in, const float* w, const float* bi
 
 int conv_wgrad(const ConvGeom& g, const float* in, const float* dout, float* dw, float* dbias, float* scratch,
                hipStream_t s) {
+    if (g.Fout >= 4 && g.sf <= 2 && ((g.nkt == 1 && (g.nkf == 1 || g.nkf == 5)) || (g.nkt == 3 && g.nkf == 3))) {
+        const long ngroups = ((long)g.B * g.Tout * g.Fout + 3) / 4;
+        long waves = (long)MAX_PARTIALS * WG_WAVES;
+        if (waves > ngroups) waves = ngroups;
+        const long gpw = (ngroups + waves - 1) / waves;
+        const int grid = (int)((ngroups + gpw * WG_WAVES - 1) / (gpw * WG_WAVES));
+        const int K = g.nkt * g.nkf * 256 + 16;
+        if (g.nkt == 3) hipLaunchKernelGGL((k_conv_wgrad_mfma<3, 3>), dim3(grid), dim3(WG_WAVES * 64), 0, s, g, in, dout, scratch, gpw);
+        else if (g.nkf == 5) hipLaunchKernelGGL((k_conv_wgrad_mfma<1, 5>), dim3(grid), dim3(WG_WAVES * 64), 0, s, g, in, dout, scratch, gpw);
+        else hipLaunchKernelGGL((k_conv_wgrad_mfma<1, 1>), dim3(grid), dim3(WG_WAVES * 64), 0, s, g, in, dout, scratch, gpw);
+        hipLaunchKernelGGL(k_wgrad_mfma_finish, dim3((K + 63) / 64), dim3(1024), 0, s, g, scratch, grid, dw, dbias);
+        return check();
+    }
     const long rows = (long)g.B * g.Tout;
     const int grid = (int)(rows < MAX_PARTIALS ? rows : MAX_PARTIALS);
     if (g.Fout * g.Cout > 1040 || g.Fin * g.Cin > 1040) return (int)hipErrorInvalidValue;
@@ -694,8 +1032,17 @@ int dw_fwd(const DwGeom& g, const float* in, const float* w, const float* bias, 
 
 int dw_wgrad(const DwGeom& g, const float* in, const float* dout, float* dw, float* dbias, float* scratch,
              hipStream_t s) {
+    if (g.C == 16 && ((g.nkt == 3 && g.nkf == 3) || (g.nkt == 3 && g.nkf == 1))) {
+        double* part = reinterpret_cast<double*>(scratch);      // <= MAX_PARTIALS * 160 doubles
+        const int grid = red_grid((long)g.B * g.Tout * g.F * 4);
+        const int K = (g.nkt * g.nkf + 1) * 16;
+        if (g.nkf == 3) hipLaunchKernelGGL((k_dw_wgrad_stream<3, 3>), dim3(grid), dim3(NT), 0, s, g, in, dout, part);
+        else hipLaunchKernelGGL((k_dw_wgrad_stream<3, 1>), dim3(grid), dim3(NT), 0, s, g, in, dout, part);
+        hipLaunchKernelGGL(k_dw_wgrad_finish2, dim3((K + 63) / 64), dim3(1024), 0, s, g, part, grid, dw, dbias);
+        return check();
+    }
     const long rows = (long)g.B * g.Tout;
-    const int grid = (int)(rows < MAX_PARTIALS ? rows : MAX_PARTIALS);
+    const int grid = (int)(rows < 256 ? rows : 256);
     if (g.F > 129) return (int)hipErrorInvalidValue;
     if (g.C == 16 && g.F <= 33) hipLaunchKernelGGL((k_dw_wgrad<16>), dim3(grid), dim3(NT), 0, s, g, in, dout, scratch);
     else if (g.C == 3) hipLaunchKernelGGL((k_dw_wgrad<3>), dim3(grid), dim3(NT), 0, s, g, in, dout, scratch);
@@ -707,17 +1054,27 @@ int dw_wgrad(const DwGeom& g, const float* in, const float* dout, float* dw, flo
 int bn_stats(const float* y, long n, int C, float* stats, float* running_mean, float* running_var, double* scratch,
              hipStream_t s) {
     const long total = n * C;
-    int grid = grid_for(total, MAX_PARTIALS);
-    hipLaunchKernelGGL(k_bn_stats, dim3(grid), dim3(NT), 0, s, y, total, C, scratch);
-    hipLaunchKernelGGL(k_bn_stats_finish, dim3(1), dim3(64), 0, s, scratch, grid, n, C, stats, running_mean, running_var);
+    if (C % 4 == 0) {
+        const int grid = red_grid(total / 4);
+        hipLaunchKernelGGL((k_bn_stats<4>), dim3(grid), dim3(NT), 0, s, y, total, C, scratch);
+        hipLaunchKernelGGL(k_bn_stats_finish, dim3(1), dim3(1024), 0, s, scratch, grid, n, C, stats, running_mean, running_var);
+    } else {
+        const int grid = red_grid(total);
+        hipLaunchKernelGGL((k_bn_stats<1>), dim3(grid), dim3(NT), 0, s, y, total, C, scratch);
+        hipLaunchKernelGGL(k_bn_stats_finish, dim3(1), dim3(1024), 0, s, scratch, grid, n, C, stats, running_mean, running_var);
+    }
     return check();
 }
 
 int bn_act(const float* y, long n, int C, const float* stats, const float* gamma, const float* beta,
            const float* res, int act, const float* slope, float* a, hipStream_t s) {
     const long total = n * C;
-    hipLaunchKernelGGL(k_bn_act, dim3(grid_for(total)), dim3(NT), 0, s, y, total, C, stats, gamma, beta, res, act,
-                       slope, a);
+    if (C % 4 == 0)
+        hipLaunchKernelGGL((k_bn_act<4>), dim3(grid_for(total / 4, 8192)), dim3(NT), 0, s, y, total, C, stats, gamma,
+                           beta, res, act, slope, a);
+    else
+        hipLaunchKernelGGL((k_bn_act<1>), dim3(grid_for(total, 8192)), dim3(NT), 0, s, y, total, C, stats, gamma, beta,
+                           res, act, slope, a);
     return check();
 }
 
@@ -725,13 +1082,23 @@ int bn_act_bwd(const float* da, const float* y, long n, int C, const float* stat
                const float* beta, const float* res, int act, const float* slope, float* dy, float* dres,
                int dres_acc, float* dgamma, float* dbeta, float* dslope, double* scratch, hipStream_t s) {
     const long total = n * C;
-    const int grid = grid_for(total, MAX_PARTIALS);
-    float* red = reinterpret_cast<float*>(scratch + (long)MAX_PARTIALS * 3 * C);
-    hipLaunchKernelGGL(k_bn_bwd_reduce, dim3(grid), dim3(NT), 0, s, da, y, total, C, stats, gamma, beta, res, act,
-                       slope, scratch);
-    hipLaunchKernelGGL(k_bn_bwd_finish, dim3(1), dim3(64), 0, s, scratch, grid, n, C, red, dgamma, dbeta, dslope);
-    hipLaunchKernelGGL(k_bn_bwd_apply, dim3(grid_for(total)), dim3(NT), 0, s, da, y, total, C, stats, gamma, beta, res,
-                       act, slope, red, dy, dres, dres_acc);
+    float* red = reinterpret_cast<float*>(scratch + (long)MAX_PARTIALS * 3 * 16);
+    if (C % 4 == 0) {
+        const int grid = red_grid(total / 4);
+        hipLaunchKernelGGL((k_bn_bwd_reduce<4>), dim3(grid), dim3(NT), 0, s, da, y, total, C, stats, gamma, beta, res,
+                           act, slope, scratch);
+        hipLaunchKernelGGL(k_bn_bwd_finish, dim3(1), dim3(1024), 0, s, scratch, grid, n, C, red, dgamma, dbeta, dslope);
+        // the apply pass keeps per-thread channel constants: its stride must be a multiple of C as well
+        hipLaunchKernelGGL((k_bn_bwd_apply<4>), dim3(grid_for(total / 4, 8192)), dim3(NT), 0, s, da, y, total, C, stats,
+                           gamma, beta, res, act, slope, red, dy, dres, dres_acc);
+    } else {
+        const int grid = red_grid(total);
+        hipLaunchKernelGGL((k_bn_bwd_reduce<1>), dim3(grid), dim3(NT), 0, s, da, y, total, C, stats, gamma, beta, res,
+                           act, slope, scratch);
+        hipLaunchKernelGGL(k_bn_bwd_finish, dim3(1), dim3(1024), 0, s, scratch, grid, n, C, red, dgamma, dbeta, dslope);
+        hipLaunchKernelGGL((k_bn_bwd_apply<1>), dim3(grid_for(total, 8192)), dim3(NT), 0, s, da, y, total, C, stats,
+                           gamma, beta, res, act, slope, red, dy, dres, dres_acc);
+    }
     return check();
 }
 
@@ -776,7 +1143,9 @@ int tra_gate_shuffle_bwd(const float* dout, const float* v, const float* g, cons
     hipLaunchKernelGGL(k_tra_dv, dim3(grid_for(rows * 8)), dim3(NT), 0, s, dy, v, B, Tt, dw_w, dv);
     const int parts = (int)(rows < MAX_PARTIALS ? rows : MAX_PARTIALS);
     hipLaunchKernelGGL(k_tra_pgrad, dim3(parts), dim3(128), 0, s, dzg, y, dy, e, B, Tt, scratch);
-    hipLaunchKernelGGL(k_tra_pgrad_finish, dim3(1), dim3(128), 0, s, scratch, parts, d_dw_w, d_dw_b, d_pw_w, d_pw_b);
+    // the four gradients are contiguous in the blob in exactly the partials' order (d_dw_w is the first)
+    (void)d_dw_b; (void)d_pw_w; (void)d_pw_b;
+    hipLaunchKernelGGL(k_reduce_partials_f, dim3(2), dim3(1024), 0, s, scratch, parts, 104, d_dw_w);
     return check();
 }
 
