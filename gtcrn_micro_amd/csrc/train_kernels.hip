@@ -374,6 +374,41 @@ __global__ __launch_bounds__(NT) void k_dw(DwGeom g, const float* __restrict__ i
     }
 }
 
+// C = 16: one thread per (position, 4 channels): every tap is one coalesced 16-byte load
+__global__ __launch_bounds__(NT) void k_dw16(DwGeom g, const float* __restrict__ in, const float* __restrict__ w,
+                                            const float* __restrict__ bias, float* __restrict__ out) {
+    __shared__ __attribute__((aligned(16))) float sW[9 * 16];   // [tap][c]
+    const int tid = threadIdx.x, ntap = g.nkt * g.nkf;
+    for (int i = tid; i < ntap * 16; i += NT) {
+        const int tap = i >> 4, c = i & 15, kt = tap / g.nkf, kf = tap - kt * g.nkf;
+        sW[i] = w[c * g.w_c + kt * g.w_kt + kf * g.w_kf];
+    }
+    __syncthreads();
+    const long units = (long)g.B * g.Tout * g.F * 4;
+    for (long i = (long)blockIdx.x * NT + tid; i < units; i += (long)gridDim.x * NT) {
+        const int q = (int)(i & 3);
+        const long p = i >> 2;
+        const int fo = (int)(p % g.F);
+        const long bt = p / g.F;
+        const int to = (int)(bt % g.Tout), b = (int)(bt / g.Tout);
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        if (bias) acc = *reinterpret_cast<const f32x4*>(bias + 4 * q);
+        for (int kt = 0; kt < g.nkt; ++kt) {
+            const int ti = to + g.t_off[kt];
+            if (ti < 0 || ti >= g.Tin) continue;
+            for (int kf = 0; kf < g.nkf; ++kf) {
+                const int fi = fo + g.f_off[kf];
+                if (fi < 0 || fi >= g.F) continue;
+                const f32x4 x = *reinterpret_cast<const f32x4*>(in + (((long)b * g.Tin + ti) * g.F + fi) * 16 + 4 * q);
+                const f32x4 wt = *reinterpret_cast<const f32x4*>(sW + (kt * g.nkf + kf) * 16 + 4 * q);
+                acc += wt * x;
+            }
+        }
+        f32x4* o = reinterpret_cast<f32x4*>(out + p * 16 + 4 * q);
+        *o = g.accumulate ? *o + acc : acc;
+    }
+}
+
 template <int C>
 __global__ __launch_bounds__(NT) void k_dw_wgrad(DwGeom g, const float* __restrict__ in,
                                                 const float* __restrict__ dout, float* __restrict__ partial) {
@@ -701,6 +736,36 @@ __global__ __launch_bounds__(1024) void k_dw_wgrad_finish2(DwGeom g, const doubl
         dw[c * g.w_c + kt * g.w_kt + kf * g.w_kf] = (float)s;
     }
 }
+// SFE_Lite weight gradient (3 channels, (1,3) taps, no bias): one thread per position, all 3 channels
+__global__ __launch_bounds__(NT) void k_sfe_wgrad(const float* __restrict__ in, const float* __restrict__ dout, long rows,
+                                                 int F, double* __restrict__ partial) {
+    __shared__ double sh[NT];
+    float v[3][3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+#pragma unroll
+        for (int e = 0; e < 3; ++e) v[k][e] = 0.f;
+    const long npos = rows * F;
+    for (long p = (long)blockIdx.x * NT + threadIdx.x; p < npos; p += (long)gridDim.x * NT) {
+        const int f = (int)(p % F);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const int fi = f + k - 1;
+            if (fi < 0 || fi >= F) continue;
+#pragma unroll
+            for (int e = 0; e < 3; ++e) v[k][e] = fmaf(dout[p * 3 + e], in[(p + k - 1) * 3 + e], v[k][e]);
+        }
+    }
+    block_reduce_store<3, 3>(v, 3, sh, partial + (long)blockIdx.x * 9);
+}
+__global__ __launch_bounds__(1024) void k_sfe_wgrad_finish(const double* __restrict__ partial, int nparts,
+                                                          float* __restrict__ dw) {
+    __shared__ double sh[16][64];
+    const double s = reduce_partials(partial, nparts, 9, sh);
+    const int k = threadIdx.x;                 // partial order [tap][c]; weight layout [c][1][1][tap]
+    if (k < 9) dw[(k % 3) * 3 + k / 3] = (float)s;
+}
+
 // generic: out[k] = sum over workgroups of float partials [nparts][K]; grid = ceil(K / 64) x 1024 threads
 __global__ __launch_bounds__(1024) void k_reduce_partials_f(const float* __restrict__ partial, int nparts, int K,
                                                            float* __restrict__ out) {
@@ -718,8 +783,22 @@ __global__ __launch_bounds__(1024) void k_reduce_partials_f(const float* __restr
 
 // --------------------------------------------------------------------------- features, mask
 // GTCRNMicro.forward prologue + ERB.bm (models/gtcrn_micro.py:510-516, :63-67): one thread per (b,t,j)
+// first / one-past-last non-zero entry of each of the `rows` rows (stride rs, element stride es) of a filterbank
+__device__ __forceinline__ void nz_ranges(const float* w, int rows, int cols, int rs, int es, int* lo, int* hi) {
+    for (int r = threadIdx.x; r < rows; r += blockDim.x) {
+        int a = cols, b = 0;
+        for (int i = 0; i < cols; ++i)
+            if (w[(long)r * rs + (long)i * es] != 0.f) { if (i < a) a = i; b = i + 1; }
+        lo[r] = a < b ? a : 0;
+        hi[r] = b;
+    }
+    __syncthreads();
+}
+
 __global__ __launch_bounds__(NT) void k_feat(const float* __restrict__ spec, long sb, long sf, long st, int B, int T,
                                             const float* __restrict__ erb_w, float* __restrict__ eb) {
+    __shared__ int lo[64], hi[64];
+    nz_ranges(erb_w, 64, 192, 192, 1, lo, hi);
     const long total = (long)B * T * 129;
     for (long p = (long)blockIdx.x * NT + threadIdx.x; p < total; p += (long)gridDim.x * NT) {
         const int j = (int)(p % 129);
@@ -732,7 +811,7 @@ __global__ __launch_bounds__(NT) void k_feat(const float* __restrict__ spec, lon
             m = sqrtf(re * re + im * im + 1e-12f);
         } else {
             const float* w = erb_w + (long)(j - 65) * 192;
-            for (int i = 0; i < 192; ++i) {
+            for (int i = lo[j - 65]; i < hi[j - 65]; ++i) {
                 const float wi = w[i];
                 if (wi != 0.f) {
                     const float r = x[(long)(65 + i) * sf], q = x[(long)(65 + i) * sf + 1];
@@ -750,6 +829,8 @@ __global__ __launch_bounds__(NT) void k_feat(const float* __restrict__ spec, lon
 __global__ __launch_bounds__(NT) void k_bs_mask(const float* __restrict__ m, const float* __restrict__ spec, long sb,
                                                long sf, long st, int B, int T, const float* __restrict__ ierb_w,
                                                float* __restrict__ out, long ob, long of, long ot) {
+    __shared__ int lo[192], hi[192];
+    nz_ranges(ierb_w, 192, 64, 64, 1, lo, hi);
     const long total = (long)B * T * 257;
     for (long p = (long)blockIdx.x * NT + threadIdx.x; p < total; p += (long)gridDim.x * NT) {
         const int f = (int)(p % 257);
@@ -761,7 +842,7 @@ __global__ __launch_bounds__(NT) void k_bs_mask(const float* __restrict__ m, con
             m0 = mm[f * 2]; m1 = mm[f * 2 + 1];
         } else {
             const float* w = ierb_w + (long)(f - 65) * 64;
-            for (int j = 0; j < 64; ++j) {
+            for (int j = lo[f - 65]; j < hi[f - 65]; ++j) {
                 const float wj = w[j];
                 if (wj != 0.f) { m0 = fmaf(wj, mm[(65 + j) * 2], m0); m1 = fmaf(wj, mm[(65 + j) * 2 + 1], m1); }
             }
@@ -776,6 +857,8 @@ __global__ __launch_bounds__(NT) void k_bs_mask(const float* __restrict__ m, con
 __global__ __launch_bounds__(NT) void k_bs_mask_bwd(const float* __restrict__ dout, long ob, long of, long ot,
                                                    const float* __restrict__ spec, long sb, long sf, long st, int B,
                                                    int T, const float* __restrict__ ierb_w, float* __restrict__ dm) {
+    __shared__ int lo[64], hi[64];
+    nz_ranges(ierb_w, 64, 192, 1, 64, lo, hi);        // columns of the (192, 64) matrix
     const long total = (long)B * T * 129;
     for (long p = (long)blockIdx.x * NT + threadIdx.x; p < total; p += (long)gridDim.x * NT) {
         const int j = (int)(p % 129);
@@ -789,7 +872,7 @@ __global__ __launch_bounds__(NT) void k_bs_mask_bwd(const float* __restrict__ do
             g0 = dr * re + di * im;
             g1 = di * re - dr * im;
         } else {
-            for (int i = 0; i < 192; ++i) {
+            for (int i = lo[j - 65]; i < hi[j - 65]; ++i) {
                 const float wi = ierb_w[(long)i * 64 + (j - 65)];
                 if (wi != 0.f) {
                     const int f = 65 + i;
@@ -1024,7 +1107,8 @@ int conv_wgrad(const ConvGeom& g, const float* in, const float* dout, float* dw,
 
 int dw_fwd(const DwGeom& g, const float* in, const float* w, const float* bias, float* out, hipStream_t s) {
     const int grid = grid_for((long)g.B * g.Tout * g.F);
-    if (g.C == 16) hipLaunchKernelGGL((k_dw<16>), dim3(grid), dim3(NT), 0, s, g, in, w, bias, out);
+    if (g.C == 16)
+        hipLaunchKernelGGL(k_dw16, dim3(grid_for((long)g.B * g.Tout * g.F * 4, 16384)), dim3(NT), 0, s, g, in, w, bias, out);
     else if (g.C == 3) hipLaunchKernelGGL((k_dw<3>), dim3(grid), dim3(NT), 0, s, g, in, w, bias, out);
     else return (int)hipErrorInvalidValue;
     return check();
@@ -1039,6 +1123,14 @@ int dw_wgrad(const DwGeom& g, const float* in, const float* dout, float* dw, flo
         if (g.nkf == 3) hipLaunchKernelGGL((k_dw_wgrad_stream<3, 3>), dim3(grid), dim3(NT), 0, s, g, in, dout, part);
         else hipLaunchKernelGGL((k_dw_wgrad_stream<3, 1>), dim3(grid), dim3(NT), 0, s, g, in, dout, part);
         hipLaunchKernelGGL(k_dw_wgrad_finish2, dim3((K + 63) / 64), dim3(1024), 0, s, g, part, grid, dw, dbias);
+        return check();
+    }
+    if (g.C == 3 && g.nkt == 1 && g.nkf == 3 && g.f_off[0] == -1 && g.f_off[2] == 1 && g.w_c == 3 && g.w_kf == 1) {
+        double* part = reinterpret_cast<double*>(scratch);
+        const long rows = (long)g.B * g.Tout;
+        const int grid = red_grid(rows * g.F);
+        hipLaunchKernelGGL(k_sfe_wgrad, dim3(grid), dim3(NT), 0, s, in, dout, rows, g.F, part);
+        hipLaunchKernelGGL(k_sfe_wgrad_finish, dim3(1), dim3(1024), 0, s, part, grid, dw);
         return check();
     }
     const long rows = (long)g.B * g.Tout;
