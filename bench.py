@@ -90,6 +90,57 @@ def cpu_baseline(params, seconds_budget=12.0):
     }
 
 
+def train_main(args):
+    """Secondary line (not the headline metric): train-step throughput, data parallel over utterance shards
+    with ONE collective per step, the all-reduce of the 19 014 gradient floats (RCCL over xGMI)."""
+    import torch
+    import torch.distributed as dist
+    from gtcrn_micro_amd.sharding import init_distributed, max_over_ranks
+    rank, local_rank, world = init_distributed(None)
+    torch.cuda.set_device(local_rank)
+    import __graft_entry__ as graft
+    if rank == 0:
+        graft.build()
+    if world > 1:
+        dist.barrier()
+    import gtcrn_micro_amd as G
+    from gtcrn_micro_amd.train import make_training, synthetic_mix, train_step
+    B = args.batch if args.batch != 256 else 512          # config 4: 512 clips per GPU
+    L = int(args.seconds * 16000)
+    T = 1 + L // 256
+    torch.manual_seed(43)                                     # identical initial weights on every rank
+    model, opt, sched, loss_func = make_training(device="cuda")
+    model.train()
+    noisy, clean = synthetic_mix(B, samples=L, seed=43 + rank)
+
+    def sync_all():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+    for _ in range(args.warmup):
+        train_step(model, opt, sched, loss_func, noisy, clean, world_size=world)
+    sync_all()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss, gn = train_step(model, opt, sched, loss_func, noisy, clean, world_size=world)
+    sync_all()
+    elapsed = max_over_ranks(time.perf_counter() - t0, "cuda")
+    if rank == 0:
+        print(json.dumps({
+            "metric": "train frames/sec (STFT x2 -> forward -> HybridLoss -> backward -> all-reduce -> clip -> Adam)",
+            "value": round(world * B * T * args.steps / elapsed, 1), "unit": "frames/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic DNS-style mixes",
+            "config": {"workload": f"train step, B={B} clips/GPU x {args.seconds:g} s (T={T}), fp32, Adam, clip 3.0",
+                       "parallelism": f"dp{world}: utterance shards + one all-reduce of 19 014 gradient floats per step"},
+            "workspace_GB": round(G.Trainer.workspace_bytes(B, T) / 2 ** 30, 2),
+            "loss": float(loss), "grad_norm": float(gn)}), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -98,6 +149,9 @@ def main():
     ap.add_argument("--batch", type=int, default=256, help="clips per GPU (BASELINE config 2: 256)")
     ap.add_argument("--seconds", type=float, default=4.0, help="clip length")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--mode", choices=["infer", "train"], default="infer",
+                    help="infer (default): the headline metric.  train: BASELINE config 4's shape -- full train steps "
+                         "(STFT x2, train-mode forward, HybridLoss, backward, gradient all-reduce, clip, Adam), fp32")
     ap.add_argument("--cpu-stub", action="store_true",
                     help="TEST ONLY (tests/test_dist_gloo.py): run the multi-rank control flow on CPU over gloo "
                          "with a stand-in for the HIP engine; the numbers it prints are meaningless")
@@ -108,6 +162,8 @@ def main():
     import torch.distributed as dist
 
     from gtcrn_micro_amd.sharding import init_distributed, max_over_ranks
+    if args.mode == "train":
+        return train_main(args)
     stub = args.cpu_stub
     rank, local_rank, world = init_distributed("gloo" if stub else None)
     if world != args.gpus and world > 1:

@@ -82,3 +82,41 @@ def test_bench_control_flow_two_ranks():
     T = 1 + 8000 // 256
     assert abs(d["value"] - 2 * 4 * T * 3 / (d["ms_per_step"] * 3 / 1e3)) / d["value"] < 1e-3
     assert "cpu_baseline" not in d and "STUB" in d["data"]
+
+
+_GRAD_WORKER = r"""
+import os, sys, json
+sys.path.insert(0, sys.argv[1])
+import torch, torch.distributed as dist
+from gtcrn_micro_amd.sharding import init_distributed
+from gtcrn_micro_amd.train import allreduce_gradients
+from gtcrn_micro_amd.models.gtcrn_micro import GTCRNMicro
+rank, local_rank, world = init_distributed("gloo")
+m = GTCRNMicro()                       # parameter containers only: nothing is computed on the CPU
+g = torch.Generator().manual_seed(100 + rank)
+for p in m.parameters():
+    if p.requires_grad:
+        p.grad = torch.randn(p.shape, generator=g)
+mine = torch.cat([p.grad.reshape(-1) for p in m.parameters() if p.grad is not None]).clone()
+n = allreduce_gradients(m, world)
+both = [torch.zeros_like(mine) for _ in range(world)]
+dist.all_gather(both, mine)
+want = (both[0] + both[1]) / 2
+got = torch.cat([p.grad.reshape(-1) for p in m.parameters() if p.grad is not None])
+ok = bool(torch.allclose(got, want, atol=1e-6)) and n == 19014
+dist.barrier()
+if rank == 0:
+    print(json.dumps({"ok": ok, "floats": n}))
+dist.destroy_process_group()
+"""
+
+
+def test_gradient_allreduce_two_ranks(tmp_path):
+    """The one exchange step of data-parallel training (train.py:87-88): the 19 014 gradient floats are
+    averaged over the ranks as one contiguous buffer."""
+    w = tmp_path / "grad_worker.py"
+    w.write_text(_GRAD_WORKER)
+    r = _torchrun([str(w), ROOT])
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+    assert json.loads(line) == {"ok": True, "floats": 19014}

@@ -169,3 +169,34 @@ def test_torch_port_matches_reference(tag):
     port = TorchPort(load_params(tag))
     assert rel_err(port.forward(g["spec"]).numpy(), g["spec_enh"]) < 2e-6
     assert rel_err(port.enhance(g["wave"][None], g["window"]).numpy()[0], g["wave_out"]) < 2e-6
+
+
+# ---- train mode: the PyTorch-CPU port (autograd) against the reference's own train step -------------------
+@pytest.mark.parametrize("tag", ["dns3", "rand"])
+def test_port_train_step_matches_reference(tag):
+    """oracle/torch_port.py in train mode is the checker of the HIP training path on shapes without a fixture:
+    pin it (forward, HybridLoss, d loss/d enh, all 248 gradients, running statistics) against the fixtures
+    the reference generated (tests/golden/make_golden_train.py)."""
+    import os
+    import numpy as np
+    from conftest import GOLDEN
+    from oracle.torch_port import TorchPort, is_trainable
+    import json
+    g = np.load(os.path.join(GOLDEN, f"trainstep_{tag}_B3_T12.npz"))
+    blob = np.fromfile(os.path.join(GOLDEN, f"params_{tag}.f32"), np.float32)
+    port = TorchPort(blob, train=True)
+    taps = {}
+    enh, loss, genh, grads = port.train_step(g["noisy_spec"], g["clean_spec"])
+    assert np.abs(enh - g["enh"]).max() / np.abs(g["enh"]).max() < 1e-4
+    assert abs(loss - float(g["loss"])) / float(g["loss"]) < 1e-5
+    assert np.abs(genh - g["grad_enh"]).max() / np.abs(g["grad_enh"]).max() < 2e-3
+    assert np.abs(grads - g["grads"]).max() / np.abs(g["grads"]).max() < 2e-3
+    assert np.abs(port.blob() - g["params_after"]).max() < 1e-5 * max(1.0, np.abs(g["params_after"]).max())
+    man = json.load(open(os.path.join(GOLDEN, "params_manifest.json")))
+    n_train = sum(int(np.prod(s)) for n, s, _ in man["tensors"] if is_trainable(n))
+    assert n_train == 19014 and sum(1 for n, _, _ in man["tensors"] if is_trainable(n)) == 248
+    port2 = TorchPort(blob, train=True)
+    port2.forward(g["noisy_spec"], taps)
+    for k in ("en0", "en1", "en2", "en4", "gtcn1", "gtcn2", "de0", "de2", "de3", "de4"):
+        ref = g["stage:" + k]
+        assert np.abs(taps[k].numpy() - ref).max() / np.abs(ref).max() < 1e-4, k
