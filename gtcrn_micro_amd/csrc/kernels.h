@@ -16,8 +16,8 @@ static_assert(TC * 33 % 16 == 0, "chunk must be a whole number of tiles");
 static_assert(NT2 % NW == 0, "tiles must divide evenly over the waves");
 
 // STFT / iSTFT geometry
-constexpr int FRAMES_PER_WAVE = 4;   // frames each of the 4 waves of a k_stft workgroup transforms
-constexpr int ISTFT_BLOCKS = 15;     // hop blocks one k_istft workgroup emits (from 16 frames)
+constexpr int FRAMES_PER_WAVE = 2;   // frames each of the 4 waves of a k_stft workgroup transforms
+constexpr int ISTFT_BLOCKS = 7;      // hop blocks one k_istft workgroup emits (from 8 frames: 38 KB of LDS, 4 workgroups per CU)
 
 // per-stream state (floats).  Rings are indexed by absolute frame number: the conv/TRA rings
 // hold 2 rows (row = frame & 1), TCN block k holds 2d rows (row = frame mod 2d, d = 2^k).
