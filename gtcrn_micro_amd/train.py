@@ -80,3 +80,26 @@ def train_step(model, optimizer, scheduler, loss_func, noisy, clean, clip_grad_n
     if scheduler is not None:
         scheduler.step()
     return loss.detach(), gn
+
+
+def save_checkpoint(path, model, optimizer, scheduler, epoch):
+    """The reference's checkpoint dict (train.py:200-216): {"epoch", "optimizer", "scheduler", "model"}, with the
+    model's 388-key state_dict on the CPU (DDP's wrapper is peeled like ``self.model.module`` there), so a
+    checkpoint written here loads into the reference and the other way round."""
+    m = model.module if hasattr(model, "module") else model
+    sd = {k: v.detach().cpu().clone() for k, v in m.state_dict().items()}
+    torch.save({"epoch": int(epoch), "optimizer": optimizer.state_dict(), "scheduler": scheduler.state_dict(),
+                "model": sd}, path)
+
+
+def load_checkpoint(path, model, optimizer=None, scheduler=None, map_location="cpu"):
+    """Counterpart of Trainer._resume_checkpoint (train.py:223-237) and of infer.py:39-41; tolerates DDP's
+    ``module.`` prefix (stream_onnx.py:45-47).  Returns the next epoch."""
+    ck = torch.load(path, map_location=map_location, weights_only=False)
+    m = model.module if hasattr(model, "module") else model
+    m.load_state_dict(ck["model"])
+    if optimizer is not None and "optimizer" in ck:
+        optimizer.load_state_dict(ck["optimizer"])
+    if scheduler is not None and "scheduler" in ck:
+        scheduler.load_state_dict(ck["scheduler"])
+    return int(ck.get("epoch", 0)) + 1

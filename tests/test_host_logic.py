@@ -105,3 +105,39 @@ def test_make_window_close_to_torch():
     from gtcrn_micro_amd import make_window
     g = golden("offline_dns3_T17.npz")
     assert np.abs(make_window(0) - g["window"]).max() < 2e-6
+
+
+def test_checkpoint_dict_round_trip(tmp_path):
+    """The reference's checkpoint layout (train.py:200-216): epoch/optimizer/scheduler/model, 388 model keys;
+    CPU-only (parameter containers), no kernels involved."""
+    import torch
+    from gtcrn_micro_amd.models.gtcrn_micro import GTCRNMicro, state_dict_to_blob
+    from gtcrn_micro_amd.train import load_checkpoint, save_checkpoint
+    from gtcrn_micro_amd.utils.scheduler import LinearWarmupCosineAnnealingLR
+    torch.manual_seed(3)
+    m = GTCRNMicro()
+    opt = torch.optim.Adam(m.parameters(), lr=1e-3)
+    sch = LinearWarmupCosineAnnealingLR(opt, 25000, 250000, 1e-3, 1e-6)
+    assert abs(opt.param_groups[0]["lr"]) < 1e-12               # step 0 of the warm-up
+    for p in m.parameters():
+        if p.requires_grad:
+            p.grad = torch.ones_like(p) * 0.01
+    opt.step(); sch.step()
+    assert abs(opt.param_groups[0]["lr"] - 4e-8) < 1e-15        # SURVEY 8f: lr after step 1 = 4e-8
+    path = str(tmp_path / "model_007.tar")
+    save_checkpoint(path, m, opt, sch, 7)
+    ck = torch.load(path, map_location="cpu", weights_only=False)
+    assert sorted(ck) == ["epoch", "model", "optimizer", "scheduler"] and len(ck["model"]) == 388
+    m2 = GTCRNMicro()
+    opt2 = torch.optim.Adam(m2.parameters(), lr=1e-3)
+    sch2 = LinearWarmupCosineAnnealingLR(opt2, 25000, 250000, 1e-3, 1e-6)
+    assert load_checkpoint(path, m2, opt2, sch2) == 8
+    assert np.array_equal(state_dict_to_blob(m2.state_dict()), state_dict_to_blob(m.state_dict()))
+    st, st2 = opt.state_dict()["state"], opt2.state_dict()["state"]
+    assert sch2.last_epoch == 1 and sorted(st) == sorted(st2) and len(st) == 248
+    k0 = sorted(st)[0]
+    assert float(st[k0]["step"]) == float(st2[k0]["step"]) == 1.0
+    # DDP-prefixed checkpoints load too
+    ck["model"] = {"module." + k: v for k, v in ck["model"].items()}
+    torch.save(ck, path)
+    assert load_checkpoint(path, GTCRNMicro()) == 8
