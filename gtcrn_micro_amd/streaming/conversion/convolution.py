@@ -6,7 +6,8 @@ Same constructor arguments, state_dict keys (``Conv2d.weight`` / ``ConvTranspose
 ``gtcrn_stream_conv2d``.  ``StreamConvTranspose2d`` keeps a ``Conv2d`` parameter holder whose weight is the
 permuted + flipped one that ``convert_to_stream`` produces (convert.py:35-48), exactly like the reference.
 Frequency stride > 1 is not supported (the model never uses it; the reference's branch for it allocates on
-the CPU, :222).  ``StreamConv1d`` (unused by the model) has no mirror.
+the CPU, :222).  ``StreamConv1d`` (:10-59, unused by the model) runs through the same kernel with one
+frequency bin.
 """
 import torch
 import torch.nn as nn
@@ -20,6 +21,26 @@ def _pair(v, what):
     if isinstance(v, (list, tuple)):
         return tuple(v)
     raise ValueError(f"Invalid {what}!")
+
+
+class StreamConv1d(nn.Module):
+    """``forward(x [bs,C,T], cache [bs,C,(K-1)*dilation]) -> (output, out_cache)``: conv over ``cat([cache, x])``
+    and, like the reference (:52-59), ``out_cache = cat([cache, x])[..., 1:]``."""
+
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, dilation=1, groups=1,
+                 bias=True, *args, **kwargs):
+        super().__init__(*args, **kwargs)
+        assert padding == 0, "Padding must be 0 to keep it causal!"
+        if stride != 1:
+            raise NotImplementedError("stride 1 only")
+        self.Conv1d = nn.Conv1d(in_channels, out_channels, kernel_size, stride=stride, padding=padding,
+                                dilation=dilation, groups=groups, bias=bias)
+
+    def forward(self, x, cache):
+        c = self.Conv1d
+        y, _ = _lib.stream_conv2d(x.unsqueeze(-1), cache.unsqueeze(-1), c.weight.unsqueeze(-1), c.bias,
+                                  c.kernel_size[0], 1, c.dilation[0], 1, 0, c.groups, transposed=False)
+        return y.squeeze(-1), torch.cat([cache, x], dim=-1)[..., 1:]
 
 
 class StreamConv2d(nn.Module):

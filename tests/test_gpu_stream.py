@@ -140,3 +140,27 @@ def test_conv_wrappers_like_reference_test(dev):
     from gtcrn_micro_amd._lib import stream_conv2d
     y, _ = stream_conv2d(cu(g["ct33_x"]), None, cu(g["ct33_w"]), cu(g["ct33_b"]), 3, 3, pad_f=1, transposed=True)
     assert np.abs(y.cpu().numpy() - g["ct33_y"][:, :, :9]).max() < 2e-6
+
+
+def test_stream_conv1d_streaming_equals_offline(dev):
+    """StreamConv1d (streaming/conversion/convolution.py:10-59): frame-by-frame == nn.Conv1d over the padded clip
+    (checker: plain PyTorch fp32 on the CPU), incl. dilation and groups; out_cache = cat([cache, x])[..., 1:]."""
+    import torch.nn as nn
+    from gtcrn_micro_amd.streaming.conversion.convolution import StreamConv1d
+    torch.manual_seed(2)
+    for cin, cout, k, d, groups in ((8, 8, 3, 1, 8), (4, 6, 3, 2, 1)):
+        ref = nn.Conv1d(cin, cout, k, dilation=d, groups=groups)
+        sc = StreamConv1d(cin, cout, k, dilation=d, groups=groups)
+        sc.Conv1d.load_state_dict(ref.state_dict())
+        sc = sc.cuda()
+        x = torch.randn(2, cin, 20)
+        H = (k - 1) * d
+        want = ref(torch.nn.functional.pad(x, [H, 0])).detach().numpy()
+        cache = torch.zeros(2, cin, H, device="cuda")
+        outs = []
+        for i in range(20):
+            o, cache = sc(x[:, :, i:i + 1].cuda(), cache)
+            assert cache.shape == (2, cin, H)
+            outs.append(o)
+        assert np.abs(torch.cat(outs, 2).cpu().numpy() - want).max() < 1e-5
+        assert torch.equal(cache.cpu(), x[:, :, 20 - H:])
