@@ -269,25 +269,34 @@ __global__ __launch_bounds__(WG_WAVES * 64) void k_conv_wgrad_mfma(ConvGeom g, c
             P.init(p0 < npos ? p0 : npos - 1, g.Fout, g.Tout);
         }
         const bool co_ok = c < g.Cout, ci_ok = c < g.Cin;
-        for (; grp < gend; ++grp) {
-            const long p = grp * 4 + k;
-            const bool pv = p < npos;
-            const float a = (pv && co_ok) ? dout[p * g.CoutT + g.cout_off + c] : 0.f;
-            bsum += a;
+        constexpr int U = 4;      // groups per iteration: all their loads are issued before the first MFMA
+        for (; grp < gend; grp += U) {
+            float a[U], bb[U][NTAP];
 #pragma unroll
-            for (int kt = 0; kt < NKT; ++kt) {
-                const int ti = P.t + g.t_off[kt];
-                const bool okt = pv && ci_ok && ti >= 0 && ti < g.Tin;
-                const long rowbase = ((long)P.b * g.Tin + ti) * g.Fin;
+            for (int u = 0; u < U; ++u) {
+                const long p = (grp + u) * 4 + k;
+                const bool pv = p < npos && grp + u < gend;
+                a[u] = (pv && co_ok) ? dout[p * g.CoutT + g.cout_off + c] : 0.f;
 #pragma unroll
-                for (int kf = 0; kf < NKF; ++kf) {
-                    int fi;
-                    const bool ok = tap_fi(g, P.f, kf, fi) && okt;
-                    const float b = ok ? in[(rowbase + fi) * g.CinT + g.cin_off + c] : 0.f;
-                    acc[kt * NKF + kf] = mfma4(a, b, acc[kt * NKF + kf]);
+                for (int kt = 0; kt < NKT; ++kt) {
+                    const int ti = P.t + g.t_off[kt];
+                    const bool okt = pv && ci_ok && ti >= 0 && ti < g.Tin;
+                    const long rowbase = ((long)P.b * g.Tin + ti) * g.Fin;
+#pragma unroll
+                    for (int kf = 0; kf < NKF; ++kf) {
+                        int fi;
+                        const bool ok = tap_fi(g, P.f, kf, fi) && okt;
+                        bb[u][kt * NKF + kf] = ok ? in[(rowbase + fi) * g.CinT + g.cin_off + c] : 0.f;
+                    }
                 }
+                P.advance(4, g.Fout, g.Tout);
             }
-            P.advance(4, g.Fout, g.Tout);
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                bsum += a[u];
+#pragma unroll
+                for (int tap = 0; tap < NTAP; ++tap) acc[tap] = mfma4(a[u], bb[u][tap], acc[tap]);
+            }
         }
     }
     // D fragment: lane (j = c, q = k) holds dW[co = 4q + r][ci = j] of each tap
@@ -551,14 +560,19 @@ __global__ __launch_bounds__(NT) void k_bn_act(const float* __restrict__ y, long
                                               const float* __restrict__ slope, float* __restrict__ a) {
     const float sl = slope ? slope[0] : 0.f;
     const long units = total / V;
+    // the stride is a multiple of C: the thread's channels and their constants are fixed
+    const int c0 = (int)((((long)blockIdx.x * NT + threadIdx.x) * V) % C);
+    float mean[V], istd[V], gm[V], bt[V];
+#pragma unroll
+    for (int e = 0; e < V; ++e) { mean[e] = stats[c0 + e]; istd[e] = stats[C + c0 + e]; gm[e] = gamma[c0 + e]; bt[e] = beta[c0 + e]; }
     for (long i = (long)blockIdx.x * NT + threadIdx.x; i < units; i += (long)gridDim.x * NT) {
-        const int c0 = (int)((i * V) % C);
         float x[V], r[V], o[V];
         load_vec<V>(y + i * V, x);
         if (res) load_vec<V>(res + i * V, r);
 #pragma unroll
         for (int e = 0; e < V; ++e) {
-            float z = gamma[c0 + e] * ((x[e] - stats[c0 + e]) * stats[C + c0 + e]) + beta[c0 + e];
+            // same expression order as the backward's recomputation of z: gamma * ((y - mean) * invstd) + beta
+            float z = gm[e] * ((x[e] - mean[e]) * istd[e]) + bt[e];
             if (res) z += r[e];
             o[e] = act_fwd(z, act, sl);
         }
