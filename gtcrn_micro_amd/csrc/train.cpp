@@ -294,10 +294,11 @@ int ensure_plan(gtcrn_trainer* t, int B, int T) {
 }
 
 int unit_fwd(gtcrn_trainer* t, Unit& u, float* prm, hipStream_t s) {
-    if (u.dw) T_RUN(gtt::dw_fwd(u.dg, u.x, prm + u.o_w, prm + u.o_b, u.y, s));
-    else T_RUN(gtt::conv_fwd(u.cg, u.x, prm + u.o_w, prm + u.o_b, u.y, s));
+    int parts = 0;   // > 0: the conv kernel produced the BatchNorm partial sums in its epilogue
+    if (u.dw) T_RUN(gtt::dw_fwd(u.dg, u.x, prm + u.o_w, prm + u.o_b, u.y, s, t->dscratch, &parts));
+    else T_RUN(gtt::conv_fwd(u.cg, u.x, prm + u.o_w, prm + u.o_b, u.y, s, t->dscratch, &parts));
     float* bn = prm + u.o_bn;   // weight, bias, running_mean, running_var (consecutive in the blob)
-    T_RUN(gtt::bn_stats(u.y, u.n, u.C, u.stats, bn + 2 * u.C, bn + 3 * u.C, t->dscratch, s));
+    T_RUN(gtt::bn_stats(u.y, u.n, u.C, u.stats, bn + 2 * u.C, bn + 3 * u.C, t->dscratch, s, parts));
     T_RUN(gtt::bn_act(u.y, u.n, u.C, u.stats, bn, bn + u.C, u.res, u.act, u.o_slope >= 0 ? prm + u.o_slope : nullptr,
                       u.a, s));
     return 0;

@@ -43,19 +43,23 @@ enum Act { ACT_NONE = 0, ACT_PRELU = 1, ACT_TANH = 2 };
 
 constexpr int MAX_PARTIALS = 1024;   // workgroups of a two-stage reduction
 
-int conv_fwd(const ConvGeom& g, const float* in, const float* w, const float* bias, float* out, hipStream_t s);
+// stat_partial/stat_parts (optional): the kernel also leaves per-workgroup sums of out and out^2 per channel
+// (layout of bn_stats' scratch) and reports their count, so the BatchNorm statistics need no extra pass.
+int conv_fwd(const ConvGeom& g, const float* in, const float* w, const float* bias, float* out, hipStream_t s,
+             double* stat_partial = nullptr, int* stat_parts = nullptr);
 // dW (and db when dbias != nullptr) of the convolution g: in = its input, dout = gradient of its output.
 // scratch: MAX_PARTIALS * (9*256 + 16) floats.
 int conv_wgrad(const ConvGeom& g, const float* in, const float* dout, float* dw, float* dbias, float* scratch,
                hipStream_t s);
-int dw_fwd(const DwGeom& g, const float* in, const float* w, const float* bias, float* out, hipStream_t s);
+int dw_fwd(const DwGeom& g, const float* in, const float* w, const float* bias, float* out, hipStream_t s,
+           double* stat_partial = nullptr, int* stat_parts = nullptr);
 int dw_wgrad(const DwGeom& g, const float* in, const float* dout, float* dw, float* dbias, float* scratch,
              hipStream_t s);
 
 // BatchNorm (train mode) of y [n][C]: batch statistics, running-statistics update (momentum 0.1, unbiased
 // variance), stats[0..C) = mean, stats[C..2C) = 1/sqrt(var + 1e-5).  scratch: MAX_PARTIALS * 2 * C doubles.
 int bn_stats(const float* y, long n, int C, float* stats, float* running_mean, float* running_var, double* scratch,
-             hipStream_t s);
+             hipStream_t s, int have_parts = 0);
 // a = act(gamma * (y - mean) * invstd + beta [+ res])
 int bn_act(const float* y, long n, int C, const float* stats, const float* gamma, const float* beta,
            const float* res, int act, const float* slope, float* a, hipStream_t s);

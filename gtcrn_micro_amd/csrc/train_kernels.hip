@@ -195,8 +195,10 @@ struct Pos {
 template <int NKT, int NKF>
 __global__ __launch_bounds__(NT) void k_conv_mfma(ConvGeom g, const float* __restrict__ in,
                                                  const float* __restrict__ w, const float* __restrict__ bias,
-                                                 float* __restrict__ out, long tiles_per_wave) {
+                                                 float* __restrict__ out, long tiles_per_wave,
+                                                 double* __restrict__ stat_partial) {
     __shared__ __attribute__((aligned(16))) float sW[NKT * NKF * 256];   // [tap][co][ci], zero padded
+    __shared__ float sStat[NT][8];
     const int tid = threadIdx.x;
     for (int i = tid; i < NKT * NKF * 256; i += NT) {
         const int tap = i >> 8, co = (i >> 4) & 15, ci = i & 15, kt = tap / NKF, kf = tap - kt * NKF;
@@ -208,7 +210,7 @@ __global__ __launch_bounds__(NT) void k_conv_mfma(ConvGeom g, const float* __res
     const long wave = (long)blockIdx.x * (NT / 64) + (tid >> 6);
     long tile = wave * tiles_per_wave;
     const long tend = tile + tiles_per_wave < ntiles ? tile + tiles_per_wave : ntiles;
-    if (tile >= tend) return;
+    f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = {0.f, 0.f, 0.f, 0.f};    // BatchNorm statistics of this lane's outputs
     Pos P;
     {
         const long p0 = tile * 16 + n;
@@ -240,8 +242,24 @@ __global__ __launch_bounds__(NT) void k_conv_mfma(ConvGeom g, const float* __res
         if (pv && cout_ok) {
             f32x4* o = reinterpret_cast<f32x4*>(out + p * g.CoutT + g.cout_off + 4 * q);
             *o = g.accumulate ? *o + acc : acc;
+            s1 += acc;
+            s2 += acc * acc;
         }
         P.advance(16, g.Fout, g.Tout);
+    }
+    if (stat_partial) {
+        // per-workgroup sums of y and y^2 per channel (the conv is followed by a train-mode BatchNorm):
+        // lanes -> LDS -> one thread per (sum, channel), fixed order; combined across workgroups by k_bn_stats_finish
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { sStat[tid][e] = s1[e]; sStat[tid][4 + e] = s2[e]; }
+        __syncthreads();
+        if (tid < 2 * g.Cout) {
+            const int which = tid / g.Cout, ch = tid - which * g.Cout, qq = ch >> 2, e = ch & 3;
+            double t = 0.0;
+            for (int l = 0; l < NT; ++l)
+                if (((l & 63) >> 4) == qq) t += (double)sStat[l][which * 4 + e];
+            stat_partial[(long)blockIdx.x * 2 * g.Cout + tid] = t;
+        }
     }
 }
 
@@ -385,8 +403,11 @@ __global__ __launch_bounds__(NT) void k_dw(DwGeom g, const float* __restrict__ i
 
 // C = 16: one thread per (position, 4 channels): every tap is one coalesced 16-byte load
 __global__ __launch_bounds__(NT) void k_dw16(DwGeom g, const float* __restrict__ in, const float* __restrict__ w,
-                                            const float* __restrict__ bias, float* __restrict__ out) {
+                                            const float* __restrict__ bias, float* __restrict__ out,
+                                            double* __restrict__ stat_partial) {
     __shared__ __attribute__((aligned(16))) float sW[9 * 16];   // [tap][c]
+    __shared__ float sStat[NT][8];
+    f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = {0.f, 0.f, 0.f, 0.f};
     const int tid = threadIdx.x, ntap = g.nkt * g.nkf;
     for (int i = tid; i < ntap * 16; i += NT) {
         const int tap = i >> 4, c = i & 15, kt = tap / g.nkf, kf = tap - kt * g.nkf;
@@ -415,6 +436,19 @@ __global__ __launch_bounds__(NT) void k_dw16(DwGeom g, const float* __restrict__
         }
         f32x4* o = reinterpret_cast<f32x4*>(out + p * 16 + 4 * q);
         *o = g.accumulate ? *o + acc : acc;
+        s1 += acc;
+        s2 += acc * acc;
+    }
+    if (stat_partial) {   // per-workgroup BatchNorm partial sums; a thread's channel quad is tid & 3
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { sStat[tid][e] = s1[e]; sStat[tid][4 + e] = s2[e]; }
+        __syncthreads();
+        if (tid < 32) {
+            const int which = tid >> 4, ch = tid & 15, qq = ch >> 2, e = ch & 3;
+            double t = 0.0;
+            for (int l = qq; l < NT; l += 4) t += (double)sStat[l][which * 4 + e];
+            stat_partial[(long)blockIdx.x * 32 + tid] = t;
+        }
     }
 }
 
@@ -1066,16 +1100,21 @@ static bool mfma_ok(const ConvGeom& g) {
            ((g.nkt == 1 && (g.nkf == 1 || g.nkf == 5)) || (g.nkt == 3 && g.nkf == 3));
 }
 
-int conv_fwd(const ConvGeom& g, const float* in, const float* w, const float* bias, float* out, hipStream_t s) {
+int conv_fwd(const ConvGeom& g, const float* in, const float* w, const float* bias, float* out, hipStream_t s,
+             double* stat_partial, int* stat_parts) {
+    if (stat_parts) *stat_parts = 0;
     if (mfma_ok(g)) {
         const long ntiles = ((long)g.B * g.Tout * g.Fout + 15) / 16;
         long waves = 256L * 4 * 4;                       // 4 workgroups of 4 waves per CU
         if (waves > ntiles) waves = ntiles;
         const long tpw = (ntiles + waves - 1) / waves;
         const int grid = (int)((ntiles + tpw * 4 - 1) / (tpw * 4));
-        if (g.nkt == 3) hipLaunchKernelGGL((k_conv_mfma<3, 3>), dim3(grid), dim3(NT), 0, s, g, in, w, bias, out, tpw);
-        else if (g.nkf == 5) hipLaunchKernelGGL((k_conv_mfma<1, 5>), dim3(grid), dim3(NT), 0, s, g, in, w, bias, out, tpw);
-        else hipLaunchKernelGGL((k_conv_mfma<1, 1>), dim3(grid), dim3(NT), 0, s, g, in, w, bias, out, tpw);
+        double* sp = (stat_partial && stat_parts && grid <= MAX_PARTIALS && g.cout_off == 0 && g.Cout == g.CoutT &&
+                      !g.accumulate) ? stat_partial : nullptr;
+        if (g.nkt == 3) hipLaunchKernelGGL((k_conv_mfma<3, 3>), dim3(grid), dim3(NT), 0, s, g, in, w, bias, out, tpw, sp);
+        else if (g.nkf == 5) hipLaunchKernelGGL((k_conv_mfma<1, 5>), dim3(grid), dim3(NT), 0, s, g, in, w, bias, out, tpw, sp);
+        else hipLaunchKernelGGL((k_conv_mfma<1, 1>), dim3(grid), dim3(NT), 0, s, g, in, w, bias, out, tpw, sp);
+        if (sp) *stat_parts = grid;
         return check();
     }
     const int grid = grid_for((long)g.B * g.Tout * g.Fout);
@@ -1119,10 +1158,17 @@ int conv_wgrad(const ConvGeom& g, const float* in, const float* dout, float* dw,
     return (int)hipErrorInvalidValue;
 }
 
-int dw_fwd(const DwGeom& g, const float* in, const float* w, const float* bias, float* out, hipStream_t s) {
+int dw_fwd(const DwGeom& g, const float* in, const float* w, const float* bias, float* out, hipStream_t s,
+           double* stat_partial, int* stat_parts) {
+    if (stat_parts) *stat_parts = 0;
     const int grid = grid_for((long)g.B * g.Tout * g.F);
-    if (g.C == 16)
-        hipLaunchKernelGGL(k_dw16, dim3(grid_for((long)g.B * g.Tout * g.F * 4, 16384)), dim3(NT), 0, s, g, in, w, bias, out);
+    if (g.C == 16) {
+        double* sp = (stat_partial && stat_parts && !g.accumulate) ? stat_partial : nullptr;
+        const int g16 = grid_for((long)g.B * g.Tout * g.F * 4, sp ? MAX_PARTIALS : 16384);
+        hipLaunchKernelGGL(k_dw16, dim3(g16), dim3(NT), 0, s, g, in, w, bias, out, sp);
+        if (sp) *stat_parts = g16;
+        return check();
+    }
     else if (g.C == 3) hipLaunchKernelGGL((k_dw<3>), dim3(grid), dim3(NT), 0, s, g, in, w, bias, out);
     else return (int)hipErrorInvalidValue;
     return check();
@@ -1158,8 +1204,13 @@ int dw_wgrad(const DwGeom& g, const float* in, const float* dout, float* dw, flo
 }
 
 int bn_stats(const float* y, long n, int C, float* stats, float* running_mean, float* running_var, double* scratch,
-             hipStream_t s) {
+             hipStream_t s, int have_parts) {
     const long total = n * C;
+    if (have_parts > 0) {     // the producing conv already left its per-workgroup sums in scratch
+        hipLaunchKernelGGL(k_bn_stats_finish, dim3(1), dim3(1024), 0, s, scratch, have_parts, n, C, stats, running_mean,
+                           running_var);
+        return check();
+    }
     if (C % 4 == 0) {
         const int grid = red_grid(total / 4);
         hipLaunchKernelGGL((k_bn_stats<4>), dim3(grid), dim3(NT), 0, s, y, total, C, scratch);
