@@ -350,6 +350,9 @@ static int check_spec_layout(const void* p, long sb, long sf, long st) {
     // the kernels move the (re, im) pair with 8-byte accesses
     if ((reinterpret_cast<uintptr_t>(p) & 7) || (sb & 1) || (sf & 1) || (st & 1))
         return fail(GTCRN_ERR_ARG, "spectrogram base must be 8-byte aligned and its strides even (re/im pairs)");
+    // inside one 16-frame chunk the kernels address with 32-bit element offsets (256 bins, 15 frames)
+    const long span = 256 * (sf < 0 ? -sf : sf) + 15 * (st < 0 ? -st : st);
+    if (span >= (1L << 31)) return fail(GTCRN_ERR_ARG, "spectrogram strides too large (a chunk must span < 2^31 floats)");
     return 0;
 }
 

@@ -348,6 +348,23 @@ __device__ __forceinline__ int ring35(const Tiles& t, int i, int g, int tbase, i
 }
 
 
+// The spectrogram elements of a chunk a thread handles: item q is element idx = tid + q*NTHR of the chunk,
+// idx -> (frame tq, bin f) with f fastest for the frame-major layout and tq fastest for the reference layout
+// (consecutive frames adjacent).  One constant division for the first item, increments afterwards.
+__device__ __forceinline__ void spec_item_first(int tid, bool t_fast, int& tq, int& f) {
+    if (t_fast) { tq = tid & (TC - 1); f = tid >> 4; }
+    else { tq = tid / NBINS; f = tid - tq * NBINS; }
+}
+__device__ __forceinline__ void spec_item_next(bool t_fast, int& tq, int& f) {
+    static_assert(NTHR % TC == 0 && NTHR >= 2 * NBINS && NTHR < 3 * NBINS, "item stride decomposition");
+    if (t_fast) f += NTHR / TC;
+    else {
+        f += NTHR - 2 * NBINS;
+        tq += 2;
+        if (f >= NBINS) { f -= NBINS; ++tq; }
+    }
+}
+
 struct BlockCtx {
     const float* pb;     // LDS: block parameters (GB_* offsets)
     const float* gA;     // LDS: dense 3x3 slot matrices (decoder) or nullptr
@@ -602,16 +619,19 @@ __global__ __launch_bounds__(NTHR) void k_encoder(const float* __restrict__ spec
     // registers, so its HBM latency is hidden behind the previous chunk's compute.
     constexpr int SPEC_ITEMS = (TC * NBINS + NTHR - 1) / NTHR;
     float2 spn[SPEC_ITEMS];
+    const int sf32 = (int)sf, st32 = (int)st;     // api.cpp checks that a chunk's offsets fit in 31 bits
     auto spec_fetch = [&](int t0f) {
         const int nf = min(TC, T - t0f);
+        const float* base = spec + (long)t0f * st;           // wave-uniform
+        int tv0 = tid;
+        asm volatile("" : "+v"(tv0));   // recomputed per chunk: keeps the item coordinates out of long-lived registers
+        int tl, f;
+        spec_item_first(tv0, t_fast, tl, f);
 #pragma unroll
         for (int q = 0; q < SPEC_ITEMS; ++q) {
-            int idx = tid + q * NTHR;
-            asm volatile("" : "+v"(idx));
-            int tl, f;
-            if (t_fast) { tl = idx & (TC - 1); f = idx >> 4; } else { f = idx % NBINS; tl = idx / NBINS; }
-            if (tl >= nf || f >= NBINS) { tl = 0; f = 0; }   // clamped: no select behind the load
-            spn[q] = *reinterpret_cast<const float2*>(spec + (long)f * sf + (long)(t0f + tl) * st);
+            const bool ok = tl < nf && f < NBINS;            // clamped: no select behind the load
+            spn[q] = *reinterpret_cast<const float2*>(base + (ok ? f * sf32 + tl * st32 : 0));
+            spec_item_next(t_fast, tl, f);
         }
     };
     spec_fetch(0);
@@ -634,19 +654,21 @@ __global__ __launch_bounds__(NTHR) void k_encoder(const float* __restrict__ spec
         // ---- A0: stage [mag, re, im] of the chunk in LDS; the magnitude (models/gtcrn_micro.py:514) is
         //      computed once per bin here.  The 65 pass-through bins of ERB.bm (:63-67) go straight to
         //      their place in EB; the 192 high bins are staged as [c][tl][257] for the band filters -------
-#pragma unroll
-        for (int q = 0; q < SPEC_ITEMS; ++q) {
-            int idx = tv + q * NTHR;
+        {
             int tl, f;
-            if (t_fast) { tl = idx & (TC - 1); f = idx >> 4; } else { f = idx % NBINS; tl = idx / NBINS; }
-            if (tl < nfr && f < NBINS) {
-                const float2 v = spn[q];
-                const bool low = f < ERB_LOW;
-                float* d = low ? sEB + tl * EB_ROW + 1 + f : sSpec + tl * NBINS + f;
-                const int cs = low ? TC * EB_ROW : TC * NBINS;
-                d[0] = __builtin_amdgcn_sqrtf(v.x * v.x + v.y * v.y + 1e-12f);
-                d[cs] = v.x;
-                d[2 * cs] = v.y;
+            spec_item_first(tv, t_fast, tl, f);
+#pragma unroll
+            for (int q = 0; q < SPEC_ITEMS; ++q) {
+                if (tl < nfr && f < NBINS) {
+                    const float2 v = spn[q];
+                    const bool low = f < ERB_LOW;
+                    float* d = low ? sEB + tl * EB_ROW + 1 + f : sSpec + tl * NBINS + f;
+                    const int cs = low ? TC * EB_ROW : TC * NBINS;
+                    d[0] = __builtin_amdgcn_sqrtf(v.x * v.x + v.y * v.y + 1e-12f);
+                    d[cs] = v.x;
+                    d[2 * cs] = v.y;
+                }
+                spec_item_next(t_fast, tl, f);
             }
         }
         STAMP(SS, 10)
@@ -1129,6 +1151,7 @@ __global__ __launch_bounds__(NTHR) void k_decoder(const float* __restrict__ xg, 
     spec += (long)b * sb;
     out += (long)b * osb;
     const bool t_fast = st < sf;
+    const int sf32 = (int)sf, st32 = (int)st, osf32 = (int)osf, ost32 = (int)ost;
     constexpr int MASK_ITEMS = (TC * NBINS + NTHR - 1) / NTHR;   // spectrogram bins per thread and chunk
     STAMP(SS, 0)
 
@@ -1277,17 +1300,20 @@ __global__ __launch_bounds__(NTHR) void k_decoder(const float* __restrict__ xg, 
         // the input spectrogram for the mask is fetched here so that its latency hides behind the
         // de_convs.4 gather below
         float2 spv[MASK_ITEMS];
-#pragma unroll
-        for (int q = 0; q < MASK_ITEMS; ++q) {
-            int idx = tid + q * NTHR;
-            // opaque per chunk: otherwise the per-item 64-bit addresses are hoisted out of the chunk
-            // loop, spilled, and every reload drains the loads in flight (scratch shares vmcnt)
-            asm volatile("" : "+v"(idx));
+        {
+            // item coordinates recomputed per chunk (opaque tid): hoisted out of the chunk loop they would be
+            // spilled, and every scratch reload drains the loads in flight (scratch shares vmcnt)
+            int tz = tid;
+            asm volatile("" : "+v"(tz));
             int tq, f;
-            if (t_fast) { tq = idx & (TC - 1); f = idx >> 4; } else { f = idx % NBINS; tq = idx / NBINS; }
-            spv[q] = make_float2(0.f, 0.f);
-            if (tq < nfr && f < NBINS)
-                spv[q] = *reinterpret_cast<const float2*>(spec + (long)f * sf + (long)(t0 + tq) * st);
+            spec_item_first(tz, t_fast, tq, f);
+            const float* sbase = spec + (long)t0 * st;       // wave-uniform; per-lane offsets fit in 31 bits (api.cpp)
+#pragma unroll
+            for (int q = 0; q < MASK_ITEMS; ++q) {
+                const bool ok = tq < nfr && f < NBINS;
+                spv[q] = *reinterpret_cast<const float2*>(sbase + (ok ? f * sf32 + tq * st32 : 0));
+                spec_item_next(t_fast, tq, f);
+            }
         }
         STAMP(SS, 15)
         wg_barrier();
@@ -1302,13 +1328,22 @@ __global__ __launch_bounds__(NTHR) void k_decoder(const float* __restrict__ xg, 
         // de_convs.4 gather + BN + Tanh: m[o][f''] = tanh(b[o] + sum_k z[(f''+2-k)/2][o*5+k]).  Branch free:
         // even f'' = 2m takes k = 0,2,4 from rows m+1, m, m-1; odd f'' = 2m+1 takes k = 1,3 from rows m+1, m
         // and a zero slot (rows 10..15 of the de_conv4 slot matrix are zero); the end records are zero.
-        for (int idx = tid; idx < 2 * nfr * F0; idx += NTHR) {
-            const int fq = idx % F0, ot = idx / F0, o = ot >= nfr ? 1 : 0, tq = ot - o * nfr;
-            const int par = fq & 1, m = fq >> 1;
-            const float* zr = sZ + (tq * DEC_Z_ROW + 1 + m) * 16;
-            const float sum = sP[D_DE4_B + o] + zr[16 + o * 5 + par] + zr[o * 5 + 2 + par] +
-                              zr[-16 + (par ? 10 : o * 5 + 4)];
-            sM[(o * TC + tq) * F0 + fq] = fast_tanh(sum);
+        {
+            static_assert(NTHR == 5 * F0 + 59, "item stride decomposition");
+            int tz = tid;
+            asm volatile("" : "+v"(tz));
+            int ot = tz / F0, fq = tz - ot * F0;      // one constant division, increments afterwards
+            for (int idx = tz; idx < 2 * nfr * F0; idx += NTHR) {
+                const int o = ot >= nfr ? 1 : 0, tq = ot - o * nfr;
+                const int par = fq & 1, m = fq >> 1;
+                const float* zr = sZ + (tq * DEC_Z_ROW + 1 + m) * 16;
+                const float sum = sP[D_DE4_B + o] + zr[16 + o * 5 + par] + zr[o * 5 + 2 + par] +
+                                  zr[-16 + (par ? 10 : o * 5 + 4)];
+                sM[(o * TC + tq) * F0 + fq] = fast_tanh(sum);
+                fq += 59;
+                ot += 5;
+                if (fq >= F0) { fq -= F0; ++ot; }
+            }
         }
         wg_barrier();
         STAMP(SS, 13)
@@ -1319,23 +1354,27 @@ __global__ __launch_bounds__(NTHR) void k_decoder(const float* __restrict__ xg, 
                     sM[(o * TC + tq) * F0 + fq];
             }
         // ---- ERB.bs + complex ratio mask + output layout --------------------------------------------
-#pragma unroll
-        for (int q = 0; q < MASK_ITEMS; ++q) {
-            int idx = tid + q * NTHR;
-            asm volatile("" : "+v"(idx));
+        {
+            int tz = tid;
+            asm volatile("" : "+v"(tz));
             int tq, f;
-            if (t_fast) { tq = idx & (TC - 1); f = idx >> 4; } else { f = idx % NBINS; tq = idx / NBINS; }
-            if (tq < nfr && f < NBINS) {
-                const f32x4 tb = ld4(sBS + f * 4);
-                const float* m0 = sM + tq * F0 + __float_as_int(tb[0]);
-                // second tap selected, not multiplied by a zero weight: for the last band it would read the
-                // first element of the next frame's row, which may be stale (0 * NaN)
-                const bool two = tb[2] != 0.f;
-                const float mr = tb[1] * m0[0] + (two ? tb[2] * m0[1] : 0.f);
-                const float mi = tb[1] * m0[TC * F0] + (two ? tb[2] * m0[TC * F0 + 1] : 0.f);
-                const float re = spv[q].x, im = spv[q].y;
-                *reinterpret_cast<float2*>(out + (long)f * osf + (long)(t0 + tq) * ost) =
-                    make_float2(re * mr - im * mi, im * mr + re * mi);
+            spec_item_first(tz, t_fast, tq, f);
+            float* obase = out + (long)t0 * ost;
+#pragma unroll
+            for (int q = 0; q < MASK_ITEMS; ++q) {
+                if (tq < nfr && f < NBINS) {
+                    const f32x4 tb = ld4(sBS + f * 4);
+                    const float* m0 = sM + tq * F0 + __float_as_int(tb[0]);
+                    // second tap selected, not multiplied by a zero weight: for the last band it would read the
+                    // first element of the next frame's row, which may be stale (0 * NaN)
+                    const bool two = tb[2] != 0.f;
+                    const float mr = tb[1] * m0[0] + (two ? tb[2] * m0[1] : 0.f);
+                    const float mi = tb[1] * m0[TC * F0] + (two ? tb[2] * m0[TC * F0 + 1] : 0.f);
+                    const float re = spv[q].x, im = spv[q].y;
+                    *reinterpret_cast<float2*>(obase + (f * osf32 + tq * ost32)) =
+                        make_float2(re * mr - im * mi, im * mr + re * mi);
+                }
+                spec_item_next(t_fast, tq, f);
             }
         }
         wg_barrier();  // sM and region A are rewritten by the next chunk
