@@ -1,8 +1,10 @@
 // train_kernels.hip -- gfx950 kernels of the train-mode forward/backward (see train_kernels.h).
 //
-// First correct version of the training row: every pass streams
-// channels-last tensors through HBM once, one thread per output position, fp32 VALU arithmetic,
-// two-stage reductions with a fixed summation order (bit-reproducible gradients; no atomics).
+// The training row is layer-at-a-time (train-mode BatchNorm needs whole-batch
+// statistics between layers), so every pass streams channels-last tensors through HBM once: dense convs,
+// their data gradients and weight gradients on the fp32 matrix cores, everything else as 16-byte-per-lane
+// streaming kernels; reductions are two-stage with a fixed summation order (per-thread fp32 over a bounded
+// run, then double): bit-reproducible gradients, no atomics.
 // Reference semantics are cited per kernel (paths relative to the reference repo).
 #include <hip/hip_runtime.h>
 
@@ -88,78 +90,6 @@ __global__ __launch_bounds__(NT) void k_conv(ConvGeom g, const float* __restrict
         float* o = out + p * g.CoutT + g.cout_off;
 #pragma unroll
         for (int co = 0; co < COUT; ++co) o[co] = g.accumulate ? o[co] + acc[co] : acc[co];
-    }
-}
-
-// weight / bias gradient: dW[co,ci,kt,kf] = sum_pos dout[pos,co] * in[tap(pos),ci]; one (ci,co) pair per
-// thread, rows (b,t) staged in LDS, per-workgroup partial sums, summed in a fixed order by k_wgrad_finish.
-template <int CIN, int COUT>
-__global__ __launch_bounds__(NT) void k_conv_wgrad(ConvGeom g, const float* __restrict__ in,
-                                                  const float* __restrict__ dout, float* __restrict__ partial) {
-    __shared__ float sD[1040];
-    __shared__ float sX[3][1040];
-    const int tid = threadIdx.x, ntap = g.nkt * g.nkf;
-    const bool active = tid < CIN * COUT;
-    const int ci = tid / COUT, co = tid - ci * COUT;
-    float acc[9], accb = 0.f;
-#pragma unroll
-    for (int k = 0; k < 9; ++k) acc[k] = 0.f;
-    const long rows = (long)g.B * g.Tout;
-    for (long row = blockIdx.x; row < rows; row += gridDim.x) {
-        const int b = (int)(row / g.Tout), to = (int)(row - (long)b * g.Tout);
-        __syncthreads();
-        for (int i = tid; i < g.Fout * COUT; i += NT)
-            sD[i] = dout[(row * g.Fout + i / COUT) * g.CoutT + g.cout_off + i % COUT];
-        for (int kt = 0; kt < g.nkt; ++kt) {
-            const int ti = to + g.t_off[kt];
-            const bool ok = ti >= 0 && ti < g.Tin;
-            for (int i = tid; i < g.Fin * CIN; i += NT)
-                sX[kt][i] = ok ? in[(((long)b * g.Tin + ti) * g.Fin + i / CIN) * g.CinT + g.cin_off + i % CIN] : 0.f;
-        }
-        __syncthreads();
-        if (active) {
-#pragma unroll
-            for (int tap = 0; tap < 9; ++tap) {
-                if (tap < ntap) {
-                    const int kt = tap / g.nkf, kf = tap - kt * g.nkf;
-                    float a = 0.f;
-                    for (int fo = 0; fo < g.Fout; ++fo) {
-                        int fi;
-                        if (tap_fi(g, fo, kf, fi)) a = fmaf(sD[fo * COUT + co], sX[kt][fi * CIN + ci], a);
-                    }
-                    acc[tap] += a;
-                }
-            }
-            if (ci == 0) {
-                float a = 0.f;
-                for (int fo = 0; fo < g.Fout; ++fo) a += sD[fo * COUT + co];
-                accb += a;
-            }
-        }
-    }
-    float* pp = partial + (long)blockIdx.x * (9 * CIN * COUT + COUT);
-    if (active) {
-#pragma unroll
-        for (int tap = 0; tap < 9; ++tap) pp[tap * CIN * COUT + tid] = acc[tap];
-        if (ci == 0) pp[9 * CIN * COUT + co] = accb;
-    }
-}
-
-__global__ void k_conv_wgrad_finish(ConvGeom g, int CIN, int COUT, const float* __restrict__ partial, int nparts,
-                                    float* __restrict__ dw, float* __restrict__ dbias) {
-    const int K = 9 * CIN * COUT + COUT, ntap = g.nkt * g.nkf;
-    for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < K; k += gridDim.x * blockDim.x) {
-        double s = 0.0;
-        for (int w = 0; w < nparts; ++w) s += partial[(long)w * K + k];
-        if (k >= 9 * CIN * COUT) {
-            if (dbias) dbias[k - 9 * CIN * COUT] = (float)s;
-        } else {
-            const int tap = k / (CIN * COUT), r = k - tap * (CIN * COUT), ci = r / COUT, co = r - ci * COUT;
-            if (tap < ntap) {
-                const int kt = tap / g.nkf, kf = tap - kt * g.nkf;
-                dw[co * g.w_co + ci * g.w_ci + kt * g.w_kt + kf * g.w_kf] = (float)s;
-            }
-        }
     }
 }
 
@@ -448,59 +378,6 @@ __global__ __launch_bounds__(NT) void k_dw16(DwGeom g, const float* __restrict__
             double t = 0.0;
             for (int l = qq; l < NT; l += 4) t += (double)sStat[l][which * 4 + e];
             stat_partial[(long)blockIdx.x * 32 + tid] = t;
-        }
-    }
-}
-
-template <int C>
-__global__ __launch_bounds__(NT) void k_dw_wgrad(DwGeom g, const float* __restrict__ in,
-                                                const float* __restrict__ dout, float* __restrict__ partial) {
-    __shared__ float sD[129 * C];
-    __shared__ float sX[3][129 * C];
-    const int tid = threadIdx.x, ntap = g.nkt * g.nkf;
-    const int tap = tid / C, c = tid - tap * C;
-    const bool active = tap < ntap, bias_thread = tid >= 9 * C && tid < 10 * C;
-    float acc = 0.f;
-    const long rows = (long)g.B * g.Tout;
-    for (long row = blockIdx.x; row < rows; row += gridDim.x) {
-        const int b = (int)(row / g.Tout), to = (int)(row - (long)b * g.Tout);
-        __syncthreads();
-        for (int i = tid; i < g.F * C; i += NT) sD[i] = dout[row * g.F * C + i];
-        for (int kt = 0; kt < g.nkt; ++kt) {
-            const int ti = to + g.t_off[kt];
-            const bool ok = ti >= 0 && ti < g.Tin;
-            for (int i = tid; i < g.F * C; i += NT) sX[kt][i] = ok ? in[((long)b * g.Tin + ti) * g.F * C + i] : 0.f;
-        }
-        __syncthreads();
-        if (active) {
-            const int kt = tap / g.nkf, kf = tap - kt * g.nkf;
-            float a = 0.f;
-            for (int fo = 0; fo < g.F; ++fo) {
-                const int fi = fo + g.f_off[kf];
-                if (fi >= 0 && fi < g.F) a = fmaf(sD[fo * C + c], sX[kt][fi * C + c], a);
-            }
-            acc += a;
-        } else if (bias_thread) {
-            float a = 0.f;
-            for (int fo = 0; fo < g.F; ++fo) a += sD[fo * C + (tid - 9 * C)];
-            acc += a;
-        }
-    }
-    if (tid < 10 * C) partial[(long)blockIdx.x * (10 * C) + tid] = (active || bias_thread) ? acc : 0.f;
-}
-
-__global__ void k_dw_wgrad_finish(DwGeom g, const float* __restrict__ partial, int nparts, float* __restrict__ dw,
-                                  float* __restrict__ dbias) {
-    const int C = g.C, K = 10 * C, ntap = g.nkt * g.nkf;
-    for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < K; k += gridDim.x * blockDim.x) {
-        double s = 0.0;
-        for (int w = 0; w < nparts; ++w) s += partial[(long)w * K + k];
-        const int tap = k / C, c = k - tap * C;
-        if (tap == 9) {
-            if (dbias) dbias[c] = (float)s;
-        } else if (tap < ntap) {
-            const int kt = tap / g.nkf, kf = tap - kt * g.nkf;
-            dw[c * g.w_c + kt * g.w_kt + kf * g.w_kf] = (float)s;
         }
     }
 }
@@ -1144,18 +1021,8 @@ int conv_wgrad(const ConvGeom& g, const float* in, const float* dout, float* dw,
         hipLaunchKernelGGL(k_wgrad_mfma_finish, dim3((K + 63) / 64), dim3(1024), 0, s, g, scratch, grid, dw, dbias);
         return check();
     }
-    const long rows = (long)g.B * g.Tout;
-    const int grid = (int)(rows < MAX_PARTIALS ? rows : MAX_PARTIALS);
-    if (g.Fout * g.Cout > 1040 || g.Fin * g.Cin > 1040) return (int)hipErrorInvalidValue;
-#define GT_WG_CASE(CI, CO)                                                                              \
-    if (g.Cin == CI && g.Cout == CO) {                                                                  \
-        hipLaunchKernelGGL((k_conv_wgrad<CI, CO>), dim3(grid), dim3(NT), 0, s, g, in, dout, scratch);   \
-        hipLaunchKernelGGL(k_conv_wgrad_finish, dim3(10), dim3(NT), 0, s, g, CI, CO, scratch, grid, dw, dbias); \
-        return check();                                                                                 \
-    }
-    GT_WG_CASE(3, 16) GT_WG_CASE(16, 16) GT_WG_CASE(8, 16) GT_WG_CASE(16, 8) GT_WG_CASE(16, 2)
-#undef GT_WG_CASE
-    return (int)hipErrorInvalidValue;
+    (void)in; (void)dout; (void)dw; (void)dbias; (void)scratch;
+    return (int)hipErrorInvalidValue;     // no such convolution in this model
 }
 
 int dw_fwd(const DwGeom& g, const float* in, const float* w, const float* bias, float* out, hipStream_t s,
@@ -1193,14 +1060,7 @@ int dw_wgrad(const DwGeom& g, const float* in, const float* dout, float* dw, flo
         hipLaunchKernelGGL(k_sfe_wgrad_finish, dim3(1), dim3(1024), 0, s, part, grid, dw);
         return check();
     }
-    const long rows = (long)g.B * g.Tout;
-    const int grid = (int)(rows < 256 ? rows : 256);
-    if (g.F > 129) return (int)hipErrorInvalidValue;
-    if (g.C == 16 && g.F <= 33) hipLaunchKernelGGL((k_dw_wgrad<16>), dim3(grid), dim3(NT), 0, s, g, in, dout, scratch);
-    else if (g.C == 3) hipLaunchKernelGGL((k_dw_wgrad<3>), dim3(grid), dim3(NT), 0, s, g, in, dout, scratch);
-    else return (int)hipErrorInvalidValue;
-    hipLaunchKernelGGL(k_dw_wgrad_finish, dim3(1), dim3(NT), 0, s, g, scratch, grid, dw, dbias);
-    return check();
+    return (int)hipErrorInvalidValue;     // no such depthwise convolution in this model
 }
 
 int bn_stats(const float* y, long n, int C, float* stats, float* running_mean, float* running_var, double* scratch,
