@@ -309,6 +309,14 @@ int unit_bwd(gtcrn_trainer* t, Unit& u, const float* prm, float* grads, const fl
              float* dres, int dres_acc, hipStream_t s) {
     const float* bn = prm + u.o_bn;
     float* gbn = grads + u.o_bn;
+    if (!u.dw && u.cg.nkt == 1 && u.cg.nkf == 1 && u.cg.sf == 1 && (u.cg.Cin % 4) == 0 && (u.cg.Cout % 4) == 0) {
+        // pointwise unit: BatchNorm backward, data gradient and weight gradient in one pass (after the reduction)
+        T_RUN(gtt::unit1x1_bwd(u.cg, u.x, u.y, da, u.res, u.stats, bn, bn + u.C, u.act,
+                               u.o_slope >= 0 ? prm + u.o_slope : nullptr, prm + u.o_w, dx, dx_acc, dres, dres_acc,
+                               grads + u.o_w, u.o_b >= 0 ? grads + u.o_b : nullptr, gbn, gbn + u.C,
+                               u.o_slope >= 0 ? grads + u.o_slope : nullptr, t->dscratch, t->fscratch, s));
+        return 0;
+    }
     T_RUN(gtt::bn_act_bwd(da, u.y, u.n, u.C, u.stats, bn, bn + u.C, u.res, u.act,
                           u.o_slope >= 0 ? prm + u.o_slope : nullptr, t->dy, dres, dres_acc, gbn, gbn + u.C,
                           u.o_slope >= 0 ? grads + u.o_slope : nullptr, t->dscratch, s));

@@ -69,6 +69,15 @@ int bn_act_bwd(const float* da, const float* y, long n, int C, const float* stat
                const float* beta, const float* res, int act, const float* slope, float* dy, float* dres,
                int dres_acc, float* dgamma, float* dbeta, float* dslope, double* scratch, hipStream_t s);
 
+// The whole backward of a pointwise (1x1) conv + BatchNorm + activation unit in two passes: the BatchNorm
+// reduction, then ONE kernel that forms dy, the data gradient dx (nullptr: not needed; dx_acc: add) and the
+// weight/bias gradients; dres (optional) receives dz for the residual branch.  Gradients of gamma, beta, the
+// PReLU slope, the conv weight and bias are WRITTEN.
+int unit1x1_bwd(const ConvGeom& g, const float* x, const float* y, const float* da, const float* res,
+                const float* stats, const float* gamma, const float* beta, int act, const float* slope,
+                const float* w, float* dx, int dx_acc, float* dres, int dres_acc, float* dw, float* dbias,
+                float* dgamma, float* dbeta, float* dslope, double* dscratch, float* fscratch, hipStream_t s);
+
 // features: spec (strided (b,f,t) + re/im) -> EB [B][T][129][3] = ERB.bm([mag,re,im]) (models/gtcrn_micro.py:510-516)
 int feat_fwd(const float* spec, long sb, long sf, long st, int B, int T, const float* erb_w, float* eb,
              hipStream_t s);

@@ -706,6 +706,131 @@ __global__ __launch_bounds__(1024) void k_reduce_partials_f(const float* __restr
     out[k] = (float)s;
 }
 
+// ------------------------------------------------------ fused backward of a 1x1 conv + BatchNorm + activation
+// For the 28 pointwise units (point_conv1/2 of the GTConv blocks, conv1/conv3 of the TCN blocks) the three
+// backward passes after the reduction -- BatchNorm/activation backward (dy), data gradient (dx = W^T dy) and
+// weight gradient (dW = sum_pos dy x^T) -- run in ONE pass over a tile of 16 positions:
+//   lane (n, q) loads da and y of position n, channels 4q..4q+3, forms dz and dy in registers (dres = dz is
+//   stored for the residual of a TCN block), feeds dy straight into the data-gradient MFMAs as the B operand,
+//   and parks the dy tile in a wave-private LDS tile from which the weight-gradient MFMAs read it back with
+//   positions as the K index (lane (c, k) = channel c of position 4u + k), next to x loaded in that layout.
+// Replaces k_bn_bwd_apply + k_conv_wgrad_mfma<1,1> + k_conv_mfma<1,1>: 4 tensor passes instead of 7.
+struct BnBwdArgs {
+    const float *stats, *gamma, *beta, *slope, *red;
+    int act;
+};
+__global__ __launch_bounds__(NT) void k_unit1x1_bwd(ConvGeom g, const float* __restrict__ x, const float* __restrict__ y,
+                                                   const float* __restrict__ da, const float* __restrict__ res,
+                                                   BnBwdArgs bn, const float* __restrict__ w,
+                                                   float* __restrict__ dx, int dx_acc, float* __restrict__ dres,
+                                                   int dres_acc, float* __restrict__ partial, long tiles_per_wave) {
+    __shared__ __attribute__((aligned(16))) float sWt[256];        // data-gradient A matrix [ci][co] = W[co][ci]
+    __shared__ __attribute__((aligned(16))) float sT[NT / 64][256];   // per wave: dy tile [pos][16]
+    __shared__ float sAcc[NT / 64][256 + 64];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, n = lane & 15, q = lane >> 4;
+    {
+        const int ci = tid >> 4, co = tid & 15;
+        sWt[tid] = (co < g.Cout && ci < g.Cin) ? w[co * g.w_co + ci * g.w_ci] : 0.f;
+    }
+    __syncthreads();
+    const long npos = (long)g.B * g.Tout * g.Fout, ntiles = (npos + 15) >> 4;
+    const long wave = (long)blockIdx.x * (NT / 64) + wv;
+    long tile = wave * tiles_per_wave;
+    const long tend = tile + tiles_per_wave < ntiles ? tile + tiles_per_wave : ntiles;
+    const bool co_ok4 = 4 * q < g.Cout, ci_ok4 = 4 * q < g.Cin;
+    const int c = n, k = q;                                         // (c, k) role of the lane in the weight gradient
+    const bool co_ok = c < g.Cout, ci_ok = c < g.Cin;
+    const float sl = bn.slope ? bn.slope[0] : 0.f;
+    f32x4 mean = {0, 0, 0, 0}, istd = mean, gm = mean, bt = mean, m1 = mean, m2 = mean;
+    if (co_ok4) {
+        mean = *reinterpret_cast<const f32x4*>(bn.stats + 4 * q);
+        istd = *reinterpret_cast<const f32x4*>(bn.stats + g.Cout + 4 * q);
+        gm = *reinterpret_cast<const f32x4*>(bn.gamma + 4 * q);
+        bt = *reinterpret_cast<const f32x4*>(bn.beta + 4 * q);
+        m1 = *reinterpret_cast<const f32x4*>(bn.red + 4 * q);
+        m2 = *reinterpret_cast<const f32x4*>(bn.red + g.Cout + 4 * q);
+    }
+    const f32x4 At = *reinterpret_cast<const f32x4*>(sWt + n * 16 + 4 * q);   // row ci = n of W^T
+    f32x4 accW = {0.f, 0.f, 0.f, 0.f};
+    float bsum = 0.f;
+    for (; tile < tend; ++tile) {
+        const long p = tile * 16 + n;
+        const bool pv = p < npos;
+        // weight-gradient operand x in (c, k) layout: 4 coalesced 256-byte wave loads, issued first
+        float xb[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const long pu = tile * 16 + 4 * u + k;
+            xb[u] = (pu < npos && ci_ok) ? x[pu * g.CinT + g.cin_off + c] : 0.f;
+        }
+        f32x4 dy = {0.f, 0.f, 0.f, 0.f};
+        if (pv && co_ok4) {
+            const f32x4 yv = *reinterpret_cast<const f32x4*>(y + p * g.Cout + 4 * q);
+            const f32x4 gv = *reinterpret_cast<const f32x4*>(da + p * g.Cout + 4 * q);
+            f32x4 rv = {0.f, 0.f, 0.f, 0.f};
+            if (res) rv = *reinterpret_cast<const f32x4*>(res + p * g.Cout + 4 * q);
+            f32x4 dzv;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float xh = (yv[e] - mean[e]) * istd[e];
+                float z = gm[e] * xh + bt[e];
+                if (res) z += rv[e];
+                float dsl;
+                const float dz = act_bwd(z, gv[e], bn.act, sl, dsl);
+                dzv[e] = dz;
+                dy[e] = gm[e] * istd[e] * (dz - m1[e] - xh * m2[e]);
+            }
+            if (dres) {
+                f32x4* dr = reinterpret_cast<f32x4*>(dres + p * g.Cout + 4 * q);
+                *dr = dres_acc ? *dr + dzv : dzv;
+            }
+        }
+        // data gradient: dx[pos][ci] = sum_co W[co][ci] dy[pos][co]
+        if (dx) {
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc = mfma4(At[e], dy[e], acc);
+            if (pv && ci_ok4) {
+                f32x4* o = reinterpret_cast<f32x4*>(dx + p * g.CinT + g.cin_off + 4 * q);
+                *o = dx_acc ? *o + acc : acc;
+            }
+        }
+        // weight gradient: dy tile through wave-private LDS into the (c, k) layout
+        *reinterpret_cast<f32x4*>(&sT[wv][n * 16 + 4 * q]) = dy;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const float a = sT[wv][(4 * u + k) * 16 + c];
+            bsum += a;
+            accW = mfma4(a, xb[u], accW);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+    (void)co_ok;
+    // per-workgroup partial dW / db, same layout as k_conv_wgrad_mfma<1,1>: [co*16 + ci] then 16 bias sums
+#pragma unroll
+    for (int r = 0; r < 4; ++r) sAcc[wv][(4 * k + r) * 16 + c] = accW[r];
+    sAcc[wv][256 + lane] = bsum;
+    __syncthreads();
+    float* pp = partial + (long)blockIdx.x * (256 + 16);
+    {
+        float t = 0.f;
+#pragma unroll
+        for (int w2 = 0; w2 < NT / 64; ++w2) t += sAcc[w2][tid];
+        pp[tid] = t;
+    }
+    if (tid < 16) {
+        float t = 0.f;
+        for (int w2 = 0; w2 < NT / 64; ++w2)
+            for (int kk = 0; kk < 4; ++kk) t += sAcc[w2][256 + kk * 16 + tid];
+        pp[256 + tid] = t;
+    }
+}
+
 // --------------------------------------------------------------------------- features, mask
 // GTCRNMicro.forward prologue + ERB.bm (models/gtcrn_micro.py:510-516, :63-67): one thread per (b,t,j)
 // first / one-past-last non-zero entry of each of the `rows` rows (stride rs, element stride es) of a filterbank
@@ -1116,6 +1241,31 @@ int bn_act_bwd(const float* da, const float* y, long n, int C, const float* stat
         hipLaunchKernelGGL((k_bn_bwd_apply<1>), dim3(grid_for(total, 8192)), dim3(NT), 0, s, da, y, total, C, stats,
                            gamma, beta, res, act, slope, red, dy, dres, dres_acc);
     }
+    return check();
+}
+
+int unit1x1_bwd(const ConvGeom& g, const float* x, const float* y, const float* da, const float* res,
+                const float* stats, const float* gamma, const float* beta, int act, const float* slope,
+                const float* w, float* dx, int dx_acc, float* dres, int dres_acc, float* dw, float* dbias,
+                float* dgamma, float* dbeta, float* dslope, double* dscratch, float* fscratch, hipStream_t s) {
+    const long n = (long)g.B * g.Tout * g.Fout, total = n * g.Cout;
+    if (g.nkt != 1 || g.nkf != 1 || g.sf != 1 || g.pf != 0 || g.Cout != g.CoutT || g.cout_off != 0 || (g.Cout % 4) ||
+        (g.Cin % 4) || (g.CinT % 4) || (g.cin_off % 4))
+        return (int)hipErrorInvalidValue;
+    float* red = reinterpret_cast<float*>(dscratch + (long)MAX_PARTIALS * 3 * 16);
+    const int rgrid = red_grid(total / 4);
+    hipLaunchKernelGGL((k_bn_bwd_reduce<4>), dim3(rgrid), dim3(NT), 0, s, da, y, total, g.Cout, stats, gamma, beta, res,
+                       act, slope, dscratch);
+    hipLaunchKernelGGL(k_bn_bwd_finish, dim3(1), dim3(1024), 0, s, dscratch, rgrid, n, g.Cout, red, dgamma, dbeta, dslope);
+    const long ntiles = (n + 15) / 16;
+    long waves = (long)MAX_PARTIALS * (NT / 64);
+    if (waves > ntiles) waves = ntiles;
+    const long tpw = (ntiles + waves - 1) / waves;
+    const int grid = (int)((ntiles + tpw * (NT / 64) - 1) / (tpw * (NT / 64)));
+    BnBwdArgs bn{stats, gamma, beta, slope, red, act};
+    hipLaunchKernelGGL(k_unit1x1_bwd, dim3(grid), dim3(NT), 0, s, g, x, y, da, res, bn, w, dx, dx_acc, dres, dres_acc,
+                       fscratch, tpw);
+    hipLaunchKernelGGL(k_wgrad_mfma_finish, dim3((256 + 16 + 63) / 64), dim3(1024), 0, s, g, fscratch, grid, dw, dbias);
     return check();
 }
 

@@ -33,10 +33,12 @@ def is_trainable(name):
 
 
 class TorchPort:
-    def __init__(self, blob, train=False):
+    def __init__(self, blob, train=False, dtype=torch.float32):
         """train=True: BatchNorm uses batch statistics and updates the running ones in place
-        (nn.BatchNorm2d in .train() mode, momentum 0.1), and trainable tensors require grad."""
-        self.p = blob_to_dict(blob)
+        (nn.BatchNorm2d in .train() mode, momentum 0.1), and trainable tensors require grad.
+        dtype=torch.float64 runs the same graph in double: the "truth" that fp32 results scatter around."""
+        self.p = {k: v.to(dtype) for k, v in blob_to_dict(blob).items()}
+        self.dtype = dtype
         self.train = bool(train)
         if self.train:
             for k, v in self.p.items():
@@ -98,7 +100,7 @@ class TorchPort:
         def tap(name, v):
             if taps is not None:
                 taps[name] = v.detach().clone()
-        spec = torch.as_tensor(spec, dtype=torch.float32)
+        spec = torch.as_tensor(spec).to(self.dtype)
         re, im = spec[..., 0].permute(0, 2, 1), spec[..., 1].permute(0, 2, 1)
         feat = torch.stack([torch.sqrt(re * re + im * im + 1e-12), re, im], dim=1)
         feat = torch.cat([feat[..., :65], F.linear(feat[..., 65:], p["erb.erb_fc.weight"])], dim=-1)
@@ -180,8 +182,8 @@ class TorchPort:
         assert self.train
         for v in self.p.values():
             v.grad = None
-        enh = self.forward(torch.as_tensor(spec, dtype=torch.float32))
-        enh.backward(torch.as_tensor(grad_enh, dtype=torch.float32))
+        enh = self.forward(torch.as_tensor(spec).to(self.dtype))
+        enh.backward(torch.as_tensor(grad_enh).to(self.dtype))
         return enh.detach().numpy(), self.grads_blob()
 
     @torch.inference_mode()

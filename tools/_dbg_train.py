@@ -27,3 +27,26 @@ for tag in ("rand", "dns3"):
     for r in rows[:25]:
         print("  %.3e %-50s ref %.3e got %.3e" % r)
     print(tag, "grad norm", np.sqrt((grads.astype(np.float64) ** 2).sum()), np.sqrt((ref.astype(np.float64) ** 2).sum()))
+# accuracy against the fp64 truth (same graph in double on the CPU)
+from oracle.torch_port import TorchPort
+torch.set_num_threads(8)
+for tag in ("rand", "dns3"):
+    g = np.load(f"{GOLD}/trainstep_{tag}_B3_T12.npz")
+    blob_np = np.fromfile(f"{GOLD}/params_{tag}.f32", np.float32)
+    _, t64 = TorchPort(blob_np, train=True, dtype=torch.float64).backward_from(g["noisy_spec"], g["grad_enh"])
+    blob = torch.from_numpy(blob_np.copy()).cuda()
+    spec = torch.from_numpy(g["noisy_spec"]).cuda()
+    tr.forward(blob, spec)
+    grads = tr.backward(blob, spec, torch.from_numpy(g["grad_enh"]).cuda()).cpu().numpy()
+    def worst(a):
+        rows = []
+        for name, numel, off in L.param_table():
+            t = t64[off:off + numel]
+            if not t.any():
+                continue
+            sc = max(np.abs(t).max(), 1e-3 * np.abs(t64).max())
+            rows.append((float(np.abs(a[off:off + numel] - t).max() / sc), name))
+        rows.sort(reverse=True)
+        return rows[:3]
+    print(tag, "HIP vs fp64:", worst(grads))
+    print(tag, "reference golden vs fp64:", worst(g["grads"]))
