@@ -324,14 +324,18 @@ __global__ __launch_bounds__(FFT_WAVES * 64) void k_istft(const float* __restric
 
 // per-lane geometry of the wave's TPW tiles; constant for the whole kernel (chunks start at multiples
 // of 16 frames, so ring rows -- frame mod 2 / mod 2d -- do not depend on the chunk either)
+// (TPW is a template parameter of the model kernels: 3 tiles per wave for full 16-frame chunks, 1 for calls of
+// at most SHORT_T frames -- streaming steps -- where the 11 first tiles already cover every valid position)
+template <int TPW>
 struct Tiles {
     int tl[TPW];    // frame inside the chunk
     int ff[TPW];    // frequency bin
     // position inside the chunk (= tile * 16 + n); one mad, cheaper than a third live register per tile
     __device__ __forceinline__ int pp(int i) const { return tl[i] * 33 + ff[i]; }
 };
-__device__ __forceinline__ Tiles make_tiles(const Lane& L) {
-    Tiles t;
+template <int TPW>
+__device__ __forceinline__ Tiles<TPW> make_tiles(const Lane& L) {
+    Tiles<TPW> t;
 #pragma unroll
     for (int i = 0; i < TPW; ++i) {
         const int p = (L.wave + i * NW) * 16 + L.n;
@@ -341,9 +345,11 @@ __device__ __forceinline__ Tiles make_tiles(const Lane& L) {
     return t;
 }
 // float offset of the lane's record in a 35-column row image (zero pad columns 0 and 34)
-__device__ __forceinline__ int o35(const Tiles& t, int i, int g) { return (t.tl[i] * 35 + 1 + t.ff[i]) * 16 + 4 * g; }
+template <int TPW>
+__device__ __forceinline__ int o35(const Tiles<TPW>& t, int i, int g) { return (t.tl[i] * 35 + 1 + t.ff[i]) * 16 + 4 * g; }
 // float offset inside a 2-row ring (row = frame & 1) of (frame tl - back, bin ff), back = 1 or 2
-__device__ __forceinline__ int ring35(const Tiles& t, int i, int g, int tbase, int back) {
+template <int TPW>
+__device__ __forceinline__ int ring35(const Tiles<TPW>& t, int i, int g, int tbase, int back) {
     return (((tbase + t.tl[i] + back) & 1) * 35 + 1 + t.ff[i]) * 16 + 4 * g;
 }
 
@@ -381,8 +387,8 @@ struct BlockCtx {
 
 // `hook` runs right after the depth-conv phase (register pressure is past its peak there, and two
 // barrier intervals of work follow): the decoder uses it to request inputs of later phases early.
-template <bool DENSE, class Hook>
-__device__ __forceinline__ void gtconv_block(f32x4 (&x)[TPW], const Tiles& tt, const BlockCtx& c,
+template <bool DENSE, int TPW, class Hook>
+__device__ __forceinline__ void gtconv_block(f32x4 (&x)[TPW], const Tiles<TPW>& tt, const BlockCtx& c,
                                              const Lane& L, Hook&& hook STAMP_PARAM) {
     const int n = L.n, g = L.g;
     const float a1 = c.pb[GB_SLOPE] - 1.0f, a2 = c.pb[GB_SLOPE + 1] - 1.0f;
@@ -574,6 +580,7 @@ static_assert(ENC_LDS_FLOATS * 4 <= 160 * 1024, "encoder LDS budget");
 static_assert(TC * 35 * 16 + TC * 33 * 16 <= TC * ENC_E0_ROW * 16, "W + S must fit in the E0 region");
 static_assert(ENC_LDS_I % 4 == 0 && ENC_LDS_H % 4 == 0 && ENC_LDS_G % 4 == 0 && ENC_LDS_A % 4 == 0, "16B carve");
 
+template <int TPW>
 __global__ __launch_bounds__(NTHR) void k_encoder(const float* __restrict__ spec, long sb, long sf, long st, int T,
                                                  const float* __restrict__ PF, const int* __restrict__ PI,
                                                  float* __restrict__ en0, float* __restrict__ en1,
@@ -603,7 +610,7 @@ __global__ __launch_bounds__(NTHR) void k_encoder(const float* __restrict__ spec
     float* stb = state ? state + (long)b * ST_FLOATS : nullptr;
     const int tbase = stb ? reinterpret_cast<const int*>(stb)[0] : 0;
     rings_load(sH, sEH, stb ? stb + ST_ENC_H : nullptr, stb ? stb + ST_ENC_E : nullptr, tid);
-    const Tiles tt = make_tiles(L);
+    const Tiles<TPW> tt = make_tiles<TPW>(L);
     wg_barrier();
 
     spec += (long)b * sb;
@@ -738,7 +745,8 @@ __global__ __launch_bounds__(NTHR) void k_encoder(const float* __restrict__ spec
             }
             constexpr int NT0 = TC * F1 / 16;  // 65 tiles
             static_assert(TC * F1 % 16 == 0, "en0 tiling");
-            for (int tile = L.wave; tile < NT0; tile += NW) {
+            const int nt0 = (nfr * F1 + 15) >> 4;              // tiles that hold a valid frame
+            for (int tile = L.wave; tile < nt0; tile += NW) {
                 const int q = tile * 16 + n, tl = q / F1, fo = q - tl * F1;
                 f32x4 bv;
 #pragma unroll
@@ -834,7 +842,7 @@ static_assert(GT_LDS_FLOATS * 4 <= 160 * 1024, "GTCN LDS budget");
 // barrier (they do not depend on this block's y1, and their latency hides behind conv1); the ring is
 // rewritten after the barrier, when every wave is past its ring reads; the chunk image alternates
 // between two buffers so that the next block's y1 never overwrites taps a slower wave still reads.
-template <int D>
+template <int D, int TPW>
 __device__ __forceinline__ void tcn_block(f32x4 (&x)[TPW], const float* pk, float* sWb, float* sHk,
                                           const int (&own)[TPW], const int (&tl)[TPW], const int (&ff)[TPW],
                                           int tb16, int nfr, int npos, const int (&pp)[TPW], const Lane& L STAMP_PARAM) {
@@ -890,6 +898,7 @@ __device__ __forceinline__ void tcn_block(f32x4 (&x)[TPW], const float* pk, floa
     STAMP(SS, 4)
 }
 
+template <int TPW>
 __global__ __launch_bounds__(NTHR) void k_gtcn(const float* __restrict__ xin, float* __restrict__ xout,
                                               const float* __restrict__ P, int T, float* __restrict__ state,
                                               int st_off, const float* __restrict__ addend,
@@ -1099,7 +1108,7 @@ static_assert(DEC_LDS_FLOATS * 4 <= 160 * 1024, "decoder LDS budget");
 static_assert(DEC_SIZE % 4 == 0 && DEC_LDS_I % 4 == 0 && DEC_LDS_H % 4 == 0 && DEC_LDS_A % 4 == 0, "16B carve");
 
 // DBG = true only for the stage-tap variant used by the parity tests (writes de0..de4 to `dbg`).
-template <bool DBG>
+template <bool DBG, int TPW>
 __global__ __launch_bounds__(NTHR) void k_decoder(const float* __restrict__ xg, const float* __restrict__ en0,
                                                  const float* __restrict__ en1, const float* __restrict__ en2,
                                                  const float* __restrict__ en3, const float* __restrict__ en4,
@@ -1143,7 +1152,7 @@ __global__ __launch_bounds__(NTHR) void k_decoder(const float* __restrict__ xg, 
     float* stb = state ? state + (long)b * ST_FLOATS : nullptr;
     const int tbase = stb ? reinterpret_cast<const int*>(stb)[0] : 0;
     rings_load(sH, sEH, stb ? stb + ST_DEC_H : nullptr, stb ? stb + ST_DEC_E : nullptr, tid);
-    const Tiles tt = make_tiles(L);
+    const Tiles<TPW> tt = make_tiles<TPW>(L);
     wg_barrier();
 
     const long ob = (long)b * T;
@@ -1527,37 +1536,53 @@ int launch_istft(const float* spec, long sb, long sf, long st, int B, int T, con
 
 int configure_kernels() {
     hipError_t e;
-    e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_encoder), hipFuncAttributeMaxDynamicSharedMemorySize,
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_encoder<TPW>), hipFuncAttributeMaxDynamicSharedMemorySize,
                             ENC_LDS_FLOATS * 4);
     if (e != hipSuccess) return (int)e;
-    e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_gtcn), hipFuncAttributeMaxDynamicSharedMemorySize,
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_encoder<1>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            ENC_LDS_FLOATS * 4);
+    if (e != hipSuccess) return (int)e;
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_gtcn<TPW>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            GT_LDS_FLOATS * 4);
+    if (e != hipSuccess) return (int)e;
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_gtcn<1>), hipFuncAttributeMaxDynamicSharedMemorySize,
                             GT_LDS_FLOATS * 4);
     if (e != hipSuccess) return (int)e;
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_gtcn_band), hipFuncAttributeMaxDynamicSharedMemorySize,
                             GB_LDS_FLOATS * 4);
     if (e != hipSuccess) return (int)e;
-    e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_decoder<false>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, DEC_LDS_FLOATS * 4);
-    if (e != hipSuccess) return (int)e;
-    e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_decoder<true>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, DEC_LDS_FLOATS * 4);
-    if (e != hipSuccess) return (int)e;
+    const void* dec[] = {reinterpret_cast<const void*>(k_decoder<false, TPW>),
+                         reinterpret_cast<const void*>(k_decoder<true, TPW>),
+                         reinterpret_cast<const void*>(k_decoder<false, 1>),
+                         reinterpret_cast<const void*>(k_decoder<true, 1>)};
+    for (const void* f : dec) {
+        e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, DEC_LDS_FLOATS * 4);
+        if (e != hipSuccess) return (int)e;
+    }
     return 0;
 }
 
 int launch_encoder(const float* spec, long sb, long sf, long st, int B, int T, const float* PF, const int* PI,
                    float* en0, float* en1, float* en2, float* en3, float* en4, float* state,
                    unsigned long long* stamps, hipStream_t s) {
-    hipLaunchKernelGGL(k_encoder, dim3(B), dim3(NTHR), ENC_LDS_FLOATS * 4, s, spec, sb, sf, st, T, PF, PI, en0, en1,
-                       en2, en3, en4, state, stamps);
+    if (T <= SHORT_T)
+        hipLaunchKernelGGL(k_encoder<1>, dim3(B), dim3(NTHR), ENC_LDS_FLOATS * 4, s, spec, sb, sf, st, T, PF, PI, en0,
+                           en1, en2, en3, en4, state, stamps);
+    else
+        hipLaunchKernelGGL(k_encoder<TPW>, dim3(B), dim3(NTHR), ENC_LDS_FLOATS * 4, s, spec, sb, sf, st, T, PF, PI,
+                           en0, en1, en2, en3, en4, state, stamps);
     GT_LAUNCH_CHECK();
     return 0;
 }
 
 int launch_gtcn(const float* xin, float* xout, const float* P, int B, int T, float* state, int st_off,
                 const float* addend, unsigned long long* stamps, hipStream_t s) {
-    hipLaunchKernelGGL(k_gtcn, dim3(B), dim3(NTHR), GT_LDS_FLOATS * 4, s, xin, xout, P, T, state, st_off, addend,
-                       stamps);
+    if (T <= SHORT_T)
+        hipLaunchKernelGGL(k_gtcn<1>, dim3(B), dim3(NTHR), GT_LDS_FLOATS * 4, s, xin, xout, P, T, state, st_off,
+                           addend, stamps);
+    else
+        hipLaunchKernelGGL(k_gtcn<TPW>, dim3(B), dim3(NTHR), GT_LDS_FLOATS * 4, s, xin, xout, P, T, state, st_off,
+                           addend, stamps);
     GT_LAUNCH_CHECK();
     return 0;
 }
@@ -1572,12 +1597,15 @@ int launch_decoder(const float* xg, const float* en0, const float* en1, const fl
                    const float* en4, const float* spec, long sb, long sf, long st, float* out, long osb, long osf,
                    long ost, int B, int T, const float* PF, const int* PI, float* state, float* dbg,
                    unsigned long long* stamps, hipStream_t s) {
-    if (dbg)
-        hipLaunchKernelGGL(k_decoder<true>, dim3(B), dim3(NTHR), DEC_LDS_FLOATS * 4, s, xg, en0, en1, en2, en3, en4,
-                           spec, sb, sf, st, out, osb, osf, ost, T, PF, PI, state, dbg, stamps);
-    else
-        hipLaunchKernelGGL(k_decoder<false>, dim3(B), dim3(NTHR), DEC_LDS_FLOATS * 4, s, xg, en0, en1, en2, en3, en4,
-                           spec, sb, sf, st, out, osb, osf, ost, T, PF, PI, state, dbg, stamps);
+#define GT_DEC(DBGV, TPWV)                                                                                         \
+    hipLaunchKernelGGL((k_decoder<DBGV, TPWV>), dim3(B), dim3(NTHR), DEC_LDS_FLOATS * 4, s, xg, en0, en1, en2, en3, \
+                       en4, spec, sb, sf, st, out, osb, osf, ost, T, PF, PI, state, dbg, stamps)
+    if (T <= SHORT_T) {
+        if (dbg) GT_DEC(true, 1); else GT_DEC(false, 1);
+    } else {
+        if (dbg) GT_DEC(true, TPW); else GT_DEC(false, TPW);
+    }
+#undef GT_DEC
     GT_LAUNCH_CHECK();
     return 0;
 }
