@@ -606,7 +606,7 @@ __global__ __launch_bounds__(NTHR) void k_encoder(const float* __restrict__ spec
 
     for (int i = tid; i < ENC_SIZE; i += NTHR) sP[i] = PF[P_ENC + i];
     for (int i = tid; i < P_INTS; i += NTHR) sI[i] = PI[i];
-    for (int i = tid; i < 3 * TC * EB_ROW + 3 * TC * F0_ROW; i += NTHR) sEB[i] = 0.f;  // zero pads once
+    // (the pad entries of EB / F0 are zeroed at the top of every chunk; nothing else of that region is read unwritten)
     float* stb = state ? state + (long)b * ST_FLOATS : nullptr;
     const int tbase = stb ? reinterpret_cast<const int*>(stb)[0] : 0;
     rings_load(sH, sEH, stb ? stb + ST_ENC_H : nullptr, stb ? stb + ST_ENC_E : nullptr, tid);
@@ -842,7 +842,10 @@ static_assert(GT_LDS_FLOATS * 4 <= 160 * 1024, "GTCN LDS budget");
 // barrier (they do not depend on this block's y1, and their latency hides behind conv1); the ring is
 // rewritten after the barrier, when every wave is past its ring reads; the chunk image alternates
 // between two buffers so that the next block's y1 never overwrites taps a slower wave still reads.
-template <int D, int TPW>
+// GRING: sHk points at the stream's ring in GLOBAL memory (short streaming calls: no LDS copy of the 63 KB of
+// rings).  The ring rows written after the barrier were read by other waves before it, so those loads must have
+// returned (vmcnt) before any wave passes the barrier.
+template <int D, bool GRING, int TPW>
 __device__ __forceinline__ void tcn_block(f32x4 (&x)[TPW], const float* pk, float* sWb, float* sHk,
                                           const int (&own)[TPW], const int (&tl)[TPW], const int (&ff)[TPW],
                                           int tb16, int nfr, int npos, const int (&pp)[TPW], const Lane& L STAMP_PARAM) {
@@ -870,7 +873,8 @@ __device__ __forceinline__ void tcn_block(f32x4 (&x)[TPW], const float* pk, floa
             st4(sWb + own[i], y1[i]);
         }
     }
-    wg_barrier();
+    if (GRING) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    else wg_barrier();
     STAMP(SS, 2)
     {
         const f32x4 w0 = ld4(pk + TCN_DW + 4 * g), w1 = ld4(pk + TCN_DW + 16 + 4 * g),
@@ -898,7 +902,7 @@ __device__ __forceinline__ void tcn_block(f32x4 (&x)[TPW], const float* pk, floa
     STAMP(SS, 4)
 }
 
-template <int TPW>
+template <int TPW, bool GRING>
 __global__ __launch_bounds__(NTHR) void k_gtcn(const float* __restrict__ xin, float* __restrict__ xout,
                                               const float* __restrict__ P, int T, float* __restrict__ state,
                                               int st_off, const float* __restrict__ addend,
@@ -907,17 +911,19 @@ __global__ __launch_bounds__(NTHR) void k_gtcn(const float* __restrict__ xin, fl
     STAMP_INIT(SS)
     float* sP = smem + GT_LDS_P;
     float* sW = smem + GT_LDS_W;
-    float* sH = smem + GT_LDS_H;
     const Lane L = lane_info();
     const int tid = L.tid, n = L.n, g = L.g;
     const int b = blockIdx.x;
     for (int i = tid; i < GTCN_SIZE; i += NTHR) sP[i] = P[i];
     float* stb = state ? state + (long)b * ST_FLOATS : nullptr;
     const int tbase = stb ? reinterpret_cast<const int*>(stb)[0] : 0;
-    for (int i = tid; i < 30 * 33 * 4; i += NTHR) {
-        const int gg = i & 3, pos = i >> 2;
-        st4(sH + pl(pos, gg), stb ? ld4(stb + st_off + pos * 16 + gg * 4) : splat(0.f));
-    }
+    // the rings [30 rows][33][16]: an LDS copy of the stream state, or (GRING) the state itself -- same layout
+    float* sH = GRING ? stb + st_off : smem + GT_LDS_H;
+    if (!GRING)
+        for (int i = tid; i < 30 * 33 * 4; i += NTHR) {
+            const int gg = i & 3, pos = i >> 2;
+            st4(sH + pl(pos, gg), stb ? ld4(stb + st_off + pos * 16 + gg * 4) : splat(0.f));
+        }
     wg_barrier();
     xin += (long)b * T * 528;
     xout += (long)b * T * 528;
@@ -946,17 +952,17 @@ __global__ __launch_bounds__(NTHR) void k_gtcn(const float* __restrict__ xin, fl
         }
         STAMP(SS, 1)
         float* sW1 = sW + TC * 33 * 16;
-        tcn_block<1>(x, sP + 0 * TCN_SIZE, sW, sH + 0 * 528, own, tl, ff, tb16, nfr, npos, pp, L STAMP_ARG);
-        tcn_block<2>(x, sP + 1 * TCN_SIZE, sW1, sH + 2 * 528, own, tl, ff, tb16, nfr, npos, pp, L STAMP_ARG);
-        tcn_block<4>(x, sP + 2 * TCN_SIZE, sW, sH + 6 * 528, own, tl, ff, tb16, nfr, npos, pp, L STAMP_ARG);
-        tcn_block<8>(x, sP + 3 * TCN_SIZE, sW1, sH + 14 * 528, own, tl, ff, tb16, nfr, npos, pp, L STAMP_ARG);
+        tcn_block<1, GRING>(x, sP + 0 * TCN_SIZE, sW, sH + 0 * 528, own, tl, ff, tb16, nfr, npos, pp, L STAMP_ARG);
+        tcn_block<2, GRING>(x, sP + 1 * TCN_SIZE, sW1, sH + 2 * 528, own, tl, ff, tb16, nfr, npos, pp, L STAMP_ARG);
+        tcn_block<4, GRING>(x, sP + 2 * TCN_SIZE, sW, sH + 6 * 528, own, tl, ff, tb16, nfr, npos, pp, L STAMP_ARG);
+        tcn_block<8, GRING>(x, sP + 3 * TCN_SIZE, sW1, sH + 14 * 528, own, tl, ff, tb16, nfr, npos, pp, L STAMP_ARG);
 #pragma unroll
         for (int i = 0; i < TPW; ++i)
             if (pp[i] < npos) st4(xout + (long)t0 * 528 + own[i], addend ? x[i] + ad[i] : x[i]);
         STAMP(SS, 5)
     }
     STAMP_OUT(SS, stamps)
-    if (stb) {
+    if (stb && !GRING) {
         wg_barrier();
         for (int i = tid; i < 30 * 33 * 4; i += NTHR) {
             const int gg = i & 3, pos = i >> 2;
@@ -1542,12 +1548,12 @@ int configure_kernels() {
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_encoder<1>), hipFuncAttributeMaxDynamicSharedMemorySize,
                             ENC_LDS_FLOATS * 4);
     if (e != hipSuccess) return (int)e;
-    e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_gtcn<TPW>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            GT_LDS_FLOATS * 4);
-    if (e != hipSuccess) return (int)e;
-    e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_gtcn<1>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            GT_LDS_FLOATS * 4);
-    if (e != hipSuccess) return (int)e;
+    const void* gt[] = {reinterpret_cast<const void*>(k_gtcn<TPW, false>), reinterpret_cast<const void*>(k_gtcn<1, false>),
+                        reinterpret_cast<const void*>(k_gtcn<1, true>)};
+    for (const void* f : gt) {
+        e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, GT_LDS_FLOATS * 4);
+        if (e != hipSuccess) return (int)e;
+    }
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_gtcn_band), hipFuncAttributeMaxDynamicSharedMemorySize,
                             GB_LDS_FLOATS * 4);
     if (e != hipSuccess) return (int)e;
@@ -1577,12 +1583,15 @@ int launch_encoder(const float* spec, long sb, long sf, long st, int B, int T, c
 
 int launch_gtcn(const float* xin, float* xout, const float* P, int B, int T, float* state, int st_off,
                 const float* addend, unsigned long long* stamps, hipStream_t s) {
-    if (T <= SHORT_T)
-        hipLaunchKernelGGL(k_gtcn<1>, dim3(B), dim3(NTHR), GT_LDS_FLOATS * 4, s, xin, xout, P, T, state, st_off,
+    if (T <= SHORT_T && state)   // streaming step: rings stay in the stream state (no LDS copy: 77 KB, 2 workgroups per CU)
+        hipLaunchKernelGGL((k_gtcn<1, true>), dim3(B), dim3(NTHR), GT_LDS_H * 4, s, xin, xout, P, T, state, st_off,
                            addend, stamps);
+    else if (T <= SHORT_T)
+        hipLaunchKernelGGL((k_gtcn<1, false>), dim3(B), dim3(NTHR), GT_LDS_FLOATS * 4, s, xin, xout, P, T, state,
+                           st_off, addend, stamps);
     else
-        hipLaunchKernelGGL(k_gtcn<TPW>, dim3(B), dim3(NTHR), GT_LDS_FLOATS * 4, s, xin, xout, P, T, state, st_off,
-                           addend, stamps);
+        hipLaunchKernelGGL((k_gtcn<TPW, false>), dim3(B), dim3(NTHR), GT_LDS_FLOATS * 4, s, xin, xout, P, T, state,
+                           st_off, addend, stamps);
     GT_LAUNCH_CHECK();
     return 0;
 }
