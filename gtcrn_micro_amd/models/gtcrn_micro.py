@@ -273,14 +273,17 @@ class GTCRNMicro(nn.Module):
             idx = torch.cuda.current_device()
         sig = self._signature()
         ent = self._engines.get(idx)
+        if ent is not None and ent[1] == sig:
+            return ent[0]
+        # after training the parameters live in one flat device blob already in the C ABI's order: one copy
+        dev = torch.device("cuda", idx)
+        blob = self._flat.cpu().numpy() if self._flat_ok(dev) else state_dict_to_blob(self.state_dict())
         if ent is None:
-            eng = _lib.Engine(state_dict_to_blob(self.state_dict()), idx)
-            self._engines[idx] = (eng, sig)
-            return eng
-        eng, old = ent
-        if old != sig:
-            eng.set_params(state_dict_to_blob(self.state_dict()))
-            self._engines[idx] = (eng, sig)
+            eng = _lib.Engine(blob, idx)
+        else:
+            eng = ent[0]
+            eng.set_params(blob)
+        self._engines[idx] = (eng, sig)
         return eng
 
     def load_state_dict(self, state_dict, strict=True, assign=False):
