@@ -1,3 +1,9 @@
+#!/usr/bin/env python3
+"""Diagnostic (GPU box): per-kernel HIP-event times of one-frame streaming steps for 1024 streams and, with
+GTCRN_LIB_VARIANT=stamps, the per-phase cycle sums of the diagnostic build.
+
+    python tools/stream_kernel_times.py
+"""
 import os, sys, numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from gtcrn_micro_amd import Engine

@@ -1,3 +1,9 @@
+#!/usr/bin/env python3
+"""Diagnostic (GPU box): per-stage forward errors and the worst per-tensor gradient errors of the HIP training
+path against the reference fixtures, and against the float64 truth (oracle/torch_port.py in double).
+
+    python tools/train_parity_report.py
+"""
 import os, sys, numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import gtcrn_micro_amd as G
