@@ -14,6 +14,8 @@
 // Reference semantics are cited per function (paths relative to the reference repo).
 #include <hip/hip_runtime.h>
 
+#include <cstdint>
+
 #include "kernels.h"
 #include "layout.h"
 
@@ -197,23 +199,42 @@ __global__ __launch_bounds__(FFT_WAVES * 64) void k_stft(const float* __restrict
     __syncthreads();
     const long nframes = (long)B * T;
     const long base = (long)blockIdx.x * (FFT_WAVES * FRAMES_PER_WAVE);
+    // samples of a frame: lane holds the pairs (2m, 2m+1), m = lane + 64 q.  Interior frames read them as one
+    // 8-byte load each; only the first and the last two frames of an utterance touch the reflected edges.
+    auto fetch = [&](long fr, float2 (&v)[4]) {
+        const bool live = fr < nframes;
+        const int b = live ? (int)(fr / T) : 0;
+        const int t = live ? (int)(fr - (long)b * T) : 0;
+        const float* x = wave + (long)b * L;
+        const long lo = 256L * t - 256;                       // first sample of the frame in the unpadded signal
+        if (lo >= 0 && lo + 512 <= L && ((reinterpret_cast<uintptr_t>(x + lo) & 7) == 0)) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) v[q] = *reinterpret_cast<const float2*>(x + lo + 2 * (lane + 64 * q));
+        } else {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const long i0 = 256L * t + 2 * (lane + 64 * q);
+                v[q] = make_float2(x[reflect_idx(i0, L)], x[reflect_idx(i0 + 1, L)]);
+            }
+        }
+    };
+    float2 cur[4], nxt[4];
+    fetch(base + wv, cur);
     for (int it = 0; it < FRAMES_PER_WAVE; ++it) {
-        // all 4 waves run the same number of iterations (the FFT uses __syncthreads)
+        // all 4 waves run the same number of iterations
         const long fr = base + (long)it * FFT_WAVES + wv;
         const bool live = fr < nframes;
         const int b = live ? (int)(fr / T) : 0;
         const int t = live ? (int)(fr - (long)b * T) : 0;
         float2* A = s_buf[wv][0];
         float2* Bf = s_buf[wv][1];
-        const float* x = wave + (long)b * L;
+        if (it + 1 < FRAMES_PER_WAVE) fetch(fr + FFT_WAVES, nxt);   // next frame's samples: in flight during this FFT
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int m = lane + 64 * q;
-            const long i0 = 256L * t + 2 * m;
             float2 v;
-            // interior frames read contiguously; only the edge frames reflect
-            v.x = x[reflect_idx(i0, L)] * s_win[2 * m];
-            v.y = x[reflect_idx(i0 + 1, L)] * s_win[2 * m + 1];
+            v.x = cur[q].x * s_win[2 * m];
+            v.y = cur[q].y * s_win[2 * m + 1];
             A[m] = v;
             if (frames_out && live) {
                 frames_out[fr * 512 + 2 * m] = v.x;
@@ -240,6 +261,8 @@ __global__ __launch_bounds__(FFT_WAVES * 64) void k_stft(const float* __restrict
             }
         }
         wave_lds_sync();
+#pragma unroll
+        for (int q = 0; q < 4; ++q) cur[q] = nxt[q];
     }
 }
 
@@ -265,20 +288,33 @@ __global__ __launch_bounds__(FFT_WAVES * 64) void k_istft(const float* __restric
     const int j0 = grp * ISTFT_BLOCKS;                        // first hop block == first frame needed
     const int nfr = min(ISTFT_BLOCKS, nblk - j0) + 1;
     constexpr int ROUNDS = (ISTFT_BLOCKS + 1 + FFT_WAVES - 1) / FFT_WAVES;
+    // bins k and 256-k of a frame (k = lane + 64 q); the next round's are fetched before this round's FFT
+    auto fetch = [&](int it, float2 (&vk)[4], float2 (&vm)[4]) {
+        const int fi = it * FFT_WAVES + wv;
+        const int t = j0 + (fi < nfr ? fi : 0);
+        const float* x = spec + (long)b * sb + (long)t * st;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int k = lane + 64 * q;
+            vk[q] = *reinterpret_cast<const float2*>(x + (long)k * sf);
+            vm[q] = *reinterpret_cast<const float2*>(x + (long)(256 - k) * sf);
+        }
+    };
+    float2 ck[4], cm[4], nk[4], nm[4];
+    fetch(0, ck, cm);
     for (int it = 0; it < ROUNDS; ++it) {
         const int fi = it * FFT_WAVES + wv;
         const bool live = fi < nfr;
-        const int t = j0 + (live ? fi : 0);
         float2* A = s_buf[wv][0];
         float2* Bf = s_buf[wv][1];
-        const float* x = spec + (long)b * sb + (long)t * st;
+        if (it + 1 < ROUNDS) fetch(it + 1, nk, nm);
         // merge: Z[k] = Xe + i Xo, Xe = (X[k]+conj(X[256-k]))/2, Xo = (X[k]-conj(X[256-k]))/2 * exp(+2 pi i k/512);
         // c2r semantics: the imaginary parts of DC and Nyquist are ignored.
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int k = lane + 64 * q;
-            float2 xk = *reinterpret_cast<const float2*>(x + (long)k * sf);
-            float2 xm = *reinterpret_cast<const float2*>(x + (long)(256 - k) * sf);
+            float2 xk = ck[q];
+            float2 xm = cm[q];
             xm.y = -xm.y;
             if (k == 0) { xk.y = 0.f; xm.y = 0.f; }
             const float2 xe = make_float2(0.5f * (xk.x + xm.x), 0.5f * (xk.y + xm.y));
@@ -299,6 +335,8 @@ __global__ __launch_bounds__(FFT_WAVES * 64) void k_istft(const float* __restric
             }
         }
         wave_lds_sync();
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { ck[q] = nk[q]; cm[q] = nm[q]; }
     }
     __syncthreads();   // the windowed frames of all four waves are overlap-added below
     // overlap-add: output block j = frame j second half + frame j+1 first half
