@@ -1104,16 +1104,26 @@ __global__ __launch_bounds__(NTHR) void k_gtcn_band(const float* __restrict__ xi
     if (addend) addend += (long)b * T * 528;
     const int f0 = L.wave * TPW;                         // first bin of this wave
     float* cw = sC + f0 * 256;
+    // the chunk's input is fetched one chunk ahead into registers (the waves run decoupled here, so an exposed
+    // HBM latency at the top of every chunk is not hidden by a barrier wait elsewhere); the addend is only
+    // needed at the store, so it is requested at the top of its own chunk
+    f32x4 xn[TPW];
+    auto fetch = [&](int t0f) {
+        const int tcf = t0f + n < T ? t0f + n : T - 1;   // clamped frame: no select behind the loads
+#pragma unroll
+        for (int i = 0; i < TPW; ++i) xn[i] = ld4(xin + (unsigned)((tcf * 33 + f0 + i) * 16 + 4 * g));
+    };
+    fetch(0);
     for (int t0 = 0; t0 < T; t0 += TC) {
         const bool live = t0 + n < T;
-        const int tc = live ? t0 + n : T - 1;            // clamped frame: no select behind the loads
+        const int tc = live ? t0 + n : T - 1;
         f32x4 x[TPW], ad[TPW];
 #pragma unroll
         for (int i = 0; i < TPW; ++i) {
-            const unsigned o = (unsigned)((tc * 33 + f0 + i) * 16 + 4 * g);
-            x[i] = ld4(xin + o);
-            if (addend) ad[i] = ld4(addend + o);
+            x[i] = xn[i];
+            if (addend) ad[i] = ld4(addend + (unsigned)((tc * 33 + f0 + i) * 16 + 4 * g));
         }
+        if (t0 + TC < T) fetch(t0 + TC);
         // opaque offset: the block parameters are re-read from LDS every chunk; hoisting the four
         // blocks' fragments out of the chunk loop would need 128 registers and spill
         int po = 0;
