@@ -781,7 +781,6 @@ __global__ __launch_bounds__(NTHR) void k_encoder(const float* __restrict__ spec
                 const int e = 4 * go + s, c = e < 15 ? e / 5 : 0, k = e < 15 ? e % 5 : 0;
                 off[s] = c * TC * F0_ROW + k;
             }
-            constexpr int NT0 = TC * F1 / 16;  // 65 tiles
             static_assert(TC * F1 % 16 == 0, "en0 tiling");
             const int nt0 = (nfr * F1 + 15) >> 4;              // tiles that hold a valid frame
             for (int tile = L.wave; tile < nt0; tile += NW) {

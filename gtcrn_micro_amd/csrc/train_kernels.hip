@@ -122,6 +122,36 @@ struct Pos {
     }
 };
 
+// Position of a grid-stride loop over flat positions, advanced by a launch-constant stride without divisions:
+// stride = a * F + r positions, a = a1 * T + a0 rows (r, a, a0 are computed on the host).
+struct StrideIter {
+    int r, a, a0;
+};
+inline StrideIter stride_iter(long stride_pos, int F, int T) {
+    StrideIter s;
+    s.r = (int)(stride_pos % F);
+    s.a = (int)(stride_pos / F);
+    s.a0 = s.a % T;
+    return s;
+}
+struct RowPos {
+    int fo, to, bt;       // bin, frame inside the utterance, flat row b*T + t
+    __device__ __forceinline__ void init(long p, int F, int T) {
+        fo = (int)(p % F);
+        bt = (int)(p / F);
+        to = bt % T;
+    }
+    __device__ __forceinline__ void advance(const StrideIter& s, int F, int T) {
+        fo += s.r;
+        int carry = 0;
+        if (fo >= F) { fo -= F; carry = 1; }
+        bt += s.a + carry;
+        to += s.a0 + carry;
+        if (to >= T) to -= T;
+        if (to >= T) to -= T;
+    }
+};
+
 template <int NKT, int NKF>
 __global__ __launch_bounds__(NT) void k_conv_mfma(ConvGeom g, const float* __restrict__ in,
                                                  const float* __restrict__ w, const float* __restrict__ bias,
@@ -334,7 +364,7 @@ __global__ __launch_bounds__(NT) void k_dw(DwGeom g, const float* __restrict__ i
 // C = 16: one thread per (position, 4 channels): every tap is one coalesced 16-byte load
 __global__ __launch_bounds__(NT) void k_dw16(DwGeom g, const float* __restrict__ in, const float* __restrict__ w,
                                             const float* __restrict__ bias, float* __restrict__ out,
-                                            double* __restrict__ stat_partial) {
+                                            double* __restrict__ stat_partial, StrideIter it) {
     __shared__ __attribute__((aligned(16))) float sW[9 * 16];   // [tap][c]
     __shared__ float sStat[NT][8];
     f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = {0.f, 0.f, 0.f, 0.f};
@@ -344,26 +374,27 @@ __global__ __launch_bounds__(NT) void k_dw16(DwGeom g, const float* __restrict__
         sW[i] = w[c * g.w_c + kt * g.w_kt + kf * g.w_kf];
     }
     __syncthreads();
+    // Tin == Tout for every depthwise conv of the model, so the tap row is (flat row + t_off): no (b, t) split
     const long units = (long)g.B * g.Tout * g.F * 4;
+    const int q = tid & 3;
+    RowPos P;
+    P.init(((long)blockIdx.x * NT + tid) >> 2, g.F, g.Tout);
     for (long i = (long)blockIdx.x * NT + tid; i < units; i += (long)gridDim.x * NT) {
-        const int q = (int)(i & 3);
         const long p = i >> 2;
-        const int fo = (int)(p % g.F);
-        const long bt = p / g.F;
-        const int to = (int)(bt % g.Tout), b = (int)(bt / g.Tout);
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
         if (bias) acc = *reinterpret_cast<const f32x4*>(bias + 4 * q);
         for (int kt = 0; kt < g.nkt; ++kt) {
-            const int ti = to + g.t_off[kt];
+            const int ti = P.to + g.t_off[kt];
             if (ti < 0 || ti >= g.Tin) continue;
             for (int kf = 0; kf < g.nkf; ++kf) {
-                const int fi = fo + g.f_off[kf];
+                const int fi = P.fo + g.f_off[kf];
                 if (fi < 0 || fi >= g.F) continue;
-                const f32x4 x = *reinterpret_cast<const f32x4*>(in + (((long)b * g.Tin + ti) * g.F + fi) * 16 + 4 * q);
+                const f32x4 x = *reinterpret_cast<const f32x4*>(in + ((long)(P.bt + g.t_off[kt]) * g.F + fi) * 16 + 4 * q);
                 const f32x4 wt = *reinterpret_cast<const f32x4*>(sW + (kt * g.nkf + kf) * 16 + 4 * q);
                 acc += wt * x;
             }
         }
+        P.advance(it, g.F, g.Tout);
         f32x4* o = reinterpret_cast<f32x4*>(out + p * 16 + 4 * q);
         *o = g.accumulate ? *o + acc : acc;
         s1 += acc;
@@ -606,7 +637,8 @@ __global__ __launch_bounds__(NT) void k_bn_bwd_apply(const float* __restrict__ d
 // per-thread fp32 partial sums, combined in double in a fixed order (workgroup, then k_dw_wgrad_finish2).
 template <int NKT, int NKF>
 __global__ __launch_bounds__(NT) void k_dw_wgrad_stream(DwGeom g, const float* __restrict__ in,
-                                                       const float* __restrict__ dout, double* __restrict__ partial) {
+                                                       const float* __restrict__ dout, double* __restrict__ partial,
+                                                       StrideIter it) {
     constexpr int NTAP = NKT * NKF;
     __shared__ double sh[NT];
     float v[NTAP + 1][4];
@@ -615,28 +647,28 @@ __global__ __launch_bounds__(NT) void k_dw_wgrad_stream(DwGeom g, const float* _
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[k][e] = 0.f;
     const long units = (long)g.B * g.Tout * g.F * 4;
+    const int q = threadIdx.x & 3;
+    RowPos P;
+    P.init(((long)blockIdx.x * NT + threadIdx.x) >> 2, g.F, g.Tout);
     for (long i = (long)blockIdx.x * NT + threadIdx.x; i < units; i += (long)gridDim.x * NT) {
-        const int q = (int)(i & 3);
         const long p = i >> 2;
-        const int fo = (int)(p % g.F);
-        const long bt = p / g.F;
-        const int to = (int)(bt % g.Tout), b = (int)(bt / g.Tout);
         const f32x4 d = *reinterpret_cast<const f32x4*>(dout + p * 16 + 4 * q);
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[NTAP][e] += d[e];
 #pragma unroll
         for (int kt = 0; kt < NKT; ++kt) {
-            const int ti = to + g.t_off[kt];
+            const int ti = P.to + g.t_off[kt];
             if (ti < 0 || ti >= g.Tin) continue;
 #pragma unroll
             for (int kf = 0; kf < NKF; ++kf) {
-                const int fi = fo + g.f_off[kf];
+                const int fi = P.fo + g.f_off[kf];
                 if (fi < 0 || fi >= g.F) continue;
-                const f32x4 x = *reinterpret_cast<const f32x4*>(in + (((long)b * g.Tin + ti) * g.F + fi) * 16 + 4 * q);
+                const f32x4 x = *reinterpret_cast<const f32x4*>(in + ((long)(P.bt + g.t_off[kt]) * g.F + fi) * 16 + 4 * q);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[kt * NKF + kf][e] = fmaf(d[e], x[e], v[kt * NKF + kf][e]);
             }
         }
+        P.advance(it, g.F, g.Tout);
     }
     block_reduce_store<NTAP + 1, 4>(v, 16, sh, partial + (long)blockIdx.x * (NTAP + 1) * 16);
 }
@@ -1157,7 +1189,9 @@ int dw_fwd(const DwGeom& g, const float* in, const float* w, const float* bias, 
     if (g.C == 16) {
         double* sp = (stat_partial && stat_parts && !g.accumulate) ? stat_partial : nullptr;
         const int g16 = grid_for((long)g.B * g.Tout * g.F * 4, sp ? MAX_PARTIALS : 16384);
-        hipLaunchKernelGGL(k_dw16, dim3(g16), dim3(NT), 0, s, g, in, w, bias, out, sp);
+        if (g.Tin != g.Tout) return (int)hipErrorInvalidValue;
+        hipLaunchKernelGGL(k_dw16, dim3(g16), dim3(NT), 0, s, g, in, w, bias, out, sp,
+                           stride_iter((long)g16 * NT / 4, g.F, g.Tout));
         if (sp) *stat_parts = g16;
         return check();
     }
@@ -1172,8 +1206,10 @@ int dw_wgrad(const DwGeom& g, const float* in, const float* dout, float* dw, flo
         double* part = reinterpret_cast<double*>(scratch);      // <= MAX_PARTIALS * 160 doubles
         const int grid = red_grid((long)g.B * g.Tout * g.F * 4);
         const int K = (g.nkt * g.nkf + 1) * 16;
-        if (g.nkf == 3) hipLaunchKernelGGL((k_dw_wgrad_stream<3, 3>), dim3(grid), dim3(NT), 0, s, g, in, dout, part);
-        else hipLaunchKernelGGL((k_dw_wgrad_stream<3, 1>), dim3(grid), dim3(NT), 0, s, g, in, dout, part);
+        if (g.Tin != g.Tout) return (int)hipErrorInvalidValue;
+        const StrideIter it = stride_iter((long)grid * NT / 4, g.F, g.Tout);
+        if (g.nkf == 3) hipLaunchKernelGGL((k_dw_wgrad_stream<3, 3>), dim3(grid), dim3(NT), 0, s, g, in, dout, part, it);
+        else hipLaunchKernelGGL((k_dw_wgrad_stream<3, 1>), dim3(grid), dim3(NT), 0, s, g, in, dout, part, it);
         hipLaunchKernelGGL(k_dw_wgrad_finish2, dim3((K + 63) / 64), dim3(1024), 0, s, g, part, grid, dw, dbias);
         return check();
     }
