@@ -87,6 +87,7 @@ def lib():
     L.gtcrn_train_forward.argtypes = [_vp, _vp, _vp, cl, cl, cl, _vp, cl, cl, cl, ci, ci, _vp]
     L.gtcrn_train_backward.argtypes = [_vp, _vp, _vp, cl, cl, cl, _vp, cl, cl, cl, _vp, _vp]
     L.gtcrn_train_tap.argtypes = [_vp, ctypes.c_char_p, _vp, ctypes.POINTER(cl), _vp]
+    L.gtcrn_train_loss.argtypes = [_vp, _vp, cl, cl, cl, _vp, cl, cl, cl, ci, ci, _vp, _vp, _vp]
     if L.gtcrn_abi_version() != 1:
         raise GtcrnError("libgtcrn_micro_hip.so ABI version mismatch")
     _lib = L
@@ -451,6 +452,27 @@ class Trainer:
             _check(lib().gtcrn_train_backward(self._h, params.data_ptr(), spec.data_ptr(), isb, isf, ist,
                                               grad_out.data_ptr(), gsb, gsf, gst, grads.data_ptr(), _stream_ptr()))
         return grads
+
+    def hybrid_loss(self, pred, true, want_grad=True):
+        """HybridLoss (loss.py:30-71) of two (B,257,T,2) spectrograms: returns (loss 0-d tensor, d loss/d pred or None)."""
+        import torch
+        _require_cuda_f32(pred, "pred")
+        _require_cuda_f32(true, "true")
+        if pred.shape != true.shape or pred.dim() != 4 or pred.shape[1] != NBINS or pred.shape[3] != 2:
+            raise GtcrnError(f"pred/true must both be (B,257,T,2), got {tuple(pred.shape)} and {tuple(true.shape)}")
+        if pred.stride(3) != 1:
+            pred = pred.contiguous()
+        if true.stride(3) != 1:
+            true = true.contiguous()
+        B, _, T, _ = pred.shape
+        loss = torch.empty((), device=pred.device, dtype=torch.float32)
+        grad = torch.empty((B, NBINS, T, 2), device=pred.device, dtype=torch.float32) if want_grad else None
+        psb, psf, pst = _spec_strides(pred)
+        tsb, tsf, tst = _spec_strides(true)
+        with torch.cuda.device(self.device):
+            _check(lib().gtcrn_train_loss(self._h, pred.data_ptr(), psb, psf, pst, true.data_ptr(), tsb, tsf, tst, B, T,
+                                          loss.data_ptr(), grad.data_ptr() if want_grad else None, _stream_ptr()))
+        return loss, grad
 
     def tap(self, name):
         """Train-mode activation of the most recent forward at a stage boundary, as (B,C,T,F)."""

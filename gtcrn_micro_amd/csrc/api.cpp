@@ -346,6 +346,8 @@ int device_twiddles(float** out) {
 }
 }  // namespace
 
+extern "C" int gtcrn_device_twiddles_(float** out) { return device_twiddles(out); }   // for train.cpp
+
 static int check_spec_layout(const void* p, long sb, long sf, long st) {
     // the kernels move the (re, im) pair with 8-byte accesses
     if ((reinterpret_cast<uintptr_t>(p) & 7) || (sb & 1) || (sf & 1) || (st & 1))

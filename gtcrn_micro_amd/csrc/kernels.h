@@ -38,6 +38,10 @@ int launch_stft(const float* wave, int B, long L, int T, const float* win, const
                 long sf, long st, float* frames, hipStream_t s);
 int launch_istft(const float* spec, long sb, long sf, long st, int B, int T, const float* win, const float* twid,
                  float* wave, hipStream_t s);
+// gspec += adjoint(iSTFT)(gwave): gwave (B, 256 (T-1)) is the gradient w.r.t. the iSTFT output ALREADY divided by
+// the window envelope; gspec (B,257,T,2 by strides) receives the gradient w.r.t. the spectrogram (accumulated).
+int launch_istft_adjoint(const float* gwave, int B, int T, const float* win, const float* twid, float* gspec, long sb,
+                         long sf, long st, hipStream_t s);
 int launch_encoder(const float* spec, long sb, long sf, long st, int B, int T, const float* PF, const int* PI,
                    float* en0, float* en1, float* en2, float* en3, float* en4, float* state,
                    unsigned long long* stamps, hipStream_t s);

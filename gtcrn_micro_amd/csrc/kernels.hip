@@ -185,6 +185,10 @@ __device__ __forceinline__ void fft256(float2* a, float2* b, const float2* tw, i
 
 constexpr int FFT_WAVES = 4;
 
+// ADJ = true: the adjoint of k_istft's linear map (the backward of torch.istft, used by the fused HybridLoss):
+// frames are cut from the ZERO-padded signal, every bin is scaled by c_k / 512 (c_k = 2 except DC and Nyquist: the
+// c2r transform reads those once) and the result is ADDED to `spec`.
+template <bool ADJ>
 __global__ __launch_bounds__(FFT_WAVES * 64) void k_stft(const float* __restrict__ wave, int B, long L, int T,
                                                         const float* __restrict__ win,
                                                         const float2* __restrict__ twid, float* __restrict__ spec,
@@ -214,7 +218,12 @@ __global__ __launch_bounds__(FFT_WAVES * 64) void k_stft(const float* __restrict
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const long i0 = 256L * t + 2 * (lane + 64 * q);
-                v[q] = make_float2(x[reflect_idx(i0, L)], x[reflect_idx(i0 + 1, L)]);
+                if (ADJ) {
+                    const long j0 = i0 - 256, j1 = j0 + 1;
+                    v[q] = make_float2(j0 >= 0 && j0 < L ? x[j0] : 0.f, j1 >= 0 && j1 < L ? x[j1] : 0.f);
+                } else {
+                    v[q] = make_float2(x[reflect_idx(i0, L)], x[reflect_idx(i0 + 1, L)]);
+                }
             }
         }
     };
@@ -255,9 +264,18 @@ __global__ __launch_bounds__(FFT_WAVES * 64) void k_stft(const float* __restrict
                 const float2 zo = make_float2(0.5f * (zk.y + zm.y), -0.5f * (zk.x - zm.x));
                 const float2 r = cmul(s_tw512[k], zo);
                 // the re/im pair is contiguous and 8-byte aligned (even strides): one 8-byte store
-                *reinterpret_cast<float2*>(o + (long)k * sf) = make_float2(ze.x + r.x, ze.y + r.y);
-                if (k == 0)  // Nyquist bin: X[256] = Re Z[0] - Im Z[0]
-                    *reinterpret_cast<float2*>(o + 256L * sf) = make_float2(zk.x - zk.y, 0.f);
+                float2* ok = reinterpret_cast<float2*>(o + (long)k * sf);
+                float2* on = reinterpret_cast<float2*>(o + 256L * sf);
+                if (ADJ) {
+                    const float ck = (k == 0 ? 1.0f : 2.0f) / 512.0f;
+                    const float2 old = *ok;
+                    *ok = make_float2(old.x + ck * (ze.x + r.x), old.y + (k == 0 ? 0.f : ck * (ze.y + r.y)));
+                    if (k == 0) { const float2 o2 = *on; *on = make_float2(o2.x + (zk.x - zk.y) * (1.0f / 512.0f), o2.y); }
+                } else {
+                    *ok = make_float2(ze.x + r.x, ze.y + r.y);
+                    if (k == 0)  // Nyquist bin: X[256] = Re Z[0] - Im Z[0]
+                        *on = make_float2(zk.x - zk.y, 0.f);
+                }
             }
         }
         wave_lds_sync();
@@ -1572,8 +1590,19 @@ int launch_stft(const float* wave, int B, long L, int T, const float* win, const
     const long nframes = (long)B * T;
     const int per = FFT_WAVES * FRAMES_PER_WAVE;
     const int grid = (int)((nframes + per - 1) / per);
-    hipLaunchKernelGGL(k_stft, dim3(grid), dim3(FFT_WAVES * 64), 0, s, wave, B, L, T, win,
+    hipLaunchKernelGGL(k_stft<false>, dim3(grid), dim3(FFT_WAVES * 64), 0, s, wave, B, L, T, win,
                        reinterpret_cast<const float2*>(twid), spec, sb, sf, st, frames);
+    GT_LAUNCH_CHECK();
+    return 0;
+}
+
+int launch_istft_adjoint(const float* gwave, int B, int T, const float* win, const float* twid, float* gspec, long sb,
+                         long sf, long st, hipStream_t s) {
+    const long nframes = (long)B * T;
+    const int per = FFT_WAVES * FRAMES_PER_WAVE;
+    const int grid = (int)((nframes + per - 1) / per);
+    hipLaunchKernelGGL(k_stft<true>, dim3(grid), dim3(FFT_WAVES * 64), 0, s, gwave, B, 256L * (T - 1), T, win,
+                       reinterpret_cast<const float2*>(twid), gspec, sb, sf, st, (float*)nullptr);
     GT_LAUNCH_CHECK();
     return 0;
 }

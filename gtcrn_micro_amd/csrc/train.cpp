@@ -16,10 +16,12 @@
 #include <string>
 #include <vector>
 
+#include "kernels.h"
 #include "pack.h"
 #include "train_kernels.h"
 
 extern "C" void gtcrn_set_error_(const char* msg);   // api.cpp: thread-local last error
+extern "C" int gtcrn_device_twiddles_(float** out);  // api.cpp: per-device FFT twiddles
 
 namespace {
 
@@ -92,6 +94,10 @@ struct gtcrn_trainer {
     float *q1 = nullptr, *q2 = nullptr, *dy = nullptr, *dv = nullptr, *dhd = nullptr, *dh = nullptr, *tmp_tra = nullptr;
     float *d65 = nullptr, *df0 = nullptr;
     std::map<std::string, std::pair<const float*, std::vector<int>>> taps;  // name -> (ptr, {T', F, C})
+    // HybridLoss workspace: the two iSTFT waveforms, the sqrt-Hann window, SI-SNR coefficients
+    float* loss_ws = nullptr;
+    size_t loss_ws_floats = 0;
+    float* d_win = nullptr;
 };
 
 namespace {
@@ -378,6 +384,8 @@ void gtcrn_trainer_destroy(gtcrn_trainer* t) {
     if (t->arena) (void)hipFree(t->arena);
     if (t->fscratch) (void)hipFree(t->fscratch);
     if (t->dscratch) (void)hipFree(t->dscratch);
+    if (t->loss_ws) (void)hipFree(t->loss_ws);
+    if (t->d_win) (void)hipFree(t->d_win);
     delete t;
 }
 
@@ -478,6 +486,47 @@ int gtcrn_train_backward(gtcrn_trainer* t, const float* d_params, const float* d
         g.f_off[0] = -1; g.f_off[1] = 0; g.f_off[2] = 1; g.w_c = 3; g.w_kt = 3; g.w_kf = 1;
         T_RUN(gtt::dw_wgrad(g, t->eb, t->df0, G + P(t, "sfe.depth_conv.weight"), nullptr, t->fscratch, s));
     }
+    return 0;
+}
+
+int gtcrn_train_loss(gtcrn_trainer* t, const float* d_pred, long pb, long pf, long pt, const float* d_true, long tb,
+                     long tf, long tt, int B, int T, float* d_loss, float* d_grad, void* stream) {
+    if (!t || !d_pred || !d_true || !d_loss || B < 1 || B > 1024 || T < 2)
+        return tfail(GTCRN_ERR_ARG, "gtcrn_train_loss: bad argument (needs 1 <= B <= 1024 utterances, T >= 2 frames)");
+    if (((pb | pf | pt | tb | tf | tt) & 1) || (reinterpret_cast<uintptr_t>(d_pred) & 7) ||
+        (reinterpret_cast<uintptr_t>(d_true) & 7))
+        return tfail(GTCRN_ERR_ARG, "gtcrn_train_loss: spectrograms must be 8-byte aligned with even strides");
+    hipStream_t s = (hipStream_t)stream;
+    const long Lw = 256L * (T - 1);
+    const size_t need = (size_t)2 * B * Lw + 2 * B + 64;
+    if (need > t->loss_ws_floats) {
+        T_HIP(hipDeviceSynchronize());
+        if (t->loss_ws) (void)hipFree(t->loss_ws);
+        t->loss_ws = nullptr; t->loss_ws_floats = 0;
+        T_HIP(hipMalloc(&t->loss_ws, need * sizeof(float)));
+        t->loss_ws_floats = need;
+    }
+    if (!t->d_win) {
+        float w[512];
+        gtcrn::make_window(0, w);      // torch.hann_window(512).pow(0.5), loss.py:50
+        T_HIP(hipMalloc(&t->d_win, sizeof(w)));
+        T_HIP(hipMemcpy(t->d_win, w, sizeof(w), hipMemcpyHostToDevice));
+    }
+    float* tw = nullptr;
+    if (gtcrn_device_twiddles_(&tw)) return GTCRN_ERR_HIP;
+    float* yp = t->loss_ws;
+    float* yt = yp + (size_t)B * Lw;
+    float* coef = yt + (size_t)B * Lw;
+    double* spec_partial = t->dscratch;                      // <= MAX_PARTIALS * 2 doubles
+    double* dwork = t->dscratch + 2 * gtt::MAX_PARTIALS;     // B * 25 doubles
+    int parts = 0;
+    T_RUN(gtt::hybrid_loss_spec(d_pred, pb, pf, pt, d_true, tb, tf, tt, B, T, d_grad, spec_partial, &parts, s));
+    T_RUN(gtk::launch_istft(d_pred, pb, pf, pt, B, T, t->d_win, tw, yp, s));
+    T_RUN(gtk::launch_istft(d_true, tb, tf, tt, B, T, t->d_win, tw, yt, s));
+    T_RUN(gtt::sisnr_terms(yp, yt, B, Lw, spec_partial, parts, (long)B * 257 * T, t->d_win, dwork, coef, d_loss,
+                           d_grad != nullptr, s));
+    if (d_grad)   // d_grad is contiguous (B,257,T,2): strides (257*T*2, T*2, 2)
+        T_RUN(gtk::launch_istft_adjoint(yp, B, T, t->d_win, tw, d_grad, 257L * T * 2, (long)T * 2, 2, s));
     return 0;
 }
 

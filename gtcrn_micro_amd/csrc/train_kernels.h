@@ -98,6 +98,16 @@ int tra_gate_shuffle_bwd(const float* dout, const float* v, const float* g, cons
                          int T, int Tt, const float* dw_w, const float* pw_w, float* dv, float* dx, float* d_dw_w,
                          float* d_dw_b, float* d_pw_w, float* d_pw_b, float* tmp, float* scratch, hipStream_t s);
 
+// HybridLoss (loss.py:30-71).  hybrid_loss_spec: the three spectral terms -- per-workgroup sums (sum of squared
+// compressed real+imag differences, sum of squared compressed-magnitude differences) into `partial`, and their
+// gradient w.r.t. pred into grad (contiguous (B,257,T,2); nullptr: value only).  sisnr_terms: from the two
+// waveforms, the SI-SNR term, the closed loss value (loss[0]) and, if want_grad, yp := d loss / d yp already
+// divided by the iSTFT envelope (input of the iSTFT adjoint).  dwork: B * 25 doubles, coef: 2 * B floats.
+int hybrid_loss_spec(const float* pred, long pb, long pf, long pt, const float* tru, long tb, long tf, long tt, int B,
+                     int T, float* grad, double* partial, int* parts, hipStream_t s);
+int sisnr_terms(float* yp, const float* yt, int B, long Lw, const double* spec_partial, int spec_parts, long N,
+                const float* win, double* dwork, float* coef, float* loss, int want_grad, hipStream_t s);
+
 int add(const float* a, const float* b, float* out, long n, hipStream_t s);
 
 }  // namespace gtt

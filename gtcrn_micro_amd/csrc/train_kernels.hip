@@ -1110,6 +1110,118 @@ __global__ __launch_bounds__(128) void k_tra_pgrad(const float* __restrict__ dzg
     partial[(long)blockIdx.x * 104 + tid] = s;
 }
 
+// ------------------------------------------------------------------------------- HybridLoss
+// loss.py:30-71: 30 * (MSE of the power-compressed real and imaginary parts) + 70 * MSE of the compressed
+// magnitudes + SI-SNR of the sqrt-Hann iSTFTs.  k_hloss_spec: value and gradient of the three spectral
+// terms in one pass over (B,257,T); the SI-SNR term needs three sums per utterance (k_sisnr_sums), from which
+// its gradient w.r.t. the predicted waveform is A_b * y_pred + B_b * y_true (k_sisnr_coef, k_sisnr_gwave);
+// the iSTFT adjoint (kernels.hip, k_stft<true>) carries it back to the spectrogram.
+__global__ __launch_bounds__(NT) void k_hloss_spec(const float* __restrict__ pred, long pb, long pf, long pt,
+                                                  const float* __restrict__ tru, long tb, long tf, long tt, int B,
+                                                  int T, float* __restrict__ grad, double* __restrict__ partial) {
+    __shared__ double sh[NT];
+    const long N = (long)B * 257 * T;
+    const float kri = 60.0f / (float)N, kmag = 140.0f / (float)N;
+    double sri = 0.0, smag = 0.0;
+    for (long i = (long)blockIdx.x * NT + threadIdx.x; i < N; i += (long)gridDim.x * NT) {
+        const int t = (int)(i % T);
+        const long bf = i / T;
+        const int f = (int)(bf % 257), b = (int)(bf / 257);
+        const float2 p = *reinterpret_cast<const float2*>(pred + (long)b * pb + (long)f * pf + (long)t * pt);
+        const float2 q = *reinterpret_cast<const float2*>(tru + (long)b * tb + (long)f * tf + (long)t * tt);
+        const float pm2 = p.x * p.x + p.y * p.y + 1e-12f, tm2 = q.x * q.x + q.y * q.y + 1e-12f;
+        const float lp = 0.5f * __log2f(pm2), lt = 0.5f * __log2f(tm2);      // log2 |.|
+        const float u = exp2f(-0.7f * lp), ut = exp2f(-0.7f * lt);            // |.|^-0.7
+        const float c = exp2f(0.3f * lp), ct = exp2f(0.3f * lt);              // |.|^0.3
+        const float da = p.x * u - q.x * ut, db = p.y * u - q.y * ut, dc = c - ct;
+        sri += (double)(da * da + db * db);
+        smag += (double)(dc * dc);
+        if (grad) {
+            const float inv = 1.0f / pm2, w = 0.7f * u * inv;
+            const float a_r = u - w * p.x * p.x, a_i = -w * p.x * p.y, b_i = u - w * p.y * p.y;
+            const float cw = 0.3f * c * inv;
+            *reinterpret_cast<float2*>(grad + i * 2) =
+                make_float2(kri * (da * a_r + db * a_i) + kmag * dc * cw * p.x,
+                            kri * (da * a_i + db * b_i) + kmag * dc * cw * p.y);
+        }
+    }
+    // workgroup sums, fixed order
+    for (int k = 0; k < 2; ++k) {
+        __syncthreads();
+        sh[threadIdx.x] = k == 0 ? sri : smag;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            double s = 0.0;
+            for (int j = 0; j < NT; ++j) s += sh[j];
+            partial[(long)blockIdx.x * 2 + k] = s;
+        }
+    }
+}
+// per utterance: dot = <yt, yp>, ett = <yt, yt>, epp = <yp, yp>; grid (chunks, B)
+__global__ __launch_bounds__(NT) void k_sisnr_sums(const float* __restrict__ yp, const float* __restrict__ yt, long Lw,
+                                                  double* __restrict__ partial) {
+    __shared__ double sh[NT];
+    const float* a = yp + (long)blockIdx.y * Lw;
+    const float* b = yt + (long)blockIdx.y * Lw;
+    double v[3] = {0.0, 0.0, 0.0};
+    for (long i = (long)blockIdx.x * NT + threadIdx.x; i < Lw; i += (long)gridDim.x * NT) {
+        const float x = a[i], y = b[i];
+        v[0] += (double)(x * y); v[1] += (double)(y * y); v[2] += (double)(x * x);
+    }
+    for (int k = 0; k < 3; ++k) {
+        __syncthreads();
+        sh[threadIdx.x] = v[k];
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            double s = 0.0;
+            for (int j = 0; j < NT; ++j) s += sh[j];
+            partial[((long)blockIdx.y * gridDim.x + blockIdx.x) * 3 + k] = s;
+        }
+    }
+}
+// one thread per utterance: -log10(|s|^2 / (|yp - s|^2 + 1e-8) + 1e-8) with s = <yt,yp> yt / (<yt,yt> + 1e-8), and the
+// coefficients of its gradient  d/d yp = A yp + B yt  (scaled by 1/B: the loss takes the batch mean).
+// Thread 0 of block 0 also closes the loss: spectral partial sums + mean SI-SNR.
+__global__ void k_sisnr_coef(const double* __restrict__ part, int chunks, int B, long N,
+                             const double* __restrict__ spec_partial, int spec_parts, float* __restrict__ coef,
+                             double* __restrict__ vals, float* __restrict__ loss) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b < B) {
+        double dot = 0.0, ett = 0.0, epp = 0.0;
+        for (int c = 0; c < chunks; ++c) {
+            dot += part[((long)b * chunks + c) * 3]; ett += part[((long)b * chunks + c) * 3 + 1];
+            epp += part[((long)b * chunks + c) * 3 + 2];
+        }
+        const double eps = 1e-8, al = dot / (ett + eps), num = al * al * ett;
+        const double den = epp - 2.0 * al * dot + al * al * ett + eps;
+        const double r = num / den;
+        vals[b] = -log10(r + eps);
+        const double c0 = (1.0 / B) * (-1.0 / ((r + eps) * 2.302585092994046));
+        const double kap = ett / (ett + eps), eta = (dot - al * ett) / (ett + eps);
+        coef[2 * b] = (float)(c0 * (-2.0 * num / (den * den)));
+        coef[2 * b + 1] = (float)(c0 * (2.0 * al * kap / den + 2.0 * num * (al + eta) / (den * den)));
+    }
+    // the last step needs every utterance's value: a single-block launch keeps it simple (B <= 1024 per block)
+    __syncthreads();
+    if (blockIdx.x == 0 && threadIdx.x == 0 && gridDim.x == 1) {
+        double sri = 0.0, smag = 0.0, ss = 0.0;
+        for (int w = 0; w < spec_parts; ++w) { sri += spec_partial[2 * w]; smag += spec_partial[2 * w + 1]; }
+        for (int i = 0; i < B; ++i) ss += vals[i];
+        loss[0] = (float)(30.0 * sri / (double)N + 70.0 * smag / (double)N + ss / B);
+    }
+}
+// gwave = (A_b yp + B_b yt) / envelope, envelope[j] = win[j & 255]^2 + win[256 + (j & 255)]^2 (k_istft divides by it)
+__global__ __launch_bounds__(NT) void k_sisnr_gwave(float* __restrict__ yp, const float* __restrict__ yt, long Lw,
+                                                   long total, const float* __restrict__ coef,
+                                                   const float* __restrict__ win) {
+    for (long i = (long)blockIdx.x * NT + threadIdx.x; i < total; i += (long)gridDim.x * NT) {
+        const int b = (int)(i / Lw), j = (int)((i - (long)b * Lw) & 255);
+        const float env = win[j] * win[j] + win[256 + j] * win[256 + j];
+        const float g = coef[2 * b] * yp[i] + coef[2 * b + 1] * yt[i];
+        yp[i] = env > 1e-11f ? g / env : g;
+    }
+}
+
 __global__ __launch_bounds__(NT) void k_add(const float* __restrict__ a, const float* __restrict__ b,
                                            float* __restrict__ out, long n) {
     for (long i = (long)blockIdx.x * NT + threadIdx.x; i < n; i += (long)gridDim.x * NT) out[i] = a[i] + b[i];
@@ -1349,6 +1461,28 @@ int tra_gate_shuffle_bwd(const float* dout, const float* v, const float* g, cons
     // the four gradients are contiguous in the blob in exactly the partials' order (d_dw_w is the first)
     (void)d_dw_b; (void)d_pw_w; (void)d_pw_b;
     hipLaunchKernelGGL(k_reduce_partials_f, dim3(2), dim3(1024), 0, s, scratch, parts, 104, d_dw_w);
+    return check();
+}
+
+int hybrid_loss_spec(const float* pred, long pb, long pf, long pt, const float* tru, long tb, long tf, long tt, int B,
+                     int T, float* grad, double* partial, int* parts, hipStream_t s) {
+    const int grid = red_grid((long)B * 257 * T);
+    hipLaunchKernelGGL(k_hloss_spec, dim3(grid), dim3(NT), 0, s, pred, pb, pf, pt, tru, tb, tf, tt, B, T, grad, partial);
+    *parts = grid;
+    return check();
+}
+int sisnr_terms(float* yp, const float* yt, int B, long Lw, const double* spec_partial, int spec_parts, long N,
+                const float* win, double* dwork, float* coef, float* loss, int want_grad, hipStream_t s) {
+    if (B > 1024) return (int)hipErrorInvalidValue;
+    const int chunks = 8;
+    double* part = dwork;                      // B * chunks * 3
+    double* vals = dwork + (long)B * chunks * 3;
+    hipLaunchKernelGGL(k_sisnr_sums, dim3(chunks, B), dim3(NT), 0, s, yp, yt, Lw, part);
+    hipLaunchKernelGGL(k_sisnr_coef, dim3(1), dim3(1024), 0, s, part, chunks, B, N, spec_partial, spec_parts, coef, vals,
+                       loss);
+    if (want_grad)
+        hipLaunchKernelGGL(k_sisnr_gwave, dim3(grid_for((long)B * Lw, 8192)), dim3(NT), 0, s, yp, yt, Lw, (long)B * Lw,
+                           coef, win);
     return check();
 }
 

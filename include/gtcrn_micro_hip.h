@@ -184,6 +184,12 @@ int gtcrn_train_forward(gtcrn_trainer *t, float *d_params, const float *d_spec, 
 int gtcrn_train_backward(gtcrn_trainer *t, const float *d_params, const float *d_spec, long sb, long sf,
                          long st, const float *d_grad_out, long gb, long gf, long gt, float *d_grads,
                          void *stream);
+/* HybridLoss (loss.py:30-71): 30 * (MSE of the 0.3-compressed real and imaginary parts) + 70 * MSE of the
+ * compressed magnitudes + SI-SNR of the sqrt-Hann iSTFTs, batch mean.  d_loss receives one float; d_grad
+ * (optional) the gradient w.r.t. d_pred as a contiguous (B,257,T,2) tensor.  Replaces
+ * `loss = self.loss_func(enhanced, clean_spec)` and the loss part of `loss.backward()` (train.py:267, 280). */
+int gtcrn_train_loss(gtcrn_trainer *t, const float *d_pred, long pb, long pf, long pt, const float *d_true, long tb,
+                     long tf, long tt, int B, int T, float *d_loss, float *d_grad, void *stream);
 /* Test hook: train-mode activation of the most recent forward at a stage boundary (en0..en4, gtcn1,
  * gtcn2, de0..de4), channels-last (B, T, F, C) in the reference's channel order; shape4 receives
  * the four extents; d_out may be NULL to query the shape. */
