@@ -469,6 +469,36 @@ __device__ __forceinline__ void gtconv_block(f32x4 (&x)[TPW], const Tiles<TPW>& 
         const f32x4 A2 = ld4(c.pb + GB_PC2_A + n * 16 + 4 * g), B2 = ld4(c.pb + GB_PC2_B + 4 * g);
         const f32x4 keep = ld4(c.pb + GB_KEEP + 4 * g);
         const long ringoff = c.sHk - c.sW;   // both live in the same LDS array
+        if constexpr (!DENSE) {
+            // depthwise 3x3, kernel-row major: the three weights of a kernel row stay in registers for all of the
+            // wave's tiles (9 LDS weight reads per block instead of 9 per tile; this phase is LDS-bound)
+            f32x4 acc[TPW];
+#pragma unroll
+            for (int i = 0; i < TPW; ++i) acc[i] = Bd;
+#pragma unroll
+            for (int kt = 0; kt < 3; ++kt) {
+                const f32x4 w0 = ld4(c.pb + GB_DW_W + (kt * 3 + 0) * 16 + 4 * g);
+                const f32x4 w1 = ld4(c.pb + GB_DW_W + (kt * 3 + 1) * 16 + 4 * g);
+                const f32x4 w2 = ld4(c.pb + GB_DW_W + (kt * 3 + 2) * 16 + 4 * g);
+                const int back = 2 - kt;                     // tap (t-2+kt, f-1+kf)
+#pragma unroll
+                for (int i = 0; i < TPW; ++i) {
+                    const int b0 = o35(tt, i, g);
+                    const int rb = back == 0 ? b0
+                                 : (tt.tl[i] >= back ? b0 - back * 35 * 16 : (int)ringoff + ring35(tt, i, g, c.tabs, back));
+                    acc[i] += w0 * ld4(c.sW + rb - 16) + w1 * ld4(c.sW + rb) + w2 * ld4(c.sW + rb + 16);
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < TPW; ++i) {
+                const f32x4 hd = prelu4(acc[i], a2);
+                f32x4 v = keep * x[i] + B2;
+#pragma unroll
+                for (int s = 0; s < 4; ++s) v = mfma(A2[s], hd[s], v);
+                x[i] = v;
+                st4(c.sS + tt.pp(i) * 16 + 4 * g, v * v);   // energies are reduced cooperatively after the barrier
+            }
+        } else {
 #pragma unroll
         for (int i = 0; i < TPW; ++i) {
             // row bases for frames t, t-1, t-2: inside the chunk image, or the ring for earlier frames
@@ -512,6 +542,7 @@ __device__ __forceinline__ void gtconv_block(f32x4 (&x)[TPW], const Tiles<TPW>& 
             __builtin_amdgcn_sched_barrier(0);
         }
     }
+        }
     wg_barrier();
     STAMP(SS, 6)
     hook();
