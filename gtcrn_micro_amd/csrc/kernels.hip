@@ -499,50 +499,42 @@ __device__ __forceinline__ void gtconv_block(f32x4 (&x)[TPW], const Tiles<TPW>& 
                 st4(c.sS + tt.pp(i) * 16 + 4 * g, v * v);   // energies are reduced cooperatively after the barrier
             }
         } else {
+            // dense transposed 3x3, tap major: each of the nine 16x16 slot matrices is read from LDS once per wave
+            // (not once per tile) and feeds one MFMA chain per tile -- TPW independent accumulator chains
+            f32x4 acc[TPW];
 #pragma unroll
-        for (int i = 0; i < TPW; ++i) {
-            // row bases for frames t, t-1, t-2: inside the chunk image, or the ring for earlier frames
-            const int b0 = o35(tt, i, g);
-            const int b1 = tt.tl[i] >= 1 ? b0 - 35 * 16 : (int)ringoff + ring35(tt, i, g, c.tabs, 1);
-            const int b2 = tt.tl[i] >= 2 ? b0 - 70 * 16 : (int)ringoff + ring35(tt, i, g, c.tabs, 2);
-            f32x4 acc = Bd, acc1 = splat(0.f);   // two chains: the dense conv is 36 dependent MFMAs otherwise
+            for (int i = 0; i < TPW; ++i) acc[i] = Bd;
 #pragma unroll
             for (int kt = 0; kt < 3; ++kt) {
-                // keep at most one kernel row (3 taps + 3 matrices) of LDS loads in flight: hoisting all
-                // nine ahead of the MFMAs costs 68 registers and pushes the kernel into scratch
-                if (DENSE && kt > 0) __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int kf = 0; kf < 3; ++kf) {
-                    // encoder: tap (t-2+kt, f-1+kf); decoder (transposed): tap (t-kt, f+1-kf)
-                    const int back = DENSE ? kt : 2 - kt;          // frames back: 0, 1, 2
-                    const int df = DENSE ? 1 - kf : kf - 1;
-                    const f32x4 tap = ld4(c.sW + (back == 0 ? b0 : (back == 1 ? b1 : b2)) + df * 16);
-                    if (DENSE) {
-                        const f32x4 A = ld4(c.gA + (kt * 3 + kf) * 256 + n * 16 + 4 * g);
-                        if ((kt * 3 + kf) & 1) {
+                    const f32x4 A = ld4(c.gA + (kt * 3 + kf) * 256 + n * 16 + 4 * g);
+                    const int back = kt, df = 1 - kf;        // decoder (transposed): tap (t-kt, f+1-kf)
 #pragma unroll
-                            for (int s = 0; s < 4; ++s) acc1 = mfma(A[s], tap[s], acc1);
-                        } else {
+                    for (int i = 0; i < TPW; ++i) {
+                        const int b0 = o35(tt, i, g);
+                        const int rb = back == 0 ? b0
+                                     : (tt.tl[i] >= back ? b0 - back * 35 * 16 : (int)ringoff + ring35(tt, i, g, c.tabs, back));
+                        const f32x4 tap = ld4(c.sW + rb + df * 16);
 #pragma unroll
-                            for (int s = 0; s < 4; ++s) acc = mfma(A[s], tap[s], acc);
-                        }
-                    } else {
-                        // depthwise weights are re-read per tap (36 registers would be pinned otherwise)
-                        acc += ld4(c.pb + GB_DW_W + (kt * 3 + kf) * 16 + 4 * g) * tap;
+                        for (int s = 0; s < 4; ++s) acc[i] = mfma(A[s], tap[s], acc[i]);
                     }
+                    // one tap's loads (a matrix + TPW records) in flight at a time: hoisting more of them ahead of
+                    // the MFMAs pushes the kernel into scratch
+                    __builtin_amdgcn_sched_barrier(0);
                 }
             }
-            if (DENSE) acc += acc1;
-            const f32x4 hd = prelu4(acc, a2);
-            f32x4 v = keep * x[i] + B2;
 #pragma unroll
-            for (int s = 0; s < 4; ++s) v = mfma(A2[s], hd[s], v);
-            x[i] = v;
-            st4(c.sS + tt.pp(i) * 16 + 4 * g, v * v);   // energies are reduced cooperatively after the barrier
-            __builtin_amdgcn_sched_barrier(0);
+            for (int i = 0; i < TPW; ++i) {
+                const f32x4 hd = prelu4(acc[i], a2);
+                f32x4 v = keep * x[i] + B2;
+#pragma unroll
+                for (int s = 0; s < 4; ++s) v = mfma(A2[s], hd[s], v);
+                x[i] = v;
+                st4(c.sS + tt.pp(i) * 16 + 4 * g, v * v);   // energies are reduced cooperatively after the barrier
+            }
         }
     }
-        }
     wg_barrier();
     STAMP(SS, 6)
     hook();
