@@ -845,23 +845,26 @@ __global__ __launch_bounds__(NTHR) void k_encoder(const float* __restrict__ spec
             const f32x4 Bv = ld4(sP + E_EN1_B + 4 * g);
             const float a = sP[E_EN1_S] - 1.0f;
             const int* ix = sI + I_ENST + 0 * 16 + 4 * g;
+            // tap major: each of the five 16x16 slot matrices is read from LDS once per wave, one MFMA chain per tile
+#pragma unroll
+            for (int i = 0; i < TPW; ++i) x[i] = Bv;
+#pragma unroll
+            for (int k = 0; k < 5; ++k) {
+                const f32x4 A = ld4(sP + E_EN1_A + k * 256 + n * 16 + 4 * g);
+#pragma unroll
+                for (int i = 0; i < TPW; ++i) {
+                    const f32x4 tap = ld4(sE0 + pl(tt.tl[i] * ENC_E0_ROW + 2 * tt.ff[i], g) + k * 16);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) x[i] = mfma(A[q], tap[q], x[i]);
+                }
+            }
 #pragma unroll
             for (int i = 0; i < TPW; ++i) {
-                f32x4 acc = Bv;
-                const int e0 = pl(tt.tl[i] * ENC_E0_ROW + 2 * tt.ff[i], g);
-#pragma unroll
-                for (int k = 0; k < 5; ++k) {
-                    const f32x4 tap = ld4(sE0 + e0 + k * 16);
-                    const f32x4 A = ld4(sP + E_EN1_A + k * 256 + n * 16 + 4 * g);
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) acc = mfma(A[q], tap[q], acc);
-                }
-                x[i] = prelu4(acc, a);
+                x[i] = prelu4(x[i], a);
                 {   // en1 in the slot order of its decoder consumer; scratch: this tile's records of F0/EB (dead)
                     const f32x4 y = permute_via_lds(sEB + tt.pp(i) * 16, ix, g, x[i]);
                     if (tt.pp(i) < nfr * 33) st4(en1 + (long)t0 * 528 + (unsigned)(tt.pp(i) * 16 + 4 * g), y);
                 }
-                __builtin_amdgcn_sched_barrier(0);
             }
         }
         wg_barrier();  // E0 is dead: its region becomes W
@@ -1335,53 +1338,61 @@ __global__ __launch_bounds__(NTHR) void k_decoder(const float* __restrict__ xg, 
             // even output 2m: k=0 <- x[m+1], k=2 <- x[m], k=4 <- x[m-1]; odd 2m+1: k=1 <- x[m+1], k=3 <- x[m]
             const float* Ae = sP + D_DE3_AE + n * 16 + 4 * g;
             const float* Ao = sP + D_DE3_AO + n * 16 + 4 * g;
+            // tap major over the three input bins f+1, f, f-1: the five slot matrices are read once per wave
+            f32x4 ae[TPW], ao[TPW];
+#pragma unroll
+            for (int i = 0; i < TPW; ++i) { ae[i] = Bv; ao[i] = Bv; }
+            {
+                const f32x4 A0 = ld4(Ae), A1 = ld4(Ao);
+#pragma unroll
+                for (int i = 0; i < TPW; ++i) {
+                    const f32x4 xp = ld4(sW + o35(tt, i, g) + 16);   // input bin f+1
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        ae[i] = mfma(A0[q], xp[q], ae[i]);
+                        ao[i] = mfma(A1[q], xp[q], ao[i]);
+                    }
+                }
+            }
+            {
+                const f32x4 A0 = ld4(Ae + 256), A1 = ld4(Ao + 256);
+#pragma unroll
+                for (int i = 0; i < TPW; ++i)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        ae[i] = mfma(A0[q], x[i][q], ae[i]);
+                        ao[i] = mfma(A1[q], x[i][q], ao[i]);
+                    }
+            }
+            {
+                const f32x4 A0 = ld4(Ae + 512);
+#pragma unroll
+                for (int i = 0; i < TPW; ++i) {
+                    const f32x4 xm = ld4(sW + o35(tt, i, g) - 16);   // input bin f-1
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) ae[i] = mfma(A0[q], xm[q], ae[i]);
+                }
+            }
+            const f32x4 A4 = ld4(sP + D_DE4_A + n * 16 + 4 * g);
 #pragma unroll
             for (int i = 0; i < TPW; ++i) {
-                const int b0 = o35(tt, i, g);
-                f32x4 ae = Bv, ao = Bv;
-                {
-                    const f32x4 xp = ld4(sW + b0 + 16);   // input bin f+1
-                    const f32x4 A0 = ld4(Ae), A1 = ld4(Ao);
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        ae = mfma(A0[q], xp[q], ae);
-                        ao = mfma(A1[q], xp[q], ao);
-                    }
-                }
-                {
-                    const f32x4 A0 = ld4(Ae + 256), A1 = ld4(Ao + 256);
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        ae = mfma(A0[q], x[i][q], ae);
-                        ao = mfma(A1[q], x[i][q], ao);
-                    }
-                }
-                {
-                    const f32x4 xm = ld4(sW + b0 - 16);   // input bin f-1
-                    const f32x4 A0 = ld4(Ae + 512);
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) ae = mfma(A0[q], xm[q], ae);
-                }
-                ae = prelu4(ae, a);
-                ao = prelu4(ao, a);
+                f32x4 e2 = prelu4(ae[i], a), o2 = prelu4(ao[i], a);
                 if (DBG && tt.pp(i) < npos) {
                     float* d3 = dbg + 3 * nbt * 528 + ((ob + t0 + tt.tl[i]) * F1) * 16 + 4 * g;
-                    st4(d3 + (2 * tt.ff[i]) * 16, ae);
-                    if (tt.ff[i] < 32) st4(d3 + (2 * tt.ff[i] + 1) * 16, ao);
+                    st4(d3 + (2 * tt.ff[i]) * 16, e2);
+                    if (tt.ff[i] < 32) st4(d3 + (2 * tt.ff[i] + 1) * 16, o2);
                 }
                 // + en_outs[0] (identity slot order), then de_convs.4 in scatter form
-                ae += s0e[i];
-                ao += s0o[i];
+                e2 += s0e[i];
+                o2 += s0o[i];
                 f32x4 e = splat(0.f), o = splat(0.f);
-                const f32x4 A4 = ld4(sP + D_DE4_A + n * 16 + 4 * g);
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    e = mfma(A4[q], ae[q], e);
-                    o = mfma(A4[q], ao[q], o);
+                    e = mfma(A4[q], e2[q], e);
+                    o = mfma(A4[q], o2[q], o);
                 }
                 ze[i] = e;
                 zo[i] = o;
-                __builtin_amdgcn_sched_barrier(0);
             }
         }
         wg_barrier();  // all taps of sW read: region A becomes Z[tl][65][16]
