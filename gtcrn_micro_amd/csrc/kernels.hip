@@ -491,13 +491,13 @@ __device__ __forceinline__ void gtconv_block(f32x4 (&x)[TPW], const Tiles<TPW>& 
             }
 #pragma unroll
             for (int i = 0; i < TPW; ++i) {
-                const f32x4 hd = prelu4(acc[i], a2);
-                f32x4 v = keep * x[i] + B2;
-#pragma unroll
-                for (int s = 0; s < 4; ++s) v = mfma(A2[s], hd[s], v);
-                x[i] = v;
-                st4(c.sS + tt.pp(i) * 16 + 4 * g, v * v);   // energies are reduced cooperatively after the barrier
+                acc[i] = prelu4(acc[i], a2);
+                x[i] = keep * x[i] + B2;
             }
+            mm16<TPW>(A2, acc, x);                            // point_conv2: the tiles' chains interleaved
+#pragma unroll
+            for (int i = 0; i < TPW; ++i)
+                st4(c.sS + tt.pp(i) * 16 + 4 * g, x[i] * x[i]);   // energies are reduced cooperatively after the barrier
         } else {
             // dense transposed 3x3, tap major: each of the nine 16x16 slot matrices is read from LDS once per wave
             // (not once per tile) and feeds one MFMA chain per tile -- TPW independent accumulator chains
@@ -526,13 +526,13 @@ __device__ __forceinline__ void gtconv_block(f32x4 (&x)[TPW], const Tiles<TPW>& 
             }
 #pragma unroll
             for (int i = 0; i < TPW; ++i) {
-                const f32x4 hd = prelu4(acc[i], a2);
-                f32x4 v = keep * x[i] + B2;
-#pragma unroll
-                for (int s = 0; s < 4; ++s) v = mfma(A2[s], hd[s], v);
-                x[i] = v;
-                st4(c.sS + tt.pp(i) * 16 + 4 * g, v * v);   // energies are reduced cooperatively after the barrier
+                acc[i] = prelu4(acc[i], a2);
+                x[i] = keep * x[i] + B2;
             }
+            mm16<TPW>(A2, acc, x);                            // point_conv2: the tiles' chains interleaved
+#pragma unroll
+            for (int i = 0; i < TPW; ++i)
+                st4(c.sS + tt.pp(i) * 16 + 4 * g, x[i] * x[i]);   // energies are reduced cooperatively after the barrier
         }
     }
     wg_barrier();
