@@ -799,7 +799,12 @@ __global__ __launch_bounds__(NTHR) void k_encoder(const float* __restrict__ spec
             const float w0 = sP[E_SFE_W + c * 3], w1 = sP[E_SFE_W + c * 3 + 1], w2 = sP[E_SFE_W + c * 3 + 2];
             const float* e = sEB + row * EB_ROW;
             float* d = sF0 + row * F0_ROW + 2;
-            for (int f = tv & 63; f < F0; f += 64) d[f] = w0 * e[f] + w1 * e[f + 1] + w2 * e[f + 2];
+            // 129 bins = 2 x 64 lanes + 1: the last bin rides on lane 0 instead of a third, nearly empty pass
+            static_assert(F0 == 129, "SFE lane mapping");
+            const int f = tv & 63;
+            d[f] = w0 * e[f] + w1 * e[f + 1] + w2 * e[f + 2];
+            d[f + 64] = w0 * e[f + 64] + w1 * e[f + 65] + w2 * e[f + 66];
+            if (f == 0) d[128] = w0 * e[128] + w1 * e[129] + w2 * e[130];
         }
         // zero the pad positions of E0 (columns 0,1,67,68 of each row): region A held the spectrogram
         if (tv < TC * 4 * 4) {
