@@ -366,8 +366,13 @@ class Engine:
                                         dst.size))
         return dst
 
-    def timing_enable(self, on=True):
-        _check(lib().gtcrn_timing_enable(self._h, int(bool(on))))
+    KERNELS = ("k_stft", "k_encoder", "k_gtcn1", "k_gtcn2", "k_decoder", "k_istft")
+
+    def timing_enable(self, on=True, only=None):
+        """HIP-event timing of the kernel launches; only="k_decoder" keeps the events of that kernel alone (an
+        event pair costs a few microseconds of dispatch gap per launch)."""
+        mode = 0 if not on else (1 if only is None else 2 + self.KERNELS.index(only))
+        _check(lib().gtcrn_timing_enable(self._h, mode))
 
     def timing_read(self):
         """{kernel name: (average ms, launches)} over the launches recorded since timing_enable(True)."""

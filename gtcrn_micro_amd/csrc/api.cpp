@@ -74,6 +74,7 @@ struct gtcrn_model {
     int stamps_cap_b = 0;
     float** d_ptr8 = nullptr;  // device table of 8 tcn cache pointers
     bool timing = false;
+    int timing_only = -1;          // >= 0: record events around this kernel only (two events per call)
     std::vector<Timing> timings;   // one entry per timed launch since gtcrn_timing_enable(m, 1)
     std::vector<Timing> ev_pool;   // recycled events
 };
@@ -126,8 +127,10 @@ struct Timer {
     gtcrn_model* m;
     hipStream_t s;
     Timer(gtcrn_model* m_, hipStream_t s_) : m(m_), s(s_) {}
+    bool on = false;
     void begin(int kernel) {
-        if (!m->timing) return;
+        on = m->timing && (m->timing_only < 0 || m->timing_only == kernel);
+        if (!on) return;
         Timing t;
         if (!m->ev_pool.empty()) {
             t = m->ev_pool.back();
@@ -141,7 +144,7 @@ struct Timer {
         m->timings.push_back(t);
     }
     void end() {
-        if (!m->timing) return;
+        if (!on) return;
         (void)hipEventRecord(m->timings.back().b, s);
     }
 };
@@ -609,6 +612,8 @@ int gtcrn_timing_enable(gtcrn_model* m, int on) {
     for (auto& t : m->timings) m->ev_pool.push_back(t);
     m->timings.clear();
     m->timing = on != 0;
+    m->timing_only = on >= 2 ? on - 2 : -1;
+    if (m->timing_only >= kNumKernels) return fail(GTCRN_ERR_ARG, "gtcrn_timing_enable: no such kernel index");
     return 0;
 }
 

@@ -155,7 +155,8 @@ int gtcrn_selftest_mfma(int device);
  * synchronisation inside the timed region).  gtcrn_timing_enable(m,1) clears the record;
  * gtcrn_timing_read returns, for kernel idx (0 k_stft, 1 k_encoder, 2 k_gtcn1, 3 k_gtcn2,
  * 4 k_decoder, 5 k_istft), the average device time in ms over the launches recorded since and
- * their count.  Used by bench.py for the roofline line. */
+ * their count.  on = 2 + idx records events around kernel idx ONLY: every event pair costs a few microseconds of
+ * dispatch gap, so the timed region of bench.py keeps just the dominant kernel's.  Used for the roofline line. */
 int gtcrn_timing_enable(gtcrn_model *m, int on);
 int gtcrn_timing_read(gtcrn_model *m, int idx, char *name, int name_cap, float *ms, int *launches);
 

@@ -46,3 +46,36 @@ def test_enhance_folder_matches_reference_example(tmp_path):
     os.remove(clean_dir / "clean_fileid_3.wav")
     with pytest.raises(FileNotFoundError):
         enhance_folder(str(noisy_dir), str(clean_dir), str(enh_dir), os.path.join(GOLDEN, "params_dns3.f32"))
+
+
+@pytest.mark.gpu
+def test_forward_wave_is_graph_capturable():
+    """gtcrn_model_reserve pre-sizes the workspace so that a whole wave -> wave call (six kernels, no allocation,
+    no synchronisation) can be captured into a HIP graph and replayed on new input."""
+    import numpy as np
+    import torch
+    from conftest import load_params
+    from gtcrn_micro_amd import Engine
+    eng = Engine(load_params("dns3"), 0)
+    B, L = 4, 256 * 40
+    win = torch.hann_window(512, device="cuda").pow(0.5)
+    wave = torch.randn(B, L, device="cuda") * 0.1
+    out = torch.empty(B, L, device="cuda")
+    eng.reserve(B, 1 + L // 256)
+    ref = eng.forward_wave(wave, win).clone()
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.stream(s):
+        eng.forward_wave(wave, win, out=out)          # warm-up on the capture stream
+        torch.cuda.synchronize()
+        with torch.cuda.graph(g, stream=s):
+            eng.forward_wave(wave, win, out=out)
+    out.zero_()
+    g.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(out, ref)
+    wave.copy_(torch.randn(B, L, device="cuda") * 0.1)   # same buffers, new content
+    g.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(out, eng.forward_wave(wave, win))
