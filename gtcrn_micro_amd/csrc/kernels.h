@@ -14,7 +14,8 @@ constexpr int NT2 = TC * 33 / 16;
 constexpr int TPW = NT2 / NW;
 // calls of at most SHORT_T frames (streaming steps) run the model kernels with ONE tile per wave: the first 11
 // tiles (176 positions) cover every valid position of up to 5 frames, so two thirds of the tile work is skipped
-constexpr int SHORT_T = (NW * 16) / 33;
+constexpr int SHORT_T = (NW * 16) / 33;           // 5 frames: one tile per wave
+constexpr int SHORT_T2 = (2 * NW * 16) / 33;      // 10 frames: two tiles per wave
 static_assert(TC * 33 % 16 == 0, "chunk must be a whole number of tiles");
 static_assert(NT2 % NW == 0, "tiles must divide evenly over the waves");
 

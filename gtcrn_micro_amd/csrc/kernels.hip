@@ -1663,8 +1663,12 @@ int configure_kernels() {
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_encoder<1>), hipFuncAttributeMaxDynamicSharedMemorySize,
                             ENC_LDS_FLOATS * 4);
     if (e != hipSuccess) return (int)e;
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_encoder<2>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            ENC_LDS_FLOATS * 4);
+    if (e != hipSuccess) return (int)e;
     const void* gt[] = {reinterpret_cast<const void*>(k_gtcn<TPW, false>), reinterpret_cast<const void*>(k_gtcn<1, false>),
-                        reinterpret_cast<const void*>(k_gtcn<1, true>)};
+                        reinterpret_cast<const void*>(k_gtcn<1, true>), reinterpret_cast<const void*>(k_gtcn<TPW, true>),
+                        reinterpret_cast<const void*>(k_gtcn<2, true>), reinterpret_cast<const void*>(k_gtcn<2, false>)};
     for (const void* f : gt) {
         e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, GT_LDS_FLOATS * 4);
         if (e != hipSuccess) return (int)e;
@@ -1675,7 +1679,9 @@ int configure_kernels() {
     const void* dec[] = {reinterpret_cast<const void*>(k_decoder<false, TPW>),
                          reinterpret_cast<const void*>(k_decoder<true, TPW>),
                          reinterpret_cast<const void*>(k_decoder<false, 1>),
-                         reinterpret_cast<const void*>(k_decoder<true, 1>)};
+                         reinterpret_cast<const void*>(k_decoder<true, 1>),
+                         reinterpret_cast<const void*>(k_decoder<false, 2>),
+                         reinterpret_cast<const void*>(k_decoder<true, 2>)};
     for (const void* f : dec) {
         e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, DEC_LDS_FLOATS * 4);
         if (e != hipSuccess) return (int)e;
@@ -1688,6 +1694,9 @@ int launch_encoder(const float* spec, long sb, long sf, long st, int B, int T, c
                    unsigned long long* stamps, hipStream_t s) {
     if (T <= SHORT_T)
         hipLaunchKernelGGL(k_encoder<1>, dim3(B), dim3(NTHR), ENC_LDS_FLOATS * 4, s, spec, sb, sf, st, T, PF, PI, en0,
+                           en1, en2, en3, en4, state, stamps);
+    else if (T <= SHORT_T2)
+        hipLaunchKernelGGL(k_encoder<2>, dim3(B), dim3(NTHR), ENC_LDS_FLOATS * 4, s, spec, sb, sf, st, T, PF, PI, en0,
                            en1, en2, en3, en4, state, stamps);
     else
         hipLaunchKernelGGL(k_encoder<TPW>, dim3(B), dim3(NTHR), ENC_LDS_FLOATS * 4, s, spec, sb, sf, st, T, PF, PI,
@@ -1704,6 +1713,15 @@ int launch_gtcn(const float* xin, float* xout, const float* P, int B, int T, flo
     else if (T <= SHORT_T)
         hipLaunchKernelGGL((k_gtcn<1, false>), dim3(B), dim3(NTHR), GT_LDS_FLOATS * 4, s, xin, xout, P, T, state,
                            st_off, addend, stamps);
+    else if (T <= SHORT_T2 && state)
+        hipLaunchKernelGGL((k_gtcn<2, true>), dim3(B), dim3(NTHR), GT_LDS_H * 4, s, xin, xout, P, T, state, st_off,
+                           addend, stamps);
+    else if (T <= SHORT_T2)
+        hipLaunchKernelGGL((k_gtcn<2, false>), dim3(B), dim3(NTHR), GT_LDS_FLOATS * 4, s, xin, xout, P, T, state,
+                           st_off, addend, stamps);
+    else if (T <= TC && state)   // one-chunk streaming call: the ring copy through LDS would cost more than it saves
+        hipLaunchKernelGGL((k_gtcn<TPW, true>), dim3(B), dim3(NTHR), GT_LDS_H * 4, s, xin, xout, P, T, state, st_off,
+                           addend, stamps);
     else
         hipLaunchKernelGGL((k_gtcn<TPW, false>), dim3(B), dim3(NTHR), GT_LDS_FLOATS * 4, s, xin, xout, P, T, state,
                            st_off, addend, stamps);
@@ -1726,6 +1744,8 @@ int launch_decoder(const float* xg, const float* en0, const float* en1, const fl
                        en4, spec, sb, sf, st, out, osb, osf, ost, T, PF, PI, state, dbg, stamps)
     if (T <= SHORT_T) {
         if (dbg) GT_DEC(true, 1); else GT_DEC(false, 1);
+    } else if (T <= SHORT_T2) {
+        if (dbg) GT_DEC(true, 2); else GT_DEC(false, 2);
     } else {
         if (dbg) GT_DEC(true, TPW); else GT_DEC(false, TPW);
     }
