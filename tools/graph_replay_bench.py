@@ -1,3 +1,5 @@
+#!/usr/bin/env python3
+"""Diagnostic (GPU box): one wave->wave step (B=256 x 4 s) as six plain launches vs the replay of a captured HIP graph."""
 import sys, time, numpy as np, torch
 sys.path.insert(0, '/root/repo')
 from gtcrn_micro_amd import Engine
