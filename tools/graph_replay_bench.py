@@ -1,9 +1,12 @@
 #!/usr/bin/env python3
 """Diagnostic (GPU box): one wave->wave step (B=256 x 4 s) as six plain launches vs the replay of a captured HIP graph."""
-import sys, time, numpy as np, torch
-sys.path.insert(0, '/root/repo')
+import os, sys, time
+import numpy as np
+import torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
 from gtcrn_micro_amd import Engine
-params = np.fromfile('/root/repo/tests/golden/params_dns3.f32', dtype=np.float32)
+params = np.fromfile(os.path.join(ROOT, 'tests', 'golden', 'params_dns3.f32'), dtype=np.float32)
 eng = Engine(params, 0)
 B, L = 256, 64000
 win = torch.hann_window(512, device='cuda').pow(0.5)
