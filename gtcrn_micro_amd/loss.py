@@ -44,9 +44,13 @@ class HybridLoss(nn.Module):
         self.register_buffer("window", torch.hann_window(512).pow(0.5), persistent=False)
 
     def forward(self, pred_stft, true_stft):
-        if pred_stft.is_cuda and pred_stft.dtype == torch.float32 and not true_stft.requires_grad \
+        if not pred_stft.is_cuda:
+            raise _lib.GtcrnError("HybridLoss needs CUDA (ROCm) tensors: this implementation has no CPU path")
+        if pred_stft.dtype == torch.float32 and not true_stft.requires_grad \
                 and 2 <= pred_stft.shape[2] and pred_stft.shape[0] <= 1024:
             return _FusedHybridLoss.apply(pred_stft, true_stft)
+        # shapes the fused kernels do not take (more than 1024 utterances, a gradient w.r.t. the target): the same
+        # loss as torch ops on the GPU
         return self.forward_torch(pred_stft, true_stft)
 
     def forward_torch(self, pred_stft, true_stft):
