@@ -70,9 +70,19 @@ def test_no_gpu_means_loud_failure():
     import torch
     if torch.cuda.is_available():
         pytest.skip("GPU present")
-    from gtcrn_micro_amd import Engine, GtcrnError
+    from gtcrn_micro_amd import Engine, GtcrnError, Trainer
     with pytest.raises(GtcrnError):
         Engine(load_params("dns3"), 0)
+    with pytest.raises(GtcrnError):
+        Trainer(0)                                   # the training path has no CPU fallback either
+
+
+def test_loss_mirror_has_no_cpu_path():
+    import torch
+    from gtcrn_micro_amd import GtcrnError
+    from gtcrn_micro_amd.loss import HybridLoss
+    with pytest.raises(GtcrnError):
+        HybridLoss()(torch.zeros(1, 257, 4, 2), torch.zeros(1, 257, 4, 2))
 
 
 def test_product_does_not_import_oracle():
