@@ -2,12 +2,12 @@
 """Diagnostic (GPU box): accuracy of the eval-mode forward against the SAME graph evaluated in float64
 (oracle/torch_port.py, dtype=float64), next to the reference's own fp32 result stored in the fixtures.
 
-    python tools/infer_accuracy_report.py
+    python tests/reports/infer_accuracy_report.py
 """
 import os, sys
 import numpy as np
 import torch
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from gtcrn_micro_amd import Engine
 from oracle.torch_port import TorchPort

@@ -2,13 +2,14 @@
 """Diagnostic (GPU box): per-stage forward errors and the worst per-tensor gradient errors of the HIP training
 path against the reference fixtures, and against the float64 truth (oracle/torch_port.py in double).
 
-    python tools/train_parity_report.py
+    python tests/reports/train_parity_report.py
 """
 import os, sys, numpy as np, torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
 import gtcrn_micro_amd as G
 import gtcrn_micro_amd._lib as L
-GOLD = "tests/golden"
+GOLD = os.path.join(ROOT, "tests", "golden")
 tr = G.Trainer(0)
 for tag in ("rand", "dns3"):
     g = np.load(f"{GOLD}/trainstep_{tag}_B3_T12.npz")
