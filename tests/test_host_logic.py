@@ -87,13 +87,13 @@ def test_loss_mirror_has_no_cpu_path():
 
 def test_product_does_not_import_oracle():
     """Only tests/, smoke() and bench.py's cpu_baseline may touch oracle/."""
-    pkg = os.path.join(ROOT, "gtcrn_micro_amd")
     pat = re.compile(r"^\s*(from|import)\s+oracle|#include\s+\".*oracle|libgtcrn_oracle|oracle\.py", re.M)
-    for dp, _, fs in os.walk(pkg):
-        for f in fs:
-            if f.endswith((".py", ".cpp", ".hip", ".h")):
-                txt = open(os.path.join(dp, f)).read()
-                assert not pat.search(txt), os.path.join(dp, f)
+    for top in ("gtcrn_micro_amd", "tools", "include"):
+        for dp, _, fs in os.walk(os.path.join(ROOT, top)):
+            for f in fs:
+                if f.endswith((".py", ".cpp", ".hip", ".h", ".sh")):
+                    txt = open(os.path.join(dp, f)).read()
+                    assert not pat.search(txt), os.path.join(dp, f)
 
 
 @pytest.mark.parametrize("tag", ["dns3", "rand"])
