@@ -151,3 +151,22 @@ def test_checkpoint_dict_round_trip(tmp_path):
     ck["model"] = {"module." + k: v for k, v in ck["model"].items()}
     torch.save(ck, path)
     assert load_checkpoint(path, GTCRNMicro()) == 8
+
+
+def test_packer_under_address_and_ub_sanitizers(tmp_path):
+    """csrc/pack.cpp (the only non-trivial host arithmetic of the product) runs clean under ASan + UBSan."""
+    import shutil
+    import subprocess
+    cxx = shutil.which("g++")
+    if cxx is None:
+        pytest.skip("no g++")
+    exe = str(tmp_path / "asan_pack_driver")
+    csrc = os.path.join(ROOT, "gtcrn_micro_amd", "csrc")
+    r = subprocess.run([cxx, "-O1", "-g", "-std=c++17", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined",
+                        "-I", csrc, "-o", exe, os.path.join(ROOT, "tests", "asan_pack_driver.cpp"),
+                        os.path.join(csrc, "pack.cpp")], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    for tag in ("dns3", "rand"):
+        r = subprocess.run([exe, os.path.join(ROOT, "tests", "golden", f"params_{tag}.f32")], capture_output=True,
+                           text=True, timeout=300)
+        assert r.returncode == 0 and "asan_pack_driver ok" in r.stdout, (r.returncode, r.stderr[-3000:])

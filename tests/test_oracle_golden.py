@@ -200,3 +200,24 @@ def test_port_train_step_matches_reference(tag):
     for k in ("en0", "en1", "en2", "en4", "gtcn1", "gtcn2", "de0", "de2", "de3", "de4"):
         ref = g["stage:" + k]
         assert np.abs(taps[k].numpy() - ref).max() / np.abs(ref).max() < 1e-4, k
+
+
+def test_oracle_under_address_and_ub_sanitizers(tmp_path):
+    """The C restatement runs clean under ASan + UBSan (CPU build; GPU sanitizers are not available on the pool)."""
+    import os
+    import shutil
+    import subprocess
+    from conftest import GOLDEN, ROOT
+    cc = shutil.which("gcc")
+    if cc is None:
+        pytest.skip("no gcc")
+    exe = str(tmp_path / "asan_driver")
+    src = [os.path.join(ROOT, "oracle", "asan_driver.c"), os.path.join(ROOT, "oracle", "gtcrn_oracle.c")]
+    r = subprocess.run([cc, "-O1", "-g", "-std=c11", "-D_GNU_SOURCE", "-fsanitize=address,undefined",
+                        "-fno-sanitize-recover=undefined", "-fopenmp", "-I", os.path.join(ROOT, "oracle"), "-o", exe]
+                       + src + ["-lm"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=0", OMP_NUM_THREADS="2")
+    r = subprocess.run([exe, os.path.join(GOLDEN, "params_dns3.f32")], capture_output=True, text=True, timeout=600,
+                       env=env)
+    assert r.returncode == 0 and "asan_driver ok" in r.stdout, (r.returncode, r.stdout[-500:], r.stderr[-3000:])
