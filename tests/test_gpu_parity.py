@@ -115,7 +115,7 @@ def test_forward_batch_and_wave(dev, engines):
     assert torch.equal(fm_out, out)
 
 
-@pytest.mark.parametrize("T", [1, 2, 15, 16, 17, 33, 251])
+@pytest.mark.parametrize("T", [1, 2, 5, 6, 10, 11, 15, 16, 17, 33, 251])   # 5/6 and 10/11: tiles-per-wave switch
 def test_forward_lengths_vs_oracle(dev, engines, oracles, T):
     rng = np.random.default_rng(T)
     spec = (rng.standard_normal((2, 257, T, 2)) * 0.5).astype(np.float32)
@@ -201,3 +201,14 @@ def test_no_dependence_on_stale_memory(dev, engines, oracles):
         got = eng.forward_spec(cu(spec)).cpu().numpy()
         assert np.isfinite(got).all(), T
         assert rel_err(got, oracles["rand"].forward(spec)) < TOL, T
+
+
+def test_extreme_inputs_stay_finite_and_match_oracle(dev, engines, oracles):
+    """Digital silence (the 1e-12 inside the magnitude, zero energies in the TRA gates) and full-scale input."""
+    for amp in (0.0, 30.0):
+        rng = np.random.default_rng(3)
+        spec = (rng.standard_normal((2, 257, 19, 2)) * amp).astype(np.float32)
+        got = engines["dns3"].forward_spec(cu(spec)).cpu().numpy()
+        want = oracles["dns3"].forward(spec)
+        assert np.isfinite(got).all()
+        assert np.abs(got - want).max() <= TOL * max(np.abs(want).max(), 1e-30) + 1e-30
