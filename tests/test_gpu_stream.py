@@ -83,13 +83,16 @@ def test_chunked_equals_offline_many_streams(dev):
     N, T = 64, 50
     spec = cu((rng.standard_normal((N, 257, T, 2)) * 0.3).astype(np.float32))
     full = eng.forward_spec(spec)
-    for chunks in ([1] * 50, [7, 16, 16, 11], [33, 17], [3, 1, 2, 44]):
+    # every kernel instantiation: one / two / three tiles per wave (calls of <= 5, <= 10, more frames), rings in the
+    # stream state (one-chunk calls) or copied through LDS (longer calls)
+    for chunks in ([1] * 50, [7, 16, 16, 11], [33, 17], [3, 1, 2, 44], [5, 6, 10, 11, 4, 14], [2] * 25, [9, 10, 15, 16]):
         st = eng.new_state(N)
         t0, outs = 0, []
         for c in chunks:
             outs.append(eng.stream_step(st, spec[:, :, t0:t0 + c]))
             t0 += c
         got = torch.cat(outs, 2)
+        assert t0 == T
         assert rel_err(got.cpu().numpy(), full.cpu().numpy()) < 2e-5, chunks
 
 
