@@ -5,58 +5,129 @@ Metric (BASELINE.json): 16 kHz frames/s through STFT -> mask -> iSTFT.
 Workload (BASELINE.json configs[1]): batch of 256 four-second 16 kHz clips per GPU, fp32,
 offline forward, wave -> wave (the caller loop of infer.py:60-76), synthetic N(0, 0.1^2) input
 already resident in HBM, shipped checkpoint weights (tests/golden/params_dns3.f32).
-One "step" = one pass of the six kernels over the batch = 256 x 251 = 64 256 frames per GPU.
+One "step" = one pass of the fused kernels over the batch = 256 x 251 = 64 256 frames per GPU.
 
-    python bench.py --gpus 1 --steps 50 --warmup 10
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
-        --master-port P bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W
 
-Multi-GPU: utterances are independent, so every rank runs its own 256-clip shard on its own
-GPU with no data-path collective (weak scaling); torch.distributed (RCCL) is used only for the
-barrier and the max-over-ranks of the elapsed time.
+With N > 1 and no WORLD_SIZE in the environment the script starts its own N ranks (one process per GPU,
+`python -m torch.distributed.run` on 127.0.0.1, like the reference's own mp.spawn, train.py:461-471) BEFORE
+anything in this process touches the GPU, relays rank 0's JSON line and exits non-zero if a rank fails or
+the line does not say n_gpus == N.  Launched under an external torchrun it reads RANK/LOCAL_RANK/WORLD_SIZE
+and refuses (non-zero exit) a WORLD_SIZE that differs from --gpus.
 
-The JSON line also carries
-  roofline     for the dominant kernel (k_decoder): algorithmic fp32 FLOPs per launch / average
-               launch duration from HIP events recorded inside the timed region, against the
-               dense fp32 MFMA peak (157.3 TFLOP/s, MI355X_MICROARCH.md); `traffic` = HBM bytes per
-               launch from the committed rocprofv3 PMC run when profiles/ has it, else null
-  cpu_baseline the PyTorch-CPU port of the path (oracle/torch_port.py, the reference's own ATen
-               op sequence) timed on this box's host cores on a bounded sample.
+Multi-GPU: utterances are independent, so every rank runs its own 256-clip shard on its own GPU with no
+data-path collective (weak scaling); torch.distributed (RCCL) is used only for the barrier and the
+max-over-ranks of the elapsed time.
+
+Besides the headline fields the JSON line carries
+  roofline      the dominant kernel: algorithmic fp32 FLOPs per launch / average launch duration from HIP
+                events recorded on the launch stream inside the timed region, against the dense fp32 MFMA
+                peak (157.3 TFLOP/s, MI355X_MICROARCH.md); `traffic` = HBM bytes per launch from the
+                committed rocprofv3 PMC run of this round when profiles/ has it, else null
+  cpu_baseline  the PyTorch-CPU port of the path (oracle/torch_port.py, the reference's own ATen op
+                sequence) timed on this box's host cores on a bounded sample (rank 0, N = 1 only)
+  stream        BASELINE configs[2]: 1024 concurrent streams per GPU, one 16 ms frame per call, state
+                resident on the device: per-call latency mean/p50/p99, RTF, frame-steps/s, fraction of the
+                94 KB/frame-stream state-traffic bound
+  train         BASELINE configs[3]: full train steps at B=512 clips per GPU (STFT x2, train-mode forward,
+                HybridLoss, backward, ONE gradient all-reduce over RCCL when N > 1, clip, Adam)
+  quant         BASELINE configs[4]: the int8-weight / fp16-activation variant when the library has it
+These secondary legs run AFTER the headline timed region and never change the headline fields.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-# algorithmic multiply-accumulates per frame, per kernel (DESIGN.md section 5; SURVEY.md 2a with the
+# algorithmic multiply-accumulates per frame, per kernel (DESIGN.md section 4; SURVEY.md 2a with the
 # ERB filterbank counted sparse as it is computed): 1 MAC = 2 FLOP
+MAC_FRONT = 1146 + 1161 + 15600 + 42240                  # ERB.bm, SFE, en_conv0, en_conv1
+MAC_GT_ENC = 13288                                       # one encoder GTConvBlock (+TRA)
 MAC_PER_FRAME = {
-    "k_encoder": 1146 + 1161 + 15600 + 42240 + 3 * 13288,
+    "k_front": MAC_FRONT,                                # round 2: STFT + front end fused (frames stay in LDS)
+    "k_encoder": MAC_FRONT + 3 * MAC_GT_ENC,             # round 1 form (front end inside the encoder)
+    "k_encoder_gt": 3 * MAC_GT_ENC,
     "k_gtcn1": 73920,
     "k_gtcn2": 73920,
     "k_decoder": 3 * 84602 + 42240 + 10400 + 764 + 1028,
 }
+# MFMA instructions (16x16x4 f32 = 2 048 FLOP each) issued per frame, incl. the zero padding of the 8->16 /
+# 16->8 pointwise and K=15 tiles (DESIGN.md section 4): executed vs algorithmic matrix work
+MFMA_PER_FRAME = {"k_encoder": 107, "k_gtcn1": 66, "k_gtcn2": 66, "k_decoder": 330}
+MODEL_MAC_PER_FRAME = MAC_FRONT + 3 * MAC_GT_ENC + 2 * 73920 + MAC_PER_FRAME["k_decoder"]
 FFT_FLOP_PER_FRAME = 2 * 11520 + 6000          # 512-point rFFT + irFFT (5 N log2 N / 2) + window/OLA
 FP32_MFMA_PEAK_TFLOPS = 157.3                   # MI355X_MICROARCH.md, dense, v_mfma_f32_16x16x4_f32
 HBM_PEAK_GBS = 8000.0
+STREAM_STATE_BYTES_PER_FRAME = 94 * 1024        # SURVEY.md 8d: ring-state traffic + the frame itself
+TRAIN_BYTES_PER_FRAME = 1.46e6                  # DESIGN.md section 8: layer-at-a-time fp32 passes
+ROUND_TAG = "r02"
 
 
-def cpu_baseline(params, seconds_budget=12.0):
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def self_launch(args, argv):
+    """--gpus N > 1 without a launcher: start N ranks as children (nothing in this process has imported torch
+    or touched the GPU), relay their output, insist on one JSON line with n_gpus == N."""
+    env = dict(os.environ)
+    env.setdefault("MASTER_ADDR", "127.0.0.1")
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "8")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + argv
+    p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    sys.stdout.write(p.stdout)
+    sys.stdout.flush()
+    if p.returncode != 0:
+        print(f"bench.py: a rank failed (launcher exit code {p.returncode})", file=sys.stderr)
+        return p.returncode or 1
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{") and '"metric"' in l]
+    if len(lines) != 1:
+        print(f"bench.py: expected one JSON line from rank 0, got {len(lines)}", file=sys.stderr)
+        return 1
+    if json.loads(lines[0]).get("n_gpus") != args.gpus:
+        print(f"bench.py: the line says n_gpus={json.loads(lines[0]).get('n_gpus')} but --gpus {args.gpus}",
+              file=sys.stderr)
+        return 1
+    return 0
+
+
+def _load_shim():
+    """TEST ONLY: tests/test_dist_gloo.py points GTCRN_BENCH_TEST_SHIM at a module that supplies a stand-in
+    engine so the multi-rank control flow can run on CPU over gloo.  bench.py itself holds no fake engine."""
+    path = os.environ.get("GTCRN_BENCH_TEST_SHIM")
+    if not path:
+        return None
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("gtcrn_bench_test_shim", path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def cpu_baseline(params, seconds_per_candidate=3.0):
     """The reference's CPU arithmetic (ATen) on a bounded sample of the same workload.
 
-    The thread count matters a lot for this 19 k-parameter model (128 threads on a 256-core host
-    are slower than 16), so a short sweep picks the best one first; `cores` reports what was used."""
+    The thread count matters a lot for this 19 k-parameter model (128 threads on a 256-core host are slower
+    than 16), so every candidate gets a >= 3 s run at B=16 and the best one is reported; the utterance-at-a-time
+    shape of infer.py (B=1) is swept and reported separately."""
     import torch
     from oracle.torch_port import TorchPort
     port = TorchPort(params)
     win = torch.hann_window(512).pow(0.5)
     g = torch.Generator().manual_seed(43)
-    B = 16
-    x = torch.randn(B, 64000, generator=g) * 0.1
+    x = torch.randn(16, 64000, generator=g) * 0.1
     default_threads = torch.get_num_threads()
 
     def rate(seconds, xin):
@@ -66,96 +137,177 @@ def cpu_baseline(params, seconds_budget=12.0):
             port.enhance(xin, win)
             n += 1
             el = time.perf_counter() - t0
-            if el >= seconds or n >= 400:
+            if el >= seconds:
                 return n * xin.shape[0] * 251 / el, n, el
 
-    sweep = {}
-    for th in sorted({1, 4, 8, 16, 32, 64, default_threads}):
-        if th > (os.cpu_count() or 1):
-            continue
+    cands = [th for th in (1, 8, 16, 32) if th <= (os.cpu_count() or 1)]
+    sweep16, sweep1, passes = {}, {}, {}
+    for th in cands:
         torch.set_num_threads(th)
-        sweep[th] = rate(1.0, x)[0]
-    best = max(sweep, key=sweep.get)
-    torch.set_num_threads(best)
-    fps, n, el = rate(seconds_budget, x)
-    fps_b1 = rate(2.0, x[:1])[0]                           # the infer.py shape: one utterance at a time
+        sweep16[th], n, el = rate(seconds_per_candidate, x)
+        passes[th] = (n, el)
+        sweep1[th] = rate(seconds_per_candidate / 2, x[:1])[0]
     torch.set_num_threads(default_threads)
+    best16 = max(sweep16, key=sweep16.get)
+    best1 = max(sweep1, key=sweep1.get)
+    n, el = passes[best16]
     return {
-        "value": round(max(fps, fps_b1), 1), "unit": "frames/s", "cores": int(best), "kind": "port",
+        "value": round(sweep16[best16], 1), "unit": "frames/s", "cores": int(best16), "kind": "port",
         "sample": f"{n} passes of 16 four-second clips (B=16, {el:.1f} s) through oracle/torch_port.py "
-                  f"(PyTorch {torch.__version__} CPU, the reference's ATen op sequence) at the best of "
-                  f"{sorted(sweep)} threads; utterance-at-a-time (B=1, infer.py style): {fps_b1:.0f} frames/s",
-        "thread_sweep_fps": {str(k): round(v) for k, v in sweep.items()},
+                  f"(PyTorch {torch.__version__} CPU, the reference's ATen op sequence) at {best16} threads, the "
+                  f"best of {cands} (>= {seconds_per_candidate:g} s each)",
+        "b1_infer_py_style": {"value": round(sweep1[best1], 1), "cores": int(best1),
+                              "sample": "one four-second clip per call (infer.py:48-107)"},
+        "thread_sweep_b16_fps": {str(k): round(v) for k, v in sweep16.items()},
+        "thread_sweep_b1_fps": {str(k): round(v) for k, v in sweep1.items()},
         "host_cpus": os.cpu_count(),
     }
 
 
+def stream_leg(eng, world, sync_all, max_over_ranks, nstreams=1024, frames=251):
+    """BASELINE configs[2]: `nstreams` concurrent streams per GPU, one frame per call (the loop of
+    gtcrn_micro_stream.py:626-635 with the state left on the device)."""
+    import numpy as np
+    import torch
+    N, T = nstreams, frames
+    torch.manual_seed(44)
+    spec = (torch.randn(N, T, 257, 2, device="cuda") * 0.3).permute(0, 2, 1, 3)   # frame-major storage
+    out = torch.empty((N, T, 257, 2), device="cuda").permute(0, 2, 1, 3)
+    eng.reserve(N, 1)
+    state = eng.new_state(N)
+    for t in range(8):
+        eng.stream_step(state, spec[:, :, t:t + 1], out=out[:, :, t:t + 1])
+    state = eng.new_state(N)
+    sync_all()
+    lat = []
+    for t in range(T):                                            # latency: one call, wait for it
+        t0 = time.perf_counter()
+        eng.stream_step(state, spec[:, :, t:t + 1], out=out[:, :, t:t + 1])
+        torch.cuda.synchronize()
+        lat.append(time.perf_counter() - t0)
+    lat = np.array(lat) * 1e3
+    full = eng.forward_spec(spec.contiguous())
+    err = float((full - out).abs().max() / full.abs().max())
+    state = eng.new_state(N)
+    sync_all()
+    t0 = time.perf_counter()
+    for t in range(T):                                            # throughput: calls queued back to back
+        eng.stream_step(state, spec[:, :, t:t + 1], out=out[:, :, t:t + 1])
+    sync_all()
+    el = max_over_ranks(time.perf_counter() - t0, "cuda")
+    fsteps = world * N * T / el
+    res = {
+        "workload": f"{N} concurrent streams per GPU x {T} single-frame calls (hop 256), state resident in HBM",
+        "streams_per_gpu": N, "calls": T,
+        "latency_ms": {"mean": round(float(lat.mean()), 4), "p50": round(float(np.percentile(lat, 50)), 4),
+                       "p99": round(float(np.percentile(lat, 99)), 4), "max": round(float(lat.max()), 4)},
+        "rtf_per_stream": round(float(lat.mean()) / 16.0, 6),
+        "frame_steps_per_s": round(fsteps, 1),
+        "ms_per_call_back_to_back": round(el / T * 1e3, 4),
+        "state_bound_frame_steps_per_s": round(HBM_PEAK_GBS * 1e9 / STREAM_STATE_BYTES_PER_FRAME, 1),
+        "frac_of_state_bound": round(fsteps / world / (HBM_PEAK_GBS * 1e9 / STREAM_STATE_BYTES_PER_FRAME), 4),
+        "stream_vs_offline_rel_err": err, "dtype": "f32",
+    }
+    del spec, out, state, full
+    torch.cuda.empty_cache()
+    return res
+
+
+def train_leg(rank, world, sync_all, max_over_ranks, B=512, seconds=4.0, steps=5, warmup=2, storage="f32"):
+    """BASELINE configs[3]: full train steps, data parallel over utterance shards with ONE collective per step."""
+    import torch
+    import gtcrn_micro_amd as G
+    from gtcrn_micro_amd.train import make_training, synthetic_mix, train_step
+    L = int(seconds * 16000)
+    T = 1 + L // 256
+    torch.manual_seed(43)                                     # identical initial weights on every rank
+    model, opt, sched, loss_func = make_training(device="cuda")
+    model.train()
+    if storage != "f32":
+        model.set_activation_storage(storage)
+    noisy, clean = synthetic_mix(B, samples=L, seed=43 + rank)
+    for _ in range(warmup):
+        train_step(model, opt, sched, loss_func, noisy, clean, world_size=world)
+    sync_all()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        loss, gn = train_step(model, opt, sched, loss_func, noisy, clean, world_size=world)
+    sync_all()
+    el = max_over_ranks(time.perf_counter() - t0, "cuda") / steps
+    ws = G.Trainer.workspace_bytes(B, T, storage) if storage != "f32" else G.Trainer.workspace_bytes(B, T)
+    byte_scale = 1.0 if storage == "f32" else 0.5
+    res = {
+        "workload": f"train step, B={B} clips/GPU x {seconds:g} s (T={T}), saved activations {storage}, fp32 "
+                    "accumulate + master weights, Adam, clip 3.0, synthetic DNS-style mixes",
+        "parallelism": f"dp{world}: utterance shards + one all-reduce of the gradient buffer per step",
+        "ms_per_step": round(el * 1e3, 3), "frames_per_s": round(world * B * T / el, 1),
+        "steps": steps, "warmup": warmup, "dtype": storage,
+        "algorithmic_TB_per_s": round(TRAIN_BYTES_PER_FRAME * byte_scale * B * T / el / 1e12, 3),
+        "workspace_GB": round(ws / 2 ** 30, 2), "loss": float(loss), "grad_norm": float(gn),
+    }
+    del model, opt, sched, noisy, clean
+    torch.cuda.empty_cache()
+    return res
+
+
 def train_main(args):
-    """Secondary line (not the headline metric): train-step throughput, data parallel over utterance shards
-    with ONE collective per step, the all-reduce of the 19 014 gradient floats (RCCL over xGMI)."""
+    """`--mode train`: only the train-step line (not the headline metric)."""
     import torch
     import torch.distributed as dist
     from gtcrn_micro_amd.sharding import init_distributed, max_over_ranks
     rank, local_rank, world = init_distributed(None)
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     torch.cuda.set_device(local_rank)
     import __graft_entry__ as graft
     if rank == 0:
         graft.build()
     if world > 1:
         dist.barrier()
-    import gtcrn_micro_amd as G
-    from gtcrn_micro_amd.train import make_training, synthetic_mix, train_step
-    B = args.batch if args.batch != 256 else 512          # config 4: 512 clips per GPU
-    L = int(args.seconds * 16000)
-    T = 1 + L // 256
-    torch.manual_seed(43)                                     # identical initial weights on every rank
-    model, opt, sched, loss_func = make_training(device="cuda")
-    model.train()
-    noisy, clean = synthetic_mix(B, samples=L, seed=43 + rank)
 
     def sync_all():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
-    for _ in range(args.warmup):
-        train_step(model, opt, sched, loss_func, noisy, clean, world_size=world)
-    sync_all()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        loss, gn = train_step(model, opt, sched, loss_func, noisy, clean, world_size=world)
-    sync_all()
-    elapsed = max_over_ranks(time.perf_counter() - t0, "cuda")
+    B = args.batch if args.batch is not None else 512         # configs[3]: 512 clips per GPU
+    r = train_leg(rank, world, sync_all, max_over_ranks, B=B, seconds=args.seconds, steps=args.steps,
+                  warmup=args.warmup, storage=args.train_storage)
     if rank == 0:
         print(json.dumps({
             "metric": "train frames/sec (STFT x2 -> forward -> HybridLoss -> backward -> all-reduce -> clip -> Adam)",
-            "value": round(world * B * T * args.steps / elapsed, 1), "unit": "frames/s", "n_gpus": world,
-            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
-            "data": "synthetic DNS-style mixes",
-            "config": {"workload": f"train step, B={B} clips/GPU x {args.seconds:g} s (T={T}), fp32, Adam, clip 3.0",
-                       "parallelism": f"dp{world}: utterance shards + one all-reduce of 19 014 gradient floats per step"},
-            "workspace_GB": round(G.Trainer.workspace_bytes(B, T) / 2 ** 30, 2),
-            "loss": float(loss), "grad_norm": float(gn)}), flush=True)
+            "value": r["frames_per_s"], "unit": "frames/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": r["ms_per_step"], "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": r["dtype"], "data": "synthetic DNS-style mixes",
+            "config": {"workload": r["workload"], "parallelism": r["parallelism"]},
+            "workspace_GB": r["workspace_GB"], "algorithmic_TB_per_s": r["algorithmic_TB_per_s"],
+            "loss": r["loss"], "grad_norm": r["grad_norm"]}), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+    return 0
 
 
-def main():
+def main(argv=None):
+    argv = list(sys.argv[1:] if argv is None else argv)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--batch", type=int, default=256, help="clips per GPU (BASELINE config 2: 256)")
+    ap.add_argument("--batch", type=int, default=None,
+                    help="clips per GPU (default: 256 for the headline, configs[1]; 512 for --mode train, configs[3])")
     ap.add_argument("--seconds", type=float, default=4.0, help="clip length")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true",
+                    help="skip the stream/train/quant legs (profiling runs of the headline path)")
     ap.add_argument("--mode", choices=["infer", "train"], default="infer",
-                    help="infer (default): the headline metric.  train: BASELINE config 4's shape -- full train steps "
-                         "(STFT x2, train-mode forward, HybridLoss, backward, gradient all-reduce, clip, Adam), fp32")
-    ap.add_argument("--cpu-stub", action="store_true",
-                    help="TEST ONLY (tests/test_dist_gloo.py): run the multi-rank control flow on CPU over gloo "
-                         "with a stand-in for the HIP engine; the numbers it prints are meaningless")
-    args = ap.parse_args()
+                    help="infer (default): the headline metric plus the secondary objects.  train: configs[3] only")
+    ap.add_argument("--train-storage", choices=["f32", "bf16"], default="f32")
+    args = ap.parse_args(argv)
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        return self_launch(args, argv)                         # before torch / HIP are touched in this process
 
     import numpy as np
     import torch
@@ -164,33 +316,25 @@ def main():
     from gtcrn_micro_amd.sharding import init_distributed, max_over_ranks
     if args.mode == "train":
         return train_main(args)
-    stub = args.cpu_stub
-    rank, local_rank, world = init_distributed("gloo" if stub else None)
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    dev = "cpu" if stub else "cuda"
-    if not stub:
+    shim = _load_shim()
+    rank, local_rank, world = init_distributed("gloo" if shim else None)
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: refusing to print a mislabelled line")
+    dev = "cpu" if shim else "cuda"
+    if not shim:
         torch.cuda.set_device(local_rank)
 
     params = np.fromfile(os.path.join(ROOT, "tests", "golden", "params_dns3.f32"), dtype=np.float32)
-    B, L = args.batch, int(args.seconds * 16000)
+    B = args.batch if args.batch is not None else 256
+    L = int(args.seconds * 16000)
     T = 1 + L // 256
     frames_per_step = B * T
     torch.manual_seed(43 + rank)                               # the reference's seed (train.py:27)
     wave = (torch.randn(B, L, device=dev) * 0.1).contiguous()
     win = torch.hann_window(512).pow(0.5).to(dev)              # infer.py:65
     out = torch.empty((B, 256 * (T - 1)), device=dev)
-    if stub:
-        class _Stub:                                           # stands in for the HIP engine on CPU
-            def forward_wave(self, w, win, out=None):
-                out.copy_(w[:, :out.shape[1]] * 0.5)
-            def timing_enable(self, on=True, only=None):
-                pass
-            def timing_read(self):
-                return {k: (1.0, args.steps) for k in MAC_PER_FRAME}
-            def reserve(self, B, T):
-                pass
-        eng = _Stub()
+    if shim:
+        eng = shim.make_engine(params, local_rank, args)
     else:
         import __graft_entry__ as graft
         if rank == 0:
@@ -204,50 +348,76 @@ def main():
     def sync_all():
         if world > 1:
             dist.barrier()
-        if not stub:
+        if not shim:
             torch.cuda.synchronize()
 
-    # warm-up: every kernel is timed with HIP events here (the per-kernel split of the JSON line) ...
+    # pre-spin (untimed): >= 0.5 s of the same work so the clocks have settled before anything is measured
+    t_spin = time.perf_counter()
+    while not shim and time.perf_counter() - t_spin < 0.6:
+        for _ in range(20):
+            eng.forward_wave(wave, win, out=out)
+        torch.cuda.synchronize()
+    # W warm-up steps with HIP events around every kernel: picks the dominant kernel
     eng.timing_enable(True)
     for _ in range(max(args.warmup, 1)):
         eng.forward_wave(wave, win, out=out)
     sync_all()
-    kern_all = eng.timing_read()
-    dom_name = max((k for k in kern_all if k in MAC_PER_FRAME), key=lambda k: kern_all[k][0]) if kern_all else "k_decoder"
-    # ... the timed region keeps only the dominant kernel's events (on the launch stream): each event pair costs a
-    # few microseconds of dispatch gap, six pairs per step would be ~4 % of the step
-    if stub:
-        eng.timing_enable(True)
-    else:
-        eng.timing_enable(True, only=dom_name)
+    kern_warm = eng.timing_read()
+    dom = max((k for k in kern_warm if k in MAC_PER_FRAME), key=lambda k: kern_warm[k][0])
+    # the timed region keeps only the dominant kernel's events (on the launch stream): each event pair costs a
+    # few microseconds of dispatch gap, one pair per kernel per step would be ~4 % of the step
+    eng.timing_enable(True, only=dom)
     sync_all()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         eng.forward_wave(wave, win, out=out)
     sync_all()
     elapsed = time.perf_counter() - t0
-    kern = dict(kern_all)
-    kern.update(eng.timing_read())                             # the dominant kernel: measured inside the timed region
-    eng.timing_enable(False)
+    dom_ms, dom_launches = eng.timing_read()[dom]
     elapsed = max_over_ranks(elapsed, dev)                     # the slowest rank defines the step time
+    # the per-kernel split: ONE separate pass of K steps with an event pair around every kernel (all kernel_ms
+    # values come from here; its step time is reported next to the headline's)
+    eng.timing_enable(True)
+    sync_all()
+    t1 = time.perf_counter()
+    for _ in range(args.steps):
+        eng.forward_wave(wave, win, out=out)
+    sync_all()
+    split_ms_per_step = (time.perf_counter() - t1) / args.steps * 1e3
+    kern = eng.timing_read()
+    eng.timing_enable(False)
     assert bool(torch.isfinite(out).all())
 
+    line = None
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
         value = world * frames_per_step * args.steps / elapsed
-        dom = max((k for k in kern if k in MAC_PER_FRAME), key=lambda k: kern[k][0])
-        dom_ms = kern[dom][0]
         flops_launch = 2.0 * MAC_PER_FRAME[dom] * frames_per_step
         achieved = flops_launch / (dom_ms * 1e-3) / 1e12
         traffic = None
-        tf = os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")
-        if os.path.exists(tf):
-            try:
-                traffic = json.load(open(tf)).get(dom, {}).get("hbm_bytes_per_launch")
-            except Exception:
-                traffic = None
-        path_flop = (2.0 * sum(MAC_PER_FRAME.values()) + FFT_FLOP_PER_FRAME) * frames_per_step
+        for tag in (ROUND_TAG, "r01"):
+            tf = os.path.join(ROOT, "profiles", f"{tag}_hbm_traffic.json")
+            if os.path.exists(tf):
+                try:
+                    traffic = json.load(open(tf)).get(dom, {}).get("hbm_bytes_per_launch")
+                except Exception:
+                    traffic = None
+                if traffic is not None:
+                    break
+        path_flop = (2.0 * MODEL_MAC_PER_FRAME + FFT_FLOP_PER_FRAME) * frames_per_step
         sum_ms = sum(v[0] for v in kern.values())
+        roof = {
+            "bound": "mfma", "kernel": dom, "achieved": round(achieved, 3), "peak": FP32_MFMA_PEAK_TFLOPS,
+            "unit": "TFLOP/s", "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
+            "flop_per_launch": flops_launch, "avg_launch_ms": round(dom_ms, 4), "launches": dom_launches,
+            # whole path against the same peak, from the headline's own step time (not from a sum of event times)
+            "path_tflops": round(path_flop / (ms_per_step * 1e-3) / 1e12, 3),
+            "path_frac": round(path_flop / (ms_per_step * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4),
+            "hbm_frac_at_boundary": round(value / world * 2048 / 1e9 / HBM_PEAK_GBS, 6),
+        }
+        if dom in MFMA_PER_FRAME:
+            roof["mfma_flop_executed_per_launch"] = 2048.0 * MFMA_PER_FRAME[dom] * frames_per_step
+            roof["mfma_padding_overhead"] = round(roof["mfma_flop_executed_per_launch"] / flops_launch - 1, 4)
         line = {
             "metric": "16 kHz frames/sec (STFT->mask->iSTFT)",
             "value": round(value, 1),
@@ -260,32 +430,57 @@ def main():
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": "f32",
-            "data": "synthetic" if not stub else "synthetic (CPU STUB: control-flow test, not a measurement)",
+            "data": "synthetic" if not shim else "synthetic (TEST SHIM: control-flow test on CPU, not a measurement)",
             "config": {"workload": f"offline wave->wave, B={B} clips/GPU x {args.seconds:g} s @16 kHz "
                                    f"(T={T} frames), fp32, shipped checkpoint weights",
                        "batch_per_gpu": B, "frames_per_step_per_gpu": frames_per_step,
                        "parallelism": f"{world} independent utterance shards, no data-path collective"},
+            "timed_region_s": round(elapsed, 4),
             "rtf_per_stream": round((elapsed / args.steps) / (B * args.seconds) * 1.0, 9),
-            "roofline": {
-                "bound": "mfma", "kernel": dom, "achieved": round(achieved, 3), "peak": FP32_MFMA_PEAK_TFLOPS,
-                "unit": "TFLOP/s", "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
-                "flop_per_launch": flops_launch, "avg_launch_ms": round(dom_ms, 4), "launches": kern[dom][1],
-                "path_tflops": round(path_flop / (sum_ms * 1e-3) / 1e12, 3),
-                "path_frac": round(path_flop / (sum_ms * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4),
-                "hbm_frac_at_boundary": round(value / world * 2048 / 1e9 / HBM_PEAK_GBS, 6),
-            },
+            "roofline": roof,
             "kernel_ms": {k: round(v[0], 4) for k, v in kern.items()},
-            "kernel_ms_note": f"{dom} from HIP events inside the timed region ({kern[dom][1]} launches); the others "
-                              "from the warm-up steps",
+            "sum_kernel_ms": round(sum_ms, 4),
+            "kernel_ms_note": f"all from ONE separate pass of {args.steps} steps with an event pair around every "
+                              f"kernel (that pass: {split_ms_per_step:.4f} ms/step); roofline.avg_launch_ms is "
+                              f"{dom}'s alone inside the headline timed region",
         }
-        if world == 1 and not args.no_cpu_baseline and not stub:
+    if not shim and not args.no_secondary:
+        legs = {}
+        try:
+            legs["stream"] = stream_leg(eng, world, sync_all, max_over_ranks)
+        except Exception as e:                                 # a secondary leg must never take the headline down
+            legs["stream"] = {"error": repr(e)}
+        try:
+            from gtcrn_micro_amd import quant
+            legs["quant"] = quant.bench_leg(params, local_rank, wave, win, world, sync_all, max_over_ranks,
+                                            steps=args.steps)
+        except ImportError:
+            pass
+        except Exception as e:
+            legs["quant"] = {"error": repr(e)}
+        del eng, wave, out
+        torch.cuda.empty_cache()
+        tr = {}
+        for storage in ("f32", "bf16"):
+            try:
+                tr[storage] = train_leg(rank, world, sync_all, max_over_ranks, storage=storage)
+            except AttributeError:
+                continue                                        # this build has no such storage variant
+            except Exception as e:
+                tr[storage] = {"error": repr(e)}
+        legs["train"] = tr
+        if line is not None:
+            line.update(legs)
+    if rank == 0:
+        if world == 1 and not args.no_cpu_baseline and not shim:
             line["cpu_baseline"] = cpu_baseline(params)
-            line["gpu_over_cpu"] = round(value / line["cpu_baseline"]["value"], 1)
+            line["gpu_over_cpu"] = round(line["value"] / line["cpu_baseline"]["value"], 1)
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+    return 0
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

@@ -62,6 +62,7 @@ def lib():
     L.gtcrn_istft.argtypes = [_vp, cl, cl, cl, ci, ci, _vp, _vp, _vp]
     L.gtcrn_forward_spec.argtypes = [_vp, _vp, cl, cl, cl, _vp, cl, cl, cl, ci, ci, _vp]
     L.gtcrn_forward_wave.argtypes = [_vp, _vp, _vp, ci, cl, _vp, _vp]
+    L.gtcrn_forward_wave_var.argtypes = [_vp, _vp, _vp, ci, cl, _vp, _vp, _vp]
     L.gtcrn_stream_state_bytes.restype = ctypes.c_size_t
     L.gtcrn_stream_reset.argtypes = [_vp, _vp, ci, _vp]
     L.gtcrn_stream_step.argtypes = [_vp, _vp, _vp, cl, cl, cl, _vp, cl, cl, cl, ci, ci, _vp]
@@ -100,11 +101,17 @@ def _check(rc):
     return rc
 
 
+_param_table = None
+
+
 def param_table():
-    """[(name, numel, offset)] of the canonical blob (reference state_dict order)."""
-    L = lib()
-    return [(L.gtcrn_param_name(i).decode(), L.gtcrn_param_numel(i), L.gtcrn_param_offset(i))
-            for i in range(L.gtcrn_param_tensors())]
+    """((name, numel, offset), ...) of the canonical blob (reference state_dict order); built once."""
+    global _param_table
+    if _param_table is None:
+        L = lib()
+        _param_table = tuple((L.gtcrn_param_name(i).decode(), L.gtcrn_param_numel(i), L.gtcrn_param_offset(i))
+                             for i in range(L.gtcrn_param_tensors()))
+    return _param_table
 
 
 def make_window(kind=0):
@@ -274,6 +281,10 @@ class Engine:
         B, _, T, _ = spec.shape
         if out is None:
             out = torch.empty((B, NBINS, T, 2), device=spec.device, dtype=torch.float32)
+        else:
+            self._check_on_device(out, "out")
+            if tuple(out.shape) != (B, NBINS, T, 2) or out.stride(3) != 1:
+                raise GtcrnError(f"out must be (B,257,{T},2) with contiguous re/im pairs, got {tuple(out.shape)}")
         isb, isf, ist = _spec_strides(spec)
         osb, osf, ost = _spec_strides(out)
         with self._dev():
@@ -281,19 +292,60 @@ class Engine:
                                             B, T, _stream_ptr()))
         return out
 
+    def _check_on_device(self, t, what, shape=None):
+        import torch
+        _require_cuda_f32(t, what)
+        if t.device.index != self.device:
+            raise GtcrnError(f"{what} is on cuda:{t.device.index}, the model on cuda:{self.device}")
+        if shape is not None and (tuple(t.shape) != tuple(shape) or not t.is_contiguous()):
+            raise GtcrnError(f"{what} must be a contiguous float32 tensor of shape {tuple(shape)}, got "
+                             f"{tuple(t.shape)} (contiguous: {t.is_contiguous()})")
+
     def forward_wave(self, wave, window, out=None):
         import torch
-        _require_cuda_f32(wave, "wave")
+        self._check_on_device(wave, "wave")
         w2 = (wave.reshape(1, -1) if wave.dim() == 1 else wave).contiguous()
+        if w2.dim() != 2:
+            raise GtcrnError(f"wave must be (B,L) or (L,), got {tuple(wave.shape)}")
         B, L = w2.shape
         T = num_frames(L)
         win = window.to(device=wave.device, dtype=torch.float32).contiguous()
         if out is None:
             out = torch.empty((B, 256 * (T - 1)), device=wave.device, dtype=torch.float32)
+        else:
+            self._check_on_device(out, "out", (B, 256 * (T - 1)))
         with self._dev():
             _check(lib().gtcrn_forward_wave(self._h, w2.data_ptr(), out.data_ptr(), B, L, win.data_ptr(),
                                             _stream_ptr()))
         return out[0] if wave.dim() == 1 else out
+
+    def forward_wave_var(self, wave, lengths, window, out=None):
+        """Clips of different lengths through ONE launch sequence: ``wave`` (B,Lmax) holds clip b in its first
+        ``lengths[b]`` samples (257 <= lengths[b] <= Lmax).  Returns (B, 256*(Lmax//256)); row b carries its
+        256*(lengths[b]//256) enhanced samples (bit-identical to forward_wave on that clip alone), the rest of the
+        row is unspecified."""
+        import torch
+        self._check_on_device(wave, "wave")
+        if wave.dim() != 2 or not wave.is_contiguous():
+            raise GtcrnError("wave must be a contiguous (B,Lmax) tensor")
+        B, L = wave.shape
+        lens = torch.as_tensor(lengths, dtype=torch.int32).reshape(-1)
+        if lens.numel() != B:
+            raise GtcrnError(f"lengths must hold {B} entries, got {lens.numel()}")
+        lmin, lmax = int(lens.min()), int(lens.max())
+        if lmin < 257 or lmax > L:
+            raise GtcrnError(f"every length must lie in [257, Lmax={L}], got min {lmin} max {lmax}")
+        lens = lens.to(wave.device)
+        T = num_frames(L)
+        win = window.to(device=wave.device, dtype=torch.float32).contiguous()
+        if out is None:
+            out = torch.empty((B, 256 * (T - 1)), device=wave.device, dtype=torch.float32)
+        else:
+            self._check_on_device(out, "out", (B, 256 * (T - 1)))
+        with self._dev():
+            _check(lib().gtcrn_forward_wave_var(self._h, wave.data_ptr(), out.data_ptr(), B, L, lens.data_ptr(),
+                                                win.data_ptr(), _stream_ptr()))
+        return out
 
     # ---- streaming -----------------------------------------------------------------------
     @staticmethod
@@ -309,13 +361,19 @@ class Engine:
 
     def stream_step(self, state, spec_t, out=None):
         import torch
-        _require_cuda_f32(spec_t, "spec")
+        self._check_on_device(spec_t, "spec")
+        if spec_t.dim() != 4 or spec_t.shape[1] != NBINS or spec_t.shape[3] != 2:
+            raise GtcrnError(f"spec must be (N,257,n,2), got {tuple(spec_t.shape)}")
         if spec_t.stride(3) != 1:
             spec_t = spec_t.contiguous()
         N, _, nfr, _ = spec_t.shape
-        assert state.shape[0] == N
+        self._check_on_device(state, "state", (N, self.state_bytes() // 4))
         if out is None:
             out = torch.empty((N, NBINS, nfr, 2), device=spec_t.device, dtype=torch.float32)
+        else:
+            self._check_on_device(out, "out")
+            if tuple(out.shape) != (N, NBINS, nfr, 2) or out.stride(3) != 1:
+                raise GtcrnError(f"out must be (N,257,{nfr},2) with contiguous re/im pairs, got {tuple(out.shape)}")
         isb, isf, ist = _spec_strides(spec_t)
         osb, osf, ost = _spec_strides(out)
         with self._dev():

@@ -9,6 +9,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -151,19 +152,19 @@ struct Timer {
 
 // the five model kernels on one stream; state == nullptr for offline
 int run_model(gtcrn_model* m, const float* spec_in, long isb, long isf, long ist, float* spec_out, long osb, long osf,
-              long ost, int B, int T, float* state, hipStream_t s) {
+              long ost, int B, int T, float* state, hipStream_t s, const int* lens = nullptr) {
     Timer tm(m, s);
     unsigned long long* stp = (m->debug && m->d_stamps) ? m->d_stamps : nullptr;
     const long sst = (long)m->stamps_cap_b * 16;
     tm.begin(1);
-    LAUNCH_TRY(gtk::launch_encoder(spec_in, isb, isf, ist, B, T, m->d_pf, m->d_pi, m->d_en0, m->d_en[0], m->d_en[1],
+    LAUNCH_TRY(gtk::launch_encoder(spec_in, isb, isf, ist, B, T, lens, m->d_pf, m->d_pi, m->d_en0, m->d_en[0], m->d_en[1],
                                    m->d_en[2], m->d_en[3], state, stp ? stp : nullptr, s));
     tm.end();
     // GTCN: offline calls (no stream state) use the frequency-band form (registers + DPP, no barrier);
     // streaming calls use the ring form, whose chunks may hold a single frame
     tm.begin(2);
     if (!state)
-        LAUNCH_TRY(gtk::launch_gtcn_band(m->d_en[3], m->d_g1, m->d_pf + gtl::P_GTCN, B, T, nullptr, s));
+        LAUNCH_TRY(gtk::launch_gtcn_band(m->d_en[3], m->d_g1, m->d_pf + gtl::P_GTCN, B, T, lens, nullptr, s));
     else
         LAUNCH_TRY(gtk::launch_gtcn(m->d_en[3], m->d_g1, m->d_pf + gtl::P_GTCN, B, T, state, gtk::ST_G1_H, nullptr,
                                     stp ? stp + sst : nullptr, s));
@@ -171,14 +172,15 @@ int run_model(gtcrn_model* m, const float* spec_in, long isb, long isf, long ist
     tm.begin(3);
     // the second stack stores gtcn2(x) + en_outs[4]: exactly the decoder's first input (Decoder.forward :467)
     if (!state)
-        LAUNCH_TRY(gtk::launch_gtcn_band(m->d_g1, m->d_g2, m->d_pf + gtl::P_GTCN + gtl::GTCN_SIZE, B, T, m->d_en[3], s));
+        LAUNCH_TRY(gtk::launch_gtcn_band(m->d_g1, m->d_g2, m->d_pf + gtl::P_GTCN + gtl::GTCN_SIZE, B, T, lens, m->d_en[3],
+                                         s));
     else
         LAUNCH_TRY(gtk::launch_gtcn(m->d_g1, m->d_g2, m->d_pf + gtl::P_GTCN + gtl::GTCN_SIZE, B, T, state,
                                     gtk::ST_G2_H, m->d_en[3], stp ? stp + 2 * sst : nullptr, s));
     tm.end();
     tm.begin(4);
     LAUNCH_TRY(gtk::launch_decoder(m->d_g2, m->d_en0, m->d_en[0], m->d_en[1], m->d_en[2], m->d_en[3], spec_in, isb, isf,
-                                   ist, spec_out, osb, osf, ost, B, T, m->d_pf, m->d_pi, state,
+                                   ist, spec_out, osb, osf, ost, B, T, lens, m->d_pf, m->d_pi, state,
                                    m->debug ? m->d_dbg : nullptr, stp ? stp + 3 * sst : nullptr, s));
     tm.end();
     m->last_B = B;
@@ -324,13 +326,16 @@ int gtcrn_make_window(int kind, float* h_w512) {
 
 long gtcrn_num_frames(long L) { return 1 + L / 256; }
 
-// twiddles are per model; the standalone STFT entry points keep one table per device
+// twiddles are per model; the standalone STFT entry points keep one immutable table per device, created once
+// under a lock (the only process-wide state of the library; never modified after its creation)
 namespace {
 float* g_twid[16] = {nullptr};
+std::mutex g_twid_mu;
 int device_twiddles(float** out) {
     int dev = 0;
     HIP_TRY(hipGetDevice(&dev));
     if (dev < 0 || dev >= 16) return fail(GTCRN_ERR_DEVICE, "device ordinal >= 16");
+    std::lock_guard<std::mutex> lock(g_twid_mu);
     if (!g_twid[dev]) {
         std::vector<float> tw(1024);
         for (int k = 0; k < 256; ++k) {
@@ -369,7 +374,7 @@ int gtcrn_stft(const float* d_wave, int B, long L, const float* d_win, float* d_
     float* tw = nullptr;
     int rc = device_twiddles(&tw);
     if (rc) return rc;
-    LAUNCH_TRY(gtk::launch_stft(d_wave, B, L, (int)gtcrn_num_frames(L), d_win, tw, d_spec, sb, sf, st, nullptr,
+    LAUNCH_TRY(gtk::launch_stft(d_wave, B, L, (int)gtcrn_num_frames(L), nullptr, d_win, tw, d_spec, sb, sf, st, nullptr,
                                 (hipStream_t)stream));
     return 0;
 }
@@ -380,7 +385,7 @@ int gtcrn_stft_frames(const float* d_wave, int B, long L, const float* d_win, fl
     float* tw = nullptr;
     int rc = device_twiddles(&tw);
     if (rc) return rc;
-    LAUNCH_TRY(gtk::launch_stft(d_wave, B, L, (int)gtcrn_num_frames(L), d_win, tw, nullptr, 0, 0, 0, d_frames,
+    LAUNCH_TRY(gtk::launch_stft(d_wave, B, L, (int)gtcrn_num_frames(L), nullptr, d_win, tw, nullptr, 0, 0, 0, d_frames,
                                 (hipStream_t)stream));
     return 0;
 }
@@ -393,7 +398,7 @@ int gtcrn_istft(const float* d_spec, long sb, long sf, long st, int B, int T, co
     float* tw = nullptr;
     int rc = device_twiddles(&tw);
     if (rc) return rc;
-    LAUNCH_TRY(gtk::launch_istft(d_spec, sb, sf, st, B, T, d_win, tw, d_wave, (hipStream_t)stream));
+    LAUNCH_TRY(gtk::launch_istft(d_spec, sb, sf, st, B, T, nullptr, d_win, tw, d_wave, (hipStream_t)stream));
     return 0;
 }
 
@@ -411,8 +416,8 @@ int gtcrn_forward_spec(gtcrn_model* m, const float* d_spec_in, long isb, long is
     return run_model(m, d_spec_in, isb, isf, ist, d_spec_out, osb, osf, ost, B, T, nullptr, s);
 }
 
-int gtcrn_forward_wave(gtcrn_model* m, const float* d_wave, float* d_wave_out, int B, long L, const float* d_win,
-                       void* stream) {
+static int forward_wave_impl(gtcrn_model* m, const float* d_wave, float* d_wave_out, int B, long L,
+                             const int* d_lengths, const float* d_win, void* stream) {
     int rc = check_model(m);
     if (rc) return rc;
     if (!d_wave || !d_wave_out || !d_win) return fail(GTCRN_ERR_ARG, "null pointer");
@@ -426,14 +431,25 @@ int gtcrn_forward_wave(gtcrn_model* m, const float* d_wave, float* d_wave_out, i
     const long sb = (long)T * 514, sf = 2, st = 514;
     Timer tm(m, s);
     tm.begin(0);
-    LAUNCH_TRY(gtk::launch_stft(d_wave, B, L, T, d_win, m->d_twid, m->d_spec_a, sb, sf, st, nullptr, s));
+    LAUNCH_TRY(gtk::launch_stft(d_wave, B, L, T, d_lengths, d_win, m->d_twid, m->d_spec_a, sb, sf, st, nullptr, s));
     tm.end();
-    rc = run_model(m, m->d_spec_a, sb, sf, st, m->d_spec_b, sb, sf, st, B, T, nullptr, s);
+    rc = run_model(m, m->d_spec_a, sb, sf, st, m->d_spec_b, sb, sf, st, B, T, nullptr, s, d_lengths);
     if (rc) return rc;
     tm.begin(5);
-    LAUNCH_TRY(gtk::launch_istft(m->d_spec_b, sb, sf, st, B, T, d_win, m->d_twid, d_wave_out, s));
+    LAUNCH_TRY(gtk::launch_istft(m->d_spec_b, sb, sf, st, B, T, d_lengths, d_win, m->d_twid, d_wave_out, s));
     tm.end();
     return 0;
+}
+
+int gtcrn_forward_wave(gtcrn_model* m, const float* d_wave, float* d_wave_out, int B, long L, const float* d_win,
+                       void* stream) {
+    return forward_wave_impl(m, d_wave, d_wave_out, B, L, nullptr, d_win, stream);
+}
+
+int gtcrn_forward_wave_var(gtcrn_model* m, const float* d_wave, float* d_wave_out, int B, long Lmax,
+                           const int* d_lengths, const float* d_win, void* stream) {
+    if (!d_lengths) return fail(GTCRN_ERR_ARG, "gtcrn_forward_wave_var: null lengths");
+    return forward_wave_impl(m, d_wave, d_wave_out, B, Lmax, d_lengths, d_win, stream);
 }
 
 size_t gtcrn_stream_state_bytes(void) { return sizeof(float) * gtk::ST_FLOATS; }

@@ -35,23 +35,26 @@ constexpr int ST_DEC_E = ST_DEC_H + 3 * 2 * 33 * 16;
 constexpr int ST_FLOATS = ST_DEC_E + 48;         // 38116 floats = 152 464 B per stream
 
 int configure_kernels();
-int launch_stft(const float* wave, int B, long L, int T, const float* win, const float* twid, float* spec, long sb,
-                long sf, long st, float* frames, hipStream_t s);
-int launch_istft(const float* spec, long sb, long sf, long st, int B, int T, const float* win, const float* twid,
-                 float* wave, hipStream_t s);
+// lens (optional, device, int32[B]): variable-length batch -- utterance b holds lens[b] <= L samples in its row of
+// L, i.e. 1 + lens[b]/256 <= T frames; L and T stay the row strides of every tensor.  nullptr: all rows are full.
+int launch_stft(const float* wave, int B, long L, int T, const int* lens, const float* win, const float* twid,
+                float* spec, long sb, long sf, long st, float* frames, hipStream_t s);
+int launch_istft(const float* spec, long sb, long sf, long st, int B, int T, const int* lens, const float* win,
+                 const float* twid, float* wave, hipStream_t s);
 // gspec += adjoint(iSTFT)(gwave): gwave (B, 256 (T-1)) is the gradient w.r.t. the iSTFT output ALREADY divided by
 // the window envelope; gspec (B,257,T,2 by strides) receives the gradient w.r.t. the spectrogram (accumulated).
 int launch_istft_adjoint(const float* gwave, int B, int T, const float* win, const float* twid, float* gspec, long sb,
                          long sf, long st, hipStream_t s);
-int launch_encoder(const float* spec, long sb, long sf, long st, int B, int T, const float* PF, const int* PI,
-                   float* en0, float* en1, float* en2, float* en3, float* en4, float* state,
+int launch_encoder(const float* spec, long sb, long sf, long st, int B, int T, const int* lens, const float* PF,
+                   const int* PI, float* en0, float* en1, float* en2, float* en3, float* en4, float* state,
                    unsigned long long* stamps, hipStream_t s);
 int launch_gtcn(const float* xin, float* xout, const float* P, int B, int T, float* state, int st_off,
                 const float* addend, unsigned long long* stamps, hipStream_t s);
-int launch_gtcn_band(const float* xin, float* xout, const float* P, int B, int T, const float* addend, hipStream_t s);
+int launch_gtcn_band(const float* xin, float* xout, const float* P, int B, int T, const int* lens, const float* addend,
+                     hipStream_t s);
 int launch_decoder(const float* xg, const float* en0, const float* en1, const float* en2, const float* en3,
                    const float* en4, const float* spec, long sb, long sf, long st, float* out, long osb, long osf,
-                   long ost, int B, int T, const float* PF, const int* PI, float* state, float* dbg,
+                   long ost, int B, int T, const int* lens, const float* PF, const int* PI, float* state, float* dbg,
                    unsigned long long* stamps, hipStream_t s);
 int launch_state_convert(float* state, int N, float* conv, float* tra, float* const* tcn8, const int* PI, int dir,
                          hipStream_t s);

@@ -190,6 +190,7 @@ constexpr int FFT_WAVES = 4;
 // c2r transform reads those once) and the result is ADDED to `spec`.
 template <bool ADJ>
 __global__ __launch_bounds__(FFT_WAVES * 64) void k_stft(const float* __restrict__ wave, int B, long L, int T,
+                                                        const int* __restrict__ lens,
                                                         const float* __restrict__ win,
                                                         const float2* __restrict__ twid, float* __restrict__ spec,
                                                         long sb, long sf, long st, float* __restrict__ frames_out) {
@@ -205,13 +206,17 @@ __global__ __launch_bounds__(FFT_WAVES * 64) void k_stft(const float* __restrict
     const long base = (long)blockIdx.x * (FFT_WAVES * FRAMES_PER_WAVE);
     // samples of a frame: lane holds the pairs (2m, 2m+1), m = lane + 64 q.  Interior frames read them as one
     // 8-byte load each; only the first and the last two frames of an utterance touch the reflected edges.
+    // lens (optional): utterance b holds lens[b] <= L samples in its row of L (variable-length batch); its frames
+    // t >= 1 + lens[b]/256 do not exist (nothing is stored for them) and its reflected edge is its own
     auto fetch = [&](long fr, float2 (&v)[4]) {
-        const bool live = fr < nframes;
+        bool live = fr < nframes;
         const int b = live ? (int)(fr / T) : 0;
-        const int t = live ? (int)(fr - (long)b * T) : 0;
+        int t = live ? (int)(fr - (long)b * T) : 0;
         const float* x = wave + (long)b * L;
+        const long Lb = lens ? (long)lens[b] : L;
+        if (t > (int)(Lb >> 8)) t = 0;                        // a frame past the utterance's end: not live, reads frame 0
         const long lo = 256L * t - 256;                       // first sample of the frame in the unpadded signal
-        if (lo >= 0 && lo + 512 <= L && ((reinterpret_cast<uintptr_t>(x + lo) & 7) == 0)) {
+        if (lo >= 0 && lo + 512 <= Lb && ((reinterpret_cast<uintptr_t>(x + lo) & 7) == 0)) {
 #pragma unroll
             for (int q = 0; q < 4; ++q) v[q] = *reinterpret_cast<const float2*>(x + lo + 2 * (lane + 64 * q));
         } else {
@@ -220,9 +225,9 @@ __global__ __launch_bounds__(FFT_WAVES * 64) void k_stft(const float* __restrict
                 const long i0 = 256L * t + 2 * (lane + 64 * q);
                 if (ADJ) {
                     const long j0 = i0 - 256, j1 = j0 + 1;
-                    v[q] = make_float2(j0 >= 0 && j0 < L ? x[j0] : 0.f, j1 >= 0 && j1 < L ? x[j1] : 0.f);
+                    v[q] = make_float2(j0 >= 0 && j0 < Lb ? x[j0] : 0.f, j1 >= 0 && j1 < Lb ? x[j1] : 0.f);
                 } else {
-                    v[q] = make_float2(x[reflect_idx(i0, L)], x[reflect_idx(i0 + 1, L)]);
+                    v[q] = make_float2(x[reflect_idx(i0, Lb)], x[reflect_idx(i0 + 1, Lb)]);
                 }
             }
         }
@@ -232,9 +237,10 @@ __global__ __launch_bounds__(FFT_WAVES * 64) void k_stft(const float* __restrict
     for (int it = 0; it < FRAMES_PER_WAVE; ++it) {
         // all 4 waves run the same number of iterations
         const long fr = base + (long)it * FFT_WAVES + wv;
-        const bool live = fr < nframes;
+        bool live = fr < nframes;
         const int b = live ? (int)(fr / T) : 0;
         const int t = live ? (int)(fr - (long)b * T) : 0;
+        if (lens && live && t > (lens[b] >> 8)) live = false;
         float2* A = s_buf[wv][0];
         float2* Bf = s_buf[wv][1];
         if (it + 1 < FRAMES_PER_WAVE) fetch(fr + FFT_WAVES, nxt);   // next frame's samples: in flight during this FFT
@@ -289,7 +295,8 @@ __global__ __launch_bounds__(FFT_WAVES * 64) void k_stft(const float* __restrict
 // c2r runs as a 256-point complex inverse FFT of the merged spectrum (scale 1/256).
 // One workgroup produces ISTFT_BLOCKS hop blocks of one utterance from ISTFT_BLOCKS+1 frames.
 __global__ __launch_bounds__(FFT_WAVES * 64) void k_istft(const float* __restrict__ spec, long sb, long sf, long st,
-                                                         int B, int T, const float* __restrict__ win,
+                                                         int B, int T, const int* __restrict__ lens,
+                                                         const float* __restrict__ win,
                                                          const float2* __restrict__ twid, float* __restrict__ wave) {
     __shared__ float2 s_tw[256];
     __shared__ float2 s_tw512[256];
@@ -300,10 +307,11 @@ __global__ __launch_bounds__(FFT_WAVES * 64) void k_istft(const float* __restric
     for (int i = tid; i < 256; i += FFT_WAVES * 64) { s_tw[i] = twid[i]; s_tw512[i] = twid[256 + i]; }
     for (int i = tid; i < 512; i += FFT_WAVES * 64) s_win[i] = win[i];
     __syncthreads();
-    const int nblk = T - 1;                                   // hop blocks of this utterance
-    const int groups = (nblk + ISTFT_BLOCKS - 1) / ISTFT_BLOCKS;
+    const int groups = (T - 1 + ISTFT_BLOCKS - 1) / ISTFT_BLOCKS;
     const int b = blockIdx.x / groups, grp = blockIdx.x - b * groups;
+    const int nblk = lens ? (lens[b] >> 8) : T - 1;           // hop blocks of this utterance (T_b - 1)
     const int j0 = grp * ISTFT_BLOCKS;                        // first hop block == first frame needed
+    if (j0 >= nblk) return;                                   // variable-length batch: past this utterance's end
     const int nfr = min(ISTFT_BLOCKS, nblk - j0) + 1;
     constexpr int ROUNDS = (ISTFT_BLOCKS + 1 + FFT_WAVES - 1) / FFT_WAVES;
     // bins k and 256-k of a frame (k = lane + 64 q); the next round's are fetched before this round's FFT
@@ -358,7 +366,7 @@ __global__ __launch_bounds__(FFT_WAVES * 64) void k_istft(const float* __restric
     }
     __syncthreads();   // the windowed frames of all four waves are overlap-added below
     // overlap-add: output block j = frame j second half + frame j+1 first half
-    float* o = wave + (long)b * 256 * nblk;
+    float* o = wave + (long)b * 256 * (T - 1);                // rows of 256 (T - 1) samples
     for (int idx = tid; idx < (nfr - 1) * 256; idx += FFT_WAVES * 64) {
         const int jb = idx >> 8, i = idx & 255;
         const float acc = s_fr[jb][256 + i] + s_fr[jb + 1][i];
@@ -659,8 +667,10 @@ static_assert(ENC_LDS_FLOATS * 4 <= 160 * 1024, "encoder LDS budget");
 static_assert(TC * 35 * 16 + TC * 33 * 16 <= TC * ENC_E0_ROW * 16, "W + S must fit in the E0 region");
 static_assert(ENC_LDS_I % 4 == 0 && ENC_LDS_H % 4 == 0 && ENC_LDS_G % 4 == 0 && ENC_LDS_A % 4 == 0, "16B carve");
 
+// lens (optional, offline only): utterance b has 1 + lens[b]/256 <= T frames; T stays the row stride of every tensor.
 template <int TPW>
 __global__ __launch_bounds__(NTHR) void k_encoder(const float* __restrict__ spec, long sb, long sf, long st, int T,
+                                                 const int* __restrict__ lens,
                                                  const float* __restrict__ PF, const int* __restrict__ PI,
                                                  float* __restrict__ en0, float* __restrict__ en1,
                                                  float* __restrict__ en2, float* __restrict__ en3,
@@ -697,6 +707,7 @@ __global__ __launch_bounds__(NTHR) void k_encoder(const float* __restrict__ spec
     // global addressing: wave-uniform base pointers (SGPR pairs) + 32-bit per-lane offsets
     en0 += ob * (F1 * 16); en1 += ob * 528; en2 += ob * 528; en3 += ob * 528; en4 += ob * 528;
     const bool t_fast = st < sf;  // reference layout (B,257,T,2): consecutive frames are adjacent
+    if (lens) T = min(T, 1 + (lens[b] >> 8));   // from here on T = this utterance's frames
     STAMP(SS, 0)
 
     // Spectrogram items of this thread: item q is element idx = tid + q*NTHR of the chunk, idx -> (tl, f)
@@ -1135,7 +1146,7 @@ __device__ __forceinline__ void tcn_block_band(f32x4 (&x)[TPW], const float* pk,
 }
 
 __global__ __launch_bounds__(NTHR) void k_gtcn_band(const float* __restrict__ xin, float* __restrict__ xout,
-                                                   const float* __restrict__ P, int T,
+                                                   const float* __restrict__ P, int T, const int* __restrict__ lens,
                                                    const float* __restrict__ addend) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* sP = smem + GB_LDS_P;
@@ -1150,6 +1161,7 @@ __global__ __launch_bounds__(NTHR) void k_gtcn_band(const float* __restrict__ xi
     xin += (long)b * T * 528;
     xout += (long)b * T * 528;
     if (addend) addend += (long)b * T * 528;
+    if (lens) T = min(T, 1 + (lens[b] >> 8));            // variable-length batch: this utterance's frames
     const int f0 = L.wave * TPW;                         // first bin of this wave
     float* cw = sC + f0 * 256;
     // the chunk's input is fetched one chunk ahead into registers (the waves run decoupled here, so an exposed
@@ -1216,6 +1228,7 @@ __global__ __launch_bounds__(NTHR) void k_decoder(const float* __restrict__ xg, 
                                                  const float* __restrict__ en3, const float* __restrict__ en4,
                                                  const float* __restrict__ spec, long sb, long sf, long st,
                                                  float* __restrict__ out, long osb, long osf, long ost, int T,
+                                                 const int* __restrict__ lens,
                                                  const float* __restrict__ PF, const int* __restrict__ PI,
                                                  float* __restrict__ state, float* __restrict__ dbg,
                                                  unsigned long long* __restrict__ stamps) {
@@ -1259,6 +1272,7 @@ __global__ __launch_bounds__(NTHR) void k_decoder(const float* __restrict__ xg, 
 
     const long ob = (long)b * T;
     const long nbt = (long)gridDim.x * T;
+    const int Tstride = T;
     spec += (long)b * sb;
     out += (long)b * osb;
     const bool t_fast = st < sf;
@@ -1271,6 +1285,7 @@ __global__ __launch_bounds__(NTHR) void k_decoder(const float* __restrict__ xg, 
     // every load's latency runs until its first use.
     // global addressing: wave-uniform chunk base pointers (SGPR pairs) + 32-bit per-lane offsets
     xg += ob * 528; en0 += ob * (F1 * 16); en1 += ob * 528; en2 += ob * 528; en3 += ob * 528;
+    if (lens) T = min(T, 1 + (lens[b] >> 8));   // variable-length batch: from here on T = this utterance's frames
     f32x4 xn[TPW];
     {
         const int np0 = min(TC, T) * 33;
@@ -1469,7 +1484,7 @@ __global__ __launch_bounds__(NTHR) void k_decoder(const float* __restrict__ xg, 
         if (DBG)
             for (int idx = tid; idx < 2 * nfr * F0; idx += NTHR) {
                 const int fq = idx % F0, ot = idx / F0, o = ot >= nfr ? 1 : 0, tq = ot - o * nfr;
-                dbg[3 * nbt * 528 + nbt * F1 * 16 + (((long)b * 2 + o) * T + t0 + tq) * F0 + fq] =
+                dbg[3 * nbt * 528 + nbt * F1 * 16 + (((long)b * 2 + o) * Tstride + t0 + tq) * F0 + fq] =
                     sM[(o * TC + tq) * F0 + fq];
             }
         // ---- ERB.bs + complex ratio mask + output layout --------------------------------------------
@@ -1624,12 +1639,12 @@ namespace gtk {
         if (e_ != hipSuccess) return (int)e_;   \
     } while (0)
 
-int launch_stft(const float* wave, int B, long L, int T, const float* win, const float* twid, float* spec, long sb,
-                long sf, long st, float* frames, hipStream_t s) {
+int launch_stft(const float* wave, int B, long L, int T, const int* lens, const float* win, const float* twid,
+                float* spec, long sb, long sf, long st, float* frames, hipStream_t s) {
     const long nframes = (long)B * T;
     const int per = FFT_WAVES * FRAMES_PER_WAVE;
     const int grid = (int)((nframes + per - 1) / per);
-    hipLaunchKernelGGL(k_stft<false>, dim3(grid), dim3(FFT_WAVES * 64), 0, s, wave, B, L, T, win,
+    hipLaunchKernelGGL(k_stft<false>, dim3(grid), dim3(FFT_WAVES * 64), 0, s, wave, B, L, T, lens, win,
                        reinterpret_cast<const float2*>(twid), spec, sb, sf, st, frames);
     GT_LAUNCH_CHECK();
     return 0;
@@ -1640,16 +1655,17 @@ int launch_istft_adjoint(const float* gwave, int B, int T, const float* win, con
     const long nframes = (long)B * T;
     const int per = FFT_WAVES * FRAMES_PER_WAVE;
     const int grid = (int)((nframes + per - 1) / per);
-    hipLaunchKernelGGL(k_stft<true>, dim3(grid), dim3(FFT_WAVES * 64), 0, s, gwave, B, 256L * (T - 1), T, win,
+    hipLaunchKernelGGL(k_stft<true>, dim3(grid), dim3(FFT_WAVES * 64), 0, s, gwave, B, 256L * (T - 1), T,
+                       (const int*)nullptr, win,
                        reinterpret_cast<const float2*>(twid), gspec, sb, sf, st, (float*)nullptr);
     GT_LAUNCH_CHECK();
     return 0;
 }
 
-int launch_istft(const float* spec, long sb, long sf, long st, int B, int T, const float* win, const float* twid,
-                 float* wave, hipStream_t s) {
+int launch_istft(const float* spec, long sb, long sf, long st, int B, int T, const int* lens, const float* win,
+                 const float* twid, float* wave, hipStream_t s) {
     const int groups = (T - 1 + ISTFT_BLOCKS - 1) / ISTFT_BLOCKS;
-    hipLaunchKernelGGL(k_istft, dim3(B * groups), dim3(FFT_WAVES * 64), 0, s, spec, sb, sf, st, B, T, win,
+    hipLaunchKernelGGL(k_istft, dim3(B * groups), dim3(FFT_WAVES * 64), 0, s, spec, sb, sf, st, B, T, lens, win,
                        reinterpret_cast<const float2*>(twid), wave);
     GT_LAUNCH_CHECK();
     return 0;
@@ -1689,17 +1705,17 @@ int configure_kernels() {
     return 0;
 }
 
-int launch_encoder(const float* spec, long sb, long sf, long st, int B, int T, const float* PF, const int* PI,
-                   float* en0, float* en1, float* en2, float* en3, float* en4, float* state,
+int launch_encoder(const float* spec, long sb, long sf, long st, int B, int T, const int* lens, const float* PF,
+                   const int* PI, float* en0, float* en1, float* en2, float* en3, float* en4, float* state,
                    unsigned long long* stamps, hipStream_t s) {
     if (T <= SHORT_T)
-        hipLaunchKernelGGL(k_encoder<1>, dim3(B), dim3(NTHR), ENC_LDS_FLOATS * 4, s, spec, sb, sf, st, T, PF, PI, en0,
-                           en1, en2, en3, en4, state, stamps);
+        hipLaunchKernelGGL(k_encoder<1>, dim3(B), dim3(NTHR), ENC_LDS_FLOATS * 4, s, spec, sb, sf, st, T, lens, PF, PI,
+                           en0, en1, en2, en3, en4, state, stamps);
     else if (T <= SHORT_T2)
-        hipLaunchKernelGGL(k_encoder<2>, dim3(B), dim3(NTHR), ENC_LDS_FLOATS * 4, s, spec, sb, sf, st, T, PF, PI, en0,
-                           en1, en2, en3, en4, state, stamps);
+        hipLaunchKernelGGL(k_encoder<2>, dim3(B), dim3(NTHR), ENC_LDS_FLOATS * 4, s, spec, sb, sf, st, T, lens, PF, PI,
+                           en0, en1, en2, en3, en4, state, stamps);
     else
-        hipLaunchKernelGGL(k_encoder<TPW>, dim3(B), dim3(NTHR), ENC_LDS_FLOATS * 4, s, spec, sb, sf, st, T, PF, PI,
+        hipLaunchKernelGGL(k_encoder<TPW>, dim3(B), dim3(NTHR), ENC_LDS_FLOATS * 4, s, spec, sb, sf, st, T, lens, PF, PI,
                            en0, en1, en2, en3, en4, state, stamps);
     GT_LAUNCH_CHECK();
     return 0;
@@ -1729,19 +1745,20 @@ int launch_gtcn(const float* xin, float* xout, const float* P, int B, int T, flo
     return 0;
 }
 
-int launch_gtcn_band(const float* xin, float* xout, const float* P, int B, int T, const float* addend, hipStream_t s) {
-    hipLaunchKernelGGL(k_gtcn_band, dim3(B), dim3(NTHR), GB_LDS_FLOATS * 4, s, xin, xout, P, T, addend);
+int launch_gtcn_band(const float* xin, float* xout, const float* P, int B, int T, const int* lens, const float* addend,
+                     hipStream_t s) {
+    hipLaunchKernelGGL(k_gtcn_band, dim3(B), dim3(NTHR), GB_LDS_FLOATS * 4, s, xin, xout, P, T, lens, addend);
     GT_LAUNCH_CHECK();
     return 0;
 }
 
 int launch_decoder(const float* xg, const float* en0, const float* en1, const float* en2, const float* en3,
                    const float* en4, const float* spec, long sb, long sf, long st, float* out, long osb, long osf,
-                   long ost, int B, int T, const float* PF, const int* PI, float* state, float* dbg,
+                   long ost, int B, int T, const int* lens, const float* PF, const int* PI, float* state, float* dbg,
                    unsigned long long* stamps, hipStream_t s) {
 #define GT_DEC(DBGV, TPWV)                                                                                         \
     hipLaunchKernelGGL((k_decoder<DBGV, TPWV>), dim3(B), dim3(NTHR), DEC_LDS_FLOATS * 4, s, xg, en0, en1, en2, en3, \
-                       en4, spec, sb, sf, st, out, osb, osf, ost, T, PF, PI, state, dbg, stamps)
+                       en4, spec, sb, sf, st, out, osb, osf, ost, T, lens, PF, PI, state, dbg, stamps)
     if (T <= SHORT_T) {
         if (dbg) GT_DEC(true, 1); else GT_DEC(false, 1);
     } else if (T <= SHORT_T2) {

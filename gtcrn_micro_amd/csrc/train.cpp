@@ -373,14 +373,19 @@ int gtcrn_trainer_create(gtcrn_trainer** out, int device) {
     gtcrn_trainer* t = new gtcrn_trainer();
     t->device = device;
     for (const auto& p : gtcrn::param_table()) t->off[p.name] = p.offset;
-    T_HIP(hipMalloc(&t->fscratch, sizeof(float) * gtt::MAX_PARTIALS * (9 * 256 + 16)));
-    T_HIP(hipMalloc(&t->dscratch, sizeof(double) * gtt::MAX_PARTIALS * 3 * 16 + 256));
+    hipError_t e = hipMalloc(&t->fscratch, sizeof(float) * gtt::MAX_PARTIALS * (9 * 256 + 16));
+    if (e == hipSuccess) e = hipMalloc(&t->dscratch, sizeof(double) * gtt::MAX_PARTIALS * 3 * 16 + 256);
+    if (e != hipSuccess) {
+        gtcrn_trainer_destroy(t);
+        return tfail(GTCRN_ERR_HIP, std::string("gtcrn_trainer_create: hipMalloc: ") + hipGetErrorString(e));
+    }
     *out = t;
     return 0;
 }
 
 void gtcrn_trainer_destroy(gtcrn_trainer* t) {
     if (!t) return;
+    (void)hipSetDevice(t->device);
     if (t->arena) (void)hipFree(t->arena);
     if (t->fscratch) (void)hipFree(t->fscratch);
     if (t->dscratch) (void)hipFree(t->dscratch);
@@ -399,6 +404,7 @@ int gtcrn_train_forward(gtcrn_trainer* t, float* d_params, const float* d_spec, 
                         float* d_out, long ob, long of, long ot, int B, int T, void* stream) {
     if (!t || !d_params || !d_spec || !d_out || B < 1 || T < 1)
         return tfail(GTCRN_ERR_ARG, "gtcrn_train_forward: bad argument");
+    T_HIP(hipSetDevice(t->device));
     hipStream_t s = (hipStream_t)stream;
     int rc = ensure_plan(t, B, T);
     if (rc) return rc;
@@ -440,6 +446,7 @@ int gtcrn_train_backward(gtcrn_trainer* t, const float* d_params, const float* d
     if (!t || !d_params || !d_spec || !d_grad_out || !d_grads)
         return tfail(GTCRN_ERR_ARG, "gtcrn_train_backward: bad argument");
     if (!t->have_fwd) return tfail(GTCRN_ERR_STATE, "gtcrn_train_backward: no forward pass to differentiate");
+    T_HIP(hipSetDevice(t->device));
     hipStream_t s = (hipStream_t)stream;
     const int B = t->B, T = t->T;
     const float* prm = d_params;
@@ -496,6 +503,7 @@ int gtcrn_train_loss(gtcrn_trainer* t, const float* d_pred, long pb, long pf, lo
     if (((pb | pf | pt | tb | tf | tt) & 1) || (reinterpret_cast<uintptr_t>(d_pred) & 7) ||
         (reinterpret_cast<uintptr_t>(d_true) & 7))
         return tfail(GTCRN_ERR_ARG, "gtcrn_train_loss: spectrograms must be 8-byte aligned with even strides");
+    T_HIP(hipSetDevice(t->device));
     hipStream_t s = (hipStream_t)stream;
     const long Lw = 256L * (T - 1);
     const size_t need = (size_t)2 * B * Lw + 2 * B + 64;
@@ -521,8 +529,8 @@ int gtcrn_train_loss(gtcrn_trainer* t, const float* d_pred, long pb, long pf, lo
     double* dwork = t->dscratch + 2 * gtt::MAX_PARTIALS;     // B * 25 doubles
     int parts = 0;
     T_RUN(gtt::hybrid_loss_spec(d_pred, pb, pf, pt, d_true, tb, tf, tt, B, T, d_grad, spec_partial, &parts, s));
-    T_RUN(gtk::launch_istft(d_pred, pb, pf, pt, B, T, t->d_win, tw, yp, s));
-    T_RUN(gtk::launch_istft(d_true, tb, tf, tt, B, T, t->d_win, tw, yt, s));
+    T_RUN(gtk::launch_istft(d_pred, pb, pf, pt, B, T, nullptr, t->d_win, tw, yp, s));
+    T_RUN(gtk::launch_istft(d_true, tb, tf, tt, B, T, nullptr, t->d_win, tw, yt, s));
     T_RUN(gtt::sisnr_terms(yp, yt, B, Lw, spec_partial, parts, (long)B * 257 * T, t->d_win, dwork, coef, d_loss,
                            d_grad != nullptr, s));
     if (d_grad)   // d_grad is contiguous (B,257,T,2): strides (257*T*2, T*2, 2)
@@ -533,6 +541,7 @@ int gtcrn_train_loss(gtcrn_trainer* t, const float* d_pred, long pb, long pf, lo
 int gtcrn_train_tap(gtcrn_trainer* t, const char* name, float* d_out, long* shape4, void* stream) {
     if (!t || !name) return tfail(GTCRN_ERR_ARG, "gtcrn_train_tap: bad argument");
     if (!t->have_fwd) return tfail(GTCRN_ERR_STATE, "gtcrn_train_tap: no forward pass yet");
+    T_HIP(hipSetDevice(t->device));
     auto it = t->taps.find(name);
     if (it == t->taps.end()) return tfail(GTCRN_ERR_ARG, std::string("gtcrn_train_tap: unknown stage ") + name);
     const std::vector<int>& sh = it->second.second;   // T', F, C

@@ -4,8 +4,13 @@ Same contract as ``infer.py:26-119``: every ``*.wav`` of the noisy folder (sorte
 checkpoint, length-matched to its clean reference (zero-pad / crop, ``:98-102``), written as
 ``<uid>_enh.wav`` and listed in ``inf.scp`` / ``ref.scp`` (``:113-119``).  Differences, all on the host side:
 
-* clips of equal length are batched through one fused wave->wave call (STFT -> model -> iSTFT on the GPU);
-* several GPUs shard the sorted file list (one process per GPU, no collective; ``sharding.shard_range``);
+* clips of ANY lengths are packed (sorted by length, so a batch holds similar ones) into full batches and go through
+  one fused wave->wave launch sequence with per-clip lengths (``gtcrn_forward_wave_var``: STFT -> model -> iSTFT on
+  the GPU, each clip bit-identical to its own single-clip result); every batch is written as soon as it is enhanced;
+* several GPUs shard the sorted file list (one process per GPU, no collective; ``sharding.shard_range``); rank 0
+  merges the per-rank lists into the single ``inf.scp`` / ``ref.scp`` the reference's eval expects;
+* a clip shorter than 257 samples cannot be reflect-padded by 256 (``torch.stft`` raises there too): it is skipped
+  with a warning instead of aborting the folder;
 * WAV I/O uses ``scipy.io.wavfile`` (16-bit PCM out, what libsndfile writes for the reference); a file that
   is not 16 kHz raises instead of being resampled (the reference needs librosa for that, ``:55-57``);
 * configuration comes from command-line flags (the reference reads two OmegaConf YAML files, ``:27-28``).
@@ -35,6 +40,8 @@ def read_wav_f32(path):
         x = x.astype(np.float32) / 32768.0
     elif x.dtype == np.int32:
         x = x.astype(np.float32) / 2147483648.0
+    elif x.dtype == np.uint8:                      # 8-bit PCM is unsigned with an offset of 128
+        x = (x.astype(np.float32) - 128.0) / 128.0
     else:
         x = x.astype(np.float32)
     return fs, x
@@ -55,60 +62,99 @@ def load_params(checkpoint):
     return state_dict_to_blob(ck["model"] if "model" in ck else ck)
 
 
-def enhance_folder(noisy_dir, clean_dir, enh_dir, checkpoint, device=0, max_batch=64, rank=0, world=1):
+MIN_SAMPLES = 257      # reflect padding by 256 needs more than 256 samples (torch.stft raises below that, infer.py:60)
+
+
+def _clip_info(noisy_dir, clean_dir, wav_name):
+    """(path, reference path, clean length) of one noisy clip; the checks of infer.py:52-96."""
+    from scipy.io import wavfile
+    path = os.path.join(noisy_dir, wav_name)
+    fileid = extract_fileid(path)
+    if fileid is None:
+        raise RuntimeError(f"Unable to extract: {path}")
+    ref_path = os.path.join(clean_dir, f"clean_fileid_{fileid}.wav")
+    if not os.path.exists(ref_path):
+        raise FileNotFoundError(f"Clean file not found for clean_fileid_{fileid}.wav, fileid={fileid}:\n {ref_path}")
+    fs_c, clean = wavfile.read(ref_path, mmap=True)
+    if fs_c != 16000:
+        raise AssertionError(f"{ref_path}: sample rate {fs_c} != 16000")
+    return path, ref_path, int(clean.shape[0])
+
+
+def merge_scp(enh_dir, world):
+    """inf.scp.rank{r} / ref.scp.rank{r} -> inf.scp / ref.scp in rank order (= sorted file order)."""
+    for fname in ("inf.scp", "ref.scp"):
+        with open(os.path.join(enh_dir, fname), "w") as out:
+            for r in range(world):
+                with open(os.path.join(enh_dir, f"{fname}.rank{r}")) as f:
+                    out.write(f.read())
+
+
+def enhance_folder(noisy_dir, clean_dir, enh_dir, checkpoint, device=0, max_batch=64, rank=0, world=1,
+                   barrier=None):
+    """barrier: a callable all ranks call once their lists are written (multi-GPU runs; main() passes
+    torch.distributed.barrier); rank 0 then merges the per-rank scp files."""
+    import warnings
+
     import torch
     from . import Engine
     from .sharding import shard_range
 
     os.makedirs(enh_dir, exist_ok=True)
     eng = Engine(load_params(checkpoint), device)
-    win = torch.hann_window(512).pow(0.5).to(f"cuda:{device}")      # infer.py:65
+    dev = f"cuda:{device}"
+    win = torch.hann_window(512).pow(0.5).to(dev)                   # infer.py:65
     names = sorted(f for f in os.listdir(noisy_dir) if f.endswith("wav"))
     lo, hi = shard_range(len(names), world, rank)
+    # pass 1 (headers only): pair every clip with its reference, learn the lengths
+    from scipy.io import wavfile
     items = []
     for wav_name in names[lo:hi]:
-        path = os.path.join(noisy_dir, wav_name)
-        fs, x = read_wav_f32(path)
+        path, ref_path, n_clean = _clip_info(noisy_dir, clean_dir, wav_name)
+        fs, x = wavfile.read(path, mmap=True)
         if fs != 16000:
             raise AssertionError(f"{path}: sample rate {fs} != 16000 (resampling is not part of this path)")
-        fileid = extract_fileid(path)
-        if fileid is None:
-            raise RuntimeError(f"Unable to extract: {path}")
-        ref_path = os.path.join(clean_dir, f"clean_fileid_{fileid}.wav")
-        if not os.path.exists(ref_path):
-            raise FileNotFoundError(f"Clean file not found for clean_fileid_{fileid}.wav, fileid={fileid}:\n {ref_path}")
-        fs_c, clean = read_wav_f32(ref_path)
-        if fs_c != fs:
-            raise AssertionError(f"{ref_path}: sample rate {fs_c} != {fs}")
-        items.append((wav_name, x, ref_path, len(clean)))
-    # batch clips of equal length through one fused call
-    by_len = {}
-    for i, it in enumerate(items):
-        by_len.setdefault(len(it[1]), []).append(i)
-    enhanced = [None] * len(items)
-    for L, idxs in by_len.items():
-        for k in range(0, len(idxs), max_batch):
-            sel = idxs[k:k + max_batch]
-            wave = torch.from_numpy(np.stack([items[i][1] for i in sel])).to(f"cuda:{device}")
-            y = eng.forward_wave(wave, win).cpu().numpy()
-            for j, i in enumerate(sel):
-                enhanced[i] = y[j]
-    inf_scp, ref_scp = [], []
-    for (wav_name, _, ref_path, n_clean), y in zip(items, enhanced):
-        if y.shape[0] < n_clean:                                   # infer.py:98-102
-            y = np.pad(y, (0, n_clean - y.shape[0]), mode="constant")
-        elif y.shape[0] > n_clean:
-            y = y[:n_clean]
-        uid = wav_name.split(".wav")[0]
-        enh_path = os.path.join(enh_dir, uid + "_enh.wav")
-        write_wav_pcm16(enh_path, y)
-        inf_scp.append((uid, enh_path))
-        ref_scp.append((uid, ref_path))
+        if x.shape[0] < MIN_SAMPLES:
+            warnings.warn(f"{path}: {x.shape[0]} samples < {MIN_SAMPLES}, cannot be reflect-padded: skipped")
+            continue
+        items.append((wav_name, path, ref_path, n_clean, int(x.shape[0])))
+    # pass 2: batches of similar lengths, each through one launch sequence, written as soon as it is done
+    order = sorted(range(len(items)), key=lambda i: items[i][4])
+    rows = {}
+    for k in range(0, len(order), max_batch):
+        sel = order[k:k + max_batch]
+        waves = [read_wav_f32(items[i][1])[1] for i in sel]
+        lens = [len(w) for w in waves]
+        Lmax = max(lens)
+        if min(lens) == Lmax:
+            y = eng.forward_wave(torch.from_numpy(np.stack(waves)).to(dev), win).cpu().numpy()
+        else:
+            host = np.zeros((len(sel), Lmax), np.float32)
+            for j, w in enumerate(waves):
+                host[j, :len(w)] = w
+            y = eng.forward_wave_var(torch.from_numpy(host).to(dev), lens, win).cpu().numpy()
+        for j, i in enumerate(sel):
+            wav_name, _, ref_path, n_clean, L = items[i]
+            yj = y[j, :256 * (L // 256)]
+            if yj.shape[0] < n_clean:                               # infer.py:98-102
+                yj = np.pad(yj, (0, n_clean - yj.shape[0]), mode="constant")
+            elif yj.shape[0] > n_clean:
+                yj = yj[:n_clean]
+            uid = wav_name.split(".wav")[0]
+            enh_path = os.path.join(enh_dir, uid + "_enh.wav")
+            write_wav_pcm16(enh_path, yj)
+            rows[i] = (uid, enh_path, ref_path)
+    inf_scp = [(rows[i][0], rows[i][1]) for i in range(len(items))]   # sorted file order, like the reference
+    ref_scp = [(rows[i][0], rows[i][2]) for i in range(len(items))]
     suffix = "" if world == 1 else f".rank{rank}"
-    for fname, rows in (("inf.scp", inf_scp), ("ref.scp", ref_scp)):
+    for fname, lst in (("inf.scp", inf_scp), ("ref.scp", ref_scp)):
         with open(os.path.join(enh_dir, fname + suffix), "w") as f:
-            for uid, p in rows:
+            for uid, p in lst:
                 f.write(f"{uid} {p}\n")
+    if world > 1 and barrier is not None:
+        barrier()
+        if rank == 0:
+            merge_scp(enh_dir, world)
     return inf_scp, ref_scp
 
 
@@ -124,7 +170,15 @@ def main(argv=None):
     from .sharding import rank_world
     rank, local_rank, world = rank_world()
     dev = int(a.device) if a.device is not None else local_rank
-    enhance_folder(a.noisy_dir, a.clean_dir, a.enh_dir, a.checkpoint, dev, a.max_batch, rank, world)
+    barrier = None
+    if world > 1:
+        import torch.distributed as dist
+        from .sharding import init_distributed
+        init_distributed(None)
+        barrier = dist.barrier
+    enhance_folder(a.noisy_dir, a.clean_dir, a.enh_dir, a.checkpoint, dev, a.max_batch, rank, world, barrier)
+    if world > 1:
+        dist.destroy_process_group()
 
 
 if __name__ == "__main__":

@@ -2,7 +2,7 @@
 
 ``GTCRNMicro`` keeps the reference's public surface -- constructor arguments
 (accepted and ignored, models/gtcrn_micro.py:486-504), ``forward(spec)`` on a
-``(B,257,T,2)`` spectrogram (:506-532), the 391 ``state_dict`` keys of the shipped
+``(B,257,T,2)`` spectrogram (:506-532), the 388 ``state_dict`` keys of the shipped
 checkpoint, ``.eval()/.to()/.parameters()`` -- but owns no arithmetic: the torch
 sub-modules below are parameter containers only, and ``forward`` hands raw device
 pointers to the HIP library through the C ABI (include/gtcrn_micro_hip.h).
@@ -190,7 +190,11 @@ class _TrainStep(torch.autograd.Function):
             raise RuntimeError("backward of a train-mode forward that is no longer the most recent one: the HIP "
                                "trainer keeps the activations of one forward pass")
         (spec,) = ctx.saved_tensors
+        # a fresh buffer per backward (p.grad may still alias the previous one under gradient accumulation); the
+        # 248 returned gradients are views of it, so autograd leaves every p.grad pointing into ONE contiguous
+        # tensor in the canonical layout -- train.allreduce_gradients() moves it as a single RCCL message
         grads = model._trainer(spec.device).backward(model._flat, spec, grad_out)
+        model._grad_flat = grads
         return (None, None) + tuple(grads[o:o + n].view(shape) for o, n, shape in model._train_slices)
 
 
@@ -214,10 +218,23 @@ class GTCRNMicro(nn.Module):
         self._nbt_flat = None
         self._stats_dirty = False
         self._fwd_serial = 0
+        self._grad_flat = None  # gradient blob of the most recent backward (canonical layout)
+        self._sig_tensors = None
 
     # -- weight hand-over -------------------------------------------------------------------
+    def _state_tensors(self):
+        """The tensors behind the state_dict, collected once (walking 388 keys on every call costs more host time
+        than a streaming frame takes on the GPU); dropped whenever storages are re-created."""
+        if self._sig_tensors is None:
+            sd = self.state_dict(keep_vars=True)
+            self._sig_tensors = ([sd[name] for name, _, _ in _lib.param_table()],
+                                 [v for k, v in sd.items() if k.endswith("num_batches_tracked")])
+        return self._sig_tensors
+
     def _signature(self):
-        return (sum(int(t._version) for t in self.state_dict(keep_vars=True).values()), self._fwd_serial)
+        """Changes whenever a weight may have changed: in-place updates (optimiser steps, load_state_dict's copy_,
+        manual edits) bump the tensors' version counters; the train forward (running statistics) bumps the serial."""
+        return (sum(int(t._version) for t in self._state_tensors()[0]), self._fwd_serial)
 
     # -- train mode: flat parameter storage ----------------------------------------------------
     def _trainer(self, device):
@@ -258,12 +275,13 @@ class GTCRNMicro(nn.Module):
         if self._flat is None or self._flat.device != device:
             return False
         base = self._flat.data_ptr()
-        sd = self.state_dict(keep_vars=True)
-        return all(sd[name].data_ptr() == base + 4 * off for name, _, off in _lib.param_table())
+        return all(t.data_ptr() == base + 4 * off
+                   for t, (_, _, off) in zip(self._state_tensors()[0], _lib.param_table()))
 
     def _apply(self, fn, *args, **kwargs):
         out = super()._apply(fn, *args, **kwargs)     # .to()/.cuda()/.float() re-create the storages
         self._flat = None
+        self._sig_tensors = None
         return out
 
     def engine(self, device):
@@ -290,6 +308,7 @@ class GTCRNMicro(nn.Module):
         if any(k.startswith("module.") for k in state_dict):
             state_dict = {k[len("module."):]: v for k, v in state_dict.items()}
         out = super().load_state_dict(state_dict, strict=strict, assign=assign)
+        self._sig_tensors = None
         for idx, (eng, _) in list(self._engines.items()):
             self._engines[idx] = (eng, None)   # force a re-fold on next use
         return out

@@ -47,11 +47,34 @@ def make_training(config=None, device="cuda"):
     return model, opt, sched, HybridLoss().to(device)
 
 
+def _flat_gradient_blob(model):
+    """The contiguous gradient blob of the last HIP backward if every ``p.grad`` is (still) a view of it, else None."""
+    flat = getattr(model, "_grad_flat", None)
+    slices = getattr(model, "_train_slices", None)
+    params = getattr(model, "_train_params", None)
+    if flat is None or slices is None or params is None:
+        return None
+    base = flat.data_ptr()
+    for p, (off, numel, _) in zip(params, slices):
+        if p.grad is None or p.grad.data_ptr() != base + 4 * off or not p.grad.is_contiguous():
+            return None
+    return flat
+
+
 def allreduce_gradients(model, world_size):
-    """The one exchange step of data-parallel training: average the gradients of the 248 trainable tensors
-    over the ranks as ONE contiguous 19 014-float buffer (76 KB; latency-bound over xGMI)."""
+    """The one exchange step of data-parallel training (the reference gets it from DDP, train.py:87-88): average
+    the gradients over the ranks as ONE contiguous message.  After a HIP backward the 248 ``.grad``s are views of
+    the kernel's own gradient blob (canonical layout: 19 014 trainable floats + the zero slots of the buffers,
+    44 938 floats = 180 KB; latency-bound over xGMI), so the blob is all-reduced in place with no packing; gradients
+    that came from elsewhere (hand-set, accumulated) are packed and unpacked.  Returns the floats on the wire."""
     import torch.distributed as dist
-    ps = [p for p in model.parameters() if p.grad is not None]
+    m = model.module if hasattr(model, "module") else model
+    flat = _flat_gradient_blob(m)
+    if flat is not None:
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+        flat.mul_(1.0 / world_size)
+        return flat.numel()
+    ps = [p for p in m.parameters() if p.grad is not None]
     flat = torch.cat([p.grad.reshape(-1) for p in ps])
     dist.all_reduce(flat, op=dist.ReduceOp.SUM)
     flat /= world_size

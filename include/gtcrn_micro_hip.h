@@ -96,6 +96,13 @@ int gtcrn_forward_spec(gtcrn_model *m, const float *d_spec_in, long isb, long is
  * STFT -> forward -> iSTFT; d_wave (B,L) -> d_wave_out (B, 256*(L/256)). */
 int gtcrn_forward_wave(gtcrn_model *m, const float *d_wave, float *d_wave_out, int B, long L,
                        const float *d_win, void *stream);
+/* The same loop for B clips of DIFFERENT lengths in one launch sequence (infer.py:48-107 takes the clips of a
+ * folder one by one, whatever their lengths): row b of d_wave (B,Lmax) holds d_lengths[b] samples
+ * (device int32[B], 257 <= d_lengths[b] <= Lmax); row b of d_wave_out (B, 256*(Lmax/256)) receives its
+ * 256*(d_lengths[b]/256) enhanced samples -- bit-identical to gtcrn_forward_wave on that clip alone; the rest
+ * of the row is left untouched.  The caller guarantees the bounds (the lengths live in device memory). */
+int gtcrn_forward_wave_var(gtcrn_model *m, const float *d_wave, float *d_wave_out, int B, long Lmax,
+                           const int *d_lengths, const float *d_win, void *stream);
 
 /* ---- streaming ----------------------------------------------------------
  * Replaces StreamGTCRNMicro.forward(spec, conv_cache, tra_cache, tcn_cache)

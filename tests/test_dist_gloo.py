@@ -53,8 +53,8 @@ dist.destroy_process_group()
 """
 
 
-def _torchrun(args, timeout=300):
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1")
+def _torchrun(args, timeout=300, extra_env=None):
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1", **(extra_env or {}))
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
            "--master-addr", "127.0.0.1", "--master-port", str(_free_port())] + args
     return subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=timeout)
@@ -69,19 +69,53 @@ def test_two_ranks_shard_and_reduce(tmp_path):
     assert json.loads(line) == {"ok": True, "shard0": [0, 129]}
 
 
-def test_bench_control_flow_two_ranks():
-    """bench.py's N>1 path end to end (barrier + max over ranks + one JSON line from rank 0)."""
-    r = _torchrun([os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
-                   "--batch", "4", "--seconds", "0.5", "--cpu-stub"])
-    assert r.returncode == 0, r.stderr[-2000:]
-    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+def _check_bench_line(stdout, steps, warmup):
+    lines = [l for l in stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1                      # only rank 0 prints
     d = json.loads(lines[0])
-    assert d["n_gpus"] == 2 and d["steps"] == 3 and d["warmup"] == 1 and d["scaling"] == "weak"
+    assert d["n_gpus"] == 2 and d["steps"] == steps and d["warmup"] == warmup and d["scaling"] == "weak"
     assert d["unit"] == "frames/s" and d["higher_is_better"] is True and d["vs_baseline"] is None
     T = 1 + 8000 // 256
-    assert abs(d["value"] - 2 * 4 * T * 3 / (d["ms_per_step"] * 3 / 1e3)) / d["value"] < 1e-3
-    assert "cpu_baseline" not in d and "STUB" in d["data"]
+    assert abs(d["value"] - 2 * 4 * T * steps / (d["ms_per_step"] * steps / 1e3)) / d["value"] < 1e-3
+    assert "cpu_baseline" not in d and "TEST SHIM" in d["data"]
+    assert "stream" not in d and "train" not in d       # the secondary legs need the HIP engine
+
+
+_SHIM_ENV = {"GTCRN_BENCH_TEST_SHIM": os.path.join(ROOT, "tests", "bench_shim.py")}
+_BENCH_ARGS = ["--gpus", "2", "--steps", "3", "--warmup", "1", "--batch", "4", "--seconds", "0.5"]
+
+
+def test_bench_control_flow_two_ranks():
+    """bench.py's N>1 path under an external launcher (the driver's form): barrier + max over ranks + one JSON
+    line from rank 0."""
+    r = _torchrun([os.path.join(ROOT, "bench.py")] + _BENCH_ARGS, extra_env=_SHIM_ENV)
+    assert r.returncode == 0, r.stderr[-2000:]
+    _check_bench_line(r.stdout, 3, 1)
+
+
+def test_bench_launches_its_own_ranks():
+    """`python bench.py --gpus 2` WITHOUT torchrun starts two ranks itself and reports n_gpus == 2."""
+    env = dict(os.environ, OMP_NUM_THREADS="1", **_SHIM_ENV)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + _BENCH_ARGS, cwd=ROOT, env=env,
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    _check_bench_line(r.stdout, 3, 1)
+
+
+def test_bench_refuses_mislabelled_world():
+    """WORLD_SIZE=2 from the launcher but --gpus 4: non-zero exit, no JSON line."""
+    args = list(_BENCH_ARGS)
+    args[1] = "4"
+    r = _torchrun([os.path.join(ROOT, "bench.py")] + args, extra_env=_SHIM_ENV)
+    assert r.returncode != 0
+    assert not [l for l in r.stdout.splitlines() if l.startswith("{")]
+
+
+def test_bench_has_no_builtin_fake_engine():
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    assert "--cpu-stub" not in src and "class _Stub" not in src
 
 
 _GRAD_WORKER = r"""
@@ -94,6 +128,7 @@ from gtcrn_micro_amd.models.gtcrn_micro import GTCRNMicro
 rank, local_rank, world = init_distributed("gloo")
 m = GTCRNMicro()                       # parameter containers only: nothing is computed on the CPU
 g = torch.Generator().manual_seed(100 + rank)
+# (1) gradients that did not come from the HIP backward (hand-set): packed, reduced, unpacked
 for p in m.parameters():
     if p.requires_grad:
         p.grad = torch.randn(p.shape, generator=g)
@@ -104,19 +139,33 @@ dist.all_gather(both, mine)
 want = (both[0] + both[1]) / 2
 got = torch.cat([p.grad.reshape(-1) for p in m.parameters() if p.grad is not None])
 ok = bool(torch.allclose(got, want, atol=1e-6)) and n == 19014
+# (2) the layout the HIP backward leaves: every .grad is a view of ONE blob in the canonical order ->
+#     the blob itself is all-reduced in place, no cat / copy-back
+m._flatten(torch.device("cpu"))
+blob = torch.randn(44938, generator=g)
+m._grad_flat = blob
+for p, (off, numel, shape) in zip(m._train_params, m._train_slices):
+    p.grad = blob[off:off + numel].view(shape)
+mine = blob.clone()
+ptr = blob.data_ptr()
+n2 = allreduce_gradients(m, world)
+both = [torch.zeros_like(mine) for _ in range(world)]
+dist.all_gather(both, mine)
+ok2 = bool(torch.allclose(blob, (both[0] + both[1]) / 2, atol=1e-6)) and n2 == 44938 and blob.data_ptr() == ptr
+ok2 = ok2 and all(p.grad.data_ptr() == ptr + 4 * off for p, (off, _, _) in zip(m._train_params, m._train_slices))
 dist.barrier()
 if rank == 0:
-    print(json.dumps({"ok": ok, "floats": n}))
+    print(json.dumps({"ok": ok, "floats": n, "ok_flat": ok2, "floats_flat": n2}))
 dist.destroy_process_group()
 """
 
 
 def test_gradient_allreduce_two_ranks(tmp_path):
-    """The one exchange step of data-parallel training (train.py:87-88): the 19 014 gradient floats are
-    averaged over the ranks as one contiguous buffer."""
+    """The one exchange step of data-parallel training (train.py:87-88): the gradients are averaged over the ranks
+    as one contiguous message -- the kernel's own gradient blob when the .grads are views of it."""
     w = tmp_path / "grad_worker.py"
     w.write_text(_GRAD_WORKER)
     r = _torchrun([str(w), ROOT])
     assert r.returncode == 0, r.stderr[-2000:]
     line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
-    assert json.loads(line) == {"ok": True, "floats": 19014}
+    assert json.loads(line) == {"ok": True, "floats": 19014, "ok_flat": True, "floats_flat": 44938}

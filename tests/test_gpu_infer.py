@@ -79,3 +79,67 @@ def test_forward_wave_is_graph_capturable():
     g.replay()
     torch.cuda.synchronize()
     assert torch.equal(out, eng.forward_wave(wave, win))
+
+
+@pytest.mark.gpu
+def test_variable_length_batch_equals_single_clips_bit_for_bit(tmp_path):
+    """infer.py:48-107 takes the clips of a folder one by one whatever their lengths; here a mixed folder is packed into
+    full batches (gtcrn_forward_wave_var, per-clip lengths inside one launch sequence).  Every clip must equal its own
+    single-clip result BIT FOR BIT, for lengths on and off the 256-sample hop, around the 16-frame chunk and the
+    7-block iSTFT group boundaries, down to the minimum of 257 samples; the folder driver writes the same wavs."""
+    import warnings
+    from scipy.io import wavfile
+    from conftest import load_params
+    from gtcrn_micro_amd import Engine, GtcrnError
+    from gtcrn_micro_amd.infer import enhance_folder
+    from oracle import oracle as O
+    p = load_params("dns3")
+    eng = Engine(p, 0)
+    win = torch.hann_window(512, device="cuda").pow(0.5)
+    lens = [257, 511, 512, 256 * 7, 256 * 7 + 255, 256 * 8, 4095, 4096, 4097, 256 * 33 + 17, 256 * 49, 16000]
+    rng = np.random.default_rng(8)
+    clips = [(rng.standard_normal(L) * 0.1).astype(np.float32) for L in lens]
+    Lmax = max(lens)
+    host = np.full((len(lens), Lmax), np.nan, np.float32)      # the padding must never be read: poison it
+    for j, c in enumerate(clips):
+        host[j, :len(c)] = c
+    out = torch.full((len(lens), 256 * (Lmax // 256)), -7.0, device="cuda")
+    y = eng.forward_wave_var(torch.from_numpy(host).cuda(), lens, win, out=out)
+    orc = O.Oracle(p)
+    for j, (c, L) in enumerate(zip(clips, lens)):
+        single = eng.forward_wave(torch.from_numpy(c).cuda(), win)
+        n = 256 * (L // 256)
+        assert single.shape[0] == n
+        assert torch.equal(y[j, :n], single), (j, L)
+        assert bool((y[j, n:] == -7.0).all())                  # the rest of the row is left untouched
+        if L in (257, 4097, 16000):
+            ref = orc.enhance(c[None])[0]
+            assert np.abs(single.cpu().numpy() - ref).max() / max(np.abs(ref).max(), 1e-9) < 1e-4
+    with pytest.raises(GtcrnError):
+        eng.forward_wave_var(torch.from_numpy(host).cuda(), [256] + lens[1:], win)       # too short to reflect-pad
+    with pytest.raises(GtcrnError):
+        eng.forward_wave_var(torch.from_numpy(host).cuda(), lens[:-1] + [Lmax + 1], win)
+    with pytest.raises(GtcrnError):
+        eng.forward_wave(torch.from_numpy(host).cuda(), win, out=torch.empty(3, 5, device="cuda"))   # wrong-sized out
+    # the folder driver: 8 clips of 8 different lengths (+ one too short to process) in batches of 4
+    noisy_dir, clean_dir, enh_dir = tmp_path / "noisy", tmp_path / "clean", tmp_path / "enh"
+    noisy_dir.mkdir(); clean_dir.mkdir()
+    pcm = [np.clip(np.rint(c * 32768), -32768, 32767).astype(np.int16) for c in clips[3:11]]
+    for k, x in enumerate(pcm):
+        wavfile.write(noisy_dir / f"n_fileid_{k}.wav", 16000, x)
+        wavfile.write(clean_dir / f"clean_fileid_{k}.wav", 16000, np.zeros(len(x), np.int16))
+    wavfile.write(noisy_dir / "n_fileid_99.wav", 16000, np.zeros(100, np.int16))
+    wavfile.write(clean_dir / "clean_fileid_99.wav", 16000, np.zeros(100, np.int16))
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        inf, _ = enhance_folder(str(noisy_dir), str(clean_dir), str(enh_dir), os.path.join(GOLDEN, "params_dns3.f32"),
+                                device=0, max_batch=4)
+    assert any("skipped" in str(x.message) for x in w)
+    assert [u for u, _ in inf] == [f"n_fileid_{k}" for k in range(8)]
+    for k, x in enumerate(pcm):
+        single = eng.forward_wave(torch.from_numpy(x.astype(np.float32) / 32768.0).cuda(), win).cpu().numpy()
+        want = np.zeros(len(x), np.float32)
+        want[:len(single)] = single
+        want = np.clip(np.rint(want * 32768.0), -32768, 32767).astype(np.int16)
+        _, got = wavfile.read(enh_dir / f"n_fileid_{k}_enh.wav")
+        assert np.array_equal(got, want), k

@@ -167,3 +167,54 @@ def test_stream_conv1d_streaming_equals_offline(dev):
             outs.append(o)
         assert np.abs(torch.cat(outs, 2).cpu().numpy() - want).max() < 1e-5
         assert torch.equal(cache.cpu(), x[:, :, 20 - H:])
+
+
+def test_config3_shape_1024_streams_single_frame_calls(dev):
+    """BASELINE configs[2] at its own shape: 1024 concurrent streams, one 16 ms frame per call (the loop of
+    gtcrn_micro_stream.py:618-635 with the state left on the device), 24 calls.  A sample of streams is checked against
+    the CPU oracle run frame by frame with its own caches; ALL streams against the offline forward of the same frames
+    (streaming == offline is the reference's own contract, tests/streaming/...); a batch of 1024 equals the same
+    streams run in batches of 64 bit for bit (4 workgroup rounds per launch must not leak between streams)."""
+    from gtcrn_micro_amd import Engine
+    from oracle import oracle as O
+    p = load_params("dns3")
+    eng = Engine(p, 0)
+    N, T = 1024, 24
+    gen = torch.Generator(device="cuda").manual_seed(1024)
+    spec = (torch.randn(N, T, 257, 2, device="cuda", generator=gen) * 0.3).permute(0, 2, 1, 3)   # frame-major storage
+    spec[5] = 0.0                                        # one silent stream
+    spec[6] *= 30.0                                      # one hot stream
+    st = eng.new_state(N)
+    outs = [eng.stream_step(st, spec[:, :, t:t + 1]) for t in range(T)]
+    got = torch.cat(outs, 2)
+    assert got.shape == (N, 257, T, 2) and bool(torch.isfinite(got).all())
+    full = eng.forward_spec(spec.contiguous())
+    err = (got - full).abs().amax(dim=(1, 2, 3)) / full.abs().amax(dim=(1, 2, 3)).clamp_min(1e-20)
+    assert float(err.max()) < 2e-5, float(err.max())
+    # oracle: streams 0, 5 (silence), 6 (hot), 511, 1023, frame by frame with the reference cache layout
+    orc = O.Oracle(p)
+    for s in (0, 5, 6, 511, 1023):
+        x = spec[s:s + 1].contiguous().cpu().numpy()
+        states = O.new_states(1)
+        ref = np.concatenate([orc.forward(x[:, :, t:t + 1], states) for t in range(T)], axis=2)
+        if s == 5:
+            assert np.abs(got[s].cpu().numpy()).max() < 1e-6 and np.abs(ref).max() < 1e-6
+        else:
+            assert rel_err(got[s:s + 1].cpu().numpy(), ref) < TOL, s
+    # batch invariance: the same streams in 16 batches of 64
+    parts = []
+    for lo in range(0, N, 64):
+        st64 = eng.new_state(64)
+        parts.append(torch.cat([eng.stream_step(st64, spec[lo:lo + 64, :, t:t + 1]) for t in range(T)], 2))
+    assert torch.equal(torch.cat(parts, 0), got)
+    # the exported caches of stream 1023 equal the oracle's after the same 24 frames
+    conv = torch.zeros(2, N, 16, 6, 33, device="cuda")
+    tra = torch.zeros(2, 3, N, 8, 2, device="cuda")
+    tcn = [[torch.zeros(N, 16, 2 * d, 33, device="cuda") for d in (1, 2, 4, 8)] for _ in range(2)]
+    eng.stream_export(st, conv, tra, tcn)
+    oc, ot, otcn = O.state_views(states[0])
+    assert rel_err(conv[:, 1023].cpu().numpy(), oc) < TOL
+    assert rel_err(tra[:, :, 1023].cpu().numpy(), ot) < TOL
+    for g in range(2):
+        for k in range(4):
+            assert rel_err(tcn[g][k][1023].cpu().numpy(), otcn[g][k]) < TOL, (g, k)

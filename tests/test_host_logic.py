@@ -170,3 +170,82 @@ def test_packer_under_address_and_ub_sanitizers(tmp_path):
         r = subprocess.run([exe, os.path.join(ROOT, "tests", "golden", f"params_{tag}.f32")], capture_output=True,
                            text=True, timeout=300)
         assert r.returncode == 0 and "asan_pack_driver ok" in r.stdout, (r.returncode, r.stderr[-3000:])
+
+
+def test_convert_to_stream_weight_contract_on_cpu():
+    """convert_to_stream is a state-dict remap (no arithmetic): every wrapper infix resolves, a ConvTranspose2d
+    weight becomes W'[o,i,a,b] = W[i,o,kT-1-a,kF-1-b] (convert.py:35-48, frozen in conv_wrappers.npz from the
+    reference's own function), an unmatched key raises ValueError("Key error!") (:54)."""
+    import torch
+    import torch.nn as nn
+    from conftest import golden
+    from gtcrn_micro_amd.streaming.conversion.convert import convert_to_stream
+    from gtcrn_micro_amd.streaming.conversion.convolution import StreamConv1d, StreamConv2d, StreamConvTranspose2d
+    g = golden("conv_wrappers.npz")
+    de = nn.ConvTranspose2d(4, 8, (3, 1), stride=(1, 1), padding=(4, 1), dilation=(2, 2))
+    with torch.no_grad():
+        de.weight.copy_(torch.from_numpy(g["ct2d_w"])); de.bias.copy_(torch.from_numpy(g["ct2d_b"]))
+    sde = StreamConvTranspose2d(4, 8, (3, 1), stride=(1, 1), padding=(0, 1), dilation=(2, 2))
+    convert_to_stream(sde, de)
+    assert np.array_equal(sde.ConvTranspose2d.weight.detach().numpy(), g["ct2d_w_stream"])
+    assert np.array_equal(sde.ConvTranspose2d.bias.detach().numpy(), g["ct2d_b"])
+    c2, s2 = nn.Conv2d(2, 3, 3), StreamConv2d(2, 3, 3)
+    convert_to_stream(s2, c2)
+    assert torch.equal(s2.Conv2d.weight, c2.weight) and torch.equal(s2.Conv2d.bias, c2.bias)
+    c1, s1 = nn.Conv1d(4, 4, 3, groups=4), StreamConv1d(4, 4, 3, groups=4)
+    convert_to_stream(s1, c1)
+    assert torch.equal(s1.Conv1d.weight, c1.weight)
+    with pytest.raises(ValueError, match="Key error!"):
+        convert_to_stream(s2, nn.Sequential(nn.Conv2d(2, 3, 3)))      # keys '0.weight', '0.bias'
+
+
+REF_CKPT = os.path.join(GOLDEN, "ckpt_ref", "model_002.tar")
+
+
+def test_reference_written_checkpoint_loads(tmp_path):
+    """A checkpoint written by the REFERENCE's own Trainer._save_checkpoint (train.py:200-221; fixture generator
+    tests/golden/make_golden_ckpt.py) resumes here: epoch, Adam state, schedule position and all 388 model keys
+    (counterpart of Trainer._resume_checkpoint, :223-237); written back with save_checkpoint it is the same dict."""
+    import torch
+    from gtcrn_micro_amd.models.gtcrn_micro import GTCRNMicro
+    from gtcrn_micro_amd.train import load_checkpoint, save_checkpoint
+    from gtcrn_micro_amd.utils.scheduler import LinearWarmupCosineAnnealingLR
+    io = np.load(os.path.join(GOLDEN, "ckpt_ref_io.npz"))
+    ck = torch.load(REF_CKPT, map_location="cpu", weights_only=False)
+    assert sorted(ck) == ["epoch", "model", "optimizer", "scheduler"] and len(ck["model"]) == 388 == int(io["n_keys"])
+    m = GTCRNMicro()
+    opt = torch.optim.Adam(m.parameters(), lr=1e-3)
+    sch = LinearWarmupCosineAnnealingLR(opt, 25000, 250000, 1e-3, 1e-6)
+    assert load_checkpoint(REF_CKPT, m, opt, sch) == 3                 # start_epoch = epoch + 1
+    sd = m.state_dict()
+    assert list(sd) == list(ck["model"])                              # same keys, same order
+    assert all(torch.equal(sd[k], ck["model"][k]) for k in sd)
+    assert abs(opt.param_groups[0]["lr"] - float(io["lr"])) < 1e-15 and sch.last_epoch == 2
+    st = opt.state_dict()["state"]
+    assert len(st) == 248 and all(float(v["step"]) == float(io["adam_step"]) for v in st.values())
+    ref_st = ck["optimizer"]["state"]
+    assert all(torch.equal(st[i]["exp_avg"], ref_st[i]["exp_avg"]) and
+               torch.equal(st[i]["exp_avg_sq"], ref_st[i]["exp_avg_sq"]) for i in ref_st)
+    # write it back: the reference's reader (torch.load + the same four keys) sees identical content
+    out = str(tmp_path / "model_003.tar")
+    save_checkpoint(out, m, opt, sch, 2)
+    ck2 = torch.load(out, map_location="cpu", weights_only=False)
+    assert ck2["epoch"] == ck["epoch"] and list(ck2["model"]) == list(ck["model"])
+    assert all(torch.equal(ck2["model"][k], ck["model"][k]) for k in ck["model"])
+    assert ck2["scheduler"]["last_epoch"] == ck["scheduler"]["last_epoch"]
+    assert ck2["optimizer"]["param_groups"][0]["lr"] == ck["optimizer"]["param_groups"][0]["lr"]
+
+
+def test_infer_host_helpers(tmp_path):
+    """Host side of the bulk driver: 8-bit PCM is unsigned with offset 128; the per-rank scp lists merge in rank order."""
+    from scipy.io import wavfile
+    from gtcrn_micro_amd.infer import extract_fileid, merge_scp, read_wav_f32
+    wavfile.write(tmp_path / "u8.wav", 16000, np.array([0, 128, 255, 64], np.uint8))
+    fs, x = read_wav_f32(str(tmp_path / "u8.wav"))
+    assert fs == 16000 and np.allclose(x, [-1.0, 0.0, 127 / 128, -0.5])
+    assert extract_fileid("/a/b/x_snr5_fileid_12.wav") == "12" and extract_fileid("nope.wav") is None
+    for r, rows in enumerate((["a 1", "b 2"], ["c 3"])):
+        for f in ("inf.scp", "ref.scp"):
+            (tmp_path / f"{f}.rank{r}").write_text("".join(x + "\n" for x in rows))
+    merge_scp(str(tmp_path), 2)
+    assert (tmp_path / "inf.scp").read_text() == "a 1\nb 2\nc 3\n" == (tmp_path / "ref.scp").read_text()
