@@ -95,7 +95,7 @@ def test_variable_length_batch_equals_single_clips_bit_for_bit(tmp_path):
     from oracle import oracle as O
     p = load_params("dns3")
     eng = Engine(p, 0)
-    win = torch.hann_window(512, device="cuda").pow(0.5)
+    win = torch.hann_window(512).pow(0.5).cuda()      # computed on the host like infer.py:65 (and enhance_folder)
     lens = [257, 511, 512, 256 * 7, 256 * 7 + 255, 256 * 8, 4095, 4096, 4097, 256 * 33 + 17, 256 * 49, 16000]
     rng = np.random.default_rng(8)
     clips = [(rng.standard_normal(L) * 0.1).astype(np.float32) for L in lens]
