@@ -24,11 +24,14 @@ def _stale(target, deps):
 def build_native(force=False, verbose=False, stamps=False):
     """stamps=True builds the diagnostic variant libgtcrn_micro_hip_stamps.so (-DGT_STAMPS: in-kernel
     s_memtime phase stamps, used only by tools/phase_profile.py; never loaded by the product path)."""
-    deps = [os.path.join(CSRC, f) for f in SOURCES + HEADERS]
+    deps = [os.path.join(CSRC, f) for f in SOURCES + HEADERS] + [os.path.abspath(__file__)]   # the flags live here
     objs = []
     # -fno-honor-nans: keeps hipcc from canonicalising (v_max x,x) in front of every v_min/v_max of the
     # PReLU; no kernel tests for or produces NaN on finite input
-    common = ["-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-result", "-fno-honor-nans"]
+    # -ffp-contract=on: multiply-adds are fused per source expression (by the front end), not opportunistically by
+    # the back end: every instantiation of a kernel template (one/two/three tiles per wave, offline / streaming /
+    # multi-stream) then rounds identically, which is what makes streamed == chunked == offline hold BIT FOR BIT
+    common = ["-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-result", "-fno-honor-nans", "-ffp-contract=on"]
     suffix = ""
     lib = LIB
     if stamps:

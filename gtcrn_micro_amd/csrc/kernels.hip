@@ -444,17 +444,37 @@ struct BlockCtx {
     float* sS;           // LDS: v^2, [position][16 slots], 33 positions per frame
     float* sG;           // LDS: gates [frame][16 slots]
     float* sEHk;         // LDS: 2-entry ring of e: [frame & 1][8]
-    float* sE;           // LDS: energies of the chunk, [2 + TC][8] (rows 0,1: the two frames before it)
-    int nfr;             // frames in this chunk
+    float* sE;           // LDS: energies of the chunk, [2 + TC][8] (rows 0,1: the two frames before it);
+                         //      multi-stream mode: [row][3][8] = frames t-2, t-1, t of each row's stream
+    float* sY;           // LDS: scratch [rows][8] behind the gate table
+    int nfr;             // frames in this chunk (multi-stream mode: live streams of this workgroup)
     int tabs;            // absolute frame index of the chunk's first frame
+    // multi-stream mode (MS): image row r holds the ONE new frame of stream r, so every temporal tap comes from that
+    // stream's own ring and nothing is shared between rows
+    int ms_roff;         // per lane: float offset from sW to this block's h ring of the lane's stream
+    int ms_tb;           // per lane: frame counter of the lane's stream
+    const int* sTB;      // LDS: frame counter per row
 };
+
+// multi-stream geometry of the single-frame streaming step: MS_STREAMS streams per workgroup = rows 0..3 of the
+// tile geometry; one tile per wave covers rows 0..5, so the images carry MS_ROWS rows (rows 4, 5 are never stored)
+constexpr int MS_STREAMS = 4;
+constexpr int MS_ROWS = 6;
+constexpr int RING_SET = 3 * 2 * 35 * 16;   // floats of one stream's three 2-row h rings in LDS
 
 // `hook` runs right after the depth-conv phase (register pressure is past its peak there, and two
 // barrier intervals of work follow): the decoder uses it to request inputs of later phases early.
-template <bool DENSE, int TPW, class Hook>
+template <bool DENSE, int TPW, bool MS, class Hook>
 __device__ __forceinline__ void gtconv_block(f32x4 (&x)[TPW], const Tiles<TPW>& tt, const BlockCtx& c,
                                              const Lane& L, Hook&& hook STAMP_PARAM) {
+    static_assert(!MS || TPW == 1, "multi-stream mode runs one tile per wave");
     const int n = L.n, g = L.g;
+    // float offset (from sW) of the record `back` frames before tile i's own position b0
+    auto tap_base = [&](int i, int back, int b0, int ringoff) -> int {
+        if (back == 0) return b0;
+        if constexpr (MS) return c.ms_roff + (((c.ms_tb + back) & 1) * 35 + 1 + tt.ff[i]) * 16 + 4 * g;
+        else return tt.tl[i] >= back ? b0 - back * 35 * 16 : ringoff + ring35(tt, i, g, c.tabs, back);
+    };
     const float a1 = c.pb[GB_SLOPE] - 1.0f, a2 = c.pb[GB_SLOPE + 1] - 1.0f;
     // ---- point_conv1 + BN + PReLU; h lives only in the LDS image from here on (its centre tap and the
     //      ring update re-read it: one ds_read_b128 each instead of 12 registers held across the phase) ----
@@ -492,8 +512,7 @@ __device__ __forceinline__ void gtconv_block(f32x4 (&x)[TPW], const Tiles<TPW>& 
 #pragma unroll
                 for (int i = 0; i < TPW; ++i) {
                     const int b0 = o35(tt, i, g);
-                    const int rb = back == 0 ? b0
-                                 : (tt.tl[i] >= back ? b0 - back * 35 * 16 : (int)ringoff + ring35(tt, i, g, c.tabs, back));
+                    const int rb = tap_base(i, back, b0, (int)ringoff);
                     acc[i] += w0 * ld4(c.sW + rb - 16) + w1 * ld4(c.sW + rb) + w2 * ld4(c.sW + rb + 16);
                 }
             }
@@ -521,8 +540,7 @@ __device__ __forceinline__ void gtconv_block(f32x4 (&x)[TPW], const Tiles<TPW>& 
 #pragma unroll
                     for (int i = 0; i < TPW; ++i) {
                         const int b0 = o35(tt, i, g);
-                        const int rb = back == 0 ? b0
-                                     : (tt.tl[i] >= back ? b0 - back * 35 * 16 : (int)ringoff + ring35(tt, i, g, c.tabs, back));
+                        const int rb = tap_base(i, back, b0, (int)ringoff);
                         const f32x4 tap = ld4(c.sW + rb + df * 16);
 #pragma unroll
                         for (int s = 0; s < 4; ++s) acc[i] = mfma(A[s], tap[s], acc[i]);
@@ -548,9 +566,15 @@ __device__ __forceinline__ void gtconv_block(f32x4 (&x)[TPW], const Tiles<TPW>& 
     hook();
     // ---- history ring of h (after every wave has read its taps) -----------------------------------
 #pragma unroll
-    for (int i = 0; i < TPW; ++i)
-        if (tt.tl[i] < c.nfr && tt.tl[i] >= c.nfr - 2)
-            st4(c.sHk + ring35(tt, i, g, c.tabs, 2), ld4(c.sW + o35(tt, i, g)));
+    for (int i = 0; i < TPW; ++i) {
+        if constexpr (MS) {
+            if (tt.tl[i] < c.nfr)
+                st4(c.sW + c.ms_roff + ((c.ms_tb & 1) * 35 + 1 + tt.ff[i]) * 16 + 4 * g, ld4(c.sW + o35(tt, i, g)));
+        } else {
+            if (tt.tl[i] < c.nfr && tt.tl[i] >= c.nfr - 2)
+                st4(c.sHk + ring35(tt, i, g, c.tabs, 2), ld4(c.sW + o35(tt, i, g)));
+        }
+    }
     // ---- TRALite, step 1: energies e[t][c] = mean_F(v^2): 32 threads per frame = 8 h' channels x 4 bin
     //      ranges (9, 9, 9, 6 bins); the four partial sums of a channel sit in one DPP quad and are
     //      combined there in a fixed order (bit-reproducible).  Written to sE[2 + t][c]; rows 0,1 of sE
@@ -564,8 +588,11 @@ __device__ __forceinline__ void gtconv_block(f32x4 (&x)[TPW], const Tiles<TPW>& 
             for (int f = 0; f < cnt; ++f) sum += sp[f * 16];
             sum += dpp_ror<0xB1>(sum);   // quad_perm [1,0,3,2]
             sum += dpp_ror<0x4E>(sum);   // quad_perm [2,3,0,1]
-            if (part == 0) c.sE[(2 + rt) * 8 + rc] = sum * (1.0f / 33.0f);
-        } else if (L.tid >= NTHR - 16) {          // an otherwise idle wave copies the ring into rows 0,1
+            if (part == 0) c.sE[(MS ? rt * 3 + 2 : 2 + rt) * 8 + rc] = sum * (1.0f / 33.0f);
+        } else if (MS && L.tid >= NTHR - 64) {    // an otherwise idle wave copies every stream's ring into its rows 0,1
+            const int q = L.tid - (NTHR - 64), sidx = q >> 4, r = (q >> 3) & 1, cc = q & 7;
+            if (sidx < c.nfr) c.sE[(sidx * 3 + r) * 8 + cc] = c.sEHk[sidx * 48 + ((c.sTB[sidx] - 2 + r) & 1) * 8 + cc];
+        } else if (!MS && L.tid >= NTHR - 16) {   // an otherwise idle wave copies the ring into rows 0,1
             const int q = L.tid - (NTHR - 16), r = q >> 3, cc = q & 7;
             c.sE[r * 8 + cc] = c.sEHk[((c.tabs - 2 + r) & 1) * 8 + cc];
         }
@@ -576,12 +603,12 @@ __device__ __forceinline__ void gtconv_block(f32x4 (&x)[TPW], const Tiles<TPW>& 
     {
         const int ro = L.tid & 7, rt = L.tid >> 3;
         if (L.tid < c.nfr * 8) {
-            const float* e = c.sE + rt * 8 + ro;                 // rows rt, rt+1, rt+2 = frames t-2, t-1, t
+            const float* e = c.sE + (MS ? rt * 24 : rt * 8) + ro;    // rows rt, rt+1, rt+2 = frames t-2, t-1, t
             const float y = c.pb[GB_TRA_DB + ro] + c.pb[GB_TRA_DW + ro * 3] * e[0] +
                             c.pb[GB_TRA_DW + ro * 3 + 1] * e[8] + c.pb[GB_TRA_DW + ro * 3 + 2] * e[16];
             // the 8 channels of a frame sit in 8 adjacent lanes of one wave: exchange y through the
-            // (now dead) first rows of sG with wave-local ordering, no workgroup barrier
-            float* sy = c.sG + TC * 16 + rt * 8;                 // scratch behind the gate table
+            // scratch behind the gate table with wave-local ordering, no workgroup barrier
+            float* sy = c.sY + rt * 8;
             sy[ro] = y;
             wave_lds_sync();
             float z = c.pb[GB_TRA_PB + ro];
@@ -590,7 +617,8 @@ __device__ __forceinline__ void gtconv_block(f32x4 (&x)[TPW], const Tiles<TPW>& 
             c.sG[rt * 16 + c.ib[ro]] = __frcp_rn(1.0f + __expf(-z));
             c.sG[rt * 16 + c.ib[8 + ro]] = 1.0f;
             // the last two frames' energies become the ring for the next chunk (row = frame & 1)
-            if (rt >= c.nfr - 2) c.sEHk[((c.tabs + rt) & 1) * 8 + ro] = e[16];
+            if constexpr (MS) c.sEHk[rt * 48 + (c.sTB[rt] & 1) * 8 + ro] = e[16];
+            else if (rt >= c.nfr - 2) c.sEHk[((c.tabs + rt) & 1) * 8 + ro] = e[16];
         }
     }
     wg_barrier();
@@ -601,9 +629,10 @@ __device__ __forceinline__ void gtconv_block(f32x4 (&x)[TPW], const Tiles<TPW>& 
 
 // zero the two pad columns of the TC rows of a 35-position row image (tid and the zero are made
 // opaque so that neither is hoisted out of the chunk loop and kept live / spilled)
+template <int ROWS = TC>
 __device__ __forceinline__ void zero_row_pads(float* img, int tid) {
     asm volatile("" : "+v"(tid));
-    if (tid < TC * 2 * 4) {
+    if (tid < ROWS * 2 * 4) {
         const int r = tid >> 3, side = (tid >> 2) & 1, gg = tid & 3;
         float z = 0.f;
         asm volatile("" : "+v"(z));
@@ -651,26 +680,37 @@ __device__ __forceinline__ f32x4 permute_via_lds(float* scratch_rec, const int* 
 // -> en_convs.0/1 (ConvBlock :142-164, Conv2d (1,5) stride (1,2)) -> 3 x GTConvBlock (:365-393).
 // Writes the five skip tensors en0 (B,T,65,16) and en1..en4 (B,T,33,16); en1..en3 are written in
 // the slot order of the decoder stage that consumes them (layout.h I_ENST), en4 in its own order.
-constexpr int ENC_LDS_P = 0;
-constexpr int ENC_LDS_I = ENC_LDS_P + ENC_SIZE;
-constexpr int ENC_LDS_H = ENC_LDS_I + P_INTS;
-constexpr int ENC_LDS_EH = ENC_LDS_H + 3 * 2 * 35 * 16;
-constexpr int ENC_LDS_G = ENC_LDS_EH + 48;
-constexpr int ENC_LDS_E = ENC_LDS_G + TC * 16 + TC * 8;    // (gates [TC][16] + y scratch [TC][8]); energies [2 + TC][8]
-constexpr int ENC_LDS_A = ENC_LDS_E + (TC + 2) * 8;        // staged spec, then E0, then W + S
+// LDS carve of k_encoder: RW image rows (TC, or MS_ROWS in multi-stream mode), NS ring sets (streams per workgroup)
 constexpr int ENC_E0_ROW = 69;
-constexpr int ENC_LDS_B = ENC_LDS_A + TC * ENC_E0_ROW * 16;  // EB + F0
 constexpr int EB_ROW = 131, F0_ROW = 136;
-constexpr int ENC_LDS_FLOATS = ENC_LDS_B + 3 * TC * EB_ROW + 3 * TC * F0_ROW;
-static_assert(3 * TC * NBINS <= TC * ENC_E0_ROW * 16, "staged [mag,re,im] chunk must fit in the E0 region");
-static_assert(ENC_LDS_FLOATS * 4 <= 160 * 1024, "encoder LDS budget");
-static_assert(TC * 35 * 16 + TC * 33 * 16 <= TC * ENC_E0_ROW * 16, "W + S must fit in the E0 region");
-static_assert(ENC_LDS_I % 4 == 0 && ENC_LDS_H % 4 == 0 && ENC_LDS_G % 4 == 0 && ENC_LDS_A % 4 == 0, "16B carve");
+template <int RW, int NS, bool MS>
+struct EncLds {
+    static constexpr int P = 0;
+    static constexpr int I = P + ENC_SIZE;
+    static constexpr int H = I + P_INTS;
+    static constexpr int EH = H + NS * RING_SET;
+    static constexpr int TB = EH + NS * 48;                    // frame counter per row (ints; multi-stream mode)
+    static constexpr int G = TB + 8;
+    static constexpr int E = G + RW * 16 + RW * 8;             // (gates [RW][16] + y scratch [RW][8]); energies
+    static constexpr int A = E + (MS ? NS * 24 : (RW + 2) * 8);   // staged spec, then E0, then W + S
+    static constexpr int B = A + RW * ENC_E0_ROW * 16;         // EB + F0
+    static constexpr int FLOATS = B + 3 * RW * EB_ROW + 3 * RW * F0_ROW;
+    static_assert(3 * RW * NBINS <= RW * ENC_E0_ROW * 16, "staged [mag,re,im] chunk must fit in the E0 region");
+    static_assert(FLOATS * 4 <= 160 * 1024, "encoder LDS budget");
+    static_assert(RW * 35 * 16 + RW * 33 * 16 <= RW * ENC_E0_ROW * 16, "W + S must fit in the E0 region");
+    static_assert(I % 4 == 0 && H % 4 == 0 && G % 4 == 0 && A % 4 == 0 && E % 4 == 0, "16B carve");
+};
+constexpr int ENC_LDS_FLOATS = EncLds<TC, 1, false>::FLOATS;
+constexpr int ENC_MS_LDS_FLOATS = EncLds<MS_ROWS, MS_STREAMS, true>::FLOATS;
 
 // lens (optional, offline only): utterance b has 1 + lens[b]/256 <= T frames; T stays the row stride of every tensor.
-template <int TPW>
+// MS (multi-stream, single-frame streaming steps): workgroup b serves streams b*MS_STREAMS .. +3 of the NB streams,
+// one new frame each; the host passes T = MS_STREAMS and the spectrogram strides sb' = MS_STREAMS * sb, st' = sb, so
+// every tensor is addressed exactly as if the streams' frames were consecutive frames of "utterance" b -- only the
+// history (rings, energies, frame counters) is per row.
+template <int TPW, bool MS>
 __global__ __launch_bounds__(NTHR) void k_encoder(const float* __restrict__ spec, long sb, long sf, long st, int T,
-                                                 const int* __restrict__ lens,
+                                                 const int* __restrict__ lens, int NB,
                                                  const float* __restrict__ PF, const int* __restrict__ PI,
                                                  float* __restrict__ en0, float* __restrict__ en1,
                                                  float* __restrict__ en2, float* __restrict__ en3,
@@ -678,17 +718,21 @@ __global__ __launch_bounds__(NTHR) void k_encoder(const float* __restrict__ spec
                                                  unsigned long long* __restrict__ stamps) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     STAMP_INIT(SS)
-    float* sP = smem + ENC_LDS_P;
-    int* sI = reinterpret_cast<int*>(smem + ENC_LDS_I);
-    float* sH = smem + ENC_LDS_H;
-    float* sEH = smem + ENC_LDS_EH;
-    float* sG = smem + ENC_LDS_G;
-    float* sSpec = smem + ENC_LDS_A;     // [3: mag, re, im][tl][257]
-    float* sE0 = smem + ENC_LDS_A;
-    float* sW = smem + ENC_LDS_A;
-    float* sS = sW + TC * 35 * 16;
-    float* sEB = smem + ENC_LDS_B;
-    float* sF0 = sEB + 3 * TC * EB_ROW;
+    constexpr int RW = MS ? MS_ROWS : TC;
+    constexpr int NS = MS ? MS_STREAMS : 1;
+    using LD = EncLds<RW, NS, MS>;
+    float* sP = smem + LD::P;
+    int* sI = reinterpret_cast<int*>(smem + LD::I);
+    float* sH = smem + LD::H;
+    float* sEH = smem + LD::EH;
+    int* sTB = reinterpret_cast<int*>(smem + LD::TB);
+    float* sG = smem + LD::G;
+    float* sSpec = smem + LD::A;     // [3: mag, re, im][tl][257]
+    float* sE0 = smem + LD::A;
+    float* sW = smem + LD::A;
+    float* sS = sW + RW * 35 * 16;
+    float* sEB = smem + LD::B;
+    float* sF0 = sEB + 3 * RW * EB_ROW;
     const Lane L = lane_info();
     const int tid = L.tid, n = L.n, g = L.g;
     const int b = blockIdx.x;
@@ -696,9 +740,19 @@ __global__ __launch_bounds__(NTHR) void k_encoder(const float* __restrict__ spec
     for (int i = tid; i < ENC_SIZE; i += NTHR) sP[i] = PF[P_ENC + i];
     for (int i = tid; i < P_INTS; i += NTHR) sI[i] = PI[i];
     // (the pad entries of EB / F0 are zeroed at the top of every chunk; nothing else of that region is read unwritten)
-    float* stb = state ? state + (long)b * ST_FLOATS : nullptr;
-    const int tbase = stb ? reinterpret_cast<const int*>(stb)[0] : 0;
-    rings_load(sH, sEH, stb ? stb + ST_ENC_H : nullptr, stb ? stb + ST_ENC_E : nullptr, tid);
+    float* stb = state ? state + (long)b * NS * ST_FLOATS : nullptr;    // first stream of this workgroup
+    const int nlive = MS ? min(NS, NB - b * NS) : 1;
+    int tbase = 0;
+    if constexpr (MS) {
+        for (int sidx = 0; sidx < NS; ++sidx) {
+            const float* ss = sidx < nlive ? stb + (long)sidx * ST_FLOATS : nullptr;
+            rings_load(sH + sidx * RING_SET, sEH + sidx * 48, ss ? ss + ST_ENC_H : nullptr, ss ? ss + ST_ENC_E : nullptr, tid);
+        }
+        if (tid < 8) sTB[tid] = tid < nlive ? reinterpret_cast<const int*>(stb + (long)tid * ST_FLOATS)[0] : 0;
+    } else {
+        tbase = stb ? reinterpret_cast<const int*>(stb)[0] : 0;
+        rings_load(sH, sEH, stb ? stb + ST_ENC_H : nullptr, stb ? stb + ST_ENC_E : nullptr, tid);
+    }
     const Tiles<TPW> tt = make_tiles<TPW>(L);
     wg_barrier();
 
@@ -708,17 +762,18 @@ __global__ __launch_bounds__(NTHR) void k_encoder(const float* __restrict__ spec
     en0 += ob * (F1 * 16); en1 += ob * 528; en2 += ob * 528; en3 += ob * 528; en4 += ob * 528;
     const bool t_fast = st < sf;  // reference layout (B,257,T,2): consecutive frames are adjacent
     if (lens) T = min(T, 1 + (lens[b] >> 8));   // from here on T = this utterance's frames
+    if constexpr (MS) T = nlive;                // one frame per live stream = nlive rows
     STAMP(SS, 0)
 
     // Spectrogram items of this thread: item q is element idx = tid + q*NTHR of the chunk, idx -> (tl, f)
     // with f fastest for the frame-major layout (consecutive bins adjacent) and tl fastest for the
     // reference layout (consecutive frames adjacent).  The chunk is fetched one chunk ahead into
     // registers, so its HBM latency is hidden behind the previous chunk's compute.
-    constexpr int SPEC_ITEMS = (TC * NBINS + NTHR - 1) / NTHR;
+    constexpr int SPEC_ITEMS = (RW * NBINS + NTHR - 1) / NTHR;
     float2 spn[SPEC_ITEMS];
     const int sf32 = (int)sf, st32 = (int)st;     // api.cpp checks that a chunk's offsets fit in 31 bits
     auto spec_fetch = [&](int t0f) {
-        const int nf = min(TC, T - t0f);
+        const int nf = min(RW, T - t0f);
         const float* base = spec + (long)t0f * st;           // wave-uniform
         int tv0 = tid;
         asm volatile("" : "+v"(tv0));   // recomputed per chunk: keeps the item coordinates out of long-lived registers
@@ -733,15 +788,15 @@ __global__ __launch_bounds__(NTHR) void k_encoder(const float* __restrict__ spec
     };
     spec_fetch(0);
 
-    for (int t0 = 0; t0 < T; t0 += TC) {
-        const int nfr = min(TC, T - t0);
+    for (int t0 = 0; t0 < T; t0 += RW) {
+        const int nfr = min(RW, T - t0);
         // the cooperative loops index from an opaque copy of tid so that their per-item offsets are
         // recomputed per chunk instead of being hoisted, spilled and reloaded (scratch shares vmcnt)
         int tv = tid;
         asm volatile("" : "+v"(tv));
         // the EB/F0 region doubles as the scratch of the en1 store (phase D), so the zero pad entries
         // (EB columns 0 and 130, F0 columns 0,1 and 131..135) are re-zeroed every chunk
-        if (tv < 3 * TC * 9) {
+        if (tv < 3 * RW * 9) {
             const int row = tv / 9, e = tv - row * 9;
             float z = 0.f;
             asm volatile("" : "+v"(z));
@@ -760,7 +815,7 @@ __global__ __launch_bounds__(NTHR) void k_encoder(const float* __restrict__ spec
                     const float2 v = spn[q];
                     const bool low = f < ERB_LOW;
                     float* d = low ? sEB + tl * EB_ROW + 1 + f : sSpec + tl * NBINS + f;
-                    const int cs = low ? TC * EB_ROW : TC * NBINS;
+                    const int cs = low ? RW * EB_ROW : RW * NBINS;
                     d[0] = __builtin_amdgcn_sqrtf(v.x * v.x + v.y * v.y + 1e-12f);
                     d[cs] = v.x;
                     d[2 * cs] = v.y;
@@ -769,12 +824,12 @@ __global__ __launch_bounds__(NTHR) void k_encoder(const float* __restrict__ spec
             }
         }
         STAMP(SS, 10)
-        if (t0 + TC < T) spec_fetch(t0 + TC);
+        if (t0 + RW < T) spec_fetch(t0 + RW);
         STAMP(SS, 11)
         wg_barrier();
         STAMP(SS, 12)
-        // ---- A: ERB.bm bands: EB[c][tl][66 + band]; items run over all TC rows of the chunk image with
-        //      power-of-two index math (rows past a short last chunk are skipped).  NTHR is a multiple of
+        // ---- A: ERB.bm bands: EB[c][tl][66 + band]; items run over all RW rows of the chunk image
+        //      (rows past a short last chunk are skipped).  NTHR is a multiple of
         //      64, so a lane keeps its band for all its items: the band's weights are read once per chunk -----
         {
             static_assert(NTHR % ERB_BANDS == 0, "lane <-> band");
@@ -788,8 +843,8 @@ __global__ __launch_bounds__(NTHR) void k_encoder(const float* __restrict__ spec
                 // they are selected away below rather than multiplied by their zero weight
                 w[i] = t[0]; w[i + 1] = t[1]; w[i + 2] = t[2]; w[i + 3] = t[3];
             }
-            for (int ct = tv >> 6; ct < 3 * TC; ct += NW) {
-                if ((ct & (TC - 1)) >= nfr) continue;
+            for (int ct = tv >> 6; ct < 3 * RW; ct += NW) {
+                if ((ct % RW) >= nfr) continue;
                 const float* sp = sSpec + ct * NBINS + ERB_LOW + lo;
                 float a0 = 0.f, a1 = 0.f;
 #pragma unroll
@@ -804,8 +859,8 @@ __global__ __launch_bounds__(NTHR) void k_encoder(const float* __restrict__ spec
         wg_barrier();
         STAMP(SS, 1)
         // ---- B: SFE_Lite depthwise (1,3): F0[c][tl][2 + f]; one (channel, frame) row per wave pass -------
-        for (int row = L.wave; row < 3 * TC; row += NW) {
-            const int tl = row & (TC - 1), c = row >> 4;
+        for (int row = L.wave; row < 3 * RW; row += NW) {
+            const int tl = row % RW, c = row / RW;
             if (tl >= nfr) continue;
             const float w0 = sP[E_SFE_W + c * 3], w1 = sP[E_SFE_W + c * 3 + 1], w2 = sP[E_SFE_W + c * 3 + 2];
             const float* e = sEB + row * EB_ROW;
@@ -818,7 +873,7 @@ __global__ __launch_bounds__(NTHR) void k_encoder(const float* __restrict__ spec
             if (f == 0) d[128] = w0 * e[128] + w1 * e[129] + w2 * e[130];
         }
         // zero the pad positions of E0 (columns 0,1,67,68 of each row): region A held the spectrogram
-        if (tv < TC * 4 * 4) {
+        if (tv < RW * 4 * 4) {
             const int r = tv >> 4, cc = (tv >> 2) & 3, gg = tv & 3;
             float z = 0.f;
             asm volatile("" : "+v"(z));
@@ -836,12 +891,15 @@ __global__ __launch_bounds__(NTHR) void k_encoder(const float* __restrict__ spec
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
                 const int e = 4 * go + s, c = e < 15 ? e / 5 : 0, k = e < 15 ? e % 5 : 0;
-                off[s] = c * TC * F0_ROW + k;
+                off[s] = c * RW * F0_ROW + k;
             }
             static_assert(TC * F1 % 16 == 0, "en0 tiling");
             const int nt0 = (nfr * F1 + 15) >> 4;              // tiles that hold a valid frame
             for (int tile = L.wave; tile < nt0; tile += NW) {
-                const int q = tile * 16 + n, tl = q / F1, fo = q - tl * F1;
+                const int q = tile * 16 + n;
+                int tl = q / F1;
+                const int fo = q - tl * F1;
+                if (MS && tl >= RW) tl = RW - 1;               // tail lanes of the last tile: stay inside the images
                 f32x4 bv;
 #pragma unroll
                 for (int s = 0; s < 4; ++s) bv[s] = sF0[off[s] + tl * F0_ROW + 2 * fo];
@@ -850,7 +908,7 @@ __global__ __launch_bounds__(NTHR) void k_encoder(const float* __restrict__ spec
                 for (int s = 0; s < 4; ++s) acc = mfma(A[s], bv[s], acc);
                 acc = prelu4(acc, a);
                 st4(sE0 + pl(tl * ENC_E0_ROW + 2 + fo, g), acc);
-                if (tl < nfr) st4(en0 + (long)t0 * (F1 * 16) + (unsigned)(q * 16 + 4 * g), acc);
+                if (q < nfr * F1) st4(en0 + (long)t0 * (F1 * 16) + (unsigned)(q * 16 + 4 * g), acc);
             }
         }
         wg_barrier();
@@ -885,7 +943,7 @@ __global__ __launch_bounds__(NTHR) void k_encoder(const float* __restrict__ spec
         }
         wg_barrier();  // E0 is dead: its region becomes W
         STAMP(SS, 4)
-        zero_row_pads(sW, tid);
+        zero_row_pads<RW>(sW, tid);
         // ---- E: 3 x GTConvBlock (depthwise) --------------------------------------------------------
 #pragma unroll 1
         for (int k = 0; k < 3; ++k) {
@@ -894,9 +952,18 @@ __global__ __launch_bounds__(NTHR) void k_encoder(const float* __restrict__ spec
             c.gA = nullptr;
             c.ib = sI + I_ENC_BLK + k * 16;
             c.sW = sW; c.sHk = sH + k * (2 * 35 * 16); c.sS = sS; c.sG = sG; c.sEHk = sEH + k * 16;
-            c.sE = smem + ENC_LDS_E;
+            c.sE = smem + LD::E;
+            c.sY = sG + RW * 16;
             c.nfr = nfr; c.tabs = tbase + t0;
-            gtconv_block<false>(x, tt, c, L, [] {} STAMP_ARG);
+            c.sTB = sTB;
+            if constexpr (MS) {
+                const int sidx = min(tt.tl[0], NS - 1);
+                c.ms_roff = (int)(sH - sW) + sidx * RING_SET + k * (2 * 35 * 16);
+                c.ms_tb = sTB[sidx];
+            } else {
+                c.ms_roff = 0; c.ms_tb = 0;
+            }
+            gtconv_block<false, TPW, MS>(x, tt, c, L, [] {} STAMP_ARG);
             if (k < 2) {
                 float* dst = k == 0 ? en2 : en3;
                 const int* ix = sI + I_ENST + (k + 1) * 16 + 4 * g;
@@ -917,7 +984,14 @@ __global__ __launch_bounds__(NTHR) void k_encoder(const float* __restrict__ spec
     }
     if (stb) {
         wg_barrier();
-        rings_store(sH, sEH, stb + ST_ENC_H, stb + ST_ENC_E, tid);
+        if constexpr (MS) {
+            for (int sidx = 0; sidx < nlive; ++sidx) {
+                float* ss = stb + (long)sidx * ST_FLOATS;
+                rings_store(sH + sidx * RING_SET, sEH + sidx * 48, ss + ST_ENC_H, ss + ST_ENC_E, tid);
+            }
+        } else {
+            rings_store(sH, sEH, stb + ST_ENC_H, stb + ST_ENC_E, tid);
+        }
     }
     STAMP_OUT(SS, stamps)
 }
@@ -1068,6 +1142,72 @@ __global__ __launch_bounds__(NTHR) void k_gtcn(const float* __restrict__ xin, fl
     }
 }
 
+// ---------------------------------------------------------------------------- GTCN, multi-stream single-frame form
+// One new frame per stream (the streaming step of gtcrn_micro_stream.py:265-350 for N streams): the TCN couples a
+// position (stream, bin) only with ITS OWN history, which lives in the stream's ring in global memory -- a lane reads
+// the rows of frames t-d and t-2d of its position and overwrites the row of t-2d with y1(t) (row = frame mod 2d).
+// Nothing is shared between lanes: no LDS image, no barrier; a tile is 16 consecutive positions of the flattened
+// (stream, bin) axis, one tile per wave, four waves per workgroup.  Same arithmetic, in the same order, as tcn_block.
+constexpr int GTMS_WAVES = 4;
+template <int D>
+__device__ __forceinline__ void tcn_block_ms(f32x4& x, const float* pk, const f32x4 t1, const f32x4 t2, float* ring_r2,
+                                             bool live, int n, int g) {
+    const float a1 = pk[TCN_SLOPE] - 1.0f, a2 = pk[TCN_SLOPE + 1] - 1.0f, a3 = pk[TCN_SLOPE + 2] - 1.0f;
+    f32x4 y1[1], acc[1], xx[1] = {x};
+    {
+        const f32x4 A = ld4(pk + TCN_A1 + n * 16 + 4 * g), Bv = ld4(pk + TCN_B1 + 4 * g);
+        acc[0] = Bv;
+        mm16<1>(A, xx, acc);
+        y1[0] = prelu4(acc[0], a1);
+    }
+    {
+        const f32x4 w0 = ld4(pk + TCN_DW + 4 * g), w1 = ld4(pk + TCN_DW + 16 + 4 * g),
+                    w2 = ld4(pk + TCN_DW + 32 + 4 * g), B2 = ld4(pk + TCN_B2 + 4 * g);
+        const f32x4 A = ld4(pk + TCN_A3 + n * 16 + 4 * g), B3 = ld4(pk + TCN_B3 + 4 * g);
+        f32x4 y2[1];
+        y2[0] = prelu4(B2 + w0 * t2 + w1 * t1 + w2 * y1[0], a2);
+        acc[0] = B3 + x;
+        mm16<1>(A, y2, acc);
+        x = prelu4(acc[0], a3);
+    }
+    if (live) st4(ring_r2, y1[0]);
+}
+
+__global__ __launch_bounds__(GTMS_WAVES * 64) void k_gtcn_ms(const float* __restrict__ xin, float* __restrict__ xout,
+                                                            const float* __restrict__ P, int NB,
+                                                            float* __restrict__ state, int st_off,
+                                                            const float* __restrict__ addend) {
+    __shared__ __attribute__((aligned(16))) float sP[GTCN_SIZE];
+    const int tid = threadIdx.x, lane = tid & 63, n = lane & 15, g = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const long p = ((long)blockIdx.x * GTMS_WAVES + wave) * 16 + n;     // position on the flattened (stream, bin) axis
+    const bool live = p < (long)NB * 33;
+    const long pc = live ? p : 0;                                        // clamped: no select behind the loads
+    const int sidx = (int)(pc / 33), ff = (int)(pc - (long)sidx * 33);
+    float* ring = state + (long)sidx * ST_FLOATS + st_off;
+    const int tb = reinterpret_cast<const int*>(state + (long)sidx * ST_FLOATS)[0];
+    // all eight history rows are requested up front; their latency hides behind the parameter copy and block 1
+    f32x4 t1[4], t2[4];
+    int r2[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int d = 1 << k, m2d = 2 * d - 1, row0 = 2 * (d - 1);
+        const int r1 = ((row0 + ((tb + d) & m2d)) * 33 + ff) * 16 + 4 * g;
+        r2[k] = ((row0 + (tb & m2d)) * 33 + ff) * 16 + 4 * g;
+        t1[k] = ld4(ring + r1);
+        t2[k] = ld4(ring + r2[k]);
+    }
+    f32x4 x = ld4(xin + pc * 16 + 4 * g), ad = splat(0.f);
+    if (addend) ad = ld4(addend + pc * 16 + 4 * g);
+    for (int i = tid; i < GTCN_SIZE; i += GTMS_WAVES * 64) sP[i] = P[i];
+    __syncthreads();
+    tcn_block_ms<1>(x, sP + 0 * TCN_SIZE, t1[0], t2[0], ring + r2[0], live, n, g);
+    tcn_block_ms<2>(x, sP + 1 * TCN_SIZE, t1[1], t2[1], ring + r2[1], live, n, g);
+    tcn_block_ms<4>(x, sP + 2 * TCN_SIZE, t1[2], t2[2], ring + r2[2], live, n, g);
+    tcn_block_ms<8>(x, sP + 3 * TCN_SIZE, t1[3], t2[3], ring + r2[3], live, n, g);
+    if (live) st4(xout + pc * 16 + 4 * g, addend ? x + ad : x);
+}
+
 // ---------------------------------------------------------------------------- GTCN, offline form
 // Same arithmetic, different ownership: wave w owns frequency bins 3w..3w+2 for ALL frames (11 waves x
 // 3 bins = 33), a tile = 16 consecutive frames of one bin (lane n <-> frame t0+n).  The TCN couples
@@ -1204,46 +1344,57 @@ __global__ __launch_bounds__(NTHR) void k_gtcn_band(const float* __restrict__ xi
 // GTConvBlocks, de_convs.3 (ConvTranspose2d (1,5) stride (1,2), 33 -> 65) in gather form,
 // de_convs.4 (16 -> 2, 65 -> 129, Tanh) in scatter form, then ERB.bs (:69-73), the complex
 // ratio mask (:478-482) and the output permute (:529-530).
-constexpr int DEC_LDS_P = 0;                                      // the whole decoder segment
-constexpr int DEC_LDS_I = DEC_LDS_P + DEC_SIZE;
-constexpr int DEC_LDS_H = DEC_LDS_I + P_INTS;
-constexpr int DEC_LDS_EH = DEC_LDS_H + 3 * 2 * 35 * 16;
-constexpr int DEC_LDS_G = DEC_LDS_EH + 48;
-constexpr int DEC_LDS_E = DEC_LDS_G + TC * 16 + TC * 8;           // (gates [TC][16] + y scratch [TC][8]); energies [2 + TC][8]
-constexpr int DEC_LDS_A = DEC_LDS_E + (TC + 2) * 8;               // W + S, later Z
-constexpr int DEC_LDS_ASZ = TC * 35 * 16 + TC * 33 * 16;
 constexpr int DEC_Z_ROW = F1 + 2;                                 // Z rows carry a zero record at both ends
-constexpr int DEC_LDS_M = DEC_LDS_A + DEC_LDS_ASZ;                // mask m [2][TC][129] (+4: the 2-tap read of the last bin)
-constexpr int DEC_LDS_BS = DEC_LDS_M + 2 * TC * F0 + 4;           // per-bin ERB.bs table {first index, w0, w1, -}
-constexpr int DEC_LDS_FLOATS = DEC_LDS_BS + NBINS * 4;
-static_assert(TC * DEC_Z_ROW * 16 <= DEC_LDS_ASZ, "Z must fit in the W + S region");
-static_assert(DEC_LDS_M % 4 == 0 && DEC_LDS_BS % 4 == 0, "16B carve");
-static_assert(DEC_LDS_FLOATS * 4 <= 160 * 1024, "decoder LDS budget");
-static_assert(DEC_SIZE % 4 == 0 && DEC_LDS_I % 4 == 0 && DEC_LDS_H % 4 == 0 && DEC_LDS_A % 4 == 0, "16B carve");
+template <int RW, int NS, bool MS>
+struct DecLds {
+    static constexpr int P = 0;                                   // the whole decoder segment
+    static constexpr int I = P + DEC_SIZE;
+    static constexpr int H = I + P_INTS;
+    static constexpr int EH = H + NS * RING_SET;
+    static constexpr int TB = EH + NS * 48;                       // frame counter per row (ints; multi-stream mode)
+    static constexpr int G = TB + 8;
+    static constexpr int E = G + RW * 16 + RW * 8;                // (gates [RW][16] + y scratch [RW][8]); energies
+    static constexpr int A = E + (MS ? NS * 24 : (RW + 2) * 8);   // W + S, later Z
+    static constexpr int ASZ = RW * 35 * 16 + RW * 33 * 16;
+    static constexpr int M = A + ASZ;                             // mask m [2][RW][129] (+4: the 2-tap read of the last bin)
+    static constexpr int BS = M + ((2 * RW * F0 + 4 + 3) & ~3);   // per-bin ERB.bs table {first index, w0, w1, -}
+    static constexpr int FLOATS = BS + NBINS * 4;
+    static_assert(RW * DEC_Z_ROW * 16 <= ASZ, "Z must fit in the W + S region");
+    static_assert(M % 4 == 0 && BS % 4 == 0, "16B carve");
+    static_assert(FLOATS * 4 <= 160 * 1024, "decoder LDS budget");
+    static_assert(DEC_SIZE % 4 == 0 && I % 4 == 0 && H % 4 == 0 && A % 4 == 0 && E % 4 == 0, "16B carve");
+};
+constexpr int DEC_LDS_FLOATS = DecLds<TC, 1, false>::FLOATS;
+constexpr int DEC_MS_LDS_FLOATS = DecLds<MS_ROWS, MS_STREAMS, true>::FLOATS;
 
 // DBG = true only for the stage-tap variant used by the parity tests (writes de0..de4 to `dbg`).
-template <bool DBG, int TPW>
+// MS: multi-stream single-frame mode, see k_encoder (NB = number of streams; the host remaps the strides).
+template <bool DBG, int TPW, bool MS>
 __global__ __launch_bounds__(NTHR) void k_decoder(const float* __restrict__ xg, const float* __restrict__ en0,
                                                  const float* __restrict__ en1, const float* __restrict__ en2,
                                                  const float* __restrict__ en3, const float* __restrict__ en4,
                                                  const float* __restrict__ spec, long sb, long sf, long st,
                                                  float* __restrict__ out, long osb, long osf, long ost, int T,
-                                                 const int* __restrict__ lens,
+                                                 const int* __restrict__ lens, int NB,
                                                  const float* __restrict__ PF, const int* __restrict__ PI,
                                                  float* __restrict__ state, float* __restrict__ dbg,
                                                  unsigned long long* __restrict__ stamps) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     STAMP_INIT(SS)
-    float* sP = smem + DEC_LDS_P;
-    int* sI = reinterpret_cast<int*>(smem + DEC_LDS_I);
-    float* sH = smem + DEC_LDS_H;
-    float* sEH = smem + DEC_LDS_EH;
-    float* sG = smem + DEC_LDS_G;
-    float* sW = smem + DEC_LDS_A;
-    float* sS = sW + TC * 35 * 16;
-    float* sZ = smem + DEC_LDS_A;
-    float* sM = smem + DEC_LDS_M;
-    float* sBS = smem + DEC_LDS_BS;
+    constexpr int RW = MS ? MS_ROWS : TC;
+    constexpr int NS = MS ? MS_STREAMS : 1;
+    using LD = DecLds<RW, NS, MS>;
+    float* sP = smem + LD::P;
+    int* sI = reinterpret_cast<int*>(smem + LD::I);
+    float* sH = smem + LD::H;
+    float* sEH = smem + LD::EH;
+    int* sTB = reinterpret_cast<int*>(smem + LD::TB);
+    float* sG = smem + LD::G;
+    float* sW = smem + LD::A;
+    float* sS = sW + RW * 35 * 16;
+    float* sZ = smem + LD::A;
+    float* sM = smem + LD::M;
+    float* sBS = smem + LD::BS;
     const Lane L = lane_info();
     const int tid = L.tid, n = L.n, g = L.g;
     const int b = blockIdx.x;
@@ -1263,10 +1414,20 @@ __global__ __launch_bounds__(NTHR) void k_decoder(const float* __restrict__ xg, 
         e[0] = __int_as_float(i0);
         st4(sBS + f * 4, e);
     }
-    if (tid < 4) sM[2 * TC * F0 + tid] = 0.f;
-    float* stb = state ? state + (long)b * ST_FLOATS : nullptr;
-    const int tbase = stb ? reinterpret_cast<const int*>(stb)[0] : 0;
-    rings_load(sH, sEH, stb ? stb + ST_DEC_H : nullptr, stb ? stb + ST_DEC_E : nullptr, tid);
+    if (tid < 4) sM[2 * RW * F0 + tid] = 0.f;
+    float* stb = state ? state + (long)b * NS * ST_FLOATS : nullptr;    // first stream of this workgroup
+    const int nlive = MS ? min(NS, NB - b * NS) : 1;
+    int tbase = 0;
+    if constexpr (MS) {
+        for (int sidx = 0; sidx < NS; ++sidx) {
+            const float* ss = sidx < nlive ? stb + (long)sidx * ST_FLOATS : nullptr;
+            rings_load(sH + sidx * RING_SET, sEH + sidx * 48, ss ? ss + ST_DEC_H : nullptr, ss ? ss + ST_DEC_E : nullptr, tid);
+        }
+        if (tid < 8) sTB[tid] = tid < nlive ? reinterpret_cast<const int*>(stb + (long)tid * ST_FLOATS)[0] : 0;
+    } else {
+        tbase = stb ? reinterpret_cast<const int*>(stb)[0] : 0;
+        rings_load(sH, sEH, stb ? stb + ST_DEC_H : nullptr, stb ? stb + ST_DEC_E : nullptr, tid);
+    }
     const Tiles<TPW> tt = make_tiles<TPW>(L);
     wg_barrier();
 
@@ -1277,7 +1438,7 @@ __global__ __launch_bounds__(NTHR) void k_decoder(const float* __restrict__ xg, 
     out += (long)b * osb;
     const bool t_fast = st < sf;
     const int sf32 = (int)sf, st32 = (int)st, osf32 = (int)osf, ost32 = (int)ost;
-    constexpr int MASK_ITEMS = (TC * NBINS + NTHR - 1) / NTHR;   // spectrogram bins per thread and chunk
+    constexpr int MASK_ITEMS = (RW * NBINS + NTHR - 1) / NTHR;   // spectrogram bins per thread and chunk
     STAMP(SS, 0)
 
     // xg already holds gtcn2(x) + en_outs[4] (k_gtcn adds it on store).  Lanes past the end of the
@@ -1286,19 +1447,20 @@ __global__ __launch_bounds__(NTHR) void k_decoder(const float* __restrict__ xg, 
     // global addressing: wave-uniform chunk base pointers (SGPR pairs) + 32-bit per-lane offsets
     xg += ob * 528; en0 += ob * (F1 * 16); en1 += ob * 528; en2 += ob * 528; en3 += ob * 528;
     if (lens) T = min(T, 1 + (lens[b] >> 8));   // variable-length batch: from here on T = this utterance's frames
+    if constexpr (MS) T = nlive;                // one frame per live stream = nlive rows
     f32x4 xn[TPW];
     {
-        const int np0 = min(TC, T) * 33;
+        const int np0 = min(RW, T) * 33;
 #pragma unroll
         for (int i = 0; i < TPW; ++i) xn[i] = ld4(xg + (unsigned)((tt.pp(i) < np0 ? tt.pp(i) : 0) * 16 + 4 * g));
     }
     (void)en4;
-    for (int t0 = 0; t0 < T; t0 += TC) {
-        const int nfr = min(TC, T - t0), npos = nfr * 33;
+    for (int t0 = 0; t0 < T; t0 += RW) {
+        const int nfr = min(RW, T - t0), npos = nfr * 33;
         f32x4 x[TPW];
 #pragma unroll
         for (int i = 0; i < TPW; ++i) x[i] = xn[i];
-        zero_row_pads(sW, tid);  // region A was Z in the previous chunk (a barrier follows in the block)
+        zero_row_pads<RW>(sW, tid);  // region A was Z in the previous chunk (a barrier follows in the block)
         STAMP(SS, 1)
         // All 256 workgroups run in lock step, so a load burst right before its use is a chip-wide HBM
         // burst (25 MB at once costs ~10 k cycles).  The inputs of the tail are therefore requested
@@ -1321,9 +1483,18 @@ __global__ __launch_bounds__(NTHR) void k_decoder(const float* __restrict__ xg, 
             c.gA = c.pb + GB_DN_A;
             c.ib = sI + I_DEC_BLK + j * 16;
             c.sW = sW; c.sHk = sH + j * (2 * 35 * 16); c.sS = sS; c.sG = sG; c.sEHk = sEH + j * 16;
-            c.sE = smem + DEC_LDS_E;
+            c.sE = smem + LD::E;
+            c.sY = sG + RW * 16;
             c.nfr = nfr; c.tabs = tbase + t0;
-            gtconv_block<true>(x, tt, c, L, hook STAMP_ARG);
+            c.sTB = sTB;
+            if constexpr (MS) {
+                const int sidx = min(tt.tl[0], NS - 1);
+                c.ms_roff = (int)(sH - sW) + sidx * RING_SET + j * (2 * 35 * 16);
+                c.ms_tb = sTB[sidx];
+            } else {
+                c.ms_roff = 0; c.ms_tb = 0;
+            }
+            gtconv_block<true, TPW, MS>(x, tt, c, L, hook STAMP_ARG);
             if (DBG)
 #pragma unroll
                 for (int i = 0; i < TPW; ++i)
@@ -1425,7 +1596,7 @@ __global__ __launch_bounds__(NTHR) void k_decoder(const float* __restrict__ xg, 
         {   // zero records at both ends of every Z row (region A held W / S)
             int tz = tid;
             asm volatile("" : "+v"(tz));
-            if (tz < TC * 2 * 4) {
+            if (tz < RW * 2 * 4) {
                 float z = 0.f;
                 asm volatile("" : "+v"(z));
                 st4(sZ + pl((tz >> 3) * DEC_Z_ROW + ((tz >> 2) & 1) * (DEC_Z_ROW - 1), tz & 3), splat(z));
@@ -1453,9 +1624,9 @@ __global__ __launch_bounds__(NTHR) void k_decoder(const float* __restrict__ xg, 
         wg_barrier();
         STAMP(SS, 12)
         // next chunk's input: x is dead, so its registers are reused for the prefetch
-        if (t0 + TC < T) {
-            const int npn = min(TC, T - t0 - TC) * 33;
-            const float* xgn = xg + (long)(t0 + TC) * 528;
+        if (t0 + RW < T) {
+            const int npn = min(RW, T - t0 - RW) * 33;
+            const float* xgn = xg + (long)(t0 + RW) * 528;
 #pragma unroll
             for (int i = 0; i < TPW; ++i) xn[i] = ld4(xgn + (unsigned)((tt.pp(i) < npn ? tt.pp(i) : 0) * 16 + 4 * g));
         }
@@ -1473,7 +1644,7 @@ __global__ __launch_bounds__(NTHR) void k_decoder(const float* __restrict__ xg, 
                 const float* zr = sZ + (tq * DEC_Z_ROW + 1 + m) * 16;
                 const float sum = sP[D_DE4_B + o] + zr[16 + o * 5 + par] + zr[o * 5 + 2 + par] +
                                   zr[-16 + (par ? 10 : o * 5 + 4)];
-                sM[(o * TC + tq) * F0 + fq] = fast_tanh(sum);
+                sM[(o * RW + tq) * F0 + fq] = fast_tanh(sum);
                 fq += 59;
                 ot += 5;
                 if (fq >= F0) { fq -= F0; ++ot; }
@@ -1485,7 +1656,7 @@ __global__ __launch_bounds__(NTHR) void k_decoder(const float* __restrict__ xg, 
             for (int idx = tid; idx < 2 * nfr * F0; idx += NTHR) {
                 const int fq = idx % F0, ot = idx / F0, o = ot >= nfr ? 1 : 0, tq = ot - o * nfr;
                 dbg[3 * nbt * 528 + nbt * F1 * 16 + (((long)b * 2 + o) * Tstride + t0 + tq) * F0 + fq] =
-                    sM[(o * TC + tq) * F0 + fq];
+                    sM[(o * RW + tq) * F0 + fq];
             }
         // ---- ERB.bs + complex ratio mask + output layout --------------------------------------------
         {
@@ -1503,7 +1674,7 @@ __global__ __launch_bounds__(NTHR) void k_decoder(const float* __restrict__ xg, 
                     // first element of the next frame's row, which may be stale (0 * NaN)
                     const bool two = tb[2] != 0.f;
                     const float mr = tb[1] * m0[0] + (two ? tb[2] * m0[1] : 0.f);
-                    const float mi = tb[1] * m0[TC * F0] + (two ? tb[2] * m0[TC * F0 + 1] : 0.f);
+                    const float mi = tb[1] * m0[RW * F0] + (two ? tb[2] * m0[RW * F0 + 1] : 0.f);
                     const float re = spv[q].x, im = spv[q].y;
                     *reinterpret_cast<float2*>(obase + (f * osf32 + tq * ost32)) =
                         make_float2(re * mr - im * mi, im * mr + re * mi);
@@ -1517,8 +1688,16 @@ __global__ __launch_bounds__(NTHR) void k_decoder(const float* __restrict__ xg, 
     STAMP_OUT(SS, stamps)
     if (stb) {
         wg_barrier();
-        rings_store(sH, sEH, stb + ST_DEC_H, stb + ST_DEC_E, tid);
-        if (tid == 0) reinterpret_cast<int*>(stb)[0] = (tbase + T) & 0xFFFF;  // frame counter (rings use mod 16)
+        if constexpr (MS) {
+            for (int sidx = 0; sidx < nlive; ++sidx) {
+                float* ss = stb + (long)sidx * ST_FLOATS;
+                rings_store(sH + sidx * RING_SET, sEH + sidx * 48, ss + ST_DEC_H, ss + ST_DEC_E, tid);
+            }
+            if (tid < nlive) reinterpret_cast<int*>(stb + (long)tid * ST_FLOATS)[0] = (sTB[tid] + 1) & 0xFFFF;
+        } else {
+            rings_store(sH, sEH, stb + ST_DEC_H, stb + ST_DEC_E, tid);
+            if (tid == 0) reinterpret_cast<int*>(stb)[0] = (tbase + T) & 0xFFFF;  // frame counter (rings use mod 16)
+        }
     }
 }
 
@@ -1673,14 +1852,18 @@ int launch_istft(const float* spec, long sb, long sf, long st, int B, int T, con
 
 int configure_kernels() {
     hipError_t e;
-    e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_encoder<TPW>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            ENC_LDS_FLOATS * 4);
+    const void* enc[] = {reinterpret_cast<const void*>(k_encoder<TPW, false>),
+                         reinterpret_cast<const void*>(k_encoder<1, false>),
+                         reinterpret_cast<const void*>(k_encoder<2, false>)};
+    for (const void* f : enc) {
+        e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, ENC_LDS_FLOATS * 4);
+        if (e != hipSuccess) return (int)e;
+    }
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_encoder<1, true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            ENC_MS_LDS_FLOATS * 4);
     if (e != hipSuccess) return (int)e;
-    e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_encoder<1>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            ENC_LDS_FLOATS * 4);
-    if (e != hipSuccess) return (int)e;
-    e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_encoder<2>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            ENC_LDS_FLOATS * 4);
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_decoder<false, 1, true>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, DEC_MS_LDS_FLOATS * 4);
     if (e != hipSuccess) return (int)e;
     const void* gt[] = {reinterpret_cast<const void*>(k_gtcn<TPW, false>), reinterpret_cast<const void*>(k_gtcn<1, false>),
                         reinterpret_cast<const void*>(k_gtcn<1, true>), reinterpret_cast<const void*>(k_gtcn<TPW, true>),
@@ -1692,12 +1875,12 @@ int configure_kernels() {
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_gtcn_band), hipFuncAttributeMaxDynamicSharedMemorySize,
                             GB_LDS_FLOATS * 4);
     if (e != hipSuccess) return (int)e;
-    const void* dec[] = {reinterpret_cast<const void*>(k_decoder<false, TPW>),
-                         reinterpret_cast<const void*>(k_decoder<true, TPW>),
-                         reinterpret_cast<const void*>(k_decoder<false, 1>),
-                         reinterpret_cast<const void*>(k_decoder<true, 1>),
-                         reinterpret_cast<const void*>(k_decoder<false, 2>),
-                         reinterpret_cast<const void*>(k_decoder<true, 2>)};
+    const void* dec[] = {reinterpret_cast<const void*>(k_decoder<false, TPW, false>),
+                         reinterpret_cast<const void*>(k_decoder<true, TPW, false>),
+                         reinterpret_cast<const void*>(k_decoder<false, 1, false>),
+                         reinterpret_cast<const void*>(k_decoder<true, 1, false>),
+                         reinterpret_cast<const void*>(k_decoder<false, 2, false>),
+                         reinterpret_cast<const void*>(k_decoder<true, 2, false>)};
     for (const void* f : dec) {
         e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, DEC_LDS_FLOATS * 4);
         if (e != hipSuccess) return (int)e;
@@ -1705,25 +1888,40 @@ int configure_kernels() {
     return 0;
 }
 
+// the multi-stream form serves single-frame streaming steps: one new frame for each of B streams
+static bool use_multi_stream(int T, const float* state, long sb) {
+    return state != nullptr && T == 1 && (MS_ROWS - 1) * (sb < 0 ? -sb : sb) < (1L << 31);
+}
+
 int launch_encoder(const float* spec, long sb, long sf, long st, int B, int T, const int* lens, const float* PF,
                    const int* PI, float* en0, float* en1, float* en2, float* en3, float* en4, float* state,
                    unsigned long long* stamps, hipStream_t s) {
-    if (T <= SHORT_T)
-        hipLaunchKernelGGL(k_encoder<1>, dim3(B), dim3(NTHR), ENC_LDS_FLOATS * 4, s, spec, sb, sf, st, T, lens, PF, PI,
-                           en0, en1, en2, en3, en4, state, stamps);
+    if (use_multi_stream(T, state, sb)) {
+        // streams b*4 .. b*4+3 become rows 0..3 of workgroup b: sb' = 4 sb, st' = sb, T' = 4
+        const int grid = (B + MS_STREAMS - 1) / MS_STREAMS;
+        hipLaunchKernelGGL((k_encoder<1, true>), dim3(grid), dim3(NTHR), ENC_MS_LDS_FLOATS * 4, s, spec,
+                           (long)MS_STREAMS * sb, sf, sb, MS_STREAMS, (const int*)nullptr, B, PF, PI, en0, en1, en2, en3,
+                           en4, state, stamps);
+    } else if (T <= SHORT_T)
+        hipLaunchKernelGGL((k_encoder<1, false>), dim3(B), dim3(NTHR), ENC_LDS_FLOATS * 4, s, spec, sb, sf, st, T, lens,
+                           B, PF, PI, en0, en1, en2, en3, en4, state, stamps);
     else if (T <= SHORT_T2)
-        hipLaunchKernelGGL(k_encoder<2>, dim3(B), dim3(NTHR), ENC_LDS_FLOATS * 4, s, spec, sb, sf, st, T, lens, PF, PI,
-                           en0, en1, en2, en3, en4, state, stamps);
+        hipLaunchKernelGGL((k_encoder<2, false>), dim3(B), dim3(NTHR), ENC_LDS_FLOATS * 4, s, spec, sb, sf, st, T, lens,
+                           B, PF, PI, en0, en1, en2, en3, en4, state, stamps);
     else
-        hipLaunchKernelGGL(k_encoder<TPW>, dim3(B), dim3(NTHR), ENC_LDS_FLOATS * 4, s, spec, sb, sf, st, T, lens, PF, PI,
-                           en0, en1, en2, en3, en4, state, stamps);
+        hipLaunchKernelGGL((k_encoder<TPW, false>), dim3(B), dim3(NTHR), ENC_LDS_FLOATS * 4, s, spec, sb, sf, st, T,
+                           lens, B, PF, PI, en0, en1, en2, en3, en4, state, stamps);
     GT_LAUNCH_CHECK();
     return 0;
 }
 
 int launch_gtcn(const float* xin, float* xout, const float* P, int B, int T, float* state, int st_off,
                 const float* addend, unsigned long long* stamps, hipStream_t s) {
-    if (T <= SHORT_T && state)   // streaming step: rings stay in the stream state (no LDS copy: 77 KB, 2 workgroups per CU)
+    if (T == 1 && state) {       // single-frame step for B streams: per-position, barrier-free form
+        const long tiles = ((long)B * 33 + 15) / 16;
+        hipLaunchKernelGGL(k_gtcn_ms, dim3((unsigned)((tiles + GTMS_WAVES - 1) / GTMS_WAVES)), dim3(GTMS_WAVES * 64), 0, s,
+                           xin, xout, P, B, state, st_off, addend);
+    } else if (T <= SHORT_T && state)   // streaming step: rings stay in the stream state (no LDS copy: 77 KB, 2 workgroups per CU)
         hipLaunchKernelGGL((k_gtcn<1, true>), dim3(B), dim3(NTHR), GT_LDS_H * 4, s, xin, xout, P, T, state, st_off,
                            addend, stamps);
     else if (T <= SHORT_T)
@@ -1757,9 +1955,14 @@ int launch_decoder(const float* xg, const float* en0, const float* en1, const fl
                    long ost, int B, int T, const int* lens, const float* PF, const int* PI, float* state, float* dbg,
                    unsigned long long* stamps, hipStream_t s) {
 #define GT_DEC(DBGV, TPWV)                                                                                         \
-    hipLaunchKernelGGL((k_decoder<DBGV, TPWV>), dim3(B), dim3(NTHR), DEC_LDS_FLOATS * 4, s, xg, en0, en1, en2, en3, \
-                       en4, spec, sb, sf, st, out, osb, osf, ost, T, lens, PF, PI, state, dbg, stamps)
-    if (T <= SHORT_T) {
+    hipLaunchKernelGGL((k_decoder<DBGV, TPWV, false>), dim3(B), dim3(NTHR), DEC_LDS_FLOATS * 4, s, xg, en0, en1, en2, \
+                       en3, en4, spec, sb, sf, st, out, osb, osf, ost, T, lens, B, PF, PI, state, dbg, stamps)
+    if (!dbg && use_multi_stream(T, state, sb) && use_multi_stream(T, state, osb)) {
+        const int grid = (B + MS_STREAMS - 1) / MS_STREAMS;
+        hipLaunchKernelGGL((k_decoder<false, 1, true>), dim3(grid), dim3(NTHR), DEC_MS_LDS_FLOATS * 4, s, xg, en0, en1,
+                           en2, en3, en4, spec, (long)MS_STREAMS * sb, sf, sb, out, (long)MS_STREAMS * osb, osf, osb,
+                           MS_STREAMS, (const int*)nullptr, B, PF, PI, state, (float*)nullptr, stamps);
+    } else if (T <= SHORT_T) {
         if (dbg) GT_DEC(true, 1); else GT_DEC(false, 1);
     } else if (T <= SHORT_T2) {
         if (dbg) GT_DEC(true, 2); else GT_DEC(false, 2);
