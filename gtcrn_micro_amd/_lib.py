@@ -63,6 +63,12 @@ def lib():
     L.gtcrn_forward_spec.argtypes = [_vp, _vp, cl, cl, cl, _vp, cl, cl, cl, ci, ci, _vp]
     L.gtcrn_forward_wave.argtypes = [_vp, _vp, _vp, ci, cl, _vp, _vp]
     L.gtcrn_forward_wave_var.argtypes = [_vp, _vp, _vp, ci, cl, _vp, _vp, _vp]
+    cf = ctypes.c_float
+    L.gtcrn_forward_spec_quant.argtypes = [_vp, _vp, cl, cl, cl, _vp, cl, cl, cl, ci, ci, cf, cf, _vp]
+    L.gtcrn_forward_wave_quant.argtypes = [_vp, _vp, _vp, ci, cl, _vp, cf, cf, _vp]
+    L.gtcrn_pack_params_quant_host.argtypes = [_c_f32p, cl, _c_f32p, ctypes.POINTER(ci)]
+    L.gtcrn_round_to_half.restype = cf
+    L.gtcrn_round_to_half.argtypes = [cf]
     L.gtcrn_stream_state_bytes.restype = ctypes.c_size_t
     L.gtcrn_stream_reset.argtypes = [_vp, _vp, ci, _vp]
     L.gtcrn_stream_step.argtypes = [_vp, _vp, _vp, cl, cl, cl, _vp, cl, cl, cl, ci, ci, _vp]
@@ -124,16 +130,23 @@ def num_frames(L):
     return int(lib().gtcrn_num_frames(int(L)))
 
 
-def pack_params_host(params):
-    """Host-only: the BN-folded slot-space buffers (floats, ints) the kernels consume."""
+def pack_params_host(params, quant=False):
+    """Host-only: the BN-folded slot-space buffers (floats, ints) the kernels consume; quant=True: with every conv /
+    linear weight as fp16(int8 * per-output-channel scale) (the configs[4] variant)."""
     params = np.ascontiguousarray(params, np.float32).ravel()
     nf, ni = ctypes.c_long(), ctypes.c_long()
     lib().gtcrn_pack_sizes(ctypes.byref(nf), ctypes.byref(ni))
     F = np.empty(nf.value, np.float32)
     I = np.empty(ni.value, np.int32)
-    _check(lib().gtcrn_pack_params_host(params.ctypes.data_as(_c_f32p), params.size, F.ctypes.data_as(_c_f32p),
-                                        I.ctypes.data_as(ctypes.POINTER(ctypes.c_int))))
+    fn = lib().gtcrn_pack_params_quant_host if quant else lib().gtcrn_pack_params_host
+    _check(fn(params.ctypes.data_as(_c_f32p), params.size, F.ctypes.data_as(_c_f32p),
+              I.ctypes.data_as(ctypes.POINTER(ctypes.c_int))))
     return F, I
+
+
+def round_to_half(x):
+    """float -> IEEE binary16 (round to nearest even) -> float, the host twin of the kernels' v_cvt_f16_f32."""
+    return float(lib().gtcrn_round_to_half(float(x)))
 
 
 def _stream_ptr(stream=None):
@@ -317,6 +330,40 @@ class Engine:
         with self._dev():
             _check(lib().gtcrn_forward_wave(self._h, w2.data_ptr(), out.data_ptr(), B, L, win.data_ptr(),
                                             _stream_ptr()))
+        return out[0] if wave.dim() == 1 else out
+
+    # ---- int8-weight / fp16-activation variant (BASELINE configs[4]; contract in include/gtcrn_micro_hip.h) ------
+    def forward_spec_quant(self, spec, in_scale=0.0, out_scale=0.0, out=None):
+        import torch
+        self._check_on_device(spec, "spec")
+        if spec.dim() != 4 or spec.shape[1] != NBINS or spec.shape[3] != 2:
+            raise GtcrnError(f"spec must be (B,257,T,2), got {tuple(spec.shape)}")
+        if spec.stride(3) != 1:
+            spec = spec.contiguous()
+        B, _, T, _ = spec.shape
+        if out is None:
+            out = torch.empty((B, NBINS, T, 2), device=spec.device, dtype=torch.float32)
+        isb, isf, ist = _spec_strides(spec)
+        osb, osf, ost = _spec_strides(out)
+        with self._dev():
+            _check(lib().gtcrn_forward_spec_quant(self._h, spec.data_ptr(), isb, isf, ist, out.data_ptr(), osb, osf,
+                                                  ost, B, T, float(in_scale), float(out_scale), _stream_ptr()))
+        return out
+
+    def forward_wave_quant(self, wave, window, in_scale=0.0, out_scale=0.0, out=None):
+        import torch
+        self._check_on_device(wave, "wave")
+        w2 = (wave.reshape(1, -1) if wave.dim() == 1 else wave).contiguous()
+        B, L = w2.shape
+        T = num_frames(L)
+        win = window.to(device=wave.device, dtype=torch.float32).contiguous()
+        if out is None:
+            out = torch.empty((B, 256 * (T - 1)), device=wave.device, dtype=torch.float32)
+        else:
+            self._check_on_device(out, "out", (B, 256 * (T - 1)))
+        with self._dev():
+            _check(lib().gtcrn_forward_wave_quant(self._h, w2.data_ptr(), out.data_ptr(), B, L, win.data_ptr(),
+                                                  float(in_scale), float(out_scale), _stream_ptr()))
         return out[0] if wave.dim() == 1 else out
 
     def forward_wave_var(self, wave, lengths, window, out=None):

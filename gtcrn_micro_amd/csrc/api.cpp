@@ -56,6 +56,7 @@ extern "C" void gtcrn_set_error_(const char* msg) { g_err = msg ? msg : ""; }
 struct gtcrn_model {
     int device = 0;
     float* d_pf = nullptr;   // packed floats (gtl::P_FLOATS)
+    float* d_pfq = nullptr;  // the same with int8-quantised weights (BASELINE configs[4] variant)
     int* d_pi = nullptr;     // packed ints (gtl::P_INTS)
     float* d_twid = nullptr; // 512 complex twiddles
     std::vector<int> h_pi;   // host copy of the int tables (slot permutations for the debug taps)
@@ -152,19 +153,21 @@ struct Timer {
 
 // the five model kernels on one stream; state == nullptr for offline
 int run_model(gtcrn_model* m, const float* spec_in, long isb, long isf, long ist, float* spec_out, long osb, long osf,
-              long ost, int B, int T, float* state, hipStream_t s, const int* lens = nullptr) {
+              long ost, int B, int T, float* state, hipStream_t s, const int* lens = nullptr,
+              const gtk::Quant* q = nullptr) {
     Timer tm(m, s);
+    const float* pf = q ? m->d_pfq : m->d_pf;
     unsigned long long* stp = (m->debug && m->d_stamps) ? m->d_stamps : nullptr;
     const long sst = (long)m->stamps_cap_b * 16;
     tm.begin(1);
-    LAUNCH_TRY(gtk::launch_encoder(spec_in, isb, isf, ist, B, T, lens, m->d_pf, m->d_pi, m->d_en0, m->d_en[0], m->d_en[1],
-                                   m->d_en[2], m->d_en[3], state, stp ? stp : nullptr, s));
+    LAUNCH_TRY(gtk::launch_encoder(spec_in, isb, isf, ist, B, T, lens, pf, m->d_pi, m->d_en0, m->d_en[0], m->d_en[1],
+                                   m->d_en[2], m->d_en[3], state, stp ? stp : nullptr, s, q));
     tm.end();
     // GTCN: offline calls (no stream state) use the frequency-band form (registers + DPP, no barrier);
     // streaming calls use the ring form, whose chunks may hold a single frame
     tm.begin(2);
     if (!state)
-        LAUNCH_TRY(gtk::launch_gtcn_band(m->d_en[3], m->d_g1, m->d_pf + gtl::P_GTCN, B, T, lens, nullptr, s));
+        LAUNCH_TRY(gtk::launch_gtcn_band(m->d_en[3], m->d_g1, pf + gtl::P_GTCN, B, T, lens, nullptr, s, q));
     else
         LAUNCH_TRY(gtk::launch_gtcn(m->d_en[3], m->d_g1, m->d_pf + gtl::P_GTCN, B, T, state, gtk::ST_G1_H, nullptr,
                                     stp ? stp + sst : nullptr, s));
@@ -172,16 +175,16 @@ int run_model(gtcrn_model* m, const float* spec_in, long isb, long isf, long ist
     tm.begin(3);
     // the second stack stores gtcn2(x) + en_outs[4]: exactly the decoder's first input (Decoder.forward :467)
     if (!state)
-        LAUNCH_TRY(gtk::launch_gtcn_band(m->d_g1, m->d_g2, m->d_pf + gtl::P_GTCN + gtl::GTCN_SIZE, B, T, lens, m->d_en[3],
-                                         s));
+        LAUNCH_TRY(gtk::launch_gtcn_band(m->d_g1, m->d_g2, pf + gtl::P_GTCN + gtl::GTCN_SIZE, B, T, lens, m->d_en[3], s,
+                                         q));
     else
         LAUNCH_TRY(gtk::launch_gtcn(m->d_g1, m->d_g2, m->d_pf + gtl::P_GTCN + gtl::GTCN_SIZE, B, T, state,
                                     gtk::ST_G2_H, m->d_en[3], stp ? stp + 2 * sst : nullptr, s));
     tm.end();
     tm.begin(4);
     LAUNCH_TRY(gtk::launch_decoder(m->d_g2, m->d_en0, m->d_en[0], m->d_en[1], m->d_en[2], m->d_en[3], spec_in, isb, isf,
-                                   ist, spec_out, osb, osf, ost, B, T, lens, m->d_pf, m->d_pi, state,
-                                   m->debug ? m->d_dbg : nullptr, stp ? stp + 3 * sst : nullptr, s));
+                                   ist, spec_out, osb, osf, ost, B, T, lens, pf, m->d_pi, state,
+                                   m->debug && !q ? m->d_dbg : nullptr, stp ? stp + 3 * sst : nullptr, s, q));
     tm.end();
     m->last_B = B;
     m->last_T = T;
@@ -201,6 +204,8 @@ int upload_params(gtcrn_model* m, const float* h_params, long n) {
     if (gtcrn::pack_params(h_params, n, F.data(), I.data(), err) != 0) return fail(GTCRN_ERR_ARG, err);
     HIP_TRY(hipMemcpy(m->d_pf, F.data(), sizeof(float) * gtl::P_FLOATS, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(m->d_pi, I.data(), sizeof(int) * gtl::P_INTS, hipMemcpyHostToDevice));
+    gtcrn::quantize_packed(F.data());
+    HIP_TRY(hipMemcpy(m->d_pfq, F.data(), sizeof(float) * gtl::P_FLOATS, hipMemcpyHostToDevice));
     m->h_pi = I;
     return 0;
 }
@@ -237,6 +242,12 @@ int gtcrn_pack_params_host(const float* h_params, long n, float* h_f, int* h_i) 
     if (gtcrn::pack_params(h_params, n, h_f, h_i, err) != 0) return fail(GTCRN_ERR_ARG, err);
     return 0;
 }
+int gtcrn_pack_params_quant_host(const float* h_params, long n, float* h_f, int* h_i) {
+    int rc = gtcrn_pack_params_host(h_params, n, h_f, h_i);
+    if (rc == 0) gtcrn::quantize_packed(h_f);
+    return rc;
+}
+float gtcrn_round_to_half(float x) { return gtcrn::round_to_half(x); }
 
 int gtcrn_model_create(gtcrn_model** out, const float* h_params, long n_floats, int device) {
     if (!out || !h_params) return fail(GTCRN_ERR_ARG, "null argument");
@@ -253,6 +264,7 @@ int gtcrn_model_create(gtcrn_model** out, const float* h_params, long n_floats, 
     gtcrn_model* m = new gtcrn_model();
     m->device = device;
     hipError_t e = hipMalloc(&m->d_pf, sizeof(float) * gtl::P_FLOATS);
+    if (e == hipSuccess) e = hipMalloc(&m->d_pfq, sizeof(float) * gtl::P_FLOATS);
     if (e == hipSuccess) e = hipMalloc(&m->d_pi, sizeof(int) * gtl::P_INTS);
     if (e == hipSuccess) e = hipMalloc(&m->d_twid, sizeof(float) * 1024);
     if (e == hipSuccess) e = hipMalloc(&m->d_ptr8, sizeof(float*) * 8);
@@ -300,6 +312,7 @@ void gtcrn_model_destroy(gtcrn_model* m) {
     if (m->d_dbg) (void)hipFree(m->d_dbg);
     if (m->d_stamps) (void)hipFree(m->d_stamps);
     if (m->d_pf) (void)hipFree(m->d_pf);
+    if (m->d_pfq) (void)hipFree(m->d_pfq);
     if (m->d_pi) (void)hipFree(m->d_pi);
     if (m->d_twid) (void)hipFree(m->d_twid);
     if (m->d_ptr8) (void)hipFree(m->d_ptr8);
@@ -417,7 +430,8 @@ int gtcrn_forward_spec(gtcrn_model* m, const float* d_spec_in, long isb, long is
 }
 
 static int forward_wave_impl(gtcrn_model* m, const float* d_wave, float* d_wave_out, int B, long L,
-                             const int* d_lengths, const float* d_win, void* stream) {
+                             const int* d_lengths, const float* d_win, void* stream,
+                             const gtk::Quant* q = nullptr) {
     int rc = check_model(m);
     if (rc) return rc;
     if (!d_wave || !d_wave_out || !d_win) return fail(GTCRN_ERR_ARG, "null pointer");
@@ -433,7 +447,7 @@ static int forward_wave_impl(gtcrn_model* m, const float* d_wave, float* d_wave_
     tm.begin(0);
     LAUNCH_TRY(gtk::launch_stft(d_wave, B, L, T, d_lengths, d_win, m->d_twid, m->d_spec_a, sb, sf, st, nullptr, s));
     tm.end();
-    rc = run_model(m, m->d_spec_a, sb, sf, st, m->d_spec_b, sb, sf, st, B, T, nullptr, s, d_lengths);
+    rc = run_model(m, m->d_spec_a, sb, sf, st, m->d_spec_b, sb, sf, st, B, T, nullptr, s, d_lengths, q);
     if (rc) return rc;
     tm.begin(5);
     LAUNCH_TRY(gtk::launch_istft(m->d_spec_b, sb, sf, st, B, T, d_lengths, d_win, m->d_twid, d_wave_out, s));
@@ -450,6 +464,36 @@ int gtcrn_forward_wave_var(gtcrn_model* m, const float* d_wave, float* d_wave_ou
                            const int* d_lengths, const float* d_win, void* stream) {
     if (!d_lengths) return fail(GTCRN_ERR_ARG, "gtcrn_forward_wave_var: null lengths");
     return forward_wave_impl(m, d_wave, d_wave_out, B, Lmax, d_lengths, d_win, stream);
+}
+
+static int quant_opts(float in_scale, float out_scale, gtk::Quant* q) {
+    if (in_scale < 0.f || out_scale < 0.f) return fail(GTCRN_ERR_ARG, "quantiser scales must be >= 0 (0 = fp16 boundary)");
+    q->in_step = in_scale / 255.0f;     // calibration maps [-scale/2, scale/2] onto the 255 int8 steps
+    q->out_step = out_scale / 255.0f;
+    return 0;
+}
+
+int gtcrn_forward_spec_quant(gtcrn_model* m, const float* d_spec_in, long isb, long isf, long ist, float* d_spec_out,
+                             long osb, long osf, long ost, int B, int T, float in_scale, float out_scale, void* stream) {
+    int rc = check_model(m);
+    if (rc) return rc;
+    if (!d_spec_in || !d_spec_out) return fail(GTCRN_ERR_ARG, "null spectrogram pointer");
+    if (B < 1 || T < 1) return fail(GTCRN_ERR_ARG, "B and T must be >= 1");
+    if (int rc0 = check_spec_layout(d_spec_in, isb, isf, ist)) return rc0;
+    if (int rc0 = check_spec_layout(d_spec_out, osb, osf, ost)) return rc0;
+    gtk::Quant q;
+    if ((rc = quant_opts(in_scale, out_scale, &q))) return rc;
+    hipStream_t s = (hipStream_t)stream;
+    rc = ensure_workspace(m, B, T, s);
+    if (rc) return rc;
+    return run_model(m, d_spec_in, isb, isf, ist, d_spec_out, osb, osf, ost, B, T, nullptr, s, nullptr, &q);
+}
+
+int gtcrn_forward_wave_quant(gtcrn_model* m, const float* d_wave, float* d_wave_out, int B, long L, const float* d_win,
+                             float in_scale, float out_scale, void* stream) {
+    gtk::Quant q;
+    if (int rc = quant_opts(in_scale, out_scale, &q)) return rc;
+    return forward_wave_impl(m, d_wave, d_wave_out, B, L, nullptr, d_win, stream, &q);
 }
 
 size_t gtcrn_stream_state_bytes(void) { return sizeof(float) * gtk::ST_FLOATS; }

@@ -34,6 +34,12 @@ constexpr int ST_DEC_H = ST_G2_H + 30 * 33 * 16;
 constexpr int ST_DEC_E = ST_DEC_H + 3 * 2 * 33 * 16;
 constexpr int ST_FLOATS = ST_DEC_E + 48;         // 38116 floats = 152 464 B per stream
 
+// int8-weight / fp16-activation variant (BASELINE configs[4]); steps > 0 add the tflite path's int8 boundary
+struct Quant {
+    float in_step = 0.f;    // input quantiser step (calib scale / 255), 0 = fp16 input
+    float out_step = 0.f;   // output quantiser step, 0 = fp16 output
+};
+
 int configure_kernels();
 // lens (optional, device, int32[B]): variable-length batch -- utterance b holds lens[b] <= L samples in its row of
 // L, i.e. 1 + lens[b]/256 <= T frames; L and T stay the row strides of every tensor.  nullptr: all rows are full.
@@ -47,15 +53,15 @@ int launch_istft_adjoint(const float* gwave, int B, int T, const float* win, con
                          long sf, long st, hipStream_t s);
 int launch_encoder(const float* spec, long sb, long sf, long st, int B, int T, const int* lens, const float* PF,
                    const int* PI, float* en0, float* en1, float* en2, float* en3, float* en4, float* state,
-                   unsigned long long* stamps, hipStream_t s);
+                   unsigned long long* stamps, hipStream_t s, const Quant* q = nullptr);
 int launch_gtcn(const float* xin, float* xout, const float* P, int B, int T, float* state, int st_off,
                 const float* addend, unsigned long long* stamps, hipStream_t s);
 int launch_gtcn_band(const float* xin, float* xout, const float* P, int B, int T, const int* lens, const float* addend,
-                     hipStream_t s);
+                     hipStream_t s, const Quant* q = nullptr);
 int launch_decoder(const float* xg, const float* en0, const float* en1, const float* en2, const float* en3,
                    const float* en4, const float* spec, long sb, long sf, long st, float* out, long osb, long osf,
                    long ost, int B, int T, const int* lens, const float* PF, const int* PI, float* state, float* dbg,
-                   unsigned long long* stamps, hipStream_t s);
+                   unsigned long long* stamps, hipStream_t s, const Quant* q = nullptr);
 int launch_state_convert(float* state, int N, float* conv, float* tra, float* const* tcn8, const int* PI, int dir,
                          hipStream_t s);
 int launch_conv2d_causal(const float* x, const float* cache, const float* w, const float* bias, float* y,

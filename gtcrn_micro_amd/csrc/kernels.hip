@@ -83,14 +83,62 @@ __device__ __forceinline__ float fast_tanh(float x) {
     return 1.0f - 2.0f * __frcp_rn(t + 1.0f);
 }
 
+// ---- the int8-weight / fp16-activation variant (template flag Q; BASELINE configs[4]) -------------------------
+// Every 16x16 slot-matrix product is ONE v_mfma_f32_16x16x16_f16 (fp16 operands, fp32 accumulate): its B operand
+// holds k = 4g..4g+3 of column n and its D fragment rows 4g..4g+3 of column n, so -- exactly like the fp32 16x16x4
+// form -- a layer's output fragment, converted to fp16, IS the next layer's B operand.  Weights arrive as
+// int8-dequantised values (the host packer quantises the BatchNorm-folded weights per output channel, pack.cpp)
+// and are exactly representable after the fp16 conversion up to 2^-11; activations are rounded to fp16 (RNE) where a
+// layer produces them (rq), everything between two roundings is fp32.
+typedef _Float16 h16x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ h16x4 to_h4(const f32x4 v) {
+    h16x4 r;
+    r[0] = (_Float16)v[0]; r[1] = (_Float16)v[1]; r[2] = (_Float16)v[2]; r[3] = (_Float16)v[3];
+    return r;
+}
+__device__ __forceinline__ f32x4 mfma_h(h16x4 a, h16x4 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x16f16(a, b, c, 0, 0, 0);
+}
+template <bool Q>
+__device__ __forceinline__ float rq1(float v) {
+    if constexpr (Q) return (float)(_Float16)v;
+    else return v;
+}
+template <bool Q>
+__device__ __forceinline__ f32x4 rq(const f32x4 v) {
+    if constexpr (Q) {
+        const h16x4 h = to_h4(v);
+        f32x4 r = {(float)h[0], (float)h[1], (float)h[2], (float)h[3]};
+        return r;
+    } else {
+        return v;
+    }
+}
+// acc += M * b for one tile (M's fragment A, activations b)
+template <bool Q>
+__device__ __forceinline__ f32x4 mm1(const f32x4 A, const f32x4 b, f32x4 acc) {
+    if constexpr (Q) {
+        return mfma_h(to_h4(A), to_h4(b), acc);
+    } else {
+#pragma unroll
+        for (int s = 0; s < 4; ++s) acc = mfma(A[s], b[s], acc);
+        return acc;
+    }
+}
 // acc[i] += M * x[i] for the wave's tiles: 4 k-steps, tiles interleaved so the dependent
 // accumulator chains (40-cycle latency vs 32-cycle issue) overlap.
-template <int N>
+template <int N, bool Q = false>
 __device__ __forceinline__ void mm16(const f32x4 A, const f32x4 (&x)[N], f32x4 (&acc)[N]) {
+    if constexpr (Q) {
+        const h16x4 ah = to_h4(A);
 #pragma unroll
-    for (int s = 0; s < 4; ++s)
+        for (int i = 0; i < N; ++i) acc[i] = mfma_h(ah, to_h4(x[i]), acc[i]);
+    } else {
 #pragma unroll
-        for (int i = 0; i < N; ++i) acc[i] = mfma(A[s], x[i][s], acc[i]);
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+            for (int i = 0; i < N; ++i) acc[i] = mfma(A[s], x[i][s], acc[i]);
+    }
 }
 
 // Diagnostic build only (-DGT_STAMPS, libgtcrn_micro_hip_stamps.so): s_memtime stamps at the
@@ -464,7 +512,7 @@ constexpr int RING_SET = 3 * 2 * 35 * 16;   // floats of one stream's three 2-ro
 
 // `hook` runs right after the depth-conv phase (register pressure is past its peak there, and two
 // barrier intervals of work follow): the decoder uses it to request inputs of later phases early.
-template <bool DENSE, int TPW, bool MS, class Hook>
+template <bool DENSE, int TPW, bool MS, bool Q, class Hook>
 __device__ __forceinline__ void gtconv_block(f32x4 (&x)[TPW], const Tiles<TPW>& tt, const BlockCtx& c,
                                              const Lane& L, Hook&& hook STAMP_PARAM) {
     static_assert(!MS || TPW == 1, "multi-stream mode runs one tile per wave");
@@ -483,9 +531,9 @@ __device__ __forceinline__ void gtconv_block(f32x4 (&x)[TPW], const Tiles<TPW>& 
         const f32x4 A = ld4(c.pb + GB_PC1_A + n * 16 + 4 * g), Bv = ld4(c.pb + GB_PC1_B + 4 * g);
 #pragma unroll
         for (int i = 0; i < TPW; ++i) h[i] = Bv;
-        mm16<TPW>(A, x, h);
+        mm16<TPW, Q>(A, x, h);
 #pragma unroll
-        for (int i = 0; i < TPW; ++i) st4(c.sW + o35(tt, i, g), prelu4(h[i], a1));
+        for (int i = 0; i < TPW; ++i) st4(c.sW + o35(tt, i, g), rq<Q>(prelu4(h[i], a1)));
     }
     wg_barrier();
     STAMP(SS, 5)
@@ -518,13 +566,15 @@ __device__ __forceinline__ void gtconv_block(f32x4 (&x)[TPW], const Tiles<TPW>& 
             }
 #pragma unroll
             for (int i = 0; i < TPW; ++i) {
-                acc[i] = prelu4(acc[i], a2);
+                acc[i] = rq<Q>(prelu4(acc[i], a2));
                 x[i] = keep * x[i] + B2;
             }
-            mm16<TPW>(A2, acc, x);                            // point_conv2: the tiles' chains interleaved
+            mm16<TPW, Q>(A2, acc, x);                         // point_conv2: the tiles' chains interleaved
 #pragma unroll
-            for (int i = 0; i < TPW; ++i)
+            for (int i = 0; i < TPW; ++i) {
+                x[i] = rq<Q>(x[i]);
                 st4(c.sS + tt.pp(i) * 16 + 4 * g, x[i] * x[i]);   // energies are reduced cooperatively after the barrier
+            }
         } else {
             // dense transposed 3x3, tap major: each of the nine 16x16 slot matrices is read from LDS once per wave
             // (not once per tile) and feeds one MFMA chain per tile -- TPW independent accumulator chains
@@ -542,8 +592,7 @@ __device__ __forceinline__ void gtconv_block(f32x4 (&x)[TPW], const Tiles<TPW>& 
                         const int b0 = o35(tt, i, g);
                         const int rb = tap_base(i, back, b0, (int)ringoff);
                         const f32x4 tap = ld4(c.sW + rb + df * 16);
-#pragma unroll
-                        for (int s = 0; s < 4; ++s) acc[i] = mfma(A[s], tap[s], acc[i]);
+                        acc[i] = mm1<Q>(A, tap, acc[i]);
                     }
                     // one tap's loads (a matrix + TPW records) in flight at a time: hoisting more of them ahead of
                     // the MFMAs pushes the kernel into scratch
@@ -552,13 +601,15 @@ __device__ __forceinline__ void gtconv_block(f32x4 (&x)[TPW], const Tiles<TPW>& 
             }
 #pragma unroll
             for (int i = 0; i < TPW; ++i) {
-                acc[i] = prelu4(acc[i], a2);
+                acc[i] = rq<Q>(prelu4(acc[i], a2));
                 x[i] = keep * x[i] + B2;
             }
-            mm16<TPW>(A2, acc, x);                            // point_conv2: the tiles' chains interleaved
+            mm16<TPW, Q>(A2, acc, x);                         // point_conv2: the tiles' chains interleaved
 #pragma unroll
-            for (int i = 0; i < TPW; ++i)
+            for (int i = 0; i < TPW; ++i) {
+                x[i] = rq<Q>(x[i]);
                 st4(c.sS + tt.pp(i) * 16 + 4 * g, x[i] * x[i]);   // energies are reduced cooperatively after the barrier
+            }
         }
     }
     wg_barrier();
@@ -614,7 +665,7 @@ __device__ __forceinline__ void gtconv_block(f32x4 (&x)[TPW], const Tiles<TPW>& 
             float z = c.pb[GB_TRA_PB + ro];
 #pragma unroll
             for (int cc = 0; cc < 8; ++cc) z += c.pb[GB_TRA_PW + ro * 8 + cc] * sy[cc];
-            c.sG[rt * 16 + c.ib[ro]] = __frcp_rn(1.0f + __expf(-z));
+            c.sG[rt * 16 + c.ib[ro]] = rq1<Q>(__frcp_rn(1.0f + __expf(-z)));
             c.sG[rt * 16 + c.ib[8 + ro]] = 1.0f;
             // the last two frames' energies become the ring for the next chunk (row = frame & 1)
             if constexpr (MS) c.sEHk[rt * 48 + (c.sTB[rt] & 1) * 8 + ro] = e[16];
@@ -624,7 +675,7 @@ __device__ __forceinline__ void gtconv_block(f32x4 (&x)[TPW], const Tiles<TPW>& 
     wg_barrier();
     STAMP(SS, 7)
 #pragma unroll
-    for (int i = 0; i < TPW; ++i) x[i] = x[i] * ld4(c.sG + tt.tl[i] * 16 + 4 * g);
+    for (int i = 0; i < TPW; ++i) x[i] = rq<Q>(x[i] * ld4(c.sG + tt.tl[i] * 16 + 4 * g));
 }
 
 // zero the two pad columns of the TC rows of a 35-position row image (tid and the zero are made
@@ -708,9 +759,11 @@ constexpr int ENC_MS_LDS_FLOATS = EncLds<MS_ROWS, MS_STREAMS, true>::FLOATS;
 // one new frame each; the host passes T = MS_STREAMS and the spectrogram strides sb' = MS_STREAMS * sb, st' = sb, so
 // every tensor is addressed exactly as if the streams' frames were consecutive frames of "utterance" b -- only the
 // history (rings, energies, frame counters) is per row.
-template <int TPW, bool MS>
+// Q: int8-weight / fp16-activation variant (PF then holds the quantised weights); qin > 0 additionally passes the
+// input spectrogram through the int8 boundary of the tflite path (x_q = round(x / qin), tflite_infer.py:79-82).
+template <int TPW, bool MS, bool Q>
 __global__ __launch_bounds__(NTHR) void k_encoder(const float* __restrict__ spec, long sb, long sf, long st, int T,
-                                                 const int* __restrict__ lens, int NB,
+                                                 const int* __restrict__ lens, int NB, float qin,
                                                  const float* __restrict__ PF, const int* __restrict__ PI,
                                                  float* __restrict__ en0, float* __restrict__ en1,
                                                  float* __restrict__ en2, float* __restrict__ en3,
@@ -812,11 +865,19 @@ __global__ __launch_bounds__(NTHR) void k_encoder(const float* __restrict__ spec
 #pragma unroll
             for (int q = 0; q < SPEC_ITEMS; ++q) {
                 if (tl < nfr && f < NBINS) {
-                    const float2 v = spn[q];
+                    float2 v = spn[q];
+                    if constexpr (Q) {
+                        if (qin > 0.f) {
+                            v.x = fminf(fmaxf(rintf(v.x / qin), -128.f), 127.f) * qin;
+                            v.y = fminf(fmaxf(rintf(v.y / qin), -128.f), 127.f) * qin;
+                        }
+                        v.x = rq1<Q>(v.x);
+                        v.y = rq1<Q>(v.y);
+                    }
                     const bool low = f < ERB_LOW;
                     float* d = low ? sEB + tl * EB_ROW + 1 + f : sSpec + tl * NBINS + f;
                     const int cs = low ? RW * EB_ROW : RW * NBINS;
-                    d[0] = __builtin_amdgcn_sqrtf(v.x * v.x + v.y * v.y + 1e-12f);
+                    d[0] = rq1<Q>(__builtin_amdgcn_sqrtf(v.x * v.x + v.y * v.y + 1e-12f));
                     d[cs] = v.x;
                     d[2 * cs] = v.y;
                 }
@@ -852,7 +913,7 @@ __global__ __launch_bounds__(NTHR) void k_encoder(const float* __restrict__ spec
                     a0 += w[i] * (i < cnt ? sp[i] : 0.f);
                     a1 += w[i + 1] * (i + 1 < cnt ? sp[i + 1] : 0.f);
                 }
-                sEB[ct * EB_ROW + 1 + ERB_LOW + band] = a0 + a1;
+                sEB[ct * EB_ROW + 1 + ERB_LOW + band] = rq1<Q>(a0 + a1);
             }
         }
         STAMP(SS, 13)
@@ -868,9 +929,9 @@ __global__ __launch_bounds__(NTHR) void k_encoder(const float* __restrict__ spec
             // 129 bins = 2 x 64 lanes + 1: the last bin rides on lane 0 instead of a third, nearly empty pass
             static_assert(F0 == 129, "SFE lane mapping");
             const int f = tv & 63;
-            d[f] = w0 * e[f] + w1 * e[f + 1] + w2 * e[f + 2];
-            d[f + 64] = w0 * e[f + 64] + w1 * e[f + 65] + w2 * e[f + 66];
-            if (f == 0) d[128] = w0 * e[128] + w1 * e[129] + w2 * e[130];
+            d[f] = rq1<Q>(w0 * e[f] + w1 * e[f + 1] + w2 * e[f + 2]);
+            d[f + 64] = rq1<Q>(w0 * e[f + 64] + w1 * e[f + 65] + w2 * e[f + 66]);
+            if (f == 0) d[128] = rq1<Q>(w0 * e[128] + w1 * e[129] + w2 * e[130]);
         }
         // zero the pad positions of E0 (columns 0,1,67,68 of each row): region A held the spectrogram
         if (tv < RW * 4 * 4) {
@@ -903,10 +964,8 @@ __global__ __launch_bounds__(NTHR) void k_encoder(const float* __restrict__ spec
                 f32x4 bv;
 #pragma unroll
                 for (int s = 0; s < 4; ++s) bv[s] = sF0[off[s] + tl * F0_ROW + 2 * fo];
-                f32x4 acc = Bv;
-#pragma unroll
-                for (int s = 0; s < 4; ++s) acc = mfma(A[s], bv[s], acc);
-                acc = prelu4(acc, a);
+                f32x4 acc = mm1<Q>(A, bv, Bv);
+                acc = rq<Q>(prelu4(acc, a));
                 st4(sE0 + pl(tl * ENC_E0_ROW + 2 + fo, g), acc);
                 if (q < nfr * F1) st4(en0 + (long)t0 * (F1 * 16) + (unsigned)(q * 16 + 4 * g), acc);
             }
@@ -928,13 +987,12 @@ __global__ __launch_bounds__(NTHR) void k_encoder(const float* __restrict__ spec
 #pragma unroll
                 for (int i = 0; i < TPW; ++i) {
                     const f32x4 tap = ld4(sE0 + pl(tt.tl[i] * ENC_E0_ROW + 2 * tt.ff[i], g) + k * 16);
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) x[i] = mfma(A[q], tap[q], x[i]);
+                    x[i] = mm1<Q>(A, tap, x[i]);
                 }
             }
 #pragma unroll
             for (int i = 0; i < TPW; ++i) {
-                x[i] = prelu4(x[i], a);
+                x[i] = rq<Q>(prelu4(x[i], a));
                 {   // en1 in the slot order of its decoder consumer; scratch: this tile's records of F0/EB (dead)
                     const f32x4 y = permute_via_lds(sEB + tt.pp(i) * 16, ix, g, x[i]);
                     if (tt.pp(i) < nfr * 33) st4(en1 + (long)t0 * 528 + (unsigned)(tt.pp(i) * 16 + 4 * g), y);
@@ -963,7 +1021,7 @@ __global__ __launch_bounds__(NTHR) void k_encoder(const float* __restrict__ spec
             } else {
                 c.ms_roff = 0; c.ms_tb = 0;
             }
-            gtconv_block<false, TPW, MS>(x, tt, c, L, [] {} STAMP_ARG);
+            gtconv_block<false, TPW, MS, Q>(x, tt, c, L, [] {} STAMP_ARG);
             if (k < 2) {
                 float* dst = k == 0 ? en2 : en3;
                 const int* ix = sI + I_ENST + (k + 1) * 16 + 4 * g;
@@ -1228,7 +1286,7 @@ static_assert(GB_LDS_FLOATS * 4 <= 160 * 1024, "band GTCN LDS budget");
 // cw: this wave's 3 tiles of the current-chunk image; hw: this wave's 3 bins of block D's history ring
 // (row = frame mod 2d); n = lane's frame inside the chunk; t0 is a multiple of 16 >= 2d, so
 // (t0 + n) mod 2d == n mod 2d.
-template <int D>
+template <int D, bool Q>
 __device__ __forceinline__ void tcn_block_band(f32x4 (&x)[TPW], const float* pk, float* cw, float* hw, bool live,
                                                const Lane& L) {
     const int n = L.n, g = L.g;
@@ -1247,10 +1305,10 @@ __device__ __forceinline__ void tcn_block_band(f32x4 (&x)[TPW], const float* pk,
         const f32x4 A = ld4(pk + TCN_A1 + n * 16 + 4 * g), Bv = ld4(pk + TCN_B1 + 4 * g);
 #pragma unroll
         for (int i = 0; i < TPW; ++i) acc[i] = Bv;
-        mm16<TPW>(A, x, acc);
+        mm16<TPW, Q>(A, x, acc);
 #pragma unroll
         for (int i = 0; i < TPW; ++i) {
-            y1[i] = prelu4(acc[i], a1);
+            y1[i] = rq<Q>(prelu4(acc[i], a1));
             st4(cw + i * 256 + n * 16 + 4 * g, y1[i]);
         }
     }
@@ -1269,12 +1327,12 @@ __device__ __forceinline__ void tcn_block_band(f32x4 (&x)[TPW], const float* pk,
         for (int i = 0; i < TPW; ++i) {
             const f32x4 u1 = ld4(cw + i * 256 + c1), u2 = ld4(cw + i * 256 + c2);
             const f32x4 p1 = n >= D ? u1 : t1[i], p2 = n >= 2 * D ? u2 : t2[i];
-            y2[i] = prelu4(B2 + w0 * p2 + w1 * p1 + w2 * y1[i], a2);
+            y2[i] = rq<Q>(prelu4(B2 + w0 * p2 + w1 * p1 + w2 * y1[i], a2));
             acc[i] = B3 + x[i];
         }
-        mm16<TPW>(A, y2, acc);
+        mm16<TPW, Q>(A, y2, acc);
 #pragma unroll
-        for (int i = 0; i < TPW; ++i) x[i] = prelu4(acc[i], a3);
+        for (int i = 0; i < TPW; ++i) x[i] = rq<Q>(prelu4(acc[i], a3));
     }
     // ring update: the last 2d frames of the chunk (every live lane for the final, partial chunk is fine:
     // later frames overwrite earlier ones of the same row only in program order of a single lane set)
@@ -1285,6 +1343,7 @@ __device__ __forceinline__ void tcn_block_band(f32x4 (&x)[TPW], const float* pk,
     (void)h_minus_c;
 }
 
+template <bool Q>
 __global__ __launch_bounds__(NTHR) void k_gtcn_band(const float* __restrict__ xin, float* __restrict__ xout,
                                                    const float* __restrict__ P, int T, const int* __restrict__ lens,
                                                    const float* __restrict__ addend) {
@@ -1329,13 +1388,13 @@ __global__ __launch_bounds__(NTHR) void k_gtcn_band(const float* __restrict__ xi
         int po = 0;
         asm volatile("" : "+v"(po));
         // block k's ring: [33 bins][2d rows][16], blocks back to back (2, 4, 8, 16 rows per bin)
-        tcn_block_band<1>(x, sP + po + 0 * TCN_SIZE, cw, sHh + 33 * 0 * 16 + f0 * 2 * 16, live, L);
-        tcn_block_band<2>(x, sP + po + 1 * TCN_SIZE, cw, sHh + 33 * 2 * 16 + f0 * 4 * 16, live, L);
-        tcn_block_band<4>(x, sP + po + 2 * TCN_SIZE, cw, sHh + 33 * 6 * 16 + f0 * 8 * 16, live, L);
-        tcn_block_band<8>(x, sP + po + 3 * TCN_SIZE, cw, sHh + 33 * 14 * 16 + f0 * 16 * 16, live, L);
+        tcn_block_band<1, Q>(x, sP + po + 0 * TCN_SIZE, cw, sHh + 33 * 0 * 16 + f0 * 2 * 16, live, L);
+        tcn_block_band<2, Q>(x, sP + po + 1 * TCN_SIZE, cw, sHh + 33 * 2 * 16 + f0 * 4 * 16, live, L);
+        tcn_block_band<4, Q>(x, sP + po + 2 * TCN_SIZE, cw, sHh + 33 * 6 * 16 + f0 * 8 * 16, live, L);
+        tcn_block_band<8, Q>(x, sP + po + 3 * TCN_SIZE, cw, sHh + 33 * 14 * 16 + f0 * 16 * 16, live, L);
 #pragma unroll
         for (int i = 0; i < TPW; ++i)
-            if (live) st4(xout + (unsigned)((tc * 33 + f0 + i) * 16 + 4 * g), addend ? x[i] + ad[i] : x[i]);
+            if (live) st4(xout + (unsigned)((tc * 33 + f0 + i) * 16 + 4 * g), addend ? rq<Q>(x[i] + ad[i]) : x[i]);
     }
 }
 
@@ -1369,13 +1428,15 @@ constexpr int DEC_MS_LDS_FLOATS = DecLds<MS_ROWS, MS_STREAMS, true>::FLOATS;
 
 // DBG = true only for the stage-tap variant used by the parity tests (writes de0..de4 to `dbg`).
 // MS: multi-stream single-frame mode, see k_encoder (NB = number of streams; the host remaps the strides).
-template <bool DBG, int TPW, bool MS>
+// Q / qin / qout: the int8-weight / fp16-activation variant and its optional int8 boundary (see k_encoder); qout is
+// the step of the output quantiser (y = (y_q - zero) * out_scale, tflite_infer.py:88-91).
+template <bool DBG, int TPW, bool MS, bool Q>
 __global__ __launch_bounds__(NTHR) void k_decoder(const float* __restrict__ xg, const float* __restrict__ en0,
                                                  const float* __restrict__ en1, const float* __restrict__ en2,
                                                  const float* __restrict__ en3, const float* __restrict__ en4,
                                                  const float* __restrict__ spec, long sb, long sf, long st,
                                                  float* __restrict__ out, long osb, long osf, long ost, int T,
-                                                 const int* __restrict__ lens, int NB,
+                                                 const int* __restrict__ lens, int NB, float qin, float qout,
                                                  const float* __restrict__ PF, const int* __restrict__ PI,
                                                  float* __restrict__ state, float* __restrict__ dbg,
                                                  unsigned long long* __restrict__ stamps) {
@@ -1494,13 +1555,13 @@ __global__ __launch_bounds__(NTHR) void k_decoder(const float* __restrict__ xg, 
             } else {
                 c.ms_roff = 0; c.ms_tb = 0;
             }
-            gtconv_block<true, TPW, MS>(x, tt, c, L, hook STAMP_ARG);
+            gtconv_block<true, TPW, MS, Q>(x, tt, c, L, hook STAMP_ARG);
             if (DBG)
 #pragma unroll
                 for (int i = 0; i < TPW; ++i)
                     if (tt.pp(i) < npos) st4(dbg + ((long)j * nbt + ob + t0) * 528 + tt.pp(i) * 16 + 4 * g, x[i]);
 #pragma unroll
-            for (int i = 0; i < TPW; ++i) x[i] += skv[i];
+            for (int i = 0; i < TPW; ++i) x[i] = rq<Q>(x[i] + skv[i]);
             STAMP(SS, 8)
         };
 #pragma unroll 1
@@ -1538,52 +1599,40 @@ __global__ __launch_bounds__(NTHR) void k_decoder(const float* __restrict__ xg, 
 #pragma unroll
                 for (int i = 0; i < TPW; ++i) {
                     const f32x4 xp = ld4(sW + o35(tt, i, g) + 16);   // input bin f+1
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        ae[i] = mfma(A0[q], xp[q], ae[i]);
-                        ao[i] = mfma(A1[q], xp[q], ao[i]);
-                    }
+                    ae[i] = mm1<Q>(A0, xp, ae[i]);
+                    ao[i] = mm1<Q>(A1, xp, ao[i]);
                 }
             }
             {
                 const f32x4 A0 = ld4(Ae + 256), A1 = ld4(Ao + 256);
 #pragma unroll
-                for (int i = 0; i < TPW; ++i)
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        ae[i] = mfma(A0[q], x[i][q], ae[i]);
-                        ao[i] = mfma(A1[q], x[i][q], ao[i]);
-                    }
+                for (int i = 0; i < TPW; ++i) {
+                    ae[i] = mm1<Q>(A0, x[i], ae[i]);
+                    ao[i] = mm1<Q>(A1, x[i], ao[i]);
+                }
             }
             {
                 const f32x4 A0 = ld4(Ae + 512);
 #pragma unroll
                 for (int i = 0; i < TPW; ++i) {
                     const f32x4 xm = ld4(sW + o35(tt, i, g) - 16);   // input bin f-1
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) ae[i] = mfma(A0[q], xm[q], ae[i]);
+                    ae[i] = mm1<Q>(A0, xm, ae[i]);
                 }
             }
             const f32x4 A4 = ld4(sP + D_DE4_A + n * 16 + 4 * g);
 #pragma unroll
             for (int i = 0; i < TPW; ++i) {
-                f32x4 e2 = prelu4(ae[i], a), o2 = prelu4(ao[i], a);
+                f32x4 e2 = rq<Q>(prelu4(ae[i], a)), o2 = rq<Q>(prelu4(ao[i], a));
                 if (DBG && tt.pp(i) < npos) {
                     float* d3 = dbg + 3 * nbt * 528 + ((ob + t0 + tt.tl[i]) * F1) * 16 + 4 * g;
                     st4(d3 + (2 * tt.ff[i]) * 16, e2);
                     if (tt.ff[i] < 32) st4(d3 + (2 * tt.ff[i] + 1) * 16, o2);
                 }
                 // + en_outs[0] (identity slot order), then de_convs.4 in scatter form
-                e2 += s0e[i];
-                o2 += s0o[i];
-                f32x4 e = splat(0.f), o = splat(0.f);
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    e = mfma(A4[q], e2[q], e);
-                    o = mfma(A4[q], o2[q], o);
-                }
-                ze[i] = e;
-                zo[i] = o;
+                e2 = rq<Q>(e2 + s0e[i]);
+                o2 = rq<Q>(o2 + s0o[i]);
+                ze[i] = mm1<Q>(A4, e2, splat(0.f));
+                zo[i] = mm1<Q>(A4, o2, splat(0.f));
             }
         }
         wg_barrier();  // all taps of sW read: region A becomes Z[tl][65][16]
@@ -1644,7 +1693,7 @@ __global__ __launch_bounds__(NTHR) void k_decoder(const float* __restrict__ xg, 
                 const float* zr = sZ + (tq * DEC_Z_ROW + 1 + m) * 16;
                 const float sum = sP[D_DE4_B + o] + zr[16 + o * 5 + par] + zr[o * 5 + 2 + par] +
                                   zr[-16 + (par ? 10 : o * 5 + 4)];
-                sM[(o * RW + tq) * F0 + fq] = fast_tanh(sum);
+                sM[(o * RW + tq) * F0 + fq] = rq1<Q>(fast_tanh(sum));
                 fq += 59;
                 ot += 5;
                 if (fq >= F0) { fq -= F0; ++ot; }
@@ -1673,11 +1722,25 @@ __global__ __launch_bounds__(NTHR) void k_decoder(const float* __restrict__ xg, 
                     // second tap selected, not multiplied by a zero weight: for the last band it would read the
                     // first element of the next frame's row, which may be stale (0 * NaN)
                     const bool two = tb[2] != 0.f;
-                    const float mr = tb[1] * m0[0] + (two ? tb[2] * m0[1] : 0.f);
-                    const float mi = tb[1] * m0[RW * F0] + (two ? tb[2] * m0[RW * F0 + 1] : 0.f);
-                    const float re = spv[q].x, im = spv[q].y;
-                    *reinterpret_cast<float2*>(obase + (f * osf32 + tq * ost32)) =
-                        make_float2(re * mr - im * mi, im * mr + re * mi);
+                    const float mr = rq1<Q>(tb[1] * m0[0] + (two ? tb[2] * m0[1] : 0.f));
+                    const float mi = rq1<Q>(tb[1] * m0[RW * F0] + (two ? tb[2] * m0[RW * F0 + 1] : 0.f));
+                    float re = spv[q].x, im = spv[q].y;
+                    if constexpr (Q) {
+                        if (qin > 0.f) {       // the mask multiplies the model's own (boundary-quantised) input
+                            re = fminf(fmaxf(rintf(re / qin), -128.f), 127.f) * qin;
+                            im = fminf(fmaxf(rintf(im / qin), -128.f), 127.f) * qin;
+                        }
+                        re = rq1<Q>(re);
+                        im = rq1<Q>(im);
+                    }
+                    float yr = rq1<Q>(re * mr - im * mi), yi = rq1<Q>(im * mr + re * mi);
+                    if constexpr (Q) {
+                        if (qout > 0.f) {
+                            yr = fminf(fmaxf(rintf(yr / qout), -128.f), 127.f) * qout;
+                            yi = fminf(fmaxf(rintf(yi / qout), -128.f), 127.f) * qout;
+                        }
+                    }
+                    *reinterpret_cast<float2*>(obase + (f * osf32 + tq * ost32)) = make_float2(yr, yi);
                 }
                 spec_item_next(t_fast, tq, f);
             }
@@ -1852,17 +1915,18 @@ int launch_istft(const float* spec, long sb, long sf, long st, int B, int T, con
 
 int configure_kernels() {
     hipError_t e;
-    const void* enc[] = {reinterpret_cast<const void*>(k_encoder<TPW, false>),
-                         reinterpret_cast<const void*>(k_encoder<1, false>),
-                         reinterpret_cast<const void*>(k_encoder<2, false>)};
+    const void* enc[] = {reinterpret_cast<const void*>(k_encoder<TPW, false, false>),
+                         reinterpret_cast<const void*>(k_encoder<1, false, false>),
+                         reinterpret_cast<const void*>(k_encoder<2, false, false>),
+                         reinterpret_cast<const void*>(k_encoder<TPW, false, true>)};
     for (const void* f : enc) {
         e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, ENC_LDS_FLOATS * 4);
         if (e != hipSuccess) return (int)e;
     }
-    e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_encoder<1, true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_encoder<1, true, false>), hipFuncAttributeMaxDynamicSharedMemorySize,
                             ENC_MS_LDS_FLOATS * 4);
     if (e != hipSuccess) return (int)e;
-    e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_decoder<false, 1, true>),
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_decoder<false, 1, true, false>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, DEC_MS_LDS_FLOATS * 4);
     if (e != hipSuccess) return (int)e;
     const void* gt[] = {reinterpret_cast<const void*>(k_gtcn<TPW, false>), reinterpret_cast<const void*>(k_gtcn<1, false>),
@@ -1872,15 +1936,19 @@ int configure_kernels() {
         e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, GT_LDS_FLOATS * 4);
         if (e != hipSuccess) return (int)e;
     }
-    e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_gtcn_band), hipFuncAttributeMaxDynamicSharedMemorySize,
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_gtcn_band<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
                             GB_LDS_FLOATS * 4);
     if (e != hipSuccess) return (int)e;
-    const void* dec[] = {reinterpret_cast<const void*>(k_decoder<false, TPW, false>),
-                         reinterpret_cast<const void*>(k_decoder<true, TPW, false>),
-                         reinterpret_cast<const void*>(k_decoder<false, 1, false>),
-                         reinterpret_cast<const void*>(k_decoder<true, 1, false>),
-                         reinterpret_cast<const void*>(k_decoder<false, 2, false>),
-                         reinterpret_cast<const void*>(k_decoder<true, 2, false>)};
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_gtcn_band<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            GB_LDS_FLOATS * 4);
+    if (e != hipSuccess) return (int)e;
+    const void* dec[] = {reinterpret_cast<const void*>(k_decoder<false, TPW, false, false>),
+                         reinterpret_cast<const void*>(k_decoder<true, TPW, false, false>),
+                         reinterpret_cast<const void*>(k_decoder<false, 1, false, false>),
+                         reinterpret_cast<const void*>(k_decoder<true, 1, false, false>),
+                         reinterpret_cast<const void*>(k_decoder<false, 2, false, false>),
+                         reinterpret_cast<const void*>(k_decoder<true, 2, false, false>),
+                         reinterpret_cast<const void*>(k_decoder<false, TPW, false, true>)};
     for (const void* f : dec) {
         e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, DEC_LDS_FLOATS * 4);
         if (e != hipSuccess) return (int)e;
@@ -1895,22 +1963,25 @@ static bool use_multi_stream(int T, const float* state, long sb) {
 
 int launch_encoder(const float* spec, long sb, long sf, long st, int B, int T, const int* lens, const float* PF,
                    const int* PI, float* en0, float* en1, float* en2, float* en3, float* en4, float* state,
-                   unsigned long long* stamps, hipStream_t s) {
-    if (use_multi_stream(T, state, sb)) {
+                   unsigned long long* stamps, hipStream_t s, const Quant* q) {
+    if (q) {   // int8-weight / fp16-activation variant: offline form only, the full-chunk instantiation
+        hipLaunchKernelGGL((k_encoder<TPW, false, true>), dim3(B), dim3(NTHR), ENC_LDS_FLOATS * 4, s, spec, sb, sf, st, T,
+                           lens, B, q->in_step, PF, PI, en0, en1, en2, en3, en4, (float*)nullptr, stamps);
+    } else if (use_multi_stream(T, state, sb)) {
         // streams b*4 .. b*4+3 become rows 0..3 of workgroup b: sb' = 4 sb, st' = sb, T' = 4
         const int grid = (B + MS_STREAMS - 1) / MS_STREAMS;
-        hipLaunchKernelGGL((k_encoder<1, true>), dim3(grid), dim3(NTHR), ENC_MS_LDS_FLOATS * 4, s, spec,
-                           (long)MS_STREAMS * sb, sf, sb, MS_STREAMS, (const int*)nullptr, B, PF, PI, en0, en1, en2, en3,
-                           en4, state, stamps);
+        hipLaunchKernelGGL((k_encoder<1, true, false>), dim3(grid), dim3(NTHR), ENC_MS_LDS_FLOATS * 4, s, spec,
+                           (long)MS_STREAMS * sb, sf, sb, MS_STREAMS, (const int*)nullptr, B, 0.f, PF, PI, en0, en1, en2,
+                           en3, en4, state, stamps);
     } else if (T <= SHORT_T)
-        hipLaunchKernelGGL((k_encoder<1, false>), dim3(B), dim3(NTHR), ENC_LDS_FLOATS * 4, s, spec, sb, sf, st, T, lens,
-                           B, PF, PI, en0, en1, en2, en3, en4, state, stamps);
+        hipLaunchKernelGGL((k_encoder<1, false, false>), dim3(B), dim3(NTHR), ENC_LDS_FLOATS * 4, s, spec, sb, sf, st, T,
+                           lens, B, 0.f, PF, PI, en0, en1, en2, en3, en4, state, stamps);
     else if (T <= SHORT_T2)
-        hipLaunchKernelGGL((k_encoder<2, false>), dim3(B), dim3(NTHR), ENC_LDS_FLOATS * 4, s, spec, sb, sf, st, T, lens,
-                           B, PF, PI, en0, en1, en2, en3, en4, state, stamps);
+        hipLaunchKernelGGL((k_encoder<2, false, false>), dim3(B), dim3(NTHR), ENC_LDS_FLOATS * 4, s, spec, sb, sf, st, T,
+                           lens, B, 0.f, PF, PI, en0, en1, en2, en3, en4, state, stamps);
     else
-        hipLaunchKernelGGL((k_encoder<TPW, false>), dim3(B), dim3(NTHR), ENC_LDS_FLOATS * 4, s, spec, sb, sf, st, T,
-                           lens, B, PF, PI, en0, en1, en2, en3, en4, state, stamps);
+        hipLaunchKernelGGL((k_encoder<TPW, false, false>), dim3(B), dim3(NTHR), ENC_LDS_FLOATS * 4, s, spec, sb, sf, st, T,
+                           lens, B, 0.f, PF, PI, en0, en1, en2, en3, en4, state, stamps);
     GT_LAUNCH_CHECK();
     return 0;
 }
@@ -1944,8 +2015,11 @@ int launch_gtcn(const float* xin, float* xout, const float* P, int B, int T, flo
 }
 
 int launch_gtcn_band(const float* xin, float* xout, const float* P, int B, int T, const int* lens, const float* addend,
-                     hipStream_t s) {
-    hipLaunchKernelGGL(k_gtcn_band, dim3(B), dim3(NTHR), GB_LDS_FLOATS * 4, s, xin, xout, P, T, lens, addend);
+                     hipStream_t s, const Quant* q) {
+    if (q)
+        hipLaunchKernelGGL(k_gtcn_band<true>, dim3(B), dim3(NTHR), GB_LDS_FLOATS * 4, s, xin, xout, P, T, lens, addend);
+    else
+        hipLaunchKernelGGL(k_gtcn_band<false>, dim3(B), dim3(NTHR), GB_LDS_FLOATS * 4, s, xin, xout, P, T, lens, addend);
     GT_LAUNCH_CHECK();
     return 0;
 }
@@ -1953,15 +2027,20 @@ int launch_gtcn_band(const float* xin, float* xout, const float* P, int B, int T
 int launch_decoder(const float* xg, const float* en0, const float* en1, const float* en2, const float* en3,
                    const float* en4, const float* spec, long sb, long sf, long st, float* out, long osb, long osf,
                    long ost, int B, int T, const int* lens, const float* PF, const int* PI, float* state, float* dbg,
-                   unsigned long long* stamps, hipStream_t s) {
+                   unsigned long long* stamps, hipStream_t s, const Quant* q) {
 #define GT_DEC(DBGV, TPWV)                                                                                         \
-    hipLaunchKernelGGL((k_decoder<DBGV, TPWV, false>), dim3(B), dim3(NTHR), DEC_LDS_FLOATS * 4, s, xg, en0, en1, en2, \
-                       en3, en4, spec, sb, sf, st, out, osb, osf, ost, T, lens, B, PF, PI, state, dbg, stamps)
-    if (!dbg && use_multi_stream(T, state, sb) && use_multi_stream(T, state, osb)) {
+    hipLaunchKernelGGL((k_decoder<DBGV, TPWV, false, false>), dim3(B), dim3(NTHR), DEC_LDS_FLOATS * 4, s, xg, en0, en1, \
+                       en2, en3, en4, spec, sb, sf, st, out, osb, osf, ost, T, lens, B, 0.f, 0.f, PF, PI, state, dbg,   \
+                       stamps)
+    if (q) {
+        hipLaunchKernelGGL((k_decoder<false, TPW, false, true>), dim3(B), dim3(NTHR), DEC_LDS_FLOATS * 4, s, xg, en0, en1,
+                           en2, en3, en4, spec, sb, sf, st, out, osb, osf, ost, T, lens, B, q->in_step, q->out_step, PF,
+                           PI, (float*)nullptr, (float*)nullptr, stamps);
+    } else if (!dbg && use_multi_stream(T, state, sb) && use_multi_stream(T, state, osb)) {
         const int grid = (B + MS_STREAMS - 1) / MS_STREAMS;
-        hipLaunchKernelGGL((k_decoder<false, 1, true>), dim3(grid), dim3(NTHR), DEC_MS_LDS_FLOATS * 4, s, xg, en0, en1,
-                           en2, en3, en4, spec, (long)MS_STREAMS * sb, sf, sb, out, (long)MS_STREAMS * osb, osf, osb,
-                           MS_STREAMS, (const int*)nullptr, B, PF, PI, state, (float*)nullptr, stamps);
+        hipLaunchKernelGGL((k_decoder<false, 1, true, false>), dim3(grid), dim3(NTHR), DEC_MS_LDS_FLOATS * 4, s, xg, en0,
+                           en1, en2, en3, en4, spec, (long)MS_STREAMS * sb, sf, sb, out, (long)MS_STREAMS * osb, osf, osb,
+                           MS_STREAMS, (const int*)nullptr, B, 0.f, 0.f, PF, PI, state, (float*)nullptr, stamps);
     } else if (T <= SHORT_T) {
         if (dbg) GT_DEC(true, 1); else GT_DEC(false, 1);
     } else if (T <= SHORT_T2) {

@@ -11,7 +11,9 @@
 //     out[2c+1] = x2[c] (models/gtcrn_micro.py:222-253)
 #include "pack.h"
 
+#include <algorithm>
 #include <cmath>
+#include <cstdint>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -316,6 +318,83 @@ int pack_params(const float* params, long n, float* F, int* I, std::string& err)
     for (int t = 0; t < 9; ++t)
         for (int s = 0; s < 16; ++s) I[I_PERM + t * 16 + s] = stored[t].l[s];
     return 0;
+}
+
+// ------------------------------------------------------------ int8-weight variant (BASELINE configs[4])
+// float -> IEEE binary16 (round to nearest even, subnormals kept) -> float: what v_cvt_f16_f32 does on the GPU
+float round_to_half(float x) {
+    uint32_t u;
+    std::memcpy(&u, &x, 4);
+    const uint32_t sign = u & 0x80000000u;
+    uint32_t a = u & 0x7FFFFFFFu;
+    if (a >= 0x7F800000u) return x;                       // inf / nan
+    if (a >= 0x477FF000u) {                               // >= 65520: rounds to infinity
+        a = 0x7F800000u;
+    } else if (a < 0x38800000u) {                         // below the smallest normal half (2^-14): subnormal grid 2^-24
+        float f;
+        std::memcpy(&f, &a, 4);
+        f = std::nearbyint(f * 16777216.0f) * (1.0f / 16777216.0f);   // default rounding mode: to nearest even
+        std::memcpy(&a, &f, 4);
+    } else {
+        const uint32_t lsb = (a >> 13) & 1u;
+        a = (a + 0xFFFu + lsb) & ~0x1FFFu;                // keep 10 mantissa bits, ties to even
+    }
+    a |= sign;
+    float r;
+    std::memcpy(&r, &a, 4);
+    return r;
+}
+
+namespace {
+// One quantisation group per output channel r: elements base[m*ms + r*rs + c*cs], m < nm, c < nc.
+// Symmetric per-channel int8 (onnx2tf -qt per-channel, scripts/onnx2tf.sh:57): scale = max|w| / 127,
+// q = round(w / scale) in [-127, 127]; the kernels consume fp16(q * scale).
+void quant_group(float* base, int rows, int rs, int nm, int ms, int nc, int cs) {
+    for (int r = 0; r < rows; ++r) {
+        double mx = 0.0;
+        for (int m = 0; m < nm; ++m)
+            for (int c = 0; c < nc; ++c) mx = std::max(mx, (double)std::fabs(base[m * ms + r * rs + c * cs]));
+        if (mx == 0.0) continue;
+        const float scale = (float)(mx / 127.0);
+        for (int m = 0; m < nm; ++m)
+            for (int c = 0; c < nc; ++c) {
+                float& w = base[m * ms + r * rs + c * cs];
+                double q = std::nearbyint((double)w / (double)scale);
+                q = q > 127.0 ? 127.0 : (q < -127.0 ? -127.0 : q);
+                w = round_to_half((float)(q * (double)scale));
+            }
+    }
+}
+void quant_gtconv(float* B, bool dense) {
+    quant_group(B + GB_PC1_A, 16, 16, 1, 0, 16, 1);
+    if (dense) quant_group(B + GB_DN_A, 16, 16, 9, 256, 16, 1);
+    else quant_group(B + GB_DW_W, 16, 1, 1, 0, 9, 16);           // [tap][channel]: one scale per channel
+    quant_group(B + GB_PC2_A, 16, 16, 1, 0, 16, 1);
+    quant_group(B + GB_TRA_DW, 8, 3, 1, 0, 3, 1);
+    quant_group(B + GB_TRA_PW, 8, 8, 1, 0, 8, 1);
+}
+}  // namespace
+
+// In place on the packed float buffer (after BatchNorm folding, which is what the exported graph holds): every
+// conv / linear weight becomes fp16(int8 * per-output-channel scale); biases, PReLU slopes and the KEEP masks stay.
+void quantize_packed(float* F) {
+    float* E = F + P_ENC;
+    float* D = F + P_DEC;
+    quant_group(E + E_ERB_W, 64, ERB_MAXBW, 1, 0, ERB_MAXBW, 1);
+    quant_group(E + E_SFE_W, 3, 3, 1, 0, 3, 1);
+    quant_group(E + E_EN0_A, 16, 16, 1, 0, 16, 1);
+    quant_group(E + E_EN1_A, 16, 16, 5, 256, 16, 1);
+    for (int k = 0; k < 3; ++k) quant_gtconv(E + E_BLK + k * GB_SIZE, false);
+    for (int t = 0; t < 8; ++t) {
+        float* T = F + P_GTCN + t * TCN_SIZE;
+        quant_group(T + TCN_A1, 16, 16, 1, 0, 16, 1);
+        quant_group(T + TCN_DW, 16, 1, 1, 0, 3, 16);
+        quant_group(T + TCN_A3, 16, 16, 1, 0, 16, 1);
+    }
+    for (int j = 0; j < 3; ++j) quant_gtconv(D + D_BLK + j * GBD_SIZE, true);
+    quant_group(D + D_DE3_AE, 16, 16, 5, 256, 16, 1);            // AE (3 matrices) + AO (2) share the output channels
+    quant_group(D + D_DE4_A, 2, 80, 5, 16, 16, 1);               // rows o*5+k: output channel o owns five rows
+    quant_group(D + D_BS_W, 192, ERB_MAXBS, 1, 0, ERB_MAXBS, 1);
 }
 
 void make_window(int kind, float* w) {

@@ -1,0 +1,86 @@
+"""The int8-weight / fp16-activation variant (BASELINE configs[4]) and its quality scoring.
+
+Counterpart of the reference's quantised deployment path (scripts/onnx2tf.sh:50-64 -> tflite_infer.py:60-107) and of
+the two closed-form scores of its evaluation (eval/eval_intrusive_metrics.py:74-91).  PARITY UNPINNED: the reference
+ships no quantised model or calibration data, so the contract is this build's own (include/gtcrn_micro_hip.h,
+gtcrn_forward_spec_quant); PESQ is a third-party C library (pesq==0.0.4) that is not available here, the scores are
+SI-SNR and SDR.  The arithmetic runs in the HIP library (Engine.forward_wave_quant); the scores are host-side numpy.
+"""
+import time
+
+import numpy as np
+
+CALIB_SCALE = 19.944473266601562          # streaming/tflite/calib_scale.txt:1 (utils/calibration_data.py:97-106)
+
+
+def sisnr_metric(ref, inf):
+    """eval_intrusive_metrics.py:74-82: both signals mean-removed, target = projection of inf on ref."""
+    ref = np.asarray(ref, np.float64)
+    inf = np.asarray(inf, np.float64)
+    inf = inf - inf.mean()
+    ref = ref - ref.mean()
+    a = np.sum(inf * ref) / np.sum(ref ** 2 + 1e-8)
+    e_tagt = a * ref
+    e_res = inf - e_tagt
+    return float(10 * np.log10((np.sum(e_tagt ** 2) + 1e-8) / (np.sum(e_res ** 2) + 1e-8)))
+
+
+def sdr_metric(ref, inf):
+    """eval_intrusive_metrics.py:85-91: mean-removed, target = ref itself."""
+    ref = np.asarray(ref, np.float64)
+    inf = np.asarray(inf, np.float64)
+    inf = inf - inf.mean()
+    ref = ref - ref.mean()
+    e_res = inf - ref
+    return float(10 * np.log10((np.sum(ref ** 2) + 1e-8) / (np.sum(e_res ** 2) + 1e-8)))
+
+
+def score(clean, estimates):
+    """Mean SI-SNR / SDR (dB) over a batch for each named estimate: {name: (B,L) array} -> {name: {...}}."""
+    out = {}
+    for name, est in estimates.items():
+        n = min(clean.shape[1], est.shape[1])
+        out[name] = {"si_snr_db": round(float(np.mean([sisnr_metric(c[:n], e[:n]) for c, e in zip(clean, est)])), 3),
+                     "sdr_db": round(float(np.mean([sdr_metric(c[:n], e[:n]) for c, e in zip(clean, est)])), 3)}
+    return out
+
+
+def bench_leg(params, device, wave, win, world, sync_all, max_over_ranks, steps=50, score_clips=32):
+    """bench.py's `quant` object: throughput of the variant on the headline workload (same B x 4 s batch, wave -> wave)
+    and the SI-SNR / SDR change against the fp32 HIP path on synthetic DNS-style mixes."""
+    import torch
+    from . import Engine
+    from .train import synthetic_mix
+    eng = Engine(params, device)
+    B, L = wave.shape
+    T = 1 + L // 256
+    out = torch.empty((B, 256 * (T - 1)), device=wave.device)
+    eng.reserve(B, T)
+    for _ in range(5):
+        eng.forward_wave_quant(wave, win, out=out)
+    sync_all()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        eng.forward_wave_quant(wave, win, out=out)
+    sync_all()
+    el = max_over_ranks(time.perf_counter() - t0, "cuda") / steps
+    # quality: same mixes through fp32, int8/fp16 and int8/fp16 + the tflite int8 boundary
+    noisy, clean = synthetic_mix(score_clips, samples=L, seed=4343, device=wave.device)
+    est = {"noisy_input": noisy[:, :256 * (T - 1)],
+           "fp32": eng.forward_wave(noisy, win),
+           "int8w_fp16a": eng.forward_wave_quant(noisy, win),
+           "int8w_fp16a_int8_io": eng.forward_wave_quant(noisy, win, CALIB_SCALE, CALIB_SCALE * 2 ** 0.5)}
+    sc = score(clean.cpu().numpy(), {k: v.cpu().numpy() for k, v in est.items()})
+    rel = float((est["int8w_fp16a"] - est["fp32"]).abs().max() / est["fp32"].abs().max())
+    return {
+        "workload": f"offline wave->wave, B={B} clips/GPU x {L / 16000:g} s, per-output-channel int8 weights, fp16 "
+                    "activations (fp16 MFMA, fp32 accumulate), fp32 STFT/iSTFT; shipped checkpoint weights",
+        "dtype": "int8 weights / fp16 activations / fp32 accumulate", "parity": "unpinned (no reference artefacts)",
+        "ms_per_step": round(el * 1e3, 4), "frames_per_s": round(world * B * T / el, 1), "steps": steps,
+        "max_rel_diff_vs_fp32_wave": rel,
+        "scores_on_synthetic_mixes": sc,
+        "si_snr_delta_db_vs_fp32": round(sc["int8w_fp16a"]["si_snr_db"] - sc["fp32"]["si_snr_db"], 3),
+        "sdr_delta_db_vs_fp32": round(sc["int8w_fp16a"]["sdr_db"] - sc["fp32"]["sdr_db"], 3),
+        "si_snr_delta_db_vs_fp32_with_int8_io": round(sc["int8w_fp16a_int8_io"]["si_snr_db"] - sc["fp32"]["si_snr_db"], 3),
+        "pesq": None, "pesq_note": "PESQ is third-party C (pesq==0.0.4), absent here: SI-SNR/SDR reported instead",
+    }

@@ -104,6 +104,29 @@ int gtcrn_forward_wave(gtcrn_model *m, const float *d_wave, float *d_wave_out, i
 int gtcrn_forward_wave_var(gtcrn_model *m, const float *d_wave, float *d_wave_out, int B, long Lmax,
                            const int *d_lengths, const float *d_win, void *stream);
 
+/* ---- int8-weight / fp16-activation variant (BASELINE configs[4]) ----------------------
+ * Replaces the quantised deployment path of the reference: onnx2tf -oiqt -qt per-channel -rtpo PReLU
+ * (scripts/onnx2tf.sh:50-64) run by tflite_infer.py:60-107.  The reference ships no quantised model, no
+ * calibration data and no TensorFlow, so this variant has its OWN stated contract -- PARITY UNPINNED:
+ *   weights      every conv / linear weight of the BatchNorm-folded graph -> symmetric int8 per output channel
+ *                (scale = max|w| / 127), consumed as fp16(int8 * scale); biases and PReLU slopes stay fp32
+ *   activations  rounded to fp16 (round to nearest even) where a layer produces them; products and sums in fp32
+ *                (v_mfma_f32_16x16x16_f16: fp16 operands, fp32 accumulate)
+ *   boundary     in_scale / out_scale > 0 add the tflite model's int8 input / output tensors:
+ *                x_q = clip(round(x / (scale/255)), -128, 127), x = x_q * scale/255 (tflite_infer.py:79-92 with zero
+ *                point 0; the calibration convention x/scale + 0.5 in [0,1] of utils/calibration_data.py:97-106 is
+ *                this quantiser, scale = 19.944473 in streaming/tflite/calib_scale.txt).  0 = fp16 boundary.
+ * Same shapes/strides as gtcrn_forward_spec / gtcrn_forward_wave (STFT and iSTFT stay fp32: they are the caller's
+ * torch.stft / torch.istft around the tflite interpreter, tflite_infer.py:63-101).  Offline only. */
+int gtcrn_forward_spec_quant(gtcrn_model *m, const float *d_spec_in, long isb, long isf, long ist,
+                             float *d_spec_out, long osb, long osf, long ost, int B, int T, float in_scale,
+                             float out_scale, void *stream);
+int gtcrn_forward_wave_quant(gtcrn_model *m, const float *d_wave, float *d_wave_out, int B, long L,
+                             const float *d_win, float in_scale, float out_scale, void *stream);
+/* Host views for CPU tests: the packed buffers with quantised weights; float -> binary16 -> float (RNE). */
+int gtcrn_pack_params_quant_host(const float *h_params, long n_floats, float *h_f, int *h_i);
+float gtcrn_round_to_half(float x);
+
 /* ---- streaming ----------------------------------------------------------
  * Replaces StreamGTCRNMicro.forward(spec, conv_cache, tra_cache, tcn_cache)
  * (gtcrn_micro_stream.py:541-574) for nstreams independent streams.  The

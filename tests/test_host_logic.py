@@ -249,3 +249,67 @@ def test_infer_host_helpers(tmp_path):
             (tmp_path / f"{f}.rank{r}").write_text("".join(x + "\n" for x in rows))
     merge_scp(str(tmp_path), 2)
     assert (tmp_path / "inf.scp").read_text() == "a 1\nb 2\nc 3\n" == (tmp_path / "ref.scp").read_text()
+
+
+def test_quantised_weight_contract_on_host():
+    """configs[4] weight contract without a GPU: the packer's quantised buffers hold fp16(int8 * per-output-channel
+    scale) -- checked against the independent restatement in oracle/quant_port.py for the dense 3x3, a pointwise,
+    a depthwise and the ERB tables -- and the host float -> half rounding equals numpy's."""
+    import torch
+    from gtcrn_micro_amd import _lib
+    from oracle.quant_port import QuantPort
+    p = load_params("rand")
+    F, I = _lib.pack_params_host(p)
+    Fq, Iq = _lib.pack_params_host(p, quant=True)
+    assert np.array_equal(I, Iq) and not np.array_equal(F, Fq)
+    port = QuantPort(p)
+    # decoder block 0, dense transposed 3x3: packed tap (kt,kf) row o col i == W'[i,o,kt,kf] (input slots of de0 are
+    # the gtcn slot order: compare as multisets per output row, which is what the per-row scale acts on)
+    wq = port.w["decoder.de_convs.0.depth_conv"].numpy()                      # (in,out,3,3)
+    # float offsets of csrc/layout.h
+    P_ENC, ENC_SIZE, GTCN_SIZE = 0, 768 + 12 + 276 + 1300 + 3 * 828, 4 * 612
+    P_DEC = P_ENC + ENC_SIZE + 2 * GTCN_SIZE
+    GB_DN_A = 828
+    for o in range(16):
+        packed = np.sort(np.concatenate([Fq[P_DEC + GB_DN_A + t * 256 + o * 16: P_DEC + GB_DN_A + t * 256 + o * 16 + 16]
+                                         for t in range(9)]))
+        assert np.array_equal(packed, np.sort(wq[:, o].ravel())), o
+        assert np.array_equal(packed, packed.astype(np.float16).astype(np.float32))        # fp16 values
+        assert not np.array_equal(packed, np.sort(np.concatenate(
+            [F[P_DEC + GB_DN_A + t * 256 + o * 16: P_DEC + GB_DN_A + t * 256 + o * 16 + 16] for t in range(9)])))
+    # en_conv1 (Conv2d 16->16, 5 taps, identity slot order): E_EN1_A[k][o][i] == W'[o,i,0,k]
+    E_EN1_A = 768 + 12 + 276
+    w1 = port.w["encoder.en_convs.1.conv"].numpy()
+    for k in range(5):
+        assert np.array_equal(Fq[E_EN1_A + k * 256: E_EN1_A + (k + 1) * 256].reshape(16, 16), w1[:, :, 0, k])
+    # ERB.bm bands: the nonzeros of row j
+    erb = port.w["erb"].numpy()
+    for j in (0, 17, 63):
+        lo, cnt = int(I[j]), int(I[64 + j])                   # I_ERB_LO, I_ERB_N: the band's support in the fp32 bank
+        assert cnt > 0 and np.array_equal(Fq[j * 12: j * 12 + cnt], erb[j, lo:lo + cnt])
+    rng = np.random.default_rng(0)
+    xs = np.concatenate([rng.standard_normal(2000).astype(np.float32) * s for s in (1e-8, 1e-5, 1e-3, 1.0, 1e3, 7e4)] +
+                        [np.array([0.0, -0.0, 65504.0, 65519.9, 65520.0, 1e6, 6.1e-5, 5.96e-8, 2.98e-8, 2.9e-8], np.float32)])
+    with np.errstate(over="ignore"):
+        want = xs.astype(np.float16).astype(np.float32)
+    got = np.array([_lib.round_to_half(float(x)) for x in xs], np.float32)
+    assert np.array_equal(got, want)
+
+
+def test_quality_scores_closed_form():
+    """quant.sisnr_metric / sdr_metric restate eval_intrusive_metrics.py:74-91: closed-form cases."""
+    from gtcrn_micro_amd.quant import sdr_metric, sisnr_metric
+    rng = np.random.default_rng(1)
+    ref = rng.standard_normal(16000)
+    noise = rng.standard_normal(16000)
+    noise -= noise.mean()
+    r0 = ref - ref.mean()
+    noise -= (noise @ r0) / (r0 @ r0) * r0                   # exactly orthogonal to the (mean-removed) reference
+    for snr in (0.0, 10.0, 30.0):
+        g = np.sqrt((r0 @ r0) / (noise @ noise) / 10 ** (snr / 10))
+        inf = ref + g * noise
+        assert abs(sisnr_metric(ref, inf) - snr) < 1e-6 and abs(sdr_metric(ref, inf) - snr) < 1e-6
+        assert abs(sisnr_metric(ref, 0.5 * inf + 3.0) - snr) < 1e-6          # scale and offset invariant
+        want = 10 * np.log10(1.0 / (0.25 + 0.25 / 10 ** (snr / 10)))       # SDR is not: residual = -ref/2 + noise/2
+        assert abs(sdr_metric(ref, 0.5 * inf) - want) < 1e-6
+    assert sdr_metric(ref, ref) > 100
