@@ -91,6 +91,9 @@ def lib():
     L.gtcrn_trainer_destroy.restype = None
     L.gtcrn_train_workspace_bytes.restype = cl
     L.gtcrn_train_workspace_bytes.argtypes = [ci, ci]
+    L.gtcrn_train_workspace_bytes2.restype = cl
+    L.gtcrn_train_workspace_bytes2.argtypes = [ci, ci, ci]
+    L.gtcrn_trainer_set_storage.argtypes = [_vp, ci]
     L.gtcrn_train_forward.argtypes = [_vp, _vp, _vp, cl, cl, cl, _vp, cl, cl, cl, ci, ci, _vp]
     L.gtcrn_train_backward.argtypes = [_vp, _vp, _vp, cl, cl, cl, _vp, cl, cl, cl, _vp, _vp]
     L.gtcrn_train_tap.argtypes = [_vp, ctypes.c_char_p, _vp, ctypes.POINTER(cl), _vp]
@@ -516,9 +519,19 @@ class Trainer:
         except Exception:
             pass
 
+    STORAGE = {"f32": 0, "fp32": 0, "bf16": 1}
+
     @staticmethod
-    def workspace_bytes(B, T):
-        return int(lib().gtcrn_train_workspace_bytes(int(B), int(T)))
+    def workspace_bytes(B, T, storage="f32"):
+        return int(lib().gtcrn_train_workspace_bytes2(int(B), int(T), Trainer.STORAGE[storage]))
+
+    def set_storage(self, storage):
+        """Storage of the saved activations: "f32" (the reference's precision) or "bf16" (BASELINE configs[3]);
+        arithmetic, statistics, gradients and weights are fp32 in both."""
+        if storage not in self.STORAGE:
+            raise GtcrnError(f"storage must be one of {sorted(self.STORAGE)}, got {storage!r}")
+        _check(lib().gtcrn_trainer_set_storage(self._h, self.STORAGE[storage]))
+        self.storage = storage
 
     def _check_blob(self, blob, what):
         _require_cuda_f32(blob, what)

@@ -76,8 +76,11 @@ struct TcnBlock {             // TCN (models/gtcrn_micro.py:256-310)
 
 struct gtcrn_trainer {
     int device = 0;
+    int bf = 0;                   // format of the saved activations / block outputs: 0 fp32, 1 bf16
+    int ybf = 0;                  // format of the saved conv outputs in front of a BatchNorm: 0 fp32, 1 bf16, 2 fp16
     int B = 0, T = 0;
     bool planned = false, have_fwd = false;
+    bool shift_ready = false;     // bf16 storage: the per-unit centring shifts hold a previous step's batch means
     float* arena = nullptr;
     size_t arena_floats = 0;
     float* fscratch = nullptr;    // wgrad / TRA partial sums
@@ -88,7 +91,8 @@ struct gtcrn_trainer {
     Unit en0, en1, de3, de4;
     GtBlock enc[3], dec[3];
     TcnBlock tcn[8];
-    float *s3 = nullptr, *s4 = nullptr;
+    float *s3 = nullptr, *s4 = nullptr, *s_tmp = nullptr;
+    bool share_sums = false;
     // backward buffers
     float *dm = nullptr, *gs0 = nullptr, *gs[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
     float *q1 = nullptr, *q2 = nullptr, *dy = nullptr, *dv = nullptr, *dhd = nullptr, *dh = nullptr, *tmp_tra = nullptr;
@@ -103,14 +107,18 @@ struct gtcrn_trainer {
 namespace {
 
 struct Bump {
-    size_t used = 0;
+    size_t used = 0;              // in floats
     float* base = nullptr;
+    int bf = 0, ybf = 0;
     float* take(size_t n) {
         n = (n + 63) & ~size_t(63);
         float* p = base ? base + used : nullptr;
         used += n;
         return p;
     }
+    // a SAVED tensor of n elements (fp32 or bf16 per the trainer's storage); handled through a float* either way
+    float* take_saved(size_t n) { return take(bf ? (n + 1) / 2 : n); }
+    float* take_saved_y(size_t n) { return take(ybf ? (n + 1) / 2 : n); }
 };
 
 ConvGeom conv_geom(int B, int T, int Tout, int Fin, int Fout, int CinT, int cin_off, int Cin, int CoutT, int Cout,
@@ -122,6 +130,7 @@ ConvGeom conv_geom(int B, int T, int Tout, int Fin, int Fout, int CinT, int cin_
     g.nkt = nkt; g.nkf = nkf; g.t_off[0] = t0; g.t_off[1] = t1; g.t_off[2] = t2;
     g.f_mode = f_mode; g.sf = sf; g.pf = pf; g.w_co = w_co; g.w_ci = w_ci; g.w_kt = w_kt; g.w_kf = w_kf;
     g.accumulate = 0;
+    g.in_bf = g.out_bf = 0;
     return g;
 }
 ConvGeom adjoint(const ConvGeom& g, int accumulate) {
@@ -133,6 +142,7 @@ ConvGeom adjoint(const ConvGeom& g, int accumulate) {
     a.f_mode = 1 - g.f_mode;
     a.w_co = g.w_ci; a.w_ci = g.w_co;
     a.accumulate = accumulate;
+    a.in_bf = a.out_bf = 0;       // gradients are fp32
     return a;
 }
 DwGeom adjoint(const DwGeom& g, int accumulate) {
@@ -140,6 +150,7 @@ DwGeom adjoint(const DwGeom& g, int accumulate) {
     a.Tin = g.Tout; a.Tout = g.Tin;
     for (int k = 0; k < 3; ++k) { a.t_off[k] = -g.t_off[k]; a.f_off[k] = -g.f_off[k]; }
     a.accumulate = accumulate;
+    a.in_bf = a.out_bf = 0;
     return a;
 }
 
@@ -157,21 +168,25 @@ void unit_params(gtcrn_trainer* t, Unit& u, const std::string& conv, const std::
 
 void alloc_unit(Bump& b, Unit& u, long n, int C) {
     u.n = n; u.C = C;
-    u.y = b.take((size_t)n * C);
-    u.a = b.take((size_t)n * C);
-    u.stats = b.take(32);
+    u.y = b.take_saved_y((size_t)n * C);
+    u.a = b.take_saved((size_t)n * C);
+    u.stats = b.take(64);               // mean[C], invstd[C]; +32: the centring shift of the stored y (bf16 storage)
+    u.cg.in_bf = u.dg.in_bf = b.bf;     // forward geometry: saved activation in -> saved conv output
+    u.cg.out_bf = u.dg.out_bf = b.ybf;
 }
 
 // lays out every tensor of one (B, T) problem in the arena; base == nullptr: size query
 size_t plan(gtcrn_trainer* t, int B, int T, float* base) {
     Bump b;
     b.base = base;
+    b.bf = t->bf;
+    b.ybf = t->ybf;
     const long n129 = (long)B * T * 129, n65 = (long)B * T * 65, n33 = (long)B * T * 33;
     const int T2 = T + 2;
     const long n33x = (long)B * T2 * 33;
     t->taps.clear();
-    t->eb = b.take(n129 * 3);
-    t->f0 = b.take(n129 * 3);
+    t->eb = b.take_saved(n129 * 3);
+    t->f0 = b.take_saved(n129 * 3);
     // encoder.en_convs.0/1: ConvBlock (models/gtcrn_micro.py:344-364)
     t->en0.cg = conv_geom(B, T, T, 129, 65, 3, 0, 3, 16, 16, 1, 5, 0, 0, 0, 0, 2, 2, 15, 5, 5, 1);
     unit_params(t, t->en0, "encoder.en_convs.0.conv", "encoder.en_convs.0.bn", "encoder.en_convs.0.act");
@@ -216,7 +231,7 @@ size_t plan(gtcrn_trainer* t, int B, int T, float* base) {
         alloc_unit(b, k.pc2, nt, 8);
         k.o_tra = P(t, p + ".tra.depth_conv.weight");
         k.e = b.take((size_t)B * Tt * 8); k.yt = b.take((size_t)B * Tt * 8); k.g = b.take((size_t)B * Tt * 8);
-        k.out = b.take(n33 * 16);
+        k.out = b.take_saved(n33 * 16);
     };
     for (int k = 0; k < 3; ++k) {
         gt_block(t->enc[k], "encoder.en_convs." + std::to_string(k + 2), false, X);
@@ -248,9 +263,14 @@ size_t plan(gtcrn_trainer* t, int B, int T, float* base) {
         X = k.c3.a;
         if ((i & 3) == 3) t->taps["gtcn" + std::to_string(i / 4 + 1)] = {X, {T, 33, 16}};
     }
+    // bf16 storage (the memory-lean variant): the decoder's sums x + skip (three block inputs, s3, s4) are not saved --
+    // one shared buffer holds the current one, the backward recomputes each from its two (saved) addends right before
+    // it is needed (five extra streaming adds).  fp32 storage keeps them all, as before.
+    t->share_sums = t->bf != 0;
+    t->s_tmp = t->share_sums ? b.take_saved(n65 * 16) : nullptr;
     for (int i = 0; i < 3; ++i) {
         GtBlock& k = t->dec[i];
-        k.s = b.take(n33 * 16);
+        k.s = t->share_sums ? t->s_tmp : b.take_saved(n33 * 16);
         gt_block(k, "decoder.de_convs." + std::to_string(i), true, k.s);
         k.pc1.x = k.s;
         // the addends of s (previous output, skip) are needed by forward() only
@@ -258,13 +278,13 @@ size_t plan(gtcrn_trainer* t, int B, int T, float* base) {
         X = k.out;
         t->taps["de" + std::to_string(i)] = {X, {T, 33, 16}};
     }
-    t->s3 = b.take(n33 * 16);
+    t->s3 = t->share_sums ? t->s_tmp : b.take_saved(n33 * 16);
     // decoder.de_convs.3: ConvTranspose2d(16,16,(1,5),stride (1,2),padding (0,2)), weight [in][out][1][5]
     t->de3.cg = conv_geom(B, T, T, 33, 65, 16, 0, 16, 16, 16, 1, 5, 0, 0, 0, 1, 2, 2, 5, 80, 5, 1);
     unit_params(t, t->de3, "decoder.de_convs.3.conv", "decoder.de_convs.3.bn", "decoder.de_convs.3.act");
     t->de3.act = gtt::ACT_PRELU; t->de3.x = t->s3;
     alloc_unit(b, t->de3, n65, 16);
-    t->s4 = b.take(n65 * 16);
+    t->s4 = t->share_sums ? t->s_tmp : b.take_saved(n65 * 16);
     t->de4.cg = conv_geom(B, T, T, 65, 129, 16, 0, 16, 2, 2, 1, 5, 0, 0, 0, 1, 2, 2, 5, 10, 5, 1);
     unit_params(t, t->de4, "decoder.de_convs.4.conv", "decoder.de_convs.4.bn", "");
     t->de4.act = gtt::ACT_TANH; t->de4.x = t->s4;
@@ -272,15 +292,23 @@ size_t plan(gtcrn_trainer* t, int B, int T, float* base) {
     t->taps["de3"] = {t->de3.a, {T, 65, 16}};
     t->taps["de4"] = {t->de4.a, {T, 129, 2}};
     // ---- backward buffers
-    t->dm = b.take(n129 * 2);
     t->gs0 = b.take(n65 * 16);
     for (int i = 1; i < 5; ++i) t->gs[i] = b.take(n33 * 16);
     t->q1 = b.take(n33 * 16); t->q2 = b.take(n33 * 16);
     t->dy = b.take((size_t)std::max(std::max(n65 * 16, n33x * 16), n129 * 3));
-    t->dv = b.take(n33x * 8); t->dhd = b.take(n33x * 16); t->dh = b.take(n33 * 16);
+    // dv, dhd, dh are contiguous: after the last GTConv block they are dead and serve as d65 (gradient of en0.a)
+    const size_t pool = (size_t)n33x * 8 + (size_t)n33x * 16 + (size_t)n33 * 16;
+    float* pl = b.take(std::max(pool + 192, (size_t)n65 * 16));
+    t->dv = pl;
+    t->dhd = pl ? pl + (((size_t)n33x * 8 + 63) & ~size_t(63)) : nullptr;
+    t->dh = pl ? t->dhd + (((size_t)n33x * 16 + 63) & ~size_t(63)) : nullptr;
+    t->d65 = pl;
     t->tmp_tra = b.take((size_t)B * T2 * 8 * 3);
-    t->d65 = b.take(n65 * 16);
-    t->df0 = b.take(n129 * 3);
+    // dm (gradient of the mask, consumed by the first backward unit) and df0 (gradient of the SFE output, produced by
+    // the last one) live in q1, which the TCN / encoder backward uses only in between
+    static_assert(129 * 3 <= 33 * 16 && 129 * 2 <= 33 * 16, "dm / df0 must fit in q1");
+    t->dm = t->q1;
+    t->df0 = t->q1;
     return b.used;
 }
 
@@ -296,17 +324,23 @@ int ensure_plan(gtcrn_trainer* t, int B, int T) {
     }
     plan(t, B, T, t->arena);
     t->B = B; t->T = T; t->planned = true; t->have_fwd = false;
+    t->shift_ready = false;       // new arena: the first forward seeds the shifts from the running means
     return 0;
 }
 
 int unit_fwd(gtcrn_trainer* t, Unit& u, float* prm, hipStream_t s) {
     int parts = 0;   // > 0: the conv kernel produced the BatchNorm partial sums in its epilogue
-    if (u.dw) T_RUN(gtt::dw_fwd(u.dg, u.x, prm + u.o_w, prm + u.o_b, u.y, s, t->dscratch, &parts));
-    else T_RUN(gtt::conv_fwd(u.cg, u.x, prm + u.o_w, prm + u.o_b, u.y, s, t->dscratch, &parts));
     float* bn = prm + u.o_bn;   // weight, bias, running_mean, running_var (consecutive in the blob)
-    T_RUN(gtt::bn_stats(u.y, u.n, u.C, u.stats, bn + 2 * u.C, bn + 3 * u.C, t->dscratch, s, parts));
+    // bf16 storage: y is stored centred on the channel's batch mean of the previous step (the running mean before the
+    // first one); the train-mode BatchNorm is shift invariant and bn_stats keeps the shift up to date
+    float* shift = t->ybf ? u.stats + 32 : nullptr;
+    if (shift && !t->shift_ready)
+        T_HIP(hipMemcpyAsync(shift, bn + 2 * u.C, sizeof(float) * u.C, hipMemcpyDeviceToDevice, s));
+    if (u.dw) T_RUN(gtt::dw_fwd(u.dg, u.x, prm + u.o_w, prm + u.o_b, u.y, s, t->dscratch, &parts, shift));
+    else T_RUN(gtt::conv_fwd(u.cg, u.x, prm + u.o_w, prm + u.o_b, u.y, s, t->dscratch, &parts, shift));
+    T_RUN(gtt::bn_stats(u.y, u.n, u.C, u.stats, bn + 2 * u.C, bn + 3 * u.C, t->dscratch, s, parts, t->ybf, shift));
     T_RUN(gtt::bn_act(u.y, u.n, u.C, u.stats, bn, bn + u.C, u.res, u.act, u.o_slope >= 0 ? prm + u.o_slope : nullptr,
-                      u.a, s));
+                      u.a, s, t->bf, t->ybf));
     return 0;
 }
 
@@ -320,12 +354,13 @@ int unit_bwd(gtcrn_trainer* t, Unit& u, const float* prm, float* grads, const fl
         T_RUN(gtt::unit1x1_bwd(u.cg, u.x, u.y, da, u.res, u.stats, bn, bn + u.C, u.act,
                                u.o_slope >= 0 ? prm + u.o_slope : nullptr, prm + u.o_w, dx, dx_acc, dres, dres_acc,
                                grads + u.o_w, u.o_b >= 0 ? grads + u.o_b : nullptr, gbn, gbn + u.C,
-                               u.o_slope >= 0 ? grads + u.o_slope : nullptr, t->dscratch, t->fscratch, s));
+                               u.o_slope >= 0 ? grads + u.o_slope : nullptr, t->dscratch, t->fscratch, s, t->bf,
+                               t->ybf));
         return 0;
     }
     T_RUN(gtt::bn_act_bwd(da, u.y, u.n, u.C, u.stats, bn, bn + u.C, u.res, u.act,
                           u.o_slope >= 0 ? prm + u.o_slope : nullptr, t->dy, dres, dres_acc, gbn, gbn + u.C,
-                          u.o_slope >= 0 ? grads + u.o_slope : nullptr, t->dscratch, s));
+                          u.o_slope >= 0 ? grads + u.o_slope : nullptr, t->dscratch, s, t->bf, t->ybf));
     if (u.dw) {
         T_RUN(gtt::dw_wgrad(u.dg, u.x, t->dy, grads + u.o_w, u.o_b >= 0 ? grads + u.o_b : nullptr, t->fscratch, s));
         if (dx) T_RUN(gtt::dw_fwd(adjoint(u.dg, dx_acc), t->dy, prm + u.o_w, nullptr, dx, s));
@@ -342,8 +377,8 @@ int gt_fwd(gtcrn_trainer* t, GtBlock& k, float* prm, hipStream_t s) {
     if ((rc = unit_fwd(t, k.depth, prm, s))) return rc;
     if ((rc = unit_fwd(t, k.pc2, prm, s))) return rc;
     const float* tr = prm + k.o_tra;   // depth_conv.weight[24], .bias[8], point_conv.weight[64], .bias[8]
-    T_RUN(gtt::tra_fwd(k.pc2.a, t->B, k.Tt, tr, tr + 24, tr + 32, tr + 96, k.e, k.yt, k.g, s));
-    T_RUN(gtt::gate_shuffle_fwd(k.pc2.a, k.g, k.xin, t->B, t->T, k.Tt, k.out, s));
+    T_RUN(gtt::tra_fwd(k.pc2.a, t->B, k.Tt, tr, tr + 24, tr + 32, tr + 96, k.e, k.yt, k.g, s, t->bf));
+    T_RUN(gtt::gate_shuffle_fwd(k.pc2.a, k.g, k.xin, t->B, t->T, k.Tt, k.out, s, t->bf));
     return 0;
 }
 // dout: gradient of k.out; dxin: gradient of the block input (all 16 channels written)
@@ -353,7 +388,7 @@ int gt_bwd(gtcrn_trainer* t, GtBlock& k, const float* prm, float* grads, const f
     float* gtr = grads + k.o_tra;
     int rc;
     T_RUN(gtt::tra_gate_shuffle_bwd(dout, k.pc2.a, k.g, k.e, k.yt, t->B, t->T, k.Tt, tr, tr + 32, t->dv, dxin, gtr,
-                                    gtr + 24, gtr + 32, gtr + 96, t->tmp_tra, t->fscratch, s));
+                                    gtr + 24, gtr + 32, gtr + 96, t->tmp_tra, t->fscratch, s, t->bf));
     if ((rc = unit_bwd(t, k.pc2, prm, grads, t->dv, t->dhd, 0, nullptr, 0, s))) return rc;
     if ((rc = unit_bwd(t, k.depth, prm, grads, t->dhd, t->dh, 0, nullptr, 0, s))) return rc;
     if ((rc = unit_bwd(t, k.pc1, prm, grads, t->dh, dxin, 0, nullptr, 0, s))) return rc;   // channels 0..7
@@ -394,10 +429,35 @@ void gtcrn_trainer_destroy(gtcrn_trainer* t) {
     delete t;
 }
 
-long gtcrn_train_workspace_bytes(int B, int T) {
+static int storage_formats(int storage, int* bf, int* ybf) {
+    // 0: fp32 | 1: bf16.  (2, 3: diagnostics used while measuring where the bf16 gradient noise comes from -- bf16
+    // activations with fp32 / centred-fp16 conv outputs; neither lowers it, the noise enters through the activations)
+    static const int F[4][2] = {{0, 0}, {1, 1}, {1, 0}, {1, 2}};
+    if (storage < 0 || storage > 3) return -1;
+    *bf = F[storage][0];
+    *ybf = F[storage][1];
+    return 0;
+}
+
+long gtcrn_train_workspace_bytes2(int B, int T, int storage) {
     gtcrn_trainer tmp;
+    if (storage_formats(storage, &tmp.bf, &tmp.ybf)) return -1;
     for (const auto& p : gtcrn::param_table()) tmp.off[p.name] = p.offset;
     return (long)(plan(&tmp, B, T, nullptr) * sizeof(float));
+}
+long gtcrn_train_workspace_bytes(int B, int T) { return gtcrn_train_workspace_bytes2(B, T, 0); }
+
+int gtcrn_trainer_set_storage(gtcrn_trainer* t, int storage) {
+    int bf = 0, ybf = 0;
+    if (!t || storage_formats(storage, &bf, &ybf))
+        return tfail(GTCRN_ERR_ARG, "gtcrn_trainer_set_storage: storage must be 0 (fp32), 1 (bf16), 2 or 3");
+    if (t->bf != bf || t->ybf != ybf) {
+        t->bf = bf;
+        t->ybf = ybf;
+        t->planned = false;      // the arena is re-laid out on the next forward
+        t->have_fwd = false;
+    }
+    return 0;
 }
 
 int gtcrn_train_forward(gtcrn_trainer* t, float* d_params, const float* d_spec, long sb, long sf, long st,
@@ -409,10 +469,11 @@ int gtcrn_train_forward(gtcrn_trainer* t, float* d_params, const float* d_spec, 
     int rc = ensure_plan(t, B, T);
     if (rc) return rc;
     float* prm = d_params;
-    T_RUN(gtt::feat_fwd(d_spec, sb, sf, st, B, T, prm + P(t, "erb.erb_fc.weight"), t->eb, s));
+    T_RUN(gtt::feat_fwd(d_spec, sb, sf, st, B, T, prm + P(t, "erb.erb_fc.weight"), t->eb, s, t->bf));
     {   // SFE_Lite: Conv2d(3,3,(1,3),padding (0,1),groups 3,bias=False), weight [3][1][1][3]
         DwGeom g{};
         g.B = B; g.Tin = T; g.Tout = T; g.F = 129; g.C = 3; g.nkt = 1; g.nkf = 3;
+        g.in_bf = g.out_bf = t->bf;
         g.f_off[0] = -1; g.f_off[1] = 0; g.f_off[2] = 1; g.w_c = 3; g.w_kt = 3; g.w_kf = 1;
         T_RUN(gtt::dw_fwd(g, t->eb, prm + P(t, "sfe.depth_conv.weight"), nullptr, t->f0, s));
     }
@@ -428,16 +489,18 @@ int gtcrn_train_forward(gtcrn_trainer* t, float* d_params, const float* d_spec, 
     const long n33 = (long)B * T * 33 * 16, n65 = (long)B * T * 65 * 16;
     const float* X = t->tcn[7].c3.a;
     for (int i = 0; i < 3; ++i) {     // Decoder.forward: x = de_convs[i](x + en_outs[4 - i]) (models/gtcrn_micro.py:463-469)
-        T_RUN(gtt::add(X, t->enc[2 - i].out, t->dec[i].s, n33, s));
+        T_RUN(gtt::add_saved(X, t->enc[2 - i].out, t->dec[i].s, n33, s, t->bf));
         if ((rc = gt_fwd(t, t->dec[i], prm, s))) return rc;
         X = t->dec[i].out;
     }
-    T_RUN(gtt::add(X, t->en1.a, t->s3, n33, s));
+    T_RUN(gtt::add_saved(X, t->en1.a, t->s3, n33, s, t->bf));
     if ((rc = unit_fwd(t, t->de3, prm, s))) return rc;
-    T_RUN(gtt::add(t->de3.a, t->en0.a, t->s4, n65, s));
+    T_RUN(gtt::add_saved(t->de3.a, t->en0.a, t->s4, n65, s, t->bf));
     if ((rc = unit_fwd(t, t->de4, prm, s))) return rc;
-    T_RUN(gtt::bs_mask_fwd(t->de4.a, d_spec, sb, sf, st, B, T, prm + P(t, "erb.ierb_fc.weight"), d_out, ob, of, ot, s));
+    T_RUN(gtt::bs_mask_fwd(t->de4.a, d_spec, sb, sf, st, B, T, prm + P(t, "erb.ierb_fc.weight"), d_out, ob, of, ot, s,
+                           t->bf));
     t->have_fwd = true;
+    t->shift_ready = true;
     return 0;
 }
 
@@ -455,13 +518,17 @@ int gtcrn_train_backward(gtcrn_trainer* t, const float* d_params, const float* d
     T_HIP(hipMemsetAsync(G, 0, sizeof(float) * GTCRN_NPARAM_FLOATS, s));
     const long n33 = (long)B * T * 33 * 16, n65 = (long)B * T * 65 * 16;
     T_RUN(gtt::bs_mask_bwd(d_grad_out, gb, gf, gt, d_spec, sb, sf, st, B, T, prm + P(t, "erb.ierb_fc.weight"), t->dm, s));
-    // de_convs.4 <- s4 = de3.a + en0.a : gs0 is the gradient of both addends
+    // de_convs.4 <- s4 = de3.a + en0.a : gs0 is the gradient of both addends (the sums are recomputed, see plan())
+    if (t->share_sums) T_RUN(gtt::add_saved(t->de3.a, t->en0.a, t->s4, n65, s, t->bf));
     if ((rc = unit_bwd(t, t->de4, prm, G, t->dm, t->gs0, 0, nullptr, 0, s))) return rc;
+    if (t->share_sums) T_RUN(gtt::add_saved(t->dec[2].out, t->en1.a, t->s3, n33, s, t->bf));
     if ((rc = unit_bwd(t, t->de3, prm, G, t->gs0, t->gs[1], 0, nullptr, 0, s))) return rc;   // gs[1]: d s3
     // decoder blocks 2,1,0: d s_i is the gradient of the previous block's output and of the skip en_outs[4-i]
     const float* dout = t->gs[1];
     for (int i = 2; i >= 0; --i) {
         float* ds = t->gs[4 - i];            // gs[2], gs[3], gs[4]
+        if (t->share_sums)
+            T_RUN(gtt::add_saved(i ? t->dec[i - 1].out : t->tcn[7].c3.a, t->enc[2 - i].out, t->dec[i].s, n33, s, t->bf));
         if ((rc = gt_bwd(t, t->dec[i], prm, G, dout, ds, s))) return rc;
         dout = ds;
     }
@@ -491,6 +558,7 @@ int gtcrn_train_backward(gtcrn_trainer* t, const float* d_params, const float* d
         DwGeom g{};
         g.B = B; g.Tin = T; g.Tout = T; g.F = 129; g.C = 3; g.nkt = 1; g.nkf = 3;
         g.f_off[0] = -1; g.f_off[1] = 0; g.f_off[2] = 1; g.w_c = 3; g.w_kt = 3; g.w_kf = 1;
+        g.in_bf = t->bf; g.out_bf = 0;
         T_RUN(gtt::dw_wgrad(g, t->eb, t->df0, G + P(t, "sfe.depth_conv.weight"), nullptr, t->fscratch, s));
     }
     return 0;
@@ -547,8 +615,7 @@ int gtcrn_train_tap(gtcrn_trainer* t, const char* name, float* d_out, long* shap
     const std::vector<int>& sh = it->second.second;   // T', F, C
     if (shape4) { shape4[0] = t->B; shape4[1] = sh[0]; shape4[2] = sh[1]; shape4[3] = sh[2]; }
     if (d_out)
-        T_HIP(hipMemcpyAsync(d_out, it->second.first, sizeof(float) * (size_t)t->B * sh[0] * sh[1] * sh[2],
-                             hipMemcpyDeviceToDevice, (hipStream_t)stream));
+        T_RUN(gtt::saved_to_f32(it->second.first, d_out, (long)t->B * sh[0] * sh[1] * sh[2], (hipStream_t)stream, t->bf));
     return 0;
 }
 

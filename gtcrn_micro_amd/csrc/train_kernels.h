@@ -27,7 +27,15 @@ struct ConvGeom {
     int f_mode, sf, pf;
     int w_co, w_ci, w_kt, w_kf; // strides (floats) into the weight tensor in the reference's layout
     int accumulate;             // 1: add to the existing output instead of overwriting it
+    int in_bf, out_bf;          // storage of `in` / `out`: 0 fp32, 1 bf16 (saved activations of the bf16 variant);
+                                // gradients are always fp32; out_bf excludes accumulate
 };
+
+// Storage of the SAVED tensors (conv outputs, activations, block outputs -- everything the backward re-reads):
+// the format arguments of the functions below (`bf`: activations / block outputs, `ybf`: conv outputs in front of a
+// BatchNorm; in_bf / out_bf of the geometries) are 0 = fp32 (the reference's precision), 1 = bf16, 2 = fp16
+// (saturating).  A 16-bit tensor is passed through the same float* handle; its elements are 2 bytes wide.
+// Arithmetic, statistics, gradients and weights are fp32 throughout.
 
 // depthwise convolution (groups = channels), C channels:
 //   out[b,to,fo,c] (+)= bias[c] + sum_{kt,kf} W[c,kt,kf] * in[b, to + t_off[kt], fo + f_off[kf], c]
@@ -37,6 +45,7 @@ struct DwGeom {
     int t_off[3], f_off[3];
     int w_c, w_kt, w_kf;
     int accumulate;
+    int in_bf, out_bf;
 };
 
 enum Act { ACT_NONE = 0, ACT_PRELU = 1, ACT_TANH = 2 };
@@ -45,29 +54,33 @@ constexpr int MAX_PARTIALS = 1024;   // workgroups of a two-stage reduction
 
 // stat_partial/stat_parts (optional): the kernel also leaves per-workgroup sums of out and out^2 per channel
 // (layout of bn_stats' scratch) and reports their count, so the BatchNorm statistics need no extra pass.
+// shift (optional, bf16 output only): out = conv(in) + bias - shift[c]; the following train-mode BatchNorm is shift
+// invariant.  bn_stats(..., shift) accounts for it in the running-mean update and sets shift[c] to this step's batch
+// mean for the next step, so the stored values stay centred (bf16 rounding relative to the spread, not the offset).
 int conv_fwd(const ConvGeom& g, const float* in, const float* w, const float* bias, float* out, hipStream_t s,
-             double* stat_partial = nullptr, int* stat_parts = nullptr);
+             double* stat_partial = nullptr, int* stat_parts = nullptr, const float* shift = nullptr);
 // dW (and db when dbias != nullptr) of the convolution g: in = its input, dout = gradient of its output.
 // scratch: MAX_PARTIALS * (9*256 + 16) floats.
 int conv_wgrad(const ConvGeom& g, const float* in, const float* dout, float* dw, float* dbias, float* scratch,
                hipStream_t s);
 int dw_fwd(const DwGeom& g, const float* in, const float* w, const float* bias, float* out, hipStream_t s,
-           double* stat_partial = nullptr, int* stat_parts = nullptr);
+           double* stat_partial = nullptr, int* stat_parts = nullptr, const float* shift = nullptr);
 int dw_wgrad(const DwGeom& g, const float* in, const float* dout, float* dw, float* dbias, float* scratch,
              hipStream_t s);
 
 // BatchNorm (train mode) of y [n][C]: batch statistics, running-statistics update (momentum 0.1, unbiased
 // variance), stats[0..C) = mean, stats[C..2C) = 1/sqrt(var + 1e-5).  scratch: MAX_PARTIALS * 2 * C doubles.
 int bn_stats(const float* y, long n, int C, float* stats, float* running_mean, float* running_var, double* scratch,
-             hipStream_t s, int have_parts = 0);
+             hipStream_t s, int have_parts = 0, int bf = 0, float* shift = nullptr);
 // a = act(gamma * (y - mean) * invstd + beta [+ res])
 int bn_act(const float* y, long n, int C, const float* stats, const float* gamma, const float* beta,
-           const float* res, int act, const float* slope, float* a, hipStream_t s);
+           const float* res, int act, const float* slope, float* a, hipStream_t s, int bf = 0, int ybf = 0);
 // backward of the same: given da, writes dy (may alias da); if dres != nullptr: dres (+)= dz (dres_acc: add);
 // dgamma/dbeta [C], dslope [1] (PReLU) are WRITTEN.  scratch: MAX_PARTIALS * 3 * C doubles + 2 * C floats.
 int bn_act_bwd(const float* da, const float* y, long n, int C, const float* stats, const float* gamma,
                const float* beta, const float* res, int act, const float* slope, float* dy, float* dres,
-               int dres_acc, float* dgamma, float* dbeta, float* dslope, double* scratch, hipStream_t s);
+               int dres_acc, float* dgamma, float* dbeta, float* dslope, double* scratch, hipStream_t s, int bf = 0,
+               int ybf = 0);
 
 // The whole backward of a pointwise (1x1) conv + BatchNorm + activation unit in two passes: the BatchNorm
 // reduction, then ONE kernel that forms dy, the data gradient dx (nullptr: not needed; dx_acc: add) and the
@@ -76,27 +89,30 @@ int bn_act_bwd(const float* da, const float* y, long n, int C, const float* stat
 int unit1x1_bwd(const ConvGeom& g, const float* x, const float* y, const float* da, const float* res,
                 const float* stats, const float* gamma, const float* beta, int act, const float* slope,
                 const float* w, float* dx, int dx_acc, float* dres, int dres_acc, float* dw, float* dbias,
-                float* dgamma, float* dbeta, float* dslope, double* dscratch, float* fscratch, hipStream_t s);
+                float* dgamma, float* dbeta, float* dslope, double* dscratch, float* fscratch, hipStream_t s,
+                int bf = 0, int ybf = 0);
 
 // features: spec (strided (b,f,t) + re/im) -> EB [B][T][129][3] = ERB.bm([mag,re,im]) (models/gtcrn_micro.py:510-516)
 int feat_fwd(const float* spec, long sb, long sf, long st, int B, int T, const float* erb_w, float* eb,
-             hipStream_t s);
+             hipStream_t s, int bf = 0);
 // mask: m [B][T][129][2] -> ERB.bs -> complex ratio mask applied to spec (:472-482, 526-530)
 int bs_mask_fwd(const float* m, const float* spec, long sb, long sf, long st, int B, int T, const float* ierb_w,
-                float* out, long ob, long of, long ot, hipStream_t s);
+                float* out, long ob, long of, long ot, hipStream_t s, int bf = 0);
 int bs_mask_bwd(const float* dout, long ob, long of, long ot, const float* spec, long sb, long sf, long st, int B,
                 int T, const float* ierb_w, float* dm, hipStream_t s);
 
 // TRALite (:122-139) on v [B][Tt][33][8]: e = mean_F v^2; y = dw conv1d k=3 causal; g = sigmoid(1x1(y))
 int tra_fwd(const float* v, int B, int Tt, const float* dw_w, const float* dw_b, const float* pw_w,
-            const float* pw_b, float* e, float* y, float* g, hipStream_t s);
+            const float* pw_b, float* e, float* y, float* g, hipStream_t s, int bf = 0);
 // out[b,t,f,2c] = v[b,t,f,c] * g[b,t,c], out[b,t,f,2c+1] = x[b,t,f,8+c]   (shuffle, :222-227), t < T
-int gate_shuffle_fwd(const float* v, const float* g, const float* x, int B, int T, int Tt, float* out, hipStream_t s);
+int gate_shuffle_fwd(const float* v, const float* g, const float* x, int B, int T, int Tt, float* out, hipStream_t s,
+                     int bf = 0);
 // backward of tra + gate + shuffle: dout [B][T][33][16] -> dv [B][Tt][33][8] (written), dx channels 8..15 (written),
 // parameter gradients written.  tmp: 3 * B*Tt*8 floats; scratch: MAX_PARTIALS * 80 floats.
 int tra_gate_shuffle_bwd(const float* dout, const float* v, const float* g, const float* e, const float* y, int B,
                          int T, int Tt, const float* dw_w, const float* pw_w, float* dv, float* dx, float* d_dw_w,
-                         float* d_dw_b, float* d_pw_w, float* d_pw_b, float* tmp, float* scratch, hipStream_t s);
+                         float* d_dw_b, float* d_pw_w, float* d_pw_b, float* tmp, float* scratch, hipStream_t s,
+                         int bf = 0);
 
 // HybridLoss (loss.py:30-71).  hybrid_loss_spec: the three spectral terms -- per-workgroup sums (sum of squared
 // compressed real+imag differences, sum of squared compressed-magnitude differences) into `partial`, and their
@@ -109,5 +125,8 @@ int sisnr_terms(float* yp, const float* yt, int B, long Lw, const double* spec_p
                 const float* win, double* dwork, float* coef, float* loss, int want_grad, hipStream_t s);
 
 int add(const float* a, const float* b, float* out, long n, hipStream_t s);
+// out = a + b on saved tensors (n % 4 == 0); saved tensor -> fp32 copy (test taps)
+int add_saved(const float* a, const float* b, float* out, long n, hipStream_t s, int bf);
+int saved_to_f32(const float* src, float* dst, long n, hipStream_t s, int bf);
 
 }  // namespace gtt

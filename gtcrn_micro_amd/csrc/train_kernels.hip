@@ -36,6 +36,66 @@ __device__ __forceinline__ bool tap_fi(const ConvGeom& g, int fo, int kf, int& f
     return fi >= 0 && fi < g.Fin;
 }
 
+// ---- storage of the SAVED tensors (conv outputs y, activations a, block outputs: what the backward re-reads) -------
+// fp32 (the reference's own precision) or bf16 (BASELINE configs[3]: half the bytes of every pass that touches them;
+// arithmetic, statistics, gradients and master weights stay fp32).  The flag is a launch constant (wave-uniform
+// branch in front of a memory access of a streaming kernel: free); a bf16 tensor is addressed through the same
+// `float*` handle, its elements are 2 bytes wide.  Stores round to nearest even (v_cvt_pk_bf16_f32).
+// format codes: 0 fp32, 1 bf16, 2 fp16 (fp16 saturates at +-65504 instead of overflowing to infinity)
+__device__ __forceinline__ float bf2f(unsigned h) { return __uint_as_float(h << 16); }
+__device__ __forceinline__ unsigned f2bf(float x) {
+    const __bf16 h = (__bf16)x;
+    return (unsigned)__builtin_bit_cast(unsigned short, h);
+}
+__device__ __forceinline__ float h2f(unsigned h) { return (float)__builtin_bit_cast(_Float16, (unsigned short)h); }
+__device__ __forceinline__ unsigned f2h(float x) {
+    const _Float16 h = (_Float16)fminf(fmaxf(x, -65504.f), 65504.f);
+    return (unsigned)__builtin_bit_cast(unsigned short, h);
+}
+__device__ __forceinline__ float dec16(unsigned h, int fmt) { return fmt == 1 ? bf2f(h) : h2f(h); }
+__device__ __forceinline__ unsigned enc16(float x, int fmt) { return fmt == 1 ? f2bf(x) : f2h(x); }
+__device__ __forceinline__ float sld1(const float* base, long idx, int fmt) {
+    return fmt ? dec16(reinterpret_cast<const unsigned short*>(base)[idx], fmt) : base[idx];
+}
+__device__ __forceinline__ void sst1(float* base, long idx, int fmt, float v) {
+    if (fmt) reinterpret_cast<unsigned short*>(base)[idx] = (unsigned short)enc16(v, fmt);
+    else base[idx] = v;
+}
+__device__ __forceinline__ f32x4 sld4(const float* base, long idx, int fmt) {      // idx % 4 == 0
+    if (fmt) {
+        const uint2 u = *reinterpret_cast<const uint2*>(reinterpret_cast<const unsigned short*>(base) + idx);
+        return f32x4{dec16(u.x & 0xFFFFu, fmt), dec16(u.x >> 16, fmt), dec16(u.y & 0xFFFFu, fmt), dec16(u.y >> 16, fmt)};
+    }
+    return *reinterpret_cast<const f32x4*>(base + idx);
+}
+__device__ __forceinline__ void sst4(float* base, long idx, int fmt, const f32x4 v) {
+    if (fmt) {
+        uint2 u;
+        u.x = enc16(v[0], fmt) | (enc16(v[1], fmt) << 16);
+        u.y = enc16(v[2], fmt) | (enc16(v[3], fmt) << 16);
+        *reinterpret_cast<uint2*>(reinterpret_cast<unsigned short*>(base) + idx) = u;
+    } else {
+        *reinterpret_cast<f32x4*>(base + idx) = v;
+    }
+}
+__device__ __forceinline__ float round16(float x, int fmt) { return fmt ? dec16(enc16(x, fmt), fmt) : x; }
+__device__ __forceinline__ f32x4 round_bf4(const f32x4 v, int fmt) {
+    return fmt ? f32x4{round16(v[0], fmt), round16(v[1], fmt), round16(v[2], fmt), round16(v[3], fmt)} : v;
+}
+template <int C>
+__device__ __forceinline__ void load_vec_s(const float* base, long idx, int bf, float (&v)[C]) {
+    if constexpr (C % 4 == 0) {
+#pragma unroll
+        for (int i = 0; i < C; i += 4) {
+            const f32x4 t = sld4(base, idx + i, bf);
+            v[i] = t[0]; v[i + 1] = t[1]; v[i + 2] = t[2]; v[i + 3] = t[3];
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < C; ++i) v[i] = sld1(base, idx + i, bf);
+    }
+}
+
 template <int C>
 __device__ __forceinline__ void load_vec(const float* p, float (&v)[C]) {
     if constexpr (C % 4 == 0) {
@@ -54,8 +114,14 @@ __device__ __forceinline__ void load_vec(const float* p, float (&v)[C]) {
 // nn.Conv2d / nn.ConvTranspose2d of ConvBlock (models/gtcrn_micro.py:142-164), GTConvBlock
 // (:167-253) and TCN conv1/conv3 (:268-287), and their data gradients.
 template <int CIN, int COUT>
+// shift (bf16 output only): the tensor is stored as y - shift[c].  A train-mode BatchNorm follows and is invariant to
+// a per-channel shift; with shift = the channel's batch mean of the PREVIOUS step (k_bn_stats_finish maintains it;
+// the running mean before the first step) the stored values are centred, so their bf16 rounding error is relative to
+// the channel's SPREAD, not to its offset (|mean| >> std would otherwise be amplified by |mean| / std after
+// normalisation).
 __global__ __launch_bounds__(NT) void k_conv(ConvGeom g, const float* __restrict__ in, const float* __restrict__ w,
-                                            const float* __restrict__ bias, float* __restrict__ out) {
+                                            const float* __restrict__ bias, float* __restrict__ out,
+                                            const float* __restrict__ shift) {
     __shared__ __attribute__((aligned(16))) float sW[9 * CIN * COUT];   // [tap][ci][co]
     const int tid = threadIdx.x, ntap = g.nkt * g.nkf;
     for (int i = tid; i < ntap * CIN * COUT; i += NT) {
@@ -71,7 +137,7 @@ __global__ __launch_bounds__(NT) void k_conv(ConvGeom g, const float* __restrict
         const int to = (int)(bt % g.Tout), b = (int)(bt / g.Tout);
         float acc[COUT];
 #pragma unroll
-        for (int co = 0; co < COUT; ++co) acc[co] = bias ? bias[co] : 0.f;
+        for (int co = 0; co < COUT; ++co) acc[co] = (bias ? bias[co] : 0.f) - (shift ? shift[co] : 0.f);
         for (int kt = 0; kt < g.nkt; ++kt) {
             const int ti = to + g.t_off[kt];
             if (ti < 0 || ti >= g.Tin) continue;
@@ -79,7 +145,7 @@ __global__ __launch_bounds__(NT) void k_conv(ConvGeom g, const float* __restrict
                 int fi;
                 if (!tap_fi(g, fo, kf, fi)) continue;
                 float xv[CIN];
-                load_vec<CIN>(in + (((long)b * g.Tin + ti) * g.Fin + fi) * g.CinT + g.cin_off, xv);
+                load_vec_s<CIN>(in, (((long)b * g.Tin + ti) * g.Fin + fi) * g.CinT + g.cin_off, g.in_bf, xv);
                 const float* wt = sW + (kt * g.nkf + kf) * CIN * COUT;
 #pragma unroll
                 for (int ci = 0; ci < CIN; ++ci)
@@ -87,9 +153,14 @@ __global__ __launch_bounds__(NT) void k_conv(ConvGeom g, const float* __restrict
                     for (int co = 0; co < COUT; ++co) acc[co] = fmaf(wt[ci * COUT + co], xv[ci], acc[co]);
             }
         }
-        float* o = out + p * g.CoutT + g.cout_off;
+        if (g.out_bf) {
 #pragma unroll
-        for (int co = 0; co < COUT; ++co) o[co] = g.accumulate ? o[co] + acc[co] : acc[co];
+            for (int co = 0; co < COUT; ++co) sst1(out, p * g.CoutT + g.cout_off + co, g.out_bf, acc[co]);
+        } else {
+            float* o = out + p * g.CoutT + g.cout_off;
+#pragma unroll
+            for (int co = 0; co < COUT; ++co) o[co] = g.accumulate ? o[co] + acc[co] : acc[co];
+        }
     }
 }
 
@@ -156,7 +227,7 @@ template <int NKT, int NKF>
 __global__ __launch_bounds__(NT) void k_conv_mfma(ConvGeom g, const float* __restrict__ in,
                                                  const float* __restrict__ w, const float* __restrict__ bias,
                                                  float* __restrict__ out, long tiles_per_wave,
-                                                 double* __restrict__ stat_partial) {
+                                                 double* __restrict__ stat_partial, const float* __restrict__ shift) {
     __shared__ __attribute__((aligned(16))) float sW[NKT * NKF * 256];   // [tap][co][ci], zero padded
     __shared__ float sStat[NT][8];
     const int tid = threadIdx.x;
@@ -178,6 +249,7 @@ __global__ __launch_bounds__(NT) void k_conv_mfma(ConvGeom g, const float* __res
     }
     f32x4 bv = {0.f, 0.f, 0.f, 0.f};
     if (bias && 4 * q < g.Cout) bv = *reinterpret_cast<const f32x4*>(bias + 4 * q);
+    if (shift && 4 * q < g.Cout) bv -= *reinterpret_cast<const f32x4*>(shift + 4 * q);
     const bool cin_ok = 4 * q < g.Cin, cout_ok = 4 * q < g.Cout;
     for (; tile < tend; ++tile) {
         const long p = tile * 16 + n;
@@ -193,15 +265,20 @@ __global__ __launch_bounds__(NT) void k_conv_mfma(ConvGeom g, const float* __res
                 int fi;
                 const bool ok = tap_fi(g, P.f, kf, fi) && okt;
                 f32x4 xv = {0.f, 0.f, 0.f, 0.f};
-                if (ok) xv = *reinterpret_cast<const f32x4*>(in + (rowbase + fi) * g.CinT + g.cin_off + 4 * q);
+                if (ok) xv = sld4(in, (rowbase + fi) * g.CinT + g.cin_off + 4 * q, g.in_bf);
                 const f32x4 A = *reinterpret_cast<const f32x4*>(sW + (kt * NKF + kf) * 256 + n * 16 + 4 * q);
 #pragma unroll
                 for (int s = 0; s < 4; ++s) acc = mfma4(A[s], xv[s], acc);
             }
         }
         if (pv && cout_ok) {
-            f32x4* o = reinterpret_cast<f32x4*>(out + p * g.CoutT + g.cout_off + 4 * q);
-            *o = g.accumulate ? *o + acc : acc;
+            if (g.out_bf) {
+                acc = round_bf4(acc, g.out_bf);   // the statistics are those of the STORED tensor (the backward re-reads it)
+                sst4(out, p * g.CoutT + g.cout_off + 4 * q, g.out_bf, acc);
+            } else {
+                f32x4* o = reinterpret_cast<f32x4*>(out + p * g.CoutT + g.cout_off + 4 * q);
+                *o = g.accumulate ? *o + acc : acc;
+            }
             s1 += acc;
             s2 += acc * acc;
         }
@@ -264,7 +341,7 @@ __global__ __launch_bounds__(WG_WAVES * 64) void k_conv_wgrad_mfma(ConvGeom g, c
                     for (int kf = 0; kf < NKF; ++kf) {
                         int fi;
                         const bool ok = tap_fi(g, P.f, kf, fi) && okt;
-                        bb[u][kt * NKF + kf] = ok ? in[(rowbase + fi) * g.CinT + g.cin_off + c] : 0.f;
+                        bb[u][kt * NKF + kf] = ok ? sld1(in, (rowbase + fi) * g.CinT + g.cin_off + c, g.in_bf) : 0.f;
                     }
                 }
                 P.advance(4, g.Fout, g.Tout);
@@ -326,7 +403,7 @@ __global__ __launch_bounds__(1024) void k_wgrad_mfma_finish(ConvGeom g, const fl
 // SFE_Lite (:77-90), encoder depth_conv groups=16 (:206-216), TCN conv2 (:273-281), + data gradients
 template <int C>
 __global__ __launch_bounds__(NT) void k_dw(DwGeom g, const float* __restrict__ in, const float* __restrict__ w,
-                                          const float* __restrict__ bias, float* __restrict__ out) {
+                                          const float* __restrict__ bias, float* __restrict__ out) {   // (no BatchNorm follows the 3-channel SFE conv: no shift)
     __shared__ float sW[9 * C];   // [tap][c]
     const int tid = threadIdx.x, ntap = g.nkt * g.nkf;
     for (int i = tid; i < ntap * C; i += NT) {
@@ -349,22 +426,28 @@ __global__ __launch_bounds__(NT) void k_dw(DwGeom g, const float* __restrict__ i
                 const int fi = fo + g.f_off[kf];
                 if (fi < 0 || fi >= g.F) continue;
                 float xv[C];
-                load_vec<C>(in + (((long)b * g.Tin + ti) * g.F + fi) * C, xv);
+                load_vec_s<C>(in, (((long)b * g.Tin + ti) * g.F + fi) * C, g.in_bf, xv);
                 const float* wt = sW + (kt * g.nkf + kf) * C;
 #pragma unroll
                 for (int c = 0; c < C; ++c) acc[c] = fmaf(wt[c], xv[c], acc[c]);
             }
         }
-        float* o = out + p * C;
+        if (g.out_bf) {
 #pragma unroll
-        for (int c = 0; c < C; ++c) o[c] = g.accumulate ? o[c] + acc[c] : acc[c];
+            for (int c = 0; c < C; ++c) sst1(out, p * C + c, g.out_bf, acc[c]);
+        } else {
+            float* o = out + p * C;
+#pragma unroll
+            for (int c = 0; c < C; ++c) o[c] = g.accumulate ? o[c] + acc[c] : acc[c];
+        }
     }
 }
 
 // C = 16: one thread per (position, 4 channels): every tap is one coalesced 16-byte load
 __global__ __launch_bounds__(NT) void k_dw16(DwGeom g, const float* __restrict__ in, const float* __restrict__ w,
                                             const float* __restrict__ bias, float* __restrict__ out,
-                                            double* __restrict__ stat_partial, StrideIter it) {
+                                            double* __restrict__ stat_partial, StrideIter it,
+                                            const float* __restrict__ shift) {
     __shared__ __attribute__((aligned(16))) float sW[9 * 16];   // [tap][c]
     __shared__ float sStat[NT][8];
     f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = {0.f, 0.f, 0.f, 0.f};
@@ -383,20 +466,26 @@ __global__ __launch_bounds__(NT) void k_dw16(DwGeom g, const float* __restrict__
         const long p = i >> 2;
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
         if (bias) acc = *reinterpret_cast<const f32x4*>(bias + 4 * q);
+        if (shift) acc -= *reinterpret_cast<const f32x4*>(shift + 4 * q);
         for (int kt = 0; kt < g.nkt; ++kt) {
             const int ti = P.to + g.t_off[kt];
             if (ti < 0 || ti >= g.Tin) continue;
             for (int kf = 0; kf < g.nkf; ++kf) {
                 const int fi = P.fo + g.f_off[kf];
                 if (fi < 0 || fi >= g.F) continue;
-                const f32x4 x = *reinterpret_cast<const f32x4*>(in + ((long)(P.bt + g.t_off[kt]) * g.F + fi) * 16 + 4 * q);
+                const f32x4 x = sld4(in, ((long)(P.bt + g.t_off[kt]) * g.F + fi) * 16 + 4 * q, g.in_bf);
                 const f32x4 wt = *reinterpret_cast<const f32x4*>(sW + (kt * g.nkf + kf) * 16 + 4 * q);
                 acc += wt * x;
             }
         }
         P.advance(it, g.F, g.Tout);
-        f32x4* o = reinterpret_cast<f32x4*>(out + p * 16 + 4 * q);
-        *o = g.accumulate ? *o + acc : acc;
+        if (g.out_bf) {
+            acc = round_bf4(acc, g.out_bf);
+            sst4(out, p * 16 + 4 * q, g.out_bf, acc);
+        } else {
+            f32x4* o = reinterpret_cast<f32x4*>(out + p * 16 + 4 * q);
+            *o = g.accumulate ? *o + acc : acc;
+        }
         s1 += acc;
         s2 += acc * acc;
     }
@@ -439,7 +528,7 @@ __device__ __forceinline__ void block_reduce_store(const float (&v)[NV][V], int 
 
 template <int V>
 __global__ __launch_bounds__(NT) void k_bn_stats(const float* __restrict__ y, long total, int C,
-                                                double* __restrict__ partial) {
+                                                double* __restrict__ partial, int bf) {
     __shared__ double sh[NT];
     float v[2][V];
 #pragma unroll
@@ -447,7 +536,7 @@ __global__ __launch_bounds__(NT) void k_bn_stats(const float* __restrict__ y, lo
     const long units = total / V;
     for (long i = (long)blockIdx.x * NT + threadIdx.x; i < units; i += (long)gridDim.x * NT) {
         float x[V];
-        load_vec<V>(y + i * V, x);
+        load_vec_s<V>(y, i * V, bf, x);
 #pragma unroll
         for (int e = 0; e < V; ++e) { v[0][e] += x[e]; v[1][e] = fmaf(x[e], x[e], v[1][e]); }
     }
@@ -469,7 +558,7 @@ __device__ __forceinline__ double reduce_partials(const double* partial, int npa
 
 __global__ __launch_bounds__(1024) void k_bn_stats_finish(const double* __restrict__ partial, int nparts, long n, int C,
                                                          float* __restrict__ stats, float* __restrict__ rmean,
-                                                         float* __restrict__ rvar) {
+                                                         float* __restrict__ rvar, float* __restrict__ shift) {
     __shared__ double sh[16][64];
     __shared__ double tot[64];
     const double s = reduce_partials(partial, nparts, 2 * C, sh);
@@ -484,7 +573,10 @@ __global__ __launch_bounds__(1024) void k_bn_stats_finish(const double* __restri
     stats[C + c] = (float)(1.0 / sqrt(var + 1e-5));
     if (rmean) {
         const double unb = n > 1 ? var * (double)n / (double)(n - 1) : var;
-        rmean[c] = (float)(0.9 * (double)rmean[c] + 0.1 * mean);
+        // shift: the tensor holds y - shift[c], so mean(y) = mean + shift[c]; that becomes the next step's shift
+        const double absmean = shift ? mean + (double)shift[c] : mean;
+        rmean[c] = (float)(0.9 * (double)rmean[c] + 0.1 * absmean);
+        if (shift) shift[c] = (float)absmean;
         rvar[c] = (float)(0.9 * (double)rvar[c] + 0.1 * unb);
     }
 }
@@ -499,7 +591,7 @@ template <int V>
 __global__ __launch_bounds__(NT) void k_bn_act(const float* __restrict__ y, long total, int C,
                                               const float* __restrict__ stats, const float* __restrict__ gamma,
                                               const float* __restrict__ beta, const float* __restrict__ res, int act,
-                                              const float* __restrict__ slope, float* __restrict__ a) {
+                                              const float* __restrict__ slope, float* __restrict__ a, int bf, int ybf) {
     const float sl = slope ? slope[0] : 0.f;
     const long units = total / V;
     // the stride is a multiple of C: the thread's channels and their constants are fixed
@@ -509,8 +601,8 @@ __global__ __launch_bounds__(NT) void k_bn_act(const float* __restrict__ y, long
     for (int e = 0; e < V; ++e) { mean[e] = stats[c0 + e]; istd[e] = stats[C + c0 + e]; gm[e] = gamma[c0 + e]; bt[e] = beta[c0 + e]; }
     for (long i = (long)blockIdx.x * NT + threadIdx.x; i < units; i += (long)gridDim.x * NT) {
         float x[V], r[V], o[V];
-        load_vec<V>(y + i * V, x);
-        if (res) load_vec<V>(res + i * V, r);
+        load_vec_s<V>(y, i * V, ybf, x);
+        if (res) load_vec_s<V>(res, i * V, bf, r);
 #pragma unroll
         for (int e = 0; e < V; ++e) {
             // same expression order as the backward's recomputation of z: gamma * ((y - mean) * invstd) + beta
@@ -518,8 +610,8 @@ __global__ __launch_bounds__(NT) void k_bn_act(const float* __restrict__ y, long
             if (res) z += r[e];
             o[e] = act_fwd(z, act, sl);
         }
-        if constexpr (V == 4) *reinterpret_cast<f32x4*>(a + i * 4) = f32x4{o[0], o[1], o[2], o[3]};
-        else a[i] = o[0];
+        if constexpr (V == 4) sst4(a, i * 4, bf, f32x4{o[0], o[1], o[2], o[3]});
+        else sst1(a, i, bf, o[0]);
     }
 }
 
@@ -536,7 +628,8 @@ __global__ __launch_bounds__(NT) void k_bn_bwd_reduce(const float* __restrict__ 
                                                      long total, int C, const float* __restrict__ stats,
                                                      const float* __restrict__ gamma, const float* __restrict__ beta,
                                                      const float* __restrict__ res, int act,
-                                                     const float* __restrict__ slope, double* __restrict__ partial) {
+                                                     const float* __restrict__ slope, double* __restrict__ partial,
+                                                     int bf, int ybf) {
     __shared__ double sh[NT];
     const float sl = slope ? slope[0] : 0.f;
     float v[3][V];
@@ -549,9 +642,9 @@ __global__ __launch_bounds__(NT) void k_bn_bwd_reduce(const float* __restrict__ 
     for (int e = 0; e < V; ++e) { mean[e] = stats[c0 + e]; istd[e] = stats[C + c0 + e]; gm[e] = gamma[c0 + e]; bt[e] = beta[c0 + e]; }
     for (long i = (long)blockIdx.x * NT + threadIdx.x; i < units; i += (long)gridDim.x * NT) {
         float x[V], g[V], r[V];
-        load_vec<V>(y + i * V, x);
+        load_vec_s<V>(y, i * V, ybf, x);
         load_vec<V>(da + i * V, g);
-        if (res) load_vec<V>(res + i * V, r);
+        if (res) load_vec_s<V>(res, i * V, bf, r);
 #pragma unroll
         for (int e = 0; e < V; ++e) {
             const float xh = (x[e] - mean[e]) * istd[e];
@@ -596,7 +689,8 @@ __global__ __launch_bounds__(NT) void k_bn_bwd_apply(const float* __restrict__ d
                                                     const float* __restrict__ gamma, const float* __restrict__ beta,
                                                     const float* __restrict__ res, int act,
                                                     const float* __restrict__ slope, const float* __restrict__ red,
-                                                    float* __restrict__ dy, float* __restrict__ dres, int dres_acc) {
+                                                    float* __restrict__ dy, float* __restrict__ dres, int dres_acc,
+                                                    int bf, int ybf) {
     const float sl = slope ? slope[0] : 0.f;
     const long units = total / V;
     const int c0 = (int)((((long)blockIdx.x * NT + threadIdx.x) * V) % C);
@@ -608,9 +702,9 @@ __global__ __launch_bounds__(NT) void k_bn_bwd_apply(const float* __restrict__ d
     }
     for (long i = (long)blockIdx.x * NT + threadIdx.x; i < units; i += (long)gridDim.x * NT) {
         float x[V], g[V], r[V], o[V], dzv[V];
-        load_vec<V>(y + i * V, x);
+        load_vec_s<V>(y, i * V, ybf, x);
         load_vec<V>(da + i * V, g);
-        if (res) load_vec<V>(res + i * V, r);
+        if (res) load_vec_s<V>(res, i * V, bf, r);
         if (dres && dres_acc) load_vec<V>(dres + i * V, dzv);
 #pragma unroll
         for (int e = 0; e < V; ++e) {
@@ -663,7 +757,7 @@ __global__ __launch_bounds__(NT) void k_dw_wgrad_stream(DwGeom g, const float* _
             for (int kf = 0; kf < NKF; ++kf) {
                 const int fi = P.fo + g.f_off[kf];
                 if (fi < 0 || fi >= g.F) continue;
-                const f32x4 x = *reinterpret_cast<const f32x4*>(in + ((long)(P.bt + g.t_off[kt]) * g.F + fi) * 16 + 4 * q);
+                const f32x4 x = sld4(in, ((long)(P.bt + g.t_off[kt]) * g.F + fi) * 16 + 4 * q, g.in_bf);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[kt * NKF + kf][e] = fmaf(d[e], x[e], v[kt * NKF + kf][e]);
             }
@@ -695,7 +789,7 @@ __global__ __launch_bounds__(1024) void k_dw_wgrad_finish2(DwGeom g, const doubl
 }
 // SFE_Lite weight gradient (3 channels, (1,3) taps, no bias): one thread per position, all 3 channels
 __global__ __launch_bounds__(NT) void k_sfe_wgrad(const float* __restrict__ in, const float* __restrict__ dout, long rows,
-                                                 int F, double* __restrict__ partial) {
+                                                 int F, double* __restrict__ partial, int bf) {
     __shared__ double sh[NT];
     float v[3][3];
 #pragma unroll
@@ -710,7 +804,7 @@ __global__ __launch_bounds__(NT) void k_sfe_wgrad(const float* __restrict__ in, 
             const int fi = f + k - 1;
             if (fi < 0 || fi >= F) continue;
 #pragma unroll
-            for (int e = 0; e < 3; ++e) v[k][e] = fmaf(dout[p * 3 + e], in[(p + k - 1) * 3 + e], v[k][e]);
+            for (int e = 0; e < 3; ++e) v[k][e] = fmaf(dout[p * 3 + e], sld1(in, (p + k - 1) * 3 + e, bf), v[k][e]);
         }
     }
     block_reduce_store<3, 3>(v, 3, sh, partial + (long)blockIdx.x * 9);
@@ -755,7 +849,8 @@ __global__ __launch_bounds__(NT) void k_unit1x1_bwd(ConvGeom g, const float* __r
                                                    const float* __restrict__ da, const float* __restrict__ res,
                                                    BnBwdArgs bn, const float* __restrict__ w,
                                                    float* __restrict__ dx, int dx_acc, float* __restrict__ dres,
-                                                   int dres_acc, float* __restrict__ partial, long tiles_per_wave) {
+                                                   int dres_acc, float* __restrict__ partial, long tiles_per_wave,
+                                                   int bf, int ybf) {
     __shared__ __attribute__((aligned(16))) float sWt[256];        // data-gradient A matrix [ci][co] = W[co][ci]
     __shared__ __attribute__((aligned(16))) float sT[NT / 64][256];   // per wave: dy tile [pos][16]
     __shared__ float sAcc[NT / 64][256 + 64];
@@ -793,14 +888,14 @@ __global__ __launch_bounds__(NT) void k_unit1x1_bwd(ConvGeom g, const float* __r
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const long pu = tile * 16 + 4 * u + k;
-            xb[u] = (pu < npos && ci_ok) ? x[pu * g.CinT + g.cin_off + c] : 0.f;
+            xb[u] = (pu < npos && ci_ok) ? sld1(x, pu * g.CinT + g.cin_off + c, bf) : 0.f;
         }
         f32x4 dy = {0.f, 0.f, 0.f, 0.f};
         if (pv && co_ok4) {
-            const f32x4 yv = *reinterpret_cast<const f32x4*>(y + p * g.Cout + 4 * q);
+            const f32x4 yv = sld4(y, p * g.Cout + 4 * q, ybf);
             const f32x4 gv = *reinterpret_cast<const f32x4*>(da + p * g.Cout + 4 * q);
             f32x4 rv = {0.f, 0.f, 0.f, 0.f};
-            if (res) rv = *reinterpret_cast<const f32x4*>(res + p * g.Cout + 4 * q);
+            if (res) rv = sld4(res, p * g.Cout + 4 * q, bf);
             f32x4 dzv;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
@@ -878,7 +973,7 @@ __device__ __forceinline__ void nz_ranges(const float* w, int rows, int cols, in
 }
 
 __global__ __launch_bounds__(NT) void k_feat(const float* __restrict__ spec, long sb, long sf, long st, int B, int T,
-                                            const float* __restrict__ erb_w, float* __restrict__ eb) {
+                                            const float* __restrict__ erb_w, float* __restrict__ eb, int bf) {
     __shared__ int lo[64], hi[64];
     nz_ranges(erb_w, 64, 192, 192, 1, lo, hi);
     const long total = (long)B * T * 129;
@@ -903,14 +998,14 @@ __global__ __launch_bounds__(NT) void k_feat(const float* __restrict__ spec, lon
                 }
             }
         }
-        eb[p * 3] = m; eb[p * 3 + 1] = re; eb[p * 3 + 2] = im;
+        sst1(eb, p * 3, bf, m); sst1(eb, p * 3 + 1, bf, re); sst1(eb, p * 3 + 2, bf, im);
     }
 }
 
 // ERB.bs (:69-73) + Mask (:472-482) + output permute (:529-530): one thread per (b,t,f)
 __global__ __launch_bounds__(NT) void k_bs_mask(const float* __restrict__ m, const float* __restrict__ spec, long sb,
                                                long sf, long st, int B, int T, const float* __restrict__ ierb_w,
-                                               float* __restrict__ out, long ob, long of, long ot) {
+                                               float* __restrict__ out, long ob, long of, long ot, int bf) {
     __shared__ int lo[192], hi[192];
     nz_ranges(ierb_w, 192, 64, 64, 1, lo, hi);
     const long total = (long)B * T * 257;
@@ -918,15 +1013,18 @@ __global__ __launch_bounds__(NT) void k_bs_mask(const float* __restrict__ m, con
         const int f = (int)(p % 257);
         const long bt = p / 257;
         const int t = (int)(bt % T), b = (int)(bt / T);
-        const float* mm = m + bt * 129 * 2;
+        const long mm = bt * 129 * 2;
         float m0 = 0.f, m1 = 0.f;
         if (f < 65) {
-            m0 = mm[f * 2]; m1 = mm[f * 2 + 1];
+            m0 = sld1(m, mm + f * 2, bf); m1 = sld1(m, mm + f * 2 + 1, bf);
         } else {
             const float* w = ierb_w + (long)(f - 65) * 64;
             for (int j = lo[f - 65]; j < hi[f - 65]; ++j) {
                 const float wj = w[j];
-                if (wj != 0.f) { m0 = fmaf(wj, mm[(65 + j) * 2], m0); m1 = fmaf(wj, mm[(65 + j) * 2 + 1], m1); }
+                if (wj != 0.f) {
+                    m0 = fmaf(wj, sld1(m, mm + (65 + j) * 2, bf), m0);
+                    m1 = fmaf(wj, sld1(m, mm + (65 + j) * 2 + 1, bf), m1);
+                }
             }
         }
         const float* x = spec + (long)b * sb + (long)t * st + (long)f * sf;
@@ -971,12 +1069,13 @@ __global__ __launch_bounds__(NT) void k_bs_mask_bwd(const float* __restrict__ do
 // ---------------------------------------------------------------------------------- TRALite
 // TRALite.forward (models/gtcrn_micro.py:122-139) with a zero cache: e = mean_F(v^2); y = causal depthwise
 // conv1d (k=3, bias) over [0,0 | e]; g = sigmoid(point_conv(y)).  v: [B][Tt][33][8].
-__global__ __launch_bounds__(NT) void k_tra_energy(const float* __restrict__ v, long rows, float* __restrict__ e) {
+__global__ __launch_bounds__(NT) void k_tra_energy(const float* __restrict__ v, long rows, float* __restrict__ e,
+                                                  int bf) {
     for (long i = (long)blockIdx.x * NT + threadIdx.x; i < rows * 8; i += (long)gridDim.x * NT) {
         const int c = (int)(i & 7);
-        const float* p = v + (i >> 3) * 33 * 8 + c;
+        const long p = (i >> 3) * 33 * 8 + c;
         float s = 0.f;
-        for (int f = 0; f < 33; ++f) s = fmaf(p[f * 8], p[f * 8], s);
+        for (int f = 0; f < 33; ++f) { const float x = sld1(v, p + f * 8, bf); s = fmaf(x, x, s); }
         e[i] = s * (1.0f / 33.0f);
     }
 }
@@ -1005,7 +1104,7 @@ __global__ __launch_bounds__(NT) void k_tra_gate(const float* __restrict__ e, in
 // TRA gate + channel shuffle (:222-227, :246-253): out[2c] = v[c] * g[c], out[2c+1] = x2[c] = x[8+c]
 __global__ __launch_bounds__(NT) void k_gate_shuffle(const float* __restrict__ v, const float* __restrict__ g,
                                                     const float* __restrict__ x, int B, int T, int Tt,
-                                                    float* __restrict__ out) {
+                                                    float* __restrict__ out, int bf) {
     const long total = (long)B * T * 33 * 8;
     for (long i = (long)blockIdx.x * NT + threadIdx.x; i < total; i += (long)gridDim.x * NT) {
         const int c = (int)(i & 7);
@@ -1014,8 +1113,8 @@ __global__ __launch_bounds__(NT) void k_gate_shuffle(const float* __restrict__ v
         const long bt = pos / 33;
         const int t = (int)(bt % T), b = (int)(bt / T);
         const long rowv = (long)b * Tt + t;
-        out[pos * 16 + 2 * c] = v[(rowv * 33 + f) * 8 + c] * g[rowv * 8 + c];
-        out[pos * 16 + 2 * c + 1] = x[pos * 16 + 8 + c];
+        sst1(out, pos * 16 + 2 * c, bf, sld1(v, (rowv * 33 + f) * 8 + c, bf) * g[rowv * 8 + c]);
+        sst1(out, pos * 16 + 2 * c + 1, bf, sld1(x, pos * 16 + 8 + c, bf));
     }
 }
 // backward, step 1: dv = dout[2c] * g (0 on the trimmed tail frames), dx[8+c] = dout[2c+1]
@@ -1041,7 +1140,7 @@ __global__ __launch_bounds__(NT) void k_gate_shuffle_bwd(const float* __restrict
 // step 2: dg = sum_F dout[2c] * v  ->  dzg = dg * g * (1 - g)
 __global__ __launch_bounds__(NT) void k_tra_dgate(const float* __restrict__ dout, const float* __restrict__ v,
                                                  const float* __restrict__ g, int B, int T, int Tt,
-                                                 float* __restrict__ dzg) {
+                                                 float* __restrict__ dzg, int bf) {
     const long total = (long)B * Tt * 8;
     for (long i = (long)blockIdx.x * NT + threadIdx.x; i < total; i += (long)gridDim.x * NT) {
         const int c = (int)(i & 7);
@@ -1050,8 +1149,8 @@ __global__ __launch_bounds__(NT) void k_tra_dgate(const float* __restrict__ dout
         float s = 0.f;
         if (t < T) {
             const float* d = dout + (((long)b * T + t) * 33) * 16 + 2 * c;
-            const float* vv = v + rowv * 33 * 8 + c;
-            for (int f = 0; f < 33; ++f) s = fmaf(d[f * 16], vv[f * 8], s);
+            const long vv = rowv * 33 * 8 + c;
+            for (int f = 0; f < 33; ++f) s = fmaf(d[f * 16], sld1(v, vv + f * 8, bf), s);
         }
         const float gg = g[i];
         dzg[i] = s * gg * (1.f - gg);
@@ -1070,7 +1169,7 @@ __global__ __launch_bounds__(NT) void k_tra_dy(const float* __restrict__ dzg, lo
 }
 // step 4: de[t][c] = sum_k dw[c][k] * dy[t + 2 - k][c];  dv += de * (2/33) * v
 __global__ __launch_bounds__(NT) void k_tra_dv(const float* __restrict__ dy, const float* __restrict__ v, int B, int Tt,
-                                              const float* __restrict__ dw_w, float* __restrict__ dv) {
+                                              const float* __restrict__ dw_w, float* __restrict__ dv, int bf) {
     const long total = (long)B * Tt * 8;
     for (long i = (long)blockIdx.x * NT + threadIdx.x; i < total; i += (long)gridDim.x * NT) {
         const int c = (int)(i & 7);
@@ -1082,9 +1181,9 @@ __global__ __launch_bounds__(NT) void k_tra_dv(const float* __restrict__ dy, con
             if (tt < Tt) de = fmaf(dw_w[c * 3 + k], dy[(rowv + 2 - k) * 8 + c], de);
         }
         de *= 2.0f / 33.0f;
-        const float* vv = v + rowv * 33 * 8 + c;
+        const long vv = rowv * 33 * 8 + c;
         float* d = dv + rowv * 33 * 8 + c;
-        for (int f = 0; f < 33; ++f) d[f * 8] = fmaf(de, vv[f * 8], d[f * 8]);
+        for (int f = 0; f < 33; ++f) d[f * 8] = fmaf(de, sld1(v, vv + f * 8, bf), d[f * 8]);
     }
 }
 // parameter gradients of the two conv1d: 104 sums over the rows (b,t), per-workgroup partials, in the order
@@ -1227,6 +1326,17 @@ __global__ __launch_bounds__(NT) void k_add(const float* __restrict__ a, const f
     for (long i = (long)blockIdx.x * NT + threadIdx.x; i < n; i += (long)gridDim.x * NT) out[i] = a[i] + b[i];
 }
 
+// forward sums of saved tensors (decoder: x + skip), vector of 4
+__global__ __launch_bounds__(NT) void k_add_saved(const float* __restrict__ a, const float* __restrict__ b,
+                                                 float* __restrict__ out, long n4, int bf) {
+    for (long i = (long)blockIdx.x * NT + threadIdx.x; i < n4; i += (long)gridDim.x * NT)
+        sst4(out, i * 4, bf, sld4(a, i * 4, bf) + sld4(b, i * 4, bf));
+}
+__global__ __launch_bounds__(NT) void k_saved_to_f32(const float* __restrict__ src, float* __restrict__ dst, long n,
+                                                    int bf) {
+    for (long i = (long)blockIdx.x * NT + threadIdx.x; i < n; i += (long)gridDim.x * NT) dst[i] = sld1(src, i, bf);
+}
+
 int check() { return (int)hipGetLastError(); }
 
 }  // namespace
@@ -1247,7 +1357,8 @@ static bool mfma_ok(const ConvGeom& g) {
 }
 
 int conv_fwd(const ConvGeom& g, const float* in, const float* w, const float* bias, float* out, hipStream_t s,
-             double* stat_partial, int* stat_parts) {
+             double* stat_partial, int* stat_parts, const float* shift) {
+    if (shift && !g.out_bf) return (int)hipErrorInvalidValue;
     if (stat_parts) *stat_parts = 0;
     if (mfma_ok(g)) {
         const long ntiles = ((long)g.B * g.Tout * g.Fout + 15) / 16;
@@ -1257,16 +1368,16 @@ int conv_fwd(const ConvGeom& g, const float* in, const float* w, const float* bi
         const int grid = (int)((ntiles + tpw * 4 - 1) / (tpw * 4));
         double* sp = (stat_partial && stat_parts && grid <= MAX_PARTIALS && g.cout_off == 0 && g.Cout == g.CoutT &&
                       !g.accumulate) ? stat_partial : nullptr;
-        if (g.nkt == 3) hipLaunchKernelGGL((k_conv_mfma<3, 3>), dim3(grid), dim3(NT), 0, s, g, in, w, bias, out, tpw, sp);
-        else if (g.nkf == 5) hipLaunchKernelGGL((k_conv_mfma<1, 5>), dim3(grid), dim3(NT), 0, s, g, in, w, bias, out, tpw, sp);
-        else hipLaunchKernelGGL((k_conv_mfma<1, 1>), dim3(grid), dim3(NT), 0, s, g, in, w, bias, out, tpw, sp);
+        if (g.nkt == 3) hipLaunchKernelGGL((k_conv_mfma<3, 3>), dim3(grid), dim3(NT), 0, s, g, in, w, bias, out, tpw, sp, shift);
+        else if (g.nkf == 5) hipLaunchKernelGGL((k_conv_mfma<1, 5>), dim3(grid), dim3(NT), 0, s, g, in, w, bias, out, tpw, sp, shift);
+        else hipLaunchKernelGGL((k_conv_mfma<1, 1>), dim3(grid), dim3(NT), 0, s, g, in, w, bias, out, tpw, sp, shift);
         if (sp) *stat_parts = grid;
         return check();
     }
     const int grid = grid_for((long)g.B * g.Tout * g.Fout);
 #define GT_CONV_CASE(CI, CO)                                                                      \
     if (g.Cin == CI && g.Cout == CO) {                                                            \
-        hipLaunchKernelGGL((k_conv<CI, CO>), dim3(grid), dim3(NT), 0, s, g, in, w, bias, out);    \
+        hipLaunchKernelGGL((k_conv<CI, CO>), dim3(grid), dim3(NT), 0, s, g, in, w, bias, out, shift); \
         return check();                                                                           \
     }
     GT_CONV_CASE(3, 16) GT_CONV_CASE(16, 3) GT_CONV_CASE(16, 16) GT_CONV_CASE(8, 16) GT_CONV_CASE(16, 8)
@@ -1295,7 +1406,8 @@ int conv_wgrad(const ConvGeom& g, const float* in, const float* dout, float* dw,
 }
 
 int dw_fwd(const DwGeom& g, const float* in, const float* w, const float* bias, float* out, hipStream_t s,
-           double* stat_partial, int* stat_parts) {
+           double* stat_partial, int* stat_parts, const float* shift) {
+    if (shift && (!g.out_bf || g.C != 16)) return (int)hipErrorInvalidValue;
     if (stat_parts) *stat_parts = 0;
     const int grid = grid_for((long)g.B * g.Tout * g.F);
     if (g.C == 16) {
@@ -1303,7 +1415,7 @@ int dw_fwd(const DwGeom& g, const float* in, const float* w, const float* bias, 
         const int g16 = grid_for((long)g.B * g.Tout * g.F * 4, sp ? MAX_PARTIALS : 16384);
         if (g.Tin != g.Tout) return (int)hipErrorInvalidValue;
         hipLaunchKernelGGL(k_dw16, dim3(g16), dim3(NT), 0, s, g, in, w, bias, out, sp,
-                           stride_iter((long)g16 * NT / 4, g.F, g.Tout));
+                           stride_iter((long)g16 * NT / 4, g.F, g.Tout), shift);
         if (sp) *stat_parts = g16;
         return check();
     }
@@ -1329,7 +1441,7 @@ int dw_wgrad(const DwGeom& g, const float* in, const float* dout, float* dw, flo
         double* part = reinterpret_cast<double*>(scratch);
         const long rows = (long)g.B * g.Tout;
         const int grid = red_grid(rows * g.F);
-        hipLaunchKernelGGL(k_sfe_wgrad, dim3(grid), dim3(NT), 0, s, in, dout, rows, g.F, part);
+        hipLaunchKernelGGL(k_sfe_wgrad, dim3(grid), dim3(NT), 0, s, in, dout, rows, g.F, part, g.in_bf);
         hipLaunchKernelGGL(k_sfe_wgrad_finish, dim3(1), dim3(1024), 0, s, part, grid, dw);
         return check();
     }
@@ -1337,57 +1449,60 @@ int dw_wgrad(const DwGeom& g, const float* in, const float* dout, float* dw, flo
 }
 
 int bn_stats(const float* y, long n, int C, float* stats, float* running_mean, float* running_var, double* scratch,
-             hipStream_t s, int have_parts) {
+             hipStream_t s, int have_parts, int bf, float* shifted) {
     const long total = n * C;
     if (have_parts > 0) {     // the producing conv already left its per-workgroup sums in scratch
         hipLaunchKernelGGL(k_bn_stats_finish, dim3(1), dim3(1024), 0, s, scratch, have_parts, n, C, stats, running_mean,
-                           running_var);
+                           running_var, shifted);
         return check();
     }
     if (C % 4 == 0) {
         const int grid = red_grid(total / 4);
-        hipLaunchKernelGGL((k_bn_stats<4>), dim3(grid), dim3(NT), 0, s, y, total, C, scratch);
-        hipLaunchKernelGGL(k_bn_stats_finish, dim3(1), dim3(1024), 0, s, scratch, grid, n, C, stats, running_mean, running_var);
+        hipLaunchKernelGGL((k_bn_stats<4>), dim3(grid), dim3(NT), 0, s, y, total, C, scratch, bf);
+        hipLaunchKernelGGL(k_bn_stats_finish, dim3(1), dim3(1024), 0, s, scratch, grid, n, C, stats, running_mean, running_var,
+                           shifted);
     } else {
         const int grid = red_grid(total);
-        hipLaunchKernelGGL((k_bn_stats<1>), dim3(grid), dim3(NT), 0, s, y, total, C, scratch);
-        hipLaunchKernelGGL(k_bn_stats_finish, dim3(1), dim3(1024), 0, s, scratch, grid, n, C, stats, running_mean, running_var);
+        hipLaunchKernelGGL((k_bn_stats<1>), dim3(grid), dim3(NT), 0, s, y, total, C, scratch, bf);
+        hipLaunchKernelGGL(k_bn_stats_finish, dim3(1), dim3(1024), 0, s, scratch, grid, n, C, stats, running_mean, running_var,
+                           shifted);
     }
     return check();
 }
 
 int bn_act(const float* y, long n, int C, const float* stats, const float* gamma, const float* beta,
-           const float* res, int act, const float* slope, float* a, hipStream_t s) {
+           const float* res, int act, const float* slope, float* a, hipStream_t s, int bf, int ybf) {
     const long total = n * C;
     if (C % 4 == 0)
         hipLaunchKernelGGL((k_bn_act<4>), dim3(grid_for(total / 4, 8192)), dim3(NT), 0, s, y, total, C, stats, gamma,
-                           beta, res, act, slope, a);
+                           beta, res, act, slope, a, bf, ybf);
     else
         hipLaunchKernelGGL((k_bn_act<1>), dim3(grid_for(total, 8192)), dim3(NT), 0, s, y, total, C, stats, gamma, beta,
-                           res, act, slope, a);
+                           res, act, slope, a, bf, ybf);
     return check();
 }
 
 int bn_act_bwd(const float* da, const float* y, long n, int C, const float* stats, const float* gamma,
                const float* beta, const float* res, int act, const float* slope, float* dy, float* dres,
-               int dres_acc, float* dgamma, float* dbeta, float* dslope, double* scratch, hipStream_t s) {
+               int dres_acc, float* dgamma, float* dbeta, float* dslope, double* scratch, hipStream_t s, int bf,
+               int ybf) {
     const long total = n * C;
     float* red = reinterpret_cast<float*>(scratch + (long)MAX_PARTIALS * 3 * 16);
     if (C % 4 == 0) {
         const int grid = red_grid(total / 4);
         hipLaunchKernelGGL((k_bn_bwd_reduce<4>), dim3(grid), dim3(NT), 0, s, da, y, total, C, stats, gamma, beta, res,
-                           act, slope, scratch);
+                           act, slope, scratch, bf, ybf);
         hipLaunchKernelGGL(k_bn_bwd_finish, dim3(1), dim3(1024), 0, s, scratch, grid, n, C, red, dgamma, dbeta, dslope);
         // the apply pass keeps per-thread channel constants: its stride must be a multiple of C as well
         hipLaunchKernelGGL((k_bn_bwd_apply<4>), dim3(grid_for(total / 4, 8192)), dim3(NT), 0, s, da, y, total, C, stats,
-                           gamma, beta, res, act, slope, red, dy, dres, dres_acc);
+                           gamma, beta, res, act, slope, red, dy, dres, dres_acc, bf, ybf);
     } else {
         const int grid = red_grid(total);
         hipLaunchKernelGGL((k_bn_bwd_reduce<1>), dim3(grid), dim3(NT), 0, s, da, y, total, C, stats, gamma, beta, res,
-                           act, slope, scratch);
+                           act, slope, scratch, bf, ybf);
         hipLaunchKernelGGL(k_bn_bwd_finish, dim3(1), dim3(1024), 0, s, scratch, grid, n, C, red, dgamma, dbeta, dslope);
         hipLaunchKernelGGL((k_bn_bwd_apply<1>), dim3(grid_for(total, 8192)), dim3(NT), 0, s, da, y, total, C, stats,
-                           gamma, beta, res, act, slope, red, dy, dres, dres_acc);
+                           gamma, beta, res, act, slope, red, dy, dres, dres_acc, bf, ybf);
     }
     return check();
 }
@@ -1395,7 +1510,8 @@ int bn_act_bwd(const float* da, const float* y, long n, int C, const float* stat
 int unit1x1_bwd(const ConvGeom& g, const float* x, const float* y, const float* da, const float* res,
                 const float* stats, const float* gamma, const float* beta, int act, const float* slope,
                 const float* w, float* dx, int dx_acc, float* dres, int dres_acc, float* dw, float* dbias,
-                float* dgamma, float* dbeta, float* dslope, double* dscratch, float* fscratch, hipStream_t s) {
+                float* dgamma, float* dbeta, float* dslope, double* dscratch, float* fscratch, hipStream_t s, int bf,
+                int ybf) {
     const long n = (long)g.B * g.Tout * g.Fout, total = n * g.Cout;
     if (g.nkt != 1 || g.nkf != 1 || g.sf != 1 || g.pf != 0 || g.Cout != g.CoutT || g.cout_off != 0 || (g.Cout % 4) ||
         (g.Cin % 4) || (g.CinT % 4) || (g.cin_off % 4))
@@ -1403,7 +1519,7 @@ int unit1x1_bwd(const ConvGeom& g, const float* x, const float* y, const float* 
     float* red = reinterpret_cast<float*>(dscratch + (long)MAX_PARTIALS * 3 * 16);
     const int rgrid = red_grid(total / 4);
     hipLaunchKernelGGL((k_bn_bwd_reduce<4>), dim3(rgrid), dim3(NT), 0, s, da, y, total, g.Cout, stats, gamma, beta, res,
-                       act, slope, dscratch);
+                       act, slope, dscratch, bf, ybf);
     hipLaunchKernelGGL(k_bn_bwd_finish, dim3(1), dim3(1024), 0, s, dscratch, rgrid, n, g.Cout, red, dgamma, dbeta, dslope);
     const long ntiles = (n + 15) / 16;
     long waves = (long)MAX_PARTIALS * (NT / 64);
@@ -1412,20 +1528,20 @@ int unit1x1_bwd(const ConvGeom& g, const float* x, const float* y, const float* 
     const int grid = (int)((ntiles + tpw * (NT / 64) - 1) / (tpw * (NT / 64)));
     BnBwdArgs bn{stats, gamma, beta, slope, red, act};
     hipLaunchKernelGGL(k_unit1x1_bwd, dim3(grid), dim3(NT), 0, s, g, x, y, da, res, bn, w, dx, dx_acc, dres, dres_acc,
-                       fscratch, tpw);
+                       fscratch, tpw, bf, ybf);
     hipLaunchKernelGGL(k_wgrad_mfma_finish, dim3((256 + 16 + 63) / 64), dim3(1024), 0, s, g, fscratch, grid, dw, dbias);
     return check();
 }
 
 int feat_fwd(const float* spec, long sb, long sf, long st, int B, int T, const float* erb_w, float* eb,
-             hipStream_t s) {
-    hipLaunchKernelGGL(k_feat, dim3(grid_for((long)B * T * 129)), dim3(NT), 0, s, spec, sb, sf, st, B, T, erb_w, eb);
+             hipStream_t s, int bf) {
+    hipLaunchKernelGGL(k_feat, dim3(grid_for((long)B * T * 129)), dim3(NT), 0, s, spec, sb, sf, st, B, T, erb_w, eb, bf);
     return check();
 }
 int bs_mask_fwd(const float* m, const float* spec, long sb, long sf, long st, int B, int T, const float* ierb_w,
-                float* out, long ob, long of, long ot, hipStream_t s) {
+                float* out, long ob, long of, long ot, hipStream_t s, int bf) {
     hipLaunchKernelGGL(k_bs_mask, dim3(grid_for((long)B * T * 257)), dim3(NT), 0, s, m, spec, sb, sf, st, B, T, ierb_w,
-                       out, ob, of, ot);
+                       out, ob, of, ot, bf);
     return check();
 }
 int bs_mask_bwd(const float* dout, long ob, long of, long ot, const float* spec, long sb, long sf, long st, int B,
@@ -1436,26 +1552,28 @@ int bs_mask_bwd(const float* dout, long ob, long of, long ot, const float* spec,
 }
 
 int tra_fwd(const float* v, int B, int Tt, const float* dw_w, const float* dw_b, const float* pw_w,
-            const float* pw_b, float* e, float* y, float* g, hipStream_t s) {
+            const float* pw_b, float* e, float* y, float* g, hipStream_t s, int bf) {
     const long rows = (long)B * Tt;
-    hipLaunchKernelGGL(k_tra_energy, dim3(grid_for(rows * 8)), dim3(NT), 0, s, v, rows, e);
+    hipLaunchKernelGGL(k_tra_energy, dim3(grid_for(rows * 8)), dim3(NT), 0, s, v, rows, e, bf);
     hipLaunchKernelGGL(k_tra_gate, dim3(grid_for(rows * 8)), dim3(NT), 0, s, e, B, Tt, dw_w, dw_b, pw_w, pw_b, y, g);
     return check();
 }
-int gate_shuffle_fwd(const float* v, const float* g, const float* x, int B, int T, int Tt, float* out, hipStream_t s) {
-    hipLaunchKernelGGL(k_gate_shuffle, dim3(grid_for((long)B * T * 33 * 8)), dim3(NT), 0, s, v, g, x, B, T, Tt, out);
+int gate_shuffle_fwd(const float* v, const float* g, const float* x, int B, int T, int Tt, float* out, hipStream_t s,
+                     int bf) {
+    hipLaunchKernelGGL(k_gate_shuffle, dim3(grid_for((long)B * T * 33 * 8)), dim3(NT), 0, s, v, g, x, B, T, Tt, out, bf);
     return check();
 }
 int tra_gate_shuffle_bwd(const float* dout, const float* v, const float* g, const float* e, const float* y, int B,
                          int T, int Tt, const float* dw_w, const float* pw_w, float* dv, float* dx, float* d_dw_w,
-                         float* d_dw_b, float* d_pw_w, float* d_pw_b, float* tmp, float* scratch, hipStream_t s) {
+                         float* d_dw_b, float* d_pw_w, float* d_pw_b, float* tmp, float* scratch, hipStream_t s,
+                         int bf) {
     const long rows = (long)B * Tt;
     float* dzg = tmp;
     float* dy = tmp + rows * 8;
     hipLaunchKernelGGL(k_gate_shuffle_bwd, dim3(grid_for(rows * 33 * 8)), dim3(NT), 0, s, dout, g, B, T, Tt, dv, dx);
-    hipLaunchKernelGGL(k_tra_dgate, dim3(grid_for(rows * 8)), dim3(NT), 0, s, dout, v, g, B, T, Tt, dzg);
+    hipLaunchKernelGGL(k_tra_dgate, dim3(grid_for(rows * 8)), dim3(NT), 0, s, dout, v, g, B, T, Tt, dzg, bf);
     hipLaunchKernelGGL(k_tra_dy, dim3(grid_for(rows * 8)), dim3(NT), 0, s, dzg, rows, pw_w, dy);
-    hipLaunchKernelGGL(k_tra_dv, dim3(grid_for(rows * 8)), dim3(NT), 0, s, dy, v, B, Tt, dw_w, dv);
+    hipLaunchKernelGGL(k_tra_dv, dim3(grid_for(rows * 8)), dim3(NT), 0, s, dy, v, B, Tt, dw_w, dv, bf);
     const int parts = (int)(rows < MAX_PARTIALS ? rows : MAX_PARTIALS);
     hipLaunchKernelGGL(k_tra_pgrad, dim3(parts), dim3(128), 0, s, dzg, y, dy, e, B, Tt, scratch);
     // the four gradients are contiguous in the blob in exactly the partials' order (d_dw_w is the first)
@@ -1483,6 +1601,16 @@ int sisnr_terms(float* yp, const float* yt, int B, long Lw, const double* spec_p
     if (want_grad)
         hipLaunchKernelGGL(k_sisnr_gwave, dim3(grid_for((long)B * Lw, 8192)), dim3(NT), 0, s, yp, yt, Lw, (long)B * Lw,
                            coef, win);
+    return check();
+}
+
+int add_saved(const float* a, const float* b, float* out, long n, hipStream_t s, int bf) {
+    if (n % 4) return (int)hipErrorInvalidValue;
+    hipLaunchKernelGGL(k_add_saved, dim3(grid_for(n / 4, 8192)), dim3(NT), 0, s, a, b, out, n / 4, bf);
+    return check();
+}
+int saved_to_f32(const float* src, float* dst, long n, hipStream_t s, int bf) {
+    hipLaunchKernelGGL(k_saved_to_f32, dim3(grid_for(n, 8192)), dim3(NT), 0, s, src, dst, n, bf);
     return check();
 }
 

@@ -219,6 +219,7 @@ class GTCRNMicro(nn.Module):
         self._stats_dirty = False
         self._fwd_serial = 0
         self._grad_flat = None  # gradient blob of the most recent backward (canonical layout)
+        self._act_storage = "f32"
         self._sig_tensors = None
 
     # -- weight hand-over -------------------------------------------------------------------
@@ -243,7 +244,18 @@ class GTCRNMicro(nn.Module):
             idx = torch.cuda.current_device()
         if idx not in self._trainers:
             self._trainers[idx] = _lib.Trainer(idx)
+            self._trainers[idx].set_storage(self._act_storage)
         return self._trainers[idx]
+
+    def set_activation_storage(self, storage):
+        """Train mode only: keep the saved activations in "f32" (default, the reference's precision) or "bf16"
+        (BASELINE configs[3]: halves the HBM traffic and the workspace of the layer-at-a-time train step; arithmetic,
+        BatchNorm statistics, gradients, Adam and the weights stay fp32).  Takes effect at the next forward."""
+        if storage not in _lib.Trainer.STORAGE:
+            raise _lib.GtcrnError(f"storage must be one of {sorted(_lib.Trainer.STORAGE)}, got {storage!r}")
+        self._act_storage = storage
+        for tr in self._trainers.values():
+            tr.set_storage(storage)
 
     def _flatten(self, device):
         """Moves the storage of every parameter and buffer into ONE canonical blob on ``device`` (the layout

@@ -209,7 +209,13 @@ int gtcrn_timing_read(gtcrn_model *m, int idx, char *name, int name_cap, float *
 typedef struct gtcrn_trainer gtcrn_trainer;
 int gtcrn_trainer_create(gtcrn_trainer **out, int device);
 void gtcrn_trainer_destroy(gtcrn_trainer *t);
-long gtcrn_train_workspace_bytes(int B, int T);   /* saved activations + gradient buffers */
+long gtcrn_train_workspace_bytes(int B, int T);   /* saved activations + gradient buffers (fp32 storage) */
+/* Storage of the SAVED activations (everything the backward re-reads): 0 = fp32, the reference's own precision
+ * (train.py:239-288 trains in fp32); 1 = bf16 (BASELINE configs[3] asks for bf16: half the bytes of every pass of the
+ * HBM-bound layer-at-a-time step).  Arithmetic, BatchNorm statistics, gradients, the gradient all-reduce, Adam and
+ * the master weights stay fp32 in both.  Takes effect at the next forward. */
+int gtcrn_trainer_set_storage(gtcrn_trainer *t, int storage);
+long gtcrn_train_workspace_bytes2(int B, int T, int storage);
 int gtcrn_train_forward(gtcrn_trainer *t, float *d_params, const float *d_spec, long sb, long sf, long st,
                         float *d_out, long ob, long of, long ot, int B, int T, void *stream);
 int gtcrn_train_backward(gtcrn_trainer *t, const float *d_params, const float *d_spec, long sb, long sf,
