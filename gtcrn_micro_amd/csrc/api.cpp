@@ -45,6 +45,8 @@ struct Timing {
     int kernel = 0;  // index into kKernelNames
     hipEvent_t a = nullptr, b = nullptr;
 };
+// index 0 / 1 are k_front / k_encoder_gt on offline calls (front end fused with the STFT, GTConv blocks alone) and
+// k_stft / k_encoder otherwise; gtcrn_timing_read reports the name of what actually ran
 const char* const kKernelNames[] = {"k_stft", "k_encoder", "k_gtcn1", "k_gtcn2", "k_decoder", "k_istft"};
 constexpr int kNumKernels = 6;
 
@@ -65,6 +67,7 @@ struct gtcrn_model {
     int last_B = 0, last_T = 0;
     float* d_en0 = nullptr;  // (B,T,65,16)
     float* d_en[4] = {nullptr, nullptr, nullptr, nullptr};  // en1..en4 (B,T,33,16)
+    float* d_en1n = nullptr; // en1 in its own slot order (input of the first GTConv block; offline calls)
     float* d_g1 = nullptr;   // gtcn1 output
     float* d_g2 = nullptr;   // gtcn2 output
     float* d_spec_a = nullptr;  // frame-major spectrograms for forward_wave (B,T,257,2)
@@ -75,6 +78,7 @@ struct gtcrn_model {
     unsigned long long* d_stamps = nullptr;  // [4 kernels][B][16] phase cycle sums (diagnostic build only)
     int stamps_cap_b = 0;
     float** d_ptr8 = nullptr;  // device table of 8 tcn cache pointers
+    bool fused_front = false;      // the last call ran k_front (+ k_encoder_gt)
     bool timing = false;
     int timing_only = -1;          // >= 0: record events around this kernel only (two events per call)
     std::vector<Timing> timings;   // one entry per timed launch since gtcrn_timing_enable(m, 1)
@@ -84,7 +88,7 @@ struct gtcrn_model {
 namespace {
 
 void free_workspace(gtcrn_model* m) {
-    float** bufs[] = {&m->d_en0, &m->d_en[0], &m->d_en[1], &m->d_en[2], &m->d_en[3], &m->d_g1, &m->d_g2,
+    float** bufs[] = {&m->d_en0, &m->d_en[0], &m->d_en[1], &m->d_en[2], &m->d_en[3], &m->d_en1n, &m->d_g1, &m->d_g2,
                       &m->d_spec_a, &m->d_spec_b};
     for (float** p : bufs) {
         if (*p) (void)hipFree(*p);
@@ -103,6 +107,7 @@ int ensure_workspace(gtcrn_model* m, int B, int T, hipStream_t s) {
         free_workspace(m);
         HIP_TRY(hipMalloc(&m->d_en0, sizeof(float) * bt * 65 * 16));
         for (int i = 0; i < 4; ++i) HIP_TRY(hipMalloc(&m->d_en[i], sizeof(float) * bt * 528));
+        HIP_TRY(hipMalloc(&m->d_en1n, sizeof(float) * bt * 528));
         HIP_TRY(hipMalloc(&m->d_g1, sizeof(float) * bt * 528));
         HIP_TRY(hipMalloc(&m->d_g2, sizeof(float) * bt * 528));
         HIP_TRY(hipMalloc(&m->d_spec_a, sizeof(float) * bt * 514));
@@ -154,14 +159,27 @@ struct Timer {
 // the five model kernels on one stream; state == nullptr for offline
 int run_model(gtcrn_model* m, const float* spec_in, long isb, long isf, long ist, float* spec_out, long osb, long osf,
               long ost, int B, int T, float* state, hipStream_t s, const int* lens = nullptr,
-              const gtk::Quant* q = nullptr) {
+              const gtk::Quant* q = nullptr, bool front_done = false) {
     Timer tm(m, s);
     const float* pf = q ? m->d_pfq : m->d_pf;
+    const float* x1 = nullptr;
+    if (!state) {
+        // offline: the frame-independent front end runs as a throughput kernel (fused with the STFT by
+        // forward_wave_impl, which passes front_done), the per-utterance kernel keeps the three GTConv blocks
+        if (!front_done) {
+            tm.begin(0);
+            LAUNCH_TRY(gtk::launch_front(nullptr, 0, spec_in, isb, isf, ist, B, T, lens, nullptr, nullptr, pf, m->d_pi,
+                                         nullptr, m->d_en0, m->d_en[0], m->d_en1n, s, q));
+            tm.end();
+        }
+        x1 = m->d_en1n;
+    }
+    m->fused_front = x1 != nullptr;
     unsigned long long* stp = (m->debug && m->d_stamps) ? m->d_stamps : nullptr;
     const long sst = (long)m->stamps_cap_b * 16;
     tm.begin(1);
     LAUNCH_TRY(gtk::launch_encoder(spec_in, isb, isf, ist, B, T, lens, pf, m->d_pi, m->d_en0, m->d_en[0], m->d_en[1],
-                                   m->d_en[2], m->d_en[3], state, stp ? stp : nullptr, s, q));
+                                   m->d_en[2], m->d_en[3], state, stp ? stp : nullptr, s, q, x1));
     tm.end();
     // GTCN: offline calls (no stream state) use the frequency-band form (registers + DPP, no barrier);
     // streaming calls use the ring form, whose chunks may hold a single frame
@@ -445,9 +463,10 @@ static int forward_wave_impl(gtcrn_model* m, const float* d_wave, float* d_wave_
     const long sb = (long)T * 514, sf = 2, st = 514;
     Timer tm(m, s);
     tm.begin(0);
-    LAUNCH_TRY(gtk::launch_stft(d_wave, B, L, T, d_lengths, d_win, m->d_twid, m->d_spec_a, sb, sf, st, nullptr, s));
+    LAUNCH_TRY(gtk::launch_front(d_wave, L, nullptr, 0, 0, 0, B, T, d_lengths, d_win, m->d_twid, q ? m->d_pfq : m->d_pf,
+                                 m->d_pi, m->d_spec_a, m->d_en0, m->d_en[0], m->d_en1n, s, q));
     tm.end();
-    rc = run_model(m, m->d_spec_a, sb, sf, st, m->d_spec_b, sb, sf, st, B, T, nullptr, s, d_lengths, q);
+    rc = run_model(m, m->d_spec_a, sb, sf, st, m->d_spec_b, sb, sf, st, B, T, nullptr, s, d_lengths, q, true);
     if (rc) return rc;
     tm.begin(5);
     LAUNCH_TRY(gtk::launch_istft(m->d_spec_b, sb, sf, st, B, T, d_lengths, d_win, m->d_twid, d_wave_out, s));
@@ -694,7 +713,10 @@ int gtcrn_timing_read(gtcrn_model* m, int idx, char* name, int name_cap, float* 
     *ms = n ? (float)(sum / n) : 0.f;
     if (launches) *launches = n;
     if (name && name_cap > 0) {
-        std::strncpy(name, kKernelNames[idx], name_cap - 1);
+        const char* nm = kKernelNames[idx];
+        if (m->fused_front && idx == 0) nm = "k_front";
+        if (m->fused_front && idx == 1) nm = "k_encoder_gt";
+        std::strncpy(name, nm, name_cap - 1);
         name[name_cap - 1] = 0;
     }
     return 0;

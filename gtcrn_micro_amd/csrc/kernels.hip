@@ -761,9 +761,12 @@ constexpr int ENC_MS_LDS_FLOATS = EncLds<MS_ROWS, MS_STREAMS, true>::FLOATS;
 // history (rings, energies, frame counters) is per row.
 // Q: int8-weight / fp16-activation variant (PF then holds the quantised weights); qin > 0 additionally passes the
 // input spectrogram through the int8 boundary of the tflite path (x_q = round(x / qin), tflite_infer.py:79-82).
-template <int TPW, bool MS, bool Q>
+// FRONT = false (offline calls): k_front has already produced en0 and en1; this kernel reads en1 in its own slot order
+// (x1) and runs only the three causal GTConv blocks.
+template <int TPW, bool MS, bool Q, bool FRONT>
 __global__ __launch_bounds__(NTHR) void k_encoder(const float* __restrict__ spec, long sb, long sf, long st, int T,
                                                  const int* __restrict__ lens, int NB, float qin,
+                                                 const float* __restrict__ x1,
                                                  const float* __restrict__ PF, const int* __restrict__ PI,
                                                  float* __restrict__ en0, float* __restrict__ en1,
                                                  float* __restrict__ en2, float* __restrict__ en3,
@@ -790,7 +793,7 @@ __global__ __launch_bounds__(NTHR) void k_encoder(const float* __restrict__ spec
     const int tid = L.tid, n = L.n, g = L.g;
     const int b = blockIdx.x;
 
-    for (int i = tid; i < ENC_SIZE; i += NTHR) sP[i] = PF[P_ENC + i];
+    for (int i = tid + (FRONT ? 0 : E_BLK); i < ENC_SIZE; i += NTHR) sP[i] = PF[P_ENC + i];
     for (int i = tid; i < P_INTS; i += NTHR) sI[i] = PI[i];
     // (the pad entries of EB / F0 are zeroed at the top of every chunk; nothing else of that region is read unwritten)
     float* stb = state ? state + (long)b * NS * ST_FLOATS : nullptr;    // first stream of this workgroup
@@ -822,7 +825,7 @@ __global__ __launch_bounds__(NTHR) void k_encoder(const float* __restrict__ spec
     // with f fastest for the frame-major layout (consecutive bins adjacent) and tl fastest for the
     // reference layout (consecutive frames adjacent).  The chunk is fetched one chunk ahead into
     // registers, so its HBM latency is hidden behind the previous chunk's compute.
-    constexpr int SPEC_ITEMS = (RW * NBINS + NTHR - 1) / NTHR;
+    constexpr int SPEC_ITEMS = FRONT ? (RW * NBINS + NTHR - 1) / NTHR : 1;
     float2 spn[SPEC_ITEMS];
     const int sf32 = (int)sf, st32 = (int)st;     // api.cpp checks that a chunk's offsets fit in 31 bits
     auto spec_fetch = [&](int t0f) {
@@ -839,10 +842,30 @@ __global__ __launch_bounds__(NTHR) void k_encoder(const float* __restrict__ spec
             spec_item_next(t_fast, tl, f);
         }
     };
-    spec_fetch(0);
+    if constexpr (FRONT) spec_fetch(0);
+    // FRONT = false: the block input of the chunk, fetched one chunk ahead (clamped: no select behind the loads)
+    f32x4 xn[TPW];
+    if constexpr (!FRONT) {
+        x1 += ob * 528;
+        const int np0 = min(RW, T) * 33;
+#pragma unroll
+        for (int i = 0; i < TPW; ++i) xn[i] = ld4(x1 + (unsigned)((tt.pp(i) < np0 ? tt.pp(i) : 0) * 16 + 4 * g));
+    }
 
     for (int t0 = 0; t0 < T; t0 += RW) {
         const int nfr = min(RW, T - t0);
+        f32x4 x[TPW];
+        if constexpr (!FRONT) {
+#pragma unroll
+            for (int i = 0; i < TPW; ++i) x[i] = xn[i];
+            if (t0 + RW < T) {
+                const int npn = min(RW, T - t0 - RW) * 33;
+                const float* xc = x1 + (long)(t0 + RW) * 528;
+#pragma unroll
+                for (int i = 0; i < TPW; ++i) xn[i] = ld4(xc + (unsigned)((tt.pp(i) < npn ? tt.pp(i) : 0) * 16 + 4 * g));
+            }
+        }
+        if constexpr (FRONT) {
         // the cooperative loops index from an opaque copy of tid so that their per-item offsets are
         // recomputed per chunk instead of being hoisted, spilled and reloaded (scratch shares vmcnt)
         int tv = tid;
@@ -973,7 +996,6 @@ __global__ __launch_bounds__(NTHR) void k_encoder(const float* __restrict__ spec
         wg_barrier();
         STAMP(SS, 3)
         // ---- D: en_convs.1 = Conv2d(16,16,(1,5),stride (1,2),pad (0,2)) + BN + PReLU -------------
-        f32x4 x[TPW];
         {
             const f32x4 Bv = ld4(sP + E_EN1_B + 4 * g);
             const float a = sP[E_EN1_S] - 1.0f;
@@ -1001,6 +1023,7 @@ __global__ __launch_bounds__(NTHR) void k_encoder(const float* __restrict__ spec
         }
         wg_barrier();  // E0 is dead: its region becomes W
         STAMP(SS, 4)
+        }   // FRONT
         zero_row_pads<RW>(sW, tid);
         // ---- E: 3 x GTConvBlock (depthwise) --------------------------------------------------------
 #pragma unroll 1
@@ -1052,6 +1075,277 @@ __global__ __launch_bounds__(NTHR) void k_encoder(const float* __restrict__ spec
         }
     }
     STAMP_OUT(SS, stamps)
+}
+
+// =============================================================================== front end (offline form)
+// Everything in front of the first GTConv block has NO dependence across frames: reflect-pad framing, window, FFT
+// (infer.py:60-67), [mag,re,im] (models/gtcrn_micro.py:510-515), ERB.bm (:63-67), SFE_Lite (:77-90) and the two
+// strided (1,5) ConvBlocks (:344-364).  Offline calls therefore run it as a THROUGHPUT kernel instead of inside the
+// lock-stepped per-utterance encoder: ONE FRAME PER WAVE from the waveform samples to en1, in 7.6 KB of wave-private
+// LDS, so the waves never meet at a barrier (persistent workgroups of eight waves, two per CU = 4 waves per SIMD: three per SIMD measured 40 % slower,
+// parameters copied to LDS once).  The frame never leaves LDS between the FFT and the convs; the spectrogram is
+// also written out once (the decoder's mask multiplies it).  Price: a frame's 65 / 33 positions fill 5 / 3 MFMA
+// tiles (80 MFMAs per frame instead of 59 for tiles cut across frames).  Same source expressions as k_encoder's
+// in-kernel front end (which the streaming forms keep), so every value is bit-identical.
+// WAVE_IN = false: the frames come from a caller spectrogram (gtcrn_forward_spec) instead of the FFT.
+// Outputs: en0 (B,T,65,16), en1 twice -- in the slot order of its decoder consumer (en1p) and in its own (en1n,
+// the input of the first GTConv block).
+constexpr int FR_WAVES = 8;
+constexpr int FR_NT = FR_WAVES * 64;
+constexpr int FR_P = 0;                                        // E_ERB_W .. E_BLK of the encoder segment
+constexpr int FR_I = FR_P + ((E_BLK + 3) & ~3);                // I_ERB_LO[64], I_ERB_N[64], I_ENST[0][16] (+pad)
+constexpr int FR_TW = FR_I + 160;                              // twiddles 256 + 256 complex, window 512
+constexpr int FR_W0 = FR_TW + 1536;                            // wave-private regions start here
+constexpr int FR_WX = 0;                                       // FFT ping (512) + pong (512, later the staged high bins), later E0 [69][16]
+constexpr int FR_WEB = FR_WX + ENC_E0_ROW * 16;                // EB [3][131] (+3 pad)
+constexpr int FR_WF0 = FR_WEB + 396;                           // F0 [3][136]; EB..F0 later the en1 permute scratch
+constexpr int FR_WSZ = FR_WF0 + 3 * F0_ROW;
+constexpr int FR_LDS_FLOATS = FR_W0 + FR_WAVES * FR_WSZ;
+static_assert(1024 <= ENC_E0_ROW * 16 && 2 * 192 <= 512, "FFT buffers / staged high bins must fit in the E0 region");
+static_assert(3 * 16 * 16 <= 396 + 3 * F0_ROW, "en1 permute scratch (3 tiles) must fit in EB + F0");
+static_assert(FR_W0 % 4 == 0 && FR_WSZ % 4 == 0 && FR_WEB % 4 == 0 && FR_WF0 % 4 == 0, "16B carve");
+static_assert(FR_LDS_FLOATS * 4 * 2 <= 160 * 1024, "two front-end workgroups per CU");
+
+template <bool WAVE_IN, bool Q>
+__global__ __launch_bounds__(FR_NT, 4) void k_front(const float* __restrict__ in, long L, long isb, long isf, long ist,
+                                                int B, int T, const int* __restrict__ lens,
+                                                const float* __restrict__ win, const float2* __restrict__ twid,
+                                                const float* __restrict__ PF, const int* __restrict__ PI,
+                                                float* __restrict__ spec, float* __restrict__ en0,
+                                                float* __restrict__ en1p, float* __restrict__ en1n, float qin) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* sP = smem + FR_P;                   // indexed with the E_* offsets of the encoder segment
+    int* sI = reinterpret_cast<int*>(smem + FR_I);
+    float2* s_tw = reinterpret_cast<float2*>(smem + FR_TW);
+    float2* s_tw512 = s_tw + 256;
+    float* s_win = smem + FR_TW + 1024;
+    const int tid = threadIdx.x, lane = tid & 63, n = lane & 15, g = lane >> 4;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    float* mine = smem + FR_W0 + wv * FR_WSZ;
+    float2* A = reinterpret_cast<float2*>(mine + FR_WX);
+    float2* Bf = A + 256;                      // FFT pong buffer, then the staged (re, im) of the 192 high bins
+    float* sE0 = mine + FR_WX;
+    float* sEB = mine + FR_WEB;
+    float* sF0 = mine + FR_WF0;
+    for (int i = tid; i < E_BLK; i += FR_NT) sP[i] = PF[P_ENC + i];
+    for (int i = tid; i < 128; i += FR_NT) sI[i] = PI[I_ERB_LO + i];
+    if (tid < 16) sI[128 + tid] = PI[I_ENST + tid];
+    if (WAVE_IN) {
+        for (int i = tid; i < 256; i += FR_NT) { s_tw[i] = twid[i]; s_tw512[i] = twid[256 + i]; }
+        for (int i = tid; i < 512; i += FR_NT) s_win[i] = win[i];
+    }
+    __syncthreads();          // the only workgroup barrier: from here on every wave works on its own frames
+    const long nframes = (long)B * T, stride = (long)gridDim.x * FR_WAVES;
+    long fr = (long)blockIdx.x * FR_WAVES + wv;
+    // frame `fr` of the flattened (utterance, frame) axis; with per-utterance lengths the frames past an utterance's
+    // end do not exist (skipped)
+    auto frame_of = [&](long f, int& b, int& t, long& Lb) -> bool {
+        if (f >= nframes) return false;
+        b = (int)(f / T);
+        t = (int)(f - (long)b * T);
+        Lb = lens ? (long)lens[b] : L;
+        return !lens || t <= (int)(Lb >> 8);
+    };
+    auto fetch = [&](long f, float2 (&v)[4]) {
+        int b, t;
+        long Lb;
+        if (!frame_of(f, b, t, Lb)) { b = 0; t = 0; Lb = lens ? (long)lens[0] : L; }     // a valid frame, not used
+        const float* x = in + (long)b * L;
+        const long lo = 256L * t - 256;
+        if (lo >= 0 && lo + 512 <= Lb && ((reinterpret_cast<uintptr_t>(x + lo) & 7) == 0)) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) v[q] = *reinterpret_cast<const float2*>(x + lo + 2 * (lane + 64 * q));
+        } else {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const long i0 = 256L * t + 2 * (lane + 64 * q);
+                v[q] = make_float2(x[reflect_idx(i0, Lb)], x[reflect_idx(i0 + 1, Lb)]);
+            }
+        }
+    };
+    // bin k of the frame -> the LDS images: low bins straight to their place in EB (ERB.bm passes them through),
+    // high bins as (re, im) pairs for the band filters; the magnitude of a high bin is formed where it is used
+    auto quant_in = [&](float2 v) -> float2 {
+        if constexpr (Q) {
+            if (qin > 0.f) {
+                v.x = fminf(fmaxf(rintf(v.x / qin), -128.f), 127.f) * qin;
+                v.y = fminf(fmaxf(rintf(v.y / qin), -128.f), 127.f) * qin;
+            }
+            v.x = rq1<Q>(v.x);
+            v.y = rq1<Q>(v.y);
+        }
+        return v;
+    };
+    auto stage = [&](int k, float2 v) {
+        v = quant_in(v);
+        if (k < ERB_LOW) {
+            float* d = sEB + 1 + k;
+            d[0] = rq1<Q>(__builtin_amdgcn_sqrtf(v.x * v.x + v.y * v.y + 1e-12f));
+            d[EB_ROW] = v.x;
+            d[2 * EB_ROW] = v.y;
+        } else {
+            Bf[k - ERB_LOW] = v;
+        }
+    };
+    float2 cur[4];
+    for (; fr < nframes; fr += stride) {
+        int b, t;
+        long Lb;
+        const bool live = frame_of(fr, b, t, Lb);
+        // (no prefetch of the next frame: four waves per SIMD hide the load, and its eight registers would spill)
+        if (WAVE_IN && live) fetch(fr, cur);
+        if (live) {
+            // ---- the frame -> [mag, re, im] in LDS (+ the spectrogram written out) --------------------------------
+            if constexpr (WAVE_IN) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int m = lane + 64 * q;
+                    float2 v;
+                    v.x = cur[q].x * s_win[2 * m];
+                    v.y = cur[q].y * s_win[2 * m + 1];
+                    A[m] = v;
+                }
+                wave_lds_sync();
+                fft256<-1>(A, Bf, s_tw, lane);
+                float* o = spec + fr * (2 * NBINS);               // frame-major (B,T,257,2)
+                float2 X[4], XN = make_float2(0.f, 0.f);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int k = lane + 64 * q;
+                    const float2 zk = A[k], zm = A[(256 - k) & 255];
+                    const float2 ze = make_float2(0.5f * (zk.x + zm.x), 0.5f * (zk.y - zm.y));
+                    const float2 zo = make_float2(0.5f * (zk.y + zm.y), -0.5f * (zk.x - zm.x));
+                    const float2 r = cmul(s_tw512[k], zo);
+                    X[q] = make_float2(ze.x + r.x, ze.y + r.y);
+                    if (k == 0) XN = make_float2(zk.x - zk.y, 0.f);   // Nyquist bin: X[256] = Re Z[0] - Im Z[0]
+                }
+                wave_lds_sync();                                  // every lane has read A and Bf is free: stage
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int k = lane + 64 * q;
+                    *reinterpret_cast<float2*>(o + 2 * k) = X[q];
+                    stage(k, X[q]);
+                }
+                if (lane == 0) {
+                    *reinterpret_cast<float2*>(o + 2 * 256) = XN;
+                    stage(256, XN);
+                }
+            } else {
+                const float* base = in + (long)b * isb + (long)t * ist;
+                for (int k = lane; k < NBINS; k += 64) stage(k, *reinterpret_cast<const float2*>(base + (long)k * isf));
+            }
+            if (lane < 6) sEB[(lane >> 1) * EB_ROW + (lane & 1) * 130] = 0.f;     // EB pad columns 0 and 130
+            wave_lds_sync();
+            // ---- A: ERB.bm: lane = band; the three channels share the band's (re, im) reads ----------------------
+            {
+                const int band = lane;
+                const int lo = sI[band], cnt = sI[64 + band];
+                float w[ERB_MAXBW];
+#pragma unroll
+                for (int i = 0; i < ERB_MAXBW; i += 4) {
+                    const f32x4 tq = ld4(sP + E_ERB_W + band * ERB_MAXBW + i);
+                    w[i] = tq[0]; w[i + 1] = tq[1]; w[i + 2] = tq[2]; w[i + 3] = tq[3];
+                }
+                float m0 = 0.f, m1 = 0.f, r0 = 0.f, r1 = 0.f, i0 = 0.f, i1 = 0.f;
+#pragma unroll
+                for (int i = 0; i < ERB_MAXBW; i += 2) {        // taps beyond the band's width are selected away
+                    const float2 va = Bf[(lo + i) & 255], vb = Bf[(lo + i + 1) & 255];
+                    const float ma = rq1<Q>(__builtin_amdgcn_sqrtf(va.x * va.x + va.y * va.y + 1e-12f));
+                    const float mb = rq1<Q>(__builtin_amdgcn_sqrtf(vb.x * vb.x + vb.y * vb.y + 1e-12f));
+                    m0 += w[i] * (i < cnt ? ma : 0.f);
+                    m1 += w[i + 1] * (i + 1 < cnt ? mb : 0.f);
+                    r0 += w[i] * (i < cnt ? va.x : 0.f);
+                    r1 += w[i + 1] * (i + 1 < cnt ? vb.x : 0.f);
+                    i0 += w[i] * (i < cnt ? va.y : 0.f);
+                    i1 += w[i + 1] * (i + 1 < cnt ? vb.y : 0.f);
+                }
+                float* d = sEB + 1 + ERB_LOW + band;
+                d[0] = rq1<Q>(m0 + m1);
+                d[EB_ROW] = rq1<Q>(r0 + r1);
+                d[2 * EB_ROW] = rq1<Q>(i0 + i1);
+            }
+            wave_lds_sync();
+            // ---- B: SFE_Lite (same row code as k_encoder) ---------------------------------------------------------
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const float w0 = sP[E_SFE_W + c * 3], w1 = sP[E_SFE_W + c * 3 + 1], w2 = sP[E_SFE_W + c * 3 + 2];
+                const float* e = sEB + c * EB_ROW;
+                float* d = sF0 + c * F0_ROW + 2;
+                const int f = lane;
+                d[f] = rq1<Q>(w0 * e[f] + w1 * e[f + 1] + w2 * e[f + 2]);
+                d[f + 64] = rq1<Q>(w0 * e[f + 64] + w1 * e[f + 65] + w2 * e[f + 66]);
+                if (f == 0) d[128] = rq1<Q>(w0 * e[128] + w1 * e[129] + w2 * e[130]);
+                if (f < 7) d[(f < 2 ? f - 2 : 127 + f)] = 0.f;   // columns 0,1 and 131..135 of the row
+            }
+            // zero the pad positions of E0 (columns 0,1,67,68): the region held the FFT buffers / staged bins
+            if (lane < 16) st4(sE0 + pl(((lane >> 2) < 2 ? (lane >> 2) : 65 + (lane >> 2)), lane & 3), splat(0.f));
+            wave_lds_sync();
+            // ---- C: en_convs.0: 65 positions = 5 tiles (the last one holds a single valid position) ---------------
+            {
+                const f32x4 Am = ld4(sP + E_EN0_A + n * 16 + 4 * g), Bv = ld4(sP + E_EN0_B + 4 * g);
+                const float a = sP[E_EN0_S] - 1.0f;
+                int off[4];
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+                    const int e = 4 * g + s, c = e < 15 ? e / 5 : 0, k = e < 15 ? e % 5 : 0;
+                    off[s] = c * F0_ROW + k;
+                }
+                float* en0c = en0 + fr * (F1 * 16);
+#pragma unroll
+                for (int tile = 0; tile < 5; ++tile) {
+                    const int q = tile * 16 + n;
+                    const int fo = q < F1 ? q : F1 - 1;          // tail lanes of the last tile recompute bin 64 (not stored)
+                    f32x4 bv;
+#pragma unroll
+                    for (int s = 0; s < 4; ++s) bv[s] = sF0[off[s] + 2 * fo];
+                    f32x4 acc = mm1<Q>(Am, bv, Bv);
+                    acc = rq<Q>(prelu4(acc, a));
+                    if (q < F1) {
+                        st4(sE0 + pl(2 + fo, g), acc);
+                        st4(en0c + (unsigned)(q * 16 + 4 * g), acc);
+                    }
+                }
+            }
+            wave_lds_sync();
+            // ---- D: en_convs.1: 33 positions = 3 tiles; stored in both slot orders ---------------------------------
+            {
+                const f32x4 Bv = ld4(sP + E_EN1_B + 4 * g);
+                const float a = sP[E_EN1_S] - 1.0f;
+                const int* ix = sI + 128 + 4 * g;
+                float* en1pc = en1p + fr * 528;
+                float* en1nc = en1n + fr * 528;
+                f32x4 x[3];
+                int ffv[3];
+#pragma unroll
+                for (int i = 0; i < 3; ++i) {
+                    const int p = i * 16 + n;
+                    ffv[i] = p < 33 ? p : 32;
+                    x[i] = Bv;
+                }
+#pragma unroll
+                for (int k = 0; k < 5; ++k) {
+                    const f32x4 Am = ld4(sP + E_EN1_A + k * 256 + n * 16 + 4 * g);
+#pragma unroll
+                    for (int i = 0; i < 3; ++i) {
+                        const f32x4 tap = ld4(sE0 + pl(2 * ffv[i], g) + k * 16);
+                        x[i] = mm1<Q>(Am, tap, x[i]);
+                    }
+                }
+                wave_lds_sync();                                  // EB / F0 are dead: they become the permute scratch
+#pragma unroll
+                for (int i = 0; i < 3; ++i) {
+                    const int p = i * 16 + n;
+                    x[i] = rq<Q>(prelu4(x[i], a));
+                    const f32x4 y = permute_via_lds(sEB + p * 16, ix, g, x[i]);
+                    if (p < 33) {
+                        st4(en1nc + (unsigned)(p * 16 + 4 * g), x[i]);
+                        st4(en1pc + (unsigned)(p * 16 + 4 * g), y);
+                    }
+                }
+            }
+            wave_lds_sync();     // every region is rewritten by the next frame
+        }
+    }
 }
 
 // ================================================================================== GTCN
@@ -1915,15 +2209,24 @@ int launch_istft(const float* spec, long sb, long sf, long st, int B, int T, con
 
 int configure_kernels() {
     hipError_t e;
-    const void* enc[] = {reinterpret_cast<const void*>(k_encoder<TPW, false, false>),
-                         reinterpret_cast<const void*>(k_encoder<1, false, false>),
-                         reinterpret_cast<const void*>(k_encoder<2, false, false>),
-                         reinterpret_cast<const void*>(k_encoder<TPW, false, true>)};
+    const void* enc[] = {reinterpret_cast<const void*>(k_encoder<TPW, false, false, true>),
+                         reinterpret_cast<const void*>(k_encoder<1, false, false, true>),
+                         reinterpret_cast<const void*>(k_encoder<2, false, false, true>),
+                         reinterpret_cast<const void*>(k_encoder<TPW, false, false, false>),
+                         reinterpret_cast<const void*>(k_encoder<1, false, false, false>),
+                         reinterpret_cast<const void*>(k_encoder<2, false, false, false>),
+                         reinterpret_cast<const void*>(k_encoder<TPW, false, true, false>)};
+    const void* fr[] = {reinterpret_cast<const void*>(k_front<true, false>), reinterpret_cast<const void*>(k_front<false, false>),
+                        reinterpret_cast<const void*>(k_front<true, true>), reinterpret_cast<const void*>(k_front<false, true>)};
+    for (const void* f : fr) {
+        e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, FR_LDS_FLOATS * 4);
+        if (e != hipSuccess) return (int)e;
+    }
     for (const void* f : enc) {
         e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, ENC_LDS_FLOATS * 4);
         if (e != hipSuccess) return (int)e;
     }
-    e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_encoder<1, true, false>), hipFuncAttributeMaxDynamicSharedMemorySize,
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_encoder<1, true, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize,
                             ENC_MS_LDS_FLOATS * 4);
     if (e != hipSuccess) return (int)e;
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_decoder<false, 1, true, false>),
@@ -1961,27 +2264,51 @@ static bool use_multi_stream(int T, const float* state, long sb) {
     return state != nullptr && T == 1 && (MS_ROWS - 1) * (sb < 0 ? -sb : sb) < (1L << 31);
 }
 
+// The offline front end (see k_front): frames from a waveform (wave != nullptr: STFT fused, the spectrogram is also
+// written frame-major to `spec_out`) or from a caller spectrogram (spec_in, strides).  Persistent grid.
+int launch_front(const float* wave, long L, const float* spec_in, long isb, long isf, long ist, int B, int T,
+                 const int* lens, const float* win, const float* twid, const float* PF, const int* PI, float* spec_out,
+                 float* en0, float* en1p, float* en1n, hipStream_t s, const Quant* q) {
+    const long wgs = ((long)B * T + FR_WAVES - 1) / FR_WAVES;
+    const int grid = (int)(wgs < 256 * 2 ? wgs : 256 * 2);              // two workgroups per CU, persistent
+    const float qin = q ? q->in_step : 0.f;
+    const float2* tw = reinterpret_cast<const float2*>(twid);
+#define GT_FRONT(WV, QV, INP)                                                                                      \
+    hipLaunchKernelGGL((k_front<WV, QV>), dim3(grid), dim3(FR_NT), FR_LDS_FLOATS * 4, s, INP, L, isb, isf, ist, B, T, \
+                       lens, win, tw, PF, PI, spec_out, en0, en1p, en1n, qin)
+    if (wave) { if (q) GT_FRONT(true, true, wave); else GT_FRONT(true, false, wave); }
+    else { if (q) GT_FRONT(false, true, spec_in); else GT_FRONT(false, false, spec_in); }
+#undef GT_FRONT
+    GT_LAUNCH_CHECK();
+    return 0;
+}
+
+// x1 != nullptr: k_front has produced en0 / en1 already, only the three GTConv blocks run here (offline calls)
 int launch_encoder(const float* spec, long sb, long sf, long st, int B, int T, const int* lens, const float* PF,
                    const int* PI, float* en0, float* en1, float* en2, float* en3, float* en4, float* state,
-                   unsigned long long* stamps, hipStream_t s, const Quant* q) {
+                   unsigned long long* stamps, hipStream_t s, const Quant* q, const float* x1) {
+#define GT_ENC(TPWV, QV, FRV)                                                                                       \
+    hipLaunchKernelGGL((k_encoder<TPWV, false, QV, FRV>), dim3(B), dim3(NTHR), ENC_LDS_FLOATS * 4, s, spec, sb, sf, st, \
+                       T, lens, B, q ? q->in_step : 0.f, x1, PF, PI, en0, en1, en2, en3, en4, state, stamps)
     if (q) {   // int8-weight / fp16-activation variant: offline form only, the full-chunk instantiation
-        hipLaunchKernelGGL((k_encoder<TPW, false, true>), dim3(B), dim3(NTHR), ENC_LDS_FLOATS * 4, s, spec, sb, sf, st, T,
-                           lens, B, q->in_step, PF, PI, en0, en1, en2, en3, en4, (float*)nullptr, stamps);
+        if (!x1 || state) return (int)hipErrorInvalidValue;
+        GT_ENC(TPW, true, false);
     } else if (use_multi_stream(T, state, sb)) {
         // streams b*4 .. b*4+3 become rows 0..3 of workgroup b: sb' = 4 sb, st' = sb, T' = 4
         const int grid = (B + MS_STREAMS - 1) / MS_STREAMS;
-        hipLaunchKernelGGL((k_encoder<1, true, false>), dim3(grid), dim3(NTHR), ENC_MS_LDS_FLOATS * 4, s, spec,
-                           (long)MS_STREAMS * sb, sf, sb, MS_STREAMS, (const int*)nullptr, B, 0.f, PF, PI, en0, en1, en2,
-                           en3, en4, state, stamps);
-    } else if (T <= SHORT_T)
-        hipLaunchKernelGGL((k_encoder<1, false, false>), dim3(B), dim3(NTHR), ENC_LDS_FLOATS * 4, s, spec, sb, sf, st, T,
-                           lens, B, 0.f, PF, PI, en0, en1, en2, en3, en4, state, stamps);
-    else if (T <= SHORT_T2)
-        hipLaunchKernelGGL((k_encoder<2, false, false>), dim3(B), dim3(NTHR), ENC_LDS_FLOATS * 4, s, spec, sb, sf, st, T,
-                           lens, B, 0.f, PF, PI, en0, en1, en2, en3, en4, state, stamps);
-    else
-        hipLaunchKernelGGL((k_encoder<TPW, false, false>), dim3(B), dim3(NTHR), ENC_LDS_FLOATS * 4, s, spec, sb, sf, st, T,
-                           lens, B, 0.f, PF, PI, en0, en1, en2, en3, en4, state, stamps);
+        hipLaunchKernelGGL((k_encoder<1, true, false, true>), dim3(grid), dim3(NTHR), ENC_MS_LDS_FLOATS * 4, s, spec,
+                           (long)MS_STREAMS * sb, sf, sb, MS_STREAMS, (const int*)nullptr, B, 0.f, (const float*)nullptr,
+                           PF, PI, en0, en1, en2, en3, en4, state, stamps);
+    } else if (x1) {
+        if (T <= SHORT_T) GT_ENC(1, false, false);
+        else if (T <= SHORT_T2) GT_ENC(2, false, false);
+        else GT_ENC(TPW, false, false);
+    } else {
+        if (T <= SHORT_T) GT_ENC(1, false, true);
+        else if (T <= SHORT_T2) GT_ENC(2, false, true);
+        else GT_ENC(TPW, false, true);
+    }
+#undef GT_ENC
     GT_LAUNCH_CHECK();
     return 0;
 }
