@@ -54,8 +54,27 @@ __device__ __forceinline__ unsigned f2h(float x) {
 }
 __device__ __forceinline__ float dec16(unsigned h, int fmt) { return fmt == 1 ? bf2f(h) : h2f(h); }
 __device__ __forceinline__ unsigned enc16(float x, int fmt) { return fmt == 1 ? f2bf(x) : f2h(x); }
+// one element.  NOTE for callers with unrolled load loops (the weight-gradient kernels): make `fmt` a COMPILE-TIME
+// constant there (template parameter).  A run-time `if (fmt)` around each load splits the loop into one basic block
+// per load, so the 36 loads of an iteration are no longer issued together (measured 1.8x longer with bf16 storage
+// than with fp32); a branch-free select form costs the fp32 path 10 % instead.
 __device__ __forceinline__ float sld1(const float* base, long idx, int fmt) {
     return fmt ? dec16(reinterpret_cast<const unsigned short*>(base)[idx], fmt) : base[idx];
+}
+// Compile-time format, load and decode SEPARATED: sld1_raw returns the dword that holds the element (for a 16-bit
+// format the aligned word, shifted so that the element sits in the low half), sld1_dec turns it into the value.
+// Callers with predicated loads (`ok ? load : 0`) keep only the raw load under the predicate and decode after ALL
+// loads of the iteration have been issued: decoding inside the predicated block puts an s_waitcnt vmcnt(0) behind
+// every load (measured: the weight-gradient kernels 1.7x slower with bf16 storage than with fp32).
+template <int FMT>
+__device__ __forceinline__ unsigned sld1_raw(const float* base, long idx) {      // NOTHING here may use the loaded value
+    if constexpr (FMT == 0) return __float_as_uint(base[idx]);
+    else return reinterpret_cast<const unsigned*>(base)[idx >> 1];
+}
+template <int FMT>
+__device__ __forceinline__ float sld1_dec(unsigned w, unsigned odd) {             // odd = idx & 1 of the element
+    if constexpr (FMT == 0) return __uint_as_float(w);
+    else return dec16((odd ? w >> 16 : w) & 0xFFFFu, FMT);
 }
 __device__ __forceinline__ void sst1(float* base, long idx, int fmt, float v) {
     if (fmt) reinterpret_cast<unsigned short*>(base)[idx] = (unsigned short)enc16(v, fmt);
@@ -301,7 +320,7 @@ __global__ __launch_bounds__(NT) void k_conv_mfma(ConvGeom g, const float* __res
 }
 
 constexpr int WG_WAVES = 4;   // waves per workgroup of the MFMA weight-gradient kernel
-template <int NKT, int NKF>
+template <int NKT, int NKF, int FMT>   // FMT: storage format of `in`, compile time (see sld1)
 __global__ __launch_bounds__(WG_WAVES * 64) void k_conv_wgrad_mfma(ConvGeom g, const float* __restrict__ in,
                                                                   const float* __restrict__ dout,
                                                                   float* __restrict__ partial,
@@ -326,12 +345,15 @@ __global__ __launch_bounds__(WG_WAVES * 64) void k_conv_wgrad_mfma(ConvGeom g, c
         const bool co_ok = c < g.Cout, ci_ok = c < g.Cin;
         constexpr int U = 4;      // groups per iteration: all their loads are issued before the first MFMA
         for (; grp < gend; grp += U) {
-            float a[U], bb[U][NTAP];
+            float a[U];
+            unsigned bb[U][NTAP];        // raw words: decoded after all loads are in flight
+            unsigned odd[U];             // bit tap: the element is the high half of its word (16-bit formats)
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 const long p = (grp + u) * 4 + k;
                 const bool pv = p < npos && grp + u < gend;
                 a[u] = (pv && co_ok) ? dout[p * g.CoutT + g.cout_off + c] : 0.f;
+                odd[u] = 0;
 #pragma unroll
                 for (int kt = 0; kt < NKT; ++kt) {
                     const int ti = P.t + g.t_off[kt];
@@ -341,7 +363,9 @@ __global__ __launch_bounds__(WG_WAVES * 64) void k_conv_wgrad_mfma(ConvGeom g, c
                     for (int kf = 0; kf < NKF; ++kf) {
                         int fi;
                         const bool ok = tap_fi(g, P.f, kf, fi) && okt;
-                        bb[u][kt * NKF + kf] = ok ? sld1(in, (rowbase + fi) * g.CinT + g.cin_off + c, g.in_bf) : 0.f;
+                        const long ix = (rowbase + fi) * g.CinT + g.cin_off + c;
+                        odd[u] |= (unsigned)(ix & 1) << (kt * NKF + kf);
+                        bb[u][kt * NKF + kf] = ok ? sld1_raw<FMT>(in, ix) : 0u;
                     }
                 }
                 P.advance(4, g.Fout, g.Tout);
@@ -350,7 +374,7 @@ __global__ __launch_bounds__(WG_WAVES * 64) void k_conv_wgrad_mfma(ConvGeom g, c
             for (int u = 0; u < U; ++u) {
                 bsum += a[u];
 #pragma unroll
-                for (int tap = 0; tap < NTAP; ++tap) acc[tap] = mfma4(a[u], bb[u][tap], acc[tap]);
+                for (int tap = 0; tap < NTAP; ++tap) acc[tap] = mfma4(a[u], sld1_dec<FMT>(bb[u][tap], (odd[u] >> tap) & 1u), acc[tap]);
             }
         }
     }
@@ -845,12 +869,13 @@ struct BnBwdArgs {
     const float *stats, *gamma, *beta, *slope, *red;
     int act;
 };
+template <int FMT, int YF>   // storage formats of x / res and of y, compile time (see sld1)
 __global__ __launch_bounds__(NT) void k_unit1x1_bwd(ConvGeom g, const float* __restrict__ x, const float* __restrict__ y,
                                                    const float* __restrict__ da, const float* __restrict__ res,
                                                    BnBwdArgs bn, const float* __restrict__ w,
                                                    float* __restrict__ dx, int dx_acc, float* __restrict__ dres,
-                                                   int dres_acc, float* __restrict__ partial, long tiles_per_wave,
-                                                   int bf, int ybf) {
+                                                   int dres_acc, float* __restrict__ partial, long tiles_per_wave) {
+    constexpr int bf = FMT, ybf = YF;
     __shared__ __attribute__((aligned(16))) float sWt[256];        // data-gradient A matrix [ci][co] = W[co][ci]
     __shared__ __attribute__((aligned(16))) float sT[NT / 64][256];   // per wave: dy tile [pos][16]
     __shared__ float sAcc[NT / 64][256 + 64];
@@ -884,12 +909,13 @@ __global__ __launch_bounds__(NT) void k_unit1x1_bwd(ConvGeom g, const float* __r
         const long p = tile * 16 + n;
         const bool pv = p < npos;
         // weight-gradient operand x in (c, k) layout: 4 coalesced 256-byte wave loads, issued first
-        float xb[4];
+        unsigned xb[4];         // raw words: decoded where they are used (see sld1_raw)
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const long pu = tile * 16 + 4 * u + k;
-            xb[u] = (pu < npos && ci_ok) ? sld1(x, pu * g.CinT + g.cin_off + c, bf) : 0.f;
+            xb[u] = (pu < npos && ci_ok) ? sld1_raw<FMT>(x, pu * g.CinT + g.cin_off + c) : 0u;
         }
+        const unsigned xodd = (unsigned)((g.cin_off + c) & 1);    // CinT is a multiple of 4 here: the parity is the channel's
         f32x4 dy = {0.f, 0.f, 0.f, 0.f};
         if (pv && co_ok4) {
             const f32x4 yv = sld4(y, p * g.Cout + 4 * q, ybf);
@@ -931,7 +957,7 @@ __global__ __launch_bounds__(NT) void k_unit1x1_bwd(ConvGeom g, const float* __r
         for (int u = 0; u < 4; ++u) {
             const float a = sT[wv][(4 * u + k) * 16 + c];
             bsum += a;
-            accW = mfma4(a, xb[u], accW);
+            accW = mfma4(a, sld1_dec<FMT>(xb[u], xodd), accW);
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
@@ -1395,9 +1421,16 @@ int conv_wgrad(const ConvGeom& g, const float* in, const float* dout, float* dw,
         const long gpw = (ngroups + waves - 1) / waves;
         const int grid = (int)((ngroups + gpw * WG_WAVES - 1) / (gpw * WG_WAVES));
         const int K = g.nkt * g.nkf * 256 + 16;
-        if (g.nkt == 3) hipLaunchKernelGGL((k_conv_wgrad_mfma<3, 3>), dim3(grid), dim3(WG_WAVES * 64), 0, s, g, in, dout, scratch, gpw);
-        else if (g.nkf == 5) hipLaunchKernelGGL((k_conv_wgrad_mfma<1, 5>), dim3(grid), dim3(WG_WAVES * 64), 0, s, g, in, dout, scratch, gpw);
-        else hipLaunchKernelGGL((k_conv_wgrad_mfma<1, 1>), dim3(grid), dim3(WG_WAVES * 64), 0, s, g, in, dout, scratch, gpw);
+#define GT_WG(KT, KF)                                                                                                  \
+    do {                                                                                                               \
+        if (g.in_bf == 0) hipLaunchKernelGGL((k_conv_wgrad_mfma<KT, KF, 0>), dim3(grid), dim3(WG_WAVES * 64), 0, s, g, in, dout, scratch, gpw); \
+        else if (g.in_bf == 1) hipLaunchKernelGGL((k_conv_wgrad_mfma<KT, KF, 1>), dim3(grid), dim3(WG_WAVES * 64), 0, s, g, in, dout, scratch, gpw); \
+        else hipLaunchKernelGGL((k_conv_wgrad_mfma<KT, KF, 2>), dim3(grid), dim3(WG_WAVES * 64), 0, s, g, in, dout, scratch, gpw); \
+    } while (0)
+        if (g.nkt == 3) GT_WG(3, 3);
+        else if (g.nkf == 5) GT_WG(1, 5);
+        else GT_WG(1, 1);
+#undef GT_WG
         hipLaunchKernelGGL(k_wgrad_mfma_finish, dim3((K + 63) / 64), dim3(1024), 0, s, g, scratch, grid, dw, dbias);
         return check();
     }
@@ -1527,8 +1560,14 @@ int unit1x1_bwd(const ConvGeom& g, const float* x, const float* y, const float* 
     const long tpw = (ntiles + waves - 1) / waves;
     const int grid = (int)((ntiles + tpw * (NT / 64) - 1) / (tpw * (NT / 64)));
     BnBwdArgs bn{stats, gamma, beta, slope, red, act};
-    hipLaunchKernelGGL(k_unit1x1_bwd, dim3(grid), dim3(NT), 0, s, g, x, y, da, res, bn, w, dx, dx_acc, dres, dres_acc,
-                       fscratch, tpw, bf, ybf);
+#define GT_U1(F, Y) hipLaunchKernelGGL((k_unit1x1_bwd<F, Y>), dim3(grid), dim3(NT), 0, s, g, x, y, da, res, bn, w, dx, dx_acc, \
+                                      dres, dres_acc, fscratch, tpw)
+    if (bf == 0 && ybf == 0) GT_U1(0, 0);
+    else if (bf == 1 && ybf == 1) GT_U1(1, 1);
+    else if (bf == 1 && ybf == 0) GT_U1(1, 0);
+    else if (bf == 1 && ybf == 2) GT_U1(1, 2);
+    else return (int)hipErrorInvalidValue;
+#undef GT_U1
     hipLaunchKernelGGL(k_wgrad_mfma_finish, dim3((256 + 16 + 63) / 64), dim3(1024), 0, s, g, fscratch, grid, dw, dbias);
     return check();
 }

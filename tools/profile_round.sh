@@ -1,18 +1,36 @@
 #!/bin/bash
 # Profiles the bench workload on the GPU box; writes raw output under gpurun_out/<tag>/.
-#   tools/profile_round.sh r01
-# Three separate rocprofv3 runs (kernel trace + stats; PMC FETCH_SIZE; PMC WRITE_SIZE), as
-# MI355X_MICROARCH.md prescribes (the TCC counters do not fit in one pass), then
+#   tools/profile_round.sh r02
+# Separate rocprofv3 runs, the program directly after `--` (MI355X_MICROARCH.md: the TCC counters do not fit in one
+# pass; PMC never together with the trace domains other than --kernel-trace):
+#   trace      kernel trace + stats of the headline path
+#   pmc_fetch / pmc_write      HBM traffic
+#   pmc_sq     wave cycles, waits, instruction counts, LDS bank conflicts
+#   pmc_sq2    matrix-pipe busy cycles, VALU/MFMA co-execution cycles, busy CU cycles, VALU / LDS active cycles,
+#              GRBM_GUI_ACTIVE (effective clock = GRBM_GUI_ACTIVE / 8 / kernel time)
+#   ub_*       tools/ubench_mfma_valu.hip (does fp32 MFMA overlap with fp32 VALU?) under the same counters
+#   stream / train             kernel trace + stats of the configs[2] / configs[3] legs
 # tools/profile_summary.py condenses them into the files committed under profiles/.
 set -u
-TAG=${1:-r01}
+TAG=${1:-r02}
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$R/gpurun_out/$TAG
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- python3 "$R/bench.py" --steps 20 --warmup 5 --no-cpu-baseline > "$OUT/trace.log" 2>&1
-rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_fetch" -- python3 "$R/bench.py" --steps 4 --warmup 2 --no-cpu-baseline > "$OUT/pmc_fetch.log" 2>&1
-rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_write" -- python3 "$R/bench.py" --steps 4 --warmup 2 --no-cpu-baseline > "$OUT/pmc_write.log" 2>&1
-rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_MFMA SQ_LDS_BANK_CONFLICT --output-format csv -d "$OUT/pmc_sq" -- python3 "$R/bench.py" --steps 4 --warmup 2 --no-cpu-baseline > "$OUT/pmc_sq.log" 2>&1
-grep -h '"metric"' "$OUT"/*.log | head -4
-find "$OUT" -name "*.csv" | head -20
+B="$R/bench.py --no-cpu-baseline --no-secondary"
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- python3 $B --steps 20 --warmup 5 > "$OUT/trace.log" 2>&1
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_fetch" -- python3 $B --steps 4 --warmup 2 > "$OUT/pmc_fetch.log" 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_write" -- python3 $B --steps 4 --warmup 2 > "$OUT/pmc_write.log" 2>&1
+rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_MFMA SQ_LDS_BANK_CONFLICT --output-format csv -d "$OUT/pmc_sq" -- python3 $B --steps 4 --warmup 2 > "$OUT/pmc_sq.log" 2>&1
+rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_VALU_MFMA_COEXEC_CYCLES SQ_BUSY_CU_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_INSTS_VALU_MFMA_MOPS_F32 GRBM_GUI_ACTIVE --output-format csv -d "$OUT/pmc_sq2" -- python3 $B --steps 4 --warmup 2 > "$OUT/pmc_sq2.log" 2>&1
+# the issue microbenchmark under the same counters
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 "$R/tools/ubench_mfma_valu.hip" -o /tmp/ub_mfma_valu > "$OUT/ub_build.log" 2>&1
+/tmp/ub_mfma_valu > "$OUT/ub_plain.log" 2>&1
+rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_VALU_MFMA_COEXEC_CYCLES SQ_BUSY_CU_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_WAVE_CYCLES GRBM_GUI_ACTIVE --output-format csv -d "$OUT/ub_pmc" -- /tmp/ub_mfma_valu > "$OUT/ub_pmc.log" 2>&1
+# configs[2] (1024 streams, single-frame calls) and configs[3] (train step, fp32 and bf16 storage)
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stream" -- python3 "$R/tools/stream_bench.py" > "$OUT/stream.log" 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/train_f32" -- python3 "$R/bench.py" --mode train --steps 3 --warmup 1 > "$OUT/train_f32.log" 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/train_bf16" -- python3 "$R/bench.py" --mode train --train-storage bf16 --steps 3 --warmup 1 > "$OUT/train_bf16.log" 2>&1
+grep -h '"metric"' "$OUT"/*.log | cut -c1-300
+cat "$OUT/ub_plain.log"
+find "$OUT" -name "*.csv" | wc -l

@@ -17,7 +17,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def short(name):
-    for k in ("k_stft", "k_istft", "k_encoder", "k_gtcn", "k_decoder", "k_state_convert"):
+    for k in ("k_front", "k_stft", "k_istft", "k_encoder", "k_gtcn_ms", "k_gtcn", "k_decoder", "k_state_convert"):
         if k in name:
             return k
     return None
@@ -53,11 +53,13 @@ def main():
                     acc[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
         return acc
     fetch, write, sq = pmc("pmc_fetch"), pmc("pmc_write"), pmc("pmc_sq")
+    for k, v in pmc("pmc_sq2").items():                 # second SQ pass: same kernels, other counters
+        sq[k].update(v)
     # MI355X_MICROARCH.md (HBM): on gfx950 FETCH_SIZE reports exactly half the bytes of a wide
     # coalesced read (16 B per lane) -> doubled for the kernels whose reads are 16 B per lane
     # (k_decoder, k_gtcn); other access widths are "uncalibrated" there, so for the kernels that
     # read 4/8 B per lane the raw value is kept and the known byte count is quoted beside it.
-    WIDE = {"k_decoder", "k_gtcn"}
+    WIDE = {"k_decoder", "k_gtcn", "k_encoder"}
     traffic = {}
     for k in sorted(set(fetch) | set(write)):
         fs = fetch.get(k, {}).get("FETCH_SIZE", [])
@@ -87,6 +89,66 @@ def main():
             for k in sorted(sq):
                 w.writerow([k] + [f"{sum(sq[k][c]) / len(sq[k][c]):.0f}" if sq[k].get(c) else "" for c in names])
         print(open(os.path.join(dst, f"{tag}_sq_counters.csv")).read())
+    # --- derived figures per kernel: executed matrix FLOP, pipe busy share, co-execution share, effective clock
+    f = newest("trace", "*kernel_stats.csv")
+    avg_ns = {short(r["Name"]): float(r["AverageNs"]) for r in csv.DictReader(open(f[0])) if short(r["Name"])} if f else {}
+    derived = {}
+    for k in sorted(sq):
+        c = {n: (sum(v) / len(v) if v else None) for n, v in sq[k].items()}
+        d = {}
+        if c.get("SQ_INSTS_MFMA") and avg_ns.get(k):
+            d["mfma_flop_executed_per_launch"] = c["SQ_INSTS_MFMA"] * 2048.0
+            d["mfma_tflops_executed"] = d["mfma_flop_executed_per_launch"] / (avg_ns[k] * 1e-9) / 1e12
+        if c.get("SQ_INSTS_VALU") and c.get("SQ_INSTS_MFMA"):
+            d["valu_per_mfma"] = c["SQ_INSTS_VALU"] / c["SQ_INSTS_MFMA"]
+        if c.get("SQ_VALU_MFMA_BUSY_CYCLES") and c.get("SQ_BUSY_CU_CYCLES"):
+            # BUSY_CU_CYCLES counts per CU, MFMA_BUSY per SIMD-quad group: report the raw ratio and both terms
+            d["mfma_busy_cycles"] = c["SQ_VALU_MFMA_BUSY_CYCLES"]
+            d["busy_cu_cycles"] = c["SQ_BUSY_CU_CYCLES"]
+            d["mfma_busy_over_busy_cu"] = c["SQ_VALU_MFMA_BUSY_CYCLES"] / c["SQ_BUSY_CU_CYCLES"]
+        if c.get("SQ_VALU_MFMA_COEXEC_CYCLES") is not None and c.get("SQ_VALU_MFMA_BUSY_CYCLES"):
+            d["coexec_over_mfma_busy"] = c["SQ_VALU_MFMA_COEXEC_CYCLES"] / c["SQ_VALU_MFMA_BUSY_CYCLES"]
+        if c.get("GRBM_GUI_ACTIVE") and avg_ns.get(k):
+            d["effective_clock_GHz"] = c["GRBM_GUI_ACTIVE"] / 8.0 / avg_ns[k]
+            d["effective_clock_note"] = "GRBM_GUI_ACTIVE / 8 XCDs / kernel time; reads high below ~0.3 ms (MI355X_MICROARCH.md)"
+        if c.get("SQ_WAIT_ANY") and c.get("SQ_WAVE_CYCLES"):
+            d["wait_any_over_wave_cycles"] = c["SQ_WAIT_ANY"] / c["SQ_WAVE_CYCLES"]
+        if d:
+            d["avg_launch_us"] = avg_ns.get(k, 0) / 1e3
+            derived[k] = d
+    if derived:
+        json.dump(derived, open(os.path.join(dst, f"{tag}_derived.json"), "w"), indent=1)
+        print(json.dumps(derived, indent=1))
+    # --- the issue microbenchmark under PMC (tools/ubench_mfma_valu.hip): one row per launch, in launch order
+    ub = newest("ub_pmc", "*counter_collection.csv")
+    if ub:
+        rows = defaultdict(dict)
+        for r in csv.DictReader(open(ub[0])):
+            rows[(int(r["Dispatch_Id"]), r["Kernel_Name"][:48])][r["Counter_Name"]] = float(r["Counter_Value"])
+        with open(os.path.join(dst, f"{tag}_ubench_mfma_valu_pmc.csv"), "w", newline="") as o:
+            names = sorted({c for v in rows.values() for c in v})
+            w = csv.writer(o)
+            w.writerow(["Dispatch", "Kernel"] + names)
+            for (d, kn), v in sorted(rows.items()):
+                w.writerow([d, kn] + [f"{v.get(c, 0):.0f}" for c in names])
+        plain = os.path.join(src, "ub_plain.log")
+        if os.path.exists(plain):
+            open(os.path.join(dst, f"{tag}_ubench_mfma_valu.txt"), "w").write(open(plain).read())
+    # --- streaming / training traces
+    for sub, pats in (("stream", ("k_encoder", "k_gtcn_ms", "k_decoder")), ("train_f32", None), ("train_bf16", None)):
+        f = newest(sub, "*kernel_stats.csv")
+        if not f:
+            continue
+        rows = list(csv.DictReader(open(f[0])))
+        with open(os.path.join(dst, f"{tag}_{sub}_kernel_stats.csv"), "w", newline="") as o:
+            w = csv.writer(o)
+            w.writerow(["Kernel", "Calls", "TotalDurationNs", "AverageNs", "Percentage"])
+            for r in rows[:40]:
+                import re
+                mm = re.search(r"(k_\w+(?:<[^>(]*>)?)", r["Name"])
+                nm = mm.group(1) if mm else r["Name"][:60]
+                if pats is None or any(p_ in nm for p_ in pats):
+                    w.writerow([nm, r["Calls"], r["TotalDurationNs"], r["AverageNs"], r["Percentage"]])
 
 
 if __name__ == "__main__":
