@@ -212,3 +212,38 @@ def test_extreme_inputs_stay_finite_and_match_oracle(dev, engines, oracles):
         want = oracles["dns3"].forward(spec)
         assert np.isfinite(got).all()
         assert np.abs(got - want).max() <= TOL * max(np.abs(want).max(), 1e-30) + 1e-30
+
+
+@pytest.mark.parametrize("tag", ["dns3", "rand"])
+def test_parity_per_band_and_elementwise(engines, oracles, tag):
+    """The headline tolerance is a max-norm ratio (max|a-b| / max|b| <= 1e-4), which cannot see a large relative error
+    in a quiet band.  Here the same forward is judged band by band and element by element on a speech-like input whose
+    spectrum falls 40 dB from the low to the high bins (plus a louder, flat noise floor in a second clip):
+      * relative L2 error per band of 16 bins, per frame block:  <= 1e-4 in every band;
+      * element-wise: |a-b| <= 1e-4 |b| + 1e-5 * (rms of b's own bin) for >= 99.5 % of the elements (measured 99.77 % / 99.99 %; the absolute
+        term covers outputs that are small by cancellation in the complex mask product re*mr - im*mi: both sides
+        are fp32 with different summation orders; with a 1e-6 floor 98.9 % / 99.97 % of the elements pass)."""
+    rng = np.random.default_rng(77)
+    T = 40
+    tilt = 10.0 ** (-2.0 * np.arange(257) / 256.0)            # -40 dB across the band
+    spec = np.stack([rng.standard_normal((257, T, 2)) * tilt[:, None, None] * 3.0,
+                     rng.standard_normal((257, T, 2)) * tilt[:, None, None] * 0.02 + rng.standard_normal((257, T, 2)) * 0.002])
+    spec = spec.astype(np.float32)
+    got = engines[tag].forward_spec(cu(spec)).cpu().numpy().astype(np.float64)
+    ref = oracles[tag].forward(spec).astype(np.float64)
+    worst_band = 0.0
+    for b in range(2):
+        for lo in range(0, 257, 16):
+            hi = min(lo + 16, 257)
+            for t0 in range(0, T, 10):
+                a, r = got[b, lo:hi, t0:t0 + 10], ref[b, lo:hi, t0:t0 + 10]
+                worst_band = max(worst_band, float(np.linalg.norm(a - r) / max(np.linalg.norm(r), 1e-30)))
+    bin_rms = np.sqrt((ref ** 2).mean(axis=(2, 3), keepdims=True))
+    ok = np.abs(got - ref) <= 1e-4 * np.abs(ref) + 1e-5 * bin_rms
+    frac = float(ok.mean())
+    frac6 = float((np.abs(got - ref) <= 1e-4 * np.abs(ref) + 1e-6 * bin_rms).mean())
+    print(f"per-band worst relative L2 [{tag}]: {worst_band:.2e}; elements within 1e-4 relative (+1e-5 / +1e-6 of the "
+          f"bin rms): {100 * frac:.3f} % / {100 * frac6:.3f} %")
+    assert worst_band < TOL, worst_band
+    assert frac >= 0.995, frac
+    assert rel_err(got, ref) < TOL
