@@ -141,6 +141,27 @@ __device__ __forceinline__ void mm16(const f32x4 A, const f32x4 (&x)[N], f32x4 (
     }
 }
 
+// Hand-off tensors (en0..en4, gtcn1, gtcn2+en4) in HBM: fp32 records, or -- in the Q variant, whose activations are
+// fp16 numbers anyway -- fp16 records of half the size in the same buffers (element offsets are unchanged: the
+// kernels index through a pointer of the element type).
+template <bool Q> struct HandOff { using t = float; };
+template <> struct HandOff<true> { using t = _Float16; };
+template <bool Q>
+__device__ __forceinline__ f32x4 ldx(const typename HandOff<Q>::t* p) {
+    if constexpr (Q) {
+        const h16x4 h = *reinterpret_cast<const h16x4*>(p);
+        f32x4 r = {(float)h[0], (float)h[1], (float)h[2], (float)h[3]};
+        return r;
+    } else {
+        return ld4(p);
+    }
+}
+template <bool Q>
+__device__ __forceinline__ void stx(typename HandOff<Q>::t* p, const f32x4 v) {
+    if constexpr (Q) *reinterpret_cast<h16x4*>(p) = to_h4(v);
+    else st4(p, v);
+}
+
 // Diagnostic build only (-DGT_STAMPS, libgtcrn_micro_hip_stamps.so): s_memtime stamps at the
 // barrier-delimited phases, summed per workgroup and written to a buffer nothing else reads.
 // In the product build these macros expand to nothing.
@@ -815,7 +836,13 @@ __global__ __launch_bounds__(NTHR) void k_encoder(const float* __restrict__ spec
     spec += (long)b * sb;
     const long ob = (long)b * T;
     // global addressing: wave-uniform base pointers (SGPR pairs) + 32-bit per-lane offsets
-    en0 += ob * (F1 * 16); en1 += ob * 528; en2 += ob * 528; en3 += ob * 528; en4 += ob * 528;
+    using ht = typename HandOff<Q>::t;
+    ht* en0h = reinterpret_cast<ht*>(en0) + ob * (F1 * 16);
+    ht* en1h = reinterpret_cast<ht*>(en1) + ob * 528;
+    ht* en2h = reinterpret_cast<ht*>(en2) + ob * 528;
+    ht* en3h = reinterpret_cast<ht*>(en3) + ob * 528;
+    ht* en4h = reinterpret_cast<ht*>(en4) + ob * 528;
+    const ht* x1h = reinterpret_cast<const ht*>(x1);
     const bool t_fast = st < sf;  // reference layout (B,257,T,2): consecutive frames are adjacent
     if (lens) T = min(T, 1 + (lens[b] >> 8));   // from here on T = this utterance's frames
     if constexpr (MS) T = nlive;                // one frame per live stream = nlive rows
@@ -846,10 +873,10 @@ __global__ __launch_bounds__(NTHR) void k_encoder(const float* __restrict__ spec
     // FRONT = false: the block input of the chunk, fetched one chunk ahead (clamped: no select behind the loads)
     f32x4 xn[TPW];
     if constexpr (!FRONT) {
-        x1 += ob * 528;
+        x1h += ob * 528;
         const int np0 = min(RW, T) * 33;
 #pragma unroll
-        for (int i = 0; i < TPW; ++i) xn[i] = ld4(x1 + (unsigned)((tt.pp(i) < np0 ? tt.pp(i) : 0) * 16 + 4 * g));
+        for (int i = 0; i < TPW; ++i) xn[i] = ldx<Q>(x1h + (unsigned)((tt.pp(i) < np0 ? tt.pp(i) : 0) * 16 + 4 * g));
     }
 
     for (int t0 = 0; t0 < T; t0 += RW) {
@@ -860,9 +887,9 @@ __global__ __launch_bounds__(NTHR) void k_encoder(const float* __restrict__ spec
             for (int i = 0; i < TPW; ++i) x[i] = xn[i];
             if (t0 + RW < T) {
                 const int npn = min(RW, T - t0 - RW) * 33;
-                const float* xc = x1 + (long)(t0 + RW) * 528;
+                const ht* xc = x1h + (long)(t0 + RW) * 528;
 #pragma unroll
-                for (int i = 0; i < TPW; ++i) xn[i] = ld4(xc + (unsigned)((tt.pp(i) < npn ? tt.pp(i) : 0) * 16 + 4 * g));
+                for (int i = 0; i < TPW; ++i) xn[i] = ldx<Q>(xc + (unsigned)((tt.pp(i) < npn ? tt.pp(i) : 0) * 16 + 4 * g));
             }
         }
         if constexpr (FRONT) {
@@ -990,7 +1017,7 @@ __global__ __launch_bounds__(NTHR) void k_encoder(const float* __restrict__ spec
                 f32x4 acc = mm1<Q>(A, bv, Bv);
                 acc = rq<Q>(prelu4(acc, a));
                 st4(sE0 + pl(tl * ENC_E0_ROW + 2 + fo, g), acc);
-                if (q < nfr * F1) st4(en0 + (long)t0 * (F1 * 16) + (unsigned)(q * 16 + 4 * g), acc);
+                if (q < nfr * F1) stx<Q>(en0h + (long)t0 * (F1 * 16) + (unsigned)(q * 16 + 4 * g), acc);
             }
         }
         wg_barrier();
@@ -1017,7 +1044,7 @@ __global__ __launch_bounds__(NTHR) void k_encoder(const float* __restrict__ spec
                 x[i] = rq<Q>(prelu4(x[i], a));
                 {   // en1 in the slot order of its decoder consumer; scratch: this tile's records of F0/EB (dead)
                     const f32x4 y = permute_via_lds(sEB + tt.pp(i) * 16, ix, g, x[i]);
-                    if (tt.pp(i) < nfr * 33) st4(en1 + (long)t0 * 528 + (unsigned)(tt.pp(i) * 16 + 4 * g), y);
+                    if (tt.pp(i) < nfr * 33) stx<Q>(en1h + (long)t0 * 528 + (unsigned)(tt.pp(i) * 16 + 4 * g), y);
                 }
             }
         }
@@ -1046,17 +1073,17 @@ __global__ __launch_bounds__(NTHR) void k_encoder(const float* __restrict__ spec
             }
             gtconv_block<false, TPW, MS, Q>(x, tt, c, L, [] {} STAMP_ARG);
             if (k < 2) {
-                float* dst = k == 0 ? en2 : en3;
+                ht* dst = k == 0 ? en2h : en3h;
                 const int* ix = sI + I_ENST + (k + 1) * 16 + 4 * g;
 #pragma unroll
                 for (int i = 0; i < TPW; ++i) {   // scratch: the tile's own v^2 records (dead after the gate barrier)
                     const f32x4 y = permute_via_lds(sS + tt.pp(i) * 16, ix, g, x[i]);
-                    if (tt.pp(i) < nfr * 33) st4(dst + (long)t0 * 528 + (unsigned)(tt.pp(i) * 16 + 4 * g), y);
+                    if (tt.pp(i) < nfr * 33) stx<Q>(dst + (long)t0 * 528 + (unsigned)(tt.pp(i) * 16 + 4 * g), y);
                 }
             } else {
 #pragma unroll
                 for (int i = 0; i < TPW; ++i)
-                    if (tt.pp(i) < nfr * 33) st4(en4 + (long)t0 * 528 + (unsigned)(tt.pp(i) * 16 + 4 * g), x[i]);
+                    if (tt.pp(i) < nfr * 33) stx<Q>(en4h + (long)t0 * 528 + (unsigned)(tt.pp(i) * 16 + 4 * g), x[i]);
             }
             STAMP(SS, 8)
         }
@@ -1290,7 +1317,8 @@ __global__ __launch_bounds__(FR_NT, 4) void k_front(const float* __restrict__ in
                     const int e = 4 * g + s, c = e < 15 ? e / 5 : 0, k = e < 15 ? e % 5 : 0;
                     off[s] = c * F0_ROW + k;
                 }
-                float* en0c = en0 + fr * (F1 * 16);
+                using ht = typename HandOff<Q>::t;
+                ht* en0c = reinterpret_cast<ht*>(en0) + fr * (F1 * 16);
 #pragma unroll
                 for (int tile = 0; tile < 5; ++tile) {
                     const int q = tile * 16 + n;
@@ -1302,7 +1330,7 @@ __global__ __launch_bounds__(FR_NT, 4) void k_front(const float* __restrict__ in
                     acc = rq<Q>(prelu4(acc, a));
                     if (q < F1) {
                         st4(sE0 + pl(2 + fo, g), acc);
-                        st4(en0c + (unsigned)(q * 16 + 4 * g), acc);
+                        stx<Q>(en0c + (unsigned)(q * 16 + 4 * g), acc);
                     }
                 }
             }
@@ -1312,8 +1340,9 @@ __global__ __launch_bounds__(FR_NT, 4) void k_front(const float* __restrict__ in
                 const f32x4 Bv = ld4(sP + E_EN1_B + 4 * g);
                 const float a = sP[E_EN1_S] - 1.0f;
                 const int* ix = sI + 128 + 4 * g;
-                float* en1pc = en1p + fr * 528;
-                float* en1nc = en1n + fr * 528;
+                using ht = typename HandOff<Q>::t;
+                ht* en1pc = reinterpret_cast<ht*>(en1p) + fr * 528;
+                ht* en1nc = reinterpret_cast<ht*>(en1n) + fr * 528;
                 f32x4 x[3];
                 int ffv[3];
 #pragma unroll
@@ -1338,8 +1367,8 @@ __global__ __launch_bounds__(FR_NT, 4) void k_front(const float* __restrict__ in
                     x[i] = rq<Q>(prelu4(x[i], a));
                     const f32x4 y = permute_via_lds(sEB + p * 16, ix, g, x[i]);
                     if (p < 33) {
-                        st4(en1nc + (unsigned)(p * 16 + 4 * g), x[i]);
-                        st4(en1pc + (unsigned)(p * 16 + 4 * g), y);
+                        stx<Q>(en1nc + (unsigned)(p * 16 + 4 * g), x[i]);
+                        stx<Q>(en1pc + (unsigned)(p * 16 + 4 * g), y);
                     }
                 }
             }
@@ -1651,9 +1680,10 @@ __global__ __launch_bounds__(NTHR) void k_gtcn_band(const float* __restrict__ xi
     for (int i = tid; i < GTCN_SIZE; i += NTHR) sP[i] = P[i];
     for (int i = tid; i < 33 * 30 * 4; i += NTHR) st4(sHh + i * 4, splat(0.f));   // zero history (frames < 0)
     __syncthreads();
-    xin += (long)b * T * 528;
-    xout += (long)b * T * 528;
-    if (addend) addend += (long)b * T * 528;
+    using ht = typename HandOff<Q>::t;
+    const ht* xinh = reinterpret_cast<const ht*>(xin) + (long)b * T * 528;
+    ht* xouth = reinterpret_cast<ht*>(xout) + (long)b * T * 528;
+    const ht* addh = addend ? reinterpret_cast<const ht*>(addend) + (long)b * T * 528 : nullptr;
     if (lens) T = min(T, 1 + (lens[b] >> 8));            // variable-length batch: this utterance's frames
     const int f0 = L.wave * TPW;                         // first bin of this wave
     float* cw = sC + f0 * 256;
@@ -1664,7 +1694,7 @@ __global__ __launch_bounds__(NTHR) void k_gtcn_band(const float* __restrict__ xi
     auto fetch = [&](int t0f) {
         const int tcf = t0f + n < T ? t0f + n : T - 1;   // clamped frame: no select behind the loads
 #pragma unroll
-        for (int i = 0; i < TPW; ++i) xn[i] = ld4(xin + (unsigned)((tcf * 33 + f0 + i) * 16 + 4 * g));
+        for (int i = 0; i < TPW; ++i) xn[i] = ldx<Q>(xinh + (unsigned)((tcf * 33 + f0 + i) * 16 + 4 * g));
     };
     fetch(0);
     for (int t0 = 0; t0 < T; t0 += TC) {
@@ -1674,7 +1704,7 @@ __global__ __launch_bounds__(NTHR) void k_gtcn_band(const float* __restrict__ xi
 #pragma unroll
         for (int i = 0; i < TPW; ++i) {
             x[i] = xn[i];
-            if (addend) ad[i] = ld4(addend + (unsigned)((tc * 33 + f0 + i) * 16 + 4 * g));
+            if (addend) ad[i] = ldx<Q>(addh + (unsigned)((tc * 33 + f0 + i) * 16 + 4 * g));
         }
         if (t0 + TC < T) fetch(t0 + TC);
         // opaque offset: the block parameters are re-read from LDS every chunk; hoisting the four
@@ -1688,7 +1718,7 @@ __global__ __launch_bounds__(NTHR) void k_gtcn_band(const float* __restrict__ xi
         tcn_block_band<8, Q>(x, sP + po + 3 * TCN_SIZE, cw, sHh + 33 * 14 * 16 + f0 * 16 * 16, live, L);
 #pragma unroll
         for (int i = 0; i < TPW; ++i)
-            if (live) st4(xout + (unsigned)((tc * 33 + f0 + i) * 16 + 4 * g), addend ? rq<Q>(x[i] + ad[i]) : x[i]);
+            if (live) stx<Q>(xouth + (unsigned)((tc * 33 + f0 + i) * 16 + 4 * g), addend ? rq<Q>(x[i] + ad[i]) : x[i]);
     }
 }
 
@@ -1800,14 +1830,19 @@ __global__ __launch_bounds__(NTHR) void k_decoder(const float* __restrict__ xg, 
     // utterance read a clamped, valid record (never stored), so no load sits behind a select and
     // every load's latency runs until its first use.
     // global addressing: wave-uniform chunk base pointers (SGPR pairs) + 32-bit per-lane offsets
-    xg += ob * 528; en0 += ob * (F1 * 16); en1 += ob * 528; en2 += ob * 528; en3 += ob * 528;
+    using ht = typename HandOff<Q>::t;
+    const ht* xgh = reinterpret_cast<const ht*>(xg) + ob * 528;
+    const ht* en0h = reinterpret_cast<const ht*>(en0) + ob * (F1 * 16);
+    const ht* en1h = reinterpret_cast<const ht*>(en1) + ob * 528;
+    const ht* en2h = reinterpret_cast<const ht*>(en2) + ob * 528;
+    const ht* en3h = reinterpret_cast<const ht*>(en3) + ob * 528;
     if (lens) T = min(T, 1 + (lens[b] >> 8));   // variable-length batch: from here on T = this utterance's frames
     if constexpr (MS) T = nlive;                // one frame per live stream = nlive rows
     f32x4 xn[TPW];
     {
         const int np0 = min(RW, T) * 33;
 #pragma unroll
-        for (int i = 0; i < TPW; ++i) xn[i] = ld4(xg + (unsigned)((tt.pp(i) < np0 ? tt.pp(i) : 0) * 16 + 4 * g));
+        for (int i = 0; i < TPW; ++i) xn[i] = ldx<Q>(xgh + (unsigned)((tt.pp(i) < np0 ? tt.pp(i) : 0) * 16 + 4 * g));
     }
     (void)en4;
     for (int t0 = 0; t0 < T; t0 += RW) {
@@ -1827,12 +1862,12 @@ __global__ __launch_bounds__(NTHR) void k_decoder(const float* __restrict__ xg, 
         auto run_block = [&](int j, auto&& hook) {
             // the skip added to this block's output (en3, en2, en1; already in this stage's slot
             // order) is fetched up front so that its latency hides behind the block
-            const float* sk = j == 0 ? en3 : (j == 1 ? en2 : en1);
+            const ht* sk = j == 0 ? en3h : (j == 1 ? en2h : en1h);
             f32x4 skv[TPW];
             sk += (long)t0 * 528;
 #pragma unroll
             for (int i = 0; i < TPW; ++i)
-                skv[i] = ld4(sk + (unsigned)((tt.pp(i) < npos ? tt.pp(i) : 0) * 16 + 4 * g));
+                skv[i] = ldx<Q>(sk + (unsigned)((tt.pp(i) < npos ? tt.pp(i) : 0) * 16 + 4 * g));
             BlockCtx c;
             c.pb = sP + D_BLK + j * GBD_SIZE;
             c.gA = c.pb + GB_DN_A;
@@ -1861,13 +1896,13 @@ __global__ __launch_bounds__(NTHR) void k_decoder(const float* __restrict__ xg, 
 #pragma unroll 1
         for (int j = 0; j < 2; ++j) run_block(j, [] {});
         run_block(2, [&] {
-            const float* en0c = en0 + (long)t0 * (F1 * 16);
+            const ht* en0c = en0h + (long)t0 * (F1 * 16);
 #pragma unroll
             for (int i = 0; i < TPW; ++i) {
                 // record of output bin 2f (even) and 2f+1 (odd; for f = 32 the clamped record is unused)
                 const unsigned o0 = (unsigned)((tt.pp(i) < npos ? tt.tl[i] * F1 + 2 * tt.ff[i] : 0) * 16 + 4 * g);
-                s0e[i] = ld4(en0c + o0);
-                s0o[i] = ld4(en0c + o0 + (tt.ff[i] < 32 ? 16u : 0u));
+                s0e[i] = ldx<Q>(en0c + o0);
+                s0o[i] = ldx<Q>(en0c + o0 + (tt.ff[i] < 32 ? 16u : 0u));
             }
         });
         // ---- de_convs.3: gather form; input image in sW rows (pad columns are zero).  Every wave is
@@ -1969,9 +2004,9 @@ __global__ __launch_bounds__(NTHR) void k_decoder(const float* __restrict__ xg, 
         // next chunk's input: x is dead, so its registers are reused for the prefetch
         if (t0 + RW < T) {
             const int npn = min(RW, T - t0 - RW) * 33;
-            const float* xgn = xg + (long)(t0 + RW) * 528;
+            const ht* xgn = xgh + (long)(t0 + RW) * 528;
 #pragma unroll
-            for (int i = 0; i < TPW; ++i) xn[i] = ld4(xgn + (unsigned)((tt.pp(i) < npn ? tt.pp(i) : 0) * 16 + 4 * g));
+            for (int i = 0; i < TPW; ++i) xn[i] = ldx<Q>(xgn + (unsigned)((tt.pp(i) < npn ? tt.pp(i) : 0) * 16 + 4 * g));
         }
         // de_convs.4 gather + BN + Tanh: m[o][f''] = tanh(b[o] + sum_k z[(f''+2-k)/2][o*5+k]).  Branch free:
         // even f'' = 2m takes k = 0,2,4 from rows m+1, m, m-1; odd f'' = 2m+1 takes k = 1,3 from rows m+1, m
