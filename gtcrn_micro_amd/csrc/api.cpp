@@ -181,24 +181,31 @@ int run_model(gtcrn_model* m, const float* spec_in, long isb, long isf, long ist
     LAUNCH_TRY(gtk::launch_encoder(spec_in, isb, isf, ist, B, T, lens, pf, m->d_pi, m->d_en0, m->d_en[0], m->d_en[1],
                                    m->d_en[2], m->d_en[3], state, stp ? stp : nullptr, s, q, x1));
     tm.end();
-    // GTCN: offline calls (no stream state) use the frequency-band form (registers + DPP, no barrier);
-    // streaming calls use the ring form, whose chunks may hold a single frame
-    tm.begin(2);
-    if (!state)
-        LAUNCH_TRY(gtk::launch_gtcn_band(m->d_en[3], m->d_g1, pf + gtl::P_GTCN, B, T, lens, nullptr, s, q));
-    else
-        LAUNCH_TRY(gtk::launch_gtcn(m->d_en[3], m->d_g1, m->d_pf + gtl::P_GTCN, B, T, state, gtk::ST_G1_H, nullptr,
-                                    stp ? stp + sst : nullptr, s));
-    tm.end();
-    tm.begin(3);
-    // the second stack stores gtcn2(x) + en_outs[4]: exactly the decoder's first input (Decoder.forward :467)
-    if (!state)
-        LAUNCH_TRY(gtk::launch_gtcn_band(m->d_g1, m->d_g2, pf + gtl::P_GTCN + gtl::GTCN_SIZE, B, T, lens, m->d_en[3], s,
-                                         q));
-    else
-        LAUNCH_TRY(gtk::launch_gtcn(m->d_g1, m->d_g2, m->d_pf + gtl::P_GTCN + gtl::GTCN_SIZE, B, T, state,
-                                    gtk::ST_G2_H, m->d_en[3], stp ? stp + 2 * sst : nullptr, s));
-    tm.end();
+    // GTCN: offline calls (no stream state) use the frequency-band form (registers + wave-private LDS, no barrier);
+    // single-frame streaming steps run BOTH stacks per position in one launch; other streaming chunkings use the
+    // ring form, whose chunks may hold any number of frames
+    if (state && T == 1) {
+        tm.begin(2);
+        LAUNCH_TRY(gtk::launch_gtcn_ms(m->d_en[3], m->d_g1, m->d_g2, pf + gtl::P_GTCN, B, state, s));
+        tm.end();
+    } else {
+        tm.begin(2);
+        if (!state)
+            LAUNCH_TRY(gtk::launch_gtcn_band(m->d_en[3], m->d_g1, pf + gtl::P_GTCN, B, T, lens, nullptr, s, q));
+        else
+            LAUNCH_TRY(gtk::launch_gtcn(m->d_en[3], m->d_g1, pf + gtl::P_GTCN, B, T, state, gtk::ST_G1_H, nullptr,
+                                        stp ? stp + sst : nullptr, s));
+        tm.end();
+        tm.begin(3);
+        // the second stack stores gtcn2(x) + en_outs[4]: exactly the decoder's first input (Decoder.forward :467)
+        if (!state)
+            LAUNCH_TRY(gtk::launch_gtcn_band(m->d_g1, m->d_g2, pf + gtl::P_GTCN + gtl::GTCN_SIZE, B, T, lens, m->d_en[3], s,
+                                             q));
+        else
+            LAUNCH_TRY(gtk::launch_gtcn(m->d_g1, m->d_g2, pf + gtl::P_GTCN + gtl::GTCN_SIZE, B, T, state, gtk::ST_G2_H,
+                                        m->d_en[3], stp ? stp + 2 * sst : nullptr, s));
+        tm.end();
+    }
     tm.begin(4);
     LAUNCH_TRY(gtk::launch_decoder(m->d_g2, m->d_en0, m->d_en[0], m->d_en[1], m->d_en[2], m->d_en[3], spec_in, isb, isf,
                                    ist, spec_out, osb, osf, ost, B, T, lens, pf, m->d_pi, state,

@@ -60,6 +60,7 @@ int launch_front(const float* wave, long L, const float* spec_in, long isb, long
                  float* en0, float* en1p, float* en1n, hipStream_t s, const Quant* q = nullptr);
 int launch_gtcn(const float* xin, float* xout, const float* P, int B, int T, float* state, int st_off,
                 const float* addend, unsigned long long* stamps, hipStream_t s);
+int launch_gtcn_ms(const float* xin, float* xout1, float* xout2, const float* P, int B, float* state, hipStream_t s);
 int launch_gtcn_band(const float* xin, float* xout, const float* P, int B, int T, const int* lens, const float* addend,
                      hipStream_t s, const Quant* q = nullptr);
 int launch_decoder(const float* xg, const float* en0, const float* en1, const float* en2, const float* en3,

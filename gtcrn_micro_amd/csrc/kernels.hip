@@ -723,6 +723,48 @@ __device__ __forceinline__ void rings_load(float* sH, float* sEH, const float* s
     }
     if (tid < 48) sEH[tid] = st_e ? st_e[tid] : 0.f;
 }
+// The same for the NS streams of a multi-stream workgroup in ONE pass: all of a thread's loads are issued before its
+// first store (four back-to-back single-stream passes would expose four global-load latencies in the prologue of a
+// kernel whose whole run time is a few of them).  st0 = state of the workgroup's first stream, h_off / e_off = float
+// offsets of the ring sets inside a stream's state; streams >= nlive get zero rings.
+template <int NS>
+__device__ __forceinline__ void rings_load_ms(float* sH, float* sEH, const float* st0, int h_off, int e_off, int nlive,
+                                              int tid) {
+    constexpr int PER = 3 * 2 * 35 * 4;                        // float4 items of one stream's image (pad columns included)
+    constexpr int ITEMS = (NS * PER + NTHR - 1) / NTHR;
+    f32x4 v[ITEMS];
+#pragma unroll
+    for (int q = 0; q < ITEMS; ++q) {
+        const int i = tid + q * NTHR;
+        const int sidx = i / PER, r = i - sidx * PER, gg = r & 3, pos = r >> 2, col = pos % 35, br = pos / 35;
+        v[q] = splat(0.f);
+        if (i < NS * PER && sidx < nlive && col >= 1 && col <= 33)
+            v[q] = ld4(st0 + (long)sidx * ST_FLOATS + h_off + ((br * 33) + col - 1) * 16 + gg * 4);
+    }
+#pragma unroll
+    for (int q = 0; q < ITEMS; ++q) {
+        const int i = tid + q * NTHR;
+        const int sidx = i / PER, r = i - sidx * PER;
+        if (i < NS * PER) st4(sH + sidx * RING_SET + pl(r >> 2, r & 3), v[q]);
+    }
+    if (tid < NS * 48) {
+        const int sidx = tid / 48, e = tid - sidx * 48;
+        sEH[tid] = sidx < nlive ? st0[(long)sidx * ST_FLOATS + e_off + e] : 0.f;
+    }
+}
+template <int NS>
+__device__ __forceinline__ void rings_store_ms(const float* sH, const float* sEH, float* st0, int h_off, int e_off,
+                                               int nlive, int tid) {
+    constexpr int PER = 3 * 2 * 33 * 4;
+    for (int i = tid; i < nlive * PER; i += NTHR) {
+        const int sidx = i / PER, r = i - sidx * PER, gg = r & 3, pos = r >> 2, f = pos % 33, br = pos / 33;
+        st4(st0 + (long)sidx * ST_FLOATS + h_off + pos * 16 + gg * 4, ld4(sH + sidx * RING_SET + pl(br * 35 + 1 + f, gg)));
+    }
+    if (tid < nlive * 48) {
+        const int sidx = tid / 48, e = tid - sidx * 48;
+        st0[(long)sidx * ST_FLOATS + e_off + e] = sEH[tid];
+    }
+}
 __device__ __forceinline__ void rings_store(const float* sH, const float* sEH, float* st_h, float* st_e, int tid) {
     for (int i = tid; i < 3 * 2 * 33 * 4; i += NTHR) {
         const int gg = i & 3, pos = i >> 2;
@@ -821,10 +863,7 @@ __global__ __launch_bounds__(NTHR) void k_encoder(const float* __restrict__ spec
     const int nlive = MS ? min(NS, NB - b * NS) : 1;
     int tbase = 0;
     if constexpr (MS) {
-        for (int sidx = 0; sidx < NS; ++sidx) {
-            const float* ss = sidx < nlive ? stb + (long)sidx * ST_FLOATS : nullptr;
-            rings_load(sH + sidx * RING_SET, sEH + sidx * 48, ss ? ss + ST_ENC_H : nullptr, ss ? ss + ST_ENC_E : nullptr, tid);
-        }
+        rings_load_ms<NS>(sH, sEH, stb, ST_ENC_H, ST_ENC_E, nlive, tid);
         if (tid < 8) sTB[tid] = tid < nlive ? reinterpret_cast<const int*>(stb + (long)tid * ST_FLOATS)[0] : 0;
     } else {
         tbase = stb ? reinterpret_cast<const int*>(stb)[0] : 0;
@@ -1093,10 +1132,7 @@ __global__ __launch_bounds__(NTHR) void k_encoder(const float* __restrict__ spec
     if (stb) {
         wg_barrier();
         if constexpr (MS) {
-            for (int sidx = 0; sidx < nlive; ++sidx) {
-                float* ss = stb + (long)sidx * ST_FLOATS;
-                rings_store(sH + sidx * RING_SET, sEH + sidx * 48, ss + ST_ENC_H, ss + ST_ENC_E, tid);
-            }
+            rings_store_ms<NS>(sH, sEH, stb, ST_ENC_H, ST_ENC_E, nlive, tid);
         } else {
             rings_store(sH, sEH, stb + ST_ENC_H, stb + ST_ENC_E, tid);
         }
@@ -1554,39 +1590,54 @@ __device__ __forceinline__ void tcn_block_ms(f32x4& x, const float* pk, const f3
     if (live) st4(ring_r2, y1[0]);
 }
 
-__global__ __launch_bounds__(GTMS_WAVES * 64) void k_gtcn_ms(const float* __restrict__ xin, float* __restrict__ xout,
-                                                            const float* __restrict__ P, int NB,
-                                                            float* __restrict__ state, int st_off,
-                                                            const float* __restrict__ addend) {
-    __shared__ __attribute__((aligned(16))) float sP[GTCN_SIZE];
+// BOTH stacks in one launch (x stays in registers across the eight blocks): xout1 = gtcn1(xin) (kept for the stage
+// taps), xout2 = gtcn2(gtcn1(xin)) + xin, exactly what Decoder.forward adds first (:467).
+__global__ __launch_bounds__(GTMS_WAVES * 64) void k_gtcn_ms(const float* __restrict__ xin, float* __restrict__ xout1,
+                                                            float* __restrict__ xout2, const float* __restrict__ P,
+                                                            int NB, float* __restrict__ state) {
+    __shared__ __attribute__((aligned(16))) float sP[2 * GTCN_SIZE];
     const int tid = threadIdx.x, lane = tid & 63, n = lane & 15, g = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const long p = ((long)blockIdx.x * GTMS_WAVES + wave) * 16 + n;     // position on the flattened (stream, bin) axis
     const bool live = p < (long)NB * 33;
     const long pc = live ? p : 0;                                        // clamped: no select behind the loads
     const int sidx = (int)(pc / 33), ff = (int)(pc - (long)sidx * 33);
-    float* ring = state + (long)sidx * ST_FLOATS + st_off;
-    const int tb = reinterpret_cast<const int*>(state + (long)sidx * ST_FLOATS)[0];
-    // all eight history rows are requested up front; their latency hides behind the parameter copy and block 1
+    float* st = state + (long)sidx * ST_FLOATS;
+    const int tb = reinterpret_cast<const int*>(st)[0];
+    // the history rows of a stack are requested up front; their latency hides behind the parameter copy / the
+    // previous stack
     f32x4 t1[4], t2[4];
     int r2[4];
+    auto fetch_rows = [&](const float* ring) {
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const int d = 1 << k, m2d = 2 * d - 1, row0 = 2 * (d - 1);
-        const int r1 = ((row0 + ((tb + d) & m2d)) * 33 + ff) * 16 + 4 * g;
-        r2[k] = ((row0 + (tb & m2d)) * 33 + ff) * 16 + 4 * g;
-        t1[k] = ld4(ring + r1);
-        t2[k] = ld4(ring + r2[k]);
-    }
-    f32x4 x = ld4(xin + pc * 16 + 4 * g), ad = splat(0.f);
-    if (addend) ad = ld4(addend + pc * 16 + 4 * g);
-    for (int i = tid; i < GTCN_SIZE; i += GTMS_WAVES * 64) sP[i] = P[i];
+        for (int k = 0; k < 4; ++k) {
+            const int d = 1 << k, m2d = 2 * d - 1, row0 = 2 * (d - 1);
+            const int r1 = ((row0 + ((tb + d) & m2d)) * 33 + ff) * 16 + 4 * g;
+            r2[k] = ((row0 + (tb & m2d)) * 33 + ff) * 16 + 4 * g;
+            t1[k] = ld4(ring + r1);
+            t2[k] = ld4(ring + r2[k]);
+        }
+    };
+    fetch_rows(st + ST_G1_H);
+    const f32x4 x0 = ld4(xin + pc * 16 + 4 * g);
+    f32x4 x = x0;
+    for (int i = tid; i < 2 * GTCN_SIZE; i += GTMS_WAVES * 64) sP[i] = P[i];
     __syncthreads();
-    tcn_block_ms<1>(x, sP + 0 * TCN_SIZE, t1[0], t2[0], ring + r2[0], live, n, g);
-    tcn_block_ms<2>(x, sP + 1 * TCN_SIZE, t1[1], t2[1], ring + r2[1], live, n, g);
-    tcn_block_ms<4>(x, sP + 2 * TCN_SIZE, t1[2], t2[2], ring + r2[2], live, n, g);
-    tcn_block_ms<8>(x, sP + 3 * TCN_SIZE, t1[3], t2[3], ring + r2[3], live, n, g);
-    if (live) st4(xout + pc * 16 + 4 * g, addend ? x + ad : x);
+#pragma unroll
+    for (int stack = 0; stack < 2; ++stack) {
+        float* ring = st + (stack == 0 ? ST_G1_H : ST_G2_H);
+        const float* pk = sP + stack * GTCN_SIZE;
+        f32x4 a1[4], a2[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { a1[k] = t1[k]; a2[k] = t2[k]; }
+        int q2[4] = {r2[0], r2[1], r2[2], r2[3]};
+        if (stack == 0) fetch_rows(st + ST_G2_H);                        // the second stack's rows: in flight during the first
+        tcn_block_ms<1>(x, pk + 0 * TCN_SIZE, a1[0], a2[0], ring + q2[0], live, n, g);
+        tcn_block_ms<2>(x, pk + 1 * TCN_SIZE, a1[1], a2[1], ring + q2[1], live, n, g);
+        tcn_block_ms<4>(x, pk + 2 * TCN_SIZE, a1[2], a2[2], ring + q2[2], live, n, g);
+        tcn_block_ms<8>(x, pk + 3 * TCN_SIZE, a1[3], a2[3], ring + q2[3], live, n, g);
+        if (live) st4((stack == 0 ? xout1 : xout2) + pc * 16 + 4 * g, stack == 0 ? x : x + x0);
+    }
 }
 
 // ---------------------------------------------------------------------------- GTCN, offline form
@@ -1731,7 +1782,7 @@ constexpr int DEC_Z_ROW = F1 + 2;                                 // Z rows carr
 template <int RW, int NS, bool MS>
 struct DecLds {
     static constexpr int P = 0;                                   // the whole decoder segment
-    static constexpr int I = P + DEC_SIZE;
+    static constexpr int I = P + D_BS_TAB;                        // (the ERB.bs table has its own region, BS)
     static constexpr int H = I + P_INTS;
     static constexpr int EH = H + NS * RING_SET;
     static constexpr int TB = EH + NS * 48;                       // frame counter per row (ints; multi-stream mode)
@@ -1743,7 +1794,7 @@ struct DecLds {
     static constexpr int BS = M + ((2 * RW * F0 + 4 + 3) & ~3);   // per-bin ERB.bs table {first index, w0, w1, -}
     static constexpr int FLOATS = BS + NBINS * 4;
     static_assert(RW * DEC_Z_ROW * 16 <= ASZ, "Z must fit in the W + S region");
-    static_assert(M % 4 == 0 && BS % 4 == 0, "16B carve");
+    static_assert(M % 4 == 0 && BS % 4 == 0 && D_BS_TAB % 4 == 0, "16B carve");
     static_assert(FLOATS * 4 <= 160 * 1024, "decoder LDS budget");
     static_assert(DEC_SIZE % 4 == 0 && I % 4 == 0 && H % 4 == 0 && A % 4 == 0 && E % 4 == 0, "16B carve");
 };
@@ -1779,35 +1830,19 @@ __global__ __launch_bounds__(NTHR) void k_decoder(const float* __restrict__ xg, 
     float* sS = sW + RW * 35 * 16;
     float* sZ = smem + LD::A;
     float* sM = smem + LD::M;
-    float* sBS = smem + LD::BS;
+    float* sBS = smem + LD::BS;              // per-bin ERB.bs table {first index, w0, w1, -}, built by the host packer
     const Lane L = lane_info();
     const int tid = L.tid, n = L.n, g = L.g;
     const int b = blockIdx.x;
-    for (int i = tid; i < DEC_SIZE; i += NTHR) sP[i] = PF[P_DEC + i];
+    for (int i = tid; i < D_BS_TAB; i += NTHR) sP[i] = PF[P_DEC + i];
     for (int i = tid; i < P_INTS; i += NTHR) sI[i] = PI[i];
-    // ERB.bs (models/gtcrn_micro.py:69-73) as a uniform 2-tap gather per output bin: the 65 low bins
-    // pass through (weight 1), the others combine at most two neighbouring ERB bands
-    for (int f = tid; f < NBINS; f += NTHR) {
-        f32x4 e = {0.f, 1.f, 0.f, 0.f};
-        int i0 = f;
-        if (f >= ERB_LOW) {
-            const int i = f - ERB_LOW, cnt = PI[I_BS_N + i];
-            i0 = ERB_LOW + PI[I_BS_LO + i];
-            e[1] = cnt > 0 ? PF[P_DEC + D_BS_W + i * ERB_MAXBS] : 0.f;
-            e[2] = cnt > 1 ? PF[P_DEC + D_BS_W + i * ERB_MAXBS + 1] : 0.f;
-        }
-        e[0] = __int_as_float(i0);
-        st4(sBS + f * 4, e);
-    }
+    for (int f = tid; f < NBINS; f += NTHR) st4(sBS + f * 4, ld4(PF + P_DEC + D_BS_TAB + f * 4));
     if (tid < 4) sM[2 * RW * F0 + tid] = 0.f;
     float* stb = state ? state + (long)b * NS * ST_FLOATS : nullptr;    // first stream of this workgroup
     const int nlive = MS ? min(NS, NB - b * NS) : 1;
     int tbase = 0;
     if constexpr (MS) {
-        for (int sidx = 0; sidx < NS; ++sidx) {
-            const float* ss = sidx < nlive ? stb + (long)sidx * ST_FLOATS : nullptr;
-            rings_load(sH + sidx * RING_SET, sEH + sidx * 48, ss ? ss + ST_DEC_H : nullptr, ss ? ss + ST_DEC_E : nullptr, tid);
-        }
+        rings_load_ms<NS>(sH, sEH, stb, ST_DEC_H, ST_DEC_E, nlive, tid);
         if (tid < 8) sTB[tid] = tid < nlive ? reinterpret_cast<const int*>(stb + (long)tid * ST_FLOATS)[0] : 0;
     } else {
         tbase = stb ? reinterpret_cast<const int*>(stb)[0] : 0;
@@ -2081,10 +2116,7 @@ __global__ __launch_bounds__(NTHR) void k_decoder(const float* __restrict__ xg, 
     if (stb) {
         wg_barrier();
         if constexpr (MS) {
-            for (int sidx = 0; sidx < nlive; ++sidx) {
-                float* ss = stb + (long)sidx * ST_FLOATS;
-                rings_store(sH + sidx * RING_SET, sEH + sidx * 48, ss + ST_DEC_H, ss + ST_DEC_E, tid);
-            }
+            rings_store_ms<NS>(sH, sEH, stb, ST_DEC_H, ST_DEC_E, nlive, tid);
             if (tid < nlive) reinterpret_cast<int*>(stb + (long)tid * ST_FLOATS)[0] = (sTB[tid] + 1) & 0xFFFF;
         } else {
             rings_store(sH, sEH, stb + ST_DEC_H, stb + ST_DEC_E, tid);
@@ -2350,11 +2382,7 @@ int launch_encoder(const float* spec, long sb, long sf, long st, int B, int T, c
 
 int launch_gtcn(const float* xin, float* xout, const float* P, int B, int T, float* state, int st_off,
                 const float* addend, unsigned long long* stamps, hipStream_t s) {
-    if (T == 1 && state) {       // single-frame step for B streams: per-position, barrier-free form
-        const long tiles = ((long)B * 33 + 15) / 16;
-        hipLaunchKernelGGL(k_gtcn_ms, dim3((unsigned)((tiles + GTMS_WAVES - 1) / GTMS_WAVES)), dim3(GTMS_WAVES * 64), 0, s,
-                           xin, xout, P, B, state, st_off, addend);
-    } else if (T <= SHORT_T && state)   // streaming step: rings stay in the stream state (no LDS copy: 77 KB, 2 workgroups per CU)
+    if (T <= SHORT_T && state)   // streaming step: rings stay in the stream state (no LDS copy: 77 KB, 2 workgroups per CU)
         hipLaunchKernelGGL((k_gtcn<1, true>), dim3(B), dim3(NTHR), GT_LDS_H * 4, s, xin, xout, P, T, state, st_off,
                            addend, stamps);
     else if (T <= SHORT_T)
@@ -2372,6 +2400,16 @@ int launch_gtcn(const float* xin, float* xout, const float* P, int B, int T, flo
     else
         hipLaunchKernelGGL((k_gtcn<TPW, false>), dim3(B), dim3(NTHR), GT_LDS_FLOATS * 4, s, xin, xout, P, T, state,
                            st_off, addend, stamps);
+    GT_LAUNCH_CHECK();
+    return 0;
+}
+
+// single-frame step for B streams: BOTH GTCN stacks, per position, barrier-free (see k_gtcn_ms); P = the two stacks'
+// parameters back to back
+int launch_gtcn_ms(const float* xin, float* xout1, float* xout2, const float* P, int B, float* state, hipStream_t s) {
+    const long tiles = ((long)B * 33 + 15) / 16;
+    hipLaunchKernelGGL(k_gtcn_ms, dim3((unsigned)((tiles + GTMS_WAVES - 1) / GTMS_WAVES)), dim3(GTMS_WAVES * 64), 0, s, xin,
+                       xout1, xout2, P, B, state);
     GT_LAUNCH_CHECK();
     return 0;
 }

@@ -77,7 +77,10 @@ constexpr int D_DE3_S = D_DE3_B + 16;
 constexpr int D_DE4_A = D_DE3_S + 4;               // 16x16: row o*5+k (10 used), cols = de3 channels
 constexpr int D_DE4_B = D_DE4_A + 256;             // 2 (+2 pad)
 constexpr int D_BS_W = D_DE4_B + 4;                // [192][ERB_MAXBS]
-constexpr int DEC_SIZE = D_BS_W + 192 * ERB_MAXBS;
+// ERB.bs as a uniform 2-tap gather per output bin, ready for the kernel: [257][4] = {first input index (int bits),
+// w0, w1, 0}: the 65 low bins pass through (index = bin, weights 1, 0), the others combine at most two bands
+constexpr int D_BS_TAB = D_BS_W + 192 * ERB_MAXBS;
+constexpr int DEC_SIZE = D_BS_TAB + NBINS * 4;
 
 // ---- whole float buffer ------------------------------------------------------
 constexpr int P_ENC = 0;

@@ -312,6 +312,20 @@ int pack_params(const float* params, long n, float* F, int* I, std::string& err)
         }
     }
     if (c.p - params != NPARAM) { err = "internal: parameter walk ended at the wrong offset"; return -1; }
+    // ERB.bs gather table (models/gtcrn_micro.py:69-73 as the kernels evaluate it)
+    for (int f = 0; f < NBINS; ++f) {
+        int i0 = f;
+        float w0 = 1.f, w1 = 0.f;
+        if (f >= ERB_LOW) {
+            const int i = f - ERB_LOW, cnt = I[I_BS_N + i];
+            i0 = ERB_LOW + I[I_BS_LO + i];
+            w0 = cnt > 0 ? D[D_BS_W + i * ERB_MAXBS] : 0.f;
+            w1 = cnt > 1 ? D[D_BS_W + i * ERB_MAXBS + 1] : 0.f;
+        }
+        float fi;
+        std::memcpy(&fi, &i0, 4);
+        D[D_BS_TAB + f * 4 + 0] = fi; D[D_BS_TAB + f * 4 + 1] = w0; D[D_BS_TAB + f * 4 + 2] = w1; D[D_BS_TAB + f * 4 + 3] = 0.f;
+    }
     Perm stored[9];
     for (int t = 0; t < 9; ++t) stored[t] = perm[t];
     for (int q = 0; q < 3; ++q) stored[1 + q] = perm[7 - q];
@@ -395,6 +409,12 @@ void quantize_packed(float* F) {
     quant_group(D + D_DE3_AE, 16, 16, 5, 256, 16, 1);            // AE (3 matrices) + AO (2) share the output channels
     quant_group(D + D_DE4_A, 2, 80, 5, 16, 16, 1);               // rows o*5+k: output channel o owns five rows
     quant_group(D + D_BS_W, 192, ERB_MAXBS, 1, 0, ERB_MAXBS, 1);
+    // the kernel-ready ERB.bs table repeats those weights (slots 1, 2 of the rows of the high bins)
+    for (int f = ERB_LOW; f < NBINS; ++f) {
+        const int i = f - ERB_LOW;
+        if (D[D_BS_TAB + f * 4 + 1] != 0.f) D[D_BS_TAB + f * 4 + 1] = D[D_BS_W + i * ERB_MAXBS];
+        if (D[D_BS_TAB + f * 4 + 2] != 0.f) D[D_BS_TAB + f * 4 + 2] = D[D_BS_W + i * ERB_MAXBS + 1];
+    }
 }
 
 void make_window(int kind, float* w) {

@@ -313,3 +313,19 @@ def test_quality_scores_closed_form():
         want = 10 * np.log10(1.0 / (0.25 + 0.25 / 10 ** (snr / 10)))       # SDR is not: residual = -ref/2 + noise/2
         assert abs(sdr_metric(ref, 0.5 * inf) - want) < 1e-6
     assert sdr_metric(ref, ref) > 100
+
+
+def test_headline_kernels_use_no_scratch():
+    """The headline kernels sit at the 168-VGPR limit of three waves per SIMD; a spill costs s_waitcnt vmcnt(0) on every
+    reload and a harmless-looking edit can tip them over (the decoder went 0.52 -> 0.60 ms that
+    way in round 2).  Compile-only check (hipcc cross-compiles without a GPU)."""
+    import subprocess
+    out = subprocess.run(["bash", os.path.join(ROOT, "tools", "kernel_resources.sh")], capture_output=True, text=True,
+                         timeout=900).stdout
+    rows = {l.split("|")[0].strip(): l for l in out.splitlines() if "ScratchSize" in l}
+    must = ["void gtk::k_front<true, false>", "void gtk::k_encoder<3, false, false, false>", "void gtk::k_gtcn_band<false>",
+            "void gtk::k_decoder<false, 3, false, false>", "gtk::k_istft", "gtk::k_gtcn_ms",
+            "void gtk::k_encoder<1, true, false, true>", "void gtk::k_decoder<false, 1, true, false>"]
+    for k in must:
+        assert k in rows, (k, sorted(rows))
+        assert "ScratchSize [bytes/lane]: 0 " in rows[k], rows[k]
