@@ -45,11 +45,17 @@ __device__ __forceinline__ void wg_barrier() {
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
-// position-major LDS image: 16 floats (one 64-byte record) per position, slot group g at +16g bytes.
-// Unswizzled on purpose: tap addresses are then "own address + compile-time constant", which keeps
-// address arithmetic off the VALU (the kernels are VALU-issue bound around the MFMAs, not LDS bound);
-// the price is a 2-way bank conflict on the tile-wide ds_read_b128 (8 instead of 4 LDS cycles).
-__device__ __forceinline__ int pl(int pos, int g) { return pos * 16 + 4 * g; }
+// position-major LDS image: one record of 16 floats per position, slot group g at +16g bytes, records RS floats apart.
+// Unswizzled on purpose: tap addresses are then "own address + compile-time constant", which keeps address arithmetic
+// off the VALU.  RS = 16 (dense 64-byte records) costs a 2-way bank conflict on every tile-wide ds_read_b128 (its
+// lane groups are {0-3,12-15,20-27}, ...: eight lanes of one slot group land on four 16-byte bank slots) and a 4-way
+// one on ds_write_b128; RS = 24 (96-byte pitch) is conflict-free for reads at ANY base record (slot = (6 R + g) mod
+// 16: the eight g-even lanes take the even slots, the eight g-odd lanes the odd ones) and 2-way for writes:
+// 4.2 vs 7.4 and 14 vs 27 cycles per wave-instruction (tools/ubench_lds.hip).  The images of the offline encoder use
+// RS = 24; kernels whose LDS budget has no room for the 50 % larger images keep RS = 16.
+constexpr int RS_WIDE = 24;
+template <int RS = 16>
+__device__ __forceinline__ int pl(int pos, int g) { return pos * RS + 4 * g; }
 __device__ __forceinline__ int pls(int pos, int slot) { return pos * 16 + slot; }
 
 __device__ __forceinline__ f32x4 mfma(float a, float b, f32x4 c) {
@@ -464,7 +470,7 @@ struct Tiles {
     int tl[TPW];    // frame inside the chunk
     int ff[TPW];    // frequency bin
     // position inside the chunk (= tile * 16 + n); one mad, cheaper than a third live register per tile
-    __device__ __forceinline__ int pp(int i) const { return tl[i] * 33 + ff[i]; }
+    __device__ __forceinline__ int pp(int i) const { return __mul24(tl[i], 33) + ff[i]; }
 };
 template <int TPW>
 __device__ __forceinline__ Tiles<TPW> make_tiles(const Lane& L) {
@@ -478,14 +484,12 @@ __device__ __forceinline__ Tiles<TPW> make_tiles(const Lane& L) {
     return t;
 }
 // float offset of the lane's record in a 35-column row image (zero pad columns 0 and 34)
-template <int TPW>
-__device__ __forceinline__ int o35(const Tiles<TPW>& t, int i, int g) { return (t.tl[i] * 35 + 1 + t.ff[i]) * 16 + 4 * g; }
-// float offset inside a 2-row ring (row = frame & 1) of (frame tl - back, bin ff), back = 1 or 2
-template <int TPW>
-__device__ __forceinline__ int ring35(const Tiles<TPW>& t, int i, int g, int tbase, int back) {
-    return (((tbase + t.tl[i] + back) & 1) * 35 + 1 + t.ff[i]) * 16 + 4 * g;
+constexpr int IMG_R0 = 2;   // image row of the chunk's first frame (rows 0, 1: the two frames before the chunk)
+template <int RS, int R0, int TPW>
+__device__ __forceinline__ int o35(const Tiles<TPW>& t, int i, int g) {
+    // 24-bit multiplies: full rate (v_mul_lo_u32 is quarter rate and the compiler cannot see the value ranges)
+    return __mul24(__mul24(t.tl[i] + R0, 35) + 1 + t.ff[i], RS) + 4 * g;
 }
-
 
 // The spectrogram elements of a chunk a thread handles: item q is element idx = tid + q*NTHR of the chunk,
 // idx -> (frame tq, bin f) with f fastest for the frame-major layout and tq fastest for the reference layout
@@ -509,7 +513,9 @@ struct BlockCtx {
     const float* gA;     // LDS: dense 3x3 slot matrices (decoder) or nullptr
     const int* ib;       // LDS: slot_of_c[8], x2slots[8]
     float* sW;           // LDS: h of this chunk, rows of 35 positions (zero pad columns 0 and 34)
-    float* sHk;          // LDS: 2-row history ring of h (row = frame & 1), rows of 35 positions
+    float* sHk;          // LDS: history ring of h (MS: rows of 35 positions, row = frame & 1; else [2 frames][33][16])
+    const float* sHtop;  // not MS: ring to copy into image rows 0, 1 at the top of this block (nullptr: already there)
+    const float* sHnext; // not MS: the NEXT block's ring, copied into rows 0, 1 once this block's taps are read (or nullptr)
     float* sS;           // LDS: v^2, [position][16 slots], 33 positions per frame
     float* sG;           // LDS: gates [frame][16 slots]
     float* sEHk;         // LDS: 2-entry ring of e: [frame & 1][8]
@@ -533,17 +539,41 @@ constexpr int RING_SET = 3 * 2 * 35 * 16;   // floats of one stream's three 2-ro
 
 // `hook` runs right after the depth-conv phase (register pressure is past its peak there, and two
 // barrier intervals of work follow): the decoder uses it to request inputs of later phases early.
-template <bool DENSE, int TPW, bool MS, bool Q, class Hook>
-__device__ __forceinline__ void gtconv_block(f32x4 (&x)[TPW], const Tiles<TPW>& tt, const BlockCtx& c,
+// history ring [2 frames][33][16] (older frame first) -> image rows 0, 1 (the pad columns are zeroed per chunk)
+template <int RS>
+__device__ __forceinline__ void ring_to_image(float* sW, const float* ring, int tid) {
+    if (tid < 2 * 33 * 4) {
+        const int row = tid >= 132 ? 1 : 0, r = tid - row * 132;
+        st4(sW + pl<RS>(row * 35 + 1 + (r >> 2), r & 3), ld4(ring + (row * 33 + (r >> 2)) * 16 + (r & 3) * 4));
+    }
+}
+
+template <bool DENSE, int TPW, bool MS, bool Q, int RS, int RSS, class Hook>
+__device__ __forceinline__ void gtconv_block(f32x4 (&x)[TPW], const Tiles<TPW>& tin, const BlockCtx& c,
                                              const Lane& L, Hook&& hook STAMP_PARAM) {
     static_assert(!MS || TPW == 1, "multi-stream mode runs one tile per wave");
     const int n = L.n, g = L.g;
+    // Image rows (not MS): rows 0, 1 hold the two frames BEFORE the chunk -- copied from the block's history ring at
+    // the top of the block -- and row 2 + tl holds frame tl of the chunk, so a temporal tap is always "own record minus
+    // a constant": no per-lane choice between image and ring, no select, no second address (IMG_R0 = 2).
+    // MS: row r holds the one new frame of stream r and the taps come from that stream's own parity-indexed ring.
+    constexpr int R0 = MS ? 0 : IMG_R0;
+    // (The offsets are derived from an opaque copy of the tiles' rows: recomputed per block -- a few full-rate integer
+    // ops -- instead of being hoisted out of the chunk loop and held in registers across the whole kernel.)
+    Tiles<TPW> tt = tin;
+#pragma unroll
+    for (int i = 0; i < TPW; ++i) asm volatile("" : "+v"(tt.tl[i]));
+    int b0s[TPW];
+#pragma unroll
+    for (int i = 0; i < TPW; ++i) b0s[i] = o35<RS, R0>(tt, i, g);
     // float offset (from sW) of the record `back` frames before tile i's own position b0
-    auto tap_base = [&](int i, int back, int b0, int ringoff) -> int {
-        if (back == 0) return b0;
-        if constexpr (MS) return c.ms_roff + (((c.ms_tb + back) & 1) * 35 + 1 + tt.ff[i]) * 16 + 4 * g;
-        else return tt.tl[i] >= back ? b0 - back * 35 * 16 : ringoff + ring35(tt, i, g, c.tabs, back);
+    auto tap_base = [&](int i, int back, int b0) -> int {
+        if constexpr (MS) return back == 0 ? b0 : c.ms_roff + (((c.ms_tb + back) & 1) * 35 + 1 + tt.ff[i]) * RS + 4 * g;
+        else return b0 - back * 35 * RS;
     };
+    if constexpr (!MS) {
+        if (c.sHtop) ring_to_image<RS>(c.sW, c.sHtop, L.tid);
+    }
     const float a1 = c.pb[GB_SLOPE] - 1.0f, a2 = c.pb[GB_SLOPE + 1] - 1.0f;
     // ---- point_conv1 + BN + PReLU; h lives only in the LDS image from here on (its centre tap and the
     //      ring update re-read it: one ds_read_b128 each instead of 12 registers held across the phase) ----
@@ -554,7 +584,7 @@ __device__ __forceinline__ void gtconv_block(f32x4 (&x)[TPW], const Tiles<TPW>& 
         for (int i = 0; i < TPW; ++i) h[i] = Bv;
         mm16<TPW, Q>(A, x, h);
 #pragma unroll
-        for (int i = 0; i < TPW; ++i) st4(c.sW + o35(tt, i, g), rq<Q>(prelu4(h[i], a1)));
+        for (int i = 0; i < TPW; ++i) st4(c.sW + b0s[i], rq<Q>(prelu4(h[i], a1)));
     }
     wg_barrier();
     STAMP(SS, 5)
@@ -565,7 +595,6 @@ __device__ __forceinline__ void gtconv_block(f32x4 (&x)[TPW], const Tiles<TPW>& 
         const f32x4 Bd = ld4(c.pb + GB_DW_B + 4 * g);
         const f32x4 A2 = ld4(c.pb + GB_PC2_A + n * 16 + 4 * g), B2 = ld4(c.pb + GB_PC2_B + 4 * g);
         const f32x4 keep = ld4(c.pb + GB_KEEP + 4 * g);
-        const long ringoff = c.sHk - c.sW;   // both live in the same LDS array
         if constexpr (!DENSE) {
             // depthwise 3x3, kernel-row major: the three weights of a kernel row stay in registers for all of the
             // wave's tiles (9 LDS weight reads per block instead of 9 per tile; this phase is LDS-bound)
@@ -580,9 +609,12 @@ __device__ __forceinline__ void gtconv_block(f32x4 (&x)[TPW], const Tiles<TPW>& 
                 const int back = 2 - kt;                     // tap (t-2+kt, f-1+kf)
 #pragma unroll
                 for (int i = 0; i < TPW; ++i) {
-                    const int b0 = o35(tt, i, g);
-                    const int rb = tap_base(i, back, b0, (int)ringoff);
-                    acc[i] += w0 * ld4(c.sW + rb - 16) + w1 * ld4(c.sW + rb) + w2 * ld4(c.sW + rb + 16);
+                    const int b0 = b0s[i];
+                    const int rb = tap_base(i, back, b0);
+                    // three fused multiply-adds per component (a sum of products added afterwards costs a fourth op)
+                    acc[i] += w0 * ld4(c.sW + rb - RS);
+                    acc[i] += w1 * ld4(c.sW + rb);
+                    acc[i] += w2 * ld4(c.sW + rb + RS);
                 }
             }
 #pragma unroll
@@ -594,7 +626,7 @@ __device__ __forceinline__ void gtconv_block(f32x4 (&x)[TPW], const Tiles<TPW>& 
 #pragma unroll
             for (int i = 0; i < TPW; ++i) {
                 x[i] = rq<Q>(x[i]);
-                st4(c.sS + tt.pp(i) * 16 + 4 * g, x[i] * x[i]);   // energies are reduced cooperatively after the barrier
+                st4(c.sS + tt.pp(i) * RSS + 4 * g, x[i] * x[i]);   // energies are reduced cooperatively after the barrier
             }
         } else {
             // dense transposed 3x3, tap major: each of the nine 16x16 slot matrices is read from LDS once per wave
@@ -610,9 +642,9 @@ __device__ __forceinline__ void gtconv_block(f32x4 (&x)[TPW], const Tiles<TPW>& 
                     const int back = kt, df = 1 - kf;        // decoder (transposed): tap (t-kt, f+1-kf)
 #pragma unroll
                     for (int i = 0; i < TPW; ++i) {
-                        const int b0 = o35(tt, i, g);
-                        const int rb = tap_base(i, back, b0, (int)ringoff);
-                        const f32x4 tap = ld4(c.sW + rb + df * 16);
+                        const int b0 = b0s[i];
+                        const int rb = tap_base(i, back, b0);
+                        const f32x4 tap = ld4(c.sW + rb + df * RS);
                         acc[i] = mm1<Q>(A, tap, acc[i]);
                     }
                     // one tap's loads (a matrix + TPW records) in flight at a time: hoisting more of them ahead of
@@ -629,22 +661,24 @@ __device__ __forceinline__ void gtconv_block(f32x4 (&x)[TPW], const Tiles<TPW>& 
 #pragma unroll
             for (int i = 0; i < TPW; ++i) {
                 x[i] = rq<Q>(x[i]);
-                st4(c.sS + tt.pp(i) * 16 + 4 * g, x[i] * x[i]);   // energies are reduced cooperatively after the barrier
+                st4(c.sS + tt.pp(i) * RSS + 4 * g, x[i] * x[i]);   // energies are reduced cooperatively after the barrier
             }
         }
     }
     wg_barrier();
     STAMP(SS, 6)
     hook();
-    // ---- history ring of h (after every wave has read its taps) -----------------------------------
+    // ---- history ring of h (after every wave has read its taps): the last two frames of the image ---------------
+    if constexpr (MS) {
 #pragma unroll
-    for (int i = 0; i < TPW; ++i) {
-        if constexpr (MS) {
+        for (int i = 0; i < TPW; ++i)
             if (tt.tl[i] < c.nfr)
-                st4(c.sW + c.ms_roff + ((c.ms_tb & 1) * 35 + 1 + tt.ff[i]) * 16 + 4 * g, ld4(c.sW + o35(tt, i, g)));
-        } else {
-            if (tt.tl[i] < c.nfr && tt.tl[i] >= c.nfr - 2)
-                st4(c.sHk + ring35(tt, i, g, c.tabs, 2), ld4(c.sW + o35(tt, i, g)));
+                st4(c.sW + c.ms_roff + ((c.ms_tb & 1) * 35 + 1 + tt.ff[i]) * RS + 4 * g, ld4(c.sW + b0s[i]));
+    } else {
+        // frames nfr-2, nfr-1 of the chunk = image rows nfr, nfr+1 (for a one-frame call row nfr is the old row 1)
+        if (L.tid >= NTHR - 2 * 33 * 4) {
+            const int q = L.tid - (NTHR - 2 * 33 * 4), row = q >= 132 ? 1 : 0, r = q - row * 132;
+            st4(c.sHk + (row * 33 + (r >> 2)) * 16 + (r & 3) * 4, ld4(c.sW + pl<RS>((c.nfr + row) * 35 + 1 + (r >> 2), r & 3)));
         }
     }
     // ---- TRALite, step 1: energies e[t][c] = mean_F(v^2): 32 threads per frame = 8 h' channels x 4 bin
@@ -654,10 +688,10 @@ __device__ __forceinline__ void gtconv_block(f32x4 (&x)[TPW], const Tiles<TPW>& 
     {
         const int part = L.tid & 3, rc = (L.tid >> 2) & 7, rt = L.tid >> 5;
         if (L.tid < c.nfr * 32) {
-            const float* sp = c.sS + (rt * 33 + part * 9) * 16 + c.ib[rc];
+            const float* sp = c.sS + (rt * 33 + part * 9) * RSS + c.ib[rc];
             const int cnt = part == 3 ? 6 : 9;
             float sum = 0.f;
-            for (int f = 0; f < cnt; ++f) sum += sp[f * 16];
+            for (int f = 0; f < cnt; ++f) sum += sp[f * RSS];
             sum += dpp_ror<0xB1>(sum);   // quad_perm [1,0,3,2]
             sum += dpp_ror<0x4E>(sum);   // quad_perm [2,3,0,1]
             if (part == 0) c.sE[(MS ? rt * 3 + 2 : 2 + rt) * 8 + rc] = sum * (1.0f / 33.0f);
@@ -670,6 +704,11 @@ __device__ __forceinline__ void gtconv_block(f32x4 (&x)[TPW], const Tiles<TPW>& 
         }
     }
     wg_barrier();
+    // rows 0, 1 of the image are free (this block's ring save, which may read row 1, is behind the barrier): the next
+    // block's history goes there now, off the critical path
+    if constexpr (!MS) {
+        if (c.sHnext) ring_to_image<RS>(c.sW, c.sHnext, L.tid);
+    }
     // ---- step 2: one thread per (frame, output channel): causal depthwise conv1d (k=3) over the energies,
     //      1x1 conv, sigmoid (models/gtcrn_micro.py:122-139) ------------------------------------------------
     {
@@ -701,25 +740,28 @@ __device__ __forceinline__ void gtconv_block(f32x4 (&x)[TPW], const Tiles<TPW>& 
 
 // zero the two pad columns of the TC rows of a 35-position row image (tid and the zero are made
 // opaque so that neither is hoisted out of the chunk loop and kept live / spilled)
-template <int ROWS = TC>
+template <int ROWS = TC, int RS = 16>
 __device__ __forceinline__ void zero_row_pads(float* img, int tid) {
     asm volatile("" : "+v"(tid));
     if (tid < ROWS * 2 * 4) {
         const int r = tid >> 3, side = (tid >> 2) & 1, gg = tid & 3;
         float z = 0.f;
         asm volatile("" : "+v"(z));
-        st4(img + pl(r * 35 + side * 34, gg), splat(z));
+        st4(img + pl<RS>(r * 35 + side * 34, gg), splat(z));
     }
 }
 
-// load / store the 2-row h rings and e rings of 3 blocks from / to the stream state
-__device__ __forceinline__ void rings_load(float* sH, float* sEH, const float* st_h, const float* st_e, int tid) {
-    for (int i = tid; i < 3 * 2 * 35 * 4; i += NTHR) {
-        const int gg = i & 3, pos = i >> 2;           // pos over 3 blocks x 2 rows x 35 columns
-        const int col = pos % 35, br = pos / 35;      // br = block*2 + row
+// load / store the h rings and e rings of 3 blocks from / to the stream state.  LDS: [3 blocks][2 frames][33][16],
+// the OLDER frame first (gtconv_block copies it into image rows 0, 1); state: row = frame & 1 (the layout the
+// multi-stream form reads in place), so frame tb - 2 + r of a stream whose next frame is tb sits in state row (tb + r) & 1.
+constexpr int RING_DENSE = 2 * 33 * 16;     // floats of one block's ring in LDS (single-stream kernels)
+__device__ __forceinline__ void rings_load(float* sH, float* sEH, const float* st_h, const float* st_e, int tb, int tid) {
+    for (int i = tid; i < 3 * 2 * 33 * 4; i += NTHR) {
+        const int gg = i & 3, pos = i >> 2;           // pos over 3 blocks x 2 frames x 33 bins
+        const int f = pos % 33, br = pos / 33, r = br & 1;
         f32x4 v = splat(0.f);
-        if (st_h && col >= 1 && col <= 33) v = ld4(st_h + ((br * 33) + col - 1) * 16 + gg * 4);
-        st4(sH + pl(pos, gg), v);
+        if (st_h) v = ld4(st_h + ((br - r + ((tb + r) & 1)) * 33 + f) * 16 + gg * 4);
+        st4(sH + pos * 16 + gg * 4, v);
     }
     if (tid < 48) sEH[tid] = st_e ? st_e[tid] : 0.f;
 }
@@ -765,11 +807,12 @@ __device__ __forceinline__ void rings_store_ms(const float* sH, const float* sEH
         st0[(long)sidx * ST_FLOATS + e_off + e] = sEH[tid];
     }
 }
-__device__ __forceinline__ void rings_store(const float* sH, const float* sEH, float* st_h, float* st_e, int tid) {
+// tb = the stream's NEXT frame index after this call (the LDS rings hold frames tb - 2, tb - 1)
+__device__ __forceinline__ void rings_store(const float* sH, const float* sEH, float* st_h, float* st_e, int tb, int tid) {
     for (int i = tid; i < 3 * 2 * 33 * 4; i += NTHR) {
         const int gg = i & 3, pos = i >> 2;
-        const int f = pos % 33, br = pos / 33;
-        st4(st_h + pos * 16 + gg * 4, ld4(sH + pl(br * 35 + 1 + f, gg)));
+        const int f = pos % 33, br = pos / 33, r = br & 1;
+        st4(st_h + ((br - r + ((tb + r) & 1)) * 33 + f) * 16 + gg * 4, ld4(sH + pos * 16 + gg * 4));
     }
     if (tid < 48) st_e[tid] = sEH[tid];
 }
@@ -797,25 +840,29 @@ __device__ __forceinline__ f32x4 permute_via_lds(float* scratch_rec, const int* 
 // LDS carve of k_encoder: RW image rows (TC, or MS_ROWS in multi-stream mode), NS ring sets (streams per workgroup)
 constexpr int ENC_E0_ROW = 69;
 constexpr int EB_ROW = 131, F0_ROW = 136;
-template <int RW, int NS, bool MS>
+template <int RW, int NS, bool MS, bool FRONT>
 struct EncLds {
+    static constexpr int RS = FRONT ? 16 : RS_WIDE;            // record pitch of the block images W, S and the h rings
     static constexpr int P = 0;
     static constexpr int I = P + ENC_SIZE;
     static constexpr int H = I + P_INTS;
-    static constexpr int EH = H + NS * RING_SET;
+    static constexpr int EH = H + (MS ? NS * RING_SET : 3 * RING_DENSE);
     static constexpr int TB = EH + NS * 48;                    // frame counter per row (ints; multi-stream mode)
     static constexpr int G = TB + 8;
     static constexpr int E = G + RW * 16 + RW * 8;             // (gates [RW][16] + y scratch [RW][8]); energies
-    static constexpr int A = E + (MS ? NS * 24 : (RW + 2) * 8);   // staged spec, then E0, then W + S
-    static constexpr int B = A + RW * ENC_E0_ROW * 16;         // EB + F0
-    static constexpr int FLOATS = B + 3 * RW * EB_ROW + 3 * RW * F0_ROW;
+    static constexpr int A = E + (MS ? NS * 24 : (RW + 2) * 8);   // FRONT: staged spec, then E0, then W + S; else W
+    static constexpr int RWI = MS ? RW : RW + IMG_R0;         // image rows (two history rows in front of the chunk)
+    static constexpr int B = A + (FRONT ? RW * ENC_E0_ROW * 16 : RWI * 35 * RS);   // FRONT: EB + F0; else S
+    static constexpr int S = FRONT ? A + RWI * 35 * 16 : B;   // FRONT: S may run over into B (EB / F0 are dead by then)
+    static constexpr int FLOATS = B + (FRONT ? 3 * RW * EB_ROW + 3 * RW * F0_ROW : RW * 33 * RS);
     static_assert(3 * RW * NBINS <= RW * ENC_E0_ROW * 16, "staged [mag,re,im] chunk must fit in the E0 region");
     static_assert(FLOATS * 4 <= 160 * 1024, "encoder LDS budget");
-    static_assert(RW * 35 * 16 + RW * 33 * 16 <= RW * ENC_E0_ROW * 16, "W + S must fit in the E0 region");
-    static_assert(I % 4 == 0 && H % 4 == 0 && G % 4 == 0 && A % 4 == 0 && E % 4 == 0, "16B carve");
+    static_assert(!FRONT || S + RW * 33 * 16 <= FLOATS, "W + S must fit in the E0 + EB + F0 regions");
+    static_assert(I % 4 == 0 && H % 4 == 0 && G % 4 == 0 && A % 4 == 0 && E % 4 == 0 && B % 4 == 0, "16B carve");
 };
-constexpr int ENC_LDS_FLOATS = EncLds<TC, 1, false>::FLOATS;
-constexpr int ENC_MS_LDS_FLOATS = EncLds<MS_ROWS, MS_STREAMS, true>::FLOATS;
+constexpr int ENC_LDS_FLOATS = EncLds<TC, 1, false, true>::FLOATS;
+constexpr int ENC_GT_LDS_FLOATS = EncLds<TC, 1, false, false>::FLOATS;
+constexpr int ENC_MS_LDS_FLOATS = EncLds<MS_ROWS, MS_STREAMS, true, true>::FLOATS;
 
 // lens (optional, offline only): utterance b has 1 + lens[b]/256 <= T frames; T stays the row stride of every tensor.
 // MS (multi-stream, single-frame streaming steps): workgroup b serves streams b*MS_STREAMS .. +3 of the NB streams,
@@ -839,7 +886,9 @@ __global__ __launch_bounds__(NTHR) void k_encoder(const float* __restrict__ spec
     STAMP_INIT(SS)
     constexpr int RW = MS ? MS_ROWS : TC;
     constexpr int NS = MS ? MS_STREAMS : 1;
-    using LD = EncLds<RW, NS, MS>;
+    using LD = EncLds<RW, NS, MS, FRONT>;
+    constexpr int RS = LD::RS;
+    static_assert(!MS || FRONT, "multi-stream steps run the whole encoder");
     float* sP = smem + LD::P;
     int* sI = reinterpret_cast<int*>(smem + LD::I);
     float* sH = smem + LD::H;
@@ -849,7 +898,7 @@ __global__ __launch_bounds__(NTHR) void k_encoder(const float* __restrict__ spec
     float* sSpec = smem + LD::A;     // [3: mag, re, im][tl][257]
     float* sE0 = smem + LD::A;
     float* sW = smem + LD::A;
-    float* sS = sW + RW * 35 * 16;
+    float* sS = smem + LD::S;
     float* sEB = smem + LD::B;
     float* sF0 = sEB + 3 * RW * EB_ROW;
     const Lane L = lane_info();
@@ -867,10 +916,11 @@ __global__ __launch_bounds__(NTHR) void k_encoder(const float* __restrict__ spec
         if (tid < 8) sTB[tid] = tid < nlive ? reinterpret_cast<const int*>(stb + (long)tid * ST_FLOATS)[0] : 0;
     } else {
         tbase = stb ? reinterpret_cast<const int*>(stb)[0] : 0;
-        rings_load(sH, sEH, stb ? stb + ST_ENC_H : nullptr, stb ? stb + ST_ENC_E : nullptr, tid);
+        rings_load(sH, sEH, stb ? stb + ST_ENC_H : nullptr, stb ? stb + ST_ENC_E : nullptr, tbase, tid);
     }
     const Tiles<TPW> tt = make_tiles<TPW>(L);
     wg_barrier();
+    if constexpr (!FRONT) ring_to_image<RS>(sW, sH, tid);   // block 0's history of the first chunk (later ones: block 2)
 
     spec += (long)b * sb;
     const long ob = (long)b * T;
@@ -1090,7 +1140,7 @@ __global__ __launch_bounds__(NTHR) void k_encoder(const float* __restrict__ spec
         wg_barrier();  // E0 is dead: its region becomes W
         STAMP(SS, 4)
         }   // FRONT
-        zero_row_pads<RW>(sW, tid);
+        zero_row_pads<LD::RWI, RS>(sW, tid);
         // ---- E: 3 x GTConvBlock (depthwise) --------------------------------------------------------
 #pragma unroll 1
         for (int k = 0; k < 3; ++k) {
@@ -1098,7 +1148,11 @@ __global__ __launch_bounds__(NTHR) void k_encoder(const float* __restrict__ spec
             c.pb = sP + E_BLK + k * GB_SIZE;
             c.gA = nullptr;
             c.ib = sI + I_ENC_BLK + k * 16;
-            c.sW = sW; c.sHk = sH + k * (2 * 35 * 16); c.sS = sS; c.sG = sG; c.sEHk = sEH + k * 16;
+            c.sW = sW; c.sHk = sH + k * RING_DENSE; c.sS = sS; c.sG = sG; c.sEHk = sEH + k * 16;
+            // FRONT: region A held the staged spectrogram / E0 until this chunk's phase D, so block 0 fetches its
+            // history itself; otherwise the image is only ever W and block 2 prepares the next chunk's block 0
+            c.sHtop = FRONT && k == 0 ? sH : nullptr;
+            c.sHnext = k < 2 ? sH + (k + 1) * RING_DENSE : (FRONT ? nullptr : sH);
             c.sE = smem + LD::E;
             c.sY = sG + RW * 16;
             c.nfr = nfr; c.tabs = tbase + t0;
@@ -1110,13 +1164,13 @@ __global__ __launch_bounds__(NTHR) void k_encoder(const float* __restrict__ spec
             } else {
                 c.ms_roff = 0; c.ms_tb = 0;
             }
-            gtconv_block<false, TPW, MS, Q>(x, tt, c, L, [] {} STAMP_ARG);
+            gtconv_block<false, TPW, MS, Q, RS, RS>(x, tt, c, L, [] {} STAMP_ARG);
             if (k < 2) {
                 ht* dst = k == 0 ? en2h : en3h;
                 const int* ix = sI + I_ENST + (k + 1) * 16 + 4 * g;
 #pragma unroll
                 for (int i = 0; i < TPW; ++i) {   // scratch: the tile's own v^2 records (dead after the gate barrier)
-                    const f32x4 y = permute_via_lds(sS + tt.pp(i) * 16, ix, g, x[i]);
+                    const f32x4 y = permute_via_lds(sS + tt.pp(i) * RS, ix, g, x[i]);
                     if (tt.pp(i) < nfr * 33) stx<Q>(dst + (long)t0 * 528 + (unsigned)(tt.pp(i) * 16 + 4 * g), y);
                 }
             } else {
@@ -1134,7 +1188,7 @@ __global__ __launch_bounds__(NTHR) void k_encoder(const float* __restrict__ spec
         if constexpr (MS) {
             rings_store_ms<NS>(sH, sEH, stb, ST_ENC_H, ST_ENC_E, nlive, tid);
         } else {
-            rings_store(sH, sEH, stb + ST_ENC_H, stb + ST_ENC_E, tid);
+            rings_store(sH, sEH, stb + ST_ENC_H, stb + ST_ENC_E, tbase + T, tid);
         }
     }
     STAMP_OUT(SS, stamps)
@@ -1651,9 +1705,10 @@ __global__ __launch_bounds__(GTMS_WAVES * 64) void k_gtcn_ms(const float* __rest
 // rotate costs ~10 issue cycles on gfx950.)  Used when there is no stream state (offline forward);
 // the ring form above serves streaming calls, where a chunk may hold a single frame.
 constexpr int GB_LDS_P = 0;
-constexpr int GB_LDS_C = GB_LDS_P + GTCN_SIZE;                 // current chunk's y1: [33 bins][16 frames][16]
-constexpr int GB_LDS_H = GB_LDS_C + 33 * 16 * 16;              // history: block k: [33 bins][2d rows][16]
-constexpr int GB_LDS_FLOATS = GB_LDS_H + 33 * 30 * 16;
+constexpr int GB_RS = RS_WIDE;                                 // record pitch (conflict-free tile reads, see pl())
+constexpr int GB_LDS_C = GB_LDS_P + GTCN_SIZE;                 // current chunk's y1: [33 bins][16 frames][GB_RS]
+constexpr int GB_LDS_H = GB_LDS_C + 33 * 16 * GB_RS;           // history: block k: [33 bins][2d rows][GB_RS]
+constexpr int GB_LDS_FLOATS = GB_LDS_H + 33 * 30 * GB_RS;
 static_assert(GB_LDS_C % 4 == 0, "16B carve");
 static_assert(GB_LDS_FLOATS * 4 <= 160 * 1024, "band GTCN LDS budget");
 
@@ -1664,12 +1719,12 @@ template <int D, bool Q>
 __device__ __forceinline__ void tcn_block_band(f32x4 (&x)[TPW], const float* pk, float* cw, float* hw, bool live,
                                                const Lane& L) {
     const int n = L.n, g = L.g;
-    constexpr int M2D = 2 * D - 1, HR = 2 * D * 16;           // ring mask, floats per bin of the ring
+    constexpr int M2D = 2 * D - 1, HR = 2 * D * GB_RS, RS = GB_RS;   // ring mask, floats per bin of the ring
     const float a1 = pk[TCN_SLOPE] - 1.0f, a2 = pk[TCN_SLOPE + 1] - 1.0f, a3 = pk[TCN_SLOPE + 2] - 1.0f;
     f32x4 y1[TPW], acc[TPW], t1[TPW], t2[TPW];
     const long h_minus_c = hw - cw;
     // taps that lie before the chunk come from the ring; they do not depend on this block's y1
-    const int r1 = ((n - D) & M2D) * 16 + 4 * g, r2 = (n & M2D) * 16 + 4 * g;
+    const int r1 = ((n - D) & M2D) * RS + 4 * g, r2 = (n & M2D) * RS + 4 * g;
 #pragma unroll
     for (int i = 0; i < TPW; ++i) {
         t1[i] = ld4(hw + i * HR + r1);
@@ -1683,7 +1738,7 @@ __device__ __forceinline__ void tcn_block_band(f32x4 (&x)[TPW], const float* pk,
 #pragma unroll
         for (int i = 0; i < TPW; ++i) {
             y1[i] = rq<Q>(prelu4(acc[i], a1));
-            st4(cw + i * 256 + n * 16 + 4 * g, y1[i]);
+            st4(cw + i * 16 * RS + n * RS + 4 * g, y1[i]);
         }
     }
     // the in-chunk taps were written by lanes of this wave: LDS operations of a wave complete in order,
@@ -1696,10 +1751,10 @@ __device__ __forceinline__ void tcn_block_band(f32x4 (&x)[TPW], const float* pk,
                     w2 = ld4(pk + TCN_DW + 32 + 4 * g), B2 = ld4(pk + TCN_B2 + 4 * g);
         const f32x4 A = ld4(pk + TCN_A3 + n * 16 + 4 * g), B3 = ld4(pk + TCN_B3 + 4 * g);
         f32x4 y2[TPW];
-        const int c1 = (n >= D ? n - D : n) * 16 + 4 * g, c2 = (n >= 2 * D ? n - 2 * D : n) * 16 + 4 * g;
+        const int c1 = (n >= D ? n - D : n) * RS + 4 * g, c2 = (n >= 2 * D ? n - 2 * D : n) * RS + 4 * g;
 #pragma unroll
         for (int i = 0; i < TPW; ++i) {
-            const f32x4 u1 = ld4(cw + i * 256 + c1), u2 = ld4(cw + i * 256 + c2);
+            const f32x4 u1 = ld4(cw + i * 16 * RS + c1), u2 = ld4(cw + i * 16 * RS + c2);
             const f32x4 p1 = n >= D ? u1 : t1[i], p2 = n >= 2 * D ? u2 : t2[i];
             y2[i] = rq<Q>(prelu4(B2 + w0 * p2 + w1 * p1 + w2 * y1[i], a2));
             acc[i] = B3 + x[i];
@@ -1729,7 +1784,7 @@ __global__ __launch_bounds__(NTHR) void k_gtcn_band(const float* __restrict__ xi
     const int tid = L.tid, n = L.n, g = L.g;
     const int b = blockIdx.x;
     for (int i = tid; i < GTCN_SIZE; i += NTHR) sP[i] = P[i];
-    for (int i = tid; i < 33 * 30 * 4; i += NTHR) st4(sHh + i * 4, splat(0.f));   // zero history (frames < 0)
+    for (int i = tid; i < 33 * 30 * GB_RS / 4; i += NTHR) st4(sHh + i * 4, splat(0.f));   // zero history (frames < 0)
     __syncthreads();
     using ht = typename HandOff<Q>::t;
     const ht* xinh = reinterpret_cast<const ht*>(xin) + (long)b * T * 528;
@@ -1737,7 +1792,7 @@ __global__ __launch_bounds__(NTHR) void k_gtcn_band(const float* __restrict__ xi
     const ht* addh = addend ? reinterpret_cast<const ht*>(addend) + (long)b * T * 528 : nullptr;
     if (lens) T = min(T, 1 + (lens[b] >> 8));            // variable-length batch: this utterance's frames
     const int f0 = L.wave * TPW;                         // first bin of this wave
-    float* cw = sC + f0 * 256;
+    float* cw = sC + f0 * 16 * GB_RS;
     // the chunk's input is fetched one chunk ahead into registers (the waves run decoupled here, so an exposed
     // HBM latency at the top of every chunk is not hidden by a barrier wait elsewhere); the addend is only
     // needed at the store, so it is requested at the top of its own chunk
@@ -1763,10 +1818,10 @@ __global__ __launch_bounds__(NTHR) void k_gtcn_band(const float* __restrict__ xi
         int po = 0;
         asm volatile("" : "+v"(po));
         // block k's ring: [33 bins][2d rows][16], blocks back to back (2, 4, 8, 16 rows per bin)
-        tcn_block_band<1, Q>(x, sP + po + 0 * TCN_SIZE, cw, sHh + 33 * 0 * 16 + f0 * 2 * 16, live, L);
-        tcn_block_band<2, Q>(x, sP + po + 1 * TCN_SIZE, cw, sHh + 33 * 2 * 16 + f0 * 4 * 16, live, L);
-        tcn_block_band<4, Q>(x, sP + po + 2 * TCN_SIZE, cw, sHh + 33 * 6 * 16 + f0 * 8 * 16, live, L);
-        tcn_block_band<8, Q>(x, sP + po + 3 * TCN_SIZE, cw, sHh + 33 * 14 * 16 + f0 * 16 * 16, live, L);
+        tcn_block_band<1, Q>(x, sP + po + 0 * TCN_SIZE, cw, sHh + (33 * 0 + f0 * 2) * GB_RS, live, L);
+        tcn_block_band<2, Q>(x, sP + po + 1 * TCN_SIZE, cw, sHh + (33 * 2 + f0 * 4) * GB_RS, live, L);
+        tcn_block_band<4, Q>(x, sP + po + 2 * TCN_SIZE, cw, sHh + (33 * 6 + f0 * 8) * GB_RS, live, L);
+        tcn_block_band<8, Q>(x, sP + po + 3 * TCN_SIZE, cw, sHh + (33 * 14 + f0 * 16) * GB_RS, live, L);
 #pragma unroll
         for (int i = 0; i < TPW; ++i)
             if (live) stx<Q>(xouth + (unsigned)((tc * 33 + f0 + i) * 16 + 4 * g), addend ? rq<Q>(x[i] + ad[i]) : x[i]);
@@ -1781,20 +1836,27 @@ __global__ __launch_bounds__(NTHR) void k_gtcn_band(const float* __restrict__ xi
 constexpr int DEC_Z_ROW = F1 + 2;                                 // Z rows carry a zero record at both ends
 template <int RW, int NS, bool MS>
 struct DecLds {
+    static constexpr int RS = MS ? 16 : RS_WIDE;                  // record pitch of the h image W (see pl())
+    static constexpr int RSS = 16;                                // ... of the v^2 image S
     static constexpr int P = 0;                                   // the whole decoder segment
     static constexpr int I = P + D_BS_TAB;                        // (the ERB.bs table has its own region, BS)
     static constexpr int H = I + P_INTS;
-    static constexpr int EH = H + NS * RING_SET;
+    static constexpr int EH = H + (MS ? NS * RING_SET : 3 * RING_DENSE);
     static constexpr int TB = EH + NS * 48;                       // frame counter per row (ints; multi-stream mode)
     static constexpr int G = TB + 8;
     static constexpr int E = G + RW * 16 + RW * 8;                // (gates [RW][16] + y scratch [RW][8]); energies
-    static constexpr int A = E + (MS ? NS * 24 : (RW + 2) * 8);   // W + S, later Z
-    static constexpr int ASZ = RW * 35 * 16 + RW * 33 * 16;
-    static constexpr int M = A + ASZ;                             // mask m [2][RW][129] (+4: the 2-tap read of the last bin)
-    static constexpr int BS = M + ((2 * RW * F0 + 4 + 3) & ~3);   // per-bin ERB.bs table {first index, w0, w1, -}
+    // region A: W + S during the blocks; afterwards Z, and behind it the mask m [2][RW][129] (+4: the 2-tap read of
+    // the last bin) -- m is written after the last block has read S and is dead before the next chunk writes S
+    static constexpr int A = E + (MS ? NS * 24 : (RW + 2) * 8);
+    static constexpr int RWI = MS ? RW : RW + IMG_R0;             // image rows (two history rows in front of the chunk)
+    static constexpr int S = A + RWI * 35 * RS;
+    static constexpr int ZSZ = RW * DEC_Z_ROW * 16;
+    static constexpr int M = A + ZSZ;
+    static constexpr int MSZ = (2 * RW * F0 + 4 + 3) & ~3;
+    static constexpr int AEND = (S + RW * 33 * RSS) > (M + MSZ) ? (S + RW * 33 * RSS) : (M + MSZ);
+    static constexpr int BS = AEND;                               // per-bin ERB.bs table {first index, w0, w1, -}
     static constexpr int FLOATS = BS + NBINS * 4;
-    static_assert(RW * DEC_Z_ROW * 16 <= ASZ, "Z must fit in the W + S region");
-    static_assert(M % 4 == 0 && BS % 4 == 0 && D_BS_TAB % 4 == 0, "16B carve");
+    static_assert(M % 4 == 0 && BS % 4 == 0 && D_BS_TAB % 4 == 0 && S % 4 == 0, "16B carve");
     static_assert(FLOATS * 4 <= 160 * 1024, "decoder LDS budget");
     static_assert(DEC_SIZE % 4 == 0 && I % 4 == 0 && H % 4 == 0 && A % 4 == 0 && E % 4 == 0, "16B carve");
 };
@@ -1826,8 +1888,9 @@ __global__ __launch_bounds__(NTHR) void k_decoder(const float* __restrict__ xg, 
     float* sEH = smem + LD::EH;
     int* sTB = reinterpret_cast<int*>(smem + LD::TB);
     float* sG = smem + LD::G;
+    constexpr int RS = LD::RS;
     float* sW = smem + LD::A;
-    float* sS = sW + RW * 35 * 16;
+    float* sS = smem + LD::S;
     float* sZ = smem + LD::A;
     float* sM = smem + LD::M;
     float* sBS = smem + LD::BS;              // per-bin ERB.bs table {first index, w0, w1, -}, built by the host packer
@@ -1846,7 +1909,7 @@ __global__ __launch_bounds__(NTHR) void k_decoder(const float* __restrict__ xg, 
         if (tid < 8) sTB[tid] = tid < nlive ? reinterpret_cast<const int*>(stb + (long)tid * ST_FLOATS)[0] : 0;
     } else {
         tbase = stb ? reinterpret_cast<const int*>(stb)[0] : 0;
-        rings_load(sH, sEH, stb ? stb + ST_DEC_H : nullptr, stb ? stb + ST_DEC_E : nullptr, tid);
+        rings_load(sH, sEH, stb ? stb + ST_DEC_H : nullptr, stb ? stb + ST_DEC_E : nullptr, tbase, tid);
     }
     const Tiles<TPW> tt = make_tiles<TPW>(L);
     wg_barrier();
@@ -1885,7 +1948,7 @@ __global__ __launch_bounds__(NTHR) void k_decoder(const float* __restrict__ xg, 
         f32x4 x[TPW];
 #pragma unroll
         for (int i = 0; i < TPW; ++i) x[i] = xn[i];
-        zero_row_pads<RW>(sW, tid);  // region A was Z in the previous chunk (a barrier follows in the block)
+        zero_row_pads<LD::RWI, RS>(sW, tid);  // region A was Z in the previous chunk (a barrier follows in the block)
         STAMP(SS, 1)
         // All 256 workgroups run in lock step, so a load burst right before its use is a chip-wide HBM
         // burst (25 MB at once costs ~10 k cycles).  The inputs of the tail are therefore requested
@@ -1907,7 +1970,9 @@ __global__ __launch_bounds__(NTHR) void k_decoder(const float* __restrict__ xg, 
             c.pb = sP + D_BLK + j * GBD_SIZE;
             c.gA = c.pb + GB_DN_A;
             c.ib = sI + I_DEC_BLK + j * 16;
-            c.sW = sW; c.sHk = sH + j * (2 * 35 * 16); c.sS = sS; c.sG = sG; c.sEHk = sEH + j * 16;
+            c.sW = sW; c.sHk = sH + j * RING_DENSE; c.sS = sS; c.sG = sG; c.sEHk = sEH + j * 16;
+            c.sHtop = j == 0 ? sH : nullptr;          // region A was Z / m in the previous chunk
+            c.sHnext = j < 2 ? sH + (j + 1) * RING_DENSE : nullptr;
             c.sE = smem + LD::E;
             c.sY = sG + RW * 16;
             c.nfr = nfr; c.tabs = tbase + t0;
@@ -1919,7 +1984,7 @@ __global__ __launch_bounds__(NTHR) void k_decoder(const float* __restrict__ xg, 
             } else {
                 c.ms_roff = 0; c.ms_tb = 0;
             }
-            gtconv_block<true, TPW, MS, Q>(x, tt, c, L, hook STAMP_ARG);
+            gtconv_block<true, TPW, MS, Q, RS, LD::RSS>(x, tt, c, L, hook STAMP_ARG);
             if (DBG)
 #pragma unroll
                 for (int i = 0; i < TPW; ++i)
@@ -1943,7 +2008,7 @@ __global__ __launch_bounds__(NTHR) void k_decoder(const float* __restrict__ xg, 
         // ---- de_convs.3: gather form; input image in sW rows (pad columns are zero).  Every wave is
         // past the last block's tap reads (they precede that block's 2nd barrier), so sW is free.
 #pragma unroll
-        for (int i = 0; i < TPW; ++i) st4(sW + o35(tt, i, g), x[i]);
+        for (int i = 0; i < TPW; ++i) st4(sW + o35<RS, LD::RWI - RW>(tt, i, g), x[i]);
         STAMP(SS, 9)
         wg_barrier();
         STAMP(SS, 10)
@@ -1962,7 +2027,7 @@ __global__ __launch_bounds__(NTHR) void k_decoder(const float* __restrict__ xg, 
                 const f32x4 A0 = ld4(Ae), A1 = ld4(Ao);
 #pragma unroll
                 for (int i = 0; i < TPW; ++i) {
-                    const f32x4 xp = ld4(sW + o35(tt, i, g) + 16);   // input bin f+1
+                    const f32x4 xp = ld4(sW + o35<RS, LD::RWI - RW>(tt, i, g) + RS);   // input bin f+1
                     ae[i] = mm1<Q>(A0, xp, ae[i]);
                     ao[i] = mm1<Q>(A1, xp, ao[i]);
                 }
@@ -1979,7 +2044,7 @@ __global__ __launch_bounds__(NTHR) void k_decoder(const float* __restrict__ xg, 
                 const f32x4 A0 = ld4(Ae + 512);
 #pragma unroll
                 for (int i = 0; i < TPW; ++i) {
-                    const f32x4 xm = ld4(sW + o35(tt, i, g) - 16);   // input bin f-1
+                    const f32x4 xm = ld4(sW + o35<RS, LD::RWI - RW>(tt, i, g) - RS);   // input bin f-1
                     ae[i] = mm1<Q>(A0, xm, ae[i]);
                 }
             }
@@ -2119,7 +2184,7 @@ __global__ __launch_bounds__(NTHR) void k_decoder(const float* __restrict__ xg, 
             rings_store_ms<NS>(sH, sEH, stb, ST_DEC_H, ST_DEC_E, nlive, tid);
             if (tid < nlive) reinterpret_cast<int*>(stb + (long)tid * ST_FLOATS)[0] = (sTB[tid] + 1) & 0xFFFF;
         } else {
-            rings_store(sH, sEH, stb + ST_DEC_H, stb + ST_DEC_E, tid);
+            rings_store(sH, sEH, stb + ST_DEC_H, stb + ST_DEC_E, tbase + T, tid);
             if (tid == 0) reinterpret_cast<int*>(stb)[0] = (tbase + T) & 0xFFFF;  // frame counter (rings use mod 16)
         }
     }
@@ -2290,7 +2355,7 @@ int configure_kernels() {
         if (e != hipSuccess) return (int)e;
     }
     for (const void* f : enc) {
-        e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, ENC_LDS_FLOATS * 4);
+        e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, max(ENC_LDS_FLOATS, ENC_GT_LDS_FLOATS) * 4);
         if (e != hipSuccess) return (int)e;
     }
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_encoder<1, true, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -2355,7 +2420,8 @@ int launch_encoder(const float* spec, long sb, long sf, long st, int B, int T, c
                    const int* PI, float* en0, float* en1, float* en2, float* en3, float* en4, float* state,
                    unsigned long long* stamps, hipStream_t s, const Quant* q, const float* x1) {
 #define GT_ENC(TPWV, QV, FRV)                                                                                       \
-    hipLaunchKernelGGL((k_encoder<TPWV, false, QV, FRV>), dim3(B), dim3(NTHR), ENC_LDS_FLOATS * 4, s, spec, sb, sf, st, \
+    hipLaunchKernelGGL((k_encoder<TPWV, false, QV, FRV>), dim3(B), dim3(NTHR),                                      \
+                       (FRV ? ENC_LDS_FLOATS : ENC_GT_LDS_FLOATS) * 4, s, spec, sb, sf, st,                         \
                        T, lens, B, q ? q->in_step : 0.f, x1, PF, PI, en0, en1, en2, en3, en4, state, stamps)
     if (q) {   // int8-weight / fp16-activation variant: offline form only, the full-chunk instantiation
         if (!x1 || state) return (int)hipErrorInvalidValue;
