@@ -29,8 +29,9 @@ def lib():
     if _lib is not None:
         return _lib
     path = LIB_PATH
-    if os.environ.get("GTCRN_LIB_VARIANT") == "stamps":      # diagnostic build, tools/phase_profile.py only
-        path = LIB_PATH.replace(".so", "_stamps.so")
+    variant = os.environ.get("GTCRN_LIB_VARIANT")
+    if variant in ("stamps", "exp"):     # diagnostic builds: tools/phase_profile.py / tools/ab_bench.py only
+        path = LIB_PATH.replace(".so", f"_{variant}.so")
     if not os.path.exists(path):
         raise GtcrnError(
             f"{path} not found: run `python -c 'import __graft_entry__ as g; g.build()'` "

@@ -21,9 +21,11 @@ def _stale(target, deps):
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build_native(force=False, verbose=False, stamps=False):
+def build_native(force=False, verbose=False, stamps=False, exp=False):
     """stamps=True builds the diagnostic variant libgtcrn_micro_hip_stamps.so (-DGT_STAMPS: in-kernel
-    s_memtime phase stamps, used only by tools/phase_profile.py; never loaded by the product path)."""
+    s_memtime phase stamps, used only by tools/phase_profile.py; never loaded by the product path).
+    exp=True builds libgtcrn_micro_hip_exp.so with -DGT_EXP: whatever kernel experiment currently sits behind
+    `#ifdef GT_EXP`, timed against the default build on the same GPU by tools/ab_bench.py."""
     deps = [os.path.join(CSRC, f) for f in SOURCES + HEADERS] + [os.path.abspath(__file__)]   # the flags live here
     objs = []
     common = ["-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-result"]
@@ -42,6 +44,10 @@ def build_native(force=False, verbose=False, stamps=False):
         common.append("-DGT_STAMPS")
         suffix = ".stamps"
         lib = LIB.replace(".so", "_stamps.so")
+    elif exp:
+        common.append("-DGT_EXP")
+        suffix = ".exp"
+        lib = LIB.replace(".so", "_exp.so")
     for src in SOURCES:
         obj = os.path.join(CSRC, os.path.splitext(src)[0] + suffix + ".o")
         objs.append(obj)

@@ -58,6 +58,10 @@ template <int RS = 16>
 __device__ __forceinline__ int pl(int pos, int g) { return pos * RS + 4 * g; }
 __device__ __forceinline__ int pls(int pos, int slot) { return pos * 16 + slot; }
 
+// float offset of lane (n, g)'s A-operand fragment inside a 16x16 slot matrix: columns 4g..4g+3 of row n; the packer
+// stores rows 4..7 and 12..15 with their halves exchanged so that the ds_read_b128 is bank-conflict free (pack.cpp)
+__device__ __forceinline__ int arow(int n, int g) { return n * 16 + 4 * (g ^ ((n >> 1) & 2)); }
+
 __device__ __forceinline__ f32x4 mfma(float a, float b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
 }
@@ -579,7 +583,7 @@ __device__ __forceinline__ void gtconv_block(f32x4 (&x)[TPW], const Tiles<TPW>& 
     //      ring update re-read it: one ds_read_b128 each instead of 12 registers held across the phase) ----
     {
         f32x4 h[TPW];
-        const f32x4 A = ld4(c.pb + GB_PC1_A + n * 16 + 4 * g), Bv = ld4(c.pb + GB_PC1_B + 4 * g);
+        const f32x4 A = ld4(c.pb + GB_PC1_A + arow(n, g)), Bv = ld4(c.pb + GB_PC1_B + 4 * g);
 #pragma unroll
         for (int i = 0; i < TPW; ++i) h[i] = Bv;
         mm16<TPW, Q>(A, x, h);
@@ -593,7 +597,7 @@ __device__ __forceinline__ void gtconv_block(f32x4 (&x)[TPW], const Tiles<TPW>& 
     //      MFMA dependency gaps); v^2 is reduced over the tile's 16 positions in registers -----------
     {
         const f32x4 Bd = ld4(c.pb + GB_DW_B + 4 * g);
-        const f32x4 A2 = ld4(c.pb + GB_PC2_A + n * 16 + 4 * g), B2 = ld4(c.pb + GB_PC2_B + 4 * g);
+        const f32x4 A2 = ld4(c.pb + GB_PC2_A + arow(n, g)), B2 = ld4(c.pb + GB_PC2_B + 4 * g);
         const f32x4 keep = ld4(c.pb + GB_KEEP + 4 * g);
         if constexpr (!DENSE) {
             // depthwise 3x3, kernel-row major: the three weights of a kernel row stay in registers for all of the
@@ -638,7 +642,7 @@ __device__ __forceinline__ void gtconv_block(f32x4 (&x)[TPW], const Tiles<TPW>& 
             for (int kt = 0; kt < 3; ++kt) {
 #pragma unroll
                 for (int kf = 0; kf < 3; ++kf) {
-                    const f32x4 A = ld4(c.gA + (kt * 3 + kf) * 256 + n * 16 + 4 * g);
+                    const f32x4 A = ld4(c.gA + (kt * 3 + kf) * 256 + arow(n, g));
                     const int back = kt, df = 1 - kf;        // decoder (transposed): tap (t-kt, f+1-kf)
 #pragma unroll
                     for (int i = 0; i < TPW; ++i) {
@@ -1083,7 +1087,7 @@ __global__ __launch_bounds__(NTHR) void k_encoder(const float* __restrict__ spec
         STAMP(SS, 2)
         // ---- C: en_convs.0 = Conv2d(3,16,(1,5),stride (1,2),pad (0,2)) + BN + PReLU --------------
         {
-            const f32x4 A = ld4(sP + E_EN0_A + n * 16 + 4 * g), Bv = ld4(sP + E_EN0_B + 4 * g);
+            const f32x4 A = ld4(sP + E_EN0_A + arow(n, g)), Bv = ld4(sP + E_EN0_B + 4 * g);
             const float a = sP[E_EN0_S] - 1.0f;
             int off[4];
             int go = g;
@@ -1121,7 +1125,7 @@ __global__ __launch_bounds__(NTHR) void k_encoder(const float* __restrict__ spec
             for (int i = 0; i < TPW; ++i) x[i] = Bv;
 #pragma unroll
             for (int k = 0; k < 5; ++k) {
-                const f32x4 A = ld4(sP + E_EN1_A + k * 256 + n * 16 + 4 * g);
+                const f32x4 A = ld4(sP + E_EN1_A + k * 256 + arow(n, g));
 #pragma unroll
                 for (int i = 0; i < TPW; ++i) {
                     const f32x4 tap = ld4(sE0 + pl(tt.tl[i] * ENC_E0_ROW + 2 * tt.ff[i], g) + k * 16);
@@ -1399,7 +1403,7 @@ __global__ __launch_bounds__(FR_NT, 4) void k_front(const float* __restrict__ in
             wave_lds_sync();
             // ---- C: en_convs.0: 65 positions = 5 tiles (the last one holds a single valid position) ---------------
             {
-                const f32x4 Am = ld4(sP + E_EN0_A + n * 16 + 4 * g), Bv = ld4(sP + E_EN0_B + 4 * g);
+                const f32x4 Am = ld4(sP + E_EN0_A + arow(n, g)), Bv = ld4(sP + E_EN0_B + 4 * g);
                 const float a = sP[E_EN0_S] - 1.0f;
                 int off[4];
 #pragma unroll
@@ -1443,7 +1447,7 @@ __global__ __launch_bounds__(FR_NT, 4) void k_front(const float* __restrict__ in
                 }
 #pragma unroll
                 for (int k = 0; k < 5; ++k) {
-                    const f32x4 Am = ld4(sP + E_EN1_A + k * 256 + n * 16 + 4 * g);
+                    const f32x4 Am = ld4(sP + E_EN1_A + k * 256 + arow(n, g));
 #pragma unroll
                     for (int i = 0; i < 3; ++i) {
                         const f32x4 tap = ld4(sE0 + pl(2 * ffv[i], g) + k * 16);
@@ -1505,7 +1509,7 @@ __device__ __forceinline__ void tcn_block(f32x4 (&x)[TPW], const float* pk, floa
         tp2[i] = ld4(sHk + r2[i]);  // frame t-2d (used when t-2d lies before the chunk)
     }
     {
-        const f32x4 A = ld4(pk + TCN_A1 + n * 16 + 4 * g), Bv = ld4(pk + TCN_B1 + 4 * g);
+        const f32x4 A = ld4(pk + TCN_A1 + arow(n, g)), Bv = ld4(pk + TCN_B1 + 4 * g);
 #pragma unroll
         for (int i = 0; i < TPW; ++i) acc[i] = Bv;
         mm16<TPW>(A, x, acc);
@@ -1521,7 +1525,7 @@ __device__ __forceinline__ void tcn_block(f32x4 (&x)[TPW], const float* pk, floa
     {
         const f32x4 w0 = ld4(pk + TCN_DW + 4 * g), w1 = ld4(pk + TCN_DW + 16 + 4 * g),
                     w2 = ld4(pk + TCN_DW + 32 + 4 * g), B2 = ld4(pk + TCN_B2 + 4 * g);
-        const f32x4 A = ld4(pk + TCN_A3 + n * 16 + 4 * g), B3 = ld4(pk + TCN_B3 + 4 * g);
+        const f32x4 A = ld4(pk + TCN_A3 + arow(n, g)), B3 = ld4(pk + TCN_B3 + 4 * g);
         f32x4 y2[TPW];
 #pragma unroll
         for (int i = 0; i < TPW; ++i) {
@@ -1626,7 +1630,7 @@ __device__ __forceinline__ void tcn_block_ms(f32x4& x, const float* pk, const f3
     const float a1 = pk[TCN_SLOPE] - 1.0f, a2 = pk[TCN_SLOPE + 1] - 1.0f, a3 = pk[TCN_SLOPE + 2] - 1.0f;
     f32x4 y1[1], acc[1], xx[1] = {x};
     {
-        const f32x4 A = ld4(pk + TCN_A1 + n * 16 + 4 * g), Bv = ld4(pk + TCN_B1 + 4 * g);
+        const f32x4 A = ld4(pk + TCN_A1 + arow(n, g)), Bv = ld4(pk + TCN_B1 + 4 * g);
         acc[0] = Bv;
         mm16<1>(A, xx, acc);
         y1[0] = prelu4(acc[0], a1);
@@ -1634,7 +1638,7 @@ __device__ __forceinline__ void tcn_block_ms(f32x4& x, const float* pk, const f3
     {
         const f32x4 w0 = ld4(pk + TCN_DW + 4 * g), w1 = ld4(pk + TCN_DW + 16 + 4 * g),
                     w2 = ld4(pk + TCN_DW + 32 + 4 * g), B2 = ld4(pk + TCN_B2 + 4 * g);
-        const f32x4 A = ld4(pk + TCN_A3 + n * 16 + 4 * g), B3 = ld4(pk + TCN_B3 + 4 * g);
+        const f32x4 A = ld4(pk + TCN_A3 + arow(n, g)), B3 = ld4(pk + TCN_B3 + 4 * g);
         f32x4 y2[1];
         y2[0] = prelu4(B2 + w0 * t2 + w1 * t1 + w2 * y1[0], a2);
         acc[0] = B3 + x;
@@ -1731,7 +1735,7 @@ __device__ __forceinline__ void tcn_block_band(f32x4 (&x)[TPW], const float* pk,
         t2[i] = ld4(hw + i * HR + r2);
     }
     {
-        const f32x4 A = ld4(pk + TCN_A1 + n * 16 + 4 * g), Bv = ld4(pk + TCN_B1 + 4 * g);
+        const f32x4 A = ld4(pk + TCN_A1 + arow(n, g)), Bv = ld4(pk + TCN_B1 + 4 * g);
 #pragma unroll
         for (int i = 0; i < TPW; ++i) acc[i] = Bv;
         mm16<TPW, Q>(A, x, acc);
@@ -1749,7 +1753,7 @@ __device__ __forceinline__ void tcn_block_band(f32x4 (&x)[TPW], const float* pk,
     {
         const f32x4 w0 = ld4(pk + TCN_DW + 4 * g), w1 = ld4(pk + TCN_DW + 16 + 4 * g),
                     w2 = ld4(pk + TCN_DW + 32 + 4 * g), B2 = ld4(pk + TCN_B2 + 4 * g);
-        const f32x4 A = ld4(pk + TCN_A3 + n * 16 + 4 * g), B3 = ld4(pk + TCN_B3 + 4 * g);
+        const f32x4 A = ld4(pk + TCN_A3 + arow(n, g)), B3 = ld4(pk + TCN_B3 + 4 * g);
         f32x4 y2[TPW];
         const int c1 = (n >= D ? n - D : n) * RS + 4 * g, c2 = (n >= 2 * D ? n - 2 * D : n) * RS + 4 * g;
 #pragma unroll
@@ -2017,8 +2021,8 @@ __global__ __launch_bounds__(NTHR) void k_decoder(const float* __restrict__ xg, 
             const f32x4 Bv = ld4(sP + D_DE3_B + 4 * g);
             const float a = sP[D_DE3_S] - 1.0f;
             // even output 2m: k=0 <- x[m+1], k=2 <- x[m], k=4 <- x[m-1]; odd 2m+1: k=1 <- x[m+1], k=3 <- x[m]
-            const float* Ae = sP + D_DE3_AE + n * 16 + 4 * g;
-            const float* Ao = sP + D_DE3_AO + n * 16 + 4 * g;
+            const float* Ae = sP + D_DE3_AE + arow(n, g);
+            const float* Ao = sP + D_DE3_AO + arow(n, g);
             // tap major over the three input bins f+1, f, f-1: the five slot matrices are read once per wave
             f32x4 ae[TPW], ao[TPW];
 #pragma unroll
@@ -2048,7 +2052,7 @@ __global__ __launch_bounds__(NTHR) void k_decoder(const float* __restrict__ xg, 
                     ae[i] = mm1<Q>(A0, xm, ae[i]);
                 }
             }
-            const f32x4 A4 = ld4(sP + D_DE4_A + n * 16 + 4 * g);
+            const f32x4 A4 = ld4(sP + D_DE4_A + arow(n, g));
 #pragma unroll
             for (int i = 0; i < TPW; ++i) {
                 f32x4 e2 = rq<Q>(prelu4(ae[i], a)), o2 = rq<Q>(prelu4(ao[i], a));

@@ -187,6 +187,41 @@ static void store_table(const Perm& producer, const Perm& consumer, int* out) {
     for (int s = 0; s < 16; ++s) out[s] = consumer.slot_of(producer.l[s]);
 }
 
+// Every 16x16 A-operand matrix is read by the kernels as one ds_read_b128 per lane: lane (n, g) takes columns
+// 4g..4g+3 of row n.  With plain 64-byte rows the eight lanes of one slot group inside a ds_read_b128 lane group
+// ({0-3,12-15,20-27}, ...) land on four 16-byte bank slots (2-way conflict).  Rows 4..7 and 12..15 are therefore
+// stored with their two 32-byte halves exchanged (quarter q of row n sits at q ^ 2 when bit 2 of n is set), which
+// puts the sixteen lanes of every group on sixteen different slots; the kernels read quarter g ^ ((n >> 1) & 2)
+// (kernels.hip: arow).  A permutation inside a row: per-row quantisation groups are unaffected.
+static void swizzle_matrix(float* M) {
+    for (int n = 0; n < 16; ++n)
+        if ((n >> 2) & 1)
+            for (int c = 0; c < 8; ++c) std::swap(M[n * 16 + c], M[n * 16 + 8 + c]);
+}
+static void swizzle_matrices(float* F) {
+    float* E = F + P_ENC;
+    float* D = F + P_DEC;
+    swizzle_matrix(E + E_EN0_A);
+    for (int k = 0; k < 5; ++k) swizzle_matrix(E + E_EN1_A + k * 256);
+    for (int k = 0; k < 3; ++k) {
+        swizzle_matrix(E + E_BLK + k * GB_SIZE + GB_PC1_A);
+        swizzle_matrix(E + E_BLK + k * GB_SIZE + GB_PC2_A);
+    }
+    for (int t = 0; t < 8; ++t) {
+        swizzle_matrix(F + P_GTCN + t * TCN_SIZE + TCN_A1);
+        swizzle_matrix(F + P_GTCN + t * TCN_SIZE + TCN_A3);
+    }
+    for (int j = 0; j < 3; ++j) {
+        float* B = D + D_BLK + j * GBD_SIZE;
+        swizzle_matrix(B + GB_PC1_A);
+        swizzle_matrix(B + GB_PC2_A);
+        for (int t = 0; t < 9; ++t) swizzle_matrix(B + GB_DN_A + t * 256);
+    }
+    for (int a = 0; a < 3; ++a) swizzle_matrix(D + D_DE3_AE + a * 256);
+    for (int a = 0; a < 2; ++a) swizzle_matrix(D + D_DE3_AO + a * 256);
+    swizzle_matrix(D + D_DE4_A);
+}
+
 }  // namespace
 
 int pack_params(const float* params, long n, float* F, int* I, std::string& err) {
@@ -331,6 +366,7 @@ int pack_params(const float* params, long n, float* F, int* I, std::string& err)
     for (int q = 0; q < 3; ++q) stored[1 + q] = perm[7 - q];
     for (int t = 0; t < 9; ++t)
         for (int s = 0; s < 16; ++s) I[I_PERM + t * 16 + s] = stored[t].l[s];
+    swizzle_matrices(F);
     return 0;
 }
 

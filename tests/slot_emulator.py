@@ -27,7 +27,12 @@ def prelu(v, a):
 
 
 def _mat(buf, off):
-    return buf[off:off + 256].reshape(16, 16)
+    """16x16 slot matrix at float offset `off`; the packer stores rows 4..7 and 12..15 with their two 8-float halves
+    exchanged (bank-conflict-free A-fragment reads, csrc/pack.cpp swizzle_matrix): undone here."""
+    m = buf[off:off + 256].reshape(16, 16).copy()
+    rows = [n for n in range(16) if (n >> 2) & 1]
+    m[rows] = np.concatenate([m[rows, 8:], m[rows, :8]], axis=1)
+    return m
 
 
 def gtconv(x, pb, ib, dense):
