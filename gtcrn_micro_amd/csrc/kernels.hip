@@ -843,13 +843,15 @@ __device__ __forceinline__ f32x4 permute_via_lds(float* scratch_rec, const int* 
 // the slot order of the decoder stage that consumes them (layout.h I_ENST), en4 in its own order.
 // LDS carve of k_encoder: RW image rows (TC, or MS_ROWS in multi-stream mode), NS ring sets (streams per workgroup)
 constexpr int ENC_E0_ROW = 69;
+constexpr int ENC_I_SKIP = I_ENC_BLK - I_BS_LO;   // integer tables the encoder never reads (not copied to LDS)
+static_assert(I_BS_LO == 128 && I_BS_N + 192 == I_ENC_BLK && ENC_I_SKIP % 4 == 0, "integer table layout");
 constexpr int EB_ROW = 131, F0_ROW = 136;
 template <int RW, int NS, bool MS, bool FRONT>
 struct EncLds {
     static constexpr int RS = FRONT ? 16 : RS_WIDE;            // record pitch of the block images W, S and the h rings
     static constexpr int P = 0;
     static constexpr int I = P + ENC_SIZE;
-    static constexpr int H = I + P_INTS;
+    static constexpr int H = I + P_INTS - ENC_I_SKIP;
     static constexpr int EH = H + (MS ? NS * RING_SET : 3 * RING_DENSE);
     static constexpr int TB = EH + NS * 48;                    // frame counter per row (ints; multi-stream mode)
     static constexpr int G = TB + 8;
@@ -910,7 +912,9 @@ __global__ __launch_bounds__(NTHR) void k_encoder(const float* __restrict__ spec
     const int b = blockIdx.x;
 
     for (int i = tid + (FRONT ? 0 : E_BLK); i < ENC_SIZE; i += NTHR) sP[i] = PF[P_ENC + i];
-    for (int i = tid; i < P_INTS; i += NTHR) sI[i] = PI[i];
+    // the integer tables without the decoder-side ERB.bs index ranges (I_BS_LO, I_BS_N): [0, I_BS_LO) stays in place,
+    // [I_ENC_BLK, P_INTS) moves down by ENC_I_SKIP
+    for (int i = tid; i < P_INTS - ENC_I_SKIP; i += NTHR) sI[i] = PI[i < I_BS_LO ? i : i + ENC_I_SKIP];
     // (the pad entries of EB / F0 are zeroed at the top of every chunk; nothing else of that region is read unwritten)
     float* stb = state ? state + (long)b * NS * ST_FLOATS : nullptr;    // first stream of this workgroup
     const int nlive = MS ? min(NS, NB - b * NS) : 1;
@@ -1119,7 +1123,7 @@ __global__ __launch_bounds__(NTHR) void k_encoder(const float* __restrict__ spec
         {
             const f32x4 Bv = ld4(sP + E_EN1_B + 4 * g);
             const float a = sP[E_EN1_S] - 1.0f;
-            const int* ix = sI + I_ENST + 0 * 16 + 4 * g;
+            const int* ix = sI + I_ENST - ENC_I_SKIP + 0 * 16 + 4 * g;
             // tap major: each of the five 16x16 slot matrices is read from LDS once per wave, one MFMA chain per tile
 #pragma unroll
             for (int i = 0; i < TPW; ++i) x[i] = Bv;
@@ -1151,7 +1155,7 @@ __global__ __launch_bounds__(NTHR) void k_encoder(const float* __restrict__ spec
             BlockCtx c;
             c.pb = sP + E_BLK + k * GB_SIZE;
             c.gA = nullptr;
-            c.ib = sI + I_ENC_BLK + k * 16;
+            c.ib = sI + I_ENC_BLK - ENC_I_SKIP + k * 16;
             c.sW = sW; c.sHk = sH + k * RING_DENSE; c.sS = sS; c.sG = sG; c.sEHk = sEH + k * 16;
             // FRONT: region A held the staged spectrogram / E0 until this chunk's phase D, so block 0 fetches its
             // history itself; otherwise the image is only ever W and block 2 prepares the next chunk's block 0
@@ -1171,7 +1175,7 @@ __global__ __launch_bounds__(NTHR) void k_encoder(const float* __restrict__ spec
             gtconv_block<false, TPW, MS, Q, RS, RS>(x, tt, c, L, [] {} STAMP_ARG);
             if (k < 2) {
                 ht* dst = k == 0 ? en2h : en3h;
-                const int* ix = sI + I_ENST + (k + 1) * 16 + 4 * g;
+                const int* ix = sI + I_ENST - ENC_I_SKIP + (k + 1) * 16 + 4 * g;
 #pragma unroll
                 for (int i = 0; i < TPW; ++i) {   // scratch: the tile's own v^2 records (dead after the gate barrier)
                     const f32x4 y = permute_via_lds(sS + tt.pp(i) * RS, ix, g, x[i]);
@@ -1838,13 +1842,14 @@ __global__ __launch_bounds__(NTHR) void k_gtcn_band(const float* __restrict__ xi
 // de_convs.4 (16 -> 2, 65 -> 129, Tanh) in scatter form, then ERB.bs (:69-73), the complex
 // ratio mask (:478-482) and the output permute (:529-530).
 constexpr int DEC_Z_ROW = F1 + 2;                                 // Z rows carry a zero record at both ends
+constexpr int DEC_ZS = 12;                                        // floats per Z record (10 live slots)
 template <int RW, int NS, bool MS>
 struct DecLds {
     static constexpr int RS = MS ? 16 : RS_WIDE;                  // record pitch of the h image W (see pl())
     static constexpr int RSS = 16;                                // ... of the v^2 image S
-    static constexpr int P = 0;                                   // the whole decoder segment
-    static constexpr int I = P + D_BS_TAB;                        // (the ERB.bs table has its own region, BS)
-    static constexpr int H = I + P_INTS;
+    static constexpr int P = 0;                                   // the decoder segment up to the ERB.bs weights
+    static constexpr int I = P + D_BS_W;                          // (the kernel-ready ERB.bs table has its own region, BS)
+    static constexpr int H = I + 48;                              // ints: the three blocks' slot tables (I_DEC_BLK)
     static constexpr int EH = H + (MS ? NS * RING_SET : 3 * RING_DENSE);
     static constexpr int TB = EH + NS * 48;                       // frame counter per row (ints; multi-stream mode)
     static constexpr int G = TB + 8;
@@ -1854,13 +1859,13 @@ struct DecLds {
     static constexpr int A = E + (MS ? NS * 24 : (RW + 2) * 8);
     static constexpr int RWI = MS ? RW : RW + IMG_R0;             // image rows (two history rows in front of the chunk)
     static constexpr int S = A + RWI * 35 * RS;
-    static constexpr int ZSZ = RW * DEC_Z_ROW * 16;
+    static constexpr int ZSZ = RW * DEC_Z_ROW * DEC_ZS;
     static constexpr int M = A + ZSZ;
     static constexpr int MSZ = (2 * RW * F0 + 4 + 3) & ~3;
     static constexpr int AEND = (S + RW * 33 * RSS) > (M + MSZ) ? (S + RW * 33 * RSS) : (M + MSZ);
     static constexpr int BS = AEND;                               // per-bin ERB.bs table {first index, w0, w1, -}
     static constexpr int FLOATS = BS + NBINS * 4;
-    static_assert(M % 4 == 0 && BS % 4 == 0 && D_BS_TAB % 4 == 0 && S % 4 == 0, "16B carve");
+    static_assert(M % 4 == 0 && BS % 4 == 0 && D_BS_W % 4 == 0 && D_BS_TAB % 4 == 0 && S % 4 == 0, "16B carve");
     static_assert(FLOATS * 4 <= 160 * 1024, "decoder LDS budget");
     static_assert(DEC_SIZE % 4 == 0 && I % 4 == 0 && H % 4 == 0 && A % 4 == 0 && E % 4 == 0, "16B carve");
 };
@@ -1896,13 +1901,14 @@ __global__ __launch_bounds__(NTHR) void k_decoder(const float* __restrict__ xg, 
     float* sW = smem + LD::A;
     float* sS = smem + LD::S;
     float* sZ = smem + LD::A;
+    constexpr int ZS = DEC_ZS;
     float* sM = smem + LD::M;
     float* sBS = smem + LD::BS;              // per-bin ERB.bs table {first index, w0, w1, -}, built by the host packer
     const Lane L = lane_info();
     const int tid = L.tid, n = L.n, g = L.g;
     const int b = blockIdx.x;
-    for (int i = tid; i < D_BS_TAB; i += NTHR) sP[i] = PF[P_DEC + i];
-    for (int i = tid; i < P_INTS; i += NTHR) sI[i] = PI[i];
+    for (int i = tid; i < D_BS_W; i += NTHR) sP[i] = PF[P_DEC + i];
+    if (tid < 48) sI[tid] = PI[I_DEC_BLK + tid];
     for (int f = tid; f < NBINS; f += NTHR) st4(sBS + f * 4, ld4(PF + P_DEC + D_BS_TAB + f * 4));
     if (tid < 4) sM[2 * RW * F0 + tid] = 0.f;
     float* stb = state ? state + (long)b * NS * ST_FLOATS : nullptr;    // first stream of this workgroup
@@ -1973,7 +1979,7 @@ __global__ __launch_bounds__(NTHR) void k_decoder(const float* __restrict__ xg, 
             BlockCtx c;
             c.pb = sP + D_BLK + j * GBD_SIZE;
             c.gA = c.pb + GB_DN_A;
-            c.ib = sI + I_DEC_BLK + j * 16;
+            c.ib = sI + j * 16;
             c.sW = sW; c.sHk = sH + j * RING_DENSE; c.sS = sS; c.sG = sG; c.sEHk = sEH + j * 16;
             c.sHtop = j == 0 ? sH : nullptr;          // region A was Z / m in the previous chunk
             c.sHnext = j < 2 ? sH + (j + 1) * RING_DENSE : nullptr;
@@ -2070,18 +2076,23 @@ __global__ __launch_bounds__(NTHR) void k_decoder(const float* __restrict__ xg, 
         }
         wg_barrier();  // all taps of sW read: region A becomes Z[tl][65][16]
         STAMP(SS, 11)
+        // Z records hold the 10 live rows of the de_convs.4 slot matrix (+2 zero ones): 12 floats, written by the slot
+        // groups g < 3.  The 48-byte pitch spreads the records over the banks (the de_convs.4 gather below reads them
+        // with 4-byte loads: a 64-byte pitch put 32 lanes on four banks)
 #pragma unroll
         for (int i = 0; i < TPW; ++i) {
-            st4(sZ + pl(tt.tl[i] * DEC_Z_ROW + 1 + 2 * tt.ff[i], g), ze[i]);
-            if (tt.ff[i] < 32) st4(sZ + pl(tt.tl[i] * DEC_Z_ROW + 2 + 2 * tt.ff[i], g), zo[i]);
+            if (g < 3) {
+                st4(sZ + (tt.tl[i] * DEC_Z_ROW + 1 + 2 * tt.ff[i]) * ZS + 4 * g, ze[i]);
+                if (tt.ff[i] < 32) st4(sZ + (tt.tl[i] * DEC_Z_ROW + 2 + 2 * tt.ff[i]) * ZS + 4 * g, zo[i]);
+            }
         }
         {   // zero records at both ends of every Z row (region A held W / S)
             int tz = tid;
             asm volatile("" : "+v"(tz));
-            if (tz < RW * 2 * 4) {
+            if (tz < RW * 2 * 4 && (tz & 3) < 3) {
                 float z = 0.f;
                 asm volatile("" : "+v"(z));
-                st4(sZ + pl((tz >> 3) * DEC_Z_ROW + ((tz >> 2) & 1) * (DEC_Z_ROW - 1), tz & 3), splat(z));
+                st4(sZ + ((tz >> 3) * DEC_Z_ROW + ((tz >> 2) & 1) * (DEC_Z_ROW - 1)) * ZS + 4 * (tz & 3), splat(z));
             }
         }
         // the input spectrogram for the mask is fetched here so that its latency hides behind the
@@ -2123,9 +2134,9 @@ __global__ __launch_bounds__(NTHR) void k_decoder(const float* __restrict__ xg, 
             for (int idx = tz; idx < 2 * nfr * F0; idx += NTHR) {
                 const int o = ot >= nfr ? 1 : 0, tq = ot - o * nfr;
                 const int par = fq & 1, m = fq >> 1;
-                const float* zr = sZ + (tq * DEC_Z_ROW + 1 + m) * 16;
-                const float sum = sP[D_DE4_B + o] + zr[16 + o * 5 + par] + zr[o * 5 + 2 + par] +
-                                  zr[-16 + (par ? 10 : o * 5 + 4)];
+                const float* zr = sZ + (tq * DEC_Z_ROW + 1 + m) * ZS;
+                const float sum = sP[D_DE4_B + o] + zr[ZS + o * 5 + par] + zr[o * 5 + 2 + par] +
+                                  zr[-ZS + (par ? 10 : o * 5 + 4)];
                 sM[(o * RW + tq) * F0 + fq] = rq1<Q>(fast_tanh(sum));
                 fq += 59;
                 ot += 5;
