@@ -53,11 +53,11 @@ int launch_istft_adjoint(const float* gwave, int B, int T, const float* win, con
                          long sf, long st, hipStream_t s);
 int launch_encoder(const float* spec, long sb, long sf, long st, int B, int T, const int* lens, const float* PF,
                    const int* PI, float* en0, float* en1, float* en2, float* en3, float* en4, float* state,
-                   unsigned long long* stamps, hipStream_t s, const Quant* q = nullptr, const float* x1 = nullptr);
+                   unsigned long long* stamps, hipStream_t s, const Quant* q = nullptr, bool front_done = false);
 // offline front end: STFT (wave) or caller spectrogram -> features, ERB, SFE, en_conv0, en_conv1 (see kernels.hip)
 int launch_front(const float* wave, long L, const float* spec_in, long isb, long isf, long ist, int B, int T,
                  const int* lens, const float* win, const float* twid, const float* PF, const int* PI, float* spec_out,
-                 float* en0, float* en1p, float* en1n, hipStream_t s, const Quant* q = nullptr);
+                 float* en0, float* en1p, hipStream_t s, const Quant* q = nullptr);
 int launch_gtcn(const float* xin, float* xout, const float* P, int B, int T, float* state, int st_off,
                 const float* addend, unsigned long long* stamps, hipStream_t s);
 int launch_gtcn_ms(const float* xin, float* xout1, float* xout2, const float* P, int B, float* state, hipStream_t s);

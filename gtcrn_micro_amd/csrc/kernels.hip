@@ -827,6 +827,9 @@ __device__ __forceinline__ void rings_store(const float* sH, const float* sEH, f
 // quarter and issues ONE coalesced 16-byte global store.  (Scattering 4-byte global stores instead
 // writes 64 partial lines per instruction and was ~3 k cycles per block.)  The four lanes of a
 // position belong to one wave, LDS operations of a wave complete in order, so no barrier is needed.
+// Scratch records PERM_RS = 20 floats apart: the 4-byte scatters of 32 lanes (16 positions x 2 slot groups) then spread
+// over the banks (2-way); at the 16-float pitch of a dense record image they pile up on four banks (8-way).
+constexpr int PERM_RS = 20;
 __device__ __forceinline__ f32x4 permute_via_lds(float* scratch_rec, const int* idx4, int g, f32x4 v) {
     scratch_rec[idx4[0]] = v[0];
     scratch_rec[idx4[1]] = v[1];
@@ -834,6 +837,14 @@ __device__ __forceinline__ f32x4 permute_via_lds(float* scratch_rec, const int* 
     scratch_rec[idx4[3]] = v[3];
     wave_lds_sync();
     return ld4(scratch_rec + 4 * g);
+}
+
+// The inverse: a record held in its consumer's slot order -> this lane's own slots (the same index table).
+__device__ __forceinline__ f32x4 unpermute_via_lds(float* scratch_rec, const int* idx4, int g, f32x4 y) {
+    st4(scratch_rec + 4 * g, y);
+    wave_lds_sync();
+    f32x4 v = {scratch_rec[idx4[0]], scratch_rec[idx4[1]], scratch_rec[idx4[2]], scratch_rec[idx4[3]]};
+    return v;
 }
 
 // =============================================================================== encoder
@@ -878,11 +889,10 @@ constexpr int ENC_MS_LDS_FLOATS = EncLds<MS_ROWS, MS_STREAMS, true, true>::FLOAT
 // Q: int8-weight / fp16-activation variant (PF then holds the quantised weights); qin > 0 additionally passes the
 // input spectrogram through the int8 boundary of the tflite path (x_q = round(x / qin), tflite_infer.py:79-82).
 // FRONT = false (offline calls): k_front has already produced en0 and en1; this kernel reads en1 in its own slot order
-// (x1) and runs only the three causal GTConv blocks.
+// and runs only the three causal GTConv blocks.
 template <int TPW, bool MS, bool Q, bool FRONT>
 __global__ __launch_bounds__(NTHR) void k_encoder(const float* __restrict__ spec, long sb, long sf, long st, int T,
                                                  const int* __restrict__ lens, int NB, float qin,
-                                                 const float* __restrict__ x1,
                                                  const float* __restrict__ PF, const int* __restrict__ PI,
                                                  float* __restrict__ en0, float* __restrict__ en1,
                                                  float* __restrict__ en2, float* __restrict__ en3,
@@ -939,7 +949,7 @@ __global__ __launch_bounds__(NTHR) void k_encoder(const float* __restrict__ spec
     ht* en2h = reinterpret_cast<ht*>(en2) + ob * 528;
     ht* en3h = reinterpret_cast<ht*>(en3) + ob * 528;
     ht* en4h = reinterpret_cast<ht*>(en4) + ob * 528;
-    const ht* x1h = reinterpret_cast<const ht*>(x1);
+    const ht* x1h = reinterpret_cast<const ht*>(en1);   // FRONT = false: k_front's en1 (decoder slot order), read here
     const bool t_fast = st < sf;  // reference layout (B,257,T,2): consecutive frames are adjacent
     if (lens) T = min(T, 1 + (lens[b] >> 8));   // from here on T = this utterance's frames
     if constexpr (MS) T = nlive;                // one frame per live stream = nlive rows
@@ -980,8 +990,14 @@ __global__ __launch_bounds__(NTHR) void k_encoder(const float* __restrict__ spec
         const int nfr = min(RW, T - t0);
         f32x4 x[TPW];
         if constexpr (!FRONT) {
+            // en1 exists only in the slot order of its decoder consumer (k_front is bound by its HBM writes: a second
+            // copy in this stage's order cost it 11 %): back to the own order through the tile's scratch records
+            // (S is dead at the top of a chunk)
+            {
+                const int* ix = sI + I_ENST - ENC_I_SKIP + 0 * 16 + 4 * g;
 #pragma unroll
-            for (int i = 0; i < TPW; ++i) x[i] = xn[i];
+                for (int i = 0; i < TPW; ++i) x[i] = unpermute_via_lds(sS + tt.pp(i) * PERM_RS, ix, g, xn[i]);
+            }
             if (t0 + RW < T) {
                 const int npn = min(RW, T - t0 - RW) * 33;
                 const ht* xc = x1h + (long)(t0 + RW) * 528;
@@ -1178,7 +1194,7 @@ __global__ __launch_bounds__(NTHR) void k_encoder(const float* __restrict__ spec
                 const int* ix = sI + I_ENST - ENC_I_SKIP + (k + 1) * 16 + 4 * g;
 #pragma unroll
                 for (int i = 0; i < TPW; ++i) {   // scratch: the tile's own v^2 records (dead after the gate barrier)
-                    const f32x4 y = permute_via_lds(sS + tt.pp(i) * RS, ix, g, x[i]);
+                    const f32x4 y = permute_via_lds(sS + tt.pp(i) * PERM_RS, ix, g, x[i]);
                     if (tt.pp(i) < nfr * 33) stx<Q>(dst + (long)t0 * 528 + (unsigned)(tt.pp(i) * 16 + 4 * g), y);
                 }
             } else {
@@ -1213,8 +1229,9 @@ __global__ __launch_bounds__(NTHR) void k_encoder(const float* __restrict__ spec
 // tiles (80 MFMAs per frame instead of 59 for tiles cut across frames).  Same source expressions as k_encoder's
 // in-kernel front end (which the streaming forms keep), so every value is bit-identical.
 // WAVE_IN = false: the frames come from a caller spectrogram (gtcrn_forward_spec) instead of the FFT.
-// Outputs: en0 (B,T,65,16), en1 twice -- in the slot order of its decoder consumer (en1p) and in its own (en1n,
-// the input of the first GTConv block).
+// Outputs: the spectrogram, en0 (B,T,65,16) and en1 (B,T,33,16) in the slot order of its decoder consumer (en1p);
+// the first GTConv block un-permutes it on load.  The kernel is bound by these HBM writes (0.53 GB per launch at
+// B = 256 x 4 s: a second copy of en1 in its own slot order made it 11 % slower).
 constexpr int FR_WAVES = 8;
 constexpr int FR_NT = FR_WAVES * 64;
 constexpr int FR_P = 0;                                        // E_ERB_W .. E_BLK of the encoder segment
@@ -1228,6 +1245,7 @@ constexpr int FR_WSZ = FR_WF0 + 3 * F0_ROW;
 constexpr int FR_LDS_FLOATS = FR_W0 + FR_WAVES * FR_WSZ;
 static_assert(1024 <= ENC_E0_ROW * 16 && 2 * 192 <= 512, "FFT buffers / staged high bins must fit in the E0 region");
 static_assert(3 * 16 * 16 <= 396 + 3 * F0_ROW, "en1 permute scratch (3 tiles) must fit in EB + F0");
+static_assert(3 * 16 * PERM_RS <= ENC_E0_ROW * 16, "en1 permute scratch (3 tiles) must fit in the E0 region");
 static_assert(FR_W0 % 4 == 0 && FR_WSZ % 4 == 0 && FR_WEB % 4 == 0 && FR_WF0 % 4 == 0, "16B carve");
 static_assert(FR_LDS_FLOATS * 4 * 2 <= 160 * 1024, "two front-end workgroups per CU");
 
@@ -1237,7 +1255,7 @@ __global__ __launch_bounds__(FR_NT, 4) void k_front(const float* __restrict__ in
                                                 const float* __restrict__ win, const float2* __restrict__ twid,
                                                 const float* __restrict__ PF, const int* __restrict__ PI,
                                                 float* __restrict__ spec, float* __restrict__ en0,
-                                                float* __restrict__ en1p, float* __restrict__ en1n, float qin) {
+                                                float* __restrict__ en1p, float qin) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* sP = smem + FR_P;                   // indexed with the E_* offsets of the encoder segment
     int* sI = reinterpret_cast<int*>(smem + FR_I);
@@ -1440,7 +1458,6 @@ __global__ __launch_bounds__(FR_NT, 4) void k_front(const float* __restrict__ in
                 const int* ix = sI + 128 + 4 * g;
                 using ht = typename HandOff<Q>::t;
                 ht* en1pc = reinterpret_cast<ht*>(en1p) + fr * 528;
-                ht* en1nc = reinterpret_cast<ht*>(en1n) + fr * 528;
                 f32x4 x[3];
                 int ffv[3];
 #pragma unroll
@@ -1463,9 +1480,8 @@ __global__ __launch_bounds__(FR_NT, 4) void k_front(const float* __restrict__ in
                 for (int i = 0; i < 3; ++i) {
                     const int p = i * 16 + n;
                     x[i] = rq<Q>(prelu4(x[i], a));
-                    const f32x4 y = permute_via_lds(sEB + p * 16, ix, g, x[i]);
+                    const f32x4 y = permute_via_lds(sE0 + p * PERM_RS, ix, g, x[i]);   // E0's taps are consumed: X region
                     if (p < 33) {
-                        stx<Q>(en1nc + (unsigned)(p * 16 + 4 * g), x[i]);
                         stx<Q>(en1pc + (unsigned)(p * 16 + 4 * g), y);
                     }
                 }
@@ -2415,14 +2431,14 @@ static bool use_multi_stream(int T, const float* state, long sb) {
 // written frame-major to `spec_out`) or from a caller spectrogram (spec_in, strides).  Persistent grid.
 int launch_front(const float* wave, long L, const float* spec_in, long isb, long isf, long ist, int B, int T,
                  const int* lens, const float* win, const float* twid, const float* PF, const int* PI, float* spec_out,
-                 float* en0, float* en1p, float* en1n, hipStream_t s, const Quant* q) {
+                 float* en0, float* en1p, hipStream_t s, const Quant* q) {
     const long wgs = ((long)B * T + FR_WAVES - 1) / FR_WAVES;
     const int grid = (int)(wgs < 256 * 2 ? wgs : 256 * 2);              // two workgroups per CU, persistent
     const float qin = q ? q->in_step : 0.f;
     const float2* tw = reinterpret_cast<const float2*>(twid);
 #define GT_FRONT(WV, QV, INP)                                                                                      \
     hipLaunchKernelGGL((k_front<WV, QV>), dim3(grid), dim3(FR_NT), FR_LDS_FLOATS * 4, s, INP, L, isb, isf, ist, B, T, \
-                       lens, win, tw, PF, PI, spec_out, en0, en1p, en1n, qin)
+                       lens, win, tw, PF, PI, spec_out, en0, en1p, qin)
     if (wave) { if (q) GT_FRONT(true, true, wave); else GT_FRONT(true, false, wave); }
     else { if (q) GT_FRONT(false, true, spec_in); else GT_FRONT(false, false, spec_in); }
 #undef GT_FRONT
@@ -2430,24 +2446,23 @@ int launch_front(const float* wave, long L, const float* spec_in, long isb, long
     return 0;
 }
 
-// x1 != nullptr: k_front has produced en0 / en1 already, only the three GTConv blocks run here (offline calls)
+// front_done: k_front has produced en0 / en1 already, only the three GTConv blocks run here (offline calls)
 int launch_encoder(const float* spec, long sb, long sf, long st, int B, int T, const int* lens, const float* PF,
                    const int* PI, float* en0, float* en1, float* en2, float* en3, float* en4, float* state,
-                   unsigned long long* stamps, hipStream_t s, const Quant* q, const float* x1) {
+                   unsigned long long* stamps, hipStream_t s, const Quant* q, bool front_done) {
 #define GT_ENC(TPWV, QV, FRV)                                                                                       \
     hipLaunchKernelGGL((k_encoder<TPWV, false, QV, FRV>), dim3(B), dim3(NTHR),                                      \
                        (FRV ? ENC_LDS_FLOATS : ENC_GT_LDS_FLOATS) * 4, s, spec, sb, sf, st,                         \
-                       T, lens, B, q ? q->in_step : 0.f, x1, PF, PI, en0, en1, en2, en3, en4, state, stamps)
+                       T, lens, B, q ? q->in_step : 0.f, PF, PI, en0, en1, en2, en3, en4, state, stamps)
     if (q) {   // int8-weight / fp16-activation variant: offline form only, the full-chunk instantiation
-        if (!x1 || state) return (int)hipErrorInvalidValue;
+        if (!front_done || state) return (int)hipErrorInvalidValue;
         GT_ENC(TPW, true, false);
     } else if (use_multi_stream(T, state, sb)) {
         // streams b*4 .. b*4+3 become rows 0..3 of workgroup b: sb' = 4 sb, st' = sb, T' = 4
         const int grid = (B + MS_STREAMS - 1) / MS_STREAMS;
         hipLaunchKernelGGL((k_encoder<1, true, false, true>), dim3(grid), dim3(NTHR), ENC_MS_LDS_FLOATS * 4, s, spec,
-                           (long)MS_STREAMS * sb, sf, sb, MS_STREAMS, (const int*)nullptr, B, 0.f, (const float*)nullptr,
-                           PF, PI, en0, en1, en2, en3, en4, state, stamps);
-    } else if (x1) {
+                           (long)MS_STREAMS * sb, sf, sb, MS_STREAMS, (const int*)nullptr, B, 0.f, PF, PI, en0, en1, en2, en3, en4, state, stamps);
+    } else if (front_done) {
         if (T <= SHORT_T) GT_ENC(1, false, false);
         else if (T <= SHORT_T2) GT_ENC(2, false, false);
         else GT_ENC(TPW, false, false);
