@@ -24,6 +24,7 @@ using namespace gtl;
 namespace gtk {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 // ----------------------------------------------------------------------------- helpers
 __device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
@@ -168,8 +169,9 @@ __device__ __forceinline__ f32x4 ldx(const typename HandOff<Q>::t* p) {
 }
 template <bool Q>
 __device__ __forceinline__ void stx(typename HandOff<Q>::t* p, const f32x4 v) {
-    if constexpr (Q) *reinterpret_cast<h16x4*>(p) = to_h4(v);
-    else st4(p, v);
+    // written once, read once by a later kernel, far larger than the caches: streaming (nontemporal) stores
+    if constexpr (Q) __builtin_nontemporal_store(to_h4(v), reinterpret_cast<h16x4*>(p));
+    else __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(p));
 }
 
 // Diagnostic build only (-DGT_STAMPS, libgtcrn_micro_hip_stamps.so): s_memtime stamps at the
@@ -1366,7 +1368,7 @@ __global__ __launch_bounds__(FR_NT, 4) void k_front(const float* __restrict__ in
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     const int k = lane + 64 * q;
-                    *reinterpret_cast<float2*>(o + 2 * k) = X[q];
+                    { const f32x2 xv = {X[q].x, X[q].y}; __builtin_nontemporal_store(xv, reinterpret_cast<f32x2*>(o + 2 * k)); }
                     stage(k, X[q]);
                 }
                 if (lane == 0) {
