@@ -167,12 +167,18 @@ __device__ __forceinline__ f32x4 ldx(const typename HandOff<Q>::t* p) {
         return ld4(p);
     }
 }
-template <bool Q>
+template <bool Q, bool NT = true>
 __device__ __forceinline__ void stx(typename HandOff<Q>::t* p, const f32x4 v) {
     // written once, read once by a later kernel, far larger than the caches: streaming (nontemporal) stores
-    if constexpr (Q) __builtin_nontemporal_store(to_h4(v), reinterpret_cast<h16x4*>(p));
-    else __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(p));
+    if constexpr (NT) {
+        if constexpr (Q) __builtin_nontemporal_store(to_h4(v), reinterpret_cast<h16x4*>(p));
+        else __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(p));
+    } else {
+        if constexpr (Q) *reinterpret_cast<h16x4*>(p) = to_h4(v);
+        else st4(p, v);
+    }
 }
+// (Also for the tensors the very next kernel reads: leaving those to the caches measured 1.5 % slower on that reader.)
 
 // Diagnostic build only (-DGT_STAMPS, libgtcrn_micro_hip_stamps.so): s_memtime stamps at the
 // barrier-delimited phases, summed per workgroup and written to a buffer nothing else reads.
@@ -1747,15 +1753,10 @@ __device__ __forceinline__ void tcn_block_band(f32x4 (&x)[TPW], const float* pk,
     const int n = L.n, g = L.g;
     constexpr int M2D = 2 * D - 1, HR = 2 * D * GB_RS, RS = GB_RS;   // ring mask, floats per bin of the ring
     const float a1 = pk[TCN_SLOPE] - 1.0f, a2 = pk[TCN_SLOPE + 1] - 1.0f, a3 = pk[TCN_SLOPE + 2] - 1.0f;
-    f32x4 y1[TPW], acc[TPW], t1[TPW], t2[TPW];
+    f32x4 y1[TPW], acc[TPW];
     const long h_minus_c = hw - cw;
-    // taps that lie before the chunk come from the ring; they do not depend on this block's y1
+    // ring rows of the taps that lie before the chunk
     const int r1 = ((n - D) & M2D) * RS + 4 * g, r2 = (n & M2D) * RS + 4 * g;
-#pragma unroll
-    for (int i = 0; i < TPW; ++i) {
-        t1[i] = ld4(hw + i * HR + r1);
-        t2[i] = ld4(hw + i * HR + r2);
-    }
     {
         const f32x4 A = ld4(pk + TCN_A1 + arow(n, g)), Bv = ld4(pk + TCN_B1 + 4 * g);
 #pragma unroll
@@ -1778,10 +1779,14 @@ __device__ __forceinline__ void tcn_block_band(f32x4 (&x)[TPW], const float* pk,
         const f32x4 A = ld4(pk + TCN_A3 + arow(n, g)), B3 = ld4(pk + TCN_B3 + 4 * g);
         f32x4 y2[TPW];
         const int c1 = (n >= D ? n - D : n) * RS + 4 * g, c2 = (n >= 2 * D ? n - 2 * D : n) * RS + 4 * g;
+        // one load per tap: the ADDRESS is chosen per lane (chunk image or ring; both sit in this wave's LDS), not the
+        // data (two loads and four selects per tap)
+        const int hc = (int)h_minus_c;
+        const int b1 = n >= D ? c1 : hc + r1, s1 = n >= D ? 16 * RS : HR;
+        const int b2 = n >= 2 * D ? c2 : hc + r2, s2 = n >= 2 * D ? 16 * RS : HR;
 #pragma unroll
         for (int i = 0; i < TPW; ++i) {
-            const f32x4 u1 = ld4(cw + i * 16 * RS + c1), u2 = ld4(cw + i * 16 * RS + c2);
-            const f32x4 p1 = n >= D ? u1 : t1[i], p2 = n >= 2 * D ? u2 : t2[i];
+            const f32x4 p1 = ld4(cw + b1 + i * s1), p2 = ld4(cw + b2 + i * s2);
             y2[i] = rq<Q>(prelu4(B2 + w0 * p2 + w1 * p1 + w2 * y1[i], a2));
             acc[i] = B3 + x[i];
         }
@@ -1795,7 +1800,6 @@ __device__ __forceinline__ void tcn_block_band(f32x4 (&x)[TPW], const float* pk,
 #pragma unroll
         for (int i = 0; i < TPW; ++i) st4(hw + i * HR + r2, y1[i]);
     }
-    (void)h_minus_c;
 }
 
 template <bool Q>
