@@ -2148,21 +2148,29 @@ __global__ __launch_bounds__(NTHR) void k_decoder(const float* __restrict__ xg, 
         // de_convs.4 gather + BN + Tanh: m[o][f''] = tanh(b[o] + sum_k z[(f''+2-k)/2][o*5+k]).  Branch free:
         // even f'' = 2m takes k = 0,2,4 from rows m+1, m, m-1; odd f'' = 2m+1 takes k = 1,3 from rows m+1, m
         // and a zero slot (rows 10..15 of the de_conv4 slot matrix are zero); the end records are zero.
+        // Thread <-> (frame parity h, output channel o, bin f'') for the whole chunk, the RW / 2 frames of that parity in
+        // an unrolled loop: everything that depends on (o, f'') is computed once per chunk and the per-frame addresses
+        // are immediate offsets (an item loop over the flattened index spent ~50 vector instructions per element on
+        // index arithmetic).  Frames past a short last chunk are computed from stale rows and never read.
         {
-            static_assert(NTHR == 5 * F0 + 59, "item stride decomposition");
+            static_assert(4 * F0 <= NTHR && RW % 2 == 0, "two threads per (o, f'')");
             int tz = tid;
             asm volatile("" : "+v"(tz));
-            int ot = tz / F0, fq = tz - ot * F0;      // one constant division, increments afterwards
-            for (int idx = tz; idx < 2 * nfr * F0; idx += NTHR) {
-                const int o = ot >= nfr ? 1 : 0, tq = ot - o * nfr;
+            if (tz < 4 * F0) {
+                const int h = tz >= 2 * F0 ? 1 : 0, c = tz - h * 2 * F0, o = c >= F0 ? 1 : 0, fq = c - o * F0;
                 const int par = fq & 1, m = fq >> 1;
-                const float* zr = sZ + (tq * DEC_Z_ROW + 1 + m) * ZS;
-                const float sum = sP[D_DE4_B + o] + zr[ZS + o * 5 + par] + zr[o * 5 + 2 + par] +
-                                  zr[-ZS + (par ? 10 : o * 5 + 4)];
-                sM[(o * RW + tq) * F0 + fq] = rq1<Q>(fast_tanh(sum));
-                fq += 59;
-                ot += 5;
-                if (fq >= F0) { fq -= F0; ++ot; }
+                const float* zr = sZ + (h * DEC_Z_ROW + 1 + m) * ZS;
+                const float* r1 = zr + ZS + o * 5 + par;
+                const float* r2 = zr + o * 5 + 2 + par;
+                const float* r3 = zr - ZS + (par ? 10 : o * 5 + 4);
+                const float bias = sP[D_DE4_B + o];
+                float* mo = sM + (o * RW + h) * F0 + fq;
+#pragma unroll
+                for (int j = 0; j < RW / 2; ++j) {
+                    constexpr int ZF = 2 * DEC_Z_ROW * ZS;          // floats between frames t and t + 2
+                    const float sum = bias + r1[j * ZF] + r2[j * ZF] + r3[j * ZF];
+                    mo[j * 2 * F0] = rq1<Q>(fast_tanh(sum));
+                }
             }
         }
         wg_barrier();
