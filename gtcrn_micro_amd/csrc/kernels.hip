@@ -700,10 +700,15 @@ __device__ __forceinline__ void gtconv_block(f32x4 (&x)[TPW], const Tiles<TPW>& 
     {
         const int part = L.tid & 3, rc = (L.tid >> 2) & 7, rt = L.tid >> 5;
         if (L.tid < c.nfr * 32) {
-            const float* sp = c.sS + (rt * 33 + part * 9) * RSS + c.ib[rc];
-            const int cnt = part == 3 ? 6 : 9;
+            // nine independent loads per thread (the last range, bins 27..32, reads bins 24..32 and drops the first
+            // three), then the same ascending-bin summation as a 9 / 6-trip loop -- whose loads went out one by one
+            const float* sp = c.sS + (rt * 33 + (part == 3 ? 24 : part * 9)) * RSS + c.ib[rc];
+            float v[9];
+#pragma unroll
+            for (int f = 0; f < 9; ++f) v[f] = sp[f * RSS];
             float sum = 0.f;
-            for (int f = 0; f < cnt; ++f) sum += sp[f * RSS];
+#pragma unroll
+            for (int f = 0; f < 9; ++f) sum += (f < 3 && part == 3) ? 0.f : v[f];
             sum += dpp_ror<0xB1>(sum);   // quad_perm [1,0,3,2]
             sum += dpp_ror<0x4E>(sum);   // quad_perm [2,3,0,1]
             if (part == 0) c.sE[(MS ? rt * 3 + 2 : 2 + rt) * 8 + rc] = sum * (1.0f / 33.0f);
