@@ -46,6 +46,7 @@ def build_native(force=False, verbose=False, stamps=False, exp=False):
         lib = LIB.replace(".so", "_stamps.so")
     elif exp:
         common.append("-DGT_EXP")
+        per_file = {k: v + os.environ.get("GT_EXP_FLAGS", "").split() for k, v in per_file.items()}
         suffix = ".exp"
         lib = LIB.replace(".so", "_exp.so")
     for src in SOURCES:

