@@ -565,7 +565,7 @@ __device__ __forceinline__ void ring_to_image(float* sW, const float* ring, int 
     }
 }
 
-template <bool DENSE, int TPW, bool MS, bool Q, int RS, int RSS, class Hook>
+template <bool DENSE, int TPW, bool MS, bool Q, int RS, int RSS, bool WIDE_TRA, class Hook>
 __device__ __forceinline__ void gtconv_block(f32x4 (&x)[TPW], const Tiles<TPW>& tin, const BlockCtx& c,
                                              const Lane& L, Hook&& hook STAMP_PARAM) {
     static_assert(!MS || TPW == 1, "multi-stream mode runs one tile per wave");
@@ -707,13 +707,19 @@ __device__ __forceinline__ void gtconv_block(f32x4 (&x)[TPW], const Tiles<TPW>& 
         if (L.tid < c.nfr * 32) {
             // nine independent loads per thread (the last range, bins 27..32, reads bins 24..32 and drops the first
             // three), then the same ascending-bin summation as a 9 / 6-trip loop -- whose loads went out one by one
-            const float* sp = c.sS + (rt * 33 + (part == 3 ? 24 : part * 9)) * RSS + c.ib[rc];
-            float v[9];
-#pragma unroll
-            for (int f = 0; f < 9; ++f) v[f] = sp[f * RSS];
             float sum = 0.f;
+            if constexpr (WIDE_TRA) {
+                const float* sp = c.sS + (rt * 33 + (part == 3 ? 24 : part * 9)) * RSS + c.ib[rc];
+                float v[9];
 #pragma unroll
-            for (int f = 0; f < 9; ++f) sum += (f < 3 && part == 3) ? 0.f : v[f];
+                for (int f = 0; f < 9; ++f) v[f] = sp[f * RSS];
+#pragma unroll
+                for (int f = 0; f < 9; ++f) sum += (f < 3 && part == 3) ? 0.f : v[f];
+            } else {   // (the one instantiation with no registers to spare: the same sums from a loop)
+                const float* sp = c.sS + (rt * 33 + part * 9) * RSS + c.ib[rc];
+                const int cnt = part == 3 ? 6 : 9;
+                for (int f = 0; f < cnt; ++f) sum += sp[f * RSS];
+            }
             sum += dpp_ror<0xB1>(sum);   // quad_perm [1,0,3,2]
             sum += dpp_ror<0x4E>(sum);   // quad_perm [2,3,0,1]
             if (part == 0) c.sE[(MS ? rt * 3 + 2 : 2 + rt) * 8 + rc] = sum * (1.0f / 33.0f);
@@ -865,6 +871,36 @@ __device__ __forceinline__ f32x4 unpermute_via_lds(float* scratch_rec, const int
     return v;
 }
 
+// The same for all of a wave's tiles at once: the index table is read once, all scatters (or record writes) go out
+// together and ONE wave-local sync separates them from the reads -- three LDS round trips per call instead of three
+// per tile (these sit in short barrier-delimited phases whose length is their longest dependency chain).
+template <int N>
+__device__ __forceinline__ void permute_tiles_via_lds(float* scratch, const int (&off)[N], const int* idx4, int g,
+                                                      const f32x4 (&v)[N], f32x4 (&y)[N]) {
+    const int i0 = idx4[0], i1 = idx4[1], i2 = idx4[2], i3 = idx4[3];
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        float* r = scratch + off[i];
+        r[i0] = v[i][0]; r[i1] = v[i][1]; r[i2] = v[i][2]; r[i3] = v[i][3];
+    }
+    wave_lds_sync();
+#pragma unroll
+    for (int i = 0; i < N; ++i) y[i] = ld4(scratch + off[i] + 4 * g);
+}
+template <int N>
+__device__ __forceinline__ void unpermute_tiles_via_lds(float* scratch, const int (&off)[N], const int* idx4, int g,
+                                                        const f32x4 (&y)[N], f32x4 (&v)[N]) {
+    const int i0 = idx4[0], i1 = idx4[1], i2 = idx4[2], i3 = idx4[3];
+#pragma unroll
+    for (int i = 0; i < N; ++i) st4(scratch + off[i] + 4 * g, y[i]);
+    wave_lds_sync();
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        const float* r = scratch + off[i];
+        v[i][0] = r[i0]; v[i][1] = r[i1]; v[i][2] = r[i2]; v[i][3] = r[i3];
+    }
+}
+
 // =============================================================================== encoder
 // spec -> [mag,re,im] (models/gtcrn_micro.py:510-515) -> ERB.bm (:63-67) -> SFE_Lite (:77-90)
 // -> en_convs.0/1 (ConvBlock :142-164, Conv2d (1,5) stride (1,2)) -> 3 x GTConvBlock (:365-393).
@@ -1013,8 +1049,10 @@ __global__ __launch_bounds__(NTHR) void k_encoder(const float* __restrict__ spec
             // (S is dead at the top of a chunk)
             {
                 const int* ix = sI + I_ENST - ENC_I_SKIP + 0 * 16 + 4 * g;
+                int po[TPW];
 #pragma unroll
-                for (int i = 0; i < TPW; ++i) x[i] = unpermute_via_lds(sS + tt.pp(i) * PERM_RS, ix, g, xn[i]);
+                for (int i = 0; i < TPW; ++i) po[i] = tt.pp(i) * PERM_RS;
+                unpermute_tiles_via_lds<TPW>(sS, po, ix, g, xn, x);
             }
             if (t0 + RW < T) {
                 const int npn = min(RW, T - t0 - RW) * 33;
@@ -1206,14 +1244,26 @@ __global__ __launch_bounds__(NTHR) void k_encoder(const float* __restrict__ spec
             } else {
                 c.ms_roff = 0; c.ms_tb = 0;
             }
-            gtconv_block<false, TPW, MS, Q, RS, RS>(x, tt, c, L, [] {} STAMP_ARG);
+            gtconv_block<false, TPW, MS, Q, RS, RS, !(FRONT && TPW == 3)>(x, tt, c, L, [] {} STAMP_ARG);
             if (k < 2) {
                 ht* dst = k == 0 ? en2h : en3h;
                 const int* ix = sI + I_ENST - ENC_I_SKIP + (k + 1) * 16 + 4 * g;
+                // scratch: the tiles' own v^2 records (dead after the gate barrier)
+                if constexpr (!FRONT) {
+                    int po[TPW];
+                    f32x4 y[TPW];
 #pragma unroll
-                for (int i = 0; i < TPW; ++i) {   // scratch: the tile's own v^2 records (dead after the gate barrier)
-                    const f32x4 y = permute_via_lds(sS + tt.pp(i) * PERM_RS, ix, g, x[i]);
-                    if (tt.pp(i) < nfr * 33) stx<Q>(dst + (long)t0 * 528 + (unsigned)(tt.pp(i) * 16 + 4 * g), y);
+                    for (int i = 0; i < TPW; ++i) po[i] = tt.pp(i) * PERM_RS;
+                    permute_tiles_via_lds<TPW>(sS, po, ix, g, x, y);
+#pragma unroll
+                    for (int i = 0; i < TPW; ++i)
+                        if (tt.pp(i) < nfr * 33) stx<Q>(dst + (long)t0 * 528 + (unsigned)(tt.pp(i) * 16 + 4 * g), y[i]);
+                } else {   // (the streaming forms carry the front end's registers: one tile at a time)
+#pragma unroll
+                    for (int i = 0; i < TPW; ++i) {
+                        const f32x4 y = permute_via_lds(sS + tt.pp(i) * PERM_RS, ix, g, x[i]);
+                        if (tt.pp(i) < nfr * 33) stx<Q>(dst + (long)t0 * 528 + (unsigned)(tt.pp(i) * 16 + 4 * g), y);
+                    }
                 }
             } else {
 #pragma unroll
@@ -1494,14 +1544,18 @@ __global__ __launch_bounds__(FR_NT, 4) void k_front(const float* __restrict__ in
                     }
                 }
                 wave_lds_sync();                                  // EB / F0 are dead: they become the permute scratch
+                {
+                    int po[3];
+                    f32x4 y[3];
 #pragma unroll
-                for (int i = 0; i < 3; ++i) {
-                    const int p = i * 16 + n;
-                    x[i] = rq<Q>(prelu4(x[i], a));
-                    const f32x4 y = permute_via_lds(sE0 + p * PERM_RS, ix, g, x[i]);   // E0's taps are consumed: X region
-                    if (p < 33) {
-                        stx<Q>(en1pc + (unsigned)(p * 16 + 4 * g), y);
+                    for (int i = 0; i < 3; ++i) {
+                        po[i] = (i * 16 + n) * PERM_RS;
+                        x[i] = rq<Q>(prelu4(x[i], a));
                     }
+                    permute_tiles_via_lds<3>(sE0, po, ix, g, x, y);     // E0's taps are consumed: X region
+#pragma unroll
+                    for (int i = 0; i < 3; ++i)
+                        if (i * 16 + n < 33) stx<Q>(en1pc + (unsigned)((i * 16 + n) * 16 + 4 * g), y[i]);
                 }
             }
             wave_lds_sync();     // every region is rewritten by the next frame
@@ -2026,7 +2080,7 @@ __global__ __launch_bounds__(NTHR) void k_decoder(const float* __restrict__ xg, 
             } else {
                 c.ms_roff = 0; c.ms_tb = 0;
             }
-            gtconv_block<true, TPW, MS, Q, RS, LD::RSS>(x, tt, c, L, hook STAMP_ARG);
+            gtconv_block<true, TPW, MS, Q, RS, LD::RSS, true>(x, tt, c, L, hook STAMP_ARG);
             if (DBG)
 #pragma unroll
                 for (int i = 0; i < TPW; ++i)
