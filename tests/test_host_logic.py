@@ -326,7 +326,10 @@ def test_headline_kernels_use_no_scratch():
     rows = {l.split("|")[0].strip(): l for l in out.splitlines() if "ScratchSize" in l}
     must = ["void gtk::k_front<true, false>", "void gtk::k_encoder<3, false, false, false>", "void gtk::k_gtcn_band<false>",
             "void gtk::k_decoder<false, 3, false, false>", "gtk::k_istft", "gtk::k_gtcn_ms",
-            "void gtk::k_encoder<1, true, false, true>", "void gtk::k_decoder<false, 1, true, false>"]
+            "void gtk::k_encoder<1, true, false, true>", "void gtk::k_decoder<false, 1, true, false>",
+            # chunked-streaming forms (in-kernel front end), one / two / three tiles per wave
+            "void gtk::k_encoder<3, false, false, true>", "void gtk::k_encoder<1, false, false, true>",
+            "void gtk::k_decoder<false, 1, false, false>", "void gtk::k_decoder<false, 2, false, false>"]
     for k in must:
         assert k in rows, (k, sorted(rows))
         assert "ScratchSize [bytes/lane]: 0 " in rows[k], rows[k]
