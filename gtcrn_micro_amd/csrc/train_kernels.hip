@@ -248,7 +248,7 @@ __global__ __launch_bounds__(NT) void k_conv_mfma(ConvGeom g, const float* __res
                                                  float* __restrict__ out, long tiles_per_wave,
                                                  double* __restrict__ stat_partial, const float* __restrict__ shift) {
     __shared__ __attribute__((aligned(16))) float sW[NKT * NKF * 256];   // [tap][co][ci], zero padded
-    __shared__ float sStat[NT][8];
+    __shared__ double sStat[NT][8];
     const int tid = threadIdx.x;
     for (int i = tid; i < NKT * NKF * 256; i += NT) {
         const int tap = i >> 8, co = (i >> 4) & 15, ci = i & 15, kt = tap / NKF, kf = tap - kt * NKF;
@@ -260,7 +260,10 @@ __global__ __launch_bounds__(NT) void k_conv_mfma(ConvGeom g, const float* __res
     const long wave = (long)blockIdx.x * (NT / 64) + (tid >> 6);
     long tile = wave * tiles_per_wave;
     const long tend = tile + tiles_per_wave < ntiles ? tile + tiles_per_wave : ntiles;
-    f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = {0.f, 0.f, 0.f, 0.f};    // BatchNorm statistics of this lane's outputs
+    // BatchNorm statistics of this lane's outputs, accumulated in DOUBLE from the first addition on (the squares are
+    // exact products of two floats): var = E[y^2] - mean^2 then survives |mean| >> std (a large conv bias, a
+    // near-constant channel), where fp32 per-thread sums lose the variance's leading digits
+    double s1[4] = {0.0, 0.0, 0.0, 0.0}, s2[4] = {0.0, 0.0, 0.0, 0.0};
     Pos P;
     {
         const long p0 = tile * 16 + n;
@@ -298,8 +301,8 @@ __global__ __launch_bounds__(NT) void k_conv_mfma(ConvGeom g, const float* __res
                 f32x4* o = reinterpret_cast<f32x4*>(out + p * g.CoutT + g.cout_off + 4 * q);
                 *o = g.accumulate ? *o + acc : acc;
             }
-            s1 += acc;
-            s2 += acc * acc;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { const double a = (double)acc[e]; s1[e] += a; s2[e] = fma(a, a, s2[e]); }
         }
         P.advance(16, g.Fout, g.Tout);
     }
@@ -313,7 +316,7 @@ __global__ __launch_bounds__(NT) void k_conv_mfma(ConvGeom g, const float* __res
             const int which = tid / g.Cout, ch = tid - which * g.Cout, qq = ch >> 2, e = ch & 3;
             double t = 0.0;
             for (int l = 0; l < NT; ++l)
-                if (((l & 63) >> 4) == qq) t += (double)sStat[l][which * 4 + e];
+                if (((l & 63) >> 4) == qq) t += sStat[l][which * 4 + e];
             stat_partial[(long)blockIdx.x * 2 * g.Cout + tid] = t;
         }
     }
@@ -473,8 +476,8 @@ __global__ __launch_bounds__(NT) void k_dw16(DwGeom g, const float* __restrict__
                                             double* __restrict__ stat_partial, StrideIter it,
                                             const float* __restrict__ shift) {
     __shared__ __attribute__((aligned(16))) float sW[9 * 16];   // [tap][c]
-    __shared__ float sStat[NT][8];
-    f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = {0.f, 0.f, 0.f, 0.f};
+    __shared__ double sStat[NT][8];
+    double s1[4] = {0.0, 0.0, 0.0, 0.0}, s2[4] = {0.0, 0.0, 0.0, 0.0};    // in double: see k_conv_mfma
     const int tid = threadIdx.x, ntap = g.nkt * g.nkf;
     for (int i = tid; i < ntap * 16; i += NT) {
         const int tap = i >> 4, c = i & 15, kt = tap / g.nkf, kf = tap - kt * g.nkf;
@@ -510,8 +513,8 @@ __global__ __launch_bounds__(NT) void k_dw16(DwGeom g, const float* __restrict__
             f32x4* o = reinterpret_cast<f32x4*>(out + p * 16 + 4 * q);
             *o = g.accumulate ? *o + acc : acc;
         }
-        s1 += acc;
-        s2 += acc * acc;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { const double a = (double)acc[e]; s1[e] += a; s2[e] = fma(a, a, s2[e]); }
     }
     if (stat_partial) {   // per-workgroup BatchNorm partial sums; a thread's channel quad is tid & 3
 #pragma unroll
@@ -520,7 +523,7 @@ __global__ __launch_bounds__(NT) void k_dw16(DwGeom g, const float* __restrict__
         if (tid < 32) {
             const int which = tid >> 4, ch = tid & 15, qq = ch >> 2, e = ch & 3;
             double t = 0.0;
-            for (int l = qq; l < NT; l += 4) t += (double)sStat[l][which * 4 + e];
+            for (int l = qq; l < NT; l += 4) t += sStat[l][which * 4 + e];
             stat_partial[(long)blockIdx.x * 32 + tid] = t;
         }
     }
@@ -532,8 +535,8 @@ __global__ __launch_bounds__(NT) void k_dw16(DwGeom g, const float* __restrict__
 // Reductions: a thread walks the tensor with a stride that is a multiple of C, so it sees fixed
 // channels; it accumulates a bounded number of elements in fp32, the per-thread sums are combined in
 // double (workgroup, then across workgroups) in a fixed order.
-template <int NV, int V>   // NV sums per channel, V channels per thread (vector width)
-__device__ __forceinline__ void block_reduce_store(const float (&v)[NV][V], int C, double* sh, double* dst) {
+template <int NV, int V, class TV>   // NV sums per channel, V channels per thread (vector width); TV float or double
+__device__ __forceinline__ void block_reduce_store(const TV (&v)[NV][V], int C, double* sh, double* dst) {
     const int tid = threadIdx.x, groups = C / V;      // threads with equal (tid % groups) share channels
 #pragma unroll
     for (int k = 0; k < NV; ++k)
@@ -554,15 +557,15 @@ template <int V>
 __global__ __launch_bounds__(NT) void k_bn_stats(const float* __restrict__ y, long total, int C,
                                                 double* __restrict__ partial, int bf) {
     __shared__ double sh[NT];
-    float v[2][V];
+    double v[2][V];    // double from the first addition on: no cancellation in E[y^2] - mean^2 (see k_conv_mfma)
 #pragma unroll
-    for (int e = 0; e < V; ++e) v[0][e] = v[1][e] = 0.f;
+    for (int e = 0; e < V; ++e) v[0][e] = v[1][e] = 0.0;
     const long units = total / V;
     for (long i = (long)blockIdx.x * NT + threadIdx.x; i < units; i += (long)gridDim.x * NT) {
         float x[V];
         load_vec_s<V>(y, i * V, bf, x);
 #pragma unroll
-        for (int e = 0; e < V; ++e) { v[0][e] += x[e]; v[1][e] = fmaf(x[e], x[e], v[1][e]); }
+        for (int e = 0; e < V; ++e) { const double a = (double)x[e]; v[0][e] += a; v[1][e] = fma(a, a, v[1][e]); }
     }
     block_reduce_store<2, V>(v, C, sh, partial + (long)blockIdx.x * 2 * C);
 }
