@@ -2252,17 +2252,41 @@ __global__ __launch_bounds__(NTHR) void k_decoder(const float* __restrict__ xg, 
             int tq, f;
             spec_item_first(tz, t_fast, tq, f);
             float* obase = out + (long)t0 * ost;
+            // items in groups of three: the table rows of a group are requested together, then its twelve mask values,
+            // then the arithmetic and the (predicated) stores -- one LDS round trip per stage and group instead of two
+            // per item (an item behind its own `if` is a basic block of its own: nothing of the next item was issued
+            // before the previous one had finished).  Out-of-range items read item 0's (valid) entries.
+            constexpr int GRP = 3;
+            static_assert(MASK_ITEMS % GRP == 0, "mask items come in groups of three");
 #pragma unroll
-            for (int q = 0; q < MASK_ITEMS; ++q) {
-                if (tq < nfr && f < NBINS) {
-                    const f32x4 tb = ld4(sBS + f * 4);
-                    const float* m0 = sM + tq * F0 + __float_as_int(tb[0]);
+            for (int q0 = 0; q0 < MASK_ITEMS; q0 += GRP) {
+                bool ok[GRP];
+                int fo[GRP];
+                const float* m0[GRP];
+                f32x4 tb[GRP];
+#pragma unroll
+                for (int j = 0; j < GRP; ++j) {
+                    ok[j] = tq < nfr && f < NBINS;
+                    const int fc = ok[j] ? f : 0, tc = ok[j] ? tq : 0;
+                    tb[j] = ld4(sBS + fc * 4);
+                    m0[j] = sM + tc * F0;
+                    fo[j] = f * osf32 + tq * ost32;
+                    spec_item_next(t_fast, tq, f);
+                }
+                float a0[GRP], a1[GRP], b0[GRP], b1[GRP];
+#pragma unroll
+                for (int j = 0; j < GRP; ++j) {
+                    const float* mp = m0[j] + __float_as_int(tb[j][0]);
+                    a0[j] = mp[0]; a1[j] = mp[1]; b0[j] = mp[RW * F0]; b1[j] = mp[RW * F0 + 1];
+                }
+#pragma unroll
+                for (int j = 0; j < GRP; ++j) {
                     // second tap selected, not multiplied by a zero weight: for the last band it would read the
                     // first element of the next frame's row, which may be stale (0 * NaN)
-                    const bool two = tb[2] != 0.f;
-                    const float mr = rq1<Q>(tb[1] * m0[0] + (two ? tb[2] * m0[1] : 0.f));
-                    const float mi = rq1<Q>(tb[1] * m0[RW * F0] + (two ? tb[2] * m0[RW * F0 + 1] : 0.f));
-                    float re = spv[q].x, im = spv[q].y;
+                    const bool two = tb[j][2] != 0.f;
+                    const float mr = rq1<Q>(tb[j][1] * a0[j] + (two ? tb[j][2] * a1[j] : 0.f));
+                    const float mi = rq1<Q>(tb[j][1] * b0[j] + (two ? tb[j][2] * b1[j] : 0.f));
+                    float re = spv[q0 + j].x, im = spv[q0 + j].y;
                     if constexpr (Q) {
                         if (qin > 0.f) {       // the mask multiplies the model's own (boundary-quantised) input
                             re = fminf(fmaxf(rintf(re / qin), -128.f), 127.f) * qin;
@@ -2278,9 +2302,8 @@ __global__ __launch_bounds__(NTHR) void k_decoder(const float* __restrict__ xg, 
                             yi = fminf(fmaxf(rintf(yi / qout), -128.f), 127.f) * qout;
                         }
                     }
-                    *reinterpret_cast<float2*>(obase + (f * osf32 + tq * ost32)) = make_float2(yr, yi);
+                    if (ok[j]) *reinterpret_cast<float2*>(obase + fo[j]) = make_float2(yr, yi);
                 }
-                spec_item_next(t_fast, tq, f);
             }
         }
         wg_barrier();  // sM and region A are rewritten by the next chunk
