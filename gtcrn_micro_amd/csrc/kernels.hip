@@ -502,10 +502,10 @@ __device__ __forceinline__ Tiles<TPW> make_tiles(const Lane& L) {
 }
 // float offset of the lane's record in a 35-column row image (zero pad columns 0 and 34)
 constexpr int IMG_R0 = 2;   // image row of the chunk's first frame (rows 0, 1: the two frames before the chunk)
-template <int RS, int R0, int TPW>
+template <int RS, int R0, int PT = 35, int TPW>
 __device__ __forceinline__ int o35(const Tiles<TPW>& t, int i, int g) {
     // 24-bit multiplies: full rate (v_mul_lo_u32 is quarter rate and the compiler cannot see the value ranges)
-    return __mul24(__mul24(t.tl[i] + R0, 35) + 1 + t.ff[i], RS) + 4 * g;
+    return __mul24(__mul24(t.tl[i] + R0, PT) + 1 + t.ff[i], RS) + 4 * g;
 }
 
 // The spectrogram elements of a chunk a thread handles: item q is element idx = tid + q*NTHR of the chunk,
@@ -557,15 +557,15 @@ constexpr int RING_SET = 3 * 2 * 35 * 16;   // floats of one stream's three 2-ro
 // `hook` runs right after the depth-conv phase (register pressure is past its peak there, and two
 // barrier intervals of work follow): the decoder uses it to request inputs of later phases early.
 // history ring [2 frames][33][16] (older frame first) -> image rows 0, 1 (the pad columns are zeroed per chunk)
-template <int RS>
+template <int RS, int PT = 35>
 __device__ __forceinline__ void ring_to_image(float* sW, const float* ring, int tid) {
     if (tid < 2 * 33 * 4) {
         const int row = tid >= 132 ? 1 : 0, r = tid - row * 132;
-        st4(sW + pl<RS>(row * 35 + 1 + (r >> 2), r & 3), ld4(ring + (row * 33 + (r >> 2)) * 16 + (r & 3) * 4));
+        st4(sW + pl<RS>(row * PT + 1 + (r >> 2), r & 3), ld4(ring + (row * 33 + (r >> 2)) * 16 + (r & 3) * 4));
     }
 }
 
-template <bool DENSE, int TPW, bool MS, bool Q, int RS, int RSS, bool WIDE_TRA, class Hook>
+template <bool DENSE, int TPW, bool MS, bool Q, int RS, int RSS, bool WIDE_TRA, int PT, class Hook>
 __device__ __forceinline__ void gtconv_block(f32x4 (&x)[TPW], const Tiles<TPW>& tin, const BlockCtx& c,
                                              const Lane& L, Hook&& hook STAMP_PARAM) {
     static_assert(!MS || TPW == 1, "multi-stream mode runs one tile per wave");
@@ -582,14 +582,14 @@ __device__ __forceinline__ void gtconv_block(f32x4 (&x)[TPW], const Tiles<TPW>& 
     for (int i = 0; i < TPW; ++i) asm volatile("" : "+v"(tt.tl[i]));
     int b0s[TPW];
 #pragma unroll
-    for (int i = 0; i < TPW; ++i) b0s[i] = o35<RS, R0>(tt, i, g);
+    for (int i = 0; i < TPW; ++i) b0s[i] = o35<RS, R0, PT>(tt, i, g);
     // float offset (from sW) of the record `back` frames before tile i's own position b0
     auto tap_base = [&](int i, int back, int b0) -> int {
         if constexpr (MS) return back == 0 ? b0 : c.ms_roff + (((c.ms_tb + back) & 1) * 35 + 1 + tt.ff[i]) * RS + 4 * g;
-        else return b0 - back * 35 * RS;
+        else return b0 - back * PT * RS;
     };
     if constexpr (!MS) {
-        if (c.sHtop) ring_to_image<RS>(c.sW, c.sHtop, L.tid);
+        if (c.sHtop) ring_to_image<RS, PT>(c.sW, c.sHtop, L.tid);
     }
     const float a1 = c.pb[GB_SLOPE] - 1.0f, a2 = c.pb[GB_SLOPE + 1] - 1.0f;
     // ---- point_conv1 + BN + PReLU; h lives only in the LDS image from here on (its centre tap and the
@@ -695,7 +695,7 @@ __device__ __forceinline__ void gtconv_block(f32x4 (&x)[TPW], const Tiles<TPW>& 
         // frames nfr-2, nfr-1 of the chunk = image rows nfr, nfr+1 (for a one-frame call row nfr is the old row 1)
         if (L.tid >= NTHR - 2 * 33 * 4) {
             const int q = L.tid - (NTHR - 2 * 33 * 4), row = q >= 132 ? 1 : 0, r = q - row * 132;
-            st4(c.sHk + (row * 33 + (r >> 2)) * 16 + (r & 3) * 4, ld4(c.sW + pl<RS>((c.nfr + row) * 35 + 1 + (r >> 2), r & 3)));
+            st4(c.sHk + (row * 33 + (r >> 2)) * 16 + (r & 3) * 4, ld4(c.sW + pl<RS>((c.nfr + row) * PT + 1 + (r >> 2), r & 3)));
         }
     }
     // ---- TRALite, step 1: energies e[t][c] = mean_F(v^2): 32 threads per frame = 8 h' channels x 4 bin
@@ -735,7 +735,7 @@ __device__ __forceinline__ void gtconv_block(f32x4 (&x)[TPW], const Tiles<TPW>& 
     // rows 0, 1 of the image are free (this block's ring save, which may read row 1, is behind the barrier): the next
     // block's history goes there now, off the critical path
     if constexpr (!MS) {
-        if (c.sHnext) ring_to_image<RS>(c.sW, c.sHnext, L.tid);
+        if (c.sHnext) ring_to_image<RS, PT>(c.sW, c.sHnext, L.tid);
     }
     // ---- step 2: one thread per (frame, output channel): causal depthwise conv1d (k=3) over the energies,
     //      1x1 conv, sigmoid (models/gtcrn_micro.py:122-139) ------------------------------------------------
@@ -768,14 +768,14 @@ __device__ __forceinline__ void gtconv_block(f32x4 (&x)[TPW], const Tiles<TPW>& 
 
 // zero the two pad columns of the TC rows of a 35-position row image (tid and the zero are made
 // opaque so that neither is hoisted out of the chunk loop and kept live / spilled)
-template <int ROWS = TC, int RS = 16>
+template <int ROWS = TC, int RS = 16, int PT = 35>
 __device__ __forceinline__ void zero_row_pads(float* img, int tid) {
     asm volatile("" : "+v"(tid));
     if (tid < ROWS * 2 * 4) {
         const int r = tid >> 3, side = (tid >> 2) & 1, gg = tid & 3;
         float z = 0.f;
         asm volatile("" : "+v"(z));
-        st4(img + pl<RS>(r * 35 + side * 34, gg), splat(z));
+        st4(img + pl<RS>(r * PT + side * 34, gg), splat(z));
     }
 }
 
@@ -923,7 +923,11 @@ struct EncLds {
     static constexpr int E = G + RW * 16 + RW * 8;             // (gates [RW][16] + y scratch [RW][8]); energies
     static constexpr int A = E + (MS ? NS * 24 : (RW + 2) * 8);   // FRONT: staged spec, then E0, then W + S; else W
     static constexpr int RWI = MS ? RW : RW + IMG_R0;         // image rows (two history rows in front of the chunk)
-    static constexpr int B = A + (FRONT ? RW * ENC_E0_ROW * 16 : RWI * 35 * RS);   // FRONT: EB + F0; else S
+    // image row pitch in records: 35 = 33 bins + two zero pad columns.  The offline form has LDS to spare and uses 41:
+    // a 16-position tile that runs over the end of a row then continues 9 = 1 (mod 8) records further on, so the
+    // conflict-free bank pattern of the 96-byte records (pl()) also holds for the ~half of the tiles that wrap (-2.6 %)
+    static constexpr int PT = FRONT ? 35 : 41;
+    static constexpr int B = A + (FRONT ? RW * ENC_E0_ROW * 16 : RWI * PT * RS);   // FRONT: EB + F0; else S
     static constexpr int S = FRONT ? A + RWI * 35 * 16 : B;   // FRONT: S may run over into B (EB / F0 are dead by then)
     static constexpr int FLOATS = B + (FRONT ? 3 * RW * EB_ROW + 3 * RW * F0_ROW : RW * 33 * RS);
     static_assert(3 * RW * NBINS <= RW * ENC_E0_ROW * 16, "staged [mag,re,im] chunk must fit in the E0 region");
@@ -992,7 +996,7 @@ __global__ __launch_bounds__(NTHR) void k_encoder(const float* __restrict__ spec
     }
     const Tiles<TPW> tt = make_tiles<TPW>(L);
     wg_barrier();
-    if constexpr (!FRONT) ring_to_image<RS>(sW, sH, tid);   // block 0's history of the first chunk (later ones: block 2)
+    if constexpr (!FRONT) ring_to_image<RS, LD::PT>(sW, sH, tid);   // block 0's history of the first chunk (later ones: block 2)
 
     spec += (long)b * sb;
     const long ob = (long)b * T;
@@ -1220,7 +1224,7 @@ __global__ __launch_bounds__(NTHR) void k_encoder(const float* __restrict__ spec
         wg_barrier();  // E0 is dead: its region becomes W
         STAMP(SS, 4)
         }   // FRONT
-        zero_row_pads<LD::RWI, RS>(sW, tid);
+        zero_row_pads<LD::RWI, RS, LD::PT>(sW, tid);
         // ---- E: 3 x GTConvBlock (depthwise) --------------------------------------------------------
 #pragma unroll 1
         for (int k = 0; k < 3; ++k) {
@@ -1244,7 +1248,7 @@ __global__ __launch_bounds__(NTHR) void k_encoder(const float* __restrict__ spec
             } else {
                 c.ms_roff = 0; c.ms_tb = 0;
             }
-            gtconv_block<false, TPW, MS, Q, RS, RS, !(FRONT && TPW == 3)>(x, tt, c, L, [] {} STAMP_ARG);
+            gtconv_block<false, TPW, MS, Q, RS, RS, !(FRONT && TPW == 3), LD::PT>(x, tt, c, L, [] {} STAMP_ARG);
             if (k < 2) {
                 ht* dst = k == 0 ? en2h : en3h;
                 const int* ix = sI + I_ENST - ENC_I_SKIP + (k + 1) * 16 + 4 * g;
@@ -2080,7 +2084,7 @@ __global__ __launch_bounds__(NTHR) void k_decoder(const float* __restrict__ xg, 
             } else {
                 c.ms_roff = 0; c.ms_tb = 0;
             }
-            gtconv_block<true, TPW, MS, Q, RS, LD::RSS, true>(x, tt, c, L, hook STAMP_ARG);
+            gtconv_block<true, TPW, MS, Q, RS, LD::RSS, true, 35>(x, tt, c, L, hook STAMP_ARG);
             if (DBG)
 #pragma unroll
                 for (int i = 0; i < TPW; ++i)
