@@ -29,6 +29,10 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 // ----------------------------------------------------------------------------- helpers
 __device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
 __device__ __forceinline__ void st4(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
+// parameter segment -> LDS, 16 bytes per lane (segment offsets and sizes are multiples of four floats, layout.h)
+__device__ __forceinline__ void copy_params(float* dst, const float* src, int n, int tid, int nthr) {
+    for (int i = 4 * tid; i < n; i += 4 * nthr) st4(dst + i, ld4(src + i));
+}
 __device__ __forceinline__ f32x4 splat(float v) { f32x4 r = {v, v, v, v}; return r; }
 
 // Workgroup barrier for LDS hand-offs only.  __syncthreads() carries a workgroup-scope release
@@ -979,7 +983,8 @@ __global__ __launch_bounds__(NTHR) void k_encoder(const float* __restrict__ spec
     const int tid = L.tid, n = L.n, g = L.g;
     const int b = blockIdx.x;
 
-    for (int i = tid + (FRONT ? 0 : E_BLK); i < ENC_SIZE; i += NTHR) sP[i] = PF[P_ENC + i];
+    static_assert(E_BLK % 4 == 0 && ENC_SIZE % 4 == 0 && P_ENC % 4 == 0, "16-byte parameter copies");
+    copy_params(sP + (FRONT ? 0 : E_BLK), PF + P_ENC + (FRONT ? 0 : E_BLK), ENC_SIZE - (FRONT ? 0 : E_BLK), tid, NTHR);
     // the integer tables without the decoder-side ERB.bs index ranges (I_BS_LO, I_BS_N): [0, I_BS_LO) stays in place,
     // [I_ENC_BLK, P_INTS) moves down by ENC_I_SKIP
     for (int i = tid; i < P_INTS - ENC_I_SKIP; i += NTHR) sI[i] = PI[i < I_BS_LO ? i : i + ENC_I_SKIP];
@@ -1342,7 +1347,7 @@ __global__ __launch_bounds__(FR_NT, 4) void k_front(const float* __restrict__ in
     float* sE0 = mine + FR_WX;
     float* sEB = mine + FR_WEB;
     float* sF0 = mine + FR_WF0;
-    for (int i = tid; i < E_BLK; i += FR_NT) sP[i] = PF[P_ENC + i];
+    copy_params(sP, PF + P_ENC, E_BLK, tid, FR_NT);
     for (int i = tid; i < 128; i += FR_NT) sI[i] = PI[I_ERB_LO + i];
     if (tid < 16) sI[128 + tid] = PI[I_ENST + tid];
     if (WAVE_IN) {
@@ -1656,7 +1661,7 @@ __global__ __launch_bounds__(NTHR) void k_gtcn(const float* __restrict__ xin, fl
     const Lane L = lane_info();
     const int tid = L.tid, n = L.n, g = L.g;
     const int b = blockIdx.x;
-    for (int i = tid; i < GTCN_SIZE; i += NTHR) sP[i] = P[i];
+    copy_params(sP, P, GTCN_SIZE, tid, NTHR);
     float* stb = state ? state + (long)b * ST_FLOATS : nullptr;
     const int tbase = stb ? reinterpret_cast<const int*>(stb)[0] : 0;
     // the rings [30 rows][33][16]: an LDS copy of the stream state, or (GRING) the state itself -- same layout
@@ -1775,7 +1780,8 @@ __global__ __launch_bounds__(GTMS_WAVES * 64) void k_gtcn_ms(const float* __rest
     fetch_rows(st + ST_G1_H);
     const f32x4 x0 = ld4(xin + pc * 16 + 4 * g);
     f32x4 x = x0;
-    for (int i = tid; i < 2 * GTCN_SIZE; i += GTMS_WAVES * 64) sP[i] = P[i];
+    static_assert(GTCN_SIZE % 4 == 0 && P_GTCN % 4 == 0 && P_DEC % 4 == 0, "16-byte parameter copies");
+    copy_params(sP, P, 2 * GTCN_SIZE, tid, GTMS_WAVES * 64);
     __syncthreads();
 #pragma unroll
     for (int stack = 0; stack < 2; ++stack) {
@@ -1881,7 +1887,7 @@ __global__ __launch_bounds__(NTHR) void k_gtcn_band(const float* __restrict__ xi
     const Lane L = lane_info();
     const int tid = L.tid, n = L.n, g = L.g;
     const int b = blockIdx.x;
-    for (int i = tid; i < GTCN_SIZE; i += NTHR) sP[i] = P[i];
+    copy_params(sP, P, GTCN_SIZE, tid, NTHR);
     for (int i = tid; i < 33 * 30 * GB_RS / 4; i += NTHR) st4(sHh + i * 4, splat(0.f));   // zero history (frames < 0)
     __syncthreads();
     using ht = typename HandOff<Q>::t;
@@ -1997,7 +2003,7 @@ __global__ __launch_bounds__(NTHR) void k_decoder(const float* __restrict__ xg, 
     const Lane L = lane_info();
     const int tid = L.tid, n = L.n, g = L.g;
     const int b = blockIdx.x;
-    for (int i = tid; i < D_BS_W; i += NTHR) sP[i] = PF[P_DEC + i];
+    copy_params(sP, PF + P_DEC, D_BS_W, tid, NTHR);
     if (tid < 48) sI[tid] = PI[I_DEC_BLK + tid];
     for (int f = tid; f < NBINS; f += NTHR) st4(sBS + f * 4, ld4(PF + P_DEC + D_BS_TAB + f * 4));
     if (tid < 4) sM[2 * RW * F0 + tid] = 0.f;
