@@ -97,6 +97,27 @@ def test_chunked_equals_offline_many_streams(dev):
         assert torch.equal(got, full), (chunks, rel_err(got.cpu().numpy(), full.cpu().numpy()))
 
 
+def test_stream_counts_that_do_not_fill_a_workgroup(dev):
+    """Single-frame steps serve four streams per workgroup: stream counts that leave the last workgroup with 1, 2 or 3
+    live streams (and a lone stream) still equal the offline result bit for bit, and mixing single-frame steps with
+    longer calls keeps the per-stream state consistent between the two kernel forms."""
+    from gtcrn_micro_amd import Engine
+    eng = Engine(load_params("dns3"), 0)
+    rng = np.random.default_rng(11)
+    T = 21
+    for N in (1, 2, 3, 5, 6, 7):
+        spec = cu((rng.standard_normal((N, 257, T, 2)) * 0.3).astype(np.float32))
+        full = eng.forward_spec(spec)
+        for chunks in ([1] * T, [1, 1, 4, 1, 1, 1, 9, 1, 1, 1]):
+            st = eng.new_state(N)
+            t0, outs = 0, []
+            for c in chunks:
+                outs.append(eng.stream_step(st, spec[:, :, t0:t0 + c]))
+                t0 += c
+            assert t0 == T
+            assert torch.equal(torch.cat(outs, 2), full), (N, chunks)
+
+
 def test_conv_wrappers_like_reference_test(dev):
     """tests/streaming/conversion/test_convolution.py of the reference, run against the HIP wrappers:
     streaming == offline for StreamConv2d(1,1,3) and StreamConvTranspose2d(4,8,(3,1),dil(2,2),pad(0,1)),
