@@ -1053,7 +1053,7 @@ __global__ __launch_bounds__(NTHR) void k_encoder(const float* __restrict__ spec
         const int nfr = min(RW, T - t0);
         f32x4 x[TPW];
         if constexpr (!FRONT) {
-            // en1 exists only in the slot order of its decoder consumer (k_front is bound by its HBM writes: a second
+            // en1 exists only in the slot order of its decoder consumer (k_front is sensitive to its output stores: a second
             // copy in this stage's order cost it 11 %): back to the own order through the tile's scratch records
             // (S is dead at the top of a chunk)
             {
@@ -1307,7 +1307,7 @@ __global__ __launch_bounds__(NTHR) void k_encoder(const float* __restrict__ spec
 // in-kernel front end (which the streaming forms keep), so every value is bit-identical.
 // WAVE_IN = false: the frames come from a caller spectrogram (gtcrn_forward_spec) instead of the FFT.
 // Outputs: the spectrogram, en0 (B,T,65,16) and en1 (B,T,33,16) in the slot order of its decoder consumer (en1p);
-// the first GTConv block un-permutes it on load.  The kernel is bound by these HBM writes (0.53 GB per launch at
+// the first GTConv block un-permutes it on load.  The kernel is sensitive to these stores (0.53 GB per launch at
 // B = 256 x 4 s: a second copy of en1 in its own slot order made it 11 % slower).
 constexpr int FR_WAVES = 8;
 constexpr int FR_NT = FR_WAVES * 64;
