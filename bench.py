@@ -116,6 +116,94 @@ def _load_shim():
     return mod
 
 
+class Watchdog:
+    """Bounds a phase that may hang on a collective (a rank that died alone leaves the others waiting in RCCL until its
+    own timeout, long after the driver has given up): after `seconds` rank 0 prints the line as it stands -- the
+    headline is complete before any secondary leg starts -- with the reason, and every rank leaves the process."""
+
+    def __init__(self, seconds, rank, get_line, what):
+        self.seconds, self.rank, self.get_line, self.what = seconds, rank, get_line, what
+        self.timer = None
+
+    def _fire(self):
+        if self.rank == 0:
+            line = self.get_line()
+            if line is not None:
+                line.setdefault("secondary_errors", {})[self.what] = (
+                    f"timed out after {self.seconds:g} s (a rank failed or hung inside a collective); line printed by "
+                    "the watchdog")
+                print(json.dumps(line), flush=True)
+        else:
+            time.sleep(2.0)                                    # let rank 0's line out first
+        os._exit(0 if self.get_line() is not None or self.rank != 0 else 1)
+
+    def __enter__(self):
+        import threading
+        self.timer = threading.Timer(self.seconds, self._fire)
+        self.timer.daemon = True
+        self.timer.start()
+        return self
+
+    def __exit__(self, *exc):
+        self.timer.cancel()
+        return False
+
+
+def gather_ranks(obj, world):
+    """[obj of rank 0, ..., obj of rank world-1] on every rank (identity when not distributed)."""
+    if world == 1:
+        return [obj]
+    import torch.distributed as dist
+    out = [None] * world
+    dist.all_gather_object(out, obj)
+    return out
+
+
+def run_leg(name, fn, rank, world, get_line, timeout_s=300.0):
+    """One secondary leg, tolerant of a rank failing alone: `fn(sync_local, record_elapsed)` runs WITHOUT collectives
+    (every rank times its own shard between device synchronisations; the ranks start together behind one barrier
+    OUTSIDE the try block), then ONE object gather, also outside the try block, carries every rank's result or error
+    to rank 0, which prices throughput with the slowest rank's time.  Legs whose work itself contains a collective
+    (the train step's gradient all-reduce) validate their allocations locally first and agree on it (see
+    train_leg).  The whole leg sits inside a watchdog."""
+    import torch
+    els = []
+
+    def sync_local():
+        if torch.cuda.is_available():
+            torch.cuda.synchronize()
+
+    def record(v, device=None):
+        els.append(float(v))
+        return float(v)
+
+    with Watchdog(timeout_s, rank, get_line, name):
+        if world > 1:
+            import torch.distributed as dist
+            dist.barrier()
+        res, err = None, None
+        try:
+            res = fn(sync_local, record)
+        except Exception as e:                                 # a secondary leg must never take the headline down
+            err = repr(e)
+        allr = gather_ranks({"res": res if rank == 0 else None, "err": err, "el": els[-1] if els else None}, world)
+    errs = {str(r): x["err"] for r, x in enumerate(allr) if x["err"]}
+    if errs:
+        return {"error": errs["0"] if world == 1 else errs}
+    res = allr[0]["res"]
+    if res is None:
+        return None
+    tl = [x["el"] for x in allr]
+    k = tl[0] / max(tl)                                        # rank 0 priced its own time; the slowest rank sets the rate
+    for key in res.pop("_rate_keys", []):
+        res[key] = round(res[key] * k, 1)
+    for key in res.pop("_time_keys", []):
+        res[key] = round(res[key] / k, 4)
+    if world > 1:
+        res["per_rank_timed_s"] = {"min": round(min(tl), 5), "max": round(max(tl), 5)}
+    return res
+
+
 def cpu_baseline(params, seconds_per_candidate=3.0):
     """The reference's CPU arithmetic (ATen) on a bounded sample of the same workload.
 
@@ -207,6 +295,7 @@ def stream_leg(eng, world, sync_all, max_over_ranks, nstreams=1024, frames=251):
         "state_bound_frame_steps_per_s": round(HBM_PEAK_GBS * 1e9 / STREAM_STATE_BYTES_PER_FRAME, 1),
         "frac_of_state_bound": round(fsteps / world / (HBM_PEAK_GBS * 1e9 / STREAM_STATE_BYTES_PER_FRAME), 4),
         "stream_vs_offline_rel_err": err, "dtype": "f32",
+        "_rate_keys": ["frame_steps_per_s"], "_time_keys": ["ms_per_call_back_to_back"],
     }
     del spec, out, state, full
     torch.cuda.empty_cache()

@@ -49,6 +49,10 @@ __device__ __forceinline__ void wave_lds_sync() {
 __device__ __forceinline__ void wg_barrier() {
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
+// ... that also publishes this wave's LDS-DMA writes (global_load_lds: counted in vmcnt)
+__device__ __forceinline__ void wg_barrier_vm() {
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
 
 // position-major LDS image: one record of 16 floats per position, slot group g at +16g bytes, records RS floats apart.
 // Unswizzled on purpose: tap addresses are then "own address + compile-time constant", which keeps address arithmetic
@@ -154,6 +158,64 @@ __device__ __forceinline__ void mm16(const f32x4 A, const f32x4 (&x)[N], f32x4 (
 #pragma unroll
             for (int i = 0; i < N; ++i) acc[i] = mfma(A[s], x[i][s], acc[i]);
     }
+}
+
+// ---- the dense 3x3 on the 16-bit matrix pipe ("split" form) --------------------------------
+// fp32 MFMA (v_mfma_f32_16x16x4_f32) runs at the fp32 VALU rate and blocks the VALU while it does.  The decoder's
+// dense transposed 3x3 (a 16 x 144 by 144 x 16 product per tile, 72 % of its matrix instructions) therefore runs on
+// v_mfma_f32_16x16x32_bf16 instead, WITHOUT giving up fp32 accuracy: both operands are split exactly into three
+// bf16 planes (x = hi + mid + lo: 3 x 8 significant bits are fp32's 24; every residual is exact in fp32) and the
+// six partial products of weight >= 2^-16 are accumulated in fp32 (hi.hi, hi.mid, mid.hi, mid.mid, hi.lo, lo.hi; the
+// dropped ones are <= 2^-24 relative).  30 instructions of 16 cycles that co-execute with the VALU replace 36 of 32
+// cycles that do not; against float64 the result is as accurate as the fp32 chain (tools/ubench_split_bf16.hip:
+// max 5.7e-7 vs 7.1e-7 of the output scale, 2.05x faster).  The weights are split by the host packer (layout.h
+// D_DN16); h is split once where point_conv1 produces it and lives in LDS as three 32-byte planes per position --
+// the same 96 bytes as the padded fp32 record it replaces.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+#ifdef GT_EXP
+constexpr bool kSplitDense = false;     // A/B reference (tools/ab_bench.py): the round-2 fp32-MFMA dense 3x3
+#else
+constexpr bool kSplitDense = true;
+#endif
+struct Split3 {
+    bf16x4 h, m, l;
+};
+__device__ __forceinline__ Split3 split3(const f32x4 v) {
+    Split3 s;
+    const f32x2 v01 = {v[0], v[1]}, v23 = {v[2], v[3]};
+    const bf16x2 h01 = __builtin_convertvector(v01, bf16x2), h23 = __builtin_convertvector(v23, bf16x2);
+    const f32x2 r01 = {v[0] - (float)h01[0], v[1] - (float)h01[1]}, r23 = {v[2] - (float)h23[0], v[3] - (float)h23[1]};
+    const bf16x2 m01 = __builtin_convertvector(r01, bf16x2), m23 = __builtin_convertvector(r23, bf16x2);
+    const f32x2 q01 = {r01[0] - (float)m01[0], r01[1] - (float)m01[1]}, q23 = {r23[0] - (float)m23[0], r23[1] - (float)m23[1]};
+    const bf16x2 l01 = __builtin_convertvector(q01, bf16x2), l23 = __builtin_convertvector(q23, bf16x2);
+    s.h[0] = h01[0]; s.h[1] = h01[1]; s.h[2] = h23[0]; s.h[3] = h23[1];
+    s.m[0] = m01[0]; s.m[1] = m01[1]; s.m[2] = m23[0]; s.m[3] = m23[1];
+    s.l[0] = l01[0]; s.l[1] = l01[1]; s.l[2] = l23[0]; s.l[3] = l23[1];
+    return s;
+}
+// the inverse, exact: mid + lo has at most 16 significant bits, hi + (mid + lo) is the fp32 value that was split
+__device__ __forceinline__ f32x4 join3(const bf16x4 h, const bf16x4 m, const bf16x4 l) {
+    f32x4 r;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) r[e] = (float)h[e] + ((float)m[e] + (float)l[e]);
+    return r;
+}
+// split record at float offset `rec` of an image with 24-float (96-byte) records: plane p at +8p floats, the lane's
+// four slots 4g..4g+3 at +2g floats inside the plane
+__device__ __forceinline__ void st_split(float* img, int rec, int g, const f32x4 v) {
+    const Split3 s = split3(v);
+    *reinterpret_cast<bf16x4*>(img + rec + 2 * g) = s.h;
+    *reinterpret_cast<bf16x4*>(img + rec + 8 + 2 * g) = s.m;
+    *reinterpret_cast<bf16x4*>(img + rec + 16 + 2 * g) = s.l;
+}
+__device__ __forceinline__ f32x4 ld_split(const float* img, int rec, int g) {
+    return join3(*reinterpret_cast<const bf16x4*>(img + rec + 2 * g), *reinterpret_cast<const bf16x4*>(img + rec + 8 + 2 * g),
+                 *reinterpret_cast<const bf16x4*>(img + rec + 16 + 2 * g));
+}
+__device__ __forceinline__ f32x4 mfma_bf(const bf16x8 a, const bf16x8 b, const f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
 }
 
 // Hand-off tensors (en0..en4, gtcn1, gtcn2+en4) in HBM: fp32 records, or -- in the Q variant, whose activations are
@@ -561,11 +623,13 @@ constexpr int RING_SET = 3 * 2 * 35 * 16;   // floats of one stream's three 2-ro
 // `hook` runs right after the depth-conv phase (register pressure is past its peak there, and two
 // barrier intervals of work follow): the decoder uses it to request inputs of later phases early.
 // history ring [2 frames][33][16] (older frame first) -> image rows 0, 1 (the pad columns are zeroed per chunk)
-template <int RS, int PT = 35>
+template <int RS, int PT = 35, bool SPLIT = false>
 __device__ __forceinline__ void ring_to_image(float* sW, const float* ring, int tid) {
     if (tid < 2 * 33 * 4) {
         const int row = tid >= 132 ? 1 : 0, r = tid - row * 132;
-        st4(sW + pl<RS>(row * PT + 1 + (r >> 2), r & 3), ld4(ring + (row * 33 + (r >> 2)) * 16 + (r & 3) * 4));
+        const f32x4 v = ld4(ring + (row * 33 + (r >> 2)) * 16 + (r & 3) * 4);
+        if constexpr (SPLIT) st_split(sW, (row * PT + 1 + (r >> 2)) * RS, r & 3, v);   // the ring is fp32, the image split
+        else st4(sW + pl<RS>(row * PT + 1 + (r >> 2), r & 3), v);
     }
 }
 
@@ -573,6 +637,9 @@ template <bool DENSE, int TPW, bool MS, bool Q, int RS, int RSS, bool WIDE_TRA, 
 __device__ __forceinline__ void gtconv_block(f32x4 (&x)[TPW], const Tiles<TPW>& tin, const BlockCtx& c,
                                              const Lane& L, Hook&& hook STAMP_PARAM) {
     static_assert(!MS || TPW == 1, "multi-stream mode runs one tile per wave");
+    // SPLIT: the dense 3x3 on the 16-bit matrix pipe; the image W then holds h as three bf16 planes per position
+    constexpr bool SPLIT = DENSE && !Q && kSplitDense;
+    static_assert(!SPLIT || RS == RS_WIDE, "the split image has 96-byte records");
     const int n = L.n, g = L.g;
     // Image rows (not MS): rows 0, 1 hold the two frames BEFORE the chunk -- copied from the block's history ring at
     // the top of the block -- and row 2 + tl holds frame tl of the chunk, so a temporal tap is always "own record minus
@@ -593,7 +660,7 @@ __device__ __forceinline__ void gtconv_block(f32x4 (&x)[TPW], const Tiles<TPW>& 
         else return b0 - back * PT * RS;
     };
     if constexpr (!MS) {
-        if (c.sHtop) ring_to_image<RS, PT>(c.sW, c.sHtop, L.tid);
+        if (c.sHtop) ring_to_image<RS, PT, SPLIT>(c.sW, c.sHtop, L.tid);
     }
     const float a1 = c.pb[GB_SLOPE] - 1.0f, a2 = c.pb[GB_SLOPE + 1] - 1.0f;
     // ---- point_conv1 + BN + PReLU; h lives only in the LDS image from here on (its centre tap and the
@@ -605,7 +672,10 @@ __device__ __forceinline__ void gtconv_block(f32x4 (&x)[TPW], const Tiles<TPW>& 
         for (int i = 0; i < TPW; ++i) h[i] = Bv;
         mm16<TPW, Q>(A, x, h);
 #pragma unroll
-        for (int i = 0; i < TPW; ++i) st4(c.sW + b0s[i], rq<Q>(prelu4(h[i], a1)));
+        for (int i = 0; i < TPW; ++i) {
+            if constexpr (SPLIT) st_split(c.sW, b0s[i] - 4 * g, g, prelu4(h[i], a1));
+            else st4(c.sW + b0s[i], rq<Q>(prelu4(h[i], a1)));
+        }
     }
     wg_barrier();
     STAMP(SS, 5)
@@ -649,6 +719,57 @@ __device__ __forceinline__ void gtconv_block(f32x4 (&x)[TPW], const Tiles<TPW>& 
                 x[i] = rq<Q>(x[i]);
                 st4(c.sS + tt.pp(i) * RSS + 4 * g, x[i] * x[i]);   // energies are reduced cooperatively after the barrier
             }
+        } else if constexpr (SPLIT) {
+            // dense transposed 3x3 on v_mfma_f32_16x16x32_bf16: K-chunk cc = taps 2cc and 2cc+1 (k = tap half * 16 + hidden
+            // channel; the lane groups g < 2 hold the first tap, g >= 2 the second); per chunk the three weight planes are
+            // read once per wave, the three h planes once per tile, six products per tile (small ones first)
+            f32x4 acc[TPW];
+            int rec0[TPW];
+#pragma unroll
+            for (int i = 0; i < TPW; ++i) { acc[i] = Bd; rec0[i] = b0s[i] - 4 * g; }
+            // (from an opaque copy of g: the five per-chunk tap selects are recomputed per block -- five vector ops --
+            // instead of being hoisted out of the chunk loop and spilled)
+            int gq = g;
+            asm volatile("" : "+v"(gq));
+            const bool second = gq >= 2;
+            const int q16 = 4 * (gq & 1);                    // channels 0..7 / 8..15 of the plane
+            // float offset of the record `back` frames before tile i's own one (MS: in that stream's ring)
+            auto rec_back = [&](int i, int back) -> int {
+                if constexpr (MS) return back == 0 ? rec0[i] : c.ms_roff + (((c.ms_tb + back) & 1) * 35 + 1 + tt.ff[i]) * RS;
+                else return rec0[i] - back * PT * RS;
+            };
+#pragma unroll
+            for (int cc = 0; cc < DN16_CHUNKS; ++cc) {
+                constexpr int NT = 9;
+                const int tA = 2 * cc, tB = 2 * cc + 1 < NT ? 2 * cc + 1 : NT - 1;   // (chunk 4: zero weights on a valid record)
+                bf16x8 ap[3];
+#pragma unroll
+                for (int p = 0; p < 3; ++p) ap[p] = *reinterpret_cast<const bf16x8*>(c.gA + (cc * 3 + p) * 256 + arow(n, g));
+#pragma unroll
+                for (int i = 0; i < TPW; ++i) {
+                    // decoder (transposed): tap (kt, kf) reads (t - kt, f + 1 - kf)
+                    const int ra = rec_back(i, tA / 3) + (1 - tA % 3) * RS, rb = rec_back(i, tB / 3) + (1 - tB % 3) * RS;
+                    const float* src = c.sW + (second ? rb : ra) + q16;
+                    bf16x8 bp[3];
+#pragma unroll
+                    for (int p = 0; p < 3; ++p) bp[p] = *reinterpret_cast<const bf16x8*>(src + 8 * p);
+                    acc[i] = mfma_bf(ap[0], bp[2], acc[i]);
+                    acc[i] = mfma_bf(ap[2], bp[0], acc[i]);
+                    acc[i] = mfma_bf(ap[1], bp[1], acc[i]);
+                    acc[i] = mfma_bf(ap[0], bp[1], acc[i]);
+                    acc[i] = mfma_bf(ap[1], bp[0], acc[i]);
+                    acc[i] = mfma_bf(ap[0], bp[0], acc[i]);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#pragma unroll
+            for (int i = 0; i < TPW; ++i) {
+                acc[i] = prelu4(acc[i], a2);
+                x[i] = keep * x[i] + B2;
+            }
+            mm16<TPW, Q>(A2, acc, x);                         // point_conv2: the tiles' chains interleaved
+#pragma unroll
+            for (int i = 0; i < TPW; ++i) st4(c.sS + tt.pp(i) * RSS + 4 * g, x[i] * x[i]);
         } else {
             // dense transposed 3x3, tap major: each of the nine 16x16 slot matrices is read from LDS once per wave
             // (not once per tile) and feeds one MFMA chain per tile -- TPW independent accumulator chains
@@ -691,15 +812,28 @@ __device__ __forceinline__ void gtconv_block(f32x4 (&x)[TPW], const Tiles<TPW>& 
     hook();
     // ---- history ring of h (after every wave has read its taps): the last two frames of the image ---------------
     if constexpr (MS) {
+        // (same record format in the image and in the LDS ring: a copy of the lane's 16 bytes -- SPLIT: three planes'
+        // 8 bytes, which sit at float offsets 2g, 8 + 2g, 16 + 2g of the 96-byte record)
 #pragma unroll
         for (int i = 0; i < TPW; ++i)
-            if (tt.tl[i] < c.nfr)
-                st4(c.sW + c.ms_roff + ((c.ms_tb & 1) * 35 + 1 + tt.ff[i]) * RS + 4 * g, ld4(c.sW + b0s[i]));
+            if (tt.tl[i] < c.nfr) {
+                const int dst = c.ms_roff + ((c.ms_tb & 1) * 35 + 1 + tt.ff[i]) * RS;
+                if constexpr (SPLIT) {
+#pragma unroll
+                    for (int p = 0; p < 3; ++p)
+                        *reinterpret_cast<f32x2*>(c.sW + dst + 8 * p + 2 * g) =
+                            *reinterpret_cast<const f32x2*>(c.sW + b0s[i] - 4 * g + 8 * p + 2 * g);
+                } else {
+                    st4(c.sW + dst + 4 * g, ld4(c.sW + b0s[i]));
+                }
+            }
     } else {
         // frames nfr-2, nfr-1 of the chunk = image rows nfr, nfr+1 (for a one-frame call row nfr is the old row 1)
         if (L.tid >= NTHR - 2 * 33 * 4) {
             const int q = L.tid - (NTHR - 2 * 33 * 4), row = q >= 132 ? 1 : 0, r = q - row * 132;
-            st4(c.sHk + (row * 33 + (r >> 2)) * 16 + (r & 3) * 4, ld4(c.sW + pl<RS>((c.nfr + row) * PT + 1 + (r >> 2), r & 3)));
+            float* dst = c.sHk + (row * 33 + (r >> 2)) * 16 + (r & 3) * 4;
+            if constexpr (SPLIT) st4(dst, ld_split(c.sW, ((c.nfr + row) * PT + 1 + (r >> 2)) * RS, r & 3));   // exact
+            else st4(dst, ld4(c.sW + pl<RS>((c.nfr + row) * PT + 1 + (r >> 2), r & 3)));
         }
     }
     // ---- TRALite, step 1: energies e[t][c] = mean_F(v^2): 32 threads per frame = 8 h' channels x 4 bin
@@ -707,8 +841,12 @@ __device__ __forceinline__ void gtconv_block(f32x4 (&x)[TPW], const Tiles<TPW>& 
     //      combined there in a fixed order (bit-reproducible).  Written to sE[2 + t][c]; rows 0,1 of sE
     //      hold the two frames before the chunk (the block's energy ring) ---------------------------------
     {
-        const int part = L.tid & 3, rc = (L.tid >> 2) & 7, rt = L.tid >> 5;
-        if (L.tid < c.nfr * 32) {
+        // (index arithmetic from an opaque copy of tid: recomputed per block instead of hoisted out of the block and
+        // chunk loops, kept live across the whole kernel and spilled -- a scratch reload drains every load in flight)
+        int tz1 = L.tid;
+        asm volatile("" : "+v"(tz1));
+        const int part = tz1 & 3, rc = (tz1 >> 2) & 7, rt = tz1 >> 5;
+        if (tz1 < c.nfr * 32) {
             // nine independent loads per thread (the last range, bins 27..32, reads bins 24..32 and drops the first
             // three), then the same ascending-bin summation as a 9 / 6-trip loop -- whose loads went out one by one
             float sum = 0.f;
@@ -727,11 +865,11 @@ __device__ __forceinline__ void gtconv_block(f32x4 (&x)[TPW], const Tiles<TPW>& 
             sum += dpp_ror<0xB1>(sum);   // quad_perm [1,0,3,2]
             sum += dpp_ror<0x4E>(sum);   // quad_perm [2,3,0,1]
             if (part == 0) c.sE[(MS ? rt * 3 + 2 : 2 + rt) * 8 + rc] = sum * (1.0f / 33.0f);
-        } else if (MS && L.tid >= NTHR - 64) {    // an otherwise idle wave copies every stream's ring into its rows 0,1
-            const int q = L.tid - (NTHR - 64), sidx = q >> 4, r = (q >> 3) & 1, cc = q & 7;
+        } else if (MS && tz1 >= NTHR - 64) {    // an otherwise idle wave copies every stream's ring into its rows 0,1
+            const int q = tz1 - (NTHR - 64), sidx = q >> 4, r = (q >> 3) & 1, cc = q & 7;
             if (sidx < c.nfr) c.sE[(sidx * 3 + r) * 8 + cc] = c.sEHk[sidx * 48 + ((c.sTB[sidx] - 2 + r) & 1) * 8 + cc];
-        } else if (!MS && L.tid >= NTHR - 16) {   // an otherwise idle wave copies the ring into rows 0,1
-            const int q = L.tid - (NTHR - 16), r = q >> 3, cc = q & 7;
+        } else if (!MS && tz1 >= NTHR - 16) {   // an otherwise idle wave copies the ring into rows 0,1
+            const int q = tz1 - (NTHR - 16), r = q >> 3, cc = q & 7;
             c.sE[r * 8 + cc] = c.sEHk[((c.tabs - 2 + r) & 1) * 8 + cc];
         }
     }
@@ -739,13 +877,15 @@ __device__ __forceinline__ void gtconv_block(f32x4 (&x)[TPW], const Tiles<TPW>& 
     // rows 0, 1 of the image are free (this block's ring save, which may read row 1, is behind the barrier): the next
     // block's history goes there now, off the critical path
     if constexpr (!MS) {
-        if (c.sHnext) ring_to_image<RS, PT>(c.sW, c.sHnext, L.tid);
+        if (c.sHnext) ring_to_image<RS, PT, SPLIT>(c.sW, c.sHnext, L.tid);
     }
     // ---- step 2: one thread per (frame, output channel): causal depthwise conv1d (k=3) over the energies,
     //      1x1 conv, sigmoid (models/gtcrn_micro.py:122-139) ------------------------------------------------
     {
-        const int ro = L.tid & 7, rt = L.tid >> 3;
-        if (L.tid < c.nfr * 8) {
+        int tz2 = L.tid;
+        asm volatile("" : "+v"(tz2));
+        const int ro = tz2 & 7, rt = tz2 >> 3;
+        if (tz2 < c.nfr * 8) {
             const float* e = c.sE + (MS ? rt * 24 : rt * 8) + ro;    // rows rt, rt+1, rt+2 = frames t-2, t-1, t
             const float y = c.pb[GB_TRA_DB + ro] + c.pb[GB_TRA_DW + ro * 3] * e[0] +
                             c.pb[GB_TRA_DW + ro * 3 + 1] * e[8] + c.pb[GB_TRA_DW + ro * 3 + 2] * e[16];
@@ -764,7 +904,8 @@ __device__ __forceinline__ void gtconv_block(f32x4 (&x)[TPW], const Tiles<TPW>& 
             else if (rt >= c.nfr - 2) c.sEHk[((c.tabs + rt) & 1) * 8 + ro] = e[16];
         }
     }
-    wg_barrier();
+    if constexpr (DENSE) wg_barrier_vm();   // the decoder's hook started the next block's weight DMA two barriers ago
+    else wg_barrier();
     STAMP(SS, 7)
 #pragma unroll
     for (int i = 0; i < TPW; ++i) x[i] = rq<Q>(x[i] * ld4(c.sG + tt.tl[i] * 16 + 4 * g));
@@ -775,11 +916,13 @@ __device__ __forceinline__ void gtconv_block(f32x4 (&x)[TPW], const Tiles<TPW>& 
 template <int ROWS = TC, int RS = 16, int PT = 35>
 __device__ __forceinline__ void zero_row_pads(float* img, int tid) {
     asm volatile("" : "+v"(tid));
-    if (tid < ROWS * 2 * 4) {
-        const int r = tid >> 3, side = (tid >> 2) & 1, gg = tid & 3;
+    // all RS floats of the record: a split image (three bf16 planes) uses the full 96 bytes
+    static_assert(ROWS * 2 * 8 <= NTHR && RS <= 32, "one thread per 16-byte piece");
+    if (tid < ROWS * 2 * 8) {
+        const int r = tid >> 4, side = (tid >> 3) & 1, gg = tid & 7;
         float z = 0.f;
         asm volatile("" : "+v"(z));
-        st4(img + pl<RS>(r * PT + side * 34, gg), splat(z));
+        if (gg < RS / 4) st4(img + (r * PT + side * 34) * RS + 4 * gg, splat(z));
     }
 }
 
@@ -801,9 +944,13 @@ __device__ __forceinline__ void rings_load(float* sH, float* sEH, const float* s
 // first store (four back-to-back single-stream passes would expose four global-load latencies in the prologue of a
 // kernel whose whole run time is a few of them).  st0 = state of the workgroup's first stream, h_off / e_off = float
 // offsets of the ring sets inside a stream's state; streams >= nlive get zero rings.
-template <int NS>
+// RS = 16: fp32 records; RS = 24 (SPLIT, the decoder): the three-plane bf16 records the dense 3x3 reads (the state in
+// HBM holds fp32 either way: the split is exact, so is its inverse in rings_store_ms).
+template <int NS, int RS = 16>
 __device__ __forceinline__ void rings_load_ms(float* sH, float* sEH, const float* st0, int h_off, int e_off, int nlive,
                                               int tid) {
+    constexpr bool SPLIT = RS == RS_WIDE;
+    constexpr int RSET = 3 * 2 * 35 * RS;
     constexpr int PER = 3 * 2 * 35 * 4;                        // float4 items of one stream's image (pad columns included)
     constexpr int ITEMS = (NS * PER + NTHR - 1) / NTHR;
     f32x4 v[ITEMS];
@@ -819,20 +966,28 @@ __device__ __forceinline__ void rings_load_ms(float* sH, float* sEH, const float
     for (int q = 0; q < ITEMS; ++q) {
         const int i = tid + q * NTHR;
         const int sidx = i / PER, r = i - sidx * PER;
-        if (i < NS * PER) st4(sH + sidx * RING_SET + pl(r >> 2, r & 3), v[q]);
+        if (i < NS * PER) {
+            if constexpr (SPLIT) st_split(sH, sidx * RSET + (r >> 2) * RS, r & 3, v[q]);
+            else st4(sH + sidx * RSET + pl(r >> 2, r & 3), v[q]);
+        }
     }
     if (tid < NS * 48) {
         const int sidx = tid / 48, e = tid - sidx * 48;
         sEH[tid] = sidx < nlive ? st0[(long)sidx * ST_FLOATS + e_off + e] : 0.f;
     }
 }
-template <int NS>
+template <int NS, int RS = 16>
 __device__ __forceinline__ void rings_store_ms(const float* sH, const float* sEH, float* st0, int h_off, int e_off,
                                                int nlive, int tid) {
+    constexpr bool SPLIT = RS == RS_WIDE;
+    constexpr int RSET = 3 * 2 * 35 * RS;
     constexpr int PER = 3 * 2 * 33 * 4;
     for (int i = tid; i < nlive * PER; i += NTHR) {
         const int sidx = i / PER, r = i - sidx * PER, gg = r & 3, pos = r >> 2, f = pos % 33, br = pos / 33;
-        st4(st0 + (long)sidx * ST_FLOATS + h_off + pos * 16 + gg * 4, ld4(sH + sidx * RING_SET + pl(br * 35 + 1 + f, gg)));
+        f32x4 v;
+        if constexpr (SPLIT) v = ld_split(sH, sidx * RSET + (br * 35 + 1 + f) * RS, gg);
+        else v = ld4(sH + sidx * RSET + pl(br * 35 + 1 + f, gg));
+        st4(st0 + (long)sidx * ST_FLOATS + h_off + pos * 16 + gg * 4, v);
     }
     if (tid < nlive * 48) {
         const int sidx = tid / 48, e = tid - sidx * 48;
@@ -1939,14 +2094,22 @@ __global__ __launch_bounds__(NTHR) void k_gtcn_band(const float* __restrict__ xi
 // ratio mask (:478-482) and the output permute (:529-530).
 constexpr int DEC_Z_ROW = F1 + 2;                                 // Z rows carry a zero record at both ends
 constexpr int DEC_ZS = 12;                                        // floats per Z record (10 live slots)
+// parameters resident in LDS: the three blocks WITHOUT their dense matrices, then the de_convs.3/4 segment; the dense
+// 3x3 of ONE block at a time sits in the stage buffer DN (the bf16 planes of all three would not fit: 45 KB), refilled
+// from L2 while the previous block's TRALite runs
+constexpr int DL_DE = 3 * GB_SIZE;                                // de_convs.3/4: D_DE3_AE .. D_BS_W
+constexpr int DL_DN = DL_DE + (D_BS_W - D_DE3_AE);                // dense stage buffer
+constexpr int DL_SIZE = DL_DN + DN16_SIZE;
+__device__ __forceinline__ constexpr int dl(int d_off) { return DL_DE + d_off - D_DE3_AE; }   // D_* offset -> LDS offset
+static_assert(DL_DE % 4 == 0 && DL_DN % 4 == 0 && DN16_SIZE >= 9 * 256 && GBD_SIZE % 4 == 0 && D_DN16 % 4 == 0, "16B carve");
 template <int RW, int NS, bool MS>
 struct DecLds {
-    static constexpr int RS = MS ? 16 : RS_WIDE;                  // record pitch of the h image W (see pl())
+    static constexpr int RS = RS_WIDE;                            // record pitch of the h image W (see pl(); split planes)
     static constexpr int RSS = 16;                                // ... of the v^2 image S
-    static constexpr int P = 0;                                   // the decoder segment up to the ERB.bs weights
-    static constexpr int I = P + D_BS_W;                          // (the kernel-ready ERB.bs table has its own region, BS)
+    static constexpr int P = 0;                                   // block parameters, de_convs.3/4, dense stage buffer
+    static constexpr int I = P + DL_SIZE;                         // (the kernel-ready ERB.bs table has its own region, BS)
     static constexpr int H = I + 48;                              // ints: the three blocks' slot tables (I_DEC_BLK)
-    static constexpr int EH = H + (MS ? NS * RING_SET : 3 * RING_DENSE);
+    static constexpr int EH = H + (MS ? NS * 3 * 2 * 35 * RS : 3 * RING_DENSE);
     static constexpr int TB = EH + NS * 48;                       // frame counter per row (ints; multi-stream mode)
     static constexpr int G = TB + 8;
     static constexpr int E = G + RW * 16 + RW * 8;                // (gates [RW][16] + y scratch [RW][8]); energies
@@ -1961,7 +2124,7 @@ struct DecLds {
     static constexpr int AEND = (S + RW * 33 * RSS) > (M + MSZ) ? (S + RW * 33 * RSS) : (M + MSZ);
     static constexpr int BS = AEND;                               // per-bin ERB.bs table {first index, w0, w1, -}
     static constexpr int FLOATS = BS + NBINS * 4;
-    static_assert(M % 4 == 0 && BS % 4 == 0 && D_BS_W % 4 == 0 && D_BS_TAB % 4 == 0 && S % 4 == 0, "16B carve");
+    static_assert(M % 4 == 0 && BS % 4 == 0 && D_BS_W % 4 == 0 && D_BS_TAB % 4 == 0 && S % 4 == 0 && DL_SIZE % 4 == 0, "16B carve");
     static_assert(FLOATS * 4 <= 160 * 1024, "decoder LDS budget");
     static_assert(DEC_SIZE % 4 == 0 && I % 4 == 0 && H % 4 == 0 && A % 4 == 0 && E % 4 == 0, "16B carve");
 };
@@ -2003,7 +2166,24 @@ __global__ __launch_bounds__(NTHR) void k_decoder(const float* __restrict__ xg, 
     const Lane L = lane_info();
     const int tid = L.tid, n = L.n, g = L.g;
     const int b = blockIdx.x;
-    copy_params(sP, PF + P_DEC, D_BS_W, tid, NTHR);
+    constexpr bool SPLIT = !Q && kSplitDense;
+    // the dense 3x3 of block j -> the stage buffer by LDS-DMA (global_load_lds_dwordx4: 1 KB pieces, wave w moves pieces
+    // w, w + 11; no registers are held while the data is in flight -- a register-staged copy spilled).  A DMA is a
+    // pending LDS write on the vector-memory counter: gtconv_block's closing barrier (and the prologue's) waits for
+    // vmcnt(0) in front of it; the first reader sits one more barrier later.
+    constexpr int DN_PIECES = (SPLIT ? DN16_SIZE : 9 * 256) / 256;
+    auto dense_fetch = [&](int j) {
+        const float* src = PF + P_DEC + (SPLIT ? D_DN16 + j * DN16_SIZE : D_BLK + j * GBD_SIZE + GB_DN_A);
+        int lz = L.lane;
+        asm volatile("" : "+v"(lz));      // per-lane source addresses recomputed per call, not hoisted and kept live
+        for (int pi = L.wave; pi < DN_PIECES; pi += NW)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + pi * 256 + 4 * lz),
+                                             (__attribute__((address_space(3))) void*)(sP + DL_DN + pi * 256), 16, 0, 0);
+    };
+    dense_fetch(0);
+#pragma unroll
+    for (int j = 0; j < 3; ++j) copy_params(sP + j * GB_SIZE, PF + P_DEC + D_BLK + j * GBD_SIZE, GB_SIZE, tid, NTHR);
+    copy_params(sP + DL_DE, PF + P_DEC + D_DE3_AE, D_BS_W - D_DE3_AE, tid, NTHR);
     if (tid < 48) sI[tid] = PI[I_DEC_BLK + tid];
     for (int f = tid; f < NBINS; f += NTHR) st4(sBS + f * 4, ld4(PF + P_DEC + D_BS_TAB + f * 4));
     if (tid < 4) sM[2 * RW * F0 + tid] = 0.f;
@@ -2011,14 +2191,14 @@ __global__ __launch_bounds__(NTHR) void k_decoder(const float* __restrict__ xg, 
     const int nlive = MS ? min(NS, NB - b * NS) : 1;
     int tbase = 0;
     if constexpr (MS) {
-        rings_load_ms<NS>(sH, sEH, stb, ST_DEC_H, ST_DEC_E, nlive, tid);
+        rings_load_ms<NS, SPLIT ? RS_WIDE : 16>(sH, sEH, stb, ST_DEC_H, ST_DEC_E, nlive, tid);
         if (tid < 8) sTB[tid] = tid < nlive ? reinterpret_cast<const int*>(stb + (long)tid * ST_FLOATS)[0] : 0;
     } else {
         tbase = stb ? reinterpret_cast<const int*>(stb)[0] : 0;
         rings_load(sH, sEH, stb ? stb + ST_DEC_H : nullptr, stb ? stb + ST_DEC_E : nullptr, tbase, tid);
     }
     const Tiles<TPW> tt = make_tiles<TPW>(L);
-    wg_barrier();
+    wg_barrier_vm();
 
     const long ob = (long)b * T;
     const long nbt = (long)gridDim.x * T;
@@ -2073,8 +2253,8 @@ __global__ __launch_bounds__(NTHR) void k_decoder(const float* __restrict__ xg, 
             for (int i = 0; i < TPW; ++i)
                 skv[i] = ldx<Q>(sk + (unsigned)((tt.pp(i) < npos ? tt.pp(i) : 0) * 16 + 4 * g));
             BlockCtx c;
-            c.pb = sP + D_BLK + j * GBD_SIZE;
-            c.gA = c.pb + GB_DN_A;
+            c.pb = sP + j * GB_SIZE;
+            c.gA = sP + DL_DN;
             c.ib = sI + j * 16;
             c.sW = sW; c.sHk = sH + j * RING_DENSE; c.sS = sS; c.sG = sG; c.sEHk = sEH + j * 16;
             c.sHtop = j == 0 ? sH : nullptr;          // region A was Z / m in the previous chunk
@@ -2085,12 +2265,16 @@ __global__ __launch_bounds__(NTHR) void k_decoder(const float* __restrict__ xg, 
             c.sTB = sTB;
             if constexpr (MS) {
                 const int sidx = min(tt.tl[0], NS - 1);
-                c.ms_roff = (int)(sH - sW) + sidx * RING_SET + j * (2 * 35 * 16);
+                constexpr int RSM = SPLIT ? RS_WIDE : 16;      // record pitch of the LDS rings (rings_load_ms)
+                c.ms_roff = (int)(sH - sW) + sidx * (3 * 2 * 35 * RSM) + j * (2 * 35 * RSM);
                 c.ms_tb = sTB[sidx];
             } else {
                 c.ms_roff = 0; c.ms_tb = 0;
             }
-            gtconv_block<true, TPW, MS, Q, RS, LD::RSS, true, 35>(x, tt, c, L, hook STAMP_ARG);
+            // the next block's dense 3x3 (block 0 of the next chunk after the last one): the DMA starts once this block's
+            // dense phase is over (the hook runs behind its closing barrier) and is waited for two barrier intervals
+            // later, one barrier (the next block's point_conv1) before its first reader
+            gtconv_block<true, TPW, MS, Q, RS, LD::RSS, true, 35>(x, tt, c, L, [&] { dense_fetch(j == 2 ? 0 : j + 1); hook(); } STAMP_ARG);
             if (DBG)
 #pragma unroll
                 for (int i = 0; i < TPW; ++i)
@@ -2120,11 +2304,11 @@ __global__ __launch_bounds__(NTHR) void k_decoder(const float* __restrict__ xg, 
         STAMP(SS, 10)
         f32x4 ze[TPW], zo[TPW];
         {
-            const f32x4 Bv = ld4(sP + D_DE3_B + 4 * g);
-            const float a = sP[D_DE3_S] - 1.0f;
+            const f32x4 Bv = ld4(sP + dl(D_DE3_B) + 4 * g);
+            const float a = sP[dl(D_DE3_S)] - 1.0f;
             // even output 2m: k=0 <- x[m+1], k=2 <- x[m], k=4 <- x[m-1]; odd 2m+1: k=1 <- x[m+1], k=3 <- x[m]
-            const float* Ae = sP + D_DE3_AE + arow(n, g);
-            const float* Ao = sP + D_DE3_AO + arow(n, g);
+            const float* Ae = sP + dl(D_DE3_AE) + arow(n, g);
+            const float* Ao = sP + dl(D_DE3_AO) + arow(n, g);
             // tap major over the three input bins f+1, f, f-1: the five slot matrices are read once per wave
             f32x4 ae[TPW], ao[TPW];
 #pragma unroll
@@ -2154,7 +2338,7 @@ __global__ __launch_bounds__(NTHR) void k_decoder(const float* __restrict__ xg, 
                     ae[i] = mm1<Q>(A0, xm, ae[i]);
                 }
             }
-            const f32x4 A4 = ld4(sP + D_DE4_A + arow(n, g));
+            const f32x4 A4 = ld4(sP + dl(D_DE4_A) + arow(n, g));
 #pragma unroll
             for (int i = 0; i < TPW; ++i) {
                 f32x4 e2 = rq<Q>(prelu4(ae[i], a)), o2 = rq<Q>(prelu4(ao[i], a));
@@ -2237,7 +2421,7 @@ __global__ __launch_bounds__(NTHR) void k_decoder(const float* __restrict__ xg, 
                 const float* r1 = zr + ZS + o * 5 + par;
                 const float* r2 = zr + o * 5 + 2 + par;
                 const float* r3 = zr - ZS + (par ? 10 : o * 5 + 4);
-                const float bias = sP[D_DE4_B + o];
+                const float bias = sP[dl(D_DE4_B) + o];
                 float* mo = sM + (o * RW + h) * F0 + fq;
 #pragma unroll
                 for (int j = 0; j < RW / 2; ++j) {
@@ -2323,7 +2507,7 @@ __global__ __launch_bounds__(NTHR) void k_decoder(const float* __restrict__ xg, 
     if (stb) {
         wg_barrier();
         if constexpr (MS) {
-            rings_store_ms<NS>(sH, sEH, stb, ST_DEC_H, ST_DEC_E, nlive, tid);
+            rings_store_ms<NS, SPLIT ? RS_WIDE : 16>(sH, sEH, stb, ST_DEC_H, ST_DEC_E, nlive, tid);
             if (tid < nlive) reinterpret_cast<int*>(stb + (long)tid * ST_FLOATS)[0] = (sTB[tid] + 1) & 0xFFFF;
         } else {
             rings_store(sH, sEH, stb + ST_DEC_H, stb + ST_DEC_E, tbase + T, tid);

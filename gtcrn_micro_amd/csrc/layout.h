@@ -80,7 +80,18 @@ constexpr int D_BS_W = D_DE4_B + 4;                // [192][ERB_MAXBS]
 // ERB.bs as a uniform 2-tap gather per output bin, ready for the kernel: [257][4] = {first input index (int bits),
 // w0, w1, 0}: the 65 low bins pass through (index = bin, weights 1, 0), the others combine at most two bands
 constexpr int D_BS_TAB = D_BS_W + 192 * ERB_MAXBS;
-constexpr int DEC_SIZE = D_BS_TAB + NBINS * 4;
+// The dense transposed 3x3 of the three decoder blocks for the 16-bit matrix pipe (kernels.hip, "split" form): every
+// folded fp32 weight is split EXACTLY into three bf16 planes (w = hi + mid + lo, 3 x 8 significant bits = fp32's 24)
+// and laid out as the A operand of v_mfma_f32_16x16x32_bf16: per block 5 K-chunks (chunk c = taps 2c and 2c+1; the
+// second half of chunk 4 is zero) x 3 planes of a [16 output rows][32 k] bf16 matrix, k = (tap - 2c) * 16 + hidden
+// channel; a matrix is 256 "floats" (bf16 pairs) with the same row swizzle as the fp32 slot matrices (pack.cpp).
+// The fp32 matrices at GB_DN_A stay in the buffer: the int8/fp16 variant and the CPU emulation of the packed
+// dataflow read them, and the planes are checked against them (tests/test_host_logic.py).
+constexpr int DN16_CHUNKS = 5;
+constexpr int DN16_MATS = DN16_CHUNKS * 3;
+constexpr int DN16_SIZE = DN16_MATS * 256;
+constexpr int D_DN16 = D_BS_TAB + NBINS * 4;       // 3 x DN16_SIZE
+constexpr int DEC_SIZE = D_DN16 + 3 * DN16_SIZE;
 
 // ---- whole float buffer ------------------------------------------------------
 constexpr int P_ENC = 0;

@@ -220,6 +220,42 @@ static void swizzle_matrices(float* F) {
     for (int a = 0; a < 3; ++a) swizzle_matrix(D + D_DE3_AE + a * 256);
     for (int a = 0; a < 2; ++a) swizzle_matrix(D + D_DE3_AO + a * 256);
     swizzle_matrix(D + D_DE4_A);
+    for (int m = 0; m < 3 * DN16_MATS; ++m) swizzle_matrix(D + D_DN16 + m * 256);
+}
+
+// float -> bfloat16 bits, round to nearest even (finite inputs)
+static uint16_t bf16_rne(float x) {
+    uint32_t u;
+    std::memcpy(&u, &x, 4);
+    u += 0x7FFFu + ((u >> 16) & 1u);
+    return (uint16_t)(u >> 16);
+}
+static float bf16_to_float(uint16_t h) {
+    const uint32_t u = (uint32_t)h << 16;
+    float f;
+    std::memcpy(&f, &u, 4);
+    return f;
+}
+// w = hi + mid + lo exactly: every residual is formed exactly in fp32 and the last one has at most 8 significant bits
+static void split3(float w, uint16_t out[3]) {
+    out[0] = bf16_rne(w);
+    const float r1 = w - bf16_to_float(out[0]);
+    out[1] = bf16_rne(r1);
+    const float r2 = r1 - bf16_to_float(out[1]);
+    out[2] = bf16_rne(r2);
+}
+
+// the bf16 planes of one decoder block's dense 3x3 (layout.h, D_DN16) from its (unswizzled) fp32 slot matrices
+static void pack_dense_planes(const float* dn32, float* dn16) {
+    uint16_t* H = reinterpret_cast<uint16_t*>(dn16);
+    for (int c = 0; c < DN16_CHUNKS; ++c)
+        for (int o = 0; o < 16; ++o)
+            for (int k = 0; k < 32; ++k) {
+                const int tap = 2 * c + (k >> 4), i = k & 15;
+                uint16_t pl3[3] = {0, 0, 0};
+                if (tap < 9) split3(dn32[tap * 256 + o * 16 + i], pl3);
+                for (int p = 0; p < 3; ++p) H[((c * 3 + p) * 256) * 2 + o * 32 + k] = pl3[p];
+            }
 }
 
 }  // namespace
@@ -314,6 +350,7 @@ int pack_params(const float* params, long n, float* F, int* I, std::string& err)
         GTRaw g = take_gt(c, true);
         cur = pack_gtconv(g, true, cur, D + D_BLK + j * GBD_SIZE, I + I_DEC_BLK + j * 16);
         perm[5 + j] = cur;
+        pack_dense_planes(D + D_BLK + j * GBD_SIZE + GB_DN_A, D + D_DN16 + j * DN16_SIZE);
     }
     // the skip added to the OUTPUT of decoder block j is en_outs[3-j]: en3 after de0, en2 after de1,
     // en1 after de2.  The encoder stores each of them in that consumer's slot order.

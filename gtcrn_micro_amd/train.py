@@ -61,12 +61,56 @@ def _flat_gradient_blob(model):
     return flat
 
 
+def _buffer_index(model, device):
+    """Positions (int64, on ``device``) of the BatchNorm running statistics inside the canonical blob: 92 tensors,
+    1 348 floats, interleaved with the trainable tensors in state_dict order.  Built once per model and device."""
+    cache = getattr(model, "_buffer_index_cache", None)
+    if cache is None or cache.device != torch.device(device):
+        idx = [torch.arange(off, off + numel) for name, numel, off in _lib.param_table()
+               if name.endswith("running_mean") or name.endswith("running_var")]
+        cache = torch.cat(idx).to(device)
+        model._buffer_index_cache = cache
+    return cache
+
+
+def broadcast_buffers(model, src=0):
+    """DistributedDataParallel's ``broadcast_buffers=True`` (the default the reference trains with, train.py:88) on the
+    explicit all-reduce path: every rank's BatchNorm running statistics and ``num_batches_tracked`` counters follow
+    rank ``src``.  BatchNorm uses LOCAL batch statistics in the forward (plain BN, not SyncBN, models/gtcrn_micro.py:159),
+    so without this the 1 348 running-stat floats (and 46 counters) drift apart per rank and a checkpoint or an eval on rank != 0 differs
+    from what the reference's DDP run would hold.  When the parameters live in the flat blob the statistics are
+    gathered into ONE message (5.4 KB), broadcast and scattered back; otherwise buffer by buffer.  Returns the floats
+    on the wire."""
+    import torch.distributed as dist
+    m = model.module if hasattr(model, "module") else model
+    flat = getattr(m, "_flat", None)
+    if flat is not None and m._flat_ok(flat.device):
+        idx = _buffer_index(m, flat.device)
+        msg = flat.index_select(0, idx)
+        dist.broadcast(msg, src=src)
+        flat.index_copy_(0, idx, msg)
+        dist.broadcast(m._nbt_flat, src=src)
+        for k, (eng, _) in list(m._engines.items()):
+            m._engines[k] = (eng, None)    # the eval engines re-fold on next use
+        return int(msg.numel())
+    n = 0
+    for b in m.buffers():
+        dist.broadcast(b.data, src=src)
+        n += b.numel() if b.dtype.is_floating_point else 0
+    return n
+
+
 def allreduce_gradients(model, world_size):
     """The one exchange step of data-parallel training (the reference gets it from DDP, train.py:87-88): average
     the gradients over the ranks as ONE contiguous message.  After a HIP backward the 248 ``.grad``s are views of
     the kernel's own gradient blob (canonical layout: 19 014 trainable floats + the zero slots of the buffers,
     44 938 floats = 180 KB; latency-bound over xGMI), so the blob is all-reduced in place with no packing; gradients
-    that came from elsewhere (hand-set, accumulated) are packed and unpacked.  Returns the floats on the wire."""
+    that came from elsewhere (hand-set, accumulated) are packed and unpacked.  Returns the floats on the wire.
+
+    Why the whole 180 KB blob and not only its 19 014 trainable floats (76 KB): the trainable tensors are interleaved
+    with the BatchNorm buffers in the canonical (state_dict) order, so the short message needs a gather kernel before
+    and a scatter kernel after the collective (two launches, ~10 us) to save ~100 KB on a ring whose per-step cost is
+    its latency (tens of microseconds over xGMI), not its bytes (100 KB at ~50 GB/s effective = 2 us)."""
     import torch.distributed as dist
     m = model.module if hasattr(model, "module") else model
     flat = _flat_gradient_blob(m)
@@ -90,6 +134,10 @@ def train_step(model, optimizer, scheduler, loss_func, noisy, clean, clip_grad_n
     """One iteration of Trainer._train_epoch (train.py:244-288); returns (loss, grad_norm) as floats."""
     dev = noisy.device
     win = window if window is not None else torch.hann_window(512, device=dev)      # train.py:252 (Hann, not sqrt)
+    if world_size > 1 and model.training:
+        # DDP semantics (broadcast_buffers=True): the buffers follow rank 0 at the start of every forward, so the
+        # running statistics a rank holds are rank 0's of the previous step plus its own update of this step
+        broadcast_buffers(model)
     noisy_spec = _lib.stft(noisy, win)
     clean_spec = _lib.stft(clean, win)
     enhanced = model(noisy_spec)

@@ -169,3 +169,59 @@ def test_gradient_allreduce_two_ranks(tmp_path):
     assert r.returncode == 0, r.stderr[-2000:]
     line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
     assert json.loads(line) == {"ok": True, "floats": 19014, "ok_flat": True, "floats_flat": 44938}
+
+
+_BUF_WORKER = r"""
+import os, sys, json
+sys.path.insert(0, sys.argv[1])
+import torch, torch.distributed as dist
+from gtcrn_micro_amd.sharding import init_distributed
+from gtcrn_micro_amd.train import broadcast_buffers, allreduce_gradients
+from gtcrn_micro_amd.models.gtcrn_micro import GTCRNMicro
+rank, local_rank, world = init_distributed("gloo")
+torch.manual_seed(7)                   # identical initial weights on every rank, like the trainer
+m = GTCRNMicro()
+m._flatten(torch.device("cpu"))        # the layout a train-mode forward leaves: everything is a view of one blob
+g = torch.Generator().manual_seed(100 + rank)
+params_before = torch.cat([p.detach().reshape(-1) for p in m.parameters() if p.requires_grad]).clone()
+# what a local-batch-statistics forward does on each rank: DIFFERENT running statistics per rank
+with torch.no_grad():
+    for name, b in m.named_buffers():
+        if name.endswith("running_mean") or name.endswith("running_var"):
+            b.add_(torch.randn(b.shape, generator=g))
+        elif name.endswith("num_batches_tracked"):
+            b.add_(1 + rank)
+n = broadcast_buffers(m)
+stats = torch.cat([b.reshape(-1).double() for name, b in m.named_buffers()
+                   if name.endswith("running_mean") or name.endswith("running_var") or name.endswith("num_batches_tracked")])
+both = [torch.zeros_like(stats) for _ in range(world)]
+dist.all_gather(both, stats)
+same = bool(torch.equal(both[0], both[1]))
+params_after = torch.cat([p.detach().reshape(-1) for p in m.parameters() if p.requires_grad])
+untouched = bool(torch.equal(params_before, params_after))
+nbt = int(next(b for name, b in m.named_buffers() if name.endswith("num_batches_tracked")))
+# a model whose tensors are NOT views of a flat blob takes the buffer-by-buffer path
+m2 = GTCRNMicro()
+with torch.no_grad():
+    for name, b in m2.named_buffers():
+        if name.endswith("running_var"):
+            b.fill_(2.0 + rank)
+broadcast_buffers(m2)
+rv = float(next(b for name, b in m2.named_buffers() if name.endswith("running_var"))[0])
+dist.barrier()
+if rank == 0:
+    print(json.dumps({"floats": n, "same": same, "params_untouched": untouched, "nbt": nbt, "rv_unflat": rv}))
+dist.destroy_process_group()
+"""
+
+
+def test_running_statistics_follow_rank0_two_ranks(tmp_path):
+    """DDP's broadcast_buffers (the reference's default, train.py:88) on the explicit all-reduce path: after
+    broadcast_buffers() both ranks hold rank 0's running statistics and counters bit for bit, the trainable
+    tensors are untouched, and the 1 348 running-stat floats travelled as one message (+ the 46 counters)."""
+    w = tmp_path / "buf_worker.py"
+    w.write_text(_BUF_WORKER)
+    r = _torchrun([str(w), ROOT])
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+    assert json.loads(line) == {"floats": 1348, "same": True, "params_untouched": True, "nbt": 1, "rv_unflat": 2.0}

@@ -333,3 +333,34 @@ def test_headline_kernels_use_no_scratch():
     for k in must:
         assert k in rows, (k, sorted(rows))
         assert "ScratchSize [bytes/lane]: 0 " in rows[k], rows[k]
+
+
+def test_dense_bf16_planes_recombine_to_the_fp32_matrices():
+    """The decoder's dense 3x3 runs on v_mfma_f32_16x16x32_bf16 from three bf16 planes per weight (layout.h D_DN16):
+    the planes must add up EXACTLY to the folded fp32 slot matrices (hi + mid + lo == w, every residual exact), sit
+    in the K order the kernel reads (chunk c = taps 2c, 2c+1; k = tap half * 16 + hidden channel), and the unused
+    half of the last chunk must be zero."""
+    from gtcrn_micro_amd import _lib
+    from tests.slot_emulator import K, _mat
+    for tag in ("dns3", "rand"):
+        F, _ = _lib.pack_params_host(load_params(tag))
+        P_DEC = K["P_DEC"]
+        for j in range(3):
+            for c in range(K["DN16_CHUNKS"]):
+                planes = []
+                for p in range(3):
+                    off = P_DEC + K["D_DN16"] + j * K["DN16_SIZE"] + (c * 3 + p) * 256
+                    m = _mat(F, off)                                   # undo the row swizzle on the 16x16-float view
+                    bits = np.ascontiguousarray(m).view(np.uint16).reshape(16, 32).astype(np.uint32) << 16
+                    planes.append(bits.view(np.float32).astype(np.float64))
+                tot = planes[0] + planes[1] + planes[2]                # exact in float64
+                assert np.all(np.abs(planes[1]) <= np.abs(planes[0]) * 2.0 ** -8 + 1e-45)
+                assert np.all(np.abs(planes[2]) <= np.abs(planes[0]) * 2.0 ** -16 + 1e-45)
+                for half in range(2):
+                    tap = 2 * c + half
+                    got = tot[:, half * 16:half * 16 + 16]
+                    if tap < 9:
+                        want = _mat(F, P_DEC + K["D_BLK"] + j * K["GBD_SIZE"] + K["GB_DN_A"] + tap * 256)
+                        assert np.array_equal(got, want.astype(np.float64)), (tag, j, c, half)
+                    else:
+                        assert not got.any()
