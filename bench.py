@@ -127,15 +127,16 @@ class Watchdog:
 
     def _fire(self):
         if self.rank == 0:
-            line = self.get_line()
+            line = self.get_line()                             # None: the line has been printed already
             if line is not None:
                 line.setdefault("secondary_errors", {})[self.what] = (
                     f"timed out after {self.seconds:g} s (a rank failed or hung inside a collective); line printed by "
                     "the watchdog")
-                print(json.dumps(line), flush=True)
+                print(json.dumps({k: v for k, v in line.items() if not k.startswith("_")}), flush=True)
         else:
             time.sleep(2.0)                                    # let rank 0's line out first
-        os._exit(0 if self.get_line() is not None or self.rank != 0 else 1)
+        sys.stdout.flush()
+        os._exit(0)
 
     def __enter__(self):
         import threading
@@ -302,19 +303,34 @@ def stream_leg(eng, world, sync_all, max_over_ranks, nstreams=1024, frames=251):
     return res
 
 
-def train_leg(rank, world, sync_all, max_over_ranks, B=512, seconds=4.0, steps=5, warmup=2, storage="f32"):
-    """BASELINE configs[3]: full train steps, data parallel over utterance shards with ONE collective per step."""
+def train_prepare(rank, B=512, seconds=4.0, storage="f32"):
+    """Everything of the train leg that can fail on ONE rank alone (allocations: the 16-29 GiB activation workspace,
+    the model, the batch) plus one complete LOCAL step with no collective, so that the ranks can agree on success
+    before the first gradient all-reduce."""
     import torch
-    import gtcrn_micro_amd as G
     from gtcrn_micro_amd.train import make_training, synthetic_mix, train_step
     L = int(seconds * 16000)
-    T = 1 + L // 256
     torch.manual_seed(43)                                     # identical initial weights on every rank
     model, opt, sched, loss_func = make_training(device="cuda")
     model.train()
     if storage != "f32":
+        if not hasattr(model, "set_activation_storage"):
+            return None                                       # this build has no such storage variant
         model.set_activation_storage(storage)
     noisy, clean = synthetic_mix(B, samples=L, seed=43 + rank)
+    train_step(model, opt, sched, loss_func, noisy, clean, world_size=1)
+    torch.cuda.synchronize()
+    return {"model": model, "opt": opt, "sched": sched, "loss": loss_func, "noisy": noisy, "clean": clean,
+            "B": B, "T": 1 + L // 256, "seconds": seconds, "storage": storage}
+
+
+def train_run(ctx, world, sync_all, max_over_ranks, steps=5, warmup=2):
+    """BASELINE configs[3]: full train steps, data parallel over utterance shards with ONE collective per step."""
+    import torch
+    import gtcrn_micro_amd as G
+    from gtcrn_micro_amd.train import train_step
+    model, opt, sched, loss_func, noisy, clean = (ctx[k] for k in ("model", "opt", "sched", "loss", "noisy", "clean"))
+    B, T, seconds, storage = ctx["B"], ctx["T"], ctx["seconds"], ctx["storage"]
     for _ in range(warmup):
         train_step(model, opt, sched, loss_func, noisy, clean, world_size=world)
     sync_all()
@@ -325,16 +341,49 @@ def train_leg(rank, world, sync_all, max_over_ranks, B=512, seconds=4.0, steps=5
     el = max_over_ranks(time.perf_counter() - t0, "cuda") / steps
     ws = G.Trainer.workspace_bytes(B, T, storage) if storage != "f32" else G.Trainer.workspace_bytes(B, T)
     byte_scale = 1.0 if storage == "f32" else 0.5
-    res = {
+    return {
         "workload": f"train step, B={B} clips/GPU x {seconds:g} s (T={T}), saved activations {storage}, fp32 "
                     "accumulate + master weights, Adam, clip 3.0, synthetic DNS-style mixes",
-        "parallelism": f"dp{world}: utterance shards + one all-reduce of the gradient buffer per step",
+        "parallelism": f"dp{world}: utterance shards + one all-reduce of the gradient buffer per step"
+                       + (" + DDP-style buffer broadcast from rank 0" if world > 1 else ""),
         "ms_per_step": round(el * 1e3, 3), "frames_per_s": round(world * B * T / el, 1),
         "steps": steps, "warmup": warmup, "dtype": storage,
         "algorithmic_TB_per_s": round(TRAIN_BYTES_PER_FRAME * byte_scale * B * T / el / 1e12, 3),
         "workspace_GB": round(ws / 2 ** 30, 2), "loss": float(loss), "grad_norm": float(gn),
+        "_rate_keys": ["frames_per_s"], "_time_keys": ["ms_per_step"],
     }
-    del model, opt, sched, noisy, clean
+
+
+def train_leg(rank, world, sync_all, max_over_ranks, B=512, seconds=4.0, steps=5, warmup=2, storage="f32"):
+    """Single-process form (`--mode train`, world == 1 callers)."""
+    ctx = train_prepare(rank, B, seconds, storage)
+    if ctx is None:
+        raise AttributeError(f"no activation storage {storage!r} in this build")
+    return train_run(ctx, world, sync_all, max_over_ranks, steps, warmup)
+
+
+def guarded_train_leg(storage, rank, world, get_line, B=512):
+    """The train leg under run_leg's rules: phase 1 = train_prepare on every rank (local; may fail alone), ONE gather of
+    the outcomes, phase 2 = the timed steps with the gradient all-reduce only if EVERY rank got through phase 1."""
+    import torch
+    box = {}
+
+    def prepare(sync_local, record):
+        box["ctx"] = train_prepare(rank, B=B, storage=storage)
+        record(0.0)
+        return {"present": box["ctx"] is not None}
+
+    r1 = run_leg(f"train_{storage}_prepare", prepare, rank, world, get_line)
+    if r1 is not None and "error" in r1:
+        box.clear()
+        torch.cuda.empty_cache()
+        return {"error": r1["error"], "phase": "prepare (no collective had been issued)"}
+    # every rank runs the same build: either all have the variant or none
+    if box.get("ctx") is None:
+        return None
+    res = run_leg(f"train_{storage}", lambda sync_local, record: train_run(box["ctx"], world, sync_local, record),
+                  rank, world, get_line)
+    box.clear()
     torch.cuda.empty_cache()
     return res
 
@@ -463,6 +512,7 @@ def main(argv=None):
     sync_all()
     elapsed = time.perf_counter() - t0
     dom_ms, dom_launches = eng.timing_read()[dom]
+    per_rank_s = [x for x in gather_ranks(elapsed, world)]     # a straggler shows up in one line
     elapsed = max_over_ranks(elapsed, dev)                     # the slowest rank defines the step time
     # the per-kernel split: ONE separate pass of K steps with an event pair around every kernel (all kernel_ms
     # values come from here; its step time is reported next to the headline's)
@@ -525,6 +575,9 @@ def main(argv=None):
                        "batch_per_gpu": B, "frames_per_step_per_gpu": frames_per_step,
                        "parallelism": f"{world} independent utterance shards, no data-path collective"},
             "timed_region_s": round(elapsed, 4),
+            "per_rank_ms_per_step": {"min": round(min(per_rank_s) / args.steps * 1e3, 4),
+                                     "max": round(max(per_rank_s) / args.steps * 1e3, 4),
+                                     "all": [round(x / args.steps * 1e3, 4) for x in per_rank_s]},
             "rtf_per_stream": round((elapsed / args.steps) / (B * args.seconds) * 1.0, 9),
             "roofline": roof,
             "kernel_ms": {k: round(v[0], 4) for k, v in kern.items()},
@@ -533,41 +586,40 @@ def main(argv=None):
                               f"kernel (that pass: {split_ms_per_step:.4f} ms/step); roofline.avg_launch_ms is "
                               f"{dom}'s alone inside the headline timed region",
         }
+    get_line = lambda: line
+
+    def put(name, val, into=None):                             # results join the line as they arrive: a watchdog
+        if line is not None and val is not None:               # print carries every leg that finished
+            (line if into is None else line.setdefault(into, {}))[name] = val
+
+    if shim and hasattr(shim, "secondary_legs"):
+        # TEST ONLY: stand-in legs that fail or hang on one rank exercise run_leg / Watchdog on CPU over gloo
+        for name, (fn, timeout_s) in shim.secondary_legs(rank, world).items():
+            put(name, run_leg(name, fn, rank, world, get_line, timeout_s))
     if not shim and not args.no_secondary:
-        legs = {}
-        try:
-            legs["stream"] = stream_leg(eng, world, sync_all, max_over_ranks)
-        except Exception as e:                                 # a secondary leg must never take the headline down
-            legs["stream"] = {"error": repr(e)}
+        put("stream", run_leg("stream", lambda sync_local, record: stream_leg(eng, world, sync_local, record),
+                              rank, world, get_line))
         try:
             from gtcrn_micro_amd import quant
-            legs["quant"] = quant.bench_leg(params, local_rank, wave, win, world, sync_all, max_over_ranks,
-                                            steps=args.steps)
         except ImportError:
-            pass
-        except Exception as e:
-            legs["quant"] = {"error": repr(e)}
+            quant = None
+        if quant is not None:
+            put("quant", run_leg("quant", lambda sync_local, record: quant.bench_leg(
+                params, local_rank, wave, win, world, sync_local, record, steps=args.steps), rank, world, get_line))
         del eng, wave, out
         torch.cuda.empty_cache()
-        tr = {}
         for storage in ("f32", "bf16"):
-            try:
-                tr[storage] = train_leg(rank, world, sync_all, max_over_ranks, storage=storage)
-            except AttributeError:
-                continue                                        # this build has no such storage variant
-            except Exception as e:
-                tr[storage] = {"error": repr(e)}
-        legs["train"] = tr
-        if line is not None:
-            line.update(legs)
+            put(storage, guarded_train_leg(storage, rank, world, get_line), into="train")
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline and not shim:
             line["cpu_baseline"] = cpu_baseline(params)
             line["gpu_over_cpu"] = round(line["value"] / line["cpu_baseline"]["value"], 1)
         print(json.dumps(line), flush=True)
     if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
+        line = None                                            # printed: a late watchdog must not print it again
+        with Watchdog(60.0, rank, lambda: None, "final barrier"):   # the line is out: nothing left to lose
+            dist.barrier()
+            dist.destroy_process_group()
     return 0
 
 

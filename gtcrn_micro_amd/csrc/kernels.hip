@@ -15,6 +15,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
+#include <type_traits>
 
 #include "kernels.h"
 #include "layout.h"
@@ -50,8 +51,10 @@ __device__ __forceinline__ void wg_barrier() {
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 // ... that also publishes this wave's LDS-DMA writes (global_load_lds: counted in vmcnt)
+// KEEP = vector-memory operations issued AFTER the DMA that may stay in flight (vmcnt retires in issue order)
+template <int KEEP = 0>
 __device__ __forceinline__ void wg_barrier_vm() {
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(KEEP) : "memory");
 }
 
 // position-major LDS image: one record of 16 floats per position, slot group g at +16g bytes, records RS floats apart.
@@ -633,7 +636,7 @@ __device__ __forceinline__ void ring_to_image(float* sW, const float* ring, int 
     }
 }
 
-template <bool DENSE, int TPW, bool MS, bool Q, int RS, int RSS, bool WIDE_TRA, int PT, class Hook>
+template <bool DENSE, int TPW, bool MS, bool Q, int RS, int RSS, bool WIDE_TRA, int PT, int VMK = 0, class Hook>
 __device__ __forceinline__ void gtconv_block(f32x4 (&x)[TPW], const Tiles<TPW>& tin, const BlockCtx& c,
                                              const Lane& L, Hook&& hook STAMP_PARAM) {
     static_assert(!MS || TPW == 1, "multi-stream mode runs one tile per wave");
@@ -904,7 +907,9 @@ __device__ __forceinline__ void gtconv_block(f32x4 (&x)[TPW], const Tiles<TPW>& 
             else if (rt >= c.nfr - 2) c.sEHk[((c.tabs + rt) & 1) * 8 + ro] = e[16];
         }
     }
-    if constexpr (DENSE) wg_barrier_vm();   // the decoder's hook started the next block's weight DMA two barriers ago
+    // the decoder's hook started the next block's weight DMA two barriers ago; the VMK loads it issued behind the DMA
+    // (en_outs[0] for the tail) stay in flight
+    if constexpr (DENSE) wg_barrier_vm<VMK>();
     else wg_barrier();
     STAMP(SS, 7)
 #pragma unroll
@@ -2176,9 +2181,19 @@ __global__ __launch_bounds__(NTHR) void k_decoder(const float* __restrict__ xg, 
         const float* src = PF + P_DEC + (SPLIT ? D_DN16 + j * DN16_SIZE : D_BLK + j * GBD_SIZE + GB_DN_A);
         int lz = L.lane;
         asm volatile("" : "+v"(lz));      // per-lane source addresses recomputed per call, not hoisted and kept live
-        for (int pi = L.wave; pi < DN_PIECES; pi += NW)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + pi * 256 + 4 * lz),
-                                             (__attribute__((address_space(3))) void*)(sP + DL_DN + pi * 256), 16, 0, 0);
+        // (inline asm, not __builtin_amdgcn_global_load_lds: with the builtin the compiler treats every later LDS read as a
+        // possible reader of the DMA and puts `s_waitcnt vmcnt(0)` in front of the next one -- which would also wait for
+        // the en0 / next-chunk prefetches issued beside it, i.e. expose their HBM latency inside TRALite.  The stage
+        // buffer has exactly one reader, two barriers away, behind the explicit vmcnt(0) of wg_barrier_vm().)
+        for (int pi = L.wave; pi < DN_PIECES; pi += NW) {
+            const float* gsrc = src + pi * 256 + 4 * lz;
+            const unsigned lds_dst = (unsigned)(size_t)(__attribute__((address_space(3))) void*)(sP + DL_DN + pi * 256);
+            unsigned keep;
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                         : "=&s"(keep)
+                         : "v"(gsrc), "s"(lds_dst)
+                         : "memory");
+        }
     };
     dense_fetch(0);
 #pragma unroll
@@ -2243,7 +2258,7 @@ __global__ __launch_bounds__(NTHR) void k_decoder(const float* __restrict__ xg, 
         f32x4 s0e[TPW], s0o[TPW];   // en_outs[0] for the even / odd output bins
         // ---- 3 x GTConvBlock (dense transposed 3x3); the last one is peeled so that s0e/s0o are live only
         //      from its hook on, not across the loop --------------------------------------------------------
-        auto run_block = [&](int j, auto&& hook) {
+        auto run_block = [&](int j, auto&& hook, auto vmk) {
             // the skip added to this block's output (en3, en2, en1; already in this stage's slot
             // order) is fetched up front so that its latency hides behind the block
             const ht* sk = j == 0 ? en3h : (j == 1 ? en2h : en1h);
@@ -2274,7 +2289,8 @@ __global__ __launch_bounds__(NTHR) void k_decoder(const float* __restrict__ xg, 
             // the next block's dense 3x3 (block 0 of the next chunk after the last one): the DMA starts once this block's
             // dense phase is over (the hook runs behind its closing barrier) and is waited for two barrier intervals
             // later, one barrier (the next block's point_conv1) before its first reader
-            gtconv_block<true, TPW, MS, Q, RS, LD::RSS, true, 35>(x, tt, c, L, [&] { dense_fetch(j == 2 ? 0 : j + 1); hook(); } STAMP_ARG);
+            gtconv_block<true, TPW, MS, Q, RS, LD::RSS, true, 35, decltype(vmk)::value>(
+                x, tt, c, L, [&] { dense_fetch(j == 2 ? 0 : j + 1); hook(); } STAMP_ARG);
             if (DBG)
 #pragma unroll
                 for (int i = 0; i < TPW; ++i)
@@ -2284,7 +2300,7 @@ __global__ __launch_bounds__(NTHR) void k_decoder(const float* __restrict__ xg, 
             STAMP(SS, 8)
         };
 #pragma unroll 1
-        for (int j = 0; j < 2; ++j) run_block(j, [] {});
+        for (int j = 0; j < 2; ++j) run_block(j, [] {}, std::integral_constant<int, 0>{});
         run_block(2, [&] {
             const ht* en0c = en0h + (long)t0 * (F1 * 16);
 #pragma unroll
@@ -2294,7 +2310,7 @@ __global__ __launch_bounds__(NTHR) void k_decoder(const float* __restrict__ xg, 
                 s0e[i] = ldx<Q>(en0c + o0);
                 s0o[i] = ldx<Q>(en0c + o0 + (tt.ff[i] < 32 ? 16u : 0u));
             }
-        });
+        }, std::integral_constant<int, 2 * TPW>{});
         // ---- de_convs.3: gather form; input image in sW rows (pad columns are zero).  Every wave is
         // past the last block's tap reads (they precede that block's 2nd barrier), so sW is free.
 #pragma unroll

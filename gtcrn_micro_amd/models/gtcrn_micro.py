@@ -40,6 +40,28 @@ def erb_filter_bank(n_low=65, n_bands=64, nfft=512, high_lim=8000.0, fs=16000):
     return np.abs(bank[:, n_low:])
 
 
+# Every (re-)registration of a parameter, buffer or sub-module anywhere in the process bumps this epoch (global torch
+# hooks, installed once): `mod.weight = nn.Parameter(...)`, parametrize / weight_norm / prune, `register_buffer`,
+# swapping a sub-module.  GTCRNMicro caches the list of tensor OBJECTS behind its state_dict; an object that is
+# replaced does not change any version counter, so the cache is rebuilt whenever the epoch moved.
+_REG_EPOCH = [0]
+
+
+def _bump_epoch(*args):
+    _REG_EPOCH[0] += 1
+    return None
+
+
+try:
+    from torch.nn.modules import module as _tmod
+    _tmod.register_module_parameter_registration_hook(_bump_epoch)
+    _tmod.register_module_buffer_registration_hook(_bump_epoch)
+    _tmod.register_module_module_registration_hook(_bump_epoch)
+    _HAVE_REG_HOOKS = True
+except Exception:                     # an older torch: fall back to walking the state_dict on every call
+    _HAVE_REG_HOOKS = False
+
+
 class _Holder(nn.Module):
     """A node of the parameter tree; it is never called."""
 
@@ -221,21 +243,30 @@ class GTCRNMicro(nn.Module):
         self._grad_flat = None  # gradient blob of the most recent backward (canonical layout)
         self._act_storage = "f32"
         self._sig_tensors = None
+        self._sig_epoch = -1
+        self._obj_serial = 0
 
     # -- weight hand-over -------------------------------------------------------------------
     def _state_tensors(self):
         """The tensors behind the state_dict, collected once (walking 388 keys on every call costs more host time
         than a streaming frame takes on the GPU); dropped whenever storages are re-created."""
-        if self._sig_tensors is None:
+        if self._sig_tensors is None or self._sig_epoch != _REG_EPOCH[0] or not _HAVE_REG_HOOKS:
+            self._sig_epoch = _REG_EPOCH[0]
             sd = self.state_dict(keep_vars=True)
-            self._sig_tensors = ([sd[name] for name, _, _ in _lib.param_table()],
-                                 [v for k, v in sd.items() if k.endswith("num_batches_tracked")])
+            new = ([sd[name] for name, _, _ in _lib.param_table()],
+                   [v for k, v in sd.items() if k.endswith("num_batches_tracked")])
+            old = self._sig_tensors
+            if old is not None and not all(a is b for a, b in zip(old[0], new[0])):
+                self._obj_serial += 1          # one of THIS model's tensors was replaced: engines must re-fold
+            self._sig_tensors = new
         return self._sig_tensors
 
     def _signature(self):
         """Changes whenever a weight may have changed: in-place updates (optimiser steps, load_state_dict's copy_,
-        manual edits) bump the tensors' version counters; the train forward (running statistics) bumps the serial."""
-        return (sum(int(t._version) for t in self._state_tensors()[0]), self._fwd_serial)
+        manual edits) bump the tensors' version counters; the train forward (running statistics) bumps the serial; a
+        REPLACED parameter / buffer object moves the registration epoch."""
+        ts = self._state_tensors()[0]
+        return (sum(int(t._version) for t in ts), self._fwd_serial, self._obj_serial)
 
     # -- train mode: flat parameter storage ----------------------------------------------------
     def _trainer(self, device):

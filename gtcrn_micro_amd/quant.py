@@ -83,4 +83,5 @@ def bench_leg(params, device, wave, win, world, sync_all, max_over_ranks, steps=
         "sdr_delta_db_vs_fp32": round(sc["int8w_fp16a"]["sdr_db"] - sc["fp32"]["sdr_db"], 3),
         "si_snr_delta_db_vs_fp32_with_int8_io": round(sc["int8w_fp16a_int8_io"]["si_snr_db"] - sc["fp32"]["si_snr_db"], 3),
         "pesq": None, "pesq_note": "PESQ is third-party C (pesq==0.0.4), absent here: SI-SNR/SDR reported instead",
+        "_rate_keys": ["frames_per_s"], "_time_keys": ["ms_per_step"],
     }

@@ -79,6 +79,9 @@ def _check_bench_line(stdout, steps, warmup):
     assert abs(d["value"] - 2 * 4 * T * steps / (d["ms_per_step"] * steps / 1e3)) / d["value"] < 1e-3
     assert "cpu_baseline" not in d and "TEST SHIM" in d["data"]
     assert "stream" not in d and "train" not in d       # the secondary legs need the HIP engine
+    pr = d["per_rank_ms_per_step"]                      # a straggler is visible in the line
+    assert len(pr["all"]) == 2 and pr["min"] <= pr["max"] and abs(pr["max"] - d["ms_per_step"]) < 1e-3
+    return d
 
 
 _SHIM_ENV = {"GTCRN_BENCH_TEST_SHIM": os.path.join(ROOT, "tests", "bench_shim.py")}
@@ -225,3 +228,26 @@ def test_running_statistics_follow_rank0_two_ranks(tmp_path):
     assert r.returncode == 0, r.stderr[-2000:]
     line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
     assert json.loads(line) == {"floats": 1348, "same": True, "params_untouched": True, "nbt": 1, "rv_unflat": 2.0}
+
+
+def test_secondary_leg_failing_on_one_rank_does_not_hang_or_lose_the_line():
+    """Rank 1 raises inside a secondary leg before any collective: the leg reports the error per rank, the legs before
+    and after it complete (priced with the slower rank's time) and the headline is intact."""
+    r = _torchrun([os.path.join(ROOT, "bench.py")] + _BENCH_ARGS, extra_env=dict(_SHIM_ENV, GTCRN_BENCH_TEST_LEGS="fail1"))
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = _check_bench_line(r.stdout, 3, 1)
+    assert d["second"] == {"error": {"1": "RuntimeError('simulated out-of-memory on rank 1')"}}
+    for name in ("first", "third"):
+        assert d[name]["units_per_s"] == 1000.0 * 0.5 and d[name]["ms"] == 20.0      # rank 0 timed 10 ms, rank 1 20 ms
+        assert d[name]["per_rank_timed_s"] == {"min": 0.01, "max": 0.02}
+
+
+def test_secondary_leg_hanging_on_one_rank_is_cut_by_the_watchdog():
+    """Rank 1 never returns from a secondary leg (the shape of a rank stuck in, or dead before, a collective): after the
+    leg's time limit rank 0 prints the line as it stands -- headline and the finished leg -- and every rank exits."""
+    r = _torchrun([os.path.join(ROOT, "bench.py")] + _BENCH_ARGS, timeout=120,
+                  extra_env=dict(_SHIM_ENV, GTCRN_BENCH_TEST_LEGS="hang1"))
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = _check_bench_line(r.stdout, 3, 1)
+    assert "timed out after 6 s" in d["secondary_errors"]["second"]
+    assert d["first"]["ms"] == 20.0 and "third" not in d

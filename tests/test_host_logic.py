@@ -364,3 +364,29 @@ def test_dense_bf16_planes_recombine_to_the_fp32_matrices():
                         assert np.array_equal(got, want.astype(np.float64)), (tag, j, c, half)
                     else:
                         assert not got.any()
+
+
+def test_replaced_parameter_object_is_noticed():
+    """the cached list of tensors behind the state_dict must not go stale when a Parameter or buffer OBJECT
+    is replaced (`mod.weight = nn.Parameter(...)`, parametrize, weight_norm, `register_buffer`): no version counter
+    moves then, so the weight signature carries a serial that the registration hooks advance."""
+    import torch
+    from gtcrn_micro_amd.models.gtcrn_micro import GTCRNMicro
+    m = GTCRNMicro()
+    sig0 = m._signature()
+    assert m._signature() == sig0                                # stable while nothing changes
+    other = torch.nn.Linear(3, 3)                                # registrations elsewhere do not disturb it
+    assert m._signature() == sig0 and other is not None
+    conv = m.encoder.en_convs[0].conv
+    old = conv.weight
+    conv.weight = torch.nn.Parameter(torch.full_like(old, 0.25))  # a NEW object, version 0 like the old one
+    sig1 = m._signature()
+    assert sig1 != sig0
+    assert any(t is conv.weight for t in m._state_tensors()[0]) and not any(t is old for t in m._state_tensors()[0])
+    bn = m.encoder.en_convs[0].bn
+    bn.register_buffer("running_mean", torch.ones(16))
+    sig2 = m._signature()
+    assert sig2 != sig1
+    with torch.no_grad():
+        conv.weight.mul_(2.0)                                    # in-place edits still move the version sum
+    assert m._signature()[0] == sig2[0] + 1 and m._signature()[2] == sig2[2]

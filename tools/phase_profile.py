@@ -14,7 +14,11 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-os.environ["GTCRN_LIB_VARIANT"] = "stamps"
+# --exp: the stamps inside the `-DGT_EXP` build (the A/B reference of the current kernel experiment)
+EXP = "--exp" in sys.argv
+os.environ["GTCRN_LIB_VARIANT"] = "exp" if EXP else "stamps"
+if EXP:
+    os.environ["GT_EXP_FLAGS"] = (os.environ.get("GT_EXP_FLAGS", "") + " -DGT_STAMPS").strip()
 
 PHASES = {
     0: {0: "prologue", 10: "A0 stage spec", 11: "A0 fetch next (issue)", 12: "A0 barrier", 13: "A erb bands", 1: "A erb barrier", 2: "B sfe", 3: "C en_conv0", 4: "D en_conv1", 5: "blk pc1", 6: "blk depth+pc2",
@@ -32,11 +36,12 @@ def main():
     ap.add_argument("--batch", type=int, default=256)
     ap.add_argument("--seconds", type=float, default=4.0)
     ap.add_argument("--json", default=None)
+    ap.add_argument("--exp", action="store_true", help="profile the -DGT_EXP build instead of the default one")
     a = ap.parse_args()
     import numpy as np
     import torch
     from gtcrn_micro_amd.build import build_native
-    build_native(stamps=True)
+    build_native(exp=True, force=True) if EXP else build_native(stamps=True)
     from gtcrn_micro_amd import Engine
     params = np.fromfile(os.path.join(ROOT, "tests", "golden", "params_dns3.f32"), dtype=np.float32)
     eng = Engine(params, 0)
