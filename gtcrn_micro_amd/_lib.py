@@ -87,6 +87,7 @@ def lib():
     L.gtcrn_selftest_mfma.argtypes = [ci]
     L.gtcrn_timing_enable.argtypes = [_vp, ci]
     L.gtcrn_timing_read.argtypes = [_vp, ci, ctypes.c_char_p, ci, _c_f32p, ctypes.POINTER(ci)]
+    L.gtcrn_timing_kernels.restype = ci
     L.gtcrn_trainer_create.argtypes = [ctypes.POINTER(_vp), ci]
     L.gtcrn_trainer_destroy.argtypes = [_vp]
     L.gtcrn_trainer_destroy.restype = None
@@ -475,12 +476,25 @@ class Engine:
                                         dst.size))
         return dst
 
-    KERNELS = ("k_stft", "k_encoder", "k_gtcn1", "k_gtcn2", "k_decoder", "k_istft")
+    _kernels = None
+
+    @classmethod
+    def kernel_names(cls):
+        """The kernels the library times, in its own order (every timed launch records which one it was)."""
+        if cls._kernels is None:
+            buf = ctypes.create_string_buffer(64)
+            ms, n = ctypes.c_float(), ctypes.c_int()
+            names = []
+            for i in range(lib().gtcrn_timing_kernels()):
+                _check(lib().gtcrn_timing_read(None, -1 - i, buf, 64, ctypes.byref(ms), ctypes.byref(n)))
+                names.append(buf.value.decode())
+            cls._kernels = tuple(names)
+        return cls._kernels
 
     def timing_enable(self, on=True, only=None):
         """HIP-event timing of the kernel launches; only="k_decoder" keeps the events of that kernel alone (an
         event pair costs a few microseconds of dispatch gap per launch)."""
-        mode = 0 if not on else (1 if only is None else 2 + self.KERNELS.index(only))
+        mode = 0 if not on else (1 if only is None else 2 + self.kernel_names().index(only))
         _check(lib().gtcrn_timing_enable(self._h, mode))
 
     def timing_read(self):
@@ -488,7 +502,7 @@ class Engine:
         out = {}
         buf = ctypes.create_string_buffer(64)
         ms, n = ctypes.c_float(), ctypes.c_int()
-        for i in range(6):
+        for i in range(len(self.kernel_names())):
             _check(lib().gtcrn_timing_read(self._h, i, buf, 64, ctypes.byref(ms), ctypes.byref(n)))
             if n.value:
                 out[buf.value.decode()] = (float(ms.value), int(n.value))

@@ -45,10 +45,11 @@ struct Timing {
     int kernel = 0;  // index into kKernelNames
     hipEvent_t a = nullptr, b = nullptr;
 };
-// index 0 / 1 are k_front / k_encoder_gt on offline calls (front end fused with the STFT, GTConv blocks alone) and
-// k_stft / k_encoder otherwise; gtcrn_timing_read reports the name of what actually ran
-const char* const kKernelNames[] = {"k_stft", "k_encoder", "k_gtcn1", "k_gtcn2", "k_decoder", "k_istft"};
-constexpr int kNumKernels = 6;
+// every timed launch records WHICH kernel it was (mixed offline / streaming calls keep their own rows)
+enum KernelId { K_STFT, K_ENCODER, K_GTCN1, K_GTCN2, K_DECODER, K_ISTFT, K_FRONT, K_ENCODER_GT, K_GTCN_MS, K_STREAM_MS, K_COUNT };
+const char* const kKernelNames[K_COUNT] = {"k_stft",  "k_encoder",    "k_gtcn1",   "k_gtcn2",    "k_decoder",
+                                           "k_istft", "k_front",      "k_encoder_gt", "k_gtcn_ms", "k_stream_ms"};
+constexpr int kNumKernels = K_COUNT;
 
 }  // namespace
 
@@ -77,7 +78,8 @@ struct gtcrn_model {
     unsigned long long* d_stamps = nullptr;  // [4 kernels][B][16] phase cycle sums (diagnostic build only)
     int stamps_cap_b = 0;
     float** d_ptr8 = nullptr;  // device table of 8 tcn cache pointers
-    bool fused_front = false;      // the last call ran k_front (+ k_encoder_gt)
+    bool last_quant = false;       // the last forward was the fp16 variant: the hand-off buffers hold fp16 records
+    bool last_fused_stream = false;  // the last forward was the single-launch streaming step: no hand-off tensors exist
     bool timing = false;
     int timing_only = -1;          // >= 0: record events around this kernel only (two events per call)
     std::vector<Timing> timings;   // one entry per timed launch since gtcrn_timing_enable(m, 1)
@@ -161,20 +163,32 @@ int run_model(gtcrn_model* m, const float* spec_in, long isb, long isf, long ist
     Timer tm(m, s);
     const float* pf = q ? m->d_pfq : m->d_pf;
     const bool offline = !state;
+    m->last_quant = q != nullptr;
+    m->last_fused_stream = false;
+    // single-frame streaming step: ONE launch, nothing handed over through HBM (the three-launch form below remains
+    // for the stage taps of the parity tests, which read the hand-off tensors)
+    if (state && T == 1 && !q && !m->debug && gtk::stream_ms_usable(isb, osb)) {
+        tm.begin(K_STREAM_MS);
+        LAUNCH_TRY(gtk::launch_stream_ms(spec_in, isb, isf, spec_out, osb, osf, B, pf, m->d_pi, state, s));
+        tm.end();
+        m->last_fused_stream = true;
+        m->last_B = B;
+        m->last_T = T;
+        return 0;
+    }
     if (offline) {
         // offline: the frame-independent front end runs as a throughput kernel (fused with the STFT by
         // forward_wave_impl, which passes front_done), the per-utterance kernel keeps the three GTConv blocks
         if (!front_done) {
-            tm.begin(0);
+            tm.begin(K_FRONT);
             LAUNCH_TRY(gtk::launch_front(nullptr, 0, spec_in, isb, isf, ist, B, T, lens, nullptr, nullptr, pf, m->d_pi,
                                          nullptr, m->d_en0, m->d_en[0], s, q));
             tm.end();
         }
     }
-    m->fused_front = offline;
     unsigned long long* stp = (m->debug && m->d_stamps) ? m->d_stamps : nullptr;
     const long sst = (long)m->stamps_cap_b * 16;
-    tm.begin(1);
+    tm.begin(offline ? K_ENCODER_GT : K_ENCODER);
     LAUNCH_TRY(gtk::launch_encoder(spec_in, isb, isf, ist, B, T, lens, pf, m->d_pi, m->d_en0, m->d_en[0], m->d_en[1],
                                    m->d_en[2], m->d_en[3], state, stp ? stp : nullptr, s, q, offline));
     tm.end();
@@ -182,18 +196,18 @@ int run_model(gtcrn_model* m, const float* spec_in, long isb, long isf, long ist
     // single-frame streaming steps run BOTH stacks per position in one launch; other streaming chunkings use the
     // ring form, whose chunks may hold any number of frames
     if (state && T == 1) {
-        tm.begin(2);
+        tm.begin(K_GTCN_MS);
         LAUNCH_TRY(gtk::launch_gtcn_ms(m->d_en[3], m->d_g1, m->d_g2, pf + gtl::P_GTCN, B, state, s));
         tm.end();
     } else {
-        tm.begin(2);
+        tm.begin(K_GTCN1);
         if (!state)
             LAUNCH_TRY(gtk::launch_gtcn_band(m->d_en[3], m->d_g1, pf + gtl::P_GTCN, B, T, lens, nullptr, s, q));
         else
             LAUNCH_TRY(gtk::launch_gtcn(m->d_en[3], m->d_g1, pf + gtl::P_GTCN, B, T, state, gtk::ST_G1_H, nullptr,
                                         stp ? stp + sst : nullptr, s));
         tm.end();
-        tm.begin(3);
+        tm.begin(K_GTCN2);
         // the second stack stores gtcn2(x) + en_outs[4]: exactly the decoder's first input (Decoder.forward :467)
         if (!state)
             LAUNCH_TRY(gtk::launch_gtcn_band(m->d_g1, m->d_g2, pf + gtl::P_GTCN + gtl::GTCN_SIZE, B, T, lens, m->d_en[3], s,
@@ -203,7 +217,7 @@ int run_model(gtcrn_model* m, const float* spec_in, long isb, long isf, long ist
                                         m->d_en[3], stp ? stp + 2 * sst : nullptr, s));
         tm.end();
     }
-    tm.begin(4);
+    tm.begin(K_DECODER);
     LAUNCH_TRY(gtk::launch_decoder(m->d_g2, m->d_en0, m->d_en[0], m->d_en[1], m->d_en[2], m->d_en[3], spec_in, isb, isf,
                                    ist, spec_out, osb, osf, ost, B, T, lens, pf, m->d_pi, state,
                                    m->debug && !q ? m->d_dbg : nullptr, stp ? stp + 3 * sst : nullptr, s, q));
@@ -466,13 +480,13 @@ static int forward_wave_impl(gtcrn_model* m, const float* d_wave, float* d_wave_
     // internal spectrograms are frame-major (B,T,257,2): sb = T*514, sf = 2, st = 514
     const long sb = (long)T * 514, sf = 2, st = 514;
     Timer tm(m, s);
-    tm.begin(0);
+    tm.begin(K_FRONT);
     LAUNCH_TRY(gtk::launch_front(d_wave, L, nullptr, 0, 0, 0, B, T, d_lengths, d_win, m->d_twid, q ? m->d_pfq : m->d_pf,
                                  m->d_pi, m->d_spec_a, m->d_en0, m->d_en[0], s, q));
     tm.end();
     rc = run_model(m, m->d_spec_a, sb, sf, st, m->d_spec_b, sb, sf, st, B, T, nullptr, s, d_lengths, q, true);
     if (rc) return rc;
-    tm.begin(5);
+    tm.begin(K_ISTFT);
     LAUNCH_TRY(gtk::launch_istft(m->d_spec_b, sb, sf, st, B, T, d_lengths, d_win, m->d_twid, d_wave_out, s));
     tm.end();
     return 0;
@@ -596,6 +610,12 @@ long gtcrn_debug_tap(gtcrn_model* m, const char* name, int b, float* h_dst, long
     if (!name || !h_dst) return fail(GTCRN_ERR_ARG, "null argument");
     const int B = m->last_B, T = m->last_T;
     if (B < 1 || b < 0 || b >= B) return fail(GTCRN_ERR_ARG, "no forward recorded or batch index out of range");
+    if (m->last_quant)
+        return fail(GTCRN_ERR_STATE, "the last forward was the int8/fp16 variant: its hand-off tensors are fp16 records, "
+                                     "the stage taps read fp32");
+    if (m->last_fused_stream)
+        return fail(GTCRN_ERR_STATE, "the last forward was a single-launch streaming step, which keeps no hand-off "
+                                     "tensors: enable debug before the step to run the three-launch form");
     const std::string nm(name);
     const long bt = (long)B * T;
     const float* src = nullptr;
@@ -700,7 +720,18 @@ int gtcrn_timing_enable(gtcrn_model* m, int on) {
     return 0;
 }
 
+int gtcrn_timing_kernels(void) { return kNumKernels; }
+
 int gtcrn_timing_read(gtcrn_model* m, int idx, char* name, int name_cap, float* ms, int* launches) {
+    if (idx < 0) {   // name query only (no model needed): idx = -1 - k
+        const int k = -1 - idx;
+        if (k >= kNumKernels || !name || name_cap < 1) return fail(GTCRN_ERR_ARG, "timing index out of range");
+        std::strncpy(name, kKernelNames[k], name_cap - 1);
+        name[name_cap - 1] = 0;
+        if (ms) *ms = 0.f;
+        if (launches) *launches = 0;
+        return 0;
+    }
     int rc = check_model(m);
     if (rc) return rc;
     if (idx < 0 || idx >= kNumKernels || !ms) return fail(GTCRN_ERR_ARG, "timing index out of range");
@@ -717,10 +748,7 @@ int gtcrn_timing_read(gtcrn_model* m, int idx, char* name, int name_cap, float* 
     *ms = n ? (float)(sum / n) : 0.f;
     if (launches) *launches = n;
     if (name && name_cap > 0) {
-        const char* nm = kKernelNames[idx];
-        if (m->fused_front && idx == 0) nm = "k_front";
-        if (m->fused_front && idx == 1) nm = "k_encoder_gt";
-        std::strncpy(name, nm, name_cap - 1);
+        std::strncpy(name, kKernelNames[idx], name_cap - 1);
         name[name_cap - 1] = 0;
     }
     return 0;

@@ -67,6 +67,10 @@ int launch_decoder(const float* xg, const float* en0, const float* en1, const fl
                    const float* en4, const float* spec, long sb, long sf, long st, float* out, long osb, long osf,
                    long ost, int B, int T, const int* lens, const float* PF, const int* PI, float* state, float* dbg,
                    unsigned long long* stamps, hipStream_t s, const Quant* q = nullptr);
+// single-frame streaming step of B streams as ONE launch (encoder -> both GTCN stacks -> decoder, nothing through HBM)
+int launch_stream_ms(const float* spec, long sb, long sf, float* out, long osb, long osf, int B, const float* PF,
+                     const int* PI, float* state, hipStream_t s);
+bool stream_ms_usable(long sb, long osb);
 int launch_state_convert(float* state, int N, float* conv, float* tra, float* const* tcn8, const int* PI, int dir,
                          hipStream_t s);
 int launch_conv2d_causal(const float* x, const float* cache, const float* w, const float* bias, float* y,

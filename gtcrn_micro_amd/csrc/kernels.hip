@@ -615,6 +615,9 @@ struct BlockCtx {
     int ms_roff;         // per lane: float offset from sW to this block's h ring of the lane's stream
     int ms_tb;           // per lane: frame counter of the lane's stream
     const int* sTB;      // LDS: frame counter per row
+    // fused single-launch streaming step (k_stream_ms): the h history is a per-block LDS image filled from the stream
+    // state; the ONE new row goes straight from the registers to the state (nullptr elsewhere: the rings live in LDS)
+    float* g_hist;       // per lane: its 16 bytes of the new history row in the stream state, or nullptr
 };
 
 // multi-stream geometry of the single-frame streaming step: MS_STREAMS streams per workgroup = rows 0..3 of the
@@ -636,9 +639,9 @@ __device__ __forceinline__ void ring_to_image(float* sW, const float* ring, int 
     }
 }
 
-template <bool DENSE, int TPW, bool MS, bool Q, int RS, int RSS, bool WIDE_TRA, int PT, int VMK = 0, class Hook>
+template <bool DENSE, int TPW, bool MS, bool Q, int RS, int RSS, bool WIDE_TRA, int PT, int VMK = 0, class Hook, class Hook3>
 __device__ __forceinline__ void gtconv_block(f32x4 (&x)[TPW], const Tiles<TPW>& tin, const BlockCtx& c,
-                                             const Lane& L, Hook&& hook STAMP_PARAM) {
+                                             const Lane& L, Hook&& hook, Hook3&& hook3 STAMP_PARAM) {
     static_assert(!MS || TPW == 1, "multi-stream mode runs one tile per wave");
     // SPLIT: the dense 3x3 on the 16-bit matrix pipe; the image W then holds h as three bf16 planes per position
     constexpr bool SPLIT = DENSE && !Q && kSplitDense;
@@ -676,8 +679,12 @@ __device__ __forceinline__ void gtconv_block(f32x4 (&x)[TPW], const Tiles<TPW>& 
         mm16<TPW, Q>(A, x, h);
 #pragma unroll
         for (int i = 0; i < TPW; ++i) {
-            if constexpr (SPLIT) st_split(c.sW, b0s[i] - 4 * g, g, prelu4(h[i], a1));
-            else st4(c.sW + b0s[i], rq<Q>(prelu4(h[i], a1)));
+            const f32x4 hv = rq<Q>(prelu4(h[i], a1));
+            if constexpr (SPLIT) st_split(c.sW, b0s[i] - 4 * g, g, hv);
+            else st4(c.sW + b0s[i], hv);
+            if constexpr (MS) {
+                if (c.g_hist && tt.tl[i] < c.nfr) st4(c.g_hist, hv);     // the stream's new history row (replaces frame t-2)
+            }
         }
     }
     wg_barrier();
@@ -819,7 +826,7 @@ __device__ __forceinline__ void gtconv_block(f32x4 (&x)[TPW], const Tiles<TPW>& 
         // 8 bytes, which sit at float offsets 2g, 8 + 2g, 16 + 2g of the 96-byte record)
 #pragma unroll
         for (int i = 0; i < TPW; ++i)
-            if (tt.tl[i] < c.nfr) {
+            if (tt.tl[i] < c.nfr && !c.g_hist) {
                 const int dst = c.ms_roff + ((c.ms_tb & 1) * 35 + 1 + tt.ff[i]) * RS;
                 if constexpr (SPLIT) {
 #pragma unroll
@@ -882,6 +889,7 @@ __device__ __forceinline__ void gtconv_block(f32x4 (&x)[TPW], const Tiles<TPW>& 
     if constexpr (!MS) {
         if (c.sHnext) ring_to_image<RS, PT, SPLIT>(c.sW, c.sHnext, L.tid);
     }
+    hook3();   // (k_stream_ms: the next block's history image, its taps are all read)
     // ---- step 2: one thread per (frame, output channel): causal depthwise conv1d (k=3) over the energies,
     //      1x1 conv, sigmoid (models/gtcrn_micro.py:122-139) ------------------------------------------------
     {
@@ -1413,7 +1421,8 @@ __global__ __launch_bounds__(NTHR) void k_encoder(const float* __restrict__ spec
             } else {
                 c.ms_roff = 0; c.ms_tb = 0;
             }
-            gtconv_block<false, TPW, MS, Q, RS, RS, !(FRONT && TPW == 3), LD::PT>(x, tt, c, L, [] {} STAMP_ARG);
+            c.g_hist = nullptr;
+            gtconv_block<false, TPW, MS, Q, RS, RS, !(FRONT && TPW == 3), LD::PT>(x, tt, c, L, [] {}, [] {} STAMP_ARG);
             if (k < 2) {
                 ht* dst = k == 0 ? en2h : en3h;
                 const int* ix = sI + I_ENST - ENC_I_SKIP + (k + 1) * 16 + 4 * g;
@@ -2289,8 +2298,9 @@ __global__ __launch_bounds__(NTHR) void k_decoder(const float* __restrict__ xg, 
             // the next block's dense 3x3 (block 0 of the next chunk after the last one): the DMA starts once this block's
             // dense phase is over (the hook runs behind its closing barrier) and is waited for two barrier intervals
             // later, one barrier (the next block's point_conv1) before its first reader
+            c.g_hist = nullptr;
             gtconv_block<true, TPW, MS, Q, RS, LD::RSS, true, 35, decltype(vmk)::value>(
-                x, tt, c, L, [&] { dense_fetch(j == 2 ? 0 : j + 1); hook(); } STAMP_ARG);
+                x, tt, c, L, [&] { dense_fetch(j == 2 ? 0 : j + 1); hook(); }, [] {} STAMP_ARG);
             if (DBG)
 #pragma unroll
                 for (int i = 0; i < TPW; ++i)
@@ -2532,6 +2542,508 @@ __global__ __launch_bounds__(NTHR) void k_decoder(const float* __restrict__ xg, 
     }
 }
 
+// =============================================================================== streaming step, ONE launch
+// StreamGTCRNMicro.forward for N streams x one new frame (gtcrn_micro_stream.py:541-574, the loop :626-635) as a
+// SINGLE kernel: in multi-stream mode a workgroup's four streams never leave it between encoder, GTCN and decoder, so
+// the three launches of that step (k_encoder<MS> -> k_gtcn_ms -> k_decoder<MS>) collapse into one:
+//   * one prologue: every parameter segment (encoder 19 KB, both GTCN stacks 20 KB, decoder 31 KB incl. the stage
+//     buffer of one block's dense planes) is resident in LDS for the whole step;
+//   * nothing is handed over through HBM: en4 -> GTCN -> decoder stay in registers (the MS tile geometry and
+//     k_gtcn_ms's flattened (stream, bin) positions are the same mapping), the skips en1..en3 stay in registers in
+//     their consumer's slot order, en0 stays in LDS;
+//   * the h history of a GTConv block is NOT a resident ring set any more (4 streams x 3 blocks x 2 rows: 54 KB fp32 for
+//     the encoder, 81 KB split for the decoder): it is a per-block LDS image of the two old rows, fetched from the
+//     stream state one block ahead (two 16-byte loads per thread) and written while the previous block's TRALite
+//     runs; the ONE new row goes straight from the registers to the state (gtconv_block, g_hist).  State traffic per
+//     block and stream: 2 rows read, 1 row written -- what SURVEY 8d's 94 KB bound counts;
+//   * every global load of a later phase is requested a phase or more ahead (GTCN rows during the last encoder block,
+//     decoder history during the GTCN, dense planes by LDS-DMA during the previous block).
+// Same helper code (gtconv_block, tcn_block_ms, the front-end expressions) as the three-launch form, same rounding:
+// streamed == offline bit for bit (tests/test_gpu_stream.py).  The three-launch form remains for the stage taps.
+struct SmLds {
+    static constexpr int RW = MS_ROWS, NS = MS_STREAMS;
+    static constexpr int PE = 0;                                  // encoder segment, then both GTCN stacks (contiguous in PF too)
+    static constexpr int PG = PE + ENC_SIZE;
+    static constexpr int PD = PG + 2 * GTCN_SIZE;                 // decoder: DL_* layout (blocks, de_convs, dense stage buffer)
+    static constexpr int I = PD + DL_SIZE;                        // ints: the tables without the ERB.bs index ranges
+    static constexpr int BS = I + ((P_INTS - ENC_I_SKIP + 3) & ~3);
+    static constexpr int EHE = BS + NBINS * 4;                    // energy rings [NS][3][2][8], encoder / decoder
+    static constexpr int EHD = EHE + NS * 48;
+    static constexpr int TB = EHD + NS * 48;
+    static constexpr int G = TB + 8;
+    static constexpr int E = G + RW * 16 + RW * 8;
+    static constexpr int EN0 = E + NS * 24;                       // en0 of the step [NS][65][16] (the decoder tail adds it)
+    static constexpr int X = EN0 + NS * F1 * 16;                  // ---- region shared by the encoder and decoder phases
+    static constexpr int HE = X;                                  // encoder: history image [NS][2][35][16]
+    static constexpr int A = HE + NS * 2 * 35 * 16;               //          staged spectrogram, then E0, then W + S
+    static constexpr int B = A + RW * ENC_E0_ROW * 16;            //          EB + F0
+    static constexpr int SE = A + RW * 35 * 16;
+    static constexpr int ENC_END = B + 3 * RW * EB_ROW + 3 * RW * F0_ROW;
+    static constexpr int RSD = RS_WIDE;                           // decoder: 96-byte records (split planes)
+    static constexpr int HD = X;                                  //          history image [NS][2][35][24]
+    static constexpr int W = HD + NS * 2 * 35 * RSD;
+    static constexpr int SD = W + RW * 35 * RSD;
+    static constexpr int ZSZ = RW * DEC_Z_ROW * DEC_ZS;
+    static constexpr int M = W + ZSZ;
+    static constexpr int MSZ = (2 * RW * F0 + 4 + 3) & ~3;
+    static constexpr int DEC_END = (SD + RW * 33 * 16) > (M + MSZ) ? (SD + RW * 33 * 16) : (M + MSZ);
+    static constexpr int FLOATS = ENC_END > DEC_END ? ENC_END : DEC_END;
+    static_assert(FLOATS * 4 <= 160 * 1024, "fused streaming step: LDS budget");
+    static_assert(SE + RW * 33 * 16 <= ENC_END && 3 * RW * NBINS <= RW * ENC_E0_ROW * 16, "encoder overlay");
+    static_assert(PG % 4 == 0 && PD % 4 == 0 && I % 4 == 0 && BS % 4 == 0 && EHE % 4 == 0 && G % 4 == 0 && E % 4 == 0 &&
+                  EN0 % 4 == 0 && X % 4 == 0 && A % 4 == 0 && B % 4 == 0 && W % 4 == 0 && SD % 4 == 0 && M % 4 == 0, "16B carve");
+};
+constexpr int SM_LDS_FLOATS = SmLds::FLOATS;
+
+__global__ __launch_bounds__(NTHR) void k_stream_ms(const float* __restrict__ spec, long sb, long sf,
+                                                   float* __restrict__ out, long osb, long osf, int NB,
+                                                   const float* __restrict__ PF, const int* __restrict__ PI,
+                                                   float* __restrict__ state) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    using LD = SmLds;
+    constexpr int RW = LD::RW, NS = LD::NS;
+    constexpr bool SPLIT = kSplitDense;
+    float* sPE = smem + LD::PE;
+    float* sPG = smem + LD::PG;
+    float* sPD = smem + LD::PD;
+    int* sI = reinterpret_cast<int*>(smem + LD::I);
+    float* sBS = smem + LD::BS;
+    float* sEHe = smem + LD::EHE;
+    float* sEHd = smem + LD::EHD;
+    int* sTB = reinterpret_cast<int*>(smem + LD::TB);
+    float* sG = smem + LD::G;
+    float* sEN0 = smem + LD::EN0;
+    const Lane L = lane_info();
+    const int tid = L.tid, n = L.n, g = L.g;
+    const int b = blockIdx.x;
+    float* stb = state + (long)b * NS * ST_FLOATS;             // first stream of this workgroup
+    const int nlive = min(NS, NB - b * NS), nfr = nlive;
+    const Tiles<1> tt = make_tiles<1>(L);
+    const int row = min(tt.tl[0], NS - 1);                      // the lane's stream (tail lanes of the tile geometry: clamped)
+    const bool lane_live = tt.tl[0] < nlive;
+    float* stl = stb + (long)(lane_live ? tt.tl[0] : 0) * ST_FLOATS;   // ... its state
+
+    // the dense 3x3 of decoder block j -> stage buffer by LDS-DMA (see k_decoder)
+    constexpr int DN_PIECES = (SPLIT ? DN16_SIZE : 9 * 256) / 256;
+    auto dense_fetch = [&](int j) {
+        const float* src = PF + P_DEC + (SPLIT ? D_DN16 + j * DN16_SIZE : D_BLK + j * GBD_SIZE + GB_DN_A);
+        int lz = L.lane;
+        asm volatile("" : "+v"(lz));
+        for (int pi = L.wave; pi < DN_PIECES; pi += NW) {
+            const float* gsrc = src + pi * 256 + 4 * lz;
+            const unsigned lds_dst = (unsigned)(size_t)(__attribute__((address_space(3))) void*)(sPD + DL_DN + pi * 256);
+            unsigned keep;
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                         : "=&s"(keep)
+                         : "v"(gsrc), "s"(lds_dst)
+                         : "memory");
+        }
+    };
+    // history rows of one block, all streams of the workgroup: [NS][2 rows (frame parity)][33][16] of the state ->
+    // two 16-byte items per thread; written to the block's LDS image later (pad columns are zeroed once per phase)
+    auto hist_fetch = [&](int st_off, f32x4 (&v)[2]) {
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int i = tid + q * NTHR, sidx = i / 264, r = i - sidx * 264;
+            const bool ok = i < NS * 264 && sidx < nlive;
+            v[q] = ld4(stb + (ok ? (long)sidx * ST_FLOATS + st_off + r * 4 : (long)ST_ENC_H));   // clamped: a valid record
+        }
+    };
+    auto hist_store = [&](float* img, auto split, const f32x4 (&v)[2]) {
+        constexpr bool SP = decltype(split)::value;
+        constexpr int RS = SP ? RS_WIDE : 16;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int i = tid + q * NTHR, sidx = i / 264, r = i - sidx * 264;
+            if (i < NS * 264) {
+                const int rw = r >= 132 ? 1 : 0, rr = r - rw * 132;
+                const f32x4 val = sidx < nlive ? v[q] : splat(0.f);
+                const int rec = (sidx * 2 * 35 + rw * 35 + 1 + (rr >> 2)) * RS;
+                if constexpr (SP) st_split(img, rec, rr & 3, val);
+                else st4(img + rec + 4 * (rr & 3), val);
+            }
+        }
+    };
+    auto hist_zero_pads = [&](float* img, int rs) {               // columns 0 and 34 of the NS * 2 image rows
+        if (tid < NS * 2 * 2 * 8) {
+            const int rw = tid >> 4, side = (tid >> 3) & 1, gg = tid & 7;
+            if (gg < rs / 4) st4(img + (rw * 35 + side * 34) * rs + 4 * gg, splat(0.f));
+        }
+    };
+
+    // ------------------------------------------------------------------------------------------------- prologue
+    dense_fetch(0);
+    static_assert(P_GTCN == P_ENC + ENC_SIZE && (ENC_SIZE + 2 * GTCN_SIZE) % 4 == 0, "encoder + GTCN segments are contiguous");
+    copy_params(sPE, PF + P_ENC, ENC_SIZE + 2 * GTCN_SIZE, tid, NTHR);
+#pragma unroll
+    for (int j = 0; j < 3; ++j) copy_params(sPD + j * GB_SIZE, PF + P_DEC + D_BLK + j * GBD_SIZE, GB_SIZE, tid, NTHR);
+    copy_params(sPD + DL_DE, PF + P_DEC + D_DE3_AE, D_BS_W - D_DE3_AE, tid, NTHR);
+    for (int i = tid; i < P_INTS - ENC_I_SKIP; i += NTHR) sI[i] = PI[i < I_BS_LO ? i : i + ENC_I_SKIP];
+    for (int f = tid; f < NBINS; f += NTHR) st4(sBS + f * 4, ld4(PF + P_DEC + D_BS_TAB + f * 4));
+    if (tid < NS * 48) {
+        const int sidx = tid / 48, e = tid - sidx * 48;
+        sEHe[tid] = sidx < nlive ? stb[(long)sidx * ST_FLOATS + ST_ENC_E + e] : 0.f;
+        sEHd[tid] = sidx < nlive ? stb[(long)sidx * ST_FLOATS + ST_DEC_E + e] : 0.f;
+    }
+    if (tid < 8) sTB[tid] = tid < nlive ? reinterpret_cast<const int*>(stb + (long)tid * ST_FLOATS)[0] : 0;
+    f32x4 hv[2];
+    hist_fetch(ST_ENC_H, hv);
+    hist_zero_pads(smem + LD::HE, 16);
+
+    // ------------------------------------------------------------------------------------------------- encoder
+    // (the front end and the three depthwise GTConv blocks of k_encoder<1, true, false, true>: same expressions)
+    float* sSpec = smem + LD::A;
+    float* sE0 = smem + LD::A;
+    float* sWe = smem + LD::A;
+    float* sSe = smem + LD::SE;
+    float* sEB = smem + LD::B;
+    float* sF0 = sEB + 3 * RW * EB_ROW;
+    // rows = streams.  Items always run bin-fastest here: the frame-fastest decomposition of spec_item_first assumes
+    // 16-row chunks, and a stream stride below the bin stride is not a layout worth a second path.
+    constexpr bool t_fast = false;
+    const int sf32 = (int)sf, st32 = (int)sb;
+    constexpr int SPEC_ITEMS = (RW * NBINS + NTHR - 1) / NTHR;
+    float2 spn[SPEC_ITEMS];                                        // kept for the mask at the end of the step
+    {
+        const float* base = spec + (long)b * NS * sb;
+        int tl, f;
+        spec_item_first(tid, t_fast, tl, f);
+#pragma unroll
+        for (int q = 0; q < SPEC_ITEMS; ++q) {
+            const bool ok = tl < nfr && f < NBINS;
+            spn[q] = *reinterpret_cast<const float2*>(base + (ok ? f * sf32 + tl * st32 : 0));
+            spec_item_next(t_fast, tl, f);
+        }
+    }
+    hist_store(smem + LD::HE, std::false_type{}, hv);
+    if (tid < 3 * RW * 9) {                                        // zero pad entries of EB / F0
+        const int rw = tid / 9, e = tid - rw * 9;
+        if (e < 2) sEB[rw * EB_ROW + e * 130] = 0.f;
+        else sF0[rw * F0_ROW + (e < 4 ? e - 2 : 127 + e)] = 0.f;
+    }
+    {   // A0: [mag, re, im] of the new frames
+        int tl, f;
+        spec_item_first(tid, t_fast, tl, f);
+#pragma unroll
+        for (int q = 0; q < SPEC_ITEMS; ++q) {
+            if (tl < nfr && f < NBINS) {
+                const float2 v = spn[q];
+                const bool low = f < ERB_LOW;
+                float* d = low ? sEB + tl * EB_ROW + 1 + f : sSpec + tl * NBINS + f;
+                const int cs = low ? RW * EB_ROW : RW * NBINS;
+                d[0] = __builtin_amdgcn_sqrtf(v.x * v.x + v.y * v.y + 1e-12f);
+                d[cs] = v.x;
+                d[2 * cs] = v.y;
+            }
+            spec_item_next(t_fast, tl, f);
+        }
+    }
+    wg_barrier_vm();                                               // (also: parameters, tables and the dense planes are in LDS)
+    {   // A: ERB.bm bands
+        const int band = tid & (ERB_BANDS - 1);
+        const int lo = sI[I_ERB_LO + band], cnt = sI[I_ERB_N + band];
+        float w[ERB_MAXBW];
+#pragma unroll
+        for (int i = 0; i < ERB_MAXBW; i += 4) {
+            const f32x4 t = ld4(sPE + E_ERB_W + band * ERB_MAXBW + i);
+            w[i] = t[0]; w[i + 1] = t[1]; w[i + 2] = t[2]; w[i + 3] = t[3];
+        }
+        for (int ct = tid >> 6; ct < 3 * RW; ct += NW) {
+            if ((ct % RW) >= nfr) continue;
+            const float* sp = sSpec + ct * NBINS + ERB_LOW + lo;
+            float a0 = 0.f, a1 = 0.f;
+#pragma unroll
+            for (int i = 0; i < ERB_MAXBW; i += 2) {
+                a0 += w[i] * (i < cnt ? sp[i] : 0.f);
+                a1 += w[i + 1] * (i + 1 < cnt ? sp[i + 1] : 0.f);
+            }
+            sEB[ct * EB_ROW + 1 + ERB_LOW + band] = a0 + a1;
+        }
+    }
+    wg_barrier();
+    // B: SFE_Lite
+    for (int rw = L.wave; rw < 3 * RW; rw += NW) {
+        const int tl = rw % RW, c = rw / RW;
+        if (tl >= nfr) continue;
+        const float w0 = sPE[E_SFE_W + c * 3], w1 = sPE[E_SFE_W + c * 3 + 1], w2 = sPE[E_SFE_W + c * 3 + 2];
+        const float* e = sEB + rw * EB_ROW;
+        float* d = sF0 + rw * F0_ROW + 2;
+        const int f = tid & 63;
+        d[f] = w0 * e[f] + w1 * e[f + 1] + w2 * e[f + 2];
+        d[f + 64] = w0 * e[f + 64] + w1 * e[f + 65] + w2 * e[f + 66];
+        if (f == 0) d[128] = w0 * e[128] + w1 * e[129] + w2 * e[130];
+    }
+    if (tid < RW * 4 * 4) {                                        // pad positions of E0
+        const int r = tid >> 4, cc = (tid >> 2) & 3, gg = tid & 3;
+        st4(sE0 + pl(r * ENC_E0_ROW + (cc < 2 ? cc : 65 + cc), gg), splat(0.f));
+    }
+    wg_barrier();
+    {   // C: en_convs.0; en0 stays in LDS for the decoder tail
+        const f32x4 A = ld4(sPE + E_EN0_A + arow(n, g)), Bv = ld4(sPE + E_EN0_B + 4 * g);
+        const float a = sPE[E_EN0_S] - 1.0f;
+        int off[4];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const int e = 4 * g + s, c = e < 15 ? e / 5 : 0, k = e < 15 ? e % 5 : 0;
+            off[s] = c * RW * F0_ROW + k;
+        }
+        const int nt0 = (nfr * F1 + 15) >> 4;
+        for (int tile = L.wave; tile < nt0; tile += NW) {
+            const int q = tile * 16 + n;
+            int tl = q / F1;
+            const int fo = q - tl * F1;
+            if (tl >= RW) tl = RW - 1;
+            f32x4 bv;
+#pragma unroll
+            for (int s = 0; s < 4; ++s) bv[s] = sF0[off[s] + tl * F0_ROW + 2 * fo];
+            f32x4 acc = mm1<false>(A, bv, Bv);
+            acc = prelu4(acc, a);
+            st4(sE0 + pl(tl * ENC_E0_ROW + 2 + fo, g), acc);
+            if (q < nfr * F1) st4(sEN0 + q * 16 + 4 * g, acc);
+        }
+    }
+    wg_barrier();
+    f32x4 x[1], en1p, en2p, en3p;
+    {   // D: en_convs.1; en1 is kept in the slot order of its decoder consumer
+        const f32x4 Bv = ld4(sPE + E_EN1_B + 4 * g);
+        const float a = sPE[E_EN1_S] - 1.0f;
+        const int* ix = sI + I_ENST - ENC_I_SKIP + 0 * 16 + 4 * g;
+        x[0] = Bv;
+#pragma unroll
+        for (int k = 0; k < 5; ++k) {
+            const f32x4 A = ld4(sPE + E_EN1_A + k * 256 + arow(n, g));
+            const f32x4 tap = ld4(sE0 + pl(tt.tl[0] * ENC_E0_ROW + 2 * tt.ff[0], g) + k * 16);
+            x[0] = mm1<false>(A, tap, x[0]);
+        }
+        x[0] = prelu4(x[0], a);
+        en1p = permute_via_lds(sEB + tt.pp(0) * 16, ix, g, x[0]);
+    }
+    wg_barrier();                                                  // E0 is dead: its region becomes W
+    zero_row_pads<RW, 16, 35>(sWe, tid);
+    // GTCN history rows of the lane's position (k_gtcn_ms): requested during the last encoder block
+    const int ffl = lane_live ? tt.ff[0] : 0;
+    const int tbl = sTB[row];
+    f32x4 t1[4], t2[4];
+    int r2[4];
+    auto fetch_rows = [&](const float* ring) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int d = 1 << k, m2d = 2 * d - 1, row0 = 2 * (d - 1);
+            const int r1 = ((row0 + ((tbl + d) & m2d)) * 33 + ffl) * 16 + 4 * g;
+            r2[k] = ((row0 + (tbl & m2d)) * 33 + ffl) * 16 + 4 * g;
+            t1[k] = ld4(ring + r1);
+            t2[k] = ld4(ring + r2[k]);
+        }
+    };
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        BlockCtx c;
+        c.pb = sPE + E_BLK + k * GB_SIZE;
+        c.gA = nullptr;
+        c.ib = sI + I_ENC_BLK - ENC_I_SKIP + k * 16;
+        c.sW = sWe; c.sHk = nullptr; c.sS = sSe; c.sG = sG; c.sEHk = sEHe + k * 16;
+        c.sHtop = nullptr; c.sHnext = nullptr;
+        c.sE = smem + LD::E;
+        c.sY = sG + RW * 16;
+        c.nfr = nfr; c.tabs = 0;
+        c.sTB = sTB;
+        c.ms_roff = (int)(smem + LD::HE - sWe) + row * (2 * 35 * 16);
+        c.ms_tb = tbl;
+        c.g_hist = stl + ST_ENC_H + ((k * 2 + (tbl & 1)) * 33 + ffl) * 16 + 4 * g;
+        if (k < 2) hist_fetch(ST_ENC_H + (k + 1) * 2 * 33 * 16, hv);
+        else fetch_rows(stl + ST_G1_H);
+        // the next block's history image is written once this block's taps are read (behind its third barrier); every
+        // history load has then been consumed before any wave stores a new row in the next block's point_conv1 phase
+        gtconv_block<false, 1, true, false, 16, 16, true, 35>(
+            x, tt, c, L, [] {}, [&] { if (k < 2) hist_store(smem + LD::HE, std::false_type{}, hv); });
+        if (k < 2) {
+            const int* ix = sI + I_ENST - ENC_I_SKIP + (k + 1) * 16 + 4 * g;
+            const f32x4 y = permute_via_lds(sSe + tt.pp(0) * PERM_RS, ix, g, x[0]);
+            if (k == 0) en2p = y; else en3p = y;
+        }
+    }
+    // ------------------------------------------------------------------------------------------------- GTCN x 2
+    // per position, nothing shared between lanes (k_gtcn_ms); the decoder's first history image is requested now
+    hist_fetch(ST_DEC_H, hv);
+    {
+        const f32x4 x0 = x[0];
+        f32x4 xx = x0;
+#pragma unroll
+        for (int stack = 0; stack < 2; ++stack) {
+            float* ring = stl + (stack == 0 ? ST_G1_H : ST_G2_H);
+            const float* pk = sPG + stack * GTCN_SIZE;
+            f32x4 a1[4], a2[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { a1[k] = t1[k]; a2[k] = t2[k]; }
+            const int q2[4] = {r2[0], r2[1], r2[2], r2[3]};
+            if (stack == 0) fetch_rows(stl + ST_G2_H);
+            tcn_block_ms<1>(xx, pk + 0 * TCN_SIZE, a1[0], a2[0], ring + q2[0], lane_live, n, g);
+            tcn_block_ms<2>(xx, pk + 1 * TCN_SIZE, a1[1], a2[1], ring + q2[1], lane_live, n, g);
+            tcn_block_ms<4>(xx, pk + 2 * TCN_SIZE, a1[2], a2[2], ring + q2[2], lane_live, n, g);
+            tcn_block_ms<8>(xx, pk + 3 * TCN_SIZE, a1[3], a2[3], ring + q2[3], lane_live, n, g);
+        }
+        x[0] = xx + x0;                                            // gtcn2(gtcn1(x)) + en_outs[4] (Decoder.forward :467)
+    }
+    // ------------------------------------------------------------------------------------------------- decoder
+    // (k_decoder<false, 1, true, false>: same expressions; skips from registers, en0 from LDS, the spectrogram from spn)
+    constexpr int RS = LD::RSD;
+    float* sHd = smem + LD::HD;
+    float* sW = smem + LD::W;
+    float* sS = smem + LD::SD;
+    float* sZ = smem + LD::W;
+    float* sM = smem + LD::M;
+    constexpr int ZS = DEC_ZS;
+    // region X is free: every wave that left the encoder's last block is behind that block's closing barrier, i.e. behind
+    // all reads of the encoder images.  The first decoder history image is written BEFORE the barrier below, so that
+    // every history load has been consumed when the first new row goes out (block 0's point_conv1 phase).
+    hist_zero_pads(sHd, RS);
+    if constexpr (SPLIT) hist_store(sHd, std::true_type{}, hv);
+    else hist_store(sHd, std::false_type{}, hv);
+    zero_row_pads<RW, RS>(sW, tid);
+    if (tid < 4) sM[2 * RW * F0 + tid] = 0.f;
+    wg_barrier();
+    const int npos = nfr * 33;
+    f32x4 s0e, s0o;
+    auto run_block = [&](int j, const f32x4 skv, auto&& hook, auto&& hook3) {
+        BlockCtx c;
+        c.pb = sPD + j * GB_SIZE;
+        c.gA = sPD + DL_DN;
+        c.ib = sI + I_DEC_BLK - ENC_I_SKIP + j * 16;
+        c.sW = sW; c.sHk = nullptr; c.sS = sS; c.sG = sG; c.sEHk = sEHd + j * 16;
+        c.sHtop = nullptr; c.sHnext = nullptr;
+        c.sE = smem + LD::E;
+        c.sY = sG + RW * 16;
+        c.nfr = nfr; c.tabs = 0;
+        c.sTB = sTB;
+        c.ms_roff = (int)(sHd - sW) + row * (2 * 35 * RS);
+        c.ms_tb = tbl;
+        c.g_hist = stl + ST_DEC_H + ((j * 2 + (tbl & 1)) * 33 + ffl) * 16 + 4 * g;
+        gtconv_block<true, 1, true, false, RS, 16, true, 35, 0>(
+            x, tt, c, L, [&] { if (j < 2) dense_fetch(j + 1); hook(); }, hook3);
+        x[0] = x[0] + skv;
+    };
+    // (the history loads of block j + 1 are issued in block j's hook, behind its dense phase, and land in the image
+    // behind its third barrier; the closing barrier of every dense block waits for vmcnt(0): DMA and history alike)
+    run_block(0, en3p, [&] { hist_fetch(ST_DEC_H + 1 * 2 * 33 * 16, hv); },
+              [&] { if constexpr (SPLIT) hist_store(sHd, std::true_type{}, hv); else hist_store(sHd, std::false_type{}, hv); });
+    run_block(1, en2p, [&] { hist_fetch(ST_DEC_H + 2 * 2 * 33 * 16, hv); },
+              [&] { if constexpr (SPLIT) hist_store(sHd, std::true_type{}, hv); else hist_store(sHd, std::false_type{}, hv); });
+    run_block(2, en1p, [&] {
+        // en_outs[0] for the even / odd output bins of the lane's position, from LDS
+        const int o0 = (tt.pp(0) < npos ? tt.tl[0] * F1 + 2 * tt.ff[0] : 0) * 16 + 4 * g;
+        s0e = ld4(sEN0 + o0);
+        s0o = ld4(sEN0 + o0 + (tt.ff[0] < 32 ? 16 : 0));
+    }, [] {});
+    // ---- de_convs.3 (gather form) + de_convs.4 (scatter form)
+    st4(sW + o35<RS, 0>(tt, 0, g), x[0]);
+    wg_barrier();
+    f32x4 ze, zo;
+    {
+        const f32x4 Bv = ld4(sPD + dl(D_DE3_B) + 4 * g);
+        const float a = sPD[dl(D_DE3_S)] - 1.0f;
+        const float* Ae = sPD + dl(D_DE3_AE) + arow(n, g);
+        const float* Ao = sPD + dl(D_DE3_AO) + arow(n, g);
+        f32x4 ae = Bv, ao = Bv;
+        {
+            const f32x4 A0 = ld4(Ae), A1 = ld4(Ao);
+            const f32x4 xp = ld4(sW + o35<RS, 0>(tt, 0, g) + RS);
+            ae = mm1<false>(A0, xp, ae);
+            ao = mm1<false>(A1, xp, ao);
+        }
+        {
+            const f32x4 A0 = ld4(Ae + 256), A1 = ld4(Ao + 256);
+            ae = mm1<false>(A0, x[0], ae);
+            ao = mm1<false>(A1, x[0], ao);
+        }
+        {
+            const f32x4 A0 = ld4(Ae + 512);
+            const f32x4 xm = ld4(sW + o35<RS, 0>(tt, 0, g) - RS);
+            ae = mm1<false>(A0, xm, ae);
+        }
+        const f32x4 A4 = ld4(sPD + dl(D_DE4_A) + arow(n, g));
+        f32x4 e2 = prelu4(ae, a), o2 = prelu4(ao, a);
+        e2 = e2 + s0e;
+        o2 = o2 + s0o;
+        ze = mm1<false>(A4, e2, splat(0.f));
+        zo = mm1<false>(A4, o2, splat(0.f));
+    }
+    wg_barrier();                                                  // region W becomes Z
+    if (g < 3) {
+        st4(sZ + (tt.tl[0] * DEC_Z_ROW + 1 + 2 * tt.ff[0]) * ZS + 4 * g, ze);
+        if (tt.ff[0] < 32) st4(sZ + (tt.tl[0] * DEC_Z_ROW + 2 + 2 * tt.ff[0]) * ZS + 4 * g, zo);
+    }
+    if (tid < RW * 2 * 4 && (tid & 3) < 3)
+        st4(sZ + ((tid >> 3) * DEC_Z_ROW + ((tid >> 2) & 1) * (DEC_Z_ROW - 1)) * ZS + 4 * (tid & 3), splat(0.f));
+    wg_barrier();
+    {   // de_convs.4 gather + BN + Tanh
+        static_assert(4 * F0 <= NTHR && RW % 2 == 0, "two threads per (o, f'')");
+        if (tid < 4 * F0) {
+            const int h = tid >= 2 * F0 ? 1 : 0, c = tid - h * 2 * F0, o = c >= F0 ? 1 : 0, fq = c - o * F0;
+            const int par = fq & 1, m = fq >> 1;
+            const float* zr = sZ + (h * DEC_Z_ROW + 1 + m) * ZS;
+            const float* r1 = zr + ZS + o * 5 + par;
+            const float* r2p = zr + o * 5 + 2 + par;
+            const float* r3 = zr - ZS + (par ? 10 : o * 5 + 4);
+            const float bias = sPD[dl(D_DE4_B) + o];
+            float* mo = sM + (o * RW + h) * F0 + fq;
+#pragma unroll
+            for (int j = 0; j < RW / 2; ++j) {
+                constexpr int ZF = 2 * DEC_Z_ROW * ZS;
+                const float sum = bias + r1[j * ZF] + r2p[j * ZF] + r3[j * ZF];
+                mo[j * 2 * F0] = fast_tanh(sum);
+            }
+        }
+    }
+    wg_barrier();
+    {   // ERB.bs + complex ratio mask + output layout
+        int tq, f;
+        spec_item_first(tid, t_fast, tq, f);
+        float* obase = out + (long)b * NS * osb;
+        const int osf32 = (int)osf, ost32 = (int)osb;
+        constexpr int GRP = 3;
+        static_assert(SPEC_ITEMS % GRP == 0, "mask items come in groups of three");
+#pragma unroll
+        for (int q0 = 0; q0 < SPEC_ITEMS; q0 += GRP) {
+            bool ok[GRP];
+            int fo[GRP];
+            const float* m0[GRP];
+            f32x4 tb[GRP];
+#pragma unroll
+            for (int j = 0; j < GRP; ++j) {
+                ok[j] = tq < nfr && f < NBINS;
+                const int fc = ok[j] ? f : 0, tc = ok[j] ? tq : 0;
+                tb[j] = ld4(sBS + fc * 4);
+                m0[j] = sM + tc * F0;
+                fo[j] = f * osf32 + tq * ost32;
+                spec_item_next(t_fast, tq, f);
+            }
+            float a0[GRP], a1[GRP], b0[GRP], b1[GRP];
+#pragma unroll
+            for (int j = 0; j < GRP; ++j) {
+                const float* mp = m0[j] + __float_as_int(tb[j][0]);
+                a0[j] = mp[0]; a1[j] = mp[1]; b0[j] = mp[RW * F0]; b1[j] = mp[RW * F0 + 1];
+            }
+#pragma unroll
+            for (int j = 0; j < GRP; ++j) {
+                const bool two = tb[j][2] != 0.f;
+                const float mr = tb[j][1] * a0[j] + (two ? tb[j][2] * a1[j] : 0.f);
+                const float mi = tb[j][1] * b0[j] + (two ? tb[j][2] * b1[j] : 0.f);
+                const float re = spn[q0 + j].x, im = spn[q0 + j].y;
+                const float yr = re * mr - im * mi, yi = im * mr + re * mi;
+                if (ok[j]) *reinterpret_cast<float2*>(obase + fo[j]) = make_float2(yr, yi);
+            }
+        }
+    }
+    // ------------------------------------------------------------------------------------------------- epilogue
+    // energy rings and frame counters (the h rows and the TCN rows went out where they were produced)
+    if (tid < nlive * 48) {
+        const int sidx = tid / 48, e = tid - sidx * 48;
+        stb[(long)sidx * ST_FLOATS + ST_ENC_E + e] = sEHe[tid];
+        stb[(long)sidx * ST_FLOATS + ST_DEC_E + e] = sEHd[tid];
+    }
+    if (tid < nlive) reinterpret_cast<int*>(stb + (long)tid * ST_FLOATS)[0] = (sTB[tid] + 1) & 0xFFFF;
+}
+
 // ==================================================================== state conversion
 // library ring state <-> the reference's caches (gtcrn_micro_stream.py:618-623, slices :416-428
 // and :490-500).  dir 0: import (reference -> rings), 1: export.  One workgroup per stream.
@@ -2706,6 +3218,9 @@ int configure_kernels() {
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_decoder<false, 1, true, false>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, DEC_MS_LDS_FLOATS * 4);
     if (e != hipSuccess) return (int)e;
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_stream_ms), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            SM_LDS_FLOATS * 4);
+    if (e != hipSuccess) return (int)e;
     const void* gt[] = {reinterpret_cast<const void*>(k_gtcn<TPW, false>), reinterpret_cast<const void*>(k_gtcn<1, false>),
                         reinterpret_cast<const void*>(k_gtcn<1, true>), reinterpret_cast<const void*>(k_gtcn<TPW, true>),
                         reinterpret_cast<const void*>(k_gtcn<2, true>), reinterpret_cast<const void*>(k_gtcn<2, false>)};
@@ -2858,6 +3373,20 @@ int launch_decoder(const float* xg, const float* en0, const float* en1, const fl
 #undef GT_DEC
     GT_LAUNCH_CHECK();
     return 0;
+}
+
+// single-frame step for B streams, ONE launch (see k_stream_ms); strides in floats of (B,257,1,2)-shaped tensors
+int launch_stream_ms(const float* spec, long sb, long sf, float* out, long osb, long osf, int B, const float* PF,
+                     const int* PI, float* state, hipStream_t s) {
+    const int grid = (B + MS_STREAMS - 1) / MS_STREAMS;
+    hipLaunchKernelGGL(k_stream_ms, dim3(grid), dim3(NTHR), SM_LDS_FLOATS * 4, s, spec, sb, sf, out, osb, osf, B, PF, PI,
+                       state);
+    GT_LAUNCH_CHECK();
+    return 0;
+}
+bool stream_ms_usable(long sb, long osb) {
+    const long a = sb < 0 ? -sb : sb, o = osb < 0 ? -osb : osb;
+    return (MS_ROWS - 1) * a < (1L << 31) && (MS_ROWS - 1) * o < (1L << 31);
 }
 
 int launch_state_convert(float* state, int N, float* conv, float* tra, float* const* tcn8, const int* PI, int dir,

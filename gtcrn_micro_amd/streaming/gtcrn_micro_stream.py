@@ -4,15 +4,58 @@
 (gtcrn_micro_stream.py:541-574): the caller owns the three caches in the reference
 shapes -- conv_cache (2,B,16,6,33), tra_cache (2,3,B,8,2), tcn_cache 2 x 4 tensors
 (B,16,2d,33) (:618-623) -- and gets them back updated (in place, like the reference).
-Internally the HIP kernels keep per-stream ring state; ``forward`` imports the
-caches, steps, and exports them again.  ``init_state`` / ``step`` is the native
-form that leaves the state on the device between frames (no conversion per frame).
+
+Internally the HIP kernels keep per-stream ring state on the device.  The reference loop
+(:626-635) passes the returned caches straight back in, frame after frame, and never looks
+inside them; converting caches -> rings -> caches on every frame would cost two extra
+kernels per 16 ms frame for nothing.  So:
+
+* **import is skipped** when the caches received are the ones returned by the previous call
+  and nobody wrote to them since (object identity + the tensors' version counters);
+* **export is lazy**: the returned caches are thin ``torch.Tensor`` subclasses over the
+  caller's own storage whose contents are brought up to date the moment anything READS
+  or WRITES them (any torch operation on them: indexing, ``.cpu()``, ``torch.equal``,
+  in-place edits, printing ...), or explicitly with ``sync_caches()``.  A caller that
+  keeps using its ORIGINAL tensor objects instead of the returned ones (legal: the
+  reference mutates them in place) cannot be intercepted, so for that call pattern the
+  export runs eagerly every frame (import is still skipped while they stay untouched).
+
+``init_state`` / ``step`` is the native form that leaves the state on the device.
 """
 import torch
-import torch.nn as nn
 
 from .. import _lib
 from ..models.gtcrn_micro import GTCRNMicro
+
+# metadata a caller (or this module) may ask of a lazy cache without needing its contents
+_META = {"shape", "dtype", "device", "layout", "requires_grad", "is_cuda", "ndim", "_version", "grad", "grad_fn",
+         "is_leaf", "names", "is_sparse", "is_quantized", "is_meta", "data_ptr", "size", "dim", "stride", "numel",
+         "is_contiguous", "storage_offset", "element_size", "nelement", "ndimension", "get_device", "__len__"}
+
+
+class _LazyCache(torch.Tensor):
+    """A cache tensor handed back by ``StreamGTCRNMicro.forward``: same storage as the caller's tensor, brought up to
+    date from the device ring state before the first operation that touches its contents."""
+
+    @staticmethod
+    def wrap(t, owner):
+        w = torch.Tensor._make_subclass(_LazyCache, t, False)
+        w._owner = owner
+        return w
+
+    @classmethod
+    def __torch_function__(cls, func, types, args=(), kwargs=None):
+        kwargs = kwargs or {}
+        name = getattr(func, "__name__", "")
+        if name == "__get__":                                      # property getter: func.__self__ is the descriptor
+            name = getattr(getattr(func, "__self__", None), "__name__", "")
+        if name not in _META:
+            for a in args:
+                owner = getattr(a, "_owner", None) if isinstance(a, _LazyCache) else None
+                if owner is not None:
+                    owner.sync_caches()
+        with torch._C.DisableTorchFunctionSubclass():
+            return func(*args, **kwargs)
 
 
 class StreamGTCRNMicro(GTCRNMicro):
@@ -21,6 +64,8 @@ class StreamGTCRNMicro(GTCRNMicro):
     def __init__(self, n_fft=512, hop_len=256, win_len=512):
         super().__init__(n_fft, hop_len, win_len)
         self._scratch = {}
+        self._bound = None          # the caches handed out by the previous call (see forward)
+        self.forward_stats = {"calls": 0, "imports": 0, "exports": 0}
 
     @staticmethod
     def init_caches(batch, device):
@@ -30,30 +75,89 @@ class StreamGTCRNMicro(GTCRNMicro):
         tcn_cache = [[torch.zeros(batch, 16, 2 * d, 33, device=device) for d in (1, 2, 4, 8)] for _ in range(2)]
         return conv_cache, tra_cache, tcn_cache
 
+    # ---- the cache <-> ring-state binding ----------------------------------------------------------
+    def _match(self, flat):
+        """0: unrelated caches (import needed); 1: exactly the lazy caches handed out last call, untouched;
+        2: the caller's own original tensors of last call, untouched."""
+        bd = self._bound
+        if bd is None:
+            return 0
+        with torch._C.DisableTorchFunctionSubclass():
+            if all(a is b for a, b in zip(flat, bd["lazy"])):
+                kind = 1
+            elif all(a is b for a, b in zip(flat, bd["orig"])):
+                kind = 2
+            else:
+                return 0
+            # in-place writes by the caller (through either object: they share the version counter) invalidate it
+            if any(t._version != v for t, v in zip(bd["orig"], bd["versions"])):
+                return 0
+        return kind
+
+    def sync_caches(self):
+        """Brings the caches handed out by the last ``forward`` up to date with the device ring state (no-op if they
+        already are).  Called automatically when a lazy cache is read or written."""
+        bd = self._bound
+        if bd is None or not bd["pending"]:
+            return
+        bd["pending"] = False
+        with torch._C.DisableTorchFunctionSubclass():
+            conv, tra = bd["orig"][0], bd["orig"][1]
+            tcn = [bd["orig"][2:6], bd["orig"][6:10]]
+            bd["eng"].stream_export(bd["state"], conv, tra, tcn)
+        self.forward_stats["exports"] += 1
+
     def forward(self, spec, conv_cache, tra_cache, tcn_cache):
         if self.training:
             raise NotImplementedError("streaming inference is eval-mode only; call .eval()")
         if not spec.is_cuda:
             raise _lib.GtcrnError("StreamGTCRNMicro.forward needs CUDA (ROCm) tensors: there is no CPU path")
         B = spec.shape[0]
-        if tuple(conv_cache.shape) != (2, B, 16, 6, 33):
-            raise AssertionError(f"conv_cache must be (2,{B},16,6,33), got {tuple(conv_cache.shape)}")
-        if tuple(tra_cache.shape) != (2, 3, B, 8, 2):
-            raise AssertionError(f"tra_cache must be (2,3,{B},8,2), got {tuple(tra_cache.shape)}")
-        for g in range(2):
-            for k, d in enumerate((1, 2, 4, 8)):
-                if tuple(tcn_cache[g][k].shape) != (B, 16, 2 * d, 33):
-                    raise AssertionError(f"tcn_cache[{g}][{k}] must be ({B},16,{2 * d},33)")
+        with torch._C.DisableTorchFunctionSubclass():
+            if tuple(conv_cache.shape) != (2, B, 16, 6, 33):
+                raise AssertionError(f"conv_cache must be (2,{B},16,6,33), got {tuple(conv_cache.shape)}")
+            if tuple(tra_cache.shape) != (2, 3, B, 8, 2):
+                raise AssertionError(f"tra_cache must be (2,3,{B},8,2), got {tuple(tra_cache.shape)}")
+            for g in range(2):
+                for k, d in enumerate((1, 2, 4, 8)):
+                    if tuple(tcn_cache[g][k].shape) != (B, 16, 2 * d, 33):
+                        raise AssertionError(f"tcn_cache[{g}][{k}] must be ({B},16,{2 * d},33)")
         eng = self.engine(spec.device)
-        key = (spec.device.index, B)
-        state = self._scratch.get(key)
-        if state is None:
-            state = eng.new_state(B)
-            self._scratch[key] = state
-        eng.stream_import(state, conv_cache, tra_cache, tcn_cache)
-        out = eng.stream_step(state, spec)
-        eng.stream_export(state, conv_cache, tra_cache, tcn_cache)
-        return out, conv_cache, tra_cache, tcn_cache
+        flat = [conv_cache, tra_cache] + [tcn_cache[g][k] for g in range(2) for k in range(4)]
+        self.forward_stats["calls"] += 1
+        kind = self._match(flat)
+        if kind and (self._bound["eng"] is not eng or self._bound["B"] != B):
+            kind = 0
+        if kind == 0:
+            # unknown or modified caches: whatever an earlier binding still owes its caller is written out first, then
+            # the ring state is rebuilt from the caches received
+            self.sync_caches()
+            key = (spec.device.index, B)
+            state = self._scratch.get(key)
+            if state is None:
+                state = eng.new_state(B)
+                self._scratch[key] = state
+            with torch._C.DisableTorchFunctionSubclass():
+                orig = [t.as_subclass(torch.Tensor) if isinstance(t, _LazyCache) else t for t in flat]
+                eng.stream_import(state, orig[0], orig[1], [orig[2:6], orig[6:10]])
+            self.forward_stats["imports"] += 1
+            lazy = [_LazyCache.wrap(t, self) for t in orig]
+            self._bound = {"eng": eng, "B": B, "state": state, "orig": orig, "lazy": lazy, "pending": False,
+                           "versions": None}
+        bd = self._bound
+        out = eng.stream_step(bd["state"], spec)
+        bd["pending"] = True
+        with torch._C.DisableTorchFunctionSubclass():
+            bd["versions"] = [t._version for t in bd["orig"]]
+        if kind != 1:
+            # the caller holds plain tensors whose reads cannot be intercepted (its own originals, or a fresh binding
+            # whose caller may go either way): keep them current.  Only a caller that passes the RETURNED caches back
+            # gets the deferred export.
+            self.sync_caches()
+        if kind == 2:
+            return out, conv_cache, tra_cache, tcn_cache
+        lz = bd["lazy"]
+        return out, lz[0], lz[1], [lz[2:6], lz[6:10]]
 
     # ---- native streaming: state stays in the library's ring layout on the device ---------------
     def init_state(self, nstreams, device="cuda"):

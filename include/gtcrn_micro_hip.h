@@ -183,11 +183,14 @@ long gtcrn_debug_stamps(gtcrn_model *m, int kernel, unsigned long long *h_dst, l
 int gtcrn_selftest_mfma(int device);
 /* HIP-event timing of every kernel launch (events recorded on the call's stream, no
  * synchronisation inside the timed region).  gtcrn_timing_enable(m,1) clears the record;
- * gtcrn_timing_read returns, for kernel idx (0 k_stft, 1 k_encoder, 2 k_gtcn1, 3 k_gtcn2,
- * 4 k_decoder, 5 k_istft), the average device time in ms over the launches recorded since and
- * their count.  on = 2 + idx records events around kernel idx ONLY: every event pair costs a few microseconds of
- * dispatch gap, so the timed region of bench.py keeps just the dominant kernel's.  Used for the roofline line. */
+ * gtcrn_timing_read returns, for kernel idx in [0, gtcrn_timing_kernels()) -- every timed launch records which
+ * kernel it was, so offline and streaming calls keep their own rows (k_front, k_encoder_gt, k_gtcn1, k_gtcn2,
+ * k_decoder, k_istft offline; k_stream_ms for single-frame streaming steps; ...) -- its name, the average device time
+ * in ms over the launches recorded since and their count.  idx = -1 - k only returns the name of kernel k (m may be
+ * NULL).  on = 2 + idx records events around kernel idx ONLY: every event pair costs a few microseconds of dispatch
+ * gap, so the timed region of bench.py keeps just the dominant kernel's.  Used for the roofline line. */
 int gtcrn_timing_enable(gtcrn_model *m, int on);
+int gtcrn_timing_kernels(void);
 int gtcrn_timing_read(gtcrn_model *m, int idx, char *name, int name_cap, float *ms, int *launches);
 
 /* ---- train step (model forward/backward) ---------------------------------

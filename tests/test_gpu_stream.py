@@ -240,3 +240,189 @@ def test_config3_shape_1024_streams_single_frame_calls(dev):
     for g in range(2):
         for k in range(4):
             assert rel_err(tcn[g][k][1023].cpu().numpy(), otcn[g][k]) < TOL, (g, k)
+
+
+def _export(eng, st, N):
+    conv = torch.zeros(2, N, 16, 6, 33, device="cuda")
+    tra = torch.zeros(2, 3, N, 8, 2, device="cuda")
+    tcn = [[torch.zeros(N, 16, 2 * d, 33, device="cuda") for d in (1, 2, 4, 8)] for _ in range(2)]
+    eng.stream_export(st, conv, tra, tcn)
+    return [conv, tra] + [t for grp in tcn for t in grp]
+
+
+def test_single_launch_step_equals_the_three_launch_form(dev):
+    """A single-frame step is ONE kernel (k_stream_ms: encoder -> both GTCN stacks -> decoder, nothing through HBM, the
+    history of a block fetched one block ahead, only the new row written back).  With the stage taps enabled the
+    library runs the three-launch form instead (its hand-off tensors are what the taps read): both forms must give
+    the same output AND leave the same stream state, bit for bit, also when the last workgroup is partly filled."""
+    from gtcrn_micro_amd import Engine
+    p = load_params("rand")
+    one, three = Engine(p, 0), Engine(p, 0)
+    three.debug_enable(True)
+    rng = np.random.default_rng(21)
+    for N in (1, 7, 64):
+        T = 19
+        spec = cu((rng.standard_normal((N, 257, T, 2)) * 0.3).astype(np.float32))
+        sa, sb_ = one.new_state(N), three.new_state(N)
+        for t in range(T):
+            ya = one.stream_step(sa, spec[:, :, t:t + 1])
+            yb = three.stream_step(sb_, spec[:, :, t:t + 1])
+            assert torch.equal(ya, yb), (N, t)
+        assert torch.equal(sa, sb_), N                             # the whole ring state, counters included
+        assert "k_stream_ms" not in three.timing_read()
+    one.timing_enable(True)
+    one.stream_step(sa, spec[:, :, :1])
+    torch.cuda.synchronize()
+    assert list(one.timing_read()) == ["k_stream_ms"]              # one launch per frame
+    one.timing_enable(False)
+    with pytest.raises(Exception):
+        one.tap("en4", 0, 1)                                       # no hand-off tensors exist after a fused step
+
+
+def test_stream_step_is_graph_capturable(dev):
+    """gtcrn_stream_step issues no allocation and no synchronisation once the workspace is reserved: the per-frame call
+    can be captured into a HIP graph and replayed frame after frame (new input copied into the captured buffer)."""
+    from gtcrn_micro_amd import Engine
+    eng = Engine(load_params("dns3"), 0)
+    N, T = 16, 12
+    gen = torch.Generator(device="cuda").manual_seed(7)
+    spec = torch.randn(N, 257, T, 2, device="cuda", generator=gen) * 0.3
+    eng.reserve(N, 1)
+    ref_state = eng.new_state(N)
+    ref = [eng.stream_step(ref_state, spec[:, :, t:t + 1]).clone() for t in range(T)]
+    x = torch.empty(N, 257, 1, 2, device="cuda")
+    y = torch.empty(N, 257, 1, 2, device="cuda")
+    st = eng.new_state(N)
+    warm = eng.new_state(N)
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.stream(s):
+        x.copy_(spec[:, :, :1])
+        eng.stream_step(warm, x, out=y)                            # warm-up on the capture stream (another state)
+        torch.cuda.synchronize()
+        with torch.cuda.graph(g, stream=s):
+            eng.stream_step(st, x, out=y)
+    st.copy_(eng.new_state(N))                                     # the capture itself did not run the step
+    for t in range(T):
+        x.copy_(spec[:, :, t:t + 1])
+        g.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(y, ref[t]), t
+    assert torch.equal(st, ref_state)
+
+
+def test_frame_counter_wraps_without_a_trace(dev):
+    """The ring state carries a 16-bit frame counter (the reference's caches have none); only its value mod 16 (ring
+    rows) and its parity matter.  A stream whose counter is poked to 65 530 and stepped across the wrap must behave
+    exactly like the same stream at a counter congruent mod 16 -- outputs, exported caches and the counter after
+    the wrap -- in the single-frame form and in a multi-frame call."""
+    from gtcrn_micro_amd import Engine
+    eng = Engine(load_params("rand"), 0)
+    rng = np.random.default_rng(33)
+    N, T0, T1 = 5, 10, 12                                          # 65530 mod 16 == 10
+    spec = cu((rng.standard_normal((N, 257, T0 + T1, 2)) * 0.3).astype(np.float32))
+    st = eng.new_state(N)
+    for t in range(T0):
+        eng.stream_step(st, spec[:, :, t:t + 1])
+    assert st.view(torch.int32)[:, 0].tolist() == [T0] * N
+    for chunks in ([1] * T1, [5, 7]):
+        a, b_ = st.clone(), st.clone()
+        b_.view(torch.int32)[:, 0] = 65530
+        t0 = T0
+        for c in chunks:
+            ya = eng.stream_step(a, spec[:, :, t0:t0 + c])
+            yb = eng.stream_step(b_, spec[:, :, t0:t0 + c])
+            assert torch.equal(ya, yb), (chunks, t0)
+            t0 += c
+        assert a.view(torch.int32)[:, 0].tolist() == [T0 + T1] * N
+        assert b_.view(torch.int32)[:, 0].tolist() == [(65530 + T1) & 0xFFFF] * N
+        for ca, cb in zip(_export(eng, a, N), _export(eng, b_, N)):
+            assert torch.equal(ca, cb), chunks
+        b_.view(torch.int32)[:, 0] = a.view(torch.int32)[:, 0]
+        assert torch.equal(a, b_)                                   # nothing else in the state differs
+
+
+def _stream_module(tag="rand"):
+    import json, os
+    from conftest import GOLDEN
+    from gtcrn_micro_amd.models.gtcrn_micro import GTCRNMicro
+    from gtcrn_micro_amd.streaming.gtcrn_micro_stream import StreamGTCRNMicro
+    from gtcrn_micro_amd.streaming.conversion.convert import convert_to_stream
+    p = load_params(tag)
+    man = json.load(open(os.path.join(GOLDEN, "params_manifest.json")))
+    model = GTCRNMicro().eval()
+    model.load_state_dict({n: torch.from_numpy(p[o:o + int(np.prod(s))].reshape(s).copy())
+                           for n, s, o in man["tensors"]}, strict=False)
+    sm = StreamGTCRNMicro().eval()
+    convert_to_stream(sm, model)
+    return sm.to("cuda")
+
+
+def test_mirror_forward_fast_path_matches_reference_caches(dev):
+    """The reference loop (gtcrn_micro_stream.py:626-635) passes the returned caches straight back in.  The mirror then
+    skips the cache -> ring import (identity + version counters) and exports lazily: the caches read at frames 0, 1
+    and 16 equal the reference's fixtures, with ONE import and three exports for 17 calls."""
+    sm = _stream_module("rand")
+    g = golden("stream_rand_T17.npz")
+    spec = cu(g["spec"])
+    conv_cache, tra_cache, tcn_cache = sm.init_caches(1, "cuda")
+    ys = []
+    with torch.no_grad():
+        for i in range(17):
+            y, conv_cache, tra_cache, tcn_cache = sm(spec[:, :, i:i + 1], conv_cache, tra_cache, tcn_cache)
+            ys.append(y)
+            if i in (0, 1, 16):                                    # reading a returned cache brings it up to date
+                assert rel_err(conv_cache.cpu().numpy(), g[f"conv_cache_f{i}"]) < TOL, i
+                assert rel_err(tra_cache.cpu().numpy(), g[f"tra_cache_f{i}"]) < TOL, i
+                for gi in range(2):
+                    for k in range(4):
+                        assert rel_err(tcn_cache[gi][k].cpu().numpy(), g[f"tcn_cache_f{i}_g{gi}_b{k}"]) < TOL, (i, gi, k)
+    assert rel_err(torch.cat(ys, 2).cpu().numpy(), g["spec_enh_stream"]) < TOL
+    assert sm.forward_stats == {"calls": 17, "imports": 1, "exports": 3}, sm.forward_stats
+
+
+def test_mirror_forward_sees_caches_the_caller_modified(dev):
+    """A caller that writes into a cache between two calls (here: resets ONE stream of three by zeroing its slices, as a
+    server does when a call ends and a new one takes the slot) must get the reference's behaviour: that stream
+    restarts from silence history, the others continue -- bit for bit what the native step gives for the same story.
+    Also: a caller that keeps passing (and reading) its ORIGINAL tensors finds them current after every call."""
+    from gtcrn_micro_amd import Engine
+    sm = _stream_module("dns3")
+    rng = np.random.default_rng(8)
+    N, T, cut = 3, 20, 8
+    spec = cu((rng.standard_normal((N, 257, T, 2)) * 0.3).astype(np.float32))
+    # expected: native steps; stream 1's state is zeroed before frame `cut`
+    eng = Engine(load_params("dns3"), 0)
+    st = eng.new_state(N)
+    want = []
+    for t in range(T):
+        if t == cut:
+            st[1].zero_()
+        want.append(eng.stream_step(st, spec[:, :, t:t + 1]))
+    want = torch.cat(want, 2)
+    conv_cache, tra_cache, tcn_cache = sm.init_caches(N, "cuda")
+    got = []
+    with torch.no_grad():
+        for t in range(T):
+            if t == cut:
+                conv_cache[:, 1] = 0.0                             # in-place edits of the RETURNED caches
+                tra_cache[:, :, 1] = 0.0
+                for grp in tcn_cache:
+                    for c in grp:
+                        c[1] = 0.0
+            y, conv_cache, tra_cache, tcn_cache = sm(spec[:, :, t:t + 1], conv_cache, tra_cache, tcn_cache)
+            got.append(y)
+    assert torch.equal(torch.cat(got, 2), want)
+    assert sm.forward_stats["imports"] == 2 and sm.forward_stats["calls"] == T          # the first call and the edit
+    # the caller's own tensors, passed and read every frame (the reference mutates them in place)
+    sm2 = _stream_module("dns3")
+    c0, t0, n0 = sm2.init_caches(N, "cuda")
+    ref = eng.new_state(N)
+    with torch.no_grad():
+        for t in range(6):
+            y, _, _, _ = sm2(spec[:, :, t:t + 1], c0, t0, n0)      # returned caches ignored on purpose
+            eng.stream_step(ref, spec[:, :, t:t + 1])
+            for a, b_ in zip([c0, t0] + [x for grp in n0 for x in grp], _export(eng, ref, N)):
+                assert type(a) is torch.Tensor and torch.equal(a, b_), t
+    assert sm2.forward_stats == {"calls": 6, "imports": 1, "exports": 6}
