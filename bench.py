@@ -194,8 +194,8 @@ def run_leg(name, fn, rank, world, get_line, timeout_s=300.0):
     res = allr[0]["res"]
     if res is None:
         return None
-    tl = [x["el"] for x in allr]
-    k = tl[0] / max(tl)                                        # rank 0 priced its own time; the slowest rank sets the rate
+    tl = [x["el"] or 0.0 for x in allr]
+    k = tl[0] / max(tl) if max(tl) > 0 else 1.0                # rank 0 priced its own time; the slowest rank sets the rate
     for key in res.pop("_rate_keys", []):
         res[key] = round(res[key] * k, 1)
     for key in res.pop("_time_keys", []):
@@ -285,6 +285,7 @@ def stream_leg(eng, world, sync_all, max_over_ranks, nstreams=1024, frames=251):
     sync_all()
     el = max_over_ranks(time.perf_counter() - t0, "cuda")
     fsteps = world * N * T / el
+    extra = stream_extras(eng, spec, N)
     res = {
         "workload": f"{N} concurrent streams per GPU x {T} single-frame calls (hop 256), state resident in HBM",
         "streams_per_gpu": N, "calls": T,
@@ -296,11 +297,95 @@ def stream_leg(eng, world, sync_all, max_over_ranks, nstreams=1024, frames=251):
         "state_bound_frame_steps_per_s": round(HBM_PEAK_GBS * 1e9 / STREAM_STATE_BYTES_PER_FRAME, 1),
         "frac_of_state_bound": round(fsteps / world / (HBM_PEAK_GBS * 1e9 / STREAM_STATE_BYTES_PER_FRAME), 4),
         "stream_vs_offline_rel_err": err, "dtype": "f32",
+        "launches_per_call": 1,
+        **extra,
         "_rate_keys": ["frame_steps_per_s"], "_time_keys": ["ms_per_call_back_to_back"],
     }
     del spec, out, state, full
     torch.cuda.empty_cache()
     return res
+
+
+def stream_extras(eng, spec, N, frames=200):
+    """Rank-local companions of the stream numbers (no collective): the step replayed from a captured HIP graph, ONE stream (the reference's own loop, gtcrn_micro_stream.py:618-635) and the
+    reference-shaped call `StreamGTCRNMicro.forward` (caller-owned caches handed back every frame) next to the native
+    `step`, for one stream and for N."""
+    import numpy as np
+    import torch
+
+    def b2b(fn, n):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for t in range(n):
+            fn(t)
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / n * 1e3
+
+    def lat(fn, n):
+        v = []
+        for t in range(n):
+            t0 = time.perf_counter()
+            fn(t)
+            torch.cuda.synchronize()
+            v.append(time.perf_counter() - t0)
+        v = np.array(v[5:]) * 1e3
+        return {"mean": round(float(v.mean()), 4), "p50": round(float(np.percentile(v, 50)), 4),
+                "p99": round(float(np.percentile(v, 99)), 4)}
+
+    T = spec.shape[2]
+    out = {}
+    y = torch.empty((N, 1, 257, 2), device="cuda").permute(0, 2, 1, 3)
+    # (b) the step replayed from a HIP graph
+    try:
+        x = torch.empty((N, 1, 257, 2), device="cuda").permute(0, 2, 1, 3)
+        stg = eng.new_state(N)
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.stream(s):
+            x.copy_(spec[:, :, :1])
+            eng.stream_step(stg, x, out=y)
+            torch.cuda.synchronize()
+            with torch.cuda.graph(g, stream=s):
+                eng.stream_step(stg, x, out=y)
+        out["graph_replay_ms_per_call_back_to_back"] = round(b2b(lambda t: g.replay(), frames), 4)
+        del g, stg
+    except Exception as e:
+        out["graph_replay_ms_per_call_back_to_back"] = repr(e)
+    # (c) ONE stream, native step
+    st1 = eng.new_state(1)
+    s1 = spec[:1]
+    y1 = torch.empty((1, 1, 257, 2), device="cuda").permute(0, 2, 1, 3)
+    out["one_stream"] = {"latency_ms": lat(lambda t: eng.stream_step(st1, s1[:, :, t % T:t % T + 1], out=y1), frames),
+                         "ms_per_call_back_to_back": round(b2b(lambda t: eng.stream_step(st1, s1[:, :, t % T:t % T + 1], out=y1), frames), 4)}
+    out["one_stream"]["rtf"] = round(out["one_stream"]["latency_ms"]["mean"] / 16.0, 6)
+    # (d) the reference-shaped call with caller-owned caches
+    try:
+        from gtcrn_micro_amd.streaming.gtcrn_micro_stream import StreamGTCRNMicro
+        from gtcrn_micro_amd.models.gtcrn_micro import load_blob_into
+        sm = StreamGTCRNMicro().eval()
+        load_blob_into(sm, np.fromfile(os.path.join(ROOT, "tests", "golden", "params_dns3.f32"), dtype=np.float32))
+        sm = sm.to("cuda")
+        mirror = {}
+        with torch.no_grad():
+            for nn_, sp in ((1, spec[:1]), (N, spec)):
+                caches = list(sm.init_caches(nn_, "cuda"))
+
+                def call(t, sp=sp, caches=caches):
+                    _, caches[0], caches[1], caches[2] = sm(sp[:, :, t % T:t % T + 1], caches[0], caches[1], caches[2])
+                for t in range(5):
+                    call(t)
+                stn = eng.new_state(nn_)
+                mirror[f"n{nn_}"] = {
+                    "forward_ms_per_call_back_to_back": round(b2b(call, frames), 4),
+                    "native_step_ms_per_call_back_to_back": round(b2b(lambda t, sp=sp, stn=stn: eng.stream_step(stn, sp[:, :, t % T:t % T + 1]), frames), 4)}
+                if nn_ == 1:
+                    mirror["n1"]["forward_latency_ms"] = lat(call, frames)
+            mirror["imports"], mirror["exports"], mirror["calls"] = (sm.forward_stats[k] for k in ("imports", "exports", "calls"))
+        out["reference_shaped_forward"] = mirror
+    except Exception as e:
+        out["reference_shaped_forward"] = {"error": repr(e)}
+    return out
 
 
 def train_prepare(rank, B=512, seconds=4.0, storage="f32"):

@@ -348,6 +348,10 @@ class Engine:
         B, _, T, _ = spec.shape
         if out is None:
             out = torch.empty((B, NBINS, T, 2), device=spec.device, dtype=torch.float32)
+        else:
+            self._check_on_device(out, "out")
+            if tuple(out.shape) != (B, NBINS, T, 2) or out.stride(3) != 1:
+                raise GtcrnError(f"out must be (B,257,{T},2) with contiguous re/im pairs, got {tuple(out.shape)}")
         isb, isf, ist = _spec_strides(spec)
         osb, osf, ost = _spec_strides(out)
         with self._dev():
@@ -359,6 +363,8 @@ class Engine:
         import torch
         self._check_on_device(wave, "wave")
         w2 = (wave.reshape(1, -1) if wave.dim() == 1 else wave).contiguous()
+        if w2.dim() != 2:
+            raise GtcrnError(f"wave must be (B,L) or (L,), got {tuple(wave.shape)}")
         B, L = w2.shape
         T = num_frames(L)
         win = window.to(device=wave.device, dtype=torch.float32).contiguous()

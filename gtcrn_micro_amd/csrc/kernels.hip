@@ -3222,7 +3222,7 @@ int configure_kernels() {
                             SM_LDS_FLOATS * 4);
     if (e != hipSuccess) return (int)e;
     const void* gt[] = {reinterpret_cast<const void*>(k_gtcn<TPW, false>), reinterpret_cast<const void*>(k_gtcn<1, false>),
-                        reinterpret_cast<const void*>(k_gtcn<1, true>), reinterpret_cast<const void*>(k_gtcn<TPW, true>),
+                        reinterpret_cast<const void*>(k_gtcn<1, true>),
                         reinterpret_cast<const void*>(k_gtcn<2, true>), reinterpret_cast<const void*>(k_gtcn<2, false>)};
     for (const void* f : gt) {
         e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, GT_LDS_FLOATS * 4);
@@ -3316,10 +3316,7 @@ int launch_gtcn(const float* xin, float* xout, const float* P, int B, int T, flo
     else if (T <= SHORT_T2)
         hipLaunchKernelGGL((k_gtcn<2, false>), dim3(B), dim3(NTHR), GT_LDS_FLOATS * 4, s, xin, xout, P, T, state,
                            st_off, addend, stamps);
-    else if (T <= TC && state)   // one-chunk streaming call: the ring copy through LDS would cost more than it saves
-        hipLaunchKernelGGL((k_gtcn<TPW, true>), dim3(B), dim3(NTHR), GT_LDS_H * 4, s, xin, xout, P, T, state, st_off,
-                           addend, stamps);
-    else
+    else   // (11..16-frame stateful calls take the LDS-ring form too: the in-state form with three tiles per wave spilled)
         hipLaunchKernelGGL((k_gtcn<TPW, false>), dim3(B), dim3(NTHR), GT_LDS_FLOATS * 4, s, xin, xout, P, T, state,
                            st_off, addend, stamps);
     GT_LAUNCH_CHECK();

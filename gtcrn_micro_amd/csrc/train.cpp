@@ -404,6 +404,10 @@ int gtcrn_trainer_create(gtcrn_trainer** out, int device) {
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev)
         return tfail(GTCRN_ERR_DEVICE, "gtcrn_trainer_create: no such HIP device (the training path has no CPU fallback)");
+    hipDeviceProp_t prop;
+    T_HIP(hipGetDeviceProperties(&prop, device));
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return tfail(GTCRN_ERR_DEVICE, std::string("gtcrn_trainer_create: built for gfx950 only, device is ") + prop.gcnArchName);
     T_HIP(hipSetDevice(device));
     gtcrn_trainer* t = new gtcrn_trainer();
     t->device = device;

@@ -49,7 +49,9 @@ __device__ __forceinline__ unsigned f2bf(float x) {
 }
 __device__ __forceinline__ float h2f(unsigned h) { return (float)__builtin_bit_cast(_Float16, (unsigned short)h); }
 __device__ __forceinline__ unsigned f2h(float x) {
-    const _Float16 h = (_Float16)fminf(fmaxf(x, -65504.f), 65504.f);
+    // saturate finite values; NaN must survive (fminf / fmaxf return the non-NaN operand and would turn it into 65504):
+    // a diverged run has to stay visibly diverged in every storage mode
+    const _Float16 h = (_Float16)(x != x ? x : fminf(fmaxf(x, -65504.f), 65504.f));
     return (unsigned)__builtin_bit_cast(unsigned short, h);
 }
 __device__ __forceinline__ float dec16(unsigned h, int fmt) { return fmt == 1 ? bf2f(h) : h2f(h); }

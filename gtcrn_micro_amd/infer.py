@@ -90,7 +90,7 @@ def merge_scp(enh_dir, world):
                     out.write(f.read())
 
 
-def enhance_folder(noisy_dir, clean_dir, enh_dir, checkpoint, device=0, max_batch=64, rank=0, world=1,
+def _enhance_shard(noisy_dir, clean_dir, enh_dir, checkpoint, device=0, max_batch=64, rank=0, world=1,
                    barrier=None):
     """barrier: a callable all ranks call once their lists are written (multi-GPU runs; main() passes
     torch.distributed.barrier); rank 0 then merges the per-rank scp files."""
@@ -151,11 +151,38 @@ def enhance_folder(noisy_dir, clean_dir, enh_dir, checkpoint, device=0, max_batc
         with open(os.path.join(enh_dir, fname + suffix), "w") as f:
             for uid, p in lst:
                 f.write(f"{uid} {p}\n")
-    if world > 1 and barrier is not None:
-        barrier()
-        if rank == 0:
-            merge_scp(enh_dir, world)
     return inf_scp, ref_scp
+
+
+def enhance_folder(noisy_dir, clean_dir, enh_dir, checkpoint, device=0, max_batch=64, rank=0, world=1, barrier=None,
+                   agree=None):
+    """Counterpart of infer.py:26-119 for a folder (see ``_enhance_shard``): every rank enhances its contiguous shard of
+    the sorted file list, then rank 0 merges the per-rank scp lists.
+
+    A failure on ONE rank (a clip with the wrong sample rate, a missing reference, an I/O error) must not leave the
+    others waiting in a collective: the per-rank work runs inside try/finally, the ranks then exchange a failure flag
+    -- ``agree(ok) -> bool`` (True only if every rank succeeded; ``main`` passes an all-reduce), or failing that the
+    plain ``barrier`` -- and only a run in which every rank succeeded is merged.  The failing rank re-raises its own
+    error; the others raise a RuntimeError naming the situation, so every process exits non-zero."""
+    err = None
+    result = None
+    try:
+        result = _enhance_shard(noisy_dir, clean_dir, enh_dir, checkpoint, device, max_batch, rank, world, barrier)
+    except BaseException as e:                                       # noqa: BLE001 -- re-raised below, after the exchange
+        err = e
+    all_ok = err is None
+    if world > 1:
+        if agree is not None:
+            all_ok = bool(agree(err is None))
+        elif barrier is not None:
+            barrier()
+    if err is not None:
+        raise err
+    if not all_ok:
+        raise RuntimeError("enhance_folder: another rank failed; its shard is incomplete, the scp lists were not merged")
+    if world > 1 and rank == 0 and (agree is not None or barrier is not None):
+        merge_scp(enh_dir, world)
+    return result
 
 
 def main(argv=None):
@@ -169,16 +196,29 @@ def main(argv=None):
     a = ap.parse_args(argv)
     from .sharding import rank_world
     rank, local_rank, world = rank_world()
+    if world > 1 and a.device is not None:
+        # init_distributed binds RCCL to cuda:LOCAL_RANK; one explicit device for every rank would put all of them
+        # on the same GPU while their communicators sit on different ones
+        ap.error("--device cannot be combined with a multi-process launch (WORLD_SIZE > 1): each rank uses cuda:LOCAL_RANK")
     dev = int(a.device) if a.device is not None else local_rank
-    barrier = None
+    barrier = agree = None
     if world > 1:
+        import torch
         import torch.distributed as dist
         from .sharding import init_distributed
         init_distributed(None)
         barrier = dist.barrier
-    enhance_folder(a.noisy_dir, a.clean_dir, a.enh_dir, a.checkpoint, dev, a.max_batch, rank, world, barrier)
-    if world > 1:
-        dist.destroy_process_group()
+
+        def agree(ok):
+            flag = torch.tensor([1 if ok else 0], dtype=torch.int32,
+                                device=f"cuda:{local_rank}" if dist.get_backend() == "nccl" else "cpu")
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            return bool(flag.item())
+    try:
+        enhance_folder(a.noisy_dir, a.clean_dir, a.enh_dir, a.checkpoint, dev, a.max_batch, rank, world, barrier, agree)
+    finally:
+        if world > 1:
+            dist.destroy_process_group()
 
 
 if __name__ == "__main__":

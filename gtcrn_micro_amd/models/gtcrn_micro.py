@@ -184,6 +184,19 @@ def state_dict_to_blob(sd):
     return torch.cat(parts).numpy()
 
 
+def load_blob_into(model, blob):
+    """The inverse of ``state_dict_to_blob``: the canonical flat fp32 blob (numpy, gtcrn_param_name order) -> the
+    module's parameters and running statistics (``num_batches_tracked`` counters are not part of the blob)."""
+    blob = np.ascontiguousarray(blob, np.float32).ravel()
+    if blob.size != _lib.NPARAM_FLOATS:
+        raise ValueError(f"parameter blob must hold {_lib.NPARAM_FLOATS} floats, got {blob.size}")
+    sd = model.state_dict()
+    new = {name: torch.from_numpy(blob[off:off + numel].copy()).view(sd[name].shape)
+           for name, numel, off in _lib.param_table()}
+    model.load_state_dict(new, strict=False)
+    return model
+
+
 def _is_trainable(name):
     return not (name.endswith("running_mean") or name.endswith("running_var") or name.startswith("erb."))
 

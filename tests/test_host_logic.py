@@ -330,9 +330,15 @@ def test_headline_kernels_use_no_scratch():
             # chunked-streaming forms (in-kernel front end), one / two / three tiles per wave
             "void gtk::k_encoder<3, false, false, true>", "void gtk::k_encoder<1, false, false, true>",
             "void gtk::k_decoder<false, 1, false, false>", "void gtk::k_decoder<false, 2, false, false>"]
+    must.append("gtk::k_stream_ms")
     for k in must:
         assert k in rows, (k, sorted(rows))
         assert "ScratchSize [bytes/lane]: 0 " in rows[k], rows[k]
+    # ... and so does every other kernel of the product path: only the stage-tap instantiations of the decoder
+    # (k_decoder<true, ...>, used by the parity tests alone) may spill
+    for k, row in rows.items():
+        if not k.startswith("void gtk::k_decoder<true"):
+            assert "ScratchSize [bytes/lane]: 0 " in row, row
 
 
 def test_dense_bf16_planes_recombine_to_the_fp32_matrices():
@@ -390,3 +396,39 @@ def test_replaced_parameter_object_is_noticed():
     with torch.no_grad():
         conv.weight.mul_(2.0)                                    # in-place edits still move the version sum
     assert m._signature()[0] == sig2[0] + 1 and m._signature()[2] == sig2[2]
+
+
+def test_folder_driver_exchanges_a_failure_flag_before_merging(tmp_path, monkeypatch):
+    """a per-file error on one rank must not leave the other ranks in a collective, and a half-finished run
+    must not be merged.  The per-rank work runs first, then `agree(ok)` is called on EVERY rank -- also on the one that
+    failed -- and only then the failing rank re-raises, the others refuse to merge."""
+    from gtcrn_micro_amd import infer
+    calls = []
+
+    def agree_all(ok):
+        calls.append(ok)
+        return ok and agree_all.others_ok
+    monkeypatch.setattr(infer, "merge_scp", lambda d, w: calls.append("merge"))
+    # (1) this rank fails: the exchange still happens, then its own error surfaces
+    monkeypatch.setattr(infer, "_enhance_shard", lambda *a, **k: (_ for _ in ()).throw(AssertionError("x.wav: sample rate 8000 != 16000")))
+    agree_all.others_ok = True
+    with pytest.raises(AssertionError, match="sample rate"):
+        infer.enhance_folder("n", "c", str(tmp_path), "ck", rank=1, world=2, agree=agree_all)
+    assert calls == [False]
+    # (2) this rank is fine, another one failed: no merge, non-zero exit
+    calls.clear()
+    monkeypatch.setattr(infer, "_enhance_shard", lambda *a, **k: ([("u", "p")], [("u", "r")]))
+    agree_all.others_ok = False
+    with pytest.raises(RuntimeError, match="another rank failed"):
+        infer.enhance_folder("n", "c", str(tmp_path), "ck", rank=0, world=2, agree=agree_all)
+    assert calls == [True]
+    # (3) everybody is fine: rank 0 merges, the others do not
+    for rank, want in ((0, [True, "merge"]), (1, [True])):
+        calls.clear()
+        agree_all.others_ok = True
+        assert infer.enhance_folder("n", "c", str(tmp_path), "ck", rank=rank, world=2, agree=agree_all)[0] == [("u", "p")]
+        assert calls == want
+    # --device with a multi-process launch puts every rank on one GPU: refused
+    monkeypatch.setenv("WORLD_SIZE", "2"); monkeypatch.setenv("RANK", "0"); monkeypatch.setenv("LOCAL_RANK", "0")
+    with pytest.raises(SystemExit):
+        infer.main(["--noisy-dir", "n", "--clean-dir", "c", "--enh-dir", str(tmp_path), "--checkpoint", "ck", "-D", "0"])
