@@ -32,13 +32,32 @@ def is_trainable(name):
     return not (name.endswith("running_mean") or name.endswith("running_var") or name.startswith("erb."))
 
 
+class _RoundSTE(torch.autograd.Function):
+    """x -> bf16(x) (round to nearest even) with a straight-through gradient: what a tensor STORED in bf16 and read
+    back by its consumers looks like to the rest of the graph."""
+
+    @staticmethod
+    def forward(ctx, x):
+        return x.to(torch.bfloat16).to(x.dtype)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g
+
+
 class TorchPort:
-    def __init__(self, blob, train=False, dtype=torch.float32):
+    def __init__(self, blob, train=False, dtype=torch.float32, store=None):
         """train=True: BatchNorm uses batch statistics and updates the running ones in place
         (nn.BatchNorm2d in .train() mode, momentum 0.1), and trainable tensors require grad.
-        dtype=torch.float64 runs the same graph in double: the "truth" that fp32 results scatter around."""
+        dtype=torch.float64 runs the same graph in double: the "truth" that fp32 results scatter around.
+        store="bf16": the graph of the HIP trainer's bf16 storage mode (BASELINE configs[3]) -- every tensor the
+        trainer writes out (features, conv outputs centred on the running mean, activations, block outputs, decoder
+        sums, the mask) is rounded to bf16 where it is produced and its consumers read the rounded value; arithmetic in
+        `dtype`.  With dtype=float64 this is the truth for THAT network: bf16-activation training computes the
+        gradient of a slightly different function than the fp32 network (tests/reports/bf16_storage_ablation.py)."""
         self.p = {k: v.to(dtype) for k, v in blob_to_dict(blob).items()}
         self.dtype = dtype
+        self.store = store
         self.train = bool(train)
         if self.train:
             for k, v in self.p.items():
@@ -46,8 +65,16 @@ class TorchPort:
                     v.requires_grad_(True)
 
     # conv + BatchNorm + activation (ConvBlock.forward, models/gtcrn_micro.py:163-164)
+    def _r(self, x):
+        return _RoundSTE.apply(x) if self.store == "bf16" else x
+
     def _bn(self, x, pre):
         p = self.p
+        if self.store == "bf16":
+            # the conv output is stored centred on the channel's mean of the previous step (the running mean before the
+            # first one, csrc/train.cpp unit_fwd); the batch statistics are taken from the stored values
+            rm = p[pre + ".running_mean"].detach().clone().view(1, -1, 1, 1)
+            x = _RoundSTE.apply(x - rm) + rm
         return F.batch_norm(x, p[pre + ".running_mean"], p[pre + ".running_var"], p[pre + ".weight"],
                             p[pre + ".bias"], self.train, 0.1, 1e-5)
 
@@ -65,27 +92,27 @@ class TorchPort:
         x1, x2 = x[:, :8], x[:, 8:]
         conv = F.conv_transpose2d if deconv else F.conv2d
         h = conv(x1, p[pre + ".point_conv1.weight"], p[pre + ".point_conv1.bias"])
-        h = F.prelu(self._bn(h, pre + ".point_bn1"), p[pre + ".point_act.weight"])
+        h = self._r(F.prelu(self._bn(h, pre + ".point_bn1"), p[pre + ".point_act.weight"]))
         if deconv:
             h = F.conv_transpose2d(h, p[pre + ".depth_conv.weight"], p[pre + ".depth_conv.bias"], padding=(0, 1))
         else:
             h = F.conv2d(F.pad(h, [0, 0, 2, 0]), p[pre + ".depth_conv.weight"], p[pre + ".depth_conv.bias"],
                          padding=(0, 1), groups=16)
-        h = F.prelu(self._bn(h, pre + ".depth_bn"), p[pre + ".depth_act.weight"])
-        h = self._bn(conv(h, p[pre + ".point_conv2.weight"], p[pre + ".point_conv2.bias"]), pre + ".point_bn2")
+        h = self._r(F.prelu(self._bn(h, pre + ".depth_bn"), p[pre + ".depth_act.weight"]))
+        h = self._r(self._bn(conv(h, p[pre + ".point_conv2.weight"], p[pre + ".point_conv2.bias"]), pre + ".point_bn2"))
         h = self._tra(h, pre + ".tra")[:, :, :x2.shape[2]]
-        return torch.stack([h, x2], dim=2).flatten(1, 2)      # out[2c] = h[c], out[2c+1] = x2[c]
+        return self._r(torch.stack([h, x2], dim=2).flatten(1, 2))      # out[2c] = h[c], out[2c+1] = x2[c]
 
     def _tcn(self, x, pre, d):
         # TCN.forward (models/gtcrn_micro.py:290-310)
         p = self.p
-        y = F.prelu(self._bn(F.conv2d(x, p[pre + ".conv1.weight"], p[pre + ".conv1.bias"]), pre + ".bn1"),
-                    p[pre + ".act1.weight"])
+        y = self._r(F.prelu(self._bn(F.conv2d(x, p[pre + ".conv1.weight"], p[pre + ".conv1.bias"]), pre + ".bn1"),
+                            p[pre + ".act1.weight"]))
         y = F.conv2d(F.pad(y, [0, 0, 2 * d, 0]), p[pre + ".conv2.weight"], p[pre + ".conv2.bias"],
                      dilation=(d, 1), groups=16)
-        y = F.prelu(self._bn(y, pre + ".bn2"), p[pre + ".act2.weight"])
+        y = self._r(F.prelu(self._bn(y, pre + ".bn2"), p[pre + ".act2.weight"]))
         y = self._bn(F.conv2d(y, p[pre + ".conv3.weight"], p[pre + ".conv3.bias"]), pre + ".bn3")
-        return F.prelu(y + x, p[pre + ".act3.weight"])
+        return self._r(F.prelu(y + x, p[pre + ".act3.weight"]))
 
     def forward(self, spec, taps=None):
         """GTCRNMicro.forward (models/gtcrn_micro.py:506-532): (B,257,T,2) -> (B,257,T,2)."""
@@ -103,13 +130,13 @@ class TorchPort:
         spec = torch.as_tensor(spec).to(self.dtype)
         re, im = spec[..., 0].permute(0, 2, 1), spec[..., 1].permute(0, 2, 1)
         feat = torch.stack([torch.sqrt(re * re + im * im + 1e-12), re, im], dim=1)
-        feat = torch.cat([feat[..., :65], F.linear(feat[..., 65:], p["erb.erb_fc.weight"])], dim=-1)
-        x = F.conv2d(feat, p["sfe.depth_conv.weight"], padding=(0, 1), groups=3)
+        feat = self._r(torch.cat([feat[..., :65], F.linear(feat[..., 65:], p["erb.erb_fc.weight"])], dim=-1))
+        x = self._r(F.conv2d(feat, p["sfe.depth_conv.weight"], padding=(0, 1), groups=3))
         skips = []
         for i in range(2):
             pre = f"encoder.en_convs.{i}"
             x = F.conv2d(x, p[pre + ".conv.weight"], p[pre + ".conv.bias"], stride=(1, 2), padding=(0, 2))
-            x = F.prelu(self._bn(x, pre + ".bn"), p[pre + ".act.weight"])
+            x = self._r(F.prelu(self._bn(x, pre + ".bn"), p[pre + ".act.weight"]))
             skips.append(x)
             tap(f"en{i}", x)
         for i in range(2, 5):
@@ -121,15 +148,15 @@ class TorchPort:
                 x = self._tcn(x, f"gtcn{g}.blocks.{k}", 1 << k)
             tap(f"gtcn{g}", x)
         for i in range(3):
-            x = self._gtconv(x + skips[4 - i], f"decoder.de_convs.{i}", True)
+            x = self._gtconv(self._r(x + skips[4 - i]), f"decoder.de_convs.{i}", True)
             tap(f"de{i}", x)
         pre = "decoder.de_convs.3"
-        x = F.conv_transpose2d(x + skips[1], p[pre + ".conv.weight"], p[pre + ".conv.bias"], stride=(1, 2), padding=(0, 2))
-        x = F.prelu(self._bn(x, pre + ".bn"), p[pre + ".act.weight"])
+        x = F.conv_transpose2d(self._r(x + skips[1]), p[pre + ".conv.weight"], p[pre + ".conv.bias"], stride=(1, 2), padding=(0, 2))
+        x = self._r(F.prelu(self._bn(x, pre + ".bn"), p[pre + ".act.weight"]))
         tap("de3", x)
         pre = "decoder.de_convs.4"
-        x = F.conv_transpose2d(x + skips[0], p[pre + ".conv.weight"], p[pre + ".conv.bias"], stride=(1, 2), padding=(0, 2))
-        m = torch.tanh(self._bn(x, pre + ".bn"))
+        x = F.conv_transpose2d(self._r(x + skips[0]), p[pre + ".conv.weight"], p[pre + ".conv.bias"], stride=(1, 2), padding=(0, 2))
+        m = self._r(torch.tanh(self._bn(x, pre + ".bn")))
         tap("de4", m)
         m = torch.cat([m[..., :65], F.linear(m[..., 65:], p["erb.ierb_fc.weight"])], dim=-1)   # (B,2,T,257)
         out_re = re * m[:, 0] - im * m[:, 1]
