@@ -473,6 +473,9 @@ __global__ __launch_bounds__(NT) void k_dw(DwGeom g, const float* __restrict__ i
 }
 
 // C = 16: one thread per (position, 4 channels): every tap is one coalesced 16-byte load
+// NKT x NKF: the tap grid as compile-time constants (3x3 encoder depth convs, 3x1 dilated TCN convs and their adjoints);
+// 0 x 0: run-time tap counts (any other shape)
+template <int NKT, int NKF>
 __global__ __launch_bounds__(NT) void k_dw16(DwGeom g, const float* __restrict__ in, const float* __restrict__ w,
                                             const float* __restrict__ bias, float* __restrict__ out,
                                             double* __restrict__ stat_partial, StrideIter it,
@@ -496,15 +499,39 @@ __global__ __launch_bounds__(NT) void k_dw16(DwGeom g, const float* __restrict__
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
         if (bias) acc = *reinterpret_cast<const f32x4*>(bias + 4 * q);
         if (shift) acc -= *reinterpret_cast<const f32x4*>(shift + 4 * q);
-        for (int kt = 0; kt < g.nkt; ++kt) {
-            const int ti = P.to + g.t_off[kt];
-            if (ti < 0 || ti >= g.Tin) continue;
-            for (int kf = 0; kf < g.nkf; ++kf) {
-                const int fi = P.fo + g.f_off[kf];
-                if (fi < 0 || fi >= g.F) continue;
-                const f32x4 x = sld4(in, ((long)(P.bt + g.t_off[kt]) * g.F + fi) * 16 + 4 * q, g.in_bf);
-                const f32x4 wt = *reinterpret_cast<const f32x4*>(sW + (kt * g.nkf + kf) * 16 + 4 * q);
-                acc += wt * x;
+        if constexpr (NKT > 0) {
+            // every tap's load is issued before the first multiply-add (a tap outside the tensor loads the centre
+            // record instead and is skipped by a select: one basic block, NKT * NKF loads in flight per thread instead
+            // of one behind each branch); same taps, same order of additions as the loop form
+            f32x4 xv[NKT * NKF];
+            bool ok[NKT * NKF];
+#pragma unroll
+            for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+                for (int kf = 0; kf < NKF; ++kf) {
+                    const int ti = P.to + g.t_off[kt], fi = P.fo + g.f_off[kf];
+                    const bool v = ti >= 0 && ti < g.Tin && fi >= 0 && fi < g.F;
+                    ok[kt * NKF + kf] = v;
+                    const long rec = v ? (long)(P.bt + g.t_off[kt]) * g.F + fi : p;
+                    xv[kt * NKF + kf] = sld4(in, rec * 16 + 4 * q, g.in_bf);
+                }
+#pragma unroll
+            for (int tp = 0; tp < NKT * NKF; ++tp) {
+                const f32x4 wt = *reinterpret_cast<const f32x4*>(sW + tp * 16 + 4 * q);
+                const f32x4 nx = acc + wt * xv[tp];
+                acc = ok[tp] ? nx : acc;
+            }
+        } else {
+            for (int kt = 0; kt < g.nkt; ++kt) {
+                const int ti = P.to + g.t_off[kt];
+                if (ti < 0 || ti >= g.Tin) continue;
+                for (int kf = 0; kf < g.nkf; ++kf) {
+                    const int fi = P.fo + g.f_off[kf];
+                    if (fi < 0 || fi >= g.F) continue;
+                    const f32x4 x = sld4(in, ((long)(P.bt + g.t_off[kt]) * g.F + fi) * 16 + 4 * q, g.in_bf);
+                    const f32x4 wt = *reinterpret_cast<const f32x4*>(sW + (kt * g.nkf + kf) * 16 + 4 * q);
+                    acc += wt * x;
+                }
             }
         }
         P.advance(it, g.F, g.Tout);
@@ -669,21 +696,34 @@ __global__ __launch_bounds__(NT) void k_bn_bwd_reduce(const float* __restrict__ 
     float mean[V], istd[V], gm[V], bt[V];
 #pragma unroll
     for (int e = 0; e < V; ++e) { mean[e] = stats[c0 + e]; istd[e] = stats[C + c0 + e]; gm[e] = gamma[c0 + e]; bt[e] = beta[c0 + e]; }
-    for (long i = (long)blockIdx.x * NT + threadIdx.x; i < units; i += (long)gridDim.x * NT) {
-        float x[V], g[V], r[V];
-        load_vec_s<V>(y, i * V, ybf, x);
-        load_vec<V>(da + i * V, g);
-        if (res) load_vec_s<V>(res, i * V, bf, r);
+    // U grid-strides per trip with all their loads issued first (a read-only pass has nothing but its own loads in
+    // flight to cover the HBM latency: two 16-byte loads per thread ran at 3.5 TB/s); the sums are still taken in index
+    // order, so the result is bit-identical to the one-stride loop
+    constexpr int U = 4;
+    const long stride = (long)gridDim.x * NT;
+    for (long i0 = (long)blockIdx.x * NT + threadIdx.x; i0 < units; i0 += U * stride) {
+        float x[U][V], g[U][V], r[U][V];
 #pragma unroll
-        for (int e = 0; e < V; ++e) {
-            const float xh = (x[e] - mean[e]) * istd[e];
-            float z = gm[e] * xh + bt[e];
-            if (res) z += r[e];
-            float dsl;
-            const float dz = act_bwd(z, g[e], act, sl, dsl);
-            v[0][e] += dz;
-            v[1][e] = fmaf(dz, xh, v[1][e]);
-            v[2][e] += dsl;
+        for (int u = 0; u < U; ++u) {
+            const long i = i0 + u * stride < units ? i0 + u * stride : i0;     // clamped: a valid element, not summed
+            load_vec_s<V>(y, i * V, ybf, x[u]);
+            load_vec<V>(da + i * V, g[u]);
+            if (res) load_vec_s<V>(res, i * V, bf, r[u]);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (i0 + u * stride >= units) break;
+#pragma unroll
+            for (int e = 0; e < V; ++e) {
+                const float xh = (x[u][e] - mean[e]) * istd[e];
+                float z = gm[e] * xh + bt[e];
+                if (res) z += r[u][e];
+                float dsl;
+                const float dz = act_bwd(z, g[u][e], act, sl, dsl);
+                v[0][e] += dz;
+                v[1][e] = fmaf(dz, xh, v[1][e]);
+                v[2][e] += dsl;
+            }
         }
     }
     block_reduce_store<3, V>(v, C, sh, partial + (long)blockIdx.x * 3 * C);
@@ -1452,8 +1492,13 @@ int dw_fwd(const DwGeom& g, const float* in, const float* w, const float* bias, 
         double* sp = (stat_partial && stat_parts && !g.accumulate) ? stat_partial : nullptr;
         const int g16 = grid_for((long)g.B * g.Tout * g.F * 4, sp ? MAX_PARTIALS : 16384);
         if (g.Tin != g.Tout) return (int)hipErrorInvalidValue;
-        hipLaunchKernelGGL(k_dw16, dim3(g16), dim3(NT), 0, s, g, in, w, bias, out, sp,
-                           stride_iter((long)g16 * NT / 4, g.F, g.Tout), shift);
+        const StrideIter it = stride_iter((long)g16 * NT / 4, g.F, g.Tout);
+        if (g.nkt == 3 && g.nkf == 3)
+            hipLaunchKernelGGL((k_dw16<3, 3>), dim3(g16), dim3(NT), 0, s, g, in, w, bias, out, sp, it, shift);
+        else if (g.nkt == 3 && g.nkf == 1)
+            hipLaunchKernelGGL((k_dw16<3, 1>), dim3(g16), dim3(NT), 0, s, g, in, w, bias, out, sp, it, shift);
+        else
+            hipLaunchKernelGGL((k_dw16<0, 0>), dim3(g16), dim3(NT), 0, s, g, in, w, bias, out, sp, it, shift);
         if (sp) *stat_parts = g16;
         return check();
     }

@@ -12,7 +12,7 @@
 #   stream / train             kernel trace + stats of the configs[2] / configs[3] legs
 # tools/profile_summary.py condenses them into the files committed under profiles/.
 set -u
-TAG=${1:-r02}
+TAG=${1:-r03}
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$R/gpurun_out/$TAG
 mkdir -p "$OUT"
@@ -22,7 +22,7 @@ rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- python3 
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_fetch" -- python3 $B --steps 4 --warmup 2 > "$OUT/pmc_fetch.log" 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_write" -- python3 $B --steps 4 --warmup 2 > "$OUT/pmc_write.log" 2>&1
 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_MFMA SQ_LDS_BANK_CONFLICT --output-format csv -d "$OUT/pmc_sq" -- python3 $B --steps 4 --warmup 2 > "$OUT/pmc_sq.log" 2>&1
-rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_VALU_MFMA_COEXEC_CYCLES SQ_BUSY_CU_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_INSTS_VALU_MFMA_MOPS_F32 GRBM_GUI_ACTIVE --output-format csv -d "$OUT/pmc_sq2" -- python3 $B --steps 4 --warmup 2 > "$OUT/pmc_sq2.log" 2>&1
+rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_VALU_MFMA_COEXEC_CYCLES SQ_BUSY_CU_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_INSTS_VALU_MFMA_MOPS_BF16 GRBM_GUI_ACTIVE --output-format csv -d "$OUT/pmc_sq2" -- python3 $B --steps 4 --warmup 2 > "$OUT/pmc_sq2.log" 2>&1
 # the issue microbenchmark under the same counters
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 "$R/tools/ubench_mfma_valu.hip" -o /tmp/ub_mfma_valu > "$OUT/ub_build.log" 2>&1
 /tmp/ub_mfma_valu > "$OUT/ub_plain.log" 2>&1

@@ -17,7 +17,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def short(name):
-    for k in ("k_front", "k_stft", "k_istft", "k_encoder", "k_gtcn_ms", "k_gtcn", "k_decoder", "k_state_convert"):
+    for k in ("k_stream_ms", "k_front", "k_stft", "k_istft", "k_encoder", "k_gtcn_ms", "k_gtcn", "k_decoder", "k_state_convert"):
         if k in name:
             return k
     return None
@@ -97,7 +97,15 @@ def main():
         c = {n: (sum(v) / len(v) if v else None) for n, v in sq[k].items()}
         d = {}
         if c.get("SQ_INSTS_MFMA") and avg_ns.get(k):
-            d["mfma_flop_executed_per_launch"] = c["SQ_INSTS_MFMA"] * 2048.0
+            if c.get("SQ_INSTS_VALU_MFMA_MOPS_BF16"):
+                # mixed matrix instructions (round 3: the decoder's dense 3x3 and the fused streaming step issue
+                # v_mfma_f32_16x16x32_bf16, 16 384 FLOP, next to v_mfma_f32_16x16x4_f32, 2 048 FLOP): SQ_INSTS_MFMA
+                # counts both kinds, the MOPS counters (512 FLOP each) separate them
+                d["mfma_mops_f32"] = c.get("SQ_INSTS_VALU_MFMA_MOPS_F32")
+                d["mfma_mops_bf16"] = c["SQ_INSTS_VALU_MFMA_MOPS_BF16"]
+                d["mfma_flop_executed_per_launch"] = 512.0 * ((c.get("SQ_INSTS_VALU_MFMA_MOPS_F32") or 0) + c["SQ_INSTS_VALU_MFMA_MOPS_BF16"])
+            else:
+                d["mfma_flop_executed_per_launch"] = c["SQ_INSTS_MFMA"] * 2048.0
             d["mfma_tflops_executed"] = d["mfma_flop_executed_per_launch"] / (avg_ns[k] * 1e-9) / 1e12
         if c.get("SQ_INSTS_VALU") and c.get("SQ_INSTS_MFMA"):
             d["valu_per_mfma"] = c["SQ_INSTS_VALU"] / c["SQ_INSTS_MFMA"]
@@ -135,7 +143,7 @@ def main():
         if os.path.exists(plain):
             open(os.path.join(dst, f"{tag}_ubench_mfma_valu.txt"), "w").write(open(plain).read())
     # --- streaming / training traces
-    for sub, pats in (("stream", ("k_encoder", "k_gtcn_ms", "k_decoder")), ("train_f32", None), ("train_bf16", None)):
+    for sub, pats in (("stream", ("k_stream_ms", "k_encoder", "k_gtcn_ms", "k_decoder")), ("train_f32", None), ("train_bf16", None)):
         f = newest(sub, "*kernel_stats.csv")
         if not f:
             continue
