@@ -177,9 +177,9 @@ __device__ __forceinline__ void mm16(const f32x4 A, const f32x4 (&x)[N], f32x4 (
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
-#ifdef GT_EXP
-constexpr bool kSplitDense = false;     // A/B reference (tools/ab_bench.py): the round-2 fp32-MFMA dense 3x3
-#else
+#ifdef GT_F32_DENSE
+constexpr bool kSplitDense = false;     // A/B reference: the round-2 fp32-MFMA dense 3x3 (GT_EXP_FLAGS=-DGT_F32_DENSE
+#else                                   // python tools/ab_bench.py; profiles/r03_ab_split_dense.txt)
 constexpr bool kSplitDense = true;
 #endif
 struct Split3 {
@@ -2131,7 +2131,11 @@ struct DecLds {
     // the last bin) -- m is written after the last block has read S and is dead before the next chunk writes S
     static constexpr int A = E + (MS ? NS * 24 : (RW + 2) * 8);
     static constexpr int RWI = MS ? RW : RW + IMG_R0;             // image rows (two history rows in front of the chunk)
-    static constexpr int S = A + RWI * 35 * RS;
+    // image row pitch in records: 41 where the LDS allows it (since round 3 the parameter region is 12 KB smaller): a
+    // tile that runs over the end of a row continues 9 = 1 (mod 8) records further on and keeps the conflict-free
+    // bank pattern (see EncLds); the multi-stream form has no room and stays at 35
+    static constexpr int PT = MS ? 35 : 41;                       // (A/B on one box: 0.4138 vs 0.4157 ms at 35)
+    static constexpr int S = A + RWI * PT * RS;
     static constexpr int ZSZ = RW * DEC_Z_ROW * DEC_ZS;
     static constexpr int M = A + ZSZ;
     static constexpr int MSZ = (2 * RW * F0 + 4 + 3) & ~3;
@@ -2258,7 +2262,7 @@ __global__ __launch_bounds__(NTHR) void k_decoder(const float* __restrict__ xg, 
         f32x4 x[TPW];
 #pragma unroll
         for (int i = 0; i < TPW; ++i) x[i] = xn[i];
-        zero_row_pads<LD::RWI, RS>(sW, tid);  // region A was Z in the previous chunk (a barrier follows in the block)
+        zero_row_pads<LD::RWI, RS, LD::PT>(sW, tid);  // region A was Z in the previous chunk (a barrier follows in the block)
         STAMP(SS, 1)
         // All 256 workgroups run in lock step, so a load burst right before its use is a chip-wide HBM
         // burst (25 MB at once costs ~10 k cycles).  The inputs of the tail are therefore requested
@@ -2299,7 +2303,7 @@ __global__ __launch_bounds__(NTHR) void k_decoder(const float* __restrict__ xg, 
             // dense phase is over (the hook runs behind its closing barrier) and is waited for two barrier intervals
             // later, one barrier (the next block's point_conv1) before its first reader
             c.g_hist = nullptr;
-            gtconv_block<true, TPW, MS, Q, RS, LD::RSS, true, 35, decltype(vmk)::value>(
+            gtconv_block<true, TPW, MS, Q, RS, LD::RSS, true, LD::PT, decltype(vmk)::value>(
                 x, tt, c, L, [&] { dense_fetch(j == 2 ? 0 : j + 1); hook(); }, [] {} STAMP_ARG);
             if (DBG)
 #pragma unroll
@@ -2324,7 +2328,7 @@ __global__ __launch_bounds__(NTHR) void k_decoder(const float* __restrict__ xg, 
         // ---- de_convs.3: gather form; input image in sW rows (pad columns are zero).  Every wave is
         // past the last block's tap reads (they precede that block's 2nd barrier), so sW is free.
 #pragma unroll
-        for (int i = 0; i < TPW; ++i) st4(sW + o35<RS, LD::RWI - RW>(tt, i, g), x[i]);
+        for (int i = 0; i < TPW; ++i) st4(sW + o35<RS, LD::RWI - RW, LD::PT>(tt, i, g), x[i]);
         STAMP(SS, 9)
         wg_barrier();
         STAMP(SS, 10)
@@ -2343,7 +2347,7 @@ __global__ __launch_bounds__(NTHR) void k_decoder(const float* __restrict__ xg, 
                 const f32x4 A0 = ld4(Ae), A1 = ld4(Ao);
 #pragma unroll
                 for (int i = 0; i < TPW; ++i) {
-                    const f32x4 xp = ld4(sW + o35<RS, LD::RWI - RW>(tt, i, g) + RS);   // input bin f+1
+                    const f32x4 xp = ld4(sW + o35<RS, LD::RWI - RW, LD::PT>(tt, i, g) + RS);   // input bin f+1
                     ae[i] = mm1<Q>(A0, xp, ae[i]);
                     ao[i] = mm1<Q>(A1, xp, ao[i]);
                 }
@@ -2360,7 +2364,7 @@ __global__ __launch_bounds__(NTHR) void k_decoder(const float* __restrict__ xg, 
                 const f32x4 A0 = ld4(Ae + 512);
 #pragma unroll
                 for (int i = 0; i < TPW; ++i) {
-                    const f32x4 xm = ld4(sW + o35<RS, LD::RWI - RW>(tt, i, g) - RS);   // input bin f-1
+                    const f32x4 xm = ld4(sW + o35<RS, LD::RWI - RW, LD::PT>(tt, i, g) - RS);   // input bin f-1
                     ae[i] = mm1<Q>(A0, xm, ae[i]);
                 }
             }

@@ -14,7 +14,8 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-# --exp: the stamps inside the `-DGT_EXP` build (the A/B reference of the current kernel experiment)
+# --exp: the stamps inside the `-DGT_EXP` build (the A/B reference of the current kernel experiment; add e.g.
+# GT_EXP_FLAGS=-DGT_F32_DENSE for the round-2 fp32-MFMA dense 3x3)
 EXP = "--exp" in sys.argv
 os.environ["GTCRN_LIB_VARIANT"] = "exp" if EXP else "stamps"
 if EXP:
