@@ -59,14 +59,18 @@ MAC_PER_FRAME = {
 }
 # MFMA instructions (16x16x4 f32 = 2 048 FLOP each) issued per frame, incl. the zero padding of the 8->16 /
 # 16->8 pointwise and K=15 tiles: executed vs algorithmic matrix work
-MFMA_PER_FRAME = {"k_encoder": 107, "k_gtcn1": 66, "k_gtcn2": 66, "k_decoder": 330}
+MFMA_PER_FRAME = {"k_encoder": 107, "k_gtcn1": 66, "k_gtcn2": 66, "k_decoder": 107.25}
+# round 3: the decoder's dense transposed 3x3 runs on v_mfma_f32_16x16x32_bf16 (16 384 FLOP each) from an exact
+# three-way bf16 split of both operands, six partial products per K-chunk: 33/16 tiles x 3 blocks x 30 per frame
+BF16_MFMA_PER_FRAME = {"k_decoder": 185.625}
+BF16_MFMA_PEAK_TFLOPS = 2500.0                  # MI355X_MICROARCH.md, dense
 MODEL_MAC_PER_FRAME = MAC_FRONT + 3 * MAC_GT_ENC + 2 * 73920 + MAC_PER_FRAME["k_decoder"]
 FFT_FLOP_PER_FRAME = 2 * 11520 + 6000          # 512-point rFFT + irFFT (5 N log2 N / 2) + window/OLA
 FP32_MFMA_PEAK_TFLOPS = 157.3                   # MI355X_MICROARCH.md, dense, v_mfma_f32_16x16x4_f32
 HBM_PEAK_GBS = 8000.0
 STREAM_STATE_BYTES_PER_FRAME = 94 * 1024        # ring-state traffic + the frame itself
 TRAIN_BYTES_PER_FRAME = 1.46e6                  # layer-at-a-time fp32 passes
-ROUND_TAG = "r02"
+ROUND_TAG = "r03"
 
 
 def _free_port():
@@ -619,7 +623,7 @@ def main(argv=None):
         flops_launch = 2.0 * MAC_PER_FRAME[dom] * frames_per_step
         achieved = flops_launch / (dom_ms * 1e-3) / 1e12
         traffic = None
-        for tag in (ROUND_TAG, "r01"):
+        for tag in (ROUND_TAG, "r02", "r01"):
             tf = os.path.join(ROOT, "profiles", f"{tag}_hbm_traffic.json")
             if os.path.exists(tf):
                 try:
@@ -640,8 +644,19 @@ def main(argv=None):
             "hbm_frac_at_boundary": round(value / world * 2048 / 1e9 / HBM_PEAK_GBS, 6),
         }
         if dom in MFMA_PER_FRAME:
-            roof["mfma_flop_executed_per_launch"] = 2048.0 * MFMA_PER_FRAME[dom] * frames_per_step
-            roof["mfma_padding_overhead"] = round(roof["mfma_flop_executed_per_launch"] / flops_launch - 1, 4)
+            # what the kernel EXECUTES on the matrix cores (frac above prices the algorithmic fp32 FLOPs against the fp32
+            # matrix peak, as the metric defines the work): zero padding of the 8->16 / 16->8 pointwise and K = 15
+            # tiles on the fp32 MFMA, and the dense 3x3 six times over on the bf16 pipe
+            f32x = 2048.0 * MFMA_PER_FRAME[dom] * frames_per_step
+            bfx = 16384.0 * BF16_MFMA_PER_FRAME.get(dom, 0.0) * frames_per_step
+            roof["executed_fp32_mfma_flop_per_launch"] = f32x
+            roof["executed_bf16_mfma_flop_per_launch"] = bfx
+            roof["executed_tflops"] = round((f32x + bfx) / (dom_ms * 1e-3) / 1e12, 1)
+            if bfx:
+                roof["executed_bf16_frac_of_bf16_peak"] = round(bfx / (dom_ms * 1e-3) / 1e12 / BF16_MFMA_PEAK_TFLOPS, 4)
+                roof["note"] = ("dense 3x3 on v_mfma_f32_16x16x32_bf16 from an exact 3-way bf16 split of both operands "
+                                "(6 products, fp32 accumulate; as accurate as the fp32 chain vs float64, "
+                                "profiles/r03_accuracy_split_vs_f32dense.txt); pointwise / strided convs on the fp32 MFMA")
         line = {
             "metric": "16 kHz frames/sec (STFT->mask->iSTFT)",
             "value": round(value, 1),

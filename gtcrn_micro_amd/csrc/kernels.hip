@@ -182,6 +182,11 @@ constexpr bool kSplitDense = false;     // A/B reference: the round-2 fp32-MFMA 
 #else                                   // python tools/ab_bench.py; profiles/r03_ab_split_dense.txt)
 constexpr bool kSplitDense = true;
 #endif
+#ifdef GT_EXP
+constexpr bool kSplitDe3 = false;       // current A/B (tools/ab_bench.py): de_convs.3 on the fp32 MFMA as in round 2
+#else
+constexpr bool kSplitDe3 = true;
+#endif
 struct Split3 {
     bf16x4 h, m, l;
 };
@@ -2111,11 +2116,104 @@ constexpr int DEC_ZS = 12;                                        // floats per 
 // parameters resident in LDS: the three blocks WITHOUT their dense matrices, then the de_convs.3/4 segment; the dense
 // 3x3 of ONE block at a time sits in the stage buffer DN (the bf16 planes of all three would not fit: 45 KB), refilled
 // from L2 while the previous block's TRALite runs
-constexpr int DL_DE = 3 * GB_SIZE;                                // de_convs.3/4: D_DE3_AE .. D_BS_W
-constexpr int DL_DN = DL_DE + (D_BS_W - D_DE3_AE);                // dense stage buffer
+constexpr int DL_DE3M = 3 * GB_SIZE;                              // de_convs.3 matrices: 9 plane matrices (split) or the 5 fp32 ones
+constexpr int DL_DE = DL_DE3M + DE3_16_MATS * 256;                // de_convs.3 bias / slope, de_convs.4: D_DE3_B .. D_BS_W
+constexpr int DL_DN = DL_DE + (D_BS_W - D_DE3_B);                 // dense stage buffer
 constexpr int DL_SIZE = DL_DN + DN16_SIZE;
-__device__ __forceinline__ constexpr int dl(int d_off) { return DL_DE + d_off - D_DE3_AE; }   // D_* offset -> LDS offset
-static_assert(DL_DE % 4 == 0 && DL_DN % 4 == 0 && DN16_SIZE >= 9 * 256 && GBD_SIZE % 4 == 0 && D_DN16 % 4 == 0, "16B carve");
+// D_* offset -> LDS offset (the fp32 de_convs.3 matrices sit at DL_DE3M when the split form is off)
+__device__ __forceinline__ constexpr int dl(int d_off) { return d_off >= D_DE3_B ? DL_DE + d_off - D_DE3_B : DL_DE3M + d_off - D_DE3_AE; }
+static_assert(DL_DE % 4 == 0 && DL_DN % 4 == 0 && DN16_SIZE >= 9 * 256 && GBD_SIZE % 4 == 0 && D_DN16 % 4 == 0 &&
+              D_DE3_16 % 4 == 0 && D_DE3_B == D_DE3_AE + 5 * 256, "16B carve");
+// the decoder's parameter segment -> LDS (everything but the blocks' dense matrices, which go through the stage buffer)
+template <bool SPLIT>
+__device__ __forceinline__ void copy_dec_params(float* sP, const float* PF, int tid, int nthr) {
+#pragma unroll
+    for (int j = 0; j < 3; ++j) copy_params(sP + j * GB_SIZE, PF + P_DEC + D_BLK + j * GBD_SIZE, GB_SIZE, tid, nthr);
+    if constexpr (SPLIT) copy_params(sP + DL_DE3M, PF + P_DEC + D_DE3_16, DE3_16_MATS * 256, tid, nthr);
+    else copy_params(sP + DL_DE3M, PF + P_DEC + D_DE3_AE, 5 * 256, tid, nthr);
+    copy_params(sP + DL_DE, PF + P_DEC + D_DE3_B, D_BS_W - D_DE3_B, tid, nthr);
+}
+
+// de_convs.3 = ConvTranspose2d(16,16,(1,5),stride (1,2)) in gather form for the wave's tiles: even output bin 2m takes
+// taps k = 0, 2, 4 from input bins m+1, m, m-1, odd bin 2m+1 takes k = 1, 3 from m+1, m.  The input image (records of
+// x, zero pad columns) is in LDS; rec0[i] = float offset of tile i's own record (slot group 0).
+// SPLIT: on v_mfma_f32_16x16x32_bf16 like the dense 3x3 (x stored as three bf16 planes): K-chunk 0 = bins (m+1 | m)
+// feeds the even AND the odd outputs (matrices E0, O0), K-chunk 1 = (m-1 | -) the even ones (E1): 18 instructions of
+// 16 cycles instead of 20 of 32.  Otherwise: five fp32 slot matrices, the centre tap from the registers.
+template <int TPW, bool SPLIT, bool Q, int RS>
+__device__ __forceinline__ void de_conv3_tiles(const float* sW, const int (&rec0)[TPW], const f32x4 (&x)[TPW],
+                                               const float* m3, const f32x4 Bv, int n, int g, f32x4 (&ae)[TPW],
+                                               f32x4 (&ao)[TPW]) {
+#pragma unroll
+    for (int i = 0; i < TPW; ++i) { ae[i] = Bv; ao[i] = Bv; }
+    if constexpr (SPLIT) {
+        int gq = g;
+        asm volatile("" : "+v"(gq));
+        const bool second = gq >= 2;
+        const int q16 = 4 * (gq & 1);
+#pragma unroll
+        for (int cc = 0; cc < 2; ++cc) {
+            bf16x8 pe[3], po[3];
+#pragma unroll
+            for (int p = 0; p < 3; ++p) {
+                pe[p] = *reinterpret_cast<const bf16x8*>(m3 + ((cc == 0 ? 0 : 2) * 3 + p) * 256 + arow(n, g));
+                if (cc == 0) po[p] = *reinterpret_cast<const bf16x8*>(m3 + (1 * 3 + p) * 256 + arow(n, g));
+            }
+#pragma unroll
+            for (int i = 0; i < TPW; ++i) {
+                // chunk 0: lane groups g < 2 read bin m+1, g >= 2 bin m; chunk 1: g < 2 bin m-1, g >= 2 zero weights
+                const int src = rec0[i] + (cc == 0 ? (second ? 0 : RS) : (second ? 0 : -RS)) + q16;
+                bf16x8 bp[3];
+#pragma unroll
+                for (int p = 0; p < 3; ++p) bp[p] = *reinterpret_cast<const bf16x8*>(sW + src + 8 * p);
+                ae[i] = mfma_bf(pe[0], bp[2], ae[i]);
+                ae[i] = mfma_bf(pe[2], bp[0], ae[i]);
+                ae[i] = mfma_bf(pe[1], bp[1], ae[i]);
+                ae[i] = mfma_bf(pe[0], bp[1], ae[i]);
+                ae[i] = mfma_bf(pe[1], bp[0], ae[i]);
+                ae[i] = mfma_bf(pe[0], bp[0], ae[i]);
+                if (cc == 0) {
+                    ao[i] = mfma_bf(po[0], bp[2], ao[i]);
+                    ao[i] = mfma_bf(po[2], bp[0], ao[i]);
+                    ao[i] = mfma_bf(po[1], bp[1], ao[i]);
+                    ao[i] = mfma_bf(po[0], bp[1], ao[i]);
+                    ao[i] = mfma_bf(po[1], bp[0], ao[i]);
+                    ao[i] = mfma_bf(po[0], bp[0], ao[i]);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    } else {
+        const float* Ae = m3 + arow(n, g);
+        const float* Ao = m3 + 3 * 256 + arow(n, g);
+        // tap major over the three input bins f+1, f, f-1: the five slot matrices are read once per wave
+        {
+            const f32x4 A0 = ld4(Ae), A1 = ld4(Ao);
+#pragma unroll
+            for (int i = 0; i < TPW; ++i) {
+                const f32x4 xp = ld4(sW + rec0[i] + 4 * g + RS);   // input bin f+1
+                ae[i] = mm1<Q>(A0, xp, ae[i]);
+                ao[i] = mm1<Q>(A1, xp, ao[i]);
+            }
+        }
+        {
+            const f32x4 A0 = ld4(Ae + 256), A1 = ld4(Ao + 256);
+#pragma unroll
+            for (int i = 0; i < TPW; ++i) {
+                ae[i] = mm1<Q>(A0, x[i], ae[i]);
+                ao[i] = mm1<Q>(A1, x[i], ao[i]);
+            }
+        }
+        {
+            const f32x4 A0 = ld4(Ae + 512);
+#pragma unroll
+            for (int i = 0; i < TPW; ++i) {
+                const f32x4 xm = ld4(sW + rec0[i] + 4 * g - RS);   // input bin f-1
+                ae[i] = mm1<Q>(A0, xm, ae[i]);
+            }
+        }
+    }
+}
 template <int RW, int NS, bool MS>
 struct DecLds {
     static constexpr int RS = RS_WIDE;                            // record pitch of the h image W (see pl(); split planes)
@@ -2209,9 +2307,8 @@ __global__ __launch_bounds__(NTHR) void k_decoder(const float* __restrict__ xg, 
         }
     };
     dense_fetch(0);
-#pragma unroll
-    for (int j = 0; j < 3; ++j) copy_params(sP + j * GB_SIZE, PF + P_DEC + D_BLK + j * GBD_SIZE, GB_SIZE, tid, NTHR);
-    copy_params(sP + DL_DE, PF + P_DEC + D_DE3_AE, D_BS_W - D_DE3_AE, tid, NTHR);
+    constexpr bool SPLIT3 = SPLIT && kSplitDe3;     // de_convs.3 in the split form too
+    copy_dec_params<SPLIT3>(sP, PF, tid, NTHR);
     if (tid < 48) sI[tid] = PI[I_DEC_BLK + tid];
     for (int f = tid; f < NBINS; f += NTHR) st4(sBS + f * 4, ld4(PF + P_DEC + D_BS_TAB + f * 4));
     if (tid < 4) sM[2 * RW * F0 + tid] = 0.f;
@@ -2327,8 +2424,13 @@ __global__ __launch_bounds__(NTHR) void k_decoder(const float* __restrict__ xg, 
         }, std::integral_constant<int, 2 * TPW>{});
         // ---- de_convs.3: gather form; input image in sW rows (pad columns are zero).  Every wave is
         // past the last block's tap reads (they precede that block's 2nd barrier), so sW is free.
+        int rec3[TPW];
 #pragma unroll
-        for (int i = 0; i < TPW; ++i) st4(sW + o35<RS, LD::RWI - RW, LD::PT>(tt, i, g), x[i]);
+        for (int i = 0; i < TPW; ++i) {
+            rec3[i] = o35<RS, LD::RWI - RW, LD::PT>(tt, i, 0);
+            if constexpr (SPLIT3) st_split(sW, rec3[i], g, x[i]);
+            else st4(sW + rec3[i] + 4 * g, x[i]);
+        }
         STAMP(SS, 9)
         wg_barrier();
         STAMP(SS, 10)
@@ -2336,38 +2438,8 @@ __global__ __launch_bounds__(NTHR) void k_decoder(const float* __restrict__ xg, 
         {
             const f32x4 Bv = ld4(sP + dl(D_DE3_B) + 4 * g);
             const float a = sP[dl(D_DE3_S)] - 1.0f;
-            // even output 2m: k=0 <- x[m+1], k=2 <- x[m], k=4 <- x[m-1]; odd 2m+1: k=1 <- x[m+1], k=3 <- x[m]
-            const float* Ae = sP + dl(D_DE3_AE) + arow(n, g);
-            const float* Ao = sP + dl(D_DE3_AO) + arow(n, g);
-            // tap major over the three input bins f+1, f, f-1: the five slot matrices are read once per wave
             f32x4 ae[TPW], ao[TPW];
-#pragma unroll
-            for (int i = 0; i < TPW; ++i) { ae[i] = Bv; ao[i] = Bv; }
-            {
-                const f32x4 A0 = ld4(Ae), A1 = ld4(Ao);
-#pragma unroll
-                for (int i = 0; i < TPW; ++i) {
-                    const f32x4 xp = ld4(sW + o35<RS, LD::RWI - RW, LD::PT>(tt, i, g) + RS);   // input bin f+1
-                    ae[i] = mm1<Q>(A0, xp, ae[i]);
-                    ao[i] = mm1<Q>(A1, xp, ao[i]);
-                }
-            }
-            {
-                const f32x4 A0 = ld4(Ae + 256), A1 = ld4(Ao + 256);
-#pragma unroll
-                for (int i = 0; i < TPW; ++i) {
-                    ae[i] = mm1<Q>(A0, x[i], ae[i]);
-                    ao[i] = mm1<Q>(A1, x[i], ao[i]);
-                }
-            }
-            {
-                const f32x4 A0 = ld4(Ae + 512);
-#pragma unroll
-                for (int i = 0; i < TPW; ++i) {
-                    const f32x4 xm = ld4(sW + o35<RS, LD::RWI - RW, LD::PT>(tt, i, g) - RS);   // input bin f-1
-                    ae[i] = mm1<Q>(A0, xm, ae[i]);
-                }
-            }
+            de_conv3_tiles<TPW, SPLIT3, Q, RS>(sW, rec3, x, sP + DL_DE3M, Bv, n, g, ae, ao);
             const f32x4 A4 = ld4(sP + dl(D_DE4_A) + arow(n, g));
 #pragma unroll
             for (int i = 0; i < TPW; ++i) {
@@ -2679,9 +2751,8 @@ __global__ __launch_bounds__(NTHR) void k_stream_ms(const float* __restrict__ sp
     dense_fetch(0);
     static_assert(P_GTCN == P_ENC + ENC_SIZE && (ENC_SIZE + 2 * GTCN_SIZE) % 4 == 0, "encoder + GTCN segments are contiguous");
     copy_params(sPE, PF + P_ENC, ENC_SIZE + 2 * GTCN_SIZE, tid, NTHR);
-#pragma unroll
-    for (int j = 0; j < 3; ++j) copy_params(sPD + j * GB_SIZE, PF + P_DEC + D_BLK + j * GBD_SIZE, GB_SIZE, tid, NTHR);
-    copy_params(sPD + DL_DE, PF + P_DEC + D_DE3_AE, D_BS_W - D_DE3_AE, tid, NTHR);
+    constexpr bool SPLIT3 = SPLIT && kSplitDe3;
+    copy_dec_params<SPLIT3>(sPD, PF, tid, NTHR);
     for (int i = tid; i < P_INTS - ENC_I_SKIP; i += NTHR) sI[i] = PI[i < I_BS_LO ? i : i + ENC_I_SKIP];
     for (int f = tid; f < NBINS; f += NTHR) st4(sBS + f * 4, ld4(PF + P_DEC + D_BS_TAB + f * 4));
     if (tid < NS * 48) {
@@ -2939,31 +3010,17 @@ __global__ __launch_bounds__(NTHR) void k_stream_ms(const float* __restrict__ sp
         s0o = ld4(sEN0 + o0 + (tt.ff[0] < 32 ? 16 : 0));
     }, [] {});
     // ---- de_convs.3 (gather form) + de_convs.4 (scatter form)
-    st4(sW + o35<RS, 0>(tt, 0, g), x[0]);
+    const int rec3[1] = {o35<RS, 0>(tt, 0, 0)};
+    if constexpr (SPLIT3) st_split(sW, rec3[0], g, x[0]);
+    else st4(sW + rec3[0] + 4 * g, x[0]);
     wg_barrier();
     f32x4 ze, zo;
     {
         const f32x4 Bv = ld4(sPD + dl(D_DE3_B) + 4 * g);
         const float a = sPD[dl(D_DE3_S)] - 1.0f;
-        const float* Ae = sPD + dl(D_DE3_AE) + arow(n, g);
-        const float* Ao = sPD + dl(D_DE3_AO) + arow(n, g);
-        f32x4 ae = Bv, ao = Bv;
-        {
-            const f32x4 A0 = ld4(Ae), A1 = ld4(Ao);
-            const f32x4 xp = ld4(sW + o35<RS, 0>(tt, 0, g) + RS);
-            ae = mm1<false>(A0, xp, ae);
-            ao = mm1<false>(A1, xp, ao);
-        }
-        {
-            const f32x4 A0 = ld4(Ae + 256), A1 = ld4(Ao + 256);
-            ae = mm1<false>(A0, x[0], ae);
-            ao = mm1<false>(A1, x[0], ao);
-        }
-        {
-            const f32x4 A0 = ld4(Ae + 512);
-            const f32x4 xm = ld4(sW + o35<RS, 0>(tt, 0, g) - RS);
-            ae = mm1<false>(A0, xm, ae);
-        }
+        f32x4 ae1[1], ao1[1];
+        de_conv3_tiles<1, SPLIT3, false, RS>(sW, rec3, x, sPD + DL_DE3M, Bv, n, g, ae1, ao1);
+        const f32x4 ae = ae1[0], ao = ao1[0];
         const f32x4 A4 = ld4(sPD + dl(D_DE4_A) + arow(n, g));
         f32x4 e2 = prelu4(ae, a), o2 = prelu4(ao, a);
         e2 = e2 + s0e;

@@ -91,7 +91,11 @@ constexpr int DN16_CHUNKS = 5;
 constexpr int DN16_MATS = DN16_CHUNKS * 3;
 constexpr int DN16_SIZE = DN16_MATS * 256;
 constexpr int D_DN16 = D_BS_TAB + NBINS * 4;       // 3 x DN16_SIZE
-constexpr int DEC_SIZE = D_DN16 + 3 * DN16_SIZE;
+// de_convs.3 (gather form) in the same split form: K-chunk 0 = input bins (m+1 | m), K-chunk 1 = (m-1 | nothing);
+// matrices E0 (even outputs, taps k = 0 | 2), O0 (odd outputs, k = 1 | 3), E1 (even, k = 4 | zero), 3 planes each
+constexpr int DE3_16_MATS = 9;
+constexpr int D_DE3_16 = D_DN16 + 3 * DN16_SIZE;   // [E0, O0, E1][3 planes][256]
+constexpr int DEC_SIZE = D_DE3_16 + DE3_16_MATS * 256;
 
 // ---- whole float buffer ------------------------------------------------------
 constexpr int P_ENC = 0;

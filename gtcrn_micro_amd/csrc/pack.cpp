@@ -221,6 +221,7 @@ static void swizzle_matrices(float* F) {
     for (int a = 0; a < 2; ++a) swizzle_matrix(D + D_DE3_AO + a * 256);
     swizzle_matrix(D + D_DE4_A);
     for (int m = 0; m < 3 * DN16_MATS; ++m) swizzle_matrix(D + D_DN16 + m * 256);
+    for (int m = 0; m < DE3_16_MATS; ++m) swizzle_matrix(D + D_DE3_16 + m * 256);
 }
 
 // float -> bfloat16 bits, round to nearest even (finite inputs)
@@ -245,17 +246,22 @@ static void split3(float w, uint16_t out[3]) {
     out[2] = bf16_rne(r2);
 }
 
+// three bf16 planes of ONE [16 rows][32 k] A-operand matrix whose K halves are the (unswizzled) fp32 slot matrices lo16
+// (k < 16) and hi16 (k >= 16; nullptr = zero): out = [3 planes][256 "floats"]
+static void pack_planes_pair(const float* lo16, const float* hi16, float* out) {
+    uint16_t* H = reinterpret_cast<uint16_t*>(out);
+    for (int o = 0; o < 16; ++o)
+        for (int k = 0; k < 32; ++k) {
+            const float* m = (k >> 4) ? hi16 : lo16;
+            uint16_t pl3[3] = {0, 0, 0};
+            if (m) split3(m[o * 16 + (k & 15)], pl3);
+            for (int p = 0; p < 3; ++p) H[(p * 256) * 2 + o * 32 + k] = pl3[p];
+        }
+}
 // the bf16 planes of one decoder block's dense 3x3 (layout.h, D_DN16) from its (unswizzled) fp32 slot matrices
 static void pack_dense_planes(const float* dn32, float* dn16) {
-    uint16_t* H = reinterpret_cast<uint16_t*>(dn16);
     for (int c = 0; c < DN16_CHUNKS; ++c)
-        for (int o = 0; o < 16; ++o)
-            for (int k = 0; k < 32; ++k) {
-                const int tap = 2 * c + (k >> 4), i = k & 15;
-                uint16_t pl3[3] = {0, 0, 0};
-                if (tap < 9) split3(dn32[tap * 256 + o * 16 + i], pl3);
-                for (int p = 0; p < 3; ++p) H[((c * 3 + p) * 256) * 2 + o * 32 + k] = pl3[p];
-            }
+        pack_planes_pair(dn32 + (2 * c) * 256, 2 * c + 1 < 9 ? dn32 + (2 * c + 1) * 256 : nullptr, dn16 + c * 3 * 256);
 }
 
 }  // namespace
@@ -371,6 +377,11 @@ int pack_params(const float* params, long n, float* F, int* I, std::string& err)
         }
         D[D_DE3_S] = *c.take(1);
         perm[8] = identity();
+        // the split form (layout.h D_DE3_16): E0 = even outputs from bins (m+1 | m), O0 = odd outputs from the same two
+        // bins, E1 = even outputs from bin m-1
+        pack_planes_pair(D + D_DE3_AE + 0 * 256, D + D_DE3_AE + 1 * 256, D + D_DE3_16 + 0 * 3 * 256);
+        pack_planes_pair(D + D_DE3_AO + 0 * 256, D + D_DE3_AO + 1 * 256, D + D_DE3_16 + 1 * 3 * 256);
+        pack_planes_pair(D + D_DE3_AE + 2 * 256, nullptr, D + D_DE3_16 + 2 * 3 * 256);
     }
     // ---- de_convs.4: ConvTranspose2d(16,2,(1,5),stride 2) + BN (+Tanh), scatter form ----------------
     {
