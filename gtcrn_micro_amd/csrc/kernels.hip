@@ -225,6 +225,21 @@ __device__ __forceinline__ f32x4 ld_split(const float* img, int rec, int g) {
 __device__ __forceinline__ f32x4 mfma_bf(const bf16x8 a, const bf16x8 b, const f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
 }
+// The int8 / fp16 variant (Q) takes the same road with ONE plane: its activations are fp16 numbers, so h lives in LDS as
+// fp16 records (the first 32 bytes of the 96-byte record) and the dense 3x3 is five v_mfma_f32_16x16x32_f16 per tile --
+// no conversion per matrix instruction (round 2 kept fp32 records and converted both operands at every one of nine
+// 16x16x16 instructions).  The weights are the packer's fp16 K-chunk matrices (pack.cpp quantize_packed).
+typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ void st_half(float* img, int rec, int g, const f32x4 v) {
+    *reinterpret_cast<h16x4*>(img + rec + 2 * g) = to_h4(v);
+}
+__device__ __forceinline__ f32x4 ld_half(const float* img, int rec, int g) {
+    const h16x4 h = *reinterpret_cast<const h16x4*>(img + rec + 2 * g);
+    f32x4 r = {(float)h[0], (float)h[1], (float)h[2], (float)h[3]};
+    return r;
+}
+// record format of a dense block's h image
+enum ImgFmt { IMG_F32 = 0, IMG_SPLIT3 = 1, IMG_HALF = 2 };
 
 // Hand-off tensors (en0..en4, gtcn1, gtcn2+en4) in HBM: fp32 records, or -- in the Q variant, whose activations are
 // fp16 numbers anyway -- fp16 records of half the size in the same buffers (element offsets are unchanged: the
@@ -634,12 +649,14 @@ constexpr int RING_SET = 3 * 2 * 35 * 16;   // floats of one stream's three 2-ro
 // `hook` runs right after the depth-conv phase (register pressure is past its peak there, and two
 // barrier intervals of work follow): the decoder uses it to request inputs of later phases early.
 // history ring [2 frames][33][16] (older frame first) -> image rows 0, 1 (the pad columns are zeroed per chunk)
-template <int RS, int PT = 35, bool SPLIT = false>
+template <int RS, int PT = 35, int FMT = IMG_F32>
 __device__ __forceinline__ void ring_to_image(float* sW, const float* ring, int tid) {
     if (tid < 2 * 33 * 4) {
         const int row = tid >= 132 ? 1 : 0, r = tid - row * 132;
         const f32x4 v = ld4(ring + (row * 33 + (r >> 2)) * 16 + (r & 3) * 4);
-        if constexpr (SPLIT) st_split(sW, (row * PT + 1 + (r >> 2)) * RS, r & 3, v);   // the ring is fp32, the image split
+        // (the ring is fp32 whatever the image holds: both conversions are exact)
+        if constexpr (FMT == IMG_SPLIT3) st_split(sW, (row * PT + 1 + (r >> 2)) * RS, r & 3, v);
+        else if constexpr (FMT == IMG_HALF) st_half(sW, (row * PT + 1 + (r >> 2)) * RS, r & 3, v);
         else st4(sW + pl<RS>(row * PT + 1 + (r >> 2), r & 3), v);
     }
 }
@@ -650,7 +667,9 @@ __device__ __forceinline__ void gtconv_block(f32x4 (&x)[TPW], const Tiles<TPW>& 
     static_assert(!MS || TPW == 1, "multi-stream mode runs one tile per wave");
     // SPLIT: the dense 3x3 on the 16-bit matrix pipe; the image W then holds h as three bf16 planes per position
     constexpr bool SPLIT = DENSE && !Q && kSplitDense;
-    static_assert(!SPLIT || RS == RS_WIDE, "the split image has 96-byte records");
+    constexpr bool HALF = DENSE && Q && !MS;              // the fp16 variant: h as fp16 records, K = 32 chunks
+    constexpr int FMT = SPLIT ? IMG_SPLIT3 : (HALF ? IMG_HALF : IMG_F32);
+    static_assert(!(SPLIT || HALF) || RS == RS_WIDE, "the split / half image has 96-byte records");
     const int n = L.n, g = L.g;
     // Image rows (not MS): rows 0, 1 hold the two frames BEFORE the chunk -- copied from the block's history ring at
     // the top of the block -- and row 2 + tl holds frame tl of the chunk, so a temporal tap is always "own record minus
@@ -671,7 +690,7 @@ __device__ __forceinline__ void gtconv_block(f32x4 (&x)[TPW], const Tiles<TPW>& 
         else return b0 - back * PT * RS;
     };
     if constexpr (!MS) {
-        if (c.sHtop) ring_to_image<RS, PT, SPLIT>(c.sW, c.sHtop, L.tid);
+        if (c.sHtop) ring_to_image<RS, PT, FMT>(c.sW, c.sHtop, L.tid);
     }
     const float a1 = c.pb[GB_SLOPE] - 1.0f, a2 = c.pb[GB_SLOPE + 1] - 1.0f;
     // ---- point_conv1 + BN + PReLU; h lives only in the LDS image from here on (its centre tap and the
@@ -686,6 +705,7 @@ __device__ __forceinline__ void gtconv_block(f32x4 (&x)[TPW], const Tiles<TPW>& 
         for (int i = 0; i < TPW; ++i) {
             const f32x4 hv = rq<Q>(prelu4(h[i], a1));
             if constexpr (SPLIT) st_split(c.sW, b0s[i] - 4 * g, g, hv);
+            else if constexpr (HALF) st_half(c.sW, b0s[i] - 4 * g, g, hv);
             else st4(c.sW + b0s[i], hv);
             if constexpr (MS) {
                 if (c.g_hist && tt.tl[i] < c.nfr) st4(c.g_hist, hv);     // the stream's new history row (replaces frame t-2)
@@ -785,6 +805,39 @@ __device__ __forceinline__ void gtconv_block(f32x4 (&x)[TPW], const Tiles<TPW>& 
             mm16<TPW, Q>(A2, acc, x);                         // point_conv2: the tiles' chains interleaved
 #pragma unroll
             for (int i = 0; i < TPW; ++i) st4(c.sS + tt.pp(i) * RSS + 4 * g, x[i] * x[i]);
+        } else if constexpr (HALF) {
+            // the fp16 variant: same K-chunks, one plane: per chunk one weight read per wave, one h read and ONE
+            // v_mfma_f32_16x16x32_f16 per tile
+            f32x4 acc[TPW];
+            int rec0[TPW];
+#pragma unroll
+            for (int i = 0; i < TPW; ++i) { acc[i] = Bd; rec0[i] = b0s[i] - 4 * g; }
+            int gq = g;
+            asm volatile("" : "+v"(gq));
+            const bool second = gq >= 2;
+            const int q16 = 4 * (gq & 1);
+#pragma unroll
+            for (int cc = 0; cc < DN16_CHUNKS; ++cc) {
+                const int tA = 2 * cc, tB = 2 * cc + 1 < 9 ? 2 * cc + 1 : 8;
+                const h16x8 ap = *reinterpret_cast<const h16x8*>(c.gA + cc * 256 + arow(n, g));
+#pragma unroll
+                for (int i = 0; i < TPW; ++i) {
+                    const int ra = rec0[i] - (tA / 3) * PT * RS + (1 - tA % 3) * RS, rb = rec0[i] - (tB / 3) * PT * RS + (1 - tB % 3) * RS;
+                    const h16x8 bp = *reinterpret_cast<const h16x8*>(c.sW + (second ? rb : ra) + q16);
+                    acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ap, bp, acc[i], 0, 0, 0);
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < TPW; ++i) {
+                acc[i] = rq<Q>(prelu4(acc[i], a2));
+                x[i] = keep * x[i] + B2;
+            }
+            mm16<TPW, Q>(A2, acc, x);
+#pragma unroll
+            for (int i = 0; i < TPW; ++i) {
+                x[i] = rq<Q>(x[i]);
+                st4(c.sS + tt.pp(i) * RSS + 4 * g, x[i] * x[i]);
+            }
         } else {
             // dense transposed 3x3, tap major: each of the nine 16x16 slot matrices is read from LDS once per wave
             // (not once per tile) and feeds one MFMA chain per tile -- TPW independent accumulator chains
@@ -848,6 +901,7 @@ __device__ __forceinline__ void gtconv_block(f32x4 (&x)[TPW], const Tiles<TPW>& 
             const int q = L.tid - (NTHR - 2 * 33 * 4), row = q >= 132 ? 1 : 0, r = q - row * 132;
             float* dst = c.sHk + (row * 33 + (r >> 2)) * 16 + (r & 3) * 4;
             if constexpr (SPLIT) st4(dst, ld_split(c.sW, ((c.nfr + row) * PT + 1 + (r >> 2)) * RS, r & 3));   // exact
+            else if constexpr (HALF) st4(dst, ld_half(c.sW, ((c.nfr + row) * PT + 1 + (r >> 2)) * RS, r & 3));
             else st4(dst, ld4(c.sW + pl<RS>((c.nfr + row) * PT + 1 + (r >> 2), r & 3)));
         }
     }
@@ -892,7 +946,7 @@ __device__ __forceinline__ void gtconv_block(f32x4 (&x)[TPW], const Tiles<TPW>& 
     // rows 0, 1 of the image are free (this block's ring save, which may read row 1, is behind the barrier): the next
     // block's history goes there now, off the critical path
     if constexpr (!MS) {
-        if (c.sHnext) ring_to_image<RS, PT, SPLIT>(c.sW, c.sHnext, L.tid);
+        if (c.sHnext) ring_to_image<RS, PT, FMT>(c.sW, c.sHnext, L.tid);
     }
     hook3();   // (k_stream_ms: the next block's history image, its taps are all read)
     // ---- step 2: one thread per (frame, output channel): causal depthwise conv1d (k=3) over the energies,
@@ -2287,9 +2341,11 @@ __global__ __launch_bounds__(NTHR) void k_decoder(const float* __restrict__ xg, 
     // w, w + 11; no registers are held while the data is in flight -- a register-staged copy spilled).  A DMA is a
     // pending LDS write on the vector-memory counter: gtconv_block's closing barrier (and the prologue's) waits for
     // vmcnt(0) in front of it; the first reader sits one more barrier later.
-    constexpr int DN_PIECES = (SPLIT ? DN16_SIZE : 9 * 256) / 256;
+    // (Q && !MS: the fp16 K-chunk matrices the packer put at the head of the block's D_DN16 slot in the quantised buffer)
+    constexpr bool HALFW = Q && !MS;
+    constexpr int DN_PIECES = SPLIT ? DN16_SIZE / 256 : (HALFW ? DN16_CHUNKS : 9);
     auto dense_fetch = [&](int j) {
-        const float* src = PF + P_DEC + (SPLIT ? D_DN16 + j * DN16_SIZE : D_BLK + j * GBD_SIZE + GB_DN_A);
+        const float* src = PF + P_DEC + ((SPLIT || HALFW) ? D_DN16 + j * DN16_SIZE : D_BLK + j * GBD_SIZE + GB_DN_A);
         int lz = L.lane;
         asm volatile("" : "+v"(lz));      // per-lane source addresses recomputed per call, not hoisted and kept live
         // (inline asm, not __builtin_amdgcn_global_load_lds: with the builtin the compiler treats every later LDS read as a

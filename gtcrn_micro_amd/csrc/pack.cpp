@@ -473,6 +473,43 @@ void quant_gtconv(float* B, bool dense) {
 }
 }  // namespace
 
+namespace {
+// IEEE binary16 bits of a float that IS a binary16 number (round_to_half's output): exact, no rounding involved
+uint16_t half_bits_exact(float x) {
+    uint32_t u;
+    std::memcpy(&u, &x, 4);
+    const uint16_t sign = (uint16_t)((u >> 16) & 0x8000u);
+    const uint32_t a = u & 0x7FFFFFFFu;
+    if (a == 0) return sign;
+    if (a >= 0x7F800000u) return (uint16_t)(sign | 0x7C00u | ((a & 0x007FFFFFu) ? 0x200u : 0u));
+    const int e = (int)(a >> 23) - 127;                       // unbiased exponent
+    const uint32_t man = (a & 0x007FFFFFu) | 0x00800000u;     // 24-bit significand
+    if (e >= -14) return (uint16_t)(sign | (uint32_t)((e + 15) << 10) | ((man >> 13) & 0x3FFu));
+    return (uint16_t)(sign | (man >> (13 + (-14 - e))));      // subnormal half: shift the significand further down
+}
+// The fp16 form of one decoder block's dense 3x3 for v_mfma_f32_16x16x32_f16 (kernels.hip, the Q variant's dense
+// phase): 5 K-chunks (taps 2c | 2c+1) of a [16 rows][32 k] fp16 matrix, 256 "floats" each, written over the head of
+// the block's D_DN16 slot (the bf16 planes there belong to the fp32 model and are not read in this variant).
+// dn32: the block's nine quantised fp32 slot matrices, ALREADY row-swizzled (swizzle_matrix).
+void pack_dense_half(const float* dn32, float* dst) {
+    for (int c = 0; c < DN16_CHUNKS; ++c) {
+        uint16_t* H = reinterpret_cast<uint16_t*>(dst + c * 256);
+        for (int o = 0; o < 16; ++o)
+            for (int k = 0; k < 32; ++k) {
+                const int tap = 2 * c + (k >> 4), i = k & 15;
+                float w = 0.f;
+                if (tap < 9) w = dn32[tap * 256 + o * 16 + (((o >> 2) & 1) ? (i ^ 8) : i)];     // undo the swizzle
+                H[o * 32 + k] = half_bits_exact(w);
+            }
+        // same row swizzle as every A-operand matrix (on the 16 x 16-float view)
+        float* M = dst + c * 256;
+        for (int n = 0; n < 16; ++n)
+            if ((n >> 2) & 1)
+                for (int q = 0; q < 8; ++q) std::swap(M[n * 16 + q], M[n * 16 + 8 + q]);
+    }
+}
+}  // namespace
+
 // In place on the packed float buffer (after BatchNorm folding, which is what the exported graph holds): every
 // conv / linear weight becomes fp16(int8 * per-output-channel scale); biases, PReLU slopes and the KEEP masks stay.
 void quantize_packed(float* F) {
@@ -489,7 +526,10 @@ void quantize_packed(float* F) {
         quant_group(T + TCN_DW, 16, 1, 1, 0, 3, 16);
         quant_group(T + TCN_A3, 16, 16, 1, 0, 16, 1);
     }
-    for (int j = 0; j < 3; ++j) quant_gtconv(D + D_BLK + j * GBD_SIZE, true);
+    for (int j = 0; j < 3; ++j) {
+        quant_gtconv(D + D_BLK + j * GBD_SIZE, true);
+        pack_dense_half(D + D_BLK + j * GBD_SIZE + GB_DN_A, D + D_DN16 + j * DN16_SIZE);
+    }
     quant_group(D + D_DE3_AE, 16, 16, 5, 256, 16, 1);            // AE (3 matrices) + AO (2) share the output channels
     quant_group(D + D_DE4_A, 2, 80, 5, 16, 16, 1);               // rows o*5+k: output channel o owns five rows
     quant_group(D + D_BS_W, 192, ERB_MAXBS, 1, 0, ERB_MAXBS, 1);

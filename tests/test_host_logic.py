@@ -277,6 +277,18 @@ def test_quantised_weight_contract_on_host():
         assert np.array_equal(packed, packed.astype(np.float16).astype(np.float32))        # fp16 values
         assert not np.array_equal(packed, np.sort(np.concatenate(
             [F[P_DEC + GB_DN_A + t * 256 + o * 16: P_DEC + GB_DN_A + t * 256 + o * 16 + 16] for t in range(9)])))
+    # the same matrices as fp16 K-chunks for v_mfma_f32_16x16x32_f16 (chunk c = taps 2c | 2c+1; written over the head
+    # of the block's D_DN16 slot in the quantised buffer): exactly the quantised fp32 values, zero in the spare half
+    from tests.slot_emulator import K as KL, _mat as unsw
+    for j in range(3):
+        for c in range(5):
+            m = unsw(Fq, P_DEC + KL["D_DN16"] + j * KL["DN16_SIZE"] + c * 256)
+            hv = np.ascontiguousarray(m).view(np.float16).reshape(16, 32).astype(np.float32)
+            for half in range(2):
+                tap = 2 * c + half
+                want = (unsw(Fq, P_DEC + KL["D_BLK"] + j * KL["GBD_SIZE"] + KL["GB_DN_A"] + tap * 256) if tap < 9
+                        else np.zeros((16, 16), np.float32))
+                assert np.array_equal(hv[:, half * 16:half * 16 + 16], want), (j, c, half)
     # en_conv1 (Conv2d 16->16, 5 taps, identity slot order): E_EN1_A[k][o][i] == W'[o,i,0,k]
     E_EN1_A = 768 + 12 + 276
     w1 = port.w["encoder.en_convs.1.conv"].numpy()
