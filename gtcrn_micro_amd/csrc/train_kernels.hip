@@ -679,13 +679,17 @@ __device__ __forceinline__ float act_bwd(float z, float g, int act, float sl, fl
 }
 
 // backward, pass 1: S1 = sum dz, S2 = sum dz * xhat, S3 = sum da * min(z, 0) (PReLU slope gradient)
-template <int V>
+// FMT >= 0: the storage formats as a compile-time constant (FMT = bf * 4 + ybf): with the run-time flags every load sits
+// behind its own wave-uniform branch, i.e. in its own basic block, and the U strides of loads below are issued one at
+// a time after all (this read-only pass ran at 3.5 TB/s); FMT < 0: run-time flags (the odd channel counts)
+template <int V, int FMT = -1>
 __global__ __launch_bounds__(NT) void k_bn_bwd_reduce(const float* __restrict__ da, const float* __restrict__ y,
                                                      long total, int C, const float* __restrict__ stats,
                                                      const float* __restrict__ gamma, const float* __restrict__ beta,
                                                      const float* __restrict__ res, int act,
                                                      const float* __restrict__ slope, double* __restrict__ partial,
-                                                     int bf, int ybf) {
+                                                     int bf_rt, int ybf_rt) {
+    const int bf = FMT >= 0 ? FMT / 4 : bf_rt, ybf = FMT >= 0 ? FMT % 4 : ybf_rt;
     __shared__ double sh[NT];
     const float sl = slope ? slope[0] : 0.f;
     float v[3][V];
@@ -1414,6 +1418,20 @@ int check() { return (int)hipGetLastError(); }
 
 // ====================================================================================== launchers
 // grid of a streaming reduction: a stride that is a multiple of C (NT is), at most MAX_PARTIALS workgroups
+static void launch_bn_bwd_reduce4(int grid, hipStream_t s, const float* da, const float* y, long total, int C,
+                                  const float* stats, const float* gamma, const float* beta, const float* res, int act,
+                                  const float* slope, double* partial, int bf, int ybf) {
+#define GT_RED(F) hipLaunchKernelGGL((k_bn_bwd_reduce<4, F>), dim3(grid), dim3(NT), 0, s, da, y, total, C, stats, gamma, \
+                                     beta, res, act, slope, partial, bf, ybf)
+    const int f = bf * 4 + ybf;
+    if (f == 0) GT_RED(0);
+    else if (f == 5) GT_RED(5);          // bf16 activations, bf16 conv outputs
+    else if (f == 4) GT_RED(4);          // (diagnostic storage codes 2, 3)
+    else if (f == 6) GT_RED(6);
+    else GT_RED(-1);
+#undef GT_RED
+}
+
 static int red_grid(long units) {
     long g = (units + NT * 8 - 1) / (NT * 8);       // >= 8 elements per thread
     if (g < 1) g = 1;
@@ -1573,8 +1591,7 @@ int bn_act_bwd(const float* da, const float* y, long n, int C, const float* stat
     float* red = reinterpret_cast<float*>(scratch + (long)MAX_PARTIALS * 3 * 16);
     if (C % 4 == 0) {
         const int grid = red_grid(total / 4);
-        hipLaunchKernelGGL((k_bn_bwd_reduce<4>), dim3(grid), dim3(NT), 0, s, da, y, total, C, stats, gamma, beta, res,
-                           act, slope, scratch, bf, ybf);
+        launch_bn_bwd_reduce4(grid, s, da, y, total, C, stats, gamma, beta, res, act, slope, scratch, bf, ybf);
         hipLaunchKernelGGL(k_bn_bwd_finish, dim3(1), dim3(1024), 0, s, scratch, grid, n, C, red, dgamma, dbeta, dslope);
         // the apply pass keeps per-thread channel constants: its stride must be a multiple of C as well
         hipLaunchKernelGGL((k_bn_bwd_apply<4>), dim3(grid_for(total / 4, 8192)), dim3(NT), 0, s, da, y, total, C, stats,
@@ -1601,8 +1618,7 @@ int unit1x1_bwd(const ConvGeom& g, const float* x, const float* y, const float* 
         return (int)hipErrorInvalidValue;
     float* red = reinterpret_cast<float*>(dscratch + (long)MAX_PARTIALS * 3 * 16);
     const int rgrid = red_grid(total / 4);
-    hipLaunchKernelGGL((k_bn_bwd_reduce<4>), dim3(rgrid), dim3(NT), 0, s, da, y, total, g.Cout, stats, gamma, beta, res,
-                       act, slope, dscratch, bf, ybf);
+    launch_bn_bwd_reduce4(rgrid, s, da, y, total, g.Cout, stats, gamma, beta, res, act, slope, dscratch, bf, ybf);
     hipLaunchKernelGGL(k_bn_bwd_finish, dim3(1), dim3(1024), 0, s, dscratch, rgrid, n, g.Cout, red, dgamma, dbeta, dslope);
     const long ntiles = (n + 15) / 16;
     long waves = (long)MAX_PARTIALS * (NT / 64);

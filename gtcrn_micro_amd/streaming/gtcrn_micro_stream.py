@@ -105,6 +105,7 @@ class StreamGTCRNMicro(GTCRNMicro):
             conv, tra = bd["orig"][0], bd["orig"][1]
             tcn = [bd["orig"][2:6], bd["orig"][6:10]]
             bd["eng"].stream_export(bd["state"], conv, tra, tcn)
+            bd["versions"] = [t._version for t in bd["orig"]]     # our own write is not a caller's edit
         self.forward_stats["exports"] += 1
 
     def forward(self, spec, conv_cache, tra_cache, tcn_cache):

@@ -444,3 +444,72 @@ def test_folder_driver_exchanges_a_failure_flag_before_merging(tmp_path, monkeyp
     monkeypatch.setenv("WORLD_SIZE", "2"); monkeypatch.setenv("RANK", "0"); monkeypatch.setenv("LOCAL_RANK", "0")
     with pytest.raises(SystemExit):
         infer.main(["--noisy-dir", "n", "--clean-dir", "c", "--enh-dir", str(tmp_path), "--checkpoint", "ck", "-D", "0"])
+
+
+def test_stream_mirror_cache_binding_logic_without_a_gpu(monkeypatch):
+    """The reference-shaped streaming call hands caller-owned caches back and forth (gtcrn_micro_stream.py:626-635).
+    The mirror skips the cache -> ring import while the caller passes back what it was handed and has not written to
+    it, and defers the ring -> cache export until a returned cache is actually read.  Host logic only: the engine is
+    replaced by a recorder whose "state" is a frame counter that import reads from / export writes to the caches."""
+    import torch
+    from gtcrn_micro_amd.streaming import gtcrn_micro_stream as M
+
+    class FakeEngine:
+        def __init__(self):
+            self.log = []
+
+        def new_state(self, n):
+            return torch.zeros(n, 1)
+
+        def stream_import(self, state, conv, tra, tcn):
+            self.log.append("import")
+            state[:, 0] = conv[0, :, 0, 0, 0]                    # the "state" of a stream lives in one cache element
+
+        def stream_export(self, state, conv, tra, tcn):
+            self.log.append("export")
+            conv[0, :, 0, 0, 0] = state[:, 0]
+
+        def stream_step(self, state, spec):
+            self.log.append("step")
+            state += 1.0
+            return spec * 2.0
+
+    sm = M.StreamGTCRNMicro().eval()
+    eng = FakeEngine()
+    monkeypatch.setattr(M.StreamGTCRNMicro, "engine", lambda self, dev: eng)
+    monkeypatch.setattr(torch.Tensor, "is_cuda", property(lambda self: True))          # no CPU path in the real one
+    B = 3
+    caches = list(sm.init_caches(B, "cpu"))
+    orig = [caches[0], caches[1]] + [t for grp in caches[2] for t in grp]
+    x = torch.ones(B, 257, 1, 2)
+    # (1) the reference loop: returned caches straight back in -> one import, one eager export (fresh binding), no more
+    for t in range(5):
+        y, caches[0], caches[1], caches[2] = sm(x, caches[0], caches[1], caches[2])
+    assert eng.log == ["import", "step", "export"] + ["step"] * 4
+    assert isinstance(caches[0], M._LazyCache) and caches[0].data_ptr() == orig[0].data_ptr()
+    # reading a returned cache brings it (and the caller's own storage) up to date, once
+    assert float(caches[0][0, 1, 0, 0, 0]) == 5.0 and eng.log[-1] == "export" and float(orig[0][0, 1, 0, 0, 0]) == 5.0
+    n = len(eng.log)
+    assert float(caches[0][0, 2, 0, 0, 0]) == 5.0 and len(eng.log) == n                  # nothing pending: no second export
+    assert caches[0].shape == (2, B, 16, 6, 33) and len(eng.log) == n                   # metadata never triggers it
+    # (2) an in-place edit between two calls is seen: export first (the edit lands on current data), then re-import
+    y, caches[0], caches[1], caches[2] = sm(x, caches[0], caches[1], caches[2])
+    caches[0][0, 1, 0, 0, 0] = 100.0
+    assert eng.log[-2:] == ["step", "export"]
+    y, caches[0], caches[1], caches[2] = sm(x, caches[0], caches[1], caches[2])
+    assert eng.log[-3:] == ["import", "step", "export"]
+    assert [float(v) for v in caches[0][0, :, 0, 0, 0]] == [7.0, 101.0, 7.0]
+    # (3) a caller that keeps its ORIGINAL tensors: no import while untouched, but an export every frame
+    sm2 = M.StreamGTCRNMicro().eval()
+    eng.log.clear()
+    c0, t0, n0 = sm2.init_caches(B, "cpu")
+    for t in range(3):
+        sm2(x, c0, t0, n0)
+        assert type(c0) is torch.Tensor and float(c0[0, 0, 0, 0, 0]) == t + 1.0
+    assert eng.log == ["import", "step", "export", "step", "export", "step", "export"]
+    c0[0, 0, 0, 0, 0] = -5.0                                                          # the caller writes its own tensor
+    sm2(x, c0, t0, n0)
+    assert eng.log[-3:] == ["import", "step", "export"] and float(c0[0, 0, 0, 0, 0]) == -4.0
+    # (4) wrong cache shapes raise the reference's AssertionError before anything runs
+    with pytest.raises(AssertionError):
+        sm2(x, c0[:, :, :, :4], t0, n0)
