@@ -138,7 +138,13 @@ float gtcrn_round_to_half(float x);
 size_t gtcrn_stream_state_bytes(void); /* per stream */
 int gtcrn_stream_reset(gtcrn_model *m, void *d_state, int nstreams, void *stream);
 /* nframes >= 1 consecutive frames per call: d_spec_t / d_spec_out_t are
- * (N,257,nframes,2) addressed with the strides given. */
+ * (N,257,nframes,2) addressed with the strides given.  nframes == 1 (the
+ * reference's loop, :626-635) is ONE kernel launch -- encoder, both GTCN stacks
+ * and decoder for four streams per workgroup, nothing handed over through HBM --
+ * asynchronous on `stream`, no allocation once gtcrn_model_reserve(N, 1) was
+ * called: capturable into a HIP graph.  (With gtcrn_debug_enable the step runs
+ * as three launches whose hand-off tensors the stage taps read.)  The state holds
+ * a 16-bit frame counter; only its value mod 16 matters, it wraps freely. */
 int gtcrn_stream_step(gtcrn_model *m, void *d_state, const float *d_spec_t, long isb, long isf, long ist,
                       float *d_spec_out_t, long osb, long osf, long ost, int nstreams, int nframes,
                       void *stream);
