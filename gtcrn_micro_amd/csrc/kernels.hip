@@ -182,8 +182,8 @@ constexpr bool kSplitDense = false;     // A/B reference: the round-2 fp32-MFMA 
 #else                                   // python tools/ab_bench.py; profiles/r03_ab_split_dense.txt)
 constexpr bool kSplitDense = true;
 #endif
-#ifdef GT_EXP
-constexpr bool kSplitDe3 = false;       // current A/B (tools/ab_bench.py): de_convs.3 on the fp32 MFMA as in round 2
+#ifdef GT_F32_DENSE
+constexpr bool kSplitDe3 = false;       // (part of the round-2 matrix path)
 #else
 constexpr bool kSplitDe3 = true;
 #endif
@@ -776,7 +776,12 @@ __device__ __forceinline__ void gtconv_block(f32x4 (&x)[TPW], const Tiles<TPW>& 
 #pragma unroll
             for (int cc = 0; cc < DN16_CHUNKS; ++cc) {
                 constexpr int NT = 9;
-                const int tA = 2 * cc, tB = 2 * cc + 1 < NT ? 2 * cc + 1 : NT - 1;   // (chunk 4: zero weights on a valid record)
+                // chunk 4 has one tap: the lane groups g >= 2 meet zero weights and read some valid record -- the one of
+                // tap 7, an ODD number of records away from tap 8's: lanes (n, g) and (n, g + 2) then fall 8 banks apart
+                // like the slot groups of an fp32 record, and the tile-wide ds_read_b128 stays conflict free (the other
+                // four chunks pair taps that are an odd number of records apart by themselves)
+                // (same-box A/B against tap 8: 0.4060 vs 0.4051 ms -- inside the noise; kept for the cleaner pattern)
+                const int tA = 2 * cc, tB = 2 * cc + 1 < NT ? 2 * cc + 1 : NT - 2;
                 bf16x8 ap[3];
 #pragma unroll
                 for (int p = 0; p < 3; ++p) ap[p] = *reinterpret_cast<const bf16x8*>(c.gA + (cc * 3 + p) * 256 + arow(n, g));
@@ -818,7 +823,7 @@ __device__ __forceinline__ void gtconv_block(f32x4 (&x)[TPW], const Tiles<TPW>& 
             const int q16 = 4 * (gq & 1);
 #pragma unroll
             for (int cc = 0; cc < DN16_CHUNKS; ++cc) {
-                const int tA = 2 * cc, tB = 2 * cc + 1 < 9 ? 2 * cc + 1 : 8;
+                const int tA = 2 * cc, tB = 2 * cc + 1 < 9 ? 2 * cc + 1 : 7;   // (chunk 4: see the split form)
                 const h16x8 ap = *reinterpret_cast<const h16x8*>(c.gA + cc * 256 + arow(n, g));
 #pragma unroll
                 for (int i = 0; i < TPW; ++i) {
