@@ -7,8 +7,8 @@ Box-to-box spread on this pool is ~2 %, more than most single optimisations are 
 behind `#ifdef GT_EXP` in the sources, both libraries are built here (gtcrn_micro_amd.build, exp=True) and the
 bench workload is run alternately through each in child processes (GTCRN_LIB_VARIANT=exp selects the second).
 Prints per-kernel milliseconds per round and the means.  Diagnostic only; nothing in the product path reads GT_EXP.
-Standing switches for the exp build (GT_EXP_FLAGS): -DGT_F32_DENSE = the round-2 fp32-MFMA dense 3x3 of the decoder
-instead of the bf16 split form (profiles/r03_ab_split_dense.txt).
+Standing switches for the exp build (GT_EXP_FLAGS): -DGT_F32_DENSE = the round-2 fp32-MFMA dense 3x3 and de_convs.3 of
+the decoder instead of the bf16 split forms (profiles/r03_ab_r3_vs_r2_matrix_path.txt).
 """
 import argparse
 import json
