@@ -1141,6 +1141,121 @@ __global__ __launch_bounds__(NT) void k_bs_mask_bwd(const float* __restrict__ do
     }
 }
 
+// ---- the same three kernels for the layout the callers actually pass: (B,257,T,2) with the FRAME axis fastest
+// (torch.stft's, st < sf).  One thread per (b,t,f) with f fastest then reads / writes the 0.5 GB spectrograms 8 bytes
+// at a time with a stride of 2 T floats (k_bs_mask_bwd ran at 0.7 TB/s).  Here a workgroup takes a tile of TT frames of
+// one utterance: lanes run along t (coalesced rows of the spectrograms), the frame-major side -- m / dm / eb, which
+// is CONTIGUOUS for a tile -- goes through LDS.  Per-element arithmetic and its order are unchanged.
+constexpr int TT = 32;
+__global__ __launch_bounds__(NT) void k_feat_t(const float* __restrict__ spec, long sb, long sf, long st, int B, int T,
+                                              const float* __restrict__ erb_w, float* __restrict__ eb, int bf) {
+    __shared__ int lo[64], hi[64];
+    __shared__ float tile[TT][129 * 3 + 1];
+    nz_ranges(erb_w, 64, 192, 192, 1, lo, hi);
+    const int tiles = (T + TT - 1) / TT;
+    const int b = blockIdx.x / tiles, t0 = (blockIdx.x - b * tiles) * TT, nt = min(TT, T - t0);
+    const int tl = threadIdx.x & (TT - 1), r = threadIdx.x / TT;
+    if (tl < nt) {
+        const float* x = spec + (long)b * sb + (long)(t0 + tl) * st;
+        for (int j = r; j < 129; j += NT / TT) {
+            float m = 0.f, re = 0.f, im = 0.f;
+            if (j < 65) {
+                re = x[(long)j * sf]; im = x[(long)j * sf + 1];
+                m = sqrtf(re * re + im * im + 1e-12f);
+            } else {
+                const float* w = erb_w + (long)(j - 65) * 192;
+                for (int i = lo[j - 65]; i < hi[j - 65]; ++i) {
+                    const float wi = w[i];
+                    if (wi != 0.f) {
+                        const float rr = x[(long)(65 + i) * sf], q = x[(long)(65 + i) * sf + 1];
+                        m = fmaf(wi, sqrtf(rr * rr + q * q + 1e-12f), m);
+                        re = fmaf(wi, rr, re);
+                        im = fmaf(wi, q, im);
+                    }
+                }
+            }
+            tile[tl][j * 3] = m; tile[tl][j * 3 + 1] = re; tile[tl][j * 3 + 2] = im;
+        }
+    }
+    __syncthreads();
+    const long base = ((long)b * T + t0) * 387;
+    for (int i = threadIdx.x; i < nt * 387; i += NT) sst1(eb, base + i, bf, tile[i / 387][i % 387]);
+}
+
+__global__ __launch_bounds__(NT) void k_bs_mask_t(const float* __restrict__ m, const float* __restrict__ spec, long sb,
+                                                 long sf, long st, int B, int T, const float* __restrict__ ierb_w,
+                                                 float* __restrict__ out, long ob, long of, long ot, int bf) {
+    __shared__ int lo[192], hi[192];
+    __shared__ float sm[TT][258 + 2];
+    nz_ranges(ierb_w, 192, 64, 64, 1, lo, hi);
+    const int tiles = (T + TT - 1) / TT;
+    const int b = blockIdx.x / tiles, t0 = (blockIdx.x - b * tiles) * TT, nt = min(TT, T - t0);
+    const long mbase = ((long)b * T + t0) * 258;
+    for (int i = threadIdx.x; i < nt * 258; i += NT) sm[i / 258][i % 258] = sld1(m, mbase + i, bf);
+    __syncthreads();
+    const int tl = threadIdx.x & (TT - 1), r = threadIdx.x / TT;
+    if (tl >= nt) return;
+    const float* xr = spec + (long)b * sb + (long)(t0 + tl) * st;
+    float* orow = out + (long)b * ob + (long)(t0 + tl) * ot;
+    const float* mt = sm[tl];
+    for (int f = r; f < 257; f += NT / TT) {
+        float m0 = 0.f, m1 = 0.f;
+        if (f < 65) {
+            m0 = mt[f * 2]; m1 = mt[f * 2 + 1];
+        } else {
+            const float* w = ierb_w + (long)(f - 65) * 64;
+            for (int j = lo[f - 65]; j < hi[f - 65]; ++j) {
+                const float wj = w[j];
+                if (wj != 0.f) {
+                    m0 = fmaf(wj, mt[(65 + j) * 2], m0);
+                    m1 = fmaf(wj, mt[(65 + j) * 2 + 1], m1);
+                }
+            }
+        }
+        const float* x = xr + (long)f * sf;
+        float* o = orow + (long)f * of;
+        o[0] = x[0] * m0 - x[1] * m1;
+        o[1] = x[1] * m0 + x[0] * m1;
+    }
+}
+
+__global__ __launch_bounds__(NT) void k_bs_mask_bwd_t(const float* __restrict__ dout, long ob, long of, long ot,
+                                                     const float* __restrict__ spec, long sb, long sf, long st, int B,
+                                                     int T, const float* __restrict__ ierb_w, float* __restrict__ dm) {
+    __shared__ int lo[64], hi[64];
+    __shared__ float sd[TT][258 + 2];
+    nz_ranges(ierb_w, 64, 192, 1, 64, lo, hi);        // columns of the (192, 64) matrix
+    const int tiles = (T + TT - 1) / TT;
+    const int b = blockIdx.x / tiles, t0 = (blockIdx.x - b * tiles) * TT, nt = min(TT, T - t0);
+    const int tl = threadIdx.x & (TT - 1), r = threadIdx.x / TT;
+    if (tl < nt) {
+        const float* x = spec + (long)b * sb + (long)(t0 + tl) * st;
+        const float* d = dout + (long)b * ob + (long)(t0 + tl) * ot;
+        for (int j = r; j < 129; j += NT / TT) {
+            float g0 = 0.f, g1 = 0.f;
+            if (j < 65) {
+                const float re = x[(long)j * sf], im = x[(long)j * sf + 1], dr = d[(long)j * of], di = d[(long)j * of + 1];
+                g0 = dr * re + di * im;
+                g1 = di * re - dr * im;
+            } else {
+                for (int i = lo[j - 65]; i < hi[j - 65]; ++i) {
+                    const float wi = ierb_w[(long)i * 64 + (j - 65)];
+                    if (wi != 0.f) {
+                        const int f = 65 + i;
+                        const float re = x[(long)f * sf], im = x[(long)f * sf + 1], dr = d[(long)f * of], di = d[(long)f * of + 1];
+                        g0 = fmaf(wi, dr * re + di * im, g0);
+                        g1 = fmaf(wi, di * re - dr * im, g1);
+                    }
+                }
+            }
+            sd[tl][j * 2] = g0; sd[tl][j * 2 + 1] = g1;
+        }
+    }
+    __syncthreads();
+    const long base = ((long)b * T + t0) * 258;
+    for (int i = threadIdx.x; i < nt * 258; i += NT) dm[base + i] = sd[i / 258][i % 258];
+}
+
 // ---------------------------------------------------------------------------------- TRALite
 // TRALite.forward (models/gtcrn_micro.py:122-139) with a zero cache: e = mean_F(v^2); y = causal depthwise
 // conv1d (k=3, bias) over [0,0 | e]; g = sigmoid(point_conv(y)).  v: [B][Tt][33][8].
@@ -1640,19 +1755,33 @@ int unit1x1_bwd(const ConvGeom& g, const float* x, const float* y, const float* 
 
 int feat_fwd(const float* spec, long sb, long sf, long st, int B, int T, const float* erb_w, float* eb,
              hipStream_t s, int bf) {
-    hipLaunchKernelGGL(k_feat, dim3(grid_for((long)B * T * 129)), dim3(NT), 0, s, spec, sb, sf, st, B, T, erb_w, eb, bf);
+    // frame axis fastest (torch.stft's layout): tiles of TT frames, lanes along t
+    if ((st < 0 ? -st : st) < (sf < 0 ? -sf : sf))
+        hipLaunchKernelGGL(k_feat_t, dim3(B * ((T + TT - 1) / TT)), dim3(NT), 0, s, spec, sb, sf, st, B, T, erb_w, eb, bf);
+    else
+        hipLaunchKernelGGL(k_feat, dim3(grid_for((long)B * T * 129)), dim3(NT), 0, s, spec, sb, sf, st, B, T, erb_w, eb, bf);
     return check();
 }
 int bs_mask_fwd(const float* m, const float* spec, long sb, long sf, long st, int B, int T, const float* ierb_w,
                 float* out, long ob, long of, long ot, hipStream_t s, int bf) {
-    hipLaunchKernelGGL(k_bs_mask, dim3(grid_for((long)B * T * 257)), dim3(NT), 0, s, m, spec, sb, sf, st, B, T, ierb_w,
-                       out, ob, of, ot, bf);
+    auto ab = [](long v) { return v < 0 ? -v : v; };
+    if (ab(st) < ab(sf) && ab(ot) < ab(of))
+        hipLaunchKernelGGL(k_bs_mask_t, dim3(B * ((T + TT - 1) / TT)), dim3(NT), 0, s, m, spec, sb, sf, st, B, T, ierb_w,
+                           out, ob, of, ot, bf);
+    else
+        hipLaunchKernelGGL(k_bs_mask, dim3(grid_for((long)B * T * 257)), dim3(NT), 0, s, m, spec, sb, sf, st, B, T, ierb_w,
+                           out, ob, of, ot, bf);
     return check();
 }
 int bs_mask_bwd(const float* dout, long ob, long of, long ot, const float* spec, long sb, long sf, long st, int B,
                 int T, const float* ierb_w, float* dm, hipStream_t s) {
-    hipLaunchKernelGGL(k_bs_mask_bwd, dim3(grid_for((long)B * T * 129)), dim3(NT), 0, s, dout, ob, of, ot, spec, sb, sf,
-                       st, B, T, ierb_w, dm);
+    auto ab = [](long v) { return v < 0 ? -v : v; };
+    if (ab(st) < ab(sf) && ab(ot) < ab(of))
+        hipLaunchKernelGGL(k_bs_mask_bwd_t, dim3(B * ((T + TT - 1) / TT)), dim3(NT), 0, s, dout, ob, of, ot, spec, sb, sf,
+                           st, B, T, ierb_w, dm);
+    else
+        hipLaunchKernelGGL(k_bs_mask_bwd, dim3(grid_for((long)B * T * 129)), dim3(NT), 0, s, dout, ob, of, ot, spec, sb, sf,
+                           st, B, T, ierb_w, dm);
     return check();
 }
 
