@@ -405,6 +405,111 @@ __global__ __launch_bounds__(WG_WAVES * 64) void k_conv_wgrad_mfma(ConvGeom g, c
     }
 }
 
+// The same weight gradient with 16-byte operand loads (round 3).  k_conv_wgrad_mfma above feeds the MFMA from 4-byte
+// loads -- lane (c, k) fetches channel c of position 4 group + k, a wave-instruction moves 256 bytes -- and ran at
+// 0.8-1.0 TB/s of operand bytes: request-bound.  Here a wave takes 16 positions per trip: lane (n, q) loads channels
+// 4q..4q+3 of position n of dout and of every tap-shifted input (ONE 16-byte load each, 1 KB per wave-instruction,
+// all issued before anything is used), parks the (1 + taps) tiles in its own 1 KB LDS slots and reads the MFMA
+// operands back as scalars -- lane (c, k) takes [4u + k][c]: 64 different banks.  Same operands into the same MFMA
+// sequence as above: bit-identical partial sums.
+template <int FMT> struct Raw4 { using t = f32x4; };
+template <> struct Raw4<1> { using t = uint2; };
+template <> struct Raw4<2> { using t = uint2; };
+template <int FMT>
+__device__ __forceinline__ typename Raw4<FMT>::t sld4_raw(const float* base, long idx) {      // idx % 4 == 0
+    if constexpr (FMT == 0) return *reinterpret_cast<const f32x4*>(base + idx);
+    else return *reinterpret_cast<const uint2*>(reinterpret_cast<const unsigned short*>(base) + idx);
+}
+template <int FMT>
+__device__ __forceinline__ f32x4 dec4(const typename Raw4<FMT>::t r) {
+    if constexpr (FMT == 0) return r;
+    else return f32x4{dec16(r.x & 0xFFFFu, FMT), dec16(r.x >> 16, FMT), dec16(r.y & 0xFFFFu, FMT), dec16(r.y >> 16, FMT)};
+}
+template <int NKT, int NKF, int FMT>
+__global__ __launch_bounds__(WG_WAVES * 64) void k_conv_wgrad_lds(ConvGeom g, const float* __restrict__ in,
+                                                                 const float* __restrict__ dout,
+                                                                 float* __restrict__ partial, long groups_per_wave) {
+    constexpr int NTAP = NKT * NKF;
+    constexpr int SLOT = (1 + NTAP) * 256 > NTAP * 256 + 64 ? (1 + NTAP) * 256 : NTAP * 256 + 64;
+    __shared__ __attribute__((aligned(16))) float sT[WG_WAVES][SLOT];   // per wave: operand tiles, later its accumulators
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, c = lane & 15, k = lane >> 4;   // = (n, q) for the loads
+    float* my = sT[wv];
+    const long npos = (long)g.B * g.Tout * g.Fout, ngroups = (npos + 3) >> 2;
+    const long wave = (long)blockIdx.x * WG_WAVES + wv;
+    long grp = wave * groups_per_wave;
+    const long gend = grp + groups_per_wave < ngroups ? grp + groups_per_wave : ngroups;
+    f32x4 acc[NTAP];
+#pragma unroll
+    for (int i = 0; i < NTAP; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float bsum = 0.f;
+    if (grp < gend) {
+        Pos P;
+        {
+            const long p0 = grp * 4 + c;
+            P.init(p0 < npos ? p0 : npos - 1, g.Fout, g.Tout);
+        }
+        const bool co_ok = 4 * k < g.Cout, ci_ok = 4 * k < g.Cin;
+        for (; grp < gend; grp += 4) {
+            const long p = grp * 4 + c;                          // this lane's position of the 16
+            const bool pv = p < npos && grp + (c >> 2) < gend;
+            f32x4 a4 = {0.f, 0.f, 0.f, 0.f};
+            typename Raw4<FMT>::t raw[NTAP];
+            if (pv && co_ok) a4 = *reinterpret_cast<const f32x4*>(dout + p * g.CoutT + g.cout_off + 4 * k);
+#pragma unroll
+            for (int kt = 0; kt < NKT; ++kt) {
+                const int ti = P.t + g.t_off[kt];
+                const bool okt = pv && ci_ok && ti >= 0 && ti < g.Tin;
+                const long rowbase = ((long)P.b * g.Tin + ti) * g.Fin;
+#pragma unroll
+                for (int kf = 0; kf < NKF; ++kf) {
+                    int fi;
+                    const bool ok = tap_fi(g, P.f, kf, fi) && okt;
+                    typename Raw4<FMT>::t z{};
+                    raw[kt * NKF + kf] = ok ? sld4_raw<FMT>(in, (rowbase + fi) * g.CinT + g.cin_off + 4 * k) : z;
+                }
+            }
+            P.advance(16, g.Fout, g.Tout);
+            *reinterpret_cast<f32x4*>(my + c * 16 + 4 * k) = a4;
+#pragma unroll
+            for (int tap = 0; tap < NTAP; ++tap)
+                *reinterpret_cast<f32x4*>(my + (1 + tap) * 256 + c * 16 + 4 * k) = dec4<FMT>(raw[tap]);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const float a = my[(4 * u + k) * 16 + c];
+                bsum += a;
+#pragma unroll
+                for (int tap = 0; tap < NTAP; ++tap) acc[tap] = mfma4(a, my[(1 + tap) * 256 + (4 * u + k) * 16 + c], acc[tap]);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        }
+    }
+    // D fragment: lane (j = c, q = k) holds dW[co = 4q + r][ci = j] of each tap (the wave's own slot: its tiles are dead)
+#pragma unroll
+    for (int tap = 0; tap < NTAP; ++tap)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) my[tap * 256 + (4 * k + r) * 16 + c] = acc[tap][r];
+    my[NTAP * 256 + lane] = bsum;
+    __syncthreads();
+    float* pp = partial + (long)blockIdx.x * (NTAP * 256 + 16);
+    for (int i = tid; i < NTAP * 256; i += WG_WAVES * 64) {
+        float s = 0.f;
+#pragma unroll
+        for (int w2 = 0; w2 < WG_WAVES; ++w2) s += sT[w2][i];
+        pp[i] = s;
+    }
+    if (tid < 16) {
+        float s = 0.f;
+        for (int w2 = 0; w2 < WG_WAVES; ++w2)
+            for (int kk = 0; kk < 4; ++kk) s += sT[w2][NTAP * 256 + kk * 16 + tid];
+        pp[NTAP * 256 + tid] = s;
+    }
+}
+
 // partial [nparts][ntap*256 + 16] -> dw (reference layout), dbias.  1024 threads = 64 outputs x 16 slices
 // of the partials; the slices are combined in a fixed order.
 __global__ __launch_bounds__(1024) void k_wgrad_mfma_finish(ConvGeom g, const float* __restrict__ partial, int nparts,
@@ -1599,16 +1704,29 @@ int conv_wgrad(const ConvGeom& g, const float* in, const float* dout, float* dw,
         const long gpw = (ngroups + waves - 1) / waves;
         const int grid = (int)((ngroups + gpw * WG_WAVES - 1) / (gpw * WG_WAVES));
         const int K = g.nkt * g.nkf * 256 + 16;
+        // 16-byte operand loads through wave-private LDS tiles when the channel counts allow them (all MFMA layers of
+        // this model); the 4-byte form otherwise
+#ifdef GT_EXP
+        const bool wide = false;
+#else
+        const bool wide = mfma_ok(g);     // channel counts / offsets in multiples of four: 16-byte operand loads
+#endif
+#define GT_WG1(K_, KT, KF)                                                                                             \
+    do {                                                                                                               \
+        if (g.in_bf == 0) hipLaunchKernelGGL((K_<KT, KF, 0>), dim3(grid), dim3(WG_WAVES * 64), 0, s, g, in, dout, scratch, gpw); \
+        else if (g.in_bf == 1) hipLaunchKernelGGL((K_<KT, KF, 1>), dim3(grid), dim3(WG_WAVES * 64), 0, s, g, in, dout, scratch, gpw); \
+        else hipLaunchKernelGGL((K_<KT, KF, 2>), dim3(grid), dim3(WG_WAVES * 64), 0, s, g, in, dout, scratch, gpw); \
+    } while (0)
 #define GT_WG(KT, KF)                                                                                                  \
     do {                                                                                                               \
-        if (g.in_bf == 0) hipLaunchKernelGGL((k_conv_wgrad_mfma<KT, KF, 0>), dim3(grid), dim3(WG_WAVES * 64), 0, s, g, in, dout, scratch, gpw); \
-        else if (g.in_bf == 1) hipLaunchKernelGGL((k_conv_wgrad_mfma<KT, KF, 1>), dim3(grid), dim3(WG_WAVES * 64), 0, s, g, in, dout, scratch, gpw); \
-        else hipLaunchKernelGGL((k_conv_wgrad_mfma<KT, KF, 2>), dim3(grid), dim3(WG_WAVES * 64), 0, s, g, in, dout, scratch, gpw); \
+        if (wide) GT_WG1(k_conv_wgrad_lds, KT, KF);                                                                    \
+        else GT_WG1(k_conv_wgrad_mfma, KT, KF);                                                                        \
     } while (0)
         if (g.nkt == 3) GT_WG(3, 3);
         else if (g.nkf == 5) GT_WG(1, 5);
         else GT_WG(1, 1);
 #undef GT_WG
+#undef GT_WG1
         hipLaunchKernelGGL(k_wgrad_mfma_finish, dim3((K + 63) / 64), dim3(1024), 0, s, g, scratch, grid, dw, dbias);
         return check();
     }
