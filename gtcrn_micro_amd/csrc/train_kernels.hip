@@ -244,7 +244,24 @@ struct RowPos {
     }
 };
 
-template <int NKT, int NKF>
+// 16-byte (4-channel) operand loads with the storage format as a compile-time constant, load and decode separated
+template <int FMT> struct Raw4 { using t = f32x4; };
+template <> struct Raw4<1> { using t = uint2; };
+template <> struct Raw4<2> { using t = uint2; };
+template <int FMT>
+__device__ __forceinline__ typename Raw4<FMT>::t sld4_raw(const float* base, long idx) {      // idx % 4 == 0
+    if constexpr (FMT == 0) return *reinterpret_cast<const f32x4*>(base + idx);
+    else return *reinterpret_cast<const uint2*>(reinterpret_cast<const unsigned short*>(base) + idx);
+}
+template <int FMT>
+__device__ __forceinline__ f32x4 dec4(const typename Raw4<FMT>::t r) {
+    if constexpr (FMT == 0) return r;
+    else return f32x4{dec16(r.x & 0xFFFFu, FMT), dec16(r.x >> 16, FMT), dec16(r.y & 0xFFFFu, FMT), dec16(r.y >> 16, FMT)};
+}
+// FIN: storage format of `in` (compile time).  All tap loads of a tile are issued before the first MFMA: a tap outside
+// the tensor loads element 0 and is zeroed by a select -- with `if (ok) load` every tap sat in its own basic block and
+// the tile paid nine L2 latencies one after the other (the 3x3 convs ran at 45 TFLOP/s, latency-bound).
+template <int NKT, int NKF, int FIN>
 __global__ __launch_bounds__(NT) void k_conv_mfma(ConvGeom g, const float* __restrict__ in,
                                                  const float* __restrict__ w, const float* __restrict__ bias,
                                                  float* __restrict__ out, long tiles_per_wave,
@@ -279,6 +296,8 @@ __global__ __launch_bounds__(NT) void k_conv_mfma(ConvGeom g, const float* __res
         const long p = tile * 16 + n;
         const bool pv = p < npos;
         f32x4 acc = bv;
+        typename Raw4<FIN>::t raw[NKT * NKF];
+        bool okv[NKT * NKF];
 #pragma unroll
         for (int kt = 0; kt < NKT; ++kt) {
             const int ti = P.t + g.t_off[kt];
@@ -288,12 +307,18 @@ __global__ __launch_bounds__(NT) void k_conv_mfma(ConvGeom g, const float* __res
             for (int kf = 0; kf < NKF; ++kf) {
                 int fi;
                 const bool ok = tap_fi(g, P.f, kf, fi) && okt;
-                f32x4 xv = {0.f, 0.f, 0.f, 0.f};
-                if (ok) xv = sld4(in, (rowbase + fi) * g.CinT + g.cin_off + 4 * q, g.in_bf);
-                const f32x4 A = *reinterpret_cast<const f32x4*>(sW + (kt * NKF + kf) * 256 + n * 16 + 4 * q);
-#pragma unroll
-                for (int s = 0; s < 4; ++s) acc = mfma4(A[s], xv[s], acc);
+                okv[kt * NKF + kf] = ok;
+                raw[kt * NKF + kf] = sld4_raw<FIN>(in, ok ? (rowbase + fi) * g.CinT + g.cin_off + 4 * q : 0L);
             }
+        }
+#pragma unroll
+        for (int tap = 0; tap < NKT * NKF; ++tap) {
+            const f32x4 d = dec4<FIN>(raw[tap]);
+            const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+            const f32x4 xv = okv[tap] ? d : zero;
+            const f32x4 A = *reinterpret_cast<const f32x4*>(sW + tap * 256 + n * 16 + 4 * q);
+#pragma unroll
+            for (int s = 0; s < 4; ++s) acc = mfma4(A[s], xv[s], acc);
         }
         if (pv && cout_ok) {
             if (g.out_bf) {
@@ -412,19 +437,6 @@ __global__ __launch_bounds__(WG_WAVES * 64) void k_conv_wgrad_mfma(ConvGeom g, c
 // all issued before anything is used), parks the (1 + taps) tiles in its own 1 KB LDS slots and reads the MFMA
 // operands back as scalars -- lane (c, k) takes [4u + k][c]: 64 different banks.  Same operands into the same MFMA
 // sequence as above: bit-identical partial sums.
-template <int FMT> struct Raw4 { using t = f32x4; };
-template <> struct Raw4<1> { using t = uint2; };
-template <> struct Raw4<2> { using t = uint2; };
-template <int FMT>
-__device__ __forceinline__ typename Raw4<FMT>::t sld4_raw(const float* base, long idx) {      // idx % 4 == 0
-    if constexpr (FMT == 0) return *reinterpret_cast<const f32x4*>(base + idx);
-    else return *reinterpret_cast<const uint2*>(reinterpret_cast<const unsigned short*>(base) + idx);
-}
-template <int FMT>
-__device__ __forceinline__ f32x4 dec4(const typename Raw4<FMT>::t r) {
-    if constexpr (FMT == 0) return r;
-    else return f32x4{dec16(r.x & 0xFFFFu, FMT), dec16(r.x >> 16, FMT), dec16(r.y & 0xFFFFu, FMT), dec16(r.y >> 16, FMT)};
-}
 template <int NKT, int NKF, int FMT>
 __global__ __launch_bounds__(WG_WAVES * 64) void k_conv_wgrad_lds(ConvGeom g, const float* __restrict__ in,
                                                                  const float* __restrict__ dout,
@@ -1677,9 +1689,16 @@ int conv_fwd(const ConvGeom& g, const float* in, const float* w, const float* bi
         const int grid = (int)((ntiles + tpw * 4 - 1) / (tpw * 4));
         double* sp = (stat_partial && stat_parts && grid <= MAX_PARTIALS && g.cout_off == 0 && g.Cout == g.CoutT &&
                       !g.accumulate) ? stat_partial : nullptr;
-        if (g.nkt == 3) hipLaunchKernelGGL((k_conv_mfma<3, 3>), dim3(grid), dim3(NT), 0, s, g, in, w, bias, out, tpw, sp, shift);
-        else if (g.nkf == 5) hipLaunchKernelGGL((k_conv_mfma<1, 5>), dim3(grid), dim3(NT), 0, s, g, in, w, bias, out, tpw, sp, shift);
-        else hipLaunchKernelGGL((k_conv_mfma<1, 1>), dim3(grid), dim3(NT), 0, s, g, in, w, bias, out, tpw, sp, shift);
+#define GT_CM(KT, KF)                                                                                                  \
+    do {                                                                                                               \
+        if (g.in_bf == 0) hipLaunchKernelGGL((k_conv_mfma<KT, KF, 0>), dim3(grid), dim3(NT), 0, s, g, in, w, bias, out, tpw, sp, shift); \
+        else if (g.in_bf == 1) hipLaunchKernelGGL((k_conv_mfma<KT, KF, 1>), dim3(grid), dim3(NT), 0, s, g, in, w, bias, out, tpw, sp, shift); \
+        else hipLaunchKernelGGL((k_conv_mfma<KT, KF, 2>), dim3(grid), dim3(NT), 0, s, g, in, w, bias, out, tpw, sp, shift); \
+    } while (0)
+        if (g.nkt == 3) GT_CM(3, 3);
+        else if (g.nkf == 5) GT_CM(1, 5);
+        else GT_CM(1, 1);
+#undef GT_CM
         if (sp) *stat_parts = grid;
         return check();
     }
