@@ -186,6 +186,31 @@ __global__ __launch_bounds__(NT) void k_conv(ConvGeom g, const float* __restrict
 }
 
 
+// sum of a double over the lanes of a wave whose lane numbers differ only in the bits LO..HI (powers of two, as xor
+// distances), largest distance first: a fixed order, every lane ends with the same total
+__device__ __forceinline__ double wave_sum_xor(double s, int lo, int hi) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1)
+        if (off <= hi && off >= lo) s += __shfl_xor(s, off, 64);
+    return s;
+}
+// sequential sum of p[w * K] for w = w0, w0 + step, ... < n, the loads issued eight at a time (one at a time every
+// load of these small second-stage reductions paid its own L2/MALL round trip: ~19 us per launch, 130 launches a step)
+template <class T>
+__device__ __forceinline__ double sum_strided(const T* __restrict__ p, int w0, int n, int step, long K) {
+    double s = 0.0;
+    int w = w0;
+    for (; w + 7 * step < n; w += 8 * step) {
+        T t[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) t[u] = p[(long)(w + u * step) * K];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) s += (double)t[u];
+    }
+    for (; w < n; w += step) s += (double)p[(long)w * K];
+    return s;
+}
+
 // ------------------------------------------------------------------ dense conv on the matrix cores
 // Same arithmetic as k_conv / k_conv_wgrad for channel counts that are multiples of 4 (all the
 // 16/8-channel layers), on v_mfma_f32_16x16x4_f32 (exact fp32 products, fp32 accumulation):
@@ -267,7 +292,7 @@ __global__ __launch_bounds__(NT) void k_conv_mfma(ConvGeom g, const float* __res
                                                  float* __restrict__ out, long tiles_per_wave,
                                                  double* __restrict__ stat_partial, const float* __restrict__ shift) {
     __shared__ __attribute__((aligned(16))) float sW[NKT * NKF * 256];   // [tap][co][ci], zero padded
-    __shared__ double sStat[NT][8];
+    __shared__ double sStat[NT / 64][32];   // per wave: sum[16], sum of squares[16]
     const int tid = threadIdx.x;
     for (int i = tid; i < NKT * NKF * 256; i += NT) {
         const int tap = i >> 8, co = (i >> 4) & 15, ci = i & 15, kt = tap / NKF, kf = tap - kt * NKF;
@@ -336,14 +361,17 @@ __global__ __launch_bounds__(NT) void k_conv_mfma(ConvGeom g, const float* __res
     if (stat_partial) {
         // per-workgroup sums of y and y^2 per channel (the conv is followed by a train-mode BatchNorm):
         // lanes -> LDS -> one thread per (sum, channel), fixed order; combined across workgroups by k_bn_stats_finish
+        // (lanes of one channel quad differ in n = lane & 15: xor distances 8..1)
 #pragma unroll
-        for (int e = 0; e < 4; ++e) { sStat[tid][e] = s1[e]; sStat[tid][4 + e] = s2[e]; }
+        for (int e = 0; e < 4; ++e) { s1[e] = wave_sum_xor(s1[e], 1, 8); s2[e] = wave_sum_xor(s2[e], 1, 8); }
+        if (n == 0)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { sStat[tid >> 6][4 * q + e] = s1[e]; sStat[tid >> 6][16 + 4 * q + e] = s2[e]; }
         __syncthreads();
         if (tid < 2 * g.Cout) {
-            const int which = tid / g.Cout, ch = tid - which * g.Cout, qq = ch >> 2, e = ch & 3;
+            const int which = tid / g.Cout, ch = tid - which * g.Cout;
             double t = 0.0;
-            for (int l = 0; l < NT; ++l)
-                if (((l & 63) >> 4) == qq) t += sStat[l][which * 4 + e];
+            for (int w = 0; w < NT / 64; ++w) t += sStat[w][which * 16 + ch];
             stat_partial[(long)blockIdx.x * 2 * g.Cout + tid] = t;
         }
     }
@@ -529,9 +557,7 @@ __global__ __launch_bounds__(1024) void k_wgrad_mfma_finish(ConvGeom g, const fl
     __shared__ double sh[16][64];
     const int ntap = g.nkt * g.nkf, K = ntap * 256 + 16;
     const int j = threadIdx.x & 63, slice = threadIdx.x >> 6, k = blockIdx.x * 64 + j;
-    double s = 0.0;
-    if (k < K)
-        for (int w = slice; w < nparts; w += 16) s += partial[(long)w * K + k];
+    double s = k < K ? sum_strided(partial + k, slice, nparts, 16, K) : 0.0;
     sh[slice][j] = s;
     __syncthreads();
     if (slice != 0 || k >= K) return;
@@ -598,7 +624,7 @@ __global__ __launch_bounds__(NT) void k_dw16(DwGeom g, const float* __restrict__
                                             double* __restrict__ stat_partial, StrideIter it,
                                             const float* __restrict__ shift) {
     __shared__ __attribute__((aligned(16))) float sW[9 * 16];   // [tap][c]
-    __shared__ double sStat[NT][8];
+    __shared__ double sStat[NT / 64][32];   // per wave: sum[16], sum of squares[16]
     double s1[4] = {0.0, 0.0, 0.0, 0.0}, s2[4] = {0.0, 0.0, 0.0, 0.0};    // in double: see k_conv_mfma
     const int tid = threadIdx.x, ntap = g.nkt * g.nkf;
     for (int i = tid; i < ntap * 16; i += NT) {
@@ -664,12 +690,14 @@ __global__ __launch_bounds__(NT) void k_dw16(DwGeom g, const float* __restrict__
     }
     if (stat_partial) {   // per-workgroup BatchNorm partial sums; a thread's channel quad is tid & 3
 #pragma unroll
-        for (int e = 0; e < 4; ++e) { sStat[tid][e] = s1[e]; sStat[tid][4 + e] = s2[e]; }
+        for (int e = 0; e < 4; ++e) { s1[e] = wave_sum_xor(s1[e], 4, 32); s2[e] = wave_sum_xor(s2[e], 4, 32); }
+        if ((tid & 63) < 4)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { sStat[tid >> 6][4 * q + e] = s1[e]; sStat[tid >> 6][16 + 4 * q + e] = s2[e]; }
         __syncthreads();
         if (tid < 32) {
-            const int which = tid >> 4, ch = tid & 15, qq = ch >> 2, e = ch & 3;
             double t = 0.0;
-            for (int l = qq; l < NT; l += 4) t += sStat[l][which * 4 + e];
+            for (int w = 0; w < NT / 64; ++w) t += sStat[w][tid];
             stat_partial[(long)blockIdx.x * 32 + tid] = t;
         }
     }
@@ -684,6 +712,29 @@ __global__ __launch_bounds__(NT) void k_dw16(DwGeom g, const float* __restrict__
 template <int NV, int V, class TV>   // NV sums per channel, V channels per thread (vector width); TV float or double
 __device__ __forceinline__ void block_reduce_store(const TV (&v)[NV][V], int C, double* sh, double* dst) {
     const int tid = threadIdx.x, groups = C / V;      // threads with equal (tid % groups) share channels
+    if ((groups & (groups - 1)) == 0 && groups <= 32) {
+        // lanes first (xor shuffles over the lane bits above the channel group), then the NT/64 waves through LDS.
+        // (The one-thread-per-channel loop over all NT entries below cost 64 dependent LDS reads per value: the
+        // 12 values of the BatchNorm backward made a 40 us tail on a 95 us streaming pass.)
+        const int lane = tid & 63, wv = tid >> 6;
+#pragma unroll
+        for (int k = 0; k < NV; ++k) {
+            double r[V];
+#pragma unroll
+            for (int e = 0; e < V; ++e) r[e] = wave_sum_xor((double)v[k][e], groups, 32);
+            __syncthreads();
+            if (lane < groups)
+#pragma unroll
+                for (int e = 0; e < V; ++e) sh[wv * C + lane * V + e] = r[e];
+            __syncthreads();
+            if (tid < C) {
+                double s = 0.0;
+                for (int w = 0; w < NT / 64; ++w) s += sh[w * C + tid];
+                dst[k * C + tid] = s;
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int k = 0; k < NV; ++k)
 #pragma unroll
@@ -719,9 +770,7 @@ __global__ __launch_bounds__(NT) void k_bn_stats(const float* __restrict__ y, lo
 // sums the per-workgroup partials [nparts][K] (K <= 64 values) with 1024 threads: 64 values x 16 slices
 __device__ __forceinline__ double reduce_partials(const double* partial, int nparts, int K, double (*sh)[64]) {
     const int j = threadIdx.x & 63, slice = threadIdx.x >> 6;
-    double s = 0.0;
-    if (j < K)
-        for (int w = slice; w < nparts; w += 16) s += partial[(long)w * K + j];
+    double s = j < K ? sum_strided(partial + j, slice, nparts, 16, K) : 0.0;
     sh[slice][j] = s;
     __syncthreads();
     if (slice == 0)
@@ -962,9 +1011,7 @@ __global__ __launch_bounds__(1024) void k_dw_wgrad_finish2(DwGeom g, const doubl
     __shared__ double sh[16][64];
     const int ntap = g.nkt * g.nkf, K = (ntap + 1) * 16;
     const int j = threadIdx.x & 63, slice = threadIdx.x >> 6, k = blockIdx.x * 64 + j;
-    double s = 0.0;
-    if (k < K)
-        for (int w = slice; w < nparts; w += 16) s += partial[(long)w * K + k];
+    double s = k < K ? sum_strided(partial + k, slice, nparts, 16, K) : 0.0;
     sh[slice][j] = s;
     __syncthreads();
     if (slice != 0 || k >= K) return;
@@ -1012,9 +1059,7 @@ __global__ __launch_bounds__(1024) void k_reduce_partials_f(const float* __restr
                                                            float* __restrict__ out) {
     __shared__ double sh[16][64];
     const int j = threadIdx.x & 63, slice = threadIdx.x >> 6, k = blockIdx.x * 64 + j;
-    double s = 0.0;
-    if (k < K)
-        for (int w = slice; w < nparts; w += 16) s += partial[(long)w * K + k];
+    double s = k < K ? sum_strided(partial + k, slice, nparts, 16, K) : 0.0;
     sh[slice][j] = s;
     __syncthreads();
     if (slice != 0 || k >= K) return;
