@@ -82,12 +82,25 @@ __device__ __forceinline__ void sst1(float* base, long idx, int fmt, float v) {
     if (fmt) reinterpret_cast<unsigned short*>(base)[idx] = (unsigned short)enc16(v, fmt);
     else base[idx] = v;
 }
+// NTL: nontemporal load, for the passes that read every element exactly once.  A tensor the PREVIOUS kernel has just
+// written (every gradient, every conv output) is still dirty in the Infinity Cache; a plain streaming read of two
+// 271 MB tensors, one of them just written, runs at 4.65 TB/s, the same read with nontemporal loads at 6.68 TB/s
+// (tools/ubench_reduce_bw.hip: without the preceding writer 6.24 against 6.53)
+#ifdef GT_EXP
+constexpr bool kNt = false;    // A/B build (tools/ab_bench.py): plain loads everywhere
+#else
+constexpr bool kNt = true;
+#endif
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+template <bool NTL = false>
 __device__ __forceinline__ f32x4 sld4(const float* base, long idx, int fmt) {      // idx % 4 == 0
     if (fmt) {
-        const uint2 u = *reinterpret_cast<const uint2*>(reinterpret_cast<const unsigned short*>(base) + idx);
+        const u32x2* p = reinterpret_cast<const u32x2*>(reinterpret_cast<const unsigned short*>(base) + idx);
+        const u32x2 u = NTL ? __builtin_nontemporal_load(p) : *p;
         return f32x4{dec16(u.x & 0xFFFFu, fmt), dec16(u.x >> 16, fmt), dec16(u.y & 0xFFFFu, fmt), dec16(u.y >> 16, fmt)};
     }
-    return *reinterpret_cast<const f32x4*>(base + idx);
+    const f32x4* p = reinterpret_cast<const f32x4*>(base + idx);
+    return NTL ? __builtin_nontemporal_load(p) : *p;
 }
 __device__ __forceinline__ void sst4(float* base, long idx, int fmt, const f32x4 v) {
     if (fmt) {
@@ -103,12 +116,12 @@ __device__ __forceinline__ float round16(float x, int fmt) { return fmt ? dec16(
 __device__ __forceinline__ f32x4 round_bf4(const f32x4 v, int fmt) {
     return fmt ? f32x4{round16(v[0], fmt), round16(v[1], fmt), round16(v[2], fmt), round16(v[3], fmt)} : v;
 }
-template <int C>
+template <int C, bool NTL = false>
 __device__ __forceinline__ void load_vec_s(const float* base, long idx, int bf, float (&v)[C]) {
     if constexpr (C % 4 == 0) {
 #pragma unroll
         for (int i = 0; i < C; i += 4) {
-            const f32x4 t = sld4(base, idx + i, bf);
+            const f32x4 t = sld4<NTL>(base, idx + i, bf);
             v[i] = t[0]; v[i + 1] = t[1]; v[i + 2] = t[2]; v[i + 3] = t[3];
         }
     } else {
@@ -117,12 +130,13 @@ __device__ __forceinline__ void load_vec_s(const float* base, long idx, int bf, 
     }
 }
 
-template <int C>
+template <int C, bool NTL = false>
 __device__ __forceinline__ void load_vec(const float* p, float (&v)[C]) {
     if constexpr (C % 4 == 0) {
 #pragma unroll
         for (int i = 0; i < C; i += 4) {
-            const f32x4 t = *reinterpret_cast<const f32x4*>(p + i);
+            const f32x4 t = NTL ? __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p + i))
+                                : *reinterpret_cast<const f32x4*>(p + i);
             v[i] = t[0]; v[i + 1] = t[1]; v[i + 2] = t[2]; v[i + 3] = t[3];
         }
     } else {
@@ -760,7 +774,7 @@ __global__ __launch_bounds__(NT) void k_bn_stats(const float* __restrict__ y, lo
     const long units = total / V;
     for (long i = (long)blockIdx.x * NT + threadIdx.x; i < units; i += (long)gridDim.x * NT) {
         float x[V];
-        load_vec_s<V>(y, i * V, bf, x);
+        load_vec_s<V, kNt>(y, i * V, bf, x);
 #pragma unroll
         for (int e = 0; e < V; ++e) { const double a = (double)x[e]; v[0][e] += a; v[1][e] = fma(a, a, v[1][e]); }
     }
@@ -823,8 +837,8 @@ __global__ __launch_bounds__(NT) void k_bn_act(const float* __restrict__ y, long
     for (int e = 0; e < V; ++e) { mean[e] = stats[c0 + e]; istd[e] = stats[C + c0 + e]; gm[e] = gamma[c0 + e]; bt[e] = beta[c0 + e]; }
     for (long i = (long)blockIdx.x * NT + threadIdx.x; i < units; i += (long)gridDim.x * NT) {
         float x[V], r[V], o[V];
-        load_vec_s<V>(y, i * V, ybf, x);
-        if (res) load_vec_s<V>(res, i * V, bf, r);
+        load_vec_s<V, kNt>(y, i * V, ybf, x);
+        if (res) load_vec_s<V, kNt>(res, i * V, bf, r);
 #pragma unroll
         for (int e = 0; e < V; ++e) {
             // same expression order as the backward's recomputation of z: gamma * ((y - mean) * invstd) + beta
@@ -847,15 +861,17 @@ __device__ __forceinline__ float act_bwd(float z, float g, int act, float sl, fl
 // backward, pass 1: S1 = sum dz, S2 = sum dz * xhat, S3 = sum da * min(z, 0) (PReLU slope gradient)
 // FMT >= 0: the storage formats as a compile-time constant (FMT = bf * 4 + ybf): with the run-time flags every load sits
 // behind its own wave-uniform branch, i.e. in its own basic block, and the U strides of loads below are issued one at
-// a time after all (this read-only pass ran at 3.5 TB/s); FMT < 0: run-time flags (the odd channel counts)
-template <int V, int FMT = -1>
+// a time after all (this read-only pass ran at 3.5 TB/s); FMT < 0: run-time flags (the odd channel counts).
+// ACT >= 0: the activation as a compile-time constant too (with the run-time switch every ELEMENT went through four
+// scalar branches: 64 taken branches per trip of a pass that should only wait for its loads)
+template <int V, int FMT = -1, int ACT = -1>
 __global__ __launch_bounds__(NT) void k_bn_bwd_reduce(const float* __restrict__ da, const float* __restrict__ y,
                                                      long total, int C, const float* __restrict__ stats,
                                                      const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                     const float* __restrict__ res, int act,
+                                                     const float* __restrict__ res, int act_rt,
                                                      const float* __restrict__ slope, double* __restrict__ partial,
                                                      int bf_rt, int ybf_rt) {
-    const int bf = FMT >= 0 ? FMT / 4 : bf_rt, ybf = FMT >= 0 ? FMT % 4 : ybf_rt;
+    const int bf = FMT >= 0 ? FMT / 4 : bf_rt, ybf = FMT >= 0 ? FMT % 4 : ybf_rt, act = ACT >= 0 ? ACT : act_rt;
     __shared__ double sh[NT];
     const float sl = slope ? slope[0] : 0.f;
     float v[3][V];
@@ -876,9 +892,9 @@ __global__ __launch_bounds__(NT) void k_bn_bwd_reduce(const float* __restrict__ 
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const long i = i0 + u * stride < units ? i0 + u * stride : i0;     // clamped: a valid element, not summed
-            load_vec_s<V>(y, i * V, ybf, x[u]);
-            load_vec<V>(da + i * V, g[u]);
-            if (res) load_vec_s<V>(res, i * V, bf, r[u]);
+            load_vec_s<V, kNt>(y, i * V, ybf, x[u]);
+            load_vec<V, kNt>(da + i * V, g[u]);
+            if (res) load_vec_s<V, kNt>(res, i * V, bf, r[u]);
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
@@ -941,10 +957,10 @@ __global__ __launch_bounds__(NT) void k_bn_bwd_apply(const float* __restrict__ d
     }
     for (long i = (long)blockIdx.x * NT + threadIdx.x; i < units; i += (long)gridDim.x * NT) {
         float x[V], g[V], r[V], o[V], dzv[V];
-        load_vec_s<V>(y, i * V, ybf, x);
-        load_vec<V>(da + i * V, g);
-        if (res) load_vec_s<V>(res, i * V, bf, r);
-        if (dres && dres_acc) load_vec<V>(dres + i * V, dzv);
+        load_vec_s<V, kNt>(y, i * V, ybf, x);
+        load_vec<V, kNt>(da + i * V, g);
+        if (res) load_vec_s<V, kNt>(res, i * V, bf, r);
+        if (dres && dres_acc) load_vec<V, kNt>(dres + i * V, dzv);
 #pragma unroll
         for (int e = 0; e < V; ++e) {
             const float xh = (x[e] - mean[e]) * istd[e];
@@ -1129,10 +1145,10 @@ __global__ __launch_bounds__(NT) void k_unit1x1_bwd(ConvGeom g, const float* __r
         const unsigned xodd = (unsigned)((g.cin_off + c) & 1);    // CinT is a multiple of 4 here: the parity is the channel's
         f32x4 dy = {0.f, 0.f, 0.f, 0.f};
         if (pv && co_ok4) {
-            const f32x4 yv = sld4(y, p * g.Cout + 4 * q, ybf);
-            const f32x4 gv = *reinterpret_cast<const f32x4*>(da + p * g.Cout + 4 * q);
+            const f32x4 yv = sld4<kNt>(y, p * g.Cout + 4 * q, ybf);
+            const f32x4 gv = sld4<kNt>(da, p * g.Cout + 4 * q, 0);
             f32x4 rv = {0.f, 0.f, 0.f, 0.f};
-            if (res) rv = sld4(res, p * g.Cout + 4 * q, bf);
+            if (res) rv = sld4<kNt>(res, p * g.Cout + 4 * q, bf);
             f32x4 dzv;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
@@ -1675,6 +1691,12 @@ __global__ __launch_bounds__(NT) void k_sisnr_gwave(float* __restrict__ yp, cons
 
 __global__ __launch_bounds__(NT) void k_add(const float* __restrict__ a, const float* __restrict__ b,
                                            float* __restrict__ out, long n) {
+    if ((n & 3) == 0 && ((reinterpret_cast<size_t>(a) | reinterpret_cast<size_t>(b) | reinterpret_cast<size_t>(out)) & 15) == 0) {
+        // (every tensor of the model: 16-byte accesses)
+        for (long i = (long)blockIdx.x * NT + threadIdx.x; i < (n >> 2); i += (long)gridDim.x * NT)
+            *reinterpret_cast<f32x4*>(out + 4 * i) = sld4<kNt>(a, 4 * i, 0) + sld4<kNt>(b, 4 * i, 0);
+        return;
+    }
     for (long i = (long)blockIdx.x * NT + threadIdx.x; i < n; i += (long)gridDim.x * NT) out[i] = a[i] + b[i];
 }
 
@@ -1682,7 +1704,7 @@ __global__ __launch_bounds__(NT) void k_add(const float* __restrict__ a, const f
 __global__ __launch_bounds__(NT) void k_add_saved(const float* __restrict__ a, const float* __restrict__ b,
                                                  float* __restrict__ out, long n4, int bf) {
     for (long i = (long)blockIdx.x * NT + threadIdx.x; i < n4; i += (long)gridDim.x * NT)
-        sst4(out, i * 4, bf, sld4(a, i * 4, bf) + sld4(b, i * 4, bf));
+        sst4(out, i * 4, bf, sld4<kNt>(a, i * 4, bf) + sld4<kNt>(b, i * 4, bf));
 }
 __global__ __launch_bounds__(NT) void k_saved_to_f32(const float* __restrict__ src, float* __restrict__ dst, long n,
                                                     int bf) {
@@ -1698,14 +1720,18 @@ int check() { return (int)hipGetLastError(); }
 static void launch_bn_bwd_reduce4(int grid, hipStream_t s, const float* da, const float* y, long total, int C,
                                   const float* stats, const float* gamma, const float* beta, const float* res, int act,
                                   const float* slope, double* partial, int bf, int ybf) {
-#define GT_RED(F) hipLaunchKernelGGL((k_bn_bwd_reduce<4, F>), dim3(grid), dim3(NT), 0, s, da, y, total, C, stats, gamma, \
-                                     beta, res, act, slope, partial, bf, ybf)
+#define GT_RED(F, A) hipLaunchKernelGGL((k_bn_bwd_reduce<4, F, A>), dim3(grid), dim3(NT), 0, s, da, y, total, C, stats, \
+                                        gamma, beta, res, act, slope, partial, bf, ybf)
     const int f = bf * 4 + ybf;
-    if (f == 0) GT_RED(0);
-    else if (f == 5) GT_RED(5);          // bf16 activations, bf16 conv outputs
-    else if (f == 4) GT_RED(4);          // (diagnostic storage codes 2, 3)
-    else if (f == 6) GT_RED(6);
-    else GT_RED(-1);
+    if (f == 0 && act == ACT_PRELU) GT_RED(0, ACT_PRELU);
+    else if (f == 0 && act == ACT_NONE) GT_RED(0, ACT_NONE);
+    else if (f == 5 && act == ACT_PRELU) GT_RED(5, ACT_PRELU);      // bf16 activations, bf16 conv outputs
+    else if (f == 5 && act == ACT_NONE) GT_RED(5, ACT_NONE);
+    else if (f == 0) GT_RED(0, -1);
+    else if (f == 5) GT_RED(5, -1);
+    else if (f == 4) GT_RED(4, -1);          // (diagnostic storage codes 2, 3)
+    else if (f == 6) GT_RED(6, -1);
+    else GT_RED(-1, -1);
 #undef GT_RED
 }
 
@@ -1770,11 +1796,7 @@ int conv_wgrad(const ConvGeom& g, const float* in, const float* dout, float* dw,
         const int K = g.nkt * g.nkf * 256 + 16;
         // 16-byte operand loads through wave-private LDS tiles when the channel counts allow them (all MFMA layers of
         // this model); the 4-byte form otherwise
-#ifdef GT_EXP
-        const bool wide = false;
-#else
         const bool wide = mfma_ok(g);     // channel counts / offsets in multiples of four: 16-byte operand loads
-#endif
 #define GT_WG1(K_, KT, KF)                                                                                             \
     do {                                                                                                               \
         if (g.in_bf == 0) hipLaunchKernelGGL((K_<KT, KF, 0>), dim3(grid), dim3(WG_WAVES * 64), 0, s, g, in, dout, scratch, gpw); \

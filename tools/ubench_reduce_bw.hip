@@ -54,6 +54,35 @@ __global__ __launch_bounds__(NT) void k_red(const f32x4* __restrict__ a, const f
     }
 }
 
+// rotating over NPAIR buffer pairs (3.3 GB): nothing of a pair is left in the 256 MB Infinity Cache when its turn comes
+// again; with WRITER the second tensor of the pair is (re)written by a streaming kernel right before it is read, as the
+// gradient `da` is in the train step
+__global__ __launch_bounds__(256) void k_fill(f32x4* __restrict__ b, long units, float v) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < units; i += (long)gridDim.x * 256) b[i] = f32x4{v, v, v, v};
+}
+constexpr int NPAIR = 6;
+template <int NT, int U, int LAYOUT, bool NTL>
+static int run_rot(const char* name, int grid, f32x4* const* a, f32x4* const* b, long units, float* out, bool writer) {
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    double us = 0.0;
+    const int R = 18;
+    for (int i = 0; i < R + 3; ++i) {
+        const int k = i % NPAIR;
+        if (writer) hipLaunchKernelGGL(k_fill, dim3(4096), dim3(256), 0, 0, b[k], units, 0.f);
+        CK(hipEventRecord(e0));
+        hipLaunchKernelGGL((k_red<NT, U, LAYOUT, NTL>), dim3(grid), dim3(NT), 0, 0, a[k], b[k], units, out);
+        CK(hipEventRecord(e1));
+        CK(hipEventSynchronize(e1));
+        float ms = 0.f;
+        CK(hipEventElapsedTime(&ms, e0, e1));
+        if (i >= 3) us += ms * 1e3 / R;
+    }
+    printf("%-44s grid %5d  %7.1f us  %5.2f TB/s  (rotating%s)\n", name, grid, us, 2.0 * units * 16 / us * 1e-6,
+           writer ? ", second tensor just written" : "");
+    return 0;
+}
+
 template <int NT, int U, int LAYOUT, bool NTL>
 static int run(const char* name, int grid, const f32x4* a, const f32x4* b, long units, float* out) {
     hipEvent_t e0, e1;
@@ -91,5 +120,18 @@ int main() {
     for (int grid : {1024, 2048}) run<256, 4, 1, true>("WG-contiguous NT256 U4 nontemporal", grid, a, b, units, out);
     for (int grid : {1024, 2048}) run<256, 4, 2, false>("wave-contiguous NT256 U4", grid, a, b, units, out);
     for (int grid : {1024, 2048}) run<256, 8, 2, false>("wave-contiguous NT256 U8", grid, a, b, units, out);
+    f32x4 *ra[NPAIR], *rb[NPAIR];
+    for (int k = 0; k < NPAIR; ++k) {
+        CK(hipMalloc(&ra[k], units * 16)); CK(hipMalloc(&rb[k], units * 16));
+        CK(hipMemset(ra[k], 0, units * 16)); CK(hipMemset(rb[k], 0, units * 16));
+    }
+    for (int w = 0; w < 2; ++w) {
+        run_rot<256, 4, 0, false>("grid-stride NT256 U4", 1024, ra, rb, units, out, w);
+        run_rot<256, 4, 0, false>("grid-stride NT256 U4", 2048, ra, rb, units, out, w);
+        run_rot<256, 8, 0, false>("grid-stride NT256 U8", 1024, ra, rb, units, out, w);
+        run_rot<256, 4, 0, true>("grid-stride NT256 U4 nontemporal", 1024, ra, rb, units, out, w);
+        run_rot<256, 4, 1, false>("WG-contiguous NT256 U4", 1024, ra, rb, units, out, w);
+        run_rot<1024, 4, 0, false>("grid-stride NT1024 U4", 256, ra, rb, units, out, w);
+    }
     return 0;
 }
