@@ -86,11 +86,12 @@ __device__ __forceinline__ void sst1(float* base, long idx, int fmt, float v) {
 // written (every gradient, every conv output) is still dirty in the Infinity Cache; a plain streaming read of two
 // 271 MB tensors, one of them just written, runs at 4.65 TB/s, the same read with nontemporal loads at 6.68 TB/s
 // (tools/ubench_reduce_bw.hip: without the preceding writer 6.24 against 6.53)
-#ifdef GT_EXP
-constexpr bool kNt = false;    // A/B build (tools/ab_bench.py): plain loads everywhere
-#else
-constexpr bool kNt = true;
-#endif
+// Same-box A/Bs of the fp32 step (tools/ab_bench.py style, GTCRN_LIB_VARIANT=exp): nontemporal loads in the read-once
+// passes 46.2-47.0 ms against 47.9-48.7 with plain loads; the same hint on loads that are re-read by neighbouring taps
+// (k_dw16, the 3x3 / 1x5 convs and weight gradients) 48.3 against 46.8 -- worse, not used; on the conv / weight-gradient
+// operands that are read once 45.8 against 45.9 -- nothing; nontemporal STORES of the streamed outputs 46.2 against 46.5.
+constexpr bool kNt = true;      // loads of the read-once passes
+constexpr bool kNtSt = true;    // stores of tensors a later kernel streams through once
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 template <bool NTL = false>
 __device__ __forceinline__ f32x4 sld4(const float* base, long idx, int fmt) {      // idx % 4 == 0
@@ -102,14 +103,17 @@ __device__ __forceinline__ f32x4 sld4(const float* base, long idx, int fmt) {   
     const f32x4* p = reinterpret_cast<const f32x4*>(base + idx);
     return NTL ? __builtin_nontemporal_load(p) : *p;
 }
+template <bool NTS = false>
 __device__ __forceinline__ void sst4(float* base, long idx, int fmt, const f32x4 v) {
     if (fmt) {
-        uint2 u;
+        u32x2 u;
         u.x = enc16(v[0], fmt) | (enc16(v[1], fmt) << 16);
         u.y = enc16(v[2], fmt) | (enc16(v[3], fmt) << 16);
-        *reinterpret_cast<uint2*>(reinterpret_cast<unsigned short*>(base) + idx) = u;
+        u32x2* p = reinterpret_cast<u32x2*>(reinterpret_cast<unsigned short*>(base) + idx);
+        if (NTS) __builtin_nontemporal_store(u, p); else *p = u;
     } else {
-        *reinterpret_cast<f32x4*>(base + idx) = v;
+        f32x4* p = reinterpret_cast<f32x4*>(base + idx);
+        if (NTS) __builtin_nontemporal_store(v, p); else *p = v;
     }
 }
 __device__ __forceinline__ float round16(float x, int fmt) { return fmt ? dec16(enc16(x, fmt), fmt) : x; }
@@ -287,10 +291,16 @@ struct RowPos {
 template <int FMT> struct Raw4 { using t = f32x4; };
 template <> struct Raw4<1> { using t = uint2; };
 template <> struct Raw4<2> { using t = uint2; };
-template <int FMT>
+template <int FMT, bool NTL = false>
 __device__ __forceinline__ typename Raw4<FMT>::t sld4_raw(const float* base, long idx) {      // idx % 4 == 0
-    if constexpr (FMT == 0) return *reinterpret_cast<const f32x4*>(base + idx);
-    else return *reinterpret_cast<const uint2*>(reinterpret_cast<const unsigned short*>(base) + idx);
+    if constexpr (FMT == 0) {
+        const f32x4* p = reinterpret_cast<const f32x4*>(base + idx);
+        return NTL ? __builtin_nontemporal_load(p) : *p;
+    } else {
+        const u32x2* p = reinterpret_cast<const u32x2*>(reinterpret_cast<const unsigned short*>(base) + idx);
+        const u32x2 u = NTL ? __builtin_nontemporal_load(p) : *p;
+        return uint2{u.x, u.y};
+    }
 }
 template <int FMT>
 __device__ __forceinline__ f32x4 dec4(const typename Raw4<FMT>::t r) {
@@ -362,10 +372,11 @@ __global__ __launch_bounds__(NT) void k_conv_mfma(ConvGeom g, const float* __res
         if (pv && cout_ok) {
             if (g.out_bf) {
                 acc = round_bf4(acc, g.out_bf);   // the statistics are those of the STORED tensor (the backward re-reads it)
-                sst4(out, p * g.CoutT + g.cout_off + 4 * q, g.out_bf, acc);
+                sst4<kNtSt>(out, p * g.CoutT + g.cout_off + 4 * q, g.out_bf, acc);
             } else {
                 f32x4* o = reinterpret_cast<f32x4*>(out + p * g.CoutT + g.cout_off + 4 * q);
-                *o = g.accumulate ? *o + acc : acc;
+                if (g.accumulate) *o = *o + acc;
+                else sst4<kNtSt>(out, p * g.CoutT + g.cout_off + 4 * q, 0, acc);
             }
 #pragma unroll
             for (int e = 0; e < 4; ++e) { const double a = (double)acc[e]; s1[e] += a; s2[e] = fma(a, a, s2[e]); }
@@ -694,10 +705,11 @@ __global__ __launch_bounds__(NT) void k_dw16(DwGeom g, const float* __restrict__
         P.advance(it, g.F, g.Tout);
         if (g.out_bf) {
             acc = round_bf4(acc, g.out_bf);
-            sst4(out, p * 16 + 4 * q, g.out_bf, acc);
+            sst4<kNtSt>(out, p * 16 + 4 * q, g.out_bf, acc);
         } else {
             f32x4* o = reinterpret_cast<f32x4*>(out + p * 16 + 4 * q);
-            *o = g.accumulate ? *o + acc : acc;
+            if (g.accumulate) *o = *o + acc;
+            else sst4<kNtSt>(out, p * 16 + 4 * q, 0, acc);
         }
 #pragma unroll
         for (int e = 0; e < 4; ++e) { const double a = (double)acc[e]; s1[e] += a; s2[e] = fma(a, a, s2[e]); }
@@ -846,7 +858,7 @@ __global__ __launch_bounds__(NT) void k_bn_act(const float* __restrict__ y, long
             if (res) z += r[e];
             o[e] = act_fwd(z, act, sl);
         }
-        if constexpr (V == 4) sst4(a, i * 4, bf, f32x4{o[0], o[1], o[2], o[3]});
+        if constexpr (V == 4) sst4<kNtSt>(a, i * 4, bf, f32x4{o[0], o[1], o[2], o[3]});
         else sst1(a, i, bf, o[0]);
     }
 }
@@ -1004,19 +1016,23 @@ __global__ __launch_bounds__(NT) void k_dw_wgrad_stream(DwGeom g, const float* _
         const f32x4 d = *reinterpret_cast<const f32x4*>(dout + p * 16 + 4 * q);
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[NTAP][e] += d[e];
+        // all tap loads first (a tap outside the tensor loads the centre record and contributes d * 0), as in k_dw16
+        f32x4 xv[NTAP];
+        bool okv[NTAP];
 #pragma unroll
-        for (int kt = 0; kt < NKT; ++kt) {
-            const int ti = P.to + g.t_off[kt];
-            if (ti < 0 || ti >= g.Tin) continue;
+        for (int kt = 0; kt < NKT; ++kt)
 #pragma unroll
             for (int kf = 0; kf < NKF; ++kf) {
-                const int fi = P.fo + g.f_off[kf];
-                if (fi < 0 || fi >= g.F) continue;
-                const f32x4 x = sld4(in, ((long)(P.bt + g.t_off[kt]) * g.F + fi) * 16 + 4 * q, g.in_bf);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[kt * NKF + kf][e] = fmaf(d[e], x[e], v[kt * NKF + kf][e]);
+                const int ti = P.to + g.t_off[kt], fi = P.fo + g.f_off[kf];
+                const bool ok = ti >= 0 && ti < g.Tin && fi >= 0 && fi < g.F;
+                const long rec = ok ? (long)(P.bt + g.t_off[kt]) * g.F + fi : p;
+                okv[kt * NKF + kf] = ok;
+                xv[kt * NKF + kf] = sld4(in, rec * 16 + 4 * q, g.in_bf);     // (no use of the value in this loop)
             }
-        }
+#pragma unroll
+        for (int tp = 0; tp < NTAP; ++tp)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[tp][e] = fmaf(d[e], okv[tp] ? xv[tp][e] : 0.f, v[tp][e]);
         P.advance(it, g.F, g.Tout);
     }
     block_reduce_store<NTAP + 1, 4>(v, 16, sh, partial + (long)blockIdx.x * (NTAP + 1) * 16);
@@ -1162,7 +1178,8 @@ __global__ __launch_bounds__(NT) void k_unit1x1_bwd(ConvGeom g, const float* __r
             }
             if (dres) {
                 f32x4* dr = reinterpret_cast<f32x4*>(dres + p * g.Cout + 4 * q);
-                *dr = dres_acc ? *dr + dzv : dzv;
+                if (dres_acc) *dr = *dr + dzv;
+                else sst4<kNtSt>(dres, p * g.Cout + 4 * q, 0, dzv);
             }
         }
         // data gradient: dx[pos][ci] = sum_co W[co][ci] dy[pos][co]
@@ -1172,7 +1189,8 @@ __global__ __launch_bounds__(NT) void k_unit1x1_bwd(ConvGeom g, const float* __r
             for (int e = 0; e < 4; ++e) acc = mfma4(At[e], dy[e], acc);
             if (pv && ci_ok4) {
                 f32x4* o = reinterpret_cast<f32x4*>(dx + p * g.CinT + g.cin_off + 4 * q);
-                *o = dx_acc ? *o + acc : acc;
+                if (dx_acc) *o = *o + acc;
+                else sst4<kNtSt>(dx, p * g.CinT + g.cin_off + 4 * q, 0, acc);
             }
         }
         // weight gradient: dy tile through wave-private LDS into the (c, k) layout
@@ -1694,7 +1712,7 @@ __global__ __launch_bounds__(NT) void k_add(const float* __restrict__ a, const f
     if ((n & 3) == 0 && ((reinterpret_cast<size_t>(a) | reinterpret_cast<size_t>(b) | reinterpret_cast<size_t>(out)) & 15) == 0) {
         // (every tensor of the model: 16-byte accesses)
         for (long i = (long)blockIdx.x * NT + threadIdx.x; i < (n >> 2); i += (long)gridDim.x * NT)
-            *reinterpret_cast<f32x4*>(out + 4 * i) = sld4<kNt>(a, 4 * i, 0) + sld4<kNt>(b, 4 * i, 0);
+            sst4<kNtSt>(out, 4 * i, 0, sld4<kNt>(a, 4 * i, 0) + sld4<kNt>(b, 4 * i, 0));
         return;
     }
     for (long i = (long)blockIdx.x * NT + threadIdx.x; i < n; i += (long)gridDim.x * NT) out[i] = a[i] + b[i];
@@ -1704,7 +1722,7 @@ __global__ __launch_bounds__(NT) void k_add(const float* __restrict__ a, const f
 __global__ __launch_bounds__(NT) void k_add_saved(const float* __restrict__ a, const float* __restrict__ b,
                                                  float* __restrict__ out, long n4, int bf) {
     for (long i = (long)blockIdx.x * NT + threadIdx.x; i < n4; i += (long)gridDim.x * NT)
-        sst4(out, i * 4, bf, sld4<kNt>(a, i * 4, bf) + sld4<kNt>(b, i * 4, bf));
+        sst4<kNtSt>(out, i * 4, bf, sld4<kNt>(a, i * 4, bf) + sld4<kNt>(b, i * 4, bf));
 }
 __global__ __launch_bounds__(NT) void k_saved_to_f32(const float* __restrict__ src, float* __restrict__ dst, long n,
                                                     int bf) {
