@@ -57,6 +57,11 @@ struct Unit {                 // conv (dense or depthwise) + BatchNorm + activat
     float* a = nullptr;       // activation output
     const float* res = nullptr;
     float* stats = nullptr;   // mean[C], invstd[C]
+    // normalise-on-load (gtt::BnPre): `pre` = the unit in front whose BatchNorm + PReLU this unit's conv applies while
+    // loading that unit's y (and whose activation it writes); `deferred` = this unit's own bn_act pass is left to its
+    // consumer.  Set for conv1 -> conv2 -> conv3 of the TCN blocks and depth_conv -> point_conv2 of the GTConv blocks.
+    Unit* pre = nullptr;
+    bool deferred = false;
 };
 
 struct GtBlock {              // GTConvBlock (models/gtcrn_micro.py:167-253)
@@ -184,6 +189,7 @@ size_t plan(gtcrn_trainer* t, int B, int T, float* base) {
     const long n129 = (long)B * T * 129, n65 = (long)B * T * 65, n33 = (long)B * T * 33;
     const int T2 = T + 2;
     const long n33x = (long)B * T2 * 33;
+    const bool fuse = t->ybf <= 1;      // (not for the fp16 diagnostic storage)
     t->taps.clear();
     t->eb = b.take_saved(n129 * 3);
     t->f0 = b.take_saved(n129 * 3);
@@ -229,6 +235,8 @@ size_t plan(gtcrn_trainer* t, int B, int T, float* base) {
         unit_params(t, k.pc2, p + ".point_conv2", p + ".point_bn2", "");
         k.pc2.act = gtt::ACT_NONE; k.pc2.x = k.depth.a;
         alloc_unit(b, k.pc2, nt, 8);
+        k.pc2.pre = fuse ? &k.depth : nullptr;
+        k.depth.deferred = fuse;
         k.o_tra = P(t, p + ".tra.depth_conv.weight");
         k.e = b.take((size_t)B * Tt * 8); k.yt = b.take((size_t)B * Tt * 8); k.g = b.take((size_t)B * Tt * 8);
         k.out = b.take_saved(n33 * 16);
@@ -260,6 +268,8 @@ size_t plan(gtcrn_trainer* t, int B, int T, float* base) {
         unit_params(t, k.c3, p + ".conv3", p + ".bn3", p + ".act3");
         k.c3.act = gtt::ACT_PRELU; k.c3.x = k.c2.a; k.c3.res = X;
         alloc_unit(b, k.c3, n33, 16);
+        k.c2.pre = fuse ? &k.c1 : nullptr; k.c1.deferred = fuse;
+        k.c3.pre = fuse ? &k.c2 : nullptr; k.c2.deferred = fuse;
         X = k.c3.a;
         if ((i & 3) == 3) t->taps["gtcn" + std::to_string(i / 4 + 1)] = {X, {T, 33, 16}};
     }
@@ -336,11 +346,29 @@ int unit_fwd(gtcrn_trainer* t, Unit& u, float* prm, hipStream_t s) {
     float* shift = t->ybf ? u.stats + 32 : nullptr;
     if (shift && !t->shift_ready)
         T_HIP(hipMemcpyAsync(shift, bn + 2 * u.C, sizeof(float) * u.C, hipMemcpyDeviceToDevice, s));
-    if (u.dw) T_RUN(gtt::dw_fwd(u.dg, u.x, prm + u.o_w, prm + u.o_b, u.y, s, t->dscratch, &parts, shift));
+    if (u.pre) {
+        const Unit& v = *u.pre;
+        const float* vbn = prm + v.o_bn;
+        gtt::BnPre bp{};
+        bp.stats = v.stats; bp.gamma = vbn; bp.beta = vbn + v.C;
+        bp.slope = v.o_slope >= 0 ? prm + v.o_slope : nullptr;
+        bp.a_out = v.a; bp.ybf = t->ybf; bp.bf = t->bf;
+        if (u.dw) {
+            DwGeom g = u.dg;
+            g.in_bf = t->ybf;
+            T_RUN(gtt::dw_fwd(g, v.y, prm + u.o_w, prm + u.o_b, u.y, s, t->dscratch, &parts, shift, &bp));
+        } else {
+            ConvGeom g = u.cg;
+            g.in_bf = t->ybf;
+            T_RUN(gtt::conv_fwd(g, v.y, prm + u.o_w, prm + u.o_b, u.y, s, t->dscratch, &parts, shift, &bp));
+        }
+    }
+    else if (u.dw) T_RUN(gtt::dw_fwd(u.dg, u.x, prm + u.o_w, prm + u.o_b, u.y, s, t->dscratch, &parts, shift));
     else T_RUN(gtt::conv_fwd(u.cg, u.x, prm + u.o_w, prm + u.o_b, u.y, s, t->dscratch, &parts, shift));
     T_RUN(gtt::bn_stats(u.y, u.n, u.C, u.stats, bn + 2 * u.C, bn + 3 * u.C, t->dscratch, s, parts, t->ybf, shift));
-    T_RUN(gtt::bn_act(u.y, u.n, u.C, u.stats, bn, bn + u.C, u.res, u.act, u.o_slope >= 0 ? prm + u.o_slope : nullptr,
-                      u.a, s, t->bf, t->ybf));
+    if (!u.deferred)
+        T_RUN(gtt::bn_act(u.y, u.n, u.C, u.stats, bn, bn + u.C, u.res, u.act, u.o_slope >= 0 ? prm + u.o_slope : nullptr,
+                          u.a, s, t->bf, t->ybf));
     return 0;
 }
 

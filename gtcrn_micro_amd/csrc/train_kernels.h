@@ -57,14 +57,26 @@ constexpr int MAX_PARTIALS = 1024;   // workgroups of a two-stage reduction
 // shift (optional, bf16 output only): out = conv(in) + bias - shift[c]; the following train-mode BatchNorm is shift
 // invariant.  bn_stats(..., shift) accounts for it in the running-mean update and sets shift[c] to this step's batch
 // mean for the next step, so the stored values stay centred (bf16 rounding relative to the spread, not the offset).
+// pre (optional; 1x1 convs over all 16 channels and the 16-channel depthwise convs with (3,1) taps): `in` is the
+// PREVIOUS unit's conv output y (format pre->ybf); the kernel applies that unit's BatchNorm + PReLU while loading
+// (same expressions as bn_act: bit-identical values), writes the activation to pre->a_out (format pre->bf) -- the
+// backward reads it -- and convolves the stored (rounded) activation.  The separate bn_act pass of the previous unit
+// (read y, write a) disappears; its consumer reads y instead of a.
+struct BnPre {
+    const float *stats, *gamma, *beta, *slope;   // of the previous unit; slope == nullptr: no activation
+    float* a_out;
+    int ybf, bf;
+};
 int conv_fwd(const ConvGeom& g, const float* in, const float* w, const float* bias, float* out, hipStream_t s,
-             double* stat_partial = nullptr, int* stat_parts = nullptr, const float* shift = nullptr);
+             double* stat_partial = nullptr, int* stat_parts = nullptr, const float* shift = nullptr,
+             const BnPre* pre = nullptr);
 // dW (and db when dbias != nullptr) of the convolution g: in = its input, dout = gradient of its output.
 // scratch: MAX_PARTIALS * (9*256 + 16) floats.
 int conv_wgrad(const ConvGeom& g, const float* in, const float* dout, float* dw, float* dbias, float* scratch,
                hipStream_t s);
 int dw_fwd(const DwGeom& g, const float* in, const float* w, const float* bias, float* out, hipStream_t s,
-           double* stat_partial = nullptr, int* stat_parts = nullptr, const float* shift = nullptr);
+           double* stat_partial = nullptr, int* stat_parts = nullptr, const float* shift = nullptr,
+           const BnPre* pre = nullptr);
 int dw_wgrad(const DwGeom& g, const float* in, const float* dout, float* dw, float* dbias, float* scratch,
              hipStream_t s);
 

@@ -307,6 +307,34 @@ __device__ __forceinline__ f32x4 dec4(const typename Raw4<FMT>::t r) {
     if constexpr (FMT == 0) return r;
     else return f32x4{dec16(r.x & 0xFFFFu, FMT), dec16(r.x >> 16, FMT), dec16(r.y & 0xFFFFu, FMT), dec16(r.y >> 16, FMT)};
 }
+// BnPre (train_kernels.h): the previous unit's BatchNorm + PReLU applied to a loaded quad of its conv output -- the
+// expressions of k_bn_act, so the values are bit-identical to the separate pass -- rounded to the activation's storage
+// format (what a later reader of the stored activation would see)
+struct PreConst {
+    f32x4 mean, istd, gm, bt;
+    float sl;
+    bool act;
+};
+__device__ __forceinline__ PreConst pre_const(const BnPre& pre, int q, int C) {
+    PreConst k;
+    k.mean = *reinterpret_cast<const f32x4*>(pre.stats + 4 * q);
+    k.istd = *reinterpret_cast<const f32x4*>(pre.stats + C + 4 * q);
+    k.gm = *reinterpret_cast<const f32x4*>(pre.gamma + 4 * q);
+    k.bt = *reinterpret_cast<const f32x4*>(pre.beta + 4 * q);
+    k.act = pre.slope != nullptr;
+    k.sl = k.act ? pre.slope[0] : 0.f;
+    return k;
+}
+__device__ __forceinline__ f32x4 pre_apply(const PreConst& k, const f32x4 y, int bf) {
+    f32x4 a;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const float z = k.gm[e] * ((y[e] - k.mean[e]) * k.istd[e]) + k.bt[e];
+        a[e] = k.act ? (z > 0.f ? z : k.sl * z) : z;
+    }
+    return round_bf4(a, bf);
+}
+
 // four consecutive elements starting at ANY element index (4-byte / 2-byte aligned): one global_load_dwordx4 /
 // dwordx2 (the hardware takes unaligned vector loads; gfx950 runs in unaligned access mode under ROCm)
 template <int FMT>
@@ -363,11 +391,14 @@ __device__ __forceinline__ f32x4 win_value(const float* base, const WinPos& w, c
 // the tensor loads element 0 and is zeroed by a select -- with `if (ok) load` every tap sat in its own basic block and
 // the tile paid nine L2 latencies one after the other (the 3x3 convs ran at 45 TFLOP/s, latency-bound).
 // WIN: the window form above (NKT = NKF = 1 then: one 16 x 16 matrix [co][j])
-template <int NKT, int NKF, int FIN, bool WIN = false>
+// PRE: 1x1 only; `in` is the previous unit's conv output, see BnPre
+template <int NKT, int NKF, int FIN, bool WIN = false, bool PRE = false>
 __global__ __launch_bounds__(NT) void k_conv_mfma(ConvGeom g, const float* __restrict__ in,
                                                  const float* __restrict__ w, const float* __restrict__ bias,
                                                  float* __restrict__ out, long tiles_per_wave,
-                                                 double* __restrict__ stat_partial, const float* __restrict__ shift) {
+                                                 double* __restrict__ stat_partial, const float* __restrict__ shift,
+                                                 BnPre pre) {
+    static_assert(!PRE || (NKT * NKF == 1 && !WIN), "normalise-on-load: pointwise convs only");
     __shared__ __attribute__((aligned(16))) float sW[NKT * NKF * 256];   // [tap][co][ci], zero padded
     __shared__ double sStat[NT / 64][32];   // per wave: sum[16], sum of squares[16]
     const int tid = threadIdx.x;
@@ -399,6 +430,8 @@ __global__ __launch_bounds__(NT) void k_conv_mfma(ConvGeom g, const float* __res
     if (bias && 4 * q < g.Cout) bv = *reinterpret_cast<const f32x4*>(bias + 4 * q);
     if (shift && 4 * q < g.Cout) bv -= *reinterpret_cast<const f32x4*>(shift + 4 * q);
     const bool cin_ok = 4 * q < g.Cin, cout_ok = 4 * q < g.Cout;
+    PreConst pk{};
+    if constexpr (PRE) pk = pre_const(pre, q, g.CinT);
     for (; tile < tend; ++tile) {
         const long p = tile * 16 + n;
         const bool pv = p < npos;
@@ -414,6 +447,7 @@ __global__ __launch_bounds__(NT) void k_conv_mfma(ConvGeom g, const float* __res
         } else {
         typename Raw4<FIN>::t raw[NKT * NKF];
         bool okv[NKT * NKF];
+        long pidx = 0;
 #pragma unroll
         for (int kt = 0; kt < NKT; ++kt) {
             const int ti = P.t + g.t_off[kt];
@@ -425,11 +459,16 @@ __global__ __launch_bounds__(NT) void k_conv_mfma(ConvGeom g, const float* __res
                 const bool ok = tap_fi(g, P.f, kf, fi) && okt;
                 okv[kt * NKF + kf] = ok;
                 raw[kt * NKF + kf] = sld4_raw<FIN>(in, ok ? (rowbase + fi) * g.CinT + g.cin_off + 4 * q : 0L);
+                if constexpr (PRE) pidx = (rowbase + fi) * g.CinT + g.cin_off + 4 * q;
             }
         }
 #pragma unroll
         for (int tap = 0; tap < NKT * NKF; ++tap) {
-            const f32x4 d = dec4<FIN>(raw[tap]);
+            f32x4 d = dec4<FIN>(raw[tap]);
+            if constexpr (PRE) {
+                d = pre_apply(pk, d, pre.bf);
+                if (okv[tap]) sst4<kNtSt>(pre.a_out, pidx, pre.bf, d);
+            }
             const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
             const f32x4 xv = okv[tap] ? d : zero;
             const f32x4 A = *reinterpret_cast<const f32x4*>(sW + tap * 256 + n * 16 + 4 * q);
@@ -908,11 +947,14 @@ __global__ __launch_bounds__(NT) void k_dw(DwGeom g, const float* __restrict__ i
 // FIN: storage format of `in` as a compile-time constant (-1: run-time g.in_bf): with the run-time flag the 16-bit
 // branch of every tap load decodes inside its own basic block, i.e. waits for that load before the next one is issued
 // (bf16 storage: k_dw16<3,3> 245 us against 165 with fp32 storage, twice the bytes)
-template <int NKT, int NKF, int FIN = -1>
+// PRE: `in` is the previous unit's conv output (see BnPre); the last temporal / middle frequency tap is the thread's
+// own position (t_off[NKT-1] == 0, f_off[NKF/2] == 0: checked by the launcher) and stores the activation
+template <int NKT, int NKF, int FIN = -1, bool PRE = false>
 __global__ __launch_bounds__(NT) void k_dw16(DwGeom g, const float* __restrict__ in, const float* __restrict__ w,
                                             const float* __restrict__ bias, float* __restrict__ out,
                                             double* __restrict__ stat_partial, StrideIter it,
-                                            const float* __restrict__ shift) {
+                                            const float* __restrict__ shift, BnPre pre) {
+    static_assert(!PRE || (FIN >= 0 && NKT > 0), "normalise-on-load needs the compile-time forms");
     __shared__ __attribute__((aligned(16))) float sW[9 * 16];   // [tap][c]
     __shared__ double sStat[NT / 64][32];   // per wave: sum[16], sum of squares[16]
     double s1[4] = {0.0, 0.0, 0.0, 0.0}, s2[4] = {0.0, 0.0, 0.0, 0.0};    // in double: see k_conv_mfma
@@ -925,6 +967,8 @@ __global__ __launch_bounds__(NT) void k_dw16(DwGeom g, const float* __restrict__
     // Tin == Tout for every depthwise conv of the model, so the tap row is (flat row + t_off): no (b, t) split
     const long units = (long)g.B * g.Tout * g.F * 4;
     const int q = tid & 3;
+    PreConst pk{};
+    if constexpr (PRE) pk = pre_const(pre, q, 16);
     RowPos P;
     P.init(((long)blockIdx.x * NT + tid) >> 2, g.F, g.Tout);
     for (long i = (long)blockIdx.x * NT + tid; i < units; i += (long)gridDim.x * NT) {
@@ -954,6 +998,10 @@ __global__ __launch_bounds__(NT) void k_dw16(DwGeom g, const float* __restrict__
 #pragma unroll
             for (int tp = 0; tp < NKT * NKF; ++tp) {
                 if constexpr (FIN >= 0) xv[tp] = dec4<FR>(xr[tp]);
+                if constexpr (PRE) {
+                    xv[tp] = pre_apply(pk, xv[tp], pre.bf);
+                    if (tp == (NKT - 1) * NKF + NKF / 2) sst4<kNtSt>(pre.a_out, p * 16 + 4 * q, pre.bf, xv[tp]);
+                }
                 const f32x4 wt = *reinterpret_cast<const f32x4*>(sW + tp * 16 + 4 * q);
                 const f32x4 nx = acc + wt * xv[tp];
                 acc = ok[tp] ? nx : acc;
@@ -2057,10 +2105,14 @@ static bool win_wgrad_ok(const ConvGeom& g) {
 }
 
 int conv_fwd(const ConvGeom& g, const float* in, const float* w, const float* bias, float* out, hipStream_t s,
-             double* stat_partial, int* stat_parts, const float* shift) {
+             double* stat_partial, int* stat_parts, const float* shift, const BnPre* pre) {
     if (shift && !g.out_bf) return (int)hipErrorInvalidValue;
     if (stat_parts) *stat_parts = 0;
-    if (win_fwd_ok(g) && stat_parts && !g.accumulate && g.Cout == 16 && g.CoutT == 16 && g.cout_off == 0) {
+    const BnPre nopre{};
+    if (pre && !(mfma_ok(g) && g.nkt == 1 && g.nkf == 1 && g.sf == 1 && g.Cin == 16 && g.CinT == 16 && g.cin_off == 0 &&
+                 g.in_bf == pre->ybf))
+        return (int)hipErrorInvalidValue;
+    if (!pre && win_fwd_ok(g) && stat_parts && !g.accumulate && g.Cout == 16 && g.CoutT == 16 && g.cout_off == 0) {
         // forward of a unit (a BatchNorm follows): the reference-ordered fmaf chain (see k_conv_win_fma)
         const long units = (long)g.B * g.Tout * g.Fout * 4;
         double* sp = stat_partial;
@@ -2083,14 +2135,19 @@ int conv_fwd(const ConvGeom& g, const float* in, const float* w, const float* bi
                       !g.accumulate) ? stat_partial : nullptr;
 #define GT_CM(KT, KF)                                                                                                  \
     do {                                                                                                               \
-        if (g.in_bf == 0) hipLaunchKernelGGL((k_conv_mfma<KT, KF, 0>), dim3(grid), dim3(NT), 0, s, g, in, w, bias, out, tpw, sp, shift); \
-        else if (g.in_bf == 1) hipLaunchKernelGGL((k_conv_mfma<KT, KF, 1>), dim3(grid), dim3(NT), 0, s, g, in, w, bias, out, tpw, sp, shift); \
-        else hipLaunchKernelGGL((k_conv_mfma<KT, KF, 2>), dim3(grid), dim3(NT), 0, s, g, in, w, bias, out, tpw, sp, shift); \
+        if (g.in_bf == 0) hipLaunchKernelGGL((k_conv_mfma<KT, KF, 0>), dim3(grid), dim3(NT), 0, s, g, in, w, bias, out, tpw, sp, shift, nopre); \
+        else if (g.in_bf == 1) hipLaunchKernelGGL((k_conv_mfma<KT, KF, 1>), dim3(grid), dim3(NT), 0, s, g, in, w, bias, out, tpw, sp, shift, nopre); \
+        else hipLaunchKernelGGL((k_conv_mfma<KT, KF, 2>), dim3(grid), dim3(NT), 0, s, g, in, w, bias, out, tpw, sp, shift, nopre); \
     } while (0)
-        if (win) {
-            if (g.in_bf == 0) hipLaunchKernelGGL((k_conv_mfma<1, 1, 0, true>), dim3(grid), dim3(NT), 0, s, g, in, w, bias, out, tpw, sp, shift);
-            else if (g.in_bf == 1) hipLaunchKernelGGL((k_conv_mfma<1, 1, 1, true>), dim3(grid), dim3(NT), 0, s, g, in, w, bias, out, tpw, sp, shift);
-            else hipLaunchKernelGGL((k_conv_mfma<1, 1, 2, true>), dim3(grid), dim3(NT), 0, s, g, in, w, bias, out, tpw, sp, shift);
+        if (pre) {
+            if (g.in_bf == 0) hipLaunchKernelGGL((k_conv_mfma<1, 1, 0, false, true>), dim3(grid), dim3(NT), 0, s, g, in, w, bias, out, tpw, sp, shift, *pre);
+            else if (g.in_bf == 1) hipLaunchKernelGGL((k_conv_mfma<1, 1, 1, false, true>), dim3(grid), dim3(NT), 0, s, g, in, w, bias, out, tpw, sp, shift, *pre);
+            else hipLaunchKernelGGL((k_conv_mfma<1, 1, 2, false, true>), dim3(grid), dim3(NT), 0, s, g, in, w, bias, out, tpw, sp, shift, *pre);
+        }
+        else if (win) {
+            if (g.in_bf == 0) hipLaunchKernelGGL((k_conv_mfma<1, 1, 0, true>), dim3(grid), dim3(NT), 0, s, g, in, w, bias, out, tpw, sp, shift, nopre);
+            else if (g.in_bf == 1) hipLaunchKernelGGL((k_conv_mfma<1, 1, 1, true>), dim3(grid), dim3(NT), 0, s, g, in, w, bias, out, tpw, sp, shift, nopre);
+            else hipLaunchKernelGGL((k_conv_mfma<1, 1, 2, true>), dim3(grid), dim3(NT), 0, s, g, in, w, bias, out, tpw, sp, shift, nopre);
         }
         else if (g.nkt == 3) GT_CM(3, 3);
         else if (g.nkf == 5) GT_CM(1, 5);
@@ -2164,9 +2221,13 @@ int conv_wgrad(const ConvGeom& g, const float* in, const float* dout, float* dw,
 }
 
 int dw_fwd(const DwGeom& g, const float* in, const float* w, const float* bias, float* out, hipStream_t s,
-           double* stat_partial, int* stat_parts, const float* shift) {
+           double* stat_partial, int* stat_parts, const float* shift, const BnPre* pre) {
     if (shift && (!g.out_bf || g.C != 16)) return (int)hipErrorInvalidValue;
     if (stat_parts) *stat_parts = 0;
+    const BnPre nopre{};
+    if (pre && !(g.C == 16 && g.nkt == 3 && g.nkf == 1 && g.t_off[2] == 0 && g.f_off[0] == 0 && g.in_bf == pre->ybf &&
+                 g.in_bf <= 1 && !g.accumulate))
+        return (int)hipErrorInvalidValue;
     const int grid = grid_for((long)g.B * g.Tout * g.F);
     if (g.C == 16) {
         double* sp = (stat_partial && stat_parts && !g.accumulate) ? stat_partial : nullptr;
@@ -2175,15 +2236,19 @@ int dw_fwd(const DwGeom& g, const float* in, const float* w, const float* bias, 
         const StrideIter it = stride_iter((long)g16 * NT / 4, g.F, g.Tout);
 #define GT_DW(KT, KF)                                                                                                   \
     do {                                                                                                               \
-        if (g.in_bf == 0) hipLaunchKernelGGL((k_dw16<KT, KF, 0>), dim3(g16), dim3(NT), 0, s, g, in, w, bias, out, sp, it, shift); \
-        else if (g.in_bf == 1) hipLaunchKernelGGL((k_dw16<KT, KF, 1>), dim3(g16), dim3(NT), 0, s, g, in, w, bias, out, sp, it, shift); \
-        else hipLaunchKernelGGL((k_dw16<KT, KF, -1>), dim3(g16), dim3(NT), 0, s, g, in, w, bias, out, sp, it, shift); \
+        if (g.in_bf == 0) hipLaunchKernelGGL((k_dw16<KT, KF, 0>), dim3(g16), dim3(NT), 0, s, g, in, w, bias, out, sp, it, shift, nopre); \
+        else if (g.in_bf == 1) hipLaunchKernelGGL((k_dw16<KT, KF, 1>), dim3(g16), dim3(NT), 0, s, g, in, w, bias, out, sp, it, shift, nopre); \
+        else hipLaunchKernelGGL((k_dw16<KT, KF, -1>), dim3(g16), dim3(NT), 0, s, g, in, w, bias, out, sp, it, shift, nopre); \
     } while (0)
-        if (g.nkt == 3 && g.nkf == 3) GT_DW(3, 3);
+        if (pre) {
+            if (g.in_bf == 0) hipLaunchKernelGGL((k_dw16<3, 1, 0, true>), dim3(g16), dim3(NT), 0, s, g, in, w, bias, out, sp, it, shift, *pre);
+            else hipLaunchKernelGGL((k_dw16<3, 1, 1, true>), dim3(g16), dim3(NT), 0, s, g, in, w, bias, out, sp, it, shift, *pre);
+        }
+        else if (g.nkt == 3 && g.nkf == 3) GT_DW(3, 3);
         else if (g.nkt == 3 && g.nkf == 1) GT_DW(3, 1);
 #undef GT_DW
         else
-            hipLaunchKernelGGL((k_dw16<0, 0>), dim3(g16), dim3(NT), 0, s, g, in, w, bias, out, sp, it, shift);
+            hipLaunchKernelGGL((k_dw16<0, 0>), dim3(g16), dim3(NT), 0, s, g, in, w, bias, out, sp, it, shift, nopre);
         if (sp) *stat_parts = g16;
         return check();
     }
