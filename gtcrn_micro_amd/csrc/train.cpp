@@ -62,6 +62,9 @@ struct Unit {                 // conv (dense or depthwise) + BatchNorm + activat
     // consumer.  Set for conv1 -> conv2 -> conv3 of the TCN blocks and depth_conv -> point_conv2 of the GTConv blocks.
     Unit* pre = nullptr;
     bool deferred = false;
+    // backward: `front` = the unit whose gradient input is this unit's dx (TCN conv2 -> conv1): the fused depthwise
+    // backward accumulates that unit's BatchNorm reduction too (gtt::dwunit_bwd)
+    Unit* front = nullptr;
 };
 
 struct GtBlock {              // GTConvBlock (models/gtcrn_micro.py:167-253)
@@ -90,6 +93,8 @@ struct gtcrn_trainer {
     size_t arena_floats = 0;
     float* fscratch = nullptr;    // wgrad / TRA partial sums
     double* dscratch = nullptr;   // BatchNorm partial sums
+    const void* red_unit = nullptr;   // backward: the unit whose BatchNorm reduction already sits in dscratch ...
+    int red_parts = 0;                // ... as this many per-workgroup partial sums (see unit_bwd)
     std::map<std::string, long> off;   // parameter name -> blob offset
     // plan
     float *eb = nullptr, *f0 = nullptr;
@@ -268,6 +273,7 @@ size_t plan(gtcrn_trainer* t, int B, int T, float* base) {
         unit_params(t, k.c3, p + ".conv3", p + ".bn3", p + ".act3");
         k.c3.act = gtt::ACT_PRELU; k.c3.x = k.c2.a; k.c3.res = X;
         alloc_unit(b, k.c3, n33, 16);
+        k.c2.front = &k.c1;
         k.c2.pre = fuse ? &k.c1 : nullptr; k.c1.deferred = fuse;
         k.c3.pre = fuse ? &k.c2 : nullptr; k.c2.deferred = fuse;
         X = k.c3.a;
@@ -377,13 +383,33 @@ int unit_bwd(gtcrn_trainer* t, Unit& u, const float* prm, float* grads, const fl
              float* dres, int dres_acc, hipStream_t s) {
     const float* bn = prm + u.o_bn;
     float* gbn = grads + u.o_bn;
+    // the BatchNorm reduction of this unit may already sit in dscratch (left by the kernel that produced da)
+    const int have_parts = t->red_unit == &u ? t->red_parts : 0;
+    t->red_unit = nullptr;
     if (!u.dw && u.cg.nkt == 1 && u.cg.nkf == 1 && u.cg.sf == 1 && (u.cg.Cin % 4) == 0 && (u.cg.Cout % 4) == 0) {
         // pointwise unit: BatchNorm backward, data gradient and weight gradient in one pass (after the reduction)
         T_RUN(gtt::unit1x1_bwd(u.cg, u.x, u.y, da, u.res, u.stats, bn, bn + u.C, u.act,
                                u.o_slope >= 0 ? prm + u.o_slope : nullptr, prm + u.o_w, dx, dx_acc, dres, dres_acc,
                                grads + u.o_w, u.o_b >= 0 ? grads + u.o_b : nullptr, gbn, gbn + u.C,
                                u.o_slope >= 0 ? grads + u.o_slope : nullptr, t->dscratch, t->fscratch, s, t->bf,
-                               t->ybf));
+                               t->ybf, have_parts));
+        return 0;
+    }
+    if (u.dw && u.C == 16 && u.dg.nkt == 3 && u.dg.nkf == 1 && u.act == gtt::ACT_PRELU && !u.res && u.o_slope >= 0 &&
+        dx && !dx_acc && !dres && t->bf == t->ybf && t->bf <= 1) {
+        // TCN conv2: dy, weight gradient and data gradient in one pass; conv1's reduction rides along
+        gtt::DwUnitNext nx{};
+        const Unit* f = u.front;
+        const bool ride = f && !f->dw && !f->res && f->act == gtt::ACT_PRELU && f->o_slope >= 0 && f->C == 16 && f->n == u.n;
+        if (ride) {
+            const float* fbn = prm + f->o_bn;
+            nx = gtt::DwUnitNext{f->y, f->stats, fbn, fbn + f->C, prm + f->o_slope};
+        }
+        int parts = 0;
+        T_RUN(gtt::dwunit_bwd(u.dg, u.x, u.y, da, u.stats, bn, bn + u.C, prm + u.o_slope, prm + u.o_w, dx,
+                              grads + u.o_w, u.o_b >= 0 ? grads + u.o_b : nullptr, gbn, gbn + u.C, grads + u.o_slope,
+                              t->dscratch, t->fscratch, s, t->bf, t->ybf, ride ? &nx : nullptr, &parts));
+        if (ride && parts > 0) { t->red_unit = f; t->red_parts = parts; }
         return 0;
     }
     T_RUN(gtt::bn_act_bwd(da, u.y, u.n, u.C, u.stats, bn, bn + u.C, u.res, u.act,
@@ -548,6 +574,7 @@ int gtcrn_train_backward(gtcrn_trainer* t, const float* d_params, const float* d
     float* G = d_grads;
     int rc;
     T_HIP(hipMemsetAsync(G, 0, sizeof(float) * GTCRN_NPARAM_FLOATS, s));
+    t->red_unit = nullptr;
     const long n33 = (long)B * T * 33 * 16, n65 = (long)B * T * 65 * 16;
     T_RUN(gtt::bs_mask_bwd(d_grad_out, gb, gf, gt, d_spec, sb, sf, st, B, T, prm + P(t, "erb.ierb_fc.weight"), t->dm, s));
     // de_convs.4 <- s4 = de3.a + en0.a : gs0 is the gradient of both addends (the sums are recomputed, see plan())

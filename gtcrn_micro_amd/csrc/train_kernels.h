@@ -102,7 +102,18 @@ int unit1x1_bwd(const ConvGeom& g, const float* x, const float* y, const float* 
                 const float* stats, const float* gamma, const float* beta, int act, const float* slope,
                 const float* w, float* dx, int dx_acc, float* dres, int dres_acc, float* dw, float* dbias,
                 float* dgamma, float* dbeta, float* dslope, double* dscratch, float* fscratch, hipStream_t s,
-                int bf = 0, int ybf = 0);
+                int bf = 0, int ybf = 0, int have_parts = 0);
+// The backward of a 16-channel depthwise (3,1) conv + BatchNorm + PReLU unit (TCN conv2) in two passes: the BatchNorm
+// reduction, then ONE kernel for dy (never stored), the weight / bias gradient and the data gradient dx.  next
+// (optional): the unit in front, whose gradient input is this dx -- its BatchNorm reduction is accumulated by the same
+// kernel (per-workgroup sums left in dscratch, their count in *next_parts: hand it to unit1x1_bwd as have_parts).
+struct DwUnitNext {
+    const float *y, *stats, *gamma, *beta, *slope;    // of the unit in front (PReLU, no residual)
+};
+int dwunit_bwd(const DwGeom& g, const float* x, const float* y, const float* da, const float* stats,
+               const float* gamma, const float* beta, const float* slope, const float* w, float* dx, float* dw,
+               float* dbias, float* dgamma, float* dbeta, float* dslope, double* dscratch, float* fscratch,
+               hipStream_t s, int bf, int ybf, const DwUnitNext* next, int* next_parts);
 
 // features: spec (strided (b,f,t) + re/im) -> EB [B][T][129][3] = ERB.bm([mag,re,im]) (models/gtcrn_micro.py:510-516)
 int feat_fwd(const float* spec, long sb, long sf, long st, int B, int T, const float* erb_w, float* eb,

@@ -1553,6 +1553,113 @@ __global__ __launch_bounds__(NT) void k_unit1x1_bwd(ConvGeom g, const float* __r
     }
 }
 
+// ------------------------------------------ fused backward of a depthwise (3,1) conv + BatchNorm + PReLU (TCN conv2)
+// After the BatchNorm reduction the three remaining passes of such a unit -- dy = BatchNorm/PReLU backward
+// (k_bn_bwd_apply: read da, y, write dy), the weight gradient (k_dw_wgrad_stream: read dy, x at three frames) and the
+// data gradient (k_dw16 on the adjoint taps: read dy at three frames, write dx) -- are ONE pass: thread (position,
+// channel quad) forms dy at its own frame t and at t + d, t + 2d (the frames its dx needs; da and y of those come from
+// the L2), multiplies dy(t) with x(t - 2d), x(t - d), x(t) for the weight gradient and writes dx; dy never exists in
+// memory.  Same per-element expressions as the separate kernels.  NEXT: the unit in FRONT (conv1) takes this dx as its
+// da, so its own first backward pass (sum dz, sum dz * xhat, sum of the slope terms) is accumulated right here from
+// one more read (its y) instead of a pass that re-reads dx and y.
+struct NextRedArgs {
+    const float *y, *stats, *gamma, *beta, *slope;
+};
+template <int FX, int FY, bool NEXT>   // storage formats of x (an activation) and of y / the next unit's y (conv outputs)
+__global__ __launch_bounds__(NT) void k_dwunit31_bwd(DwGeom g, const float* __restrict__ x, const float* __restrict__ y,
+                                                    const float* __restrict__ da, BnBwdArgs bn,
+                                                    const float* __restrict__ w, float* __restrict__ dx,
+                                                    double* __restrict__ wpartial, NextRedArgs nx,
+                                                    double* __restrict__ rpartial, StrideIter it) {
+    __shared__ double sh[NT];
+    const int tid = threadIdx.x, q = tid & 3;
+    const f32x4 mean = *reinterpret_cast<const f32x4*>(bn.stats + 4 * q), istd = *reinterpret_cast<const f32x4*>(bn.stats + 16 + 4 * q);
+    const f32x4 gm = *reinterpret_cast<const f32x4*>(bn.gamma + 4 * q), bt = *reinterpret_cast<const f32x4*>(bn.beta + 4 * q);
+    const f32x4 m1 = *reinterpret_cast<const f32x4*>(bn.red + 4 * q), m2 = *reinterpret_cast<const f32x4*>(bn.red + 16 + 4 * q);
+    const float sl = bn.slope[0];
+    f32x4 wk[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) wk[k][e] = w[(4 * q + e) * g.w_c + k * g.w_kt];
+    f32x4 nmean = {0, 0, 0, 0}, nistd = nmean, ngm = nmean, nbt = nmean;
+    float nsl = 0.f;
+    if constexpr (NEXT) {
+        nmean = *reinterpret_cast<const f32x4*>(nx.stats + 4 * q); nistd = *reinterpret_cast<const f32x4*>(nx.stats + 16 + 4 * q);
+        ngm = *reinterpret_cast<const f32x4*>(nx.gamma + 4 * q); nbt = *reinterpret_cast<const f32x4*>(nx.beta + 4 * q);
+        nsl = nx.slope[0];
+    }
+    float vw[4][4], vr[3][4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { vw[0][e] = vw[1][e] = vw[2][e] = vw[3][e] = 0.f; vr[0][e] = vr[1][e] = vr[2][e] = 0.f; }
+    const int d1 = -g.t_off[1], d2 = -g.t_off[0];            // taps at t - 2d, t - d, t
+    const long units = (long)g.B * g.Tout * g.F * 4;
+    RowPos P;
+    P.init(((long)blockIdx.x * NT + tid) >> 2, g.F, g.Tout);
+    for (long i = (long)blockIdx.x * NT + tid; i < units; i += (long)gridDim.x * NT) {
+        const long p = i >> 2;
+        const bool f1 = P.to + d1 < g.Tout, f2 = P.to + d2 < g.Tout;     // frames t + d, t + 2d exist
+        const bool b1 = P.to - d1 >= 0, b2 = P.to - d2 >= 0;             // frames t - d, t - 2d exist
+        const long rf[3] = {p, f1 ? p + (long)d1 * g.F : p, f2 ? p + (long)d2 * g.F : p};
+        const long rb[3] = {b2 ? p - (long)d2 * g.F : p, b1 ? p - (long)d1 * g.F : p, p};
+        typename Raw4<FY>::t yr[3], ynr{};
+        typename Raw4<FX>::t xr[3];
+        f32x4 gr[3];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            yr[j] = sld4_raw<FY>(y, rf[j] * 16 + 4 * q);
+            gr[j] = *reinterpret_cast<const f32x4*>(da + rf[j] * 16 + 4 * q);
+            xr[j] = sld4_raw<FX>(x, rb[j] * 16 + 4 * q);
+        }
+        if constexpr (NEXT) ynr = sld4_raw<FY>(nx.y, p * 16 + 4 * q);
+        f32x4 dyv[3];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const f32x4 yv = dec4<FY>(yr[j]);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float xh = (yv[e] - mean[e]) * istd[e];
+                const float z = gm[e] * xh + bt[e];
+                const float dz = z > 0.f ? gr[j][e] : sl * gr[j][e];
+                dyv[j][e] = gm[e] * istd[e] * (dz - m1[e] - xh * m2[e]);
+            }
+        }
+        const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+        dyv[1] = f1 ? dyv[1] : zero;
+        dyv[2] = f2 ? dyv[2] : zero;
+        const f32x4 x0 = b2 ? dec4<FX>(xr[0]) : zero, x1 = b1 ? dec4<FX>(xr[1]) : zero, x2 = dec4<FX>(xr[2]);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            vw[0][e] = fmaf(dyv[0][e], x0[e], vw[0][e]);
+            vw[1][e] = fmaf(dyv[0][e], x1[e], vw[1][e]);
+            vw[2][e] = fmaf(dyv[0][e], x2[e], vw[2][e]);
+            vw[3][e] += dyv[0][e];
+        }
+        // dx(t) = w[0] dy(t + 2d) + w[1] dy(t + d) + w[2] dy(t): the adjoint taps in the order of k_dw16
+        f32x4 acc = zero;
+        acc = acc + wk[0] * dyv[2];
+        acc = acc + wk[1] * dyv[1];
+        acc = acc + wk[2] * dyv[0];
+        sst4<kNtSt>(dx, p * 16 + 4 * q, 0, acc);
+        if constexpr (NEXT) {
+            const f32x4 yn = dec4<FY>(ynr);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float xh = (yn[e] - nmean[e]) * nistd[e];
+                const float z = ngm[e] * xh + nbt[e];
+                float dsl;
+                const float dz = act_bwd(z, acc[e], ACT_PRELU, nsl, dsl);
+                vr[0][e] += dz;
+                vr[1][e] = fmaf(dz, xh, vr[1][e]);
+                vr[2][e] += dsl;
+            }
+        }
+        P.advance(it, g.F, g.Tout);
+    }
+    block_reduce_store<4, 4>(vw, 16, sh, wpartial + (long)blockIdx.x * 64);
+    if constexpr (NEXT) block_reduce_store<3, 4>(vr, 16, sh, rpartial + (long)blockIdx.x * 48);
+}
+
 // --------------------------------------------------------------------------- features, mask
 // GTCRNMicro.forward prologue + ERB.bm (models/gtcrn_micro.py:510-516, :63-67): one thread per (b,t,j)
 // first / one-past-last non-zero entry of each of the `rows` rows (stride rs, element stride es) of a filterbank
@@ -2346,18 +2453,53 @@ int bn_act_bwd(const float* da, const float* y, long n, int C, const float* stat
     return check();
 }
 
+int dwunit_bwd(const DwGeom& g, const float* x, const float* y, const float* da, const float* stats,
+               const float* gamma, const float* beta, const float* slope, const float* w, float* dx, float* dw,
+               float* dbias, float* dgamma, float* dbeta, float* dslope, double* dscratch, float* fscratch,
+               hipStream_t s, int bf, int ybf, const DwUnitNext* next, int* next_parts) {
+    if (next_parts) *next_parts = 0;
+    if (g.C != 16 || g.nkt != 3 || g.nkf != 1 || g.t_off[2] != 0 || g.f_off[0] != 0 || g.t_off[0] != 2 * g.t_off[1] ||
+        g.Tin != g.Tout || !slope || !dx || bf > 1 || ybf > 1 || bf != ybf)
+        return (int)hipErrorInvalidValue;
+    const long n = (long)g.B * g.Tout * g.F, total = n * 16;
+    float* red = reinterpret_cast<float*>(dscratch + (long)MAX_PARTIALS * 3 * 16);
+    const int rgrid = red_grid(total / 4);
+    launch_bn_bwd_reduce4(rgrid, s, da, y, total, 16, stats, gamma, beta, nullptr, ACT_PRELU, slope, dscratch, bf, ybf);
+    hipLaunchKernelGGL(k_bn_bwd_finish, dim3(1), dim3(1024), 0, s, dscratch, rgrid, n, 16, red, dgamma, dbeta, dslope);
+    const int grid = red_grid(total / 4);
+    const StrideIter it = stride_iter((long)grid * NT / 4, g.F, g.Tout);
+    double* wpart = reinterpret_cast<double*>(fscratch);      // [grid][64]
+    BnBwdArgs bn{stats, gamma, beta, slope, red, ACT_PRELU};
+    NextRedArgs nx{};
+    const bool nxt = next && next->slope;
+    if (nxt) nx = NextRedArgs{next->y, next->stats, next->gamma, next->beta, next->slope};
+#define GT_DU(F)                                                                                                        \
+    do {                                                                                                               \
+        if (nxt) hipLaunchKernelGGL((k_dwunit31_bwd<F, F, true>), dim3(grid), dim3(NT), 0, s, g, x, y, da, bn, w, dx, wpart, nx, dscratch, it); \
+        else hipLaunchKernelGGL((k_dwunit31_bwd<F, F, false>), dim3(grid), dim3(NT), 0, s, g, x, y, da, bn, w, dx, wpart, nx, dscratch, it); \
+    } while (0)
+    if (bf == 0) GT_DU(0);
+    else GT_DU(1);
+#undef GT_DU
+    hipLaunchKernelGGL(k_dw_wgrad_finish2, dim3(1), dim3(1024), 0, s, g, wpart, grid, dw, dbias);
+    if (nxt && next_parts) *next_parts = grid;
+    return check();
+}
+
 int unit1x1_bwd(const ConvGeom& g, const float* x, const float* y, const float* da, const float* res,
                 const float* stats, const float* gamma, const float* beta, int act, const float* slope,
                 const float* w, float* dx, int dx_acc, float* dres, int dres_acc, float* dw, float* dbias,
                 float* dgamma, float* dbeta, float* dslope, double* dscratch, float* fscratch, hipStream_t s, int bf,
-                int ybf) {
+                int ybf, int have_parts) {
     const long n = (long)g.B * g.Tout * g.Fout, total = n * g.Cout;
     if (g.nkt != 1 || g.nkf != 1 || g.sf != 1 || g.pf != 0 || g.Cout != g.CoutT || g.cout_off != 0 || (g.Cout % 4) ||
         (g.Cin % 4) || (g.CinT % 4) || (g.cin_off % 4))
         return (int)hipErrorInvalidValue;
     float* red = reinterpret_cast<float*>(dscratch + (long)MAX_PARTIALS * 3 * 16);
-    const int rgrid = red_grid(total / 4);
-    launch_bn_bwd_reduce4(rgrid, s, da, y, total, g.Cout, stats, gamma, beta, res, act, slope, dscratch, bf, ybf);
+    const int rgrid = have_parts > 0 ? have_parts : red_grid(total / 4);
+    // (have_parts: the kernel that produced da left the per-workgroup sums of this pass in dscratch -- dwunit_bwd)
+    if (have_parts <= 0)
+        launch_bn_bwd_reduce4(rgrid, s, da, y, total, g.Cout, stats, gamma, beta, res, act, slope, dscratch, bf, ybf);
     hipLaunchKernelGGL(k_bn_bwd_finish, dim3(1), dim3(1024), 0, s, dscratch, rgrid, n, g.Cout, red, dgamma, dbeta, dslope);
     const long ntiles = (n + 15) / 16;
     long waves = (long)MAX_PARTIALS * (NT / 64);
