@@ -24,6 +24,15 @@ inline int grid_for(long n, int cap = 4096) {
     return (int)g;
 }
 
+// XCD-aware workgroup numbering for the grid-stride kernels that read temporal taps: the hardware deals workgroups
+// round-robin to the 8 XCDs (each with its own L2), so with the plain blockIdx the rows t - d, t + d a thread needs
+// were fetched by workgroups on OTHER XCDs and every line crossed the fabric three times.  With this numbering XCD x
+// sweeps one contiguous eighth of each grid-stride window and the taps hit its own L2.
+__device__ __forceinline__ unsigned xcd_block() {
+    const unsigned b = blockIdx.x, n = gridDim.x;
+    return (n & 7u) == 0 ? (b & 7u) * (n >> 3) + (b >> 3) : b;
+}
+
 // frequency index of the input tap (ConvGeom); false when the tap falls outside / between samples
 __device__ __forceinline__ bool tap_fi(const ConvGeom& g, int fo, int kf, int& fi) {
     if (g.f_mode == 0) {
@@ -518,7 +527,8 @@ __global__ __launch_bounds__(NT) void k_conv_mfma(ConvGeom g, const float* __res
 // from the float64 truth exactly as the reference's do (1.6e-3 of a tensor's scale) instead of by 1.1e-4
 // (tests/test_gpu_train.py::test_gradients_against_fp64_truth).  626 -> ~200 us at B = 512.
 template <int FIN>
-__global__ __launch_bounds__(NT) void k_conv_win_fma(ConvGeom g, const float* __restrict__ in, const float* __restrict__ w,
+// (launch bound: 4 workgroups per CU, so that the 1024-workgroup grid is resident in one round)
+__global__ __launch_bounds__(NT, 4) void k_conv_win_fma(ConvGeom g, const float* __restrict__ in, const float* __restrict__ w,
                                                     const float* __restrict__ bias, float* __restrict__ out,
                                                     double* __restrict__ stat_partial, StrideIter it,
                                                     const float* __restrict__ shift) {
@@ -954,6 +964,7 @@ __global__ __launch_bounds__(NT) void k_dw16(DwGeom g, const float* __restrict__
                                             const float* __restrict__ bias, float* __restrict__ out,
                                             double* __restrict__ stat_partial, StrideIter it,
                                             const float* __restrict__ shift, BnPre pre) {
+    const unsigned vb = xcd_block();
     static_assert(!PRE || (FIN >= 0 && NKT > 0), "normalise-on-load needs the compile-time forms");
     __shared__ __attribute__((aligned(16))) float sW[9 * 16];   // [tap][c]
     __shared__ double sStat[NT / 64][32];   // per wave: sum[16], sum of squares[16]
@@ -970,8 +981,8 @@ __global__ __launch_bounds__(NT) void k_dw16(DwGeom g, const float* __restrict__
     PreConst pk{};
     if constexpr (PRE) pk = pre_const(pre, q, 16);
     RowPos P;
-    P.init(((long)blockIdx.x * NT + tid) >> 2, g.F, g.Tout);
-    for (long i = (long)blockIdx.x * NT + tid; i < units; i += (long)gridDim.x * NT) {
+    P.init(((long)vb * NT + tid) >> 2, g.F, g.Tout);
+    for (long i = (long)vb * NT + tid; i < units; i += (long)gridDim.x * NT) {
         const long p = i >> 2;
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
         if (bias) acc = *reinterpret_cast<const f32x4*>(bias + 4 * q);
@@ -1041,7 +1052,7 @@ __global__ __launch_bounds__(NT) void k_dw16(DwGeom g, const float* __restrict__
         if (tid < 32) {
             double t = 0.0;
             for (int w = 0; w < NT / 64; ++w) t += sStat[w][tid];
-            stat_partial[(long)blockIdx.x * 32 + tid] = t;
+            stat_partial[(long)vb * 32 + tid] = t;
         }
     }
 }
@@ -1317,6 +1328,7 @@ template <int NKT, int NKF, int FIN = -1>     // FIN: storage format of `in`, co
 __global__ __launch_bounds__(NT) void k_dw_wgrad_stream(DwGeom g, const float* __restrict__ in,
                                                        const float* __restrict__ dout, double* __restrict__ partial,
                                                        StrideIter it) {
+    const unsigned vb = xcd_block();
     constexpr int NTAP = NKT * NKF;
     __shared__ double sh[NT];
     float v[NTAP + 1][4];
@@ -1327,8 +1339,8 @@ __global__ __launch_bounds__(NT) void k_dw_wgrad_stream(DwGeom g, const float* _
     const long units = (long)g.B * g.Tout * g.F * 4;
     const int q = threadIdx.x & 3;
     RowPos P;
-    P.init(((long)blockIdx.x * NT + threadIdx.x) >> 2, g.F, g.Tout);
-    for (long i = (long)blockIdx.x * NT + threadIdx.x; i < units; i += (long)gridDim.x * NT) {
+    P.init(((long)vb * NT + threadIdx.x) >> 2, g.F, g.Tout);
+    for (long i = (long)vb * NT + threadIdx.x; i < units; i += (long)gridDim.x * NT) {
         const long p = i >> 2;
         const f32x4 d = *reinterpret_cast<const f32x4*>(dout + p * 16 + 4 * q);
 #pragma unroll
@@ -1359,7 +1371,7 @@ __global__ __launch_bounds__(NT) void k_dw_wgrad_stream(DwGeom g, const float* _
             for (int e = 0; e < 4; ++e) v[tp][e] = fmaf(d[e], okv[tp] ? xv[tp][e] : 0.f, v[tp][e]);
         P.advance(it, g.F, g.Tout);
     }
-    block_reduce_store<NTAP + 1, 4>(v, 16, sh, partial + (long)blockIdx.x * (NTAP + 1) * 16);
+    block_reduce_store<NTAP + 1, 4>(v, 16, sh, partial + (long)vb * (NTAP + 1) * 16);
 }
 // partial [nparts][(ntap+1)*16] (tap-major, bias last) -> dw, dbias; grid = ceil(K / 64) workgroups of 1024
 __global__ __launch_bounds__(1024) void k_dw_wgrad_finish2(DwGeom g, const double* __restrict__ partial, int nparts,
@@ -1571,6 +1583,7 @@ __global__ __launch_bounds__(NT) void k_dwunit31_bwd(DwGeom g, const float* __re
                                                     const float* __restrict__ w, float* __restrict__ dx,
                                                     double* __restrict__ wpartial, NextRedArgs nx,
                                                     double* __restrict__ rpartial, StrideIter it) {
+    const unsigned vb = xcd_block();
     __shared__ double sh[NT];
     const int tid = threadIdx.x, q = tid & 3;
     const f32x4 mean = *reinterpret_cast<const f32x4*>(bn.stats + 4 * q), istd = *reinterpret_cast<const f32x4*>(bn.stats + 16 + 4 * q);
@@ -1595,8 +1608,8 @@ __global__ __launch_bounds__(NT) void k_dwunit31_bwd(DwGeom g, const float* __re
     const int d1 = -g.t_off[1], d2 = -g.t_off[0];            // taps at t - 2d, t - d, t
     const long units = (long)g.B * g.Tout * g.F * 4;
     RowPos P;
-    P.init(((long)blockIdx.x * NT + tid) >> 2, g.F, g.Tout);
-    for (long i = (long)blockIdx.x * NT + tid; i < units; i += (long)gridDim.x * NT) {
+    P.init(((long)vb * NT + tid) >> 2, g.F, g.Tout);
+    for (long i = (long)vb * NT + tid; i < units; i += (long)gridDim.x * NT) {
         const long p = i >> 2;
         const bool f1 = P.to + d1 < g.Tout, f2 = P.to + d2 < g.Tout;     // frames t + d, t + 2d exist
         const bool b1 = P.to - d1 >= 0, b2 = P.to - d2 >= 0;             // frames t - d, t - 2d exist
@@ -1656,8 +1669,8 @@ __global__ __launch_bounds__(NT) void k_dwunit31_bwd(DwGeom g, const float* __re
         }
         P.advance(it, g.F, g.Tout);
     }
-    block_reduce_store<4, 4>(vw, 16, sh, wpartial + (long)blockIdx.x * 64);
-    if constexpr (NEXT) block_reduce_store<3, 4>(vr, 16, sh, rpartial + (long)blockIdx.x * 48);
+    block_reduce_store<4, 4>(vw, 16, sh, wpartial + (long)vb * 64);
+    if constexpr (NEXT) block_reduce_store<3, 4>(vr, 16, sh, rpartial + (long)vb * 48);
 }
 
 // --------------------------------------------------------------------------- features, mask
@@ -2466,7 +2479,9 @@ int dwunit_bwd(const DwGeom& g, const float* x, const float* y, const float* da,
     const int rgrid = red_grid(total / 4);
     launch_bn_bwd_reduce4(rgrid, s, da, y, total, 16, stats, gamma, beta, nullptr, ACT_PRELU, slope, dscratch, bf, ybf);
     hipLaunchKernelGGL(k_bn_bwd_finish, dim3(1), dim3(1024), 0, s, dscratch, rgrid, n, 16, red, dgamma, dbeta, dslope);
-    const int grid = red_grid(total / 4);
+    // 164 VGPRs: three workgroups per CU -- a grid of 3 x 256 keeps every workgroup resident (with 1024 the last 256
+    // would run alone at a third of the occupancy)
+    const int grid = red_grid(total / 4) > 768 ? 768 : red_grid(total / 4);
     const StrideIter it = stride_iter((long)grid * NT / 4, g.F, g.Tout);
     double* wpart = reinterpret_cast<double*>(fscratch);      // [grid][64]
     BnBwdArgs bn{stats, gamma, beta, slope, red, ACT_PRELU};
