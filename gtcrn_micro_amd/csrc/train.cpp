@@ -240,6 +240,7 @@ size_t plan(gtcrn_trainer* t, int B, int T, float* base) {
         unit_params(t, k.pc2, p + ".point_conv2", p + ".point_bn2", "");
         k.pc2.act = gtt::ACT_NONE; k.pc2.x = k.depth.a;
         alloc_unit(b, k.pc2, nt, 8);
+        k.pc2.front = &k.depth;
         k.pc2.pre = fuse ? &k.depth : nullptr;
         k.depth.deferred = fuse;
         k.o_tra = P(t, p + ".tra.depth_conv.weight");
@@ -274,6 +275,8 @@ size_t plan(gtcrn_trainer* t, int B, int T, float* base) {
         k.c3.act = gtt::ACT_PRELU; k.c3.x = k.c2.a; k.c3.res = X;
         alloc_unit(b, k.c3, n33, 16);
         k.c2.front = &k.c1;
+        k.c3.front = &k.c2;
+        k.c1.front = i > 0 ? &t->tcn[i - 1].c3 : nullptr;
         k.c2.pre = fuse ? &k.c1 : nullptr; k.c1.deferred = fuse;
         k.c3.pre = fuse ? &k.c2 : nullptr; k.c2.deferred = fuse;
         X = k.c3.a;
@@ -386,35 +389,40 @@ int unit_bwd(gtcrn_trainer* t, Unit& u, const float* prm, float* grads, const fl
     // the BatchNorm reduction of this unit may already sit in dscratch (left by the kernel that produced da)
     const int have_parts = t->red_unit == &u ? t->red_parts : 0;
     t->red_unit = nullptr;
+    // the unit in front (backward order) whose gradient input is this unit's dx: its reduction can ride along
+    const Unit* f = u.front;
+    const bool ride = f && dx && f->C == 16 && f->act == gtt::ACT_PRELU && f->o_slope >= 0 && t->bf == t->ybf && t->bf <= 1;
+    gtt::DwUnitNext nx{};
+    if (ride) {
+        const float* fbn = prm + f->o_bn;
+        nx.y = f->y; nx.stats = f->stats; nx.gamma = fbn; nx.beta = fbn + f->C; nx.slope = prm + f->o_slope;
+        nx.res = f->res;
+    }
     if (!u.dw && u.cg.nkt == 1 && u.cg.nkf == 1 && u.cg.sf == 1 && (u.cg.Cin % 4) == 0 && (u.cg.Cout % 4) == 0) {
         // pointwise unit: BatchNorm backward, data gradient and weight gradient in one pass (after the reduction)
+        int parts = 0;
         T_RUN(gtt::unit1x1_bwd(u.cg, u.x, u.y, da, u.res, u.stats, bn, bn + u.C, u.act,
                                u.o_slope >= 0 ? prm + u.o_slope : nullptr, prm + u.o_w, dx, dx_acc, dres, dres_acc,
                                grads + u.o_w, u.o_b >= 0 ? grads + u.o_b : nullptr, gbn, gbn + u.C,
                                u.o_slope >= 0 ? grads + u.o_slope : nullptr, t->dscratch, t->fscratch, s, t->bf,
-                               t->ybf, have_parts));
+                               t->ybf, have_parts, ride && f->n == u.n ? &nx : nullptr, &parts));
+        if (parts > 0) { t->red_unit = f; t->red_parts = parts; }
         return 0;
     }
     if (u.dw && u.C == 16 && u.dg.nkt == 3 && u.dg.nkf == 1 && u.act == gtt::ACT_PRELU && !u.res && u.o_slope >= 0 &&
         dx && !dx_acc && !dres && t->bf == t->ybf && t->bf <= 1) {
         // TCN conv2: dy, weight gradient and data gradient in one pass; conv1's reduction rides along
-        gtt::DwUnitNext nx{};
-        const Unit* f = u.front;
-        const bool ride = f && !f->dw && !f->res && f->act == gtt::ACT_PRELU && f->o_slope >= 0 && f->C == 16 && f->n == u.n;
-        if (ride) {
-            const float* fbn = prm + f->o_bn;
-            nx = gtt::DwUnitNext{f->y, f->stats, fbn, fbn + f->C, prm + f->o_slope};
-        }
+        const bool ride2 = ride && !f->res && f->n == u.n;
         int parts = 0;
         T_RUN(gtt::dwunit_bwd(u.dg, u.x, u.y, da, u.stats, bn, bn + u.C, prm + u.o_slope, prm + u.o_w, dx,
                               grads + u.o_w, u.o_b >= 0 ? grads + u.o_b : nullptr, gbn, gbn + u.C, grads + u.o_slope,
-                              t->dscratch, t->fscratch, s, t->bf, t->ybf, ride ? &nx : nullptr, &parts));
-        if (ride && parts > 0) { t->red_unit = f; t->red_parts = parts; }
+                              t->dscratch, t->fscratch, s, t->bf, t->ybf, ride2 ? &nx : nullptr, &parts, have_parts));
+        if (ride2 && parts > 0) { t->red_unit = f; t->red_parts = parts; }
         return 0;
     }
     T_RUN(gtt::bn_act_bwd(da, u.y, u.n, u.C, u.stats, bn, bn + u.C, u.res, u.act,
                           u.o_slope >= 0 ? prm + u.o_slope : nullptr, t->dy, dres, dres_acc, gbn, gbn + u.C,
-                          u.o_slope >= 0 ? grads + u.o_slope : nullptr, t->dscratch, s, t->bf, t->ybf));
+                          u.o_slope >= 0 ? grads + u.o_slope : nullptr, t->dscratch, s, t->bf, t->ybf, have_parts));
     if (u.dw) {
         T_RUN(gtt::dw_wgrad(u.dg, u.x, t->dy, grads + u.o_w, u.o_b >= 0 ? grads + u.o_b : nullptr, t->fscratch, s));
         if (dx) T_RUN(gtt::dw_fwd(adjoint(u.dg, dx_acc), t->dy, prm + u.o_w, nullptr, dx, s));

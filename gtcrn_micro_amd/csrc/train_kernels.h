@@ -92,8 +92,13 @@ int bn_act(const float* y, long n, int C, const float* stats, const float* gamma
 int bn_act_bwd(const float* da, const float* y, long n, int C, const float* stats, const float* gamma,
                const float* beta, const float* res, int act, const float* slope, float* dy, float* dres,
                int dres_acc, float* dgamma, float* dbeta, float* dslope, double* scratch, hipStream_t s, int bf = 0,
-               int ybf = 0);
+               int ybf = 0, int have_parts = 0);
 
+// the unit in FRONT of a unit in the backward order, whose gradient input is that unit's dx: see `next` below
+struct DwUnitNext {
+    const float *y, *stats, *gamma, *beta, *slope;    // of the unit in front (16 channels, PReLU)
+    const float* res = nullptr;                       // its residual input (unit1x1_bwd only)
+};
 // The whole backward of a pointwise (1x1) conv + BatchNorm + activation unit in two passes: the BatchNorm
 // reduction, then ONE kernel that forms dy, the data gradient dx (nullptr: not needed; dx_acc: add) and the
 // weight/bias gradients; dres (optional) receives dz for the residual branch.  Gradients of gamma, beta, the
@@ -102,18 +107,16 @@ int unit1x1_bwd(const ConvGeom& g, const float* x, const float* y, const float* 
                 const float* stats, const float* gamma, const float* beta, int act, const float* slope,
                 const float* w, float* dx, int dx_acc, float* dres, int dres_acc, float* dw, float* dbias,
                 float* dgamma, float* dbeta, float* dslope, double* dscratch, float* fscratch, hipStream_t s,
-                int bf = 0, int ybf = 0, int have_parts = 0);
+                int bf = 0, int ybf = 0, int have_parts = 0, const DwUnitNext* next = nullptr,
+                int* next_parts = nullptr);
 // The backward of a 16-channel depthwise (3,1) conv + BatchNorm + PReLU unit (TCN conv2) in two passes: the BatchNorm
 // reduction, then ONE kernel for dy (never stored), the weight / bias gradient and the data gradient dx.  next
 // (optional): the unit in front, whose gradient input is this dx -- its BatchNorm reduction is accumulated by the same
 // kernel (per-workgroup sums left in dscratch, their count in *next_parts: hand it to unit1x1_bwd as have_parts).
-struct DwUnitNext {
-    const float *y, *stats, *gamma, *beta, *slope;    // of the unit in front (PReLU, no residual)
-};
 int dwunit_bwd(const DwGeom& g, const float* x, const float* y, const float* da, const float* stats,
                const float* gamma, const float* beta, const float* slope, const float* w, float* dx, float* dw,
                float* dbias, float* dgamma, float* dbeta, float* dslope, double* dscratch, float* fscratch,
-               hipStream_t s, int bf, int ybf, const DwUnitNext* next, int* next_parts);
+               hipStream_t s, int bf, int ybf, const DwUnitNext* next, int* next_parts, int have_parts = 0);
 
 // features: spec (strided (b,f,t) + re/im) -> EB [B][T][129][3] = ERB.bm([mag,re,im]) (models/gtcrn_micro.py:510-516)
 int feat_fwd(const float* spec, long sb, long sf, long st, int B, int T, const float* erb_w, float* eb,

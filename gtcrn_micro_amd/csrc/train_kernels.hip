@@ -1448,13 +1448,32 @@ struct BnBwdArgs {
     const float *stats, *gamma, *beta, *slope, *red;
     int act;
 };
-template <int FMT, int YF>   // storage formats of x / res and of y, compile time (see sld1)
+// the unit whose gradient input is the dx a backward kernel produces (16 channels, PReLU; res: its residual input or
+// nullptr): that unit's first backward pass -- sum dz, sum dz * xhat, sum of the slope terms -- is accumulated by the
+// producing kernel from one more read of its y (and res) instead of a pass that re-reads dx as well
+struct NextRedArgs {
+    const float *y, *stats, *gamma, *beta, *slope, *res;
+};
+// NEXT: see NextRedArgs; rpartial [gridDim.x][48] doubles
+template <int FMT, int YF, bool NEXT = false>   // storage formats of x / res and of y, compile time (see sld1)
 __global__ __launch_bounds__(NT) void k_unit1x1_bwd(ConvGeom g, const float* __restrict__ x, const float* __restrict__ y,
                                                    const float* __restrict__ da, const float* __restrict__ res,
                                                    BnBwdArgs bn, const float* __restrict__ w,
                                                    float* __restrict__ dx, int dx_acc, float* __restrict__ dres,
-                                                   int dres_acc, float* __restrict__ partial, long tiles_per_wave) {
+                                                   int dres_acc, float* __restrict__ partial, long tiles_per_wave,
+                                                   NextRedArgs nx, double* __restrict__ rpartial) {
     constexpr int bf = FMT, ybf = YF;
+    __shared__ double sRed[NEXT ? NT / 64 : 1][48];
+    f32x4 nmean = {0, 0, 0, 0}, nistd = nmean, ngm = nmean, nbt = nmean;
+    float nsl = 0.f, vr[3][4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) vr[0][e] = vr[1][e] = vr[2][e] = 0.f;
+    if constexpr (NEXT) {
+        const int q4 = 4 * ((threadIdx.x & 63) >> 4);
+        nmean = *reinterpret_cast<const f32x4*>(nx.stats + q4); nistd = *reinterpret_cast<const f32x4*>(nx.stats + 16 + q4);
+        ngm = *reinterpret_cast<const f32x4*>(nx.gamma + q4); nbt = *reinterpret_cast<const f32x4*>(nx.beta + q4);
+        nsl = nx.slope[0];
+    }
     __shared__ __attribute__((aligned(16))) float sWt[256];        // data-gradient A matrix [ci][co] = W[co][ci]
     __shared__ __attribute__((aligned(16))) float sT[NT / 64][256];   // per wave: dy tile [pos][16]
     __shared__ float sAcc[NT / 64][256 + 64];
@@ -1495,6 +1514,11 @@ __global__ __launch_bounds__(NT) void k_unit1x1_bwd(ConvGeom g, const float* __r
             xb[u] = (pu < npos && ci_ok) ? sld1_raw<FMT>(x, pu * g.CinT + g.cin_off + c) : 0u;
         }
         const unsigned xodd = (unsigned)((g.cin_off + c) & 1);    // CinT is a multiple of 4 here: the parity is the channel's
+        f32x4 ynx = {0.f, 0.f, 0.f, 0.f}, rnx = ynx;
+        if constexpr (NEXT) {      // (Cin == CinT == 16 with NEXT: the launcher checks)
+            ynx = sld4<kNt>(nx.y, (pv ? p : 0) * 16 + 4 * q, ybf);
+            if (nx.res) rnx = sld4<kNt>(nx.res, (pv ? p : 0) * 16 + 4 * q, bf);
+        }
         f32x4 dy = {0.f, 0.f, 0.f, 0.f};
         if (pv && co_ok4) {
             const f32x4 yv = sld4<kNt>(y, p * g.Cout + 4 * q, ybf);
@@ -1525,8 +1549,24 @@ __global__ __launch_bounds__(NT) void k_unit1x1_bwd(ConvGeom g, const float* __r
             for (int e = 0; e < 4; ++e) acc = mfma4(At[e], dy[e], acc);
             if (pv && ci_ok4) {
                 f32x4* o = reinterpret_cast<f32x4*>(dx + p * g.CinT + g.cin_off + 4 * q);
-                if (dx_acc) *o = *o + acc;
+                if (dx_acc) {
+                    acc = *o + acc;
+                    *o = acc;
+                }
                 else sst4<kNtSt>(dx, p * g.CinT + g.cin_off + 4 * q, 0, acc);
+                if constexpr (NEXT) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float xh = (ynx[e] - nmean[e]) * nistd[e];
+                        float z = ngm[e] * xh + nbt[e];
+                        if (nx.res) z += rnx[e];
+                        float dsl;
+                        const float dz = act_bwd(z, acc[e], ACT_PRELU, nsl, dsl);
+                        vr[0][e] += dz;
+                        vr[1][e] = fmaf(dz, xh, vr[1][e]);
+                        vr[2][e] += dsl;
+                    }
+                }
             }
         }
         // weight gradient: dy tile through wave-private LDS into the (c, k) layout
@@ -1563,6 +1603,22 @@ __global__ __launch_bounds__(NT) void k_unit1x1_bwd(ConvGeom g, const float* __r
             for (int kk = 0; kk < 4; ++kk) t += sAcc[w2][256 + kk * 16 + tid];
         pp[256 + tid] = t;
     }
+    if constexpr (NEXT) {
+        // lanes of one channel quad differ in n (xor distances 8..1), then the waves through LDS
+#pragma unroll
+        for (int k3 = 0; k3 < 3; ++k3)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const double t = wave_sum_xor((double)vr[k3][e], 1, 8);
+                if (n == 0) sRed[wv][k3 * 16 + 4 * q + e] = t;
+            }
+        __syncthreads();
+        if (tid < 48) {
+            double t = 0.0;
+            for (int w2 = 0; w2 < NT / 64; ++w2) t += sRed[w2][tid];
+            rpartial[(long)blockIdx.x * 48 + tid] = t;
+        }
+    }
 }
 
 // ------------------------------------------ fused backward of a depthwise (3,1) conv + BatchNorm + PReLU (TCN conv2)
@@ -1574,9 +1630,6 @@ __global__ __launch_bounds__(NT) void k_unit1x1_bwd(ConvGeom g, const float* __r
 // memory.  Same per-element expressions as the separate kernels.  NEXT: the unit in FRONT (conv1) takes this dx as its
 // da, so its own first backward pass (sum dz, sum dz * xhat, sum of the slope terms) is accumulated right here from
 // one more read (its y) instead of a pass that re-reads dx and y.
-struct NextRedArgs {
-    const float *y, *stats, *gamma, *beta, *slope;
-};
 template <int FX, int FY, bool NEXT>   // storage formats of x (an activation) and of y / the next unit's y (conv outputs)
 __global__ __launch_bounds__(NT) void k_dwunit31_bwd(DwGeom g, const float* __restrict__ x, const float* __restrict__ y,
                                                     const float* __restrict__ da, BnBwdArgs bn,
@@ -2445,12 +2498,13 @@ int bn_act(const float* y, long n, int C, const float* stats, const float* gamma
 int bn_act_bwd(const float* da, const float* y, long n, int C, const float* stats, const float* gamma,
                const float* beta, const float* res, int act, const float* slope, float* dy, float* dres,
                int dres_acc, float* dgamma, float* dbeta, float* dslope, double* scratch, hipStream_t s, int bf,
-               int ybf) {
+               int ybf, int have_parts) {
     const long total = n * C;
     float* red = reinterpret_cast<float*>(scratch + (long)MAX_PARTIALS * 3 * 16);
     if (C % 4 == 0) {
-        const int grid = red_grid(total / 4);
-        launch_bn_bwd_reduce4(grid, s, da, y, total, C, stats, gamma, beta, res, act, slope, scratch, bf, ybf);
+        const int grid = have_parts > 0 ? have_parts : red_grid(total / 4);
+        if (have_parts <= 0)
+            launch_bn_bwd_reduce4(grid, s, da, y, total, C, stats, gamma, beta, res, act, slope, scratch, bf, ybf);
         hipLaunchKernelGGL(k_bn_bwd_finish, dim3(1), dim3(1024), 0, s, scratch, grid, n, C, red, dgamma, dbeta, dslope);
         // the apply pass keeps per-thread channel constants: its stride must be a multiple of C as well
         hipLaunchKernelGGL((k_bn_bwd_apply<4>), dim3(grid_for(total / 4, 8192)), dim3(NT), 0, s, da, y, total, C, stats,
@@ -2466,18 +2520,20 @@ int bn_act_bwd(const float* da, const float* y, long n, int C, const float* stat
     return check();
 }
 
+constexpr int NEXT_GRID = 768;    // workgroups of k_unit1x1_bwd<.., NEXT>: 126-138 VGPRs = 3 per CU, all resident
 int dwunit_bwd(const DwGeom& g, const float* x, const float* y, const float* da, const float* stats,
                const float* gamma, const float* beta, const float* slope, const float* w, float* dx, float* dw,
                float* dbias, float* dgamma, float* dbeta, float* dslope, double* dscratch, float* fscratch,
-               hipStream_t s, int bf, int ybf, const DwUnitNext* next, int* next_parts) {
+               hipStream_t s, int bf, int ybf, const DwUnitNext* next, int* next_parts, int have_parts) {
     if (next_parts) *next_parts = 0;
     if (g.C != 16 || g.nkt != 3 || g.nkf != 1 || g.t_off[2] != 0 || g.f_off[0] != 0 || g.t_off[0] != 2 * g.t_off[1] ||
         g.Tin != g.Tout || !slope || !dx || bf > 1 || ybf > 1 || bf != ybf)
         return (int)hipErrorInvalidValue;
     const long n = (long)g.B * g.Tout * g.F, total = n * 16;
     float* red = reinterpret_cast<float*>(dscratch + (long)MAX_PARTIALS * 3 * 16);
-    const int rgrid = red_grid(total / 4);
-    launch_bn_bwd_reduce4(rgrid, s, da, y, total, 16, stats, gamma, beta, nullptr, ACT_PRELU, slope, dscratch, bf, ybf);
+    const int rgrid = have_parts > 0 ? have_parts : red_grid(total / 4);
+    if (have_parts <= 0)
+        launch_bn_bwd_reduce4(rgrid, s, da, y, total, 16, stats, gamma, beta, nullptr, ACT_PRELU, slope, dscratch, bf, ybf);
     hipLaunchKernelGGL(k_bn_bwd_finish, dim3(1), dim3(1024), 0, s, dscratch, rgrid, n, 16, red, dgamma, dbeta, dslope);
     // 164 VGPRs: three workgroups per CU -- a grid of 3 x 256 keeps every workgroup resident (with 1024 the last 256
     // would run alone at a third of the occupancy)
@@ -2487,7 +2543,7 @@ int dwunit_bwd(const DwGeom& g, const float* x, const float* y, const float* da,
     BnBwdArgs bn{stats, gamma, beta, slope, red, ACT_PRELU};
     NextRedArgs nx{};
     const bool nxt = next && next->slope;
-    if (nxt) nx = NextRedArgs{next->y, next->stats, next->gamma, next->beta, next->slope};
+    if (nxt) nx = NextRedArgs{next->y, next->stats, next->gamma, next->beta, next->slope, nullptr};
 #define GT_DU(F)                                                                                                        \
     do {                                                                                                               \
         if (nxt) hipLaunchKernelGGL((k_dwunit31_bwd<F, F, true>), dim3(grid), dim3(NT), 0, s, g, x, y, da, bn, w, dx, wpart, nx, dscratch, it); \
@@ -2505,7 +2561,8 @@ int unit1x1_bwd(const ConvGeom& g, const float* x, const float* y, const float* 
                 const float* stats, const float* gamma, const float* beta, int act, const float* slope,
                 const float* w, float* dx, int dx_acc, float* dres, int dres_acc, float* dw, float* dbias,
                 float* dgamma, float* dbeta, float* dslope, double* dscratch, float* fscratch, hipStream_t s, int bf,
-                int ybf, int have_parts) {
+                int ybf, int have_parts, const DwUnitNext* next, int* next_parts) {
+    if (next_parts) *next_parts = 0;
     const long n = (long)g.B * g.Tout * g.Fout, total = n * g.Cout;
     if (g.nkt != 1 || g.nkf != 1 || g.sf != 1 || g.pf != 0 || g.Cout != g.CoutT || g.cout_off != 0 || (g.Cout % 4) ||
         (g.Cin % 4) || (g.CinT % 4) || (g.cin_off % 4))
@@ -2517,19 +2574,30 @@ int unit1x1_bwd(const ConvGeom& g, const float* x, const float* y, const float* 
         launch_bn_bwd_reduce4(rgrid, s, da, y, total, g.Cout, stats, gamma, beta, res, act, slope, dscratch, bf, ybf);
     hipLaunchKernelGGL(k_bn_bwd_finish, dim3(1), dim3(1024), 0, s, dscratch, rgrid, n, g.Cout, red, dgamma, dbeta, dslope);
     const long ntiles = (n + 15) / 16;
-    long waves = (long)MAX_PARTIALS * (NT / 64);
+    // the unit in front takes this dx as its gradient input: its reduction rides along (its partial sums replace this
+    // unit's, which the finish kernel above has consumed, in dscratch)
+    const bool nxt = next && next->slope && dx && g.Cin == 16 && g.CinT == 16 && g.cin_off == 0 && bf == ybf;
+    long waves = (long)(nxt ? NEXT_GRID : MAX_PARTIALS) * (NT / 64);
     if (waves > ntiles) waves = ntiles;
     const long tpw = (ntiles + waves - 1) / waves;
     const int grid = (int)((ntiles + tpw * (NT / 64) - 1) / (tpw * (NT / 64)));
     BnBwdArgs bn{stats, gamma, beta, slope, red, act};
-#define GT_U1(F, Y) hipLaunchKernelGGL((k_unit1x1_bwd<F, Y>), dim3(grid), dim3(NT), 0, s, g, x, y, da, res, bn, w, dx, dx_acc, \
-                                      dres, dres_acc, fscratch, tpw)
+    NextRedArgs nx{};
+    if (nxt) nx = NextRedArgs{next->y, next->stats, next->gamma, next->beta, next->slope, next->res};
+#define GT_U1(F, Y)                                                                                                     \
+    do {                                                                                                               \
+        if (nxt) hipLaunchKernelGGL((k_unit1x1_bwd<F, Y, true>), dim3(grid), dim3(NT), 0, s, g, x, y, da, res, bn, w, dx, dx_acc, \
+                                    dres, dres_acc, fscratch, tpw, nx, dscratch);                                       \
+        else hipLaunchKernelGGL((k_unit1x1_bwd<F, Y, false>), dim3(grid), dim3(NT), 0, s, g, x, y, da, res, bn, w, dx, dx_acc, \
+                                dres, dres_acc, fscratch, tpw, nx, dscratch);                                           \
+    } while (0)
     if (bf == 0 && ybf == 0) GT_U1(0, 0);
     else if (bf == 1 && ybf == 1) GT_U1(1, 1);
     else if (bf == 1 && ybf == 0) GT_U1(1, 0);
     else if (bf == 1 && ybf == 2) GT_U1(1, 2);
     else return (int)hipErrorInvalidValue;
 #undef GT_U1
+    if (nxt && next_parts) *next_parts = grid;
     hipLaunchKernelGGL(k_wgrad_mfma_finish, dim3((256 + 16 + 63) / 64), dim3(1024), 0, s, g, fscratch, grid, dw, dbias);
     return check();
 }
