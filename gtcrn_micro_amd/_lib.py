@@ -96,6 +96,7 @@ def lib():
     L.gtcrn_train_workspace_bytes2.restype = cl
     L.gtcrn_train_workspace_bytes2.argtypes = [ci, ci, ci]
     L.gtcrn_trainer_set_storage.argtypes = [_vp, ci]
+    L.gtcrn_trainer_set_fusions.argtypes = [_vp, ci]
     L.gtcrn_train_forward.argtypes = [_vp, _vp, _vp, cl, cl, cl, _vp, cl, cl, cl, ci, ci, _vp]
     L.gtcrn_train_backward.argtypes = [_vp, _vp, _vp, cl, cl, cl, _vp, cl, cl, cl, _vp, _vp]
     L.gtcrn_train_tap.argtypes = [_vp, ctypes.c_char_p, _vp, ctypes.POINTER(cl), _vp]
@@ -553,6 +554,10 @@ class Trainer:
             raise GtcrnError(f"storage must be one of {sorted(self.STORAGE)}, got {storage!r}")
         _check(lib().gtcrn_trainer_set_storage(self._h, self.STORAGE[storage]))
         self.storage = storage
+
+    def set_fusions(self, mask):
+        """Diagnostic (gtcrn_trainer_set_fusions): 7 = all pass fusions (default), 0 = the layer-at-a-time passes."""
+        _check(lib().gtcrn_trainer_set_fusions(self._h, int(mask)))
 
     def _check_blob(self, blob, what):
         _require_cuda_f32(blob, what)

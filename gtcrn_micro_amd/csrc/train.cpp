@@ -93,6 +93,7 @@ struct gtcrn_trainer {
     size_t arena_floats = 0;
     float* fscratch = nullptr;    // wgrad / TRA partial sums
     double* dscratch = nullptr;   // BatchNorm partial sums
+    int fusions = 7;                  // gtcrn_trainer_set_fusions: 1 normalise-on-load, 2 depthwise backward, 4 riding reductions
     const void* red_unit = nullptr;   // backward: the unit whose BatchNorm reduction already sits in dscratch ...
     int red_parts = 0;                // ... as this many per-workgroup partial sums (see unit_bwd)
     std::map<std::string, long> off;   // parameter name -> blob offset
@@ -194,7 +195,7 @@ size_t plan(gtcrn_trainer* t, int B, int T, float* base) {
     const long n129 = (long)B * T * 129, n65 = (long)B * T * 65, n33 = (long)B * T * 33;
     const int T2 = T + 2;
     const long n33x = (long)B * T2 * 33;
-    const bool fuse = t->ybf <= 1;      // (not for the fp16 diagnostic storage)
+    const bool fuse = t->ybf <= 1 && (t->fusions & 1);      // (not for the fp16 diagnostic storage)
     t->taps.clear();
     t->eb = b.take_saved(n129 * 3);
     t->f0 = b.take_saved(n129 * 3);
@@ -391,7 +392,8 @@ int unit_bwd(gtcrn_trainer* t, Unit& u, const float* prm, float* grads, const fl
     t->red_unit = nullptr;
     // the unit in front (backward order) whose gradient input is this unit's dx: its reduction can ride along
     const Unit* f = u.front;
-    const bool ride = f && dx && f->C == 16 && f->act == gtt::ACT_PRELU && f->o_slope >= 0 && t->bf == t->ybf && t->bf <= 1;
+    const bool ride = f && dx && f->C == 16 && f->act == gtt::ACT_PRELU && f->o_slope >= 0 && t->bf == t->ybf && t->bf <= 1 &&
+                      (t->fusions & 4);
     gtt::DwUnitNext nx{};
     if (ride) {
         const float* fbn = prm + f->o_bn;
@@ -410,7 +412,7 @@ int unit_bwd(gtcrn_trainer* t, Unit& u, const float* prm, float* grads, const fl
         return 0;
     }
     if (u.dw && u.C == 16 && u.dg.nkt == 3 && u.dg.nkf == 1 && u.act == gtt::ACT_PRELU && !u.res && u.o_slope >= 0 &&
-        dx && !dx_acc && !dres && t->bf == t->ybf && t->bf <= 1) {
+        dx && !dx_acc && !dres && t->bf == t->ybf && t->bf <= 1 && (t->fusions & 2)) {
         // TCN conv2: dy, weight gradient and data gradient in one pass; conv1's reduction rides along
         const bool ride2 = ride && !f->res && f->n == u.n;
         int parts = 0;
@@ -521,6 +523,16 @@ int gtcrn_trainer_set_storage(gtcrn_trainer* t, int storage) {
         t->bf = bf;
         t->ybf = ybf;
         t->planned = false;      // the arena is re-laid out on the next forward
+        t->have_fwd = false;
+    }
+    return 0;
+}
+
+int gtcrn_trainer_set_fusions(gtcrn_trainer* t, int mask) {
+    if (!t || mask < 0 || mask > 7) return tfail(GTCRN_ERR_ARG, "gtcrn_trainer_set_fusions: mask must be 0..7");
+    if (t->fusions != mask) {
+        t->fusions = mask;
+        t->planned = false;      // the unit links are laid out again on the next forward
         t->have_fwd = false;
     }
     return 0;
