@@ -2000,10 +2000,14 @@ __global__ __launch_bounds__(NT) void k_gate_shuffle(const float* __restrict__ v
         sst1(out, pos * 16 + 2 * c + 1, bf, sld1(x, pos * 16 + 8 + c, bf));
     }
 }
-// backward, step 1: dv = dout[2c] * g (0 on the trimmed tail frames), dx[8+c] = dout[2c+1]
+// backward, last step (after k_tra_dgate / k_tra_dy): dv = dout[2c] * g (0 on the trimmed tail frames) + de * (2/33) * v
+// with de[t][c] = sum_k dw[c][k] * dy[t + 2 - k][c] (the energy path of TRALite), dx[8+c] = dout[2c+1].  One pass: the
+// gate path used to be stored first and the energy path added by a read-modify-write pass of its own (k_tra_dv,
+// 146 us per block).  Same expression, fmaf(de, v, dout * g), as the two passes.
 __global__ __launch_bounds__(NT) void k_gate_shuffle_bwd(const float* __restrict__ dout, const float* __restrict__ g,
-                                                        int B, int T, int Tt, float* __restrict__ dv,
-                                                        float* __restrict__ dx) {
+                                                        const float* __restrict__ dy, const float* __restrict__ v,
+                                                        const float* __restrict__ dw_w, int B, int T, int Tt,
+                                                        float* __restrict__ dv, float* __restrict__ dx, int bf) {
     const long total = (long)B * Tt * 33 * 8;
     for (long i = (long)blockIdx.x * NT + threadIdx.x; i < total; i += (long)gridDim.x * NT) {
         const int c = (int)(i & 7);
@@ -2017,7 +2021,13 @@ __global__ __launch_bounds__(NT) void k_gate_shuffle_bwd(const float* __restrict
             r = dout[pos * 16 + 2 * c] * g[rowv * 8 + c];
             dx[pos * 16 + 8 + c] = dout[pos * 16 + 2 * c + 1];
         }
-        dv[i] = r;
+        float de = 0.f;
+        for (int k = 0; k < 3; ++k) {
+            const int tt = t + 2 - k;
+            if (tt < Tt) de = fmaf(dw_w[c * 3 + k], dy[(rowv + 2 - k) * 8 + c], de);
+        }
+        de *= 2.0f / 33.0f;
+        dv[i] = fmaf(de, sld1(v, i, bf), r);
     }
 }
 // step 2: dg = sum_F dout[2c] * v  ->  dzg = dg * g * (1 - g)
@@ -2050,46 +2060,38 @@ __global__ __launch_bounds__(NT) void k_tra_dy(const float* __restrict__ dzg, lo
         dy[i] = s;
     }
 }
-// step 4: de[t][c] = sum_k dw[c][k] * dy[t + 2 - k][c];  dv += de * (2/33) * v
-__global__ __launch_bounds__(NT) void k_tra_dv(const float* __restrict__ dy, const float* __restrict__ v, int B, int Tt,
-                                              const float* __restrict__ dw_w, float* __restrict__ dv, int bf) {
-    const long total = (long)B * Tt * 8;
-    for (long i = (long)blockIdx.x * NT + threadIdx.x; i < total; i += (long)gridDim.x * NT) {
-        const int c = (int)(i & 7);
-        const long rowv = i >> 3;
-        const int t = (int)(rowv % Tt);
-        float de = 0.f;
-        for (int k = 0; k < 3; ++k) {
-            const int tt = t + 2 - k;
-            if (tt < Tt) de = fmaf(dw_w[c * 3 + k], dy[(rowv + 2 - k) * 8 + c], de);
-        }
-        de *= 2.0f / 33.0f;
-        const long vv = rowv * 33 * 8 + c;
-        float* d = dv + rowv * 33 * 8 + c;
-        for (int f = 0; f < 33; ++f) d[f * 8] = fmaf(de, sld1(v, vv + f * 8, bf), d[f * 8]);
-    }
-}
 // parameter gradients of the two conv1d: 104 sums over the rows (b,t), per-workgroup partials, in the order
 // the blob stores them: [0,24) d dw_w[c][k] = sum dy[t][c] * e[t-2+k][c]   [24,32) d dw_b[c] = sum dy[c]
 //                       [32,96) d pw_w[co][c] = sum dzg[co] * y[c]         [96,104) d pw_b[co] = sum dzg[co]
-__global__ __launch_bounds__(128) void k_tra_pgrad(const float* __restrict__ dzg, const float* __restrict__ y,
-                                                  const float* __restrict__ dy, const float* __restrict__ e, int B,
-                                                  int Tt, float* __restrict__ partial) {
-    const int tid = threadIdx.x;
-    if (tid >= 104) return;
+// (1024 threads = 8 row slices x 128: with one 128-thread slice per workgroup the ~127 rows of a workgroup were a serial
+// chain of dependent-latency loads, 107 us for 16 MB of input)
+__global__ __launch_bounds__(1024) void k_tra_pgrad(const float* __restrict__ dzg, const float* __restrict__ y,
+                                                   const float* __restrict__ dy, const float* __restrict__ e, int B,
+                                                   int Tt, float* __restrict__ partial) {
+    __shared__ float sh[8][104];
+    const int tid = threadIdx.x & 127, slice = threadIdx.x >> 7;
     const long rows = (long)B * Tt;
     const long per = (rows + gridDim.x - 1) / gridDim.x;
     const long r0 = (long)blockIdx.x * per, r1 = r0 + per < rows ? r0 + per : rows;
     float s = 0.f;
-    for (long r = r0; r < r1; ++r) {
-        if (tid < 24) {
-            const int c = tid / 3, k = tid % 3, t = (int)(r % Tt);
-            if (t - 2 + k >= 0) s = fmaf(dy[r * 8 + c], e[(r - 2 + k) * 8 + c], s);
-        } else if (tid < 32) s += dy[r * 8 + tid - 24];
-        else if (tid < 96) s = fmaf(dzg[r * 8 + ((tid - 32) >> 3)], y[r * 8 + ((tid - 32) & 7)], s);
-        else s += dzg[r * 8 + tid - 96];
+    if (tid < 104) {
+        for (long r = r0 + slice; r < r1; r += 8) {
+            if (tid < 24) {
+                const int c = tid / 3, k = tid % 3, t = (int)(r % Tt);
+                if (t - 2 + k >= 0) s = fmaf(dy[r * 8 + c], e[(r - 2 + k) * 8 + c], s);
+            } else if (tid < 32) s += dy[r * 8 + tid - 24];
+            else if (tid < 96) s = fmaf(dzg[r * 8 + ((tid - 32) >> 3)], y[r * 8 + ((tid - 32) & 7)], s);
+            else s += dzg[r * 8 + tid - 96];
+        }
+        sh[slice][tid] = s;
     }
-    partial[(long)blockIdx.x * 104 + tid] = s;
+    __syncthreads();
+    if (slice == 0 && tid < 104) {
+        float t = 0.f;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) t += sh[q][tid];
+        partial[(long)blockIdx.x * 104 + tid] = t;
+    }
 }
 
 // ------------------------------------------------------------------------------- HybridLoss
@@ -2653,12 +2655,12 @@ int tra_gate_shuffle_bwd(const float* dout, const float* v, const float* g, cons
     const long rows = (long)B * Tt;
     float* dzg = tmp;
     float* dy = tmp + rows * 8;
-    hipLaunchKernelGGL(k_gate_shuffle_bwd, dim3(grid_for(rows * 33 * 8)), dim3(NT), 0, s, dout, g, B, T, Tt, dv, dx);
     hipLaunchKernelGGL(k_tra_dgate, dim3(grid_for(rows * 8)), dim3(NT), 0, s, dout, v, g, B, T, Tt, dzg, bf);
     hipLaunchKernelGGL(k_tra_dy, dim3(grid_for(rows * 8)), dim3(NT), 0, s, dzg, rows, pw_w, dy);
-    hipLaunchKernelGGL(k_tra_dv, dim3(grid_for(rows * 8)), dim3(NT), 0, s, dy, v, B, Tt, dw_w, dv, bf);
+    hipLaunchKernelGGL(k_gate_shuffle_bwd, dim3(grid_for(rows * 33 * 8)), dim3(NT), 0, s, dout, g, dy, v, dw_w, B, T, Tt, dv,
+                       dx, bf);
     const int parts = (int)(rows < MAX_PARTIALS ? rows : MAX_PARTIALS);
-    hipLaunchKernelGGL(k_tra_pgrad, dim3(parts), dim3(128), 0, s, dzg, y, dy, e, B, Tt, scratch);
+    hipLaunchKernelGGL(k_tra_pgrad, dim3(parts), dim3(1024), 0, s, dzg, y, dy, e, B, Tt, scratch);
     // the four gradients are contiguous in the blob in exactly the partials' order (d_dw_w is the first)
     (void)d_dw_b; (void)d_pw_w; (void)d_pw_b;
     hipLaunchKernelGGL(k_reduce_partials_f, dim3(2), dim3(1024), 0, s, scratch, parts, 104, d_dw_w);
