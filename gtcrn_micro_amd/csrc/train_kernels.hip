@@ -1988,16 +1988,21 @@ __global__ __launch_bounds__(NT) void k_tra_gate(const float* __restrict__ e, in
 __global__ __launch_bounds__(NT) void k_gate_shuffle(const float* __restrict__ v, const float* __restrict__ g,
                                                     const float* __restrict__ x, int B, int T, int Tt,
                                                     float* __restrict__ out, int bf) {
-    const long total = (long)B * T * 33 * 8;
+    // thread (position, half h): channels 4h..4h+3 -> output slots 8h..8h+7; 16-byte accesses throughout
+    const long total = (long)B * T * 33 * 2;
     for (long i = (long)blockIdx.x * NT + threadIdx.x; i < total; i += (long)gridDim.x * NT) {
-        const int c = (int)(i & 7);
-        const long pos = i >> 3;                      // (b, t, f) over T frames
+        const int h = (int)(i & 1);
+        const long pos = i >> 1;                      // (b, t, f) over T frames
         const int f = (int)(pos % 33);
         const long bt = pos / 33;
         const int t = (int)(bt % T), b = (int)(bt / T);
         const long rowv = (long)b * Tt + t;
-        sst1(out, pos * 16 + 2 * c, bf, sld1(v, (rowv * 33 + f) * 8 + c, bf) * g[rowv * 8 + c]);
-        sst1(out, pos * 16 + 2 * c + 1, bf, sld1(x, pos * 16 + 8 + c, bf));
+        const f32x4 vv = sld4<kNt>(v, (rowv * 33 + f) * 8 + 4 * h, bf);
+        const f32x4 gg = *reinterpret_cast<const f32x4*>(g + rowv * 8 + 4 * h);
+        const f32x4 xx = sld4(x, pos * 16 + 8 + 4 * h, bf);
+        const f32x4 p = vv * gg;
+        sst4<kNtSt>(out, pos * 16 + 8 * h, bf, f32x4{p[0], xx[0], p[1], xx[1]});
+        sst4<kNtSt>(out, pos * 16 + 8 * h + 4, bf, f32x4{p[2], xx[2], p[3], xx[3]});
     }
 }
 // backward, last step (after k_tra_dgate / k_tra_dy): dv = dout[2c] * g (0 on the trimmed tail frames) + de * (2/33) * v
@@ -2008,45 +2013,71 @@ __global__ __launch_bounds__(NT) void k_gate_shuffle_bwd(const float* __restrict
                                                         const float* __restrict__ dy, const float* __restrict__ v,
                                                         const float* __restrict__ dw_w, int B, int T, int Tt,
                                                         float* __restrict__ dv, float* __restrict__ dx, int bf) {
-    const long total = (long)B * Tt * 33 * 8;
+    // thread (position of the T' frames, half h): channels 4h..4h+3; 16-byte accesses
+    const long total = (long)B * Tt * 33 * 2;
     for (long i = (long)blockIdx.x * NT + threadIdx.x; i < total; i += (long)gridDim.x * NT) {
-        const int c = (int)(i & 7);
-        const long posv = i >> 3;
+        const int h = (int)(i & 1);
+        const long posv = i >> 1;
         const int f = (int)(posv % 33);
         const long rowv = posv / 33;
         const int t = (int)(rowv % Tt), b = (int)(rowv / Tt);
-        float r = 0.f;
+        f32x4 r = {0.f, 0.f, 0.f, 0.f};
         if (t < T) {
             const long pos = ((long)b * T + t) * 33 + f;
-            r = dout[pos * 16 + 2 * c] * g[rowv * 8 + c];
-            dx[pos * 16 + 8 + c] = dout[pos * 16 + 2 * c + 1];
+            const f32x4 d0 = sld4<kNt>(dout, pos * 16 + 8 * h, 0), d1 = sld4<kNt>(dout, pos * 16 + 8 * h + 4, 0);
+            const f32x4 gg = *reinterpret_cast<const f32x4*>(g + rowv * 8 + 4 * h);
+            r = f32x4{d0[0], d0[2], d1[0], d1[2]} * gg;
+            sst4(dx, pos * 16 + 8 + 4 * h, 0, f32x4{d0[1], d0[3], d1[1], d1[3]});
         }
-        float de = 0.f;
+        f32x4 de = {0.f, 0.f, 0.f, 0.f};
         for (int k = 0; k < 3; ++k) {
             const int tt = t + 2 - k;
-            if (tt < Tt) de = fmaf(dw_w[c * 3 + k], dy[(rowv + 2 - k) * 8 + c], de);
+            if (tt < Tt) {
+                const f32x4 dyv = *reinterpret_cast<const f32x4*>(dy + (rowv + 2 - k) * 8 + 4 * h);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) de[e] = fmaf(dw_w[(4 * h + e) * 3 + k], dyv[e], de[e]);
+            }
         }
-        de *= 2.0f / 33.0f;
-        dv[i] = fmaf(de, sld1(v, i, bf), r);
+        const f32x4 vv = sld4<kNt>(v, posv * 8 + 4 * h, bf);
+        f32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = fmaf(de[e] * (2.0f / 33.0f), vv[e], r[e]);
+        sst4<kNtSt>(dv, posv * 8 + 4 * h, 0, o);
     }
 }
 // step 2: dg = sum_F dout[2c] * v  ->  dzg = dg * g * (1 - g)
 __global__ __launch_bounds__(NT) void k_tra_dgate(const float* __restrict__ dout, const float* __restrict__ v,
                                                  const float* __restrict__ g, int B, int T, int Tt,
                                                  float* __restrict__ dzg, int bf) {
-    const long total = (long)B * Tt * 8;
-    for (long i = (long)blockIdx.x * NT + threadIdx.x; i < total; i += (long)gridDim.x * NT) {
-        const int c = (int)(i & 7);
-        const long rowv = i >> 3;
+    // one wave per row (b, t): lane (position, quad q) takes dout slots 4q..4q+3 = channels 2q, 2q+1 (16-byte loads;
+    // one thread per (row, channel) walked the 33 bins with 4-byte loads at a 64-byte stride), then the lanes of a
+    // quad are summed by xor shuffles
+    const long rows = (long)B * Tt;
+    const int lane = threadIdx.x & 63, q = lane & 3;
+    const long nw = (long)gridDim.x * (NT / 64);
+    for (long rowv = (long)blockIdx.x * (NT / 64) + (threadIdx.x >> 6); rowv < rows; rowv += nw) {
         const int t = (int)(rowv % Tt), b = (int)(rowv / Tt);
-        float s = 0.f;
+        float s0 = 0.f, s1 = 0.f;
         if (t < T) {
-            const float* d = dout + (((long)b * T + t) * 33) * 16 + 2 * c;
-            const long vv = rowv * 33 * 8 + c;
-            for (int f = 0; f < 33; ++f) s = fmaf(d[f * 16], sld1(v, vv + f * 8, bf), s);
+            const long dbase = (((long)b * T + t) * 33) * 16, vbase = rowv * 33 * 8;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const int it = lane + 64 * k;
+                if (it < 132) {
+                    const int pos = it >> 2;
+                    const f32x4 d = *reinterpret_cast<const f32x4*>(dout + dbase + pos * 16 + 4 * q);
+                    s0 = fmaf(d[0], sld1(v, vbase + pos * 8 + 2 * q, bf), s0);
+                    s1 = fmaf(d[2], sld1(v, vbase + pos * 8 + 2 * q + 1, bf), s1);
+                }
+            }
         }
-        const float gg = g[i];
-        dzg[i] = s * gg * (1.f - gg);
+#pragma unroll
+        for (int off = 32; off >= 4; off >>= 1) { s0 += __shfl_xor(s0, off, 64); s1 += __shfl_xor(s1, off, 64); }
+        if (lane < 4) {
+            const float g0 = g[rowv * 8 + 2 * q], g1 = g[rowv * 8 + 2 * q + 1];
+            dzg[rowv * 8 + 2 * q] = s0 * g0 * (1.f - g0);
+            dzg[rowv * 8 + 2 * q + 1] = s1 * g1 * (1.f - g1);
+        }
     }
 }
 // step 3: dy[c] = sum_co pw[co][c] * dzg[co]
@@ -2645,7 +2676,7 @@ int tra_fwd(const float* v, int B, int Tt, const float* dw_w, const float* dw_b,
 }
 int gate_shuffle_fwd(const float* v, const float* g, const float* x, int B, int T, int Tt, float* out, hipStream_t s,
                      int bf) {
-    hipLaunchKernelGGL(k_gate_shuffle, dim3(grid_for((long)B * T * 33 * 8)), dim3(NT), 0, s, v, g, x, B, T, Tt, out, bf);
+    hipLaunchKernelGGL(k_gate_shuffle, dim3(grid_for((long)B * T * 33 * 2)), dim3(NT), 0, s, v, g, x, B, T, Tt, out, bf);
     return check();
 }
 int tra_gate_shuffle_bwd(const float* dout, const float* v, const float* g, const float* e, const float* y, int B,
@@ -2655,9 +2686,9 @@ int tra_gate_shuffle_bwd(const float* dout, const float* v, const float* g, cons
     const long rows = (long)B * Tt;
     float* dzg = tmp;
     float* dy = tmp + rows * 8;
-    hipLaunchKernelGGL(k_tra_dgate, dim3(grid_for(rows * 8)), dim3(NT), 0, s, dout, v, g, B, T, Tt, dzg, bf);
+    hipLaunchKernelGGL(k_tra_dgate, dim3(grid_for(rows * 64, 8192)), dim3(NT), 0, s, dout, v, g, B, T, Tt, dzg, bf);
     hipLaunchKernelGGL(k_tra_dy, dim3(grid_for(rows * 8)), dim3(NT), 0, s, dzg, rows, pw_w, dy);
-    hipLaunchKernelGGL(k_gate_shuffle_bwd, dim3(grid_for(rows * 33 * 8)), dim3(NT), 0, s, dout, g, dy, v, dw_w, B, T, Tt, dv,
+    hipLaunchKernelGGL(k_gate_shuffle_bwd, dim3(grid_for(rows * 33 * 2)), dim3(NT), 0, s, dout, g, dy, v, dw_w, B, T, Tt, dv,
                        dx, bf);
     const int parts = (int)(rows < MAX_PARTIALS ? rows : MAX_PARTIALS);
     hipLaunchKernelGGL(k_tra_pgrad, dim3(parts), dim3(1024), 0, s, dzg, y, dy, e, B, Tt, scratch);
