@@ -244,6 +244,8 @@ size_t plan(gtcrn_trainer* t, int B, int T, float* base) {
         k.pc2.front = &k.depth;
         k.pc2.pre = fuse ? &k.depth : nullptr;
         k.depth.deferred = fuse;
+        // (point_conv1 -> depth_conv is NOT fused: nine taps each re-apply the BatchNorm + PReLU -- the depthwise 3x3
+        // took 312 us against 163 + 107 for the two passes; the dense 3x3 is MFMA-bound already)
         k.o_tra = P(t, p + ".tra.depth_conv.weight");
         k.e = b.take((size_t)B * Tt * 8); k.yt = b.take((size_t)B * Tt * 8); k.g = b.take((size_t)B * Tt * 8);
         k.out = b.take_saved(n33 * 16);
@@ -280,6 +282,10 @@ size_t plan(gtcrn_trainer* t, int B, int T, float* base) {
         k.c1.front = i > 0 ? &t->tcn[i - 1].c3 : nullptr;
         k.c2.pre = fuse ? &k.c1 : nullptr; k.c1.deferred = fuse;
         k.c3.pre = fuse ? &k.c2 : nullptr; k.c2.deferred = fuse;
+        // conv1 of the NEXT block applies this block's bn3 + residual + PReLU (the last block keeps its own pass)
+        k.c1.pre = fuse && i > 0 ? &t->tcn[i - 1].c3 : nullptr;
+        if (i > 0) t->tcn[i - 1].c3.deferred = fuse;
+        k.c3.deferred = false;
         X = k.c3.a;
         if ((i & 3) == 3) t->taps["gtcn" + std::to_string(i / 4 + 1)] = {X, {T, 33, 16}};
     }
@@ -363,6 +369,7 @@ int unit_fwd(gtcrn_trainer* t, Unit& u, float* prm, hipStream_t s) {
         bp.stats = v.stats; bp.gamma = vbn; bp.beta = vbn + v.C;
         bp.slope = v.o_slope >= 0 ? prm + v.o_slope : nullptr;
         bp.a_out = v.a; bp.ybf = t->ybf; bp.bf = t->bf;
+        bp.res = v.res;
         if (u.dw) {
             DwGeom g = u.dg;
             g.in_bf = t->ybf;

@@ -66,6 +66,7 @@ struct BnPre {
     const float *stats, *gamma, *beta, *slope;   // of the previous unit; slope == nullptr: no activation
     float* a_out;
     int ybf, bf;
+    const float* res;                            // its residual input (format bf) or nullptr; pointwise convs only
 };
 int conv_fwd(const ConvGeom& g, const float* in, const float* w, const float* bias, float* out, hipStream_t s,
              double* stat_partial = nullptr, int* stat_parts = nullptr, const float* shift = nullptr,

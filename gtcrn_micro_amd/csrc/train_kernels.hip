@@ -334,11 +334,13 @@ __device__ __forceinline__ PreConst pre_const(const BnPre& pre, int q, int C) {
     k.sl = k.act ? pre.slope[0] : 0.f;
     return k;
 }
-__device__ __forceinline__ f32x4 pre_apply(const PreConst& k, const f32x4 y, int bf) {
+__device__ __forceinline__ f32x4 pre_apply(const PreConst& k, const f32x4 y, int bf, bool has_res = false,
+                                           const f32x4 r = f32x4{0.f, 0.f, 0.f, 0.f}) {
     f32x4 a;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-        const float z = k.gm[e] * ((y[e] - k.mean[e]) * k.istd[e]) + k.bt[e];
+        float z = k.gm[e] * ((y[e] - k.mean[e]) * k.istd[e]) + k.bt[e];
+        if (has_res) z += r[e];
         a[e] = k.act ? (z > 0.f ? z : k.sl * z) : z;
     }
     return round_bf4(a, bf);
@@ -457,6 +459,7 @@ __global__ __launch_bounds__(NT) void k_conv_mfma(ConvGeom g, const float* __res
         typename Raw4<FIN>::t raw[NKT * NKF];
         bool okv[NKT * NKF];
         long pidx = 0;
+        f32x4 pres = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int kt = 0; kt < NKT; ++kt) {
             const int ti = P.t + g.t_off[kt];
@@ -468,14 +471,17 @@ __global__ __launch_bounds__(NT) void k_conv_mfma(ConvGeom g, const float* __res
                 const bool ok = tap_fi(g, P.f, kf, fi) && okt;
                 okv[kt * NKF + kf] = ok;
                 raw[kt * NKF + kf] = sld4_raw<FIN>(in, ok ? (rowbase + fi) * g.CinT + g.cin_off + 4 * q : 0L);
-                if constexpr (PRE) pidx = (rowbase + fi) * g.CinT + g.cin_off + 4 * q;
+                if constexpr (PRE) {
+                    pidx = (rowbase + fi) * g.CinT + g.cin_off + 4 * q;
+                    if (pre.res) pres = sld4(pre.res, ok ? pidx : 0L, pre.bf);
+                }
             }
         }
 #pragma unroll
         for (int tap = 0; tap < NKT * NKF; ++tap) {
             f32x4 d = dec4<FIN>(raw[tap]);
             if constexpr (PRE) {
-                d = pre_apply(pk, d, pre.bf);
+                d = pre_apply(pk, d, pre.bf, pre.res != nullptr, pres);
                 if (okv[tap]) sst4<kNtSt>(pre.a_out, pidx, pre.bf, d);
             }
             const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
@@ -2432,7 +2438,7 @@ int dw_fwd(const DwGeom& g, const float* in, const float* w, const float* bias, 
     if (stat_parts) *stat_parts = 0;
     const BnPre nopre{};
     if (pre && !(g.C == 16 && g.nkt == 3 && g.nkf == 1 && g.t_off[2] == 0 && g.f_off[0] == 0 && g.in_bf == pre->ybf &&
-                 g.in_bf <= 1 && !g.accumulate))
+                 g.in_bf <= 1 && !g.accumulate && !pre->res))
         return (int)hipErrorInvalidValue;
     const int grid = grid_for((long)g.B * g.Tout * g.F);
     if (g.C == 16) {
