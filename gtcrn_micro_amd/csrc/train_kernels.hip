@@ -45,6 +45,22 @@ __device__ __forceinline__ bool tap_fi(const ConvGeom& g, int fo, int kf, int& f
     return fi >= 0 && fi < g.Fin;
 }
 
+// the same with the stride known to be 1 at compile time (the 3x3 and 1x1 layers): two adds and a range check instead
+// of the run-time mode / stride / parity logic -- which cost ~50 scalar and vector instructions per tap of the MFMA
+// conv kernels, issued between MFMAs that block the vector unit
+template <bool SF1>      // SF1: stride 1; otherwise stride 2 (the 1x5 layers), branch free
+__device__ __forceinline__ bool tap_fi_t(const ConvGeom& g, int fo, int kf, int& fi) {
+    if constexpr (SF1) {
+        fi = g.f_mode ? fo + g.pf - kf : fo - g.pf + kf;
+        return fi >= 0 && fi < g.Fin;
+    } else {
+        const int n0 = fo * 2 - g.pf + kf, n1 = fo + g.pf - kf;
+        fi = g.f_mode ? n1 >> 1 : n0;
+        const bool par = g.f_mode ? (n1 >= 0 && (n1 & 1) == 0) : true;
+        return par && fi >= 0 && fi < g.Fin;
+    }
+}
+
 // ---- storage of the SAVED tensors (conv outputs y, activations a, block outputs: what the backward re-reads) -------
 // fp32 (the reference's own precision) or bf16 (BASELINE configs[3]: half the bytes of every pass that touches them;
 // arithmetic, statistics, gradients and master weights stay fp32).  The flag is a launch constant (wave-uniform
@@ -468,7 +484,7 @@ __global__ __launch_bounds__(NT) void k_conv_mfma(ConvGeom g, const float* __res
 #pragma unroll
             for (int kf = 0; kf < NKF; ++kf) {
                 int fi;
-                const bool ok = tap_fi(g, P.f, kf, fi) && okt;
+                const bool ok = tap_fi_t<NKF != 5>(g, P.f, kf, fi) && okt;      // (only the 1x5 layers are strided)
                 okv[kt * NKF + kf] = ok;
                 raw[kt * NKF + kf] = sld4_raw<FIN>(in, ok ? (rowbase + fi) * g.CinT + g.cin_off + 4 * q : 0L);
                 if constexpr (PRE) {
@@ -736,7 +752,7 @@ __global__ __launch_bounds__(WG_WAVES * 64) void k_conv_wgrad_lds(ConvGeom g, co
 #pragma unroll
                 for (int kf = 0; kf < NKF; ++kf) {
                     int fi;
-                    const bool ok = tap_fi(g, P.f, kf, fi) && okt;
+                    const bool ok = tap_fi_t<NKF != 5>(g, P.f, kf, fi) && okt;
                     typename Raw4<FMT>::t z{};
                     raw[kt * NKF + kf] = ok ? sld4_raw<FMT>(in, (rowbase + fi) * g.CinT + g.cin_off + 4 * k) : z;
                 }
@@ -2299,7 +2315,8 @@ static int red_grid(long units) {
 static bool mfma_ok(const ConvGeom& g) {
     return (g.Cin % 4) == 0 && (g.Cout % 4) == 0 && (g.CinT % 4) == 0 && (g.CoutT % 4) == 0 && (g.cin_off % 4) == 0 &&
            (g.cout_off % 4) == 0 && g.Fout >= 16 && g.sf <= 2 &&
-           ((g.nkt == 1 && (g.nkf == 1 || g.nkf == 5)) || (g.nkt == 3 && g.nkf == 3));
+           ((g.nkt == 1 && ((g.nkf == 1 && g.sf == 1) || (g.nkf == 5 && g.sf == 2))) ||
+            (g.nkt == 3 && g.nkf == 3 && g.sf == 1));
 }
 
 // the window forms (see win_pos): a (1, nkf) conv with stride 2 between a tensor of exactly 16 channels and a narrow
