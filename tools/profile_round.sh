@@ -9,7 +9,8 @@
 #   pmc_sq2    matrix-pipe busy cycles, VALU/MFMA co-execution cycles, busy CU cycles, VALU / LDS active cycles,
 #              GRBM_GUI_ACTIVE (effective clock = GRBM_GUI_ACTIVE / 8 / kernel time)
 #   ub_*       tools/ubench_mfma_valu.hip (does fp32 MFMA overlap with fp32 VALU?) under the same counters
-#   stream / train             kernel trace + stats of the configs[2] / configs[3] legs
+#   stream / train             kernel trace + stats of the configs[2] / configs[3] legs; train_pmc_*: HBM counters of the
+#                              fp32 train step
 # tools/profile_summary.py condenses them into the files committed under profiles/.
 set -u
 TAG=${1:-r03}
@@ -31,6 +32,9 @@ rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_VALU_MFMA_COEXEC_CYCL
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stream" -- python3 "$R/tools/stream_bench.py" > "$OUT/stream.log" 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/train_f32" -- python3 "$R/bench.py" --mode train --steps 3 --warmup 1 > "$OUT/train_f32.log" 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/train_bf16" -- python3 "$R/bench.py" --mode train --train-storage bf16 --steps 3 --warmup 1 > "$OUT/train_bf16.log" 2>&1
+# HBM counters of the fp32 train step (tools/profile_summary.py -> profiles/<tag>_train_hbm_traffic.json)
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$OUT/train_pmc_fetch" -- python3 "$R/bench.py" --mode train --steps 2 --warmup 1 > "$OUT/train_pmc_fetch.log" 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$OUT/train_pmc_write" -- python3 "$R/bench.py" --mode train --steps 2 --warmup 1 > "$OUT/train_pmc_write.log" 2>&1
 grep -h '"metric"' "$OUT"/*.log | cut -c1-300
 cat "$OUT/ub_plain.log"
 find "$OUT" -name "*.csv" | wc -l

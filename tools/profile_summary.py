@@ -89,6 +89,50 @@ def main():
             for k in sorted(sq):
                 w.writerow([k] + [f"{sum(sq[k][c]) / len(sq[k][c]):.0f}" if sq[k].get(c) else "" for c in names])
         print(open(os.path.join(dst, f"{tag}_sq_counters.csv")).read())
+    # --- train step: HBM counters per kernel next to its average time (tools/profile_round.sh train_pmc_* passes)
+    import re
+
+    def tshort(name):       # any kernel of this repo, with its template arguments
+        mm = re.search(r"(k_\w+(?:<[^>(]*>)?)", name)
+        return mm.group(1) if mm else None
+
+    def tpmc(sub):
+        acc = defaultdict(lambda: defaultdict(list))
+        for f in newest(sub, "*counter_collection.csv"):
+            for r in csv.DictReader(open(f)):
+                k = tshort(r["Kernel_Name"])
+                if k:
+                    acc[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
+        return acc
+    tf, tw = tpmc("train_pmc_fetch"), tpmc("train_pmc_write")
+    if tf or tw:
+        f = newest("train_f32", "*kernel_stats.csv")
+        rows = list(csv.DictReader(open(f[0]))) if f else []
+        t_ns = {tshort(r["Name"]): float(r["AverageNs"]) for r in rows if tshort(r["Name"])}
+        calls = {tshort(r["Name"]): int(r["Calls"]) for r in rows if tshort(r["Name"])}
+        out = {"note": "FETCH_SIZE / WRITE_SIZE in KB per launch, averaged over the launches of a kernel (layers of "
+                       "different sizes share a kernel); FETCH_SIZE is tallied at half the bytes for 16 B-per-lane "
+                       "coalesced reads on gfx950 (MI355X_MICROARCH.md), so read_bytes_x2 is the figure to use for the "
+                       "kernels that load 16 bytes per lane (all the large ones here); TB_per_s = (2 x fetch + write) / "
+                       "average time"}
+        tot = 0.0
+        for k in sorted(set(tf) | set(tw), key=lambda k: -calls.get(k, 0) * t_ns.get(k, 0.0)):
+            fs = tf.get(k, {}).get("FETCH_SIZE", [])
+            ws = tw.get(k, {}).get("WRITE_SIZE", [])
+            if k not in t_ns or not (fs or ws):
+                continue
+            fkb = sum(fs) / len(fs) if fs else 0.0
+            wkb = sum(ws) / len(ws) if ws else 0.0
+            byt = (2 * fkb + wkb) * 1024
+            out[k] = {"launches_per_profile": calls[k], "avg_us": round(t_ns[k] / 1e3, 1),
+                      "FETCH_SIZE_KB_raw": round(fkb, 1), "WRITE_SIZE_KB": round(wkb, 1),
+                      "read_bytes_x2_plus_write_MB": round(byt / 1e6, 1),
+                      "TB_per_s": round(byt / t_ns[k] / 1e3, 2)}
+            tot += byt * calls[k]
+        steps = 5       # bench.py --mode train --steps 3 --warmup 1 runs 1 + 1 + 3 steps
+        out["total_GB_per_step"] = round(tot / steps / 1e9, 1)
+        json.dump(out, open(os.path.join(dst, f"{tag}_train_hbm_traffic.json"), "w"), indent=1)
+        print("train traffic: %.1f GB per step" % out["total_GB_per_step"])
     # --- derived figures per kernel: executed matrix FLOP, pipe busy share, co-execution share, effective clock
     f = newest("trace", "*kernel_stats.csv")
     avg_ns = {short(r["Name"]): float(r["AverageNs"]) for r in csv.DictReader(open(f[0])) if short(r["Name"])} if f else {}
