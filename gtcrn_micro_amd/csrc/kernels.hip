@@ -48,13 +48,21 @@ __device__ __forceinline__ void wave_lds_sync() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 __device__ __forceinline__ void wg_barrier() {
+#ifdef GT_EXP_NOBARRIER      // timing experiment only (results are wrong): what the barrier skew costs
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#else
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#endif
 }
 // ... that also publishes this wave's LDS-DMA writes (global_load_lds: counted in vmcnt)
 // KEEP = vector-memory operations issued AFTER the DMA that may stay in flight (vmcnt retires in issue order)
 template <int KEEP = 0>
 __device__ __forceinline__ void wg_barrier_vm() {
+#ifdef GT_EXP_NOBARRIER
+    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(KEEP) : "memory");
+#else
     asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(KEEP) : "memory");
+#endif
 }
 
 // position-major LDS image: one record of 16 floats per position, slot group g at +16g bytes, records RS floats apart.
