@@ -70,7 +70,8 @@ FFT_FLOP_PER_FRAME = 2 * 11520 + 6000          # 512-point rFFT + irFFT (5 N log
 FP32_MFMA_PEAK_TFLOPS = 157.3                   # MI355X_MICROARCH.md, dense, v_mfma_f32_16x16x4_f32
 HBM_PEAK_GBS = 8000.0
 STREAM_STATE_BYTES_PER_FRAME = 94 * 1024        # ring-state traffic + the frame itself
-TRAIN_BYTES_PER_FRAME = 1.46e6                  # layer-at-a-time fp32 passes
+TRAIN_HBM_BYTES_PER_FRAME_F32 = 163.9e9 / (512 * 251)   # counter-measured HBM traffic of the fp32 step (round 3,
+                                                        # profiles/r03_train_hbm_traffic.json; 1.46 MB before the fusions)
 ROUND_TAG = "r03"
 
 
@@ -430,7 +431,6 @@ def train_run(ctx, world, sync_all, max_over_ranks, steps=5, warmup=2):
     sync_all()
     el = max_over_ranks(time.perf_counter() - t0, "cuda") / steps
     ws = G.Trainer.workspace_bytes(B, T, storage) if storage != "f32" else G.Trainer.workspace_bytes(B, T)
-    byte_scale = 1.0 if storage == "f32" else 0.5
     return {
         "workload": f"train step, B={B} clips/GPU x {seconds:g} s (T={T}), saved activations {storage}, fp32 "
                     "accumulate + master weights, Adam, clip 3.0, synthetic DNS-style mixes",
@@ -438,7 +438,8 @@ def train_run(ctx, world, sync_all, max_over_ranks, steps=5, warmup=2):
                        + (" + DDP-style buffer broadcast from rank 0" if world > 1 else ""),
         "ms_per_step": round(el * 1e3, 3), "frames_per_s": round(world * B * T / el, 1),
         "steps": steps, "warmup": warmup, "dtype": storage,
-        "algorithmic_TB_per_s": round(TRAIN_BYTES_PER_FRAME * byte_scale * B * T / el / 1e12, 3),
+        # HBM rate from the counter-measured bytes of the fp32 step (not measured for bf16 storage: null)
+        "hbm_TB_per_s": round(TRAIN_HBM_BYTES_PER_FRAME_F32 * B * T / el / 1e12, 3) if storage == "f32" else None,
         "workspace_GB": round(ws / 2 ** 30, 2), "loss": float(loss), "grad_norm": float(gn),
         "_rate_keys": ["frames_per_s"], "_time_keys": ["ms_per_step"],
     }
@@ -507,7 +508,7 @@ def train_main(args):
             "warmup": args.warmup, "ms_per_step": r["ms_per_step"], "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": r["dtype"], "data": "synthetic DNS-style mixes",
             "config": {"workload": r["workload"], "parallelism": r["parallelism"]},
-            "workspace_GB": r["workspace_GB"], "algorithmic_TB_per_s": r["algorithmic_TB_per_s"],
+            "workspace_GB": r["workspace_GB"], "hbm_TB_per_s": r["hbm_TB_per_s"],
             "loss": r["loss"], "grad_norm": r["grad_norm"]}), flush=True)
     if world > 1:
         dist.barrier()
