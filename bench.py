@@ -70,9 +70,12 @@ FFT_FLOP_PER_FRAME = 2 * 11520 + 6000          # 512-point rFFT + irFFT (5 N log
 FP32_MFMA_PEAK_TFLOPS = 157.3                   # MI355X_MICROARCH.md, dense, v_mfma_f32_16x16x4_f32
 HBM_PEAK_GBS = 8000.0
 STREAM_STATE_BYTES_PER_FRAME = 94 * 1024        # ring-state traffic + the frame itself
-TRAIN_HBM_BYTES_PER_FRAME_F32 = 163.9e9 / (512 * 251)   # counter-measured HBM traffic of the fp32 step (round 3,
-                                                        # profiles/r03_train_hbm_traffic.json; 1.46 MB before the fusions)
-ROUND_TAG = "r03"
+# counter-measured HBM traffic of one B = 512 x 4 s train step per storage mode (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE
+# passes, FETCH doubled for the 16-byte-per-lane reads; tools/profile_summary.py); a mode without counters reports null
+TRAIN_HBM_BYTES_PER_STEP = {"f32": 163.9e9}
+TRAIN_HBM_SOURCE = {"f32": "profiles/r03_train_hbm_traffic.json"}
+ROUND_TAG = "r04"
+WATCHDOG_EXIT_CODE = 3                                  # exit status of every rank when a watchdog had to cut a leg
 
 
 def _free_port():
@@ -125,7 +128,8 @@ def _load_shim():
 class Watchdog:
     """Bounds a phase that may hang on a collective (a rank that died alone leaves the others waiting in RCCL until its
     own timeout, long after the driver has given up): after `seconds` rank 0 prints the line as it stands -- the
-    headline is complete before any secondary leg starts -- with the reason, and every rank leaves the process."""
+    headline is complete before any secondary leg starts -- with the reason, and every rank leaves the process with a
+    NON-ZERO status (WATCHDOG_EXIT_CODE): the line is kept, the failure is not hidden from torchrun / the driver."""
 
     def __init__(self, seconds, rank, get_line, what):
         self.seconds, self.rank, self.get_line, self.what = seconds, rank, get_line, what
@@ -142,7 +146,9 @@ class Watchdog:
         else:
             time.sleep(2.0)                                    # let rank 0's line out first
         sys.stdout.flush()
-        os._exit(0)
+        # a rank hung or died inside a collective: the line (with the reason) is out, but the run did NOT succeed --
+        # the launcher and the driver must see a failure.  No re-exec, no clean-up through the hung runtime.
+        os._exit(WATCHDOG_EXIT_CODE)
 
     def __enter__(self):
         import threading
@@ -394,12 +400,46 @@ def stream_extras(eng, spec, N, frames=200):
     return out
 
 
+def batch_sweep_leg(eng, win, world, sync_all, max_over_ranks):
+    """Shapes other than the headline's, wave -> wave, per GPU: the reference's own call shape (ONE clip per call,
+    infer.py:48: a 31-second example-length clip and a 4-second one), a small batch, the headline batch, one clip more
+    than a round of 256 workgroups, and two rounds.  frames/s per shape; `rel` = per-frame cost relative to B = 256."""
+    import torch
+    shapes = [("1x31s", 1, 496000), ("1x4s", 1, 64000), ("32x4s", 32, 64000), ("256x4s", 256, 64000),
+              ("257x4s", 257, 64000), ("512x4s", 512, 64000)]
+    res, last = {}, 0.0
+    for name, B, L in shapes:
+        T = 1 + L // 256
+        torch.manual_seed(45)
+        x = torch.randn(B, L, device="cuda") * 0.1
+        y = torch.empty((B, 256 * (T - 1)), device="cuda")
+        eng.reserve(B, T)
+        iters = 30 if B * T < 40000 else 12
+        for _ in range(3):
+            eng.forward_wave(x, win, out=y)
+        sync_all()
+        t0 = time.perf_counter()
+        for _ in range(iters):
+            eng.forward_wave(x, win, out=y)
+        sync_all()
+        last = time.perf_counter() - t0
+        el = last / iters
+        res[name] = {"B": B, "T": T, "ms_per_call": round(el * 1e3, 4), "frames_per_s": round(world * B * T / el, 1)}
+        del x, y
+    base = res["256x4s"]["ms_per_call"] / (256 * 251)
+    for v in res.values():
+        v["per_frame_cost_rel_256"] = round(v["ms_per_call"] / (v["B"] * v["T"]) / base, 3)
+    max_over_ranks(last, "cuda")
+    torch.cuda.empty_cache()
+    return {"workload": "offline wave->wave at other batch shapes, per GPU (B x clip length)", **res}
+
+
 def train_prepare(rank, B=512, seconds=4.0, storage="f32"):
     """Everything of the train leg that can fail on ONE rank alone (allocations: the 16-29 GiB activation workspace,
-    the model, the batch) plus one complete LOCAL step with no collective, so that the ranks can agree on success
-    before the first gradient all-reduce."""
+    the model, the batch) plus one LOCAL, side-effect-free forward + backward with no collective, so that the ranks can
+    agree on success before the first gradient all-reduce."""
     import torch
-    from gtcrn_micro_amd.train import make_training, synthetic_mix, train_step
+    from gtcrn_micro_amd.train import make_training, synthetic_mix, validate_step
     L = int(seconds * 16000)
     torch.manual_seed(43)                                     # identical initial weights on every rank
     model, opt, sched, loss_func = make_training(device="cuda")
@@ -409,7 +449,10 @@ def train_prepare(rank, B=512, seconds=4.0, storage="f32"):
             return None                                       # this build has no such storage variant
         model.set_activation_storage(storage)
     noisy, clean = synthetic_mix(B, samples=L, seed=43 + rank)
-    train_step(model, opt, sched, loss_func, noisy, clean, world_size=1)
+    # forward + loss + backward on this rank's own shard, then everything it touched (running statistics, gradients) is
+    # put back: NO optimizer / scheduler step, so the replicas still hold identical weights and Adam state when the
+    # data-parallel steps start (a full local step here made every rank apply a different update first)
+    validate_step(model, loss_func, noisy, clean)
     torch.cuda.synchronize()
     return {"model": model, "opt": opt, "sched": sched, "loss": loss_func, "noisy": noisy, "clean": clean,
             "B": B, "T": 1 + L // 256, "seconds": seconds, "storage": storage}
@@ -422,15 +465,32 @@ def train_run(ctx, world, sync_all, max_over_ranks, steps=5, warmup=2):
     from gtcrn_micro_amd.train import train_step
     model, opt, sched, loss_func, noisy, clean = (ctx[k] for k in ("model", "opt", "sched", "loss", "noisy", "clean"))
     B, T, seconds, storage = ctx["B"], ctx["T"], ctx["seconds"], ctx["storage"]
+    if world > 1:
+        # what DistributedDataParallel does at construction (train.py:88): every replica starts from rank 0's
+        # parameters and buffers, whatever happened before
+        from gtcrn_micro_amd.train import broadcast_parameters
+        broadcast_parameters(model)
     for _ in range(warmup):
         train_step(model, opt, sched, loss_func, noisy, clean, world_size=world)
     sync_all()
+    stats = {}
     t0 = time.perf_counter()
     for _ in range(steps):
-        loss, gn = train_step(model, opt, sched, loss_func, noisy, clean, world_size=world)
+        loss, gn = train_step(model, opt, sched, loss_func, noisy, clean, world_size=world, stats=stats)
     sync_all()
     el = max_over_ranks(time.perf_counter() - t0, "cuda") / steps
+    # the exchange step alone (buffer broadcast + gradient all-reduce), from device events around it; 0 at N = 1
+    xch = [a.elapsed_time(b) for a, b in stats.get("exchange_events", [])]
+    allreduce_ms = round(sum(xch) / len(xch), 4) if xch else 0.0
     ws = G.Trainer.workspace_bytes(B, T, storage) if storage != "f32" else G.Trainer.workspace_bytes(B, T)
+    hbm_bytes = TRAIN_HBM_BYTES_PER_STEP.get(storage)
+    if hbm_bytes is not None:
+        hbm_bytes = hbm_bytes * (B * T) / (512 * 251)          # the counters were taken at B = 512 x 4 s
+    roof = None if hbm_bytes is None else {
+        "bound": "hbm", "achieved": round(hbm_bytes / el / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        "frac": round(hbm_bytes / el / 1e9 / HBM_PEAK_GBS, 4), "traffic": hbm_bytes,
+        "note": "whole train step: counter-measured HBM bytes per step (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, "
+                f"{TRAIN_HBM_SOURCE.get(storage)}) over this run's step time"}
     return {
         "workload": f"train step, B={B} clips/GPU x {seconds:g} s (T={T}), saved activations {storage}, fp32 "
                     "accumulate + master weights, Adam, clip 3.0, synthetic DNS-style mixes",
@@ -438,8 +498,8 @@ def train_run(ctx, world, sync_all, max_over_ranks, steps=5, warmup=2):
                        + (" + DDP-style buffer broadcast from rank 0" if world > 1 else ""),
         "ms_per_step": round(el * 1e3, 3), "frames_per_s": round(world * B * T / el, 1),
         "steps": steps, "warmup": warmup, "dtype": storage,
-        # HBM rate from the counter-measured bytes of the fp32 step (not measured for bf16 storage: null)
-        "hbm_TB_per_s": round(TRAIN_HBM_BYTES_PER_FRAME_F32 * B * T / el / 1e12, 3) if storage == "f32" else None,
+        "hbm_TB_per_s": None if hbm_bytes is None else round(hbm_bytes / el / 1e12, 3),
+        "roofline": roof, "allreduce_ms": allreduce_ms,
         "workspace_GB": round(ws / 2 ** 30, 2), "loss": float(loss), "grad_norm": float(gn),
         "_rate_keys": ["frames_per_s"], "_time_keys": ["ms_per_step"],
     }
@@ -525,6 +585,8 @@ def main(argv=None):
     ap.add_argument("--batch", type=int, default=None,
                     help="clips per GPU (default: 256 for the headline, configs[1]; 512 for --mode train, configs[3])")
     ap.add_argument("--seconds", type=float, default=4.0, help="clip length")
+    ap.add_argument("--repeats", type=int, default=5,
+                    help="timed regions of --steps steps each; the line reports the median one (and min / max)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true",
                     help="skip the stream/train/quant legs (profiling runs of the headline path)")
@@ -596,15 +658,24 @@ def main(argv=None):
     # the timed region keeps only the dominant kernel's events (on the launch stream): each event pair costs a
     # few microseconds of dispatch gap, one pair per kernel per step would be ~4 % of the step
     eng.timing_enable(True, only=dom)
-    sync_all()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        eng.forward_wave(wave, win, out=out)
-    sync_all()
-    elapsed = time.perf_counter() - t0
+    # R timed regions of EXACTLY K steps each, every one bracketed by barrier + synchronize on both sides and priced
+    # with the slowest rank; the line reports min / median / max and `value` is the MEDIAN region (a single 20-50 ms
+    # region is one sample of a box whose clocks move by a few percent)
+    regions = []
+    for _ in range(max(args.repeats, 1)):
+        sync_all()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            eng.forward_wave(wave, win, out=out)
+        sync_all()
+        mine = time.perf_counter() - t0
+        regions.append((max_over_ranks(mine, dev), mine))
     dom_ms, dom_launches = eng.timing_read()[dom]
-    per_rank_s = [x for x in gather_ranks(elapsed, world)]     # a straggler shows up in one line
-    elapsed = max_over_ranks(elapsed, dev)                     # the slowest rank defines the step time
+    order = sorted(range(len(regions)), key=lambda i: regions[i][0])
+    med = order[(len(order) - 1) // 2]                         # the (lower) median region: an actually measured one
+    elapsed = regions[med][0]                                  # the slowest rank defines the step time
+    per_rank_s = [x for x in gather_ranks(regions[med][1], world)]   # a straggler shows up in one line
+    region_ms = sorted(r[0] / args.steps * 1e3 for r in regions)
     # the per-kernel split: ONE separate pass of K steps with an event pair around every kernel (all kernel_ms
     # values come from here; its step time is reported next to the headline's)
     eng.timing_enable(True)
@@ -677,6 +748,11 @@ def main(argv=None):
                        "batch_per_gpu": B, "frames_per_step_per_gpu": frames_per_step,
                        "parallelism": f"{world} independent utterance shards, no data-path collective"},
             "timed_region_s": round(elapsed, 4),
+            "repeats": {"regions": len(regions), "steps_per_region": args.steps,
+                        "ms_per_step": {"min": round(region_ms[0], 4), "median": round(elapsed / args.steps * 1e3, 4),
+                                        "max": round(region_ms[-1], 4)},
+                        "note": "value / ms_per_step / timed_region_s are the median region's; the roofline's launch "
+                                "average runs over all regions"},
             "per_rank_ms_per_step": {"min": round(min(per_rank_s) / args.steps * 1e3, 4),
                                      "max": round(max(per_rank_s) / args.steps * 1e3, 4),
                                      "all": [round(x / args.steps * 1e3, 4) for x in per_rank_s]},
@@ -701,6 +777,9 @@ def main(argv=None):
     if not shim and not args.no_secondary:
         put("stream", run_leg("stream", lambda sync_local, record: stream_leg(eng, world, sync_local, record),
                               rank, world, get_line))
+        put("batch_sweep", run_leg("batch_sweep", lambda sync_local, record: batch_sweep_leg(
+            eng, win, world, sync_local, record), rank, world, get_line))
+        eng.reserve(B, T)
         try:
             from gtcrn_micro_amd import quant
         except ImportError:

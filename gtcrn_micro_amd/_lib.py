@@ -85,6 +85,7 @@ def lib():
     L.gtcrn_debug_stamps.restype = cl
     L.gtcrn_debug_stamps.argtypes = [_vp, ci, ctypes.POINTER(ctypes.c_ulonglong), cl]
     L.gtcrn_selftest_mfma.argtypes = [ci]
+    L.gtcrn_selftest_split3.argtypes = [ci, _c_f32p, cl, _c_f32p, _c_f32p, _c_f32p, _c_f32p, _c_f32p]
     L.gtcrn_timing_enable.argtypes = [_vp, ci]
     L.gtcrn_timing_read.argtypes = [_vp, ci, ctypes.c_char_p, ci, _c_f32p, ctypes.POINTER(ci)]
     L.gtcrn_timing_kernels.restype = ci
@@ -518,6 +519,24 @@ class Engine:
 
 def selftest_mfma(device=0):
     _check(lib().gtcrn_selftest_mfma(int(device)))
+
+
+def selftest_split3(x, A=None, B=None, device=0):
+    """Device-side split3 / join3 / split_mm6 (the dense 3x3's exact bf16 split) on the given fp32 values: returns
+    (planes (3,n), joined (n,)) and, with A (16,32) and B (32,16), also D (16,16) = A @ B through the six products."""
+    x = np.ascontiguousarray(x, np.float32).ravel()
+    planes = np.empty((3, x.size), np.float32)
+    joined = np.empty(x.size, np.float32)
+    f = lambda a: a.ctypes.data_as(_c_f32p)
+    if A is None:
+        _check(lib().gtcrn_selftest_split3(int(device), f(x), x.size, f(planes), f(joined), None, None, None))
+        return planes, joined
+    A = np.ascontiguousarray(A, np.float32)
+    B = np.ascontiguousarray(B, np.float32)
+    assert A.shape == (16, 32) and B.shape == (32, 16)
+    D = np.empty((16, 16), np.float32)
+    _check(lib().gtcrn_selftest_split3(int(device), f(x), x.size, f(planes), f(joined), f(A), f(B), f(D)))
+    return planes, joined, D
 
 
 class Trainer:

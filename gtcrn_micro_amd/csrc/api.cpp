@@ -708,6 +708,32 @@ int gtcrn_selftest_mfma(int device) {
     return 0;
 }
 
+int gtcrn_selftest_split3(int device, const float* h_x, long n, float* h_planes, float* h_joined, const float* h_A,
+                          const float* h_B, float* h_D) {
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(GTCRN_ERR_DEVICE, "no HIP device");
+    if (!h_x || !h_planes || !h_joined || n < 4 || (n & 3)) return fail(GTCRN_ERR_ARG, "n must be a positive multiple of 4");
+    if ((h_A || h_B || h_D) && !(h_A && h_B && h_D)) return fail(GTCRN_ERR_ARG, "A, B and D come together");
+    HIP_TRY(hipSetDevice(device));
+    float *dx = nullptr, *dp = nullptr, *dj = nullptr, *dm = nullptr;
+    HIP_TRY(hipMalloc(&dx, sizeof(float) * n));
+    HIP_TRY(hipMalloc(&dp, sizeof(float) * 3 * n));
+    HIP_TRY(hipMalloc(&dj, sizeof(float) * n));
+    HIP_TRY(hipMalloc(&dm, sizeof(float) * (512 + 512 + 256)));
+    HIP_TRY(hipMemcpy(dx, h_x, sizeof(float) * n, hipMemcpyHostToDevice));
+    if (h_A) {
+        HIP_TRY(hipMemcpy(dm, h_A, sizeof(float) * 512, hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(dm + 512, h_B, sizeof(float) * 512, hipMemcpyHostToDevice));
+    }
+    LAUNCH_TRY(gtk::launch_selftest_split3(dx, n, dp, dj, h_A ? dm : nullptr, dm + 512, dm + 1024, nullptr));
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(h_planes, dp, sizeof(float) * 3 * n, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(h_joined, dj, sizeof(float) * n, hipMemcpyDeviceToHost));
+    if (h_D) HIP_TRY(hipMemcpy(h_D, dm + 1024, sizeof(float) * 256, hipMemcpyDeviceToHost));
+    (void)hipFree(dx); (void)hipFree(dp); (void)hipFree(dj); (void)hipFree(dm);
+    return 0;
+}
+
 int gtcrn_timing_enable(gtcrn_model* m, int on) {
     int rc = check_model(m);
     if (rc) return rc;

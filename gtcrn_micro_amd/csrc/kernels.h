@@ -77,5 +77,8 @@ int launch_conv2d_causal(const float* x, const float* cache, const float* w, con
                          float* cache_out, int B, int Cin, int Cout, int T, int F, int kt, int kf, int dt, int df,
                          int pf, int groups, int transposed, int Fout, hipStream_t s);
 int launch_selftest(const float* A, const float* Bm, const float* C, float* D, hipStream_t s);
+// n (a multiple of 4) values -> planes [3][n] and joined [n]; A (16x32), Bm (32x16) -> D (16x16) through split_mm6
+int launch_selftest_split3(const float* x, long n, float* planes, float* joined, const float* A, const float* Bm,
+                           float* D, hipStream_t s);
 
 }  // namespace gtk

@@ -233,6 +233,18 @@ __device__ __forceinline__ f32x4 ld_split(const float* img, int rec, int g) {
 __device__ __forceinline__ f32x4 mfma_bf(const bf16x8 a, const bf16x8 b, const f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
 }
+// acc += A * B for one K = 32 chunk from the split planes {hi, mid, lo} of both operands: the six partial products of
+// weight >= 2^-16, the small ones first.  The ONE place the product set is written down: the dense 3x3, de_convs.3 and
+// the device self test (gtcrn_selftest_split3, tests/test_gpu_parity.py) all go through it.
+__device__ __forceinline__ f32x4 split_mm6(const bf16x8 (&ap)[3], const bf16x8 (&bp)[3], f32x4 acc) {
+    acc = mfma_bf(ap[0], bp[2], acc);
+    acc = mfma_bf(ap[2], bp[0], acc);
+    acc = mfma_bf(ap[1], bp[1], acc);
+    acc = mfma_bf(ap[0], bp[1], acc);
+    acc = mfma_bf(ap[1], bp[0], acc);
+    acc = mfma_bf(ap[0], bp[0], acc);
+    return acc;
+}
 // The int8 / fp16 variant (Q) takes the same road with ONE plane: its activations are fp16 numbers, so h lives in LDS as
 // fp16 records (the first 32 bytes of the 96-byte record) and the dense 3x3 is five v_mfma_f32_16x16x32_f16 per tile --
 // no conversion per matrix instruction (round 2 kept fp32 records and converted both operands at every one of nine
@@ -801,12 +813,7 @@ __device__ __forceinline__ void gtconv_block(f32x4 (&x)[TPW], const Tiles<TPW>& 
                     bf16x8 bp[3];
 #pragma unroll
                     for (int p = 0; p < 3; ++p) bp[p] = *reinterpret_cast<const bf16x8*>(src + 8 * p);
-                    acc[i] = mfma_bf(ap[0], bp[2], acc[i]);
-                    acc[i] = mfma_bf(ap[2], bp[0], acc[i]);
-                    acc[i] = mfma_bf(ap[1], bp[1], acc[i]);
-                    acc[i] = mfma_bf(ap[0], bp[1], acc[i]);
-                    acc[i] = mfma_bf(ap[1], bp[0], acc[i]);
-                    acc[i] = mfma_bf(ap[0], bp[0], acc[i]);
+                    acc[i] = split_mm6(ap, bp, acc[i]);
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
@@ -2233,20 +2240,8 @@ __device__ __forceinline__ void de_conv3_tiles(const float* sW, const int (&rec0
                 bf16x8 bp[3];
 #pragma unroll
                 for (int p = 0; p < 3; ++p) bp[p] = *reinterpret_cast<const bf16x8*>(sW + src + 8 * p);
-                ae[i] = mfma_bf(pe[0], bp[2], ae[i]);
-                ae[i] = mfma_bf(pe[2], bp[0], ae[i]);
-                ae[i] = mfma_bf(pe[1], bp[1], ae[i]);
-                ae[i] = mfma_bf(pe[0], bp[1], ae[i]);
-                ae[i] = mfma_bf(pe[1], bp[0], ae[i]);
-                ae[i] = mfma_bf(pe[0], bp[0], ae[i]);
-                if (cc == 0) {
-                    ao[i] = mfma_bf(po[0], bp[2], ao[i]);
-                    ao[i] = mfma_bf(po[2], bp[0], ao[i]);
-                    ao[i] = mfma_bf(po[1], bp[1], ao[i]);
-                    ao[i] = mfma_bf(po[0], bp[1], ao[i]);
-                    ao[i] = mfma_bf(po[1], bp[0], ao[i]);
-                    ao[i] = mfma_bf(po[0], bp[0], ao[i]);
-                }
+                ae[i] = split_mm6(pe, bp, ae[i]);
+                if (cc == 0) ao[i] = split_mm6(po, bp, ao[i]);
             }
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -3280,6 +3275,46 @@ __global__ void k_selftest(const float* __restrict__ A, const float* __restrict_
     for (int r = 0; r < 4; ++r) D[(4 * g + r) * 16 + n] = c[r];
 }
 
+// split3 / join3 / split_mm6 on caller-chosen values (gtcrn_selftest_split3): element i -> its three bf16 planes (as
+// floats) and the re-joined value; and D (16x16) = A (16x32) * B (32x16) through the six-product helper from operands
+// split ON THE DEVICE, with the lane maps of the dense 3x3 (A fragment: row n, k = 8g..8g+7; B: column n, k = 8g..8g+7).
+__global__ void k_selftest_split3(const float* __restrict__ x, long n, float* __restrict__ planes,
+                                  float* __restrict__ joined, const float* __restrict__ A,
+                                  const float* __restrict__ Bm, float* __restrict__ D) {
+    for (long i = 4L * (blockIdx.x * blockDim.x + threadIdx.x); i < n; i += 4L * gridDim.x * blockDim.x) {
+        const f32x4 v = ld4(x + i);
+        const Split3 s = split3(v);
+        const f32x4 j = join3(s.h, s.m, s.l);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            planes[i + e] = (float)s.h[e];
+            planes[n + i + e] = (float)s.m[e];
+            planes[2 * n + i + e] = (float)s.l[e];
+        }
+        st4(joined + i, j);
+    }
+    if (blockIdx.x == 0 && threadIdx.x < 64 && A) {
+        const int lane = threadIdx.x, nn = lane & 15, g = lane >> 4;
+        bf16x8 ap[3], bp[3];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const Split3 sa = split3(ld4(A + nn * 32 + 8 * g + 4 * h));
+            f32x4 bv;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) bv[e] = Bm[(8 * g + 4 * h + e) * 16 + nn];
+            const Split3 sb = split3(bv);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                ap[0][4 * h + e] = sa.h[e]; ap[1][4 * h + e] = sa.m[e]; ap[2][4 * h + e] = sa.l[e];
+                bp[0][4 * h + e] = sb.h[e]; bp[1][4 * h + e] = sb.m[e]; bp[2][4 * h + e] = sb.l[e];
+            }
+        }
+        const f32x4 c = split_mm6(ap, bp, splat(0.f));
+#pragma unroll
+        for (int r = 0; r < 4; ++r) D[(4 * g + r) * 16 + nn] = c[r];
+    }
+}
+
 }  // namespace gtk
 
 // ============================================================================== launchers
@@ -3530,6 +3565,13 @@ int launch_conv2d_causal(const float* x, const float* cache, const float* w, con
     const int grid = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
     hipLaunchKernelGGL(k_conv2d_causal, dim3(grid > 0 ? grid : 1), dim3(256), 0, s, x, cache, w, bias, y, cache_out, B,
                        Cin, Cout, T, F, kt, kf, dt, df, pf, groups, transposed, Fout);
+    GT_LAUNCH_CHECK();
+    return 0;
+}
+
+int launch_selftest_split3(const float* x, long n, float* planes, float* joined, const float* A, const float* Bm,
+                           float* D, hipStream_t s) {
+    hipLaunchKernelGGL(k_selftest_split3, dim3(64), dim3(256), 0, s, x, n, planes, joined, A, Bm, D);
     GT_LAUNCH_CHECK();
     return 0;
 }

@@ -168,8 +168,8 @@ def enhance_folder(noisy_dir, clean_dir, enh_dir, checkpoint, device=0, max_batc
     result = None
     try:
         result = _enhance_shard(noisy_dir, clean_dir, enh_dir, checkpoint, device, max_batch, rank, world, barrier)
-    except BaseException as e:                                       # noqa: BLE001 -- re-raised below, after the exchange
-        err = e
+    except Exception as e:           # re-raised below, after the exchange.  NOT BaseException: a KeyboardInterrupt or
+        err = e                      # SystemExit must leave at once instead of waiting in a collective first
     all_ok = err is None
     if world > 1:
         if agree is not None:

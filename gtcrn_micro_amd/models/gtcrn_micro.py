@@ -193,7 +193,13 @@ def load_blob_into(model, blob):
     sd = model.state_dict()
     new = {name: torch.from_numpy(blob[off:off + numel].copy()).view(sd[name].shape)
            for name, numel, off in _lib.param_table()}
-    model.load_state_dict(new, strict=False)
+    res = model.load_state_dict(new, strict=False)
+    # strict in everything but the counters the blob does not carry: a key or shape-table mismatch must not leave
+    # tensors silently unloaded
+    missing = [k for k in res.missing_keys if not k.endswith("num_batches_tracked")]
+    if missing or res.unexpected_keys:
+        raise KeyError(f"load_blob_into: the blob's tensor table does not match the module (missing {missing[:5]}, "
+                       f"unexpected {list(res.unexpected_keys)[:5]})")
     return model
 
 

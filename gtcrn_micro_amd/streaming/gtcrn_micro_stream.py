@@ -15,7 +15,9 @@ kernels per 16 ms frame for nothing.  So:
 * **export is lazy**: the returned caches are thin ``torch.Tensor`` subclasses over the
   caller's own storage whose contents are brought up to date the moment anything READS
   or WRITES them (any torch operation on them: indexing, ``.cpu()``, ``torch.equal``,
-  in-place edits, printing ...), or explicitly with ``sync_caches()``.  A caller that
+  in-place edits, printing, ``data_ptr()`` / ``__dlpack__`` / ``__cuda_array_interface__`` ...),
+  or explicitly with ``sync_caches()`` -- REQUIRED before a raw pointer obtained EARLIER (or
+  from the caller's original tensor objects) is read by foreign code.  A caller that
   keeps using its ORIGINAL tensor objects instead of the returned ones (legal: the
   reference mutates them in place) cannot be intercepted, so for that call pattern the
   export runs eagerly every frame (import is still skipped while they stay untouched).
@@ -27,10 +29,13 @@ import torch
 from .. import _lib
 from ..models.gtcrn_micro import GTCRNMicro
 
-# metadata a caller (or this module) may ask of a lazy cache without needing its contents
+# metadata a caller (or this module) may ask of a lazy cache without needing its contents.  NOT in the list, on
+# purpose: everything that hands out the memory itself -- ``data_ptr``, ``untyped_storage``, ``__cuda_array_interface__``,
+# ``__dlpack__`` -- so a caller that passes a returned cache's raw pointer to its own kernels reads current data.
 _META = {"shape", "dtype", "device", "layout", "requires_grad", "is_cuda", "ndim", "_version", "grad", "grad_fn",
-         "is_leaf", "names", "is_sparse", "is_quantized", "is_meta", "data_ptr", "size", "dim", "stride", "numel",
-         "is_contiguous", "storage_offset", "element_size", "nelement", "ndimension", "get_device", "__len__"}
+         "is_leaf", "names", "is_sparse", "is_quantized", "is_meta", "size", "dim", "stride", "numel",
+         "is_contiguous", "storage_offset", "element_size", "nelement", "ndimension", "get_device", "__len__",
+         "is_inference"}
 
 
 class _LazyCache(torch.Tensor):
@@ -42,6 +47,29 @@ class _LazyCache(torch.Tensor):
         w = torch.Tensor._make_subclass(_LazyCache, t, False)
         w._owner = owner
         return w
+
+    def __deepcopy__(self, memo):
+        """``copy.deepcopy`` of a returned cache: an ordinary tensor holding the current contents."""
+        owner = getattr(self, "_owner", None)
+        if owner is not None:
+            owner.sync_caches()
+        with torch._C.DisableTorchFunctionSubclass():
+            return self.as_subclass(torch.Tensor).clone()
+
+    def _current(self):
+        owner = getattr(self, "_owner", None)
+        if owner is not None:
+            owner.sync_caches()
+        with torch._C.DisableTorchFunctionSubclass():
+            return self.as_subclass(torch.Tensor)
+
+    # the zero-copy export protocols, spelled out (they hand the memory to foreign code)
+    def __dlpack__(self, *args, **kwargs):
+        return self._current().__dlpack__(*args, **kwargs)
+
+    @property
+    def __cuda_array_interface__(self):
+        return self._current().__cuda_array_interface__
 
     @classmethod
     def __torch_function__(cls, func, types, args=(), kwargs=None):
@@ -126,13 +154,26 @@ class StreamGTCRNMicro(GTCRNMicro):
         eng = self.engine(spec.device)
         flat = [conv_cache, tra_cache] + [tcn_cache[g][k] for g in range(2) for k in range(4)]
         self.forward_stats["calls"] += 1
+        with torch._C.DisableTorchFunctionSubclass():
+            untracked = any(t.is_inference() for t in flat)
+        if untracked:
+            # Caches created under torch.inference_mode() (infer.py runs in it) carry no version counter, so a caller's
+            # edit between two calls could not be seen: such caches take the plain route every frame -- import, step,
+            # export into the caller's own tensors, which are returned as they are (the reference's in-place contract).
+            return self._forward_eager(eng, spec, B, flat, conv_cache, tra_cache, tcn_cache)
         kind = self._match(flat)
         if kind and (self._bound["eng"] is not eng or self._bound["B"] != B):
             kind = 0
         if kind == 0:
-            # unknown or modified caches: whatever an earlier binding still owes its caller is written out first, then
+            # unknown or modified caches: whatever an earlier binding still owes its caller is written out first -- this
+            # module's own, and the binding of ANY OTHER StreamGTCRNMicro that handed these caches out (an A/B of two
+            # models, a hot swap via convert_to_stream mid-stream: their pending export is this call's input) -- then
             # the ring state is rebuilt from the caches received
             self.sync_caches()
+            for t in flat:
+                owner = getattr(t, "_owner", None) if isinstance(t, _LazyCache) else None
+                if owner is not None and owner is not self:
+                    owner.sync_caches()
             key = (spec.device.index, B)
             state = self._scratch.get(key)
             if state is None:
@@ -159,6 +200,22 @@ class StreamGTCRNMicro(GTCRNMicro):
             return out, conv_cache, tra_cache, tcn_cache
         lz = bd["lazy"]
         return out, lz[0], lz[1], [lz[2:6], lz[6:10]]
+
+    def _forward_eager(self, eng, spec, B, flat, conv_cache, tra_cache, tcn_cache):
+        """import -> step -> export on every call: for caches whose edits cannot be tracked (inference tensors)."""
+        self.sync_caches()                                   # an earlier (tracked) binding may still owe an export
+        self._bound = None
+        key = (spec.device.index, B)
+        state = self._scratch.get(key)
+        if state is None:
+            state = eng.new_state(B)
+            self._scratch[key] = state
+        eng.stream_import(state, flat[0], flat[1], [flat[2:6], flat[6:10]])
+        self.forward_stats["imports"] += 1
+        out = eng.stream_step(state, spec)
+        eng.stream_export(state, flat[0], flat[1], [flat[2:6], flat[6:10]])
+        self.forward_stats["exports"] += 1
+        return out, conv_cache, tra_cache, tcn_cache
 
     # ---- native streaming: state stays in the library's ring layout on the device ---------------
     def init_state(self, nstreams, device="cuda"):

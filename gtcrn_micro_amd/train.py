@@ -100,6 +100,28 @@ def broadcast_buffers(model, src=0):
     return n
 
 
+def broadcast_parameters(model, src=0):
+    """What DistributedDataParallel does when it wraps a module (train.py:88): every rank's parameters AND buffers are
+    overwritten with rank ``src``'s, so the replicas start identical whatever each process did before.  ONE message
+    when the model lives in the flat blob (44 938 floats + the 46 counters), tensor by tensor otherwise.  Returns the
+    floats on the wire."""
+    import torch.distributed as dist
+    m = model.module if hasattr(model, "module") else model
+    flat = getattr(m, "_flat", None)
+    if flat is not None and m._flat_ok(flat.device):
+        dist.broadcast(flat, src=src)
+        dist.broadcast(m._nbt_flat, src=src)
+        for k, (eng, _) in list(m._engines.items()):
+            m._engines[k] = (eng, None)    # the eval engines re-fold on next use
+        return int(flat.numel())
+    n = 0
+    with torch.no_grad():
+        for t in list(m.parameters()) + list(m.buffers()):
+            dist.broadcast(t.data, src=src)
+            n += t.numel() if t.dtype.is_floating_point else 0
+    return n
+
+
 def allreduce_gradients(model, world_size):
     """The one exchange step of data-parallel training (the reference gets it from DDP, train.py:87-88): average
     the gradients over the ranks as ONE contiguous message.  After a HIP backward the 248 ``.grad``s are views of
@@ -129,15 +151,47 @@ def allreduce_gradients(model, world_size):
     return flat.numel()
 
 
+def validate_step(model, loss_func, noisy, clean, window=None):
+    """Forward + HybridLoss + backward of one batch with NO lasting effect: no optimizer or scheduler step, the
+    BatchNorm running statistics and counters are put back, the gradients are cleared.  For callers that must find out
+    whether a train step FITS (workspace allocation, kernels) before committing to a collective step: replicas that
+    each ran a full local step first would apply different updates and start data-parallel training from different
+    weights.  Returns the loss."""
+    m = model.module if hasattr(model, "module") else model
+    win = window if window is not None else torch.hann_window(512, device=noisy.device)
+    saved = [b.detach().clone() for b in m.buffers()]
+    loss = loss_func(model(_lib.stft(noisy, win)), _lib.stft(clean, win))
+    loss.backward()
+    with torch.no_grad():
+        for b, v in zip(m.buffers(), saved):
+            b.copy_(v)
+    for p in m.parameters():
+        p.grad = None
+    return loss.detach()
+
+
 def train_step(model, optimizer, scheduler, loss_func, noisy, clean, clip_grad_norm_value=3.0, world_size=1,
-               window=None):
-    """One iteration of Trainer._train_epoch (train.py:244-288); returns (loss, grad_norm) as floats."""
+               window=None, stats=None):
+    """One iteration of Trainer._train_epoch (train.py:244-288); returns (loss, grad_norm) as floats.
+    stats (optional dict): device events around the exchange steps (buffer broadcast, gradient all-reduce) are
+    appended to stats["exchange_events"] as (start, end) pairs, so a caller can report what the collectives cost."""
     dev = noisy.device
     win = window if window is not None else torch.hann_window(512, device=dev)      # train.py:252 (Hann, not sqrt)
+    timed = stats is not None and world_size > 1 and dev.type == "cuda"
+
+    def exchange(fn):
+        if not timed:
+            return fn()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        fn()
+        b.record()
+        stats.setdefault("exchange_events", []).append((a, b))
+
     if world_size > 1 and model.training:
         # DDP semantics (broadcast_buffers=True): the buffers follow rank 0 at the start of every forward, so the
         # running statistics a rank holds are rank 0's of the previous step plus its own update of this step
-        broadcast_buffers(model)
+        exchange(lambda: broadcast_buffers(model))
     noisy_spec = _lib.stft(noisy, win)
     clean_spec = _lib.stft(clean, win)
     enhanced = model(noisy_spec)
@@ -145,7 +199,7 @@ def train_step(model, optimizer, scheduler, loss_func, noisy, clean, clip_grad_n
     optimizer.zero_grad()
     loss.backward()
     if world_size > 1:
-        allreduce_gradients(model, world_size)
+        exchange(lambda: allreduce_gradients(model, world_size))
     gn = torch.nn.utils.clip_grad_norm_(model.parameters(), clip_grad_norm_value)
     optimizer.step()
     if scheduler is not None:

@@ -187,6 +187,12 @@ long gtcrn_debug_stamps(gtcrn_model *m, int kernel, unsigned long long *h_dst, l
 /* Checks the MFMA f32 16x16x4 lane maps the kernels rely on (exact integer
  * data, asymmetric operands).  0 = as assumed. */
 int gtcrn_selftest_mfma(int device);
+/* The exact three-way bf16 split the dense 3x3 runs on (kernels.hip split3 / join3 / split_mm6), on caller-chosen
+ * values: h_x[n] (n a multiple of 4) -> h_planes[3][n] (hi, mid, lo as floats) and h_joined[n] (= h_x bit for bit
+ * wherever all three planes are normal numbers); optionally h_A (16x32, row major) * h_B (32x16) -> h_D (16x16)
+ * through the same six-product helper the kernels use, from operands split on the device.  Host pointers. */
+int gtcrn_selftest_split3(int device, const float *h_x, long n, float *h_planes, float *h_joined, const float *h_A,
+                          const float *h_B, float *h_D);
 /* HIP-event timing of every kernel launch (events recorded on the call's stream, no
  * synchronisation inside the timed region).  gtcrn_timing_enable(m,1) clears the record;
  * gtcrn_timing_read returns, for kernel idx in [0, gtcrn_timing_kernels()) -- every timed launch records which

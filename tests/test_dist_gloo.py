@@ -230,6 +230,83 @@ def test_running_statistics_follow_rank0_two_ranks(tmp_path):
     assert json.loads(line) == {"floats": 1348, "same": True, "params_untouched": True, "nbt": 1, "rv_unflat": 2.0}
 
 
+_DP_WORKER = r"""
+import os, sys, json
+sys.path.insert(0, sys.argv[1])
+import torch, torch.distributed as dist
+from gtcrn_micro_amd.sharding import init_distributed
+from gtcrn_micro_amd.train import allreduce_gradients, broadcast_buffers, broadcast_parameters
+from gtcrn_micro_amd.models.gtcrn_micro import GTCRNMicro
+rank, local_rank, world = init_distributed("gloo")
+torch.manual_seed(500 + rank)          # DIFFERENT initial weights per rank: whatever happened before the dp steps
+m = GTCRNMicro()
+m._flatten(torch.device("cpu"))
+def everything():
+    return torch.cat([t.detach().reshape(-1).double() for t in list(m.parameters()) + list(m.buffers())])
+def same_on_all_ranks(v):
+    both = [torch.zeros_like(v) for _ in range(world)]
+    dist.all_gather(both, v)
+    return bool(torch.equal(both[0], both[1]))
+differ_before = not same_on_all_ranks(everything())
+n = broadcast_parameters(m)            # DDP's construction-time broadcast (train.py:88)
+equal_after_broadcast = same_on_all_ranks(everything())
+opt = torch.optim.Adam(m.parameters(), lr=1e-3)
+g = torch.Generator().manual_seed(900 + rank)
+equal_after_steps = True
+for step in range(3):                  # the dp step of train_step() with the HIP backward replaced by rank-specific
+    with torch.no_grad():              # gradients (and rank-specific running statistics from the local batches)
+        for name, b in m.named_buffers():
+            if name.endswith("running_mean") or name.endswith("running_var"):
+                b.add_(torch.randn(b.shape, generator=g) * 0.01)
+    broadcast_buffers(m)
+    blob = torch.randn(44938, generator=g)
+    m._grad_flat = blob
+    for p, (off, numel, shape) in zip(m._train_params, m._train_slices):
+        p.grad = blob[off:off + numel].view(shape)
+    allreduce_gradients(m, world)
+    torch.nn.utils.clip_grad_norm_(m.parameters(), 3.0)
+    opt.step()
+    equal_after_steps = equal_after_steps and same_on_all_ranks(everything())
+adam = torch.cat([st["exp_avg"].reshape(-1).double() for st in opt.state.values()])
+adam_equal = same_on_all_ranks(adam)
+# a model whose tensors are NOT views of a flat blob takes the tensor-by-tensor path
+torch.manual_seed(700 + rank)
+m2 = GTCRNMicro()
+broadcast_parameters(m2)
+v2 = torch.cat([t.detach().reshape(-1).double() for t in list(m2.parameters()) + list(m2.buffers())])
+unflat_equal = same_on_all_ranks(v2)
+dist.barrier()
+if rank == 0:
+    print(json.dumps({"differ_before": differ_before, "floats": n, "equal_after_broadcast": equal_after_broadcast,
+                      "equal_after_steps": equal_after_steps, "adam_equal": adam_equal, "unflat_equal": unflat_equal}))
+dist.destroy_process_group()
+"""
+
+
+def test_replicas_stay_bit_equal_through_data_parallel_steps(tmp_path):
+    """The dp semantics the train leg claims: replicas that start from DIFFERENT weights are made identical by the
+    construction-time broadcast (DDP, train.py:88), and stay identical -- parameters, running statistics, Adam
+    moments, bit for bit -- through steps of buffer broadcast -> rank-specific gradients -> ONE all-reduce -> clip ->
+    Adam.  (bench.py's train leg used to run a full LOCAL step per rank before the dp steps: the replicas diverged.)"""
+    w = tmp_path / "dp_worker.py"
+    w.write_text(_DP_WORKER)
+    r = _torchrun([str(w), ROOT])
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+    assert json.loads(line) == {"differ_before": True, "floats": 44938, "equal_after_broadcast": True,
+                                "equal_after_steps": True, "adam_equal": True, "unflat_equal": True}
+
+
+def test_train_leg_prepare_has_no_optimizer_step():
+    """bench.py's train_prepare validates the allocations with validate_step (forward + backward, state restored), never
+    with a full train_step: a local optimizer step per rank is what made the replicas diverge."""
+    import ast
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    fn = next(n for n in ast.walk(ast.parse(src)) if isinstance(n, ast.FunctionDef) and n.name == "train_prepare")
+    called = {c.func.id for c in ast.walk(fn) if isinstance(c, ast.Call) and isinstance(c.func, ast.Name)}
+    assert "validate_step" in called and "train_step" not in called
+
+
 def test_secondary_leg_failing_on_one_rank_does_not_hang_or_lose_the_line():
     """Rank 1 raises inside a secondary leg before any collective: the leg reports the error per rank, the legs before
     and after it complete (priced with the slower rank's time) and the headline is intact."""
@@ -244,10 +321,11 @@ def test_secondary_leg_failing_on_one_rank_does_not_hang_or_lose_the_line():
 
 def test_secondary_leg_hanging_on_one_rank_is_cut_by_the_watchdog():
     """Rank 1 never returns from a secondary leg (the shape of a rank stuck in, or dead before, a collective): after the
-    leg's time limit rank 0 prints the line as it stands -- headline and the finished leg -- and every rank exits."""
+    leg's time limit rank 0 prints the line as it stands -- headline and the finished leg -- and every rank exits with a
+    non-zero status (a watchdog on a process that may hold the GPU must not report success; no re-exec)."""
     r = _torchrun([os.path.join(ROOT, "bench.py")] + _BENCH_ARGS, timeout=120,
                   extra_env=dict(_SHIM_ENV, GTCRN_BENCH_TEST_LEGS="hang1"))
-    assert r.returncode == 0, r.stderr[-2000:]
+    assert r.returncode != 0            # a rank hung: the line is kept, but the launcher / driver see a FAILED run
     d = _check_bench_line(r.stdout, 3, 1)
     assert "timed out after 6 s" in d["secondary_errors"]["second"]
     assert d["first"]["ms"] == 20.0 and "third" not in d

@@ -4,7 +4,7 @@ bit-exact for framing/indexing."""
 import numpy as np
 import pytest
 
-from conftest import golden, load_params, rel_err
+from conftest import REG, REG_STAGE, check_parity, golden, load_params, rel_err
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-4
@@ -97,6 +97,8 @@ def test_forward_every_stage_vs_golden(dev, engines, tag):
     errs["out"] = rel_err(out, g["spec_enh"])
     bad = {k: v for k, v in errs.items() if not v < TOL}
     assert not bad, errs
+    bad = {k: v for k, v in errs.items() if not v < (REG if k == "out" else REG_STAGE)}     # regression guard
+    assert not bad, errs
 
 
 def test_forward_batch_and_wave(dev, engines):
@@ -104,10 +106,10 @@ def test_forward_batch_and_wave(dev, engines):
     g = golden("offline_dns3_B3_T12.npz")
     eng = engines["dns3"]
     out = eng.forward_spec(cu(g["spec"]))
-    assert rel_err(out.cpu().numpy(), g["spec_enh"]) < TOL
+    check_parity(out.cpu().numpy(), g["spec_enh"], "B=3 spec")
     win = cu(G.make_window(0))
     y = eng.forward_wave(cu(g["wave"]), win).cpu().numpy()
-    assert rel_err(y, g["wave_out"]) < TOL
+    check_parity(y, g["wave_out"], "B=3 wave")
     # non-contiguous (frame-major) input and output views
     fm_in = cu(np.transpose(g["spec"], (0, 2, 1, 3)).copy()).permute(0, 2, 1, 3)
     fm_out = torch.empty((3, 12, 257, 2), device="cuda").permute(0, 2, 1, 3)
@@ -121,7 +123,7 @@ def test_forward_lengths_vs_oracle(dev, engines, oracles, T):
     spec = (rng.standard_normal((2, 257, T, 2)) * 0.5).astype(np.float32)
     got = engines["rand"].forward_spec(cu(spec)).cpu().numpy()
     want = oracles["rand"].forward(spec)
-    assert rel_err(got, want) < TOL
+    check_parity(got, want, f"T={T}")
 
 
 def test_reference_example_pair(dev, engines):
@@ -144,7 +146,8 @@ def test_reference_causality_test(dev, engines):
     y2 = eng.forward_wave(cu(g["x2"]), win).cpu().numpy()[0]
     assert np.abs(y1[:16000 - 512] - y2[:16000 - 512]).max() == 0.0
     assert np.abs(y1[16000:] - y2[16000:]).max() > 0
-    assert rel_err(y1, g["y1"]) < TOL and rel_err(y2, g["y2"]) < TOL
+    check_parity(y1, g["y1"], "causality y1")
+    check_parity(y2, g["y2"], "causality y2")
 
 
 def test_module_mirror_forward(dev):
@@ -161,14 +164,14 @@ def test_module_mirror_forward(dev):
     m = m.to("cuda")
     with torch.inference_mode():
         out = m(cu(g["spec"]))
-    assert rel_err(out.cpu().numpy(), g["spec_enh"]) < TOL
+    check_parity(out.cpu().numpy(), g["spec_enh"], "module forward")
     # infer.py usage: stft(...)[None] -> model -> [0] -> view_as_complex -> istft
     import gtcrn_micro_amd as G
     win = torch.hann_window(512).pow(0.5).cuda()
     spec = G.stft(cu(g["wave"]), win)
     y = m(spec[None])[0]
     wav = G.istft(y, win)
-    assert rel_err(wav.cpu().numpy(), g["wave_out"]) < TOL
+    check_parity(wav.cpu().numpy(), g["wave_out"], "module wave")
 
 
 def test_full_size_batch_invariance(dev, engines):
@@ -200,7 +203,7 @@ def test_no_dependence_on_stale_memory(dev, engines, oracles):
         spec = (rng.standard_normal((3, 257, T, 2)) * 0.5).astype(np.float32)
         got = eng.forward_spec(cu(spec)).cpu().numpy()
         assert np.isfinite(got).all(), T
-        assert rel_err(got, oracles["rand"].forward(spec)) < TOL, T
+        check_parity(got, oracles["rand"].forward(spec), f"T={T} after poison")
 
 
 def test_extreme_inputs_stay_finite_and_match_oracle(dev, engines, oracles):
@@ -246,4 +249,4 @@ def test_parity_per_band_and_elementwise(engines, oracles, tag):
           f"bin rms): {100 * frac:.3f} % / {100 * frac6:.3f} %")
     assert worst_band < TOL, worst_band
     assert frac >= 0.995, frac
-    assert rel_err(got, ref) < TOL
+    check_parity(got, ref, "tilted spectrum")

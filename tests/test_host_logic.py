@@ -513,3 +513,60 @@ def test_stream_mirror_cache_binding_logic_without_a_gpu(monkeypatch):
     # (4) wrong cache shapes raise the reference's AssertionError before anything runs
     with pytest.raises(AssertionError):
         sm2(x, c0[:, :, :, :4], t0, n0)
+    # (5) a raw pointer is a read: data_ptr() of a returned cache brings the memory up to date first (a caller that
+    #     hands the pointer to its own kernels must not see stale contents); so do __dlpack__ and deepcopy
+    import copy
+    sm3 = M.StreamGTCRNMicro().eval()
+    eng.log.clear()
+    caches = list(sm3.init_caches(B, "cpu"))
+    own = caches[0]
+    for t in range(3):
+        y, caches[0], caches[1], caches[2] = sm3(x, caches[0], caches[1], caches[2])
+    assert eng.log[-1] == "step" and float(own.as_subclass(torch.Tensor)[0, 0, 0, 0, 0]) == 1.0    # stale: export pending
+    ptr = caches[0].data_ptr()
+    assert eng.log[-1] == "export" and ptr == own.data_ptr() and float(own[0, 0, 0, 0, 0]) == 3.0
+    y, caches[0], caches[1], caches[2] = sm3(x, caches[0], caches[1], caches[2])
+    dup = copy.deepcopy(caches[0])
+    assert type(dup) is torch.Tensor and float(dup[0, 0, 0, 0, 0]) == 4.0 and dup.data_ptr() != ptr
+    y, caches[0], caches[1], caches[2] = sm3(x, caches[0], caches[1], caches[2])
+    assert eng.log[-1] == "step"
+    torch.from_dlpack(caches[1])                                                      # calls caches[1].__dlpack__()
+    assert eng.log[-1] == "export"
+    # (6) caches created under torch.inference_mode() (infer.py runs in it) track no version counter: the plain route,
+    #     import -> step -> export on every call, the caller's own tensors returned; edits are always seen
+    sm4 = M.StreamGTCRNMicro().eval()
+    eng.log.clear()
+    with torch.inference_mode():
+        ci, ti, ni = sm4.init_caches(B, "cpu")
+        assert ci.is_inference()
+        for t in range(3):
+            y, ci2, ti2, ni2 = sm4(x, ci, ti, ni)
+            assert ci2 is ci and type(ci2) is torch.Tensor and float(ci[0, 0, 0, 0, 0]) == t + 1.0
+        ci[0, 0, 0, 0, 0] = 40.0
+        sm4(x, ci, ti, ni)
+        assert float(ci[0, 0, 0, 0, 0]) == 41.0
+    assert eng.log == ["import", "step", "export"] * 4
+    # ... while ordinary caches handed through inference_mode keep the fast path, edits included
+    sm5 = M.StreamGTCRNMicro().eval()
+    eng.log.clear()
+    caches = list(sm5.init_caches(B, "cpu"))
+    with torch.inference_mode():
+        for t in range(4):
+            y, caches[0], caches[1], caches[2] = sm5(x, caches[0], caches[1], caches[2])
+        assert eng.log == ["import", "step", "export", "step", "step", "step"]
+        caches[0][0, 0, 0, 0, 0] = 7.0
+        y, caches[0], caches[1], caches[2] = sm5(x, caches[0], caches[1], caches[2])
+        assert eng.log[-4:] == ["export", "import", "step", "export"] and float(caches[0][0, 0, 0, 0, 0]) == 8.0
+    # (7) hand-over between two models (an A/B, a hot swap via convert_to_stream mid-stream): model B receives the
+    #     lazy caches model A handed out with A's export still pending -- A must write them out before B imports
+    smA, smB = M.StreamGTCRNMicro().eval(), M.StreamGTCRNMicro().eval()
+    eng.log.clear()
+    caches = list(smA.init_caches(B, "cpu"))
+    for t in range(4):
+        y, caches[0], caches[1], caches[2] = smA(x, caches[0], caches[1], caches[2])
+    assert eng.log[-1] == "step"                                                      # A owes an export
+    y, caches[0], caches[1], caches[2] = smB(x, caches[0], caches[1], caches[2])
+    assert eng.log[-4:] == ["export", "import", "step", "export"]
+    assert float(caches[0][0, 0, 0, 0, 0]) == 5.0                                     # 4 frames in A + 1 in B
+    y, caches[0], caches[1], caches[2] = smA(x, caches[0], caches[1], caches[2])      # and back again
+    assert float(caches[0][0, 0, 0, 0, 0]) == 6.0
