@@ -466,7 +466,9 @@ class Engine:
 
     # ---- test / measurement hooks ------------------------------------------------------------
     def debug_enable(self, on=True):
-        _check(lib().gtcrn_debug_enable(self._h, int(bool(on))))
+        """True / 1: stage taps (and phase stamps in the diagnostic build); 2: phase stamps only (single-frame streaming
+        steps keep their one-launch form)."""
+        _check(lib().gtcrn_debug_enable(self._h, 2 if on == 2 else int(bool(on))))
 
     def tap(self, name, b, T):
         F = {"en0": 65, "de3": 65}.get(name, 33)

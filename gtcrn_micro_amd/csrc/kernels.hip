@@ -2313,7 +2313,9 @@ constexpr int DEC_MS_LDS_FLOATS = DecLds<MS_ROWS, MS_STREAMS, true>::FLOATS;
 // MS: multi-stream single-frame mode, see k_encoder (NB = number of streams; the host remaps the strides).
 // Q / qin / qout: the int8-weight / fp16-activation variant and its optional int8 boundary (see k_encoder); qout is
 // the step of the output quantiser (y = (y_q - zero) * out_scale, tflite_infer.py:88-91).
-template <bool DBG, int TPW, bool MS, bool Q>
+// TAIL = false (offline calls): the kernel stops behind the last GTConv block and hands its output (+ en_outs[1]) to
+// k_back through `xtail` -- everything after it has no dependence across frames (see k_back).
+template <bool DBG, int TPW, bool MS, bool Q, bool TAIL = true>
 __global__ __launch_bounds__(NTHR) void k_decoder(const float* __restrict__ xg, const float* __restrict__ en0,
                                                  const float* __restrict__ en1, const float* __restrict__ en2,
                                                  const float* __restrict__ en3, const float* __restrict__ en4,
@@ -2322,9 +2324,10 @@ __global__ __launch_bounds__(NTHR) void k_decoder(const float* __restrict__ xg, 
                                                  const int* __restrict__ lens, int NB, float qin, float qout,
                                                  const float* __restrict__ PF, const int* __restrict__ PI,
                                                  float* __restrict__ state, float* __restrict__ dbg,
-                                                 unsigned long long* __restrict__ stamps) {
+                                                 unsigned long long* __restrict__ stamps, float* __restrict__ xtail) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     STAMP_INIT(SS)
+    static_assert(TAIL || (!MS && !Q), "the split form serves offline fp32 calls");
     constexpr int RW = MS ? MS_ROWS : TC;
     constexpr int NS = MS ? MS_STREAMS : 1;
     using LD = DecLds<RW, NS, MS>;
@@ -2372,10 +2375,15 @@ __global__ __launch_bounds__(NTHR) void k_decoder(const float* __restrict__ xg, 
     };
     dense_fetch(0);
     constexpr bool SPLIT3 = SPLIT && kSplitDe3;     // de_convs.3 in the split form too
-    copy_dec_params<SPLIT3>(sP, PF, tid, NTHR);
+    if constexpr (TAIL) {
+        copy_dec_params<SPLIT3>(sP, PF, tid, NTHR);
+        for (int f = tid; f < NBINS; f += NTHR) st4(sBS + f * 4, ld4(PF + P_DEC + D_BS_TAB + f * 4));
+        if (tid < 4) sM[2 * RW * F0 + tid] = 0.f;
+    } else {                                        // the three blocks only
+#pragma unroll
+        for (int j = 0; j < 3; ++j) copy_params(sP + j * GB_SIZE, PF + P_DEC + D_BLK + j * GBD_SIZE, GB_SIZE, tid, NTHR);
+    }
     if (tid < 48) sI[tid] = PI[I_DEC_BLK + tid];
-    for (int f = tid; f < NBINS; f += NTHR) st4(sBS + f * 4, ld4(PF + P_DEC + D_BS_TAB + f * 4));
-    if (tid < 4) sM[2 * RW * F0 + tid] = 0.f;
     float* stb = state ? state + (long)b * NS * ST_FLOATS : nullptr;    // first stream of this workgroup
     const int nlive = MS ? min(NS, NB - b * NS) : 1;
     int tbase = 0;
@@ -2388,6 +2396,9 @@ __global__ __launch_bounds__(NTHR) void k_decoder(const float* __restrict__ xg, 
     }
     const Tiles<TPW> tt = make_tiles<TPW>(L);
     wg_barrier_vm();
+    // TAIL = false: region A is only ever W, so block 0's history of the first chunk goes into image rows 0, 1 here and
+    // block 2 prepares the next chunk's (as in the offline encoder)
+    if constexpr (!TAIL) ring_to_image<RS, LD::PT, SPLIT ? IMG_SPLIT3 : IMG_F32>(sW, sH, tid);
 
     const long ob = (long)b * T;
     const long nbt = (long)gridDim.x * T;
@@ -2446,8 +2457,8 @@ __global__ __launch_bounds__(NTHR) void k_decoder(const float* __restrict__ xg, 
             c.gA = sP + DL_DN;
             c.ib = sI + j * 16;
             c.sW = sW; c.sHk = sH + j * RING_DENSE; c.sS = sS; c.sG = sG; c.sEHk = sEH + j * 16;
-            c.sHtop = j == 0 ? sH : nullptr;          // region A was Z / m in the previous chunk
-            c.sHnext = j < 2 ? sH + (j + 1) * RING_DENSE : nullptr;
+            c.sHtop = (TAIL && j == 0) ? sH : nullptr;          // region A was Z / m in the previous chunk
+            c.sHnext = j < 2 ? sH + (j + 1) * RING_DENSE : (TAIL ? nullptr : sH);
             c.sE = smem + LD::E;
             c.sY = sG + RW * 16;
             c.nfr = nfr; c.tabs = tbase + t0;
@@ -2476,6 +2487,23 @@ __global__ __launch_bounds__(NTHR) void k_decoder(const float* __restrict__ xg, 
         };
 #pragma unroll 1
         for (int j = 0; j < 2; ++j) run_block(j, [] {}, std::integral_constant<int, 0>{});
+        if constexpr (!TAIL) {
+            run_block(2, [] {}, std::integral_constant<int, 0>{});
+            // hand-off to k_back: this chunk's x (written once, read once: streaming stores), then the next chunk's input
+            using ht2 = typename HandOff<Q>::t;
+            ht2* xt = reinterpret_cast<ht2*>(xtail) + (ob + t0) * 528;
+#pragma unroll
+            for (int i = 0; i < TPW; ++i)
+                if (tt.pp(i) < npos) stx<Q>(xt + (unsigned)(tt.pp(i) * 16 + 4 * g), x[i]);
+            if (t0 + RW < T) {
+                const int npn = min(RW, T - t0 - RW) * 33;
+                const ht* xgn = xgh + (long)(t0 + RW) * 528;
+#pragma unroll
+                for (int i = 0; i < TPW; ++i) xn[i] = ldx<Q>(xgn + (unsigned)((tt.pp(i) < npn ? tt.pp(i) : 0) * 16 + 4 * g));
+            }
+            STAMP(SS, 9)
+            continue;
+        }
         run_block(2, [&] {
             const ht* en0c = en0h + (long)t0 * (F1 * 16);
 #pragma unroll
@@ -2682,6 +2710,212 @@ __global__ __launch_bounds__(NTHR) void k_decoder(const float* __restrict__ xg, 
     }
 }
 
+// =============================================================================== decoder tail (offline form)
+// Everything BEHIND the last GTConv block has no dependence across frames either: de_convs.3 (models/gtcrn_micro.py:
+// 405-462, ConvTranspose2d (1,5) stride (1,2), 33 -> 65), + en_outs[0], de_convs.4 (16 -> 2, 65 -> 129, Tanh), ERB.bs
+// (:69-73), the complex ratio mask (:478-482) and the output permute (:529-530).  Inside the lock-stepped per-utterance
+// decoder these phases were 35 % of its cycles -- five barrier-delimited latency chains per 16-frame chunk with most
+// threads idle in two of them (tools/phase_profile.py) -- so offline calls run them, like the front end, as a THROUGHPUT
+// kernel: ONE FRAME PER WAVE in 4.4 KB of wave-private LDS, no workgroup barrier after the prologue, persistent
+// workgroups of eight waves.  k_decoder<.., TAIL = false> keeps the three causal blocks and hands x = de2 + en_outs[1]
+// over in HBM (2 112 B per frame each way).  Price: a frame's 33 positions fill three MFMA tiles (48 slots).  Same source
+// expressions as the in-kernel tail (which the streaming forms keep), so every value is bit-identical.
+constexpr int BK_WAVES = 8;
+constexpr int BK_NT = BK_WAVES * 64;
+constexpr int BK_P = 0;                                           // DL_DE3M .. DL_DN of the decoder's LDS parameter layout
+constexpr int BK_BS = BK_P + (DL_DN - DL_DE3M);                   // per-bin ERB.bs table
+constexpr int BK_W0 = BK_BS + NBINS * 4;                          // wave-private regions start here
+constexpr int BK_WA = 0;                                          // x image [35 records][24] (pad columns 0, 34), then Z [67][12]
+constexpr int BK_WA_SZ = 35 * RS_WIDE > DEC_Z_ROW * DEC_ZS ? 35 * RS_WIDE : DEC_Z_ROW * DEC_ZS;
+constexpr int BK_WM = BK_WA + BK_WA_SZ;                           // mask m [2][129] (+4: the 2-tap read of the last bin)
+constexpr int BK_WSZ = BK_WM + ((2 * F0 + 4 + 3) & ~3);
+constexpr int BK_LDS_FLOATS = BK_W0 + BK_WAVES * BK_WSZ;
+static_assert(BK_BS % 4 == 0 && BK_W0 % 4 == 0 && BK_WM % 4 == 0 && BK_WSZ % 4 == 0, "16B carve");
+static_assert(BK_LDS_FLOATS * 4 * 2 <= 160 * 1024, "two tail workgroups per CU");
+
+template <bool DBG, bool Q>
+__global__ __launch_bounds__(BK_NT, 4) void k_back(const float* __restrict__ xd, const float* __restrict__ en0,
+                                               const float* __restrict__ spec, long sb, long sf, long st,
+                                               float* __restrict__ out, long osb, long osf, long ost, int B, int T,
+                                               const int* __restrict__ lens, float qin, float qout,
+                                               const float* __restrict__ PF, float* __restrict__ dbg) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr bool SPLIT3 = !Q && kSplitDense && kSplitDe3;
+    constexpr int RS = RS_WIDE, ZS = DEC_ZS;
+    float* sPk = smem + BK_P;
+    const float* sP = sPk - DL_DE3M;           // indexed with the DL_* / dl() offsets of the decoder's LDS layout
+    float* sBS = smem + BK_BS;
+    const int tid = threadIdx.x, lane = tid & 63, n = lane & 15, g = lane >> 4;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    float* mine = smem + BK_W0 + wv * BK_WSZ;
+    float* sW = mine + BK_WA;
+    float* sZ = mine + BK_WA;
+    float* sM = mine + BK_WM;
+    if constexpr (SPLIT3) copy_params(sPk, PF + P_DEC + D_DE3_16, DE3_16_MATS * 256, tid, BK_NT);
+    else copy_params(sPk, PF + P_DEC + D_DE3_AE, 5 * 256, tid, BK_NT);
+    copy_params(sPk + (DL_DE - DL_DE3M), PF + P_DEC + D_DE3_B, D_BS_W - D_DE3_B, tid, BK_NT);
+    for (int f = tid; f < NBINS; f += BK_NT) st4(sBS + f * 4, ld4(PF + P_DEC + D_BS_TAB + f * 4));
+    if (lane < 4) sM[2 * F0 + lane] = 0.f;
+    // pad columns 0 and 34 of the x image: written once, the frames only ever write columns 1..33 -- but the region is
+    // also Z, so they are re-zeroed per frame below
+    __syncthreads();          // the only workgroup barrier: from here on every wave works on its own frames
+    const long nframes = (long)B * T, stride = (long)gridDim.x * BK_WAVES;
+    const long nbt = nframes;
+    using ht = typename HandOff<Q>::t;
+    const ht* xdh = reinterpret_cast<const ht*>(xd);
+    const ht* en0h = reinterpret_cast<const ht*>(en0);
+    const int sf32 = (int)sf, osf32 = (int)osf;
+    // the lane's three positions of the frame (33 positions = 3 tiles, the last one holds a single valid position)
+    int ffv[3];
+    bool pv[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const int p = i * 16 + n;
+        pv[i] = p < 33;
+        ffv[i] = pv[i] ? p : 32;
+    }
+    constexpr int MASK_ITEMS = (NBINS + 63) / 64;                  // bins per lane: 5 (the last round holds bin 256 only)
+    for (long fr = (long)blockIdx.x * BK_WAVES + wv; fr < nframes; fr += stride) {
+        const int b = (int)(fr / T), t = (int)(fr - (long)b * T);
+        if (lens && t > (lens[b] >> 8)) continue;                   // variable-length batch: past this utterance's end
+        // (four waves per SIMD hide the load latencies; every load sits where its registers are live shortest -- a
+        // whole-frame prefetch at the top spilled at the 128-register budget of that occupancy)
+        f32x4 x[3];
+        const ht* xf = xdh + fr * 528;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) x[i] = ldx<Q>(xf + (unsigned)(ffv[i] * 16 + 4 * g));
+        // ---- de_convs.3: gather form; the frame's x as an image in LDS (pad columns zero)
+        int rec3[3];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            rec3[i] = (1 + ffv[i]) * RS;
+            if (pv[i]) {
+                if constexpr (SPLIT3) st_split(sW, rec3[i], g, x[i]);
+                else st4(sW + rec3[i] + 4 * g, x[i]);
+            }
+        }
+        if (lane < 12) st4(sW + (lane >= 6 ? 34 : 0) * RS + 4 * (lane >= 6 ? lane - 6 : lane), splat(0.f));
+        wave_lds_sync();
+        f32x4 ze[3], zo[3];
+        {
+            const f32x4 Bv = ld4(sP + dl(D_DE3_B) + 4 * g);
+            const float a = sP[dl(D_DE3_S)] - 1.0f;
+            f32x4 ae[3], ao[3];
+            de_conv3_tiles<3, SPLIT3, Q, RS>(sW, rec3, x, sP + DL_DE3M, Bv, n, g, ae, ao);
+            // en_outs[0] for the even / odd output bins (requested behind the de_convs.3 products: their registers
+            // are free again; the activation arithmetic below runs while the loads are in flight)
+            f32x4 s0e[3], s0o[3];
+            const ht* e0f = en0h + fr * (F1 * 16);
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                const unsigned o0 = (unsigned)((2 * ffv[i]) * 16 + 4 * g);
+                s0e[i] = ldx<Q>(e0f + o0);
+                s0o[i] = ldx<Q>(e0f + o0 + (ffv[i] < 32 ? 16u : 0u));
+            }
+            const f32x4 A4 = ld4(sP + dl(D_DE4_A) + arow(n, g));
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                ae[i] = rq<Q>(prelu4(ae[i], a));
+                ao[i] = rq<Q>(prelu4(ao[i], a));
+                if (DBG && pv[i]) {
+                    float* d3 = dbg + 3 * nbt * 528 + (fr * F1) * 16 + 4 * g;
+                    st4(d3 + (2 * ffv[i]) * 16, ae[i]);
+                    if (ffv[i] < 32) st4(d3 + (2 * ffv[i] + 1) * 16, ao[i]);
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                // + en_outs[0] (identity slot order), then de_convs.4 in scatter form
+                const f32x4 e2 = rq<Q>(ae[i] + s0e[i]);
+                const f32x4 o2 = rq<Q>(ao[i] + s0o[i]);
+                ze[i] = mm1<Q>(A4, e2, splat(0.f));
+                zo[i] = mm1<Q>(A4, o2, splat(0.f));
+            }
+        }
+        wave_lds_sync();      // all taps of the image read: the region becomes Z [67][12]
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            if (g < 3 && pv[i]) {
+                st4(sZ + (1 + 2 * ffv[i]) * ZS + 4 * g, ze[i]);
+                if (ffv[i] < 32) st4(sZ + (2 + 2 * ffv[i]) * ZS + 4 * g, zo[i]);
+            }
+        }
+        if (lane < 8 && (lane & 3) < 3) st4(sZ + ((lane >> 2) * (DEC_Z_ROW - 1)) * ZS + 4 * (lane & 3), splat(0.f));
+        // the input spectrogram for the mask: in flight during the gather below
+        float2 spv[MASK_ITEMS];
+        const float* sbase = spec + (long)b * sb + (long)t * st;
+#pragma unroll
+        for (int q = 0; q < MASK_ITEMS; ++q) {
+            const int f = lane + 64 * q;
+            spv[q] = *reinterpret_cast<const float2*>(sbase + (f < NBINS ? f * sf32 : 0));
+        }
+        wave_lds_sync();
+        // ---- de_convs.4 gather + BN + Tanh: m[o][f''] = tanh(b[o] + sum_k z[(f''+2-k)/2][o*5+k]) (see k_decoder)
+#pragma unroll
+        for (int q = 0; q < (2 * F0 + 63) / 64; ++q) {
+            const int c = lane + 64 * q;
+            if (c < 2 * F0) {
+                const int o = c >= F0 ? 1 : 0, fq = c - o * F0;
+                const int par = fq & 1, m = fq >> 1;
+                const float* zr = sZ + (1 + m) * ZS;
+                const float* r1 = zr + ZS + o * 5 + par;
+                const float* r2 = zr + o * 5 + 2 + par;
+                const float* r3 = zr - ZS + (par ? 10 : o * 5 + 4);
+                const float bias = sP[dl(D_DE4_B) + o];
+                const float sum = bias + r1[0] + r2[0] + r3[0];
+                sM[o * F0 + fq] = rq1<Q>(fast_tanh(sum));
+            }
+        }
+        wave_lds_sync();
+        if (DBG)
+            for (int c = lane; c < 2 * F0; c += 64) {
+                const int o = c >= F0 ? 1 : 0, fq = c - o * F0;
+                dbg[3 * nbt * 528 + nbt * F1 * 16 + (((long)b * 2 + o) * T + t) * F0 + fq] = sM[o * F0 + fq];
+            }
+        // ---- ERB.bs + complex ratio mask + output layout
+        {
+            float* obase = out + (long)b * osb + (long)t * ost;
+            f32x4 tb[MASK_ITEMS];
+#pragma unroll
+            for (int q = 0; q < MASK_ITEMS; ++q) {
+                const int f = lane + 64 * q;
+                tb[q] = ld4(sBS + (f < NBINS ? f : 0) * 4);
+            }
+            float a0[MASK_ITEMS], a1[MASK_ITEMS], b0[MASK_ITEMS], b1[MASK_ITEMS];
+#pragma unroll
+            for (int q = 0; q < MASK_ITEMS; ++q) {
+                const float* mp = sM + __float_as_int(tb[q][0]);
+                a0[q] = mp[0]; a1[q] = mp[1]; b0[q] = mp[F0]; b1[q] = mp[F0 + 1];
+            }
+#pragma unroll
+            for (int q = 0; q < MASK_ITEMS; ++q) {
+                const int f = lane + 64 * q;
+                const bool two = tb[q][2] != 0.f;
+                const float mr = rq1<Q>(tb[q][1] * a0[q] + (two ? tb[q][2] * a1[q] : 0.f));
+                const float mi = rq1<Q>(tb[q][1] * b0[q] + (two ? tb[q][2] * b1[q] : 0.f));
+                float re = spv[q].x, im = spv[q].y;
+                if constexpr (Q) {
+                    if (qin > 0.f) {
+                        re = fminf(fmaxf(rintf(re / qin), -128.f), 127.f) * qin;
+                        im = fminf(fmaxf(rintf(im / qin), -128.f), 127.f) * qin;
+                    }
+                    re = rq1<Q>(re);
+                    im = rq1<Q>(im);
+                }
+                float yr = rq1<Q>(re * mr - im * mi), yi = rq1<Q>(im * mr + re * mi);
+                if constexpr (Q) {
+                    if (qout > 0.f) {
+                        yr = fminf(fmaxf(rintf(yr / qout), -128.f), 127.f) * qout;
+                        yi = fminf(fmaxf(rintf(yi / qout), -128.f), 127.f) * qout;
+                    }
+                }
+                if (f < NBINS) *reinterpret_cast<float2*>(obase + f * osf32) = make_float2(yr, yi);
+            }
+        }
+        wave_lds_sync();      // every region is rewritten by the next frame
+    }
+}
+
 // =============================================================================== streaming step, ONE launch
 // StreamGTCRNMicro.forward for N streams x one new frame (gtcrn_micro_stream.py:541-574, the loop :626-635) as a
 // SINGLE kernel: in multi-stream mode a workgroup's four streams never leave it between encoder, GTCN and decoder, so
@@ -2735,11 +2969,15 @@ struct SmLds {
 };
 constexpr int SM_LDS_FLOATS = SmLds::FLOATS;
 
+// (diagnostic build: phase stamps 0 prologue .. first barrier, 1 ERB bands, 2 SFE, 3 en_conv0, 4 en_conv1; encoder blocks
+// 10 pc1 / 11 depth + pc2 / 12 TRALite, 8 after a block; 9 both GTCN stacks; 13 decoder set-up; decoder blocks 5 / 6 / 7;
+// 14 de_convs.3/4 .. tanh, 15 mask + epilogue)
 __global__ __launch_bounds__(NTHR) void k_stream_ms(const float* __restrict__ spec, long sb, long sf,
                                                    float* __restrict__ out, long osb, long osf, int NB,
                                                    const float* __restrict__ PF, const int* __restrict__ PI,
-                                                   float* __restrict__ state) {
+                                                   float* __restrict__ state, unsigned long long* __restrict__ stamps) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
+    STAMP_INIT(SS)
     using LD = SmLds;
     constexpr int RW = LD::RW, NS = LD::NS;
     constexpr bool SPLIT = kSplitDense;
@@ -2878,6 +3116,7 @@ __global__ __launch_bounds__(NTHR) void k_stream_ms(const float* __restrict__ sp
         }
     }
     wg_barrier_vm();                                               // (also: parameters, tables and the dense planes are in LDS)
+    STAMP(SS, 0)
     {   // A: ERB.bm bands
         const int band = tid & (ERB_BANDS - 1);
         const int lo = sI[I_ERB_LO + band], cnt = sI[I_ERB_N + band];
@@ -2900,6 +3139,7 @@ __global__ __launch_bounds__(NTHR) void k_stream_ms(const float* __restrict__ sp
         }
     }
     wg_barrier();
+    STAMP(SS, 1)
     // B: SFE_Lite
     for (int rw = L.wave; rw < 3 * RW; rw += NW) {
         const int tl = rw % RW, c = rw / RW;
@@ -2917,6 +3157,7 @@ __global__ __launch_bounds__(NTHR) void k_stream_ms(const float* __restrict__ sp
         st4(sE0 + pl(r * ENC_E0_ROW + (cc < 2 ? cc : 65 + cc), gg), splat(0.f));
     }
     wg_barrier();
+    STAMP(SS, 2)
     {   // C: en_convs.0; en0 stays in LDS for the decoder tail
         const f32x4 A = ld4(sPE + E_EN0_A + arow(n, g)), Bv = ld4(sPE + E_EN0_B + 4 * g);
         const float a = sPE[E_EN0_S] - 1.0f;
@@ -2942,6 +3183,7 @@ __global__ __launch_bounds__(NTHR) void k_stream_ms(const float* __restrict__ sp
         }
     }
     wg_barrier();
+    STAMP(SS, 3)
     f32x4 x[1], en1p, en2p, en3p;
     {   // D: en_convs.1; en1 is kept in the slot order of its decoder consumer
         const f32x4 Bv = ld4(sPE + E_EN1_B + 4 * g);
@@ -2958,6 +3200,7 @@ __global__ __launch_bounds__(NTHR) void k_stream_ms(const float* __restrict__ sp
         en1p = permute_via_lds(sEB + tt.pp(0) * 16, ix, g, x[0]);
     }
     wg_barrier();                                                  // E0 is dead: its region becomes W
+    STAMP(SS, 4)
     zero_row_pads<RW, 16, 35>(sWe, tid);
     // GTCN history rows of the lane's position (k_gtcn_ms): requested during the last encoder block
     const int ffl = lane_live ? tt.ff[0] : 0;
@@ -2994,13 +3237,18 @@ __global__ __launch_bounds__(NTHR) void k_stream_ms(const float* __restrict__ sp
         // the next block's history image is written once this block's taps are read (behind its third barrier); every
         // history load has then been consumed before any wave stores a new row in the next block's point_conv1 phase
         gtconv_block<false, 1, true, false, 16, 16, true, 35>(
-            x, tt, c, L, [] {}, [&] { if (k < 2) hist_store(smem + LD::HE, std::false_type{}, hv); });
+            x, tt, c, L, [] {}, [&] { if (k < 2) hist_store(smem + LD::HE, std::false_type{}, hv); } STAMP_ARG);
         if (k < 2) {
             const int* ix = sI + I_ENST - ENC_I_SKIP + (k + 1) * 16 + 4 * g;
             const f32x4 y = permute_via_lds(sSe + tt.pp(0) * PERM_RS, ix, g, x[0]);
             if (k == 0) en2p = y; else en3p = y;
         }
+        STAMP(SS, 8)
     }
+#ifdef GT_STAMPS     // the encoder blocks' phase sums move to slots 10..12: the decoder blocks reuse 5..7
+    SS.acc[10] = SS.acc[5]; SS.acc[11] = SS.acc[6]; SS.acc[12] = SS.acc[7];
+    SS.acc[5] = SS.acc[6] = SS.acc[7] = 0;
+#endif
     // ------------------------------------------------------------------------------------------------- GTCN x 2
     // per position, nothing shared between lanes (k_gtcn_ms); the decoder's first history image is requested now
     hist_fetch(ST_DEC_H, hv);
@@ -3023,6 +3271,7 @@ __global__ __launch_bounds__(NTHR) void k_stream_ms(const float* __restrict__ sp
         }
         x[0] = xx + x0;                                            // gtcn2(gtcn1(x)) + en_outs[4] (Decoder.forward :467)
     }
+    STAMP(SS, 9)
     // ------------------------------------------------------------------------------------------------- decoder
     // (k_decoder<false, 1, true, false>: same expressions; skips from registers, en0 from LDS, the spectrogram from spn)
     constexpr int RS = LD::RSD;
@@ -3041,6 +3290,7 @@ __global__ __launch_bounds__(NTHR) void k_stream_ms(const float* __restrict__ sp
     zero_row_pads<RW, RS>(sW, tid);
     if (tid < 4) sM[2 * RW * F0 + tid] = 0.f;
     wg_barrier();
+    STAMP(SS, 13)
     const int npos = nfr * 33;
     f32x4 s0e, s0o;
     auto run_block = [&](int j, const f32x4 skv, auto&& hook, auto&& hook3) {
@@ -3058,8 +3308,9 @@ __global__ __launch_bounds__(NTHR) void k_stream_ms(const float* __restrict__ sp
         c.ms_tb = tbl;
         c.g_hist = stl + ST_DEC_H + ((j * 2 + (tbl & 1)) * 33 + ffl) * 16 + 4 * g;
         gtconv_block<true, 1, true, false, RS, 16, true, 35, 0>(
-            x, tt, c, L, [&] { if (j < 2) dense_fetch(j + 1); hook(); }, hook3);
+            x, tt, c, L, [&] { if (j < 2) dense_fetch(j + 1); hook(); }, hook3 STAMP_ARG);
         x[0] = x[0] + skv;
+        STAMP(SS, 8)
     };
     // (the history loads of block j + 1 are issued in block j's hook, behind its dense phase, and land in the image
     // behind its third barrier; the closing barrier of every dense block waits for vmcnt(0): DMA and history alike)
@@ -3120,6 +3371,7 @@ __global__ __launch_bounds__(NTHR) void k_stream_ms(const float* __restrict__ sp
         }
     }
     wg_barrier();
+    STAMP(SS, 14)
     {   // ERB.bs + complex ratio mask + output layout
         int tq, f;
         spec_item_first(tid, t_fast, tq, f);
@@ -3167,6 +3419,8 @@ __global__ __launch_bounds__(NTHR) void k_stream_ms(const float* __restrict__ sp
         stb[(long)sidx * ST_FLOATS + ST_DEC_E + e] = sEHd[tid];
     }
     if (tid < nlive) reinterpret_cast<int*>(stb + (long)tid * ST_FLOATS)[0] = (sTB[tid] + 1) & 0xFFFF;
+    STAMP(SS, 15)
+    STAMP_OUT(SS, stamps)
 }
 
 // ==================================================================== state conversion
@@ -3399,7 +3653,18 @@ int configure_kernels() {
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_gtcn_band<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
                             GB_LDS_FLOATS * 4);
     if (e != hipSuccess) return (int)e;
-    const void* dec[] = {reinterpret_cast<const void*>(k_decoder<false, TPW, false, false>),
+    const void* bk[] = {reinterpret_cast<const void*>(k_back<false, false>), reinterpret_cast<const void*>(k_back<true, false>)};
+    for (const void* f : bk) {
+        e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, BK_LDS_FLOATS * 4);
+        if (e != hipSuccess) return (int)e;
+    }
+    const void* dec[] = {reinterpret_cast<const void*>(k_decoder<false, TPW, false, false, false>),
+                         reinterpret_cast<const void*>(k_decoder<true, TPW, false, false, false>),
+                         reinterpret_cast<const void*>(k_decoder<false, 1, false, false, false>),
+                         reinterpret_cast<const void*>(k_decoder<true, 1, false, false, false>),
+                         reinterpret_cast<const void*>(k_decoder<false, 2, false, false, false>),
+                         reinterpret_cast<const void*>(k_decoder<true, 2, false, false, false>),
+                         reinterpret_cast<const void*>(k_decoder<false, TPW, false, false>),
                          reinterpret_cast<const void*>(k_decoder<true, TPW, false, false>),
                          reinterpret_cast<const void*>(k_decoder<false, 1, false, false>),
                          reinterpret_cast<const void*>(k_decoder<true, 1, false, false>),
@@ -3508,23 +3773,33 @@ int launch_gtcn_band(const float* xin, float* xout, const float* P, int B, int T
     return 0;
 }
 
+// xtail != nullptr (offline fp32 calls): the blocks-only form; k_back (launch_back) finishes the frames from xtail
 int launch_decoder(const float* xg, const float* en0, const float* en1, const float* en2, const float* en3,
                    const float* en4, const float* spec, long sb, long sf, long st, float* out, long osb, long osf,
                    long ost, int B, int T, const int* lens, const float* PF, const int* PI, float* state, float* dbg,
-                   unsigned long long* stamps, hipStream_t s, const Quant* q) {
+                   unsigned long long* stamps, hipStream_t s, const Quant* q, float* xtail) {
 #define GT_DEC(DBGV, TPWV)                                                                                         \
-    hipLaunchKernelGGL((k_decoder<DBGV, TPWV, false, false>), dim3(B), dim3(NTHR), DEC_LDS_FLOATS * 4, s, xg, en0, en1, \
-                       en2, en3, en4, spec, sb, sf, st, out, osb, osf, ost, T, lens, B, 0.f, 0.f, PF, PI, state, dbg,   \
-                       stamps)
+    do {                                                                                                           \
+        if (xtail)                                                                                                 \
+            hipLaunchKernelGGL((k_decoder<DBGV, TPWV, false, false, false>), dim3(B), dim3(NTHR), DEC_LDS_FLOATS * 4, s, xg, \
+                               en0, en1, en2, en3, en4, spec, sb, sf, st, out, osb, osf, ost, T, lens, B, 0.f, 0.f, PF, PI, \
+                               state, dbg, stamps, xtail);                                                          \
+        else                                                                                                       \
+            hipLaunchKernelGGL((k_decoder<DBGV, TPWV, false, false>), dim3(B), dim3(NTHR), DEC_LDS_FLOATS * 4, s, xg, en0, \
+                               en1, en2, en3, en4, spec, sb, sf, st, out, osb, osf, ost, T, lens, B, 0.f, 0.f, PF, PI,    \
+                               state, dbg, stamps, (float*)nullptr);                                               \
+    } while (0)
+    if (xtail && (q || state)) return (int)hipErrorInvalidValue;
     if (q) {
         hipLaunchKernelGGL((k_decoder<false, TPW, false, true>), dim3(B), dim3(NTHR), DEC_LDS_FLOATS * 4, s, xg, en0, en1,
                            en2, en3, en4, spec, sb, sf, st, out, osb, osf, ost, T, lens, B, q->in_step, q->out_step, PF,
-                           PI, (float*)nullptr, (float*)nullptr, stamps);
+                           PI, (float*)nullptr, (float*)nullptr, stamps, (float*)nullptr);
     } else if (!dbg && use_multi_stream(T, state, sb) && use_multi_stream(T, state, osb)) {
         const int grid = (B + MS_STREAMS - 1) / MS_STREAMS;
         hipLaunchKernelGGL((k_decoder<false, 1, true, false>), dim3(grid), dim3(NTHR), DEC_MS_LDS_FLOATS * 4, s, xg, en0,
                            en1, en2, en3, en4, spec, (long)MS_STREAMS * sb, sf, sb, out, (long)MS_STREAMS * osb, osf, osb,
-                           MS_STREAMS, (const int*)nullptr, B, 0.f, 0.f, PF, PI, state, (float*)nullptr, stamps);
+                           MS_STREAMS, (const int*)nullptr, B, 0.f, 0.f, PF, PI, state, (float*)nullptr, stamps,
+                           (float*)nullptr);
     } else if (T <= SHORT_T) {
         if (dbg) GT_DEC(true, 1); else GT_DEC(false, 1);
     } else if (T <= SHORT_T2) {
@@ -3537,12 +3812,27 @@ int launch_decoder(const float* xg, const float* en0, const float* en1, const fl
     return 0;
 }
 
+// the decoder's frame-independent tail (see k_back): persistent grid, one frame per wave
+int launch_back(const float* xd, const float* en0, const float* spec, long sb, long sf, long st, float* out, long osb,
+                long osf, long ost, int B, int T, const int* lens, const float* PF, float* dbg, hipStream_t s) {
+    const long wgs = ((long)B * T + BK_WAVES - 1) / BK_WAVES;
+    const int grid = (int)(wgs < 256 * 2 ? wgs : 256 * 2);              // two workgroups per CU, persistent
+    if (dbg)
+        hipLaunchKernelGGL((k_back<true, false>), dim3(grid), dim3(BK_NT), BK_LDS_FLOATS * 4, s, xd, en0, spec, sb, sf, st,
+                           out, osb, osf, ost, B, T, lens, 0.f, 0.f, PF, dbg);
+    else
+        hipLaunchKernelGGL((k_back<false, false>), dim3(grid), dim3(BK_NT), BK_LDS_FLOATS * 4, s, xd, en0, spec, sb, sf, st,
+                           out, osb, osf, ost, B, T, lens, 0.f, 0.f, PF, dbg);
+    GT_LAUNCH_CHECK();
+    return 0;
+}
+
 // single-frame step for B streams, ONE launch (see k_stream_ms); strides in floats of (B,257,1,2)-shaped tensors
 int launch_stream_ms(const float* spec, long sb, long sf, float* out, long osb, long osf, int B, const float* PF,
-                     const int* PI, float* state, hipStream_t s) {
+                     const int* PI, float* state, unsigned long long* stamps, hipStream_t s) {
     const int grid = (B + MS_STREAMS - 1) / MS_STREAMS;
     hipLaunchKernelGGL(k_stream_ms, dim3(grid), dim3(NTHR), SM_LDS_FLOATS * 4, s, spec, sb, sf, out, osb, osf, B, PF, PI,
-                       state);
+                       state, stamps);
     GT_LAUNCH_CHECK();
     return 0;
 }

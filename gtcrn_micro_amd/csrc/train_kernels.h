@@ -29,7 +29,15 @@ struct ConvGeom {
     int accumulate;             // 1: add to the existing output instead of overwriting it
     int in_bf, out_bf;          // storage of `in` / `out`: 0 fp32, 1 bf16 (saved activations of the bf16 variant);
                                 // gradients are always fp32; out_bf excludes accumulate
+    // "bf16 saves, exact chain" storage (see Save2 below): a SECOND copy of the output in format out2_bf; `out` must
+    // then be fp32.  nullptr: none.
+    float* out2;
+    int out2_bf;
 };
+// Storage mode "bf16 saves, exact forward chain" (gtcrn_trainer_set_storage 4): every forward tensor is written TWICE --
+// the fp32 value the next layer reads (`out`: the forward is then the fp32 network, bit for bit) and the 16-bit copy the
+// backward re-reads (`out2`, centred by `shift` like the plain bf16 mode's).  The statistics a conv accumulates in its
+// epilogue are those of the fp32 values.  Only the forward kernels know about it; the backward is the bf16 mode's.
 
 // Storage of the SAVED tensors (conv outputs, activations, block outputs -- everything the backward re-reads):
 // the format arguments of the functions below (`bf`: activations / block outputs, `ybf`: conv outputs in front of a
@@ -46,6 +54,8 @@ struct DwGeom {
     int w_c, w_kt, w_kf;
     int accumulate;
     int in_bf, out_bf;
+    float* out2;                // second copy of the output (see ConvGeom)
+    int out2_bf;
 };
 
 enum Act { ACT_NONE = 0, ACT_PRELU = 1, ACT_TANH = 2 };
@@ -67,6 +77,10 @@ struct BnPre {
     float* a_out;
     int ybf, bf;
     const float* res;                            // its residual input (format bf) or nullptr; pointwise convs only
+    // exact chain (ConvGeom::out2): the activation enters the convolution UNROUNDED, a_out still receives its 16-bit
+    // copy, a_chain (optional) the fp32 value for the other readers of this activation (residual, skip); res is fp32
+    int exact;
+    float* a_chain;
 };
 int conv_fwd(const ConvGeom& g, const float* in, const float* w, const float* bias, float* out, hipStream_t s,
              double* stat_partial = nullptr, int* stat_parts = nullptr, const float* shift = nullptr,
@@ -83,11 +97,15 @@ int dw_wgrad(const DwGeom& g, const float* in, const float* dout, float* dw, flo
 
 // BatchNorm (train mode) of y [n][C]: batch statistics, running-statistics update (momentum 0.1, unbiased
 // variance), stats[0..C) = mean, stats[C..2C) = 1/sqrt(var + 1e-5).  scratch: MAX_PARTIALS * 2 * C doubles.
+// stats_b (exact chain only; the statistics are then those of the UNSHIFTED fp32 tensor while the backward's 16-bit copy
+// holds y - shift): receives mean - shift (the mean of the stored copy) and invstd -- what the backward kernels take as
+// `stats` -- before shift is moved to this step's mean.
 int bn_stats(const float* y, long n, int C, float* stats, float* running_mean, float* running_var, double* scratch,
-             hipStream_t s, int have_parts = 0, int bf = 0, float* shift = nullptr);
-// a = act(gamma * (y - mean) * invstd + beta [+ res])
+             hipStream_t s, int have_parts = 0, int bf = 0, float* shift = nullptr, float* stats_b = nullptr);
+// a = act(gamma * (y - mean) * invstd + beta [+ res]); a2 (optional, format a2_bf): second copy of a (exact chain)
 int bn_act(const float* y, long n, int C, const float* stats, const float* gamma, const float* beta,
-           const float* res, int act, const float* slope, float* a, hipStream_t s, int bf = 0, int ybf = 0);
+           const float* res, int act, const float* slope, float* a, hipStream_t s, int bf = 0, int ybf = 0,
+           float* a2 = nullptr, int a2_bf = 0);
 // backward of the same: given da, writes dy (may alias da); if dres != nullptr: dres (+)= dz (dres_acc: add);
 // dgamma/dbeta [C], dslope [1] (PReLU) are WRITTEN.  scratch: MAX_PARTIALS * 3 * C doubles + 2 * C floats.
 int bn_act_bwd(const float* da, const float* y, long n, int C, const float* stats, const float* gamma,
@@ -121,7 +139,7 @@ int dwunit_bwd(const DwGeom& g, const float* x, const float* y, const float* da,
 
 // features: spec (strided (b,f,t) + re/im) -> EB [B][T][129][3] = ERB.bm([mag,re,im]) (models/gtcrn_micro.py:510-516)
 int feat_fwd(const float* spec, long sb, long sf, long st, int B, int T, const float* erb_w, float* eb,
-             hipStream_t s, int bf = 0);
+             hipStream_t s, int bf = 0, float* eb2 = nullptr, int eb2_bf = 0);
 // mask: m [B][T][129][2] -> ERB.bs -> complex ratio mask applied to spec (:472-482, 526-530)
 int bs_mask_fwd(const float* m, const float* spec, long sb, long sf, long st, int B, int T, const float* ierb_w,
                 float* out, long ob, long of, long ot, hipStream_t s, int bf = 0);
@@ -133,7 +151,7 @@ int tra_fwd(const float* v, int B, int Tt, const float* dw_w, const float* dw_b,
             const float* pw_b, float* e, float* y, float* g, hipStream_t s, int bf = 0);
 // out[b,t,f,2c] = v[b,t,f,c] * g[b,t,c], out[b,t,f,2c+1] = x[b,t,f,8+c]   (shuffle, :222-227), t < T
 int gate_shuffle_fwd(const float* v, const float* g, const float* x, int B, int T, int Tt, float* out, hipStream_t s,
-                     int bf = 0);
+                     int bf = 0, float* out2 = nullptr, int out2_bf = 0);
 // backward of tra + gate + shuffle: dout [B][T][33][16] -> dv [B][Tt][33][8] (written), dx channels 8..15 (written),
 // parameter gradients written.  tmp: 3 * B*Tt*8 floats; scratch: MAX_PARTIALS * 80 floats.
 int tra_gate_shuffle_bwd(const float* dout, const float* v, const float* g, const float* e, const float* y, int B,

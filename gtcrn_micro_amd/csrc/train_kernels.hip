@@ -201,7 +201,7 @@ __global__ __launch_bounds__(NT) void k_conv(ConvGeom g, const float* __restrict
         const int to = (int)(bt % g.Tout), b = (int)(bt / g.Tout);
         float acc[COUT];
 #pragma unroll
-        for (int co = 0; co < COUT; ++co) acc[co] = (bias ? bias[co] : 0.f) - (shift ? shift[co] : 0.f);
+        for (int co = 0; co < COUT; ++co) acc[co] = (bias ? bias[co] : 0.f) - ((shift && !g.out2) ? shift[co] : 0.f);
         for (int kt = 0; kt < g.nkt; ++kt) {
             const int ti = to + g.t_off[kt];
             if (ti < 0 || ti >= g.Tin) continue;
@@ -217,7 +217,13 @@ __global__ __launch_bounds__(NT) void k_conv(ConvGeom g, const float* __restrict
                     for (int co = 0; co < COUT; ++co) acc[co] = fmaf(wt[ci * COUT + co], xv[ci], acc[co]);
             }
         }
-        if (g.out_bf) {
+        if (g.out2) {      // exact chain: fp32 for the next layer, the centred 16-bit copy for the backward
+#pragma unroll
+            for (int co = 0; co < COUT; ++co) {
+                out[p * g.CoutT + g.cout_off + co] = acc[co];
+                sst1(g.out2, p * g.CoutT + g.cout_off + co, g.out2_bf, acc[co] - (shift ? shift[co] : 0.f));
+            }
+        } else if (g.out_bf) {
 #pragma unroll
             for (int co = 0; co < COUT; ++co) sst1(out, p * g.CoutT + g.cout_off + co, g.out_bf, acc[co]);
         } else {
@@ -350,6 +356,12 @@ __device__ __forceinline__ PreConst pre_const(const BnPre& pre, int q, int C) {
     k.sl = k.act ? pre.slope[0] : 0.f;
     return k;
 }
+// the previous unit's activation, handed on by a normalise-on-load conv: rounded 16-bit copy for the backward (always),
+// and in the exact-chain mode the fp32 value for the activation's other readers
+__device__ __forceinline__ void pre_store(const BnPre& pre, long idx, const f32x4 a) {
+    sst4<kNtSt>(pre.a_out, idx, pre.bf, a);
+    if (pre.exact && pre.a_chain) sst4<kNtSt>(pre.a_chain, idx, 0, a);
+}
 __device__ __forceinline__ f32x4 pre_apply(const PreConst& k, const f32x4 y, int bf, bool has_res = false,
                                            const f32x4 r = f32x4{0.f, 0.f, 0.f, 0.f}) {
     f32x4 a;
@@ -455,7 +467,11 @@ __global__ __launch_bounds__(NT) void k_conv_mfma(ConvGeom g, const float* __res
     }
     f32x4 bv = {0.f, 0.f, 0.f, 0.f};
     if (bias && 4 * q < g.Cout) bv = *reinterpret_cast<const f32x4*>(bias + 4 * q);
-    if (shift && 4 * q < g.Cout) bv -= *reinterpret_cast<const f32x4*>(shift + 4 * q);
+    f32x4 sh2 = {0.f, 0.f, 0.f, 0.f};        // exact chain: the shift centres the 16-bit copy only
+    if (shift && 4 * q < g.Cout) {
+        if (g.out2) sh2 = *reinterpret_cast<const f32x4*>(shift + 4 * q);
+        else bv -= *reinterpret_cast<const f32x4*>(shift + 4 * q);
+    }
     const bool cin_ok = 4 * q < g.Cin, cout_ok = 4 * q < g.Cout;
     PreConst pk{};
     if constexpr (PRE) pk = pre_const(pre, q, g.CinT);
@@ -489,7 +505,7 @@ __global__ __launch_bounds__(NT) void k_conv_mfma(ConvGeom g, const float* __res
                 raw[kt * NKF + kf] = sld4_raw<FIN>(in, ok ? (rowbase + fi) * g.CinT + g.cin_off + 4 * q : 0L);
                 if constexpr (PRE) {
                     pidx = (rowbase + fi) * g.CinT + g.cin_off + 4 * q;
-                    if (pre.res) pres = sld4(pre.res, ok ? pidx : 0L, pre.bf);
+                    if (pre.res) pres = sld4(pre.res, ok ? pidx : 0L, pre.exact ? 0 : pre.bf);
                 }
             }
         }
@@ -497,8 +513,8 @@ __global__ __launch_bounds__(NT) void k_conv_mfma(ConvGeom g, const float* __res
         for (int tap = 0; tap < NKT * NKF; ++tap) {
             f32x4 d = dec4<FIN>(raw[tap]);
             if constexpr (PRE) {
-                d = pre_apply(pk, d, pre.bf, pre.res != nullptr, pres);
-                if (okv[tap]) sst4<kNtSt>(pre.a_out, pidx, pre.bf, d);
+                d = pre_apply(pk, d, pre.exact ? 0 : pre.bf, pre.res != nullptr, pres);
+                if (okv[tap]) pre_store(pre, pidx, d);
             }
             const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
             const f32x4 xv = okv[tap] ? d : zero;
@@ -508,7 +524,10 @@ __global__ __launch_bounds__(NT) void k_conv_mfma(ConvGeom g, const float* __res
         }
         }
         if (pv && cout_ok) {
-            if (g.out_bf) {
+            if (g.out2) {     // exact chain: fp32 for the next layer (and the statistics), centred 16-bit copy for the backward
+                sst4<kNtSt>(out, p * g.CoutT + g.cout_off + 4 * q, 0, acc);
+                sst4<kNtSt>(g.out2, p * g.CoutT + g.cout_off + 4 * q, g.out2_bf, acc - sh2);
+            } else if (g.out_bf) {
                 acc = round_bf4(acc, g.out_bf);   // the statistics are those of the STORED tensor (the backward re-reads it)
                 sst4<kNtSt>(out, p * g.CoutT + g.cout_off + 4 * q, g.out_bf, acc);
             } else {
@@ -570,7 +589,11 @@ __global__ __launch_bounds__(NT, 4) void k_conv_win_fma(ConvGeom g, const float*
     P.init(((long)blockIdx.x * NT + tid) >> 2, g.Fout, g.Tout);
     f32x4 bv = {0.f, 0.f, 0.f, 0.f};
     if (bias) bv = *reinterpret_cast<const f32x4*>(bias + 4 * q);
-    if (shift) bv -= *reinterpret_cast<const f32x4*>(shift + 4 * q);
+    f32x4 sh2 = {0.f, 0.f, 0.f, 0.f};        // exact chain: the shift centres the 16-bit copy only
+    if (shift) {
+        if (g.out2) sh2 = *reinterpret_cast<const f32x4*>(shift + 4 * q);
+        else bv -= *reinterpret_cast<const f32x4*>(shift + 4 * q);
+    }
     for (long i = (long)blockIdx.x * NT + tid; i < units; i += (long)gridDim.x * NT) {
         const long p = i >> 2;
         const int e0 = (P.fo * g.sf - g.pf) * g.Cin;
@@ -602,7 +625,10 @@ __global__ __launch_bounds__(NT, 4) void k_conv_win_fma(ConvGeom g, const float*
             for (int e = 0; e < 4; ++e) acc[e] = fmaf(wt[e], x[j], acc[e]);
         }
         P.advance(it, g.Fout, g.Tout);
-        if (g.out_bf) {
+        if (g.out2) {
+            sst4<kNtSt>(out, p * 16 + 4 * q, 0, acc);
+            sst4<kNtSt>(g.out2, p * 16 + 4 * q, g.out2_bf, acc - sh2);
+        } else if (g.out_bf) {
             acc = round_bf4(acc, g.out_bf);
             sst4<kNtSt>(out, p * 16 + 4 * q, g.out_bf, acc);
         } else {
@@ -962,7 +988,10 @@ __global__ __launch_bounds__(NT) void k_dw(DwGeom g, const float* __restrict__ i
                 for (int c = 0; c < C; ++c) acc[c] = fmaf(wt[c], xv[c], acc[c]);
             }
         }
-        if (g.out_bf) {
+        if (g.out2) {
+#pragma unroll
+            for (int c = 0; c < C; ++c) { out[p * C + c] = acc[c]; sst1(g.out2, p * C + c, g.out2_bf, acc[c]); }
+        } else if (g.out_bf) {
 #pragma unroll
             for (int c = 0; c < C; ++c) sst1(out, p * C + c, g.out_bf, acc[c]);
         } else {
@@ -1008,7 +1037,7 @@ __global__ __launch_bounds__(NT) void k_dw16(DwGeom g, const float* __restrict__
         const long p = i >> 2;
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
         if (bias) acc = *reinterpret_cast<const f32x4*>(bias + 4 * q);
-        if (shift) acc -= *reinterpret_cast<const f32x4*>(shift + 4 * q);
+        if (shift && !g.out2) acc -= *reinterpret_cast<const f32x4*>(shift + 4 * q);
         if constexpr (NKT > 0) {
             // every tap's load is issued before the first multiply-add (a tap outside the tensor loads the centre
             // record instead and is skipped by a select: one basic block, NKT * NKF loads in flight per thread instead
@@ -1032,8 +1061,8 @@ __global__ __launch_bounds__(NT) void k_dw16(DwGeom g, const float* __restrict__
             for (int tp = 0; tp < NKT * NKF; ++tp) {
                 if constexpr (FIN >= 0) xv[tp] = dec4<FR>(xr[tp]);
                 if constexpr (PRE) {
-                    xv[tp] = pre_apply(pk, xv[tp], pre.bf);
-                    if (tp == (NKT - 1) * NKF + NKF / 2) sst4<kNtSt>(pre.a_out, p * 16 + 4 * q, pre.bf, xv[tp]);
+                    xv[tp] = pre_apply(pk, xv[tp], pre.exact ? 0 : pre.bf);
+                    if (tp == (NKT - 1) * NKF + NKF / 2) pre_store(pre, p * 16 + 4 * q, xv[tp]);
                 }
                 const f32x4 wt = *reinterpret_cast<const f32x4*>(sW + tp * 16 + 4 * q);
                 const f32x4 nx = acc + wt * xv[tp];
@@ -1053,7 +1082,12 @@ __global__ __launch_bounds__(NT) void k_dw16(DwGeom g, const float* __restrict__
             }
         }
         P.advance(it, g.F, g.Tout);
-        if (g.out_bf) {
+        if (g.out2) {      // exact chain (see k_conv_mfma)
+            sst4<kNtSt>(out, p * 16 + 4 * q, 0, acc);
+            f32x4 c2 = acc;
+            if (shift) c2 -= *reinterpret_cast<const f32x4*>(shift + 4 * q);
+            sst4<kNtSt>(g.out2, p * 16 + 4 * q, g.out2_bf, c2);
+        } else if (g.out_bf) {
             acc = round_bf4(acc, g.out_bf);
             sst4<kNtSt>(out, p * 16 + 4 * q, g.out_bf, acc);
         } else {
@@ -1156,7 +1190,8 @@ __device__ __forceinline__ double reduce_partials(const double* partial, int npa
 
 __global__ __launch_bounds__(1024) void k_bn_stats_finish(const double* __restrict__ partial, int nparts, long n, int C,
                                                          float* __restrict__ stats, float* __restrict__ rmean,
-                                                         float* __restrict__ rvar, float* __restrict__ shift) {
+                                                         float* __restrict__ rvar, float* __restrict__ shift,
+                                                         float* __restrict__ stats_b) {
     __shared__ double sh[16][64];
     __shared__ double tot[64];
     const double s = reduce_partials(partial, nparts, 2 * C, sh);
@@ -1169,10 +1204,16 @@ __global__ __launch_bounds__(1024) void k_bn_stats_finish(const double* __restri
     if (var < 0.0) var = 0.0;
     stats[c] = (float)mean;
     stats[C + c] = (float)(1.0 / sqrt(var + 1e-5));
+    if (stats_b) {
+        // exact chain: the sums are those of the UNSHIFTED fp32 tensor; the backward's copy holds y - shift[c], whose
+        // mean is mean - shift[c] (the same float expression the stores used would give it to within the copy's rounding)
+        stats_b[c] = (float)(mean - (double)(shift ? shift[c] : 0.f));
+        stats_b[C + c] = stats[C + c];
+    }
     if (rmean) {
         const double unb = n > 1 ? var * (double)n / (double)(n - 1) : var;
         // shift: the tensor holds y - shift[c], so mean(y) = mean + shift[c]; that becomes the next step's shift
-        const double absmean = shift ? mean + (double)shift[c] : mean;
+        const double absmean = (shift && !stats_b) ? mean + (double)shift[c] : mean;
         rmean[c] = (float)(0.9 * (double)rmean[c] + 0.1 * absmean);
         if (shift) shift[c] = (float)absmean;
         rvar[c] = (float)(0.9 * (double)rvar[c] + 0.1 * unb);
@@ -1189,7 +1230,8 @@ template <int V>
 __global__ __launch_bounds__(NT) void k_bn_act(const float* __restrict__ y, long total, int C,
                                               const float* __restrict__ stats, const float* __restrict__ gamma,
                                               const float* __restrict__ beta, const float* __restrict__ res, int act,
-                                              const float* __restrict__ slope, float* __restrict__ a, int bf, int ybf) {
+                                              const float* __restrict__ slope, float* __restrict__ a, int bf, int ybf,
+                                              float* __restrict__ a2, int a2_bf) {
     const float sl = slope ? slope[0] : 0.f;
     const long units = total / V;
     // the stride is a multiple of C: the thread's channels and their constants are fixed
@@ -1210,6 +1252,10 @@ __global__ __launch_bounds__(NT) void k_bn_act(const float* __restrict__ y, long
         }
         if constexpr (V == 4) sst4<kNtSt>(a, i * 4, bf, f32x4{o[0], o[1], o[2], o[3]});
         else sst1(a, i, bf, o[0]);
+        if (a2) {          // exact chain: the backward's 16-bit copy next to the fp32 value
+            if constexpr (V == 4) sst4<kNtSt>(a2, i * 4, a2_bf, f32x4{o[0], o[1], o[2], o[3]});
+            else sst1(a2, i, a2_bf, o[0]);
+        }
     }
 }
 
@@ -1763,7 +1809,8 @@ __device__ __forceinline__ void nz_ranges(const float* w, int rows, int cols, in
 }
 
 __global__ __launch_bounds__(NT) void k_feat(const float* __restrict__ spec, long sb, long sf, long st, int B, int T,
-                                            const float* __restrict__ erb_w, float* __restrict__ eb, int bf) {
+                                            const float* __restrict__ erb_w, float* __restrict__ eb, int bf,
+                                            float* __restrict__ eb2, int eb2_bf) {
     __shared__ int lo[64], hi[64];
     nz_ranges(erb_w, 64, 192, 192, 1, lo, hi);
     const long total = (long)B * T * 129;
@@ -1789,6 +1836,7 @@ __global__ __launch_bounds__(NT) void k_feat(const float* __restrict__ spec, lon
             }
         }
         sst1(eb, p * 3, bf, m); sst1(eb, p * 3 + 1, bf, re); sst1(eb, p * 3 + 2, bf, im);
+        if (eb2) { sst1(eb2, p * 3, eb2_bf, m); sst1(eb2, p * 3 + 1, eb2_bf, re); sst1(eb2, p * 3 + 2, eb2_bf, im); }
     }
 }
 
@@ -1863,7 +1911,8 @@ __global__ __launch_bounds__(NT) void k_bs_mask_bwd(const float* __restrict__ do
 // is CONTIGUOUS for a tile -- goes through LDS.  Per-element arithmetic and its order are unchanged.
 constexpr int TT = 32;
 __global__ __launch_bounds__(NT) void k_feat_t(const float* __restrict__ spec, long sb, long sf, long st, int B, int T,
-                                              const float* __restrict__ erb_w, float* __restrict__ eb, int bf) {
+                                              const float* __restrict__ erb_w, float* __restrict__ eb, int bf,
+                                              float* __restrict__ eb2, int eb2_bf) {
     __shared__ int lo[64], hi[64];
     __shared__ float tile[TT][129 * 3 + 1];
     nz_ranges(erb_w, 64, 192, 192, 1, lo, hi);
@@ -1894,7 +1943,10 @@ __global__ __launch_bounds__(NT) void k_feat_t(const float* __restrict__ spec, l
     }
     __syncthreads();
     const long base = ((long)b * T + t0) * 387;
-    for (int i = threadIdx.x; i < nt * 387; i += NT) sst1(eb, base + i, bf, tile[i / 387][i % 387]);
+    for (int i = threadIdx.x; i < nt * 387; i += NT) {
+        sst1(eb, base + i, bf, tile[i / 387][i % 387]);
+        if (eb2) sst1(eb2, base + i, eb2_bf, tile[i / 387][i % 387]);
+    }
 }
 
 __global__ __launch_bounds__(NT) void k_bs_mask_t(const float* __restrict__ m, const float* __restrict__ spec, long sb,
@@ -2009,7 +2061,8 @@ __global__ __launch_bounds__(NT) void k_tra_gate(const float* __restrict__ e, in
 // TRA gate + channel shuffle (:222-227, :246-253): out[2c] = v[c] * g[c], out[2c+1] = x2[c] = x[8+c]
 __global__ __launch_bounds__(NT) void k_gate_shuffle(const float* __restrict__ v, const float* __restrict__ g,
                                                     const float* __restrict__ x, int B, int T, int Tt,
-                                                    float* __restrict__ out, int bf) {
+                                                    float* __restrict__ out, int bf, float* __restrict__ out2,
+                                                    int out2_bf) {
     // thread (position, half h): channels 4h..4h+3 -> output slots 8h..8h+7; 16-byte accesses throughout
     const long total = (long)B * T * 33 * 2;
     for (long i = (long)blockIdx.x * NT + threadIdx.x; i < total; i += (long)gridDim.x * NT) {
@@ -2025,6 +2078,10 @@ __global__ __launch_bounds__(NT) void k_gate_shuffle(const float* __restrict__ v
         const f32x4 p = vv * gg;
         sst4<kNtSt>(out, pos * 16 + 8 * h, bf, f32x4{p[0], xx[0], p[1], xx[1]});
         sst4<kNtSt>(out, pos * 16 + 8 * h + 4, bf, f32x4{p[2], xx[2], p[3], xx[3]});
+        if (out2) {
+            sst4<kNtSt>(out2, pos * 16 + 8 * h, out2_bf, f32x4{p[0], xx[0], p[1], xx[1]});
+            sst4<kNtSt>(out2, pos * 16 + 8 * h + 4, out2_bf, f32x4{p[2], xx[2], p[3], xx[3]});
+        }
     }
 }
 // backward, last step (after k_tra_dgate / k_tra_dy): dv = dout[2c] * g (0 on the trimmed tail frames) + de * (2/33) * v
@@ -2335,7 +2392,8 @@ static bool win_wgrad_ok(const ConvGeom& g) {
 
 int conv_fwd(const ConvGeom& g, const float* in, const float* w, const float* bias, float* out, hipStream_t s,
              double* stat_partial, int* stat_parts, const float* shift, const BnPre* pre) {
-    if (shift && !g.out_bf) return (int)hipErrorInvalidValue;
+    if (shift && !g.out_bf && !g.out2) return (int)hipErrorInvalidValue;
+    if (g.out2 && (g.out_bf || g.accumulate)) return (int)hipErrorInvalidValue;   // exact chain: fp32 `out`, plain store
     if (stat_parts) *stat_parts = 0;
     const BnPre nopre{};
     if (pre && !(mfma_ok(g) && g.nkt == 1 && g.nkf == 1 && g.sf == 1 && g.Cin == 16 && g.CinT == 16 && g.cin_off == 0 &&
@@ -2451,7 +2509,8 @@ int conv_wgrad(const ConvGeom& g, const float* in, const float* dout, float* dw,
 
 int dw_fwd(const DwGeom& g, const float* in, const float* w, const float* bias, float* out, hipStream_t s,
            double* stat_partial, int* stat_parts, const float* shift, const BnPre* pre) {
-    if (shift && (!g.out_bf || g.C != 16)) return (int)hipErrorInvalidValue;
+    if (shift && ((!g.out_bf && !g.out2) || g.C != 16)) return (int)hipErrorInvalidValue;
+    if (g.out2 && (g.out_bf || g.accumulate)) return (int)hipErrorInvalidValue;
     if (stat_parts) *stat_parts = 0;
     const BnPre nopre{};
     if (pre && !(g.C == 16 && g.nkt == 3 && g.nkf == 1 && g.t_off[2] == 0 && g.f_off[0] == 0 && g.in_bf == pre->ybf &&
@@ -2518,36 +2577,37 @@ int dw_wgrad(const DwGeom& g, const float* in, const float* dout, float* dw, flo
 }
 
 int bn_stats(const float* y, long n, int C, float* stats, float* running_mean, float* running_var, double* scratch,
-             hipStream_t s, int have_parts, int bf, float* shifted) {
+             hipStream_t s, int have_parts, int bf, float* shifted, float* stats_b) {
     const long total = n * C;
     if (have_parts > 0) {     // the producing conv already left its per-workgroup sums in scratch
         hipLaunchKernelGGL(k_bn_stats_finish, dim3(1), dim3(1024), 0, s, scratch, have_parts, n, C, stats, running_mean,
-                           running_var, shifted);
+                           running_var, shifted, stats_b);
         return check();
     }
     if (C % 4 == 0) {
         const int grid = red_grid(total / 4);
         hipLaunchKernelGGL((k_bn_stats<4>), dim3(grid), dim3(NT), 0, s, y, total, C, scratch, bf);
         hipLaunchKernelGGL(k_bn_stats_finish, dim3(1), dim3(1024), 0, s, scratch, grid, n, C, stats, running_mean, running_var,
-                           shifted);
+                           shifted, stats_b);
     } else {
         const int grid = red_grid(total);
         hipLaunchKernelGGL((k_bn_stats<1>), dim3(grid), dim3(NT), 0, s, y, total, C, scratch, bf);
         hipLaunchKernelGGL(k_bn_stats_finish, dim3(1), dim3(1024), 0, s, scratch, grid, n, C, stats, running_mean, running_var,
-                           shifted);
+                           shifted, stats_b);
     }
     return check();
 }
 
 int bn_act(const float* y, long n, int C, const float* stats, const float* gamma, const float* beta,
-           const float* res, int act, const float* slope, float* a, hipStream_t s, int bf, int ybf) {
+           const float* res, int act, const float* slope, float* a, hipStream_t s, int bf, int ybf, float* a2,
+           int a2_bf) {
     const long total = n * C;
     if (C % 4 == 0)
         hipLaunchKernelGGL((k_bn_act<4>), dim3(grid_for(total / 4, 8192)), dim3(NT), 0, s, y, total, C, stats, gamma,
-                           beta, res, act, slope, a, bf, ybf);
+                           beta, res, act, slope, a, bf, ybf, a2, a2_bf);
     else
         hipLaunchKernelGGL((k_bn_act<1>), dim3(grid_for(total, 8192)), dim3(NT), 0, s, y, total, C, stats, gamma, beta,
-                           res, act, slope, a, bf, ybf);
+                           res, act, slope, a, bf, ybf, a2, a2_bf);
     return check();
 }
 
@@ -2659,12 +2719,14 @@ int unit1x1_bwd(const ConvGeom& g, const float* x, const float* y, const float* 
 }
 
 int feat_fwd(const float* spec, long sb, long sf, long st, int B, int T, const float* erb_w, float* eb,
-             hipStream_t s, int bf) {
+             hipStream_t s, int bf, float* eb2, int eb2_bf) {
     // frame axis fastest (torch.stft's layout): tiles of TT frames, lanes along t
     if ((st < 0 ? -st : st) < (sf < 0 ? -sf : sf))
-        hipLaunchKernelGGL(k_feat_t, dim3(B * ((T + TT - 1) / TT)), dim3(NT), 0, s, spec, sb, sf, st, B, T, erb_w, eb, bf);
+        hipLaunchKernelGGL(k_feat_t, dim3(B * ((T + TT - 1) / TT)), dim3(NT), 0, s, spec, sb, sf, st, B, T, erb_w, eb, bf,
+                           eb2, eb2_bf);
     else
-        hipLaunchKernelGGL(k_feat, dim3(grid_for((long)B * T * 129)), dim3(NT), 0, s, spec, sb, sf, st, B, T, erb_w, eb, bf);
+        hipLaunchKernelGGL(k_feat, dim3(grid_for((long)B * T * 129)), dim3(NT), 0, s, spec, sb, sf, st, B, T, erb_w, eb, bf,
+                           eb2, eb2_bf);
     return check();
 }
 int bs_mask_fwd(const float* m, const float* spec, long sb, long sf, long st, int B, int T, const float* ierb_w,
@@ -2698,8 +2760,9 @@ int tra_fwd(const float* v, int B, int Tt, const float* dw_w, const float* dw_b,
     return check();
 }
 int gate_shuffle_fwd(const float* v, const float* g, const float* x, int B, int T, int Tt, float* out, hipStream_t s,
-                     int bf) {
-    hipLaunchKernelGGL(k_gate_shuffle, dim3(grid_for((long)B * T * 33 * 2)), dim3(NT), 0, s, v, g, x, B, T, Tt, out, bf);
+                     int bf, float* out2, int out2_bf) {
+    hipLaunchKernelGGL(k_gate_shuffle, dim3(grid_for((long)B * T * 33 * 2)), dim3(NT), 0, s, v, g, x, B, T, Tt, out, bf,
+                       out2, out2_bf);
     return check();
 }
 int tra_gate_shuffle_bwd(const float* dout, const float* v, const float* g, const float* e, const float* y, int B,

@@ -178,6 +178,8 @@ int gtcrn_pack_params_host(const float *h_params, long n_floats, float *h_f, int
  * the reference's (C,T,F) layout and logical channel order, for batch item b.
  * Names: en0..en4, gtcn1, gtcn2, de0..de4 (de* need gtcn_debug_enable(m,1)
  * before the forward).  Returns element count, or a negative status. */
+/* on = 2 (diagnostic build): phase stamps only -- a single-frame streaming step stays the ONE-launch form (its
+ * stamps land in kernel slot 0 of gtcrn_debug_stamps, one row per workgroup of four streams). */
 int gtcrn_debug_enable(gtcrn_model *m, int on);
 long gtcrn_debug_tap(gtcrn_model *m, const char *name, int b, float *h_dst, long cap);
 /* Diagnostic build only (libgtcrn_micro_hip_stamps.so, -DGT_STAMPS): per-workgroup sums of shader

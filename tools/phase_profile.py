@@ -30,6 +30,12 @@ PHASES = {
 }
 PHASES[2] = PHASES[1]
 NAMES = ["k_encoder", "k_gtcn1", "k_gtcn2", "k_decoder"]
+# --stream N: the single-launch streaming step (k_stream_ms), one row of stamps per workgroup of four streams
+STREAM_PHASES = {0: "prologue .. first barrier (params, rings, spec, [mag,re,im])", 1: "ERB bands", 2: "SFE", 3: "en_conv0",
+                 4: "en_conv1", 10: "enc blk pc1 (x3)", 11: "enc blk depth+pc2 (x3)", 12: "enc blk TRALite (x3)",
+                 9: "GTCN x 2 (8 TCN blocks, per position)", 13: "decoder set-up", 5: "dec blk pc1+split (x3)",
+                 6: "dec blk dense+pc2 (x3)", 7: "dec blk TRALite (x3)", 8: "after a block (skip add / permute) (x6)",
+                 14: "de_convs.3/4, Z, gather+tanh", 15: "mask + store + epilogue"}
 
 
 def main():
@@ -38,6 +44,7 @@ def main():
     ap.add_argument("--seconds", type=float, default=4.0)
     ap.add_argument("--json", default=None)
     ap.add_argument("--exp", action="store_true", help="profile the -DGT_EXP build instead of the default one")
+    ap.add_argument("--stream", type=int, default=0, help="profile single-frame streaming steps of this many streams")
     a = ap.parse_args()
     import numpy as np
     import torch
@@ -46,6 +53,32 @@ def main():
     from gtcrn_micro_amd import Engine
     params = np.fromfile(os.path.join(ROOT, "tests", "golden", "params_dns3.f32"), dtype=np.float32)
     eng = Engine(params, 0)
+    if a.stream:
+        N = a.stream
+        torch.manual_seed(44)
+        spec = (torch.randn(N, 40, 257, 2, device="cuda") * 0.3).permute(0, 2, 1, 3)
+        st = eng.new_state(N)
+        for t in range(20):
+            eng.stream_step(st, spec[:, :, t:t + 1])
+        eng.debug_enable(2)                       # stamps only: the step stays ONE launch
+        eng.timing_enable(True)
+        for t in range(20, 40):
+            eng.stream_step(st, spec[:, :, t:t + 1])
+        torch.cuda.synchronize()
+        kern = eng.timing_read()
+        stp = eng.stamps(0, N).astype(np.float64)[: (N + 3) // 4]          # the LAST step's stamps, one row per workgroup
+        avg = stp.mean(axis=0)
+        tot = avg.sum()
+        us = kern.get("k_stream_ms", (0, 0))[0] * 1e3
+        print(f"\nk_stream_ms, {N} streams: {tot:,.0f} cycles per workgroup (launch {us:.1f} us -> {tot / max(us, 1e-9):.0f} cycles/us)")
+        out = {"streams": N, "launch_us": us, "cycles": tot, "phases": {}}
+        for i, nm in STREAM_PHASES.items():
+            print(f"   {nm:<62} {avg[i]:>10,.0f}  {100 * avg[i] / tot:5.1f} %")
+            out["phases"][nm] = avg[i]
+        if a.json:
+            os.makedirs(os.path.dirname(os.path.abspath(a.json)), exist_ok=True)
+            json.dump(out, open(a.json, "w"), indent=1)
+        return
     B, L = a.batch, int(a.seconds * 16000)
     torch.manual_seed(43)
     wave = torch.randn(B, L, device="cuda") * 0.1
