@@ -55,19 +55,17 @@ MAC_PER_FRAME = {
     "k_encoder_gt": 3 * MAC_GT_ENC,
     "k_gtcn1": 73920,
     "k_gtcn2": 73920,
-    "k_decoder": 3 * 84602,                              # round 4: the three dense GTConv blocks (+TRA) only ...
-    "k_back": 42240 + 10400 + 764 + 1028,                # ... de_convs.3/4, ERB.bs, mask: the frame-independent tail
+    "k_decoder": 3 * 84602 + 42240 + 10400 + 764 + 1028,
 }
 # MFMA instructions (16x16x4 f32 = 2 048 FLOP each) issued per frame, incl. the zero padding of the 8->16 /
 # 16->8 pointwise and K=15 tiles: executed vs algorithmic matrix work
-MFMA_PER_FRAME = {"k_encoder": 107, "k_gtcn1": 66, "k_gtcn2": 66, "k_decoder": 49.5, "k_back": 24.0}
+MFMA_PER_FRAME = {"k_encoder": 107, "k_gtcn1": 66, "k_gtcn2": 66, "k_decoder": 66.0}
 # round 3: the decoder's dense transposed 3x3 and de_convs.3 run on v_mfma_f32_16x16x32_bf16 (16 384 FLOP each) from an
-# exact three-way bf16 split of both operands, six partial products per K-chunk: 33/16 tiles x 3 blocks x 30 per frame in
-# k_decoder, 3 tiles x 18 in k_back (one frame per wave: 33 positions fill three tiles); the fp32 MFMA keeps the
-# pointwise convs (33/16 x 3 x 8) and de_convs.4 (3 x 8)
-BF16_MFMA_PER_FRAME = {"k_decoder": 185.625, "k_back": 54.0}
+# exact three-way bf16 split of both operands, six partial products per K-chunk: 33/16 tiles x (3 blocks x 30 + 18)
+# per frame; the fp32 MFMA keeps the pointwise convs and de_convs.4: 33/16 x (3 x 8 + 8)
+BF16_MFMA_PER_FRAME = {"k_decoder": 222.75}
 BF16_MFMA_PEAK_TFLOPS = 2500.0                  # MI355X_MICROARCH.md, dense
-MODEL_MAC_PER_FRAME = MAC_FRONT + 3 * MAC_GT_ENC + 2 * 73920 + MAC_PER_FRAME["k_decoder"] + MAC_PER_FRAME["k_back"]
+MODEL_MAC_PER_FRAME = MAC_FRONT + 3 * MAC_GT_ENC + 2 * 73920 + MAC_PER_FRAME["k_decoder"]
 FFT_FLOP_PER_FRAME = 2 * 11520 + 6000          # 512-point rFFT + irFFT (5 N log2 N / 2) + window/OLA
 FP32_MFMA_PEAK_TFLOPS = 157.3                   # MI355X_MICROARCH.md, dense, v_mfma_f32_16x16x4_f32
 HBM_PEAK_GBS = 8000.0
@@ -729,7 +727,7 @@ def main(argv=None):
             roof["executed_tflops"] = round((f32x + bfx) / (dom_ms * 1e-3) / 1e12, 1)
             if bfx:
                 roof["executed_bf16_frac_of_bf16_peak"] = round(bfx / (dom_ms * 1e-3) / 1e12 / BF16_MFMA_PEAK_TFLOPS, 4)
-                roof["note"] = ("dense 3x3 (and de_convs.3 in k_back) on v_mfma_f32_16x16x32_bf16 from an exact 3-way bf16 split "
+                roof["note"] = ("dense 3x3 and de_convs.3 on v_mfma_f32_16x16x32_bf16 from an exact 3-way bf16 split "
                                 "of both operands (6 products, fp32 accumulate; held to the float64 graph by "
                                 "tests/test_gpu_precision.py); pointwise convs on the fp32 MFMA")
         line = {

