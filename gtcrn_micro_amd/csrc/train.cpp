@@ -57,6 +57,15 @@ struct Unit {                 // conv (dense or depthwise) + BatchNorm + activat
     float* a = nullptr;       // activation output
     const float* res = nullptr;
     float* stats = nullptr;   // mean[C], invstd[C]
+    // "bf16 saves, exact chain" storage (gtcrn_trainer_set_storage 4): x, y, a, res above are the 16-bit copies the
+    // BACKWARD reads; the forward runs on the fp32 twins below (short-lived buffers of the chain pool, see plan()) and
+    // writes both.  ac == nullptr: nobody but a fused consumer reads this activation in fp32.  bstats: what the
+    // backward takes as the unit's statistics (== stats except in that mode: the mean of the centred 16-bit copy)
+    const float* xc = nullptr;
+    float* yc = nullptr;
+    float* ac = nullptr;
+    const float* resc = nullptr;
+    const float* bstats = nullptr;
     // normalise-on-load (gtt::BnPre): `pre` = the unit in front whose BatchNorm + PReLU this unit's conv applies while
     // loading that unit's y (and whose activation it writes); `deferred` = this unit's own bn_act pass is left to its
     // consumer.  Set for conv1 -> conv2 -> conv3 of the TCN blocks and depth_conv -> point_conv2 of the GTConv blocks.
@@ -74,6 +83,8 @@ struct GtBlock {              // GTConvBlock (models/gtcrn_micro.py:167-253)
     const float* xin = nullptr;  // block input (after the skip add in the decoder)
     float* s = nullptr;       // decoder: x + skip
     float *e = nullptr, *yt = nullptr, *g = nullptr, *out = nullptr;
+    const float* xinc = nullptr; // exact chain: fp32 twins of xin / s / out
+    float *sc = nullptr, *outc = nullptr;
 };
 
 struct TcnBlock {             // TCN (models/gtcrn_micro.py:256-310)
@@ -86,6 +97,9 @@ struct gtcrn_trainer {
     int device = 0;
     int bf = 0;                   // format of the saved activations / block outputs: 0 fp32, 1 bf16
     int ybf = 0;                  // format of the saved conv outputs in front of a BatchNorm: 0 fp32, 1 bf16, 2 fp16
+    int exact = 0;                // 1: bf16 SAVES only -- the forward chain itself runs in fp32 (storage code 4)
+    float *ebc = nullptr, *f0c = nullptr, *s3c = nullptr, *s4c = nullptr;   // fp32 twins of eb, f0, s3, s4 (exact chain)
+    const float *dec_in[3] = {nullptr, nullptr, nullptr};                   // ... of the decoder blocks' first addends
     int B = 0, T = 0;
     bool planned = false, have_fwd = false;
     bool shift_ready = false;     // bf16 storage: the per-unit centring shifts hold a previous step's batch means
@@ -120,7 +134,7 @@ namespace {
 struct Bump {
     size_t used = 0;              // in floats
     float* base = nullptr;
-    int bf = 0, ybf = 0;
+    int bf = 0, ybf = 0, exact = 0;
     float* take(size_t n) {
         n = (n + 63) & ~size_t(63);
         float* p = base ? base + used : nullptr;
@@ -181,10 +195,48 @@ void alloc_unit(Bump& b, Unit& u, long n, int C) {
     u.n = n; u.C = C;
     u.y = b.take_saved_y((size_t)n * C);
     u.a = b.take_saved((size_t)n * C);
-    u.stats = b.take(64);               // mean[C], invstd[C]; +32: the centring shift of the stored y (bf16 storage)
+    u.stats = b.take(128);              // mean[C], invstd[C]; +32: the centring shift of the stored y (bf16 storage);
+                                        // +64: mean - shift, invstd for the backward (exact chain, see bn_stats)
+    u.bstats = b.exact ? u.stats + 64 : u.stats;
     u.cg.in_bf = u.dg.in_bf = b.bf;     // forward geometry: saved activation in -> saved conv output
     u.cg.out_bf = u.dg.out_bf = b.ybf;
 }
+
+// The fp32 buffers of the exact chain live only from their producer to their last forward reader, so they come from a
+// small pool with explicit lifetimes (first fit, coalescing free list), laid over the region of the backward's scratch
+// tensors: nothing of the chain is needed once the forward is done, nothing of the backward's before it starts.
+struct ChainPool {
+    std::vector<std::pair<size_t, size_t>> fr;     // free blocks (offset, size), sorted by offset
+    size_t hi = 0;
+    static size_t rnd(size_t n) { return (n + 63) & ~size_t(63); }
+    size_t get(size_t n) {
+        n = rnd(n);
+        for (size_t i = 0; i < fr.size(); ++i)
+            if (fr[i].second >= n) {
+                const size_t o = fr[i].first;
+                if (fr[i].second == n) fr.erase(fr.begin() + i);
+                else { fr[i].first += n; fr[i].second -= n; }
+                return o;
+            }
+        if (!fr.empty() && fr.back().first + fr.back().second == hi) {      // grow the last free block
+            const size_t o = fr.back().first;
+            hi = o + n;
+            fr.pop_back();
+            return o;
+        }
+        const size_t o = hi;
+        hi += n;
+        return o;
+    }
+    void put(size_t o, size_t n) {
+        n = rnd(n);
+        size_t i = 0;
+        while (i < fr.size() && fr[i].first < o) ++i;
+        fr.insert(fr.begin() + i, {o, n});
+        if (i + 1 < fr.size() && fr[i].first + fr[i].second == fr[i + 1].first) { fr[i].second += fr[i + 1].second; fr.erase(fr.begin() + i + 1); }
+        if (i > 0 && fr[i - 1].first + fr[i - 1].second == fr[i].first) { fr[i - 1].second += fr[i].second; fr.erase(fr.begin() + i); }
+    }
+};
 
 // lays out every tensor of one (B, T) problem in the arena; base == nullptr: size query
 size_t plan(gtcrn_trainer* t, int B, int T, float* base) {
@@ -192,11 +244,20 @@ size_t plan(gtcrn_trainer* t, int B, int T, float* base) {
     b.base = base;
     b.bf = t->bf;
     b.ybf = t->ybf;
+    b.exact = t->exact;
     const long n129 = (long)B * T * 129, n65 = (long)B * T * 65, n33 = (long)B * T * 33;
     const int T2 = T + 2;
     const long n33x = (long)B * T2 * 33;
     const bool fuse = t->ybf <= 1 && (t->fusions & 1);      // (not for the fp16 diagnostic storage)
     t->taps.clear();
+    {   // (the fp32 twins of the exact chain are assigned at the end; a unit that has none must not keep an old one)
+        Unit* all[4 + 6 * 3 + 8 * 3] = {&t->en0, &t->en1, &t->de3, &t->de4};
+        int n = 4;
+        for (int k = 0; k < 3; ++k)
+            for (GtBlock* g : {&t->enc[k], &t->dec[k]}) { all[n++] = &g->pc1; all[n++] = &g->depth; all[n++] = &g->pc2; }
+        for (int i = 0; i < 8; ++i) { all[n++] = &t->tcn[i].c1; all[n++] = &t->tcn[i].c2; all[n++] = &t->tcn[i].c3; }
+        for (int i = 0; i < n; ++i) { all[i]->xc = nullptr; all[i]->yc = nullptr; all[i]->ac = nullptr; all[i]->resc = nullptr; }
+    }
     t->eb = b.take_saved(n129 * 3);
     t->f0 = b.take_saved(n129 * 3);
     // encoder.en_convs.0/1: ConvBlock (models/gtcrn_micro.py:344-364)
@@ -318,6 +379,7 @@ size_t plan(gtcrn_trainer* t, int B, int T, float* base) {
     t->taps["de3"] = {t->de3.a, {T, 65, 16}};
     t->taps["de4"] = {t->de4.a, {T, 129, 2}};
     // ---- backward buffers
+    const size_t bwd_begin = b.used;
     t->gs0 = b.take(n65 * 16);
     for (int i = 1; i < 5; ++i) t->gs[i] = b.take(n33 * 16);
     t->q1 = b.take(n33 * 16); t->q2 = b.take(n33 * 16);
@@ -335,7 +397,111 @@ size_t plan(gtcrn_trainer* t, int B, int T, float* base) {
     static_assert(129 * 3 <= 33 * 16 && 129 * 2 <= 33 * 16, "dm / df0 must fit in q1");
     t->dm = t->q1;
     t->df0 = t->q1;
-    return b.used;
+    if (!t->exact) return b.used;
+    // ---- exact chain: the fp32 twins, in forward order, each alive from its producer to its last forward reader
+    ChainPool cp;
+    float* cbase = base ? base + bwd_begin : nullptr;
+    auto get = [&](size_t n) -> float* {
+        const size_t o = cp.get(n);
+        return cbase ? cbase + o : reinterpret_cast<float*>(sizeof(float) * (o + 64));     // (size query: a fake, distinct address)
+    };
+    auto put = [&](const float* p, size_t n) {
+        const float* b0 = cbase ? cbase : reinterpret_cast<const float*>(sizeof(float) * 64);
+        cp.put((size_t)(p - b0), n);
+    };
+    const size_t N129 = (size_t)n129 * 3, N65 = (size_t)n65 * 16, N33 = (size_t)n33 * 16;
+    t->ebc = get(N129);
+    t->f0c = get(N129);
+    put(t->ebc, N129);                                              // feat -> SFE
+    auto plain_unit = [&](Unit& u, const float* xin, size_t ny, size_t nxin, bool free_in) {
+        u.xc = xin;
+        u.yc = get(ny);
+        if (free_in) put(xin, nxin);
+        u.ac = get(ny);
+        put(u.yc, ny);
+    };
+    plain_unit(t->en0, t->f0c, N65, N129, true);                    // en0.ac lives until s4
+    plain_unit(t->en1, t->en0.ac, N33, N65, false);                 // en1.ac lives until s3
+    auto gt_chain = [&](GtBlock& k, const float* xin, bool deconv) {
+        const size_t nt16 = (size_t)(deconv ? n33x : n33) * 16, nt8 = nt16 / 2;
+        k.xinc = xin;
+        k.pc1.xc = xin;
+        k.pc1.yc = get(N33);
+        k.pc1.ac = get(N33);
+        put(k.pc1.yc, N33);
+        k.depth.xc = k.pc1.ac;
+        k.depth.yc = get(nt16);
+        put(k.pc1.ac, N33);
+        if (!k.depth.deferred) { k.depth.ac = get(nt16); put(k.depth.yc, nt16); } else k.depth.ac = nullptr;
+        k.pc2.xc = k.depth.deferred ? nullptr : k.depth.ac;
+        k.pc2.yc = get(nt8);
+        if (k.depth.deferred) put(k.depth.yc, nt16); else put(k.depth.ac, nt16);
+        k.pc2.ac = get(nt8);
+        put(k.pc2.yc, nt8);
+        k.outc = get(N33);
+        put(k.pc2.ac, nt8);
+    };
+    const float* Xc = t->en1.ac;
+    for (int k = 0; k < 3; ++k) {                                   // the encoder outputs live until the decoder's adds
+        gt_chain(t->enc[k], Xc, false);
+        Xc = t->enc[k].outc;
+    }
+    {
+        const float* Xin = Xc;                                      // fp32 input of the block being laid out
+        for (int i = 0; i < 8; ++i) {
+            TcnBlock& k = t->tcn[i];
+            if (k.c1.pre) {
+                // conv1 finishes the previous block: it reads that block's conv3 output and residual input and writes
+                // its activation -- this block's input and residual -- in both forms
+                Unit& pv = t->tcn[i - 1].c3;
+                pv.ac = get(N33);
+                k.c1.yc = get(N33);
+                put(pv.yc, N33);
+                if (i - 1 > 0) put(pv.resc, N33);                   // (block 0's input is enc[2].outc: a skip, it stays)
+                Xin = pv.ac;
+                k.c1.xc = nullptr;
+            } else {
+                k.c1.xc = Xin;
+                k.c1.yc = get(N33);
+            }
+            k.c3.resc = Xin;
+            auto next_unit = [&](Unit& u, Unit& v) {                // u reads v: fused v.yc, else v.ac
+                if (!v.deferred) { v.ac = get(N33); put(v.yc, N33); }
+                u.xc = v.deferred ? nullptr : v.ac;
+                u.yc = get(N33);
+                put(v.deferred ? v.yc : v.ac, N33);
+            };
+            next_unit(k.c2, k.c1);
+            next_unit(k.c3, k.c2);
+            if (!k.c3.deferred) {                                   // its own bn_act pass (the last block; or no fusion)
+                k.c3.ac = get(N33);
+                put(k.c3.yc, N33);
+                if (i > 0) put(Xin, N33);
+                Xin = k.c3.ac;
+            }
+        }
+        Xc = Xin;
+    }
+    for (int i = 0; i < 3; ++i) {
+        GtBlock& k = t->dec[i];
+        t->dec_in[i] = Xc;
+        k.sc = get(N33);
+        put(Xc, N33);
+        put(t->enc[2 - i].outc, N33);
+        gt_chain(k, k.sc, true);
+        put(k.sc, N33);
+        Xc = k.outc;
+    }
+    t->s3c = get(N33);
+    put(Xc, N33);
+    put(t->en1.ac, N33);
+    plain_unit(t->de3, t->s3c, N65, N33, true);
+    t->s4c = get(N65);
+    put(t->de3.ac, N65);
+    put(t->en0.ac, N65);
+    plain_unit(t->de4, t->s4c, (size_t)n129 * 2, N65, true);
+    put(t->de4.ac, (size_t)n129 * 2);
+    return std::max(b.used, bwd_begin + cp.hi);
 }
 
 int ensure_plan(gtcrn_trainer* t, int B, int T) {
@@ -359,9 +525,48 @@ int unit_fwd(gtcrn_trainer* t, Unit& u, float* prm, hipStream_t s) {
     float* bn = prm + u.o_bn;   // weight, bias, running_mean, running_var (consecutive in the blob)
     // bf16 storage: y is stored centred on the channel's batch mean of the previous step (the running mean before the
     // first one); the train-mode BatchNorm is shift invariant and bn_stats keeps the shift up to date
-    float* shift = t->ybf ? u.stats + 32 : nullptr;
+    float* shift = (t->ybf && !t->exact) ? u.stats + 32 : nullptr;
     if (shift && !t->shift_ready)
         T_HIP(hipMemcpyAsync(shift, bn + 2 * u.C, sizeof(float) * u.C, hipMemcpyDeviceToDevice, s));
+    if (t->exact) {
+        // bf16 saves, exact chain: the unit runs exactly as in fp32 storage on the chain's fp32 tensors; the 16-bit
+        // copies for the backward are second stores -- of the activation by whoever produces it, of the conv output y by
+        // whoever CONSUMES it (this unit's bn_act, or the next unit's normalise-on-load conv): centred on this step's
+        // mean and kept on the forward's side of the PReLU kink (gtt::BnPre::y_out, bn_act's y2)
+        if (u.pre) {
+            const Unit& v = *u.pre;
+            const float* vbn = prm + v.o_bn;
+            gtt::BnPre bp{};
+            bp.stats = v.stats; bp.gamma = vbn; bp.beta = vbn + v.C;
+            bp.slope = v.o_slope >= 0 ? prm + v.o_slope : nullptr;
+            bp.a_out = v.a; bp.ybf = 0; bp.bf = t->bf;
+            bp.res = v.resc;
+            bp.exact = 1; bp.a_chain = v.ac; bp.y_out = v.y; bp.ybf_out = t->ybf;
+            if (u.dw) {
+                DwGeom g = u.dg;
+                g.in_bf = 0; g.out_bf = 0;
+                T_RUN(gtt::dw_fwd(g, v.yc, prm + u.o_w, prm + u.o_b, u.yc, s, t->dscratch, &parts, nullptr, &bp));
+            } else {
+                ConvGeom g = u.cg;
+                g.in_bf = 0; g.out_bf = 0;
+                T_RUN(gtt::conv_fwd(g, v.yc, prm + u.o_w, prm + u.o_b, u.yc, s, t->dscratch, &parts, nullptr, &bp));
+            }
+        } else if (u.dw) {
+            DwGeom g = u.dg;
+            g.in_bf = 0; g.out_bf = 0;
+            T_RUN(gtt::dw_fwd(g, u.xc, prm + u.o_w, prm + u.o_b, u.yc, s, t->dscratch, &parts));
+        } else {
+            ConvGeom g = u.cg;
+            g.in_bf = 0; g.out_bf = 0;
+            T_RUN(gtt::conv_fwd(g, u.xc, prm + u.o_w, prm + u.o_b, u.yc, s, t->dscratch, &parts));
+        }
+        T_RUN(gtt::bn_stats(u.yc, u.n, u.C, u.stats, bn + 2 * u.C, bn + 3 * u.C, t->dscratch, s, parts, 0, nullptr,
+                            u.stats + 64));
+        if (!u.deferred)
+            T_RUN(gtt::bn_act(u.yc, u.n, u.C, u.stats, bn, bn + u.C, u.resc, u.act, u.o_slope >= 0 ? prm + u.o_slope : nullptr,
+                              u.ac, s, 0, 0, u.a, t->bf, u.y, t->ybf));
+        return 0;
+    }
     if (u.pre) {
         const Unit& v = *u.pre;
         const float* vbn = prm + v.o_bn;
@@ -404,13 +609,13 @@ int unit_bwd(gtcrn_trainer* t, Unit& u, const float* prm, float* grads, const fl
     gtt::DwUnitNext nx{};
     if (ride) {
         const float* fbn = prm + f->o_bn;
-        nx.y = f->y; nx.stats = f->stats; nx.gamma = fbn; nx.beta = fbn + f->C; nx.slope = prm + f->o_slope;
+        nx.y = f->y; nx.stats = f->bstats; nx.gamma = fbn; nx.beta = fbn + f->C; nx.slope = prm + f->o_slope;
         nx.res = f->res;
     }
     if (!u.dw && u.cg.nkt == 1 && u.cg.nkf == 1 && u.cg.sf == 1 && (u.cg.Cin % 4) == 0 && (u.cg.Cout % 4) == 0) {
         // pointwise unit: BatchNorm backward, data gradient and weight gradient in one pass (after the reduction)
         int parts = 0;
-        T_RUN(gtt::unit1x1_bwd(u.cg, u.x, u.y, da, u.res, u.stats, bn, bn + u.C, u.act,
+        T_RUN(gtt::unit1x1_bwd(u.cg, u.x, u.y, da, u.res, u.bstats, bn, bn + u.C, u.act,
                                u.o_slope >= 0 ? prm + u.o_slope : nullptr, prm + u.o_w, dx, dx_acc, dres, dres_acc,
                                grads + u.o_w, u.o_b >= 0 ? grads + u.o_b : nullptr, gbn, gbn + u.C,
                                u.o_slope >= 0 ? grads + u.o_slope : nullptr, t->dscratch, t->fscratch, s, t->bf,
@@ -423,13 +628,13 @@ int unit_bwd(gtcrn_trainer* t, Unit& u, const float* prm, float* grads, const fl
         // TCN conv2: dy, weight gradient and data gradient in one pass; conv1's reduction rides along
         const bool ride2 = ride && !f->res && f->n == u.n;
         int parts = 0;
-        T_RUN(gtt::dwunit_bwd(u.dg, u.x, u.y, da, u.stats, bn, bn + u.C, prm + u.o_slope, prm + u.o_w, dx,
+        T_RUN(gtt::dwunit_bwd(u.dg, u.x, u.y, da, u.bstats, bn, bn + u.C, prm + u.o_slope, prm + u.o_w, dx,
                               grads + u.o_w, u.o_b >= 0 ? grads + u.o_b : nullptr, gbn, gbn + u.C, grads + u.o_slope,
                               t->dscratch, t->fscratch, s, t->bf, t->ybf, ride2 ? &nx : nullptr, &parts, have_parts));
         if (ride2 && parts > 0) { t->red_unit = f; t->red_parts = parts; }
         return 0;
     }
-    T_RUN(gtt::bn_act_bwd(da, u.y, u.n, u.C, u.stats, bn, bn + u.C, u.res, u.act,
+    T_RUN(gtt::bn_act_bwd(da, u.y, u.n, u.C, u.bstats, bn, bn + u.C, u.res, u.act,
                           u.o_slope >= 0 ? prm + u.o_slope : nullptr, t->dy, dres, dres_acc, gbn, gbn + u.C,
                           u.o_slope >= 0 ? grads + u.o_slope : nullptr, t->dscratch, s, t->bf, t->ybf, have_parts));
     if (u.dw) {
@@ -448,6 +653,11 @@ int gt_fwd(gtcrn_trainer* t, GtBlock& k, float* prm, hipStream_t s) {
     if ((rc = unit_fwd(t, k.depth, prm, s))) return rc;
     if ((rc = unit_fwd(t, k.pc2, prm, s))) return rc;
     const float* tr = prm + k.o_tra;   // depth_conv.weight[24], .bias[8], point_conv.weight[64], .bias[8]
+    if (t->exact) {
+        T_RUN(gtt::tra_fwd(k.pc2.ac, t->B, k.Tt, tr, tr + 24, tr + 32, tr + 96, k.e, k.yt, k.g, s, 0));
+        T_RUN(gtt::gate_shuffle_fwd(k.pc2.ac, k.g, k.xinc, t->B, t->T, k.Tt, k.outc, s, 0, k.out, t->bf));
+        return 0;
+    }
     T_RUN(gtt::tra_fwd(k.pc2.a, t->B, k.Tt, tr, tr + 24, tr + 32, tr + 96, k.e, k.yt, k.g, s, t->bf));
     T_RUN(gtt::gate_shuffle_fwd(k.pc2.a, k.g, k.xin, t->B, t->T, k.Tt, k.out, s, t->bf));
     return 0;
@@ -507,8 +717,11 @@ void gtcrn_trainer_destroy(gtcrn_trainer* t) {
 static int storage_formats(int storage, int* bf, int* ybf) {
     // 0: fp32 | 1: bf16.  (2, 3: diagnostics used while measuring where the bf16 gradient noise comes from -- bf16
     // activations with fp32 / centred-fp16 conv outputs; neither lowers it, the noise enters through the activations)
-    static const int F[4][2] = {{0, 0}, {1, 1}, {1, 0}, {1, 2}};
-    if (storage < 0 || storage > 3) return -1;
+    // 4: bf16 SAVES only -- what the backward re-reads is stored as in mode 1, but the forward chain itself stays fp32
+    // (every forward tensor is written twice): the forward IS the fp32 network's, the gradient differs from it only
+    // by the rounding of the saved tensors
+    static const int F[5][2] = {{0, 0}, {1, 1}, {1, 0}, {1, 2}, {1, 1}};
+    if (storage < 0 || storage > 4) return -1;
     *bf = F[storage][0];
     *ybf = F[storage][1];
     return 0;
@@ -517,6 +730,7 @@ static int storage_formats(int storage, int* bf, int* ybf) {
 long gtcrn_train_workspace_bytes2(int B, int T, int storage) {
     gtcrn_trainer tmp;
     if (storage_formats(storage, &tmp.bf, &tmp.ybf)) return -1;
+    tmp.exact = storage == 4;
     for (const auto& p : gtcrn::param_table()) tmp.off[p.name] = p.offset;
     return (long)(plan(&tmp, B, T, nullptr) * sizeof(float));
 }
@@ -525,10 +739,13 @@ long gtcrn_train_workspace_bytes(int B, int T) { return gtcrn_train_workspace_by
 int gtcrn_trainer_set_storage(gtcrn_trainer* t, int storage) {
     int bf = 0, ybf = 0;
     if (!t || storage_formats(storage, &bf, &ybf))
-        return tfail(GTCRN_ERR_ARG, "gtcrn_trainer_set_storage: storage must be 0 (fp32), 1 (bf16), 2 or 3");
-    if (t->bf != bf || t->ybf != ybf) {
+        return tfail(GTCRN_ERR_ARG, "gtcrn_trainer_set_storage: storage must be 0 (fp32), 1 (bf16), 4 (bf16 saves, fp32 "
+                                    "forward chain), or the diagnostic codes 2, 3");
+    const int exact = storage == 4;
+    if (t->bf != bf || t->ybf != ybf || t->exact != exact) {
         t->bf = bf;
         t->ybf = ybf;
+        t->exact = exact;
         t->planned = false;      // the arena is re-laid out on the next forward
         t->have_fwd = false;
     }
@@ -554,13 +771,20 @@ int gtcrn_train_forward(gtcrn_trainer* t, float* d_params, const float* d_spec, 
     int rc = ensure_plan(t, B, T);
     if (rc) return rc;
     float* prm = d_params;
-    T_RUN(gtt::feat_fwd(d_spec, sb, sf, st, B, T, prm + P(t, "erb.erb_fc.weight"), t->eb, s, t->bf));
+    const bool ex = t->exact != 0;
+    if (ex) T_RUN(gtt::feat_fwd(d_spec, sb, sf, st, B, T, prm + P(t, "erb.erb_fc.weight"), t->ebc, s, 0, t->eb, t->bf));
+    else T_RUN(gtt::feat_fwd(d_spec, sb, sf, st, B, T, prm + P(t, "erb.erb_fc.weight"), t->eb, s, t->bf));
     {   // SFE_Lite: Conv2d(3,3,(1,3),padding (0,1),groups 3,bias=False), weight [3][1][1][3]
         DwGeom g{};
         g.B = B; g.Tin = T; g.Tout = T; g.F = 129; g.C = 3; g.nkt = 1; g.nkf = 3;
         g.in_bf = g.out_bf = t->bf;
         g.f_off[0] = -1; g.f_off[1] = 0; g.f_off[2] = 1; g.w_c = 3; g.w_kt = 3; g.w_kf = 1;
-        T_RUN(gtt::dw_fwd(g, t->eb, prm + P(t, "sfe.depth_conv.weight"), nullptr, t->f0, s));
+        if (ex) {
+            g.in_bf = g.out_bf = 0; g.out2 = t->f0; g.out2_bf = t->bf;
+            T_RUN(gtt::dw_fwd(g, t->ebc, prm + P(t, "sfe.depth_conv.weight"), nullptr, t->f0c, s));
+        } else {
+            T_RUN(gtt::dw_fwd(g, t->eb, prm + P(t, "sfe.depth_conv.weight"), nullptr, t->f0, s));
+        }
     }
     if ((rc = unit_fwd(t, t->en0, prm, s))) return rc;
     if ((rc = unit_fwd(t, t->en1, prm, s))) return rc;
@@ -572,6 +796,21 @@ int gtcrn_train_forward(gtcrn_trainer* t, float* d_params, const float* d_spec, 
         if ((rc = unit_fwd(t, t->tcn[i].c3, prm, s))) return rc;
     }
     const long n33 = (long)B * T * 33 * 16, n65 = (long)B * T * 65 * 16;
+    if (ex) {
+        // the decoder's sums x + skip in fp32 (the backward recomputes its own from the 16-bit copies, see plan())
+        for (int i = 0; i < 3; ++i) {
+            T_RUN(gtt::add(t->dec_in[i], t->enc[2 - i].outc, t->dec[i].sc, n33, s));
+            if ((rc = gt_fwd(t, t->dec[i], prm, s))) return rc;
+        }
+        T_RUN(gtt::add(t->dec[2].outc, t->en1.ac, t->s3c, n33, s));
+        if ((rc = unit_fwd(t, t->de3, prm, s))) return rc;
+        T_RUN(gtt::add(t->de3.ac, t->en0.ac, t->s4c, n65, s));
+        if ((rc = unit_fwd(t, t->de4, prm, s))) return rc;
+        T_RUN(gtt::bs_mask_fwd(t->de4.ac, d_spec, sb, sf, st, B, T, prm + P(t, "erb.ierb_fc.weight"), d_out, ob, of, ot, s, 0));
+        t->have_fwd = true;
+        t->shift_ready = true;
+        return 0;
+    }
     const float* X = t->tcn[7].c3.a;
     for (int i = 0; i < 3; ++i) {     // Decoder.forward: x = de_convs[i](x + en_outs[4 - i]) (models/gtcrn_micro.py:463-469)
         T_RUN(gtt::add_saved(X, t->enc[2 - i].out, t->dec[i].s, n33, s, t->bf));

@@ -29,15 +29,15 @@ struct ConvGeom {
     int accumulate;             // 1: add to the existing output instead of overwriting it
     int in_bf, out_bf;          // storage of `in` / `out`: 0 fp32, 1 bf16 (saved activations of the bf16 variant);
                                 // gradients are always fp32; out_bf excludes accumulate
-    // "bf16 saves, exact chain" storage (see Save2 below): a SECOND copy of the output in format out2_bf; `out` must
-    // then be fp32.  nullptr: none.
-    float* out2;
+    float* out2;                // (unused by the dense convs: see DwGeom)
     int out2_bf;
 };
-// Storage mode "bf16 saves, exact forward chain" (gtcrn_trainer_set_storage 4): every forward tensor is written TWICE --
-// the fp32 value the next layer reads (`out`: the forward is then the fp32 network, bit for bit) and the 16-bit copy the
-// backward re-reads (`out2`, centred by `shift` like the plain bf16 mode's).  The statistics a conv accumulates in its
-// epilogue are those of the fp32 values.  Only the forward kernels know about it; the backward is the bf16 mode's.
+// Storage mode "bf16 saves, exact forward chain" (gtcrn_trainer_set_storage 4): the forward runs on fp32 tensors exactly as
+// in mode 0 (it IS the fp32 network, bit for bit), and every tensor the backward re-reads is ALSO written as a 16-bit
+// copy: activations / block outputs / features by their producer (a second store), conv outputs y by their CONSUMER
+// (bn_act or the normalise-on-load conv), which knows this step's statistics and stores bf16(y - mean) on the same side
+// of the PReLU kink as the forward's value (ycopy_value in train_kernels.hip).  Only the forward kernels know about the
+// mode; the backward is the bf16 mode's, with statistics (0, invstd) for the centred copies.
 
 // Storage of the SAVED tensors (conv outputs, activations, block outputs -- everything the backward re-reads):
 // the format arguments of the functions below (`bf`: activations / block outputs, `ybf`: conv outputs in front of a
@@ -54,8 +54,8 @@ struct DwGeom {
     int w_c, w_kt, w_kf;
     int accumulate;
     int in_bf, out_bf;
-    float* out2;                // second copy of the output (see ConvGeom)
-    int out2_bf;
+    float* out2;                // exact chain: second copy of the output in format out2_bf (`out` is fp32 then); the
+    int out2_bf;                // 3-channel SFE conv only (its output is a conv input the backward re-reads, no BatchNorm)
 };
 
 enum Act { ACT_NONE = 0, ACT_PRELU = 1, ACT_TANH = 2 };
@@ -77,10 +77,13 @@ struct BnPre {
     float* a_out;
     int ybf, bf;
     const float* res;                            // its residual input (format bf) or nullptr; pointwise convs only
-    // exact chain (ConvGeom::out2): the activation enters the convolution UNROUNDED, a_out still receives its 16-bit
-    // copy, a_chain (optional) the fp32 value for the other readers of this activation (residual, skip); res is fp32
+    // exact chain: `in` is fp32, the activation enters the convolution UNROUNDED, a_out still receives its 16-bit copy,
+    // a_chain (optional) the fp32 value for the other readers of this activation (residual, skip), res is fp32; y_out
+    // (format ybf_out) receives the centred 16-bit copy of the previous unit's conv output for the backward
     int exact;
     float* a_chain;
+    float* y_out;
+    int ybf_out;
 };
 int conv_fwd(const ConvGeom& g, const float* in, const float* w, const float* bias, float* out, hipStream_t s,
              double* stat_partial = nullptr, int* stat_parts = nullptr, const float* shift = nullptr,
@@ -97,15 +100,15 @@ int dw_wgrad(const DwGeom& g, const float* in, const float* dout, float* dw, flo
 
 // BatchNorm (train mode) of y [n][C]: batch statistics, running-statistics update (momentum 0.1, unbiased
 // variance), stats[0..C) = mean, stats[C..2C) = 1/sqrt(var + 1e-5).  scratch: MAX_PARTIALS * 2 * C doubles.
-// stats_b (exact chain only; the statistics are then those of the UNSHIFTED fp32 tensor while the backward's 16-bit copy
-// holds y - shift): receives mean - shift (the mean of the stored copy) and invstd -- what the backward kernels take as
-// `stats` -- before shift is moved to this step's mean.
+// stats_b (exact chain only): the statistics the BACKWARD uses for the 16-bit copy of y, which its consumer writes as
+// bf16(y - mean): (0, invstd).
 int bn_stats(const float* y, long n, int C, float* stats, float* running_mean, float* running_var, double* scratch,
              hipStream_t s, int have_parts = 0, int bf = 0, float* shift = nullptr, float* stats_b = nullptr);
-// a = act(gamma * (y - mean) * invstd + beta [+ res]); a2 (optional, format a2_bf): second copy of a (exact chain)
+// a = act(gamma * (y - mean) * invstd + beta [+ res]); exact chain: a2 (format a2_bf) = second copy of a, y2 (format
+// y2_bf) = the centred copy of y for the backward
 int bn_act(const float* y, long n, int C, const float* stats, const float* gamma, const float* beta,
            const float* res, int act, const float* slope, float* a, hipStream_t s, int bf = 0, int ybf = 0,
-           float* a2 = nullptr, int a2_bf = 0);
+           float* a2 = nullptr, int a2_bf = 0, float* y2 = nullptr, int y2_bf = 0);
 // backward of the same: given da, writes dy (may alias da); if dres != nullptr: dres (+)= dz (dres_acc: add);
 // dgamma/dbeta [C], dslope [1] (PReLU) are WRITTEN.  scratch: MAX_PARTIALS * 3 * C doubles + 2 * C floats.
 int bn_act_bwd(const float* da, const float* y, long n, int C, const float* stats, const float* gamma,

@@ -201,7 +201,7 @@ __global__ __launch_bounds__(NT) void k_conv(ConvGeom g, const float* __restrict
         const int to = (int)(bt % g.Tout), b = (int)(bt / g.Tout);
         float acc[COUT];
 #pragma unroll
-        for (int co = 0; co < COUT; ++co) acc[co] = (bias ? bias[co] : 0.f) - ((shift && !g.out2) ? shift[co] : 0.f);
+        for (int co = 0; co < COUT; ++co) acc[co] = (bias ? bias[co] : 0.f) - (shift ? shift[co] : 0.f);
         for (int kt = 0; kt < g.nkt; ++kt) {
             const int ti = to + g.t_off[kt];
             if (ti < 0 || ti >= g.Tin) continue;
@@ -217,13 +217,7 @@ __global__ __launch_bounds__(NT) void k_conv(ConvGeom g, const float* __restrict
                     for (int co = 0; co < COUT; ++co) acc[co] = fmaf(wt[ci * COUT + co], xv[ci], acc[co]);
             }
         }
-        if (g.out2) {      // exact chain: fp32 for the next layer, the centred 16-bit copy for the backward
-#pragma unroll
-            for (int co = 0; co < COUT; ++co) {
-                out[p * g.CoutT + g.cout_off + co] = acc[co];
-                sst1(g.out2, p * g.CoutT + g.cout_off + co, g.out2_bf, acc[co] - (shift ? shift[co] : 0.f));
-            }
-        } else if (g.out_bf) {
+        if (g.out_bf) {
 #pragma unroll
             for (int co = 0; co < COUT; ++co) sst1(out, p * g.CoutT + g.cout_off + co, g.out_bf, acc[co]);
         } else {
@@ -356,11 +350,51 @@ __device__ __forceinline__ PreConst pre_const(const BnPre& pre, int q, int C) {
     k.sl = k.act ? pre.slope[0] : 0.f;
     return k;
 }
+// Exact chain: the 16-bit copy of a conv output y that the BACKWARD re-reads, written by y's consumer (which knows this
+// step's statistics): yt = bf16(y - mean), i.e. centred exactly (the backward's statistics for it are mean 0, invstd),
+// and -- the part that matters -- on the SAME side of the PReLU kink as the forward's z: the backward recomputes
+// z = gamma * (yt * invstd) + beta [+ bf16(res)] from the copy, and where plain rounding would move it across zero
+// (a fraction ~1e-3 of the elements of a layer, each then wrong by (1 - slope) * da: 2-3 % of the layer's gradient in
+// relative L2, ~5 % over the depth of the network -- measured) the neighbouring bf16 value is stored instead.
+__device__ __forceinline__ float bf16_step(float v, bool up) {       // next bf16 value above / below v (v is a bf16 value)
+    unsigned u = __float_as_uint(v);
+    if ((u << 1) == 0) return __uint_as_float(up ? 0x00010000u : 0x80010000u);
+    const bool neg = (u >> 31) != 0;
+    u = (up != neg) ? u + 0x10000u : u - 0x10000u;
+    return __uint_as_float(u);
+}
+__device__ __forceinline__ float ycopy_value(float y, float z, float mean, float istd, float gm, float bt, bool has_res,
+                                             float res, int bf, bool kink) {
+    float yt = round16(y - mean, bf);
+    if (kink && bf == 1) {
+        const float rt = has_res ? round16(res, bf) : 0.f;            // what the backward will load as the residual
+        auto zb = [&](float v) { float q = gm * ((v - 0.f) * istd) + bt; if (has_res) q += rt; return q; };
+        if ((zb(yt) > 0.f) != (z > 0.f)) {
+            const float up = bf16_step(yt, true), dn = bf16_step(yt, false);
+            if ((zb(up) > 0.f) == (z > 0.f)) yt = up;
+            else if ((zb(dn) > 0.f) == (z > 0.f)) yt = dn;
+        }
+    }
+    return yt;
+}
 // the previous unit's activation, handed on by a normalise-on-load conv: rounded 16-bit copy for the backward (always),
 // and in the exact-chain mode the fp32 value for the activation's other readers
 __device__ __forceinline__ void pre_store(const BnPre& pre, long idx, const f32x4 a) {
     sst4<kNtSt>(pre.a_out, idx, pre.bf, a);
     if (pre.exact && pre.a_chain) sst4<kNtSt>(pre.a_chain, idx, 0, a);
+}
+// ... and, exact chain, the centred copy of the previous unit's conv output y (see ycopy_value)
+__device__ __forceinline__ void pre_store_y(const BnPre& pre, const PreConst& k, long idx, const f32x4 y, bool has_res,
+                                            const f32x4 r) {
+    if (!pre.exact || !pre.y_out) return;
+    f32x4 t;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        float z = k.gm[e] * ((y[e] - k.mean[e]) * k.istd[e]) + k.bt[e];
+        if (has_res) z += r[e];
+        t[e] = ycopy_value(y[e], z, k.mean[e], k.istd[e], k.gm[e], k.bt[e], has_res, r[e], pre.ybf_out, k.act);
+    }
+    sst4<kNtSt>(pre.y_out, idx, pre.ybf_out, t);
 }
 __device__ __forceinline__ f32x4 pre_apply(const PreConst& k, const f32x4 y, int bf, bool has_res = false,
                                            const f32x4 r = f32x4{0.f, 0.f, 0.f, 0.f}) {
@@ -467,11 +501,7 @@ __global__ __launch_bounds__(NT) void k_conv_mfma(ConvGeom g, const float* __res
     }
     f32x4 bv = {0.f, 0.f, 0.f, 0.f};
     if (bias && 4 * q < g.Cout) bv = *reinterpret_cast<const f32x4*>(bias + 4 * q);
-    f32x4 sh2 = {0.f, 0.f, 0.f, 0.f};        // exact chain: the shift centres the 16-bit copy only
-    if (shift && 4 * q < g.Cout) {
-        if (g.out2) sh2 = *reinterpret_cast<const f32x4*>(shift + 4 * q);
-        else bv -= *reinterpret_cast<const f32x4*>(shift + 4 * q);
-    }
+    if (shift && 4 * q < g.Cout) bv -= *reinterpret_cast<const f32x4*>(shift + 4 * q);
     const bool cin_ok = 4 * q < g.Cin, cout_ok = 4 * q < g.Cout;
     PreConst pk{};
     if constexpr (PRE) pk = pre_const(pre, q, g.CinT);
@@ -513,8 +543,12 @@ __global__ __launch_bounds__(NT) void k_conv_mfma(ConvGeom g, const float* __res
         for (int tap = 0; tap < NKT * NKF; ++tap) {
             f32x4 d = dec4<FIN>(raw[tap]);
             if constexpr (PRE) {
+                const f32x4 yraw = d;
                 d = pre_apply(pk, d, pre.exact ? 0 : pre.bf, pre.res != nullptr, pres);
-                if (okv[tap]) pre_store(pre, pidx, d);
+                if (okv[tap]) {
+                    pre_store(pre, pidx, d);
+                    pre_store_y(pre, pk, pidx, yraw, pre.res != nullptr, pres);
+                }
             }
             const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
             const f32x4 xv = okv[tap] ? d : zero;
@@ -524,10 +558,7 @@ __global__ __launch_bounds__(NT) void k_conv_mfma(ConvGeom g, const float* __res
         }
         }
         if (pv && cout_ok) {
-            if (g.out2) {     // exact chain: fp32 for the next layer (and the statistics), centred 16-bit copy for the backward
-                sst4<kNtSt>(out, p * g.CoutT + g.cout_off + 4 * q, 0, acc);
-                sst4<kNtSt>(g.out2, p * g.CoutT + g.cout_off + 4 * q, g.out2_bf, acc - sh2);
-            } else if (g.out_bf) {
+            if (g.out_bf) {
                 acc = round_bf4(acc, g.out_bf);   // the statistics are those of the STORED tensor (the backward re-reads it)
                 sst4<kNtSt>(out, p * g.CoutT + g.cout_off + 4 * q, g.out_bf, acc);
             } else {
@@ -589,11 +620,7 @@ __global__ __launch_bounds__(NT, 4) void k_conv_win_fma(ConvGeom g, const float*
     P.init(((long)blockIdx.x * NT + tid) >> 2, g.Fout, g.Tout);
     f32x4 bv = {0.f, 0.f, 0.f, 0.f};
     if (bias) bv = *reinterpret_cast<const f32x4*>(bias + 4 * q);
-    f32x4 sh2 = {0.f, 0.f, 0.f, 0.f};        // exact chain: the shift centres the 16-bit copy only
-    if (shift) {
-        if (g.out2) sh2 = *reinterpret_cast<const f32x4*>(shift + 4 * q);
-        else bv -= *reinterpret_cast<const f32x4*>(shift + 4 * q);
-    }
+    if (shift) bv -= *reinterpret_cast<const f32x4*>(shift + 4 * q);
     for (long i = (long)blockIdx.x * NT + tid; i < units; i += (long)gridDim.x * NT) {
         const long p = i >> 2;
         const int e0 = (P.fo * g.sf - g.pf) * g.Cin;
@@ -625,10 +652,7 @@ __global__ __launch_bounds__(NT, 4) void k_conv_win_fma(ConvGeom g, const float*
             for (int e = 0; e < 4; ++e) acc[e] = fmaf(wt[e], x[j], acc[e]);
         }
         P.advance(it, g.Fout, g.Tout);
-        if (g.out2) {
-            sst4<kNtSt>(out, p * 16 + 4 * q, 0, acc);
-            sst4<kNtSt>(g.out2, p * 16 + 4 * q, g.out2_bf, acc - sh2);
-        } else if (g.out_bf) {
+        if (g.out_bf) {
             acc = round_bf4(acc, g.out_bf);
             sst4<kNtSt>(out, p * 16 + 4 * q, g.out_bf, acc);
         } else {
@@ -1037,7 +1061,7 @@ __global__ __launch_bounds__(NT) void k_dw16(DwGeom g, const float* __restrict__
         const long p = i >> 2;
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
         if (bias) acc = *reinterpret_cast<const f32x4*>(bias + 4 * q);
-        if (shift && !g.out2) acc -= *reinterpret_cast<const f32x4*>(shift + 4 * q);
+        if (shift) acc -= *reinterpret_cast<const f32x4*>(shift + 4 * q);
         if constexpr (NKT > 0) {
             // every tap's load is issued before the first multiply-add (a tap outside the tensor loads the centre
             // record instead and is skipped by a select: one basic block, NKT * NKF loads in flight per thread instead
@@ -1061,8 +1085,12 @@ __global__ __launch_bounds__(NT) void k_dw16(DwGeom g, const float* __restrict__
             for (int tp = 0; tp < NKT * NKF; ++tp) {
                 if constexpr (FIN >= 0) xv[tp] = dec4<FR>(xr[tp]);
                 if constexpr (PRE) {
+                    const f32x4 yraw = xv[tp];
                     xv[tp] = pre_apply(pk, xv[tp], pre.exact ? 0 : pre.bf);
-                    if (tp == (NKT - 1) * NKF + NKF / 2) pre_store(pre, p * 16 + 4 * q, xv[tp]);
+                    if (tp == (NKT - 1) * NKF + NKF / 2) {
+                        pre_store(pre, p * 16 + 4 * q, xv[tp]);
+                        pre_store_y(pre, pk, p * 16 + 4 * q, yraw, false, f32x4{0.f, 0.f, 0.f, 0.f});
+                    }
                 }
                 const f32x4 wt = *reinterpret_cast<const f32x4*>(sW + tp * 16 + 4 * q);
                 const f32x4 nx = acc + wt * xv[tp];
@@ -1082,12 +1110,7 @@ __global__ __launch_bounds__(NT) void k_dw16(DwGeom g, const float* __restrict__
             }
         }
         P.advance(it, g.F, g.Tout);
-        if (g.out2) {      // exact chain (see k_conv_mfma)
-            sst4<kNtSt>(out, p * 16 + 4 * q, 0, acc);
-            f32x4 c2 = acc;
-            if (shift) c2 -= *reinterpret_cast<const f32x4*>(shift + 4 * q);
-            sst4<kNtSt>(g.out2, p * 16 + 4 * q, g.out2_bf, c2);
-        } else if (g.out_bf) {
+        if (g.out_bf) {
             acc = round_bf4(acc, g.out_bf);
             sst4<kNtSt>(out, p * 16 + 4 * q, g.out_bf, acc);
         } else {
@@ -1205,9 +1228,9 @@ __global__ __launch_bounds__(1024) void k_bn_stats_finish(const double* __restri
     stats[c] = (float)mean;
     stats[C + c] = (float)(1.0 / sqrt(var + 1e-5));
     if (stats_b) {
-        // exact chain: the sums are those of the UNSHIFTED fp32 tensor; the backward's copy holds y - shift[c], whose
-        // mean is mean - shift[c] (the same float expression the stores used would give it to within the copy's rounding)
-        stats_b[c] = (float)(mean - (double)(shift ? shift[c] : 0.f));
+        // exact chain: the backward's 16-bit copy of this tensor is written by its consumer as bf16(y - stats[c]):
+        // centred on THIS step's mean, so the backward's statistics for it are mean 0 and the same invstd
+        stats_b[c] = 0.f;
         stats_b[C + c] = stats[C + c];
     }
     if (rmean) {
@@ -1231,7 +1254,7 @@ __global__ __launch_bounds__(NT) void k_bn_act(const float* __restrict__ y, long
                                               const float* __restrict__ stats, const float* __restrict__ gamma,
                                               const float* __restrict__ beta, const float* __restrict__ res, int act,
                                               const float* __restrict__ slope, float* __restrict__ a, int bf, int ybf,
-                                              float* __restrict__ a2, int a2_bf) {
+                                              float* __restrict__ a2, int a2_bf, float* __restrict__ y2, int y2_bf) {
     const float sl = slope ? slope[0] : 0.f;
     const long units = total / V;
     // the stride is a multiple of C: the thread's channels and their constants are fixed
@@ -1240,7 +1263,7 @@ __global__ __launch_bounds__(NT) void k_bn_act(const float* __restrict__ y, long
 #pragma unroll
     for (int e = 0; e < V; ++e) { mean[e] = stats[c0 + e]; istd[e] = stats[C + c0 + e]; gm[e] = gamma[c0 + e]; bt[e] = beta[c0 + e]; }
     for (long i = (long)blockIdx.x * NT + threadIdx.x; i < units; i += (long)gridDim.x * NT) {
-        float x[V], r[V], o[V];
+        float x[V], r[V], o[V], yt[V];
         load_vec_s<V, kNt>(y, i * V, ybf, x);
         if (res) load_vec_s<V, kNt>(res, i * V, bf, r);
 #pragma unroll
@@ -1249,6 +1272,12 @@ __global__ __launch_bounds__(NT) void k_bn_act(const float* __restrict__ y, long
             float z = gm[e] * ((x[e] - mean[e]) * istd[e]) + bt[e];
             if (res) z += r[e];
             o[e] = act_fwd(z, act, sl);
+            if (y2) yt[e] = ycopy_value(x[e], z, mean[e], istd[e], gm[e], bt[e], res != nullptr, res ? r[e] : 0.f, y2_bf,
+                                        act == ACT_PRELU);
+        }
+        if (y2) {          // exact chain: the centred, kink-consistent 16-bit copy of y for the backward
+            if constexpr (V == 4) sst4<kNtSt>(y2, i * 4, y2_bf, f32x4{yt[0], yt[1], yt[2], yt[3]});
+            else sst1(y2, i, y2_bf, yt[0]);
         }
         if constexpr (V == 4) sst4<kNtSt>(a, i * 4, bf, f32x4{o[0], o[1], o[2], o[3]});
         else sst1(a, i, bf, o[0]);
@@ -2392,8 +2421,8 @@ static bool win_wgrad_ok(const ConvGeom& g) {
 
 int conv_fwd(const ConvGeom& g, const float* in, const float* w, const float* bias, float* out, hipStream_t s,
              double* stat_partial, int* stat_parts, const float* shift, const BnPre* pre) {
-    if (shift && !g.out_bf && !g.out2) return (int)hipErrorInvalidValue;
-    if (g.out2 && (g.out_bf || g.accumulate)) return (int)hipErrorInvalidValue;   // exact chain: fp32 `out`, plain store
+    if (shift && !g.out_bf) return (int)hipErrorInvalidValue;
+    if (g.out2) return (int)hipErrorInvalidValue;      // (a second output copy: the 3-channel depthwise conv only)
     if (stat_parts) *stat_parts = 0;
     const BnPre nopre{};
     if (pre && !(mfma_ok(g) && g.nkt == 1 && g.nkf == 1 && g.sf == 1 && g.Cin == 16 && g.CinT == 16 && g.cin_off == 0 &&
@@ -2509,8 +2538,8 @@ int conv_wgrad(const ConvGeom& g, const float* in, const float* dout, float* dw,
 
 int dw_fwd(const DwGeom& g, const float* in, const float* w, const float* bias, float* out, hipStream_t s,
            double* stat_partial, int* stat_parts, const float* shift, const BnPre* pre) {
-    if (shift && ((!g.out_bf && !g.out2) || g.C != 16)) return (int)hipErrorInvalidValue;
-    if (g.out2 && (g.out_bf || g.accumulate)) return (int)hipErrorInvalidValue;
+    if (shift && (!g.out_bf || g.C != 16)) return (int)hipErrorInvalidValue;
+    if (g.out2 && (g.out_bf || g.accumulate || g.C != 3)) return (int)hipErrorInvalidValue;
     if (stat_parts) *stat_parts = 0;
     const BnPre nopre{};
     if (pre && !(g.C == 16 && g.nkt == 3 && g.nkf == 1 && g.t_off[2] == 0 && g.f_off[0] == 0 && g.in_bf == pre->ybf &&
@@ -2600,14 +2629,14 @@ int bn_stats(const float* y, long n, int C, float* stats, float* running_mean, f
 
 int bn_act(const float* y, long n, int C, const float* stats, const float* gamma, const float* beta,
            const float* res, int act, const float* slope, float* a, hipStream_t s, int bf, int ybf, float* a2,
-           int a2_bf) {
+           int a2_bf, float* y2, int y2_bf) {
     const long total = n * C;
     if (C % 4 == 0)
         hipLaunchKernelGGL((k_bn_act<4>), dim3(grid_for(total / 4, 8192)), dim3(NT), 0, s, y, total, C, stats, gamma,
-                           beta, res, act, slope, a, bf, ybf, a2, a2_bf);
+                           beta, res, act, slope, a, bf, ybf, a2, a2_bf, y2, y2_bf);
     else
         hipLaunchKernelGGL((k_bn_act<1>), dim3(grid_for(total, 8192)), dim3(NT), 0, s, y, total, C, stats, gamma, beta,
-                           res, act, slope, a, bf, ybf, a2, a2_bf);
+                           res, act, slope, a, bf, ybf, a2, a2_bf, y2, y2_bf);
     return check();
 }
 

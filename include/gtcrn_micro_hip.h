@@ -229,8 +229,12 @@ void gtcrn_trainer_destroy(gtcrn_trainer *t);
 long gtcrn_train_workspace_bytes(int B, int T);   /* saved activations + gradient buffers (fp32 storage) */
 /* Storage of the SAVED activations (everything the backward re-reads): 0 = fp32, the reference's own precision
  * (train.py:239-288 trains in fp32); 1 = bf16 (BASELINE configs[3] asks for bf16: half the bytes of every pass of the
- * HBM-bound layer-at-a-time step).  Arithmetic, BatchNorm statistics, gradients, the gradient all-reduce, Adam and
- * the master weights stay fp32 in both.  Takes effect at the next forward. */
+ * HBM-bound layer-at-a-time step; the forward then IS the bf16-activation network: its consumers read the rounded
+ * values); 4 = bf16 SAVES with an exact forward chain: every forward tensor is written twice -- the fp32 value the next
+ * layer reads and the bf16 copy the backward re-reads -- so the output equals mode 0's bit for bit and the gradient
+ * differs from mode 0's only by the rounding of the saved tensors, at mode 1's workspace (the fp32 buffers of the chain
+ * are short-lived and share the backward's scratch region).  Arithmetic, BatchNorm statistics, gradients, the gradient
+ * all-reduce, Adam and the master weights stay fp32 in all modes.  Takes effect at the next forward. */
 int gtcrn_trainer_set_storage(gtcrn_trainer *t, int storage);
 long gtcrn_train_workspace_bytes2(int B, int T, int storage);
 /* Diagnostic: which pass fusions of the train step are active (default: all).  bit 0: BatchNorm + PReLU of a unit
