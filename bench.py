@@ -72,8 +72,12 @@ HBM_PEAK_GBS = 8000.0
 STREAM_STATE_BYTES_PER_FRAME = 94 * 1024        # ring-state traffic + the frame itself
 # counter-measured HBM traffic of one B = 512 x 4 s train step per storage mode (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE
 # passes, FETCH doubled for the 16-byte-per-lane reads; tools/profile_summary.py); a mode without counters reports null
-TRAIN_HBM_BYTES_PER_STEP = {"f32": 163.9e9}
-TRAIN_HBM_SOURCE = {"f32": "profiles/r03_train_hbm_traffic.json"}
+# (round 4: every storage mode, dispatch by dispatch.  The x2 on FETCH_SIZE is calibrated for 16-byte-per-lane reads; the
+# 16-bit tensors are read 8 bytes per lane, for which the guide gives no factor: for the two 16-bit modes the figure
+# below is the UPPER reading, `traffic_lower` the raw one -- the truth lies between)
+TRAIN_HBM_BYTES_PER_STEP = {"f32": 163.9e9, "bf16": 114.5e9, "bf16_saves": 150.2e9}
+TRAIN_HBM_BYTES_PER_STEP_LOWER = {"f32": 163.9e9, "bf16": 76.7e9, "bf16_saves": 105.5e9}
+TRAIN_HBM_SOURCE = {m: "profiles/r04_train_hbm_traffic.json" for m in ("f32", "bf16", "bf16_saves")}
 ROUND_TAG = "r04"
 WATCHDOG_EXIT_CODE = 3                                  # exit status of every rank when a watchdog had to cut a leg
 
@@ -489,6 +493,7 @@ def train_run(ctx, world, sync_all, max_over_ranks, steps=5, warmup=2):
     roof = None if hbm_bytes is None else {
         "bound": "hbm", "achieved": round(hbm_bytes / el / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
         "frac": round(hbm_bytes / el / 1e9 / HBM_PEAK_GBS, 4), "traffic": hbm_bytes,
+        "traffic_lower": TRAIN_HBM_BYTES_PER_STEP_LOWER[storage] * (B * T) / (512 * 251),
         "note": "whole train step: counter-measured HBM bytes per step (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, "
                 f"{TRAIN_HBM_SOURCE.get(storage)}) over this run's step time"}
     return {

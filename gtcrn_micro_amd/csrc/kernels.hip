@@ -35,6 +35,46 @@ __device__ __forceinline__ void copy_params(float* dst, const float* src, int n,
     for (int i = 4 * tid; i < n; i += 4 * nthr) st4(dst + i, ld4(src + i));
 }
 __device__ __forceinline__ f32x4 splat(float v) { f32x4 r = {v, v, v, v}; return r; }
+// Parameter segments -> LDS by LDS-DMA (global_load_lds_dwordx4): one instruction moves 1 KB (64 lanes x 16 bytes) from
+// per-lane global addresses to a wave-uniform LDS base, holds no registers while in flight and is counted in vmcnt, so a
+// later `s_waitcnt vmcnt(N)` + barrier publishes it.  (Inline asm: with the builtin the compiler would put vmcnt(0) in
+// front of the next LDS read; it does not know these instructions, so every wait IT inserts for a register load that
+// is issued later also drains them -- in-order return -- and a group must be issued behind the consumption of the
+// register loads it is meant to overlap with.)
+__device__ __forceinline__ void lds_dma_1k(const float* gsrc_lane, const float* lds_piece) {
+    const unsigned lds_dst = (unsigned)(size_t)(__attribute__((address_space(3))) const void*)lds_piece;
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(gsrc_lane), "s"(lds_dst)
+                 : "memory");
+}
+struct DmaSeg {
+    int src, dst, n;      // float offsets of the segment in the global parameter buffer / in LDS, floats (a multiple of 4)
+};
+// A GROUP of segments, cut into 1 KB pieces that are dealt round-robin to the NWAVES waves: every wave issues EXACTLY
+// PER_WAVE instructions (the counted waits need one number for all waves), a wave whose turn runs past the last piece
+// repeats piece 0 -- the same bytes to the same place.  The last piece of a segment is partial: its tail lanes sit out.
+template <int NSEG, int PER_WAVE, int NWAVES>
+__device__ __forceinline__ void lds_dma_group(const DmaSeg (&seg)[NSEG], const float* gbase, float* lbase, int wave, int lane) {
+    int total = 0;
+#pragma unroll
+    for (int k = 0; k < NSEG; ++k) total += (seg[k].n + 255) >> 8;
+#pragma unroll
+    for (int j = 0; j < PER_WAVE; ++j) {
+        int pi = wave + j * NWAVES;
+        if (pi >= total) pi = 0;
+        int src = 0, dst = 0, n = 0;
+#pragma unroll
+        for (int k = NSEG - 1; k >= 0; --k) {            // the segment piece pi falls into (pieces are numbered segment by segment)
+            int first = 0;
+#pragma unroll
+            for (int q = 0; q < k; ++q) first += (seg[q].n + 255) >> 8;
+            if (pi >= first && n == 0) { src = seg[k].src + (pi - first) * 256; dst = seg[k].dst + (pi - first) * 256; n = seg[k].n - (pi - first) * 256; }
+        }
+        if (4 * lane < n) lds_dma_1k(gbase + src + 4 * lane, lbase + dst);
+    }
+}
 
 // Workgroup barrier for LDS hand-offs only.  __syncthreads() carries a workgroup-scope release
 // fence, which on gfx950 drains vmcnt: every barrier would then wait for all global loads and
@@ -2960,13 +3000,21 @@ __global__ __launch_bounds__(NTHR) void k_stream_ms(const float* __restrict__ sp
     };
 
     // ------------------------------------------------------------------------------------------------- prologue
-    dense_fetch(0);
+    // Every parameter segment is resident in LDS for the whole step (86 KB); they arrive by LDS-DMA in the order of their
+    // first use, and only what the front end needs is waited for at the first barrier:
+    //   group A  encoder front end (ERB bands, SFE, en_convs.0/1: 9 KB)          -> waited for here (one piece per wave)
+    //   group B  the three encoder blocks                                         -> counted wait at the barrier behind en_conv1
+    //   group C  both GTCN stacks;  group D  decoder blocks, de_convs.3/4, ERB.bs table, block 0's dense planes
+    // B, C, D (7 pieces per wave) are issued BEHIND the consumption of this phase's register loads (spectrogram, first
+    // history rows, integer tables) and are in flight during the front end's four phases.
     static_assert(P_GTCN == P_ENC + ENC_SIZE && (ENC_SIZE + 2 * GTCN_SIZE) % 4 == 0, "encoder + GTCN segments are contiguous");
-    copy_params(sPE, PF + P_ENC, ENC_SIZE + 2 * GTCN_SIZE, tid, NTHR);
     constexpr bool SPLIT3 = SPLIT && kSplitDe3;
-    copy_dec_params<SPLIT3>(sPD, PF, tid, NTHR);
+    {
+        const DmaSeg ga[1] = {{P_ENC, LD::PE, E_BLK}};
+        static_assert((E_BLK + 255) / 256 <= NW, "group A: one piece per wave");
+        lds_dma_group<1, 1, NW>(ga, PF, smem, L.wave, L.lane);
+    }
     for (int i = tid; i < P_INTS - ENC_I_SKIP; i += NTHR) sI[i] = PI[i < I_BS_LO ? i : i + ENC_I_SKIP];
-    for (int f = tid; f < NBINS; f += NTHR) st4(sBS + f * 4, ld4(PF + P_DEC + D_BS_TAB + f * 4));
     if (tid < NS * 48) {
         const int sidx = tid / 48, e = tid - sidx * 48;
         sEHe[tid] = sidx < nlive ? stb[(long)sidx * ST_FLOATS + ST_ENC_E + e] : 0.f;
@@ -3025,7 +3073,26 @@ __global__ __launch_bounds__(NTHR) void k_stream_ms(const float* __restrict__ sp
             spec_item_next(t_fast, tl, f);
         }
     }
-    wg_barrier_vm();                                               // (also: parameters, tables and the dense planes are in LDS)
+    // groups B, C, D: behind the consumption of every register load above (see lds_dma_1k)
+    constexpr int DMA_B = 1, DMA_C = 2, DMA_D = 4;
+    {
+        const DmaSeg gb[1] = {{P_ENC + E_BLK, LD::PE + E_BLK, ENC_SIZE - E_BLK}};
+        const DmaSeg gc[1] = {{P_GTCN, LD::PG, 2 * GTCN_SIZE}};
+        const DmaSeg gd[7] = {{P_DEC + D_BLK + 0 * GBD_SIZE, LD::PD + 0 * GB_SIZE, GB_SIZE},
+                              {P_DEC + D_BLK + 1 * GBD_SIZE, LD::PD + 1 * GB_SIZE, GB_SIZE},
+                              {P_DEC + D_BLK + 2 * GBD_SIZE, LD::PD + 2 * GB_SIZE, GB_SIZE},
+                              {P_DEC + (SPLIT3 ? D_DE3_16 : D_DE3_AE), LD::PD + DL_DE3M, SPLIT3 ? DE3_16_MATS * 256 : 5 * 256},
+                              {P_DEC + D_DE3_B, LD::PD + DL_DE, D_BS_W - D_DE3_B},
+                              {P_DEC + D_BS_TAB, LD::BS, NBINS * 4},
+                              {P_DEC + (SPLIT ? D_DN16 : D_BLK + GB_DN_A), LD::PD + DL_DN, DN_PIECES * 256}};
+        static_assert((ENC_SIZE - E_BLK + 255) / 256 <= DMA_B * NW && (2 * GTCN_SIZE + 255) / 256 <= DMA_C * NW, "groups B, C");
+        static_assert(3 * ((GB_SIZE + 255) / 256) + (SPLIT3 ? DE3_16_MATS : 5) + (D_BS_W - D_DE3_B + 255) / 256 +
+                      (NBINS * 4 + 255) / 256 + DN_PIECES <= DMA_D * NW, "group D");
+        lds_dma_group<1, DMA_B, NW>(gb, PF, smem, L.wave, L.lane);
+        lds_dma_group<1, DMA_C, NW>(gc, PF, smem, L.wave, L.lane);
+        lds_dma_group<7, DMA_D, NW>(gd, PF, smem, L.wave, L.lane);
+    }
+    wg_barrier_vm<DMA_B + DMA_C + DMA_D>();                        // group A has landed; B, C, D stay in flight
     STAMP(SS, 0)
     {   // A: ERB.bm bands
         const int band = tid & (ERB_BANDS - 1);
@@ -3109,7 +3176,7 @@ __global__ __launch_bounds__(NTHR) void k_stream_ms(const float* __restrict__ sp
         x[0] = prelu4(x[0], a);
         en1p = permute_via_lds(sEB + tt.pp(0) * 16, ix, g, x[0]);
     }
-    wg_barrier();                                                  // E0 is dead: its region becomes W
+    wg_barrier_vm<DMA_C + DMA_D>();                                // E0 is dead: its region becomes W; group B (block parameters) has landed
     STAMP(SS, 4)
     zero_row_pads<RW, 16, 35>(sWe, tid);
     // GTCN history rows of the lane's position (k_gtcn_ms): requested during the last encoder block

@@ -13,7 +13,7 @@
 #                              fp32 train step
 # tools/profile_summary.py condenses them into the files committed under profiles/.
 set -u
-TAG=${1:-r03}
+TAG=${1:-r04}
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$R/gpurun_out/$TAG
 mkdir -p "$OUT"
@@ -32,9 +32,14 @@ rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_VALU_MFMA_COEXEC_CYCL
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stream" -- python3 "$R/tools/stream_bench.py" > "$OUT/stream.log" 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/train_f32" -- python3 "$R/bench.py" --mode train --steps 3 --warmup 1 > "$OUT/train_f32.log" 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/train_bf16" -- python3 "$R/bench.py" --mode train --train-storage bf16 --steps 3 --warmup 1 > "$OUT/train_bf16.log" 2>&1
-# HBM counters of the fp32 train step (tools/profile_summary.py -> profiles/<tag>_train_hbm_traffic.json)
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/train_bf16_saves" -- python3 "$R/bench.py" --mode train --train-storage bf16_saves --steps 3 --warmup 1 > "$OUT/train_bf16_saves.log" 2>&1
+# HBM counters of the train step, every storage mode (tools/profile_summary.py -> profiles/<tag>_train_hbm_traffic.json)
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$OUT/train_pmc_fetch" -- python3 "$R/bench.py" --mode train --steps 2 --warmup 1 > "$OUT/train_pmc_fetch.log" 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$OUT/train_pmc_write" -- python3 "$R/bench.py" --mode train --steps 2 --warmup 1 > "$OUT/train_pmc_write.log" 2>&1
+for M in bf16 bf16_saves; do
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$OUT/train_${M}_pmc_fetch" -- python3 "$R/bench.py" --mode train --train-storage $M --steps 2 --warmup 1 > "$OUT/train_${M}_pmc_fetch.log" 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$OUT/train_${M}_pmc_write" -- python3 "$R/bench.py" --mode train --train-storage $M --steps 2 --warmup 1 > "$OUT/train_${M}_pmc_write.log" 2>&1
+done
 grep -h '"metric"' "$OUT"/*.log | cut -c1-300
 cat "$OUT/ub_plain.log"
 find "$OUT" -name "*.csv" | wc -l
