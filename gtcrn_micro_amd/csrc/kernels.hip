@@ -761,7 +761,11 @@ __device__ __forceinline__ void ring_to_image(float* sW, const float* ring, int 
     }
 }
 
-template <bool DENSE, int TPW, bool MS, bool Q, int RS, int RSS, bool WIDE_TRA, int PT, int VMK = 0, class Hook, class Hook3>
+// VMK1 >= 0 (dense blocks of the fused streaming step): the DMA of this block's dense planes is waited for at the block's
+// FIRST barrier -- `s_waitcnt vmcnt(VMK1)`, VMK1 = the vector-memory operations EVERY wave has issued behind it -- instead
+// of at the previous block's closing barrier, which then waits for LDS only.
+template <bool DENSE, int TPW, bool MS, bool Q, int RS, int RSS, bool WIDE_TRA, int PT, int VMK = 0, int VMK1 = -1, class Hook,
+          class Hook3>
 __device__ __forceinline__ void gtconv_block(f32x4 (&x)[TPW], const Tiles<TPW>& tin, const BlockCtx& c,
                                              const Lane& L, Hook&& hook, Hook3&& hook3 STAMP_PARAM) {
     static_assert(!MS || TPW == 1, "multi-stream mode runs one tile per wave");
@@ -812,7 +816,12 @@ __device__ __forceinline__ void gtconv_block(f32x4 (&x)[TPW], const Tiles<TPW>& 
             }
         }
     }
-    wg_barrier();
+    // Fused streaming step, dense blocks: this block's dense planes were requested by LDS-DMA behind the PREVIOUS block's
+    // dense phase and are first read behind this barrier.  Vector-memory operations a wave has issued since: the two
+    // history loads of the next block (every wave issues both) and the new-row store above (live lanes only: not every
+    // wave) -- so "at most two outstanding" (VMK1 = 2) retires the DMA in every wave.
+    if constexpr (VMK1 >= 0) wg_barrier_vm<VMK1>();
+    else wg_barrier();
     STAMP(SS, 5)
     // ---- depth conv + BN + PReLU, then point_conv2 + BN in place over the x1 slots; one tile at a
     //      time so that the tap registers die with the tile (the partner waves on the SIMD fill the
@@ -977,6 +986,10 @@ __device__ __forceinline__ void gtconv_block(f32x4 (&x)[TPW], const Tiles<TPW>& 
     }
     wg_barrier();
     STAMP(SS, 6)
+    // (single-frame steps: hook3 -- the next block's history image, whose loads were requested a block ago -- runs FIRST:
+    // the waits the compiler puts in front of those registers also drain every vector-memory operation issued before
+    // them, and hook() is where the next block's dense planes go out by DMA)
+    if constexpr (MS) hook3();
     hook();
     // ---- history ring of h (after every wave has read its taps): the last two frames of the image ---------------
     if constexpr (MS) {
@@ -1005,79 +1018,122 @@ __device__ __forceinline__ void gtconv_block(f32x4 (&x)[TPW], const Tiles<TPW>& 
             else st4(dst, ld4(c.sW + pl<RS>((c.nfr + row) * PT + 1 + (r >> 2), r & 3)));
         }
     }
-    // ---- TRALite, step 1: energies e[t][c] = mean_F(v^2): 32 threads per frame = 8 h' channels x 4 bin
-    //      ranges (9, 9, 9, 6 bins); the four partial sums of a channel sit in one DPP quad and are
-    //      combined there in a fixed order (bit-reproducible).  Written to sE[2 + t][c]; rows 0,1 of sE
-    //      hold the two frames before the chunk (the block's energy ring) ---------------------------------
-    {
-        // (index arithmetic from an opaque copy of tid: recomputed per block instead of hoisted out of the block and
-        // chunk loops, kept live across the whole kernel and spilled -- a scratch reload drains every load in flight)
+    if constexpr (MS) {
+        // ---- TRALite of a single-frame step, ONE barrier interval.  Every image row is its own stream with ONE new
+        //      frame, so the energies of frames t-2, t-1 come from that stream's ring (sEHk), not from other threads: the
+        //      lane that holds a channel's total (part == 0 of its DPP quad) goes straight on to the causal conv1d, the
+        //      1x1 and the sigmoid -- the eight channels of a frame sit in one wave and meet through wave-private LDS.
+        //      Same sums in the same order, same expressions as the two-step form below: bit-identical gates.  (The
+        //      next block's history image -- hook3 -- has only to wait for this block's taps: it ran above.)
         int tz1 = L.tid;
         asm volatile("" : "+v"(tz1));
         const int part = tz1 & 3, rc = (tz1 >> 2) & 7, rt = tz1 >> 5;
         if (tz1 < c.nfr * 32) {
-            // nine independent loads per thread (the last range, bins 27..32, reads bins 24..32 and drops the first
-            // three), then the same ascending-bin summation as a 9 / 6-trip loop -- whose loads went out one by one
             float sum = 0.f;
-            if constexpr (WIDE_TRA) {
+            {
                 const float* sp = c.sS + (rt * 33 + (part == 3 ? 24 : part * 9)) * RSS + c.ib[rc];
                 float v[9];
 #pragma unroll
                 for (int f = 0; f < 9; ++f) v[f] = sp[f * RSS];
 #pragma unroll
                 for (int f = 0; f < 9; ++f) sum += (f < 3 && part == 3) ? 0.f : v[f];
-            } else {   // (the one instantiation with no registers to spare: the same sums from a loop)
-                const float* sp = c.sS + (rt * 33 + part * 9) * RSS + c.ib[rc];
-                const int cnt = part == 3 ? 6 : 9;
-                for (int f = 0; f < cnt; ++f) sum += sp[f * RSS];
             }
+            // the ring entries and this channel's parameters: requested beside the energy loads
+            const int tb = c.sTB[rt];
+            const float e2 = c.sEHk[rt * 48 + ((tb - 2) & 1) * 8 + rc], e1 = c.sEHk[rt * 48 + ((tb - 1) & 1) * 8 + rc];
             sum += dpp_ror<0xB1>(sum);   // quad_perm [1,0,3,2]
             sum += dpp_ror<0x4E>(sum);   // quad_perm [2,3,0,1]
-            if (part == 0) c.sE[(MS ? rt * 3 + 2 : 2 + rt) * 8 + rc] = sum * (1.0f / 33.0f);
-        } else if (MS && tz1 >= NTHR - 64) {    // an otherwise idle wave copies every stream's ring into its rows 0,1
-            const int q = tz1 - (NTHR - 64), sidx = q >> 4, r = (q >> 3) & 1, cc = q & 7;
-            if (sidx < c.nfr) c.sE[(sidx * 3 + r) * 8 + cc] = c.sEHk[sidx * 48 + ((c.sTB[sidx] - 2 + r) & 1) * 8 + cc];
-        } else if (!MS && tz1 >= NTHR - 16) {   // an otherwise idle wave copies the ring into rows 0,1
-            const int q = tz1 - (NTHR - 16), r = q >> 3, cc = q & 7;
-            c.sE[r * 8 + cc] = c.sEHk[((c.tabs - 2 + r) & 1) * 8 + cc];
-        }
-    }
-    wg_barrier();
-    // rows 0, 1 of the image are free (this block's ring save, which may read row 1, is behind the barrier): the next
-    // block's history goes there now, off the critical path
-    if constexpr (!MS) {
-        if (c.sHnext) ring_to_image<RS, PT, FMT>(c.sW, c.sHnext, L.tid);
-    }
-    hook3();   // (k_stream_ms: the next block's history image, its taps are all read)
-    // ---- step 2: one thread per (frame, output channel): causal depthwise conv1d (k=3) over the energies,
-    //      1x1 conv, sigmoid (models/gtcrn_micro.py:122-139) ------------------------------------------------
-    {
-        int tz2 = L.tid;
-        asm volatile("" : "+v"(tz2));
-        const int ro = tz2 & 7, rt = tz2 >> 3;
-        if (tz2 < c.nfr * 8) {
-            const float* e = c.sE + (MS ? rt * 24 : rt * 8) + ro;    // rows rt, rt+1, rt+2 = frames t-2, t-1, t
-            const float y = c.pb[GB_TRA_DB + ro] + c.pb[GB_TRA_DW + ro * 3] * e[0] +
-                            c.pb[GB_TRA_DW + ro * 3 + 1] * e[8] + c.pb[GB_TRA_DW + ro * 3 + 2] * e[16];
-            // the 8 channels of a frame sit in 8 adjacent lanes of one wave: exchange y through the
-            // scratch behind the gate table with wave-local ordering, no workgroup barrier
-            float* sy = c.sY + rt * 8;
-            sy[ro] = y;
-            wave_lds_sync();
-            float z = c.pb[GB_TRA_PB + ro];
+            if (part == 0) {
+                const int ro = rc;
+                const float e0 = sum * (1.0f / 33.0f);
+                const float y = c.pb[GB_TRA_DB + ro] + c.pb[GB_TRA_DW + ro * 3] * e2 +
+                                c.pb[GB_TRA_DW + ro * 3 + 1] * e1 + c.pb[GB_TRA_DW + ro * 3 + 2] * e0;
+                float* sy = c.sY + rt * 8;
+                sy[ro] = y;
+                wave_lds_sync();
+                float z = c.pb[GB_TRA_PB + ro];
 #pragma unroll
-            for (int cc = 0; cc < 8; ++cc) z += c.pb[GB_TRA_PW + ro * 8 + cc] * sy[cc];
-            c.sG[rt * 16 + c.ib[ro]] = rq1<Q>(__frcp_rn(1.0f + __expf(-z)));
-            c.sG[rt * 16 + c.ib[8 + ro]] = 1.0f;
-            // the last two frames' energies become the ring for the next chunk (row = frame & 1)
-            if constexpr (MS) c.sEHk[rt * 48 + (c.sTB[rt] & 1) * 8 + ro] = e[16];
-            else if (rt >= c.nfr - 2) c.sEHk[((c.tabs + rt) & 1) * 8 + ro] = e[16];
+                for (int cc = 0; cc < 8; ++cc) z += c.pb[GB_TRA_PW + ro * 8 + cc] * sy[cc];
+                c.sG[rt * 16 + c.ib[ro]] = rq1<Q>(__frcp_rn(1.0f + __expf(-z)));
+                c.sG[rt * 16 + c.ib[8 + ro]] = 1.0f;
+                c.sEHk[rt * 48 + (tb & 1) * 8 + ro] = e0;        // the new frame's energy replaces frame t-2's
+            }
+        }
+    } else {
+        // ---- TRALite, step 1: energies e[t][c] = mean_F(v^2): 32 threads per frame = 8 h' channels x 4 bin
+        //      ranges (9, 9, 9, 6 bins); the four partial sums of a channel sit in one DPP quad and are
+        //      combined there in a fixed order (bit-reproducible).  Written to sE[2 + t][c]; rows 0,1 of sE
+        //      hold the two frames before the chunk (the block's energy ring) ---------------------------------
+        {
+            // (index arithmetic from an opaque copy of tid: recomputed per block instead of hoisted out of the block and
+            // chunk loops, kept live across the whole kernel and spilled -- a scratch reload drains every load in flight)
+            int tz1 = L.tid;
+            asm volatile("" : "+v"(tz1));
+            const int part = tz1 & 3, rc = (tz1 >> 2) & 7, rt = tz1 >> 5;
+            if (tz1 < c.nfr * 32) {
+                // nine independent loads per thread (the last range, bins 27..32, reads bins 24..32 and drops the first
+                // three), then the same ascending-bin summation as a 9 / 6-trip loop -- whose loads went out one by one
+                float sum = 0.f;
+                if constexpr (WIDE_TRA) {
+                    const float* sp = c.sS + (rt * 33 + (part == 3 ? 24 : part * 9)) * RSS + c.ib[rc];
+                    float v[9];
+    #pragma unroll
+                    for (int f = 0; f < 9; ++f) v[f] = sp[f * RSS];
+    #pragma unroll
+                    for (int f = 0; f < 9; ++f) sum += (f < 3 && part == 3) ? 0.f : v[f];
+                } else {   // (the one instantiation with no registers to spare: the same sums from a loop)
+                    const float* sp = c.sS + (rt * 33 + part * 9) * RSS + c.ib[rc];
+                    const int cnt = part == 3 ? 6 : 9;
+                    for (int f = 0; f < cnt; ++f) sum += sp[f * RSS];
+                }
+                sum += dpp_ror<0xB1>(sum);   // quad_perm [1,0,3,2]
+                sum += dpp_ror<0x4E>(sum);   // quad_perm [2,3,0,1]
+                if (part == 0) c.sE[(MS ? rt * 3 + 2 : 2 + rt) * 8 + rc] = sum * (1.0f / 33.0f);
+            } else if (MS && tz1 >= NTHR - 64) {    // an otherwise idle wave copies every stream's ring into its rows 0,1
+                const int q = tz1 - (NTHR - 64), sidx = q >> 4, r = (q >> 3) & 1, cc = q & 7;
+                if (sidx < c.nfr) c.sE[(sidx * 3 + r) * 8 + cc] = c.sEHk[sidx * 48 + ((c.sTB[sidx] - 2 + r) & 1) * 8 + cc];
+            } else if (!MS && tz1 >= NTHR - 16) {   // an otherwise idle wave copies the ring into rows 0,1
+                const int q = tz1 - (NTHR - 16), r = q >> 3, cc = q & 7;
+                c.sE[r * 8 + cc] = c.sEHk[((c.tabs - 2 + r) & 1) * 8 + cc];
+            }
+        }
+        wg_barrier();
+        // rows 0, 1 of the image are free (this block's ring save, which may read row 1, is behind the barrier): the next
+        // block's history goes there now, off the critical path
+        if constexpr (!MS) {
+            if (c.sHnext) ring_to_image<RS, PT, FMT>(c.sW, c.sHnext, L.tid);
+        }
+        hook3();   // (k_stream_ms: the next block's history image, its taps are all read)
+        // ---- step 2: one thread per (frame, output channel): causal depthwise conv1d (k=3) over the energies,
+        //      1x1 conv, sigmoid (models/gtcrn_micro.py:122-139) ------------------------------------------------
+        {
+            int tz2 = L.tid;
+            asm volatile("" : "+v"(tz2));
+            const int ro = tz2 & 7, rt = tz2 >> 3;
+            if (tz2 < c.nfr * 8) {
+                const float* e = c.sE + (MS ? rt * 24 : rt * 8) + ro;    // rows rt, rt+1, rt+2 = frames t-2, t-1, t
+                const float y = c.pb[GB_TRA_DB + ro] + c.pb[GB_TRA_DW + ro * 3] * e[0] +
+                                c.pb[GB_TRA_DW + ro * 3 + 1] * e[8] + c.pb[GB_TRA_DW + ro * 3 + 2] * e[16];
+                // the 8 channels of a frame sit in 8 adjacent lanes of one wave: exchange y through the
+                // scratch behind the gate table with wave-local ordering, no workgroup barrier
+                float* sy = c.sY + rt * 8;
+                sy[ro] = y;
+                wave_lds_sync();
+                float z = c.pb[GB_TRA_PB + ro];
+    #pragma unroll
+                for (int cc = 0; cc < 8; ++cc) z += c.pb[GB_TRA_PW + ro * 8 + cc] * sy[cc];
+                c.sG[rt * 16 + c.ib[ro]] = rq1<Q>(__frcp_rn(1.0f + __expf(-z)));
+                c.sG[rt * 16 + c.ib[8 + ro]] = 1.0f;
+                // the last two frames' energies become the ring for the next chunk (row = frame & 1)
+                if constexpr (MS) c.sEHk[rt * 48 + (c.sTB[rt] & 1) * 8 + ro] = e[16];
+                else if (rt >= c.nfr - 2) c.sEHk[((c.tabs + rt) & 1) * 8 + ro] = e[16];
+            }
         }
     }
     // the decoder's hook started the next block's weight DMA two barriers ago; the VMK loads it issued behind the DMA
     // (en_outs[0] for the tail) stay in flight
-    if constexpr (DENSE) wg_barrier_vm<VMK>();
-    else wg_barrier();
+    if constexpr (DENSE && VMK1 < 0) wg_barrier_vm<VMK>();
+    else wg_barrier();               // (VMK1 >= 0: the DMA is waited for at the next block's first barrier)
     STAMP(SS, 7)
 #pragma unroll
     for (int i = 0; i < TPW; ++i) x[i] = rq<Q>(x[i] * ld4(c.sG + tt.tl[i] * 16 + 4 * g));
@@ -3270,7 +3326,7 @@ __global__ __launch_bounds__(NTHR) void k_stream_ms(const float* __restrict__ sp
     STAMP(SS, 13)
     const int npos = nfr * 33;
     f32x4 s0e, s0o;
-    auto run_block = [&](int j, const f32x4 skv, auto&& hook, auto&& hook3) {
+    auto run_block = [&](int j, const f32x4 skv, auto&& hook, auto&& hook3, auto vmk1) {
         BlockCtx c;
         c.pb = sPD + j * GB_SIZE;
         c.gA = sPD + DL_DN;
@@ -3284,23 +3340,30 @@ __global__ __launch_bounds__(NTHR) void k_stream_ms(const float* __restrict__ sp
         c.ms_roff = (int)(sHd - sW) + row * (2 * 35 * RS);
         c.ms_tb = tbl;
         c.g_hist = stl + ST_DEC_H + ((j * 2 + (tbl & 1)) * 33 + ffl) * 16 + 4 * g;
-        gtconv_block<true, 1, true, false, RS, 16, true, 35, 0>(
+        gtconv_block<true, 1, true, false, RS, 16, true, 35, 0, decltype(vmk1)::value>(
             x, tt, c, L, [&] { if (j < 2) dense_fetch(j + 1); hook(); }, hook3 STAMP_ARG);
         x[0] = x[0] + skv;
         STAMP(SS, 8)
     };
-    // (the history loads of block j + 1 are issued in block j's hook, behind its dense phase, and land in the image
-    // behind its third barrier; the closing barrier of every dense block waits for vmcnt(0): DMA and history alike)
-    run_block(0, en3p, [&] { hist_fetch(ST_DEC_H + 1 * 2 * 33 * 16, hv); },
-              [&] { if constexpr (SPLIT) hist_store(sHd, std::true_type{}, hv); else hist_store(sHd, std::false_type{}, hv); });
-    run_block(1, en2p, [&] { hist_fetch(ST_DEC_H + 2 * 2 * 33 * 16, hv); },
-              [&] { if constexpr (SPLIT) hist_store(sHd, std::true_type{}, hv); else hist_store(sHd, std::false_type{}, hv); });
+    // (block j + 1's history rows are requested at the top of block j -- its own image is complete, hv is free -- and
+    // land in the image once block j's taps are read; the dense planes of block j + 1 go out by DMA behind block j's dense
+    // phase and are waited for at block j + 1's FIRST barrier, one phase before their first reader: see gtconv_block)
+    // (first-barrier wait of a block = the vector-memory operations EVERY wave issues behind the DMA of its planes: blocks
+    // 0 and 1 the two history loads of the next block; block 2 none -- its wait also takes the live waves' new-row store)
+    hist_fetch(ST_DEC_H + 1 * 2 * 33 * 16, hv);
+    run_block(0, en3p, [] {},
+              [&] { if constexpr (SPLIT) hist_store(sHd, std::true_type{}, hv); else hist_store(sHd, std::false_type{}, hv); },
+              std::integral_constant<int, 2>{});
+    hist_fetch(ST_DEC_H + 2 * 2 * 33 * 16, hv);
+    run_block(1, en2p, [] {},
+              [&] { if constexpr (SPLIT) hist_store(sHd, std::true_type{}, hv); else hist_store(sHd, std::false_type{}, hv); },
+              std::integral_constant<int, 2>{});
     run_block(2, en1p, [&] {
         // en_outs[0] for the even / odd output bins of the lane's position, from LDS
         const int o0 = (tt.pp(0) < npos ? tt.tl[0] * F1 + 2 * tt.ff[0] : 0) * 16 + 4 * g;
         s0e = ld4(sEN0 + o0);
         s0o = ld4(sEN0 + o0 + (tt.ff[0] < 32 ? 16 : 0));
-    }, [] {});
+    }, [] {}, std::integral_constant<int, 0>{});
     // ---- de_convs.3 (gather form) + de_convs.4 (scatter form)
     const int rec3[1] = {o35<RS, 0>(tt, 0, 0)};
     if constexpr (SPLIT3) st_split(sW, rec3[0], g, x[0]);
