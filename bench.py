@@ -433,6 +433,30 @@ def batch_sweep_leg(eng, win, world, sync_all, max_over_ranks):
     base = res["256x4s"]["ms_per_call"] / (256 * 251)
     for v in res.values():
         v["per_frame_cost_rel_256"] = round(v["ms_per_call"] / (v["B"] * v["T"]) / base, 3)
+    # a folder-like batch (enhance_folder's call): 48 clips of 2 .. 10 s in one variable-length launch sequence, with the
+    # per-utterance kernels in time spans over the lengths (the default) and with one workgroup per utterance
+    B, L = 48, 160000
+    lens = torch.randint(32000, L + 1, (B,), generator=torch.Generator().manual_seed(46))
+    frames = int((1 + lens // 256).sum())
+    x = torch.randn(B, L, device="cuda") * 0.1
+    y = torch.empty((B, 256 * (L // 256)), device="cuda")
+    eng.reserve(B, 1 + L // 256)
+    var = {"B": B, "frames": frames}
+    for key, on in (("spans", True), ("one_workgroup_per_utterance", False)):
+        eng.var_spans_enable(on)
+        for _ in range(3):
+            eng.forward_wave_var(x, lens, win, out=y)
+        sync_all()
+        t0 = time.perf_counter()
+        for _ in range(12):
+            eng.forward_wave_var(x, lens, win, out=y)
+        sync_all()
+        el = (time.perf_counter() - t0) / 12
+        var[key] = {"ms_per_call": round(el * 1e3, 4), "frames_per_s": round(world * frames / el, 1),
+                    "per_frame_cost_rel_256": round(el * 1e3 / frames / base, 3)}
+    eng.var_spans_enable(True)
+    res["48x2-10s_var"] = var
+    del x, y
     max_over_ranks(last, "cuda")
     torch.cuda.empty_cache()
     return {"workload": "offline wave->wave at other batch shapes, per GPU (B x clip length)", **res}

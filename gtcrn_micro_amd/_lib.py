@@ -80,6 +80,7 @@ def lib():
     L.gtcrn_pack_sizes.restype = None
     L.gtcrn_pack_params_host.argtypes = [_c_f32p, cl, _c_f32p, ctypes.POINTER(ci)]
     L.gtcrn_debug_enable.argtypes = [_vp, ci]
+    L.gtcrn_var_spans_enable.argtypes = [_vp, ci]
     L.gtcrn_debug_tap.restype = cl
     L.gtcrn_debug_tap.argtypes = [_vp, ctypes.c_char_p, ci, _c_f32p, cl]
     L.gtcrn_debug_stamps.restype = cl
@@ -469,6 +470,10 @@ class Engine:
         """True / 1: stage taps (and phase stamps in the diagnostic build); 2: phase stamps only (single-frame streaming
         steps keep their one-launch form)."""
         _check(lib().gtcrn_debug_enable(self._h, 2 if on == 2 else int(bool(on))))
+
+    def var_spans_enable(self, on=True):
+        """Variable-length batches in time spans (default on; results are bit-identical either way -- the A/B switch)."""
+        _check(lib().gtcrn_var_spans_enable(self._h, int(bool(on))))
 
     def tap(self, name, b, T):
         F = {"en0": 65, "de3": 65}.get(name, 33)

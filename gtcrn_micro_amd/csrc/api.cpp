@@ -62,6 +62,8 @@ struct gtcrn_model {
     float* d_pfq = nullptr;  // the same with int8-quantised weights (BASELINE configs[4] variant)
     int* d_pi = nullptr;     // packed ints (gtl::P_INTS)
     float* d_twid = nullptr; // 512 complex twiddles
+    int* d_pref = nullptr;   // prefix table of a variable-length batch (1025 ints, see gtk::launch_len_prefix)
+    bool var_spans = true;   // variable-length batches run in time spans (off: one workgroup per utterance, the A/B switch)
     std::vector<int> h_pi;   // host copy of the int tables (slot permutations for the debug taps)
     // workspace for B x T
     long cap_bt = 0;         // capacity in (batch * frames)
@@ -122,11 +124,13 @@ int ensure_workspace(gtcrn_model* m, int B, int T, hipStream_t s) {
         m->dbg_cap_bt = bt;
     }
     if (m->debug && B > m->stamps_cap_b) {
+        // one row per WORKGROUP: launches in time spans run up to 2048 of them whatever the batch
+        const int rows = B > 2048 ? B : 2048;
         if (m->d_stamps) (void)hipFree(m->d_stamps);
         m->d_stamps = nullptr;
-        HIP_TRY(hipMalloc(&m->d_stamps, sizeof(unsigned long long) * 4 * B * 16));
-        HIP_TRY(hipMemset(m->d_stamps, 0, sizeof(unsigned long long) * 4 * B * 16));
-        m->stamps_cap_b = B;
+        HIP_TRY(hipMalloc(&m->d_stamps, sizeof(unsigned long long) * 4 * rows * 16));
+        HIP_TRY(hipMemset(m->d_stamps, 0, sizeof(unsigned long long) * 4 * rows * 16));
+        m->stamps_cap_b = rows;
     }
     return 0;
 }
@@ -188,11 +192,18 @@ int run_model(gtcrn_model* m, const float* spec_in, long isb, long isf, long ist
             tm.end();
         }
     }
+    // variable-length offline batches: the per-utterance kernels share the frames that exist (time spans over a prefix
+    // table of the lengths) -- unless the batch is whole rounds of the chip already
+    const int* pref = nullptr;
+    if (offline && lens && !q && front_done && m->var_spans && gtk::var_spans_usable(B) && B % 256 != 0) {
+        LAUNCH_TRY(gtk::launch_len_prefix(lens, B, T, m->d_pref, s));
+        pref = m->d_pref;
+    }
     unsigned long long* stp = (m->debug && m->d_stamps) ? m->d_stamps : nullptr;
     const long sst = (long)m->stamps_cap_b * 16;
     tm.begin(offline ? K_ENCODER_GT : K_ENCODER);
     LAUNCH_TRY(gtk::launch_encoder(spec_in, isb, isf, ist, B, T, lens, pf, m->d_pi, m->d_en0, m->d_en[0], m->d_en[1],
-                                   m->d_en[2], m->d_en[3], state, stp ? stp : nullptr, s, q, offline));
+                                   m->d_en[2], m->d_en[3], state, stp ? stp : nullptr, s, q, offline, pref));
     tm.end();
     // GTCN: offline calls (no stream state) use the frequency-band form (registers + wave-private LDS, no barrier);
     // single-frame streaming steps run BOTH stacks per position in one launch; other streaming chunkings use the
@@ -204,7 +215,7 @@ int run_model(gtcrn_model* m, const float* spec_in, long isb, long isf, long ist
     } else {
         tm.begin(K_GTCN1);
         if (!state)
-            LAUNCH_TRY(gtk::launch_gtcn_band(m->d_en[3], m->d_g1, pf + gtl::P_GTCN, B, T, lens, nullptr, s, q));
+            LAUNCH_TRY(gtk::launch_gtcn_band(m->d_en[3], m->d_g1, pf + gtl::P_GTCN, B, T, lens, nullptr, s, q, pref));
         else
             LAUNCH_TRY(gtk::launch_gtcn(m->d_en[3], m->d_g1, pf + gtl::P_GTCN, B, T, state, gtk::ST_G1_H, nullptr,
                                         stp ? stp + sst : nullptr, s));
@@ -213,7 +224,7 @@ int run_model(gtcrn_model* m, const float* spec_in, long isb, long isf, long ist
         // the second stack stores gtcn2(x) + en_outs[4]: exactly the decoder's first input (Decoder.forward :467)
         if (!state)
             LAUNCH_TRY(gtk::launch_gtcn_band(m->d_g1, m->d_g2, pf + gtl::P_GTCN + gtl::GTCN_SIZE, B, T, lens, m->d_en[3], s,
-                                             q));
+                                             q, pref));
         else
             LAUNCH_TRY(gtk::launch_gtcn(m->d_g1, m->d_g2, pf + gtl::P_GTCN + gtl::GTCN_SIZE, B, T, state, gtk::ST_G2_H,
                                         m->d_en[3], stp ? stp + 2 * sst : nullptr, s));
@@ -222,7 +233,7 @@ int run_model(gtcrn_model* m, const float* spec_in, long isb, long isf, long ist
     tm.begin(K_DECODER);
     LAUNCH_TRY(gtk::launch_decoder(m->d_g2, m->d_en0, m->d_en[0], m->d_en[1], m->d_en[2], m->d_en[3], spec_in, isb, isf,
                                    ist, spec_out, osb, osf, ost, B, T, lens, pf, m->d_pi, state,
-                                   m->debug && !q ? m->d_dbg : nullptr, stp ? stp + 3 * sst : nullptr, s, q));
+                                   m->debug && !q ? m->d_dbg : nullptr, stp ? stp + 3 * sst : nullptr, s, q, pref));
     tm.end();
     m->last_B = B;
     m->last_T = T;
@@ -305,6 +316,7 @@ int gtcrn_model_create(gtcrn_model** out, const float* h_params, long n_floats, 
     if (e == hipSuccess) e = hipMalloc(&m->d_pfq, sizeof(float) * gtl::P_FLOATS);
     if (e == hipSuccess) e = hipMalloc(&m->d_pi, sizeof(int) * gtl::P_INTS);
     if (e == hipSuccess) e = hipMalloc(&m->d_twid, sizeof(float) * 1024);
+    if (e == hipSuccess) e = hipMalloc(&m->d_pref, sizeof(int) * 1025);
     if (e == hipSuccess) e = hipMalloc(&m->d_ptr8, sizeof(float*) * 8);
     if (e != hipSuccess) {
         gtcrn_model_destroy(m);
@@ -353,6 +365,7 @@ void gtcrn_model_destroy(gtcrn_model* m) {
     if (m->d_pfq) (void)hipFree(m->d_pfq);
     if (m->d_pi) (void)hipFree(m->d_pi);
     if (m->d_twid) (void)hipFree(m->d_twid);
+    if (m->d_pref) (void)hipFree(m->d_pref);
     if (m->d_ptr8) (void)hipFree(m->d_ptr8);
     for (auto* v : {&m->timings, &m->ev_pool})
         for (auto& t : *v) {
@@ -604,6 +617,13 @@ int gtcrn_debug_enable(gtcrn_model* m, int on) {
     if (rc) return rc;
     m->debug = on != 0;
     m->debug_keep_fused = on == 2;
+    return 0;
+}
+
+int gtcrn_var_spans_enable(gtcrn_model* m, int on) {
+    int rc = check_model(m);
+    if (rc) return rc;
+    m->var_spans = on != 0;
     return 0;
 }
 

@@ -53,7 +53,8 @@ int launch_istft_adjoint(const float* gwave, int B, int T, const float* win, con
                          long sf, long st, hipStream_t s);
 int launch_encoder(const float* spec, long sb, long sf, long st, int B, int T, const int* lens, const float* PF,
                    const int* PI, float* en0, float* en1, float* en2, float* en3, float* en4, float* state,
-                   unsigned long long* stamps, hipStream_t s, const Quant* q = nullptr, bool front_done = false);
+                   unsigned long long* stamps, hipStream_t s, const Quant* q = nullptr, bool front_done = false,
+                   const int* pref = nullptr);
 // offline front end: STFT (wave) or caller spectrogram -> features, ERB, SFE, en_conv0, en_conv1 (see kernels.hip)
 int launch_front(const float* wave, long L, const float* spec_in, long isb, long isf, long ist, int B, int T,
                  const int* lens, const float* win, const float* twid, const float* PF, const int* PI, float* spec_out,
@@ -62,11 +63,16 @@ int launch_gtcn(const float* xin, float* xout, const float* P, int B, int T, flo
                 const float* addend, unsigned long long* stamps, hipStream_t s);
 int launch_gtcn_ms(const float* xin, float* xout1, float* xout2, const float* P, int B, float* state, hipStream_t s);
 int launch_gtcn_band(const float* xin, float* xout, const float* P, int B, int T, const int* lens, const float* addend,
-                     hipStream_t s, const Quant* q = nullptr);
+                     hipStream_t s, const Quant* q = nullptr, const int* pref = nullptr);
 int launch_decoder(const float* xg, const float* en0, const float* en1, const float* en2, const float* en3,
                    const float* en4, const float* spec, long sb, long sf, long st, float* out, long osb, long osf,
                    long ost, int B, int T, const int* lens, const float* PF, const int* PI, float* state, float* dbg,
-                   unsigned long long* stamps, hipStream_t s, const Quant* q = nullptr);
+                   unsigned long long* stamps, hipStream_t s, const Quant* q = nullptr, const int* pref = nullptr);
+// Variable-length batches in time spans: pref (device, int32[B + 1]) = prefix sums of the utterances' frame counts, made
+// from lens by launch_len_prefix (B <= 1024: var_spans_usable); the three per-utterance launchers above then run whole
+// rounds of 256 workgroups, each taking an equal share of the frames that exist, instead of one workgroup per utterance.
+bool var_spans_usable(int B);
+int launch_len_prefix(const int* lens, int B, int T, int* pref, hipStream_t s);
 // single-frame streaming step of B streams as ONE launch (encoder -> both GTCN stacks -> decoder, nothing through HBM)
 int launch_stream_ms(const float* spec, long sb, long sf, float* out, long osb, long osf, int B, const float* PF,
                      const int* PI, float* state, unsigned long long* stamps, hipStream_t s);

@@ -627,31 +627,55 @@ __global__ __launch_bounds__(FFT_WAVES * 64) void k_istft(const float* __restric
 // is computed from zero history starting H frames early and its first H frames are not stored -- from frame t_lo on
 // every value is bit-identical to the unsegmented run (same arithmetic, chunk alignment plays no role:
 // chunked == offline holds bit for bit already).  nwg == B gives back one workgroup per utterance, no halo.
-struct Span {
-    int b;      // utterance
-    int fb;     // first frame processed (absolute, inside the utterance)
-    int wlo;    // first LOCAL frame (relative to fb) whose results are stored: the warm-up frames in front are not
-    int nT;     // frames processed (warm-up included)
+// The share of one workgroup is walked segment by segment.  pref (optional, device, int32[B + 1]): prefix sums of the
+// utterances' frame counts for a variable-length batch (utterance b holds pref[b+1] - pref[b] <= T frames; T stays the row
+// stride of every tensor); nullptr: every utterance has T frames.  Everything here is wave uniform and kept in plain
+// 32-bit scalars (structs passed around by reference ended up in scratch memory).
+struct SpanIter {
+    int g, g1;     // next frame of the flattened (utterance, frame) axis, end of the share
+    int b;         // utterance that holds frame g
+    int pb;        // flattened index of that utterance's first frame
 };
-// (plain scalars in and out -- everything here is wave uniform and has to stay in scalar registers; a struct array
-// indexed by the segment counter, and even structs filled through a helper lambda, ended up in scratch memory)
-__device__ __forceinline__ int wg_spans(int wg, int nwg, int B, int T, int halo, Span& sp0, Span& sp1) {
-    const long total = (long)B * T;
-    const long per = (total + nwg - 1) / nwg;            // <= T: the launchers use nwg >= B
-    const long g0 = (long)wg * per, g1 = min(total, g0 + per);
-    const int b0 = (int)(g0 / T), b1 = (int)((g1 - 1) / T);
-    const int tl0 = (int)(g0 - (long)b0 * T);
-    const bool two = b1 != b0;
-    const int fb0 = tl0 > halo ? tl0 - halo : 0;
-    sp0.b = b0;
-    sp0.fb = fb0;
-    sp0.wlo = tl0 - fb0;
-    sp0.nT = (two ? T : (int)(g1 - (long)b0 * T)) - fb0;
-    sp1.b = b1;
-    sp1.fb = 0;
-    sp1.wlo = 0;
-    sp1.nT = (int)(g1 - (long)b1 * T);
-    return g0 >= g1 ? 0 : (two ? 2 : 1);
+__device__ __forceinline__ bool span_begin(SpanIter& it, int wg, int nwg, int B, int T, const int* __restrict__ pref) {
+    const int total = pref ? pref[B] : B * T;
+    int per = (total + nwg - 1) / nwg;
+    if (pref) per = max(per, 4);             // (uniform batches: the host plan keeps shares above a few frames)
+    it.g = wg * per;
+    it.g1 = min(total, it.g + per);
+    if (it.g >= it.g1) return false;
+    if (pref) {
+        int lo = 0, hi = B;                  // the utterance with pref[b] <= g < pref[b + 1] (empty ones cannot hold g)
+        while (hi - lo > 1) {
+            const int mid = (lo + hi) >> 1;
+            if (pref[mid] <= it.g) lo = mid; else hi = mid;
+        }
+        it.b = lo;
+        it.pb = pref[lo];
+    } else {
+        it.b = it.g / T;
+        it.pb = it.b * T;
+    }
+    return true;
+}
+// the next segment of the share: utterance sb, first frame processed sfb (halo frames of warm-up in front of the share's
+// own first frame, when it starts inside the utterance), first LOCAL frame stored swlo, frames processed snT
+__device__ __forceinline__ bool span_next(SpanIter& it, int B, int T, const int* __restrict__ pref, int halo, int& sb, int& sfb,
+                                          int& swlo, int& snT) {
+    int Tb = 0;
+    while (it.g < it.g1) {                   // (skips utterances of zero frames in a prefix table)
+        Tb = pref ? pref[it.b + 1] - it.pb : T;
+        if (it.g - it.pb < Tb) break;
+        it.pb += Tb;
+        ++it.b;
+    }
+    if (it.g >= it.g1) return false;
+    const int t_lo = it.g - it.pb, t_hi = min(Tb, it.g1 - it.pb);
+    sb = it.b;
+    sfb = t_lo > halo ? t_lo - halo : 0;
+    swlo = t_lo - sfb;
+    snT = t_hi - sfb;
+    it.g = it.pb + t_hi;
+    return true;
 }
 constexpr int HALO_BLOCKS = 12;   // three GTConv blocks: 3 x (2 conv frames + 2 TRA energies)
 constexpr int HALO_GTCN = 30;     // one GTCN stack: 2 x (1 + 2 + 4 + 8)
@@ -1335,7 +1359,7 @@ constexpr int ENC_MS_LDS_FLOATS = EncLds<MS_ROWS, MS_STREAMS, true, true>::FLOAT
 // input spectrogram through the int8 boundary of the tflite path (x_q = round(x / qin), tflite_infer.py:79-82).
 // FRONT = false (offline calls): k_front has already produced en0 and en1; this kernel reads en1 in its own slot order
 // and runs only the three causal GTConv blocks.
-// SPANS: the workgroups of an offline launch share the (utterance, frame) axis (see wg_spans); a separate instantiation,
+// SPANS: the workgroups of an offline launch share the (utterance, frame) axis (see span_begin); a separate instantiation,
 // so that the one-workgroup-per-utterance form (the headline shape) keeps its registers
 template <int TPW, bool MS, bool Q, bool FRONT, bool SPANS = false>
 __global__ __launch_bounds__(NTHR) void k_encoder(const float* __restrict__ spec, long sb, long sf, long st, int T,
@@ -1367,18 +1391,16 @@ __global__ __launch_bounds__(NTHR) void k_encoder(const float* __restrict__ spec
     const Lane L = lane_info();
     const int tid = L.tid, n = L.n, g = L.g;
     // offline calls (no stream state, no per-utterance lengths, FRONT = false): the workgroups share the (utterance,
-    // frame) axis, a share is one or two segments (see wg_spans); everything else: one workgroup per utterance / stream
+    // frame) axis, a share is a run of segments (see span_begin / span_next); everything else: one workgroup per utterance / stream
     const int Tstride = T;
-    Span sp0, sp1;
-    int nseg = 1;
-    sp0.b = blockIdx.x; sp0.fb = 0; sp0.wlo = 0; sp0.nT = T;
-    sp1 = sp0;
     static_assert(!SPANS || (!MS && !FRONT), "time spans: offline blocks-only form");
-    if constexpr (SPANS) {
-        nseg = wg_spans(blockIdx.x, gridDim.x, NB, T, HALO_BLOCKS, sp0, sp1);
-        if (nseg == 0) return;
+    SpanIter sit;
+    int s_b = blockIdx.x, s_fb = 0, s_wlo = 0, s_nT = T;
+    if constexpr (SPANS) {     // (`lens` is the PREFIX table of a variable-length batch here, see span_begin)
+        if (!span_begin(sit, blockIdx.x, gridDim.x, NB, T, lens)) return;
+        span_next(sit, NB, Tstride, lens, HALO_BLOCKS, s_b, s_fb, s_wlo, s_nT);
     }
-    int b = sp0.b;
+    int b = s_b;
 
     static_assert(E_BLK % 4 == 0 && ENC_SIZE % 4 == 0 && P_ENC % 4 == 0, "16-byte parameter copies");
     copy_params(sP + (FRONT ? 0 : E_BLK), PF + P_ENC + (FRONT ? 0 : E_BLK), ENC_SIZE - (FRONT ? 0 : E_BLK), tid, NTHR);
@@ -1420,9 +1442,11 @@ __global__ __launch_bounds__(NTHR) void k_encoder(const float* __restrict__ spec
         T = snT;
         wlo_v = swlo;
     };
-    seg_setup(sp0.b, sp0.fb, sp0.wlo, sp0.nT);
+    seg_setup(s_b, s_fb, s_wlo, s_nT);
     const bool t_fast = st < sf;  // reference layout (B,257,T,2): consecutive frames are adjacent
-    if (lens) T = min(T, 1 + (lens[b] >> 8));   // from here on T = this utterance's frames
+    if constexpr (!SPANS) {
+        if (lens) T = min(T, 1 + (lens[b] >> 8));   // from here on T = this utterance's frames
+    }
     if constexpr (MS) T = nlive;                // one frame per live stream = nlive rows
     STAMP(SS, 0)
 
@@ -1695,14 +1719,13 @@ segment_top:
         STAMP(SS, 9)
     }
     if constexpr (SPANS) {
-        if (nseg > 1) {
+        if (span_next(sit, NB, Tstride, lens, HALO_BLOCKS, s_b, s_fb, s_wlo, s_nT)) {
             // the share runs on into the next utterance: zero history again (every wave is behind the barrier that closed
             // the last chunk, i.e. behind all reads of the rings and images), then the same chunk loop
-            nseg = 1;
             rings_load(sH, sEH, nullptr, nullptr, 0, tid);
             wg_barrier();
             ring_to_image<RS, LD::PT>(sW, sH, tid);
-            seg_setup(sp1.b, sp1.fb, sp1.wlo, sp1.nT);
+            seg_setup(s_b, s_fb, s_wlo, s_nT);
             goto segment_top;
         }
     }
@@ -2298,7 +2321,7 @@ __device__ __forceinline__ void tcn_block_band(f32x4 (&x)[TPW], const float* pk,
     }
 }
 
-// B, T: batch and row stride; gridDim.x workgroups share the (utterance, frame) axis (see wg_spans); lens != nullptr
+// B, T: batch and row stride; gridDim.x workgroups share the (utterance, frame) axis (see span_begin); lens != nullptr
 // (variable-length batch): one workgroup per utterance.
 template <bool Q, bool SPANS = false>
 __global__ __launch_bounds__(NTHR) void k_gtcn_band(const float* __restrict__ xin, float* __restrict__ xout,
@@ -2310,15 +2333,12 @@ __global__ __launch_bounds__(NTHR) void k_gtcn_band(const float* __restrict__ xi
     float* sHh = smem + GB_LDS_H;
     const Lane L = lane_info();
     const int tid = L.tid, n = L.n, g = L.g;
-    Span sp0, sp1;
-    sp1.b = 0; sp1.fb = 0; sp1.wlo = 0; sp1.nT = 0;
-    int nseg;
-    if constexpr (SPANS) {
-        nseg = wg_spans(blockIdx.x, gridDim.x, B, T, HALO_GTCN, sp0, sp1);
-        if (nseg == 0) return;
+    SpanIter sit;
+    int s_b = blockIdx.x, s_fb = 0, s_wlo = 0, s_nT = T;
+    if constexpr (SPANS) {       // (`lens` is the PREFIX table of a variable-length batch here, see span_begin)
+        if (!span_begin(sit, blockIdx.x, gridDim.x, B, T, lens)) return;
     } else {                     // one workgroup per utterance (lens: a variable-length batch, this utterance's frames)
-        sp0.b = blockIdx.x; sp0.fb = 0; sp0.wlo = 0; sp0.nT = lens ? min(T, 1 + (lens[blockIdx.x] >> 8)) : T;
-        nseg = 1;
+        s_nT = lens ? min(T, 1 + (lens[blockIdx.x] >> 8)) : T;
     }
     copy_params(sP, P, GTCN_SIZE, tid, NTHR);
     for (int i = tid; i < 33 * 30 * GB_RS / 4; i += NTHR) st4(sHh + i * 4, splat(0.f));   // zero history (frames < 0)
@@ -2326,14 +2346,17 @@ __global__ __launch_bounds__(NTHR) void k_gtcn_band(const float* __restrict__ xi
     using ht = typename HandOff<Q>::t;
     const int f0 = L.wave * TPW;                         // first bin of this wave
     float* cw = sC + f0 * 16 * GB_RS;
-    for (int sg = 0; sg < nseg; ++sg) {
-        Span S;                                          // (field by field: a struct select takes the structs' addresses)
-        S.b = sg ? sp1.b : sp0.b; S.fb = sg ? sp1.fb : sp0.fb; S.wlo = sg ? sp1.wlo : sp0.wlo; S.nT = sg ? sp1.nT : sp0.nT;
-        const long rb = (long)S.b * T + S.fb;            // first row of the segment in the hand-off tensors
+    for (int sg = 0;; ++sg) {
+        if constexpr (SPANS) {
+            if (!span_next(sit, B, T, lens, HALO_GTCN, s_b, s_fb, s_wlo, s_nT)) break;
+        } else if (sg > 0) {
+            break;
+        }
+        const long rb = (long)s_b * T + s_fb;            // first row of the segment in the hand-off tensors
         const ht* xinh = reinterpret_cast<const ht*>(xin) + rb * 528;
         ht* xouth = reinterpret_cast<ht*>(xout) + rb * 528;
         const ht* addh = addend ? reinterpret_cast<const ht*>(addend) + rb * 528 : nullptr;
-        const int Ts = S.nT, wlo = SPANS ? S.wlo : 0;
+        const int Ts = s_nT, wlo = SPANS ? s_wlo : 0;
         if (sg > 0) {
             // a second segment starts a new utterance: its history is zero again.  The rings are wave private (this
             // wave's three bins of every block), so no workgroup barrier: block k's slice is [3 bins][2d rows][GB_RS]
@@ -2547,18 +2570,16 @@ __global__ __launch_bounds__(NTHR) void k_decoder(const float* __restrict__ xg, 
     const Lane L = lane_info();
     const int tid = L.tid, n = L.n, g = L.g;
     // offline calls (no stream state, no per-utterance lengths): the workgroups share the (utterance, frame) axis, a share
-    // is one or two segments (see wg_spans); everything else: one workgroup per utterance / group of streams
+    // is one or two segments (see span_begin); everything else: one workgroup per utterance / group of streams
     const int Tstride = T;
-    Span sp0, sp1;
-    int nseg = 1;
-    sp0.b = blockIdx.x; sp0.fb = 0; sp0.wlo = 0; sp0.nT = T;
-    sp1 = sp0;
     static_assert(!SPANS || (!MS && !Q), "time spans: offline fp32 form");
-    if constexpr (SPANS) {
-        nseg = wg_spans(blockIdx.x, gridDim.x, NB, T, HALO_BLOCKS, sp0, sp1);
-        if (nseg == 0) return;
+    SpanIter sit;
+    int s_b = blockIdx.x, s_fb = 0, s_wlo = 0, s_nT = T;
+    if constexpr (SPANS) {     // (`lens` is the PREFIX table of a variable-length batch here, see span_begin)
+        if (!span_begin(sit, blockIdx.x, gridDim.x, NB, T, lens)) return;
+        span_next(sit, NB, Tstride, lens, HALO_BLOCKS, s_b, s_fb, s_wlo, s_nT);
     }
-    int b = sp0.b;
+    int b = s_b;
     constexpr bool SPLIT = !Q && kSplitDense;
     // the dense 3x3 of block j -> the stage buffer by LDS-DMA (global_load_lds_dwordx4: 1 KB pieces, wave w moves pieces
     // w, w + 11; no registers are held while the data is in flight -- a register-staged copy spilled).  A DMA is a
@@ -2632,8 +2653,10 @@ __global__ __launch_bounds__(NTHR) void k_decoder(const float* __restrict__ xg, 
         T = snT;
         wlo_v = swlo;
     };
-    seg_setup(sp0.b, sp0.fb, sp0.wlo, sp0.nT);
-    if (lens) T = min(T, 1 + (lens[b] >> 8));   // variable-length batch: from here on T = this utterance's frames
+    seg_setup(s_b, s_fb, s_wlo, s_nT);
+    if constexpr (!SPANS) {
+        if (lens) T = min(T, 1 + (lens[b] >> 8));   // variable-length batch: from here on T = this utterance's frames
+    }
     if constexpr (MS) T = nlive;                // one frame per live stream = nlive rows
     f32x4 xn[TPW];
 segment_top:
@@ -2899,13 +2922,12 @@ segment_top:
         STAMP(SS, 14)
     }
     if constexpr (SPANS) {
-        if (nseg > 1) {
+        if (span_next(sit, NB, Tstride, lens, HALO_BLOCKS, s_b, s_fb, s_wlo, s_nT)) {
             // the share runs on into the next utterance: zero history again (every wave is behind the barrier that closed
             // the last chunk), then the same chunk loop; block 0 copies its (zero) history into the image itself
-            nseg = 1;
             rings_load(sH, sEH, nullptr, nullptr, 0, tid);
             wg_barrier();
-            seg_setup(sp1.b, sp1.fb, sp1.wlo, sp1.nT);
+            seg_setup(s_b, s_fb, s_wlo, s_nT);
             goto segment_top;
         }
     }
@@ -3609,6 +3631,30 @@ __global__ void k_selftest_split3(const float* __restrict__ x, long n, float* __
     }
 }
 
+// Prefix table of a variable-length batch for the time spans (span_begin): pref[b] = frames of utterances [0, b), with
+// utterance b holding min(T, 1 + (lens[b] >> 8)) frames (lens in samples, the STFT's frame count).  One workgroup,
+// B <= PREF_MAX_B.
+constexpr int PREF_MAX_B = 1024;
+__global__ __launch_bounds__(PREF_MAX_B) void k_len_prefix(const int* __restrict__ lens, int B, int T, int* __restrict__ pref) {
+    __shared__ int sc[PREF_MAX_B];
+    const int i = threadIdx.x;
+    int v = 0;
+    if (i < B) {
+        const int l = lens[i];
+        v = l < 0 ? 0 : min(T, 1 + (l >> 8));
+    }
+    sc[i] = v;
+    __syncthreads();
+    for (int d = 1; d < PREF_MAX_B; d <<= 1) {          // inclusive scan, ten doubling steps
+        const int add = i >= d ? sc[i - d] : 0;
+        __syncthreads();
+        sc[i] += add;
+        __syncthreads();
+    }
+    if (i < B) pref[i + 1] = sc[i];
+    if (i == 0) pref[0] = 0;
+}
+
 }  // namespace gtk
 
 // ============================================================================== launchers
@@ -3620,7 +3666,7 @@ namespace gtk {
         if (e_ != hipSuccess) return (int)e_;   \
     } while (0)
 
-// How an offline launch of a per-utterance kernel covers B utterances of T frames (see wg_spans):
+// How an offline launch of a per-utterance kernel covers B utterances of T frames (see span_begin):
 //   nA    utterances [0, nA) run one workgroup per utterance (no warm-up) -- whole rounds of 256, or everything;
 //   nwgB  workgroups share the (utterance, frame) axis of the remaining B - nA utterances (0: none remain).
 // Candidates: everything one per utterance; everything in 256 k shares; the whole rounds one per utterance and only the
@@ -3663,6 +3709,17 @@ static SpanPlan span_plan(int B, int T, int halo, bool allowed) {
 int span_workgroups(int B, int T, int halo, bool allowed) {      // (diagnostics: the share count of a uniform plan)
     const SpanPlan p = span_plan(B, T, halo, allowed);
     return p.nwgB ? p.nwgB : B;
+}
+
+// Variable-length batches: the lengths live on the device, so the plan cannot use them -- every workgroup of whole
+// rounds of the chip takes an equal share of the frames that exist (prefix table from launch_len_prefix).
+bool var_spans_usable(int B) { return B >= 1 && B <= PREF_MAX_B; }
+static int var_span_workgroups(int B) { return 256 * ((B + 255) / 256); }
+int launch_len_prefix(const int* lens, int B, int T, int* pref, hipStream_t s) {
+    if (!var_spans_usable(B)) return (int)hipErrorInvalidValue;
+    hipLaunchKernelGGL(k_len_prefix, dim3(1), dim3(PREF_MAX_B), 0, s, lens, B, T, pref);
+    GT_LAUNCH_CHECK();
+    return 0;
 }
 
 int launch_stft(const float* wave, int B, long L, int T, const int* lens, const float* win, const float* twid,
@@ -3785,9 +3842,16 @@ int launch_front(const float* wave, long L, const float* spec_in, long isb, long
 // front_done: k_front has produced en0 / en1 already, only the three GTConv blocks run here (offline calls)
 int launch_encoder(const float* spec, long sb, long sf, long st, int B, int T, const int* lens, const float* PF,
                    const int* PI, float* en0, float* en1, float* en2, float* en3, float* en4, float* state,
-                   unsigned long long* stamps, hipStream_t s, const Quant* q, bool front_done) {
-    // offline fp32 blocks-only form: the workgroups may share the (utterance, frame) axis (wg_spans, SPANS instantiation)
+                   unsigned long long* stamps, hipStream_t s, const Quant* q, bool front_done, const int* pref) {
+    // offline fp32 blocks-only form: the workgroups may share the (utterance, frame) axis (span_begin, SPANS instantiation)
     const SpanPlan pl = span_plan(B, T, HALO_BLOCKS, front_done && !state && !q && lens == nullptr);
+    if (pref && front_done && !state && !q) {          // variable-length batch in shares (pref: see launch_len_prefix)
+        hipLaunchKernelGGL((k_encoder<TPW, false, false, false, true>), dim3(var_span_workgroups(B)), dim3(NTHR),
+                           ENC_GT_LDS_FLOATS * 4, s, spec, sb, sf, st, T, pref, B, 0.f, PF, PI, en0, en1, en2, en3, en4, state,
+                           stamps);
+        GT_LAUNCH_CHECK();
+        return 0;
+    }
 #define GT_ENC(TPWV, QV, FRV)                                                                                       \
     hipLaunchKernelGGL((k_encoder<TPWV, false, QV, FRV>), dim3(B), dim3(NTHR),                                      \
                        (FRV ? ENC_LDS_FLOATS : ENC_GT_LDS_FLOATS) * 4, s, spec, sb, sf, st,                         \
@@ -3855,7 +3919,13 @@ int launch_gtcn_ms(const float* xin, float* xout1, float* xout2, const float* P,
 }
 
 int launch_gtcn_band(const float* xin, float* xout, const float* P, int B, int T, const int* lens, const float* addend,
-                     hipStream_t s, const Quant* q) {
+                     hipStream_t s, const Quant* q, const int* pref) {
+    if (pref && !q) {
+        hipLaunchKernelGGL((k_gtcn_band<false, true>), dim3(var_span_workgroups(B)), dim3(NTHR), GB_LDS_FLOATS * 4, s, xin, xout,
+                           P, B, T, pref, addend);
+        GT_LAUNCH_CHECK();
+        return 0;
+    }
     if (q) {
         hipLaunchKernelGGL(k_gtcn_band<true>, dim3(B), dim3(NTHR), GB_LDS_FLOATS * 4, s, xin, xout, P, B, T, lens, addend);
         GT_LAUNCH_CHECK();
@@ -3877,8 +3947,21 @@ int launch_gtcn_band(const float* xin, float* xout, const float* P, int B, int T
 int launch_decoder(const float* xg, const float* en0, const float* en1, const float* en2, const float* en3,
                    const float* en4, const float* spec, long sb, long sf, long st, float* out, long osb, long osf,
                    long ost, int B, int T, const int* lens, const float* PF, const int* PI, float* state, float* dbg,
-                   unsigned long long* stamps, hipStream_t s, const Quant* q) {
-    // offline fp32 calls: the workgroups may share the (utterance, frame) axis (wg_spans, SPANS instantiation); the stage
+                   unsigned long long* stamps, hipStream_t s, const Quant* q, const int* pref) {
+    if (pref && !state && !q) {                        // variable-length batch in shares (pref: see launch_len_prefix)
+        const int nwg = var_span_workgroups(B);
+        if (dbg)
+            hipLaunchKernelGGL((k_decoder<true, TPW, false, false, true>), dim3(nwg), dim3(NTHR), DEC_LDS_FLOATS * 4, s, xg, en0,
+                               en1, en2, en3, en4, spec, sb, sf, st, out, osb, osf, ost, T, pref, B, 0.f, 0.f, PF, PI, state, dbg,
+                               stamps);
+        else
+            hipLaunchKernelGGL((k_decoder<false, TPW, false, false, true>), dim3(nwg), dim3(NTHR), DEC_LDS_FLOATS * 4, s, xg, en0,
+                               en1, en2, en3, en4, spec, sb, sf, st, out, osb, osf, ost, T, pref, B, 0.f, 0.f, PF, PI, state, dbg,
+                               stamps);
+        GT_LAUNCH_CHECK();
+        return 0;
+    }
+    // offline fp32 calls: the workgroups may share the (utterance, frame) axis (span_begin, SPANS instantiation); the stage
     // taps (dbg) index by the batch position, so a debug run is never split into two launches
     SpanPlan pl = span_plan(B, T, HALO_BLOCKS, !state && !q && lens == nullptr);
     if (dbg && pl.nA && pl.nwgB) {

@@ -181,6 +181,11 @@ int gtcrn_pack_params_host(const float *h_params, long n_floats, float *h_f, int
 /* on = 2 (diagnostic build): phase stamps only -- a single-frame streaming step stays the ONE-launch form (its
  * stamps land in kernel slot 0 of gtcrn_debug_stamps, one row per workgroup of four streams). */
 int gtcrn_debug_enable(gtcrn_model *m, int on);
+/* Variable-length batches (gtcrn_forward_wave_var) of B <= 1024 utterances that are not whole rounds of 256 run the
+ * per-utterance kernels in time spans: 256-workgroup rounds share the frames that exist, so a folder of a few dozen
+ * files fills the chip.  Results are bit-identical either way; on = 0 goes back to one workgroup per utterance (the A/B
+ * switch of tests and measurements).  Default on. */
+int gtcrn_var_spans_enable(gtcrn_model *m, int on);
 long gtcrn_debug_tap(gtcrn_model *m, const char *name, int b, float *h_dst, long cap);
 /* Diagnostic build only (libgtcrn_micro_hip_stamps.so, -DGT_STAMPS): per-workgroup sums of shader
  * cycles spent in each barrier-delimited phase of kernel 0 encoder, 1 gtcn1, 2 gtcn2, 3 decoder,

@@ -105,6 +105,11 @@ def test_variable_length_batch_equals_single_clips_bit_for_bit(tmp_path):
         host[j, :len(c)] = c
     out = torch.full((len(lens), 256 * (Lmax // 256)), -7.0, device="cuda")
     y = eng.forward_wave_var(torch.from_numpy(host).cuda(), lens, win, out=out)
+    # (B = 12 runs in time spans over the lengths' prefix table; one workgroup per utterance gives the same bits)
+    eng.var_spans_enable(False)
+    y0 = eng.forward_wave_var(torch.from_numpy(host).cuda(), lens, win)
+    assert all(torch.equal(y0[j, :256 * (L // 256)], y[j, :256 * (L // 256)]) for j, L in enumerate(lens))
+    eng.var_spans_enable(True)
     orc = O.Oracle(p)
     for j, (c, L) in enumerate(zip(clips, lens)):
         single = eng.forward_wave(torch.from_numpy(c).cuda(), win)
@@ -143,3 +148,32 @@ def test_variable_length_batch_equals_single_clips_bit_for_bit(tmp_path):
         want = np.clip(np.rint(want * 32768.0), -32768, 32767).astype(np.int16)
         _, got = wavfile.read(enh_dir / f"n_fileid_{k}_enh.wav")
         assert np.array_equal(got, want), k
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,Lmax,seed", [(3, 40000, 1), (40, 48000, 2), (255, 9000, 3), (300, 6000, 4), (1025, 2000, 5)])
+def test_variable_length_batches_in_time_spans_equal_one_workgroup_per_utterance(B, Lmax, seed):
+    """Variable-length batches that are not whole rounds of 256 share the frames that exist between 256 k workgroups
+    (prefix table of the lengths, span_begin in kernels.hip); more than 1024 utterances fall back to one workgroup per
+    utterance.  Either way every sample equals the unshared launch bit for bit, including utterances of the minimum
+    length and shares that cross several short utterances."""
+    from conftest import load_params
+    from gtcrn_micro_amd import Engine
+    eng = Engine(load_params("dns3"), 0)
+    win = torch.hann_window(512).pow(0.5).cuda()
+    rng = np.random.default_rng(seed)
+    lens = rng.integers(257, Lmax + 1, B).tolist()
+    lens[0] = Lmax
+    if B > 2:
+        lens[1] = 257                                   # one frame pair: shorter than any share's warm-up
+        lens[B // 2] = min(Lmax, 256 * 16 + 1)
+    wave = torch.randn(B, Lmax, device="cuda", generator=torch.Generator("cuda").manual_seed(seed)) * 0.1
+    y = eng.forward_wave_var(wave, lens, win)
+    eng.var_spans_enable(False)
+    y0 = eng.forward_wave_var(wave, lens, win)
+    eng.var_spans_enable(True)
+    valid = torch.arange(y.shape[1], device="cuda")[None] < torch.tensor([256 * (L // 256) for L in lens], device="cuda")[:, None]
+    assert torch.equal(torch.where(valid, y, 0), torch.where(valid, y0, 0))      # (the rest of a row is unspecified)
+    j = B // 2
+    single = eng.forward_wave(wave[j, :lens[j]].contiguous(), win)
+    assert torch.equal(y[j, :single.shape[0]], single)
