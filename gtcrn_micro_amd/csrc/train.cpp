@@ -74,6 +74,11 @@ struct Unit {                 // conv (dense or depthwise) + BatchNorm + activat
     // backward: `front` = the unit whose gradient input is this unit's dx (TCN conv2 -> conv1): the fused depthwise
     // backward accumulates that unit's BatchNorm reduction too (gtt::dwunit_bwd)
     Unit* front = nullptr;
+    // `lean`: this unit's activation has ONE forward reader (a normalise-on-load conv, which forms it from y) and one
+    // backward reader (that conv's fused backward, which recomputes it from y too: gtt::DwUnitNext::recompute_x), so it
+    // is never stored -- a == nullptr.  Set by plan() for conv1 / conv2 of the TCN blocks and depth_conv of the GTConv
+    // blocks when fusion bits 1, 4 (and 2 for conv1) and 8 are on.
+    bool lean = false;
 };
 
 struct GtBlock {              // GTConvBlock (models/gtcrn_micro.py:167-253)
@@ -107,7 +112,8 @@ struct gtcrn_trainer {
     size_t arena_floats = 0;
     float* fscratch = nullptr;    // wgrad / TRA partial sums
     double* dscratch = nullptr;   // BatchNorm partial sums
-    int fusions = 7;                  // gtcrn_trainer_set_fusions: 1 normalise-on-load, 2 depthwise backward, 4 riding reductions
+    int fusions = 15;                 // gtcrn_trainer_set_fusions: 1 normalise-on-load, 2 depthwise backward, 4 riding reductions,
+                                      // 8 single-reader activations recomputed in the backward instead of stored
     const void* red_unit = nullptr;   // backward: the unit whose BatchNorm reduction already sits in dscratch ...
     int red_parts = 0;                // ... as this many per-workgroup partial sums (see unit_bwd)
     std::map<std::string, long> off;   // parameter name -> blob offset
@@ -191,10 +197,11 @@ void unit_params(gtcrn_trainer* t, Unit& u, const std::string& conv, const std::
     u.o_slope = act.empty() ? -1 : P(t, act + ".weight");
 }
 
-void alloc_unit(Bump& b, Unit& u, long n, int C) {
+void alloc_unit(Bump& b, Unit& u, long n, int C, bool lean = false) {
     u.n = n; u.C = C;
+    u.lean = lean;
     u.y = b.take_saved_y((size_t)n * C);
-    u.a = b.take_saved((size_t)n * C);
+    u.a = lean ? nullptr : b.take_saved((size_t)n * C);
     u.stats = b.take(128);              // mean[C], invstd[C]; +32: the centring shift of the stored y (bf16 storage);
                                         // +64: mean - shift, invstd for the backward (exact chain, see bn_stats)
     u.bstats = b.exact ? u.stats + 64 : u.stats;
@@ -249,6 +256,10 @@ size_t plan(gtcrn_trainer* t, int B, int T, float* base) {
     const int T2 = T + 2;
     const long n33x = (long)B * T2 * 33;
     const bool fuse = t->ybf <= 1 && (t->fusions & 1);      // (not for the fp16 diagnostic storage)
+    // activations whose only readers are a normalise-on-load conv and that conv's fused backward are not stored (the
+    // conditions under which unit_bwd takes those fused forms with a riding reduction)
+    const bool lean = fuse && t->bf == t->ybf && (t->fusions & 4) && (t->fusions & 8);
+    const bool lean_c1 = lean && (t->fusions & 2);
     t->taps.clear();
     {   // (the fp32 twins of the exact chain are assigned at the end; a unit that has none must not keep an old one)
         Unit* all[4 + 6 * 3 + 8 * 3] = {&t->en0, &t->en1, &t->de3, &t->de4};
@@ -296,7 +307,7 @@ size_t plan(gtcrn_trainer* t, int B, int T, float* base) {
         }
         unit_params(t, k.depth, p + ".depth_conv", p + ".depth_bn", p + ".depth_act");
         k.depth.act = gtt::ACT_PRELU; k.depth.x = k.pc1.a;
-        alloc_unit(b, k.depth, nt, 16);
+        alloc_unit(b, k.depth, nt, 16, lean);
         // point_conv2: Conv2d(16,8,1) weight [8][16] / ConvTranspose2d(16,8,1) weight [16][8]
         k.pc2.cg = conv_geom(B, Tt, Tt, 33, 33, 16, 0, 16, 8, 8, 1, 1, 0, 0, 0, 0, 1, 0, deconv ? 1 : 16, deconv ? 8 : 1, 1, 1);
         unit_params(t, k.pc2, p + ".point_conv2", p + ".point_bn2", "");
@@ -324,7 +335,7 @@ size_t plan(gtcrn_trainer* t, int B, int T, float* base) {
         k.c1.cg = conv_geom(B, T, T, 33, 33, 16, 0, 16, 16, 16, 1, 1, 0, 0, 0, 0, 1, 0, 16, 1, 1, 1);
         unit_params(t, k.c1, p + ".conv1", p + ".bn1", p + ".act1");
         k.c1.act = gtt::ACT_PRELU; k.c1.x = X;
-        alloc_unit(b, k.c1, n33, 16);
+        alloc_unit(b, k.c1, n33, 16, lean_c1);
         k.c2.dw = true;
         DwGeom g{};
         g.B = B; g.Tin = T; g.Tout = T; g.F = 33; g.C = 16; g.nkt = 3; g.nkf = 1;
@@ -333,7 +344,7 @@ size_t plan(gtcrn_trainer* t, int B, int T, float* base) {
         k.c2.dg = g;
         unit_params(t, k.c2, p + ".conv2", p + ".bn2", p + ".act2");
         k.c2.act = gtt::ACT_PRELU; k.c2.x = k.c1.a;
-        alloc_unit(b, k.c2, n33, 16);
+        alloc_unit(b, k.c2, n33, 16, lean);
         k.c3.cg = k.c1.cg;
         unit_params(t, k.c3, p + ".conv3", p + ".bn3", p + ".act3");
         k.c3.act = gtt::ACT_PRELU; k.c3.x = k.c2.a; k.c3.res = X;
@@ -611,6 +622,10 @@ int unit_bwd(gtcrn_trainer* t, Unit& u, const float* prm, float* grads, const fl
         const float* fbn = prm + f->o_bn;
         nx.y = f->y; nx.stats = f->bstats; nx.gamma = fbn; nx.beta = fbn + f->C; nx.slope = prm + f->o_slope;
         nx.res = f->res;
+        // this unit's input IS that unit's activation (conv3 <- conv2 <- conv1 <- the previous block's conv3,
+        // point_conv2 <- depth_conv): recomputed from the y the reduction reads anyway instead of loaded
+        if ((t->fusions & 8) && u.x == f->a)
+            nx.recompute_x = (t->bf && !t->exact) ? 2 : 1;
     }
     if (!u.dw && u.cg.nkt == 1 && u.cg.nkf == 1 && u.cg.sf == 1 && (u.cg.Cin % 4) == 0 && (u.cg.Cout % 4) == 0) {
         // pointwise unit: BatchNorm backward, data gradient and weight gradient in one pass (after the reduction)
@@ -753,7 +768,7 @@ int gtcrn_trainer_set_storage(gtcrn_trainer* t, int storage) {
 }
 
 int gtcrn_trainer_set_fusions(gtcrn_trainer* t, int mask) {
-    if (!t || mask < 0 || mask > 7) return tfail(GTCRN_ERR_ARG, "gtcrn_trainer_set_fusions: mask must be 0..7");
+    if (!t || mask < 0 || mask > 15) return tfail(GTCRN_ERR_ARG, "gtcrn_trainer_set_fusions: mask must be 0..15");
     if (t->fusions != mask) {
         t->fusions = mask;
         t->planned = false;      // the unit links are laid out again on the next forward

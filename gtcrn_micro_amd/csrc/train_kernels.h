@@ -120,6 +120,9 @@ int bn_act_bwd(const float* da, const float* y, long n, int C, const float* stat
 struct DwUnitNext {
     const float *y, *stats, *gamma, *beta, *slope;    // of the unit in front (16 channels, PReLU)
     const float* res = nullptr;                       // its residual input (unit1x1_bwd only)
+    // 1 / 2: that unit's activation IS the input x of the unit whose backward runs, and x is recomputed from y (and
+    // res) instead of being read (x may then be nullptr); 2: rounded to bf16 as the forward's consumer saw it
+    int recompute_x = 0;
 };
 // The whole backward of a pointwise (1x1) conv + BatchNorm + activation unit in two passes: the BatchNorm
 // reduction, then ONE kernel that forms dy, the data gradient dx (nullptr: not needed; dx_acc: add) and the

@@ -380,7 +380,7 @@ __device__ __forceinline__ float ycopy_value(float y, float z, float mean, float
 // the previous unit's activation, handed on by a normalise-on-load conv: rounded 16-bit copy for the backward (always),
 // and in the exact-chain mode the fp32 value for the activation's other readers
 __device__ __forceinline__ void pre_store(const BnPre& pre, long idx, const f32x4 a) {
-    sst4<kNtSt>(pre.a_out, idx, pre.bf, a);
+    if (pre.a_out) sst4<kNtSt>(pre.a_out, idx, pre.bf, a);      // (nullptr: the backward recomputes it from y, see NextRedArgs)
     if (pre.exact && pre.a_chain) sst4<kNtSt>(pre.a_chain, idx, 0, a);
 }
 // ... and, exact chain, the centred copy of the previous unit's conv output y (see ycopy_value)
@@ -1548,11 +1548,16 @@ struct BnBwdArgs {
 // the unit whose gradient input is the dx a backward kernel produces (16 channels, PReLU; res: its residual input or
 // nullptr): that unit's first backward pass -- sum dz, sum dz * xhat, sum of the slope terms -- is accumulated by the
 // producing kernel from one more read of its y (and res) instead of a pass that re-reads dx as well
+// XR (with NEXT): that unit's activation is this unit's input x, and it is not read but RECOMPUTED from the y (and res)
+// loaded for the reduction -- one tensor read less, and the forward need not store the activation at all when this
+// backward is its only other reader.  xround: the forward's consumer convolved the activation rounded to the 16-bit
+// storage format (bf16 storage; not the exact chain), so the recomputed one is rounded the same way.
 struct NextRedArgs {
     const float *y, *stats, *gamma, *beta, *slope, *res;
+    int xround;
 };
 // NEXT: see NextRedArgs; rpartial [gridDim.x][48] doubles
-template <int FMT, int YF, bool NEXT = false>   // storage formats of x / res and of y, compile time (see sld1)
+template <int FMT, int YF, bool NEXT = false, bool XR = false>   // storage formats of x / res and of y, compile time (see sld1)
 __global__ __launch_bounds__(NT) void k_unit1x1_bwd(ConvGeom g, const float* __restrict__ x, const float* __restrict__ y,
                                                    const float* __restrict__ da, const float* __restrict__ res,
                                                    BnBwdArgs bn, const float* __restrict__ w,
@@ -1573,6 +1578,8 @@ __global__ __launch_bounds__(NT) void k_unit1x1_bwd(ConvGeom g, const float* __r
     }
     __shared__ __attribute__((aligned(16))) float sWt[256];        // data-gradient A matrix [ci][co] = W[co][ci]
     __shared__ __attribute__((aligned(16))) float sT[NT / 64][256];   // per wave: dy tile [pos][16]
+    __shared__ __attribute__((aligned(16))) float sX[XR ? NT / 64 : 1][XR ? 256 : 4];   // XR: the recomputed x tile [pos][16]
+    static_assert(!XR || NEXT, "x is recomputed from the NEXT unit's y");
     __shared__ float sAcc[NT / 64][256 + 64];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, n = lane & 15, q = lane >> 4;
     {
@@ -1604,17 +1611,35 @@ __global__ __launch_bounds__(NT) void k_unit1x1_bwd(ConvGeom g, const float* __r
         const long p = tile * 16 + n;
         const bool pv = p < npos;
         // weight-gradient operand x in (c, k) layout: 4 coalesced 256-byte wave loads, issued first
-        unsigned xb[4];         // raw words: decoded where they are used (see sld1_raw)
+        unsigned xb[4] = {0u, 0u, 0u, 0u};         // raw words: decoded where they are used (see sld1_raw)
+        if constexpr (!XR) {
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const long pu = tile * 16 + 4 * u + k;
-            xb[u] = (pu < npos && ci_ok) ? sld1_raw<FMT>(x, pu * g.CinT + g.cin_off + c) : 0u;
+            for (int u = 0; u < 4; ++u) {
+                const long pu = tile * 16 + 4 * u + k;
+                xb[u] = (pu < npos && ci_ok) ? sld1_raw<FMT>(x, pu * g.CinT + g.cin_off + c) : 0u;
+            }
         }
         const unsigned xodd = (unsigned)((g.cin_off + c) & 1);    // CinT is a multiple of 4 here: the parity is the channel's
         f32x4 ynx = {0.f, 0.f, 0.f, 0.f}, rnx = ynx;
+        f32x4 nxh = ynx, nz = ynx;                                // the NEXT unit's xhat and pre-activation z of this lane's quad
         if constexpr (NEXT) {      // (Cin == CinT == 16 with NEXT: the launcher checks)
             ynx = sld4<kNt>(nx.y, (pv ? p : 0) * 16 + 4 * q, ybf);
             if (nx.res) rnx = sld4<kNt>(nx.res, (pv ? p : 0) * 16 + 4 * q, bf);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                nxh[e] = (ynx[e] - nmean[e]) * nistd[e];
+                nz[e] = ngm[e] * nxh[e] + nbt[e];
+                if (nx.res) nz[e] += rnx[e];
+            }
+            if constexpr (XR) {    // x = PReLU(z), the expressions of pre_apply / k_bn_act
+                f32x4 xa;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float a = nz[e] > 0.f ? nz[e] : nsl * nz[e];
+                    xa[e] = pv ? (nx.xround ? round16(a, 1) : a) : 0.f;
+                }
+                *reinterpret_cast<f32x4*>(&sX[wv][n * 16 + 4 * q]) = xa;
+            }
         }
         f32x4 dy = {0.f, 0.f, 0.f, 0.f};
         if (pv && co_ok4) {
@@ -1654,13 +1679,10 @@ __global__ __launch_bounds__(NT) void k_unit1x1_bwd(ConvGeom g, const float* __r
                 if constexpr (NEXT) {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        const float xh = (ynx[e] - nmean[e]) * nistd[e];
-                        float z = ngm[e] * xh + nbt[e];
-                        if (nx.res) z += rnx[e];
                         float dsl;
-                        const float dz = act_bwd(z, acc[e], ACT_PRELU, nsl, dsl);
+                        const float dz = act_bwd(nz[e], acc[e], ACT_PRELU, nsl, dsl);
                         vr[0][e] += dz;
-                        vr[1][e] = fmaf(dz, xh, vr[1][e]);
+                        vr[1][e] = fmaf(dz, nxh[e], vr[1][e]);
                         vr[2][e] += dsl;
                     }
                 }
@@ -1675,7 +1697,8 @@ __global__ __launch_bounds__(NT) void k_unit1x1_bwd(ConvGeom g, const float* __r
         for (int u = 0; u < 4; ++u) {
             const float a = sT[wv][(4 * u + k) * 16 + c];
             bsum += a;
-            accW = mfma4(a, sld1_dec<FMT>(xb[u], xodd), accW);
+            if constexpr (XR) accW = mfma4(a, sX[wv][(4 * u + k) * 16 + c], accW);
+            else accW = mfma4(a, sld1_dec<FMT>(xb[u], xodd), accW);
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
@@ -1727,7 +1750,8 @@ __global__ __launch_bounds__(NT) void k_unit1x1_bwd(ConvGeom g, const float* __r
 // memory.  Same per-element expressions as the separate kernels.  NEXT: the unit in FRONT (conv1) takes this dx as its
 // da, so its own first backward pass (sum dz, sum dz * xhat, sum of the slope terms) is accumulated right here from
 // one more read (its y) instead of a pass that re-reads dx and y.
-template <int FX, int FY, bool NEXT>   // storage formats of x (an activation) and of y / the next unit's y (conv outputs)
+// XR (with NEXT): x IS that unit's activation and is recomputed from its y at the three tap frames (see NextRedArgs).
+template <int FX, int FY, bool NEXT, bool XR = false>   // storage formats of x (an activation) and of y / the next unit's y (conv outputs)
 __global__ __launch_bounds__(NT) void k_dwunit31_bwd(DwGeom g, const float* __restrict__ x, const float* __restrict__ y,
                                                     const float* __restrict__ da, BnBwdArgs bn,
                                                     const float* __restrict__ w, float* __restrict__ dx,
@@ -1765,14 +1789,16 @@ __global__ __launch_bounds__(NT) void k_dwunit31_bwd(DwGeom g, const float* __re
         const bool b1 = P.to - d1 >= 0, b2 = P.to - d2 >= 0;             // frames t - d, t - 2d exist
         const long rf[3] = {p, f1 ? p + (long)d1 * g.F : p, f2 ? p + (long)d2 * g.F : p};
         const long rb[3] = {b2 ? p - (long)d2 * g.F : p, b1 ? p - (long)d1 * g.F : p, p};
-        typename Raw4<FY>::t yr[3], ynr{};
-        typename Raw4<FX>::t xr[3];
+        typename Raw4<FY>::t yr[3], ynr{}, ybr[2] = {};
+        typename Raw4<FX>::t xr[3] = {};
         f32x4 gr[3];
+        static_assert(!XR || NEXT, "x is recomputed from the NEXT unit's y");
 #pragma unroll
         for (int j = 0; j < 3; ++j) {
             yr[j] = sld4_raw<FY>(y, rf[j] * 16 + 4 * q);
             gr[j] = *reinterpret_cast<const f32x4*>(da + rf[j] * 16 + 4 * q);
-            xr[j] = sld4_raw<FX>(x, rb[j] * 16 + 4 * q);
+            if constexpr (!XR) xr[j] = sld4_raw<FX>(x, rb[j] * 16 + 4 * q);
+            else if (j < 2) ybr[j] = sld4_raw<FY>(nx.y, rb[j] * 16 + 4 * q);
         }
         if constexpr (NEXT) ynr = sld4_raw<FY>(nx.y, p * 16 + 4 * q);
         f32x4 dyv[3];
@@ -1790,7 +1816,24 @@ __global__ __launch_bounds__(NT) void k_dwunit31_bwd(DwGeom g, const float* __re
         const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
         dyv[1] = f1 ? dyv[1] : zero;
         dyv[2] = f2 ? dyv[2] : zero;
-        const f32x4 x0 = b2 ? dec4<FX>(xr[0]) : zero, x1 = b1 ? dec4<FX>(xr[1]) : zero, x2 = dec4<FX>(xr[2]);
+        f32x4 x0, x1, x2;
+        if constexpr (XR) {
+            auto xact = [&](const f32x4 yv) {        // PReLU(BatchNorm(y)) of the unit in front, as pre_apply forms it
+                f32x4 a;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float z = ngm[e] * ((yv[e] - nmean[e]) * nistd[e]) + nbt[e];
+                    const float v = z > 0.f ? z : nsl * z;
+                    a[e] = nx.xround ? round16(v, 1) : v;
+                }
+                return a;
+            };
+            x0 = b2 ? xact(dec4<FY>(ybr[0])) : zero;
+            x1 = b1 ? xact(dec4<FY>(ybr[1])) : zero;
+            x2 = xact(dec4<FY>(ynr));
+        } else {
+            x0 = b2 ? dec4<FX>(xr[0]) : zero; x1 = b1 ? dec4<FX>(xr[1]) : zero; x2 = dec4<FX>(xr[2]);
+        }
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             vw[0][e] = fmaf(dyv[0][e], x0[e], vw[0][e]);
@@ -2688,10 +2731,13 @@ int dwunit_bwd(const DwGeom& g, const float* x, const float* y, const float* da,
     BnBwdArgs bn{stats, gamma, beta, slope, red, ACT_PRELU};
     NextRedArgs nx{};
     const bool nxt = next && next->slope;
-    if (nxt) nx = NextRedArgs{next->y, next->stats, next->gamma, next->beta, next->slope, nullptr};
+    const bool xr = nxt && next->recompute_x;
+    if (!x && !xr) return (int)hipErrorInvalidValue;
+    if (nxt) nx = NextRedArgs{next->y, next->stats, next->gamma, next->beta, next->slope, nullptr, next->recompute_x == 2};
 #define GT_DU(F)                                                                                                        \
     do {                                                                                                               \
-        if (nxt) hipLaunchKernelGGL((k_dwunit31_bwd<F, F, true>), dim3(grid), dim3(NT), 0, s, g, x, y, da, bn, w, dx, wpart, nx, dscratch, it); \
+        if (xr) hipLaunchKernelGGL((k_dwunit31_bwd<F, F, true, true>), dim3(grid), dim3(NT), 0, s, g, x, y, da, bn, w, dx, wpart, nx, dscratch, it); \
+        else if (nxt) hipLaunchKernelGGL((k_dwunit31_bwd<F, F, true>), dim3(grid), dim3(NT), 0, s, g, x, y, da, bn, w, dx, wpart, nx, dscratch, it); \
         else hipLaunchKernelGGL((k_dwunit31_bwd<F, F, false>), dim3(grid), dim3(NT), 0, s, g, x, y, da, bn, w, dx, wpart, nx, dscratch, it); \
     } while (0)
     if (bf == 0) GT_DU(0);
@@ -2722,16 +2768,22 @@ int unit1x1_bwd(const ConvGeom& g, const float* x, const float* y, const float* 
     // the unit in front takes this dx as its gradient input: its reduction rides along (its partial sums replace this
     // unit's, which the finish kernel above has consumed, in dscratch)
     const bool nxt = next && next->slope && dx && g.Cin == 16 && g.CinT == 16 && g.cin_off == 0 && bf == ybf;
-    long waves = (long)(nxt ? NEXT_GRID : MAX_PARTIALS) * (NT / 64);
+    // (the recomputing form needs 120 VGPRs: four workgroups per CU, 1024 resident)
+    const bool xr_ = nxt && next->recompute_x;
+    long waves = (long)(nxt && !xr_ ? NEXT_GRID : MAX_PARTIALS) * (NT / 64);
     if (waves > ntiles) waves = ntiles;
     const long tpw = (ntiles + waves - 1) / waves;
     const int grid = (int)((ntiles + tpw * (NT / 64) - 1) / (tpw * (NT / 64)));
     BnBwdArgs bn{stats, gamma, beta, slope, red, act};
     NextRedArgs nx{};
-    if (nxt) nx = NextRedArgs{next->y, next->stats, next->gamma, next->beta, next->slope, next->res};
+    const bool xr = nxt && next->recompute_x;
+    if (!x && !xr) return (int)hipErrorInvalidValue;
+    if (nxt) nx = NextRedArgs{next->y, next->stats, next->gamma, next->beta, next->slope, next->res, next->recompute_x == 2};
 #define GT_U1(F, Y)                                                                                                     \
     do {                                                                                                               \
-        if (nxt) hipLaunchKernelGGL((k_unit1x1_bwd<F, Y, true>), dim3(grid), dim3(NT), 0, s, g, x, y, da, res, bn, w, dx, dx_acc, \
+        if (xr) hipLaunchKernelGGL((k_unit1x1_bwd<F, Y, true, true>), dim3(grid), dim3(NT), 0, s, g, x, y, da, res, bn, w, dx, dx_acc, \
+                                   dres, dres_acc, fscratch, tpw, nx, dscratch);                                        \
+        else if (nxt) hipLaunchKernelGGL((k_unit1x1_bwd<F, Y, true>), dim3(grid), dim3(NT), 0, s, g, x, y, da, res, bn, w, dx, dx_acc, \
                                     dres, dres_acc, fscratch, tpw, nx, dscratch);                                       \
         else hipLaunchKernelGGL((k_unit1x1_bwd<F, Y, false>), dim3(grid), dim3(NT), 0, s, g, x, y, da, res, bn, w, dx, dx_acc, \
                                 dres, dres_acc, fscratch, tpw, nx, dscratch);                                           \

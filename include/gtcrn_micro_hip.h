@@ -245,8 +245,11 @@ long gtcrn_train_workspace_bytes2(int B, int T, int storage);
 /* Diagnostic: which pass fusions of the train step are active (default: all).  bit 0: BatchNorm + PReLU of a unit
  * applied by the conv that consumes it (normalise-on-load; the forward is bit-identical with and without), bit 1: the
  * depthwise unit's backward in one pass, bit 2: BatchNorm reductions accumulated by the kernel that produces their
- * gradient input.  0 runs the layer-at-a-time passes (tests/test_gpu_train.py compares the two).  Takes effect at the
- * next forward; not part of the reference's interface. */
+ * gradient input, bit 3 (needs bits 0 and 2): an activation whose only readers are a normalise-on-load conv and that
+ * conv's fused backward is not stored -- the backward recomputes it from the conv output it reads anyway (22 of the 46
+ * units: one tensor write less in the forward, one read less in the backward, 6 GiB less workspace at B = 512).
+ * 0 runs the layer-at-a-time passes (tests/test_gpu_train.py compares them).  Takes effect at the next forward; not
+ * part of the reference's interface. */
 int gtcrn_trainer_set_fusions(gtcrn_trainer *t, int mask);
 int gtcrn_train_forward(gtcrn_trainer *t, float *d_params, const float *d_spec, long sb, long sf, long st,
                         float *d_out, long ob, long of, long ot, int B, int T, void *stream);
