@@ -112,8 +112,9 @@ struct gtcrn_trainer {
     size_t arena_floats = 0;
     float* fscratch = nullptr;    // wgrad / TRA partial sums
     double* dscratch = nullptr;   // BatchNorm partial sums
-    int fusions = 15;                 // gtcrn_trainer_set_fusions: 1 normalise-on-load, 2 depthwise backward, 4 riding reductions,
-                                      // 8 single-reader activations recomputed in the backward instead of stored
+    int fusions = 31;                 // gtcrn_trainer_set_fusions: 1 normalise-on-load, 2 depthwise backward, 4 riding reductions,
+                                      // 8 single-reader activations recomputed in the backward instead of stored,
+                                      // 16 skip gradients accumulated in place (no add passes in the backward)
     const void* red_unit = nullptr;   // backward: the unit whose BatchNorm reduction already sits in dscratch ...
     int red_parts = 0;                // ... as this many per-workgroup partial sums (see unit_bwd)
     std::map<std::string, long> off;   // parameter name -> blob offset
@@ -677,17 +678,18 @@ int gt_fwd(gtcrn_trainer* t, GtBlock& k, float* prm, hipStream_t s) {
     T_RUN(gtt::gate_shuffle_fwd(k.pc2.a, k.g, k.xin, t->B, t->T, k.Tt, k.out, s, t->bf));
     return 0;
 }
-// dout: gradient of k.out; dxin: gradient of the block input (all 16 channels written)
-int gt_bwd(gtcrn_trainer* t, GtBlock& k, const float* prm, float* grads, const float* dout, float* dxin,
+// dout: gradient of k.out; dxin: gradient of the block input (all 16 channels written; acc: ADDED to what dxin holds --
+// the gradient the same tensor received as a decoder skip)
+int gt_bwd(gtcrn_trainer* t, GtBlock& k, const float* prm, float* grads, const float* dout, float* dxin, int acc,
            hipStream_t s) {
     const float* tr = prm + k.o_tra;
     float* gtr = grads + k.o_tra;
     int rc;
     T_RUN(gtt::tra_gate_shuffle_bwd(dout, k.pc2.a, k.g, k.e, k.yt, t->B, t->T, k.Tt, tr, tr + 32, t->dv, dxin, gtr,
-                                    gtr + 24, gtr + 32, gtr + 96, t->tmp_tra, t->fscratch, s, t->bf));
+                                    gtr + 24, gtr + 32, gtr + 96, t->tmp_tra, t->fscratch, s, t->bf, acc));
     if ((rc = unit_bwd(t, k.pc2, prm, grads, t->dv, t->dhd, 0, nullptr, 0, s))) return rc;
     if ((rc = unit_bwd(t, k.depth, prm, grads, t->dhd, t->dh, 0, nullptr, 0, s))) return rc;
-    if ((rc = unit_bwd(t, k.pc1, prm, grads, t->dh, dxin, 0, nullptr, 0, s))) return rc;   // channels 0..7
+    if ((rc = unit_bwd(t, k.pc1, prm, grads, t->dh, dxin, acc, nullptr, 0, s))) return rc;   // channels 0..7
     return 0;
 }
 
@@ -768,7 +770,7 @@ int gtcrn_trainer_set_storage(gtcrn_trainer* t, int storage) {
 }
 
 int gtcrn_trainer_set_fusions(gtcrn_trainer* t, int mask) {
-    if (!t || mask < 0 || mask > 15) return tfail(GTCRN_ERR_ARG, "gtcrn_trainer_set_fusions: mask must be 0..15");
+    if (!t || mask < 0 || mask > 31) return tfail(GTCRN_ERR_ARG, "gtcrn_trainer_set_fusions: mask must be 0..31");
     if (t->fusions != mask) {
         t->fusions = mask;
         t->planned = false;      // the unit links are laid out again on the next forward
@@ -869,31 +871,47 @@ int gtcrn_train_backward(gtcrn_trainer* t, const float* d_params, const float* d
         float* ds = t->gs[4 - i];            // gs[2], gs[3], gs[4]
         if (t->share_sums)
             T_RUN(gtt::add_saved(i ? t->dec[i - 1].out : t->tcn[7].c3.a, t->enc[2 - i].out, t->dec[i].s, n33, s, t->bf));
-        if ((rc = gt_bwd(t, t->dec[i], prm, G, dout, ds, s))) return rc;
+        if ((rc = gt_bwd(t, t->dec[i], prm, G, dout, ds, 0, s))) return rc;
         dout = ds;
     }
+    // Every encoder tensor en_outs[j] receives two gradients: the decoder's skip (gs[j], gs0 for j = 0 -- complete by
+    // now) and the main path's.  The main-path producer ADDS its part into the skip's buffer (accumulating stores of the
+    // kernels that form it) instead of a separate pass that reads both and writes the sum: five adds per step gone.
     // GTCN: out = act3(bn3(conv3(..)) + x): dx = dz3 (residual) + conv1 data gradient
     float* qa = t->q1;
     float* qb = t->q2;
+    const bool inplace = (t->fusions & 16) != 0;
     for (int i = 7; i >= 0; --i) {
         TcnBlock& k = t->tcn[i];
-        if ((rc = unit_bwd(t, k.c3, prm, G, dout, t->dhd, 0, qa, 0, s))) return rc;     // dhd: d a2, qa: residual part
+        // block 0's input is en_outs[4]: both parts go on top of gs[4] (block 7 read it as its gradient input long ago)
+        float* dxk = (i == 0 && inplace) ? t->gs[4] : qa;
+        const int acc = (i == 0 && inplace) ? 1 : 0;
+        if ((rc = unit_bwd(t, k.c3, prm, G, dout, t->dhd, 0, dxk, acc, s))) return rc;    // dhd: d a2, dxk: residual part
         if ((rc = unit_bwd(t, k.c2, prm, G, t->dhd, t->dh, 0, nullptr, 0, s))) return rc;  // dh: d a1
-        if ((rc = unit_bwd(t, k.c1, prm, G, t->dh, qa, 1, nullptr, 0, s))) return rc;     // += conv1 data gradient
-        dout = qa;
+        if ((rc = unit_bwd(t, k.c1, prm, G, t->dh, dxk, 1, nullptr, 0, s))) return rc;     // += conv1 data gradient
+        dout = dxk;
         float* tq = qa; qa = qb; qb = tq;
     }
-    // encoder blocks 2,1,0: total gradient of en_outs[k+2] = main path + decoder skip
-    for (int k = 2; k >= 0; --k) {
-        T_RUN(gtt::add(dout, t->gs[k + 2], qa, n33, s));
-        if ((rc = gt_bwd(t, t->enc[k], prm, G, qa, qb, s))) return rc;
-        dout = qb;
-        float* tq = qa; qa = qb; qb = tq;
+    if (!inplace) {      // (fusion bit 4 off: the separate adds, total gradient of en_outs[k+2] = main path + decoder skip)
+        for (int k = 2; k >= 0; --k) {
+            T_RUN(gtt::add(dout, t->gs[k + 2], qa, n33, s));
+            if ((rc = gt_bwd(t, t->enc[k], prm, G, qa, qb, 0, s))) return rc;
+            dout = qb;
+            float* tq = qa; qa = qb; qb = tq;
+        }
+        T_RUN(gtt::add(dout, t->gs[1], qa, n33, s));                    // d en1.a
+        if ((rc = unit_bwd(t, t->en1, prm, G, qa, t->d65, 0, nullptr, 0, s))) return rc;
+        T_RUN(gtt::add(t->d65, t->gs0, t->d65, n65, s));                // d en0.a
+        if ((rc = unit_bwd(t, t->en0, prm, G, t->d65, t->df0, 0, nullptr, 0, s))) return rc;
+    } else {
+        // encoder blocks 2,1,0: dout = total gradient of en_outs[k+2]; the block's input gradient lands on gs[k+1]
+        for (int k = 2; k >= 0; --k) {
+            if ((rc = gt_bwd(t, t->enc[k], prm, G, dout, t->gs[k + 1], 1, s))) return rc;
+            dout = t->gs[k + 1];
+        }
+        if ((rc = unit_bwd(t, t->en1, prm, G, dout, t->gs0, 1, nullptr, 0, s))) return rc;     // gs0 += : d en0.a
+        if ((rc = unit_bwd(t, t->en0, prm, G, t->gs0, t->df0, 0, nullptr, 0, s))) return rc;
     }
-    T_RUN(gtt::add(dout, t->gs[1], qa, n33, s));                    // d en1.a
-    if ((rc = unit_bwd(t, t->en1, prm, G, qa, t->d65, 0, nullptr, 0, s))) return rc;
-    T_RUN(gtt::add(t->d65, t->gs0, t->d65, n65, s));                // d en0.a
-    if ((rc = unit_bwd(t, t->en0, prm, G, t->d65, t->df0, 0, nullptr, 0, s))) return rc;
     {   // SFE weight gradient (no bias); the ERB bank is frozen and the input is data: the chain ends here
         DwGeom g{};
         g.B = B; g.Tin = T; g.Tout = T; g.F = 129; g.C = 3; g.nkt = 1; g.nkf = 3;

@@ -158,12 +158,12 @@ int tra_fwd(const float* v, int B, int Tt, const float* dw_w, const float* dw_b,
 // out[b,t,f,2c] = v[b,t,f,c] * g[b,t,c], out[b,t,f,2c+1] = x[b,t,f,8+c]   (shuffle, :222-227), t < T
 int gate_shuffle_fwd(const float* v, const float* g, const float* x, int B, int T, int Tt, float* out, hipStream_t s,
                      int bf = 0, float* out2 = nullptr, int out2_bf = 0);
-// backward of tra + gate + shuffle: dout [B][T][33][16] -> dv [B][Tt][33][8] (written), dx channels 8..15 (written),
-// parameter gradients written.  tmp: 3 * B*Tt*8 floats; scratch: MAX_PARTIALS * 80 floats.
+// backward of tra + gate + shuffle: dout [B][T][33][16] -> dv [B][Tt][33][8] (written), dx channels 8..15 (written; dx_acc:
+// added to what dx holds), parameter gradients written.  tmp: 3 * B*Tt*8 floats; scratch: MAX_PARTIALS * 80 floats.
 int tra_gate_shuffle_bwd(const float* dout, const float* v, const float* g, const float* e, const float* y, int B,
                          int T, int Tt, const float* dw_w, const float* pw_w, float* dv, float* dx, float* d_dw_w,
                          float* d_dw_b, float* d_pw_w, float* d_pw_b, float* tmp, float* scratch, hipStream_t s,
-                         int bf = 0);
+                         int bf = 0, int dx_acc = 0);
 
 // HybridLoss (loss.py:30-71).  hybrid_loss_spec: the three spectral terms -- per-workgroup sums (sum of squared
 // compressed real+imag differences, sum of squared compressed-magnitude differences) into `partial`, and their

@@ -2163,8 +2163,10 @@ __global__ __launch_bounds__(NT) void k_gate_shuffle(const float* __restrict__ v
 __global__ __launch_bounds__(NT) void k_gate_shuffle_bwd(const float* __restrict__ dout, const float* __restrict__ g,
                                                         const float* __restrict__ dy, const float* __restrict__ v,
                                                         const float* __restrict__ dw_w, int B, int T, int Tt,
-                                                        float* __restrict__ dv, float* __restrict__ dx, int bf) {
-    // thread (position of the T' frames, half h): channels 4h..4h+3; 16-byte accesses
+                                                        float* __restrict__ dv, float* __restrict__ dx, int bf,
+                                                        int dx_acc) {
+    // thread (position of the T' frames, half h): channels 4h..4h+3; 16-byte accesses.  dx_acc: the pass-through half
+    // is ADDED to what dx holds (the skip gradient of the same tensor, see gtcrn_train_backward)
     const long total = (long)B * Tt * 33 * 2;
     for (long i = (long)blockIdx.x * NT + threadIdx.x; i < total; i += (long)gridDim.x * NT) {
         const int h = (int)(i & 1);
@@ -2178,7 +2180,9 @@ __global__ __launch_bounds__(NT) void k_gate_shuffle_bwd(const float* __restrict
             const f32x4 d0 = sld4<kNt>(dout, pos * 16 + 8 * h, 0), d1 = sld4<kNt>(dout, pos * 16 + 8 * h + 4, 0);
             const f32x4 gg = *reinterpret_cast<const f32x4*>(g + rowv * 8 + 4 * h);
             r = f32x4{d0[0], d0[2], d1[0], d1[2]} * gg;
-            sst4(dx, pos * 16 + 8 + 4 * h, 0, f32x4{d0[1], d0[3], d1[1], d1[3]});
+            f32x4 px = f32x4{d0[1], d0[3], d1[1], d1[3]};
+            if (dx_acc) px = px + *reinterpret_cast<const f32x4*>(dx + pos * 16 + 8 + 4 * h);
+            sst4(dx, pos * 16 + 8 + 4 * h, 0, px);
         }
         f32x4 de = {0.f, 0.f, 0.f, 0.f};
         for (int k = 0; k < 3; ++k) {
@@ -2849,14 +2853,14 @@ int gate_shuffle_fwd(const float* v, const float* g, const float* x, int B, int 
 int tra_gate_shuffle_bwd(const float* dout, const float* v, const float* g, const float* e, const float* y, int B,
                          int T, int Tt, const float* dw_w, const float* pw_w, float* dv, float* dx, float* d_dw_w,
                          float* d_dw_b, float* d_pw_w, float* d_pw_b, float* tmp, float* scratch, hipStream_t s,
-                         int bf) {
+                         int bf, int dx_acc) {
     const long rows = (long)B * Tt;
     float* dzg = tmp;
     float* dy = tmp + rows * 8;
     hipLaunchKernelGGL(k_tra_dgate, dim3(grid_for(rows * 64, 8192)), dim3(NT), 0, s, dout, v, g, B, T, Tt, dzg, bf);
     hipLaunchKernelGGL(k_tra_dy, dim3(grid_for(rows * 8)), dim3(NT), 0, s, dzg, rows, pw_w, dy);
     hipLaunchKernelGGL(k_gate_shuffle_bwd, dim3(grid_for(rows * 33 * 2)), dim3(NT), 0, s, dout, g, dy, v, dw_w, B, T, Tt, dv,
-                       dx, bf);
+                       dx, bf, dx_acc);
     const int parts = (int)(rows < MAX_PARTIALS ? rows : MAX_PARTIALS);
     hipLaunchKernelGGL(k_tra_pgrad, dim3(parts), dim3(1024), 0, s, dzg, y, dy, e, B, Tt, scratch);
     // the four gradients are contiguous in the blob in exactly the partials' order (d_dw_w is the first)

@@ -248,6 +248,8 @@ long gtcrn_train_workspace_bytes2(int B, int T, int storage);
  * gradient input, bit 3 (needs bits 0 and 2): an activation whose only readers are a normalise-on-load conv and that
  * conv's fused backward is not stored -- the backward recomputes it from the conv output it reads anyway (22 of the 46
  * units: one tensor write less in the forward, one read less in the backward, 6 GiB less workspace at B = 512).
+ * bit 4: the two gradients every encoder output receives (decoder skip + main path) are summed by accumulating stores
+ * of the kernels that produce the second one, not by five add passes.
  * 0 runs the layer-at-a-time passes (tests/test_gpu_train.py compares them).  Takes effect at the next forward; not
  * part of the reference's interface. */
 int gtcrn_trainer_set_fusions(gtcrn_trainer *t, int mask);
