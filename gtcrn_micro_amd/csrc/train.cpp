@@ -112,9 +112,10 @@ struct gtcrn_trainer {
     size_t arena_floats = 0;
     float* fscratch = nullptr;    // wgrad / TRA partial sums
     double* dscratch = nullptr;   // BatchNorm partial sums
-    int fusions = 31;                 // gtcrn_trainer_set_fusions: 1 normalise-on-load, 2 depthwise backward, 4 riding reductions,
+    int fusions = 63;                 // gtcrn_trainer_set_fusions: 1 normalise-on-load, 2 depthwise backward, 4 riding reductions,
                                       // 8 single-reader activations recomputed in the backward instead of stored,
-                                      // 16 skip gradients accumulated in place (no add passes in the backward)
+                                      // 16 skip gradients accumulated in place (no add passes in the backward),
+                                      // 32 reductions riding in the adjoint convs of the 3x3 units and of en_convs.1
     const void* red_unit = nullptr;   // backward: the unit whose BatchNorm reduction already sits in dscratch ...
     int red_parts = 0;                // ... as this many per-workgroup partial sums (see unit_bwd)
     std::map<std::string, long> off;   // parameter name -> blob offset
@@ -281,6 +282,9 @@ size_t plan(gtcrn_trainer* t, int B, int T, float* base) {
     unit_params(t, t->en1, "encoder.en_convs.1.conv", "encoder.en_convs.1.bn", "encoder.en_convs.1.act");
     t->en1.act = gtt::ACT_PRELU; t->en1.x = t->en0.a;
     alloc_unit(b, t->en1, n33, 16);
+    // en_convs.1's adjoint produces en_convs.0's gradient input -- the TOTAL one only when it accumulates on top of the
+    // skip's part (fusion bit 4)
+    t->en1.front = (t->fusions & 16) ? &t->en0 : nullptr;
     t->taps["en0"] = {t->en0.a, {T, 65, 16}};
     t->taps["en1"] = {t->en1.a, {T, 33, 16}};
     const float* X = t->en1.a;
@@ -315,6 +319,7 @@ size_t plan(gtcrn_trainer* t, int B, int T, float* base) {
         k.pc2.act = gtt::ACT_NONE; k.pc2.x = k.depth.a;
         alloc_unit(b, k.pc2, nt, 8);
         k.pc2.front = &k.depth;
+        k.depth.front = &k.pc1;          // the depth conv's adjoint produces point_conv1's gradient input
         k.pc2.pre = fuse ? &k.depth : nullptr;
         k.depth.deferred = fuse;
         // (point_conv1 -> depth_conv is NOT fused: nine taps each re-apply the BatchNorm + PReLU -- the depthwise 3x3
@@ -653,13 +658,27 @@ int unit_bwd(gtcrn_trainer* t, Unit& u, const float* prm, float* grads, const fl
     T_RUN(gtt::bn_act_bwd(da, u.y, u.n, u.C, u.bstats, bn, bn + u.C, u.res, u.act,
                           u.o_slope >= 0 ? prm + u.o_slope : nullptr, t->dy, dres, dres_acc, gbn, gbn + u.C,
                           u.o_slope >= 0 ? grads + u.o_slope : nullptr, t->dscratch, s, t->bf, t->ybf, have_parts));
+    // the adjoint conv produces the gradient input of the unit in front: that unit's reduction rides in its epilogue
+    // (depthwise / dense 3x3 -> point_conv1, en_convs.1 -> en_convs.0; fusion bit 5).  dscratch is free again: this
+    // unit's own partial sums were consumed by bn_act_bwd above
+    bool ride_adj = ride && (t->fusions & 32) && !f->res && dx && !u.res && !dres;
+    if (ride_adj) {
+        if (u.dw) ride_adj = u.C == 16 && u.dg.nkt == 3 && u.dg.nkf == 3 && f->n == (long)u.dg.B * u.dg.Tin * u.dg.F;
+        else ride_adj = u.cg.Cin == 16 && u.cg.CinT == 16 && u.cg.cin_off == 0 && (u.cg.Cin % 4) == 0 && (u.cg.Cout % 4) == 0 &&
+                        ((u.cg.nkt == 3 && u.cg.nkf == 3) || (u.cg.nkt == 1 && u.cg.nkf == 5)) &&
+                        f->n == (long)u.cg.B * u.cg.Tin * u.cg.Fin;
+    }
+    int parts = 0;
     if (u.dw) {
         T_RUN(gtt::dw_wgrad(u.dg, u.x, t->dy, grads + u.o_w, u.o_b >= 0 ? grads + u.o_b : nullptr, t->fscratch, s));
-        if (dx) T_RUN(gtt::dw_fwd(adjoint(u.dg, dx_acc), t->dy, prm + u.o_w, nullptr, dx, s));
+        if (dx) T_RUN(gtt::dw_fwd(adjoint(u.dg, dx_acc), t->dy, prm + u.o_w, nullptr, dx, s, ride_adj ? t->dscratch : nullptr,
+                                  ride_adj ? &parts : nullptr, nullptr, nullptr, ride_adj ? &nx : nullptr, t->ybf));
     } else {
         T_RUN(gtt::conv_wgrad(u.cg, u.x, t->dy, grads + u.o_w, u.o_b >= 0 ? grads + u.o_b : nullptr, t->fscratch, s));
-        if (dx) T_RUN(gtt::conv_fwd(adjoint(u.cg, dx_acc), t->dy, prm + u.o_w, nullptr, dx, s));
+        if (dx) T_RUN(gtt::conv_fwd(adjoint(u.cg, dx_acc), t->dy, prm + u.o_w, nullptr, dx, s, ride_adj ? t->dscratch : nullptr,
+                                    ride_adj ? &parts : nullptr, nullptr, nullptr, ride_adj ? &nx : nullptr, t->ybf));
     }
+    if (ride_adj && parts > 0) { t->red_unit = f; t->red_parts = parts; }
     return 0;
 }
 
@@ -770,7 +789,7 @@ int gtcrn_trainer_set_storage(gtcrn_trainer* t, int storage) {
 }
 
 int gtcrn_trainer_set_fusions(gtcrn_trainer* t, int mask) {
-    if (!t || mask < 0 || mask > 31) return tfail(GTCRN_ERR_ARG, "gtcrn_trainer_set_fusions: mask must be 0..31");
+    if (!t || mask < 0 || mask > 63) return tfail(GTCRN_ERR_ARG, "gtcrn_trainer_set_fusions: mask must be 0..63");
     if (t->fusions != mask) {
         t->fusions = mask;
         t->planned = false;      // the unit links are laid out again on the next forward

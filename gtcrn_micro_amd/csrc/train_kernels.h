@@ -85,16 +85,20 @@ struct BnPre {
     float* y_out;
     int ybf_out;
 };
+struct DwUnitNext;
+// next (backward launches only): the output is the gradient input of that unit -- its BatchNorm reduction rides in the
+// epilogue (see DwUnitNext below; 3x3 and 1x5 dense adjoints, the depthwise 3x3 adjoint), per-workgroup sums in
+// stat_partial, their count in *stat_parts; next_yfmt: the storage format of that unit's y
 int conv_fwd(const ConvGeom& g, const float* in, const float* w, const float* bias, float* out, hipStream_t s,
              double* stat_partial = nullptr, int* stat_parts = nullptr, const float* shift = nullptr,
-             const BnPre* pre = nullptr);
+             const BnPre* pre = nullptr, const DwUnitNext* next = nullptr, int next_yfmt = 0);
 // dW (and db when dbias != nullptr) of the convolution g: in = its input, dout = gradient of its output.
 // scratch: MAX_PARTIALS * (9*256 + 16) floats.
 int conv_wgrad(const ConvGeom& g, const float* in, const float* dout, float* dw, float* dbias, float* scratch,
                hipStream_t s);
 int dw_fwd(const DwGeom& g, const float* in, const float* w, const float* bias, float* out, hipStream_t s,
            double* stat_partial = nullptr, int* stat_parts = nullptr, const float* shift = nullptr,
-           const BnPre* pre = nullptr);
+           const BnPre* pre = nullptr, const DwUnitNext* next = nullptr, int next_yfmt = 0);
 int dw_wgrad(const DwGeom& g, const float* in, const float* dout, float* dw, float* dbias, float* scratch,
              hipStream_t s);
 

@@ -460,18 +460,62 @@ __device__ __forceinline__ f32x4 win_value(const float* base, const WinPos& w, c
     }
     return x;
 }
+// the unit whose gradient input is the dx a backward kernel produces (16 channels, PReLU; res: its residual input or
+// nullptr): that unit's first backward pass -- sum dz, sum dz * xhat, sum of the slope terms -- is accumulated by the
+// producing kernel from one more read of its y (and res) instead of a pass that re-reads dx as well
+// XR (with NEXT): that unit's activation is this unit's input x, and it is not read but RECOMPUTED from the y (and res)
+// loaded for the reduction -- one tensor read less, and the forward need not store the activation at all when this
+// backward is its only other reader.  xround: the forward's consumer convolved the activation rounded to the 16-bit
+// storage format (bf16 storage; not the exact chain), so the recomputed one is rounded the same way.
+struct NextRedArgs {
+    const float *y, *stats, *gamma, *beta, *slope, *res;
+    int xround;
+    int yfmt;      // storage format of y (the kernels that do not take it as a template parameter: conv / depthwise adjoints)
+};
+// ... the same riding reduction in the epilogue of a conv that produces that gradient input as its OUTPUT (the adjoint
+// conv of a depthwise / dense 3x3 unit, of en_convs.1): constants of the lane's channel quad, and the three sums
+struct NextConst {
+    f32x4 mean, istd, gm, bt;
+    float sl;
+};
+__device__ __forceinline__ NextConst next_const(const NextRedArgs& nx, int q4) {
+    NextConst k;
+    k.mean = *reinterpret_cast<const f32x4*>(nx.stats + q4); k.istd = *reinterpret_cast<const f32x4*>(nx.stats + 16 + q4);
+    k.gm = *reinterpret_cast<const f32x4*>(nx.gamma + q4); k.bt = *reinterpret_cast<const f32x4*>(nx.beta + q4);
+    k.sl = nx.slope[0];
+    return k;
+}
+__device__ __forceinline__ void next_accum(const NextConst& k, const f32x4 y, const f32x4 g, float (&vr)[3][4]) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const float xh = (y[e] - k.mean[e]) * k.istd[e];
+        const float z = k.gm[e] * xh + k.bt[e];
+        const float dz = z > 0.f ? g[e] : k.sl * g[e];          // act_bwd, PReLU
+        vr[0][e] += dz;
+        vr[1][e] = fmaf(dz, xh, vr[1][e]);
+        vr[2][e] += z > 0.f ? 0.f : g[e] * z;
+    }
+}
 // FIN: storage format of `in` (compile time).  All tap loads of a tile are issued before the first MFMA: a tap outside
 // the tensor loads element 0 and is zeroed by a select -- with `if (ok) load` every tap sat in its own basic block and
 // the tile paid nine L2 latencies one after the other (the 3x3 convs ran at 45 TFLOP/s, latency-bound).
 // WIN: the window form above (NKT = NKF = 1 then: one 16 x 16 matrix [co][j])
 // PRE: 1x1 only; `in` is the previous unit's conv output, see BnPre
-template <int NKT, int NKF, int FIN, bool WIN = false, bool PRE = false>
+// NEXT: the output IS the gradient input of a 16-channel PReLU unit (see NextRedArgs): its reduction rides in the epilogue,
+// per-workgroup sums [48] into stat_partial (which the forward's statistics do not use in a backward launch)
+template <int NKT, int NKF, int FIN, bool WIN = false, bool PRE = false, int NEXT = 0>   // NEXT: 1 + storage format of that y
 __global__ __launch_bounds__(NT) void k_conv_mfma(ConvGeom g, const float* __restrict__ in,
                                                  const float* __restrict__ w, const float* __restrict__ bias,
                                                  float* __restrict__ out, long tiles_per_wave,
                                                  double* __restrict__ stat_partial, const float* __restrict__ shift,
-                                                 BnPre pre) {
+                                                 BnPre pre, NextRedArgs nx) {
     static_assert(!PRE || (NKT * NKF == 1 && !WIN), "normalise-on-load: pointwise convs only");
+    static_assert(!NEXT || (!PRE && !WIN), "riding reduction: plain adjoint launches");
+    NextConst nk{};
+    float vr[3][4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) vr[0][e] = vr[1][e] = vr[2][e] = 0.f;
+    if constexpr (NEXT) nk = next_const(nx, 4 * ((threadIdx.x & 63) >> 4));
     __shared__ __attribute__((aligned(16))) float sW[NKT * NKF * 256];   // [tap][co][ci], zero padded
     __shared__ double sStat[NT / 64][32];   // per wave: sum[16], sum of squares[16]
     const int tid = threadIdx.x;
@@ -509,6 +553,8 @@ __global__ __launch_bounds__(NT) void k_conv_mfma(ConvGeom g, const float* __res
         const long p = tile * 16 + n;
         const bool pv = p < npos;
         f32x4 acc = bv;
+        f32x4 ynx = {0.f, 0.f, 0.f, 0.f};
+        if constexpr (NEXT) ynx = dec4<NEXT ? NEXT - 1 : 0>(sld4_raw<NEXT ? NEXT - 1 : 0, true>(nx.y, (pv ? p : 0) * 16 + 4 * q));   // (CoutT == 16: the launcher checks)
         if constexpr (WIN) {
             const long rowlen = (long)g.Fin * g.Cin;
             const WinPos wp = win_pos(P, pv, q, g.Cin, g.Cin * g.nkf, g.sf, g.pf, g.Tin, rowlen, (long)g.B * g.Tin * rowlen);
@@ -563,13 +609,33 @@ __global__ __launch_bounds__(NT) void k_conv_mfma(ConvGeom g, const float* __res
                 sst4<kNtSt>(out, p * g.CoutT + g.cout_off + 4 * q, g.out_bf, acc);
             } else {
                 f32x4* o = reinterpret_cast<f32x4*>(out + p * g.CoutT + g.cout_off + 4 * q);
-                if (g.accumulate) *o = *o + acc;
+                if (g.accumulate) { acc = *o + acc; *o = acc; }
                 else sst4<kNtSt>(out, p * g.CoutT + g.cout_off + 4 * q, 0, acc);
             }
+            if constexpr (NEXT) next_accum(nk, ynx, acc, vr);          // (acc: the value the tensor now holds)
+            else {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) { const double a = (double)acc[e]; s1[e] += a; s2[e] = fma(a, a, s2[e]); }
+                for (int e = 0; e < 4; ++e) { const double a = (double)acc[e]; s1[e] += a; s2[e] = fma(a, a, s2[e]); }
+            }
         }
         P.advance(16, g.Fout, g.Tout);
+    }
+    if constexpr (NEXT) {
+        __shared__ double sRed[NT / 64][48];
+#pragma unroll
+        for (int k3 = 0; k3 < 3; ++k3)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const double t = wave_sum_xor((double)vr[k3][e], 1, 8);
+                if (n == 0) sRed[tid >> 6][k3 * 16 + 4 * q + e] = t;
+            }
+        __syncthreads();
+        if (tid < 48) {
+            double t = 0.0;
+            for (int w2 = 0; w2 < NT / 64; ++w2) t += sRed[w2][tid];
+            stat_partial[(long)blockIdx.x * 48 + tid] = t;
+        }
+        return;
     }
     if (stat_partial) {
         // per-workgroup sums of y and y^2 per channel (the conv is followed by a train-mode BatchNorm):
@@ -1034,12 +1100,21 @@ __global__ __launch_bounds__(NT) void k_dw(DwGeom g, const float* __restrict__ i
 // (bf16 storage: k_dw16<3,3> 245 us against 165 with fp32 storage, twice the bytes)
 // PRE: `in` is the previous unit's conv output (see BnPre); the last temporal / middle frequency tap is the thread's
 // own position (t_off[NKT-1] == 0, f_off[NKF/2] == 0: checked by the launcher) and stores the activation
-template <int NKT, int NKF, int FIN = -1, bool PRE = false>
+template <int NV, int V, class TV>
+__device__ __forceinline__ void block_reduce_store(const TV (&v)[NV][V], int C, double* sh, double* dst);
+// NEXT: see k_conv_mfma
+template <int NKT, int NKF, int FIN = -1, bool PRE = false, int NEXT = 0>
 __global__ __launch_bounds__(NT) void k_dw16(DwGeom g, const float* __restrict__ in, const float* __restrict__ w,
                                             const float* __restrict__ bias, float* __restrict__ out,
                                             double* __restrict__ stat_partial, StrideIter it,
-                                            const float* __restrict__ shift, BnPre pre) {
+                                            const float* __restrict__ shift, BnPre pre, NextRedArgs nx) {
     const unsigned vb = xcd_block();
+    static_assert(!NEXT || (!PRE && NKT > 0), "riding reduction: plain adjoint launches");
+    NextConst nk{};
+    float vr[3][4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) vr[0][e] = vr[1][e] = vr[2][e] = 0.f;
+    if constexpr (NEXT) nk = next_const(nx, 4 * (threadIdx.x & 3));
     static_assert(!PRE || (FIN >= 0 && NKT > 0), "normalise-on-load needs the compile-time forms");
     __shared__ __attribute__((aligned(16))) float sW[9 * 16];   // [tap][c]
     __shared__ double sStat[NT / 64][32];   // per wave: sum[16], sum of squares[16]
@@ -1062,6 +1137,8 @@ __global__ __launch_bounds__(NT) void k_dw16(DwGeom g, const float* __restrict__
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
         if (bias) acc = *reinterpret_cast<const f32x4*>(bias + 4 * q);
         if (shift) acc -= *reinterpret_cast<const f32x4*>(shift + 4 * q);
+        f32x4 ynx = {0.f, 0.f, 0.f, 0.f};
+        if constexpr (NEXT) ynx = dec4<NEXT ? NEXT - 1 : 0>(sld4_raw<NEXT ? NEXT - 1 : 0, true>(nx.y, p * 16 + 4 * q));
         if constexpr (NKT > 0) {
             // every tap's load is issued before the first multiply-add (a tap outside the tensor loads the centre
             // record instead and is skipped by a select: one basic block, NKT * NKF loads in flight per thread instead
@@ -1115,11 +1192,19 @@ __global__ __launch_bounds__(NT) void k_dw16(DwGeom g, const float* __restrict__
             sst4<kNtSt>(out, p * 16 + 4 * q, g.out_bf, acc);
         } else {
             f32x4* o = reinterpret_cast<f32x4*>(out + p * 16 + 4 * q);
-            if (g.accumulate) *o = *o + acc;
+            if (g.accumulate) { acc = *o + acc; *o = acc; }
             else sst4<kNtSt>(out, p * 16 + 4 * q, 0, acc);
         }
+        if constexpr (NEXT) next_accum(nk, ynx, acc, vr);
+        else {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) { const double a = (double)acc[e]; s1[e] += a; s2[e] = fma(a, a, s2[e]); }
+            for (int e = 0; e < 4; ++e) { const double a = (double)acc[e]; s1[e] += a; s2[e] = fma(a, a, s2[e]); }
+        }
+    }
+    if constexpr (NEXT) {
+        __shared__ double shn[NT];
+        block_reduce_store<3, 4>(vr, 16, shn, stat_partial + (long)vb * 48);
+        return;
     }
     if (stat_partial) {   // per-workgroup BatchNorm partial sums; a thread's channel quad is tid & 3
 #pragma unroll
@@ -1544,17 +1629,6 @@ __global__ __launch_bounds__(1024) void k_reduce_partials_f(const float* __restr
 struct BnBwdArgs {
     const float *stats, *gamma, *beta, *slope, *red;
     int act;
-};
-// the unit whose gradient input is the dx a backward kernel produces (16 channels, PReLU; res: its residual input or
-// nullptr): that unit's first backward pass -- sum dz, sum dz * xhat, sum of the slope terms -- is accumulated by the
-// producing kernel from one more read of its y (and res) instead of a pass that re-reads dx as well
-// XR (with NEXT): that unit's activation is this unit's input x, and it is not read but RECOMPUTED from the y (and res)
-// loaded for the reduction -- one tensor read less, and the forward need not store the activation at all when this
-// backward is its only other reader.  xround: the forward's consumer convolved the activation rounded to the 16-bit
-// storage format (bf16 storage; not the exact chain), so the recomputed one is rounded the same way.
-struct NextRedArgs {
-    const float *y, *stats, *gamma, *beta, *slope, *res;
-    int xround;
 };
 // NEXT: see NextRedArgs; rpartial [gridDim.x][48] doubles
 template <int FMT, int YF, bool NEXT = false, bool XR = false>   // storage formats of x / res and of y, compile time (see sld1)
@@ -2466,12 +2540,42 @@ static bool win_wgrad_ok(const ConvGeom& g) {
     return g.Cout * g.nkf <= 16 && g.CoutT == g.Cout && g.cout_off == 0 && g.Cin == 16 && g.CinT == 16 && g.cin_off == 0;
 }
 
+static NextRedArgs next_args(const DwUnitNext* next, int yfmt) {
+    NextRedArgs nx{};
+    if (next) nx = NextRedArgs{next->y, next->stats, next->gamma, next->beta, next->slope, nullptr, 0, yfmt};
+    return nx;
+}
 int conv_fwd(const ConvGeom& g, const float* in, const float* w, const float* bias, float* out, hipStream_t s,
-             double* stat_partial, int* stat_parts, const float* shift, const BnPre* pre) {
+             double* stat_partial, int* stat_parts, const float* shift, const BnPre* pre, const DwUnitNext* next,
+             int next_yfmt) {
     if (shift && !g.out_bf) return (int)hipErrorInvalidValue;
     if (g.out2) return (int)hipErrorInvalidValue;      // (a second output copy: the 3-channel depthwise conv only)
     if (stat_parts) *stat_parts = 0;
     const BnPre nopre{};
+    const NextRedArgs nonx{};
+    if (next) {
+        // a backward launch whose output is the gradient input of the unit `next` (16 channels, PReLU, no residual):
+        // that unit's BatchNorm reduction rides in the epilogue -- per-workgroup sums in stat_partial, their count in
+        // *stat_parts (hand it to that unit's backward as have_parts)
+        if (!stat_partial || !stat_parts || pre || shift || next->res || !next->slope || !mfma_ok(g) || g.in_bf != 0 ||
+            g.out_bf != 0 || g.Cout != 16 || g.CoutT != 16 || g.cout_off != 0 ||
+            !((g.nkt == 3 && g.nkf == 3) || (g.nkt == 1 && g.nkf == 5)))
+            return (int)hipErrorInvalidValue;
+        const long ntiles = ((long)g.B * g.Tout * g.Fout + 15) / 16;
+        long waves = (long)MAX_PARTIALS * 4;
+        if (waves > ntiles) waves = ntiles;
+        const long tpw = (ntiles + waves - 1) / waves;
+        const int grid = (int)((ntiles + tpw * 4 - 1) / (tpw * 4));
+        const NextRedArgs nx = next_args(next, next_yfmt);
+        if (next_yfmt < 0 || next_yfmt > 1) return (int)hipErrorInvalidValue;
+#define GT_CN(KT, KF, NX) hipLaunchKernelGGL((k_conv_mfma<KT, KF, 0, false, false, NX>), dim3(grid), dim3(NT), 0, s, g, in, w, bias, \
+                                             out, tpw, stat_partial, shift, nopre, nx)
+        if (g.nkt == 3) { if (next_yfmt) GT_CN(3, 3, 2); else GT_CN(3, 3, 1); }
+        else { if (next_yfmt) GT_CN(1, 5, 2); else GT_CN(1, 5, 1); }
+#undef GT_CN
+        *stat_parts = grid;
+        return check();
+    }
     if (pre && !(mfma_ok(g) && g.nkt == 1 && g.nkf == 1 && g.sf == 1 && g.Cin == 16 && g.CinT == 16 && g.cin_off == 0 &&
                  g.in_bf == pre->ybf))
         return (int)hipErrorInvalidValue;
@@ -2498,19 +2602,19 @@ int conv_fwd(const ConvGeom& g, const float* in, const float* w, const float* bi
                       !g.accumulate) ? stat_partial : nullptr;
 #define GT_CM(KT, KF)                                                                                                  \
     do {                                                                                                               \
-        if (g.in_bf == 0) hipLaunchKernelGGL((k_conv_mfma<KT, KF, 0>), dim3(grid), dim3(NT), 0, s, g, in, w, bias, out, tpw, sp, shift, nopre); \
-        else if (g.in_bf == 1) hipLaunchKernelGGL((k_conv_mfma<KT, KF, 1>), dim3(grid), dim3(NT), 0, s, g, in, w, bias, out, tpw, sp, shift, nopre); \
-        else hipLaunchKernelGGL((k_conv_mfma<KT, KF, 2>), dim3(grid), dim3(NT), 0, s, g, in, w, bias, out, tpw, sp, shift, nopre); \
+        if (g.in_bf == 0) hipLaunchKernelGGL((k_conv_mfma<KT, KF, 0>), dim3(grid), dim3(NT), 0, s, g, in, w, bias, out, tpw, sp, shift, nopre, nonx); \
+        else if (g.in_bf == 1) hipLaunchKernelGGL((k_conv_mfma<KT, KF, 1>), dim3(grid), dim3(NT), 0, s, g, in, w, bias, out, tpw, sp, shift, nopre, nonx); \
+        else hipLaunchKernelGGL((k_conv_mfma<KT, KF, 2>), dim3(grid), dim3(NT), 0, s, g, in, w, bias, out, tpw, sp, shift, nopre, nonx); \
     } while (0)
         if (pre) {
-            if (g.in_bf == 0) hipLaunchKernelGGL((k_conv_mfma<1, 1, 0, false, true>), dim3(grid), dim3(NT), 0, s, g, in, w, bias, out, tpw, sp, shift, *pre);
-            else if (g.in_bf == 1) hipLaunchKernelGGL((k_conv_mfma<1, 1, 1, false, true>), dim3(grid), dim3(NT), 0, s, g, in, w, bias, out, tpw, sp, shift, *pre);
-            else hipLaunchKernelGGL((k_conv_mfma<1, 1, 2, false, true>), dim3(grid), dim3(NT), 0, s, g, in, w, bias, out, tpw, sp, shift, *pre);
+            if (g.in_bf == 0) hipLaunchKernelGGL((k_conv_mfma<1, 1, 0, false, true>), dim3(grid), dim3(NT), 0, s, g, in, w, bias, out, tpw, sp, shift, *pre, nonx);
+            else if (g.in_bf == 1) hipLaunchKernelGGL((k_conv_mfma<1, 1, 1, false, true>), dim3(grid), dim3(NT), 0, s, g, in, w, bias, out, tpw, sp, shift, *pre, nonx);
+            else hipLaunchKernelGGL((k_conv_mfma<1, 1, 2, false, true>), dim3(grid), dim3(NT), 0, s, g, in, w, bias, out, tpw, sp, shift, *pre, nonx);
         }
         else if (win) {
-            if (g.in_bf == 0) hipLaunchKernelGGL((k_conv_mfma<1, 1, 0, true>), dim3(grid), dim3(NT), 0, s, g, in, w, bias, out, tpw, sp, shift, nopre);
-            else if (g.in_bf == 1) hipLaunchKernelGGL((k_conv_mfma<1, 1, 1, true>), dim3(grid), dim3(NT), 0, s, g, in, w, bias, out, tpw, sp, shift, nopre);
-            else hipLaunchKernelGGL((k_conv_mfma<1, 1, 2, true>), dim3(grid), dim3(NT), 0, s, g, in, w, bias, out, tpw, sp, shift, nopre);
+            if (g.in_bf == 0) hipLaunchKernelGGL((k_conv_mfma<1, 1, 0, true>), dim3(grid), dim3(NT), 0, s, g, in, w, bias, out, tpw, sp, shift, nopre, nonx);
+            else if (g.in_bf == 1) hipLaunchKernelGGL((k_conv_mfma<1, 1, 1, true>), dim3(grid), dim3(NT), 0, s, g, in, w, bias, out, tpw, sp, shift, nopre, nonx);
+            else hipLaunchKernelGGL((k_conv_mfma<1, 1, 2, true>), dim3(grid), dim3(NT), 0, s, g, in, w, bias, out, tpw, sp, shift, nopre, nonx);
         }
         else if (g.nkt == 3) GT_CM(3, 3);
         else if (g.nkf == 5) GT_CM(1, 5);
@@ -2584,11 +2688,29 @@ int conv_wgrad(const ConvGeom& g, const float* in, const float* dout, float* dw,
 }
 
 int dw_fwd(const DwGeom& g, const float* in, const float* w, const float* bias, float* out, hipStream_t s,
-           double* stat_partial, int* stat_parts, const float* shift, const BnPre* pre) {
+           double* stat_partial, int* stat_parts, const float* shift, const BnPre* pre, const DwUnitNext* next,
+           int next_yfmt) {
     if (shift && (!g.out_bf || g.C != 16)) return (int)hipErrorInvalidValue;
     if (g.out2 && (g.out_bf || g.accumulate || g.C != 3)) return (int)hipErrorInvalidValue;
     if (stat_parts) *stat_parts = 0;
     const BnPre nopre{};
+    const NextRedArgs nonx{};
+    if (next) {      // see conv_fwd
+        if (!stat_partial || !stat_parts || pre || shift || next->res || !next->slope || g.C != 16 || g.nkt != 3 ||
+            g.nkf != 3 || g.in_bf != 0 || g.out_bf != 0 || g.Tin != g.Tout)
+            return (int)hipErrorInvalidValue;
+        const int g16 = grid_for((long)g.B * g.Tout * g.F * 4, MAX_PARTIALS);
+        const StrideIter it = stride_iter((long)g16 * NT / 4, g.F, g.Tout);
+        if (next_yfmt < 0 || next_yfmt > 1) return (int)hipErrorInvalidValue;
+        if (next_yfmt)
+            hipLaunchKernelGGL((k_dw16<3, 3, 0, false, 2>), dim3(g16), dim3(NT), 0, s, g, in, w, bias, out, stat_partial, it,
+                               shift, nopre, next_args(next, next_yfmt));
+        else
+            hipLaunchKernelGGL((k_dw16<3, 3, 0, false, 1>), dim3(g16), dim3(NT), 0, s, g, in, w, bias, out, stat_partial, it,
+                               shift, nopre, next_args(next, next_yfmt));
+        *stat_parts = g16;
+        return check();
+    }
     if (pre && !(g.C == 16 && g.nkt == 3 && g.nkf == 1 && g.t_off[2] == 0 && g.f_off[0] == 0 && g.in_bf == pre->ybf &&
                  g.in_bf <= 1 && !g.accumulate && !pre->res))
         return (int)hipErrorInvalidValue;
@@ -2600,19 +2722,19 @@ int dw_fwd(const DwGeom& g, const float* in, const float* w, const float* bias, 
         const StrideIter it = stride_iter((long)g16 * NT / 4, g.F, g.Tout);
 #define GT_DW(KT, KF)                                                                                                   \
     do {                                                                                                               \
-        if (g.in_bf == 0) hipLaunchKernelGGL((k_dw16<KT, KF, 0>), dim3(g16), dim3(NT), 0, s, g, in, w, bias, out, sp, it, shift, nopre); \
-        else if (g.in_bf == 1) hipLaunchKernelGGL((k_dw16<KT, KF, 1>), dim3(g16), dim3(NT), 0, s, g, in, w, bias, out, sp, it, shift, nopre); \
-        else hipLaunchKernelGGL((k_dw16<KT, KF, -1>), dim3(g16), dim3(NT), 0, s, g, in, w, bias, out, sp, it, shift, nopre); \
+        if (g.in_bf == 0) hipLaunchKernelGGL((k_dw16<KT, KF, 0>), dim3(g16), dim3(NT), 0, s, g, in, w, bias, out, sp, it, shift, nopre, nonx); \
+        else if (g.in_bf == 1) hipLaunchKernelGGL((k_dw16<KT, KF, 1>), dim3(g16), dim3(NT), 0, s, g, in, w, bias, out, sp, it, shift, nopre, nonx); \
+        else hipLaunchKernelGGL((k_dw16<KT, KF, -1>), dim3(g16), dim3(NT), 0, s, g, in, w, bias, out, sp, it, shift, nopre, nonx); \
     } while (0)
         if (pre) {
-            if (g.in_bf == 0) hipLaunchKernelGGL((k_dw16<3, 1, 0, true>), dim3(g16), dim3(NT), 0, s, g, in, w, bias, out, sp, it, shift, *pre);
-            else hipLaunchKernelGGL((k_dw16<3, 1, 1, true>), dim3(g16), dim3(NT), 0, s, g, in, w, bias, out, sp, it, shift, *pre);
+            if (g.in_bf == 0) hipLaunchKernelGGL((k_dw16<3, 1, 0, true>), dim3(g16), dim3(NT), 0, s, g, in, w, bias, out, sp, it, shift, *pre, nonx);
+            else hipLaunchKernelGGL((k_dw16<3, 1, 1, true>), dim3(g16), dim3(NT), 0, s, g, in, w, bias, out, sp, it, shift, *pre, nonx);
         }
         else if (g.nkt == 3 && g.nkf == 3) GT_DW(3, 3);
         else if (g.nkt == 3 && g.nkf == 1) GT_DW(3, 1);
 #undef GT_DW
         else
-            hipLaunchKernelGGL((k_dw16<0, 0>), dim3(g16), dim3(NT), 0, s, g, in, w, bias, out, sp, it, shift, nopre);
+            hipLaunchKernelGGL((k_dw16<0, 0>), dim3(g16), dim3(NT), 0, s, g, in, w, bias, out, sp, it, shift, nopre, nonx);
         if (sp) *stat_parts = g16;
         return check();
     }

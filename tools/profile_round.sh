@@ -12,13 +12,16 @@
 #   stream / train             kernel trace + stats of the configs[2] / configs[3] legs; train_pmc_*: HBM counters of the
 #                              fp32 train step
 # tools/profile_summary.py condenses them into the files committed under profiles/.
+# Second argument: which sections to run -- all (default), headline, stream, train.
 set -u
 TAG=${1:-r04}
+WHAT=${2:-all}
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$R/gpurun_out/$TAG
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 B="$R/bench.py --no-cpu-baseline --no-secondary"
+if [ "$WHAT" = all ] || [ "$WHAT" = headline ]; then
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- python3 $B --steps 20 --warmup 5 > "$OUT/trace.log" 2>&1
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_fetch" -- python3 $B --steps 4 --warmup 2 > "$OUT/pmc_fetch.log" 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_write" -- python3 $B --steps 4 --warmup 2 > "$OUT/pmc_write.log" 2>&1
@@ -28,8 +31,12 @@ rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_VALU_MFMA_COEXEC_CYCL
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 "$R/tools/ubench_mfma_valu.hip" -o /tmp/ub_mfma_valu > "$OUT/ub_build.log" 2>&1
 /tmp/ub_mfma_valu > "$OUT/ub_plain.log" 2>&1
 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_VALU_MFMA_COEXEC_CYCLES SQ_BUSY_CU_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_WAVE_CYCLES GRBM_GUI_ACTIVE --output-format csv -d "$OUT/ub_pmc" -- /tmp/ub_mfma_valu > "$OUT/ub_pmc.log" 2>&1
+fi
 # configs[2] (1024 streams, single-frame calls) and configs[3] (train step, fp32 and bf16 storage)
+if [ "$WHAT" = all ] || [ "$WHAT" = stream ]; then
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stream" -- python3 "$R/tools/stream_bench.py" > "$OUT/stream.log" 2>&1
+fi
+if [ "$WHAT" = all ] || [ "$WHAT" = train ]; then
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/train_f32" -- python3 "$R/bench.py" --mode train --steps 3 --warmup 1 > "$OUT/train_f32.log" 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/train_bf16" -- python3 "$R/bench.py" --mode train --train-storage bf16 --steps 3 --warmup 1 > "$OUT/train_bf16.log" 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/train_bf16_saves" -- python3 "$R/bench.py" --mode train --train-storage bf16_saves --steps 3 --warmup 1 > "$OUT/train_bf16_saves.log" 2>&1
@@ -40,6 +47,7 @@ for M in bf16 bf16_saves; do
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$OUT/train_${M}_pmc_fetch" -- python3 "$R/bench.py" --mode train --train-storage $M --steps 2 --warmup 1 > "$OUT/train_${M}_pmc_fetch.log" 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$OUT/train_${M}_pmc_write" -- python3 "$R/bench.py" --mode train --train-storage $M --steps 2 --warmup 1 > "$OUT/train_${M}_pmc_write.log" 2>&1
 done
+fi
 grep -h '"metric"' "$OUT"/*.log | cut -c1-300
-cat "$OUT/ub_plain.log"
+[ -f "$OUT/ub_plain.log" ] && cat "$OUT/ub_plain.log"
 find "$OUT" -name "*.csv" | wc -l
