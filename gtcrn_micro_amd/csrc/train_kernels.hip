@@ -1652,7 +1652,7 @@ __global__ __launch_bounds__(NT) void k_unit1x1_bwd(ConvGeom g, const float* __r
     }
     __shared__ __attribute__((aligned(16))) float sWt[256];        // data-gradient A matrix [ci][co] = W[co][ci]
     __shared__ __attribute__((aligned(16))) float sT[NT / 64][256];   // per wave: dy tile [pos][16]
-    __shared__ __attribute__((aligned(16))) float sX[XR ? NT / 64 : 1][XR ? 256 : 4];   // XR: the recomputed x tile [pos][16]
+    __shared__ __attribute__((aligned(16))) float sX[NT / 64][256];   // per wave: the x tile [pos][16] (loaded, or XR: recomputed)
     static_assert(!XR || NEXT, "x is recomputed from the NEXT unit's y");
     __shared__ float sAcc[NT / 64][256 + 64];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, n = lane & 15, q = lane >> 4;
@@ -1684,16 +1684,11 @@ __global__ __launch_bounds__(NT) void k_unit1x1_bwd(ConvGeom g, const float* __r
     for (; tile < tend; ++tile) {
         const long p = tile * 16 + n;
         const bool pv = p < npos;
-        // weight-gradient operand x in (c, k) layout: 4 coalesced 256-byte wave loads, issued first
-        unsigned xb[4] = {0u, 0u, 0u, 0u};         // raw words: decoded where they are used (see sld1_raw)
-        if constexpr (!XR) {
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const long pu = tile * 16 + 4 * u + k;
-                xb[u] = (pu < npos && ci_ok) ? sld1_raw<FMT>(x, pu * g.CinT + g.cin_off + c) : 0u;
-            }
-        }
-        const unsigned xodd = (unsigned)((g.cin_off + c) & 1);    // CinT is a multiple of 4 here: the parity is the channel's
+        // weight-gradient operand x: ONE 16-byte load per lane in the (position, channel quad) layout, issued first; it
+        // reaches the (channel, position) layout the MFMA wants through a wave-private LDS tile like dy (four 4-byte
+        // loads per lane in that layout directly cost four requests per tile: the Cin = 8 units ran at 3.2 TB/s)
+        typename Raw4<FMT>::t xraw{};
+        if constexpr (!XR) xraw = sld4_raw<FMT, true>(x, (pv && ci_ok4) ? p * g.CinT + g.cin_off + 4 * q : 0L);
         f32x4 ynx = {0.f, 0.f, 0.f, 0.f}, rnx = ynx;
         f32x4 nxh = ynx, nz = ynx;                                // the NEXT unit's xhat and pre-activation z of this lane's quad
         if constexpr (NEXT) {      // (Cin == CinT == 16 with NEXT: the launcher checks)
@@ -1714,6 +1709,10 @@ __global__ __launch_bounds__(NT) void k_unit1x1_bwd(ConvGeom g, const float* __r
                 }
                 *reinterpret_cast<f32x4*>(&sX[wv][n * 16 + 4 * q]) = xa;
             }
+        }
+        if constexpr (!XR) {
+            const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+            *reinterpret_cast<f32x4*>(&sX[wv][n * 16 + 4 * q]) = (pv && ci_ok4) ? dec4<FMT>(xraw) : zero4;
         }
         f32x4 dy = {0.f, 0.f, 0.f, 0.f};
         if (pv && co_ok4) {
@@ -1771,14 +1770,13 @@ __global__ __launch_bounds__(NT) void k_unit1x1_bwd(ConvGeom g, const float* __r
         for (int u = 0; u < 4; ++u) {
             const float a = sT[wv][(4 * u + k) * 16 + c];
             bsum += a;
-            if constexpr (XR) accW = mfma4(a, sX[wv][(4 * u + k) * 16 + c], accW);
-            else accW = mfma4(a, sld1_dec<FMT>(xb[u], xodd), accW);
+            accW = mfma4(a, sX[wv][(4 * u + k) * 16 + c], accW);
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     }
-    (void)co_ok;
+    (void)co_ok; (void)ci_ok;
     // per-workgroup partial dW / db, same layout as k_conv_wgrad_mfma<1,1>: [co*16 + ci] then 16 bias sums
 #pragma unroll
     for (int r = 0; r < 4; ++r) sAcc[wv][(4 * k + r) * 16 + c] = accW[r];
