@@ -147,6 +147,13 @@ int dwunit_bwd(const DwGeom& g, const float* x, const float* y, const float* da,
                float* dbias, float* dgamma, float* dbeta, float* dslope, double* dscratch, float* fscratch,
                hipStream_t s, int bf, int ybf, const DwUnitNext* next, int* next_parts, int have_parts = 0);
 
+// The same for the 16-channel depthwise 3x3 unit of the encoder's GTConv blocks (F == 33; taps t-2..t, f-1..f+1): one
+// LDS-tiled kernel for dy, the weight / bias gradient and dx.
+int dwunit33_bwd(const DwGeom& g, const float* x, const float* y, const float* da, const float* stats,
+                 const float* gamma, const float* beta, const float* slope, const float* w, float* dx, float* dw,
+                 float* dbias, float* dgamma, float* dbeta, float* dslope, double* dscratch, float* fscratch,
+                 hipStream_t s, int bf, int ybf, const DwUnitNext* next, int* next_parts, int have_parts = 0);
+
 // features: spec (strided (b,f,t) + re/im) -> EB [B][T][129][3] = ERB.bm([mag,re,im]) (models/gtcrn_micro.py:510-516)
 int feat_fwd(const float* spec, long sb, long sf, long st, int B, int T, const float* erb_w, float* eb,
              hipStream_t s, int bf = 0, float* eb2 = nullptr, int eb2_bf = 0);

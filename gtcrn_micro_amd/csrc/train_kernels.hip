@@ -1938,6 +1938,114 @@ __global__ __launch_bounds__(NT) void k_dwunit31_bwd(DwGeom g, const float* __re
     if constexpr (NEXT) block_reduce_store<3, 4>(vr, 16, sh, rpartial + (long)vb * 48);
 }
 
+// ------------------------------------------ fused backward of a depthwise 3x3 conv + BatchNorm + PReLU (encoder depth_conv)
+// After the BatchNorm reduction the unit's three remaining passes -- dy (k_bn_bwd_apply: read da, y, write dy), the weight
+// gradient (k_dw_wgrad_stream<3,3>: read dy, x at nine taps) and the data gradient (k_dw16<3,3> on the adjoint taps: read
+// dy at nine taps, write dx) -- as ONE pass over LDS tiles: a workgroup takes D33_TF frames of one utterance (all 33
+// bins, 16 channels), forms dy for those frames and the two after them (what its dx rows need; 2 / D33_TF recomputed)
+// into one LDS image, copies x of those frames and the two before them (what its dW terms need) into a second one
+// (35-column rows: zero pads instead of bin-edge tests), and after one barrier every thread (position, channel quad)
+// reads its nine dy taps and nine x taps from LDS: dy never exists in memory and da, y, x are read once.  Same per-element
+// expressions and the same order of additions as the separate kernels.  NEXT: the unit in front (point_conv1) takes this dx
+// as its da -- its first backward pass rides along as in k_dwunit31_bwd.
+constexpr int D33_TF = 12, D33_ROWS = D33_TF + 2;
+template <int FX, int FY, bool NEXT>   // storage formats of x (an activation) and of y / the next unit's y (conv outputs)
+__global__ __launch_bounds__(NT) void k_dwunit33_bwd(DwGeom g, const float* __restrict__ x, const float* __restrict__ y,
+                                                    const float* __restrict__ da, BnBwdArgs bn,
+                                                    const float* __restrict__ w, float* __restrict__ dx,
+                                                    double* __restrict__ wpartial, NextRedArgs nx,
+                                                    double* __restrict__ rpartial, int tiles_t) {
+    __shared__ __attribute__((aligned(16))) float sDy[D33_ROWS * 35 * 16];   // row r = frame t0 + r, column 1 + bin
+    __shared__ __attribute__((aligned(16))) float sXi[D33_ROWS * 35 * 16];   // row r = frame t0 - 2 + r
+    __shared__ double sh[NT];
+    const int tid = threadIdx.x, q = tid & 3;
+    const f32x4 mean = *reinterpret_cast<const f32x4*>(bn.stats + 4 * q), istd = *reinterpret_cast<const f32x4*>(bn.stats + 16 + 4 * q);
+    const f32x4 gm = *reinterpret_cast<const f32x4*>(bn.gamma + 4 * q), bt = *reinterpret_cast<const f32x4*>(bn.beta + 4 * q);
+    const f32x4 m1 = *reinterpret_cast<const f32x4*>(bn.red + 4 * q), m2 = *reinterpret_cast<const f32x4*>(bn.red + 16 + 4 * q);
+    const float sl = bn.slope[0];
+    f32x4 wk[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) wk[k][e] = w[(4 * q + e) * g.w_c + (k / 3) * g.w_kt + (k % 3) * g.w_kf];
+    NextConst nk{};
+    if constexpr (NEXT) nk = next_const(nx, 4 * q);
+    float vw[10][4], vr[3][4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+#pragma unroll
+        for (int k = 0; k < 10; ++k) vw[k][e] = 0.f;
+        vr[0][e] = vr[1][e] = vr[2][e] = 0.f;
+    }
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+    for (int i = tid; i < D33_ROWS * 2 * 4 * 2; i += NT) {          // pad columns 0 and 34 of both images, once
+        const int qq = i & 3, side = (i >> 2) & 1, r = (i >> 3) % D33_ROWS, img = i / (8 * D33_ROWS);
+        *reinterpret_cast<f32x4*>((img ? sXi : sDy) + (r * 35 + side * 34) * 16 + 4 * qq) = zero;
+    }
+    const int T = g.Tout, F = g.F;                                   // F == 33: the launcher checks
+    const long ntiles = (long)g.B * tiles_t;
+    for (long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int b = (int)(tile / tiles_t), t0 = (int)(tile - (long)b * tiles_t) * D33_TF;
+        const long rowb = (long)b * T;
+        __syncthreads();                                             // the previous tile's readers are done
+        // ---- stage 1: dy of frames t0 .. t0 + D33_ROWS - 1, x of frames t0 - 2 .. t0 + D33_ROWS - 3 (zero outside the tensor)
+        for (int it = tid; it < D33_ROWS * 33 * 4; it += NT) {       // (NT % 4 == 0: the item's quad is the thread's)
+            const int pos = it >> 2, r = pos / 33, f = pos - r * 33;
+            const int td = t0 + r, tx = t0 - 2 + r;
+            const bool okd = td < T, okx = tx >= 0 && tx < T;
+            const long pd = (rowb + (okd ? td : 0)) * F + f, px = (rowb + (okx ? tx : 0)) * F + f;
+            const typename Raw4<FY>::t yr = sld4_raw<FY, true>(y, pd * 16 + 4 * q);
+            const f32x4 gr = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(da + pd * 16 + 4 * q));
+            const typename Raw4<FX>::t xr = sld4_raw<FX, true>(x, px * 16 + 4 * q);
+            const f32x4 yv = dec4<FY>(yr);
+            f32x4 dyv;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float xh = (yv[e] - mean[e]) * istd[e];
+                const float z = gm[e] * xh + bt[e];
+                const float dz = z > 0.f ? gr[e] : sl * gr[e];
+                dyv[e] = gm[e] * istd[e] * (dz - m1[e] - xh * m2[e]);
+            }
+            *reinterpret_cast<f32x4*>(sDy + (r * 35 + 1 + f) * 16 + 4 * q) = okd ? dyv : zero;
+            *reinterpret_cast<f32x4*>(sXi + (r * 35 + 1 + f) * 16 + 4 * q) = okx ? dec4<FX>(xr) : zero;
+        }
+        __syncthreads();
+        // ---- stage 2: the tile's own frames t0 .. t0 + D33_TF - 1
+        const int nrow = T - t0 < D33_TF ? T - t0 : D33_TF;
+        for (int it = tid; it < nrow * 33 * 4; it += NT) {
+            const int pos = it >> 2, r = pos / 33, f = pos - r * 33;
+            const long p = (rowb + t0 + r) * F + f;
+            typename Raw4<FY>::t ynr{};
+            if constexpr (NEXT) ynr = sld4_raw<FY, true>(nx.y, p * 16 + 4 * q);
+            // dx(t, f) = sum w[kt][kf] dy(t + 2 - kt, f + 1 - kf): the adjoint taps in the order of k_dw16
+            const float* dq = sDy + (r * 35 + 1 + f) * 16 + 4 * q;
+            f32x4 acc = zero;
+#pragma unroll
+            for (int kt = 0; kt < 3; ++kt)
+#pragma unroll
+                for (int kf = 0; kf < 3; ++kf)
+                    acc = acc + wk[kt * 3 + kf] * *reinterpret_cast<const f32x4*>(dq + ((2 - kt) * 35 + 1 - kf) * 16);
+            sst4<kNtSt>(dx, p * 16 + 4 * q, 0, acc);
+            if constexpr (NEXT) next_accum(nk, dec4<FY>(ynr), acc, vr);
+            // dW[kt][kf] += dy(t, f) x(t - 2 + kt, f - 1 + kf); db += dy(t, f)
+            const f32x4 d = *reinterpret_cast<const f32x4*>(dq);
+            const float* xq = sXi + (r * 35 + 1 + f) * 16 + 4 * q;
+#pragma unroll
+            for (int kt = 0; kt < 3; ++kt)
+#pragma unroll
+                for (int kf = 0; kf < 3; ++kf) {
+                    const f32x4 xv = *reinterpret_cast<const f32x4*>(xq + (kt * 35 + kf - 1) * 16);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) vw[kt * 3 + kf][e] = fmaf(d[e], xv[e], vw[kt * 3 + kf][e]);
+                }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) vw[9][e] += d[e];
+        }
+    }
+    block_reduce_store<10, 4>(vw, 16, sh, wpartial + (long)blockIdx.x * 160);
+    if constexpr (NEXT) block_reduce_store<3, 4>(vr, 16, sh, rpartial + (long)blockIdx.x * 48);
+}
+
 // --------------------------------------------------------------------------- features, mask
 // GTCRNMicro.forward prologue + ERB.bm (models/gtcrn_micro.py:510-516, :63-67): one thread per (b,t,j)
 // first / one-past-last non-zero entry of each of the `rows` rows (stride rs, element stride es) of a filterbank
@@ -2868,6 +2976,43 @@ int dwunit_bwd(const DwGeom& g, const float* x, const float* y, const float* da,
     else GT_DU(1);
 #undef GT_DU
     hipLaunchKernelGGL(k_dw_wgrad_finish2, dim3(1), dim3(1024), 0, s, g, wpart, grid, dw, dbias);
+    if (nxt && next_parts) *next_parts = grid;
+    return check();
+}
+
+int dwunit33_bwd(const DwGeom& g, const float* x, const float* y, const float* da, const float* stats,
+                 const float* gamma, const float* beta, const float* slope, const float* w, float* dx, float* dw,
+                 float* dbias, float* dgamma, float* dbeta, float* dslope, double* dscratch, float* fscratch,
+                 hipStream_t s, int bf, int ybf, const DwUnitNext* next, int* next_parts, int have_parts) {
+    if (next_parts) *next_parts = 0;
+    if (g.C != 16 || g.F != 33 || g.nkt != 3 || g.nkf != 3 || g.t_off[0] != -2 || g.t_off[1] != -1 || g.t_off[2] != 0 ||
+        g.f_off[0] != -1 || g.f_off[1] != 0 || g.f_off[2] != 1 || g.Tin != g.Tout || !slope || !dx || !x || bf > 1 || ybf > 1 ||
+        bf != ybf)
+        return (int)hipErrorInvalidValue;
+    const long n = (long)g.B * g.Tout * g.F, total = n * 16;
+    float* red = reinterpret_cast<float*>(dscratch + (long)MAX_PARTIALS * 3 * 16);
+    const int rgrid = have_parts > 0 ? have_parts : red_grid(total / 4);
+    if (have_parts <= 0)
+        launch_bn_bwd_reduce4(rgrid, s, da, y, total, 16, stats, gamma, beta, nullptr, ACT_PRELU, slope, dscratch, bf, ybf);
+    hipLaunchKernelGGL(k_bn_bwd_finish, dim3(1), dim3(1024), 0, s, dscratch, rgrid, n, 16, red, dgamma, dbeta, dslope);
+    const int tiles_t = (g.Tout + D33_TF - 1) / D33_TF;
+    const long ntiles = (long)g.B * tiles_t;
+    // 64 KB of LDS: two workgroups per CU, 512 resident -- whole rounds of them
+    const int grid = (int)(ntiles < 512 ? ntiles : 512);
+    double* wpart = reinterpret_cast<double*>(fscratch);      // [grid][160]
+    BnBwdArgs bn{stats, gamma, beta, slope, red, ACT_PRELU};
+    NextRedArgs nx{};
+    const bool nxt = next && next->slope && !next->res;
+    if (nxt) nx = NextRedArgs{next->y, next->stats, next->gamma, next->beta, next->slope, nullptr, 0, ybf};
+#define GT_D33(F)                                                                                                       \
+    do {                                                                                                               \
+        if (nxt) hipLaunchKernelGGL((k_dwunit33_bwd<F, F, true>), dim3(grid), dim3(NT), 0, s, g, x, y, da, bn, w, dx, wpart, nx, dscratch, tiles_t); \
+        else hipLaunchKernelGGL((k_dwunit33_bwd<F, F, false>), dim3(grid), dim3(NT), 0, s, g, x, y, da, bn, w, dx, wpart, nx, dscratch, tiles_t); \
+    } while (0)
+    if (bf == 0) GT_D33(0);
+    else GT_D33(1);
+#undef GT_D33
+    hipLaunchKernelGGL(k_dw_wgrad_finish2, dim3((160 + 63) / 64), dim3(1024), 0, s, g, wpart, grid, dw, dbias);
     if (nxt && next_parts) *next_parts = grid;
     return check();
 }
