@@ -112,11 +112,11 @@ struct gtcrn_trainer {
     size_t arena_floats = 0;
     float* fscratch = nullptr;    // wgrad / TRA partial sums
     double* dscratch = nullptr;   // BatchNorm partial sums
-    int fusions = 127;                 // gtcrn_trainer_set_fusions: 1 normalise-on-load, 2 depthwise backward, 4 riding reductions,
+    int fusions = 255;                 // gtcrn_trainer_set_fusions: 1 normalise-on-load, 2 depthwise backward, 4 riding reductions,
                                       // 8 single-reader activations recomputed in the backward instead of stored,
                                       // 16 skip gradients accumulated in place (no add passes in the backward),
                                       // 32 reductions riding in the adjoint convs of the 3x3 units and of en_convs.1,
-                                      // 64 the depthwise 3x3 unit's backward in one LDS-tiled pass
+                                      // 64 the depthwise 3x3 unit's backward in one LDS-tiled pass, 128 the dense 3x3 unit's
     const void* red_unit = nullptr;   // backward: the unit whose BatchNorm reduction already sits in dscratch ...
     int red_parts = 0;                // ... as this many per-workgroup partial sums (see unit_bwd)
     std::map<std::string, long> off;   // parameter name -> blob offset
@@ -667,6 +667,18 @@ int unit_bwd(gtcrn_trainer* t, Unit& u, const float* prm, float* grads, const fl
         if (ride3 && parts > 0) { t->red_unit = f; t->red_parts = parts; }
         return 0;
     }
+    if (!u.dw && u.cg.nkt == 3 && u.cg.nkf == 3 && u.cg.f_mode == 1 && u.cg.Tout == u.cg.Tin + 2 && u.C == 16 &&
+        u.act == gtt::ACT_PRELU && !u.res && u.o_slope >= 0 && dx && !dx_acc && !dres && u.x && t->bf == t->ybf && t->bf <= 1 &&
+        (t->fusions & 128)) {
+        // decoder depth_conv (dense transposed 3x3): dy and both matrix products from LDS tiles; point_conv1's reduction rides
+        const bool ride3 = ride && !f->res && f->n == (long)u.cg.B * u.cg.Tin * u.cg.Fin;
+        int parts = 0;
+        T_RUN(gtt::dense33_bwd(u.cg, u.x, u.y, da, u.bstats, bn, bn + u.C, prm + u.o_slope, prm + u.o_w, dx, grads + u.o_w,
+                               u.o_b >= 0 ? grads + u.o_b : nullptr, gbn, gbn + u.C, grads + u.o_slope, t->dscratch,
+                               t->fscratch, s, t->bf, t->ybf, ride3 ? &nx : nullptr, &parts, have_parts));
+        if (ride3 && parts > 0) { t->red_unit = f; t->red_parts = parts; }
+        return 0;
+    }
     T_RUN(gtt::bn_act_bwd(da, u.y, u.n, u.C, u.bstats, bn, bn + u.C, u.res, u.act,
                           u.o_slope >= 0 ? prm + u.o_slope : nullptr, t->dy, dres, dres_acc, gbn, gbn + u.C,
                           u.o_slope >= 0 ? grads + u.o_slope : nullptr, t->dscratch, s, t->bf, t->ybf, have_parts));
@@ -801,7 +813,7 @@ int gtcrn_trainer_set_storage(gtcrn_trainer* t, int storage) {
 }
 
 int gtcrn_trainer_set_fusions(gtcrn_trainer* t, int mask) {
-    if (!t || mask < 0 || mask > 127) return tfail(GTCRN_ERR_ARG, "gtcrn_trainer_set_fusions: mask must be 0..127");
+    if (!t || mask < 0 || mask > 255) return tfail(GTCRN_ERR_ARG, "gtcrn_trainer_set_fusions: mask must be 0..255");
     if (t->fusions != mask) {
         t->fusions = mask;
         t->planned = false;      // the unit links are laid out again on the next forward

@@ -154,6 +154,13 @@ int dwunit33_bwd(const DwGeom& g, const float* x, const float* y, const float* d
                  float* dbias, float* dgamma, float* dbeta, float* dslope, double* dscratch, float* fscratch,
                  hipStream_t s, int bf, int ybf, const DwUnitNext* next, int* next_parts, int have_parts = 0);
 
+// ... and for the decoder's dense transposed 3x3 unit (ConvTranspose2d(16,16,(3,3)): 33 bins, T + 2 output frames): both
+// matrix products (data gradient, weight gradient) from LDS images of dy and x.
+int dense33_bwd(const ConvGeom& g, const float* x, const float* y, const float* da, const float* stats,
+                const float* gamma, const float* beta, const float* slope, const float* w, float* dx, float* dw,
+                float* dbias, float* dgamma, float* dbeta, float* dslope, double* dscratch, float* fscratch,
+                hipStream_t s, int bf, int ybf, const DwUnitNext* next, int* next_parts, int have_parts = 0);
+
 // features: spec (strided (b,f,t) + re/im) -> EB [B][T][129][3] = ERB.bm([mag,re,im]) (models/gtcrn_micro.py:510-516)
 int feat_fwd(const float* spec, long sb, long sf, long st, int B, int T, const float* erb_w, float* eb,
              hipStream_t s, int bf = 0, float* eb2 = nullptr, int eb2_bf = 0);

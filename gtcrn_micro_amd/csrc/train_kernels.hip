@@ -2046,6 +2046,156 @@ __global__ __launch_bounds__(NT) void k_dwunit33_bwd(DwGeom g, const float* __re
     if constexpr (NEXT) block_reduce_store<3, 4>(vr, 16, sh, rpartial + (long)blockIdx.x * 48);
 }
 
+// ------------------------------------------ fused backward of the dense transposed 3x3 conv + BatchNorm + PReLU (decoder depth_conv)
+// The same LDS tiling for the decoder's depth_conv (ConvTranspose2d(16,16,(3,3)): y[to][fo] = sum W[kt][kf] x[to - kt][fo + 1 - kf],
+// T + 2 output frames).  After the BatchNorm reduction: k_bn_bwd_apply (read da, y, write dy) + k_conv_wgrad_lds<3,3> (read dy, x at
+// nine taps) + the adjoint k_conv_mfma<3,3> (read dy at nine taps, write dx) were three latency-bound passes over global
+// memory (2.3-2.5 TB/s).  Here a workgroup forms dy of D9_TF + 2 frames into one LDS image, copies x of the same span (two
+// frames earlier) into a second, and both matrix products take their operands from LDS:
+//   dx[ti][fi] = sum_taps W[tap]^T dy[ti + kt][fi - 1 + kf]       36 MFMAs per 16 positions, B operand = one ds_read_b128 per tap
+//   dW[tap]   += dy[to][fo] (x) x[to - kt][fo + 1 - kf]            36 MFMAs per 16 positions, positions as the K index (lane (c, k)
+//                                                                  reads channel c of position 4u + k of either image)
+// in the accumulation order of the separate kernels (tap-major chains).  NEXT: point_conv1's reduction rides on dx.
+constexpr int D9_TF = 12, D9_ROWS = D9_TF + 2, D9_IMG = D9_ROWS * 35 * 16;
+constexpr int D9_LDS_FLOATS = 2 * D9_IMG + 9 * 256;
+static_assert(D9_LDS_FLOATS * 4 * 2 <= 160 * 1024, "two workgroups per CU");
+static_assert((NT / 64) * (9 * 256 + 64) <= 2 * D9_IMG, "the accumulator tiles reuse the images");
+template <int FX, int FY, bool NEXT>
+__global__ __launch_bounds__(NT) void k_dense33_bwd(ConvGeom g, const float* __restrict__ x, const float* __restrict__ y,
+                                                   const float* __restrict__ da, BnBwdArgs bn,
+                                                   const float* __restrict__ w, float* __restrict__ dx,
+                                                   float* __restrict__ wpartial, NextRedArgs nx,
+                                                   double* __restrict__ rpartial, int tiles_t) {
+    extern __shared__ __attribute__((aligned(16))) float smem_d9[];
+    float* sDy = smem_d9;                  // row r = dy frame t0 + r, column 1 + bin (pads 0, 34)
+    float* sXi = sDy + D9_IMG;             // row r = x frame t0 - 2 + r
+    float* sWa = sXi + D9_IMG;             // [tap][ci][co]: the A fragments of the data gradient
+    __shared__ double sRed[NEXT ? NT / 64 : 1][48];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, n = lane & 15, q = lane >> 4, qs = tid & 3;
+    for (int i = tid; i < 9 * 256; i += NT) {
+        const int tap = i >> 8, ci = (i >> 4) & 15, co = i & 15;
+        sWa[i] = w[co * g.w_co + ci * g.w_ci + (tap / 3) * g.w_kt + (tap % 3) * g.w_kf];
+    }
+    const f32x4 mean = *reinterpret_cast<const f32x4*>(bn.stats + 4 * qs), istd = *reinterpret_cast<const f32x4*>(bn.stats + 16 + 4 * qs);
+    const f32x4 gm = *reinterpret_cast<const f32x4*>(bn.gamma + 4 * qs), bt = *reinterpret_cast<const f32x4*>(bn.beta + 4 * qs);
+    const f32x4 m1 = *reinterpret_cast<const f32x4*>(bn.red + 4 * qs), m2 = *reinterpret_cast<const f32x4*>(bn.red + 16 + 4 * qs);
+    const float sl = bn.slope[0];
+    NextConst nk{};
+    if constexpr (NEXT) nk = next_const(nx, 4 * q);
+    float vr[3][4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) vr[0][e] = vr[1][e] = vr[2][e] = 0.f;
+    f32x4 accW[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) accW[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float bsum = 0.f;
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+    for (int i = tid; i < D9_ROWS * 2 * 4 * 2; i += NT) {          // pad columns 0 and 34 of both images, once
+        const int qq = i & 3, side = (i >> 2) & 1, r = (i >> 3) % D9_ROWS, img = i / (8 * D9_ROWS);
+        *reinterpret_cast<f32x4*>((img ? sXi : sDy) + (r * 35 + side * 34) * 16 + 4 * qq) = zero;
+    }
+    const int T = g.Tin, T2 = g.Tout;                              // x frames, dy frames (T + 2); 33 bins: the launcher checks
+    const long ntiles = (long)g.B * tiles_t;
+    for (long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int b = (int)(tile / tiles_t), t0 = (int)(tile - (long)b * tiles_t) * D9_TF;
+        __syncthreads();                                             // the previous tile's readers are done
+        // ---- stage 1: dy of frames t0 .. t0 + D9_ROWS - 1, x of frames t0 - 2 .. t0 + D9_ROWS - 3 (zero outside the tensors)
+        for (int it = tid; it < D9_ROWS * 33 * 4; it += NT) {        // (NT % 4 == 0: the item's quad is qs)
+            const int pos = it >> 2, r = pos / 33, f = pos - r * 33;
+            const int td = t0 + r, tx = t0 - 2 + r;
+            const bool okd = td < T2, okx = tx >= 0 && tx < T;
+            const long pd = ((long)b * T2 + (okd ? td : 0)) * 33 + f, px = ((long)b * T + (okx ? tx : 0)) * 33 + f;
+            const typename Raw4<FY>::t yr = sld4_raw<FY, true>(y, pd * 16 + 4 * qs);
+            const f32x4 gr = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(da + pd * 16 + 4 * qs));
+            const typename Raw4<FX>::t xr = sld4_raw<FX, true>(x, px * 16 + 4 * qs);
+            const f32x4 yv = dec4<FY>(yr);
+            f32x4 dyv;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float xh = (yv[e] - mean[e]) * istd[e];
+                const float z = gm[e] * xh + bt[e];
+                const float dz = z > 0.f ? gr[e] : sl * gr[e];
+                dyv[e] = gm[e] * istd[e] * (dz - m1[e] - xh * m2[e]);
+            }
+            *reinterpret_cast<f32x4*>(sDy + (r * 35 + 1 + f) * 16 + 4 * qs) = okd ? dyv : zero;
+            *reinterpret_cast<f32x4*>(sXi + (r * 35 + 1 + f) * 16 + 4 * qs) = okx ? dec4<FX>(xr) : zero;
+        }
+        __syncthreads();
+        // ---- stage 2: 16-position tiles of the D9_TF x 33 owned positions, one wave each
+        const int own_x = (T - t0 < D9_TF ? (T - t0 > 0 ? T - t0 : 0) : D9_TF) * 33;      // positions whose dx this tile writes
+        const int own_d = (T2 - t0 < D9_TF ? T2 - t0 : D9_TF) * 33;                        // dy positions whose dW terms it adds
+        for (int nt = wv; nt * 16 < own_d; nt += NT / 64) {
+            if (nt * 16 < own_x) {
+                // data gradient of position pl (lane (n, q): input channels 4q .. 4q + 3)
+                const int pl = nt * 16 + n, pc = pl < own_x ? pl : 0, r = pc / 33, f = pc - r * 33;
+                const long gp = ((long)b * T + t0 + r) * 33 + f;
+                typename Raw4<FY>::t ynr{};
+                if constexpr (NEXT) ynr = sld4_raw<FY, true>(nx.y, gp * 16 + 4 * q);
+                const float* dq = sDy + (r * 35 + f) * 16 + 4 * q;
+                f32x4 acc = zero;
+#pragma unroll
+                for (int tap = 0; tap < 9; ++tap) {
+                    const f32x4 A = *reinterpret_cast<const f32x4*>(sWa + tap * 256 + n * 16 + 4 * q);
+                    const f32x4 Bv = *reinterpret_cast<const f32x4*>(dq + ((tap / 3) * 35 + tap % 3) * 16);   // dy[ti + kt][fi - 1 + kf]
+#pragma unroll
+                    for (int s2 = 0; s2 < 4; ++s2) acc = mfma4(A[s2], Bv[s2], acc);
+                }
+                if (pl < own_x) {
+                    sst4<kNtSt>(dx, gp * 16 + 4 * q, 0, acc);
+                    if constexpr (NEXT) next_accum(nk, dec4<FY>(ynr), acc, vr);
+                }
+            }
+            // weight gradient: lane (c = n, k = q) takes channel c of positions 4u + k
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int pu = nt * 16 + 4 * u + q, pc = pu < own_d ? pu : 0, r = pc / 33, f = pc - r * 33;
+                float a = sDy[(r * 35 + 1 + f) * 16 + n];
+                a = pu < own_d ? a : 0.f;
+                bsum += a;
+                const float* xq = sXi + ((r + 2) * 35 + f + 2) * 16 + n;       // x[to - kt][fo + 1 - kf] at row + 2 - kt, column + 2 - kf
+#pragma unroll
+                for (int tap = 0; tap < 9; ++tap) accW[tap] = mfma4(a, xq[-((tap / 3) * 35 + tap % 3) * 16], accW[tap]);
+            }
+        }
+    }
+    __syncthreads();                                                 // the images are dead: the accumulators go there
+    float* my = smem_d9 + wv * (9 * 256 + 64);
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) my[tap * 256 + (4 * q + r) * 16 + n] = accW[tap][r];
+    my[9 * 256 + lane] = bsum;
+    __syncthreads();
+    float* pp = wpartial + (long)blockIdx.x * (9 * 256 + 16);
+    for (int i = tid; i < 9 * 256; i += NT) {
+        float t = 0.f;
+#pragma unroll
+        for (int w2 = 0; w2 < NT / 64; ++w2) t += smem_d9[w2 * (9 * 256 + 64) + i];
+        pp[i] = t;
+    }
+    if (tid < 16) {
+        float t = 0.f;
+        for (int w2 = 0; w2 < NT / 64; ++w2)
+            for (int kk = 0; kk < 4; ++kk) t += smem_d9[w2 * (9 * 256 + 64) + 9 * 256 + kk * 16 + tid];
+        pp[9 * 256 + tid] = t;
+    }
+    if constexpr (NEXT) {
+#pragma unroll
+        for (int k3 = 0; k3 < 3; ++k3)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const double t = wave_sum_xor((double)vr[k3][e], 1, 8);
+                if (n == 0) sRed[wv][k3 * 16 + 4 * q + e] = t;
+            }
+        __syncthreads();
+        if (tid < 48) {
+            double t = 0.0;
+            for (int w2 = 0; w2 < NT / 64; ++w2) t += sRed[w2][tid];
+            rpartial[(long)blockIdx.x * 48 + tid] = t;
+        }
+    }
+}
+
 // --------------------------------------------------------------------------- features, mask
 // GTCRNMicro.forward prologue + ERB.bm (models/gtcrn_micro.py:510-516, :63-67): one thread per (b,t,j)
 // first / one-past-last non-zero entry of each of the `rows` rows (stride rs, element stride es) of a filterbank
@@ -3013,6 +3163,50 @@ int dwunit33_bwd(const DwGeom& g, const float* x, const float* y, const float* d
     else GT_D33(1);
 #undef GT_D33
     hipLaunchKernelGGL(k_dw_wgrad_finish2, dim3((160 + 63) / 64), dim3(1024), 0, s, g, wpart, grid, dw, dbias);
+    if (nxt && next_parts) *next_parts = grid;
+    return check();
+}
+
+int dense33_bwd(const ConvGeom& g, const float* x, const float* y, const float* da, const float* stats,
+                const float* gamma, const float* beta, const float* slope, const float* w, float* dx, float* dw,
+                float* dbias, float* dgamma, float* dbeta, float* dslope, double* dscratch, float* fscratch,
+                hipStream_t s, int bf, int ybf, const DwUnitNext* next, int* next_parts, int have_parts) {
+    if (next_parts) *next_parts = 0;
+    // the decoder's ConvTranspose2d(16,16,(3,3),padding (0,1)) in gather form: taps t, t-1, t-2, transposed in frequency
+    if (g.nkt != 3 || g.nkf != 3 || g.t_off[0] != 0 || g.t_off[1] != -1 || g.t_off[2] != -2 || g.f_mode != 1 || g.sf != 1 ||
+        g.pf != 1 || g.Fin != 33 || g.Fout != 33 || g.Cin != 16 || g.CinT != 16 || g.cin_off != 0 || g.Cout != 16 ||
+        g.CoutT != 16 || g.cout_off != 0 || g.Tout != g.Tin + 2 || !slope || !dx || !x || bf > 1 || ybf > 1 || bf != ybf)
+        return (int)hipErrorInvalidValue;
+    const long n = (long)g.B * g.Tout * g.Fout, total = n * 16;
+    float* red = reinterpret_cast<float*>(dscratch + (long)MAX_PARTIALS * 3 * 16);
+    const int rgrid = have_parts > 0 ? have_parts : red_grid(total / 4);
+    if (have_parts <= 0)
+        launch_bn_bwd_reduce4(rgrid, s, da, y, total, 16, stats, gamma, beta, nullptr, ACT_PRELU, slope, dscratch, bf, ybf);
+    hipLaunchKernelGGL(k_bn_bwd_finish, dim3(1), dim3(1024), 0, s, dscratch, rgrid, n, 16, red, dgamma, dbeta, dslope);
+    const int tiles_t = (g.Tout + D9_TF - 1) / D9_TF;
+    const long ntiles = (long)g.B * tiles_t;
+    const int grid = (int)(ntiles < 512 ? ntiles : 512);           // 72 KB of LDS: two workgroups per CU, all resident
+    BnBwdArgs bn{stats, gamma, beta, slope, red, ACT_PRELU};
+    NextRedArgs nx{};
+    const bool nxt = next && next->slope && !next->res;
+    if (nxt) nx = NextRedArgs{next->y, next->stats, next->gamma, next->beta, next->slope, nullptr, 0, ybf};
+    static bool lds_set[4] = {false, false, false, false};
+#define GT_D9(F, NXV, SLOT)                                                                                             \
+    do {                                                                                                               \
+        if (!lds_set[SLOT]) {                                                                                          \
+            hipError_t e_ = hipFuncSetAttribute(reinterpret_cast<const void*>(k_dense33_bwd<F, F, NXV>),                \
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, D9_LDS_FLOATS * 4);         \
+            if (e_ != hipSuccess) return (int)e_;                                                                      \
+            lds_set[SLOT] = true;                                                                                      \
+        }                                                                                                              \
+        hipLaunchKernelGGL((k_dense33_bwd<F, F, NXV>), dim3(grid), dim3(NT), D9_LDS_FLOATS * 4, s, g, x, y, da, bn, w, dx, \
+                           fscratch, nx, dscratch, tiles_t);                                                           \
+    } while (0)
+    if (bf == 0) { if (nxt) GT_D9(0, true, 0); else GT_D9(0, false, 1); }
+    else { if (nxt) GT_D9(1, true, 2); else GT_D9(1, false, 3); }
+#undef GT_D9
+    const int K = 9 * 256 + 16;
+    hipLaunchKernelGGL(k_wgrad_mfma_finish, dim3((K + 63) / 64), dim3(1024), 0, s, g, fscratch, grid, dw, dbias);
     if (nxt && next_parts) *next_parts = grid;
     return check();
 }
