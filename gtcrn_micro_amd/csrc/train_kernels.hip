@@ -2056,6 +2056,12 @@ __global__ __launch_bounds__(NT) void k_dwunit33_bwd(DwGeom g, const float* __re
 //   dW[tap]   += dy[to][fo] (x) x[to - kt][fo + 1 - kf]            36 MFMAs per 16 positions, positions as the K index (lane (c, k)
 //                                                                  reads channel c of position 4u + k of either image)
 // in the accumulation order of the separate kernels (tap-major chains).  NEXT: point_conv1's reduction rides on dx.
+// 596 us per launch against 860 for the three passes.  Timed apart (same launch with one stage compiled out): the fill alone
+// 186 us, the matrix stage alone 444 us (its MFMAs alone would be 252): the stages barely overlap and the matrix stage runs
+// at 57 % of the pipe (fp32 MFMA does not co-issue with the index / reduction VALU work; 25 position tiles on 4 waves).
+// Tried on top, none faster: six waves per workgroup, the next tile's fill prefetched into registers (the riding
+// reduction's own load then waits for the whole prefetch: vmcnt retires in order), producer / matrix wave specialisation
+// with double-buffered images (one workgroup per CU: -0.54 ms per step against -0.78), staggering the two workgroups of a CU.
 constexpr int D9_TF = 12, D9_ROWS = D9_TF + 2, D9_IMG = D9_ROWS * 35 * 16;
 constexpr int D9_LDS_FLOATS = 2 * D9_IMG + 9 * 256;
 static_assert(D9_LDS_FLOATS * 4 * 2 <= 160 * 1024, "two workgroups per CU");
@@ -2146,16 +2152,26 @@ __global__ __launch_bounds__(NT) void k_dense33_bwd(ConvGeom g, const float* __r
                 }
             }
             // weight gradient: lane (c = n, k = q) takes channel c of positions 4u + k
+            // (all forty operand reads of the sixteen positions first, then the 36 MFMAs: read-then-use per MFMA left the
+            // matrix pipe waiting for an LDS round trip every one or two instructions)
+            float av[4], bv[4][9];
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 const int pu = nt * 16 + 4 * u + q, pc = pu < own_d ? pu : 0, r = pc / 33, f = pc - r * 33;
-                float a = sDy[(r * 35 + 1 + f) * 16 + n];
-                a = pu < own_d ? a : 0.f;
-                bsum += a;
+                const float a = sDy[(r * 35 + 1 + f) * 16 + n];
+                av[u] = pu < own_d ? a : 0.f;
                 const float* xq = sXi + ((r + 2) * 35 + f + 2) * 16 + n;       // x[to - kt][fo + 1 - kf] at row + 2 - kt, column + 2 - kf
 #pragma unroll
-                for (int tap = 0; tap < 9; ++tap) accW[tap] = mfma4(a, xq[-((tap / 3) * 35 + tap % 3) * 16], accW[tap]);
+                for (int tap = 0; tap < 9; ++tap) bv[u][tap] = xq[-((tap / 3) * 35 + tap % 3) * 16];
             }
+            __builtin_amdgcn_sched_barrier(0);        // (the scheduler interleaves them again otherwise)
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                bsum += av[u];
+#pragma unroll
+                for (int tap = 0; tap < 9; ++tap) accW[tap] = mfma4(av[u], bv[u][tap], accW[tap]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
         }
     }
     __syncthreads();                                                 // the images are dead: the accumulators go there
