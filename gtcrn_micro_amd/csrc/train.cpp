@@ -112,11 +112,12 @@ struct gtcrn_trainer {
     size_t arena_floats = 0;
     float* fscratch = nullptr;    // wgrad / TRA partial sums
     double* dscratch = nullptr;   // BatchNorm partial sums
-    int fusions = 255;                 // gtcrn_trainer_set_fusions: 1 normalise-on-load, 2 depthwise backward, 4 riding reductions,
+    int fusions = 511;                 // gtcrn_trainer_set_fusions: 1 normalise-on-load, 2 depthwise backward, 4 riding reductions,
                                       // 8 single-reader activations recomputed in the backward instead of stored,
                                       // 16 skip gradients accumulated in place (no add passes in the backward),
                                       // 32 reductions riding in the adjoint convs of the 3x3 units and of en_convs.1,
-                                      // 64 the depthwise 3x3 unit's backward in one LDS-tiled pass, 128 the dense 3x3 unit's
+                                      // 64 the depthwise 3x3 unit's backward in one LDS-tiled pass, 128 the dense 3x3 unit's,
+                                      // 256 point_conv1's BatchNorm + PReLU applied by the LDS-tiled depth convs while staging
     const void* red_unit = nullptr;   // backward: the unit whose BatchNorm reduction already sits in dscratch ...
     int red_parts = 0;                // ... as this many per-workgroup partial sums (see unit_bwd)
     std::map<std::string, long> off;   // parameter name -> blob offset
@@ -323,8 +324,11 @@ size_t plan(gtcrn_trainer* t, int B, int T, float* base) {
         k.depth.front = &k.pc1;          // the depth conv's adjoint produces point_conv1's gradient input
         k.pc2.pre = fuse ? &k.depth : nullptr;
         k.depth.deferred = fuse;
-        // (point_conv1 -> depth_conv is NOT fused: nine taps each re-apply the BatchNorm + PReLU -- the depthwise 3x3
-        // took 312 us against 163 + 107 for the two passes; the dense 3x3 is MFMA-bound already)
+        // point_conv1 -> depth_conv: nine global taps each re-applying the BatchNorm + PReLU were slower than the separate
+        // pass (312 us against 163 + 107); the LDS-tiled depth convs form the activation once while staging (fusion bit 8)
+        const bool fuse_pc1 = fuse && (t->fusions & 256);
+        k.depth.pre = fuse_pc1 ? &k.pc1 : nullptr;
+        k.pc1.deferred = fuse_pc1;
         k.o_tra = P(t, p + ".tra.depth_conv.weight");
         k.e = b.take((size_t)B * Tt * 8); k.yt = b.take((size_t)B * Tt * 8); k.g = b.take((size_t)B * Tt * 8);
         k.out = b.take_saved(n33 * 16);
@@ -445,11 +449,10 @@ size_t plan(gtcrn_trainer* t, int B, int T, float* base) {
         k.xinc = xin;
         k.pc1.xc = xin;
         k.pc1.yc = get(N33);
-        k.pc1.ac = get(N33);
-        put(k.pc1.yc, N33);
-        k.depth.xc = k.pc1.ac;
+        if (!k.pc1.deferred) { k.pc1.ac = get(N33); put(k.pc1.yc, N33); } else k.pc1.ac = nullptr;
+        k.depth.xc = k.pc1.deferred ? nullptr : k.pc1.ac;
         k.depth.yc = get(nt16);
-        put(k.pc1.ac, N33);
+        put(k.pc1.deferred ? k.pc1.yc : k.pc1.ac, N33);
         if (!k.depth.deferred) { k.depth.ac = get(nt16); put(k.depth.yc, nt16); } else k.depth.ac = nullptr;
         k.pc2.xc = k.depth.deferred ? nullptr : k.depth.ac;
         k.pc2.yc = get(nt8);
@@ -813,7 +816,7 @@ int gtcrn_trainer_set_storage(gtcrn_trainer* t, int storage) {
 }
 
 int gtcrn_trainer_set_fusions(gtcrn_trainer* t, int mask) {
-    if (!t || mask < 0 || mask > 255) return tfail(GTCRN_ERR_ARG, "gtcrn_trainer_set_fusions: mask must be 0..255");
+    if (!t || mask < 0 || mask > 511) return tfail(GTCRN_ERR_ARG, "gtcrn_trainer_set_fusions: mask must be 0..511");
     if (t->fusions != mask) {
         t->fusions = mask;
         t->planned = false;      // the unit links are laid out again on the next forward

@@ -1938,6 +1938,189 @@ __global__ __launch_bounds__(NT) void k_dwunit31_bwd(DwGeom g, const float* __re
     if constexpr (NEXT) block_reduce_store<3, 4>(vr, 16, sh, rpartial + (long)vb * 48);
 }
 
+// ---------------------------------------------- depth_conv FORWARD with point_conv1's BatchNorm + PReLU applied while staging
+// point_conv1 -> depth_conv could not use the normalise-on-load forms above: nine taps would each re-apply the BatchNorm +
+// PReLU (measured: slower than the separate k_bn_act pass).  With an LDS tile the activation is formed ONCE per element
+// while the tile is staged -- the expressions of k_bn_act (pre_apply): bit-identical values -- the nine taps read it from
+// LDS, and the owned rows go out to the saved activation (and, exact chain, the centred copy of y) as the separate pass
+// wrote them.  k_bn_act (read y, write a) + a conv that re-reads a through nine global taps become one pass: read y, write
+// a, write the conv output.  Same accumulation order as k_dw16 / k_conv_mfma (bias first, taps kt-major): the conv outputs
+// are bit-identical; the BatchNorm partial sums are taken in double as there.
+constexpr int F33_TF = 12, F33_ROWS = F33_TF + 2;
+// stages rows r = input frames t0 - 2 + r (zero outside [0, T)) of utterance b into img [F33_ROWS][35][16] (pads untouched)
+template <int FIN, int NTH>
+__device__ __forceinline__ void stage_pre_tile(float* img, const float* __restrict__ in, const BnPre& pre, const PreConst& pk, int b,
+                                               int t0, int T, int tid, int q) {
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+    constexpr int ITEMS = F33_ROWS * 33 * 4, UN = 3;
+    for (int it0 = tid; it0 < ITEMS; it0 += UN * NTH) {              // (NTH % 4 == 0: every item's quad is q)
+        typename Raw4<FIN>::t yr[UN];
+        long idx[UN];
+        int rec[UN], rr[UN];
+        bool ok[UN], live[UN];
+#pragma unroll
+        for (int j = 0; j < UN; ++j) {
+            const int it = it0 + j * NTH;
+            live[j] = it < ITEMS;
+            const int pos = (live[j] ? it : 0) >> 2, r = pos / 33, f = pos - r * 33, tx = t0 - 2 + r;
+            ok[j] = tx >= 0 && tx < T;
+            idx[j] = (((long)b * T + (ok[j] ? tx : 0)) * 33 + f) * 16 + 4 * q;
+            yr[j] = sld4_raw<FIN, true>(in, idx[j]);
+            rec[j] = (r * 35 + 1 + f) * 16 + 4 * q;
+            rr[j] = r;
+        }
+#pragma unroll
+        for (int j = 0; j < UN; ++j) {
+            const f32x4 yraw = dec4<FIN>(yr[j]);
+            const f32x4 a = pre_apply(pk, yraw, pre.exact ? 0 : pre.bf);
+            if (live[j]) {
+                *reinterpret_cast<f32x4*>(img + rec[j]) = ok[j] ? a : zero;
+                if (ok[j] && rr[j] >= 2) {                              // the tile's own frames: each element once
+                    pre_store(pre, idx[j], a);
+                    pre_store_y(pre, pk, idx[j], yraw, false, zero);
+                }
+            }
+        }
+    }
+}
+template <int FIN>
+__global__ __launch_bounds__(NT) void k_dw33_fwd_pre(DwGeom g, const float* __restrict__ in, const float* __restrict__ w,
+                                                    const float* __restrict__ bias, float* __restrict__ out,
+                                                    double* __restrict__ stat_partial, const float* __restrict__ shift,
+                                                    BnPre pre, int tiles_t) {
+    __shared__ __attribute__((aligned(16))) float sA[F33_ROWS * 35 * 16];
+    __shared__ __attribute__((aligned(16))) float sW[9 * 16];       // [tap][c]
+    __shared__ double sStat[NT / 64][32];
+    const int tid = threadIdx.x, q = tid & 3;
+    for (int i = tid; i < 9 * 16; i += NT) {
+        const int tap = i >> 4, c = i & 15;
+        sW[i] = w[c * g.w_c + (tap / 3) * g.w_kt + (tap % 3) * g.w_kf];
+    }
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+    for (int i = tid; i < F33_ROWS * 2 * 4; i += NT) {
+        const int qq = i & 3, side = (i >> 2) & 1, r = i >> 3;
+        *reinterpret_cast<f32x4*>(sA + (r * 35 + side * 34) * 16 + 4 * qq) = zero;
+    }
+    const PreConst pk = pre_const(pre, q, 16);
+    f32x4 b0 = zero;
+    if (bias) b0 = *reinterpret_cast<const f32x4*>(bias + 4 * q);
+    if (shift) b0 -= *reinterpret_cast<const f32x4*>(shift + 4 * q);
+    double s1[4] = {0.0, 0.0, 0.0, 0.0}, s2[4] = {0.0, 0.0, 0.0, 0.0};
+    const int T = g.Tout;
+    const long ntiles = (long)g.B * tiles_t;
+    for (long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int b = (int)(tile / tiles_t), t0 = (int)(tile - (long)b * tiles_t) * F33_TF;
+        __syncthreads();
+        stage_pre_tile<FIN, NT>(sA, in, pre, pk, b, t0, T, tid, q);
+        __syncthreads();
+        const int nrow = T - t0 < F33_TF ? T - t0 : F33_TF;
+        for (int it = tid; it < nrow * 33 * 4; it += NT) {
+            const int pos = it >> 2, r = pos / 33, f = pos - r * 33;
+            const long p = ((long)b * T + t0 + r) * 33 + f;
+            const float* aq = sA + (r * 35 + f) * 16 + 4 * q;       // tap (kt, kf): input frame t - 2 + kt, bin f - 1 + kf
+            f32x4 acc = b0;
+#pragma unroll
+            for (int kt = 0; kt < 3; ++kt)
+#pragma unroll
+                for (int kf = 0; kf < 3; ++kf)
+                    acc = acc + *reinterpret_cast<const f32x4*>(sW + (kt * 3 + kf) * 16 + 4 * q) *
+                                    *reinterpret_cast<const f32x4*>(aq + (kt * 35 + kf) * 16);
+            if (g.out_bf) {
+                acc = round_bf4(acc, g.out_bf);
+                sst4<kNtSt>(out, p * 16 + 4 * q, g.out_bf, acc);
+            } else {
+                sst4<kNtSt>(out, p * 16 + 4 * q, 0, acc);
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { const double a = (double)acc[e]; s1[e] += a; s2[e] = fma(a, a, s2[e]); }
+        }
+    }
+    if (stat_partial) {   // per-workgroup BatchNorm partial sums; a thread's channel quad is tid & 3 (as k_dw16)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { s1[e] = wave_sum_xor(s1[e], 4, 32); s2[e] = wave_sum_xor(s2[e], 4, 32); }
+        if ((tid & 63) < 4)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { sStat[tid >> 6][4 * q + e] = s1[e]; sStat[tid >> 6][16 + 4 * q + e] = s2[e]; }
+        __syncthreads();
+        if (tid < 32) {
+            double t = 0.0;
+            for (int w2 = 0; w2 < NT / 64; ++w2) t += sStat[w2][tid];
+            stat_partial[(long)blockIdx.x * 32 + tid] = t;
+        }
+    }
+}
+// the decoder's dense transposed 3x3: y[to][fo] = b + sum W[kt][kf] a[to - kt][fo + 1 - kf], T + 2 output frames; per 16 output
+// positions 36 MFMAs whose B operands are ds_read_b128 of the staged activation
+template <int FIN>
+__global__ __launch_bounds__(NT) void k_dense33_fwd_pre(ConvGeom g, const float* __restrict__ in, const float* __restrict__ w,
+                                                       const float* __restrict__ bias, float* __restrict__ out,
+                                                       double* __restrict__ stat_partial, const float* __restrict__ shift,
+                                                       BnPre pre, int tiles_t) {
+    __shared__ __attribute__((aligned(16))) float sA[F33_ROWS * 35 * 16];
+    __shared__ __attribute__((aligned(16))) float sW[9 * 256];      // [tap][co][ci]
+    __shared__ double sStat[NT / 64][32];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, n = lane & 15, q = lane >> 4, qs = tid & 3;
+    for (int i = tid; i < 9 * 256; i += NT) {
+        const int tap = i >> 8, co = (i >> 4) & 15, ci = i & 15;
+        sW[i] = w[co * g.w_co + ci * g.w_ci + (tap / 3) * g.w_kt + (tap % 3) * g.w_kf];
+    }
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+    for (int i = tid; i < F33_ROWS * 2 * 4; i += NT) {
+        const int qq = i & 3, side = (i >> 2) & 1, r = i >> 3;
+        *reinterpret_cast<f32x4*>(sA + (r * 35 + side * 34) * 16 + 4 * qq) = zero;
+    }
+    const PreConst pk = pre_const(pre, qs, 16);
+    f32x4 bv = zero;
+    if (bias) bv = *reinterpret_cast<const f32x4*>(bias + 4 * q);
+    if (shift) bv -= *reinterpret_cast<const f32x4*>(shift + 4 * q);
+    double s1[4] = {0.0, 0.0, 0.0, 0.0}, s2[4] = {0.0, 0.0, 0.0, 0.0};
+    const int T = g.Tin, T2 = g.Tout;
+    const long ntiles = (long)g.B * tiles_t;
+    for (long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int b = (int)(tile / tiles_t), t0 = (int)(tile - (long)b * tiles_t) * F33_TF;
+        __syncthreads();
+        stage_pre_tile<FIN, NT>(sA, in, pre, pk, b, t0, T, tid, qs);
+        __syncthreads();
+        const int own = (T2 - t0 < F33_TF ? T2 - t0 : F33_TF) * 33;
+        for (int nt = wv; nt * 16 < own; nt += NT / 64) {
+            const int pl = nt * 16 + n, pc = pl < own ? pl : 0, r = pc / 33, f = pc - r * 33;
+            const long p = ((long)b * T2 + t0 + r) * 33 + f;
+            const float* aq = sA + ((r + 2) * 35 + f + 2) * 16 + 4 * q;    // tap (kt, kf): a[to - kt][fo + 1 - kf]
+            f32x4 acc = bv;
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) {
+                const f32x4 A = *reinterpret_cast<const f32x4*>(sW + tap * 256 + n * 16 + 4 * q);
+                const f32x4 Bq = *reinterpret_cast<const f32x4*>(aq - ((tap / 3) * 35 + tap % 3) * 16);
+#pragma unroll
+                for (int s2i = 0; s2i < 4; ++s2i) acc = mfma4(A[s2i], Bq[s2i], acc);
+            }
+            if (pl < own) {
+                if (g.out_bf) {
+                    acc = round_bf4(acc, g.out_bf);
+                    sst4<kNtSt>(out, p * 16 + 4 * q, g.out_bf, acc);
+                } else {
+                    sst4<kNtSt>(out, p * 16 + 4 * q, 0, acc);
+                }
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { const double a = (double)acc[e]; s1[e] += a; s2[e] = fma(a, a, s2[e]); }
+            }
+        }
+    }
+    if (stat_partial) {   // as k_conv_mfma: lanes of one channel quad differ in n (xor distances 8..1), then the waves through LDS
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { s1[e] = wave_sum_xor(s1[e], 1, 8); s2[e] = wave_sum_xor(s2[e], 1, 8); }
+        if (n == 0)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { sStat[wv][4 * q + e] = s1[e]; sStat[wv][16 + 4 * q + e] = s2[e]; }
+        __syncthreads();
+        if (tid < 32) {
+            double t = 0.0;
+            for (int w2 = 0; w2 < NT / 64; ++w2) t += sStat[w2][tid];
+            stat_partial[(long)blockIdx.x * 32 + tid] = t;
+        }
+    }
+}
+
 // ------------------------------------------ fused backward of a depthwise 3x3 conv + BatchNorm + PReLU (encoder depth_conv)
 // After the BatchNorm reduction the unit's three remaining passes -- dy (k_bn_bwd_apply: read da, y, write dy), the weight
 // gradient (k_dw_wgrad_stream<3,3>: read dy, x at nine taps) and the data gradient (k_dw16<3,3> on the adjoint taps: read
@@ -2848,6 +3031,21 @@ int conv_fwd(const ConvGeom& g, const float* in, const float* w, const float* bi
         *stat_parts = grid;
         return check();
     }
+    if (pre && g.nkt == 3 && g.nkf == 3) {
+        // the decoder's dense transposed 3x3 behind a deferred unit (depth_conv <- point_conv1): the LDS-tiled form
+        if (g.t_off[0] != 0 || g.t_off[1] != -1 || g.t_off[2] != -2 || g.f_mode != 1 || g.sf != 1 || g.pf != 1 || g.Fin != 33 ||
+            g.Fout != 33 || g.Cin != 16 || g.CinT != 16 || g.cin_off != 0 || g.Cout != 16 || g.CoutT != 16 || g.cout_off != 0 ||
+            g.Tout != g.Tin + 2 || g.in_bf != (pre->exact ? 0 : pre->ybf) || g.in_bf > 1 || g.accumulate || pre->res || !stat_partial ||
+            !stat_parts)
+            return (int)hipErrorInvalidValue;
+        const int tiles_t = (g.Tout + F33_TF - 1) / F33_TF;
+        const long ntiles = (long)g.B * tiles_t;
+        const int gridt = (int)(ntiles < MAX_PARTIALS ? ntiles : MAX_PARTIALS);
+        if (g.in_bf == 0) hipLaunchKernelGGL((k_dense33_fwd_pre<0>), dim3(gridt), dim3(NT), 0, s, g, in, w, bias, out, stat_partial, shift, *pre, tiles_t);
+        else hipLaunchKernelGGL((k_dense33_fwd_pre<1>), dim3(gridt), dim3(NT), 0, s, g, in, w, bias, out, stat_partial, shift, *pre, tiles_t);
+        *stat_parts = gridt;
+        return check();
+    }
     if (pre && !(mfma_ok(g) && g.nkt == 1 && g.nkf == 1 && g.sf == 1 && g.Cin == 16 && g.CinT == 16 && g.cin_off == 0 &&
                  g.in_bf == pre->ybf))
         return (int)hipErrorInvalidValue;
@@ -2981,6 +3179,20 @@ int dw_fwd(const DwGeom& g, const float* in, const float* w, const float* bias, 
             hipLaunchKernelGGL((k_dw16<3, 3, 0, false, 1>), dim3(g16), dim3(NT), 0, s, g, in, w, bias, out, stat_partial, it,
                                shift, nopre, next_args(next, next_yfmt));
         *stat_parts = g16;
+        return check();
+    }
+    if (pre && g.C == 16 && g.nkt == 3 && g.nkf == 3) {
+        // depthwise 3x3 behind a deferred unit (encoder depth_conv <- point_conv1): the LDS-tiled form
+        if (g.F != 33 || g.t_off[0] != -2 || g.t_off[1] != -1 || g.t_off[2] != 0 || g.f_off[0] != -1 || g.f_off[1] != 0 ||
+            g.f_off[2] != 1 || g.Tin != g.Tout || g.in_bf != (pre->exact ? 0 : pre->ybf) || g.in_bf > 1 || g.accumulate || pre->res ||
+            !stat_partial || !stat_parts)
+            return (int)hipErrorInvalidValue;
+        const int tiles_t = (g.Tout + F33_TF - 1) / F33_TF;
+        const long ntiles = (long)g.B * tiles_t;
+        const int gridt = (int)(ntiles < MAX_PARTIALS ? ntiles : MAX_PARTIALS);
+        if (g.in_bf == 0) hipLaunchKernelGGL((k_dw33_fwd_pre<0>), dim3(gridt), dim3(NT), 0, s, g, in, w, bias, out, stat_partial, shift, *pre, tiles_t);
+        else hipLaunchKernelGGL((k_dw33_fwd_pre<1>), dim3(gridt), dim3(NT), 0, s, g, in, w, bias, out, stat_partial, shift, *pre, tiles_t);
+        *stat_parts = gridt;
         return check();
     }
     if (pre && !(g.C == 16 && g.nkt == 3 && g.nkf == 1 && g.t_off[2] == 0 && g.f_off[0] == 0 && g.in_bf == pre->ybf &&

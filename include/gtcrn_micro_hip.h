@@ -252,7 +252,8 @@ long gtcrn_train_workspace_bytes2(int B, int T, int storage);
  * of the kernels that produce the second one, not by five add passes.  bit 5 (needs bit 2): the reductions of
  * point_conv1 (six blocks) and en_convs.0 ride in the adjoint conv that produces their gradient input.  bit 6: the
  * backward of the encoder's depthwise 3x3 unit (dy, weight gradient, data gradient) in one LDS-tiled pass.  bit 7: the
- * same for the decoder's dense transposed 3x3 unit (both matrix products from LDS images of dy and x).
+ * same for the decoder's dense transposed 3x3 unit (both matrix products from LDS images of dy and x).  bit 8 (needs bit
+ * 0): point_conv1's BatchNorm + PReLU applied by LDS-tiled depth convs while they stage their input tile.
  * 0 runs the layer-at-a-time passes (tests/test_gpu_train.py compares them).  Takes effect at the next forward; not
  * part of the reference's interface. */
 int gtcrn_trainer_set_fusions(gtcrn_trainer *t, int mask);
