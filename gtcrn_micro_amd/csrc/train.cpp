@@ -299,7 +299,10 @@ size_t plan(gtcrn_trainer* t, int B, int T, float* base) {
         k.pc1.cg = conv_geom(B, T, T, 33, 33, 16, 0, 8, 16, 16, 1, 1, 0, 0, 0, 0, 1, 0, deconv ? 1 : 8, deconv ? 16 : 1, 1, 1);
         unit_params(t, k.pc1, p + ".point_conv1", p + ".point_bn1", p + ".point_act");
         k.pc1.act = gtt::ACT_PRELU; k.pc1.x = xin;
-        alloc_unit(b, k.pc1, n33, 16);
+        // point_conv1's activation: read once by the LDS-tiled depth conv (from y, fusion bit 8) and once by that conv's
+        // fused backward, which stages it from y as well (bits 6 / 7): never stored then
+        const bool lean_pc1 = lean && (t->fusions & 256) && (t->fusions & (deconv ? 128 : 64));
+        alloc_unit(b, k.pc1, n33, 16, lean_pc1);
         if (deconv) {
             // depth_conv: ConvTranspose2d(16,16,(3,3),padding=(0,1)), weight [in][out][kt][kf]; T+2 output frames
             k.depth.cg = conv_geom(B, T, T2, 33, 33, 16, 0, 16, 16, 16, 3, 3, 0, -1, -2, 1, 1, 1, 9, 144, 3, 1);
@@ -660,7 +663,7 @@ int unit_bwd(gtcrn_trainer* t, Unit& u, const float* prm, float* grads, const fl
         return 0;
     }
     if (u.dw && u.C == 16 && u.dg.nkt == 3 && u.dg.nkf == 3 && u.dg.F == 33 && u.dg.Tin == u.dg.Tout && u.act == gtt::ACT_PRELU &&
-        !u.res && u.o_slope >= 0 && dx && !dx_acc && !dres && u.x && t->bf == t->ybf && t->bf <= 1 && (t->fusions & 64)) {
+        !u.res && u.o_slope >= 0 && dx && !dx_acc && !dres && t->bf == t->ybf && t->bf <= 1 && (t->fusions & 64)) {
         // encoder depth_conv: dy, weight gradient and data gradient in one LDS-tiled pass; point_conv1's reduction rides along
         const bool ride3 = ride && !f->res && f->n == u.n;
         int parts = 0;
@@ -671,7 +674,7 @@ int unit_bwd(gtcrn_trainer* t, Unit& u, const float* prm, float* grads, const fl
         return 0;
     }
     if (!u.dw && u.cg.nkt == 3 && u.cg.nkf == 3 && u.cg.f_mode == 1 && u.cg.Tout == u.cg.Tin + 2 && u.C == 16 &&
-        u.act == gtt::ACT_PRELU && !u.res && u.o_slope >= 0 && dx && !dx_acc && !dres && u.x && t->bf == t->ybf && t->bf <= 1 &&
+        u.act == gtt::ACT_PRELU && !u.res && u.o_slope >= 0 && dx && !dx_acc && !dres && t->bf == t->ybf && t->bf <= 1 &&
         (t->fusions & 128)) {
         // decoder depth_conv (dense transposed 3x3): dy and both matrix products from LDS tiles; point_conv1's reduction rides
         const bool ride3 = ride && !f->res && f->n == (long)u.cg.B * u.cg.Tin * u.cg.Fin;

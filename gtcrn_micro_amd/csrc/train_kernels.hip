@@ -485,6 +485,17 @@ __device__ __forceinline__ NextConst next_const(const NextRedArgs& nx, int q4) {
     k.sl = nx.slope[0];
     return k;
 }
+// that unit's activation PReLU(BatchNorm(y)) as pre_apply / k_bn_act form it (xround: rounded to bf16 like the stored one)
+__device__ __forceinline__ f32x4 next_act(const NextConst& k, const f32x4 y, int xround) {
+    f32x4 a;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const float z = k.gm[e] * ((y[e] - k.mean[e]) * k.istd[e]) + k.bt[e];
+        const float v = z > 0.f ? z : k.sl * z;
+        a[e] = xround ? round16(v, 1) : v;
+    }
+    return a;
+}
 __device__ __forceinline__ void next_accum(const NextConst& k, const f32x4 y, const f32x4 g, float (&vr)[3][4]) {
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
@@ -2132,7 +2143,8 @@ __global__ __launch_bounds__(NT) void k_dense33_fwd_pre(ConvGeom g, const float*
 // expressions and the same order of additions as the separate kernels.  NEXT: the unit in front (point_conv1) takes this dx
 // as its da -- its first backward pass rides along as in k_dwunit31_bwd.
 constexpr int D33_TF = 12, D33_ROWS = D33_TF + 2;
-template <int FX, int FY, bool NEXT>   // storage formats of x (an activation) and of y / the next unit's y (conv outputs)
+// XR (with NEXT): x IS that unit's activation and is rebuilt from its y while the tile is staged (see NextRedArgs).
+template <int FX, int FY, bool NEXT, bool XR = false>   // storage formats of x (an activation) and of y / the next unit's y (conv outputs)
 __global__ __launch_bounds__(NT) void k_dwunit33_bwd(DwGeom g, const float* __restrict__ x, const float* __restrict__ y,
                                                     const float* __restrict__ da, BnBwdArgs bn,
                                                     const float* __restrict__ w, float* __restrict__ dx,
@@ -2179,7 +2191,11 @@ __global__ __launch_bounds__(NT) void k_dwunit33_bwd(DwGeom g, const float* __re
             const long pd = (rowb + (okd ? td : 0)) * F + f, px = (rowb + (okx ? tx : 0)) * F + f;
             const typename Raw4<FY>::t yr = sld4_raw<FY, true>(y, pd * 16 + 4 * q);
             const f32x4 gr = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(da + pd * 16 + 4 * q));
-            const typename Raw4<FX>::t xr = sld4_raw<FX, true>(x, px * 16 + 4 * q);
+            typename Raw4<FX>::t xr{};
+            typename Raw4<FY>::t xyr{};
+            static_assert(!XR || NEXT, "x is rebuilt from the NEXT unit's y");
+            if constexpr (XR) xyr = sld4_raw<FY, true>(nx.y, px * 16 + 4 * q);
+            else xr = sld4_raw<FX, true>(x, px * 16 + 4 * q);
             const f32x4 yv = dec4<FY>(yr);
             f32x4 dyv;
 #pragma unroll
@@ -2190,7 +2206,10 @@ __global__ __launch_bounds__(NT) void k_dwunit33_bwd(DwGeom g, const float* __re
                 dyv[e] = gm[e] * istd[e] * (dz - m1[e] - xh * m2[e]);
             }
             *reinterpret_cast<f32x4*>(sDy + (r * 35 + 1 + f) * 16 + 4 * q) = okd ? dyv : zero;
-            *reinterpret_cast<f32x4*>(sXi + (r * 35 + 1 + f) * 16 + 4 * q) = okx ? dec4<FX>(xr) : zero;
+            f32x4 xval;
+            if constexpr (XR) xval = next_act(nk, dec4<FY>(xyr), nx.xround);
+            else xval = dec4<FX>(xr);
+            *reinterpret_cast<f32x4*>(sXi + (r * 35 + 1 + f) * 16 + 4 * q) = okx ? xval : zero;
         }
         __syncthreads();
         // ---- stage 2: the tile's own frames t0 .. t0 + D33_TF - 1
@@ -2249,7 +2268,7 @@ constexpr int D9_TF = 12, D9_ROWS = D9_TF + 2, D9_IMG = D9_ROWS * 35 * 16;
 constexpr int D9_LDS_FLOATS = 2 * D9_IMG + 9 * 256;
 static_assert(D9_LDS_FLOATS * 4 * 2 <= 160 * 1024, "two workgroups per CU");
 static_assert((NT / 64) * (9 * 256 + 64) <= 2 * D9_IMG, "the accumulator tiles reuse the images");
-template <int FX, int FY, bool NEXT>
+template <int FX, int FY, bool NEXT, bool XR = false>      // XR: see k_dwunit33_bwd
 __global__ __launch_bounds__(NT) void k_dense33_bwd(ConvGeom g, const float* __restrict__ x, const float* __restrict__ y,
                                                    const float* __restrict__ da, BnBwdArgs bn,
                                                    const float* __restrict__ w, float* __restrict__ dx,
@@ -2269,8 +2288,10 @@ __global__ __launch_bounds__(NT) void k_dense33_bwd(ConvGeom g, const float* __r
     const f32x4 gm = *reinterpret_cast<const f32x4*>(bn.gamma + 4 * qs), bt = *reinterpret_cast<const f32x4*>(bn.beta + 4 * qs);
     const f32x4 m1 = *reinterpret_cast<const f32x4*>(bn.red + 4 * qs), m2 = *reinterpret_cast<const f32x4*>(bn.red + 16 + 4 * qs);
     const float sl = bn.slope[0];
-    NextConst nk{};
+    NextConst nk{}, nks{};
     if constexpr (NEXT) nk = next_const(nx, 4 * q);
+    if constexpr (XR) nks = next_const(nx, 4 * qs);        // (the staging quad)
+    static_assert(!XR || NEXT, "x is rebuilt from the NEXT unit's y");
     float vr[3][4];
 #pragma unroll
     for (int e = 0; e < 4; ++e) vr[0][e] = vr[1][e] = vr[2][e] = 0.f;
@@ -2296,7 +2317,10 @@ __global__ __launch_bounds__(NT) void k_dense33_bwd(ConvGeom g, const float* __r
             const long pd = ((long)b * T2 + (okd ? td : 0)) * 33 + f, px = ((long)b * T + (okx ? tx : 0)) * 33 + f;
             const typename Raw4<FY>::t yr = sld4_raw<FY, true>(y, pd * 16 + 4 * qs);
             const f32x4 gr = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(da + pd * 16 + 4 * qs));
-            const typename Raw4<FX>::t xr = sld4_raw<FX, true>(x, px * 16 + 4 * qs);
+            typename Raw4<FX>::t xr{};
+            typename Raw4<FY>::t xyr{};
+            if constexpr (XR) xyr = sld4_raw<FY, true>(nx.y, px * 16 + 4 * qs);
+            else xr = sld4_raw<FX, true>(x, px * 16 + 4 * qs);
             const f32x4 yv = dec4<FY>(yr);
             f32x4 dyv;
 #pragma unroll
@@ -2307,7 +2331,10 @@ __global__ __launch_bounds__(NT) void k_dense33_bwd(ConvGeom g, const float* __r
                 dyv[e] = gm[e] * istd[e] * (dz - m1[e] - xh * m2[e]);
             }
             *reinterpret_cast<f32x4*>(sDy + (r * 35 + 1 + f) * 16 + 4 * qs) = okd ? dyv : zero;
-            *reinterpret_cast<f32x4*>(sXi + (r * 35 + 1 + f) * 16 + 4 * qs) = okx ? dec4<FX>(xr) : zero;
+            f32x4 xval;
+            if constexpr (XR) xval = next_act(nks, dec4<FY>(xyr), nx.xround);
+            else xval = dec4<FX>(xr);
+            *reinterpret_cast<f32x4*>(sXi + (r * 35 + 1 + f) * 16 + 4 * qs) = okx ? xval : zero;
         }
         __syncthreads();
         // ---- stage 2: 16-position tiles of the D9_TF x 33 owned positions, one wave each
@@ -3364,7 +3391,7 @@ int dwunit33_bwd(const DwGeom& g, const float* x, const float* y, const float* d
                  hipStream_t s, int bf, int ybf, const DwUnitNext* next, int* next_parts, int have_parts) {
     if (next_parts) *next_parts = 0;
     if (g.C != 16 || g.F != 33 || g.nkt != 3 || g.nkf != 3 || g.t_off[0] != -2 || g.t_off[1] != -1 || g.t_off[2] != 0 ||
-        g.f_off[0] != -1 || g.f_off[1] != 0 || g.f_off[2] != 1 || g.Tin != g.Tout || !slope || !dx || !x || bf > 1 || ybf > 1 ||
+        g.f_off[0] != -1 || g.f_off[1] != 0 || g.f_off[2] != 1 || g.Tin != g.Tout || !slope || !dx || bf > 1 || ybf > 1 ||
         bf != ybf)
         return (int)hipErrorInvalidValue;
     const long n = (long)g.B * g.Tout * g.F, total = n * 16;
@@ -3381,10 +3408,13 @@ int dwunit33_bwd(const DwGeom& g, const float* x, const float* y, const float* d
     BnBwdArgs bn{stats, gamma, beta, slope, red, ACT_PRELU};
     NextRedArgs nx{};
     const bool nxt = next && next->slope && !next->res;
-    if (nxt) nx = NextRedArgs{next->y, next->stats, next->gamma, next->beta, next->slope, nullptr, 0, ybf};
+    const bool xr = nxt && next->recompute_x;
+    if (!x && !xr) return (int)hipErrorInvalidValue;
+    if (nxt) nx = NextRedArgs{next->y, next->stats, next->gamma, next->beta, next->slope, nullptr, next->recompute_x == 2, ybf};
 #define GT_D33(F)                                                                                                       \
     do {                                                                                                               \
-        if (nxt) hipLaunchKernelGGL((k_dwunit33_bwd<F, F, true>), dim3(grid), dim3(NT), 0, s, g, x, y, da, bn, w, dx, wpart, nx, dscratch, tiles_t); \
+        if (xr) hipLaunchKernelGGL((k_dwunit33_bwd<F, F, true, true>), dim3(grid), dim3(NT), 0, s, g, x, y, da, bn, w, dx, wpart, nx, dscratch, tiles_t); \
+        else if (nxt) hipLaunchKernelGGL((k_dwunit33_bwd<F, F, true>), dim3(grid), dim3(NT), 0, s, g, x, y, da, bn, w, dx, wpart, nx, dscratch, tiles_t); \
         else hipLaunchKernelGGL((k_dwunit33_bwd<F, F, false>), dim3(grid), dim3(NT), 0, s, g, x, y, da, bn, w, dx, wpart, nx, dscratch, tiles_t); \
     } while (0)
     if (bf == 0) GT_D33(0);
@@ -3403,7 +3433,7 @@ int dense33_bwd(const ConvGeom& g, const float* x, const float* y, const float* 
     // the decoder's ConvTranspose2d(16,16,(3,3),padding (0,1)) in gather form: taps t, t-1, t-2, transposed in frequency
     if (g.nkt != 3 || g.nkf != 3 || g.t_off[0] != 0 || g.t_off[1] != -1 || g.t_off[2] != -2 || g.f_mode != 1 || g.sf != 1 ||
         g.pf != 1 || g.Fin != 33 || g.Fout != 33 || g.Cin != 16 || g.CinT != 16 || g.cin_off != 0 || g.Cout != 16 ||
-        g.CoutT != 16 || g.cout_off != 0 || g.Tout != g.Tin + 2 || !slope || !dx || !x || bf > 1 || ybf > 1 || bf != ybf)
+        g.CoutT != 16 || g.cout_off != 0 || g.Tout != g.Tin + 2 || !slope || !dx || bf > 1 || ybf > 1 || bf != ybf)
         return (int)hipErrorInvalidValue;
     const long n = (long)g.B * g.Tout * g.Fout, total = n * 16;
     float* red = reinterpret_cast<float*>(dscratch + (long)MAX_PARTIALS * 3 * 16);
@@ -3417,21 +3447,23 @@ int dense33_bwd(const ConvGeom& g, const float* x, const float* y, const float* 
     BnBwdArgs bn{stats, gamma, beta, slope, red, ACT_PRELU};
     NextRedArgs nx{};
     const bool nxt = next && next->slope && !next->res;
-    if (nxt) nx = NextRedArgs{next->y, next->stats, next->gamma, next->beta, next->slope, nullptr, 0, ybf};
-    static bool lds_set[4] = {false, false, false, false};
-#define GT_D9(F, NXV, SLOT)                                                                                             \
+    const bool xr = nxt && next->recompute_x;
+    if (!x && !xr) return (int)hipErrorInvalidValue;
+    if (nxt) nx = NextRedArgs{next->y, next->stats, next->gamma, next->beta, next->slope, nullptr, next->recompute_x == 2, ybf};
+    static bool lds_set[6] = {false, false, false, false, false, false};
+#define GT_D9(F, NXV, XRV, SLOT)                                                                                        \
     do {                                                                                                               \
         if (!lds_set[SLOT]) {                                                                                          \
-            hipError_t e_ = hipFuncSetAttribute(reinterpret_cast<const void*>(k_dense33_bwd<F, F, NXV>),                \
+            hipError_t e_ = hipFuncSetAttribute(reinterpret_cast<const void*>(k_dense33_bwd<F, F, NXV, XRV>),           \
                                                 hipFuncAttributeMaxDynamicSharedMemorySize, D9_LDS_FLOATS * 4);         \
             if (e_ != hipSuccess) return (int)e_;                                                                      \
             lds_set[SLOT] = true;                                                                                      \
         }                                                                                                              \
-        hipLaunchKernelGGL((k_dense33_bwd<F, F, NXV>), dim3(grid), dim3(NT), D9_LDS_FLOATS * 4, s, g, x, y, da, bn, w, dx, \
+        hipLaunchKernelGGL((k_dense33_bwd<F, F, NXV, XRV>), dim3(grid), dim3(NT), D9_LDS_FLOATS * 4, s, g, x, y, da, bn, w, dx, \
                            fscratch, nx, dscratch, tiles_t);                                                           \
     } while (0)
-    if (bf == 0) { if (nxt) GT_D9(0, true, 0); else GT_D9(0, false, 1); }
-    else { if (nxt) GT_D9(1, true, 2); else GT_D9(1, false, 3); }
+    if (bf == 0) { if (xr) GT_D9(0, true, true, 4); else if (nxt) GT_D9(0, true, false, 0); else GT_D9(0, false, false, 1); }
+    else { if (xr) GT_D9(1, true, true, 5); else if (nxt) GT_D9(1, true, false, 2); else GT_D9(1, false, false, 3); }
 #undef GT_D9
     const int K = 9 * 256 + 16;
     hipLaunchKernelGGL(k_wgrad_mfma_finish, dim3((K + 63) / 64), dim3(1024), 0, s, g, fscratch, grid, dw, dbias);
