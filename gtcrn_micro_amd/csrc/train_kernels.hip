@@ -3450,15 +3450,13 @@ int dense33_bwd(const ConvGeom& g, const float* x, const float* y, const float* 
     const bool xr = nxt && next->recompute_x;
     if (!x && !xr) return (int)hipErrorInvalidValue;
     if (nxt) nx = NextRedArgs{next->y, next->stats, next->gamma, next->beta, next->slope, nullptr, next->recompute_x == 2, ybf};
-    static bool lds_set[6] = {false, false, false, false, false, false};
+    // (the attribute belongs to the current device's copy of the kernel: set on every launch -- a host-side table lookup --
+    // rather than remembered per process, which would miss a second device)
 #define GT_D9(F, NXV, XRV, SLOT)                                                                                        \
     do {                                                                                                               \
-        if (!lds_set[SLOT]) {                                                                                          \
-            hipError_t e_ = hipFuncSetAttribute(reinterpret_cast<const void*>(k_dense33_bwd<F, F, NXV, XRV>),           \
-                                                hipFuncAttributeMaxDynamicSharedMemorySize, D9_LDS_FLOATS * 4);         \
-            if (e_ != hipSuccess) return (int)e_;                                                                      \
-            lds_set[SLOT] = true;                                                                                      \
-        }                                                                                                              \
+        hipError_t e_ = hipFuncSetAttribute(reinterpret_cast<const void*>(k_dense33_bwd<F, F, NXV, XRV>),               \
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, D9_LDS_FLOATS * 4);             \
+        if (e_ != hipSuccess) return (int)e_;                                                                          \
         hipLaunchKernelGGL((k_dense33_bwd<F, F, NXV, XRV>), dim3(grid), dim3(NT), D9_LDS_FLOATS * 4, s, g, x, y, da, bn, w, dx, \
                            fscratch, nx, dscratch, tiles_t);                                                           \
     } while (0)
