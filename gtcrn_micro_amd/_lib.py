@@ -585,7 +585,7 @@ class Trainer:
         self.storage = storage
 
     def set_fusions(self, mask):
-        """Diagnostic (gtcrn_trainer_set_fusions): 511 = all pass fusions (default), 7 = round 3's (every activation
+        """Diagnostic (gtcrn_trainer_set_fusions): 1023 = all pass fusions (default), 7 = round 3's (every activation
         stored, separate skip-gradient adds), 0 = the layer-at-a-time passes."""
         _check(lib().gtcrn_trainer_set_fusions(self._h, int(mask)))
 

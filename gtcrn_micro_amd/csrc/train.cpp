@@ -112,12 +112,13 @@ struct gtcrn_trainer {
     size_t arena_floats = 0;
     float* fscratch = nullptr;    // wgrad / TRA partial sums
     double* dscratch = nullptr;   // BatchNorm partial sums
-    int fusions = 511;                 // gtcrn_trainer_set_fusions: 1 normalise-on-load, 2 depthwise backward, 4 riding reductions,
+    int fusions = 1023;                 // gtcrn_trainer_set_fusions: 1 normalise-on-load, 2 depthwise backward, 4 riding reductions,
                                       // 8 single-reader activations recomputed in the backward instead of stored,
                                       // 16 skip gradients accumulated in place (no add passes in the backward),
                                       // 32 reductions riding in the adjoint convs of the 3x3 units and of en_convs.1,
                                       // 64 the depthwise 3x3 unit's backward in one LDS-tiled pass, 128 the dense 3x3 unit's,
-                                      // 256 point_conv1's BatchNorm + PReLU applied by the LDS-tiled depth convs while staging
+                                      // 256 point_conv1's BatchNorm + PReLU applied by the LDS-tiled depth convs while staging,
+                                      // 512 the backward of en_convs.1 / de_convs.3 from LDS tiles
     const void* red_unit = nullptr;   // backward: the unit whose BatchNorm reduction already sits in dscratch ...
     int red_parts = 0;                // ... as this many per-workgroup partial sums (see unit_bwd)
     std::map<std::string, long> off;   // parameter name -> blob offset
@@ -685,6 +686,18 @@ int unit_bwd(gtcrn_trainer* t, Unit& u, const float* prm, float* grads, const fl
         if (ride3 && parts > 0) { t->red_unit = f; t->red_parts = parts; }
         return 0;
     }
+    if (!u.dw && u.cg.nkt == 1 && u.cg.nkf == 5 && u.cg.sf == 2 && u.cg.Cin == 16 && u.cg.Cout == 16 && u.C == 16 &&
+        u.act == gtt::ACT_PRELU && !u.res && u.o_slope >= 0 && dx && !dres && u.x && t->bf == t->ybf && t->bf <= 1 &&
+        (t->fusions & 512)) {
+        // en_convs.1 / de_convs.3: dy and both matrix products from LDS tiles; en_convs.0's reduction rides on en_convs.1's dx
+        const bool ride5 = ride && (t->fusions & 32) && !f->res && u.cg.f_mode == 0 && f->n == (long)u.cg.B * u.cg.Tin * u.cg.Fin;
+        int parts = 0;
+        T_RUN(gtt::conv15_bwd(u.cg, u.x, u.y, da, u.bstats, bn, bn + u.C, prm + u.o_slope, prm + u.o_w, dx, dx_acc,
+                              grads + u.o_w, u.o_b >= 0 ? grads + u.o_b : nullptr, gbn, gbn + u.C, grads + u.o_slope,
+                              t->dscratch, t->fscratch, s, t->bf, t->ybf, ride5 ? &nx : nullptr, &parts, have_parts));
+        if (ride5 && parts > 0) { t->red_unit = f; t->red_parts = parts; }
+        return 0;
+    }
     T_RUN(gtt::bn_act_bwd(da, u.y, u.n, u.C, u.bstats, bn, bn + u.C, u.res, u.act,
                           u.o_slope >= 0 ? prm + u.o_slope : nullptr, t->dy, dres, dres_acc, gbn, gbn + u.C,
                           u.o_slope >= 0 ? grads + u.o_slope : nullptr, t->dscratch, s, t->bf, t->ybf, have_parts));
@@ -819,7 +832,7 @@ int gtcrn_trainer_set_storage(gtcrn_trainer* t, int storage) {
 }
 
 int gtcrn_trainer_set_fusions(gtcrn_trainer* t, int mask) {
-    if (!t || mask < 0 || mask > 511) return tfail(GTCRN_ERR_ARG, "gtcrn_trainer_set_fusions: mask must be 0..511");
+    if (!t || mask < 0 || mask > 1023) return tfail(GTCRN_ERR_ARG, "gtcrn_trainer_set_fusions: mask must be 0..1023");
     if (t->fusions != mask) {
         t->fusions = mask;
         t->planned = false;      // the unit links are laid out again on the next forward

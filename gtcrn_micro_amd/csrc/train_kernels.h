@@ -161,6 +161,13 @@ int dense33_bwd(const ConvGeom& g, const float* x, const float* y, const float* 
                 float* dbias, float* dgamma, float* dbeta, float* dslope, double* dscratch, float* fscratch,
                 hipStream_t s, int bf, int ybf, const DwUnitNext* next, int* next_parts, int have_parts = 0);
 
+// ... and for the two 16 -> 16 (1,5) stride-2 units, en_convs.1 (Conv2d, 65 -> 33 bins) and de_convs.3 (ConvTranspose2d,
+// 33 -> 65 bins): dy and x of eight frames in LDS, weight gradient and data gradient from there; dx may accumulate.
+int conv15_bwd(const ConvGeom& g, const float* x, const float* y, const float* da, const float* stats,
+               const float* gamma, const float* beta, const float* slope, const float* w, float* dx, int dx_acc,
+               float* dw, float* dbias, float* dgamma, float* dbeta, float* dslope, double* dscratch, float* fscratch,
+               hipStream_t s, int bf, int ybf, const DwUnitNext* next, int* next_parts, int have_parts = 0);
+
 // features: spec (strided (b,f,t) + re/im) -> EB [B][T][129][3] = ERB.bm([mag,re,im]) (models/gtcrn_micro.py:510-516)
 int feat_fwd(const float* spec, long sb, long sf, long st, int B, int T, const float* erb_w, float* eb,
              hipStream_t s, int bf = 0, float* eb2 = nullptr, int eb2_bf = 0);

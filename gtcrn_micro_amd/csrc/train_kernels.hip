@@ -2422,6 +2422,221 @@ __global__ __launch_bounds__(NT) void k_dense33_bwd(ConvGeom g, const float* __r
     }
 }
 
+// ------------------------------------------ fused backward of the two 16 -> 16 (1,5) stride-2 units (en_convs.1, de_convs.3)
+// en_convs.1 is Conv2d(16,16,(1,5),stride (1,2),padding (0,2)): y_n[fn] = sum_kf W[kf] x_w[2 fn - 2 + kf] (65 -> 33 bins);
+// de_convs.3 is the ConvTranspose2d of the same shape: y_w[fw] = sum over (fn, kf) with fw = 2 fn - 2 + kf of W[kf] x_n[fn]
+// (33 -> 65 bins).  Both couple a NARROW tensor (33 bins) with a WIDE one (65 bins) through the same index relation
+// fw = 2 fn - 2 + kf, with dy on the narrow side for en_convs.1 and on the wide side for de_convs.3 (DYW).  Their backward
+// was k_bn_bwd_apply (dy written) + k_conv_wgrad_lds<1,5> + the adjoint k_conv_mfma<1,5>: here a workgroup takes C15_TF
+// frames of one utterance (no halo: the taps run along frequency only), forms dy from da, y into the LDS image of its side,
+// copies x into the other image (rows padded with zero columns for the out-of-range taps), and both matrix products read
+// LDS:   dW[kf] += dy (x) x over the 33 narrow positions of a frame       (positions as the MFMA K index)
+//        dx     = sum_kf W[kf]^T dy[...]                                   (on the x side; en_convs.1: the wide side, where a
+//                                                                         position meets taps of one parity only -- the other
+//                                                                         taps enter as zero operands)
+// dx may ACCUMULATE (en_convs.1: on top of the skip gradient of en_outs[0]) and carry the NEXT unit's riding reduction.
+constexpr int C15_TF = 8, C15_NW = 33 + 2, C15_WW = 65 + 4;        // narrow rows: pads -1, 33; wide rows: pads -2, -1, 65, 66
+constexpr int C15_NIMG = C15_TF * C15_NW * 16, C15_WIMG = C15_TF * C15_WW * 16;
+template <bool DYW, int FX, int FY, int NEXT>      // NEXT: 0 none, 1 + storage format of that unit's y
+__global__ __launch_bounds__(NT) void k_conv15_bwd(ConvGeom g, const float* __restrict__ x, const float* __restrict__ y,
+                                                  const float* __restrict__ da, BnBwdArgs bn,
+                                                  const float* __restrict__ w, float* __restrict__ dx, int dx_acc,
+                                                  float* __restrict__ wpartial, NextRedArgs nx,
+                                                  double* __restrict__ rpartial, int tiles_t) {
+    __shared__ __attribute__((aligned(16))) float sN[C15_NIMG];      // narrow side: column 1 + fn
+    __shared__ __attribute__((aligned(16))) float sWd[C15_WIMG];     // wide side: column 2 + fw
+    __shared__ __attribute__((aligned(16))) float sWa[5 * 256];      // [kf][ci][co]: A fragments of the data gradient
+    __shared__ double sRed[NEXT ? NT / 64 : 1][48];
+    __shared__ float sB[NT / 64][16];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, n = lane & 15, q = lane >> 4, qs = tid & 3;
+    for (int i = tid; i < 5 * 256; i += NT) {
+        const int kf = i >> 8, ci = (i >> 4) & 15, co = i & 15;
+        sWa[i] = w[co * g.w_co + ci * g.w_ci + kf * g.w_kf];
+    }
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+    for (int i = tid; i < C15_TF * 2 * 4; i += NT) {                 // narrow pads
+        const int qq = i & 3, side = (i >> 2) & 1, r = i >> 3;
+        *reinterpret_cast<f32x4*>(sN + (r * C15_NW + side * 34) * 16 + 4 * qq) = zero;
+    }
+    for (int i = tid; i < C15_TF * 4 * 4; i += NT) {                 // wide pads: columns 0, 1, 67, 68
+        const int qq = i & 3, c4 = (i >> 2) & 3, r = i >> 4;
+        *reinterpret_cast<f32x4*>(sWd + (r * C15_WW + (c4 < 2 ? c4 : 65 + c4)) * 16 + 4 * qq) = zero;
+    }
+    const f32x4 mean = *reinterpret_cast<const f32x4*>(bn.stats + 4 * qs), istd = *reinterpret_cast<const f32x4*>(bn.stats + 16 + 4 * qs);
+    const f32x4 gm = *reinterpret_cast<const f32x4*>(bn.gamma + 4 * qs), bt = *reinterpret_cast<const f32x4*>(bn.beta + 4 * qs);
+    const f32x4 m1 = *reinterpret_cast<const f32x4*>(bn.red + 4 * qs), m2 = *reinterpret_cast<const f32x4*>(bn.red + 16 + 4 * qs);
+    const float sl = bn.slope[0];
+    NextConst nk{};
+    if constexpr (NEXT != 0) nk = next_const(nx, 4 * q);
+    float vr[3][4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) vr[0][e] = vr[1][e] = vr[2][e] = 0.f;
+    f32x4 accW[5];
+#pragma unroll
+    for (int i = 0; i < 5; ++i) accW[i] = zero;
+    f32x4 bq = zero;                                                 // bias gradient of the staging quad
+    float* sDyI = DYW ? sWd : sN;                                    // dy lives on the wide side for de_convs.3
+    float* sXI = DYW ? sN : sWd;
+    constexpr int FD = DYW ? 65 : 33, FXB = DYW ? 33 : 65;           // bins of dy / of x (and dx)
+    constexpr int CD = DYW ? C15_WW : C15_NW, CX = DYW ? C15_NW : C15_WW, OD = DYW ? 2 : 1, OX = DYW ? 1 : 2;
+    const int T = g.Tout;                                            // (Tin == Tout)
+    const long ntiles = (long)g.B * tiles_t;
+    for (long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int b = (int)(tile / tiles_t), t0 = (int)(tile - (long)b * tiles_t) * C15_TF;
+        const int nrow = T - t0 < C15_TF ? T - t0 : C15_TF;
+        __syncthreads();
+        // ---- stage 1: dy (from da, y) and x of the tile's frames; rows past the utterance's end are zero
+        for (int it0 = tid; it0 < C15_TF * FD * 4; it0 += 2 * NT) {
+            typename Raw4<FY>::t yr[2];
+            f32x4 gr[2];
+            int rec[2];
+            bool ok[2], live[2];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int it = it0 + j * NT;
+                live[j] = it < C15_TF * FD * 4;
+                const int pos = (live[j] ? it : 0) >> 2, r = pos / FD, f = pos - r * FD;
+                ok[j] = r < nrow;
+                const long p = ((long)b * T + t0 + (ok[j] ? r : 0)) * FD + f;
+                yr[j] = sld4_raw<FY, true>(y, p * 16 + 4 * qs);
+                gr[j] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(da + p * 16 + 4 * qs));
+                rec[j] = (r * CD + OD + f) * 16 + 4 * qs;
+            }
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const f32x4 yv = dec4<FY>(yr[j]);
+                f32x4 dyv;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float xh = (yv[e] - mean[e]) * istd[e];
+                    const float z = gm[e] * xh + bt[e];
+                    const float dz = z > 0.f ? gr[j][e] : sl * gr[j][e];
+                    dyv[e] = gm[e] * istd[e] * (dz - m1[e] - xh * m2[e]);
+                }
+                if (live[j]) {
+                    *reinterpret_cast<f32x4*>(sDyI + rec[j]) = ok[j] ? dyv : zero;
+                    if (ok[j]) bq = bq + dyv;
+                }
+            }
+        }
+        for (int it0 = tid; it0 < C15_TF * FXB * 4; it0 += 2 * NT) {
+            typename Raw4<FX>::t xr[2];
+            int rec[2];
+            bool ok[2], live[2];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int it = it0 + j * NT;
+                live[j] = it < C15_TF * FXB * 4;
+                const int pos = (live[j] ? it : 0) >> 2, r = pos / FXB, f = pos - r * FXB;
+                ok[j] = r < nrow;
+                const long p = ((long)b * T + t0 + (ok[j] ? r : 0)) * FXB + f;
+                xr[j] = sld4_raw<FX, true>(x, p * 16 + 4 * qs);
+                rec[j] = (r * CX + OX + f) * 16 + 4 * qs;
+            }
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+                if (live[j]) *reinterpret_cast<f32x4*>(sXI + rec[j]) = ok[j] ? dec4<FX>(xr[j]) : zero;
+        }
+        __syncthreads();
+        // ---- stage 2a: weight gradient over the narrow positions (lane (c = n, k = q): channel c of positions 4u + k)
+        const int ownn = nrow * 33;
+        for (int nt = wv; nt * 16 < ownn; nt += NT / 64) {
+            float av[4], bv[4][5];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int pu = nt * 16 + 4 * u + q, pc = pu < ownn ? pu : 0, r = pc / 33, fn = pc - r * 33;
+                const float nar = sN[(r * C15_NW + 1 + fn) * 16 + n];
+                av[u] = pu < ownn ? nar : 0.f;
+                const float* wq = sWd + (r * C15_WW + 2 * fn) * 16 + n;            // wide bin 2 fn - 2 + kf at column 2 fn + kf
+#pragma unroll
+                for (int kf = 0; kf < 5; ++kf) bv[u][kf] = wq[kf * 16];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int kf = 0; kf < 5; ++kf) {
+                    // D[co][ci]: the A operand carries dy, the B operand x
+                    if constexpr (DYW) accW[kf] = mfma4(bv[u][kf], av[u], accW[kf]);
+                    else accW[kf] = mfma4(av[u], bv[u][kf], accW[kf]);
+                }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        // ---- stage 2b: data gradient over the positions of x (lane (n, q): input channels 4q .. 4q + 3)
+        const int ownx = nrow * FXB;
+        for (int nt = wv; nt * 16 < ownx; nt += NT / 64) {
+            const int pl = nt * 16 + n, pc = pl < ownx ? pl : 0, r = pc / FXB, f = pc - r * FXB;
+            const long gp = ((long)b * T + t0 + r) * FXB + f;
+            typename Raw4<(NEXT ? NEXT - 1 : 0)>::t ynr{};
+            if constexpr (NEXT != 0) ynr = sld4_raw<(NEXT ? NEXT - 1 : 0), true>(nx.y, gp * 16 + 4 * q);
+            f32x4 old = zero;
+            if (dx_acc) old = *reinterpret_cast<const f32x4*>(dx + gp * 16 + 4 * q);
+            f32x4 acc = zero;
+#pragma unroll
+            for (int kf = 0; kf < 5; ++kf) {
+                const f32x4 A = *reinterpret_cast<const f32x4*>(sWa + kf * 256 + n * 16 + 4 * q);
+                f32x4 Bv;
+                if constexpr (DYW) {                     // x narrow, dy wide: dx[fn] = sum_kf W[kf]^T dy[2 fn - 2 + kf]
+                    Bv = *reinterpret_cast<const f32x4*>(sWd + (r * C15_WW + 2 * f + kf) * 16 + 4 * q);
+                } else {                                  // x wide, dy narrow: fn = (fw + 2 - kf) / 2 for the taps of fw's parity
+                    const int num = f + 2 - kf;
+                    const f32x4 v = *reinterpret_cast<const f32x4*>(sN + (r * C15_NW + 1 + (num >> 1)) * 16 + 4 * q);
+                    Bv = (num & 1) ? zero : v;
+                }
+#pragma unroll
+                for (int s2 = 0; s2 < 4; ++s2) acc = mfma4(A[s2], Bv[s2], acc);
+            }
+            if (pl < ownx) {
+                acc = acc + old;
+                sst4<kNtSt>(dx, gp * 16 + 4 * q, 0, acc);
+                if constexpr (NEXT != 0) next_accum(nk, dec4<(NEXT ? NEXT - 1 : 0)>(ynr), acc, vr);
+            }
+        }
+    }
+    __syncthreads();                                                 // the images are dead: the accumulators go there
+    static_assert((NT / 64) * (5 * 256) <= C15_WIMG, "accumulator tiles fit in the wide image");
+    float* my = sWd + wv * (5 * 256);
+#pragma unroll
+    for (int kf = 0; kf < 5; ++kf)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) my[kf * 256 + (4 * q + r) * 16 + n] = accW[kf][r];
+    // bias gradient: the staging quads' sums of dy (thread quad qs; lanes with equal qs differ in the other lane bits)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        float t = bq[e];
+        t += __shfl_xor(t, 4, 64); t += __shfl_xor(t, 8, 64); t += __shfl_xor(t, 16, 64); t += __shfl_xor(t, 32, 64);
+        if (lane < 4) sB[wv][4 * lane + e] = t;
+    }
+    __syncthreads();
+    float* pp = wpartial + (long)blockIdx.x * (5 * 256 + 16);
+    for (int i = tid; i < 5 * 256; i += NT) {
+        float t = 0.f;
+#pragma unroll
+        for (int w2 = 0; w2 < NT / 64; ++w2) t += sWd[w2 * (5 * 256) + i];
+        pp[i] = t;
+    }
+    if (tid < 16) {
+        float t = 0.f;
+        for (int w2 = 0; w2 < NT / 64; ++w2) t += sB[w2][tid];
+        pp[5 * 256 + tid] = t;
+    }
+    if constexpr (NEXT != 0) {
+#pragma unroll
+        for (int k3 = 0; k3 < 3; ++k3)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const double t = wave_sum_xor((double)vr[k3][e], 1, 8);
+                if (n == 0) sRed[wv][k3 * 16 + 4 * q + e] = t;
+            }
+        __syncthreads();
+        if (tid < 48) {
+            double t = 0.0;
+            for (int w2 = 0; w2 < NT / 64; ++w2) t += sRed[w2][tid];
+            rpartial[(long)blockIdx.x * 48 + tid] = t;
+        }
+    }
+}
+
 // --------------------------------------------------------------------------- features, mask
 // GTCRNMicro.forward prologue + ERB.bm (models/gtcrn_micro.py:510-516, :63-67): one thread per (b,t,j)
 // first / one-past-last non-zero entry of each of the `rows` rows (stride rs, element stride es) of a filterbank
@@ -3464,6 +3679,42 @@ int dense33_bwd(const ConvGeom& g, const float* x, const float* y, const float* 
     else { if (xr) GT_D9(1, true, true, 5); else if (nxt) GT_D9(1, true, false, 2); else GT_D9(1, false, false, 3); }
 #undef GT_D9
     const int K = 9 * 256 + 16;
+    hipLaunchKernelGGL(k_wgrad_mfma_finish, dim3((K + 63) / 64), dim3(1024), 0, s, g, fscratch, grid, dw, dbias);
+    if (nxt && next_parts) *next_parts = grid;
+    return check();
+}
+
+int conv15_bwd(const ConvGeom& g, const float* x, const float* y, const float* da, const float* stats,
+               const float* gamma, const float* beta, const float* slope, const float* w, float* dx, int dx_acc,
+               float* dw, float* dbias, float* dgamma, float* dbeta, float* dslope, double* dscratch, float* fscratch,
+               hipStream_t s, int bf, int ybf, const DwUnitNext* next, int* next_parts, int have_parts) {
+    if (next_parts) *next_parts = 0;
+    const bool dyw = g.f_mode == 1;
+    if (g.nkt != 1 || g.nkf != 5 || g.t_off[0] != 0 || g.sf != 2 || g.pf != 2 || g.Cin != 16 || g.CinT != 16 || g.cin_off != 0 ||
+        g.Cout != 16 || g.CoutT != 16 || g.cout_off != 0 || g.Tin != g.Tout || g.Fin != (dyw ? 33 : 65) || g.Fout != (dyw ? 65 : 33) ||
+        !slope || !dx || !x || bf > 1 || ybf > 1 || bf != ybf || (next && dyw))
+        return (int)hipErrorInvalidValue;
+    const long n = (long)g.B * g.Tout * g.Fout, total = n * 16;
+    float* red = reinterpret_cast<float*>(dscratch + (long)MAX_PARTIALS * 3 * 16);
+    const int rgrid = have_parts > 0 ? have_parts : red_grid(total / 4);
+    if (have_parts <= 0)
+        launch_bn_bwd_reduce4(rgrid, s, da, y, total, 16, stats, gamma, beta, nullptr, ACT_PRELU, slope, dscratch, bf, ybf);
+    hipLaunchKernelGGL(k_bn_bwd_finish, dim3(1), dim3(1024), 0, s, dscratch, rgrid, n, 16, red, dgamma, dbeta, dslope);
+    const int tiles_t = (g.Tout + C15_TF - 1) / C15_TF;
+    const long ntiles = (long)g.B * tiles_t;
+    const int grid = (int)(ntiles < 512 ? ntiles : 512);           // 61 KB of LDS: two workgroups per CU, all resident
+    BnBwdArgs bn{stats, gamma, beta, slope, red, ACT_PRELU};
+    NextRedArgs nx{};
+    const bool nxt = next && next->slope && !next->res;
+    if (nxt) nx = NextRedArgs{next->y, next->stats, next->gamma, next->beta, next->slope, nullptr, 0, ybf};
+#define GT_C15(DW_, F, NXV)                                                                                             \
+    hipLaunchKernelGGL((k_conv15_bwd<DW_, F, F, NXV>), dim3(grid), dim3(NT), 0, s, g, x, y, da, bn, w, dx, dx_acc, fscratch, nx, \
+                       dscratch, tiles_t)
+    if (dyw) { if (bf == 0) GT_C15(true, 0, 0); else GT_C15(true, 1, 0); }
+    else if (nxt) { if (bf == 0) GT_C15(false, 0, 1); else GT_C15(false, 1, 2); }
+    else { if (bf == 0) GT_C15(false, 0, 0); else GT_C15(false, 1, 0); }
+#undef GT_C15
+    const int K = 5 * 256 + 16;
     hipLaunchKernelGGL(k_wgrad_mfma_finish, dim3((K + 63) / 64), dim3(1024), 0, s, g, fscratch, grid, dw, dbias);
     if (nxt && next_parts) *next_parts = grid;
     return check();

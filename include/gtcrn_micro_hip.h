@@ -253,7 +253,8 @@ long gtcrn_train_workspace_bytes2(int B, int T, int storage);
  * point_conv1 (six blocks) and en_convs.0 ride in the adjoint conv that produces their gradient input.  bit 6: the
  * backward of the encoder's depthwise 3x3 unit (dy, weight gradient, data gradient) in one LDS-tiled pass.  bit 7: the
  * same for the decoder's dense transposed 3x3 unit (both matrix products from LDS images of dy and x).  bit 8 (needs bit
- * 0): point_conv1's BatchNorm + PReLU applied by LDS-tiled depth convs while they stage their input tile.
+ * 0): point_conv1's BatchNorm + PReLU applied by LDS-tiled depth convs while they stage their input tile.  bit 9: the
+ * backward of the two 16 -> 16 (1,5) stride-2 units (en_convs.1, de_convs.3) from LDS tiles.
  * 0 runs the layer-at-a-time passes (tests/test_gpu_train.py compares them).  Takes effect at the next forward; not
  * part of the reference's interface. */
 int gtcrn_trainer_set_fusions(gtcrn_trainer *t, int mask);
