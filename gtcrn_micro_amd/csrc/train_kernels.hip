@@ -2485,25 +2485,29 @@ __global__ __launch_bounds__(NT) void k_conv15_bwd(ConvGeom g, const float* __re
         const int b = (int)(tile / tiles_t), t0 = (int)(tile - (long)b * tiles_t) * C15_TF;
         const int nrow = T - t0 < C15_TF ? T - t0 : C15_TF;
         __syncthreads();
-        // ---- stage 1: dy (from da, y) and x of the tile's frames; rows past the utterance's end are zero
-        for (int it0 = tid; it0 < C15_TF * FD * 4; it0 += 2 * NT) {
-            typename Raw4<FY>::t yr[2];
-            f32x4 gr[2];
-            int rec[2];
-            bool ok[2], live[2];
+        // ---- stage 1: dy (from da, y) and x of the tile's frames; rows past the utterance's end are zero.  EVERY load of the
+        //      tile is issued before the first is used (two items per trip were six exposed round trips per tile)
+        {
+            constexpr int ND = (C15_TF * FD * 4 + NT - 1) / NT, NX = (C15_TF * FXB * 4 + NT - 1) / NT;
+            typename Raw4<FY>::t yr[ND];
+            f32x4 gr[ND];
+            typename Raw4<FX>::t xr[NX];
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const int it = it0 + j * NT;
-                live[j] = it < C15_TF * FD * 4;
-                const int pos = (live[j] ? it : 0) >> 2, r = pos / FD, f = pos - r * FD;
-                ok[j] = r < nrow;
-                const long p = ((long)b * T + t0 + (ok[j] ? r : 0)) * FD + f;
+            for (int j = 0; j < ND; ++j) {
+                const int it = tid + j * NT, pos = (it < C15_TF * FD * 4 ? it : 0) >> 2, r = pos / FD, f = pos - r * FD;
+                const long p = ((long)b * T + t0 + (r < nrow ? r : 0)) * FD + f;
                 yr[j] = sld4_raw<FY, true>(y, p * 16 + 4 * qs);
                 gr[j] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(da + p * 16 + 4 * qs));
-                rec[j] = (r * CD + OD + f) * 16 + 4 * qs;
             }
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
+            for (int j = 0; j < NX; ++j) {
+                const int it = tid + j * NT, pos = (it < C15_TF * FXB * 4 ? it : 0) >> 2, r = pos / FXB, f = pos - r * FXB;
+                const long p = ((long)b * T + t0 + (r < nrow ? r : 0)) * FXB + f;
+                xr[j] = sld4_raw<FX, true>(x, p * 16 + 4 * qs);
+            }
+#pragma unroll
+            for (int j = 0; j < ND; ++j) {
+                const int it = tid + j * NT, pos = (it < C15_TF * FD * 4 ? it : 0) >> 2, r = pos / FD, f = pos - r * FD;
                 const f32x4 yv = dec4<FY>(yr[j]);
                 f32x4 dyv;
 #pragma unroll
@@ -2513,29 +2517,17 @@ __global__ __launch_bounds__(NT) void k_conv15_bwd(ConvGeom g, const float* __re
                     const float dz = z > 0.f ? gr[j][e] : sl * gr[j][e];
                     dyv[e] = gm[e] * istd[e] * (dz - m1[e] - xh * m2[e]);
                 }
-                if (live[j]) {
-                    *reinterpret_cast<f32x4*>(sDyI + rec[j]) = ok[j] ? dyv : zero;
-                    if (ok[j]) bq = bq + dyv;
+                if (it < C15_TF * FD * 4) {
+                    *reinterpret_cast<f32x4*>(sDyI + (r * CD + OD + f) * 16 + 4 * qs) = r < nrow ? dyv : zero;
+                    if (r < nrow) bq = bq + dyv;
                 }
             }
-        }
-        for (int it0 = tid; it0 < C15_TF * FXB * 4; it0 += 2 * NT) {
-            typename Raw4<FX>::t xr[2];
-            int rec[2];
-            bool ok[2], live[2];
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const int it = it0 + j * NT;
-                live[j] = it < C15_TF * FXB * 4;
-                const int pos = (live[j] ? it : 0) >> 2, r = pos / FXB, f = pos - r * FXB;
-                ok[j] = r < nrow;
-                const long p = ((long)b * T + t0 + (ok[j] ? r : 0)) * FXB + f;
-                xr[j] = sld4_raw<FX, true>(x, p * 16 + 4 * qs);
-                rec[j] = (r * CX + OX + f) * 16 + 4 * qs;
+            for (int j = 0; j < NX; ++j) {
+                const int it = tid + j * NT, pos = (it < C15_TF * FXB * 4 ? it : 0) >> 2, r = pos / FXB, f = pos - r * FXB;
+                if (it < C15_TF * FXB * 4)
+                    *reinterpret_cast<f32x4*>(sXI + (r * CX + OX + f) * 16 + 4 * qs) = r < nrow ? dec4<FX>(xr[j]) : zero;
             }
-#pragma unroll
-            for (int j = 0; j < 2; ++j)
-                if (live[j]) *reinterpret_cast<f32x4*>(sXI + rec[j]) = ok[j] ? dec4<FX>(xr[j]) : zero;
         }
         __syncthreads();
         // ---- stage 2a: weight gradient over the narrow positions (lane (c = n, k = q): channel c of positions 4u + k)
