@@ -2310,31 +2310,43 @@ __global__ __launch_bounds__(NT) void k_dense33_bwd(ConvGeom g, const float* __r
         const int b = (int)(tile / tiles_t), t0 = (int)(tile - (long)b * tiles_t) * D9_TF;
         __syncthreads();                                             // the previous tile's readers are done
         // ---- stage 1: dy of frames t0 .. t0 + D9_ROWS - 1, x of frames t0 - 2 .. t0 + D9_ROWS - 3 (zero outside the tensors)
-        for (int it = tid; it < D9_ROWS * 33 * 4; it += NT) {        // (NT % 4 == 0: the item's quad is qs)
-            const int pos = it >> 2, r = pos / 33, f = pos - r * 33;
-            const int td = t0 + r, tx = t0 - 2 + r;
-            const bool okd = td < T2, okx = tx >= 0 && tx < T;
-            const long pd = ((long)b * T2 + (okd ? td : 0)) * 33 + f, px = ((long)b * T + (okx ? tx : 0)) * 33 + f;
-            const typename Raw4<FY>::t yr = sld4_raw<FY, true>(y, pd * 16 + 4 * qs);
-            const f32x4 gr = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(da + pd * 16 + 4 * qs));
-            typename Raw4<FX>::t xr{};
-            typename Raw4<FY>::t xyr{};
-            if constexpr (XR) xyr = sld4_raw<FY, true>(nx.y, px * 16 + 4 * qs);
-            else xr = sld4_raw<FX, true>(x, px * 16 + 4 * qs);
-            const f32x4 yv = dec4<FY>(yr);
-            f32x4 dyv;
+        {   // (every load of the tile first: one item at a time the fill was a chain of exposed round trips)
+            constexpr int ITEMS = D9_ROWS * 33 * 4, NI = (ITEMS + NT - 1) / NT;      // (NT % 4 == 0: every item's quad is qs)
+            typename Raw4<FY>::t yr[NI];
+            f32x4 gr[NI];
+            typename Raw4<FX>::t xr[NI];
+            typename Raw4<FY>::t xyr[NI];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const float xh = (yv[e] - mean[e]) * istd[e];
-                const float z = gm[e] * xh + bt[e];
-                const float dz = z > 0.f ? gr[e] : sl * gr[e];
-                dyv[e] = gm[e] * istd[e] * (dz - m1[e] - xh * m2[e]);
+            for (int j = 0; j < NI; ++j) {
+                const int it = tid + j * NT, pos = (it < ITEMS ? it : 0) >> 2, r = pos / 33, f = pos - r * 33;
+                const int td = t0 + r, tx = t0 - 2 + r;
+                const long pd = ((long)b * T2 + (td < T2 ? td : 0)) * 33 + f, px = ((long)b * T + ((tx >= 0 && tx < T) ? tx : 0)) * 33 + f;
+                yr[j] = sld4_raw<FY, true>(y, pd * 16 + 4 * qs);
+                gr[j] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(da + pd * 16 + 4 * qs));
+                if constexpr (XR) xyr[j] = sld4_raw<FY, true>(nx.y, px * 16 + 4 * qs);
+                else xr[j] = sld4_raw<FX, true>(x, px * 16 + 4 * qs);
             }
-            *reinterpret_cast<f32x4*>(sDy + (r * 35 + 1 + f) * 16 + 4 * qs) = okd ? dyv : zero;
-            f32x4 xval;
-            if constexpr (XR) xval = next_act(nks, dec4<FY>(xyr), nx.xround);
-            else xval = dec4<FX>(xr);
-            *reinterpret_cast<f32x4*>(sXi + (r * 35 + 1 + f) * 16 + 4 * qs) = okx ? xval : zero;
+#pragma unroll
+            for (int j = 0; j < NI; ++j) {
+                const int it = tid + j * NT, pos = (it < ITEMS ? it : 0) >> 2, r = pos / 33, f = pos - r * 33;
+                const int td = t0 + r, tx = t0 - 2 + r;
+                const f32x4 yv = dec4<FY>(yr[j]);
+                f32x4 dyv;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float xh = (yv[e] - mean[e]) * istd[e];
+                    const float z = gm[e] * xh + bt[e];
+                    const float dz = z > 0.f ? gr[j][e] : sl * gr[j][e];
+                    dyv[e] = gm[e] * istd[e] * (dz - m1[e] - xh * m2[e]);
+                }
+                f32x4 xval;
+                if constexpr (XR) xval = next_act(nks, dec4<FY>(xyr[j]), nx.xround);
+                else xval = dec4<FX>(xr[j]);
+                if (it < ITEMS) {
+                    *reinterpret_cast<f32x4*>(sDy + (r * 35 + 1 + f) * 16 + 4 * qs) = td < T2 ? dyv : zero;
+                    *reinterpret_cast<f32x4*>(sXi + (r * 35 + 1 + f) * 16 + 4 * qs) = (tx >= 0 && tx < T) ? xval : zero;
+                }
+            }
         }
         __syncthreads();
         // ---- stage 2: 16-position tiles of the D9_TF x 33 owned positions, one wave each
