@@ -1963,7 +1963,8 @@ template <int FIN, int NTH>
 __device__ __forceinline__ void stage_pre_tile(float* img, const float* __restrict__ in, const BnPre& pre, const PreConst& pk, int b,
                                                int t0, int T, int tid, int q) {
     const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
-    constexpr int ITEMS = F33_ROWS * 33 * 4, UN = 3;
+    // (every load of the tile is issued before the first is used: UN covers the tile in one trip)
+    constexpr int ITEMS = F33_ROWS * 33 * 4, UN = (ITEMS + NTH - 1) / NTH;
     for (int it0 = tid; it0 < ITEMS; it0 += UN * NTH) {              // (NTH % 4 == 0: every item's quad is q)
         typename Raw4<FIN>::t yr[UN];
         long idx[UN];
