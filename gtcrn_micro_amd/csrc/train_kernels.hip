@@ -3147,14 +3147,21 @@ __global__ void k_sisnr_coef(const double* __restrict__ part, int chunks, int B,
         coef[2 * b] = (float)(c0 * (-2.0 * num / (den * den)));
         coef[2 * b + 1] = (float)(c0 * (2.0 * al * kap / den + 2.0 * num * (al + eta) / (den * den)));
     }
-    // the last step needs every utterance's value: a single-block launch keeps it simple (B <= 1024 per block)
+    // the last step needs every utterance's value: a single-block launch keeps it simple (B <= 1024 per block).  Every
+    // thread takes a strided share of the spectral partials and its own utterance's value, then a fixed-order tree in LDS
+    // (one thread walking ~2 500 values one dependent load at a time took 157 us of every step)
+    if (gridDim.x != 1) return;
+    __shared__ double sh[3][1024];
+    const int t = threadIdx.x, nth = blockDim.x;
+    double sri = 0.0, smag = 0.0;
+    for (int w = t; w < spec_parts; w += nth) { sri += spec_partial[2 * w]; smag += spec_partial[2 * w + 1]; }
+    sh[0][t] = sri; sh[1][t] = smag; sh[2][t] = b < B ? vals[b] : 0.0;       // (vals[b]: this thread's own store above)
     __syncthreads();
-    if (blockIdx.x == 0 && threadIdx.x == 0 && gridDim.x == 1) {
-        double sri = 0.0, smag = 0.0, ss = 0.0;
-        for (int w = 0; w < spec_parts; ++w) { sri += spec_partial[2 * w]; smag += spec_partial[2 * w + 1]; }
-        for (int i = 0; i < B; ++i) ss += vals[i];
-        loss[0] = (float)(30.0 * sri / (double)N + 70.0 * smag / (double)N + ss / B);
+    for (int h = nth >> 1; h >= 1; h >>= 1) {                                 // (nth is a power of two: 1024)
+        if (t < h) { sh[0][t] += sh[0][t + h]; sh[1][t] += sh[1][t + h]; sh[2][t] += sh[2][t + h]; }
+        __syncthreads();
     }
+    if (t == 0) loss[0] = (float)(30.0 * sh[0][0] / (double)N + 70.0 * sh[1][0] / (double)N + sh[2][0] / B);
 }
 // gwave = (A_b yp + B_b yt) / envelope, envelope[j] = win[j & 255]^2 + win[256 + (j & 255)]^2 (k_istft divides by it)
 __global__ __launch_bounds__(NT) void k_sisnr_gwave(float* __restrict__ yp, const float* __restrict__ yt, long Lw,
