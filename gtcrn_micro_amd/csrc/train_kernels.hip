@@ -710,6 +710,7 @@ __global__ __launch_bounds__(NT, 4) void k_conv_win_fma(ConvGeom g, const float*
             raw[v] = sldw_raw<FIN>(in, inside[v] ? base + 4 * v : 0L);
         }
         float x[16];
+        bool slow = false;
 #pragma unroll
         for (int v = 0; v < 4; ++v) {
             const f32x4 d = dec4<FIN>(raw[v]);
@@ -718,7 +719,15 @@ __global__ __launch_bounds__(NT, 4) void k_conv_win_fma(ConvGeom g, const float*
                 const int j = 4 * v + s;
                 const bool ok = j < J && e0 + j >= 0 && e0 + j < rowlen;
                 x[j] = (ok && inside[v]) ? d[s] : 0.f;
-                if (ok && !inside[v]) x[j] = sld1(in, base + j, FIN);       // first / last position of the tensor only
+                slow = slow || (ok && !inside[v]);
+            }
+        }
+        if (slow) {      // a window that leaves the tensor: the first / last position of the whole tensor only -- ONE branch
+                         // (an `if` per element put each of the sixteen in a basic block of its own: 82 exec-mask regions)
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const bool ok = j < J && e0 + j >= 0 && e0 + j < rowlen;
+                if (ok && !inside[j >> 2]) x[j] = sld1(in, base + j, FIN);
             }
         }
         f32x4 acc = bv;
