@@ -2784,15 +2784,34 @@ __global__ __launch_bounds__(NT) void k_feat_t(const float* __restrict__ spec, l
                 re = x[(long)j * sf]; im = x[(long)j * sf + 1];
                 m = sqrtf(re * re + im * im + 1e-12f);
             } else {
+                // a band's bins are requested TOGETHER (up to BW; a band of the shipped bank has at most 11), then the
+                // multiply-adds in ascending-bin order: one bin per trip behind `if (w != 0)` was a chain of dependent
+                // round trips (415 us at 1.4 TB/s).  Bins past the band's end load a valid bin and meet a zero weight
+                // (m + 0 * x: the same value for finite input, and what the reference's dense matmul computes).
+                constexpr int BW = 12;
                 const float* w = erb_w + (long)(j - 65) * 192;
-                for (int i = lo[j - 65]; i < hi[j - 65]; ++i) {
+                const int l0 = lo[j - 65], h0 = hi[j - 65];
+                float2 xv[BW];
+                float wv[BW];
+#pragma unroll
+                for (int u = 0; u < BW; ++u) {
+                    const int i = l0 + u < 192 ? l0 + u : 191;
+                    xv[u] = *reinterpret_cast<const float2*>(x + (long)(65 + i) * sf);
+                    wv[u] = l0 + u < h0 ? w[i] : 0.f;
+                }
+#pragma unroll
+                for (int u = 0; u < BW; ++u) {
+                    const float rr = xv[u].x, q = xv[u].y;
+                    m = fmaf(wv[u], sqrtf(rr * rr + q * q + 1e-12f), m);
+                    re = fmaf(wv[u], rr, re);
+                    im = fmaf(wv[u], q, im);
+                }
+                for (int i = l0 + BW; i < h0; ++i) {              // (a wider band of some other bank)
                     const float wi = w[i];
-                    if (wi != 0.f) {
-                        const float rr = x[(long)(65 + i) * sf], q = x[(long)(65 + i) * sf + 1];
-                        m = fmaf(wi, sqrtf(rr * rr + q * q + 1e-12f), m);
-                        re = fmaf(wi, rr, re);
-                        im = fmaf(wi, q, im);
-                    }
+                    const float rr = x[(long)(65 + i) * sf], q = x[(long)(65 + i) * sf + 1];
+                    m = fmaf(wi, sqrtf(rr * rr + q * q + 1e-12f), m);
+                    re = fmaf(wi, rr, re);
+                    im = fmaf(wi, q, im);
                 }
             }
             tile[tl][j * 3] = m; tile[tl][j * 3 + 1] = re; tile[tl][j * 3 + 2] = im;
@@ -2822,24 +2841,36 @@ __global__ __launch_bounds__(NT) void k_bs_mask_t(const float* __restrict__ m, c
     const float* xr = spec + (long)b * sb + (long)(t0 + tl) * st;
     float* orow = out + (long)b * ob + (long)(t0 + tl) * ot;
     const float* mt = sm[tl];
-    for (int f = r; f < 257; f += NT / TT) {
-        float m0 = 0.f, m1 = 0.f;
-        if (f < 65) {
-            m0 = mt[f * 2]; m1 = mt[f * 2 + 1];
-        } else {
-            const float* w = ierb_w + (long)(f - 65) * 64;
-            for (int j = lo[f - 65]; j < hi[f - 65]; ++j) {
-                const float wj = w[j];
-                if (wj != 0.f) {
-                    m0 = fmaf(wj, mt[(65 + j) * 2], m0);
-                    m1 = fmaf(wj, mt[(65 + j) * 2 + 1], m1);
+    // (the spectrogram values of eight of the thread's bins are requested together: one bin per trip was 33 dependent
+    // round trips per thread)
+    constexpr int RS_ = NT / TT, UB = 8;
+    for (int f0 = r; f0 < 257; f0 += UB * RS_) {
+        float2 xv[UB];
+#pragma unroll
+        for (int u = 0; u < UB; ++u) {
+            const int f = f0 + u * RS_;
+            xv[u] = *reinterpret_cast<const float2*>(xr + (long)(f < 257 ? f : 0) * sf);
+        }
+#pragma unroll
+        for (int u = 0; u < UB; ++u) {
+            const int f = f0 + u * RS_;
+            if (f >= 257) break;
+            float m0 = 0.f, m1 = 0.f;
+            if (f < 65) {
+                m0 = mt[f * 2]; m1 = mt[f * 2 + 1];
+            } else {
+                const float* w = ierb_w + (long)(f - 65) * 64;
+                for (int j = lo[f - 65]; j < hi[f - 65]; ++j) {
+                    const float wj = w[j];
+                    if (wj != 0.f) {
+                        m0 = fmaf(wj, mt[(65 + j) * 2], m0);
+                        m1 = fmaf(wj, mt[(65 + j) * 2 + 1], m1);
+                    }
                 }
             }
+            float* o = orow + (long)f * of;
+            *reinterpret_cast<float2*>(o) = make_float2(xv[u].x * m0 - xv[u].y * m1, xv[u].y * m0 + xv[u].x * m1);
         }
-        const float* x = xr + (long)f * sf;
-        float* o = orow + (long)f * of;
-        o[0] = x[0] * m0 - x[1] * m1;
-        o[1] = x[1] * m0 + x[0] * m1;
     }
 }
 
@@ -2862,14 +2893,28 @@ __global__ __launch_bounds__(NT) void k_bs_mask_bwd_t(const float* __restrict__ 
                 g0 = dr * re + di * im;
                 g1 = di * re - dr * im;
             } else {
-                for (int i = lo[j - 65]; i < hi[j - 65]; ++i) {
+                constexpr int BW = 12;                              // (see k_feat_t)
+                const int l0 = lo[j - 65], h0 = hi[j - 65];
+                float2 xv[BW], dv[BW];
+                float wv[BW];
+#pragma unroll
+                for (int u = 0; u < BW; ++u) {
+                    const int i = l0 + u < 192 ? l0 + u : 191;
+                    xv[u] = *reinterpret_cast<const float2*>(x + (long)(65 + i) * sf);
+                    dv[u] = *reinterpret_cast<const float2*>(d + (long)(65 + i) * of);
+                    wv[u] = l0 + u < h0 ? ierb_w[(long)i * 64 + (j - 65)] : 0.f;
+                }
+#pragma unroll
+                for (int u = 0; u < BW; ++u) {
+                    g0 = fmaf(wv[u], dv[u].x * xv[u].x + dv[u].y * xv[u].y, g0);
+                    g1 = fmaf(wv[u], dv[u].y * xv[u].x - dv[u].x * xv[u].y, g1);
+                }
+                for (int i = l0 + BW; i < h0; ++i) {
                     const float wi = ierb_w[(long)i * 64 + (j - 65)];
-                    if (wi != 0.f) {
-                        const int f = 65 + i;
-                        const float re = x[(long)f * sf], im = x[(long)f * sf + 1], dr = d[(long)f * of], di = d[(long)f * of + 1];
-                        g0 = fmaf(wi, dr * re + di * im, g0);
-                        g1 = fmaf(wi, di * re - dr * im, g1);
-                    }
+                    const int f = 65 + i;
+                    const float re = x[(long)f * sf], im = x[(long)f * sf + 1], dr = d[(long)f * of], di = d[(long)f * of + 1];
+                    g0 = fmaf(wi, dr * re + di * im, g0);
+                    g1 = fmaf(wi, di * re - dr * im, g1);
                 }
             }
             sd[tl][j * 2] = g0; sd[tl][j * 2 + 1] = g1;
@@ -3794,8 +3839,12 @@ int unit1x1_bwd(const ConvGeom& g, const float* x, const float* y, const float* 
 
 int feat_fwd(const float* spec, long sb, long sf, long st, int B, int T, const float* erb_w, float* eb,
              hipStream_t s, int bf, float* eb2, int eb2_bf) {
-    // frame axis fastest (torch.stft's layout): tiles of TT frames, lanes along t
-    if ((st < 0 ? -st : st) < (sf < 0 ? -sf : sf))
+    // frame axis fastest (torch.stft's layout): tiles of TT frames, lanes along t (8-byte (re, im) accesses: even strides
+    // and an 8-byte aligned base, which is what a complex tensor viewed as real has; anything else takes the generic form)
+    auto pair_ok = [](const float* p, long a, long b2, long c) {
+        return ((a | b2 | c) & 1) == 0 && (reinterpret_cast<uintptr_t>(p) & 7) == 0;
+    };
+    if ((st < 0 ? -st : st) < (sf < 0 ? -sf : sf) && pair_ok(spec, sb, sf, st))
         hipLaunchKernelGGL(k_feat_t, dim3(B * ((T + TT - 1) / TT)), dim3(NT), 0, s, spec, sb, sf, st, B, T, erb_w, eb, bf,
                            eb2, eb2_bf);
     else
@@ -3806,7 +3855,10 @@ int feat_fwd(const float* spec, long sb, long sf, long st, int B, int T, const f
 int bs_mask_fwd(const float* m, const float* spec, long sb, long sf, long st, int B, int T, const float* ierb_w,
                 float* out, long ob, long of, long ot, hipStream_t s, int bf) {
     auto ab = [](long v) { return v < 0 ? -v : v; };
-    if (ab(st) < ab(sf) && ab(ot) < ab(of))
+    auto pair_ok = [](const float* p, long a, long b2, long c) {
+        return ((a | b2 | c) & 1) == 0 && (reinterpret_cast<uintptr_t>(p) & 7) == 0;
+    };
+    if (ab(st) < ab(sf) && ab(ot) < ab(of) && pair_ok(spec, sb, sf, st) && pair_ok(out, ob, of, ot))
         hipLaunchKernelGGL(k_bs_mask_t, dim3(B * ((T + TT - 1) / TT)), dim3(NT), 0, s, m, spec, sb, sf, st, B, T, ierb_w,
                            out, ob, of, ot, bf);
     else
@@ -3817,7 +3869,10 @@ int bs_mask_fwd(const float* m, const float* spec, long sb, long sf, long st, in
 int bs_mask_bwd(const float* dout, long ob, long of, long ot, const float* spec, long sb, long sf, long st, int B,
                 int T, const float* ierb_w, float* dm, hipStream_t s) {
     auto ab = [](long v) { return v < 0 ? -v : v; };
-    if (ab(st) < ab(sf) && ab(ot) < ab(of))
+    auto pair_ok = [](const float* p, long a, long b2, long c) {
+        return ((a | b2 | c) & 1) == 0 && (reinterpret_cast<uintptr_t>(p) & 7) == 0;
+    };
+    if (ab(st) < ab(sf) && ab(ot) < ab(of) && pair_ok(spec, sb, sf, st) && pair_ok(dout, ob, of, ot))
         hipLaunchKernelGGL(k_bs_mask_bwd_t, dim3(B * ((T + TT - 1) / TT)), dim3(NT), 0, s, dout, ob, of, ot, spec, sb, sf,
                            st, B, T, ierb_w, dm);
     else
