@@ -103,6 +103,7 @@ def lib():
     L.gtcrn_train_backward.argtypes = [_vp, _vp, _vp, cl, cl, cl, _vp, cl, cl, cl, _vp, _vp]
     L.gtcrn_train_tap.argtypes = [_vp, ctypes.c_char_p, _vp, ctypes.POINTER(cl), _vp]
     L.gtcrn_train_loss.argtypes = [_vp, _vp, cl, cl, cl, _vp, cl, cl, cl, ci, ci, _vp, _vp, _vp]
+    L.gtcrn_train_loss_strided.argtypes = [_vp, _vp, cl, cl, cl, _vp, cl, cl, cl, ci, ci, _vp, _vp, cl, cl, cl, _vp]
     if L.gtcrn_abi_version() != 1:
         raise GtcrnError("libgtcrn_micro_hip.so ABI version mismatch")
     _lib = L
@@ -171,6 +172,21 @@ def _spec_strides(t):
     return t.stride(0), t.stride(1), t.stride(2)
 
 
+def empty_spec(B, T, device, frame_major=False):
+    """An uninitialised (B,257,T,2) float32 spectrogram.  frame_major: the memory is (B,T,257,2) -- a frame's 257 bins are
+    one 2 KB row, which is how every kernel of this library walks a spectrogram -- viewed in the reference's shape."""
+    import torch
+    if frame_major:
+        return torch.empty((B, T, NBINS, 2), device=device, dtype=torch.float32).permute(0, 2, 1, 3)
+    return torch.empty((B, NBINS, T, 2), device=device, dtype=torch.float32)
+
+
+def _empty_spec_like(t):
+    """A new spectrogram with the shape of t and t's memory order (frame-major stays frame-major)."""
+    B, _, T, _ = t.shape
+    return empty_spec(B, T, t.device, frame_major=abs(t.stride(2)) > abs(t.stride(1)))
+
+
 def _require_cuda_f32(t, what):
     import torch
     if not isinstance(t, torch.Tensor) or not t.is_cuda:
@@ -179,8 +195,9 @@ def _require_cuda_f32(t, what):
         raise GtcrnError(f"{what} must be float32")
 
 
-def stft(wave, window, out=None):
-    """torch.stft(x,512,256,512,window,return_complex=False) on the GPU: (B,L) or (L,) -> (B,257,T,2)/(257,T,2)."""
+def stft(wave, window, out=None, frame_major=False):
+    """torch.stft(x,512,256,512,window,return_complex=False) on the GPU: (B,L) or (L,) -> (B,257,T,2)/(257,T,2).
+    frame_major: see empty_spec (same shape and values, the library's preferred memory order)."""
     import torch
     _require_cuda_f32(wave, "wave")
     squeeze = wave.dim() == 1
@@ -191,7 +208,7 @@ def stft(wave, window, out=None):
         raise GtcrnError("reflect padding needs more than 256 samples")
     T = num_frames(L)
     win = window.to(device=wave.device, dtype=torch.float32).contiguous()
-    spec = out if out is not None else torch.empty((B, NBINS, T, 2), device=wave.device, dtype=torch.float32)
+    spec = out if out is not None else empty_spec(B, T, wave.device, frame_major)
     sb, sf, st = _spec_strides(spec)
     with torch.cuda.device(wave.device):
         _check(lib().gtcrn_stft(w2.data_ptr(), B, L, win.data_ptr(), spec.data_ptr(), sb, sf, st, _stream_ptr()))
@@ -605,7 +622,7 @@ class Trainer:
             spec = spec.contiguous()
         B, _, T, _ = spec.shape
         if out is None:
-            out = torch.empty((B, NBINS, T, 2), device=spec.device, dtype=torch.float32)
+            out = _empty_spec_like(spec)
         isb, isf, ist = _spec_strides(spec)
         osb, osf, ost = _spec_strides(out)
         with torch.cuda.device(self.device):
@@ -645,12 +662,14 @@ class Trainer:
             true = true.contiguous()
         B, _, T, _ = pred.shape
         loss = torch.empty((), device=pred.device, dtype=torch.float32)
-        grad = torch.empty((B, NBINS, T, 2), device=pred.device, dtype=torch.float32) if want_grad else None
+        grad = _empty_spec_like(pred) if want_grad else None      # (the gradient takes pred's memory order)
         psb, psf, pst = _spec_strides(pred)
         tsb, tsf, tst = _spec_strides(true)
+        gsb, gsf, gst = _spec_strides(grad) if want_grad else (0, 0, 0)
         with torch.cuda.device(self.device):
-            _check(lib().gtcrn_train_loss(self._h, pred.data_ptr(), psb, psf, pst, true.data_ptr(), tsb, tsf, tst, B, T,
-                                          loss.data_ptr(), grad.data_ptr() if want_grad else None, _stream_ptr()))
+            _check(lib().gtcrn_train_loss_strided(self._h, pred.data_ptr(), psb, psf, pst, true.data_ptr(), tsb, tsf, tst,
+                                                  B, T, loss.data_ptr(), grad.data_ptr() if want_grad else None,
+                                                  gsb, gsf, gst, _stream_ptr()))
         return loss, grad
 
     def tap(self, name):

@@ -986,11 +986,21 @@ int gtcrn_train_backward(gtcrn_trainer* t, const float* d_params, const float* d
 
 int gtcrn_train_loss(gtcrn_trainer* t, const float* d_pred, long pb, long pf, long pt, const float* d_true, long tb,
                      long tf, long tt, int B, int T, float* d_loss, float* d_grad, void* stream) {
+    // d_grad contiguous (B,257,T,2): strides (257*T*2, T*2, 2)
+    return gtcrn_train_loss_strided(t, d_pred, pb, pf, pt, d_true, tb, tf, tt, B, T, d_loss, d_grad, 257L * T * 2, (long)T * 2, 2,
+                                    stream);
+}
+
+int gtcrn_train_loss_strided(gtcrn_trainer* t, const float* d_pred, long pb, long pf, long pt, const float* d_true, long tb,
+                             long tf, long tt, int B, int T, float* d_loss, float* d_grad, long gb, long gf, long gt,
+                             void* stream) {
     if (!t || !d_pred || !d_true || !d_loss || B < 1 || B > 1024 || T < 2)
         return tfail(GTCRN_ERR_ARG, "gtcrn_train_loss: bad argument (needs 1 <= B <= 1024 utterances, T >= 2 frames)");
     if (((pb | pf | pt | tb | tf | tt) & 1) || (reinterpret_cast<uintptr_t>(d_pred) & 7) ||
         (reinterpret_cast<uintptr_t>(d_true) & 7))
         return tfail(GTCRN_ERR_ARG, "gtcrn_train_loss: spectrograms must be 8-byte aligned with even strides");
+    if (d_grad && (((gb | gf | gt) & 1) || (reinterpret_cast<uintptr_t>(d_grad) & 7)))
+        return tfail(GTCRN_ERR_ARG, "gtcrn_train_loss: the gradient must be 8-byte aligned with even strides");
     T_HIP(hipSetDevice(t->device));
     hipStream_t s = (hipStream_t)stream;
     const long Lw = 256L * (T - 1);
@@ -1016,13 +1026,12 @@ int gtcrn_train_loss(gtcrn_trainer* t, const float* d_pred, long pb, long pf, lo
     double* spec_partial = t->dscratch;                      // <= MAX_PARTIALS * 2 doubles
     double* dwork = t->dscratch + 2 * gtt::MAX_PARTIALS;     // B * 25 doubles
     int parts = 0;
-    T_RUN(gtt::hybrid_loss_spec(d_pred, pb, pf, pt, d_true, tb, tf, tt, B, T, d_grad, spec_partial, &parts, s));
+    T_RUN(gtt::hybrid_loss_spec(d_pred, pb, pf, pt, d_true, tb, tf, tt, B, T, d_grad, gb, gf, gt, spec_partial, &parts, s));
     T_RUN(gtk::launch_istft(d_pred, pb, pf, pt, B, T, nullptr, t->d_win, tw, yp, s));
     T_RUN(gtk::launch_istft(d_true, tb, tf, tt, B, T, nullptr, t->d_win, tw, yt, s));
     T_RUN(gtt::sisnr_terms(yp, yt, B, Lw, spec_partial, parts, (long)B * 257 * T, t->d_win, dwork, coef, d_loss,
                            d_grad != nullptr, s));
-    if (d_grad)   // d_grad is contiguous (B,257,T,2): strides (257*T*2, T*2, 2)
-        T_RUN(gtk::launch_istft_adjoint(yp, B, T, t->d_win, tw, d_grad, 257L * T * 2, (long)T * 2, 2, s));
+    if (d_grad) T_RUN(gtk::launch_istft_adjoint(yp, B, T, t->d_win, tw, d_grad, gb, gf, gt, s));
     return 0;
 }
 

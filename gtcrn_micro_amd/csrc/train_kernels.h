@@ -196,7 +196,7 @@ int tra_gate_shuffle_bwd(const float* dout, const float* v, const float* g, cons
 // waveforms, the SI-SNR term, the closed loss value (loss[0]) and, if want_grad, yp := d loss / d yp already
 // divided by the iSTFT envelope (input of the iSTFT adjoint).  dwork: B * 25 doubles, coef: 2 * B floats.
 int hybrid_loss_spec(const float* pred, long pb, long pf, long pt, const float* tru, long tb, long tf, long tt, int B,
-                     int T, float* grad, double* partial, int* parts, hipStream_t s);
+                     int T, float* grad, long gb, long gf, long gt, double* partial, int* parts, hipStream_t s);
 int sisnr_terms(float* yp, const float* yt, int B, long Lw, const double* spec_partial, int spec_parts, long N,
                 const float* win, double* dwork, float* coef, float* loss, int want_grad, hipStream_t s);
 

@@ -3116,17 +3116,27 @@ __global__ __launch_bounds__(1024) void k_tra_pgrad(const float* __restrict__ dz
 // terms in one pass over (B,257,T); the SI-SNR term needs three sums per utterance (k_sisnr_sums), from which
 // its gradient w.r.t. the predicted waveform is A_b * y_pred + B_b * y_true (k_sisnr_coef, k_sisnr_gwave);
 // the iSTFT adjoint (kernels.hip, k_stft<true>) carries it back to the spectrogram.
+// FMAJ: the elements are walked bin-fastest (frame-major spectrograms: st > sf), otherwise frame-fastest (torch.stft's layout)
+template <bool FMAJ>
 __global__ __launch_bounds__(NT) void k_hloss_spec(const float* __restrict__ pred, long pb, long pf, long pt,
                                                   const float* __restrict__ tru, long tb, long tf, long tt, int B,
-                                                  int T, float* __restrict__ grad, double* __restrict__ partial) {
+                                                  int T, float* __restrict__ grad, long gb, long gf, long gt,
+                                                  double* __restrict__ partial) {
     __shared__ double sh[NT];
     const long N = (long)B * 257 * T;
     const float kri = 60.0f / (float)N, kmag = 140.0f / (float)N;
     double sri = 0.0, smag = 0.0;
     for (long i = (long)blockIdx.x * NT + threadIdx.x; i < N; i += (long)gridDim.x * NT) {
-        const int t = (int)(i % T);
-        const long bf = i / T;
-        const int f = (int)(bf % 257), b = (int)(bf / 257);
+        int t, f, b;
+        if constexpr (FMAJ) {
+            f = (int)(i % 257);
+            const long bt = i / 257;
+            t = (int)(bt % T); b = (int)(bt / T);
+        } else {
+            t = (int)(i % T);
+            const long bf = i / T;
+            f = (int)(bf % 257); b = (int)(bf / 257);
+        }
         const float2 p = *reinterpret_cast<const float2*>(pred + (long)b * pb + (long)f * pf + (long)t * pt);
         const float2 q = *reinterpret_cast<const float2*>(tru + (long)b * tb + (long)f * tf + (long)t * tt);
         const float pm2 = p.x * p.x + p.y * p.y + 1e-12f, tm2 = q.x * q.x + q.y * q.y + 1e-12f;
@@ -3140,7 +3150,7 @@ __global__ __launch_bounds__(NT) void k_hloss_spec(const float* __restrict__ pre
             const float inv = 1.0f / pm2, w = 0.7f * u * inv;
             const float a_r = u - w * p.x * p.x, a_i = -w * p.x * p.y, b_i = u - w * p.y * p.y;
             const float cw = 0.3f * c * inv;
-            *reinterpret_cast<float2*>(grad + i * 2) =
+            *reinterpret_cast<float2*>(grad + (long)b * gb + (long)f * gf + (long)t * gt) =
                 make_float2(kri * (da * a_r + db * a_i) + kmag * dc * cw * p.x,
                             kri * (da * a_i + db * b_i) + kmag * dc * cw * p.y);
         }
@@ -3914,9 +3924,14 @@ int tra_gate_shuffle_bwd(const float* dout, const float* v, const float* g, cons
 }
 
 int hybrid_loss_spec(const float* pred, long pb, long pf, long pt, const float* tru, long tb, long tf, long tt, int B,
-                     int T, float* grad, double* partial, int* parts, hipStream_t s) {
+                     int T, float* grad, long gb, long gf, long gt, double* partial, int* parts, hipStream_t s) {
     const int grid = red_grid((long)B * 257 * T);
-    hipLaunchKernelGGL(k_hloss_spec, dim3(grid), dim3(NT), 0, s, pred, pb, pf, pt, tru, tb, tf, tt, B, T, grad, partial);
+    if ((pt < 0 ? -pt : pt) > (pf < 0 ? -pf : pf))
+        hipLaunchKernelGGL(k_hloss_spec<true>, dim3(grid), dim3(NT), 0, s, pred, pb, pf, pt, tru, tb, tf, tt, B, T, grad, gb, gf, gt,
+                           partial);
+    else
+        hipLaunchKernelGGL(k_hloss_spec<false>, dim3(grid), dim3(NT), 0, s, pred, pb, pf, pt, tru, tb, tf, tt, B, T, grad, gb, gf, gt,
+                           partial);
     *parts = grid;
     return check();
 }

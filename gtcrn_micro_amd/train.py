@@ -192,8 +192,10 @@ def train_step(model, optimizer, scheduler, loss_func, noisy, clean, clip_grad_n
         # DDP semantics (broadcast_buffers=True): the buffers follow rank 0 at the start of every forward, so the
         # running statistics a rank holds are rank 0's of the previous step plus its own update of this step
         exchange(lambda: broadcast_buffers(model))
-    noisy_spec = _lib.stft(noisy, win)
-    clean_spec = _lib.stft(clean, win)
+    # (B,257,T,2)-shaped like torch.stft's, in the library's frame-major memory order: the model output and the loss gradient
+    # follow the input's order, so every kernel of the step walks whole 2 KB frames
+    noisy_spec = _lib.stft(noisy, win, frame_major=True)
+    clean_spec = _lib.stft(clean, win, frame_major=True)
     enhanced = model(noisy_spec)
     loss = loss_func(enhanced, clean_spec)
     optimizer.zero_grad()

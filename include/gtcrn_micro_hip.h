@@ -269,6 +269,12 @@ int gtcrn_train_backward(gtcrn_trainer *t, const float *d_params, const float *d
  * `loss = self.loss_func(enhanced, clean_spec)` and the loss part of `loss.backward()` (train.py:267, 280). */
 int gtcrn_train_loss(gtcrn_trainer *t, const float *d_pred, long pb, long pf, long pt, const float *d_true, long tb,
                      long tf, long tt, int B, int T, float *d_loss, float *d_grad, void *stream);
+/* The same with the gradient addressed by strides (gb, gf, gt) like the spectrograms: a caller that keeps its
+ * spectrograms frame-major -- (B,257,T,2)-shaped views of (B,T,257,2) memory, which every kernel of the step then reads
+ * and writes in 2 KB rows -- gets the gradient in that layout too. */
+int gtcrn_train_loss_strided(gtcrn_trainer *t, const float *d_pred, long pb, long pf, long pt, const float *d_true,
+                             long tb, long tf, long tt, int B, int T, float *d_loss, float *d_grad, long gb, long gf,
+                             long gt, void *stream);
 /* Test hook: train-mode activation of the most recent forward at a stage boundary (en0..en4, gtcn1,
  * gtcn2, de0..de4), channels-last (B, T, F, C) in the reference's channel order; shape4 receives
  * the four extents; d_out may be NULL to query the shape. */
