@@ -75,8 +75,8 @@ STREAM_STATE_BYTES_PER_FRAME = 94 * 1024        # ring-state traff
 # (round 4: every storage mode, dispatch by dispatch.  The x2 on FETCH_SIZE is calibrated for 16-byte-per-lane reads; the
 # 16-bit tensors are read 8 bytes per lane, for which the guide gives no factor: for the two 16-bit modes the figure
 # below is the UPPER reading, `traffic_lower` the raw one -- the truth lies between)
-TRAIN_HBM_BYTES_PER_STEP = {"f32": 134.3e9, "bf16": 94.3e9, "bf16_saves": 127.3e9}
-TRAIN_HBM_BYTES_PER_STEP_LOWER = {"f32": 134.3e9, "bf16": 62.7e9, "bf16_saves": 89.4e9}
+TRAIN_HBM_BYTES_PER_STEP = {"f32": 131.4e9, "bf16": 91.4e9, "bf16_saves": 124.5e9}
+TRAIN_HBM_BYTES_PER_STEP_LOWER = {"f32": 131.4e9, "bf16": 60.9e9, "bf16_saves": 87.6e9}
 TRAIN_HBM_SOURCE = {m: "profiles/r04_train_hbm_traffic.json" for m in ("f32", "bf16", "bf16_saves")}
 ROUND_TAG = "r04"
 WATCHDOG_EXIT_CODE = 3                                  # exit status of every rank when a watchdog had to cut a leg

@@ -11,7 +11,8 @@
 #   ub_*       tools/ubench_mfma_valu.hip (does fp32 MFMA overlap with fp32 VALU?) under the same counters
 #   stream / train             kernel trace + stats of the configs[2] / configs[3] legs; train_pmc_*: HBM counters of the
 #                              fp32 train step
-# tools/profile_summary.py condenses them into the files committed under profiles/.
+# tools/profile_summary.py condenses them into the files committed under profiles/ (it takes the NEWEST file of a pass:
+# copy gpurun_out/<tag> with `cp -a`, a plain `cp -r` resets the modification times and the choice becomes arbitrary).
 # Second argument: which sections to run -- all (default), headline, stream, train.
 set -u
 TAG=${1:-r04}
