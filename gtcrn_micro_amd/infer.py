@@ -90,10 +90,39 @@ def merge_scp(enh_dir, world):
                     out.write(f.read())
 
 
+def _finish_clip(y_row, item, enh_dir):
+    """Length-match one enhanced row to its clean reference (infer.py:98-102), write it, return its scp entry."""
+    wav_name, _, ref_path, n_clean, L = item
+    yj = y_row[:256 * (L // 256)]
+    if yj.shape[0] < n_clean:
+        yj = np.pad(yj, (0, n_clean - yj.shape[0]), mode="constant")
+    elif yj.shape[0] > n_clean:
+        yj = yj[:n_clean]
+    uid = wav_name.split(".wav")[0]
+    enh_path = os.path.join(enh_dir, uid + "_enh.wav")
+    write_wav_pcm16(enh_path, yj)
+    return uid, enh_path, ref_path
+
+
 def _enhance_shard(noisy_dir, clean_dir, enh_dir, checkpoint, device=0, max_batch=64, rank=0, world=1,
-                   barrier=None):
+                   barrier=None, pipeline=True, stats=None, stages=3):
     """barrier: a callable all ranks call once their lists are written (multi-GPU runs; main() passes
-    torch.distributed.barrier); rank 0 then merges the per-rank scp files."""
+    torch.distributed.barrier); rank 0 then merges the per-rank scp files.
+
+    pipeline=True (default): the shard runs as a three-stage pipeline over `stages` staging slots, each a pinned host
+    input buffer, a device input / output pair and a pinned host output buffer:
+      reader thread   wav files -> float32 rows of slot k's pinned input buffer (zero tails)
+      launch thread   (the caller's) H2D on a copy-in HIP stream, the six kernels on the compute stream, D2H on a
+                      copy-out stream -- all asynchronous, ordered by events; batch k+1 uploads while k computes
+      writer thread   waits for slot k's D2H event, length-matches and writes the 16-bit files, frees the slot
+    so disk reads, PCIe both ways, the kernels and disk writes of different batches overlap.  The batches and the
+    kernels are the ones of the serial form (pipeline=False: read -> pageable copy -> kernels -> copy back -> write, one
+    batch after the other, what round 4 shipped), so every output file is bit-identical between the two.
+    stats (optional dict) receives: clips, frames, wall_s, frames_per_s, gpu_busy_frac (device time of the kernel
+    sequences / wall time, from events), h2d_bytes, d2h_bytes."""
+    import queue
+    import threading
+    import time
     import warnings
 
     import torch
@@ -113,37 +142,152 @@ def _enhance_shard(noisy_dir, clean_dir, enh_dir, checkpoint, device=0, max_batc
         path, ref_path, n_clean = _clip_info(noisy_dir, clean_dir, wav_name)
         fs, x = wavfile.read(path, mmap=True)
         if fs != 16000:
-            raise AssertionError(f"{path}: sample rate {fs} != 16000 (resampling is not part of this path)")
+            raise AssertionError(f"{path}: sample rate {fs} != 16000 (resampling is not part of this path: the "
+                                 "reference resamples with librosa, infer.py:54-57; resample the folder first)")
         if x.shape[0] < MIN_SAMPLES:
             warnings.warn(f"{path}: {x.shape[0]} samples < {MIN_SAMPLES}, cannot be reflect-padded: skipped")
             continue
         items.append((wav_name, path, ref_path, n_clean, int(x.shape[0])))
     # pass 2: batches of similar lengths, each through one launch sequence, written as soon as it is done
     order = sorted(range(len(items)), key=lambda i: items[i][4])
+    batches = [order[k:k + max_batch] for k in range(0, len(order), max_batch)]
     rows = {}
-    for k in range(0, len(order), max_batch):
-        sel = order[k:k + max_batch]
-        waves = [read_wav_f32(items[i][1])[1] for i in sel]
-        lens = [len(w) for w in waves]
-        Lmax = max(lens)
-        if min(lens) == Lmax:
-            y = eng.forward_wave(torch.from_numpy(np.stack(waves)).to(dev), win).cpu().numpy()
-        else:
-            host = np.zeros((len(sel), Lmax), np.float32)
-            for j, w in enumerate(waves):
-                host[j, :len(w)] = w
-            y = eng.forward_wave_var(torch.from_numpy(host).to(dev), lens, win).cpu().numpy()
-        for j, i in enumerate(sel):
-            wav_name, _, ref_path, n_clean, L = items[i]
-            yj = y[j, :256 * (L // 256)]
-            if yj.shape[0] < n_clean:                               # infer.py:98-102
-                yj = np.pad(yj, (0, n_clean - yj.shape[0]), mode="constant")
-            elif yj.shape[0] > n_clean:
-                yj = yj[:n_clean]
-            uid = wav_name.split(".wav")[0]
-            enh_path = os.path.join(enh_dir, uid + "_enh.wav")
-            write_wav_pcm16(enh_path, yj)
-            rows[i] = (uid, enh_path, ref_path)
+    t_start = time.perf_counter()
+    frames = sum(1 + items[i][4] // 256 for i in order)
+    busy_ms = 0.0
+    nbytes = [0, 0]
+
+    if not pipeline or not batches:
+        for sel in batches:
+            waves = [read_wav_f32(items[i][1])[1] for i in sel]
+            lens = [len(w) for w in waves]
+            Lmax = max(lens)
+            if min(lens) == Lmax:
+                y = eng.forward_wave(torch.from_numpy(np.stack(waves)).to(dev), win).cpu().numpy()
+            else:
+                host = np.zeros((len(sel), Lmax), np.float32)
+                for j, w in enumerate(waves):
+                    host[j, :len(w)] = w
+                y = eng.forward_wave_var(torch.from_numpy(host).to(dev), lens, win).cpu().numpy()
+            nbytes[0] += 4 * len(sel) * Lmax
+            nbytes[1] += 4 * y.size
+            for j, i in enumerate(sel):
+                rows[i] = _finish_clip(y[j], items[i], enh_dir)
+    else:
+        # ---- staging slots: capacity = the largest batch (clips x longest clip) of this shard
+        cap = max(len(sel) * max(items[i][4] for i in sel) for sel in batches)
+        nslot = max(1, min(int(stages), len(batches)))
+        with torch.cuda.device(device):
+            slots = [{"hin": torch.empty(cap, dtype=torch.float32, pin_memory=True),
+                      "hout": torch.empty(cap, dtype=torch.float32, pin_memory=True),
+                      "din": torch.empty(cap, dtype=torch.float32, device=dev),
+                      "dout": torch.empty(cap, dtype=torch.float32, device=dev)} for _ in range(nslot)]
+            s_in, s_cmp, s_out = torch.cuda.Stream(), torch.cuda.Stream(), torch.cuda.Stream()
+        free = threading.Semaphore(nslot)
+        q_read, q_write = queue.Queue(), queue.Queue()
+        abort = threading.Event()
+        errors = []
+
+        def reader():
+            try:
+                for k, sel in enumerate(batches):
+                    while not free.acquire(timeout=0.2):
+                        if abort.is_set():
+                            return
+                    if abort.is_set():
+                        return
+                    lens = [items[i][4] for i in sel]
+                    Lmax = max(lens)
+                    hin = slots[k % nslot]["hin"].numpy()[:len(sel) * Lmax].reshape(len(sel), Lmax)
+                    for j, i in enumerate(sel):
+                        w = read_wav_f32(items[i][1])[1]
+                        if len(w) != lens[j]:
+                            raise RuntimeError(f"{items[i][1]} changed length while the folder was being enhanced")
+                        hin[j, :len(w)] = w
+                        hin[j, len(w):] = 0.0
+                    q_read.put((k, sel, lens, Lmax))
+            except Exception as e:
+                errors.append(e)
+                abort.set()
+            finally:
+                q_read.put(None)
+
+        def writer():
+            try:
+                while True:
+                    job = q_write.get()
+                    if job is None:
+                        return
+                    k, sel, Lout, ev_done, ev_a, ev_b = job
+                    ev_done.synchronize()
+                    y = slots[k % nslot]["hout"].numpy()[:len(sel) * Lout].reshape(len(sel), Lout)
+                    for j, i in enumerate(sel):
+                        rows[i] = _finish_clip(y[j], items[i], enh_dir)
+                    busy.append(ev_a.elapsed_time(ev_b))
+                    free.release()
+            except Exception as e:
+                errors.append(e)
+                abort.set()
+
+        busy = []
+        th_r = threading.Thread(target=reader, name="gtcrn-folder-reader", daemon=True)
+        th_w = threading.Thread(target=writer, name="gtcrn-folder-writer", daemon=True)
+        th_r.start()
+        th_w.start()
+        try:
+            with torch.cuda.device(device):
+                while not abort.is_set():
+                    try:
+                        job = q_read.get(timeout=0.2)
+                    except queue.Empty:
+                        continue
+                    if job is None:
+                        break
+                    k, sel, lens, Lmax = job
+                    sl = slots[k % nslot]
+                    n, Lout = len(sel), 256 * (Lmax // 256)
+                    x = sl["din"][:n * Lmax].view(n, Lmax)
+                    y = sl["dout"][:n * Lout].view(n, Lout)
+                    with torch.cuda.stream(s_in):
+                        x.copy_(sl["hin"][:n * Lmax].view(n, Lmax), non_blocking=True)
+                        ev_in = torch.cuda.Event()
+                        ev_in.record()
+                    with torch.cuda.stream(s_cmp):
+                        s_cmp.wait_event(ev_in)
+                        ev_a, ev_b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                        ev_a.record()
+                        if min(lens) == Lmax:
+                            eng.forward_wave(x, win, out=y)
+                        else:
+                            eng.forward_wave_var(x, lens, win, out=y)
+                        ev_b.record()
+                    with torch.cuda.stream(s_out):
+                        s_out.wait_event(ev_b)
+                        sl["hout"][:n * Lout].view(n, Lout).copy_(y, non_blocking=True)
+                        ev_done = torch.cuda.Event()
+                        ev_done.record()
+                    nbytes[0] += 4 * n * Lmax
+                    nbytes[1] += 4 * n * Lout
+                    q_write.put((k, sel, Lout, ev_done, ev_a, ev_b))
+        except Exception as e:
+            errors.append(e)
+            abort.set()
+        finally:
+            q_write.put(None)
+            th_w.join()
+            if errors:
+                abort.set()
+            th_r.join()
+            torch.cuda.synchronize(device)
+        if errors:
+            raise errors[0]
+        busy_ms = float(sum(busy))
+    wall = time.perf_counter() - t_start
+    if stats is not None:
+        stats.update({"clips": len(items), "batches": len(batches), "frames": int(frames), "wall_s": wall,
+                      "frames_per_s": frames / wall if wall > 0 else 0.0,
+                      "gpu_busy_frac": (busy_ms * 1e-3 / wall) if (pipeline and wall > 0) else None,
+                      "h2d_bytes": nbytes[0], "d2h_bytes": nbytes[1], "pipeline": bool(pipeline)})
     inf_scp = [(rows[i][0], rows[i][1]) for i in range(len(items))]   # sorted file order, like the reference
     ref_scp = [(rows[i][0], rows[i][2]) for i in range(len(items))]
     suffix = "" if world == 1 else f".rank{rank}"
@@ -155,7 +299,7 @@ def _enhance_shard(noisy_dir, clean_dir, enh_dir, checkpoint, device=0, max_batc
 
 
 def enhance_folder(noisy_dir, clean_dir, enh_dir, checkpoint, device=0, max_batch=64, rank=0, world=1, barrier=None,
-                   agree=None):
+                   agree=None, pipeline=True, stats=None):
     """Counterpart of infer.py:26-119 for a folder (see ``_enhance_shard``): every rank enhances its contiguous shard of
     the sorted file list, then rank 0 merges the per-rank scp lists.
 
@@ -167,7 +311,8 @@ def enhance_folder(noisy_dir, clean_dir, enh_dir, checkpoint, device=0, max_batc
     err = None
     result = None
     try:
-        result = _enhance_shard(noisy_dir, clean_dir, enh_dir, checkpoint, device, max_batch, rank, world, barrier)
+        result = _enhance_shard(noisy_dir, clean_dir, enh_dir, checkpoint, device, max_batch, rank, world, barrier,
+                                pipeline=pipeline, stats=stats)
     except Exception as e:           # re-raised below, after the exchange.  NOT BaseException: a KeyboardInterrupt or
         err = e                      # SystemExit must leave at once instead of waiting in a collective first
     all_ok = err is None
@@ -193,6 +338,9 @@ def main(argv=None):
     ap.add_argument("--checkpoint", required=True, help="reference .tar checkpoint or raw fp32 blob (.f32)")
     ap.add_argument("-D", "--device", default=None, help="GPU index (default: LOCAL_RANK or 0)")
     ap.add_argument("--max-batch", type=int, default=64)
+    ap.add_argument("--serial", action="store_true",
+                    help="one batch after the other with pageable copies (the A/B of the pipelined default)")
+    ap.add_argument("--stats", action="store_true", help="print this rank's throughput / GPU-busy figures as JSON")
     a = ap.parse_args(argv)
     from .sharding import rank_world
     rank, local_rank, world = rank_world()
@@ -215,7 +363,12 @@ def main(argv=None):
             dist.all_reduce(flag, op=dist.ReduceOp.MIN)
             return bool(flag.item())
     try:
-        enhance_folder(a.noisy_dir, a.clean_dir, a.enh_dir, a.checkpoint, dev, a.max_batch, rank, world, barrier, agree)
+        st = {} if a.stats else None
+        enhance_folder(a.noisy_dir, a.clean_dir, a.enh_dir, a.checkpoint, dev, a.max_batch, rank, world, barrier, agree,
+                       pipeline=not a.serial, stats=st)
+        if st is not None:
+            import json
+            print(json.dumps({"rank": rank, **st}), flush=True)
     finally:
         if world > 1:
             dist.destroy_process_group()

@@ -389,6 +389,14 @@ class GTCRNMicro(nn.Module):
             if torch.is_grad_enabled():
                 return _TrainStep.apply(spec, self, *self._train_params)
             return _TrainStep.forward(_NoCtx(), spec, self)
+        # .eval(): the fused inference kernels have no backward.  The reference's module would build a graph here when
+        # grad mode is on; a caller that asks for the INPUT gradient gets an error instead of a tensor that silently
+        # has no grad_fn.  (Parameters that require grad do not trigger it: the reference's own causality test calls
+        # the eval-mode model outside no_grad, tests/models/test_gtcrn_micro.py:7-24 -- INTEGRATION.md section 5.)
+        if torch.is_grad_enabled() and spec.requires_grad:
+            raise _lib.GtcrnError("GTCRNMicro.forward in .eval() mode cannot be differentiated (the fused inference "
+                                  "kernels keep no activations): call .train() for a backward pass, or detach the "
+                                  "input / use torch.no_grad() for inference")
         return self.engine(spec.device).forward_spec(spec)
 
 

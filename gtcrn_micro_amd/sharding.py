@@ -58,3 +58,97 @@ def sum_over_ranks(value, device="cpu"):
     t = torch.tensor([float(value)], dtype=torch.float64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.SUM)
     return float(t.item())
+
+
+# ---- rank -> NUMA node of its GPU ------------------------------------------------------------------------------
+# An 8-GPU MI355X node has two sockets with four GPUs behind each; a rank whose host thread (launches, pinned staging
+# buffers, the folder driver's reader / writer threads) runs on the other socket pays a cross-socket hop per launch and
+# per staged byte.  torchrun does not bind; the reference's mp.spawn (train.py:461-471) does not either.  This binds the
+# calling process to the CPUs of its GPU's NUMA node from sysfs alone -- it must run BEFORE torch / HIP are imported
+# (threads created earlier keep their old mask) and never re-executes anything.
+
+def _read(path):
+    try:
+        with open(path) as f:
+            return f.read().strip()
+    except OSError:
+        return None
+
+
+def parse_cpulist(text):
+    """'0-3,8,10-11' -> [0,1,2,3,8,10,11] (the kernel's cpulist format)."""
+    cpus = []
+    for part in (text or "").split(","):
+        part = part.strip()
+        if not part:
+            continue
+        if "-" in part:
+            lo, hi = part.split("-", 1)
+            cpus.extend(range(int(lo), int(hi) + 1))
+        else:
+            cpus.append(int(part))
+    return cpus
+
+
+def gpu_numa_nodes(sysfs_root="/"):
+    """NUMA node of every GPU in HIP enumeration order: the KFD topology lists the nodes in the order the runtime
+    enumerates them (CPU nodes have no `drm_render_minor`), and the render node's PCI device carries `numa_node`.
+    [] when the topology is not readable (no GPU, container without /sys/class/kfd)."""
+    base = os.path.join(sysfs_root, "sys/class/kfd/kfd/topology/nodes")
+    try:
+        nodes = sorted((int(n) for n in os.listdir(base) if n.isdigit()))
+    except OSError:
+        return []
+    out = []
+    for n in nodes:
+        props = _read(os.path.join(base, str(n), "properties")) or ""
+        kv = dict(line.split(None, 1) for line in props.splitlines() if len(line.split(None, 1)) == 2)
+        minor = int(kv.get("drm_render_minor", "0") or 0)
+        if int(kv.get("simd_count", "0") or 0) == 0 or minor <= 0:
+            continue                                           # a CPU node
+        numa = _read(os.path.join(sysfs_root, f"sys/class/drm/renderD{minor}/device/numa_node"))
+        out.append(int(numa) if numa not in (None, "") else -1)
+    return out
+
+
+def _visible_index(local_rank):
+    """The physical GPU index behind `local_rank` when HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES / CUDA_VISIBLE_DEVICES
+    hold a numeric list (the launcher's usual form); otherwise local_rank itself."""
+    for var in ("HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES"):
+        v = os.environ.get(var)
+        if v:
+            items = [x.strip() for x in v.split(",") if x.strip()]
+            if all(x.isdigit() for x in items) and local_rank < len(items):
+                return int(items[local_rank])
+            return local_rank
+    return local_rank
+
+
+def bind_rank_to_gpu_numa(local_rank, sysfs_root="/", apply=True):
+    """Restricts the calling process to the CPUs of the NUMA node its GPU hangs off (intersected with the CPUs it is
+    allowed to use now).  Returns a dict describing what was done -- {"numa_node", "cpus", "bound"} -- so the bench line
+    can say so; a node without topology files, a GPU that reports no node (-1: single-socket box) or an empty
+    intersection leave the mask alone ("bound": False).  Call it first thing in a rank's process."""
+    info = {"numa_node": None, "cpus": None, "bound": False}
+    numas = gpu_numa_nodes(sysfs_root)
+    idx = _visible_index(local_rank)
+    if not numas or idx >= len(numas) or numas[idx] < 0:
+        return info
+    node = numas[idx]
+    info["numa_node"] = node
+    cpus = parse_cpulist(_read(os.path.join(sysfs_root, f"sys/devices/system/node/node{node}/cpulist")))
+    try:
+        allowed = os.sched_getaffinity(0)
+    except (AttributeError, OSError):
+        return info
+    want = sorted(set(cpus) & set(allowed))
+    if not want:
+        return info
+    info["cpus"] = len(want)
+    if apply:
+        try:
+            os.sched_setaffinity(0, want)
+        except OSError:
+            return info
+    info["bound"] = True
+    return info

@@ -122,12 +122,28 @@ def broadcast_parameters(model, src=0):
     return n
 
 
-def allreduce_gradients(model, world_size):
+def _loss_slot(model, device):
+    """A float of the gradient blob that is ALWAYS zero after a backward (the first BatchNorm running-mean position:
+    buffers receive no gradient): the train loss rides there through the gradient all-reduce."""
+    slot = getattr(model, "_loss_slot_cache", None)
+    if slot is None:                      # from the host-side table: no device read, no synchronisation
+        slot = next(off for name, _, off in _lib.param_table() if name.endswith("running_mean"))
+        model._loss_slot_cache = slot
+    return slot
+
+
+def allreduce_gradients(model, world_size, loss=None):
     """The one exchange step of data-parallel training (the reference gets it from DDP, train.py:87-88): average
     the gradients over the ranks as ONE contiguous message.  After a HIP backward the 248 ``.grad``s are views of
     the kernel's own gradient blob (canonical layout: 19 014 trainable floats + the zero slots of the buffers,
     44 938 floats = 180 KB; latency-bound over xGMI), so the blob is all-reduced in place with no packing; gradients
-    that came from elsewhere (hand-set, accumulated) are packed and unpacked.  Returns the floats on the wire.
+    that came from elsewhere (hand-set, accumulated) are packed and unpacked.
+
+    ``loss`` (optional 0-d tensor): the reference averages the step's loss over the ranks with a collective of its own
+    (``reduce_value(loss)``, train.py:268-269, utils/distributed_utils.py:69-79).  Here it travels in one of the
+    25 924 zero slots of the same message -- no second collective: the slot is written before the all-reduce, read and
+    cleared after it.  Returns the all-rank mean loss (a 0-d tensor) when ``loss`` is given, else the floats on the
+    wire.
 
     Why the whole 180 KB blob and not only its 19 014 trainable floats (76 KB): the trainable tensors are interleaved
     with the BatchNorm buffers in the canonical (state_dict) order, so the short message needs a gather kernel before
@@ -137,18 +153,28 @@ def allreduce_gradients(model, world_size):
     m = model.module if hasattr(model, "module") else model
     flat = _flat_gradient_blob(m)
     if flat is not None:
+        slot = _loss_slot(m, flat.device) if loss is not None else None
+        if slot is not None:
+            flat[slot:slot + 1].copy_(loss.detach().reshape(1))
         dist.all_reduce(flat, op=dist.ReduceOp.SUM)
         flat.mul_(1.0 / world_size)
-        return flat.numel()
+        if slot is None:
+            return flat.numel()
+        mean_loss = flat[slot].clone()
+        flat[slot:slot + 1].zero_()          # the slot is a buffer's gradient position again: zero
+        return mean_loss
     ps = [p for p in m.parameters() if p.grad is not None]
-    flat = torch.cat([p.grad.reshape(-1) for p in ps])
+    parts = [p.grad.reshape(-1) for p in ps]
+    if loss is not None:
+        parts.append(loss.detach().reshape(1).to(parts[0].dtype))
+    flat = torch.cat(parts)
     dist.all_reduce(flat, op=dist.ReduceOp.SUM)
     flat /= world_size
     off = 0
     for p in ps:
         p.grad.copy_(flat[off:off + p.numel()].view_as(p.grad))
         off += p.numel()
-    return flat.numel()
+    return flat[off].clone() if loss is not None else flat.numel()
 
 
 def validate_step(model, loss_func, noisy, clean, window=None):
@@ -170,9 +196,41 @@ def validate_step(model, loss_func, noisy, clean, window=None):
     return loss.detach()
 
 
+def validate_batch(model, loss_func, noisy, clean, world_size=1, window=None):
+    """One iteration of Trainer._validation_epoch (train.py:301-342): Hann-window STFTs of the pair, the eval-mode
+    forward under ``torch.inference_mode`` (the fused inference kernels, BatchNorm running statistics), HybridLoss
+    (value only: no gradient is formed), the all-rank mean of the loss when world_size > 1 (``reduce_value``,
+    train.py:330-331), and the enhanced waveform by the Hann-window iSTFT, padded / cropped to the clean length as
+    train.py:343-350 does before scoring.  Returns (loss, enhanced_wave).  PESQ scoring (third-party C, CPU) is the
+    caller's, as in the reference.  The model must be in ``.eval()`` mode (Trainer.train() switches it, train.py:414-417)."""
+    m = model.module if hasattr(model, "module") else model
+    if m.training:
+        raise _lib.GtcrnError("validate_batch: call model.eval() first (the validation epoch runs the eval-mode model, "
+                              "train.py:414-417)")
+    win = window if window is not None else torch.hann_window(512, device=noisy.device)
+    with torch.inference_mode():
+        noisy_spec = _lib.stft(noisy, win, frame_major=True)
+        clean_spec = _lib.stft(clean, win, frame_major=True)
+        enhanced = model(noisy_spec)
+        loss = loss_func(enhanced, clean_spec)
+        if world_size > 1:
+            import torch.distributed as dist
+            loss = loss.clone()
+            dist.all_reduce(loss, op=dist.ReduceOp.SUM)
+            loss = loss / world_size
+        wave = _lib.istft(enhanced, win)
+        L = clean.shape[-1]
+        if wave.shape[-1] < L:
+            wave = torch.nn.functional.pad(wave, (0, L - wave.shape[-1]))
+        elif wave.shape[-1] > L:
+            wave = wave[..., :L]
+    return loss, wave
+
+
 def train_step(model, optimizer, scheduler, loss_func, noisy, clean, clip_grad_norm_value=3.0, world_size=1,
                window=None, stats=None):
-    """One iteration of Trainer._train_epoch (train.py:244-288); returns (loss, grad_norm) as floats.
+    """One iteration of Trainer._train_epoch (train.py:244-288); returns (loss, grad_norm) as 0-d device tensors (no host
+    synchronisation inside the step); with world_size > 1 the loss is the mean over the ranks (train.py:268-269).
     stats (optional dict): device events around the exchange steps (buffer broadcast, gradient all-reduce) are
     appended to stats["exchange_events"] as (start, end) pairs, so a caller can report what the collectives cost."""
     dev = noisy.device
@@ -201,7 +259,11 @@ def train_step(model, optimizer, scheduler, loss_func, noisy, clean, clip_grad_n
     optimizer.zero_grad()
     loss.backward()
     if world_size > 1:
-        exchange(lambda: allreduce_gradients(model, world_size))
+        # the gradient all-reduce also carries the loss: what comes back is the all-rank mean, as the reference's
+        # reduce_value(loss) returns it (train.py:268-269) -- one collective, not two
+        box = {}
+        exchange(lambda: box.__setitem__("loss", allreduce_gradients(model, world_size, loss=loss)))
+        loss = box["loss"]
     gn = torch.nn.utils.clip_grad_norm_(model.parameters(), clip_grad_norm_value)
     optimizer.step()
     if scheduler is not None:

@@ -53,9 +53,9 @@ dist.destroy_process_group()
 """
 
 
-def _torchrun(args, timeout=300, extra_env=None):
+def _torchrun(args, timeout=300, extra_env=None, nproc=2):
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1", **(extra_env or {}))
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc),
            "--master-addr", "127.0.0.1", "--master-port", str(_free_port())] + args
     return subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=timeout)
 
@@ -69,18 +69,21 @@ def test_two_ranks_shard_and_reduce(tmp_path):
     assert json.loads(line) == {"ok": True, "shard0": [0, 129]}
 
 
-def _check_bench_line(stdout, steps, warmup):
+def _check_bench_line(stdout, steps, warmup, world=2):
     lines = [l for l in stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1                      # only rank 0 prints
     d = json.loads(lines[0])
-    assert d["n_gpus"] == 2 and d["steps"] == steps and d["warmup"] == warmup and d["scaling"] == "weak"
+    assert d["n_gpus"] == world and d["steps"] == steps and d["warmup"] == warmup and d["scaling"] == "weak"
     assert d["unit"] == "frames/s" and d["higher_is_better"] is True and d["vs_baseline"] is None
     T = 1 + 8000 // 256
-    assert abs(d["value"] - 2 * 4 * T * steps / (d["ms_per_step"] * steps / 1e3)) / d["value"] < 1e-3
+    assert abs(d["value"] - world * 4 * T * steps / (d["ms_per_step"] * steps / 1e3)) / d["value"] < 1e-3
     assert "cpu_baseline" not in d and "TEST SHIM" in d["data"]
     assert "stream" not in d and "train" not in d       # the secondary legs need the HIP engine
     pr = d["per_rank_ms_per_step"]                      # a straggler is visible in the line
-    assert len(pr["all"]) == 2 and pr["min"] <= pr["max"] and abs(pr["max"] - d["ms_per_step"]) < 1e-3
+    assert len(pr["all"]) == world and pr["min"] <= pr["max"] and abs(pr["max"] - d["ms_per_step"]) < 1e-3
+    # host-side cost of a step per rank (what N processes on one host contend with) and where each rank was bound
+    assert len(d["host_us_per_step_per_rank"]) == world and d["host_us_per_step"] == max(d["host_us_per_step_per_rank"])
+    assert len(d["numa_binding"]) == world and all(set(b) == {"numa_node", "cpus", "bound"} for b in d["numa_binding"])
     return d
 
 
@@ -329,3 +332,172 @@ def test_secondary_leg_hanging_on_one_rank_is_cut_by_the_watchdog():
     d = _check_bench_line(r.stdout, 3, 1)
     assert "timed out after 6 s" in d["secondary_errors"]["second"]
     assert d["first"]["ms"] == 20.0 and "third" not in d
+
+
+# ---- world_size 8: what an 8-GPU node runs (no such node is available to the builder: CPU ranks over gloo) ---------
+
+_WORKER8 = r"""
+import os, sys, json
+sys.path.insert(0, sys.argv[1])
+import torch, torch.distributed as dist
+from gtcrn_micro_amd.sharding import init_distributed, shard_range, max_over_ranks, sum_over_ranks
+rank, local_rank, world = init_distributed("gloo")
+assert world == 8 and dist.get_backend() == "gloo"
+ok = True
+for n in (1027, 256 * 8, 5, 0):        # BASELINE configs[1] x 8, a ragged list, fewer items than ranks, nothing
+    lo, hi = shard_range(n, world, rank)
+    mine = torch.zeros(max(n, 1), dtype=torch.int64); mine[lo:hi] = 1
+    dist.all_reduce(mine)
+    ok = ok and (n == 0 or (int(mine[:n].min()) == 1 and int(mine[:n].max()) == 1))
+    ok = ok and sum_over_ranks(hi - lo) == n
+assert max_over_ranks(1.0 + rank) == 8.0
+dist.barrier()
+if rank == 0:
+    print(json.dumps({"ok": bool(ok)}))
+dist.destroy_process_group()
+"""
+
+
+def test_eight_ranks_shard_and_reduce(tmp_path):
+    w = tmp_path / "worker8.py"
+    w.write_text(_WORKER8)
+    r = _torchrun([str(w), ROOT], nproc=8)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1]) == {"ok": True}
+
+
+def test_bench_control_flow_eight_ranks():
+    """`bench.py --gpus 8` as the driver launches it (external torchrun, one rank per GPU): one line, 8 entries in
+    per_rank_ms_per_step / host_us_per_step_per_rank / numa_binding."""
+    args = list(_BENCH_ARGS)
+    args[1] = "8"
+    r = _torchrun([os.path.join(ROOT, "bench.py")] + args, extra_env=_SHIM_ENV, nproc=8, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    _check_bench_line(r.stdout, 3, 1, world=8)
+
+
+_SCP_WORKER = r"""
+import os, sys, json
+sys.path.insert(0, sys.argv[1])
+import torch, torch.distributed as dist
+from gtcrn_micro_amd.sharding import init_distributed, shard_range
+from gtcrn_micro_amd import infer
+rank, local_rank, world = init_distributed("gloo")
+enh = sys.argv[2]
+names = sorted(f"mix_fileid_{k}.wav" for k in range(int(sys.argv[3])))
+def fake_shard(noisy_dir, clean_dir, enh_dir, checkpoint, device, max_batch, rank, world, barrier, **kw):
+    # the host side of _enhance_shard without the GPU: this rank's slice of the SORTED list, written as its scp files
+    lo, hi = shard_range(len(names), world, rank)
+    os.makedirs(enh_dir, exist_ok=True)
+    inf = [(n[:-4], os.path.join(enh_dir, n[:-4] + "_enh.wav")) for n in names[lo:hi]]
+    ref = [(n[:-4], os.path.join(clean_dir, "clean_" + n.split("_", 1)[1])) for n in names[lo:hi]]
+    for fname, lst in (("inf.scp", inf), ("ref.scp", ref)):
+        with open(os.path.join(enh_dir, f"{fname}.rank{rank}"), "w") as f:
+            for uid, p in lst:
+                f.write(f"{uid} {p}\n")
+    return inf, ref
+infer._enhance_shard = fake_shard
+def agree(ok):
+    flag = torch.tensor([1 if ok else 0], dtype=torch.int32)
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+    return bool(flag.item())
+infer.enhance_folder("noisy", "clean", enh, "ck", rank=rank, world=world, barrier=dist.barrier, agree=agree)
+dist.barrier()
+if rank == 0:
+    got = [l.split()[0] for l in open(os.path.join(enh, "inf.scp"))]
+    ref = [l.split()[0] for l in open(os.path.join(enh, "ref.scp"))]
+    print(json.dumps({"merged_sorted": got == [n[:-4] for n in names], "ref_same_order": ref == got, "n": len(got)}))
+dist.destroy_process_group()
+"""
+
+
+@pytest.mark.parametrize("nfiles", [37, 5])
+def test_folder_driver_scp_merge_eight_ranks(tmp_path, nfiles):
+    """infer.py:113-119 writes ONE inf.scp / ref.scp in sorted file order; with eight ranks each writes its shard's
+    lists and rank 0 merges them in rank order = sorted order, also when some ranks hold no file at all."""
+    w = tmp_path / "scp_worker.py"
+    w.write_text(_SCP_WORKER)
+    r = _torchrun([str(w), ROOT, str(tmp_path / "enh"), str(nfiles)], nproc=8)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+    assert json.loads(line) == {"merged_sorted": True, "ref_same_order": True, "n": nfiles}
+
+
+_DP8_WORKER = r"""
+import os, sys, json
+sys.path.insert(0, sys.argv[1])
+import torch, torch.distributed as dist
+from gtcrn_micro_amd.sharding import init_distributed
+from gtcrn_micro_amd.train import allreduce_gradients, broadcast_buffers, broadcast_parameters, _loss_slot
+from gtcrn_micro_amd.models.gtcrn_micro import GTCRNMicro
+from gtcrn_micro_amd import _lib
+rank, local_rank, world = init_distributed("gloo")
+torch.manual_seed(500 + rank)          # DIFFERENT initial weights per rank
+m = GTCRNMicro()
+m._flatten(torch.device("cpu"))
+def everything():
+    return torch.cat([t.detach().reshape(-1).double() for t in list(m.parameters()) + list(m.buffers())])
+def same_on_all_ranks(v):
+    allv = [torch.zeros_like(v) for _ in range(world)]
+    dist.all_gather(allv, v)
+    return all(bool(torch.equal(allv[0], x)) for x in allv[1:])
+broadcast_parameters(m)
+equal_after_broadcast = same_on_all_ranks(everything())
+opt = torch.optim.Adam(m.parameters(), lr=1e-3)
+g = torch.Generator().manual_seed(900 + rank)
+bufmask = torch.ones(44938, dtype=torch.bool)
+for p, (off, numel, shape) in zip(m._train_params, m._train_slices):
+    bufmask[off:off + numel] = False
+equal_after_steps, losses_ok, slot_clean = True, True, True
+for step in range(2):
+    broadcast_buffers(m)
+    blob = torch.randn(44938, generator=g)
+    blob[bufmask] = 0.0                # what the HIP backward leaves: buffers have no gradient
+    m._grad_flat = blob
+    for p, (off, numel, shape) in zip(m._train_params, m._train_slices):
+        p.grad = blob[off:off + numel].view(shape)
+    loss = torch.tensor(10.0 * step + rank)            # this rank's loss of the step
+    mean = allreduce_gradients(m, world, loss=loss)    # rides in a zero slot of the SAME message
+    losses_ok = losses_ok and abs(float(mean) - (10.0 * step + (world - 1) / 2)) < 1e-5
+    slot_clean = slot_clean and float(blob[_loss_slot(m, blob.device)]) == 0.0 and bool((blob[bufmask] == 0).all())
+    torch.nn.utils.clip_grad_norm_(m.parameters(), 3.0)
+    opt.step()
+    equal_after_steps = equal_after_steps and same_on_all_ranks(everything())
+# gradients that are NOT views of the blob: the loss is appended to the packed message
+for p in m.parameters():
+    if p.requires_grad:
+        p.grad = torch.randn(p.shape, generator=g)
+m._grad_flat = None
+mean2 = allreduce_gradients(m, world, loss=torch.tensor(float(rank)))
+packed_ok = abs(float(mean2) - (world - 1) / 2) < 1e-5
+dist.barrier()
+if rank == 0:
+    print(json.dumps({"equal_after_broadcast": equal_after_broadcast, "equal_after_steps": equal_after_steps,
+                      "losses_ok": losses_ok, "slot_clean": slot_clean, "packed_ok": packed_ok}))
+dist.destroy_process_group()
+"""
+
+
+def test_eight_replicas_stay_bit_equal_and_the_loss_rides_in_the_gradient_message(tmp_path):
+    """World size 8: construction-time broadcast, then dp steps (buffer broadcast -> rank-specific gradients -> ONE
+    all-reduce -> clip -> Adam) keep all eight replicas bit-equal; the step's loss travels in a zero slot of the
+    gradient blob and comes back as the all-rank mean (reduce_value, train.py:268-269) with NO collective of its own;
+    the slot is zero again afterwards (it is a buffer's gradient position)."""
+    w = tmp_path / "dp8_worker.py"
+    w.write_text(_DP8_WORKER)
+    r = _torchrun([str(w), ROOT], nproc=8, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+    assert json.loads(line) == {"equal_after_broadcast": True, "equal_after_steps": True, "losses_ok": True,
+                                "slot_clean": True, "packed_ok": True}
+
+
+def test_train_step_issues_no_separate_loss_collective():
+    """train_step's only collectives are broadcast_buffers and allreduce_gradients (which carries the loss)."""
+    import ast
+    src = open(os.path.join(ROOT, "gtcrn_micro_amd", "train.py")).read()
+    fn = next(n for n in ast.walk(ast.parse(src)) if isinstance(n, ast.FunctionDef) and n.name == "train_step")
+    attrs = {c.func.attr for c in ast.walk(fn) if isinstance(c, ast.Call) and isinstance(c.func, ast.Attribute)}
+    assert "all_reduce" not in attrs and "reduce" not in attrs
+    names = {c.func.id for c in ast.walk(fn) if isinstance(c, ast.Call) and isinstance(c.func, ast.Name)}
+    assert {"allreduce_gradients", "broadcast_buffers"} <= names

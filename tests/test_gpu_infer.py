@@ -177,3 +177,53 @@ def test_variable_length_batches_in_time_spans_equal_one_workgroup_per_utterance
     j = B // 2
     single = eng.forward_wave(wave[j, :lens[j]].contiguous(), win)
     assert torch.equal(y[j, :single.shape[0]], single)
+
+
+@pytest.mark.gpu
+def test_pipelined_folder_driver_writes_the_serial_drivers_bytes(tmp_path):
+    """The folder driver as a pipeline (reader thread -> pinned staging -> H2D || kernels || D2H on three HIP streams ->
+    writer thread) against its serial form (one batch after the other, pageable copies): 40 clips of 8 lengths in batches
+    of 6 over 3 staging slots -- more batches than slots, so every slot is reused -- must give byte-identical wav files
+    and the same scp lists; the statistics object is filled; a reader failure (a file that disappears) is raised, not hung."""
+    from scipy.io import wavfile
+    from gtcrn_micro_amd.infer import enhance_folder
+    noisy_dir, clean_dir = tmp_path / "noisy", tmp_path / "clean"
+    noisy_dir.mkdir(); clean_dir.mkdir()
+    rng = np.random.default_rng(11)
+    lens = [3000, 4096, 4097, 9000, 9000, 12345, 16000, 20000]
+    for k in range(40):
+        L = lens[k % len(lens)] + (k // len(lens)) * 7
+        wavfile.write(noisy_dir / f"n_fileid_{k}.wav", 16000, (rng.standard_normal(L) * 3000).astype(np.int16))
+        wavfile.write(clean_dir / f"clean_fileid_{k}.wav", 16000, np.zeros(L + (k % 3) * 100 - 100, np.int16))
+    ck = os.path.join(GOLDEN, "params_dns3.f32")
+    st_p, st_s = {}, {}
+    inf_p, ref_p = enhance_folder(str(noisy_dir), str(clean_dir), str(tmp_path / "enh_p"), ck, max_batch=6, stats=st_p)
+    inf_s, ref_s = enhance_folder(str(noisy_dir), str(clean_dir), str(tmp_path / "enh_s"), ck, max_batch=6, pipeline=False,
+                                  stats=st_s)
+    assert [u for u, _ in inf_p] == [u for u, _ in inf_s] == sorted(f"n_fileid_{k}" for k in range(40))
+    assert [r for _, r in ref_p] == [r for _, r in ref_s]
+    for u, _ in inf_p:
+        a = open(tmp_path / "enh_p" / f"{u}_enh.wav", "rb").read()
+        b = open(tmp_path / "enh_s" / f"{u}_enh.wav", "rb").read()
+        assert a == b and len(a) > 44, u
+    assert st_p["clips"] == st_s["clips"] == 40 and st_p["batches"] == 7 and st_p["frames"] == st_s["frames"]
+    assert st_p["pipeline"] is True and 0.0 < st_p["gpu_busy_frac"] <= 1.0 and st_s["gpu_busy_frac"] is None
+    assert st_p["h2d_bytes"] == st_s["h2d_bytes"] and st_p["d2h_bytes"] == st_s["d2h_bytes"]
+    # a failing stage surfaces as an exception of the call (and the threads end): a clip that vanishes after pass 1
+    import gtcrn_micro_amd.infer as I
+    real = I.read_wav_f32
+    calls = {"n": 0}
+
+    def flaky(path):
+        calls["n"] += 1
+        if calls["n"] == 9:
+            raise OSError("simulated read error")
+        return real(path)
+    I.read_wav_f32 = flaky
+    try:
+        with pytest.raises(OSError, match="simulated read error"):
+            enhance_folder(str(noisy_dir), str(clean_dir), str(tmp_path / "enh_x"), ck, max_batch=6)
+    finally:
+        I.read_wav_f32 = real
+    import threading
+    assert not [t for t in threading.enumerate() if t.name.startswith("gtcrn-folder-")]

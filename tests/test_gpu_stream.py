@@ -465,3 +465,27 @@ def test_mirror_forward_under_inference_mode_and_two_model_handover(dev):
             got.append(y)
     assert torch.equal(torch.cat(got, 2), want)
     assert smA.forward_stats["imports"] == 2 and smB.forward_stats["imports"] == 1
+
+
+def test_65536_streams_past_the_infinity_cache_equal_small_batches(dev):
+    """bench.py's stream_capacity leg runs 65 536 (and more) concurrent streams per GPU: 10 GB of ring state, stream
+    offsets past 2^31 bytes and 2^31 floats of state, 16 384 workgroups per launch.  Streams are independent, so any
+    stream of the big batch must equal the same frames through a batch of four, bit for bit -- first, last and the
+    ones either side of the 2^31-float boundary of the state tensor (stream 56 341)."""
+    from gtcrn_micro_amd import Engine
+    eng = Engine(load_params("dns3"), 0)
+    N, T = 65536, 3
+    gen = torch.Generator(device="cuda").manual_seed(65536)
+    spec = (torch.randn(N, T, 257, 2, device="cuda", generator=gen) * 0.3).permute(0, 2, 1, 3)
+    st = eng.new_state(N)
+    assert st.numel() > 2 ** 31
+    got = torch.cat([eng.stream_step(st, spec[:, :, t:t + 1]) for t in range(T)], 2)
+    assert bool(torch.isfinite(got).all())
+    for lo in (0, 56340, 65532):
+        st4 = eng.new_state(4)
+        want = torch.cat([eng.stream_step(st4, spec[lo:lo + 4, :, t:t + 1]) for t in range(T)], 2)
+        assert torch.equal(got[lo:lo + 4], want), lo
+        # ... and the ring state the big launch left for these streams is the small launch's
+        assert torch.equal(st[lo:lo + 4], st4), lo
+    del st, spec, got
+    torch.cuda.empty_cache()

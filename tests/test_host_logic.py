@@ -579,3 +579,69 @@ def test_stream_mirror_cache_binding_logic_without_a_gpu(monkeypatch):
     assert float(caches[0][0, 0, 0, 0, 0]) == 5.0                                     # 4 frames in A + 1 in B
     y, caches[0], caches[1], caches[2] = smA(x, caches[0], caches[1], caches[2])      # and back again
     assert float(caches[0][0, 0, 0, 0, 0]) == 6.0
+
+
+# ---- rank -> NUMA node binding (sharding.bind_rank_to_gpu_numa) on a fake sysfs tree ---------------------------------
+
+def _fake_sysfs(root, gpus, cpulists):
+    """gpus: [(render minor, numa node)] in KFD order behind two CPU nodes; cpulists: {node: "a-b"}."""
+    nodes = os.path.join(root, "sys/class/kfd/kfd/topology/nodes")
+    for n in range(2):                                          # CPU nodes: no SIMDs, no render minor
+        os.makedirs(os.path.join(nodes, str(n)))
+        open(os.path.join(nodes, str(n), "properties"), "w").write("cpu_cores_count 64\nsimd_count 0\ndrm_render_minor 0\n")
+    for k, (minor, numa) in enumerate(gpus):
+        d = os.path.join(nodes, str(2 + k))
+        os.makedirs(d)
+        open(os.path.join(d, "properties"), "w").write(f"cpu_cores_count 0\nsimd_count 1024\ndrm_render_minor {minor}\n")
+        dev = os.path.join(root, f"sys/class/drm/renderD{minor}/device")
+        os.makedirs(dev)
+        open(os.path.join(dev, "numa_node"), "w").write(f"{numa}\n")
+    for node, cl in cpulists.items():
+        d = os.path.join(root, f"sys/devices/system/node/node{node}")
+        os.makedirs(d)
+        open(os.path.join(d, "cpulist"), "w").write(cl + "\n")
+
+
+def test_rank_is_bound_to_the_numa_node_of_its_gpu(tmp_path, monkeypatch):
+    from gtcrn_micro_amd import sharding as S
+    assert S.parse_cpulist("0-3,8,10-11") == [0, 1, 2, 3, 8, 10, 11] and S.parse_cpulist("") == []
+    allowed = sorted(os.sched_getaffinity(0))
+    half = max(1, len(allowed) // 2)
+    lo, hi = allowed[:half], allowed[half:] or allowed[:half]
+    fmt = lambda c: ",".join(str(x) for x in c)
+    root = str(tmp_path)
+    # eight GPUs, render minors out of order on purpose: four behind each socket
+    _fake_sysfs(root, [(128 + k, 0 if k < 4 else 1) for k in (0, 1, 2, 3, 4, 5, 6, 7)], {0: fmt(lo), 1: fmt(hi)})
+    assert S.gpu_numa_nodes(root) == [0, 0, 0, 0, 1, 1, 1, 1]
+    for v in ("HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES"):
+        monkeypatch.delenv(v, raising=False)
+    i0 = S.bind_rank_to_gpu_numa(1, root, apply=False)
+    i1 = S.bind_rank_to_gpu_numa(6, root, apply=False)
+    assert i0 == {"numa_node": 0, "cpus": len(lo), "bound": True} and i1 == {"numa_node": 1, "cpus": len(hi), "bound": True}
+    # a launcher that remaps the devices: local rank 0 is physical GPU 5 -> node 1
+    monkeypatch.setenv("HIP_VISIBLE_DEVICES", "5,6")
+    assert S.bind_rank_to_gpu_numa(0, root, apply=False)["numa_node"] == 1
+    monkeypatch.delenv("HIP_VISIBLE_DEVICES")
+    # really applied (and restored): the process mask becomes the node's CPUs
+    try:
+        got = S.bind_rank_to_gpu_numa(2, root, apply=True)
+        assert got["bound"] and sorted(os.sched_getaffinity(0)) == lo
+    finally:
+        os.sched_setaffinity(0, allowed)
+    # nothing to go by: no topology, a GPU without a node, CPUs we may not use -> the mask is left alone
+    assert S.bind_rank_to_gpu_numa(0, str(tmp_path / "nowhere")) == {"numa_node": None, "cpus": None, "bound": False}
+    root2 = str(tmp_path / "single")
+    _fake_sysfs(root2, [(128, -1)], {})
+    assert S.bind_rank_to_gpu_numa(0, root2)["bound"] is False
+    root3 = str(tmp_path / "foreign")
+    _fake_sysfs(root3, [(128, 0)], {0: "100000-100003"})
+    assert S.bind_rank_to_gpu_numa(0, root3) == {"numa_node": 0, "cpus": None, "bound": False}
+    assert sorted(os.sched_getaffinity(0)) == allowed
+
+
+def test_sharding_module_needs_no_torch_at_import():
+    """bench.py binds the rank's CPUs BEFORE torch / HIP are imported: sharding.py must import with the stdlib alone."""
+    import ast
+    src = open(os.path.join(ROOT, "gtcrn_micro_amd", "sharding.py")).read()
+    top = [n for n in ast.parse(src).body if isinstance(n, (ast.Import, ast.ImportFrom))]
+    assert [a.name for n in top for a in n.names] == ["os"]
