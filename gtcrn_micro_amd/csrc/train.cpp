@@ -11,6 +11,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cmath>
 #include <cstring>
 #include <map>
 #include <string>
@@ -1045,6 +1046,23 @@ int gtcrn_train_tap(gtcrn_trainer* t, const char* name, float* d_out, long* shap
     if (shape4) { shape4[0] = t->B; shape4[1] = sh[0]; shape4[2] = sh[1]; shape4[3] = sh[2]; }
     if (d_out)
         T_RUN(gtt::saved_to_f32(it->second.first, d_out, (long)t->B * sh[0] * sh[1] * sh[2], (hipStream_t)stream, t->bf));
+    return 0;
+}
+
+int gtcrn_clip_adam_step(int device, float* d_params, float* d_grads, float* d_exp_avg, float* d_exp_avg_sq,
+                         const float* d_mask, long n, float max_norm, double lr, double beta1, double beta2, double eps,
+                         double weight_decay, long step, float* d_norm_out, void* stream) {
+    if (!d_params || !d_grads || !d_exp_avg || !d_exp_avg_sq || !d_mask || n < 1 || n > (1L << 30) || step < 1 ||
+        !(beta1 >= 0.0 && beta1 < 1.0) || !(beta2 >= 0.0 && beta2 < 1.0) || !(eps >= 0.0) || !(lr >= 0.0))
+        return tfail(GTCRN_ERR_ARG, "gtcrn_clip_adam_step: bad argument (needs device pointers, 1 <= n, step >= 1, "
+                                    "0 <= beta < 1, eps >= 0, lr >= 0)");
+    T_HIP(hipSetDevice(device));
+    // torch.optim.Adam (_single_tensor_adam, not capturable): the bias corrections are Python floats (double)
+    const double bc1 = 1.0 - std::pow(beta1, (double)step);
+    const double bc2 = 1.0 - std::pow(beta2, (double)step);
+    T_RUN(gtt::clip_adam(d_params, d_grads, d_exp_avg, d_exp_avg_sq, d_mask, (int)n, max_norm, (float)beta1, (float)beta2,
+                         (float)(1.0 - beta1), (float)(1.0 - beta2), (float)(lr / bc1), (float)std::sqrt(bc2), (float)eps,
+                         (float)weight_decay, d_norm_out, (hipStream_t)stream));
     return 0;
 }
 

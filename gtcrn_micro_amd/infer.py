@@ -105,7 +105,7 @@ def _finish_clip(y_row, item, enh_dir):
 
 
 def _enhance_shard(noisy_dir, clean_dir, enh_dir, checkpoint, device=0, max_batch=64, rank=0, world=1,
-                   barrier=None, pipeline=True, stats=None, stages=3):
+                   barrier=None, pipeline=True, stats=None, stages=3, io_threads=4):
     """barrier: a callable all ranks call once their lists are written (multi-GPU runs; main() passes
     torch.distributed.barrier); rank 0 then merges the per-rank scp files.
 
@@ -115,6 +115,7 @@ def _enhance_shard(noisy_dir, clean_dir, enh_dir, checkpoint, device=0, max_batc
       launch thread   (the caller's) H2D on a copy-in HIP stream, the six kernels on the compute stream, D2H on a
                       copy-out stream -- all asynchronous, ordered by events; batch k+1 uploads while k computes
       writer thread   waits for slot k's D2H event, length-matches and writes the 16-bit files, frees the slot
+    (the reader and the writer each spread the clips of a batch over `io_threads` pool threads)
     so disk reads, PCIe both ways, the kernels and disk writes of different batches overlap.  The batches and the
     kernels are the ones of the serial form (pipeline=False: read -> pageable copy -> kernels -> copy back -> write, one
     batch after the other, what round 4 shipped), so every output file is bit-identical between the two.
@@ -199,12 +200,14 @@ def _enhance_shard(noisy_dir, clean_dir, enh_dir, checkpoint, device=0, max_batc
                     lens = [items[i][4] for i in sel]
                     Lmax = max(lens)
                     hin = slots[k % nslot]["hin"].numpy()[:len(sel) * Lmax].reshape(len(sel), Lmax)
-                    for j, i in enumerate(sel):
-                        w = read_wav_f32(items[i][1])[1]
+
+                    def fill(j, hin=hin, sel=sel, lens=lens):
+                        w = read_wav_f32(items[sel[j]][1])[1]
                         if len(w) != lens[j]:
-                            raise RuntimeError(f"{items[i][1]} changed length while the folder was being enhanced")
+                            raise RuntimeError(f"{items[sel[j]][1]} changed length while the folder was being enhanced")
                         hin[j, :len(w)] = w
                         hin[j, len(w):] = 0.0
+                    list(pool_r.map(fill, range(len(sel))))          # (numpy's conversions and file reads drop the GIL)
                     q_read.put((k, sel, lens, Lmax))
             except Exception as e:
                 errors.append(e)
@@ -221,8 +224,9 @@ def _enhance_shard(noisy_dir, clean_dir, enh_dir, checkpoint, device=0, max_batc
                     k, sel, Lout, ev_done, ev_a, ev_b = job
                     ev_done.synchronize()
                     y = slots[k % nslot]["hout"].numpy()[:len(sel) * Lout].reshape(len(sel), Lout)
-                    for j, i in enumerate(sel):
-                        rows[i] = _finish_clip(y[j], items[i], enh_dir)
+                    for i, row in zip(sel, pool_w.map(lambda j, y=y, sel=sel: _finish_clip(y[j], items[sel[j]], enh_dir),
+                                                      range(len(sel)))):
+                        rows[i] = row
                     busy.append(ev_a.elapsed_time(ev_b))
                     free.release()
             except Exception as e:
@@ -230,6 +234,9 @@ def _enhance_shard(noisy_dir, clean_dir, enh_dir, checkpoint, device=0, max_batc
                 abort.set()
 
         busy = []
+        from concurrent.futures import ThreadPoolExecutor
+        pool_r = ThreadPoolExecutor(max(1, int(io_threads)), thread_name_prefix="gtcrn-folder-rd")
+        pool_w = ThreadPoolExecutor(max(1, int(io_threads)), thread_name_prefix="gtcrn-folder-wr")
         th_r = threading.Thread(target=reader, name="gtcrn-folder-reader", daemon=True)
         th_w = threading.Thread(target=writer, name="gtcrn-folder-writer", daemon=True)
         th_r.start()
@@ -278,6 +285,8 @@ def _enhance_shard(noisy_dir, clean_dir, enh_dir, checkpoint, device=0, max_batc
             if errors:
                 abort.set()
             th_r.join()
+            pool_r.shutdown(wait=True)
+            pool_w.shutdown(wait=True)
             torch.cuda.synchronize(device)
         if errors:
             raise errors[0]
@@ -299,7 +308,7 @@ def _enhance_shard(noisy_dir, clean_dir, enh_dir, checkpoint, device=0, max_batc
 
 
 def enhance_folder(noisy_dir, clean_dir, enh_dir, checkpoint, device=0, max_batch=64, rank=0, world=1, barrier=None,
-                   agree=None, pipeline=True, stats=None):
+                   agree=None, pipeline=True, stats=None, io_threads=4):
     """Counterpart of infer.py:26-119 for a folder (see ``_enhance_shard``): every rank enhances its contiguous shard of
     the sorted file list, then rank 0 merges the per-rank scp lists.
 
@@ -312,7 +321,7 @@ def enhance_folder(noisy_dir, clean_dir, enh_dir, checkpoint, device=0, max_batc
     result = None
     try:
         result = _enhance_shard(noisy_dir, clean_dir, enh_dir, checkpoint, device, max_batch, rank, world, barrier,
-                                pipeline=pipeline, stats=stats)
+                                pipeline=pipeline, stats=stats, io_threads=io_threads)
     except Exception as e:           # re-raised below, after the exchange.  NOT BaseException: a KeyboardInterrupt or
         err = e                      # SystemExit must leave at once instead of waiting in a collective first
     all_ok = err is None

@@ -259,6 +259,9 @@ class GTCRNMicro(nn.Module):
         self._nbt_flat = None
         self._stats_dirty = False
         self._fwd_serial = 0
+        self._opt_serial = 0    # in-place weight updates by the fused optimizer kernel (utils/optim.py)
+        self._train_slices = None
+        self._train_params = None
         self._grad_flat = None  # gradient blob of the most recent backward (canonical layout)
         self._act_storage = "f32"
         self._sig_tensors = None
@@ -285,7 +288,7 @@ class GTCRNMicro(nn.Module):
         manual edits) bump the tensors' version counters; the train forward (running statistics) bumps the serial; a
         REPLACED parameter / buffer object moves the registration epoch."""
         ts = self._state_tensors()[0]
-        return (sum(int(t._version) for t in ts), self._fwd_serial, self._obj_serial)
+        return (sum(int(t._version) for t in ts), self._fwd_serial, self._obj_serial, self._opt_serial)
 
     # -- train mode: flat parameter storage ----------------------------------------------------
     def _trainer(self, device):

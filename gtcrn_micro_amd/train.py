@@ -36,12 +36,18 @@ def synthetic_mix(batch, samples=64000, seed=43, device="cuda"):
     return noisy.to(device), clean.to(device)
 
 
-def make_training(config=None, device="cuda"):
-    """Model, Adam, scheduler and loss with the reference's defaults (conf/cfg_train_DNS3.yaml)."""
+def make_training(config=None, device="cuda", fused_optimizer=True):
+    """Model, Adam, scheduler and loss with the reference's defaults (conf/cfg_train_DNS3.yaml).
+    fused_optimizer: ``utils.optim.FlatAdam`` (clip + Adam as one HIP launch over the flat blobs; same update rule and
+    state_dict as torch.optim.Adam) instead of ``torch.optim.Adam`` itself (train.py:90)."""
     cfg = {"lr": 1e-3, "warmup_steps": 25000, "decay_until_step": 250000, "max_lr": 1e-3, "min_lr": 1e-6}
     cfg.update(config or {})
     model = GTCRNMicro().to(device)
-    opt = torch.optim.Adam(model.parameters(), lr=cfg["lr"])
+    if fused_optimizer:
+        from .utils.optim import FlatAdam
+        opt = FlatAdam(model, lr=cfg["lr"])
+    else:
+        opt = torch.optim.Adam(model.parameters(), lr=cfg["lr"])
     sched = LinearWarmupCosineAnnealingLR(opt, cfg["warmup_steps"], cfg["decay_until_step"], cfg["max_lr"],
                                           cfg["min_lr"])
     return model, opt, sched, HybridLoss().to(device)
@@ -264,8 +270,11 @@ def train_step(model, optimizer, scheduler, loss_func, noisy, clean, clip_grad_n
         box = {}
         exchange(lambda: box.__setitem__("loss", allreduce_gradients(model, world_size, loss=loss)))
         loss = box["loss"]
-    gn = torch.nn.utils.clip_grad_norm_(model.parameters(), clip_grad_norm_value)
-    optimizer.step()
+    if hasattr(optimizer, "step_clipped"):
+        gn = optimizer.step_clipped(clip_grad_norm_value)      # clip_grad_norm_ + Adam: one launch (utils/optim.py)
+    else:
+        gn = torch.nn.utils.clip_grad_norm_(model.parameters(), clip_grad_norm_value)
+        optimizer.step()
     if scheduler is not None:
         scheduler.step()
     return loss.detach(), gn
