@@ -105,7 +105,9 @@ def lib():
     L.gtcrn_train_loss.argtypes = [_vp, _vp, cl, cl, cl, _vp, cl, cl, cl, ci, ci, _vp, _vp, _vp]
     L.gtcrn_train_loss_strided.argtypes = [_vp, _vp, cl, cl, cl, _vp, cl, cl, cl, ci, ci, _vp, _vp, cl, cl, cl, _vp]
     cd = ctypes.c_double
-    L.gtcrn_clip_adam_step.argtypes = [ci, _vp, _vp, _vp, _vp, _vp, cl, cf, cd, cd, cd, cd, cd, cl, _vp, _vp]
+    L.gtcrn_clip_adam_step.argtypes = [ci, _vp, _vp, _vp, _vp, _vp, cl, cf, cd, cd, cd, cd, cd, cl, _vp, _vp, _vp]
+    L.gtcrn_clip_adam_workspace_bytes.restype = cl
+    L.gtcrn_clip_adam_workspace_bytes.argtypes = [cl]
     if L.gtcrn_abi_version() != 1:
         raise GtcrnError("libgtcrn_micro_hip.so ABI version mismatch")
     _lib = L
@@ -685,9 +687,12 @@ class Trainer:
         return out.permute(0, 3, 1, 2).contiguous()
 
 
+_adam_ws = {}
+
+
 def clip_adam_step(params, grads, exp_avg, exp_avg_sq, mask, step, lr, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0,
                    max_norm=0.0, norm_out=None):
-    """clip_grad_norm_(max_norm) + torch.optim.Adam.step() over flat fp32 device blobs in one launch
+    """clip_grad_norm_(max_norm) + torch.optim.Adam.step() over flat fp32 device blobs in two launches
     (gtcrn_clip_adam_step).  norm_out: optional 2-float device tensor (total norm, clip coefficient)."""
     import torch
     n = params.numel()
@@ -699,8 +704,14 @@ def clip_adam_step(params, grads, exp_avg, exp_avg_sq, mask, step, lr, betas=(0.
         _require_cuda_f32(norm_out, "norm_out")
         if norm_out.numel() < 2 or not norm_out.is_contiguous():
             raise GtcrnError("norm_out must hold 2 contiguous floats")
+    key = (params.device.index, n)
+    ws = _adam_ws.get(key)
+    if ws is None:      # zeroed once: every call leaves the ticket at zero again
+        ws = _adam_ws[key] = torch.zeros((int(lib().gtcrn_clip_adam_workspace_bytes(n)) + 7) // 8, dtype=torch.float64,
+                                         device=params.device)
     with torch.cuda.device(params.device):
         _check(lib().gtcrn_clip_adam_step(params.device.index, params.data_ptr(), grads.data_ptr(), exp_avg.data_ptr(),
                                           exp_avg_sq.data_ptr(), mask.data_ptr(), n, float(max_norm), float(lr),
                                           float(betas[0]), float(betas[1]), float(eps), float(weight_decay), int(step),
-                                          norm_out.data_ptr() if norm_out is not None else None, _stream_ptr()))
+                                          norm_out.data_ptr() if norm_out is not None else None, ws.data_ptr(),
+                                          _stream_ptr()))

@@ -1049,20 +1049,29 @@ int gtcrn_train_tap(gtcrn_trainer* t, const char* name, float* d_out, long* shap
     return 0;
 }
 
+long gtcrn_clip_adam_workspace_bytes(long n) { return n < 1 ? -1 : 64 + 8 * ((n + 255) / 256); }
+
 int gtcrn_clip_adam_step(int device, float* d_params, float* d_grads, float* d_exp_avg, float* d_exp_avg_sq,
                          const float* d_mask, long n, float max_norm, double lr, double beta1, double beta2, double eps,
-                         double weight_decay, long step, float* d_norm_out, void* stream) {
-    if (!d_params || !d_grads || !d_exp_avg || !d_exp_avg_sq || !d_mask || n < 1 || n > (1L << 30) || step < 1 ||
-        !(beta1 >= 0.0 && beta1 < 1.0) || !(beta2 >= 0.0 && beta2 < 1.0) || !(eps >= 0.0) || !(lr >= 0.0))
-        return tfail(GTCRN_ERR_ARG, "gtcrn_clip_adam_step: bad argument (needs device pointers, 1 <= n, step >= 1, "
-                                    "0 <= beta < 1, eps >= 0, lr >= 0)");
+                         double weight_decay, long step, float* d_norm_out, void* d_workspace, void* stream) {
+    if (!d_params || !d_grads || !d_exp_avg || !d_exp_avg_sq || !d_mask || !d_workspace || n < 1 || n > (1L << 30) ||
+        step < 1 || !(beta1 >= 0.0 && beta1 < 1.0) || !(beta2 >= 0.0 && beta2 < 1.0) || !(eps >= 0.0) || !(lr >= 0.0) ||
+        (reinterpret_cast<uintptr_t>(d_workspace) & 7))
+        return tfail(GTCRN_ERR_ARG, "gtcrn_clip_adam_step: bad argument (needs device pointers, an 8-byte aligned "
+                                    "workspace, 1 <= n, step >= 1, 0 <= beta < 1, eps >= 0, lr >= 0)");
     T_HIP(hipSetDevice(device));
+    // workspace: [0] the last-workgroup ticket (0 between calls), [8..16) norm / coefficient when the caller wants
+    // neither, [64..) one double per workgroup of the norm
+    char* ws = static_cast<char*>(d_workspace);
+    unsigned* counter = reinterpret_cast<unsigned*>(ws);
+    float* norm = d_norm_out ? d_norm_out : reinterpret_cast<float*>(ws + 8);
+    double* partial = reinterpret_cast<double*>(ws + 64);
     // torch.optim.Adam (_single_tensor_adam, not capturable): the bias corrections are Python floats (double)
     const double bc1 = 1.0 - std::pow(beta1, (double)step);
     const double bc2 = 1.0 - std::pow(beta2, (double)step);
     T_RUN(gtt::clip_adam(d_params, d_grads, d_exp_avg, d_exp_avg_sq, d_mask, (int)n, max_norm, (float)beta1, (float)beta2,
                          (float)(1.0 - beta1), (float)(1.0 - beta2), (float)(lr / bc1), (float)std::sqrt(bc2), (float)eps,
-                         (float)weight_decay, d_norm_out, (hipStream_t)stream));
+                         (float)weight_decay, norm, partial, counter, (hipStream_t)stream));
     return 0;
 }
 

@@ -205,13 +205,14 @@ int add(const float* a, const float* b, float* out, long n, hipStream_t s);
 int add_saved(const float* a, const float* b, float* out, long n, hipStream_t s, int bf);
 int saved_to_f32(const float* src, float* dst, long n, hipStream_t s, int bf);
 
-// clip_grad_norm_(max_norm) + torch.optim.Adam.step() over flat blobs of n floats in ONE launch (train.py:282-285):
+// clip_grad_norm_(max_norm) + torch.optim.Adam.step() over flat blobs of n floats in two launches (train.py:282-285):
 // p / g / m / v = parameters, gradients, exp_avg, exp_avg_sq; mask[i] != 0 marks the trainable elements (others are
 // left alone and do not count in the norm); max_norm <= 0: no clipping; omb1 = 1 - beta1, omb2 = 1 - beta2, step_size =
 // lr / (1 - beta1^t), bc2_sqrt = sqrt(1 - beta2^t) as the host computes them in double (what torch.optim.Adam does);
-// out_norm (optional, 2 floats): total norm, clip coefficient.
+// out_norm (2 floats): total norm, clip coefficient.  partial: (n + 255) / 256 doubles of scratch; counter: one
+// unsigned that is 0 on entry and 0 again on completion (the last-workgroup ticket of the norm).
 int clip_adam(float* p, float* g, float* m, float* v, const float* mask, int n, float max_norm, float beta1, float beta2,
               float omb1, float omb2, float step_size, float bc2_sqrt, float eps, float weight_decay, float* out_norm,
-              hipStream_t s);
+              double* partial, unsigned* counter, hipStream_t s);
 
 }  // namespace gtt

@@ -3277,54 +3277,80 @@ __global__ __launch_bounds__(NT) void k_saved_to_f32(const float* __restrict__ s
 }
 
 
-// ------------------------------------------------------------ clip_grad_norm_ + Adam over the flat blob, ONE launch
+// ------------------------------------------------------------ clip_grad_norm_ + Adam over the flat blobs, two launches
 // train.py:282-285: torch.nn.utils.clip_grad_norm_(model.parameters(), 3.0); optimizer.step() (torch.optim.Adam, no
 // amsgrad, L2 weight decay 0 by default).  In PyTorch that is one norm kernel per tensor + stack + norm + a foreach
 // multiply, then the foreach Adam over 248 views: ~300 launches and ~200 tiny buffer copies per step for 19 014 floats.
-// Parameters, gradients and both moments are views of four flat blobs in the canonical layout here, so the whole update
-// is one workgroup: (1) sum of squares of the gradient blob in double, fixed order (thread-strided, then a tree over the
-// 1024 threads), total norm, clip coefficient min(max_norm / (norm + 1e-6), 1) as clip_grad_norm_ computes it; (2) the
-// Adam update of every element whose mask is set (the trainable tensors; BatchNorm running statistics and the ERB
-// bank have no gradient and must not move), gradients written back scaled as clip_grad_norm_ leaves them.
-// 45 k elements x 5 arrays = 0.9 MB through one CU: a few microseconds, no atomics, bit-reproducible.
-__global__ __launch_bounds__(1024) void k_clip_adam(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m,
-                                                   float* __restrict__ v, const float* __restrict__ mask, int n,
-                                                   float max_norm, float beta1, float beta2, float omb1, float omb2,
-                                                   float step_size, float bc2_sqrt, float eps, float weight_decay,
-                                                   float* __restrict__ out_norm) {
-    __shared__ double sh[1024];
-    const int tid = threadIdx.x;
-    double s = 0.0;
-    for (int i = tid; i < n; i += 1024) {
-        const double x = (double)(mask[i] != 0.f ? g[i] : 0.f);
-        s = fma(x, x, s);
-    }
-    sh[tid] = s;
+// Parameters, gradients and both moments are views of four flat blobs in the canonical layout here:
+//  k_grad_sqsum  one element per thread, sum of squares of the masked gradient in double per workgroup (fixed-order
+//                tree); the LAST workgroup to arrive (a ticket from one atomic counter; the partials were published with a
+//                device-scope fence) adds the partials in index order -- the arrival order does not enter the result --
+//                and stores the total norm and the clip coefficient min(max_norm / (norm + 1e-6), 1), exactly what
+//                clip_grad_norm_ computes; it also resets the counter for the next step
+//  k_adam_flat   one element per thread: gradient scaled in place as clip_grad_norm_ leaves it, Adam moments and
+//                parameter updated where the mask is set (BatchNorm running statistics and the ERB bank carry no
+//                gradient and must not move)
+// (A first version did both phases in ONE workgroup of 1024 threads, 44 elements per thread: each of its 88 trips
+// paid a full memory latency and the "fused" step was 0.4 ms SLOWER than PyTorch's 300 launches, same-box A/B.)
+constexpr int ADAM_NT = 256;
+__global__ __launch_bounds__(ADAM_NT) void k_grad_sqsum(const float* __restrict__ g, const float* __restrict__ mask, int n,
+                                                       float max_norm, double* __restrict__ partial,
+                                                       unsigned* __restrict__ counter, float* __restrict__ out_norm) {
+    __shared__ double sh[ADAM_NT];
+    __shared__ unsigned ticket;
+    const int tid = threadIdx.x, i = blockIdx.x * ADAM_NT + tid;
+    double x = 0.0;
+    if (i < n && mask[i] != 0.f) x = (double)g[i];
+    sh[tid] = x * x;
     __syncthreads();
-    for (int o = 512; o > 0; o >>= 1) {
+    for (int o = ADAM_NT / 2; o > 0; o >>= 1) {
         if (tid < o) sh[tid] += sh[tid + o];
         __syncthreads();
     }
-    const float norm = (float)sqrt(sh[0]);
-    float coef = 1.f;
-    if (max_norm > 0.f) {
-        coef = max_norm / (norm + 1e-6f);
-        coef = coef > 1.f ? 1.f : coef;              // (a NaN norm stays NaN, as torch.clamp leaves it)
+    if (tid == 0) {
+        partial[blockIdx.x] = sh[0];
+        __threadfence();                                   // the partial is visible device-wide before the ticket is
+        ticket = atomicAdd(counter, 1u);
     }
-    if (tid == 0 && out_norm) { out_norm[0] = norm; out_norm[1] = coef; }
-    for (int i = tid; i < n; i += 1024) {
-        if (mask[i] == 0.f) continue;
-        float gi = g[i];
-        if (max_norm > 0.f) { gi *= coef; g[i] = gi; }          // clip_grad_norm_ scales the gradients in place
-        float pi = p[i];
-        if (weight_decay != 0.f) gi = fmaf(weight_decay, pi, gi);   // Adam's L2 form: grad += wd * param
-        float mi = m[i], vi = v[i];
-        mi = mi + (gi - mi) * omb1;                             // exp_avg.lerp_(grad, 1 - beta1)
-        vi = fmaf(vi, beta2, omb2 * gi * gi);                  // exp_avg_sq.mul_(beta2).addcmul_(grad, grad, 1 - beta2)
-        const float denom = sqrtf(vi) / bc2_sqrt + eps;
-        pi = pi - step_size * (mi / denom);                     // param.addcdiv_(exp_avg, denom, value=-step_size)
-        m[i] = mi; v[i] = vi; p[i] = pi;
+    __syncthreads();
+    if (ticket != gridDim.x - 1) return;
+    __threadfence();
+    double s = 0.0;
+    for (int b = tid; b < (int)gridDim.x; b += ADAM_NT) s += __builtin_nontemporal_load(partial + b);
+    sh[tid] = s;
+    __syncthreads();
+    for (int o = ADAM_NT / 2; o > 0; o >>= 1) {
+        if (tid < o) sh[tid] += sh[tid + o];
+        __syncthreads();
     }
+    if (tid == 0) {
+        const float norm = (float)sqrt(sh[0]);
+        float coef = 1.f;
+        if (max_norm > 0.f) {
+            coef = max_norm / (norm + 1e-6f);
+            coef = coef > 1.f ? 1.f : coef;                // (a NaN norm stays NaN, as torch.clamp leaves it)
+        }
+        out_norm[0] = norm;
+        out_norm[1] = coef;
+        *counter = 0u;
+    }
+}
+
+__global__ __launch_bounds__(ADAM_NT) void k_adam_flat(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m,
+                                                      float* __restrict__ v, const float* __restrict__ mask, int n,
+                                                      int clip, float beta2, float omb1, float omb2, float step_size,
+                                                      float bc2_sqrt, float eps, float weight_decay,
+                                                      const float* __restrict__ norm) {
+    const int i = blockIdx.x * ADAM_NT + threadIdx.x;
+    if (i >= n || mask[i] == 0.f) return;
+    float gi = g[i], pi = p[i], mi = m[i], vi = v[i];
+    if (clip) { gi *= norm[1]; g[i] = gi; }                     // clip_grad_norm_ scales the gradients in place
+    if (weight_decay != 0.f) gi = fmaf(weight_decay, pi, gi);   // Adam's L2 form: grad += wd * param
+    mi = mi + (gi - mi) * omb1;                                 // exp_avg.lerp_(grad, 1 - beta1)
+    vi = fmaf(vi, beta2, omb2 * gi * gi);                       // exp_avg_sq.mul_(beta2).addcmul_(grad, grad, 1 - beta2)
+    const float denom = sqrtf(vi) / bc2_sqrt + eps;
+    pi = pi - step_size * (mi / denom);                         // param.addcdiv_(exp_avg, denom, value=-step_size)
+    m[i] = mi; v[i] = vi; p[i] = pi;
 }
 
 int check() { return (int)hipGetLastError(); }
@@ -4028,9 +4054,12 @@ int saved_to_f32(const float* src, float* dst, long n, hipStream_t s, int bf) {
 
 int clip_adam(float* p, float* g, float* m, float* v, const float* mask, int n, float max_norm, float beta1, float beta2,
               float omb1, float omb2, float step_size, float bc2_sqrt, float eps, float weight_decay, float* out_norm,
-              hipStream_t s) {
-    hipLaunchKernelGGL(k_clip_adam, dim3(1), dim3(1024), 0, s, p, g, m, v, mask, n, max_norm, beta1, beta2, omb1, omb2,
-                       step_size, bc2_sqrt, eps, weight_decay, out_norm);
+              double* partial, unsigned* counter, hipStream_t s) {
+    (void)beta1;
+    const int grid = (n + ADAM_NT - 1) / ADAM_NT;
+    hipLaunchKernelGGL(k_grad_sqsum, dim3(grid), dim3(ADAM_NT), 0, s, g, mask, n, max_norm, partial, counter, out_norm);
+    hipLaunchKernelGGL(k_adam_flat, dim3(grid), dim3(ADAM_NT), 0, s, p, g, m, v, mask, n, max_norm > 0.f ? 1 : 0, beta2,
+                       omb1, omb2, step_size, bc2_sqrt, eps, weight_decay, out_norm);
     return check();
 }
 int add(const float* a, const float* b, float* out, long n, hipStream_t s) {

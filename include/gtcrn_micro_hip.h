@@ -275,17 +275,20 @@ int gtcrn_train_loss(gtcrn_trainer *t, const float *d_pred, long pb, long pf, lo
 int gtcrn_train_loss_strided(gtcrn_trainer *t, const float *d_pred, long pb, long pf, long pt, const float *d_true,
                              long tb, long tf, long tt, int B, int T, float *d_loss, float *d_grad, long gb, long gf,
                              long gt, void *stream);
-/* clip_grad_norm_ + Adam in ONE launch over flat blobs.  Replaces `torch.nn.utils.clip_grad_norm_(self.model.parameters(),
+/* clip_grad_norm_ + Adam over flat blobs in two launches.  Replaces `torch.nn.utils.clip_grad_norm_(self.model.parameters(),
  * clip_grad_norm_value)` + `self.optimizer.step()` (train.py:282-285; Adam(lr) from train.py:90, conf/cfg_train_DNS3.yaml
- * clip 3.0) for a model whose parameters, gradients and Adam moments are views of four blobs in the canonical layout:
- * total 2-norm of the masked gradient (double accumulation, fixed order), gradients scaled in place by
- * min(max_norm / (norm + 1e-6), 1) (max_norm <= 0: no clipping), then torch.optim.Adam's update (no amsgrad; L2
- * weight_decay added to the gradient; bias corrections from `step` >= 1 in double) of every element with d_mask != 0.
- * d_norm_out (optional, 2 floats): the total norm clip_grad_norm_ returns, and the clip coefficient.  The learning-rate
- * schedule stays with the caller (utils/scheduler.py is host scalar arithmetic).  Asynchronous on `stream`. */
+ * clip 3.0) for a model whose parameters, gradients and Adam moments are views of four blobs in the canonical layout
+ * (PyTorch walks the 248 views: ~300 launches per step): total 2-norm of the masked gradient (double accumulation,
+ * fixed order), gradients scaled in place by min(max_norm / (norm + 1e-6), 1) (max_norm <= 0: no clipping), then
+ * torch.optim.Adam's update (no amsgrad; L2 weight_decay added to the gradient; bias corrections from `step` >= 1 in
+ * double) of every element with d_mask != 0.  d_norm_out (optional, 2 floats): the total norm clip_grad_norm_ returns,
+ * and the clip coefficient.  d_workspace: gtcrn_clip_adam_workspace_bytes(n) bytes of device memory, zeroed ONCE by the
+ * caller (it holds the norm's last-workgroup ticket, which every call leaves at zero).  The learning-rate schedule stays
+ * with the caller (utils/scheduler.py is host scalar arithmetic).  Asynchronous on `stream`. */
+long gtcrn_clip_adam_workspace_bytes(long n);
 int gtcrn_clip_adam_step(int device, float *d_params, float *d_grads, float *d_exp_avg, float *d_exp_avg_sq,
                          const float *d_mask, long n, float max_norm, double lr, double beta1, double beta2, double eps,
-                         double weight_decay, long step, float *d_norm_out, void *stream);
+                         double weight_decay, long step, float *d_norm_out, void *d_workspace, void *stream);
 /* Test hook: train-mode activation of the most recent forward at a stage boundary (en0..en4, gtcn1,
  * gtcn2, de0..de4), channels-last (B, T, F, C) in the reference's channel order; shape4 receives
  * the four extents; d_out may be NULL to query the shape. */
