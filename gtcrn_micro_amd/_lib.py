@@ -97,6 +97,8 @@ def lib():
     L.gtcrn_train_workspace_bytes.argtypes = [ci, ci]
     L.gtcrn_train_workspace_bytes2.restype = cl
     L.gtcrn_train_workspace_bytes2.argtypes = [ci, ci, ci]
+    L.gtcrn_trainer_workspace_bytes.restype = cl
+    L.gtcrn_trainer_workspace_bytes.argtypes = [_vp, ci, ci]
     L.gtcrn_trainer_set_storage.argtypes = [_vp, ci]
     L.gtcrn_trainer_set_fusions.argtypes = [_vp, ci]
     L.gtcrn_train_forward.argtypes = [_vp, _vp, _vp, cl, cl, cl, _vp, cl, cl, cl, ci, ci, _vp]
@@ -605,9 +607,15 @@ class Trainer:
         _check(lib().gtcrn_trainer_set_storage(self._h, self.STORAGE[storage]))
         self.storage = storage
 
+    def planned_workspace_bytes(self, B, T):
+        """Workspace of a (B, T) problem with THIS trainer's storage mode and fusion mask (the static
+        ``workspace_bytes`` describes the default mask only)."""
+        return int(_check(lib().gtcrn_trainer_workspace_bytes(self._h, int(B), int(T))))
+
     def set_fusions(self, mask):
-        """Diagnostic (gtcrn_trainer_set_fusions): 1023 = all pass fusions (default), 7 = round 3's (every activation
-        stored, separate skip-gradient adds), 0 = the layer-at-a-time passes."""
+        """Diagnostic (gtcrn_trainer_set_fusions): 2047 = all pass fusions (default), 1023 = without the in-launch finish
+        of the BatchNorm reductions (round 4's), 7 = round 3's (every activation stored, separate skip-gradient adds),
+        0 = the layer-at-a-time passes."""
         _check(lib().gtcrn_trainer_set_fusions(self._h, int(mask)))
 
     def _check_blob(self, blob, what):

@@ -113,13 +113,17 @@ struct gtcrn_trainer {
     size_t arena_floats = 0;
     float* fscratch = nullptr;    // wgrad / TRA partial sums
     double* dscratch = nullptr;   // BatchNorm partial sums
-    int fusions = 1023;                 // gtcrn_trainer_set_fusions: 1 normalise-on-load, 2 depthwise backward, 4 riding reductions,
+    double* fin_gpart = nullptr;  // in-launch finish of the BatchNorm reductions (fusion bit 10): group sums and
+    unsigned* fin_ctr = nullptr;  // arrival counters (zero between launches), see train_kernels.h
+    int fusions = 2047;                 // gtcrn_trainer_set_fusions: 1 normalise-on-load, 2 depthwise backward, 4 riding reductions,
                                       // 8 single-reader activations recomputed in the backward instead of stored,
                                       // 16 skip gradients accumulated in place (no add passes in the backward),
                                       // 32 reductions riding in the adjoint convs of the 3x3 units and of en_convs.1,
                                       // 64 the depthwise 3x3 unit's backward in one LDS-tiled pass, 128 the dense 3x3 unit's,
                                       // 256 point_conv1's BatchNorm + PReLU applied by the LDS-tiled depth convs while staging,
-                                      // 512 the backward of en_convs.1 / de_convs.3 from LDS tiles
+                                      // 512 the backward of en_convs.1 / de_convs.3 from LDS tiles,
+                                      // 1024 the second stage of every BatchNorm reduction in the last workgroup of the
+                                      // kernel that produces its partial sums (no finish launches)
     const void* red_unit = nullptr;   // backward: the unit whose BatchNorm reduction already sits in dscratch ...
     int red_parts = 0;                // ... as this many per-workgroup partial sums (see unit_bwd)
     std::map<std::string, long> off;   // parameter name -> blob offset
@@ -559,6 +563,8 @@ int unit_fwd(gtcrn_trainer* t, Unit& u, float* prm, hipStream_t s) {
         // copies for the backward are second stores -- of the activation by whoever produces it, of the conv output y by
         // whoever CONSUMES it (this unit's bn_act, or the next unit's normalise-on-load conv): centred on this step's
         // mean and kept on the forward's side of the PReLU kink (gtt::BnPre::y_out, bn_act's y2)
+        // (the statistics' second stage runs in the conv kernel's last workgroup when fusion bit 10 is on: parts < 0)
+        const gtt::StatFin sf{u.n, u.C, u.stats, bn + 2 * u.C, bn + 3 * u.C, nullptr, u.stats + 64};
         if (u.pre) {
             const Unit& v = *u.pre;
             const float* vbn = prm + v.o_bn;
@@ -571,20 +577,20 @@ int unit_fwd(gtcrn_trainer* t, Unit& u, float* prm, hipStream_t s) {
             if (u.dw) {
                 DwGeom g = u.dg;
                 g.in_bf = 0; g.out_bf = 0;
-                T_RUN(gtt::dw_fwd(g, v.yc, prm + u.o_w, prm + u.o_b, u.yc, s, t->dscratch, &parts, nullptr, &bp));
+                T_RUN(gtt::dw_fwd(g, v.yc, prm + u.o_w, prm + u.o_b, u.yc, s, t->dscratch, &parts, nullptr, &bp, nullptr, 0, &sf));
             } else {
                 ConvGeom g = u.cg;
                 g.in_bf = 0; g.out_bf = 0;
-                T_RUN(gtt::conv_fwd(g, v.yc, prm + u.o_w, prm + u.o_b, u.yc, s, t->dscratch, &parts, nullptr, &bp));
+                T_RUN(gtt::conv_fwd(g, v.yc, prm + u.o_w, prm + u.o_b, u.yc, s, t->dscratch, &parts, nullptr, &bp, nullptr, 0, &sf));
             }
         } else if (u.dw) {
             DwGeom g = u.dg;
             g.in_bf = 0; g.out_bf = 0;
-            T_RUN(gtt::dw_fwd(g, u.xc, prm + u.o_w, prm + u.o_b, u.yc, s, t->dscratch, &parts));
+            T_RUN(gtt::dw_fwd(g, u.xc, prm + u.o_w, prm + u.o_b, u.yc, s, t->dscratch, &parts, nullptr, nullptr, nullptr, 0, &sf));
         } else {
             ConvGeom g = u.cg;
             g.in_bf = 0; g.out_bf = 0;
-            T_RUN(gtt::conv_fwd(g, u.xc, prm + u.o_w, prm + u.o_b, u.yc, s, t->dscratch, &parts));
+            T_RUN(gtt::conv_fwd(g, u.xc, prm + u.o_w, prm + u.o_b, u.yc, s, t->dscratch, &parts, nullptr, nullptr, nullptr, 0, &sf));
         }
         T_RUN(gtt::bn_stats(u.yc, u.n, u.C, u.stats, bn + 2 * u.C, bn + 3 * u.C, t->dscratch, s, parts, 0, nullptr,
                             u.stats + 64));
@@ -593,6 +599,7 @@ int unit_fwd(gtcrn_trainer* t, Unit& u, float* prm, hipStream_t s) {
                               u.ac, s, 0, 0, u.a, t->bf, u.y, t->ybf));
         return 0;
     }
+    const gtt::StatFin sf{u.n, u.C, u.stats, bn + 2 * u.C, bn + 3 * u.C, shift, nullptr};
     if (u.pre) {
         const Unit& v = *u.pre;
         const float* vbn = prm + v.o_bn;
@@ -604,15 +611,15 @@ int unit_fwd(gtcrn_trainer* t, Unit& u, float* prm, hipStream_t s) {
         if (u.dw) {
             DwGeom g = u.dg;
             g.in_bf = t->ybf;
-            T_RUN(gtt::dw_fwd(g, v.y, prm + u.o_w, prm + u.o_b, u.y, s, t->dscratch, &parts, shift, &bp));
+            T_RUN(gtt::dw_fwd(g, v.y, prm + u.o_w, prm + u.o_b, u.y, s, t->dscratch, &parts, shift, &bp, nullptr, 0, &sf));
         } else {
             ConvGeom g = u.cg;
             g.in_bf = t->ybf;
-            T_RUN(gtt::conv_fwd(g, v.y, prm + u.o_w, prm + u.o_b, u.y, s, t->dscratch, &parts, shift, &bp));
+            T_RUN(gtt::conv_fwd(g, v.y, prm + u.o_w, prm + u.o_b, u.y, s, t->dscratch, &parts, shift, &bp, nullptr, 0, &sf));
         }
     }
-    else if (u.dw) T_RUN(gtt::dw_fwd(u.dg, u.x, prm + u.o_w, prm + u.o_b, u.y, s, t->dscratch, &parts, shift));
-    else T_RUN(gtt::conv_fwd(u.cg, u.x, prm + u.o_w, prm + u.o_b, u.y, s, t->dscratch, &parts, shift));
+    else if (u.dw) T_RUN(gtt::dw_fwd(u.dg, u.x, prm + u.o_w, prm + u.o_b, u.y, s, t->dscratch, &parts, shift, nullptr, nullptr, 0, &sf));
+    else T_RUN(gtt::conv_fwd(u.cg, u.x, prm + u.o_w, prm + u.o_b, u.y, s, t->dscratch, &parts, shift, nullptr, nullptr, 0, &sf));
     T_RUN(gtt::bn_stats(u.y, u.n, u.C, u.stats, bn + 2 * u.C, bn + 3 * u.C, t->dscratch, s, parts, t->ybf, shift));
     if (!u.deferred)
         T_RUN(gtt::bn_act(u.y, u.n, u.C, u.stats, bn, bn + u.C, u.res, u.act, u.o_slope >= 0 ? prm + u.o_slope : nullptr,
@@ -637,6 +644,8 @@ int unit_bwd(gtcrn_trainer* t, Unit& u, const float* prm, float* grads, const fl
         const float* fbn = prm + f->o_bn;
         nx.y = f->y; nx.stats = f->bstats; nx.gamma = fbn; nx.beta = fbn + f->C; nx.slope = prm + f->o_slope;
         nx.res = f->res;
+        // (in-launch finish, fusion bit 10: where that unit's parameter gradients go; the launchers ignore it when off)
+        nx.dgamma = grads + f->o_bn; nx.dbeta = grads + f->o_bn + f->C; nx.dslope = grads + f->o_slope; nx.n = f->n;
         // this unit's input IS that unit's activation (conv3 <- conv2 <- conv1 <- the previous block's conv3,
         // point_conv2 <- depth_conv): recomputed from the y the reduction reads anyway instead of loaded
         if ((t->fusions & 8) && u.x == f->a)
@@ -650,7 +659,7 @@ int unit_bwd(gtcrn_trainer* t, Unit& u, const float* prm, float* grads, const fl
                                grads + u.o_w, u.o_b >= 0 ? grads + u.o_b : nullptr, gbn, gbn + u.C,
                                u.o_slope >= 0 ? grads + u.o_slope : nullptr, t->dscratch, t->fscratch, s, t->bf,
                                t->ybf, have_parts, ride && f->n == u.n ? &nx : nullptr, &parts));
-        if (parts > 0) { t->red_unit = f; t->red_parts = parts; }
+        if (parts != 0) { t->red_unit = f; t->red_parts = parts; }
         return 0;
     }
     if (u.dw && u.C == 16 && u.dg.nkt == 3 && u.dg.nkf == 1 && u.act == gtt::ACT_PRELU && !u.res && u.o_slope >= 0 &&
@@ -661,7 +670,7 @@ int unit_bwd(gtcrn_trainer* t, Unit& u, const float* prm, float* grads, const fl
         T_RUN(gtt::dwunit_bwd(u.dg, u.x, u.y, da, u.bstats, bn, bn + u.C, prm + u.o_slope, prm + u.o_w, dx,
                               grads + u.o_w, u.o_b >= 0 ? grads + u.o_b : nullptr, gbn, gbn + u.C, grads + u.o_slope,
                               t->dscratch, t->fscratch, s, t->bf, t->ybf, ride2 ? &nx : nullptr, &parts, have_parts));
-        if (ride2 && parts > 0) { t->red_unit = f; t->red_parts = parts; }
+        if (ride2 && parts != 0) { t->red_unit = f; t->red_parts = parts; }
         return 0;
     }
     if (u.dw && u.C == 16 && u.dg.nkt == 3 && u.dg.nkf == 3 && u.dg.F == 33 && u.dg.Tin == u.dg.Tout && u.act == gtt::ACT_PRELU &&
@@ -672,7 +681,7 @@ int unit_bwd(gtcrn_trainer* t, Unit& u, const float* prm, float* grads, const fl
         T_RUN(gtt::dwunit33_bwd(u.dg, u.x, u.y, da, u.bstats, bn, bn + u.C, prm + u.o_slope, prm + u.o_w, dx,
                                 grads + u.o_w, u.o_b >= 0 ? grads + u.o_b : nullptr, gbn, gbn + u.C, grads + u.o_slope,
                                 t->dscratch, t->fscratch, s, t->bf, t->ybf, ride3 ? &nx : nullptr, &parts, have_parts));
-        if (ride3 && parts > 0) { t->red_unit = f; t->red_parts = parts; }
+        if (ride3 && parts != 0) { t->red_unit = f; t->red_parts = parts; }
         return 0;
     }
     if (!u.dw && u.cg.nkt == 3 && u.cg.nkf == 3 && u.cg.f_mode == 1 && u.cg.Tout == u.cg.Tin + 2 && u.C == 16 &&
@@ -684,7 +693,7 @@ int unit_bwd(gtcrn_trainer* t, Unit& u, const float* prm, float* grads, const fl
         T_RUN(gtt::dense33_bwd(u.cg, u.x, u.y, da, u.bstats, bn, bn + u.C, prm + u.o_slope, prm + u.o_w, dx, grads + u.o_w,
                                u.o_b >= 0 ? grads + u.o_b : nullptr, gbn, gbn + u.C, grads + u.o_slope, t->dscratch,
                                t->fscratch, s, t->bf, t->ybf, ride3 ? &nx : nullptr, &parts, have_parts));
-        if (ride3 && parts > 0) { t->red_unit = f; t->red_parts = parts; }
+        if (ride3 && parts != 0) { t->red_unit = f; t->red_parts = parts; }
         return 0;
     }
     if (!u.dw && u.cg.nkt == 1 && u.cg.nkf == 5 && u.cg.sf == 2 && u.cg.Cin == 16 && u.cg.Cout == 16 && u.C == 16 &&
@@ -696,7 +705,7 @@ int unit_bwd(gtcrn_trainer* t, Unit& u, const float* prm, float* grads, const fl
         T_RUN(gtt::conv15_bwd(u.cg, u.x, u.y, da, u.bstats, bn, bn + u.C, prm + u.o_slope, prm + u.o_w, dx, dx_acc,
                               grads + u.o_w, u.o_b >= 0 ? grads + u.o_b : nullptr, gbn, gbn + u.C, grads + u.o_slope,
                               t->dscratch, t->fscratch, s, t->bf, t->ybf, ride5 ? &nx : nullptr, &parts, have_parts));
-        if (ride5 && parts > 0) { t->red_unit = f; t->red_parts = parts; }
+        if (ride5 && parts != 0) { t->red_unit = f; t->red_parts = parts; }
         return 0;
     }
     T_RUN(gtt::bn_act_bwd(da, u.y, u.n, u.C, u.bstats, bn, bn + u.C, u.res, u.act,
@@ -722,7 +731,7 @@ int unit_bwd(gtcrn_trainer* t, Unit& u, const float* prm, float* grads, const fl
         if (dx) T_RUN(gtt::conv_fwd(adjoint(u.cg, dx_acc), t->dy, prm + u.o_w, nullptr, dx, s, ride_adj ? t->dscratch : nullptr,
                                     ride_adj ? &parts : nullptr, nullptr, nullptr, ride_adj ? &nx : nullptr, t->ybf));
     }
-    if (ride_adj && parts > 0) { t->red_unit = f; t->red_parts = parts; }
+    if (ride_adj && parts != 0) { t->red_unit = f; t->red_parts = parts; }
     return 0;
 }
 
@@ -775,6 +784,9 @@ int gtcrn_trainer_create(gtcrn_trainer** out, int device) {
     for (const auto& p : gtcrn::param_table()) t->off[p.name] = p.offset;
     hipError_t e = hipMalloc(&t->fscratch, sizeof(float) * gtt::MAX_PARTIALS * (9 * 256 + 16));
     if (e == hipSuccess) e = hipMalloc(&t->dscratch, sizeof(double) * gtt::MAX_PARTIALS * 3 * 16 + 256);
+    if (e == hipSuccess) e = hipMalloc(&t->fin_gpart, sizeof(double) * gtt::FIN_GPART_DOUBLES);
+    if (e == hipSuccess) e = hipMalloc(&t->fin_ctr, sizeof(unsigned) * gtt::FIN_CTR_WORDS);
+    if (e == hipSuccess) e = hipMemset(t->fin_ctr, 0, sizeof(unsigned) * gtt::FIN_CTR_WORDS);
     if (e != hipSuccess) {
         gtcrn_trainer_destroy(t);
         return tfail(GTCRN_ERR_HIP, std::string("gtcrn_trainer_create: hipMalloc: ") + hipGetErrorString(e));
@@ -789,6 +801,8 @@ void gtcrn_trainer_destroy(gtcrn_trainer* t) {
     if (t->arena) (void)hipFree(t->arena);
     if (t->fscratch) (void)hipFree(t->fscratch);
     if (t->dscratch) (void)hipFree(t->dscratch);
+    if (t->fin_gpart) (void)hipFree(t->fin_gpart);
+    if (t->fin_ctr) (void)hipFree(t->fin_ctr);
     if (t->loss_ws) (void)hipFree(t->loss_ws);
     if (t->d_win) (void)hipFree(t->d_win);
     delete t;
@@ -816,6 +830,17 @@ long gtcrn_train_workspace_bytes2(int B, int T, int storage) {
 }
 long gtcrn_train_workspace_bytes(int B, int T) { return gtcrn_train_workspace_bytes2(B, T, 0); }
 
+long gtcrn_trainer_workspace_bytes(gtcrn_trainer* t, int B, int T) {
+    if (!t || B < 1 || T < 1) return -1;
+    gtcrn_trainer tmp;                 // planned with THIS trainer's storage mode and fusion mask (a mask that stores
+    tmp.bf = t->bf;                    // every activation needs about 6 GiB more at B = 512 than the default)
+    tmp.ybf = t->ybf;
+    tmp.exact = t->exact;
+    tmp.fusions = t->fusions;
+    tmp.off = t->off;
+    return (long)(plan(&tmp, B, T, nullptr) * sizeof(float));
+}
+
 int gtcrn_trainer_set_storage(gtcrn_trainer* t, int storage) {
     int bf = 0, ybf = 0;
     if (!t || storage_formats(storage, &bf, &ybf))
@@ -833,7 +858,7 @@ int gtcrn_trainer_set_storage(gtcrn_trainer* t, int storage) {
 }
 
 int gtcrn_trainer_set_fusions(gtcrn_trainer* t, int mask) {
-    if (!t || mask < 0 || mask > 1023) return tfail(GTCRN_ERR_ARG, "gtcrn_trainer_set_fusions: mask must be 0..1023");
+    if (!t || mask < 0 || mask > 2047) return tfail(GTCRN_ERR_ARG, "gtcrn_trainer_set_fusions: mask must be 0..2047");
     if (t->fusions != mask) {
         t->fusions = mask;
         t->planned = false;      // the unit links are laid out again on the next forward
@@ -850,6 +875,10 @@ int gtcrn_train_forward(gtcrn_trainer* t, float* d_params, const float* d_spec, 
     hipStream_t s = (hipStream_t)stream;
     int rc = ensure_plan(t, B, T);
     if (rc) return rc;
+    // in-launch finish of the BatchNorm reductions: this call's context; the arrival counters start at zero whatever a
+    // failed or interrupted call may have left in them
+    gtt::set_fin_context((t->fusions & 1024) != 0, t->fin_gpart, t->fin_ctr);
+    T_HIP(hipMemsetAsync(t->fin_ctr, 0, sizeof(unsigned) * gtt::FIN_CTR_WORDS, s));
     float* prm = d_params;
     const bool ex = t->exact != 0;
     if (ex) T_RUN(gtt::feat_fwd(d_spec, sb, sf, st, B, T, prm + P(t, "erb.erb_fc.weight"), t->ebc, s, 0, t->eb, t->bf));
@@ -920,6 +949,8 @@ int gtcrn_train_backward(gtcrn_trainer* t, const float* d_params, const float* d
     float* G = d_grads;
     int rc;
     T_HIP(hipMemsetAsync(G, 0, sizeof(float) * GTCRN_NPARAM_FLOATS, s));
+    gtt::set_fin_context((t->fusions & 1024) != 0, t->fin_gpart, t->fin_ctr);
+    T_HIP(hipMemsetAsync(t->fin_ctr, 0, sizeof(unsigned) * gtt::FIN_CTR_WORDS, s));
     t->red_unit = nullptr;
     const long n33 = (long)B * T * 33 * 16, n65 = (long)B * T * 65 * 16;
     T_RUN(gtt::bs_mask_bwd(d_grad_out, gb, gf, gt, d_spec, sb, sf, st, B, T, prm + P(t, "erb.ierb_fc.weight"), t->dm, s));

@@ -62,6 +62,22 @@ enum Act { ACT_NONE = 0, ACT_PRELU = 1, ACT_TANH = 2 };
 
 constexpr int MAX_PARTIALS = 1024;   // workgroups of a two-stage reduction
 
+// In-launch finish of the BatchNorm reductions (fusion bit 10): the last workgroup of the kernel that produces the
+// per-workgroup sums also adds them up and evaluates the result (statistics + running estimates in the forward; the
+// means, dgamma, dbeta, dslope in the backward) -- no second-stage kernel (92 of them per step before).  The trainer
+// owns the buffers: FIN_GPART_DOUBLES doubles of group sums and FIN_CTR_WORDS counters that are ZERO between launches
+// (allocated zeroed, reset by the last arrivers, zeroed again at the start of every forward / backward call).
+constexpr int FIN_GPART_DOUBLES = 32 * 64;
+constexpr int FIN_CTR_WORDS = 64;
+void set_fin_context(bool on, double* gpart, unsigned* ctr);      // thread local; on = false: finish kernels as before
+// what the statistics finish of a forward unit needs; given to conv_fwd / dw_fwd (sf), they run it in the producing
+// kernel when the context is on: *stat_parts is then NEGATIVE and bn_stats(have_parts < 0) has nothing left to do
+struct StatFin {
+    long n;
+    int C;
+    float *stats, *running_mean, *running_var, *shift, *stats_b;
+};
+
 // stat_partial/stat_parts (optional): the kernel also leaves per-workgroup sums of out and out^2 per channel
 // (layout of bn_stats' scratch) and reports their count, so the BatchNorm statistics need no extra pass.
 // shift (optional, bf16 output only): out = conv(in) + bias - shift[c]; the following train-mode BatchNorm is shift
@@ -91,14 +107,16 @@ struct DwUnitNext;
 // stat_partial, their count in *stat_parts; next_yfmt: the storage format of that unit's y
 int conv_fwd(const ConvGeom& g, const float* in, const float* w, const float* bias, float* out, hipStream_t s,
              double* stat_partial = nullptr, int* stat_parts = nullptr, const float* shift = nullptr,
-             const BnPre* pre = nullptr, const DwUnitNext* next = nullptr, int next_yfmt = 0);
+             const BnPre* pre = nullptr, const DwUnitNext* next = nullptr, int next_yfmt = 0,
+             const StatFin* sf = nullptr);
 // dW (and db when dbias != nullptr) of the convolution g: in = its input, dout = gradient of its output.
 // scratch: MAX_PARTIALS * (9*256 + 16) floats.
 int conv_wgrad(const ConvGeom& g, const float* in, const float* dout, float* dw, float* dbias, float* scratch,
                hipStream_t s);
 int dw_fwd(const DwGeom& g, const float* in, const float* w, const float* bias, float* out, hipStream_t s,
            double* stat_partial = nullptr, int* stat_parts = nullptr, const float* shift = nullptr,
-           const BnPre* pre = nullptr, const DwUnitNext* next = nullptr, int next_yfmt = 0);
+           const BnPre* pre = nullptr, const DwUnitNext* next = nullptr, int next_yfmt = 0,
+           const StatFin* sf = nullptr);
 int dw_wgrad(const DwGeom& g, const float* in, const float* dout, float* dw, float* dbias, float* scratch,
              hipStream_t s);
 
@@ -127,6 +145,11 @@ struct DwUnitNext {
     // 1 / 2: that unit's activation IS the input x of the unit whose backward runs, and x is recomputed from y (and
     // res) instead of being read (x may then be nullptr); 2: rounded to bf16 as the forward's consumer saw it
     int recompute_x = 0;
+    // in-launch finish (fusion bit 10): where that unit's parameter gradients go and its position count; with n > 0 the
+    // producing kernel's last workgroup also finishes the reduction and *next_parts comes back NEGATIVE (-1 - slot of
+    // the means, see parts_slot in train_kernels.hip): hand it to that unit's backward as have_parts
+    float *dgamma = nullptr, *dbeta = nullptr, *dslope = nullptr;
+    long n = 0;
 };
 // The whole backward of a pointwise (1x1) conv + BatchNorm + activation unit in two passes: the BatchNorm
 // reduction, then ONE kernel that forms dy, the data gradient dx (nullptr: not needed; dx_acc: add) and the

@@ -33,6 +33,143 @@ __device__ __forceinline__ unsigned xcd_block() {
     return (n & 7u) == 0 ? (b & 7u) * (n >> 3) + (b >> 3) : b;
 }
 
+// ------------------------------------------------------------------ in-launch finish of the two-stage reductions
+// Every BatchNorm of a step needs two whole-batch reductions (forward: sum y, sum y^2; backward: sum dz, sum dz xhat, the
+// slope terms).  Their first stage runs inside a streaming kernel (per-workgroup sums of K <= 48 doubles); the second
+// stage used to be a kernel of its own -- 92 launches of 9-11 us per step, one 1024-thread workgroup each, almost all of
+// it load latency over up to 1 024 partials (profiles/r04_train_f32_kernel_stats.csv: k_bn_stats_finish 46 x 11.3 us,
+// k_bn_bwd_finish 46 x 9.5 us: 0.96 ms of a 30 ms step for 0.3 MB of data).  Now the LAST workgroup to finish does it,
+// in two levels so that no workgroup reads more than 32 partials (one latency round of eight loads per thread):
+//   level 1  workgroups are numbered in groups of FIN_G = 32; the last arriver of a group (a ticket from the group's
+//            counter) adds the group's partials -- in index order, the arrival order does not enter the result -- into
+//            one group sum;
+//   level 2  the last group to finish (a ticket from the launch's counter) adds the <= 32 group sums and evaluates the
+//            finish (statistics + running estimates, or the backward's means and parameter gradients).
+// Hand-off between workgroups (cdna_hip_programming.md, guideline 16, counter form): partials and group sums are stored
+// write-through (agent-scope relaxed atomic stores = sc1) by wave 0, which drains them (s_waitcnt vmcnt(0)) before its
+// lane 0 takes the ticket (agent-scope relaxed fetch_add); the reducer reads them with agent-scope relaxed atomic loads
+// (sc1: never from its CU's L1).  No fence, no spin.  The counters are zero between launches: the last arrivers reset
+// them, the trainer zeroes them when it is created and at the start of every forward / backward call.
+// Results are bit-reproducible (fixed order) and equal the former finish kernels' to the last bit of the float they
+// produce except where a double sum rounds differently in its 53rd bit -- the fusion tests compare forwards bit for bit.
+constexpr int FIN_G = 32;            // workgroups per group
+constexpr int FIN_GROUPS = 32;       // MAX_PARTIALS / FIN_G
+static_assert(FIN_G * FIN_GROUPS >= MAX_PARTIALS, "group table too small");
+struct FinArgs {
+    int kind;                        // 0: off (the host launches the finish kernel), 1: forward statistics, 2: backward
+    int C;
+    long n;
+    double* gpart;                   // [FIN_GROUPS][64]
+    unsigned* ctr;                   // [0]: groups finished, [1 + g]: workgroups of group g finished
+    float *o0, *o1, *o2, *o3, *o4;   // kind 1: stats, running_mean, running_var, shift, stats_b; kind 2: red, dgamma, dbeta, dslope
+};
+typedef __attribute__((address_space(1))) unsigned long long gu64_t;
+typedef __attribute__((address_space(1))) unsigned gu32_t;
+__device__ __forceinline__ void st_pub(double* p, double v) {
+    __hip_atomic_store((gu64_t*)p, (unsigned long long)__double_as_longlong(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ double ld_pub(const double* p) {
+    return __longlong_as_double((long long)__hip_atomic_load((gu64_t*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+}
+// statistics of a train-mode BatchNorm from tot[0..C) = sum y, tot[C..2C) = sum y^2 (threads c < C)
+__device__ __forceinline__ void bn_stats_math(const double* tot, long n, int C, float* stats, float* rmean, float* rvar,
+                                              float* shift, float* stats_b) {
+    const int c = threadIdx.x;
+    if (c >= C) return;
+    const double mean = tot[c] / (double)n;
+    double var = tot[C + c] / (double)n - mean * mean;
+    if (var < 0.0) var = 0.0;
+    stats[c] = (float)mean;
+    stats[C + c] = (float)(1.0 / sqrt(var + 1e-5));
+    if (stats_b) {
+        // exact chain: the backward's 16-bit copy of this tensor is written by its consumer as bf16(y - stats[c]):
+        // centred on THIS step's mean, so the backward's statistics for it are mean 0 and the same invstd
+        stats_b[c] = 0.f;
+        stats_b[C + c] = stats[C + c];
+    }
+    if (rmean) {
+        const double unb = n > 1 ? var * (double)n / (double)(n - 1) : var;
+        // shift: the tensor holds y - shift[c], so mean(y) = mean + shift[c]; that becomes the next step's shift
+        const double absmean = (shift && !stats_b) ? mean + (double)shift[c] : mean;
+        rmean[c] = (float)(0.9 * (double)rmean[c] + 0.1 * absmean);
+        if (shift) shift[c] = (float)absmean;
+        rvar[c] = (float)(0.9 * (double)rvar[c] + 0.1 * unb);
+    }
+}
+// first backward pass of a BatchNorm from tot[0..C) = sum dz, tot[C..2C) = sum dz xhat, tot[2C..3C) = slope terms
+__device__ __forceinline__ void bn_bwd_math(const double* tot, long n, int C, float* red, float* dgamma, float* dbeta,
+                                            float* dslope) {
+    const int c = threadIdx.x;
+    if (c < C) {
+        red[c] = (float)(tot[c] / (double)n);
+        red[C + c] = (float)(tot[C + c] / (double)n);
+        if (dgamma) dgamma[c] = (float)tot[C + c];
+        if (dbeta) dbeta[c] = (float)tot[c];
+    }
+    if (c == 0 && dslope) {
+        double t = 0.0;
+        for (int i = 0; i < C; ++i) t += tot[2 * C + i];
+        dslope[0] = (float)t;
+    }
+}
+// sum over q = sl, sl + 4, ... < cnt of src[q * stride + j] (j < K), eight loads in flight, fixed order
+__device__ __forceinline__ double fin_gather(const double* src, int stride, int cnt, int j, int K, int sl) {
+    const int jj = j < K ? j : K - 1;
+    double v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+        const int q = sl + 4 * u;
+        v[u] = ld_pub(src + (long)(q < cnt ? q : cnt - 1) * stride + jj);     // clamped: a valid element, not summed
+    }
+    double s = 0.0;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) s += (sl + 4 * u < cnt) ? v[u] : 0.0;
+    return s;
+}
+// Called by EVERY thread of the workgroup, as its last action, after threads tid < K (wave 0) have stored
+// partial[vb * K + tid] with st_pub.  vb: this workgroup's index in [0, nblk) (any bijection of blockIdx.x).
+__device__ __forceinline__ void fin_reduce(const double* partial, int K, int vb, int nblk, const FinArgs& fa) {
+    __shared__ double f_sh[NT / 64][64];
+    __shared__ double f_tot[64];
+    __shared__ unsigned f_tk;
+    const int tid = threadIdx.x, j = tid & 63, sl = tid >> 6;
+    const int grp = vb / FIN_G, ngrp = (nblk + FIN_G - 1) / FIN_G, g0 = grp * FIN_G;
+    const int gsz = nblk - g0 < FIN_G ? nblk - g0 : FIN_G;
+    if (tid < 64) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // wave 0's partial has left the CU (sc1 stores)
+        if (tid == 0) f_tk = __hip_atomic_fetch_add((gu32_t*)(fa.ctr + 1 + grp), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+    if (f_tk != (unsigned)(gsz - 1)) return;                      // (uniform) not the group's last arriver
+    f_sh[sl][j] = fin_gather(partial + (long)g0 * K, K, gsz, j, K, sl);
+    __syncthreads();
+    if (tid < 64) {
+        if (tid < K) st_pub(fa.gpart + grp * 64 + tid, (f_sh[0][tid] + f_sh[1][tid]) + (f_sh[2][tid] + f_sh[3][tid]));
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (tid == 0) {
+            __hip_atomic_store((gu32_t*)(fa.ctr + 1 + grp), 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            f_tk = __hip_atomic_fetch_add((gu32_t*)fa.ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+    __syncthreads();
+    if (f_tk != (unsigned)(ngrp - 1)) return;                     // not the launch's last group
+    f_sh[sl][j] = fin_gather(fa.gpart, 64, ngrp, j, K, sl);
+    __syncthreads();
+    if (tid < 64) {
+        f_tot[tid] = (f_sh[0][tid] + f_sh[1][tid]) + (f_sh[2][tid] + f_sh[3][tid]);
+        if (tid == 0) __hip_atomic_store((gu32_t*)fa.ctr, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+    if (fa.kind == 1) bn_stats_math(f_tot, fa.n, fa.C, fa.o0, fa.o1, fa.o2, fa.o3, fa.o4);
+    else bn_bwd_math(f_tot, fa.n, fa.C, fa.o0, fa.o1, fa.o2, fa.o3);
+}
+static_assert(NT / 64 == 4, "fin_reduce adds four slices");
+// one partial value: plain store when the host finishes (the finish kernel runs behind a kernel boundary), published otherwise
+__device__ __forceinline__ void st_part(double* p, double v, const FinArgs& fa) {
+    if (fa.kind) st_pub(p, v);
+    else *p = v;
+}
+
 // frequency index of the input tap (ConvGeom); false when the tap falls outside / between samples
 __device__ __forceinline__ bool tap_fi(const ConvGeom& g, int fo, int kf, int& fi) {
     if (g.f_mode == 0) {
@@ -519,7 +656,7 @@ __global__ __launch_bounds__(NT) void k_conv_mfma(ConvGeom g, const float* __res
                                                  const float* __restrict__ w, const float* __restrict__ bias,
                                                  float* __restrict__ out, long tiles_per_wave,
                                                  double* __restrict__ stat_partial, const float* __restrict__ shift,
-                                                 BnPre pre, NextRedArgs nx) {
+                                                 BnPre pre, NextRedArgs nx, FinArgs fa) {
     static_assert(!PRE || (NKT * NKF == 1 && !WIN), "normalise-on-load: pointwise convs only");
     static_assert(!NEXT || (!PRE && !WIN), "riding reduction: plain adjoint launches");
     NextConst nk{};
@@ -644,8 +781,9 @@ __global__ __launch_bounds__(NT) void k_conv_mfma(ConvGeom g, const float* __res
         if (tid < 48) {
             double t = 0.0;
             for (int w2 = 0; w2 < NT / 64; ++w2) t += sRed[w2][tid];
-            stat_partial[(long)blockIdx.x * 48 + tid] = t;
+            st_part(stat_partial + (long)blockIdx.x * 48 + tid, t, fa);
         }
+        if (fa.kind) fin_reduce(stat_partial, 48, blockIdx.x, gridDim.x, fa);
         return;
     }
     if (stat_partial) {
@@ -662,8 +800,9 @@ __global__ __launch_bounds__(NT) void k_conv_mfma(ConvGeom g, const float* __res
             const int which = tid / g.Cout, ch = tid - which * g.Cout;
             double t = 0.0;
             for (int w = 0; w < NT / 64; ++w) t += sStat[w][which * 16 + ch];
-            stat_partial[(long)blockIdx.x * 2 * g.Cout + tid] = t;
+            st_part(stat_partial + (long)blockIdx.x * 2 * g.Cout + tid, t, fa);
         }
+        if (fa.kind) fin_reduce(stat_partial, 2 * g.Cout, blockIdx.x, gridDim.x, fa);
     }
 }
 
@@ -680,7 +819,7 @@ template <int FIN>
 __global__ __launch_bounds__(NT, 4) void k_conv_win_fma(ConvGeom g, const float* __restrict__ in, const float* __restrict__ w,
                                                     const float* __restrict__ bias, float* __restrict__ out,
                                                     double* __restrict__ stat_partial, StrideIter it,
-                                                    const float* __restrict__ shift) {
+                                                    const float* __restrict__ shift, FinArgs fa) {
     __shared__ __attribute__((aligned(16))) float sW[256];   // [j][co], j = kf * Cin + ci
     __shared__ double sStat[NT / 64][32];
     double s1[4] = {0.0, 0.0, 0.0, 0.0}, s2[4] = {0.0, 0.0, 0.0, 0.0};    // in double: see k_conv_mfma
@@ -757,8 +896,9 @@ __global__ __launch_bounds__(NT, 4) void k_conv_win_fma(ConvGeom g, const float*
         if (tid < 32) {
             double t = 0.0;
             for (int w2 = 0; w2 < NT / 64; ++w2) t += sStat[w2][tid];
-            stat_partial[(long)blockIdx.x * 32 + tid] = t;
+            st_part(stat_partial + (long)blockIdx.x * 32 + tid, t, fa);
         }
+        if (fa.kind) fin_reduce(stat_partial, 32, blockIdx.x, gridDim.x, fa);
     }
 }
 
@@ -1121,13 +1261,13 @@ __global__ __launch_bounds__(NT) void k_dw(DwGeom g, const float* __restrict__ i
 // PRE: `in` is the previous unit's conv output (see BnPre); the last temporal / middle frequency tap is the thread's
 // own position (t_off[NKT-1] == 0, f_off[NKF/2] == 0: checked by the launcher) and stores the activation
 template <int NV, int V, class TV>
-__device__ __forceinline__ void block_reduce_store(const TV (&v)[NV][V], int C, double* sh, double* dst);
+__device__ __forceinline__ void block_reduce_store(const TV (&v)[NV][V], int C, double* sh, double* dst, bool pub = false);
 // NEXT: see k_conv_mfma
 template <int NKT, int NKF, int FIN = -1, bool PRE = false, int NEXT = 0>
 __global__ __launch_bounds__(NT) void k_dw16(DwGeom g, const float* __restrict__ in, const float* __restrict__ w,
                                             const float* __restrict__ bias, float* __restrict__ out,
                                             double* __restrict__ stat_partial, StrideIter it,
-                                            const float* __restrict__ shift, BnPre pre, NextRedArgs nx) {
+                                            const float* __restrict__ shift, BnPre pre, NextRedArgs nx, FinArgs fa) {
     const unsigned vb = xcd_block();
     static_assert(!NEXT || (!PRE && NKT > 0), "riding reduction: plain adjoint launches");
     NextConst nk{};
@@ -1223,7 +1363,8 @@ __global__ __launch_bounds__(NT) void k_dw16(DwGeom g, const float* __restrict__
     }
     if constexpr (NEXT) {
         __shared__ double shn[NT];
-        block_reduce_store<3, 4>(vr, 16, shn, stat_partial + (long)vb * 48);
+        block_reduce_store<3, 4>(vr, 16, shn, stat_partial + (long)vb * 48, fa.kind != 0);
+        if (fa.kind) fin_reduce(stat_partial, 48, (int)vb, gridDim.x, fa);
         return;
     }
     if (stat_partial) {   // per-workgroup BatchNorm partial sums; a thread's channel quad is tid & 3
@@ -1236,8 +1377,9 @@ __global__ __launch_bounds__(NT) void k_dw16(DwGeom g, const float* __restrict__
         if (tid < 32) {
             double t = 0.0;
             for (int w = 0; w < NT / 64; ++w) t += sStat[w][tid];
-            stat_partial[(long)vb * 32 + tid] = t;
+            st_part(stat_partial + (long)vb * 32 + tid, t, fa);
         }
+        if (fa.kind) fin_reduce(stat_partial, 32, (int)vb, gridDim.x, fa);
     }
 }
 
@@ -1248,7 +1390,7 @@ __global__ __launch_bounds__(NT) void k_dw16(DwGeom g, const float* __restrict__
 // channels; it accumulates a bounded number of elements in fp32, the per-thread sums are combined in
 // double (workgroup, then across workgroups) in a fixed order.
 template <int NV, int V, class TV>   // NV sums per channel, V channels per thread (vector width); TV float or double
-__device__ __forceinline__ void block_reduce_store(const TV (&v)[NV][V], int C, double* sh, double* dst) {
+__device__ __forceinline__ void block_reduce_store(const TV (&v)[NV][V], int C, double* sh, double* dst, bool pub) {
     const int tid = threadIdx.x, groups = C / V;      // threads with equal (tid % groups) share channels
     if ((groups & (groups - 1)) == 0 && groups <= 32) {
         // lanes first (xor shuffles over the lane bits above the channel group), then the NT/64 waves through LDS.
@@ -1268,7 +1410,8 @@ __device__ __forceinline__ void block_reduce_store(const TV (&v)[NV][V], int C, 
             if (tid < C) {
                 double s = 0.0;
                 for (int w = 0; w < NT / 64; ++w) s += sh[w * C + tid];
-                dst[k * C + tid] = s;
+                if (pub) st_pub(dst + k * C + tid, s);
+                else dst[k * C + tid] = s;
             }
         }
         return;
@@ -1283,14 +1426,15 @@ __device__ __forceinline__ void block_reduce_store(const TV (&v)[NV][V], int C, 
             if (tid < groups) {
                 double s = 0.0;
                 for (int i = tid; i < NT; i += groups) s += sh[i];
-                dst[k * C + tid * V + e] = s;
+                if (pub) st_pub(dst + k * C + tid * V + e, s);
+                else dst[k * C + tid * V + e] = s;
             }
         }
 }
 
 template <int V>
 __global__ __launch_bounds__(NT) void k_bn_stats(const float* __restrict__ y, long total, int C,
-                                                double* __restrict__ partial, int bf) {
+                                                double* __restrict__ partial, int bf, FinArgs fa) {
     __shared__ double sh[NT];
     double v[2][V];    // double from the first addition on: no cancellation in E[y^2] - mean^2 (see k_conv_mfma)
 #pragma unroll
@@ -1302,7 +1446,8 @@ __global__ __launch_bounds__(NT) void k_bn_stats(const float* __restrict__ y, lo
 #pragma unroll
         for (int e = 0; e < V; ++e) { const double a = (double)x[e]; v[0][e] += a; v[1][e] = fma(a, a, v[1][e]); }
     }
-    block_reduce_store<2, V>(v, C, sh, partial + (long)blockIdx.x * 2 * C);
+    block_reduce_store<2, V>(v, C, sh, partial + (long)blockIdx.x * 2 * C, fa.kind != 0);
+    if (fa.kind) fin_reduce(partial, 2 * C, blockIdx.x, gridDim.x, fa);
 }
 
 // sums the per-workgroup partials [nparts][K] (K <= 64 values) with 1024 threads: 64 values x 16 slices
@@ -1320,32 +1465,13 @@ __global__ __launch_bounds__(1024) void k_bn_stats_finish(const double* __restri
                                                          float* __restrict__ stats, float* __restrict__ rmean,
                                                          float* __restrict__ rvar, float* __restrict__ shift,
                                                          float* __restrict__ stats_b) {
+    // (the separate second stage: runs only with the in-launch finish switched off, fusion bit 10)
     __shared__ double sh[16][64];
     __shared__ double tot[64];
     const double s = reduce_partials(partial, nparts, 2 * C, sh);
     if (threadIdx.x < 2 * C) tot[threadIdx.x] = s;
     __syncthreads();
-    const int c = threadIdx.x;
-    if (c >= C) return;
-    const double mean = tot[c] / (double)n;
-    double var = tot[C + c] / (double)n - mean * mean;
-    if (var < 0.0) var = 0.0;
-    stats[c] = (float)mean;
-    stats[C + c] = (float)(1.0 / sqrt(var + 1e-5));
-    if (stats_b) {
-        // exact chain: the backward's 16-bit copy of this tensor is written by its consumer as bf16(y - stats[c]):
-        // centred on THIS step's mean, so the backward's statistics for it are mean 0 and the same invstd
-        stats_b[c] = 0.f;
-        stats_b[C + c] = stats[C + c];
-    }
-    if (rmean) {
-        const double unb = n > 1 ? var * (double)n / (double)(n - 1) : var;
-        // shift: the tensor holds y - shift[c], so mean(y) = mean + shift[c]; that becomes the next step's shift
-        const double absmean = (shift && !stats_b) ? mean + (double)shift[c] : mean;
-        rmean[c] = (float)(0.9 * (double)rmean[c] + 0.1 * absmean);
-        if (shift) shift[c] = (float)absmean;
-        rvar[c] = (float)(0.9 * (double)rvar[c] + 0.1 * unb);
-    }
+    bn_stats_math(tot, n, C, stats, rmean, rvar, shift, stats_b);
 }
 
 __device__ __forceinline__ float act_fwd(float z, int act, float slope) {
@@ -1412,7 +1538,7 @@ __global__ __launch_bounds__(NT) void k_bn_bwd_reduce(const float* __restrict__ 
                                                      const float* __restrict__ gamma, const float* __restrict__ beta,
                                                      const float* __restrict__ res, int act_rt,
                                                      const float* __restrict__ slope, double* __restrict__ partial,
-                                                     int bf_rt, int ybf_rt) {
+                                                     int bf_rt, int ybf_rt, FinArgs fa) {
     const int bf = FMT >= 0 ? FMT / 4 : bf_rt, ybf = FMT >= 0 ? FMT % 4 : ybf_rt, act = ACT >= 0 ? ACT : act_rt;
     __shared__ double sh[NT];
     const float sl = slope ? slope[0] : 0.f;
@@ -1454,7 +1580,8 @@ __global__ __launch_bounds__(NT) void k_bn_bwd_reduce(const float* __restrict__ 
             }
         }
     }
-    block_reduce_store<3, V>(v, C, sh, partial + (long)blockIdx.x * 3 * C);
+    block_reduce_store<3, V>(v, C, sh, partial + (long)blockIdx.x * 3 * C, fa.kind != 0);
+    if (fa.kind) fin_reduce(partial, 3 * C, blockIdx.x, gridDim.x, fa);
 }
 
 __global__ __launch_bounds__(1024) void k_bn_bwd_finish(const double* __restrict__ partial, int nparts, long n, int C,
@@ -1465,18 +1592,7 @@ __global__ __launch_bounds__(1024) void k_bn_bwd_finish(const double* __restrict
     const double s = reduce_partials(partial, nparts, 3 * C, sh);
     if (threadIdx.x < 3 * C) tot[threadIdx.x] = s;
     __syncthreads();
-    const int c = threadIdx.x;
-    if (c < C) {
-        red[c] = (float)(tot[c] / (double)n);
-        red[C + c] = (float)(tot[C + c] / (double)n);
-        if (dgamma) dgamma[c] = (float)tot[C + c];
-        if (dbeta) dbeta[c] = (float)tot[c];
-    }
-    if (c == 0 && dslope) {
-        double t = 0.0;
-        for (int i = 0; i < C; ++i) t += tot[2 * C + i];
-        dslope[0] = (float)t;
-    }
+    bn_bwd_math(tot, n, C, red, dgamma, dbeta, dslope);
 }
 
 // pass 2: dy = gamma * invstd * (dz - mean(dz) - xhat * mean(dz * xhat)); dres (+)= dz
@@ -1657,7 +1773,7 @@ __global__ __launch_bounds__(NT) void k_unit1x1_bwd(ConvGeom g, const float* __r
                                                    BnBwdArgs bn, const float* __restrict__ w,
                                                    float* __restrict__ dx, int dx_acc, float* __restrict__ dres,
                                                    int dres_acc, float* __restrict__ partial, long tiles_per_wave,
-                                                   NextRedArgs nx, double* __restrict__ rpartial) {
+                                                   NextRedArgs nx, double* __restrict__ rpartial, FinArgs fa) {
     constexpr int bf = FMT, ybf = YF;
     __shared__ double sRed[NEXT ? NT / 64 : 1][48];
     f32x4 nmean = {0, 0, 0, 0}, nistd = nmean, ngm = nmean, nbt = nmean;
@@ -1828,8 +1944,9 @@ __global__ __launch_bounds__(NT) void k_unit1x1_bwd(ConvGeom g, const float* __r
         if (tid < 48) {
             double t = 0.0;
             for (int w2 = 0; w2 < NT / 64; ++w2) t += sRed[w2][tid];
-            rpartial[(long)blockIdx.x * 48 + tid] = t;
+            st_part(rpartial + (long)blockIdx.x * 48 + tid, t, fa);
         }
+        if (fa.kind) fin_reduce(rpartial, 48, blockIdx.x, gridDim.x, fa);
     }
 }
 
@@ -1848,7 +1965,7 @@ __global__ __launch_bounds__(NT) void k_dwunit31_bwd(DwGeom g, const float* __re
                                                     const float* __restrict__ da, BnBwdArgs bn,
                                                     const float* __restrict__ w, float* __restrict__ dx,
                                                     double* __restrict__ wpartial, NextRedArgs nx,
-                                                    double* __restrict__ rpartial, StrideIter it) {
+                                                    double* __restrict__ rpartial, StrideIter it, FinArgs fa) {
     const unsigned vb = xcd_block();
     __shared__ double sh[NT];
     const int tid = threadIdx.x, q = tid & 3;
@@ -1955,7 +2072,10 @@ __global__ __launch_bounds__(NT) void k_dwunit31_bwd(DwGeom g, const float* __re
         P.advance(it, g.F, g.Tout);
     }
     block_reduce_store<4, 4>(vw, 16, sh, wpartial + (long)vb * 64);
-    if constexpr (NEXT) block_reduce_store<3, 4>(vr, 16, sh, rpartial + (long)vb * 48);
+    if constexpr (NEXT) {
+        block_reduce_store<3, 4>(vr, 16, sh, rpartial + (long)vb * 48, fa.kind != 0);
+        if (fa.kind) fin_reduce(rpartial, 48, (int)vb, gridDim.x, fa);
+    }
 }
 
 // ---------------------------------------------- depth_conv FORWARD with point_conv1's BatchNorm + PReLU applied while staging
@@ -2008,7 +2128,7 @@ template <int FIN>
 __global__ __launch_bounds__(NT) void k_dw33_fwd_pre(DwGeom g, const float* __restrict__ in, const float* __restrict__ w,
                                                     const float* __restrict__ bias, float* __restrict__ out,
                                                     double* __restrict__ stat_partial, const float* __restrict__ shift,
-                                                    BnPre pre, int tiles_t) {
+                                                    BnPre pre, int tiles_t, FinArgs fa) {
     __shared__ __attribute__((aligned(16))) float sA[F33_ROWS * 35 * 16];
     __shared__ __attribute__((aligned(16))) float sW[9 * 16];       // [tap][c]
     __shared__ double sStat[NT / 64][32];
@@ -2066,8 +2186,9 @@ __global__ __launch_bounds__(NT) void k_dw33_fwd_pre(DwGeom g, const float* __re
         if (tid < 32) {
             double t = 0.0;
             for (int w2 = 0; w2 < NT / 64; ++w2) t += sStat[w2][tid];
-            stat_partial[(long)blockIdx.x * 32 + tid] = t;
+            st_part(stat_partial + (long)blockIdx.x * 32 + tid, t, fa);
         }
+        if (fa.kind) fin_reduce(stat_partial, 32, blockIdx.x, gridDim.x, fa);
     }
 }
 // the decoder's dense transposed 3x3: y[to][fo] = b + sum W[kt][kf] a[to - kt][fo + 1 - kf], T + 2 output frames; per 16 output
@@ -2076,7 +2197,7 @@ template <int FIN>
 __global__ __launch_bounds__(NT) void k_dense33_fwd_pre(ConvGeom g, const float* __restrict__ in, const float* __restrict__ w,
                                                        const float* __restrict__ bias, float* __restrict__ out,
                                                        double* __restrict__ stat_partial, const float* __restrict__ shift,
-                                                       BnPre pre, int tiles_t) {
+                                                       BnPre pre, int tiles_t, FinArgs fa) {
     __shared__ __attribute__((aligned(16))) float sA[F33_ROWS * 35 * 16];
     __shared__ __attribute__((aligned(16))) float sW[9 * 256];      // [tap][co][ci]
     __shared__ double sStat[NT / 64][32];
@@ -2137,8 +2258,9 @@ __global__ __launch_bounds__(NT) void k_dense33_fwd_pre(ConvGeom g, const float*
         if (tid < 32) {
             double t = 0.0;
             for (int w2 = 0; w2 < NT / 64; ++w2) t += sStat[w2][tid];
-            stat_partial[(long)blockIdx.x * 32 + tid] = t;
+            st_part(stat_partial + (long)blockIdx.x * 32 + tid, t, fa);
         }
+        if (fa.kind) fin_reduce(stat_partial, 32, blockIdx.x, gridDim.x, fa);
     }
 }
 
@@ -2159,7 +2281,7 @@ __global__ __launch_bounds__(NT) void k_dwunit33_bwd(DwGeom g, const float* __re
                                                     const float* __restrict__ da, BnBwdArgs bn,
                                                     const float* __restrict__ w, float* __restrict__ dx,
                                                     double* __restrict__ wpartial, NextRedArgs nx,
-                                                    double* __restrict__ rpartial, int tiles_t) {
+                                                    double* __restrict__ rpartial, int tiles_t, FinArgs fa) {
     __shared__ __attribute__((aligned(16))) float sDy[D33_ROWS * 35 * 16];   // row r = frame t0 + r, column 1 + bin
     __shared__ __attribute__((aligned(16))) float sXi[D33_ROWS * 35 * 16];   // row r = frame t0 - 2 + r
     __shared__ double sh[NT];
@@ -2255,7 +2377,10 @@ __global__ __launch_bounds__(NT) void k_dwunit33_bwd(DwGeom g, const float* __re
         }
     }
     block_reduce_store<10, 4>(vw, 16, sh, wpartial + (long)blockIdx.x * 160);
-    if constexpr (NEXT) block_reduce_store<3, 4>(vr, 16, sh, rpartial + (long)blockIdx.x * 48);
+    if constexpr (NEXT) {
+        block_reduce_store<3, 4>(vr, 16, sh, rpartial + (long)blockIdx.x * 48, fa.kind != 0);
+        if (fa.kind) fin_reduce(rpartial, 48, blockIdx.x, gridDim.x, fa);
+    }
 }
 
 // ------------------------------------------ fused backward of the dense transposed 3x3 conv + BatchNorm + PReLU (decoder depth_conv)
@@ -2283,7 +2408,7 @@ __global__ __launch_bounds__(NT) void k_dense33_bwd(ConvGeom g, const float* __r
                                                    const float* __restrict__ da, BnBwdArgs bn,
                                                    const float* __restrict__ w, float* __restrict__ dx,
                                                    float* __restrict__ wpartial, NextRedArgs nx,
-                                                   double* __restrict__ rpartial, int tiles_t) {
+                                                   double* __restrict__ rpartial, int tiles_t, FinArgs fa) {
     extern __shared__ __attribute__((aligned(16))) float smem_d9[];
     float* sDy = smem_d9;                  // row r = dy frame t0 + r, column 1 + bin (pads 0, 34)
     float* sXi = sDy + D9_IMG;             // row r = x frame t0 - 2 + r
@@ -2439,8 +2564,9 @@ __global__ __launch_bounds__(NT) void k_dense33_bwd(ConvGeom g, const float* __r
         if (tid < 48) {
             double t = 0.0;
             for (int w2 = 0; w2 < NT / 64; ++w2) t += sRed[w2][tid];
-            rpartial[(long)blockIdx.x * 48 + tid] = t;
+            st_part(rpartial + (long)blockIdx.x * 48 + tid, t, fa);
         }
+        if (fa.kind) fin_reduce(rpartial, 48, blockIdx.x, gridDim.x, fa);
     }
 }
 
@@ -2464,7 +2590,7 @@ __global__ __launch_bounds__(NT) void k_conv15_bwd(ConvGeom g, const float* __re
                                                   const float* __restrict__ da, BnBwdArgs bn,
                                                   const float* __restrict__ w, float* __restrict__ dx, int dx_acc,
                                                   float* __restrict__ wpartial, NextRedArgs nx,
-                                                  double* __restrict__ rpartial, int tiles_t) {
+                                                  double* __restrict__ rpartial, int tiles_t, FinArgs fa) {
     __shared__ __attribute__((aligned(16))) float sN[C15_NIMG];      // narrow side: column 1 + fn
     __shared__ __attribute__((aligned(16))) float sWd[C15_WIMG];     // wide side: column 2 + fw
     __shared__ __attribute__((aligned(16))) float sWa[5 * 256];      // [kf][ci][co]: A fragments of the data gradient
@@ -2646,8 +2772,9 @@ __global__ __launch_bounds__(NT) void k_conv15_bwd(ConvGeom g, const float* __re
         if (tid < 48) {
             double t = 0.0;
             for (int w2 = 0; w2 < NT / 64; ++w2) t += sRed[w2][tid];
-            rpartial[(long)blockIdx.x * 48 + tid] = t;
+            st_part(rpartial + (long)blockIdx.x * 48 + tid, t, fa);
         }
+        if (fa.kind) fin_reduce(rpartial, 48, blockIdx.x, gridDim.x, fa);
     }
 }
 
@@ -3355,15 +3482,45 @@ __global__ __launch_bounds__(ADAM_NT) void k_adam_flat(float* __restrict__ p, fl
 
 int check() { return (int)hipGetLastError(); }
 
+// ---- in-launch finish: host side.  The trainer hands over its group-sum / counter buffers per call (thread local: one
+// caller thread per trainer); `on` = fusion bit 10.
+struct FinCtx { bool on = false; double* gpart = nullptr; unsigned* ctr = nullptr; };
+thread_local FinCtx g_fin;
+inline FinArgs fin_off() { FinArgs f{}; return f; }
+inline FinArgs fin_stats(const StatFin* sf) {
+    FinArgs f{};
+    if (!g_fin.on || !sf || !g_fin.gpart) return f;
+    f.kind = 1; f.C = sf->C; f.n = sf->n; f.gpart = g_fin.gpart; f.ctr = g_fin.ctr;
+    f.o0 = sf->stats; f.o1 = sf->running_mean; f.o2 = sf->running_var; f.o3 = sf->shift; f.o4 = sf->stats_b;
+    return f;
+}
+inline FinArgs fin_bwd(long n, int C, float* red, float* dgamma, float* dbeta, float* dslope) {
+    FinArgs f{};
+    if (!g_fin.on || !g_fin.gpart || n <= 0) return f;
+    f.kind = 2; f.C = C; f.n = n; f.gpart = g_fin.gpart; f.ctr = g_fin.ctr;
+    f.o0 = red; f.o1 = dgamma; f.o2 = dbeta; f.o3 = dslope;
+    return f;
+}
+// the backward's means live in one of two slots behind the partial sums: a kernel that reads its unit's pair from one slot
+// while its last workgroup writes the NEXT unit's pair uses the other
+inline float* red_slot(double* dscratch, int slot) {
+    return reinterpret_cast<float*>(dscratch + (long)MAX_PARTIALS * 3 * 16) + 32 * slot;
+}
+// have_parts of a backward launcher: > 0 partial sums wait in dscratch (finish kernel needed), 0 nothing yet, < 0 the
+// producing kernel's last workgroup also ran the finish: the pair is in slot -have_parts - 1
+inline int parts_slot(int have_parts) { return have_parts < 0 ? -have_parts - 1 : 0; }
+
 }  // namespace
+
+void set_fin_context(bool on, double* gpart, unsigned* ctr) { g_fin.on = on; g_fin.gpart = gpart; g_fin.ctr = ctr; }
 
 // ====================================================================================== launchers
 // grid of a streaming reduction: a stride that is a multiple of C (NT is), at most MAX_PARTIALS workgroups
 static void launch_bn_bwd_reduce4(int grid, hipStream_t s, const float* da, const float* y, long total, int C,
                                   const float* stats, const float* gamma, const float* beta, const float* res, int act,
-                                  const float* slope, double* partial, int bf, int ybf) {
+                                  const float* slope, double* partial, int bf, int ybf, const FinArgs& fa) {
 #define GT_RED(F, A) hipLaunchKernelGGL((k_bn_bwd_reduce<4, F, A>), dim3(grid), dim3(NT), 0, s, da, y, total, C, stats, \
-                                        gamma, beta, res, act, slope, partial, bf, ybf)
+                                        gamma, beta, res, act, slope, partial, bf, ybf, fa)
     const int f = bf * 4 + ybf;
     if (f == 0 && act == ACT_PRELU) GT_RED(0, ACT_PRELU);
     else if (f == 0 && act == ACT_NONE) GT_RED(0, ACT_NONE);
@@ -3383,6 +3540,32 @@ static int red_grid(long units) {
     if (g > MAX_PARTIALS) g = MAX_PARTIALS;
     return (int)g;
 }
+
+// First pass of a unit's backward (C % 4 == 0): sum dz, sum dz xhat, the slope terms, then the means and dgamma / dbeta /
+// dslope.  Either the kernel that produced da has done all of it (have_parts < 0, in-launch finish), or its partial sums
+// wait in dscratch (have_parts > 0: the finish kernel), or the pass runs now -- with its finish in its own last
+// workgroup when the context is on.  Returns the slot that holds the unit's means (red_slot).
+static int bwd_first_pass(int have_parts, hipStream_t s, const float* da, const float* y, long n, int C, const float* stats,
+                          const float* gamma, const float* beta, const float* res, int act, const float* slope,
+                          double* dscratch, int bf, int ybf, float* dgamma, float* dbeta, float* dslope) {
+    if (have_parts < 0) return parts_slot(have_parts);
+    float* red = red_slot(dscratch, 0);
+    if (have_parts > 0) {
+        hipLaunchKernelGGL(k_bn_bwd_finish, dim3(1), dim3(1024), 0, s, dscratch, have_parts, n, C, red, dgamma, dbeta, dslope);
+        return 0;
+    }
+    const int rgrid = red_grid(n * C / 4);
+    const FinArgs fa = fin_bwd(n, C, red, dgamma, dbeta, dslope);
+    launch_bn_bwd_reduce4(rgrid, s, da, y, n * C, C, stats, gamma, beta, res, act, slope, dscratch, bf, ybf, fa);
+    if (!fa.kind)
+        hipLaunchKernelGGL(k_bn_bwd_finish, dim3(1), dim3(1024), 0, s, dscratch, rgrid, n, C, red, dgamma, dbeta, dslope);
+    return 0;
+}
+// the riding reduction's in-launch finish: that unit's means go into the slot this launch does NOT read
+static FinArgs next_fin(bool nxt, const DwUnitNext* next, double* dscratch, int slot) {
+    return nxt ? fin_bwd(next->n, 16, red_slot(dscratch, 1 - slot), next->dgamma, next->dbeta, next->dslope) : fin_off();
+}
+static int next_parts_value(const FinArgs& nfa, int slot, int grid) { return nfa.kind ? -1 - (1 - slot) : grid; }
 
 static bool mfma_ok(const ConvGeom& g) {
     return (g.Cin % 4) == 0 && (g.Cout % 4) == 0 && (g.CinT % 4) == 0 && (g.CoutT % 4) == 0 && (g.cin_off % 4) == 0 &&
@@ -3412,12 +3595,15 @@ static NextRedArgs next_args(const DwUnitNext* next, int yfmt) {
 }
 int conv_fwd(const ConvGeom& g, const float* in, const float* w, const float* bias, float* out, hipStream_t s,
              double* stat_partial, int* stat_parts, const float* shift, const BnPre* pre, const DwUnitNext* next,
-             int next_yfmt) {
+             int next_yfmt, const StatFin* sf) {
     if (shift && !g.out_bf) return (int)hipErrorInvalidValue;
     if (g.out2) return (int)hipErrorInvalidValue;      // (a second output copy: the 3-channel depthwise conv only)
     if (stat_parts) *stat_parts = 0;
     const BnPre nopre{};
     const NextRedArgs nonx{};
+    // in-launch finish: of this unit's statistics (forward, sf) or of the riding reduction (backward, next->n > 0)
+    const FinArgs fa = next ? fin_bwd(next->n, 16, red_slot(stat_partial, 0), next->dgamma, next->dbeta, next->dslope)
+                            : fin_stats(sf);
     if (next) {
         // a backward launch whose output is the gradient input of the unit `next` (16 channels, PReLU, no residual):
         // that unit's BatchNorm reduction rides in the epilogue -- per-workgroup sums in stat_partial, their count in
@@ -3434,11 +3620,11 @@ int conv_fwd(const ConvGeom& g, const float* in, const float* w, const float* bi
         const NextRedArgs nx = next_args(next, next_yfmt);
         if (next_yfmt < 0 || next_yfmt > 1) return (int)hipErrorInvalidValue;
 #define GT_CN(KT, KF, NX) hipLaunchKernelGGL((k_conv_mfma<KT, KF, 0, false, false, NX>), dim3(grid), dim3(NT), 0, s, g, in, w, bias, \
-                                             out, tpw, stat_partial, shift, nopre, nx)
+                                             out, tpw, stat_partial, shift, nopre, nx, fa)
         if (g.nkt == 3) { if (next_yfmt) GT_CN(3, 3, 2); else GT_CN(3, 3, 1); }
         else { if (next_yfmt) GT_CN(1, 5, 2); else GT_CN(1, 5, 1); }
 #undef GT_CN
-        *stat_parts = grid;
+        *stat_parts = fa.kind ? -1 : grid;           // (folded: that unit's means are in slot 0)
         return check();
     }
     if (pre && g.nkt == 3 && g.nkf == 3) {
@@ -3451,9 +3637,9 @@ int conv_fwd(const ConvGeom& g, const float* in, const float* w, const float* bi
         const int tiles_t = (g.Tout + F33_TF - 1) / F33_TF;
         const long ntiles = (long)g.B * tiles_t;
         const int gridt = (int)(ntiles < MAX_PARTIALS ? ntiles : MAX_PARTIALS);
-        if (g.in_bf == 0) hipLaunchKernelGGL((k_dense33_fwd_pre<0>), dim3(gridt), dim3(NT), 0, s, g, in, w, bias, out, stat_partial, shift, *pre, tiles_t);
-        else hipLaunchKernelGGL((k_dense33_fwd_pre<1>), dim3(gridt), dim3(NT), 0, s, g, in, w, bias, out, stat_partial, shift, *pre, tiles_t);
-        *stat_parts = gridt;
+        if (g.in_bf == 0) hipLaunchKernelGGL((k_dense33_fwd_pre<0>), dim3(gridt), dim3(NT), 0, s, g, in, w, bias, out, stat_partial, shift, *pre, tiles_t, fa);
+        else hipLaunchKernelGGL((k_dense33_fwd_pre<1>), dim3(gridt), dim3(NT), 0, s, g, in, w, bias, out, stat_partial, shift, *pre, tiles_t, fa);
+        *stat_parts = fa.kind ? -gridt : gridt;
         return check();
     }
     if (pre && !(mfma_ok(g) && g.nkt == 1 && g.nkf == 1 && g.sf == 1 && g.Cin == 16 && g.CinT == 16 && g.cin_off == 0 &&
@@ -3465,10 +3651,11 @@ int conv_fwd(const ConvGeom& g, const float* in, const float* w, const float* bi
         double* sp = stat_partial;
         const int g16 = grid_for(units, sp ? MAX_PARTIALS : 16384);
         const StrideIter it = stride_iter((long)g16 * NT / 4, g.Fout, g.Tout);
-        if (g.in_bf == 0) hipLaunchKernelGGL((k_conv_win_fma<0>), dim3(g16), dim3(NT), 0, s, g, in, w, bias, out, sp, it, shift);
-        else if (g.in_bf == 1) hipLaunchKernelGGL((k_conv_win_fma<1>), dim3(g16), dim3(NT), 0, s, g, in, w, bias, out, sp, it, shift);
-        else hipLaunchKernelGGL((k_conv_win_fma<2>), dim3(g16), dim3(NT), 0, s, g, in, w, bias, out, sp, it, shift);
-        if (sp) *stat_parts = g16;
+        const FinArgs fw = sp ? fa : fin_off();
+        if (g.in_bf == 0) hipLaunchKernelGGL((k_conv_win_fma<0>), dim3(g16), dim3(NT), 0, s, g, in, w, bias, out, sp, it, shift, fw);
+        else if (g.in_bf == 1) hipLaunchKernelGGL((k_conv_win_fma<1>), dim3(g16), dim3(NT), 0, s, g, in, w, bias, out, sp, it, shift, fw);
+        else hipLaunchKernelGGL((k_conv_win_fma<2>), dim3(g16), dim3(NT), 0, s, g, in, w, bias, out, sp, it, shift, fw);
+        if (sp) *stat_parts = fw.kind ? -g16 : g16;
         return check();
     }
     const bool win = win_fwd_ok(g);
@@ -3480,27 +3667,28 @@ int conv_fwd(const ConvGeom& g, const float* in, const float* w, const float* bi
         const int grid = (int)((ntiles + tpw * 4 - 1) / (tpw * 4));
         double* sp = (stat_partial && stat_parts && grid <= MAX_PARTIALS && g.cout_off == 0 && g.Cout == g.CoutT &&
                       !g.accumulate) ? stat_partial : nullptr;
+        const FinArgs fm = sp ? fa : fin_off();
 #define GT_CM(KT, KF)                                                                                                  \
     do {                                                                                                               \
-        if (g.in_bf == 0) hipLaunchKernelGGL((k_conv_mfma<KT, KF, 0>), dim3(grid), dim3(NT), 0, s, g, in, w, bias, out, tpw, sp, shift, nopre, nonx); \
-        else if (g.in_bf == 1) hipLaunchKernelGGL((k_conv_mfma<KT, KF, 1>), dim3(grid), dim3(NT), 0, s, g, in, w, bias, out, tpw, sp, shift, nopre, nonx); \
-        else hipLaunchKernelGGL((k_conv_mfma<KT, KF, 2>), dim3(grid), dim3(NT), 0, s, g, in, w, bias, out, tpw, sp, shift, nopre, nonx); \
+        if (g.in_bf == 0) hipLaunchKernelGGL((k_conv_mfma<KT, KF, 0>), dim3(grid), dim3(NT), 0, s, g, in, w, bias, out, tpw, sp, shift, nopre, nonx, fm); \
+        else if (g.in_bf == 1) hipLaunchKernelGGL((k_conv_mfma<KT, KF, 1>), dim3(grid), dim3(NT), 0, s, g, in, w, bias, out, tpw, sp, shift, nopre, nonx, fm); \
+        else hipLaunchKernelGGL((k_conv_mfma<KT, KF, 2>), dim3(grid), dim3(NT), 0, s, g, in, w, bias, out, tpw, sp, shift, nopre, nonx, fm); \
     } while (0)
         if (pre) {
-            if (g.in_bf == 0) hipLaunchKernelGGL((k_conv_mfma<1, 1, 0, false, true>), dim3(grid), dim3(NT), 0, s, g, in, w, bias, out, tpw, sp, shift, *pre, nonx);
-            else if (g.in_bf == 1) hipLaunchKernelGGL((k_conv_mfma<1, 1, 1, false, true>), dim3(grid), dim3(NT), 0, s, g, in, w, bias, out, tpw, sp, shift, *pre, nonx);
-            else hipLaunchKernelGGL((k_conv_mfma<1, 1, 2, false, true>), dim3(grid), dim3(NT), 0, s, g, in, w, bias, out, tpw, sp, shift, *pre, nonx);
+            if (g.in_bf == 0) hipLaunchKernelGGL((k_conv_mfma<1, 1, 0, false, true>), dim3(grid), dim3(NT), 0, s, g, in, w, bias, out, tpw, sp, shift, *pre, nonx, fm);
+            else if (g.in_bf == 1) hipLaunchKernelGGL((k_conv_mfma<1, 1, 1, false, true>), dim3(grid), dim3(NT), 0, s, g, in, w, bias, out, tpw, sp, shift, *pre, nonx, fm);
+            else hipLaunchKernelGGL((k_conv_mfma<1, 1, 2, false, true>), dim3(grid), dim3(NT), 0, s, g, in, w, bias, out, tpw, sp, shift, *pre, nonx, fm);
         }
         else if (win) {
-            if (g.in_bf == 0) hipLaunchKernelGGL((k_conv_mfma<1, 1, 0, true>), dim3(grid), dim3(NT), 0, s, g, in, w, bias, out, tpw, sp, shift, nopre, nonx);
-            else if (g.in_bf == 1) hipLaunchKernelGGL((k_conv_mfma<1, 1, 1, true>), dim3(grid), dim3(NT), 0, s, g, in, w, bias, out, tpw, sp, shift, nopre, nonx);
-            else hipLaunchKernelGGL((k_conv_mfma<1, 1, 2, true>), dim3(grid), dim3(NT), 0, s, g, in, w, bias, out, tpw, sp, shift, nopre, nonx);
+            if (g.in_bf == 0) hipLaunchKernelGGL((k_conv_mfma<1, 1, 0, true>), dim3(grid), dim3(NT), 0, s, g, in, w, bias, out, tpw, sp, shift, nopre, nonx, fm);
+            else if (g.in_bf == 1) hipLaunchKernelGGL((k_conv_mfma<1, 1, 1, true>), dim3(grid), dim3(NT), 0, s, g, in, w, bias, out, tpw, sp, shift, nopre, nonx, fm);
+            else hipLaunchKernelGGL((k_conv_mfma<1, 1, 2, true>), dim3(grid), dim3(NT), 0, s, g, in, w, bias, out, tpw, sp, shift, nopre, nonx, fm);
         }
         else if (g.nkt == 3) GT_CM(3, 3);
         else if (g.nkf == 5) GT_CM(1, 5);
         else GT_CM(1, 1);
 #undef GT_CM
-        if (sp) *stat_parts = grid;
+        if (sp) *stat_parts = fm.kind ? -grid : grid;
         return check();
     }
     const int grid = grid_for((long)g.B * g.Tout * g.Fout);
@@ -3569,12 +3757,14 @@ int conv_wgrad(const ConvGeom& g, const float* in, const float* dout, float* dw,
 
 int dw_fwd(const DwGeom& g, const float* in, const float* w, const float* bias, float* out, hipStream_t s,
            double* stat_partial, int* stat_parts, const float* shift, const BnPre* pre, const DwUnitNext* next,
-           int next_yfmt) {
+           int next_yfmt, const StatFin* sf) {
     if (shift && (!g.out_bf || g.C != 16)) return (int)hipErrorInvalidValue;
     if (g.out2 && (g.out_bf || g.accumulate || g.C != 3)) return (int)hipErrorInvalidValue;
     if (stat_parts) *stat_parts = 0;
     const BnPre nopre{};
     const NextRedArgs nonx{};
+    const FinArgs fa = next ? fin_bwd(next->n, 16, red_slot(stat_partial, 0), next->dgamma, next->dbeta, next->dslope)
+                            : fin_stats(sf);            // see conv_fwd
     if (next) {      // see conv_fwd
         if (!stat_partial || !stat_parts || pre || shift || next->res || !next->slope || g.C != 16 || g.nkt != 3 ||
             g.nkf != 3 || g.in_bf != 0 || g.out_bf != 0 || g.Tin != g.Tout)
@@ -3584,11 +3774,11 @@ int dw_fwd(const DwGeom& g, const float* in, const float* w, const float* bias, 
         if (next_yfmt < 0 || next_yfmt > 1) return (int)hipErrorInvalidValue;
         if (next_yfmt)
             hipLaunchKernelGGL((k_dw16<3, 3, 0, false, 2>), dim3(g16), dim3(NT), 0, s, g, in, w, bias, out, stat_partial, it,
-                               shift, nopre, next_args(next, next_yfmt));
+                               shift, nopre, next_args(next, next_yfmt), fa);
         else
             hipLaunchKernelGGL((k_dw16<3, 3, 0, false, 1>), dim3(g16), dim3(NT), 0, s, g, in, w, bias, out, stat_partial, it,
-                               shift, nopre, next_args(next, next_yfmt));
-        *stat_parts = g16;
+                               shift, nopre, next_args(next, next_yfmt), fa);
+        *stat_parts = fa.kind ? -1 : g16;
         return check();
     }
     if (pre && g.C == 16 && g.nkt == 3 && g.nkf == 3) {
@@ -3600,9 +3790,9 @@ int dw_fwd(const DwGeom& g, const float* in, const float* w, const float* bias, 
         const int tiles_t = (g.Tout + F33_TF - 1) / F33_TF;
         const long ntiles = (long)g.B * tiles_t;
         const int gridt = (int)(ntiles < MAX_PARTIALS ? ntiles : MAX_PARTIALS);
-        if (g.in_bf == 0) hipLaunchKernelGGL((k_dw33_fwd_pre<0>), dim3(gridt), dim3(NT), 0, s, g, in, w, bias, out, stat_partial, shift, *pre, tiles_t);
-        else hipLaunchKernelGGL((k_dw33_fwd_pre<1>), dim3(gridt), dim3(NT), 0, s, g, in, w, bias, out, stat_partial, shift, *pre, tiles_t);
-        *stat_parts = gridt;
+        if (g.in_bf == 0) hipLaunchKernelGGL((k_dw33_fwd_pre<0>), dim3(gridt), dim3(NT), 0, s, g, in, w, bias, out, stat_partial, shift, *pre, tiles_t, fa);
+        else hipLaunchKernelGGL((k_dw33_fwd_pre<1>), dim3(gridt), dim3(NT), 0, s, g, in, w, bias, out, stat_partial, shift, *pre, tiles_t, fa);
+        *stat_parts = fa.kind ? -gridt : gridt;
         return check();
     }
     if (pre && !(g.C == 16 && g.nkt == 3 && g.nkf == 1 && g.t_off[2] == 0 && g.f_off[0] == 0 && g.in_bf == pre->ybf &&
@@ -3611,25 +3801,26 @@ int dw_fwd(const DwGeom& g, const float* in, const float* w, const float* bias, 
     const int grid = grid_for((long)g.B * g.Tout * g.F);
     if (g.C == 16) {
         double* sp = (stat_partial && stat_parts && !g.accumulate) ? stat_partial : nullptr;
+        const FinArgs fd = sp ? fa : fin_off();
         const int g16 = grid_for((long)g.B * g.Tout * g.F * 4, sp ? MAX_PARTIALS : 16384);
         if (g.Tin != g.Tout) return (int)hipErrorInvalidValue;
         const StrideIter it = stride_iter((long)g16 * NT / 4, g.F, g.Tout);
 #define GT_DW(KT, KF)                                                                                                   \
     do {                                                                                                               \
-        if (g.in_bf == 0) hipLaunchKernelGGL((k_dw16<KT, KF, 0>), dim3(g16), dim3(NT), 0, s, g, in, w, bias, out, sp, it, shift, nopre, nonx); \
-        else if (g.in_bf == 1) hipLaunchKernelGGL((k_dw16<KT, KF, 1>), dim3(g16), dim3(NT), 0, s, g, in, w, bias, out, sp, it, shift, nopre, nonx); \
-        else hipLaunchKernelGGL((k_dw16<KT, KF, -1>), dim3(g16), dim3(NT), 0, s, g, in, w, bias, out, sp, it, shift, nopre, nonx); \
+        if (g.in_bf == 0) hipLaunchKernelGGL((k_dw16<KT, KF, 0>), dim3(g16), dim3(NT), 0, s, g, in, w, bias, out, sp, it, shift, nopre, nonx, fd); \
+        else if (g.in_bf == 1) hipLaunchKernelGGL((k_dw16<KT, KF, 1>), dim3(g16), dim3(NT), 0, s, g, in, w, bias, out, sp, it, shift, nopre, nonx, fd); \
+        else hipLaunchKernelGGL((k_dw16<KT, KF, -1>), dim3(g16), dim3(NT), 0, s, g, in, w, bias, out, sp, it, shift, nopre, nonx, fd); \
     } while (0)
         if (pre) {
-            if (g.in_bf == 0) hipLaunchKernelGGL((k_dw16<3, 1, 0, true>), dim3(g16), dim3(NT), 0, s, g, in, w, bias, out, sp, it, shift, *pre, nonx);
-            else hipLaunchKernelGGL((k_dw16<3, 1, 1, true>), dim3(g16), dim3(NT), 0, s, g, in, w, bias, out, sp, it, shift, *pre, nonx);
+            if (g.in_bf == 0) hipLaunchKernelGGL((k_dw16<3, 1, 0, true>), dim3(g16), dim3(NT), 0, s, g, in, w, bias, out, sp, it, shift, *pre, nonx, fd);
+            else hipLaunchKernelGGL((k_dw16<3, 1, 1, true>), dim3(g16), dim3(NT), 0, s, g, in, w, bias, out, sp, it, shift, *pre, nonx, fd);
         }
         else if (g.nkt == 3 && g.nkf == 3) GT_DW(3, 3);
         else if (g.nkt == 3 && g.nkf == 1) GT_DW(3, 1);
 #undef GT_DW
         else
-            hipLaunchKernelGGL((k_dw16<0, 0>), dim3(g16), dim3(NT), 0, s, g, in, w, bias, out, sp, it, shift, nopre, nonx);
-        if (sp) *stat_parts = g16;
+            hipLaunchKernelGGL((k_dw16<0, 0>), dim3(g16), dim3(NT), 0, s, g, in, w, bias, out, sp, it, shift, nopre, nonx, fd);
+        if (sp) *stat_parts = fd.kind ? -g16 : g16;
         return check();
     }
     else if (g.C == 3) hipLaunchKernelGGL((k_dw<3>), dim3(grid), dim3(NT), 0, s, g, in, w, bias, out);
@@ -3671,21 +3862,26 @@ int dw_wgrad(const DwGeom& g, const float* in, const float* dout, float* dw, flo
 int bn_stats(const float* y, long n, int C, float* stats, float* running_mean, float* running_var, double* scratch,
              hipStream_t s, int have_parts, int bf, float* shifted, float* stats_b) {
     const long total = n * C;
+    if (have_parts < 0) return 0;    // the producing conv's last workgroup finished the statistics (in-launch finish)
     if (have_parts > 0) {     // the producing conv already left its per-workgroup sums in scratch
         hipLaunchKernelGGL(k_bn_stats_finish, dim3(1), dim3(1024), 0, s, scratch, have_parts, n, C, stats, running_mean,
                            running_var, shifted, stats_b);
         return check();
     }
+    const StatFin sf{n, C, stats, running_mean, running_var, shifted, stats_b};
+    const FinArgs fa = fin_stats(&sf);
     if (C % 4 == 0) {
         const int grid = red_grid(total / 4);
-        hipLaunchKernelGGL((k_bn_stats<4>), dim3(grid), dim3(NT), 0, s, y, total, C, scratch, bf);
-        hipLaunchKernelGGL(k_bn_stats_finish, dim3(1), dim3(1024), 0, s, scratch, grid, n, C, stats, running_mean, running_var,
-                           shifted, stats_b);
+        hipLaunchKernelGGL((k_bn_stats<4>), dim3(grid), dim3(NT), 0, s, y, total, C, scratch, bf, fa);
+        if (!fa.kind)
+            hipLaunchKernelGGL(k_bn_stats_finish, dim3(1), dim3(1024), 0, s, scratch, grid, n, C, stats, running_mean,
+                               running_var, shifted, stats_b);
     } else {
         const int grid = red_grid(total);
-        hipLaunchKernelGGL((k_bn_stats<1>), dim3(grid), dim3(NT), 0, s, y, total, C, scratch, bf);
-        hipLaunchKernelGGL(k_bn_stats_finish, dim3(1), dim3(1024), 0, s, scratch, grid, n, C, stats, running_mean, running_var,
-                           shifted, stats_b);
+        hipLaunchKernelGGL((k_bn_stats<1>), dim3(grid), dim3(NT), 0, s, y, total, C, scratch, bf, fa);
+        if (!fa.kind)
+            hipLaunchKernelGGL(k_bn_stats_finish, dim3(1), dim3(1024), 0, s, scratch, grid, n, C, stats, running_mean,
+                               running_var, shifted, stats_b);
     }
     return check();
 }
@@ -3708,20 +3904,20 @@ int bn_act_bwd(const float* da, const float* y, long n, int C, const float* stat
                int dres_acc, float* dgamma, float* dbeta, float* dslope, double* scratch, hipStream_t s, int bf,
                int ybf, int have_parts) {
     const long total = n * C;
-    float* red = reinterpret_cast<float*>(scratch + (long)MAX_PARTIALS * 3 * 16);
     if (C % 4 == 0) {
-        const int grid = have_parts > 0 ? have_parts : red_grid(total / 4);
-        if (have_parts <= 0)
-            launch_bn_bwd_reduce4(grid, s, da, y, total, C, stats, gamma, beta, res, act, slope, scratch, bf, ybf);
-        hipLaunchKernelGGL(k_bn_bwd_finish, dim3(1), dim3(1024), 0, s, scratch, grid, n, C, red, dgamma, dbeta, dslope);
+        const int slot = bwd_first_pass(have_parts, s, da, y, n, C, stats, gamma, beta, res, act, slope, scratch, bf, ybf,
+                                        dgamma, dbeta, dslope);
         // the apply pass keeps per-thread channel constants: its stride must be a multiple of C as well
         hipLaunchKernelGGL((k_bn_bwd_apply<4>), dim3(grid_for(total / 4, 8192)), dim3(NT), 0, s, da, y, total, C, stats,
-                           gamma, beta, res, act, slope, red, dy, dres, dres_acc, bf, ybf);
+                           gamma, beta, res, act, slope, red_slot(scratch, slot), dy, dres, dres_acc, bf, ybf);
     } else {
+        float* red = red_slot(scratch, 0);
         const int grid = red_grid(total);
+        const FinArgs fa = fin_bwd(n, C, red, dgamma, dbeta, dslope);
         hipLaunchKernelGGL((k_bn_bwd_reduce<1>), dim3(grid), dim3(NT), 0, s, da, y, total, C, stats, gamma, beta, res,
-                           act, slope, scratch, bf, ybf);
-        hipLaunchKernelGGL(k_bn_bwd_finish, dim3(1), dim3(1024), 0, s, scratch, grid, n, C, red, dgamma, dbeta, dslope);
+                           act, slope, scratch, bf, ybf, fa);
+        if (!fa.kind)
+            hipLaunchKernelGGL(k_bn_bwd_finish, dim3(1), dim3(1024), 0, s, scratch, grid, n, C, red, dgamma, dbeta, dslope);
         hipLaunchKernelGGL((k_bn_bwd_apply<1>), dim3(grid_for(total, 8192)), dim3(NT), 0, s, da, y, total, C, stats,
                            gamma, beta, res, act, slope, red, dy, dres, dres_acc, bf, ybf);
     }
@@ -3738,11 +3934,9 @@ int dwunit_bwd(const DwGeom& g, const float* x, const float* y, const float* da,
         g.Tin != g.Tout || !slope || !dx || bf > 1 || ybf > 1 || bf != ybf)
         return (int)hipErrorInvalidValue;
     const long n = (long)g.B * g.Tout * g.F, total = n * 16;
-    float* red = reinterpret_cast<float*>(dscratch + (long)MAX_PARTIALS * 3 * 16);
-    const int rgrid = have_parts > 0 ? have_parts : red_grid(total / 4);
-    if (have_parts <= 0)
-        launch_bn_bwd_reduce4(rgrid, s, da, y, total, 16, stats, gamma, beta, nullptr, ACT_PRELU, slope, dscratch, bf, ybf);
-    hipLaunchKernelGGL(k_bn_bwd_finish, dim3(1), dim3(1024), 0, s, dscratch, rgrid, n, 16, red, dgamma, dbeta, dslope);
+    const int slot = bwd_first_pass(have_parts, s, da, y, n, 16, stats, gamma, beta, nullptr, ACT_PRELU, slope, dscratch, bf, ybf,
+                                    dgamma, dbeta, dslope);
+    float* red = red_slot(dscratch, slot);
     // 164 VGPRs: three workgroups per CU -- a grid of 3 x 256 keeps every workgroup resident (with 1024 the last 256
     // would run alone at a third of the occupancy)
     const int grid = red_grid(total / 4) > 768 ? 768 : red_grid(total / 4);
@@ -3754,17 +3948,18 @@ int dwunit_bwd(const DwGeom& g, const float* x, const float* y, const float* da,
     const bool xr = nxt && next->recompute_x;
     if (!x && !xr) return (int)hipErrorInvalidValue;
     if (nxt) nx = NextRedArgs{next->y, next->stats, next->gamma, next->beta, next->slope, nullptr, next->recompute_x == 2};
+    const FinArgs nfa = next_fin(nxt, next, dscratch, slot);
 #define GT_DU(F)                                                                                                        \
     do {                                                                                                               \
-        if (xr) hipLaunchKernelGGL((k_dwunit31_bwd<F, F, true, true>), dim3(grid), dim3(NT), 0, s, g, x, y, da, bn, w, dx, wpart, nx, dscratch, it); \
-        else if (nxt) hipLaunchKernelGGL((k_dwunit31_bwd<F, F, true>), dim3(grid), dim3(NT), 0, s, g, x, y, da, bn, w, dx, wpart, nx, dscratch, it); \
-        else hipLaunchKernelGGL((k_dwunit31_bwd<F, F, false>), dim3(grid), dim3(NT), 0, s, g, x, y, da, bn, w, dx, wpart, nx, dscratch, it); \
+        if (xr) hipLaunchKernelGGL((k_dwunit31_bwd<F, F, true, true>), dim3(grid), dim3(NT), 0, s, g, x, y, da, bn, w, dx, wpart, nx, dscratch, it, nfa); \
+        else if (nxt) hipLaunchKernelGGL((k_dwunit31_bwd<F, F, true>), dim3(grid), dim3(NT), 0, s, g, x, y, da, bn, w, dx, wpart, nx, dscratch, it, nfa); \
+        else hipLaunchKernelGGL((k_dwunit31_bwd<F, F, false>), dim3(grid), dim3(NT), 0, s, g, x, y, da, bn, w, dx, wpart, nx, dscratch, it, nfa); \
     } while (0)
     if (bf == 0) GT_DU(0);
     else GT_DU(1);
 #undef GT_DU
     hipLaunchKernelGGL(k_dw_wgrad_finish2, dim3(1), dim3(1024), 0, s, g, wpart, grid, dw, dbias);
-    if (nxt && next_parts) *next_parts = grid;
+    if (nxt && next_parts) *next_parts = next_parts_value(nfa, slot, grid);
     return check();
 }
 
@@ -3777,12 +3972,10 @@ int dwunit33_bwd(const DwGeom& g, const float* x, const float* y, const float* d
         g.f_off[0] != -1 || g.f_off[1] != 0 || g.f_off[2] != 1 || g.Tin != g.Tout || !slope || !dx || bf > 1 || ybf > 1 ||
         bf != ybf)
         return (int)hipErrorInvalidValue;
-    const long n = (long)g.B * g.Tout * g.F, total = n * 16;
-    float* red = reinterpret_cast<float*>(dscratch + (long)MAX_PARTIALS * 3 * 16);
-    const int rgrid = have_parts > 0 ? have_parts : red_grid(total / 4);
-    if (have_parts <= 0)
-        launch_bn_bwd_reduce4(rgrid, s, da, y, total, 16, stats, gamma, beta, nullptr, ACT_PRELU, slope, dscratch, bf, ybf);
-    hipLaunchKernelGGL(k_bn_bwd_finish, dim3(1), dim3(1024), 0, s, dscratch, rgrid, n, 16, red, dgamma, dbeta, dslope);
+    const long n = (long)g.B * g.Tout * g.F;
+    const int slot = bwd_first_pass(have_parts, s, da, y, n, 16, stats, gamma, beta, nullptr, ACT_PRELU, slope, dscratch, bf, ybf,
+                                    dgamma, dbeta, dslope);
+    float* red = red_slot(dscratch, slot);
     const int tiles_t = (g.Tout + D33_TF - 1) / D33_TF;
     const long ntiles = (long)g.B * tiles_t;
     // 64 KB of LDS: two workgroups per CU, 512 resident -- whole rounds of them
@@ -3794,17 +3987,18 @@ int dwunit33_bwd(const DwGeom& g, const float* x, const float* y, const float* d
     const bool xr = nxt && next->recompute_x;
     if (!x && !xr) return (int)hipErrorInvalidValue;
     if (nxt) nx = NextRedArgs{next->y, next->stats, next->gamma, next->beta, next->slope, nullptr, next->recompute_x == 2, ybf};
+    const FinArgs nfa = next_fin(nxt, next, dscratch, slot);
 #define GT_D33(F)                                                                                                       \
     do {                                                                                                               \
-        if (xr) hipLaunchKernelGGL((k_dwunit33_bwd<F, F, true, true>), dim3(grid), dim3(NT), 0, s, g, x, y, da, bn, w, dx, wpart, nx, dscratch, tiles_t); \
-        else if (nxt) hipLaunchKernelGGL((k_dwunit33_bwd<F, F, true>), dim3(grid), dim3(NT), 0, s, g, x, y, da, bn, w, dx, wpart, nx, dscratch, tiles_t); \
-        else hipLaunchKernelGGL((k_dwunit33_bwd<F, F, false>), dim3(grid), dim3(NT), 0, s, g, x, y, da, bn, w, dx, wpart, nx, dscratch, tiles_t); \
+        if (xr) hipLaunchKernelGGL((k_dwunit33_bwd<F, F, true, true>), dim3(grid), dim3(NT), 0, s, g, x, y, da, bn, w, dx, wpart, nx, dscratch, tiles_t, nfa); \
+        else if (nxt) hipLaunchKernelGGL((k_dwunit33_bwd<F, F, true>), dim3(grid), dim3(NT), 0, s, g, x, y, da, bn, w, dx, wpart, nx, dscratch, tiles_t, nfa); \
+        else hipLaunchKernelGGL((k_dwunit33_bwd<F, F, false>), dim3(grid), dim3(NT), 0, s, g, x, y, da, bn, w, dx, wpart, nx, dscratch, tiles_t, nfa); \
     } while (0)
     if (bf == 0) GT_D33(0);
     else GT_D33(1);
 #undef GT_D33
     hipLaunchKernelGGL(k_dw_wgrad_finish2, dim3((160 + 63) / 64), dim3(1024), 0, s, g, wpart, grid, dw, dbias);
-    if (nxt && next_parts) *next_parts = grid;
+    if (nxt && next_parts) *next_parts = next_parts_value(nfa, slot, grid);
     return check();
 }
 
@@ -3818,12 +4012,10 @@ int dense33_bwd(const ConvGeom& g, const float* x, const float* y, const float* 
         g.pf != 1 || g.Fin != 33 || g.Fout != 33 || g.Cin != 16 || g.CinT != 16 || g.cin_off != 0 || g.Cout != 16 ||
         g.CoutT != 16 || g.cout_off != 0 || g.Tout != g.Tin + 2 || !slope || !dx || bf > 1 || ybf > 1 || bf != ybf)
         return (int)hipErrorInvalidValue;
-    const long n = (long)g.B * g.Tout * g.Fout, total = n * 16;
-    float* red = reinterpret_cast<float*>(dscratch + (long)MAX_PARTIALS * 3 * 16);
-    const int rgrid = have_parts > 0 ? have_parts : red_grid(total / 4);
-    if (have_parts <= 0)
-        launch_bn_bwd_reduce4(rgrid, s, da, y, total, 16, stats, gamma, beta, nullptr, ACT_PRELU, slope, dscratch, bf, ybf);
-    hipLaunchKernelGGL(k_bn_bwd_finish, dim3(1), dim3(1024), 0, s, dscratch, rgrid, n, 16, red, dgamma, dbeta, dslope);
+    const long n = (long)g.B * g.Tout * g.Fout;
+    const int slot = bwd_first_pass(have_parts, s, da, y, n, 16, stats, gamma, beta, nullptr, ACT_PRELU, slope, dscratch, bf, ybf,
+                                    dgamma, dbeta, dslope);
+    float* red = red_slot(dscratch, slot);
     const int tiles_t = (g.Tout + D9_TF - 1) / D9_TF;
     const long ntiles = (long)g.B * tiles_t;
     const int grid = (int)(ntiles < 512 ? ntiles : 512);           // 72 KB of LDS: two workgroups per CU, all resident
@@ -3833,6 +4025,7 @@ int dense33_bwd(const ConvGeom& g, const float* x, const float* y, const float* 
     const bool xr = nxt && next->recompute_x;
     if (!x && !xr) return (int)hipErrorInvalidValue;
     if (nxt) nx = NextRedArgs{next->y, next->stats, next->gamma, next->beta, next->slope, nullptr, next->recompute_x == 2, ybf};
+    const FinArgs nfa = next_fin(nxt, next, dscratch, slot);
     // (the attribute belongs to the current device's copy of the kernel: set on every launch -- a host-side table lookup --
     // rather than remembered per process, which would miss a second device)
 #define GT_D9(F, NXV, XRV, SLOT)                                                                                        \
@@ -3841,14 +4034,14 @@ int dense33_bwd(const ConvGeom& g, const float* x, const float* y, const float* 
                                             hipFuncAttributeMaxDynamicSharedMemorySize, D9_LDS_FLOATS * 4);             \
         if (e_ != hipSuccess) return (int)e_;                                                                          \
         hipLaunchKernelGGL((k_dense33_bwd<F, F, NXV, XRV>), dim3(grid), dim3(NT), D9_LDS_FLOATS * 4, s, g, x, y, da, bn, w, dx, \
-                           fscratch, nx, dscratch, tiles_t);                                                           \
+                           fscratch, nx, dscratch, tiles_t, nfa);                                                      \
     } while (0)
     if (bf == 0) { if (xr) GT_D9(0, true, true, 4); else if (nxt) GT_D9(0, true, false, 0); else GT_D9(0, false, false, 1); }
     else { if (xr) GT_D9(1, true, true, 5); else if (nxt) GT_D9(1, true, false, 2); else GT_D9(1, false, false, 3); }
 #undef GT_D9
     const int K = 9 * 256 + 16;
     hipLaunchKernelGGL(k_wgrad_mfma_finish, dim3((K + 63) / 64), dim3(1024), 0, s, g, fscratch, grid, dw, dbias);
-    if (nxt && next_parts) *next_parts = grid;
+    if (nxt && next_parts) *next_parts = next_parts_value(nfa, slot, grid);
     return check();
 }
 
@@ -3862,12 +4055,10 @@ int conv15_bwd(const ConvGeom& g, const float* x, const float* y, const float* d
         g.Cout != 16 || g.CoutT != 16 || g.cout_off != 0 || g.Tin != g.Tout || g.Fin != (dyw ? 33 : 65) || g.Fout != (dyw ? 65 : 33) ||
         !slope || !dx || !x || bf > 1 || ybf > 1 || bf != ybf || (next && dyw))
         return (int)hipErrorInvalidValue;
-    const long n = (long)g.B * g.Tout * g.Fout, total = n * 16;
-    float* red = reinterpret_cast<float*>(dscratch + (long)MAX_PARTIALS * 3 * 16);
-    const int rgrid = have_parts > 0 ? have_parts : red_grid(total / 4);
-    if (have_parts <= 0)
-        launch_bn_bwd_reduce4(rgrid, s, da, y, total, 16, stats, gamma, beta, nullptr, ACT_PRELU, slope, dscratch, bf, ybf);
-    hipLaunchKernelGGL(k_bn_bwd_finish, dim3(1), dim3(1024), 0, s, dscratch, rgrid, n, 16, red, dgamma, dbeta, dslope);
+    const long n = (long)g.B * g.Tout * g.Fout;
+    const int slot = bwd_first_pass(have_parts, s, da, y, n, 16, stats, gamma, beta, nullptr, ACT_PRELU, slope, dscratch, bf, ybf,
+                                    dgamma, dbeta, dslope);
+    float* red = red_slot(dscratch, slot);
     const int tiles_t = (g.Tout + C15_TF - 1) / C15_TF;
     const long ntiles = (long)g.B * tiles_t;
     const int grid = (int)(ntiles < 512 ? ntiles : 512);           // 61 KB of LDS: two workgroups per CU, all resident
@@ -3875,16 +4066,17 @@ int conv15_bwd(const ConvGeom& g, const float* x, const float* y, const float* d
     NextRedArgs nx{};
     const bool nxt = next && next->slope && !next->res;
     if (nxt) nx = NextRedArgs{next->y, next->stats, next->gamma, next->beta, next->slope, nullptr, 0, ybf};
+    const FinArgs nfa = next_fin(nxt, next, dscratch, slot);
 #define GT_C15(DW_, F, NXV)                                                                                             \
     hipLaunchKernelGGL((k_conv15_bwd<DW_, F, F, NXV>), dim3(grid), dim3(NT), 0, s, g, x, y, da, bn, w, dx, dx_acc, fscratch, nx, \
-                       dscratch, tiles_t)
+                       dscratch, tiles_t, nfa)
     if (dyw) { if (bf == 0) GT_C15(true, 0, 0); else GT_C15(true, 1, 0); }
     else if (nxt) { if (bf == 0) GT_C15(false, 0, 1); else GT_C15(false, 1, 2); }
     else { if (bf == 0) GT_C15(false, 0, 0); else GT_C15(false, 1, 0); }
 #undef GT_C15
     const int K = 5 * 256 + 16;
     hipLaunchKernelGGL(k_wgrad_mfma_finish, dim3((K + 63) / 64), dim3(1024), 0, s, g, fscratch, grid, dw, dbias);
-    if (nxt && next_parts) *next_parts = grid;
+    if (nxt && next_parts) *next_parts = next_parts_value(nfa, slot, grid);
     return check();
 }
 
@@ -3894,16 +4086,13 @@ int unit1x1_bwd(const ConvGeom& g, const float* x, const float* y, const float* 
                 float* dgamma, float* dbeta, float* dslope, double* dscratch, float* fscratch, hipStream_t s, int bf,
                 int ybf, int have_parts, const DwUnitNext* next, int* next_parts) {
     if (next_parts) *next_parts = 0;
-    const long n = (long)g.B * g.Tout * g.Fout, total = n * g.Cout;
+    const long n = (long)g.B * g.Tout * g.Fout;
     if (g.nkt != 1 || g.nkf != 1 || g.sf != 1 || g.pf != 0 || g.Cout != g.CoutT || g.cout_off != 0 || (g.Cout % 4) ||
         (g.Cin % 4) || (g.CinT % 4) || (g.cin_off % 4))
         return (int)hipErrorInvalidValue;
-    float* red = reinterpret_cast<float*>(dscratch + (long)MAX_PARTIALS * 3 * 16);
-    const int rgrid = have_parts > 0 ? have_parts : red_grid(total / 4);
-    // (have_parts: the kernel that produced da left the per-workgroup sums of this pass in dscratch -- dwunit_bwd)
-    if (have_parts <= 0)
-        launch_bn_bwd_reduce4(rgrid, s, da, y, total, g.Cout, stats, gamma, beta, res, act, slope, dscratch, bf, ybf);
-    hipLaunchKernelGGL(k_bn_bwd_finish, dim3(1), dim3(1024), 0, s, dscratch, rgrid, n, g.Cout, red, dgamma, dbeta, dslope);
+    const int slot = bwd_first_pass(have_parts, s, da, y, n, g.Cout, stats, gamma, beta, res, act, slope, dscratch, bf, ybf,
+                                    dgamma, dbeta, dslope);
+    float* red = red_slot(dscratch, slot);
     const long ntiles = (n + 15) / 16;
     // the unit in front takes this dx as its gradient input: its reduction rides along (its partial sums replace this
     // unit's, which the finish kernel above has consumed, in dscratch)
@@ -3919,14 +4108,15 @@ int unit1x1_bwd(const ConvGeom& g, const float* x, const float* y, const float* 
     const bool xr = nxt && next->recompute_x;
     if (!x && !xr) return (int)hipErrorInvalidValue;
     if (nxt) nx = NextRedArgs{next->y, next->stats, next->gamma, next->beta, next->slope, next->res, next->recompute_x == 2};
+    const FinArgs nfa = next_fin(nxt, next, dscratch, slot);
 #define GT_U1(F, Y)                                                                                                     \
     do {                                                                                                               \
         if (xr) hipLaunchKernelGGL((k_unit1x1_bwd<F, Y, true, true>), dim3(grid), dim3(NT), 0, s, g, x, y, da, res, bn, w, dx, dx_acc, \
-                                   dres, dres_acc, fscratch, tpw, nx, dscratch);                                        \
+                                   dres, dres_acc, fscratch, tpw, nx, dscratch, nfa);                                   \
         else if (nxt) hipLaunchKernelGGL((k_unit1x1_bwd<F, Y, true>), dim3(grid), dim3(NT), 0, s, g, x, y, da, res, bn, w, dx, dx_acc, \
-                                    dres, dres_acc, fscratch, tpw, nx, dscratch);                                       \
+                                    dres, dres_acc, fscratch, tpw, nx, dscratch, nfa);                                  \
         else hipLaunchKernelGGL((k_unit1x1_bwd<F, Y, false>), dim3(grid), dim3(NT), 0, s, g, x, y, da, res, bn, w, dx, dx_acc, \
-                                dres, dres_acc, fscratch, tpw, nx, dscratch);                                           \
+                                dres, dres_acc, fscratch, tpw, nx, dscratch, nfa);                                      \
     } while (0)
     if (bf == 0 && ybf == 0) GT_U1(0, 0);
     else if (bf == 1 && ybf == 1) GT_U1(1, 1);
@@ -3934,7 +4124,7 @@ int unit1x1_bwd(const ConvGeom& g, const float* x, const float* y, const float* 
     else if (bf == 1 && ybf == 2) GT_U1(1, 2);
     else return (int)hipErrorInvalidValue;
 #undef GT_U1
-    if (nxt && next_parts) *next_parts = grid;
+    if (nxt && next_parts) *next_parts = next_parts_value(nfa, slot, grid);
     hipLaunchKernelGGL(k_wgrad_mfma_finish, dim3((256 + 16 + 63) / 64), dim3(1024), 0, s, g, fscratch, grid, dw, dbias);
     return check();
 }

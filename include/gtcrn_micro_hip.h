@@ -241,7 +241,11 @@ long gtcrn_train_workspace_bytes(int B, int T);   /* saved activations + gradien
  * are short-lived and share the backward's scratch region).  Arithmetic, BatchNorm statistics, gradients, the gradient
  * all-reduce, Adam and the master weights stay fp32 in all modes.  Takes effect at the next forward. */
 int gtcrn_trainer_set_storage(gtcrn_trainer *t, int storage);
+/* Workspace of a (B, T) problem in `storage` with the DEFAULT fusion mask (every pass fusion on).  A trainer whose mask
+ * was changed with gtcrn_trainer_set_fusions stores more tensors (about 6 GiB more at B = 512 with mask 7):
+ * gtcrn_trainer_workspace_bytes plans with the trainer's own storage mode and mask. */
 long gtcrn_train_workspace_bytes2(int B, int T, int storage);
+long gtcrn_trainer_workspace_bytes(gtcrn_trainer *t, int B, int T);
 /* Diagnostic: which pass fusions of the train step are active (default: all).  bit 0: BatchNorm + PReLU of a unit
  * applied by the conv that consumes it (normalise-on-load; the forward is bit-identical with and without), bit 1: the
  * depthwise unit's backward in one pass, bit 2: BatchNorm reductions accumulated by the kernel that produces their
@@ -254,7 +258,10 @@ long gtcrn_train_workspace_bytes2(int B, int T, int storage);
  * backward of the encoder's depthwise 3x3 unit (dy, weight gradient, data gradient) in one LDS-tiled pass.  bit 7: the
  * same for the decoder's dense transposed 3x3 unit (both matrix products from LDS images of dy and x).  bit 8 (needs bit
  * 0): point_conv1's BatchNorm + PReLU applied by LDS-tiled depth convs while they stage their input tile.  bit 9: the
- * backward of the two 16 -> 16 (1,5) stride-2 units (en_convs.1, de_convs.3) from LDS tiles.
+ * backward of the two 16 -> 16 (1,5) stride-2 units (en_convs.1, de_convs.3) from LDS tiles.  bit 10: the second
+ * stage of every BatchNorm reduction (forward statistics + running estimates; backward means, dgamma, dbeta, dslope) runs
+ * in the LAST workgroup of the kernel that produces the per-workgroup sums (two-level last-arriver reduction, agent-scope
+ * write-through hand-off, fixed summation order) instead of 92 one-workgroup finish launches per step.  Default 2047.
  * 0 runs the layer-at-a-time passes (tests/test_gpu_train.py compares them).  Takes effect at the next forward; not
  * part of the reference's interface. */
 int gtcrn_trainer_set_fusions(gtcrn_trainer *t, int mask);
