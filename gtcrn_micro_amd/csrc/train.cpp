@@ -80,6 +80,9 @@ struct Unit {                 // conv (dense or depthwise) + BatchNorm + activat
     // is never stored -- a == nullptr.  Set by plan() for conv1 / conv2 of the TCN blocks and depth_conv of the GTConv
     // blocks when fusion bits 1, 4 (and 2 for conv1) and 8 are on.
     bool lean = false;
+    // fusion bit 11: `a` holds activation + post (the next decoder layer's input x + skip, written by this unit's bn_act);
+    // the plain activation is not stored
+    const float* post = nullptr;
 };
 
 struct GtBlock {              // GTConvBlock (models/gtcrn_micro.py:167-253)
@@ -91,6 +94,7 @@ struct GtBlock {              // GTConvBlock (models/gtcrn_micro.py:167-253)
     float *e = nullptr, *yt = nullptr, *g = nullptr, *out = nullptr;
     const float* xinc = nullptr; // exact chain: fp32 twins of xin / s / out
     float *sc = nullptr, *outc = nullptr;
+    const float* post = nullptr; // fusion bit 11: `out` holds block output + post (see Unit::post)
 };
 
 struct TcnBlock {             // TCN (models/gtcrn_micro.py:256-310)
@@ -115,7 +119,7 @@ struct gtcrn_trainer {
     double* dscratch = nullptr;   // BatchNorm partial sums
     double* fin_gpart = nullptr;  // in-launch finish of the BatchNorm reductions (fusion bit 10): group sums and
     unsigned* fin_ctr = nullptr;  // arrival counters (zero between launches), see train_kernels.h
-    int fusions = 2047;                 // gtcrn_trainer_set_fusions: 1 normalise-on-load, 2 depthwise backward, 4 riding reductions,
+    int fusions = 4095;                 // gtcrn_trainer_set_fusions: 1 normalise-on-load, 2 depthwise backward, 4 riding reductions,
                                       // 8 single-reader activations recomputed in the backward instead of stored,
                                       // 16 skip gradients accumulated in place (no add passes in the backward),
                                       // 32 reductions riding in the adjoint convs of the 3x3 units and of en_convs.1,
@@ -123,7 +127,8 @@ struct gtcrn_trainer {
                                       // 256 point_conv1's BatchNorm + PReLU applied by the LDS-tiled depth convs while staging,
                                       // 512 the backward of en_convs.1 / de_convs.3 from LDS tiles,
                                       // 1024 the second stage of every BatchNorm reduction in the last workgroup of the
-                                      // kernel that produces its partial sums (no finish launches)
+                                      // kernel that produces its partial sums (no finish launches),
+                                      // 2048 (fp32 storage) the decoder's sums x + skip written by the layer that produces x
     const void* red_unit = nullptr;   // backward: the unit whose BatchNorm reduction already sits in dscratch ...
     int red_parts = 0;                // ... as this many per-workgroup partial sums (see unit_bwd)
     std::map<std::string, long> off;   // parameter name -> blob offset
@@ -139,6 +144,8 @@ struct gtcrn_trainer {
     float *q1 = nullptr, *q2 = nullptr, *dy = nullptr, *dv = nullptr, *dhd = nullptr, *dh = nullptr, *tmp_tra = nullptr;
     float *d65 = nullptr, *df0 = nullptr;
     std::map<std::string, std::pair<const float*, std::vector<int>>> taps;  // name -> (ptr, {T', F, C})
+    std::map<std::string, const float*> tap_minus;   // fusion bit 11: the tap is ptr - this (the stored tensor is a sum)
+    bool fuse_sums = false;
     // HybridLoss workspace: the two iSTFT waveforms, the sqrt-Hann window, SI-SNR coefficients
     float* loss_ws = nullptr;
     size_t loss_ws_floats = 0;
@@ -270,7 +277,12 @@ size_t plan(gtcrn_trainer* t, int B, int T, float* base) {
     // conditions under which unit_bwd takes those fused forms with a riding reduction)
     const bool lean = fuse && t->bf == t->ybf && (t->fusions & 4) && (t->fusions & 8);
     const bool lean_c1 = lean && (t->fusions & 2);
+    // fusion bit 11 (fp32 storage: every sum x + skip of the decoder is saved anyway): a sum is written by the layer that
+    // PRODUCES x -- the last TCN block's bn_act, the decoder blocks' gate/shuffle, de_convs.3's bn_act -- instead of a pass
+    // that reads x and the skip and writes the sum; x itself (an output nobody else reads) is not stored
+    t->fuse_sums = (t->fusions & 2048) && t->bf == 0 && !t->exact;
     t->taps.clear();
+    t->tap_minus.clear();
     {   // (the fp32 twins of the exact chain are assigned at the end; a unit that has none must not keep an old one)
         Unit* all[4 + 6 * 3 + 8 * 3] = {&t->en0, &t->en1, &t->de3, &t->de4};
         int n = 4;
@@ -340,7 +352,8 @@ size_t plan(gtcrn_trainer* t, int B, int T, float* base) {
         k.pc1.deferred = fuse_pc1;
         k.o_tra = P(t, p + ".tra.depth_conv.weight");
         k.e = b.take((size_t)B * Tt * 8); k.yt = b.take((size_t)B * Tt * 8); k.g = b.take((size_t)B * Tt * 8);
-        k.out = b.take_saved(n33 * 16);
+        k.out = (deconv && t->fuse_sums) ? nullptr : b.take_saved(n33 * 16);     // (fused: the next layer's sum buffer)
+        k.post = nullptr;
     };
     for (int k = 0; k < 3; ++k) {
         gt_block(t->enc[k], "encoder.en_convs." + std::to_string(k + 2), false, X);
@@ -368,7 +381,9 @@ size_t plan(gtcrn_trainer* t, int B, int T, float* base) {
         k.c3.cg = k.c1.cg;
         unit_params(t, k.c3, p + ".conv3", p + ".bn3", p + ".act3");
         k.c3.act = gtt::ACT_PRELU; k.c3.x = k.c2.a; k.c3.res = X;
-        alloc_unit(b, k.c3, n33, 16);
+        alloc_unit(b, k.c3, n33, 16, i == 7 && t->fuse_sums);     // (fused: block 7's output lives in dec[0].s)
+        k.c3.lean = false;
+        k.c3.post = nullptr;
         k.c2.front = &k.c1;
         k.c3.front = &k.c2;
         k.c1.front = i > 0 ? &t->tcn[i - 1].c3 : nullptr;
@@ -386,23 +401,43 @@ size_t plan(gtcrn_trainer* t, int B, int T, float* base) {
     // it is needed (five extra streaming adds).  fp32 storage keeps them all, as before.
     t->share_sums = t->bf != 0;
     t->s_tmp = t->share_sums ? b.take_saved(n65 * 16) : nullptr;
+    t->de3.post = nullptr;
     for (int i = 0; i < 3; ++i) {
         GtBlock& k = t->dec[i];
         k.s = t->share_sums ? t->s_tmp : b.take_saved(n33 * 16);
+        k.post = nullptr;
+    }
+    t->s3 = t->share_sums ? t->s_tmp : (t->fuse_sums ? b.take_saved(n33 * 16) : nullptr);
+    if (t->fuse_sums) {
+        t->tcn[7].c3.post = t->enc[2].out;              // dec[0].s = gtcn2 output + en_outs[4]
+        t->tcn[7].c3.a = t->dec[0].s;
+        t->taps["gtcn2"] = {t->dec[0].s, {T, 33, 16}};
+        t->tap_minus["gtcn2"] = t->enc[2].out;
+    }
+    for (int i = 0; i < 3; ++i) {
+        GtBlock& k = t->dec[i];
         gt_block(k, "decoder.de_convs." + std::to_string(i), true, k.s);
         k.pc1.x = k.s;
         // the addends of s (previous output, skip) are needed by forward() only
         (void)skips;
+        if (t->fuse_sums) {
+            // (gt_block took a buffer for the block output: hand the sum's buffer to it instead)
+            k.out = i < 2 ? t->dec[i + 1].s : t->s3;
+            k.post = i < 2 ? t->enc[1 - i].out : t->en1.a;
+            t->tap_minus["de" + std::to_string(i)] = k.post;
+        }
         X = k.out;
         t->taps["de" + std::to_string(i)] = {X, {T, 33, 16}};
     }
-    t->s3 = t->share_sums ? t->s_tmp : b.take_saved(n33 * 16);
+    if (!t->share_sums && !t->fuse_sums) t->s3 = b.take_saved(n33 * 16);
     // decoder.de_convs.3: ConvTranspose2d(16,16,(1,5),stride (1,2),padding (0,2)), weight [in][out][1][5]
     t->de3.cg = conv_geom(B, T, T, 33, 65, 16, 0, 16, 16, 16, 1, 5, 0, 0, 0, 1, 2, 2, 5, 80, 5, 1);
     unit_params(t, t->de3, "decoder.de_convs.3.conv", "decoder.de_convs.3.bn", "decoder.de_convs.3.act");
     t->de3.act = gtt::ACT_PRELU; t->de3.x = t->s3;
-    alloc_unit(b, t->de3, n65, 16);
+    alloc_unit(b, t->de3, n65, 16, t->fuse_sums);       // (fused: the activation lives in s4 as de3.a + en_outs[0])
+    t->de3.lean = false;
     t->s4 = t->share_sums ? t->s_tmp : b.take_saved(n65 * 16);
+    if (t->fuse_sums) { t->de3.a = t->s4; t->de3.post = t->en0.a; t->tap_minus["de3"] = t->en0.a; }
     t->de4.cg = conv_geom(B, T, T, 65, 129, 16, 0, 16, 2, 2, 1, 5, 0, 0, 0, 1, 2, 2, 5, 10, 5, 1);
     unit_params(t, t->de4, "decoder.de_convs.4.conv", "decoder.de_convs.4.bn", "");
     t->de4.act = gtt::ACT_TANH; t->de4.x = t->s4;
@@ -623,7 +658,7 @@ int unit_fwd(gtcrn_trainer* t, Unit& u, float* prm, hipStream_t s) {
     T_RUN(gtt::bn_stats(u.y, u.n, u.C, u.stats, bn + 2 * u.C, bn + 3 * u.C, t->dscratch, s, parts, t->ybf, shift));
     if (!u.deferred)
         T_RUN(gtt::bn_act(u.y, u.n, u.C, u.stats, bn, bn + u.C, u.res, u.act, u.o_slope >= 0 ? prm + u.o_slope : nullptr,
-                          u.a, s, t->bf, t->ybf));
+                          u.a, s, t->bf, t->ybf, nullptr, 0, nullptr, 0, u.post));
     return 0;
 }
 
@@ -747,7 +782,7 @@ int gt_fwd(gtcrn_trainer* t, GtBlock& k, float* prm, hipStream_t s) {
         return 0;
     }
     T_RUN(gtt::tra_fwd(k.pc2.a, t->B, k.Tt, tr, tr + 24, tr + 32, tr + 96, k.e, k.yt, k.g, s, t->bf));
-    T_RUN(gtt::gate_shuffle_fwd(k.pc2.a, k.g, k.xin, t->B, t->T, k.Tt, k.out, s, t->bf));
+    T_RUN(gtt::gate_shuffle_fwd(k.pc2.a, k.g, k.xin, t->B, t->T, k.Tt, k.out, s, t->bf, nullptr, 0, k.post));
     return 0;
 }
 // dout: gradient of k.out; dxin: gradient of the block input (all 16 channels written; acc: ADDED to what dxin holds --
@@ -858,7 +893,7 @@ int gtcrn_trainer_set_storage(gtcrn_trainer* t, int storage) {
 }
 
 int gtcrn_trainer_set_fusions(gtcrn_trainer* t, int mask) {
-    if (!t || mask < 0 || mask > 2047) return tfail(GTCRN_ERR_ARG, "gtcrn_trainer_set_fusions: mask must be 0..2047");
+    if (!t || mask < 0 || mask > 4095) return tfail(GTCRN_ERR_ARG, "gtcrn_trainer_set_fusions: mask must be 0..4095");
     if (t->fusions != mask) {
         t->fusions = mask;
         t->planned = false;      // the unit links are laid out again on the next forward
@@ -921,14 +956,15 @@ int gtcrn_train_forward(gtcrn_trainer* t, float* d_params, const float* d_spec, 
         return 0;
     }
     const float* X = t->tcn[7].c3.a;
+    const bool fs = t->fuse_sums;     // every sum below was written by the layer in front of it (fusion bit 11)
     for (int i = 0; i < 3; ++i) {     // Decoder.forward: x = de_convs[i](x + en_outs[4 - i]) (models/gtcrn_micro.py:463-469)
-        T_RUN(gtt::add_saved(X, t->enc[2 - i].out, t->dec[i].s, n33, s, t->bf));
+        if (!fs) T_RUN(gtt::add_saved(X, t->enc[2 - i].out, t->dec[i].s, n33, s, t->bf));
         if ((rc = gt_fwd(t, t->dec[i], prm, s))) return rc;
         X = t->dec[i].out;
     }
-    T_RUN(gtt::add_saved(X, t->en1.a, t->s3, n33, s, t->bf));
+    if (!fs) T_RUN(gtt::add_saved(X, t->en1.a, t->s3, n33, s, t->bf));
     if ((rc = unit_fwd(t, t->de3, prm, s))) return rc;
-    T_RUN(gtt::add_saved(t->de3.a, t->en0.a, t->s4, n65, s, t->bf));
+    if (!fs) T_RUN(gtt::add_saved(t->de3.a, t->en0.a, t->s4, n65, s, t->bf));
     if ((rc = unit_fwd(t, t->de4, prm, s))) return rc;
     T_RUN(gtt::bs_mask_fwd(t->de4.a, d_spec, sb, sf, st, B, T, prm + P(t, "erb.ierb_fc.weight"), d_out, ob, of, ot, s,
                            t->bf));
@@ -1075,8 +1111,13 @@ int gtcrn_train_tap(gtcrn_trainer* t, const char* name, float* d_out, long* shap
     if (it == t->taps.end()) return tfail(GTCRN_ERR_ARG, std::string("gtcrn_train_tap: unknown stage ") + name);
     const std::vector<int>& sh = it->second.second;   // T', F, C
     if (shape4) { shape4[0] = t->B; shape4[1] = sh[0]; shape4[2] = sh[1]; shape4[3] = sh[2]; }
-    if (d_out)
-        T_RUN(gtt::saved_to_f32(it->second.first, d_out, (long)t->B * sh[0] * sh[1] * sh[2], (hipStream_t)stream, t->bf));
+    if (d_out) {
+        // (fusion bit 11: a block output that was stored only as block output + skip is recovered by subtracting the skip
+        // -- equal to the unfused tap up to the rounding of the sum)
+        auto mi = t->tap_minus.find(name);
+        T_RUN(gtt::saved_to_f32(it->second.first, d_out, (long)t->B * sh[0] * sh[1] * sh[2], (hipStream_t)stream, t->bf,
+                                mi == t->tap_minus.end() ? nullptr : mi->second));
+    }
     return 0;
 }
 

@@ -127,10 +127,11 @@ int dw_wgrad(const DwGeom& g, const float* in, const float* dout, float* dw, flo
 int bn_stats(const float* y, long n, int C, float* stats, float* running_mean, float* running_var, double* scratch,
              hipStream_t s, int have_parts = 0, int bf = 0, float* shift = nullptr, float* stats_b = nullptr);
 // a = act(gamma * (y - mean) * invstd + beta [+ res]); exact chain: a2 (format a2_bf) = second copy of a, y2 (format
-// y2_bf) = the centred copy of y for the backward
+// y2_bf) = the centred copy of y for the backward.  post (format bf; not with a2 / y2): added AFTER the activation -- what is
+// stored is a + post, the next decoder layer's input x + skip (fusion bit 11: the activation has no other reader)
 int bn_act(const float* y, long n, int C, const float* stats, const float* gamma, const float* beta,
            const float* res, int act, const float* slope, float* a, hipStream_t s, int bf = 0, int ybf = 0,
-           float* a2 = nullptr, int a2_bf = 0, float* y2 = nullptr, int y2_bf = 0);
+           float* a2 = nullptr, int a2_bf = 0, float* y2 = nullptr, int y2_bf = 0, const float* post = nullptr);
 // backward of the same: given da, writes dy (may alias da); if dres != nullptr: dres (+)= dz (dres_acc: add);
 // dgamma/dbeta [C], dslope [1] (PReLU) are WRITTEN.  scratch: MAX_PARTIALS * 3 * C doubles + 2 * C floats.
 int bn_act_bwd(const float* da, const float* y, long n, int C, const float* stats, const float* gamma,
@@ -204,8 +205,9 @@ int bs_mask_bwd(const float* dout, long ob, long of, long ot, const float* spec,
 int tra_fwd(const float* v, int B, int Tt, const float* dw_w, const float* dw_b, const float* pw_w,
             const float* pw_b, float* e, float* y, float* g, hipStream_t s, int bf = 0);
 // out[b,t,f,2c] = v[b,t,f,c] * g[b,t,c], out[b,t,f,2c+1] = x[b,t,f,8+c]   (shuffle, :222-227), t < T
+// skip (format bf; not with out2): out = the block output + skip, see bn_act's post
 int gate_shuffle_fwd(const float* v, const float* g, const float* x, int B, int T, int Tt, float* out, hipStream_t s,
-                     int bf = 0, float* out2 = nullptr, int out2_bf = 0);
+                     int bf = 0, float* out2 = nullptr, int out2_bf = 0, const float* skip = nullptr);
 // backward of tra + gate + shuffle: dout [B][T][33][16] -> dv [B][Tt][33][8] (written), dx channels 8..15 (written; dx_acc:
 // added to what dx holds), parameter gradients written.  tmp: 3 * B*Tt*8 floats; scratch: MAX_PARTIALS * 80 floats.
 int tra_gate_shuffle_bwd(const float* dout, const float* v, const float* g, const float* e, const float* y, int B,
@@ -226,7 +228,7 @@ int sisnr_terms(float* yp, const float* yt, int B, long Lw, const double* spec_p
 int add(const float* a, const float* b, float* out, long n, hipStream_t s);
 // out = a + b on saved tensors (n % 4 == 0); saved tensor -> fp32 copy (test taps)
 int add_saved(const float* a, const float* b, float* out, long n, hipStream_t s, int bf);
-int saved_to_f32(const float* src, float* dst, long n, hipStream_t s, int bf);
+int saved_to_f32(const float* src, float* dst, long n, hipStream_t s, int bf, const float* minus = nullptr);   // dst = src [- minus]
 
 // clip_grad_norm_(max_norm) + torch.optim.Adam.step() over flat blobs of n floats in two launches (train.py:282-285):
 // p / g / m / v = parameters, gradients, exp_avg, exp_avg_sq; mask[i] != 0 marks the trainable elements (others are

@@ -1485,7 +1485,8 @@ __global__ __launch_bounds__(NT) void k_bn_act(const float* __restrict__ y, long
                                               const float* __restrict__ stats, const float* __restrict__ gamma,
                                               const float* __restrict__ beta, const float* __restrict__ res, int act,
                                               const float* __restrict__ slope, float* __restrict__ a, int bf, int ybf,
-                                              float* __restrict__ a2, int a2_bf, float* __restrict__ y2, int y2_bf) {
+                                              float* __restrict__ a2, int a2_bf, float* __restrict__ y2, int y2_bf,
+                                              const float* __restrict__ post) {
     const float sl = slope ? slope[0] : 0.f;
     const long units = total / V;
     // the stride is a multiple of C: the thread's channels and their constants are fixed
@@ -1494,15 +1495,19 @@ __global__ __launch_bounds__(NT) void k_bn_act(const float* __restrict__ y, long
 #pragma unroll
     for (int e = 0; e < V; ++e) { mean[e] = stats[c0 + e]; istd[e] = stats[C + c0 + e]; gm[e] = gamma[c0 + e]; bt[e] = beta[c0 + e]; }
     for (long i = (long)blockIdx.x * NT + threadIdx.x; i < units; i += (long)gridDim.x * NT) {
-        float x[V], r[V], o[V], yt[V];
+        float x[V], r[V], o[V], yt[V], pa[V];
         load_vec_s<V, kNt>(y, i * V, ybf, x);
         if (res) load_vec_s<V, kNt>(res, i * V, bf, r);
+        if (post) load_vec_s<V, kNt>(post, i * V, bf, pa);
 #pragma unroll
         for (int e = 0; e < V; ++e) {
             // same expression order as the backward's recomputation of z: gamma * ((y - mean) * invstd) + beta
             float z = gm[e] * ((x[e] - mean[e]) * istd[e]) + bt[e];
             if (res) z += r[e];
             o[e] = act_fwd(z, act, sl);
+            // post: the decoder's skip is added AFTER the activation and the sum is what gets stored (the next layer's
+            // input x + skip; the activation itself has no other reader) -- the same fp32 add the separate pass made
+            if (post) o[e] += pa[e];
             if (y2) yt[e] = ycopy_value(x[e], z, mean[e], istd[e], gm[e], bt[e], res != nullptr, res ? r[e] : 0.f, y2_bf,
                                         act == ACT_PRELU);
         }
@@ -3106,8 +3111,10 @@ __global__ __launch_bounds__(NT) void k_tra_gate(const float* __restrict__ e, in
 __global__ __launch_bounds__(NT) void k_gate_shuffle(const float* __restrict__ v, const float* __restrict__ g,
                                                     const float* __restrict__ x, int B, int T, int Tt,
                                                     float* __restrict__ out, int bf, float* __restrict__ out2,
-                                                    int out2_bf) {
+                                                    int out2_bf, const float* __restrict__ skip) {
     // thread (position, half h): channels 4h..4h+3 -> output slots 8h..8h+7; 16-byte accesses throughout
+    // skip (optional, format bf): out = block output + skip, the next decoder layer's input (Decoder.forward,
+    // models/gtcrn_micro.py:463-469: x = de_convs[i](x + en_outs[4 - i])) -- the block output has no other reader
     const long total = (long)B * T * 33 * 2;
     for (long i = (long)blockIdx.x * NT + threadIdx.x; i < total; i += (long)gridDim.x * NT) {
         const int h = (int)(i & 1);
@@ -3120,6 +3127,12 @@ __global__ __launch_bounds__(NT) void k_gate_shuffle(const float* __restrict__ v
         const f32x4 gg = *reinterpret_cast<const f32x4*>(g + rowv * 8 + 4 * h);
         const f32x4 xx = sld4(x, pos * 16 + 8 + 4 * h, bf);
         const f32x4 p = vv * gg;
+        if (skip) {
+            const f32x4 k0 = sld4<kNt>(skip, pos * 16 + 8 * h, bf), k1 = sld4<kNt>(skip, pos * 16 + 8 * h + 4, bf);
+            sst4<kNtSt>(out, pos * 16 + 8 * h, bf, f32x4{p[0], xx[0], p[1], xx[1]} + k0);
+            sst4<kNtSt>(out, pos * 16 + 8 * h + 4, bf, f32x4{p[2], xx[2], p[3], xx[3]} + k1);
+            continue;
+        }
         sst4<kNtSt>(out, pos * 16 + 8 * h, bf, f32x4{p[0], xx[0], p[1], xx[1]});
         sst4<kNtSt>(out, pos * 16 + 8 * h + 4, bf, f32x4{p[2], xx[2], p[3], xx[3]});
         if (out2) {
@@ -3399,8 +3412,9 @@ __global__ __launch_bounds__(NT) void k_add_saved(const float* __restrict__ a, c
         sst4<kNtSt>(out, i * 4, bf, sld4<kNt>(a, i * 4, bf) + sld4<kNt>(b, i * 4, bf));
 }
 __global__ __launch_bounds__(NT) void k_saved_to_f32(const float* __restrict__ src, float* __restrict__ dst, long n,
-                                                    int bf) {
-    for (long i = (long)blockIdx.x * NT + threadIdx.x; i < n; i += (long)gridDim.x * NT) dst[i] = sld1(src, i, bf);
+                                                    int bf, const float* __restrict__ minus) {
+    for (long i = (long)blockIdx.x * NT + threadIdx.x; i < n; i += (long)gridDim.x * NT)
+        dst[i] = minus ? sld1(src, i, bf) - sld1(minus, i, bf) : sld1(src, i, bf);
 }
 
 
@@ -3888,14 +3902,15 @@ int bn_stats(const float* y, long n, int C, float* stats, float* running_mean, f
 
 int bn_act(const float* y, long n, int C, const float* stats, const float* gamma, const float* beta,
            const float* res, int act, const float* slope, float* a, hipStream_t s, int bf, int ybf, float* a2,
-           int a2_bf, float* y2, int y2_bf) {
+           int a2_bf, float* y2, int y2_bf, const float* post) {
     const long total = n * C;
+    if (post && (a2 || y2)) return (int)hipErrorInvalidValue;      // (the exact chain adds its sums in passes of their own)
     if (C % 4 == 0)
         hipLaunchKernelGGL((k_bn_act<4>), dim3(grid_for(total / 4, 8192)), dim3(NT), 0, s, y, total, C, stats, gamma,
-                           beta, res, act, slope, a, bf, ybf, a2, a2_bf, y2, y2_bf);
+                           beta, res, act, slope, a, bf, ybf, a2, a2_bf, y2, y2_bf, post);
     else
         hipLaunchKernelGGL((k_bn_act<1>), dim3(grid_for(total, 8192)), dim3(NT), 0, s, y, total, C, stats, gamma, beta,
-                           res, act, slope, a, bf, ybf, a2, a2_bf, y2, y2_bf);
+                           res, act, slope, a, bf, ybf, a2, a2_bf, y2, y2_bf, post);
     return check();
 }
 
@@ -4181,9 +4196,10 @@ int tra_fwd(const float* v, int B, int Tt, const float* dw_w, const float* dw_b,
     return check();
 }
 int gate_shuffle_fwd(const float* v, const float* g, const float* x, int B, int T, int Tt, float* out, hipStream_t s,
-                     int bf, float* out2, int out2_bf) {
+                     int bf, float* out2, int out2_bf, const float* skip) {
+    if (skip && out2) return (int)hipErrorInvalidValue;
     hipLaunchKernelGGL(k_gate_shuffle, dim3(grid_for((long)B * T * 33 * 2)), dim3(NT), 0, s, v, g, x, B, T, Tt, out, bf,
-                       out2, out2_bf);
+                       out2, out2_bf, skip);
     return check();
 }
 int tra_gate_shuffle_bwd(const float* dout, const float* v, const float* g, const float* e, const float* y, int B,
@@ -4237,8 +4253,8 @@ int add_saved(const float* a, const float* b, float* out, long n, hipStream_t s,
     hipLaunchKernelGGL(k_add_saved, dim3(grid_for(n / 4, 8192)), dim3(NT), 0, s, a, b, out, n / 4, bf);
     return check();
 }
-int saved_to_f32(const float* src, float* dst, long n, hipStream_t s, int bf) {
-    hipLaunchKernelGGL(k_saved_to_f32, dim3(grid_for(n, 8192)), dim3(NT), 0, s, src, dst, n, bf);
+int saved_to_f32(const float* src, float* dst, long n, hipStream_t s, int bf, const float* minus) {
+    hipLaunchKernelGGL(k_saved_to_f32, dim3(grid_for(n, 8192)), dim3(NT), 0, s, src, dst, n, bf, minus);
     return check();
 }
 

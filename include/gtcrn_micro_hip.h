@@ -261,7 +261,10 @@ long gtcrn_trainer_workspace_bytes(gtcrn_trainer *t, int B, int T);
  * backward of the two 16 -> 16 (1,5) stride-2 units (en_convs.1, de_convs.3) from LDS tiles.  bit 10: the second
  * stage of every BatchNorm reduction (forward statistics + running estimates; backward means, dgamma, dbeta, dslope) runs
  * in the LAST workgroup of the kernel that produces the per-workgroup sums (two-level last-arriver reduction, agent-scope
- * write-through hand-off, fixed summation order) instead of 92 one-workgroup finish launches per step.  Default 2047.
+ * write-through hand-off, fixed summation order) instead of 92 one-workgroup finish launches per step.  bit 11 (fp32
+ * storage): each of the decoder's five sums x + en_outs[..] (models/gtcrn_micro.py:463-469) is written by the layer
+ * that produces x (the last TCN block's normalise pass, the decoder blocks' gate/shuffle, de_convs.3's normalise pass)
+ * instead of an add pass; x itself is not stored (its test tap is sum - skip).  Default 4095.
  * 0 runs the layer-at-a-time passes (tests/test_gpu_train.py compares them).  Takes effect at the next forward; not
  * part of the reference's interface. */
 int gtcrn_trainer_set_fusions(gtcrn_trainer *t, int mask);
