@@ -95,6 +95,8 @@ struct GtBlock {              // GTConvBlock (models/gtcrn_micro.py:167-253)
     const float* xinc = nullptr; // exact chain: fp32 twins of xin / s / out
     float *sc = nullptr, *outc = nullptr;
     const float* post = nullptr; // fusion bit 11: `out` holds block output + post (see Unit::post)
+    bool bn2_load = false;       // fusion bit 12: TRALite and the gate/shuffle apply point_bn2 while loading point_conv2's
+                                 // output; pc2.a is not stored and its normalise pass does not run
 };
 
 struct TcnBlock {             // TCN (models/gtcrn_micro.py:256-310)
@@ -119,7 +121,7 @@ struct gtcrn_trainer {
     double* dscratch = nullptr;   // BatchNorm partial sums
     double* fin_gpart = nullptr;  // in-launch finish of the BatchNorm reductions (fusion bit 10): group sums and
     unsigned* fin_ctr = nullptr;  // arrival counters (zero between launches), see train_kernels.h
-    int fusions = 4095;                 // gtcrn_trainer_set_fusions: 1 normalise-on-load, 2 depthwise backward, 4 riding reductions,
+    int fusions = 8191;                 // gtcrn_trainer_set_fusions: 1 normalise-on-load, 2 depthwise backward, 4 riding reductions,
                                       // 8 single-reader activations recomputed in the backward instead of stored,
                                       // 16 skip gradients accumulated in place (no add passes in the backward),
                                       // 32 reductions riding in the adjoint convs of the 3x3 units and of en_convs.1,
@@ -128,7 +130,8 @@ struct gtcrn_trainer {
                                       // 512 the backward of en_convs.1 / de_convs.3 from LDS tiles,
                                       // 1024 the second stage of every BatchNorm reduction in the last workgroup of the
                                       // kernel that produces its partial sums (no finish launches),
-                                      // 2048 (fp32 storage) the decoder's sums x + skip written by the layer that produces x
+                                      // 2048 (fp32 storage) the decoder's sums x + skip written by the layer that produces x,
+                                      // 4096 point_bn2 applied on load by TRALite / gate-shuffle (forward and backward)
     const void* red_unit = nullptr;   // backward: the unit whose BatchNorm reduction already sits in dscratch ...
     int red_parts = 0;                // ... as this many per-workgroup partial sums (see unit_bwd)
     std::map<std::string, long> off;   // parameter name -> blob offset
@@ -340,7 +343,13 @@ size_t plan(gtcrn_trainer* t, int B, int T, float* base) {
         k.pc2.cg = conv_geom(B, Tt, Tt, 33, 33, 16, 0, 16, 8, 8, 1, 1, 0, 0, 0, 0, 1, 0, deconv ? 1 : 16, deconv ? 8 : 1, 1, 1);
         unit_params(t, k.pc2, p + ".point_conv2", p + ".point_bn2", "");
         k.pc2.act = gtt::ACT_NONE; k.pc2.x = k.depth.a;
-        alloc_unit(b, k.pc2, nt, 8);
+        // point_bn2 has no activation behind it and four readers that can normalise on load (TRALite's energy, the
+        // gate/shuffle, and their two backward passes): its output is then never stored (not in the exact-chain mode,
+        // whose backward reads 16-bit copies written by that pass)
+        k.bn2_load = fuse && !t->exact && (t->fusions & 4096);
+        alloc_unit(b, k.pc2, nt, 8, k.bn2_load);
+        k.pc2.lean = false;
+        k.pc2.deferred = k.bn2_load;
         k.pc2.front = &k.depth;
         k.depth.front = &k.pc1;          // the depth conv's adjoint produces point_conv1's gradient input
         k.pc2.pre = fuse ? &k.depth : nullptr;
@@ -781,8 +790,12 @@ int gt_fwd(gtcrn_trainer* t, GtBlock& k, float* prm, hipStream_t s) {
         T_RUN(gtt::gate_shuffle_fwd(k.pc2.ac, k.g, k.xinc, t->B, t->T, k.Tt, k.outc, s, 0, k.out, t->bf));
         return 0;
     }
-    T_RUN(gtt::tra_fwd(k.pc2.a, t->B, k.Tt, tr, tr + 24, tr + 32, tr + 96, k.e, k.yt, k.g, s, t->bf));
-    T_RUN(gtt::gate_shuffle_fwd(k.pc2.a, k.g, k.xin, t->B, t->T, k.Tt, k.out, s, t->bf, nullptr, 0, k.post));
+    const float* bn2 = prm + k.pc2.o_bn;
+    const gtt::TraBn tb{k.pc2.stats, bn2, bn2 + 8, t->ybf};
+    const gtt::TraBn* ptb = k.bn2_load ? &tb : nullptr;
+    const float* v = k.bn2_load ? k.pc2.y : k.pc2.a;
+    T_RUN(gtt::tra_fwd(v, t->B, k.Tt, tr, tr + 24, tr + 32, tr + 96, k.e, k.yt, k.g, s, t->bf, ptb));
+    T_RUN(gtt::gate_shuffle_fwd(v, k.g, k.xin, t->B, t->T, k.Tt, k.out, s, t->bf, nullptr, 0, k.post, ptb));
     return 0;
 }
 // dout: gradient of k.out; dxin: gradient of the block input (all 16 channels written; acc: ADDED to what dxin holds --
@@ -792,8 +805,11 @@ int gt_bwd(gtcrn_trainer* t, GtBlock& k, const float* prm, float* grads, const f
     const float* tr = prm + k.o_tra;
     float* gtr = grads + k.o_tra;
     int rc;
-    T_RUN(gtt::tra_gate_shuffle_bwd(dout, k.pc2.a, k.g, k.e, k.yt, t->B, t->T, k.Tt, tr, tr + 32, t->dv, dxin, gtr,
-                                    gtr + 24, gtr + 32, gtr + 96, t->tmp_tra, t->fscratch, s, t->bf, acc));
+    const float* bn2 = prm + k.pc2.o_bn;
+    const gtt::TraBn tb{k.pc2.bstats, bn2, bn2 + 8, t->ybf};
+    T_RUN(gtt::tra_gate_shuffle_bwd(dout, k.bn2_load ? k.pc2.y : k.pc2.a, k.g, k.e, k.yt, t->B, t->T, k.Tt, tr, tr + 32, t->dv,
+                                    dxin, gtr, gtr + 24, gtr + 32, gtr + 96, t->tmp_tra, t->fscratch, s, t->bf, acc,
+                                    k.bn2_load ? &tb : nullptr));
     if ((rc = unit_bwd(t, k.pc2, prm, grads, t->dv, t->dhd, 0, nullptr, 0, s))) return rc;
     if ((rc = unit_bwd(t, k.depth, prm, grads, t->dhd, t->dh, 0, nullptr, 0, s))) return rc;
     if ((rc = unit_bwd(t, k.pc1, prm, grads, t->dh, dxin, acc, nullptr, 0, s))) return rc;   // channels 0..7
@@ -893,7 +909,7 @@ int gtcrn_trainer_set_storage(gtcrn_trainer* t, int storage) {
 }
 
 int gtcrn_trainer_set_fusions(gtcrn_trainer* t, int mask) {
-    if (!t || mask < 0 || mask > 4095) return tfail(GTCRN_ERR_ARG, "gtcrn_trainer_set_fusions: mask must be 0..4095");
+    if (!t || mask < 0 || mask > 8191) return tfail(GTCRN_ERR_ARG, "gtcrn_trainer_set_fusions: mask must be 0..8191");
     if (t->fusions != mask) {
         t->fusions = mask;
         t->planned = false;      // the unit links are laid out again on the next forward

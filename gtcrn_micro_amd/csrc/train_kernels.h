@@ -201,19 +201,27 @@ int bs_mask_fwd(const float* m, const float* spec, long sb, long sf, long st, in
 int bs_mask_bwd(const float* dout, long ob, long of, long ot, const float* spec, long sb, long sf, long st, int B,
                 int T, const float* ierb_w, float* dm, hipStream_t s);
 
+// point_bn2 on load (fusion bit 12): with tb != nullptr the `v` of the three TRALite entry points below is point_conv2's conv
+// OUTPUT (format tb->ybf) and they apply point_bn2 (no activation follows it) themselves, rounding to `bf` as the stored
+// activation was -- same values as the separate normalise pass, which disappears together with the stored activation
+struct TraBn {
+    const float *stats, *gamma, *beta;     // mean[8] invstd[8], weight, bias of point_bn2
+    int ybf;
+};
 // TRALite (:122-139) on v [B][Tt][33][8]: e = mean_F v^2; y = dw conv1d k=3 causal; g = sigmoid(1x1(y))
 int tra_fwd(const float* v, int B, int Tt, const float* dw_w, const float* dw_b, const float* pw_w,
-            const float* pw_b, float* e, float* y, float* g, hipStream_t s, int bf = 0);
+            const float* pw_b, float* e, float* y, float* g, hipStream_t s, int bf = 0, const TraBn* tb = nullptr);
 // out[b,t,f,2c] = v[b,t,f,c] * g[b,t,c], out[b,t,f,2c+1] = x[b,t,f,8+c]   (shuffle, :222-227), t < T
 // skip (format bf; not with out2): out = the block output + skip, see bn_act's post
 int gate_shuffle_fwd(const float* v, const float* g, const float* x, int B, int T, int Tt, float* out, hipStream_t s,
-                     int bf = 0, float* out2 = nullptr, int out2_bf = 0, const float* skip = nullptr);
+                     int bf = 0, float* out2 = nullptr, int out2_bf = 0, const float* skip = nullptr,
+                     const TraBn* tb = nullptr);
 // backward of tra + gate + shuffle: dout [B][T][33][16] -> dv [B][Tt][33][8] (written), dx channels 8..15 (written; dx_acc:
 // added to what dx holds), parameter gradients written.  tmp: 3 * B*Tt*8 floats; scratch: MAX_PARTIALS * 80 floats.
 int tra_gate_shuffle_bwd(const float* dout, const float* v, const float* g, const float* e, const float* y, int B,
                          int T, int Tt, const float* dw_w, const float* pw_w, float* dv, float* dx, float* d_dw_w,
                          float* d_dw_b, float* d_pw_w, float* d_pw_b, float* tmp, float* scratch, hipStream_t s,
-                         int bf = 0, int dx_acc = 0);
+                         int bf = 0, int dx_acc = 0, const TraBn* tb = nullptr);
 
 // HybridLoss (loss.py:30-71).  hybrid_loss_spec: the three spectral terms -- per-workgroup sums (sum of squared
 // compressed real+imag differences, sum of squared compressed-magnitude differences) into `partial`, and their

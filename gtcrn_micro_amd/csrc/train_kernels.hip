@@ -3073,14 +3073,50 @@ __global__ __launch_bounds__(NT) void k_bs_mask_bwd_t(const float* __restrict__ 
 }
 
 // ---------------------------------------------------------------------------------- TRALite
+// point_bn2 on load (fusion bit 12): TRALite's input v is point_bn2(point_conv2(.)) with NO activation behind it
+// (models/gtcrn_micro.py:222-223, 248), read by four kernels -- energy, gate/shuffle and their two backward passes.  With
+// bn.stats != nullptr they take point_conv2's conv output y (format bn.ybf) instead and normalise it themselves: k_bn_act's
+// expression, rounded to the activations' storage format bf exactly as the stored activation was, so every value is the
+// one the separate pass (read y, write v: six launches per step) produced, bit for bit -- and v is never stored.
+struct BnLoad { const float *stats, *gamma, *beta; int ybf; };
+struct BnLoad4 { f32x4 mean, istd, gm, bt; };
+__device__ __forceinline__ BnLoad4 bnl_const(const BnLoad& b, int c0) {     // channels c0 .. c0 + 3 of 8
+    BnLoad4 k{};
+    if (b.stats) {
+        k.mean = *reinterpret_cast<const f32x4*>(b.stats + c0); k.istd = *reinterpret_cast<const f32x4*>(b.stats + 8 + c0);
+        k.gm = *reinterpret_cast<const f32x4*>(b.gamma + c0); k.bt = *reinterpret_cast<const f32x4*>(b.beta + c0);
+    }
+    return k;
+}
+__device__ __forceinline__ float bnl_apply1(float y, float mean, float istd, float gm, float bt, int bf) {
+    return round16(gm * ((y - mean) * istd) + bt, bf);
+}
+template <bool NTL>
+__device__ __forceinline__ f32x4 bnl_ld4(const BnLoad& b, const BnLoad4& k, const float* v, long idx, int bf) {
+    if (!b.stats) return sld4<NTL>(v, idx, bf);
+    const f32x4 y = sld4<NTL>(v, idx, b.ybf);
+    f32x4 a;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) a[e] = bnl_apply1(y[e], k.mean[e], k.istd[e], k.gm[e], k.bt[e], bf);
+    return a;
+}
 // TRALite.forward (models/gtcrn_micro.py:122-139) with a zero cache: e = mean_F(v^2); y = causal depthwise
 // conv1d (k=3, bias) over [0,0 | e]; g = sigmoid(point_conv(y)).  v: [B][Tt][33][8].
 __global__ __launch_bounds__(NT) void k_tra_energy(const float* __restrict__ v, long rows, float* __restrict__ e,
-                                                  int bf) {
+                                                  int bf, BnLoad bn) {
+    const int c_ = threadIdx.x & 7;                   // (the grid stride is a multiple of 8: a thread's channel is fixed)
+    const float mean = bn.stats ? bn.stats[c_] : 0.f, istd = bn.stats ? bn.stats[8 + c_] : 0.f;
+    const float gm = bn.stats ? bn.gamma[c_] : 0.f, bt = bn.stats ? bn.beta[c_] : 0.f;
     for (long i = (long)blockIdx.x * NT + threadIdx.x; i < rows * 8; i += (long)gridDim.x * NT) {
         const int c = (int)(i & 7);
         const long p = (i >> 3) * 33 * 8 + c;
         float s = 0.f;
+        if (bn.stats) {
+            for (int f = 0; f < 33; ++f) {
+                const float x = bnl_apply1(sld1(v, p + f * 8, bn.ybf), mean, istd, gm, bt, bf);
+                s = fmaf(x, x, s);
+            }
+        } else
         for (int f = 0; f < 33; ++f) { const float x = sld1(v, p + f * 8, bf); s = fmaf(x, x, s); }
         e[i] = s * (1.0f / 33.0f);
     }
@@ -3111,11 +3147,12 @@ __global__ __launch_bounds__(NT) void k_tra_gate(const float* __restrict__ e, in
 __global__ __launch_bounds__(NT) void k_gate_shuffle(const float* __restrict__ v, const float* __restrict__ g,
                                                     const float* __restrict__ x, int B, int T, int Tt,
                                                     float* __restrict__ out, int bf, float* __restrict__ out2,
-                                                    int out2_bf, const float* __restrict__ skip) {
+                                                    int out2_bf, const float* __restrict__ skip, BnLoad bn) {
     // thread (position, half h): channels 4h..4h+3 -> output slots 8h..8h+7; 16-byte accesses throughout
     // skip (optional, format bf): out = block output + skip, the next decoder layer's input (Decoder.forward,
     // models/gtcrn_micro.py:463-469: x = de_convs[i](x + en_outs[4 - i])) -- the block output has no other reader
     const long total = (long)B * T * 33 * 2;
+    const BnLoad4 bk = bnl_const(bn, 4 * (threadIdx.x & 1));      // (even grid stride: a thread's half h is fixed)
     for (long i = (long)blockIdx.x * NT + threadIdx.x; i < total; i += (long)gridDim.x * NT) {
         const int h = (int)(i & 1);
         const long pos = i >> 1;                      // (b, t, f) over T frames
@@ -3123,7 +3160,7 @@ __global__ __launch_bounds__(NT) void k_gate_shuffle(const float* __restrict__ v
         const long bt = pos / 33;
         const int t = (int)(bt % T), b = (int)(bt / T);
         const long rowv = (long)b * Tt + t;
-        const f32x4 vv = sld4<kNt>(v, (rowv * 33 + f) * 8 + 4 * h, bf);
+        const f32x4 vv = bnl_ld4<kNt>(bn, bk, v, (rowv * 33 + f) * 8 + 4 * h, bf);
         const f32x4 gg = *reinterpret_cast<const f32x4*>(g + rowv * 8 + 4 * h);
         const f32x4 xx = sld4(x, pos * 16 + 8 + 4 * h, bf);
         const f32x4 p = vv * gg;
@@ -3149,10 +3186,11 @@ __global__ __launch_bounds__(NT) void k_gate_shuffle_bwd(const float* __restrict
                                                         const float* __restrict__ dy, const float* __restrict__ v,
                                                         const float* __restrict__ dw_w, int B, int T, int Tt,
                                                         float* __restrict__ dv, float* __restrict__ dx, int bf,
-                                                        int dx_acc) {
+                                                        int dx_acc, BnLoad bn) {
     // thread (position of the T' frames, half h): channels 4h..4h+3; 16-byte accesses.  dx_acc: the pass-through half
     // is ADDED to what dx holds (the skip gradient of the same tensor, see gtcrn_train_backward)
     const long total = (long)B * Tt * 33 * 2;
+    const BnLoad4 bk = bnl_const(bn, 4 * (threadIdx.x & 1));
     for (long i = (long)blockIdx.x * NT + threadIdx.x; i < total; i += (long)gridDim.x * NT) {
         const int h = (int)(i & 1);
         const long posv = i >> 1;
@@ -3178,7 +3216,7 @@ __global__ __launch_bounds__(NT) void k_gate_shuffle_bwd(const float* __restrict
                 for (int e = 0; e < 4; ++e) de[e] = fmaf(dw_w[(4 * h + e) * 3 + k], dyv[e], de[e]);
             }
         }
-        const f32x4 vv = sld4<kNt>(v, posv * 8 + 4 * h, bf);
+        const f32x4 vv = bnl_ld4<kNt>(bn, bk, v, posv * 8 + 4 * h, bf);
         f32x4 o;
 #pragma unroll
         for (int e = 0; e < 4; ++e) o[e] = fmaf(de[e] * (2.0f / 33.0f), vv[e], r[e]);
@@ -3188,12 +3226,17 @@ __global__ __launch_bounds__(NT) void k_gate_shuffle_bwd(const float* __restrict
 // step 2: dg = sum_F dout[2c] * v  ->  dzg = dg * g * (1 - g)
 __global__ __launch_bounds__(NT) void k_tra_dgate(const float* __restrict__ dout, const float* __restrict__ v,
                                                  const float* __restrict__ g, int B, int T, int Tt,
-                                                 float* __restrict__ dzg, int bf) {
+                                                 float* __restrict__ dzg, int bf, BnLoad bn) {
     // one wave per row (b, t): lane (position, quad q) takes dout slots 4q..4q+3 = channels 2q, 2q+1 (16-byte loads;
     // one thread per (row, channel) walked the 33 bins with 4-byte loads at a 64-byte stride), then the lanes of a
     // quad are summed by xor shuffles
     const long rows = (long)B * Tt;
     const int lane = threadIdx.x & 63, q = lane & 3;
+    float bm[2] = {0.f, 0.f}, bi[2] = {0.f, 0.f}, bg[2] = {0.f, 0.f}, bb[2] = {0.f, 0.f};   // channels 2q, 2q + 1
+    if (bn.stats)
+        for (int e = 0; e < 2; ++e) {
+            bm[e] = bn.stats[2 * q + e]; bi[e] = bn.stats[8 + 2 * q + e]; bg[e] = bn.gamma[2 * q + e]; bb[e] = bn.beta[2 * q + e];
+        }
     const long nw = (long)gridDim.x * (NT / 64);
     for (long rowv = (long)blockIdx.x * (NT / 64) + (threadIdx.x >> 6); rowv < rows; rowv += nw) {
         const int t = (int)(rowv % Tt), b = (int)(rowv / Tt);
@@ -3206,8 +3249,13 @@ __global__ __launch_bounds__(NT) void k_tra_dgate(const float* __restrict__ dout
                 if (it < 132) {
                     const int pos = it >> 2;
                     const f32x4 d = *reinterpret_cast<const f32x4*>(dout + dbase + pos * 16 + 4 * q);
-                    s0 = fmaf(d[0], sld1(v, vbase + pos * 8 + 2 * q, bf), s0);
-                    s1 = fmaf(d[2], sld1(v, vbase + pos * 8 + 2 * q + 1, bf), s1);
+                    if (bn.stats) {
+                        s0 = fmaf(d[0], bnl_apply1(sld1(v, vbase + pos * 8 + 2 * q, bn.ybf), bm[0], bi[0], bg[0], bb[0], bf), s0);
+                        s1 = fmaf(d[2], bnl_apply1(sld1(v, vbase + pos * 8 + 2 * q + 1, bn.ybf), bm[1], bi[1], bg[1], bb[1], bf), s1);
+                    } else {
+                        s0 = fmaf(d[0], sld1(v, vbase + pos * 8 + 2 * q, bf), s0);
+                        s1 = fmaf(d[2], sld1(v, vbase + pos * 8 + 2 * q + 1, bf), s1);
+                    }
                 }
             }
         }
@@ -4188,31 +4236,36 @@ int bs_mask_bwd(const float* dout, long ob, long of, long ot, const float* spec,
     return check();
 }
 
+static BnLoad bn_load(const TraBn* tb) {
+    BnLoad b{};
+    if (tb && tb->stats) b = BnLoad{tb->stats, tb->gamma, tb->beta, tb->ybf};
+    return b;
+}
 int tra_fwd(const float* v, int B, int Tt, const float* dw_w, const float* dw_b, const float* pw_w,
-            const float* pw_b, float* e, float* y, float* g, hipStream_t s, int bf) {
+            const float* pw_b, float* e, float* y, float* g, hipStream_t s, int bf, const TraBn* tb) {
     const long rows = (long)B * Tt;
-    hipLaunchKernelGGL(k_tra_energy, dim3(grid_for(rows * 8)), dim3(NT), 0, s, v, rows, e, bf);
+    hipLaunchKernelGGL(k_tra_energy, dim3(grid_for(rows * 8)), dim3(NT), 0, s, v, rows, e, bf, bn_load(tb));
     hipLaunchKernelGGL(k_tra_gate, dim3(grid_for(rows * 8)), dim3(NT), 0, s, e, B, Tt, dw_w, dw_b, pw_w, pw_b, y, g);
     return check();
 }
 int gate_shuffle_fwd(const float* v, const float* g, const float* x, int B, int T, int Tt, float* out, hipStream_t s,
-                     int bf, float* out2, int out2_bf, const float* skip) {
+                     int bf, float* out2, int out2_bf, const float* skip, const TraBn* tb) {
     if (skip && out2) return (int)hipErrorInvalidValue;
     hipLaunchKernelGGL(k_gate_shuffle, dim3(grid_for((long)B * T * 33 * 2)), dim3(NT), 0, s, v, g, x, B, T, Tt, out, bf,
-                       out2, out2_bf, skip);
+                       out2, out2_bf, skip, bn_load(tb));
     return check();
 }
 int tra_gate_shuffle_bwd(const float* dout, const float* v, const float* g, const float* e, const float* y, int B,
                          int T, int Tt, const float* dw_w, const float* pw_w, float* dv, float* dx, float* d_dw_w,
                          float* d_dw_b, float* d_pw_w, float* d_pw_b, float* tmp, float* scratch, hipStream_t s,
-                         int bf, int dx_acc) {
+                         int bf, int dx_acc, const TraBn* tb) {
     const long rows = (long)B * Tt;
     float* dzg = tmp;
     float* dy = tmp + rows * 8;
-    hipLaunchKernelGGL(k_tra_dgate, dim3(grid_for(rows * 64, 8192)), dim3(NT), 0, s, dout, v, g, B, T, Tt, dzg, bf);
+    hipLaunchKernelGGL(k_tra_dgate, dim3(grid_for(rows * 64, 8192)), dim3(NT), 0, s, dout, v, g, B, T, Tt, dzg, bf, bn_load(tb));
     hipLaunchKernelGGL(k_tra_dy, dim3(grid_for(rows * 8)), dim3(NT), 0, s, dzg, rows, pw_w, dy);
     hipLaunchKernelGGL(k_gate_shuffle_bwd, dim3(grid_for(rows * 33 * 2)), dim3(NT), 0, s, dout, g, dy, v, dw_w, B, T, Tt, dv,
-                       dx, bf, dx_acc);
+                       dx, bf, dx_acc, bn_load(tb));
     const int parts = (int)(rows < MAX_PARTIALS ? rows : MAX_PARTIALS);
     hipLaunchKernelGGL(k_tra_pgrad, dim3(parts), dim3(1024), 0, s, dzg, y, dy, e, B, Tt, scratch);
     // the four gradients are contiguous in the blob in exactly the partials' order (d_dw_w is the first)

@@ -40,7 +40,9 @@ class FlatAdam(torch.optim.Optimizer):
         super().__init__(list(m.parameters()), defaults)
         self._model = m
         self._m = self._v = self._mask = None
-        self._step_t = torch.tensor(0.0)          # ONE step counter shared by the per-parameter state entries
+        self._nstep = 0
+        self._steps = []          # one 0-d CPU tensor per parameter, like torch.optim.Adam's state["step"] (a tensor shared
+                                  # by all entries would be incremented 248 times per step by an Adam that loaded this state)
 
     # -- flat moments -------------------------------------------------------------------------------------------------
     def _adopt(self, device):
@@ -57,15 +59,17 @@ class FlatAdam(torch.optim.Optimizer):
             if "exp_avg" in st:
                 fm[off:off + numel].copy_(st["exp_avg"].reshape(-1))
                 fv[off:off + numel].copy_(st["exp_avg_sq"].reshape(-1))
-                step = float(st["step"]) if step is None else step
+                step = int(float(st["step"])) if step is None else step
             mask[off:off + numel] = 1.0
         if step is not None:
-            self._step_t = torch.tensor(step)
+            self._nstep = step
+        self._steps = []
         for p, (off, numel, shape) in zip(m._train_params, m._train_slices):
             st = self.state[p]
-            st["step"] = self._step_t
+            st["step"] = torch.tensor(float(self._nstep))
             st["exp_avg"] = fm[off:off + numel].view(shape)
             st["exp_avg_sq"] = fv[off:off + numel].view(shape)
+            self._steps.append(st["step"])
         self._m, self._v, self._mask = fm, fv, mask
 
     def load_state_dict(self, state_dict):
@@ -94,9 +98,10 @@ class FlatAdam(torch.optim.Optimizer):
                 if p.grad is not None:
                     g[off:off + numel].copy_(p.grad.reshape(-1))
         grp = self.param_groups[0]
-        self._step_t += 1
+        self._nstep += 1
+        torch._foreach_add_(self._steps, 1)         # (host tensors: what a state_dict carries)
         norm = torch.empty(2, device=flat.device, dtype=torch.float32)
-        _lib.clip_adam_step(flat, g, self._m, self._v, self._mask, int(self._step_t), grp["lr"], grp["betas"], grp["eps"],
+        _lib.clip_adam_step(flat, g, self._m, self._v, self._mask, self._nstep, grp["lr"], grp["betas"], grp["eps"],
                             grp["weight_decay"], max_norm, norm)
         if packed and max_norm > 0:
             for p, (off, numel, _) in zip(m._train_params, m._train_slices):

@@ -264,7 +264,10 @@ long gtcrn_trainer_workspace_bytes(gtcrn_trainer *t, int B, int T);
  * write-through hand-off, fixed summation order) instead of 92 one-workgroup finish launches per step.  bit 11 (fp32
  * storage): each of the decoder's five sums x + en_outs[..] (models/gtcrn_micro.py:463-469) is written by the layer
  * that produces x (the last TCN block's normalise pass, the decoder blocks' gate/shuffle, de_convs.3's normalise pass)
- * instead of an add pass; x itself is not stored (its test tap is sum - skip).  Default 4095.
+ * instead of an add pass; x itself is not stored (its test tap is sum - skip).  bit 12 (needs bit 0; not in storage
+ * mode 4): point_bn2 -- the one BatchNorm with no activation behind it -- is applied on load by its four readers
+ * (TRALite's energy, the gate/shuffle, their two backward passes): six normalise passes per step and the tensor they
+ * wrote are gone, the values are the same bit for bit.  Default 8191.
  * 0 runs the layer-at-a-time passes (tests/test_gpu_train.py compares them).  Takes effect at the next forward; not
  * part of the reference's interface. */
 int gtcrn_trainer_set_fusions(gtcrn_trainer *t, int mask);
