@@ -665,10 +665,49 @@ def batch_sweep_leg(eng, win, world, sync_all, max_over_ranks):
         last = time.perf_counter() - t0
         el = last / iters
         res[name] = {"B": B, "T": T, "ms_per_call": round(el * 1e3, 4), "frames_per_s": round(world * B * T / el, 1)}
+        if B <= 32:
+            # the small shapes are launch-bound (six launches + span bookkeeping on ~0.03 ms of work): the same call captured
+            # ONCE into a HIP graph and replayed -- what a serving loop with fixed shapes would do (the call is capturable:
+            # no allocation, no synchronisation inside; tests/test_gpu_infer.py::test_forward_wave_is_graph_capturable)
+            try:
+                cs = torch.cuda.Stream()
+                cs.wait_stream(torch.cuda.current_stream())
+                gr = torch.cuda.CUDAGraph()
+                with torch.cuda.stream(cs):
+                    eng.forward_wave(x, win, out=y)
+                    torch.cuda.synchronize()
+                    with torch.cuda.graph(gr, stream=cs):
+                        eng.forward_wave(x, win, out=y)
+                for _ in range(3):
+                    gr.replay()
+                sync_all()
+                t0 = time.perf_counter()
+                for _ in range(iters):
+                    gr.replay()
+                sync_all()
+                ge = (time.perf_counter() - t0) / iters
+                # latency of ONE call (enqueue + wait), direct and replayed: what a caller that needs the result sees
+                def one(fn, n=20):
+                    v = []
+                    for _ in range(n):
+                        t1 = time.perf_counter()
+                        fn()
+                        torch.cuda.synchronize()
+                        v.append(time.perf_counter() - t1)
+                    return sorted(v)[n // 2]
+                res[name]["graph_replay"] = {"ms_per_call": round(ge * 1e3, 4),
+                                             "frames_per_s": round(world * B * T / ge, 1),
+                                             "latency_ms_direct": round(one(lambda: eng.forward_wave(x, win, out=y)) * 1e3, 4),
+                                             "latency_ms_replay": round(one(gr.replay) * 1e3, 4)}
+                del gr
+            except Exception as e:
+                res[name]["graph_replay"] = {"error": repr(e)}
         del x, y
     base = res["256x4s"]["ms_per_call"] / (256 * 251)
     for v in res.values():
         v["per_frame_cost_rel_256"] = round(v["ms_per_call"] / (v["B"] * v["T"]) / base, 3)
+        if "ms_per_call" in v.get("graph_replay", {}):
+            v["graph_replay"]["per_frame_cost_rel_256"] = round(v["graph_replay"]["ms_per_call"] / (v["B"] * v["T"]) / base, 3)
     # a folder-like batch (enhance_folder's call): 48 clips of 2 .. 10 s in one variable-length launch sequence, with the
     # per-utterance kernels in time spans over the lengths (the default) and with one workgroup per utterance
     B, L = 48, 160000

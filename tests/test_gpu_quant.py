@@ -74,3 +74,33 @@ def test_quant_wave_path_and_batch_invariance(dev):
                                             "q": y.cpu().numpy()})
     assert all(np.isfinite(v["si_snr_db"]) and np.isfinite(v["sdr_db"]) for v in sc.values())
     assert abs(sc["q"]["si_snr_db"] - sc["fp32"]["si_snr_db"]) < 3.0
+
+
+def test_quant_full_size_batch_invariance(dev):
+    """BASELINE configs[4] at its own shape: B = 256 four-second clips through the int8-weight / fp16-activation variant in
+    ONE call; three utterances (first, middle, last) equal their own B = 1 runs bit for bit -- one workgroup per
+    utterance, no leakage between the 256 workgroups of a launch, the fp16 hand-off records of the right utterance; the
+    whole batch is finite and differs from the fp32 path (it IS the quantised computation)."""
+    from gtcrn_micro_amd import Engine
+    eng = Engine(load_params("dns3"), 0)
+    win = torch.hann_window(512).pow(0.5).cuda()
+    B, L = 256, 64000
+    gen = torch.Generator(device="cuda").manual_seed(256)
+    wave = torch.randn(B, L, device="cuda", generator=gen) * 0.1
+    wave[7] = 0.0                                        # a silent clip
+    y = eng.forward_wave_quant(wave, win)
+    assert y.shape == (B, 64000) and bool(torch.isfinite(y).all())
+    for b in (0, 7, 128, 255):
+        single = eng.forward_wave_quant(wave[b].contiguous(), win)
+        assert torch.equal(y[b], single), b
+    assert float(y[7].abs().max()) < 1e-4
+    fp32 = eng.forward_wave(wave, win)
+    d = float((y - fp32).abs().max() / fp32.abs().max())
+    assert 1e-4 < d < 0.5, d
+    # the spectrogram boundary at the same size, with the reference's int8 I/O convention as well
+    spec = torch.randn(B, 251, 257, 2, device="cuda", generator=gen).permute(0, 2, 1, 3) * 0.3
+    from oracle.quant_port import CALIB_SCALE
+    for scales in ((0.0, 0.0), (CALIB_SCALE, CALIB_SCALE * 2 ** 0.5)):
+        ys = eng.forward_spec_quant(spec, *scales)
+        for b in (0, 255):
+            assert torch.equal(ys[b:b + 1], eng.forward_spec_quant(spec[b:b + 1].contiguous(), *scales)), (b, scales)

@@ -13,9 +13,9 @@
 #                              fp32 train step
 # tools/profile_summary.py condenses them into the files committed under profiles/ (it takes the NEWEST file of a pass:
 # copy gpurun_out/<tag> with `cp -a`, a plain `cp -r` resets the modification times and the choice becomes arbitrary).
-# Second argument: which sections to run -- all (default), headline, stream, train.
+# Second argument: which sections to run -- all (default), headline, stream, train, cal.
 set -u
-TAG=${1:-r04}
+TAG=${1:-r05}
 WHAT=${2:-all}
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$R/gpurun_out/$TAG
@@ -36,6 +36,18 @@ fi
 # configs[2] (1024 streams, single-frame calls) and configs[3] (train step, fp32 and bf16 storage)
 if [ "$WHAT" = all ] || [ "$WHAT" = stream ]; then
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stream" -- python3 "$R/tools/stream_bench.py" > "$OUT/stream.log" 2>&1
+# HBM counters of the single-launch streaming step inside and past the Infinity Cache (state 0.16 / 2.5 / 10 GB)
+for N in 1024 16384 65536; do
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$OUT/stream_pmc_${N}_fetch" -- python3 "$R/tools/stream_bench.py" --streams $N --frames 16 > "$OUT/stream_pmc_${N}_fetch.log" 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$OUT/stream_pmc_${N}_write" -- python3 "$R/tools/stream_bench.py" --streams $N --frames 16 > "$OUT/stream_pmc_${N}_write.log" 2>&1
+done
+fi
+# FETCH_SIZE / WRITE_SIZE calibration for 4 / 8 / 16 bytes per lane (tools/ubench_fetch_size.hip, tools/fetch_calibration.py)
+if [ "$WHAT" = all ] || [ "$WHAT" = cal ]; then
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 "$R/tools/ubench_fetch_size.hip" -o /tmp/ub_fetch > "$OUT/fetch_cal_build.log" 2>&1
+/tmp/ub_fetch > "$OUT/fetch_cal_plain.log" 2>&1
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$OUT/fetch_cal_f" -- /tmp/ub_fetch 1 > "$OUT/fetch_cal_f.log" 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$OUT/fetch_cal_w" -- /tmp/ub_fetch 1 > "$OUT/fetch_cal_w.log" 2>&1
 fi
 if [ "$WHAT" = all ] || [ "$WHAT" = train ]; then
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/train_f32" -- python3 "$R/bench.py" --mode train --steps 3 --warmup 1 > "$OUT/train_f32.log" 2>&1

@@ -153,6 +153,26 @@ def main():
         out["per_storage_mode"] = modes
         json.dump(out, open(os.path.join(dst, f"{tag}_train_hbm_traffic.json"), "w"), indent=1)
         print("train traffic: %.1f GB per step" % out["total_GB_per_step"], json.dumps(modes))
+    # --- the single-launch streaming step under the HBM counters at several stream counts (state inside / past the
+    # Infinity Cache): bytes per frame-step against SURVEY 8d's 94 KB state-traffic figure
+    sres = {}
+    for N in (1024, 16384, 65536):
+        fs = [v for k, c in pmc(f"stream_pmc_{N}_fetch").items() if k == "k_stream_ms" for v in c.get("FETCH_SIZE", [])]
+        ws = [v for k, c in pmc(f"stream_pmc_{N}_write").items() if k == "k_stream_ms" for v in c.get("WRITE_SIZE", [])]
+        if not fs and not ws:
+            continue
+        fkb = sum(fs) / len(fs) if fs else 0.0
+        wkb = sum(ws) / len(ws) if ws else 0.0
+        byt = (2 * fkb + wkb) * 1024                           # 16-byte-per-lane reads: FETCH_SIZE x 2
+        sres[str(N)] = {"launches_sampled": max(len(fs), len(ws)), "FETCH_SIZE_KB_raw_per_step": round(fkb, 1),
+                        "WRITE_SIZE_KB_per_step": round(wkb, 1), "hbm_bytes_per_step": round(byt),
+                        "bytes_per_frame_step": round(byt / N, 1), "of_94KB_state_figure": round(byt / N / (94 * 1024), 3),
+                        "state_MiB": round(N * 152464 / 2 ** 20, 1)}
+    if sres:
+        sres["note"] = ("k_stream_ms, one launch per single-frame step of N streams; FETCH_SIZE x 2 + WRITE_SIZE per launch "
+                        "(the counters sit on the L2's memory side: Infinity-Cache hits are counted, MI355X_MICROARCH.md)")
+        json.dump(sres, open(os.path.join(dst, f"{tag}_stream_hbm_traffic.json"), "w"), indent=1)
+        print(json.dumps(sres, indent=1))
     # --- derived figures per kernel: executed matrix FLOP, pipe busy share, co-execution share, effective clock
     f = newest("trace", "*kernel_stats.csv")
     avg_ns = {short(r["Name"]): float(r["AverageNs"]) for r in csv.DictReader(open(f[0])) if short(r["Name"])} if f else {}
