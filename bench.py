@@ -615,8 +615,26 @@ def stream_capacity_leg(eng, world, sync_all, max_over_ranks, sizes=(1024, 4096,
         sync_all()
         last_el = time.perf_counter() - t0
         ms = last_el / calls * 1e3
+        # the same steps in the three-launch form (encoder / both GTCN stacks / decoder as kernels of their own, hand-offs
+        # through HBM: smaller workgroups' worth of LDS per kernel, three launches): the A/B of the one-launch step
+        ms3 = None
+        if hasattr(eng, "stream_form") and N <= 65536:
+            try:
+                eng.reserve(N, 1)
+                eng.stream_form(1)
+                for t in range(2):
+                    eng.stream_step(state, spec[:, :, t % frames:t % frames + 1], out=out)
+                sync_all()
+                t0 = time.perf_counter()
+                for t in range(calls):
+                    eng.stream_step(state, spec[:, :, t % frames:t % frames + 1], out=out)
+                sync_all()
+                ms3 = (time.perf_counter() - t0) / calls * 1e3
+            finally:
+                eng.stream_form(0)
         fs = N / (ms * 1e-3)
         res[str(N)] = {"ms_per_step": round(ms, 4), "frame_steps_per_s": round(world * fs, 1),
+                       "three_launch_form_ms_per_step": None if ms3 is None else round(ms3, 4),
                        "state_GB": round(N * sb / 1e9, 3), "state_in_infinity_cache": bool(N * sb <= 256 * 2**20),
                        "frac_of_state_bound": round(fs / bound, 4),
                        "state_bound_GBps_equiv": round(fs * STREAM_STATE_BYTES_PER_FRAME / 1e9, 1),

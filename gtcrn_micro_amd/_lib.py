@@ -81,6 +81,7 @@ def lib():
     L.gtcrn_pack_params_host.argtypes = [_c_f32p, cl, _c_f32p, ctypes.POINTER(ci)]
     L.gtcrn_debug_enable.argtypes = [_vp, ci]
     L.gtcrn_var_spans_enable.argtypes = [_vp, ci]
+    L.gtcrn_stream_form.argtypes = [_vp, ci]
     L.gtcrn_debug_tap.restype = cl
     L.gtcrn_debug_tap.argtypes = [_vp, ctypes.c_char_p, ci, _c_f32p, cl]
     L.gtcrn_debug_stamps.restype = cl
@@ -497,6 +498,11 @@ class Engine:
     def var_spans_enable(self, on=True):
         """Variable-length batches in time spans (default on; results are bit-identical either way -- the A/B switch)."""
         _check(lib().gtcrn_var_spans_enable(self._h, int(bool(on))))
+
+    def stream_form(self, form=0):
+        """Single-frame streaming steps: 0 = one launch per step (default), 1 = the three-launch form (A/B switch;
+        bit-identical results)."""
+        _check(lib().gtcrn_stream_form(self._h, int(form)))
 
     def tap(self, name, b, T):
         F = {"en0": 65, "de3": 65}.get(name, 33)

@@ -64,6 +64,8 @@ struct gtcrn_model {
     float* d_twid = nullptr; // 512 complex twiddles
     int* d_pref = nullptr;   // prefix table of a variable-length batch (1025 ints, see gtk::launch_len_prefix)
     bool var_spans = true;   // variable-length batches run in time spans (off: one workgroup per utterance, the A/B switch)
+    int stream_form = 0;     // single-frame streaming steps: 0 = ONE launch (k_stream_ms), 1 = the three-launch form
+                             // (encoder / both GTCN stacks / decoder, hand-offs through HBM): the A/B switch
     std::vector<int> h_pi;   // host copy of the int tables (slot permutations for the debug taps)
     // workspace for B x T
     long cap_bt = 0;         // capacity in (batch * frames)
@@ -172,7 +174,7 @@ int run_model(gtcrn_model* m, const float* spec_in, long isb, long isf, long ist
     m->last_fused_stream = false;
     // single-frame streaming step: ONE launch, nothing handed over through HBM (the three-launch form below remains
     // for the stage taps of the parity tests, which read the hand-off tensors)
-    if (state && T == 1 && !q && (!m->debug || m->debug_keep_fused) && gtk::stream_ms_usable(isb, osb)) {
+    if (state && T == 1 && !q && (!m->debug || m->debug_keep_fused) && m->stream_form == 0 && gtk::stream_ms_usable(isb, osb)) {
         tm.begin(K_STREAM_MS);
         LAUNCH_TRY(gtk::launch_stream_ms(spec_in, isb, isf, spec_out, osb, osf, B, pf, m->d_pi, state,
                                          (m->debug && m->d_stamps) ? m->d_stamps : nullptr, s));
@@ -624,6 +626,14 @@ int gtcrn_var_spans_enable(gtcrn_model* m, int on) {
     int rc = check_model(m);
     if (rc) return rc;
     m->var_spans = on != 0;
+    return 0;
+}
+
+int gtcrn_stream_form(gtcrn_model* m, int form) {
+    int rc = check_model(m);
+    if (rc) return rc;
+    if (form < 0 || form > 1) return fail(GTCRN_ERR_ARG, "gtcrn_stream_form: 0 (one launch) or 1 (three launches)");
+    m->stream_form = form;
     return 0;
 }
 

@@ -697,6 +697,71 @@ __global__ __launch_bounds__(NT) void k_conv_mfma(ConvGeom g, const float* __res
     const bool cin_ok = 4 * q < g.Cin, cout_ok = 4 * q < g.Cout;
     PreConst pk{};
     if constexpr (PRE) pk = pre_const(pre, q, g.CinT);
+    if constexpr (NKT * NKF == 1 && !WIN && !NEXT) {
+        // Pointwise convs (28 launches of a step, 21 of them normalise-on-load): SOFTWARE-PIPELINED over the wave's tiles --
+        // the loads of tile i + 1 (its 16 bytes per lane of input, and of the residual) are in flight while tile i is
+        // normalised, multiplied and stored.  With one tile's loads per wave at a time the kernel had 20 KB in flight per
+        // CU (five waves per SIMD x 1 KB) against the ~47 KB that 6 TB/s x the memory latency asks for: it moved 3.6 TB/s
+        // in fp32 storage and took the SAME time on half the bytes in bf16 storage (profiles/r05_train_*_kernel_stats.csv).
+        // Same expressions in the same order per tile: bit-identical results.
+        struct TileIn {
+            typename Raw4<FIN>::t raw;
+            f32x4 pres;
+            long pidx;
+            bool ok;
+        };
+        auto fetch = [&](const Pos& Q, bool pv_, TileIn& ti_) {
+            const int ti = Q.t + g.t_off[0];
+            const bool okt = pv_ && cin_ok && ti >= 0 && ti < g.Tin;
+            const long rowbase = ((long)Q.b * g.Tin + ti) * g.Fin;
+            int fi;
+            ti_.ok = tap_fi_t<true>(g, Q.f, 0, fi) && okt;
+            ti_.pidx = (rowbase + fi) * g.CinT + g.cin_off + 4 * q;
+            ti_.raw = sld4_raw<FIN>(in, ti_.ok ? ti_.pidx : 0L);
+            ti_.pres = f32x4{0.f, 0.f, 0.f, 0.f};
+            if constexpr (PRE)
+                if (pre.res) ti_.pres = sld4(pre.res, ti_.ok ? ti_.pidx : 0L, pre.exact ? 0 : pre.bf);
+        };
+        TileIn cur, nxt;
+        if (tile < tend) fetch(P, tile * 16 + n < npos, cur);
+        for (; tile < tend; ++tile) {
+            const long p = tile * 16 + n;
+            const bool pv = p < npos;
+            Pos Pn = P;
+            Pn.advance(16, g.Fout, g.Tout);
+            nxt = cur;
+            if (tile + 1 < tend) fetch(Pn, p + 16 < npos, nxt);          // (wave-uniform branch)
+            f32x4 acc = bv;
+            f32x4 d = dec4<FIN>(cur.raw);
+            if constexpr (PRE) {
+                const f32x4 yraw = d;
+                d = pre_apply(pk, d, pre.exact ? 0 : pre.bf, pre.res != nullptr, cur.pres);
+                if (cur.ok) {
+                    pre_store(pre, cur.pidx, d);
+                    pre_store_y(pre, pk, cur.pidx, yraw, pre.res != nullptr, cur.pres);
+                }
+            }
+            const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+            const f32x4 xv = cur.ok ? d : zero;
+            const f32x4 A = *reinterpret_cast<const f32x4*>(sW + n * 16 + 4 * q);
+#pragma unroll
+            for (int s4 = 0; s4 < 4; ++s4) acc = mfma4(A[s4], xv[s4], acc);
+            if (pv && cout_ok) {
+                if (g.out_bf) {
+                    acc = round_bf4(acc, g.out_bf);
+                    sst4<kNtSt>(out, p * g.CoutT + g.cout_off + 4 * q, g.out_bf, acc);
+                } else {
+                    f32x4* o = reinterpret_cast<f32x4*>(out + p * g.CoutT + g.cout_off + 4 * q);
+                    if (g.accumulate) { acc = *o + acc; *o = acc; }
+                    else sst4<kNtSt>(out, p * g.CoutT + g.cout_off + 4 * q, 0, acc);
+                }
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { const double a = (double)acc[e]; s1[e] += a; s2[e] = fma(a, a, s2[e]); }
+            }
+            cur = nxt;
+            P = Pn;
+        }
+    } else
     for (; tile < tend; ++tile) {
         const long p = tile * 16 + n;
         const bool pv = p < npos;

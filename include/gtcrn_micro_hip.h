@@ -186,6 +186,11 @@ int gtcrn_debug_enable(gtcrn_model *m, int on);
  * files fills the chip.  Results are bit-identical either way; on = 0 goes back to one workgroup per utterance (the A/B
  * switch of tests and measurements).  Default on. */
 int gtcrn_var_spans_enable(gtcrn_model *m, int on);
+/* Single-frame streaming steps (gtcrn_stream_step with nframes == 1): form 0 (default) runs the whole step as ONE
+ * kernel per four streams, nothing handed over through HBM; form 1 runs the three-launch form (encoder, both GTCN
+ * stacks, decoder; hand-off tensors in HBM) that the stage taps use.  Bit-identical outputs and ring state
+ * (tests/test_gpu_stream.py); the A/B switch of the capacity measurements. */
+int gtcrn_stream_form(gtcrn_model *m, int form);
 long gtcrn_debug_tap(gtcrn_model *m, const char *name, int b, float *h_dst, long cap);
 /* Diagnostic build only (libgtcrn_micro_hip_stamps.so, -DGT_STAMPS): per-workgroup sums of shader
  * cycles spent in each barrier-delimited phase of kernel 0 encoder, 1 gtcn1, 2 gtcn2, 3 decoder,

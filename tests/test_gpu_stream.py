@@ -489,3 +489,24 @@ def test_65536_streams_past_the_infinity_cache_equal_small_batches(dev):
         assert torch.equal(st[lo:lo + 4], st4), lo
     del st, spec, got
     torch.cuda.empty_cache()
+
+
+def test_stream_form_switch_gives_the_same_bits(dev):
+    """gtcrn_stream_form: the one-launch step (default) against the three-launch form without the stage taps (the A/B of
+    bench.py's stream_capacity leg): 70 streams (17 full workgroups of four + one of two), five frames -- outputs and
+    the whole ring state bit-equal; a wrong form is refused."""
+    from gtcrn_micro_amd import Engine, GtcrnError
+    eng = Engine(load_params("dns3"), 0)
+    N, T = 70, 5
+    gen = torch.Generator(device="cuda").manual_seed(70)
+    spec = (torch.randn(N, T, 257, 2, device="cuda", generator=gen) * 0.3).permute(0, 2, 1, 3)
+    st0, st1 = eng.new_state(N), eng.new_state(N)
+    a = torch.cat([eng.stream_step(st0, spec[:, :, t:t + 1]) for t in range(T)], 2)
+    eng.stream_form(1)
+    try:
+        b = torch.cat([eng.stream_step(st1, spec[:, :, t:t + 1]) for t in range(T)], 2)
+    finally:
+        eng.stream_form(0)
+    assert torch.equal(a, b) and torch.equal(st0, st1)
+    with pytest.raises(GtcrnError):
+        eng.stream_form(2)

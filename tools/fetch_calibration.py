@@ -22,14 +22,17 @@ def collect(d, counter):
 
 
 def label(name):
+    def width(n):
+        m = re.search(r"__vector\((\d)\)|ext_vector_type\((\d)\)", n)
+        return 4 * int(m.group(1) or m.group(2)) if m else 4
     if "rd_bf16x4" in name:
-        return "read 8 B/lane (4 x bf16, nontemporal)"
-    if name.startswith("void rd<") or " rd<" in name or name.startswith("rd<"):
-        w = 4 if "ext_vector_type" not in name else 4 * int(re.search(r"ext_vector_type\((\d)\)", name).group(1))
-        return f"read {w} B/lane ({'nontemporal' if 'true>' in name else 'plain'})"
+        return "read 8 B/lane (4 x bf16 decoded, nontemporal)"
+    if "rd<" in name:
+        head = name[name.index("rd<"):name.index(">(") + 1]
+        return f"read {width(head)} B/lane ({'nontemporal' if 'true>' in head else 'plain'})"
     if "cp<" in name:
-        w = 4 if "ext_vector_type" not in name else 4 * int(re.search(r"ext_vector_type\((\d)\)", name).group(1))
-        return f"copy {w} B/lane"
+        head = name[name.index("cp<"):name.index(">(") + 1]
+        return f"copy {width(head)} B/lane"
     return None
 
 

@@ -59,7 +59,10 @@ def main():
     # coalesced read (16 B per lane) -> doubled for the kernels whose reads are 16 B per lane
     # (k_decoder, k_gtcn); other access widths are "uncalibrated" there, so for the kernels that
     # read 4/8 B per lane the raw value is kept and the known byte count is quoted beside it.
-    WIDE = {"k_decoder", "k_gtcn", "k_encoder"}
+    # Round 5 calibrated the other widths (tools/ubench_fetch_size.hip -> profiles/r05_fetch_calibration.json): a fully
+    # coalesced streaming read is tallied at HALF its bytes at 4, 8 and 16 bytes per lane alike, plain or nontemporal
+    # (factor 2.000 +- 1e-4 on 1 GiB); WRITE_SIZE is exact at every width.  One multiplier for every kernel.
+    WIDE = {"k_decoder", "k_gtcn", "k_encoder", "k_front", "k_istft", "k_stft", "k_stream_ms", "k_gtcn_ms", "k_state_convert"}
     traffic = {}
     for k in sorted(set(fetch) | set(write)):
         fs = fetch.get(k, {}).get("FETCH_SIZE", [])
@@ -71,8 +74,9 @@ def main():
             "FETCH_SIZE_KB_raw_per_launch": fkb, "WRITE_SIZE_KB_per_launch": wkb,
             "fetch_multiplier": mult,
             "hbm_bytes_per_launch": (mult * fkb * 1024 if fkb is not None else 0) + (wkb * 1024 if wkb is not None else 0),
-            "note": ("FETCH_SIZE doubled: 16 B/lane coalesced reads are tallied at 64 B per 128 B request on gfx950"
-                     if mult == 2 else "4/8 B per lane reads: FETCH_SIZE left raw (uncalibrated width)"),
+            "note": ("FETCH_SIZE doubled: coalesced streaming reads are tallied at half their bytes on gfx950 at 4, 8 and 16 B "
+                     "per lane (calibrated: profiles/r05_fetch_calibration.json)"
+                     if mult == 2 else "FETCH_SIZE left raw"),
             "launches_sampled": max(len(fs), len(ws)),
         }
     if traffic:
@@ -148,8 +152,9 @@ def main():
             if tot_f or tot_w:
                 modes[mode] = {"FETCH_SIZE_GB_raw_per_step": round(tot_f * 1024 / 4 / 1e9, 2),
                                "WRITE_SIZE_GB_per_step": round(tot_w * 1024 / 4 / 1e9, 2),
-                               "GB_per_step_fetch_x2": round((2 * tot_f + tot_w) * 1024 / 4 / 1e9, 1),
-                               "GB_per_step_fetch_x1": round((tot_f + tot_w) * 1024 / 4 / 1e9, 1)}
+                               # ONE figure since round 5: the x2 holds for the 8-byte-per-lane reads of the 16-bit
+                               # tensors too (profiles/r05_fetch_calibration.json)
+                               "GB_per_step": round((2 * tot_f + tot_w) * 1024 / 4 / 1e9, 1)}
         out["per_storage_mode"] = modes
         json.dump(out, open(os.path.join(dst, f"{tag}_train_hbm_traffic.json"), "w"), indent=1)
         print("train traffic: %.1f GB per step" % out["total_GB_per_step"], json.dumps(modes))
