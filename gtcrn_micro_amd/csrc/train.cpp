@@ -860,15 +860,15 @@ void gtcrn_trainer_destroy(gtcrn_trainer* t) {
 }
 
 static int storage_formats(int storage, int* bf, int* ybf) {
-    // 0: fp32 | 1: bf16.  (2, 3: diagnostics used while measuring where the bf16 gradient noise comes from -- bf16
-    // activations with fp32 / centred-fp16 conv outputs; neither lowers it, the noise enters through the activations)
-    // 4: bf16 SAVES only -- what the backward re-reads is stored as in mode 1, but the forward chain itself stays fp32
-    // (every forward tensor is written twice): the forward IS the fp32 network's, the gradient differs from it only
-    // by the rounding of the saved tensors
-    static const int F[5][2] = {{0, 0}, {1, 1}, {1, 0}, {1, 2}, {1, 1}};
-    if (storage < 0 || storage > 4) return -1;
-    *bf = F[storage][0];
-    *ybf = F[storage][1];
+    // 0: fp32 | 1: bf16 | 4: bf16 SAVES only -- what the backward re-reads is stored as in mode 1, but the forward chain
+    // itself stays fp32 (every forward tensor is written twice): the forward IS the fp32 network's, the gradient differs
+    // from it only by the rounding of the saved tensors.
+    // (2, 3 were diagnostics of rounds 2-4 -- bf16 activations with fp32 / centred-fp16 conv outputs, used to find out where
+    // the bf16 gradient noise comes from (neither lowers it: it enters through the activations).  Removed in round 5 with
+    // the fp16 format they needed: its run-time format switch cost every 16-bit conversion of the bf16 modes.)
+    if (storage != 0 && storage != 1 && storage != 4) return -1;
+    *bf = storage ? 1 : 0;
+    *ybf = storage ? 1 : 0;
     return 0;
 }
 
@@ -895,8 +895,8 @@ long gtcrn_trainer_workspace_bytes(gtcrn_trainer* t, int B, int T) {
 int gtcrn_trainer_set_storage(gtcrn_trainer* t, int storage) {
     int bf = 0, ybf = 0;
     if (!t || storage_formats(storage, &bf, &ybf))
-        return tfail(GTCRN_ERR_ARG, "gtcrn_trainer_set_storage: storage must be 0 (fp32), 1 (bf16), 4 (bf16 saves, fp32 "
-                                    "forward chain), or the diagnostic codes 2, 3");
+        return tfail(GTCRN_ERR_ARG, "gtcrn_trainer_set_storage: storage must be 0 (fp32), 1 (bf16) or 4 (bf16 saves, fp32 "
+                                    "forward chain)");
     const int exact = storage == 4;
     if (t->bf != bf || t->ybf != ybf || t->exact != exact) {
         t->bf = bf;

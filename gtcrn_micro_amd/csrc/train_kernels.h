@@ -41,8 +41,9 @@ struct ConvGeom {
 
 // Storage of the SAVED tensors (conv outputs, activations, block outputs -- everything the backward re-reads):
 // the format arguments of the functions below (`bf`: activations / block outputs, `ybf`: conv outputs in front of a
-// BatchNorm; in_bf / out_bf of the geometries) are 0 = fp32 (the reference's precision), 1 = bf16, 2 = fp16
-// (saturating).  A 16-bit tensor is passed through the same float* handle; its elements are 2 bytes wide.
+// BatchNorm; in_bf / out_bf of the geometries) are 0 = fp32 (the reference's precision), 1 = bf16 (the saturating fp16
+// code 2 of the diagnostic storage modes of rounds 2-4 is gone: its run-time format switch made every 16-bit conversion
+// compute both encodings).  A 16-bit tensor is passed through the same float* handle; its elements are 2 bytes wide.
 // Arithmetic, statistics, gradients and weights are fp32 throughout.
 
 // depthwise convolution (groups = channels), C channels:

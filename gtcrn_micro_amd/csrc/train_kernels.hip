@@ -203,21 +203,19 @@ __device__ __forceinline__ bool tap_fi_t(const ConvGeom& g, int fo, int kf, int&
 // arithmetic, statistics, gradients and master weights stay fp32).  The flag is a launch constant (wave-uniform
 // branch in front of a memory access of a streaming kernel: free); a bf16 tensor is addressed through the same
 // `float*` handle, its elements are 2 bytes wide.  Stores round to nearest even (v_cvt_pk_bf16_f32).
-// format codes: 0 fp32, 1 bf16, 2 fp16 (fp16 saturates at +-65504 instead of overflowing to infinity)
+// format codes: 0 fp32, non-zero bf16.  (Rounds 2-4 also carried a saturating fp16 format, code 2, for the diagnostic storage
+// modes that located the bf16 gradient noise.  With the format a RUN-TIME argument of most helpers below, every 16-bit
+// conversion then computed BOTH encodings and selected one -- about 12 vector instructions per rounded element instead
+// of 3 -- which is why k_dw16<3,1,PRE> took 165 us on bf16 tensors against 127 us on fp32 ones
+// (profiles/r05_train_{f32,bf16}_kernel_stats.csv).  Round 5 removed the fp16 format: the diagnostics are answered,
+// DESIGN.md section 8.)
 __device__ __forceinline__ float bf2f(unsigned h) { return __uint_as_float(h << 16); }
 __device__ __forceinline__ unsigned f2bf(float x) {
     const __bf16 h = (__bf16)x;
     return (unsigned)__builtin_bit_cast(unsigned short, h);
 }
-__device__ __forceinline__ float h2f(unsigned h) { return (float)__builtin_bit_cast(_Float16, (unsigned short)h); }
-__device__ __forceinline__ unsigned f2h(float x) {
-    // saturate finite values; NaN must survive (fminf / fmaxf return the non-NaN operand and would turn it into 65504):
-    // a diverged run has to stay visibly diverged in every storage mode
-    const _Float16 h = (_Float16)(x != x ? x : fminf(fmaxf(x, -65504.f), 65504.f));
-    return (unsigned)__builtin_bit_cast(unsigned short, h);
-}
-__device__ __forceinline__ float dec16(unsigned h, int fmt) { return fmt == 1 ? bf2f(h) : h2f(h); }
-__device__ __forceinline__ unsigned enc16(float x, int fmt) { return fmt == 1 ? f2bf(x) : f2h(x); }
+__device__ __forceinline__ float dec16(unsigned h, int fmt) { (void)fmt; return bf2f(h); }
+__device__ __forceinline__ unsigned enc16(float x, int fmt) { (void)fmt; return f2bf(x); }
 // one element.  NOTE for callers with unrolled load loops (the weight-gradient kernels): make `fmt` a COMPILE-TIME
 // constant there (template parameter).  A run-time `if (fmt)` around each load splits the loop into one basic block
 // per load, so the 36 loads of an iteration are no longer issued together (measured 1.8x longer with bf16 storage
@@ -697,7 +695,7 @@ __global__ __launch_bounds__(NT) void k_conv_mfma(ConvGeom g, const float* __res
     const bool cin_ok = 4 * q < g.Cin, cout_ok = 4 * q < g.Cout;
     PreConst pk{};
     if constexpr (PRE) pk = pre_const(pre, q, g.CinT);
-    if constexpr (NKT * NKF == 1 && !WIN && !NEXT) {
+    if constexpr (NKT * NKF == 1 && !WIN && !NEXT && FIN != 0) {
         // Pointwise convs (28 launches of a step, 21 of them normalise-on-load): SOFTWARE-PIPELINED over the wave's tiles --
         // the loads of tile i + 1 (its 16 bytes per lane of input, and of the residual) are in flight while tile i is
         // normalised, multiplied and stored.  With one tile's loads per wave at a time the kernel had 20 KB in flight per
