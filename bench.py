@@ -75,10 +75,31 @@ STREAM_STATE_BYTES_PER_FRAME = 94 * 1024        # ring-state traff
 # (round 4: every storage mode, dispatch by dispatch.  The x2 on FETCH_SIZE is calibrated for 16-byte-per-lane reads; the
 # 16-bit tensors are read 8 bytes per lane, for which the guide gives no factor: for the two 16-bit modes the figure
 # below is the UPPER reading, `traffic_lower` the raw one -- the truth lies between)
-TRAIN_HBM_BYTES_PER_STEP = {"f32": 131.4e9, "bf16": 91.4e9, "bf16_saves": 124.5e9}
-TRAIN_HBM_BYTES_PER_STEP_LOWER = {"f32": 131.4e9, "bf16": 60.9e9, "bf16_saves": 87.6e9}
-TRAIN_HBM_SOURCE = {m: "profiles/r04_train_hbm_traffic.json" for m in ("f32", "bf16", "bf16_saves")}
 ROUND_TAG = "r05"
+
+
+def train_hbm_bytes():
+    """Counter-measured HBM bytes of one B = 512 x 4 s train step per storage mode, read from the newest committed profile
+    (tools/profile_summary.py -> profiles/<tag>_train_hbm_traffic.json; FETCH_SIZE x 2 + WRITE_SIZE: the x 2 holds at 4, 8
+    and 16 bytes per lane, profiles/r05_fetch_calibration.json -- ONE figure per mode since round 5).  A constant of the
+    profiled build, not of the run that prints it: the source file is named in the line."""
+    for tag in (ROUND_TAG, "r04"):
+        fn = os.path.join(ROOT, "profiles", f"{tag}_train_hbm_traffic.json")
+        try:
+            modes = json.load(open(fn)).get("per_storage_mode", {})
+        except (OSError, ValueError):
+            continue
+        out = {}
+        for m, v in modes.items():
+            gb = v.get("GB_per_step", v.get("GB_per_step_fetch_x2"))
+            if gb:
+                out[m] = gb * 1e9
+        if out:
+            return out, f"profiles/{tag}_train_hbm_traffic.json"
+    return {}, None
+
+
+TRAIN_HBM_BYTES_PER_STEP, TRAIN_HBM_SOURCE_FILE = train_hbm_bytes()
 WATCHDOG_EXIT_CODE = 3                                  # exit status of every rank when a watchdog had to cut a leg
 
 
@@ -735,19 +756,21 @@ def batch_sweep_leg(eng, win, world, sync_all, max_over_ranks):
     y = torch.empty((B, 256 * (L // 256)), device="cuda")
     eng.reserve(B, 1 + L // 256)
     var = {"B": B, "frames": frames}
-    for key, on in (("spans", True), ("one_workgroup_per_utterance", False)):
-        eng.var_spans_enable(on)
-        for _ in range(3):
-            eng.forward_wave_var(x, lens, win, out=y)
-        sync_all()
-        t0 = time.perf_counter()
-        for _ in range(12):
-            eng.forward_wave_var(x, lens, win, out=y)
-        sync_all()
-        el = (time.perf_counter() - t0) / 12
-        var[key] = {"ms_per_call": round(el * 1e3, 4), "frames_per_s": round(world * frames / el, 1),
-                    "per_frame_cost_rel_256": round(el * 1e3 / frames / base, 3)}
-    eng.var_spans_enable(True)
+    try:
+        for key, on in (("spans", True), ("one_workgroup_per_utterance", False)):
+            eng.var_spans_enable(on)
+            for _ in range(3):
+                eng.forward_wave_var(x, lens, win, out=y)
+            sync_all()
+            t0 = time.perf_counter()
+            for _ in range(12):
+                eng.forward_wave_var(x, lens, win, out=y)
+            sync_all()
+            el = (time.perf_counter() - t0) / 12
+            var[key] = {"ms_per_call": round(el * 1e3, 4), "frames_per_s": round(world * frames / el, 1),
+                        "per_frame_cost_rel_256": round(el * 1e3 / frames / base, 3)}
+    finally:
+        eng.var_spans_enable(True)          # the engine is shared with the later legs: never leave the A/B switch off
     res["48x2-10s_var"] = var
     del x, y
     max_over_ranks(last, "cuda")
@@ -810,9 +833,9 @@ def train_run(ctx, world, sync_all, max_over_ranks, steps=5, warmup=2):
     roof = None if hbm_bytes is None else {
         "bound": "hbm", "achieved": round(hbm_bytes / el / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
         "frac": round(hbm_bytes / el / 1e9 / HBM_PEAK_GBS, 4), "traffic": hbm_bytes,
-        "traffic_lower": TRAIN_HBM_BYTES_PER_STEP_LOWER[storage] * (B * T) / (512 * 251),
-        "note": "whole train step: counter-measured HBM bytes per step (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, "
-                f"{TRAIN_HBM_SOURCE.get(storage)}) over this run's step time"}
+        "traffic_source": f"{TRAIN_HBM_SOURCE_FILE}: rocprofv3 FETCH_SIZE x 2 + WRITE_SIZE of the profiled build on the "
+                          "builder's box (a constant of that build, scaled by B x T; NOT measured by this run)",
+        "note": "whole train step: counter-measured HBM bytes per step over this run's step time"}
     return {
         "workload": f"train step, B={B} clips/GPU x {seconds:g} s (T={T}), saved activations {storage}, fp32 "
                     "accumulate + master weights, Adam, clip 3.0, synthetic DNS-style mixes",

@@ -708,9 +708,24 @@ long gtcrn_debug_stamps(gtcrn_model* m, int kernel, unsigned long long* h_dst, l
     return n;
 }
 
+namespace {
+// the self-tests own their scratch buffers and the device selection: both are put back on EVERY exit path
+struct DevBuf {
+    float* p = nullptr;
+    ~DevBuf() { if (p) (void)hipFree(p); }
+    hipError_t alloc(size_t bytes) { return hipMalloc(&p, bytes); }
+};
+struct DeviceScope {
+    int prev = -1;
+    DeviceScope() { if (hipGetDevice(&prev) != hipSuccess) prev = -1; }
+    ~DeviceScope() { if (prev >= 0) (void)hipSetDevice(prev); }
+};
+}  // namespace
+
 int gtcrn_selftest_mfma(int device) {
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(GTCRN_ERR_DEVICE, "no HIP device");
+    DeviceScope restore;
     HIP_TRY(hipSetDevice(device));
     float hA[64], hB[64], hC[256], hD[256], ref[256];
     for (int i = 0; i < 16; ++i)
@@ -724,16 +739,16 @@ int gtcrn_selftest_mfma(int device) {
             for (int k = 0; k < 4; ++k) s += hA[i * 4 + k] * hB[k * 16 + j];
             ref[i * 16 + j] = s;
         }
-    float *dA = nullptr, *dB = nullptr, *dC = nullptr, *dD = nullptr;
-    HIP_TRY(hipMalloc(&dA, sizeof(hA))); HIP_TRY(hipMalloc(&dB, sizeof(hB)));
-    HIP_TRY(hipMalloc(&dC, sizeof(hC))); HIP_TRY(hipMalloc(&dD, sizeof(hD)));
+    DevBuf bA, bB, bC, bD;
+    HIP_TRY(bA.alloc(sizeof(hA))); HIP_TRY(bB.alloc(sizeof(hB)));
+    HIP_TRY(bC.alloc(sizeof(hC))); HIP_TRY(bD.alloc(sizeof(hD)));
+    float *dA = bA.p, *dB = bB.p, *dC = bC.p, *dD = bD.p;
     HIP_TRY(hipMemcpy(dA, hA, sizeof(hA), hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(dB, hB, sizeof(hB), hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(dC, hC, sizeof(hC), hipMemcpyHostToDevice));
     LAUNCH_TRY(gtk::launch_selftest(dA, dB, dC, dD, nullptr));
     HIP_TRY(hipDeviceSynchronize());
     HIP_TRY(hipMemcpy(hD, dD, sizeof(hD), hipMemcpyDeviceToHost));
-    (void)hipFree(dA); (void)hipFree(dB); (void)hipFree(dC); (void)hipFree(dD);
     int bad = 0;
     for (int i = 0; i < 256; ++i) bad += hD[i] != ref[i];
     if (bad) return fail(GTCRN_ERR_DEVICE, "MFMA 16x16x4 f32 lane map differs from the assumed one (" +
@@ -747,12 +762,14 @@ int gtcrn_selftest_split3(int device, const float* h_x, long n, float* h_planes,
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(GTCRN_ERR_DEVICE, "no HIP device");
     if (!h_x || !h_planes || !h_joined || n < 4 || (n & 3)) return fail(GTCRN_ERR_ARG, "n must be a positive multiple of 4");
     if ((h_A || h_B || h_D) && !(h_A && h_B && h_D)) return fail(GTCRN_ERR_ARG, "A, B and D come together");
+    DeviceScope restore;
     HIP_TRY(hipSetDevice(device));
-    float *dx = nullptr, *dp = nullptr, *dj = nullptr, *dm = nullptr;
-    HIP_TRY(hipMalloc(&dx, sizeof(float) * n));
-    HIP_TRY(hipMalloc(&dp, sizeof(float) * 3 * n));
-    HIP_TRY(hipMalloc(&dj, sizeof(float) * n));
-    HIP_TRY(hipMalloc(&dm, sizeof(float) * (512 + 512 + 256)));
+    DevBuf bx, bp, bj, bm;             // (freed on every exit path, ADVICE r4: a failing call leaked all four)
+    HIP_TRY(bx.alloc(sizeof(float) * n));
+    HIP_TRY(bp.alloc(sizeof(float) * 3 * n));
+    HIP_TRY(bj.alloc(sizeof(float) * n));
+    HIP_TRY(bm.alloc(sizeof(float) * (512 + 512 + 256)));
+    float *dx = bx.p, *dp = bp.p, *dj = bj.p, *dm = bm.p;
     HIP_TRY(hipMemcpy(dx, h_x, sizeof(float) * n, hipMemcpyHostToDevice));
     if (h_A) {
         HIP_TRY(hipMemcpy(dm, h_A, sizeof(float) * 512, hipMemcpyHostToDevice));
@@ -763,7 +780,6 @@ int gtcrn_selftest_split3(int device, const float* h_x, long n, float* h_planes,
     HIP_TRY(hipMemcpy(h_planes, dp, sizeof(float) * 3 * n, hipMemcpyDeviceToHost));
     HIP_TRY(hipMemcpy(h_joined, dj, sizeof(float) * n, hipMemcpyDeviceToHost));
     if (h_D) HIP_TRY(hipMemcpy(h_D, dm + 1024, sizeof(float) * 256, hipMemcpyDeviceToHost));
-    (void)hipFree(dx); (void)hipFree(dp); (void)hipFree(dj); (void)hipFree(dm);
     return 0;
 }
 

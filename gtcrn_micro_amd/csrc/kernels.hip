@@ -3676,9 +3676,12 @@ struct SpanPlan {
     int nA, nwgB;
 };
 static long span_chunks(long frames) { return (frames + TC - 1) / TC * TC; }
+// (every round of workgroups also pays its prologue once -- parameters into LDS, rings zeroed, the first loads' latency:
+// about half a chunk; without the term a plan of several rounds of one-frame shares looked as cheap as one round)
+constexpr long SPAN_ROUND_FIXED = TC / 2;
 static long spans_cost(int nu, int T, int halo, int nwg) {
     const long total = (long)nu * T, per = (total + nwg - 1) / nwg;
-    return (long)(nwg / 256) * (span_chunks(per + halo) + ((T % per) ? TC : 0));
+    return (long)(nwg / 256) * (span_chunks(per + halo) + ((T % per) ? TC : 0) + SPAN_ROUND_FIXED);
 }
 static int best_spans(int nu, int T, int halo, long* cost) {
     int best = 0;
@@ -3696,13 +3699,13 @@ static int best_spans(int nu, int T, int halo, long* cost) {
 static SpanPlan span_plan(int B, int T, int halo, bool allowed) {
     SpanPlan p{B, 0};
     if (!allowed) return p;
-    long best = (long)((B + 255) / 256) * span_chunks(T), c = 0;
+    long best = (long)((B + 255) / 256) * (span_chunks(T) + SPAN_ROUND_FIXED), c = 0;
     const int all = best_spans(B, T, halo, &c);
     if (all && c < best) { best = c; p = SpanPlan{0, all}; }
     const int q = B / 256, r = B % 256;
     if (q >= 1 && r > 0) {
         const int rem = best_spans(r, T, halo, &c);
-        if (rem && (long)q * span_chunks(T) + c < best) p = SpanPlan{256 * q, rem};
+        if (rem && (long)q * (span_chunks(T) + SPAN_ROUND_FIXED) + c < best) p = SpanPlan{256 * q, rem};
     }
     return p;
 }
