@@ -645,3 +645,27 @@ def test_sharding_module_needs_no_torch_at_import():
     src = open(os.path.join(ROOT, "gtcrn_micro_amd", "sharding.py")).read()
     top = [n for n in ast.parse(src).body if isinstance(n, (ast.Import, ast.ImportFrom))]
     assert [a.name for n in top for a in n.names] == ["os"]
+
+
+def test_folder_driver_wav_fast_paths_are_the_generic_ones_byte_for_byte(tmp_path):
+    """The folder driver writes its 16-bit files with a hand-packed canonical header and reads mono 16-bit inputs from
+    their byte offset (infer.write_wav_pcm16 / read_pcm16_into): the bytes on disk are scipy.io.wavfile.write's, the
+    samples read are read_wav_f32's -- lengths 0 and 1, clipping and rounding ties included."""
+    from scipy.io import wavfile
+    from gtcrn_micro_amd.infer import read_pcm16_into, read_wav_f32, write_wav_pcm16
+    rng = np.random.default_rng(5)
+    for k, n in enumerate((0, 1, 257, 12345)):
+        x = (rng.standard_normal(n) * 0.6).astype(np.float32)
+        if n > 4:
+            x[:5] = [1.5, -1.5, 0.5 / 32768.0, 1.5 / 32768.0, -2.5 / 32768.0]      # clipping; rint's ties to even
+        a, b = tmp_path / f"a{k}.wav", tmp_path / f"b{k}.wav"
+        write_wav_pcm16(str(a), x)
+        wavfile.write(str(b), 16000, np.clip(np.rint(x * 32768.0), -32768, 32767).astype(np.int16))
+        assert a.read_bytes() == b.read_bytes(), n
+        if n:
+            fs, m = wavfile.read(str(b), mmap=True)
+            row = np.full(n + 7, np.nan, np.float32)
+            read_pcm16_into(str(b), int(m.offset), n, row)
+            assert np.array_equal(row[:n], read_wav_f32(str(b))[1]) and np.isnan(row[n:]).all()
+            with pytest.raises(RuntimeError):
+                read_pcm16_into(str(b), int(m.offset), n + 1, np.empty(n + 1, np.float32))     # the file got shorter
