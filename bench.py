@@ -584,6 +584,7 @@ def folder_leg(rank, world, local_rank, nclips=512):
             enh = os.path.join(root, "enh_" + key)
             enhance_folder(noisy, clean, enh, ck, device=local_rank, max_batch=64, pipeline=pipe, stats=st)
             out[key] = {"wall_s": round(st["wall_s"], 3), "frames_per_s": round(st["frames_per_s"], 1),
+                        "setup_s": round(st.get("setup_s", 0.0), 3),
                         "gpu_busy_frac": None if st["gpu_busy_frac"] is None else round(st["gpu_busy_frac"], 4)}
         # same bytes on disk from both forms
         same = all(open(os.path.join(root, "enh_pipelined", f), "rb").read() ==
@@ -594,6 +595,8 @@ def folder_leg(rank, world, local_rank, nclips=512):
                         "by length, one GPU",
             "clips": int(nclips), "frames": int(st["frames"]), "audio_s": round(float(lens.sum()) / 16000.0, 1),
             "frames_per_s": out["pipelined"]["frames_per_s"], "wall_s": out["pipelined"]["wall_s"],
+            "setup_s": out["pipelined"]["setup_s"],
+            "frames_per_s_after_setup": round(st["frames"] / max(out["pipelined"]["wall_s"] - out["pipelined"]["setup_s"], 1e-6), 1),
             "gpu_busy_frac": out["pipelined"]["gpu_busy_frac"],
             "serial": out["serial"], "speedup_over_serial": round(out["serial"]["wall_s"] / out["pipelined"]["wall_s"], 2),
             "files_identical_to_serial": bool(same), "host_cpus": os.cpu_count(),

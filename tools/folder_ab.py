@@ -18,6 +18,6 @@ for rep in range(3):
     for key, kw in (("serial", dict(pipeline=False)), ("pipe_io1", dict(io_threads=1)), ("pipe_io2", dict(io_threads=2)), ("pipe_io4", dict(io_threads=4)), ("pipe_io8", dict(io_threads=8))):
         st = {}
         enhance_folder(noisy, clean, os.path.join(root, "enh_" + key), ck, device=0, max_batch=64, stats=st, **kw)
-        res.setdefault(key, []).append(round(st["wall_s"], 4))
+        res.setdefault(key, []).append((round(st["wall_s"], 4), round(st.get("setup_s", 0.0), 4)))
 print(json.dumps(res))
 shutil.rmtree(root, ignore_errors=True)
