@@ -61,16 +61,6 @@ def write_wav_pcm16(path, x, fs=16000):
         data.tofile(f)
 
 
-def read_pcm16_into(path, offset, n, row):
-    """The fast path of the folder driver: ``n`` 16-bit samples at byte ``offset`` of a PCM file (both learnt from the
-    header in pass 1) straight into the float32 row ``row[:n]`` -- the same values as ``read_wav_f32`` (int16 / 32768 is
-    exact in fp32), without the generic reader's per-file Python."""
-    raw = np.fromfile(path, dtype="<i2", count=n, offset=offset)
-    if raw.size != n:
-        raise RuntimeError(f"{path} changed length while the folder was being enhanced")
-    np.multiply(raw, np.float32(1.0 / 32768.0), out=row[:n])
-
-
 def load_params(checkpoint):
     """``.tar``/``.pt`` checkpoint of the reference (``ckpt["model"]``, train.py:200-216) or a raw fp32 blob."""
     if checkpoint.endswith((".f32", ".bin")):
@@ -200,20 +190,28 @@ def _enhance_shard(noisy_dir, clean_dir, enh_dir, checkpoint, device=0, max_batc
             for j, i in enumerate(sel):
                 rows[i] = _finish_clip(y[j], items[i], enh_dir)
     else:
-        # ---- staging slots: capacity = the largest batch (clips x longest clip) of this shard
+        # ---- staging slots: capacity = the largest batch (clips x longest clip) of this shard.  The samples cross the
+        # host link as what they are on disk: 16-bit PCM in (a batch of mono 16-bit files is read straight into the pinned
+        # buffer and widened to float32 on the DEVICE: int16 / 32768 is exact), 16-bit PCM out (rint(y * 32768) clipped to
+        # the int16 range on the device -- numpy's rint and torch.round both round half to even -- so the host writes the
+        # bytes it receives).  Half the link traffic, and no per-sample work on the host at all; a batch with any other kind
+        # of file goes through the generic reader into float32 staging.
         cap = max(len(sel) * max(items[i][4] for i in sel) for sel in batches)
         nslot = max(1, min(int(stages), len(batches)))
         with torch.cuda.device(device):
-            slots = [{"hin": torch.empty(cap, dtype=torch.float32, pin_memory=True),
-                      "hout": torch.empty(cap, dtype=torch.float32, pin_memory=True),
-                      "din": torch.empty(cap, dtype=torch.float32, device=dev),
-                      "dout": torch.empty(cap, dtype=torch.float32, device=dev)} for _ in range(nslot)]
+            slots = [{"hin": torch.empty(cap * 4, dtype=torch.uint8, pin_memory=True),
+                      "hout": torch.empty(cap, dtype=torch.int16, pin_memory=True),
+                      "din": torch.empty(cap * 4, dtype=torch.uint8, device=dev),
+                      "dout": torch.empty(cap, dtype=torch.int16, device=dev)} for _ in range(nslot)]
+            xf = torch.empty(cap, dtype=torch.float32, device=dev)      # the compute stream takes one batch at a time:
+            yf = torch.empty(cap, dtype=torch.float32, device=dev)      # ONE float pair serves every slot
             s_in, s_cmp, s_out = torch.cuda.Stream(), torch.cuda.Stream(), torch.cuda.Stream()
         setup_s = time.perf_counter() - t_start       # page-locking the staging buffers: a fixed cost per shard
         free = threading.Semaphore(nslot)
         q_read, q_write = queue.Queue(), queue.Queue()
         abort = threading.Event()
         errors = []
+        generic = read_wav_f32 is not _READ_WAV_F32    # (a test swapped the generic reader: do not bypass it)
 
         def reader():
             try:
@@ -225,25 +223,49 @@ def _enhance_shard(noisy_dir, clean_dir, enh_dir, checkpoint, device=0, max_batc
                         return
                     lens = [items[i][4] for i in sel]
                     Lmax = max(lens)
-                    hin = slots[k % nslot]["hin"].numpy()[:len(sel) * Lmax].reshape(len(sel), Lmax)
+                    pcm = (not generic) and all(fast.get(i) is not None for i in sel)
+                    raw = slots[k % nslot]["hin"].numpy()
+                    hin = (raw[:len(sel) * Lmax * 2].view(np.int16) if pcm else raw[:len(sel) * Lmax * 4].view(np.float32)
+                           ).reshape(len(sel), Lmax)
 
-                    def fill(j, hin=hin, sel=sel, lens=lens):
-                        off = fast.get(sel[j])
-                        if off is not None and read_wav_f32 is _READ_WAV_F32:
-                            read_pcm16_into(items[sel[j]][1], off, lens[j], hin[j])
+                    def fill(j, hin=hin, sel=sel, lens=lens, pcm=pcm):
+                        path = items[sel[j]][1]
+                        if pcm:
+                            with open(path, "rb", buffering=0) as f:
+                                f.seek(fast[sel[j]])
+                                got = f.readinto(memoryview(hin[j, :lens[j]]).cast("B"))
+                            if got != 2 * lens[j]:
+                                raise RuntimeError(f"{path} changed length while the folder was being enhanced")
                         else:
-                            w = read_wav_f32(items[sel[j]][1])[1]
+                            w = read_wav_f32(path)[1]
                             if len(w) != lens[j]:
-                                raise RuntimeError(f"{items[sel[j]][1]} changed length while the folder was being enhanced")
+                                raise RuntimeError(f"{path} changed length while the folder was being enhanced")
                             hin[j, :len(w)] = w
-                        hin[j, lens[j]:] = 0.0
-                    list(pool_r.map(fill, range(len(sel))))          # (numpy's conversions and file reads drop the GIL)
-                    q_read.put((k, sel, lens, Lmax))
+                        hin[j, lens[j]:] = 0
+                    list(pool_r.map(fill, range(len(sel))))          # (file reads drop the GIL)
+                    q_read.put((k, sel, lens, Lmax, pcm))
             except Exception as e:
                 errors.append(e)
                 abort.set()
             finally:
                 q_read.put(None)
+
+        def finish_i16(row, item):
+            """The int16 form of _finish_clip: crop to the enhanced length, pad / crop to the clean length (infer.py:98-102),
+            canonical header + the samples as received."""
+            import struct
+            wav_name, _, ref_path, n_clean, L = item
+            n = min(256 * (L // 256), n_clean)
+            uid = wav_name.split(".wav")[0]
+            enh_path = os.path.join(enh_dir, uid + "_enh.wav")
+            header = struct.pack("<4sI4s4sIHHIIHH4sI", b"RIFF", 36 + 2 * n_clean, b"WAVE", b"fmt ", 16, 1, 1, 16000, 32000, 2,
+                                 16, b"data", 2 * n_clean)
+            with open(enh_path, "wb") as f:
+                f.write(header)
+                row[:n].tofile(f)
+                if n_clean > n:
+                    f.write(bytes(2 * (n_clean - n)))
+            return uid, enh_path, ref_path
 
         def writer():
             try:
@@ -254,7 +276,7 @@ def _enhance_shard(noisy_dir, clean_dir, enh_dir, checkpoint, device=0, max_batc
                     k, sel, Lout, ev_done, ev_a, ev_b = job
                     ev_done.synchronize()
                     y = slots[k % nslot]["hout"].numpy()[:len(sel) * Lout].reshape(len(sel), Lout)
-                    for i, row in zip(sel, pool_w.map(lambda j, y=y, sel=sel: _finish_clip(y[j], items[sel[j]], enh_dir),
+                    for i, row in zip(sel, pool_w.map(lambda j, y=y, sel=sel: finish_i16(y[j], items[sel[j]]),
                                                       range(len(sel)))):
                         rows[i] = row
                     busy.append(ev_a.elapsed_time(ev_b))
@@ -280,31 +302,40 @@ def _enhance_shard(noisy_dir, clean_dir, enh_dir, checkpoint, device=0, max_batc
                         continue
                     if job is None:
                         break
-                    k, sel, lens, Lmax = job
+                    k, sel, lens, Lmax, pcm = job
                     sl = slots[k % nslot]
                     n, Lout = len(sel), 256 * (Lmax // 256)
-                    x = sl["din"][:n * Lmax].view(n, Lmax)
-                    y = sl["dout"][:n * Lout].view(n, Lout)
+                    nb = n * Lmax * (2 if pcm else 4)
+                    x = xf[:n * Lmax].view(n, Lmax)
+                    y = yf[:n * Lout].view(n, Lout)
                     with torch.cuda.stream(s_in):
-                        x.copy_(sl["hin"][:n * Lmax].view(n, Lmax), non_blocking=True)
+                        sl["din"][:nb].copy_(sl["hin"][:nb], non_blocking=True)
                         ev_in = torch.cuda.Event()
                         ev_in.record()
                     with torch.cuda.stream(s_cmp):
                         s_cmp.wait_event(ev_in)
                         ev_a, ev_b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                         ev_a.record()
+                        if pcm:
+                            x.copy_(sl["din"][:nb].view(torch.int16).view(n, Lmax))     # int16 -> float32, exact
+                            x.mul_(1.0 / 32768.0)
+                        else:
+                            x.copy_(sl["din"][:nb].view(torch.float32).view(n, Lmax))
                         if min(lens) == Lmax:
                             eng.forward_wave(x, win, out=y)
                         else:
                             eng.forward_wave_var(x, lens, win, out=y)
+                        # write_wav_pcm16's conversion on the device: rint(y * 32768) clipped to the int16 range
+                        y.mul_(32768.0).round_().clamp_(-32768.0, 32767.0)
+                        sl["dout"][:n * Lout].view(n, Lout).copy_(y)
                         ev_b.record()
                     with torch.cuda.stream(s_out):
                         s_out.wait_event(ev_b)
-                        sl["hout"][:n * Lout].view(n, Lout).copy_(y, non_blocking=True)
+                        sl["hout"][:n * Lout].copy_(sl["dout"][:n * Lout], non_blocking=True)
                         ev_done = torch.cuda.Event()
                         ev_done.record()
-                    nbytes[0] += 4 * n * Lmax
-                    nbytes[1] += 4 * n * Lout
+                    nbytes[0] += nb
+                    nbytes[1] += 2 * n * Lout
                     q_write.put((k, sel, Lout, ev_done, ev_a, ev_b))
         except Exception as e:
             errors.append(e)

@@ -193,7 +193,12 @@ def test_pipelined_folder_driver_writes_the_serial_drivers_bytes(tmp_path):
     lens = [3000, 4096, 4097, 9000, 9000, 12345, 16000, 20000]
     for k in range(40):
         L = lens[k % len(lens)] + (k // len(lens)) * 7
-        wavfile.write(noisy_dir / f"n_fileid_{k}.wav", 16000, (rng.standard_normal(L) * 3000).astype(np.int16))
+        x = (rng.standard_normal(L) * 3000).astype(np.int16)
+        if k == 3:
+            x[:4] = [32767, -32768, 32767, -32768]                  # full scale: the output clips
+        # two files are NOT mono 16-bit PCM (32-bit PCM, float): their batches take the generic reader + float32 staging
+        wavfile.write(noisy_dir / f"n_fileid_{k}.wav", 16000,
+                      x.astype(np.int32) << 16 if k == 17 else (x.astype(np.float32) / 32768.0 if k == 30 else x))
         wavfile.write(clean_dir / f"clean_fileid_{k}.wav", 16000, np.zeros(L + (k % 3) * 100 - 100, np.int16))
     ck = os.path.join(GOLDEN, "params_dns3.f32")
     st_p, st_s = {}, {}
@@ -208,7 +213,8 @@ def test_pipelined_folder_driver_writes_the_serial_drivers_bytes(tmp_path):
         assert a == b and len(a) > 44, u
     assert st_p["clips"] == st_s["clips"] == 40 and st_p["batches"] == 7 and st_p["frames"] == st_s["frames"]
     assert st_p["pipeline"] is True and 0.0 < st_p["gpu_busy_frac"] <= 1.0 and st_s["gpu_busy_frac"] is None
-    assert st_p["h2d_bytes"] == st_s["h2d_bytes"] and st_p["d2h_bytes"] == st_s["d2h_bytes"]
+    # the pipeline moves the samples as 16-bit PCM both ways (converted on the device): half the serial form's bytes
+    assert 2 * st_p["h2d_bytes"] == st_s["h2d_bytes"] and 2 * st_p["d2h_bytes"] == st_s["d2h_bytes"]
     # a failing stage surfaces as an exception of the call (and the threads end): a clip that vanishes after pass 1
     import gtcrn_micro_amd.infer as I
     real = I.read_wav_f32

@@ -647,12 +647,13 @@ def test_sharding_module_needs_no_torch_at_import():
     assert [a.name for n in top for a in n.names] == ["os"]
 
 
-def test_folder_driver_wav_fast_paths_are_the_generic_ones_byte_for_byte(tmp_path):
-    """The folder driver writes its 16-bit files with a hand-packed canonical header and reads mono 16-bit inputs from
-    their byte offset (infer.write_wav_pcm16 / read_pcm16_into): the bytes on disk are scipy.io.wavfile.write's, the
-    samples read are read_wav_f32's -- lengths 0 and 1, clipping and rounding ties included."""
+def test_folder_driver_wav_writer_is_scipys_byte_for_byte(tmp_path):
+    """The folder driver writes its 16-bit files with a hand-packed canonical header (infer.write_wav_pcm16; the pipelined
+    form packs the same header around int16 samples converted on the device): the bytes on disk are
+    scipy.io.wavfile.write's -- lengths 0 and 1, clipping and rounding ties included -- and a mono 16-bit file's samples
+    start at the offset pass 1 learns from the memory map."""
     from scipy.io import wavfile
-    from gtcrn_micro_amd.infer import read_pcm16_into, read_wav_f32, write_wav_pcm16
+    from gtcrn_micro_amd.infer import read_wav_f32, write_wav_pcm16
     rng = np.random.default_rng(5)
     for k, n in enumerate((0, 1, 257, 12345)):
         x = (rng.standard_normal(n) * 0.6).astype(np.float32)
@@ -664,8 +665,5 @@ def test_folder_driver_wav_fast_paths_are_the_generic_ones_byte_for_byte(tmp_pat
         assert a.read_bytes() == b.read_bytes(), n
         if n:
             fs, m = wavfile.read(str(b), mmap=True)
-            row = np.full(n + 7, np.nan, np.float32)
-            read_pcm16_into(str(b), int(m.offset), n, row)
-            assert np.array_equal(row[:n], read_wav_f32(str(b))[1]) and np.isnan(row[n:]).all()
-            with pytest.raises(RuntimeError):
-                read_pcm16_into(str(b), int(m.offset), n + 1, np.empty(n + 1, np.float32))     # the file got shorter
+            raw = np.fromfile(str(b), dtype="<i2", count=n, offset=int(m.offset))
+            assert np.array_equal(raw.astype(np.float32) * np.float32(1.0 / 32768.0), read_wav_f32(str(b))[1])
