@@ -213,8 +213,9 @@ def test_pipelined_folder_driver_writes_the_serial_drivers_bytes(tmp_path):
         assert a == b and len(a) > 44, u
     assert st_p["clips"] == st_s["clips"] == 40 and st_p["batches"] == 7 and st_p["frames"] == st_s["frames"]
     assert st_p["pipeline"] is True and 0.0 < st_p["gpu_busy_frac"] <= 1.0 and st_s["gpu_busy_frac"] is None
-    # the pipeline moves the samples as 16-bit PCM both ways (converted on the device): half the serial form's bytes
-    assert 2 * st_p["h2d_bytes"] == st_s["h2d_bytes"] and 2 * st_p["d2h_bytes"] == st_s["d2h_bytes"]
+    # the pipeline moves the samples as 16-bit PCM (converted on the device): half the serial form's bytes out, and in for
+    # every batch of plain 16-bit files (the two batches holding the 32-bit and the float file are staged as float32)
+    assert 2 * st_p["d2h_bytes"] == st_s["d2h_bytes"] and st_s["h2d_bytes"] / 2 < st_p["h2d_bytes"] < st_s["h2d_bytes"]
     # a failing stage surfaces as an exception of the call (and the threads end): a clip that vanishes after pass 1
     import gtcrn_micro_amd.infer as I
     real = I.read_wav_f32
