@@ -940,7 +940,7 @@ def main(argv=None):
                     help="skip the stream/train/quant legs (profiling runs of the headline path)")
     ap.add_argument("--mode", choices=["infer", "train"], default="infer",
                     help="infer (default): the headline metric plus the secondary objects.  train: configs[3] only")
-    ap.add_argument("--train-storage", choices=["f32", "bf16", "bf16_saves"], default="f32")
+    ap.add_argument("--train-storage", choices=["f32", "bf16", "bf16_saves", "bf16_grads"], default="f32")
     args = ap.parse_args(argv)
     if args.gpus < 1:
         raise SystemExit("--gpus must be >= 1")
@@ -1172,7 +1172,7 @@ def main(argv=None):
                 params, local_rank, wave, win, world, sync_local, record, steps=args.steps), rank, world, get_line))
         del eng, wave, out
         torch.cuda.empty_cache()
-        for storage in ("f32", "bf16", "bf16_saves"):
+        for storage in ("f32", "bf16", "bf16_saves", "bf16_grads"):
             put(storage, guarded_train_leg(storage, rank, world, get_line), into="train")
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline and not shim:

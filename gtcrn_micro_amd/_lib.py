@@ -598,7 +598,8 @@ class Trainer:
 
     # "bf16_saves": what the backward re-reads is stored in bf16 (as in "bf16") while the forward chain itself stays fp32
     # -- the forward is the fp32 network's, bit for bit; the gradient differs only by the rounding of the saved tensors
-    STORAGE = {"f32": 0, "fp32": 0, "bf16": 1, "bf16_saves": 4}
+    # "bf16_grads": "bf16" with the gradients handed between units stored in bf16 too (what bf16 autocast training keeps)
+    STORAGE = {"f32": 0, "fp32": 0, "bf16": 1, "bf16_saves": 4, "bf16_grads": 5}
 
     @staticmethod
     def workspace_bytes(B, T, storage="f32"):
@@ -606,8 +607,9 @@ class Trainer:
 
     def set_storage(self, storage):
         """Storage of the saved activations: "f32" (the reference's precision), "bf16" (BASELINE configs[3]: bf16
-        activations in the forward too) or "bf16_saves" (bf16 copies for the backward only, fp32 forward chain);
-        arithmetic, statistics, gradients and weights are fp32 in all of them."""
+        activations in the forward too), "bf16_saves" (bf16 copies for the backward only, fp32 forward chain) or
+        "bf16_grads" ("bf16" whose inter-unit gradient tensors are bf16 as well); arithmetic, statistics, parameter
+        gradients and weights are fp32 in all of them."""
         if storage not in self.STORAGE:
             raise GtcrnError(f"storage must be one of {sorted(self.STORAGE)}, got {storage!r}")
         _check(lib().gtcrn_trainer_set_storage(self._h, self.STORAGE[storage]))

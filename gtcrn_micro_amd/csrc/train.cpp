@@ -110,6 +110,7 @@ struct gtcrn_trainer {
     int bf = 0;                   // format of the saved activations / block outputs: 0 fp32, 1 bf16
     int ybf = 0;                  // format of the saved conv outputs in front of a BatchNorm: 0 fp32, 1 bf16, 2 fp16
     int exact = 0;                // 1: bf16 SAVES only -- the forward chain itself runs in fp32 (storage code 4)
+    int gbf = 0;                  // 1: the gradient tensors handed between units are bf16 as well (storage code 5, with bf = ybf = 1)
     float *ebc = nullptr, *f0c = nullptr, *s3c = nullptr, *s4c = nullptr;   // fp32 twins of eb, f0, s3, s4 (exact chain)
     const float *dec_in[3] = {nullptr, nullptr, nullptr};                   // ... of the decoder blocks' first addends
     int B = 0, T = 0;
@@ -168,7 +169,10 @@ struct Bump {
         return p;
     }
     // a SAVED tensor of n elements (fp32 or bf16 per the trainer's storage); handled through a float* either way
+    int gbf = 0;
     float* take_saved(size_t n) { return take(bf ? (n + 1) / 2 : n); }
+    size_t gsz(size_t n) const { return gbf ? (n + 1) / 2 : n; }       // floats of an inter-unit gradient tensor of n elements
+    float* take_grad(size_t n) { return take(gsz(n)); }
     float* take_saved_y(size_t n) { return take(ybf ? (n + 1) / 2 : n); }
 };
 
@@ -272,6 +276,7 @@ size_t plan(gtcrn_trainer* t, int B, int T, float* base) {
     b.bf = t->bf;
     b.ybf = t->ybf;
     b.exact = t->exact;
+    b.gbf = t->gbf;
     const long n129 = (long)B * T * 129, n65 = (long)B * T * 65, n33 = (long)B * T * 33;
     const int T2 = T + 2;
     const long n33x = (long)B * T2 * 33;
@@ -455,16 +460,20 @@ size_t plan(gtcrn_trainer* t, int B, int T, float* base) {
     t->taps["de4"] = {t->de4.a, {T, 129, 2}};
     // ---- backward buffers
     const size_t bwd_begin = b.used;
-    t->gs0 = b.take(n65 * 16);
-    for (int i = 1; i < 5; ++i) t->gs[i] = b.take(n33 * 16);
-    t->q1 = b.take(n33 * 16); t->q2 = b.take(n33 * 16);
+    // (take_grad: the tensors handed from one unit's backward to the next are bf16 in storage mode 5; dy -- a unit's own
+    // scratch between its BatchNorm backward and its convs -- and dm / df0 at the two ends of the chain stay fp32)
+    t->gs0 = b.take_grad(n65 * 16);
+    for (int i = 1; i < 5; ++i) t->gs[i] = b.take_grad(n33 * 16);
+    t->q1 = b.take(std::max(b.gsz((size_t)n33 * 16), (size_t)n129 * 3));     // (also dm and df0, fp32: see below)
+    t->q2 = b.take_grad(n33 * 16);
     t->dy = b.take((size_t)std::max(std::max(n65 * 16, n33x * 16), n129 * 3));
     // dv, dhd, dh are contiguous: after the last GTConv block they are dead and serve as d65 (gradient of en0.a)
-    const size_t pool = (size_t)n33x * 8 + (size_t)n33x * 16 + (size_t)n33 * 16;
-    float* pl = b.take(std::max(pool + 192, (size_t)n65 * 16));
+    const size_t sz_dv = (b.gsz((size_t)n33x * 8) + 63) & ~size_t(63), sz_dhd = (b.gsz((size_t)n33x * 16) + 63) & ~size_t(63);
+    const size_t pool = sz_dv + sz_dhd + b.gsz((size_t)n33 * 16);
+    float* pl = b.take(std::max(pool + 192, b.gsz((size_t)n65 * 16)));
     t->dv = pl;
-    t->dhd = pl ? pl + (((size_t)n33x * 8 + 63) & ~size_t(63)) : nullptr;
-    t->dh = pl ? t->dhd + (((size_t)n33x * 16 + 63) & ~size_t(63)) : nullptr;
+    t->dhd = pl ? pl + sz_dv : nullptr;
+    t->dh = pl ? t->dhd + sz_dhd : nullptr;
     t->d65 = pl;
     t->tmp_tra = b.take((size_t)B * T2 * 8 * 3);
     // dm (gradient of the mask, consumed by the first backward unit) and df0 (gradient of the SFE output, produced by
@@ -672,8 +681,14 @@ int unit_fwd(gtcrn_trainer* t, Unit& u, float* prm, hipStream_t s) {
 }
 
 // da: gradient w.r.t. u.a (read only).  dx: where the data gradient goes (nullptr: not needed).
+// da_bf / dx_bf (-1: the trainer's gradient format t->gbf): storage format of da (and dres) / of dx.  Everything between two
+// units is in the trainer's format; the two ends of the chain -- dm, the mask's gradient, and df0, the SFE output's -- are fp32.
 int unit_bwd(gtcrn_trainer* t, Unit& u, const float* prm, float* grads, const float* da, float* dx, int dx_acc,
-             float* dres, int dres_acc, hipStream_t s) {
+             float* dres, int dres_acc, hipStream_t s, int da_bf = -1, int dx_bf = -1) {
+    if (da_bf < 0) da_bf = t->gbf;
+    if (dx_bf < 0) dx_bf = t->gbf;
+    const int gb = (da_bf && dx_bf) ? 1 : 0;          // the fused backward kernels take ONE gradient format
+    const bool fused_ok = da_bf == dx_bf;             // (a unit whose two sides differ takes the pass-by-pass form)
     const float* bn = prm + u.o_bn;
     float* gbn = grads + u.o_bn;
     // the BatchNorm reduction of this unit may already sit in dscratch (left by the kernel that produced da)
@@ -695,40 +710,40 @@ int unit_bwd(gtcrn_trainer* t, Unit& u, const float* prm, float* grads, const fl
         if ((t->fusions & 8) && u.x == f->a)
             nx.recompute_x = (t->bf && !t->exact) ? 2 : 1;
     }
-    if (!u.dw && u.cg.nkt == 1 && u.cg.nkf == 1 && u.cg.sf == 1 && (u.cg.Cin % 4) == 0 && (u.cg.Cout % 4) == 0) {
+    if (fused_ok && !u.dw && u.cg.nkt == 1 && u.cg.nkf == 1 && u.cg.sf == 1 && (u.cg.Cin % 4) == 0 && (u.cg.Cout % 4) == 0) {
         // pointwise unit: BatchNorm backward, data gradient and weight gradient in one pass (after the reduction)
         int parts = 0;
         T_RUN(gtt::unit1x1_bwd(u.cg, u.x, u.y, da, u.res, u.bstats, bn, bn + u.C, u.act,
                                u.o_slope >= 0 ? prm + u.o_slope : nullptr, prm + u.o_w, dx, dx_acc, dres, dres_acc,
                                grads + u.o_w, u.o_b >= 0 ? grads + u.o_b : nullptr, gbn, gbn + u.C,
                                u.o_slope >= 0 ? grads + u.o_slope : nullptr, t->dscratch, t->fscratch, s, t->bf,
-                               t->ybf, have_parts, ride && f->n == u.n ? &nx : nullptr, &parts));
+                               t->ybf, have_parts, ride && f->n == u.n ? &nx : nullptr, &parts, gb));
         if (parts != 0) { t->red_unit = f; t->red_parts = parts; }
         return 0;
     }
-    if (u.dw && u.C == 16 && u.dg.nkt == 3 && u.dg.nkf == 1 && u.act == gtt::ACT_PRELU && !u.res && u.o_slope >= 0 &&
+    if (fused_ok && u.dw && u.C == 16 && u.dg.nkt == 3 && u.dg.nkf == 1 && u.act == gtt::ACT_PRELU && !u.res && u.o_slope >= 0 &&
         dx && !dx_acc && !dres && t->bf == t->ybf && t->bf <= 1 && (t->fusions & 2)) {
         // TCN conv2: dy, weight gradient and data gradient in one pass; conv1's reduction rides along
         const bool ride2 = ride && !f->res && f->n == u.n;
         int parts = 0;
         T_RUN(gtt::dwunit_bwd(u.dg, u.x, u.y, da, u.bstats, bn, bn + u.C, prm + u.o_slope, prm + u.o_w, dx,
                               grads + u.o_w, u.o_b >= 0 ? grads + u.o_b : nullptr, gbn, gbn + u.C, grads + u.o_slope,
-                              t->dscratch, t->fscratch, s, t->bf, t->ybf, ride2 ? &nx : nullptr, &parts, have_parts));
+                              t->dscratch, t->fscratch, s, t->bf, t->ybf, ride2 ? &nx : nullptr, &parts, have_parts, gb));
         if (ride2 && parts != 0) { t->red_unit = f; t->red_parts = parts; }
         return 0;
     }
-    if (u.dw && u.C == 16 && u.dg.nkt == 3 && u.dg.nkf == 3 && u.dg.F == 33 && u.dg.Tin == u.dg.Tout && u.act == gtt::ACT_PRELU &&
+    if (fused_ok && u.dw && u.C == 16 && u.dg.nkt == 3 && u.dg.nkf == 3 && u.dg.F == 33 && u.dg.Tin == u.dg.Tout && u.act == gtt::ACT_PRELU &&
         !u.res && u.o_slope >= 0 && dx && !dx_acc && !dres && t->bf == t->ybf && t->bf <= 1 && (t->fusions & 64)) {
         // encoder depth_conv: dy, weight gradient and data gradient in one LDS-tiled pass; point_conv1's reduction rides along
         const bool ride3 = ride && !f->res && f->n == u.n;
         int parts = 0;
         T_RUN(gtt::dwunit33_bwd(u.dg, u.x, u.y, da, u.bstats, bn, bn + u.C, prm + u.o_slope, prm + u.o_w, dx,
                                 grads + u.o_w, u.o_b >= 0 ? grads + u.o_b : nullptr, gbn, gbn + u.C, grads + u.o_slope,
-                                t->dscratch, t->fscratch, s, t->bf, t->ybf, ride3 ? &nx : nullptr, &parts, have_parts));
+                                t->dscratch, t->fscratch, s, t->bf, t->ybf, ride3 ? &nx : nullptr, &parts, have_parts, gb));
         if (ride3 && parts != 0) { t->red_unit = f; t->red_parts = parts; }
         return 0;
     }
-    if (!u.dw && u.cg.nkt == 3 && u.cg.nkf == 3 && u.cg.f_mode == 1 && u.cg.Tout == u.cg.Tin + 2 && u.C == 16 &&
+    if (fused_ok && !u.dw && u.cg.nkt == 3 && u.cg.nkf == 3 && u.cg.f_mode == 1 && u.cg.Tout == u.cg.Tin + 2 && u.C == 16 &&
         u.act == gtt::ACT_PRELU && !u.res && u.o_slope >= 0 && dx && !dx_acc && !dres && t->bf == t->ybf && t->bf <= 1 &&
         (t->fusions & 128)) {
         // decoder depth_conv (dense transposed 3x3): dy and both matrix products from LDS tiles; point_conv1's reduction rides
@@ -736,11 +751,11 @@ int unit_bwd(gtcrn_trainer* t, Unit& u, const float* prm, float* grads, const fl
         int parts = 0;
         T_RUN(gtt::dense33_bwd(u.cg, u.x, u.y, da, u.bstats, bn, bn + u.C, prm + u.o_slope, prm + u.o_w, dx, grads + u.o_w,
                                u.o_b >= 0 ? grads + u.o_b : nullptr, gbn, gbn + u.C, grads + u.o_slope, t->dscratch,
-                               t->fscratch, s, t->bf, t->ybf, ride3 ? &nx : nullptr, &parts, have_parts));
+                               t->fscratch, s, t->bf, t->ybf, ride3 ? &nx : nullptr, &parts, have_parts, gb));
         if (ride3 && parts != 0) { t->red_unit = f; t->red_parts = parts; }
         return 0;
     }
-    if (!u.dw && u.cg.nkt == 1 && u.cg.nkf == 5 && u.cg.sf == 2 && u.cg.Cin == 16 && u.cg.Cout == 16 && u.C == 16 &&
+    if (fused_ok && !u.dw && u.cg.nkt == 1 && u.cg.nkf == 5 && u.cg.sf == 2 && u.cg.Cin == 16 && u.cg.Cout == 16 && u.C == 16 &&
         u.act == gtt::ACT_PRELU && !u.res && u.o_slope >= 0 && dx && !dres && u.x && t->bf == t->ybf && t->bf <= 1 &&
         (t->fusions & 512)) {
         // en_convs.1 / de_convs.3: dy and both matrix products from LDS tiles; en_convs.0's reduction rides on en_convs.1's dx
@@ -748,13 +763,13 @@ int unit_bwd(gtcrn_trainer* t, Unit& u, const float* prm, float* grads, const fl
         int parts = 0;
         T_RUN(gtt::conv15_bwd(u.cg, u.x, u.y, da, u.bstats, bn, bn + u.C, prm + u.o_slope, prm + u.o_w, dx, dx_acc,
                               grads + u.o_w, u.o_b >= 0 ? grads + u.o_b : nullptr, gbn, gbn + u.C, grads + u.o_slope,
-                              t->dscratch, t->fscratch, s, t->bf, t->ybf, ride5 ? &nx : nullptr, &parts, have_parts));
+                              t->dscratch, t->fscratch, s, t->bf, t->ybf, ride5 ? &nx : nullptr, &parts, have_parts, gb));
         if (ride5 && parts != 0) { t->red_unit = f; t->red_parts = parts; }
         return 0;
     }
     T_RUN(gtt::bn_act_bwd(da, u.y, u.n, u.C, u.bstats, bn, bn + u.C, u.res, u.act,
                           u.o_slope >= 0 ? prm + u.o_slope : nullptr, t->dy, dres, dres_acc, gbn, gbn + u.C,
-                          u.o_slope >= 0 ? grads + u.o_slope : nullptr, t->dscratch, s, t->bf, t->ybf, have_parts));
+                          u.o_slope >= 0 ? grads + u.o_slope : nullptr, t->dscratch, s, t->bf, t->ybf, have_parts, da_bf));
     // the adjoint conv produces the gradient input of the unit in front: that unit's reduction rides in its epilogue
     // (depthwise / dense 3x3 -> point_conv1, en_convs.1 -> en_convs.0; fusion bit 5).  dscratch is free again: this
     // unit's own partial sums were consumed by bn_act_bwd above
@@ -768,11 +783,15 @@ int unit_bwd(gtcrn_trainer* t, Unit& u, const float* prm, float* grads, const fl
     int parts = 0;
     if (u.dw) {
         T_RUN(gtt::dw_wgrad(u.dg, u.x, t->dy, grads + u.o_w, u.o_b >= 0 ? grads + u.o_b : nullptr, t->fscratch, s));
-        if (dx) T_RUN(gtt::dw_fwd(adjoint(u.dg, dx_acc), t->dy, prm + u.o_w, nullptr, dx, s, ride_adj ? t->dscratch : nullptr,
+        DwGeom ag = adjoint(u.dg, dx_acc);
+        ag.out_bf = dx_bf;                            // (dy, the adjoint's input, is this unit's fp32 scratch)
+        if (dx) T_RUN(gtt::dw_fwd(ag, t->dy, prm + u.o_w, nullptr, dx, s, ride_adj ? t->dscratch : nullptr,
                                   ride_adj ? &parts : nullptr, nullptr, nullptr, ride_adj ? &nx : nullptr, t->ybf));
     } else {
         T_RUN(gtt::conv_wgrad(u.cg, u.x, t->dy, grads + u.o_w, u.o_b >= 0 ? grads + u.o_b : nullptr, t->fscratch, s));
-        if (dx) T_RUN(gtt::conv_fwd(adjoint(u.cg, dx_acc), t->dy, prm + u.o_w, nullptr, dx, s, ride_adj ? t->dscratch : nullptr,
+        ConvGeom ag = adjoint(u.cg, dx_acc);
+        ag.out_bf = dx_bf;
+        if (dx) T_RUN(gtt::conv_fwd(ag, t->dy, prm + u.o_w, nullptr, dx, s, ride_adj ? t->dscratch : nullptr,
                                     ride_adj ? &parts : nullptr, nullptr, nullptr, ride_adj ? &nx : nullptr, t->ybf));
     }
     if (ride_adj && parts != 0) { t->red_unit = f; t->red_parts = parts; }
@@ -809,7 +828,7 @@ int gt_bwd(gtcrn_trainer* t, GtBlock& k, const float* prm, float* grads, const f
     const gtt::TraBn tb{k.pc2.bstats, bn2, bn2 + 8, t->ybf};
     T_RUN(gtt::tra_gate_shuffle_bwd(dout, k.bn2_load ? k.pc2.y : k.pc2.a, k.g, k.e, k.yt, t->B, t->T, k.Tt, tr, tr + 32, t->dv,
                                     dxin, gtr, gtr + 24, gtr + 32, gtr + 96, t->tmp_tra, t->fscratch, s, t->bf, acc,
-                                    k.bn2_load ? &tb : nullptr));
+                                    k.bn2_load ? &tb : nullptr, t->gbf));
     if ((rc = unit_bwd(t, k.pc2, prm, grads, t->dv, t->dhd, 0, nullptr, 0, s))) return rc;
     if ((rc = unit_bwd(t, k.depth, prm, grads, t->dhd, t->dh, 0, nullptr, 0, s))) return rc;
     if ((rc = unit_bwd(t, k.pc1, prm, grads, t->dh, dxin, acc, nullptr, 0, s))) return rc;   // channels 0..7
@@ -862,11 +881,12 @@ void gtcrn_trainer_destroy(gtcrn_trainer* t) {
 static int storage_formats(int storage, int* bf, int* ybf) {
     // 0: fp32 | 1: bf16 | 4: bf16 SAVES only -- what the backward re-reads is stored as in mode 1, but the forward chain
     // itself stays fp32 (every forward tensor is written twice): the forward IS the fp32 network's, the gradient differs
-    // from it only by the rounding of the saved tensors.
+    // from it only by the rounding of the saved tensors | 5: mode 1 with the gradients handed between units in bf16 too
+    // (round 5: what bf16 autocast training stores; the forward is mode 1's bit for bit).
     // (2, 3 were diagnostics of rounds 2-4 -- bf16 activations with fp32 / centred-fp16 conv outputs, used to find out where
     // the bf16 gradient noise comes from (neither lowers it: it enters through the activations).  Removed in round 5 with
     // the fp16 format they needed: its run-time format switch cost every 16-bit conversion of the bf16 modes.)
-    if (storage != 0 && storage != 1 && storage != 4) return -1;
+    if (storage != 0 && storage != 1 && storage != 4 && storage != 5) return -1;
     *bf = storage ? 1 : 0;
     *ybf = storage ? 1 : 0;
     return 0;
@@ -876,6 +896,7 @@ long gtcrn_train_workspace_bytes2(int B, int T, int storage) {
     gtcrn_trainer tmp;
     if (storage_formats(storage, &tmp.bf, &tmp.ybf)) return -1;
     tmp.exact = storage == 4;
+    tmp.gbf = storage == 5;
     for (const auto& p : gtcrn::param_table()) tmp.off[p.name] = p.offset;
     return (long)(plan(&tmp, B, T, nullptr) * sizeof(float));
 }
@@ -887,6 +908,7 @@ long gtcrn_trainer_workspace_bytes(gtcrn_trainer* t, int B, int T) {
     tmp.bf = t->bf;                    // every activation needs about 6 GiB more at B = 512 than the default)
     tmp.ybf = t->ybf;
     tmp.exact = t->exact;
+    tmp.gbf = t->gbf;
     tmp.fusions = t->fusions;
     tmp.off = t->off;
     return (long)(plan(&tmp, B, T, nullptr) * sizeof(float));
@@ -895,13 +917,14 @@ long gtcrn_trainer_workspace_bytes(gtcrn_trainer* t, int B, int T) {
 int gtcrn_trainer_set_storage(gtcrn_trainer* t, int storage) {
     int bf = 0, ybf = 0;
     if (!t || storage_formats(storage, &bf, &ybf))
-        return tfail(GTCRN_ERR_ARG, "gtcrn_trainer_set_storage: storage must be 0 (fp32), 1 (bf16) or 4 (bf16 saves, fp32 "
-                                    "forward chain)");
-    const int exact = storage == 4;
-    if (t->bf != bf || t->ybf != ybf || t->exact != exact) {
+        return tfail(GTCRN_ERR_ARG, "gtcrn_trainer_set_storage: storage must be 0 (fp32), 1 (bf16), 4 (bf16 saves, fp32 "
+                                    "forward chain) or 5 (bf16 with bf16 gradient hand-offs)");
+    const int exact = storage == 4, gbf = storage == 5;
+    if (t->bf != bf || t->ybf != ybf || t->exact != exact || t->gbf != gbf) {
         t->bf = bf;
         t->ybf = ybf;
         t->exact = exact;
+        t->gbf = gbf;
         t->planned = false;      // the arena is re-laid out on the next forward
         t->have_fwd = false;
     }
@@ -1008,7 +1031,10 @@ int gtcrn_train_backward(gtcrn_trainer* t, const float* d_params, const float* d
     T_RUN(gtt::bs_mask_bwd(d_grad_out, gb, gf, gt, d_spec, sb, sf, st, B, T, prm + P(t, "erb.ierb_fc.weight"), t->dm, s));
     // de_convs.4 <- s4 = de3.a + en0.a : gs0 is the gradient of both addends (the sums are recomputed, see plan())
     if (t->share_sums) T_RUN(gtt::add_saved(t->de3.a, t->en0.a, t->s4, n65, s, t->bf));
-    if ((rc = unit_bwd(t, t->de4, prm, G, t->dm, t->gs0, 0, nullptr, 0, s))) return rc;
+    if (t->gbf && !(t->fusions & 16))
+        return tfail(GTCRN_ERR_STATE, "gtcrn_train_backward: bf16 gradient hand-offs (storage 5) need fusion bit 4 (skip "
+                                      "gradients accumulated in place: the separate add passes are fp32)");
+    if ((rc = unit_bwd(t, t->de4, prm, G, t->dm, t->gs0, 0, nullptr, 0, s, 0, -1))) return rc;      // (dm: fp32)
     if (t->share_sums) T_RUN(gtt::add_saved(t->dec[2].out, t->en1.a, t->s3, n33, s, t->bf));
     if ((rc = unit_bwd(t, t->de3, prm, G, t->gs0, t->gs[1], 0, nullptr, 0, s))) return rc;   // gs[1]: d s3
     // decoder blocks 2,1,0: d s_i is the gradient of the previous block's output and of the skip en_outs[4-i]
@@ -1056,7 +1082,7 @@ int gtcrn_train_backward(gtcrn_trainer* t, const float* d_params, const float* d
             dout = t->gs[k + 1];
         }
         if ((rc = unit_bwd(t, t->en1, prm, G, dout, t->gs0, 1, nullptr, 0, s))) return rc;     // gs0 += : d en0.a
-        if ((rc = unit_bwd(t, t->en0, prm, G, t->gs0, t->df0, 0, nullptr, 0, s))) return rc;
+        if ((rc = unit_bwd(t, t->en0, prm, G, t->gs0, t->df0, 0, nullptr, 0, s, -1, 0))) return rc;      // (df0: fp32)
     }
     {   // SFE weight gradient (no bias); the ERB bank is frozen and the input is data: the chain ends here
         DwGeom g{};

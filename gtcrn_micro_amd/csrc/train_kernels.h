@@ -39,6 +39,10 @@ struct ConvGeom {
 // of the PReLU kink as the forward's value (ycopy_value in train_kernels.hip).  Only the forward kernels know about the
 // mode; the backward is the bf16 mode's, with statistics (0, invstd) for the centred copies.
 
+// gbf (the backward entry points): storage format of the GRADIENT tensors handed between units (da / dx / dres / dout /
+// dv): 0 fp32 (every mode up to round 4), 1 bf16 (storage mode 5, with bf = ybf = 1): a unit rounds the gradient it hands
+// on to bf16 where it stores it -- what autocast-style bf16 training does -- which halves the remaining fp32 streams of
+// the bf16 mode; the arithmetic inside a unit, the BatchNorm reductions and every parameter gradient stay fp32.
 // Storage of the SAVED tensors (conv outputs, activations, block outputs -- everything the backward re-reads):
 // the format arguments of the functions below (`bf`: activations / block outputs, `ybf`: conv outputs in front of a
 // BatchNorm; in_bf / out_bf of the geometries) are 0 = fp32 (the reference's precision), 1 = bf16 (the saturating fp16
@@ -138,7 +142,7 @@ int bn_act(const float* y, long n, int C, const float* stats, const float* gamma
 int bn_act_bwd(const float* da, const float* y, long n, int C, const float* stats, const float* gamma,
                const float* beta, const float* res, int act, const float* slope, float* dy, float* dres,
                int dres_acc, float* dgamma, float* dbeta, float* dslope, double* scratch, hipStream_t s, int bf = 0,
-               int ybf = 0, int have_parts = 0);
+               int ybf = 0, int have_parts = 0, int gbf = 0);
 
 // the unit in FRONT of a unit in the backward order, whose gradient input is that unit's dx: see `next` below
 struct DwUnitNext {
@@ -162,7 +166,7 @@ int unit1x1_bwd(const ConvGeom& g, const float* x, const float* y, const float* 
                 const float* w, float* dx, int dx_acc, float* dres, int dres_acc, float* dw, float* dbias,
                 float* dgamma, float* dbeta, float* dslope, double* dscratch, float* fscratch, hipStream_t s,
                 int bf = 0, int ybf = 0, int have_parts = 0, const DwUnitNext* next = nullptr,
-                int* next_parts = nullptr);
+                int* next_parts = nullptr, int gbf = 0);
 // The backward of a 16-channel depthwise (3,1) conv + BatchNorm + PReLU unit (TCN conv2) in two passes: the BatchNorm
 // reduction, then ONE kernel for dy (never stored), the weight / bias gradient and the data gradient dx.  next
 // (optional): the unit in front, whose gradient input is this dx -- its BatchNorm reduction is accumulated by the same
@@ -170,28 +174,28 @@ int unit1x1_bwd(const ConvGeom& g, const float* x, const float* y, const float* 
 int dwunit_bwd(const DwGeom& g, const float* x, const float* y, const float* da, const float* stats,
                const float* gamma, const float* beta, const float* slope, const float* w, float* dx, float* dw,
                float* dbias, float* dgamma, float* dbeta, float* dslope, double* dscratch, float* fscratch,
-               hipStream_t s, int bf, int ybf, const DwUnitNext* next, int* next_parts, int have_parts = 0);
+               hipStream_t s, int bf, int ybf, const DwUnitNext* next, int* next_parts, int have_parts = 0, int gbf = 0);
 
 // The same for the 16-channel depthwise 3x3 unit of the encoder's GTConv blocks (F == 33; taps t-2..t, f-1..f+1): one
 // LDS-tiled kernel for dy, the weight / bias gradient and dx.
 int dwunit33_bwd(const DwGeom& g, const float* x, const float* y, const float* da, const float* stats,
                  const float* gamma, const float* beta, const float* slope, const float* w, float* dx, float* dw,
                  float* dbias, float* dgamma, float* dbeta, float* dslope, double* dscratch, float* fscratch,
-                 hipStream_t s, int bf, int ybf, const DwUnitNext* next, int* next_parts, int have_parts = 0);
+                 hipStream_t s, int bf, int ybf, const DwUnitNext* next, int* next_parts, int have_parts = 0, int gbf = 0);
 
 // ... and for the decoder's dense transposed 3x3 unit (ConvTranspose2d(16,16,(3,3)): 33 bins, T + 2 output frames): both
 // matrix products (data gradient, weight gradient) from LDS images of dy and x.
 int dense33_bwd(const ConvGeom& g, const float* x, const float* y, const float* da, const float* stats,
                 const float* gamma, const float* beta, const float* slope, const float* w, float* dx, float* dw,
                 float* dbias, float* dgamma, float* dbeta, float* dslope, double* dscratch, float* fscratch,
-                hipStream_t s, int bf, int ybf, const DwUnitNext* next, int* next_parts, int have_parts = 0);
+                hipStream_t s, int bf, int ybf, const DwUnitNext* next, int* next_parts, int have_parts = 0, int gbf = 0);
 
 // ... and for the two 16 -> 16 (1,5) stride-2 units, en_convs.1 (Conv2d, 65 -> 33 bins) and de_convs.3 (ConvTranspose2d,
 // 33 -> 65 bins): dy and x of eight frames in LDS, weight gradient and data gradient from there; dx may accumulate.
 int conv15_bwd(const ConvGeom& g, const float* x, const float* y, const float* da, const float* stats,
                const float* gamma, const float* beta, const float* slope, const float* w, float* dx, int dx_acc,
                float* dw, float* dbias, float* dgamma, float* dbeta, float* dslope, double* dscratch, float* fscratch,
-               hipStream_t s, int bf, int ybf, const DwUnitNext* next, int* next_parts, int have_parts = 0);
+               hipStream_t s, int bf, int ybf, const DwUnitNext* next, int* next_parts, int have_parts = 0, int gbf = 0);
 
 // features: spec (strided (b,f,t) + re/im) -> EB [B][T][129][3] = ERB.bm([mag,re,im]) (models/gtcrn_micro.py:510-516)
 int feat_fwd(const float* spec, long sb, long sf, long st, int B, int T, const float* erb_w, float* eb,
@@ -222,7 +226,7 @@ int gate_shuffle_fwd(const float* v, const float* g, const float* x, int B, int 
 int tra_gate_shuffle_bwd(const float* dout, const float* v, const float* g, const float* e, const float* y, int B,
                          int T, int Tt, const float* dw_w, const float* pw_w, float* dv, float* dx, float* d_dw_w,
                          float* d_dw_b, float* d_pw_w, float* d_pw_b, float* tmp, float* scratch, hipStream_t s,
-                         int bf = 0, int dx_acc = 0, const TraBn* tb = nullptr);
+                         int bf = 0, int dx_acc = 0, const TraBn* tb = nullptr, int gbf = 0);
 
 // HybridLoss (loss.py:30-71).  hybrid_loss_spec: the three spectral terms -- per-workgroup sums (sum of squared
 // compressed real+imag differences, sum of squared compressed-magnitude differences) into `partial`, and their

@@ -816,6 +816,8 @@ __global__ __launch_bounds__(NT) void k_conv_mfma(ConvGeom g, const float* __res
         }
         if (pv && cout_ok) {
             if (g.out_bf) {
+                // (accumulate with a 16-bit output: the adjoint convs of storage mode 5, whose dx is a bf16 gradient tensor)
+                if (g.accumulate) acc = sld4(out, p * g.CoutT + g.cout_off + 4 * q, g.out_bf) + acc;
                 acc = round_bf4(acc, g.out_bf);   // the statistics are those of the STORED tensor (the backward re-reads it)
                 sst4<kNtSt>(out, p * g.CoutT + g.cout_off + 4 * q, g.out_bf, acc);
             } else {
@@ -1411,6 +1413,7 @@ __global__ __launch_bounds__(NT) void k_dw16(DwGeom g, const float* __restrict__
         }
         P.advance(it, g.F, g.Tout);
         if (g.out_bf) {
+            if (g.accumulate) acc = sld4(out, p * 16 + 4 * q, g.out_bf) + acc;
             acc = round_bf4(acc, g.out_bf);
             sst4<kNtSt>(out, p * 16 + 4 * q, g.out_bf, acc);
         } else {
@@ -1600,7 +1603,7 @@ __device__ __forceinline__ float act_bwd(float z, float g, int act, float sl, fl
 // a time after all (this read-only pass ran at 3.5 TB/s); FMT < 0: run-time flags (the odd channel counts).
 // ACT >= 0: the activation as a compile-time constant too (with the run-time switch every ELEMENT went through four
 // scalar branches: 64 taken branches per trip of a pass that should only wait for its loads)
-template <int V, int FMT = -1, int ACT = -1>
+template <int V, int FMT = -1, int ACT = -1, int GF = 0>      // GF: storage format of da (see k_unit1x1_bwd)
 __global__ __launch_bounds__(NT) void k_bn_bwd_reduce(const float* __restrict__ da, const float* __restrict__ y,
                                                      long total, int C, const float* __restrict__ stats,
                                                      const float* __restrict__ gamma, const float* __restrict__ beta,
@@ -1629,7 +1632,7 @@ __global__ __launch_bounds__(NT) void k_bn_bwd_reduce(const float* __restrict__ 
         for (int u = 0; u < U; ++u) {
             const long i = i0 + u * stride < units ? i0 + u * stride : i0;     // clamped: a valid element, not summed
             load_vec_s<V, kNt>(y, i * V, ybf, x[u]);
-            load_vec<V, kNt>(da + i * V, g[u]);
+            load_vec_s<V, kNt>(da, i * V, GF, g[u]);
             if (res) load_vec_s<V, kNt>(res, i * V, bf, r[u]);
         }
 #pragma unroll
@@ -1671,7 +1674,7 @@ __global__ __launch_bounds__(NT) void k_bn_bwd_apply(const float* __restrict__ d
                                                     const float* __restrict__ res, int act,
                                                     const float* __restrict__ slope, const float* __restrict__ red,
                                                     float* __restrict__ dy, float* __restrict__ dres, int dres_acc,
-                                                    int bf, int ybf) {
+                                                    int bf, int ybf, int gbf) {
     const float sl = slope ? slope[0] : 0.f;
     const long units = total / V;
     const int c0 = (int)((((long)blockIdx.x * NT + threadIdx.x) * V) % C);
@@ -1684,9 +1687,9 @@ __global__ __launch_bounds__(NT) void k_bn_bwd_apply(const float* __restrict__ d
     for (long i = (long)blockIdx.x * NT + threadIdx.x; i < units; i += (long)gridDim.x * NT) {
         float x[V], g[V], r[V], o[V], dzv[V];
         load_vec_s<V, kNt>(y, i * V, ybf, x);
-        load_vec<V, kNt>(da + i * V, g);
+        load_vec_s<V, kNt>(da, i * V, gbf, g);
         if (res) load_vec_s<V, kNt>(res, i * V, bf, r);
-        if (dres && dres_acc) load_vec<V, kNt>(dres + i * V, dzv);
+        if (dres && dres_acc) load_vec_s<V, kNt>(dres, i * V, gbf, dzv);
 #pragma unroll
         for (int e = 0; e < V; ++e) {
             const float xh = (x[e] - mean[e]) * istd[e];
@@ -1698,11 +1701,11 @@ __global__ __launch_bounds__(NT) void k_bn_bwd_apply(const float* __restrict__ d
             o[e] = gm[e] * istd[e] * (dz - m1[e] - xh * m2[e]);
         }
         if constexpr (V == 4) {
-            *reinterpret_cast<f32x4*>(dy + i * 4) = f32x4{o[0], o[1], o[2], o[3]};
-            if (dres) *reinterpret_cast<f32x4*>(dres + i * 4) = f32x4{dzv[0], dzv[1], dzv[2], dzv[3]};
+            *reinterpret_cast<f32x4*>(dy + i * 4) = f32x4{o[0], o[1], o[2], o[3]};     // (dy: this unit's own scratch, fp32)
+            if (dres) sst4(dres, i * 4, gbf, f32x4{dzv[0], dzv[1], dzv[2], dzv[3]});
         } else {
             dy[i] = o[0];
-            if (dres) dres[i] = dzv[0];
+            if (dres) sst1(dres, i, gbf, dzv[0]);
         }
     }
 }
@@ -1835,7 +1838,10 @@ struct BnBwdArgs {
     int act;
 };
 // NEXT: see NextRedArgs; rpartial [gridDim.x][48] doubles
-template <int FMT, int YF, bool NEXT = false, bool XR = false>   // storage formats of x / res and of y, compile time (see sld1)
+// GF: storage format of the GRADIENT tensors handed between units (da, dx, dres): 0 fp32, 1 bf16 (storage mode 5: the
+// inter-unit gradients of the bf16 mode are rounded to bf16 where a unit stores them -- what autocast-style training does --
+// which halves the remaining fp32 streams of that mode; arithmetic, reductions and parameter gradients stay fp32)
+template <int FMT, int YF, bool NEXT = false, bool XR = false, int GF = 0>   // storage formats of x / res and of y, compile time (see sld1)
 __global__ __launch_bounds__(NT) void k_unit1x1_bwd(ConvGeom g, const float* __restrict__ x, const float* __restrict__ y,
                                                    const float* __restrict__ da, const float* __restrict__ res,
                                                    BnBwdArgs bn, const float* __restrict__ w,
@@ -1921,7 +1927,7 @@ __global__ __launch_bounds__(NT) void k_unit1x1_bwd(ConvGeom g, const float* __r
         f32x4 dy = {0.f, 0.f, 0.f, 0.f};
         if (pv && co_ok4) {
             const f32x4 yv = sld4<kNt>(y, p * g.Cout + 4 * q, ybf);
-            const f32x4 gv = sld4<kNt>(da, p * g.Cout + 4 * q, 0);
+            const f32x4 gv = sld4<kNt>(da, p * g.Cout + 4 * q, GF);
             f32x4 rv = {0.f, 0.f, 0.f, 0.f};
             if (res) rv = sld4<kNt>(res, p * g.Cout + 4 * q, bf);
             f32x4 dzv;
@@ -1936,9 +1942,14 @@ __global__ __launch_bounds__(NT) void k_unit1x1_bwd(ConvGeom g, const float* __r
                 dy[e] = gm[e] * istd[e] * (dz - m1[e] - xh * m2[e]);
             }
             if (dres) {
-                f32x4* dr = reinterpret_cast<f32x4*>(dres + p * g.Cout + 4 * q);
-                if (dres_acc) *dr = *dr + dzv;
-                else sst4<kNtSt>(dres, p * g.Cout + 4 * q, 0, dzv);
+                if constexpr (GF == 0) {
+                    f32x4* dr = reinterpret_cast<f32x4*>(dres + p * g.Cout + 4 * q);
+                    if (dres_acc) *dr = *dr + dzv;
+                    else sst4<kNtSt>(dres, p * g.Cout + 4 * q, 0, dzv);
+                } else {
+                    if (dres_acc) sst4(dres, p * g.Cout + 4 * q, GF, sld4(dres, p * g.Cout + 4 * q, GF) + dzv);
+                    else sst4<kNtSt>(dres, p * g.Cout + 4 * q, GF, dzv);
+                }
             }
         }
         // data gradient: dx[pos][ci] = sum_co W[co][ci] dy[pos][co]
@@ -1947,12 +1958,19 @@ __global__ __launch_bounds__(NT) void k_unit1x1_bwd(ConvGeom g, const float* __r
 #pragma unroll
             for (int e = 0; e < 4; ++e) acc = mfma4(At[e], dy[e], acc);
             if (pv && ci_ok4) {
-                f32x4* o = reinterpret_cast<f32x4*>(dx + p * g.CinT + g.cin_off + 4 * q);
-                if (dx_acc) {
-                    acc = *o + acc;
-                    *o = acc;
+                if constexpr (GF == 0) {
+                    f32x4* o = reinterpret_cast<f32x4*>(dx + p * g.CinT + g.cin_off + 4 * q);
+                    if (dx_acc) {
+                        acc = *o + acc;
+                        *o = acc;
+                    }
+                    else sst4<kNtSt>(dx, p * g.CinT + g.cin_off + 4 * q, 0, acc);
+                } else {
+                    if (dx_acc) acc = sld4(dx, p * g.CinT + g.cin_off + 4 * q, GF) + acc;
+                    acc = round_bf4(acc, GF);          // (the riding reduction below sees the value the tensor now holds)
+                    if (dx_acc) sst4(dx, p * g.CinT + g.cin_off + 4 * q, GF, acc);
+                    else sst4<kNtSt>(dx, p * g.CinT + g.cin_off + 4 * q, GF, acc);
                 }
-                else sst4<kNtSt>(dx, p * g.CinT + g.cin_off + 4 * q, 0, acc);
                 if constexpr (NEXT) {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
@@ -2028,7 +2046,7 @@ __global__ __launch_bounds__(NT) void k_unit1x1_bwd(ConvGeom g, const float* __r
 // da, so its own first backward pass (sum dz, sum dz * xhat, sum of the slope terms) is accumulated right here from
 // one more read (its y) instead of a pass that re-reads dx and y.
 // XR (with NEXT): x IS that unit's activation and is recomputed from its y at the three tap frames (see NextRedArgs).
-template <int FX, int FY, bool NEXT, bool XR = false>   // storage formats of x (an activation) and of y / the next unit's y (conv outputs)
+template <int FX, int FY, bool NEXT, bool XR = false, int GF = 0>   // storage formats of x (an activation), of y / the next unit's y (conv outputs), of da / dx
 __global__ __launch_bounds__(NT) void k_dwunit31_bwd(DwGeom g, const float* __restrict__ x, const float* __restrict__ y,
                                                     const float* __restrict__ da, BnBwdArgs bn,
                                                     const float* __restrict__ w, float* __restrict__ dx,
@@ -2068,12 +2086,13 @@ __global__ __launch_bounds__(NT) void k_dwunit31_bwd(DwGeom g, const float* __re
         const long rb[3] = {b2 ? p - (long)d2 * g.F : p, b1 ? p - (long)d1 * g.F : p, p};
         typename Raw4<FY>::t yr[3], ynr{}, ybr[2] = {};
         typename Raw4<FX>::t xr[3] = {};
+        typename Raw4<GF>::t grr[3];
         f32x4 gr[3];
         static_assert(!XR || NEXT, "x is recomputed from the NEXT unit's y");
 #pragma unroll
         for (int j = 0; j < 3; ++j) {
             yr[j] = sld4_raw<FY>(y, rf[j] * 16 + 4 * q);
-            gr[j] = *reinterpret_cast<const f32x4*>(da + rf[j] * 16 + 4 * q);
+            grr[j] = sld4_raw<GF>(da, rf[j] * 16 + 4 * q);
             if constexpr (!XR) xr[j] = sld4_raw<FX>(x, rb[j] * 16 + 4 * q);
             else if (j < 2) ybr[j] = sld4_raw<FY>(nx.y, rb[j] * 16 + 4 * q);
         }
@@ -2082,6 +2101,7 @@ __global__ __launch_bounds__(NT) void k_dwunit31_bwd(DwGeom g, const float* __re
 #pragma unroll
         for (int j = 0; j < 3; ++j) {
             const f32x4 yv = dec4<FY>(yr[j]);
+            gr[j] = dec4<GF>(grr[j]);
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const float xh = (yv[e] - mean[e]) * istd[e];
@@ -2123,7 +2143,8 @@ __global__ __launch_bounds__(NT) void k_dwunit31_bwd(DwGeom g, const float* __re
         acc = acc + wk[0] * dyv[2];
         acc = acc + wk[1] * dyv[1];
         acc = acc + wk[2] * dyv[0];
-        sst4<kNtSt>(dx, p * 16 + 4 * q, 0, acc);
+        acc = round_bf4(acc, GF);
+        sst4<kNtSt>(dx, p * 16 + 4 * q, GF, acc);
         if constexpr (NEXT) {
             const f32x4 yn = dec4<FY>(ynr);
 #pragma unroll
@@ -2344,7 +2365,7 @@ __global__ __launch_bounds__(NT) void k_dense33_fwd_pre(ConvGeom g, const float*
 // as its da -- its first backward pass rides along as in k_dwunit31_bwd.
 constexpr int D33_TF = 12, D33_ROWS = D33_TF + 2;
 // XR (with NEXT): x IS that unit's activation and is rebuilt from its y while the tile is staged (see NextRedArgs).
-template <int FX, int FY, bool NEXT, bool XR = false>   // storage formats of x (an activation) and of y / the next unit's y (conv outputs)
+template <int FX, int FY, bool NEXT, bool XR = false, int GF = 0>   // storage formats of x (an activation), of y / the next unit's y (conv outputs), of da / dx
 __global__ __launch_bounds__(NT) void k_dwunit33_bwd(DwGeom g, const float* __restrict__ x, const float* __restrict__ y,
                                                     const float* __restrict__ da, BnBwdArgs bn,
                                                     const float* __restrict__ w, float* __restrict__ dx,
@@ -2390,13 +2411,14 @@ __global__ __launch_bounds__(NT) void k_dwunit33_bwd(DwGeom g, const float* __re
             const bool okd = td < T, okx = tx >= 0 && tx < T;
             const long pd = (rowb + (okd ? td : 0)) * F + f, px = (rowb + (okx ? tx : 0)) * F + f;
             const typename Raw4<FY>::t yr = sld4_raw<FY, true>(y, pd * 16 + 4 * q);
-            const f32x4 gr = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(da + pd * 16 + 4 * q));
+            const typename Raw4<GF>::t grr = sld4_raw<GF, true>(da, pd * 16 + 4 * q);
             typename Raw4<FX>::t xr{};
             typename Raw4<FY>::t xyr{};
             static_assert(!XR || NEXT, "x is rebuilt from the NEXT unit's y");
             if constexpr (XR) xyr = sld4_raw<FY, true>(nx.y, px * 16 + 4 * q);
             else xr = sld4_raw<FX, true>(x, px * 16 + 4 * q);
             const f32x4 yv = dec4<FY>(yr);
+            const f32x4 gr = dec4<GF>(grr);
             f32x4 dyv;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
@@ -2427,7 +2449,8 @@ __global__ __launch_bounds__(NT) void k_dwunit33_bwd(DwGeom g, const float* __re
 #pragma unroll
                 for (int kf = 0; kf < 3; ++kf)
                     acc = acc + wk[kt * 3 + kf] * *reinterpret_cast<const f32x4*>(dq + ((2 - kt) * 35 + 1 - kf) * 16);
-            sst4<kNtSt>(dx, p * 16 + 4 * q, 0, acc);
+            acc = round_bf4(acc, GF);
+            sst4<kNtSt>(dx, p * 16 + 4 * q, GF, acc);
             if constexpr (NEXT) next_accum(nk, dec4<FY>(ynr), acc, vr);
             // dW[kt][kf] += dy(t, f) x(t - 2 + kt, f - 1 + kf); db += dy(t, f)
             const f32x4 d = *reinterpret_cast<const f32x4*>(dq);
@@ -2471,7 +2494,7 @@ constexpr int D9_TF = 12, D9_ROWS = D9_TF + 2, D9_IMG = D9_ROWS * 35 * 16;
 constexpr int D9_LDS_FLOATS = 2 * D9_IMG + 9 * 256;
 static_assert(D9_LDS_FLOATS * 4 * 2 <= 160 * 1024, "two workgroups per CU");
 static_assert((NT / 64) * (9 * 256 + 64) <= 2 * D9_IMG, "the accumulator tiles reuse the images");
-template <int FX, int FY, bool NEXT, bool XR = false>      // XR: see k_dwunit33_bwd
+template <int FX, int FY, bool NEXT, bool XR = false, int GF = 0>      // XR, GF: see k_dwunit33_bwd
 __global__ __launch_bounds__(NT) void k_dense33_bwd(ConvGeom g, const float* __restrict__ x, const float* __restrict__ y,
                                                    const float* __restrict__ da, BnBwdArgs bn,
                                                    const float* __restrict__ w, float* __restrict__ dx,
@@ -2516,7 +2539,7 @@ __global__ __launch_bounds__(NT) void k_dense33_bwd(ConvGeom g, const float* __r
         {   // (every load of the tile first: one item at a time the fill was a chain of exposed round trips)
             constexpr int ITEMS = D9_ROWS * 33 * 4, NI = (ITEMS + NT - 1) / NT;      // (NT % 4 == 0: every item's quad is qs)
             typename Raw4<FY>::t yr[NI];
-            f32x4 gr[NI];
+            typename Raw4<GF>::t gr[NI];
             typename Raw4<FX>::t xr[NI];
             typename Raw4<FY>::t xyr[NI];
 #pragma unroll
@@ -2525,7 +2548,7 @@ __global__ __launch_bounds__(NT) void k_dense33_bwd(ConvGeom g, const float* __r
                 const int td = t0 + r, tx = t0 - 2 + r;
                 const long pd = ((long)b * T2 + (td < T2 ? td : 0)) * 33 + f, px = ((long)b * T + ((tx >= 0 && tx < T) ? tx : 0)) * 33 + f;
                 yr[j] = sld4_raw<FY, true>(y, pd * 16 + 4 * qs);
-                gr[j] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(da + pd * 16 + 4 * qs));
+                gr[j] = sld4_raw<GF, true>(da, pd * 16 + 4 * qs);
                 if constexpr (XR) xyr[j] = sld4_raw<FY, true>(nx.y, px * 16 + 4 * qs);
                 else xr[j] = sld4_raw<FX, true>(x, px * 16 + 4 * qs);
             }
@@ -2534,12 +2557,13 @@ __global__ __launch_bounds__(NT) void k_dense33_bwd(ConvGeom g, const float* __r
                 const int it = tid + j * NT, pos = (it < ITEMS ? it : 0) >> 2, r = pos / 33, f = pos - r * 33;
                 const int td = t0 + r, tx = t0 - 2 + r;
                 const f32x4 yv = dec4<FY>(yr[j]);
+                const f32x4 gj = dec4<GF>(gr[j]);
                 f32x4 dyv;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const float xh = (yv[e] - mean[e]) * istd[e];
                     const float z = gm[e] * xh + bt[e];
-                    const float dz = z > 0.f ? gr[j][e] : sl * gr[j][e];
+                    const float dz = z > 0.f ? gj[e] : sl * gj[e];
                     dyv[e] = gm[e] * istd[e] * (dz - m1[e] - xh * m2[e]);
                 }
                 f32x4 xval;
@@ -2572,7 +2596,8 @@ __global__ __launch_bounds__(NT) void k_dense33_bwd(ConvGeom g, const float* __r
                     for (int s2 = 0; s2 < 4; ++s2) acc = mfma4(A[s2], Bv[s2], acc);
                 }
                 if (pl < own_x) {
-                    sst4<kNtSt>(dx, gp * 16 + 4 * q, 0, acc);
+                    acc = round_bf4(acc, GF);
+                    sst4<kNtSt>(dx, gp * 16 + 4 * q, GF, acc);
                     if constexpr (NEXT) next_accum(nk, dec4<FY>(ynr), acc, vr);
                 }
             }
@@ -2653,7 +2678,7 @@ __global__ __launch_bounds__(NT) void k_dense33_bwd(ConvGeom g, const float* __r
 // dx may ACCUMULATE (en_convs.1: on top of the skip gradient of en_outs[0]) and carry the NEXT unit's riding reduction.
 constexpr int C15_TF = 8, C15_NW = 33 + 2, C15_WW = 65 + 4;        // narrow rows: pads -1, 33; wide rows: pads -2, -1, 65, 66
 constexpr int C15_NIMG = C15_TF * C15_NW * 16, C15_WIMG = C15_TF * C15_WW * 16;
-template <bool DYW, int FX, int FY, int NEXT>      // NEXT: 0 none, 1 + storage format of that unit's y
+template <bool DYW, int FX, int FY, int NEXT, int GF = 0>      // NEXT: 0 none, 1 + storage format of that unit's y; GF: see k_unit1x1_bwd
 __global__ __launch_bounds__(NT) void k_conv15_bwd(ConvGeom g, const float* __restrict__ x, const float* __restrict__ y,
                                                   const float* __restrict__ da, BnBwdArgs bn,
                                                   const float* __restrict__ w, float* __restrict__ dx, int dx_acc,
@@ -2706,14 +2731,14 @@ __global__ __launch_bounds__(NT) void k_conv15_bwd(ConvGeom g, const float* __re
         {
             constexpr int ND = (C15_TF * FD * 4 + NT - 1) / NT, NX = (C15_TF * FXB * 4 + NT - 1) / NT;
             typename Raw4<FY>::t yr[ND];
-            f32x4 gr[ND];
+            typename Raw4<GF>::t gr[ND];
             typename Raw4<FX>::t xr[NX];
 #pragma unroll
             for (int j = 0; j < ND; ++j) {
                 const int it = tid + j * NT, pos = (it < C15_TF * FD * 4 ? it : 0) >> 2, r = pos / FD, f = pos - r * FD;
                 const long p = ((long)b * T + t0 + (r < nrow ? r : 0)) * FD + f;
                 yr[j] = sld4_raw<FY, true>(y, p * 16 + 4 * qs);
-                gr[j] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(da + p * 16 + 4 * qs));
+                gr[j] = sld4_raw<GF, true>(da, p * 16 + 4 * qs);
             }
 #pragma unroll
             for (int j = 0; j < NX; ++j) {
@@ -2725,12 +2750,13 @@ __global__ __launch_bounds__(NT) void k_conv15_bwd(ConvGeom g, const float* __re
             for (int j = 0; j < ND; ++j) {
                 const int it = tid + j * NT, pos = (it < C15_TF * FD * 4 ? it : 0) >> 2, r = pos / FD, f = pos - r * FD;
                 const f32x4 yv = dec4<FY>(yr[j]);
+                const f32x4 gj = dec4<GF>(gr[j]);
                 f32x4 dyv;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const float xh = (yv[e] - mean[e]) * istd[e];
                     const float z = gm[e] * xh + bt[e];
-                    const float dz = z > 0.f ? gr[j][e] : sl * gr[j][e];
+                    const float dz = z > 0.f ? gj[e] : sl * gj[e];
                     dyv[e] = gm[e] * istd[e] * (dz - m1[e] - xh * m2[e]);
                 }
                 if (it < C15_TF * FD * 4) {
@@ -2778,7 +2804,7 @@ __global__ __launch_bounds__(NT) void k_conv15_bwd(ConvGeom g, const float* __re
             typename Raw4<(NEXT ? NEXT - 1 : 0)>::t ynr{};
             if constexpr (NEXT != 0) ynr = sld4_raw<(NEXT ? NEXT - 1 : 0), true>(nx.y, gp * 16 + 4 * q);
             f32x4 old = zero;
-            if (dx_acc) old = *reinterpret_cast<const f32x4*>(dx + gp * 16 + 4 * q);
+            if (dx_acc) old = sld4(dx, gp * 16 + 4 * q, GF);
             f32x4 acc = zero;
 #pragma unroll
             for (int kf = 0; kf < 5; ++kf) {
@@ -2795,8 +2821,8 @@ __global__ __launch_bounds__(NT) void k_conv15_bwd(ConvGeom g, const float* __re
                 for (int s2 = 0; s2 < 4; ++s2) acc = mfma4(A[s2], Bv[s2], acc);
             }
             if (pl < ownx) {
-                acc = acc + old;
-                sst4<kNtSt>(dx, gp * 16 + 4 * q, 0, acc);
+                acc = round_bf4(acc + old, GF);
+                sst4<kNtSt>(dx, gp * 16 + 4 * q, GF, acc);
                 if constexpr (NEXT != 0) next_accum(nk, dec4<(NEXT ? NEXT - 1 : 0)>(ynr), acc, vr);
             }
         }
@@ -3249,7 +3275,7 @@ __global__ __launch_bounds__(NT) void k_gate_shuffle_bwd(const float* __restrict
                                                         const float* __restrict__ dy, const float* __restrict__ v,
                                                         const float* __restrict__ dw_w, int B, int T, int Tt,
                                                         float* __restrict__ dv, float* __restrict__ dx, int bf,
-                                                        int dx_acc, BnLoad bn) {
+                                                        int dx_acc, BnLoad bn, int gbf) {
     // thread (position of the T' frames, half h): channels 4h..4h+3; 16-byte accesses.  dx_acc: the pass-through half
     // is ADDED to what dx holds (the skip gradient of the same tensor, see gtcrn_train_backward)
     const long total = (long)B * Tt * 33 * 2;
@@ -3263,12 +3289,12 @@ __global__ __launch_bounds__(NT) void k_gate_shuffle_bwd(const float* __restrict
         f32x4 r = {0.f, 0.f, 0.f, 0.f};
         if (t < T) {
             const long pos = ((long)b * T + t) * 33 + f;
-            const f32x4 d0 = sld4<kNt>(dout, pos * 16 + 8 * h, 0), d1 = sld4<kNt>(dout, pos * 16 + 8 * h + 4, 0);
+            const f32x4 d0 = sld4<kNt>(dout, pos * 16 + 8 * h, gbf), d1 = sld4<kNt>(dout, pos * 16 + 8 * h + 4, gbf);   // gbf: format of dout / dx / dv
             const f32x4 gg = *reinterpret_cast<const f32x4*>(g + rowv * 8 + 4 * h);
             r = f32x4{d0[0], d0[2], d1[0], d1[2]} * gg;
             f32x4 px = f32x4{d0[1], d0[3], d1[1], d1[3]};
-            if (dx_acc) px = px + *reinterpret_cast<const f32x4*>(dx + pos * 16 + 8 + 4 * h);
-            sst4(dx, pos * 16 + 8 + 4 * h, 0, px);
+            if (dx_acc) px = px + sld4(dx, pos * 16 + 8 + 4 * h, gbf);
+            sst4(dx, pos * 16 + 8 + 4 * h, gbf, px);
         }
         f32x4 de = {0.f, 0.f, 0.f, 0.f};
         for (int k = 0; k < 3; ++k) {
@@ -3283,13 +3309,13 @@ __global__ __launch_bounds__(NT) void k_gate_shuffle_bwd(const float* __restrict
         f32x4 o;
 #pragma unroll
         for (int e = 0; e < 4; ++e) o[e] = fmaf(de[e] * (2.0f / 33.0f), vv[e], r[e]);
-        sst4<kNtSt>(dv, posv * 8 + 4 * h, 0, o);
+        sst4<kNtSt>(dv, posv * 8 + 4 * h, gbf, o);
     }
 }
 // step 2: dg = sum_F dout[2c] * v  ->  dzg = dg * g * (1 - g)
 __global__ __launch_bounds__(NT) void k_tra_dgate(const float* __restrict__ dout, const float* __restrict__ v,
                                                  const float* __restrict__ g, int B, int T, int Tt,
-                                                 float* __restrict__ dzg, int bf, BnLoad bn) {
+                                                 float* __restrict__ dzg, int bf, BnLoad bn, int gbf) {
     // one wave per row (b, t): lane (position, quad q) takes dout slots 4q..4q+3 = channels 2q, 2q+1 (16-byte loads;
     // one thread per (row, channel) walked the 33 bins with 4-byte loads at a 64-byte stride), then the lanes of a
     // quad are summed by xor shuffles
@@ -3311,7 +3337,7 @@ __global__ __launch_bounds__(NT) void k_tra_dgate(const float* __restrict__ dout
                 const int it = lane + 64 * k;
                 if (it < 132) {
                     const int pos = it >> 2;
-                    const f32x4 d = *reinterpret_cast<const f32x4*>(dout + dbase + pos * 16 + 4 * q);
+                    const f32x4 d = sld4(dout, dbase + pos * 16 + 4 * q, gbf);
                     if (bn.stats) {
                         s0 = fmaf(d[0], bnl_apply1(sld1(v, vbase + pos * 8 + 2 * q, bn.ybf), bm[0], bi[0], bg[0], bb[0], bf), s0);
                         s1 = fmaf(d[2], bnl_apply1(sld1(v, vbase + pos * 8 + 2 * q + 1, bn.ybf), bm[1], bi[1], bg[1], bb[1], bf), s1);
@@ -3643,19 +3669,22 @@ void set_fin_context(bool on, double* gpart, unsigned* ctr) { g_fin.on = on; g_f
 // grid of a streaming reduction: a stride that is a multiple of C (NT is), at most MAX_PARTIALS workgroups
 static void launch_bn_bwd_reduce4(int grid, hipStream_t s, const float* da, const float* y, long total, int C,
                                   const float* stats, const float* gamma, const float* beta, const float* res, int act,
-                                  const float* slope, double* partial, int bf, int ybf, const FinArgs& fa) {
-#define GT_RED(F, A) hipLaunchKernelGGL((k_bn_bwd_reduce<4, F, A>), dim3(grid), dim3(NT), 0, s, da, y, total, C, stats, \
-                                        gamma, beta, res, act, slope, partial, bf, ybf, fa)
+                                  const float* slope, double* partial, int bf, int ybf, const FinArgs& fa, int gbf = 0) {
+#define GT_RED(F, A, GF_) hipLaunchKernelGGL((k_bn_bwd_reduce<4, F, A, GF_>), dim3(grid), dim3(NT), 0, s, da, y, total, C, stats, \
+                                             gamma, beta, res, act, slope, partial, bf, ybf, fa)
     const int f = bf * 4 + ybf;
-    if (f == 0 && act == ACT_PRELU) GT_RED(0, ACT_PRELU);
-    else if (f == 0 && act == ACT_NONE) GT_RED(0, ACT_NONE);
-    else if (f == 5 && act == ACT_PRELU) GT_RED(5, ACT_PRELU);      // bf16 activations, bf16 conv outputs
-    else if (f == 5 && act == ACT_NONE) GT_RED(5, ACT_NONE);
-    else if (f == 0) GT_RED(0, -1);
-    else if (f == 5) GT_RED(5, -1);
-    else if (f == 4) GT_RED(4, -1);          // (diagnostic storage codes 2, 3)
-    else if (f == 6) GT_RED(6, -1);
-    else GT_RED(-1, -1);
+    if (gbf) {                                                       // bf16 gradient hand-offs (storage mode 5)
+        if (f == 5 && act == ACT_PRELU) GT_RED(5, ACT_PRELU, 1);
+        else if (f == 5 && act == ACT_NONE) GT_RED(5, ACT_NONE, 1);
+        else GT_RED(-1, -1, 1);
+    }
+    else if (f == 0 && act == ACT_PRELU) GT_RED(0, ACT_PRELU, 0);
+    else if (f == 0 && act == ACT_NONE) GT_RED(0, ACT_NONE, 0);
+    else if (f == 5 && act == ACT_PRELU) GT_RED(5, ACT_PRELU, 0);      // bf16 activations, bf16 conv outputs
+    else if (f == 5 && act == ACT_NONE) GT_RED(5, ACT_NONE, 0);
+    else if (f == 0) GT_RED(0, -1, 0);
+    else if (f == 5) GT_RED(5, -1, 0);
+    else GT_RED(-1, -1, 0);
 #undef GT_RED
 }
 
@@ -3672,7 +3701,7 @@ static int red_grid(long units) {
 // workgroup when the context is on.  Returns the slot that holds the unit's means (red_slot).
 static int bwd_first_pass(int have_parts, hipStream_t s, const float* da, const float* y, long n, int C, const float* stats,
                           const float* gamma, const float* beta, const float* res, int act, const float* slope,
-                          double* dscratch, int bf, int ybf, float* dgamma, float* dbeta, float* dslope) {
+                          double* dscratch, int bf, int ybf, float* dgamma, float* dbeta, float* dslope, int gbf = 0) {
     if (have_parts < 0) return parts_slot(have_parts);
     float* red = red_slot(dscratch, 0);
     if (have_parts > 0) {
@@ -3681,7 +3710,7 @@ static int bwd_first_pass(int have_parts, hipStream_t s, const float* da, const 
     }
     const int rgrid = red_grid(n * C / 4);
     const FinArgs fa = fin_bwd(n, C, red, dgamma, dbeta, dslope);
-    launch_bn_bwd_reduce4(rgrid, s, da, y, n * C, C, stats, gamma, beta, res, act, slope, dscratch, bf, ybf, fa);
+    launch_bn_bwd_reduce4(rgrid, s, da, y, n * C, C, stats, gamma, beta, res, act, slope, dscratch, bf, ybf, fa, gbf);
     if (!fa.kind)
         hipLaunchKernelGGL(k_bn_bwd_finish, dim3(1), dim3(1024), 0, s, dscratch, rgrid, n, C, red, dgamma, dbeta, dslope);
     return 0;
@@ -3734,7 +3763,7 @@ int conv_fwd(const ConvGeom& g, const float* in, const float* w, const float* bi
         // that unit's BatchNorm reduction rides in the epilogue -- per-workgroup sums in stat_partial, their count in
         // *stat_parts (hand it to that unit's backward as have_parts)
         if (!stat_partial || !stat_parts || pre || shift || next->res || !next->slope || !mfma_ok(g) || g.in_bf != 0 ||
-            g.out_bf != 0 || g.Cout != 16 || g.CoutT != 16 || g.cout_off != 0 ||
+            g.Cout != 16 || g.CoutT != 16 || g.cout_off != 0 ||
             !((g.nkt == 3 && g.nkf == 3) || (g.nkt == 1 && g.nkf == 5)))
             return (int)hipErrorInvalidValue;
         const long ntiles = ((long)g.B * g.Tout * g.Fout + 15) / 16;
@@ -3892,7 +3921,7 @@ int dw_fwd(const DwGeom& g, const float* in, const float* w, const float* bias, 
                             : fin_stats(sf);            // see conv_fwd
     if (next) {      // see conv_fwd
         if (!stat_partial || !stat_parts || pre || shift || next->res || !next->slope || g.C != 16 || g.nkt != 3 ||
-            g.nkf != 3 || g.in_bf != 0 || g.out_bf != 0 || g.Tin != g.Tout)
+            g.nkf != 3 || g.in_bf != 0 || g.Tin != g.Tout)
             return (int)hipErrorInvalidValue;
         const int g16 = grid_for((long)g.B * g.Tout * g.F * 4, MAX_PARTIALS);
         const StrideIter it = stride_iter((long)g16 * NT / 4, g.F, g.Tout);
@@ -4028,14 +4057,15 @@ int bn_act(const float* y, long n, int C, const float* stats, const float* gamma
 int bn_act_bwd(const float* da, const float* y, long n, int C, const float* stats, const float* gamma,
                const float* beta, const float* res, int act, const float* slope, float* dy, float* dres,
                int dres_acc, float* dgamma, float* dbeta, float* dslope, double* scratch, hipStream_t s, int bf,
-               int ybf, int have_parts) {
+               int ybf, int have_parts, int gbf) {
     const long total = n * C;
+    if (gbf && (C % 4 != 0 || !bf)) return (int)hipErrorInvalidValue;      // (bf16 gradients: the 16-bit modes' wide units)
     if (C % 4 == 0) {
         const int slot = bwd_first_pass(have_parts, s, da, y, n, C, stats, gamma, beta, res, act, slope, scratch, bf, ybf,
-                                        dgamma, dbeta, dslope);
+                                        dgamma, dbeta, dslope, gbf);
         // the apply pass keeps per-thread channel constants: its stride must be a multiple of C as well
         hipLaunchKernelGGL((k_bn_bwd_apply<4>), dim3(grid_for(total / 4, 8192)), dim3(NT), 0, s, da, y, total, C, stats,
-                           gamma, beta, res, act, slope, red_slot(scratch, slot), dy, dres, dres_acc, bf, ybf);
+                           gamma, beta, res, act, slope, red_slot(scratch, slot), dy, dres, dres_acc, bf, ybf, gbf);
     } else {
         float* red = red_slot(scratch, 0);
         const int grid = red_grid(total);
@@ -4045,7 +4075,7 @@ int bn_act_bwd(const float* da, const float* y, long n, int C, const float* stat
         if (!fa.kind)
             hipLaunchKernelGGL(k_bn_bwd_finish, dim3(1), dim3(1024), 0, s, scratch, grid, n, C, red, dgamma, dbeta, dslope);
         hipLaunchKernelGGL((k_bn_bwd_apply<1>), dim3(grid_for(total, 8192)), dim3(NT), 0, s, da, y, total, C, stats,
-                           gamma, beta, res, act, slope, red, dy, dres, dres_acc, bf, ybf);
+                           gamma, beta, res, act, slope, red, dy, dres, dres_acc, bf, ybf, 0);
     }
     return check();
 }
@@ -4054,14 +4084,14 @@ constexpr int NEXT_GRID = 768;    // workgroups of k_unit1x1_bwd<.., NEXT>: 126-
 int dwunit_bwd(const DwGeom& g, const float* x, const float* y, const float* da, const float* stats,
                const float* gamma, const float* beta, const float* slope, const float* w, float* dx, float* dw,
                float* dbias, float* dgamma, float* dbeta, float* dslope, double* dscratch, float* fscratch,
-               hipStream_t s, int bf, int ybf, const DwUnitNext* next, int* next_parts, int have_parts) {
+               hipStream_t s, int bf, int ybf, const DwUnitNext* next, int* next_parts, int have_parts, int gbf) {
     if (next_parts) *next_parts = 0;
     if (g.C != 16 || g.nkt != 3 || g.nkf != 1 || g.t_off[2] != 0 || g.f_off[0] != 0 || g.t_off[0] != 2 * g.t_off[1] ||
-        g.Tin != g.Tout || !slope || !dx || bf > 1 || ybf > 1 || bf != ybf)
+        g.Tin != g.Tout || !slope || !dx || bf > 1 || ybf > 1 || bf != ybf || (gbf && !bf))
         return (int)hipErrorInvalidValue;
     const long n = (long)g.B * g.Tout * g.F, total = n * 16;
     const int slot = bwd_first_pass(have_parts, s, da, y, n, 16, stats, gamma, beta, nullptr, ACT_PRELU, slope, dscratch, bf, ybf,
-                                    dgamma, dbeta, dslope);
+                                    dgamma, dbeta, dslope, gbf);
     float* red = red_slot(dscratch, slot);
     // 164 VGPRs: three workgroups per CU -- a grid of 3 x 256 keeps every workgroup resident (with 1024 the last 256
     // would run alone at a third of the occupancy)
@@ -4075,14 +4105,15 @@ int dwunit_bwd(const DwGeom& g, const float* x, const float* y, const float* da,
     if (!x && !xr) return (int)hipErrorInvalidValue;
     if (nxt) nx = NextRedArgs{next->y, next->stats, next->gamma, next->beta, next->slope, nullptr, next->recompute_x == 2};
     const FinArgs nfa = next_fin(nxt, next, dscratch, slot);
-#define GT_DU(F)                                                                                                        \
+#define GT_DU(F, GF_)                                                                                                   \
     do {                                                                                                               \
-        if (xr) hipLaunchKernelGGL((k_dwunit31_bwd<F, F, true, true>), dim3(grid), dim3(NT), 0, s, g, x, y, da, bn, w, dx, wpart, nx, dscratch, it, nfa); \
-        else if (nxt) hipLaunchKernelGGL((k_dwunit31_bwd<F, F, true>), dim3(grid), dim3(NT), 0, s, g, x, y, da, bn, w, dx, wpart, nx, dscratch, it, nfa); \
-        else hipLaunchKernelGGL((k_dwunit31_bwd<F, F, false>), dim3(grid), dim3(NT), 0, s, g, x, y, da, bn, w, dx, wpart, nx, dscratch, it, nfa); \
+        if (xr) hipLaunchKernelGGL((k_dwunit31_bwd<F, F, true, true, GF_>), dim3(grid), dim3(NT), 0, s, g, x, y, da, bn, w, dx, wpart, nx, dscratch, it, nfa); \
+        else if (nxt) hipLaunchKernelGGL((k_dwunit31_bwd<F, F, true, false, GF_>), dim3(grid), dim3(NT), 0, s, g, x, y, da, bn, w, dx, wpart, nx, dscratch, it, nfa); \
+        else hipLaunchKernelGGL((k_dwunit31_bwd<F, F, false, false, GF_>), dim3(grid), dim3(NT), 0, s, g, x, y, da, bn, w, dx, wpart, nx, dscratch, it, nfa); \
     } while (0)
-    if (bf == 0) GT_DU(0);
-    else GT_DU(1);
+    if (bf == 0) GT_DU(0, 0);
+    else if (gbf) GT_DU(1, 1);
+    else GT_DU(1, 0);
 #undef GT_DU
     hipLaunchKernelGGL(k_dw_wgrad_finish2, dim3(1), dim3(1024), 0, s, g, wpart, grid, dw, dbias);
     if (nxt && next_parts) *next_parts = next_parts_value(nfa, slot, grid);
@@ -4092,15 +4123,16 @@ int dwunit_bwd(const DwGeom& g, const float* x, const float* y, const float* da,
 int dwunit33_bwd(const DwGeom& g, const float* x, const float* y, const float* da, const float* stats,
                  const float* gamma, const float* beta, const float* slope, const float* w, float* dx, float* dw,
                  float* dbias, float* dgamma, float* dbeta, float* dslope, double* dscratch, float* fscratch,
-                 hipStream_t s, int bf, int ybf, const DwUnitNext* next, int* next_parts, int have_parts) {
+                 hipStream_t s, int bf, int ybf, const DwUnitNext* next, int* next_parts, int have_parts, int gbf) {
     if (next_parts) *next_parts = 0;
+    if (gbf && !bf) return (int)hipErrorInvalidValue;
     if (g.C != 16 || g.F != 33 || g.nkt != 3 || g.nkf != 3 || g.t_off[0] != -2 || g.t_off[1] != -1 || g.t_off[2] != 0 ||
         g.f_off[0] != -1 || g.f_off[1] != 0 || g.f_off[2] != 1 || g.Tin != g.Tout || !slope || !dx || bf > 1 || ybf > 1 ||
         bf != ybf)
         return (int)hipErrorInvalidValue;
     const long n = (long)g.B * g.Tout * g.F;
     const int slot = bwd_first_pass(have_parts, s, da, y, n, 16, stats, gamma, beta, nullptr, ACT_PRELU, slope, dscratch, bf, ybf,
-                                    dgamma, dbeta, dslope);
+                                    dgamma, dbeta, dslope, gbf);
     float* red = red_slot(dscratch, slot);
     const int tiles_t = (g.Tout + D33_TF - 1) / D33_TF;
     const long ntiles = (long)g.B * tiles_t;
@@ -4114,14 +4146,15 @@ int dwunit33_bwd(const DwGeom& g, const float* x, const float* y, const float* d
     if (!x && !xr) return (int)hipErrorInvalidValue;
     if (nxt) nx = NextRedArgs{next->y, next->stats, next->gamma, next->beta, next->slope, nullptr, next->recompute_x == 2, ybf};
     const FinArgs nfa = next_fin(nxt, next, dscratch, slot);
-#define GT_D33(F)                                                                                                       \
+#define GT_D33(F, GF_)                                                                                                  \
     do {                                                                                                               \
-        if (xr) hipLaunchKernelGGL((k_dwunit33_bwd<F, F, true, true>), dim3(grid), dim3(NT), 0, s, g, x, y, da, bn, w, dx, wpart, nx, dscratch, tiles_t, nfa); \
-        else if (nxt) hipLaunchKernelGGL((k_dwunit33_bwd<F, F, true>), dim3(grid), dim3(NT), 0, s, g, x, y, da, bn, w, dx, wpart, nx, dscratch, tiles_t, nfa); \
-        else hipLaunchKernelGGL((k_dwunit33_bwd<F, F, false>), dim3(grid), dim3(NT), 0, s, g, x, y, da, bn, w, dx, wpart, nx, dscratch, tiles_t, nfa); \
+        if (xr) hipLaunchKernelGGL((k_dwunit33_bwd<F, F, true, true, GF_>), dim3(grid), dim3(NT), 0, s, g, x, y, da, bn, w, dx, wpart, nx, dscratch, tiles_t, nfa); \
+        else if (nxt) hipLaunchKernelGGL((k_dwunit33_bwd<F, F, true, false, GF_>), dim3(grid), dim3(NT), 0, s, g, x, y, da, bn, w, dx, wpart, nx, dscratch, tiles_t, nfa); \
+        else hipLaunchKernelGGL((k_dwunit33_bwd<F, F, false, false, GF_>), dim3(grid), dim3(NT), 0, s, g, x, y, da, bn, w, dx, wpart, nx, dscratch, tiles_t, nfa); \
     } while (0)
-    if (bf == 0) GT_D33(0);
-    else GT_D33(1);
+    if (bf == 0) GT_D33(0, 0);
+    else if (gbf) GT_D33(1, 1);
+    else GT_D33(1, 0);
 #undef GT_D33
     hipLaunchKernelGGL(k_dw_wgrad_finish2, dim3((160 + 63) / 64), dim3(1024), 0, s, g, wpart, grid, dw, dbias);
     if (nxt && next_parts) *next_parts = next_parts_value(nfa, slot, grid);
@@ -4131,8 +4164,9 @@ int dwunit33_bwd(const DwGeom& g, const float* x, const float* y, const float* d
 int dense33_bwd(const ConvGeom& g, const float* x, const float* y, const float* da, const float* stats,
                 const float* gamma, const float* beta, const float* slope, const float* w, float* dx, float* dw,
                 float* dbias, float* dgamma, float* dbeta, float* dslope, double* dscratch, float* fscratch,
-                hipStream_t s, int bf, int ybf, const DwUnitNext* next, int* next_parts, int have_parts) {
+                hipStream_t s, int bf, int ybf, const DwUnitNext* next, int* next_parts, int have_parts, int gbf) {
     if (next_parts) *next_parts = 0;
+    if (gbf && !bf) return (int)hipErrorInvalidValue;
     // the decoder's ConvTranspose2d(16,16,(3,3),padding (0,1)) in gather form: taps t, t-1, t-2, transposed in frequency
     if (g.nkt != 3 || g.nkf != 3 || g.t_off[0] != 0 || g.t_off[1] != -1 || g.t_off[2] != -2 || g.f_mode != 1 || g.sf != 1 ||
         g.pf != 1 || g.Fin != 33 || g.Fout != 33 || g.Cin != 16 || g.CinT != 16 || g.cin_off != 0 || g.Cout != 16 ||
@@ -4140,7 +4174,7 @@ int dense33_bwd(const ConvGeom& g, const float* x, const float* y, const float* 
         return (int)hipErrorInvalidValue;
     const long n = (long)g.B * g.Tout * g.Fout;
     const int slot = bwd_first_pass(have_parts, s, da, y, n, 16, stats, gamma, beta, nullptr, ACT_PRELU, slope, dscratch, bf, ybf,
-                                    dgamma, dbeta, dslope);
+                                    dgamma, dbeta, dslope, gbf);
     float* red = red_slot(dscratch, slot);
     const int tiles_t = (g.Tout + D9_TF - 1) / D9_TF;
     const long ntiles = (long)g.B * tiles_t;
@@ -4154,16 +4188,17 @@ int dense33_bwd(const ConvGeom& g, const float* x, const float* y, const float* 
     const FinArgs nfa = next_fin(nxt, next, dscratch, slot);
     // (the attribute belongs to the current device's copy of the kernel: set on every launch -- a host-side table lookup --
     // rather than remembered per process, which would miss a second device)
-#define GT_D9(F, NXV, XRV, SLOT)                                                                                        \
+#define GT_D9(F, NXV, XRV, GF_)                                                                                         \
     do {                                                                                                               \
-        hipError_t e_ = hipFuncSetAttribute(reinterpret_cast<const void*>(k_dense33_bwd<F, F, NXV, XRV>),               \
+        hipError_t e_ = hipFuncSetAttribute(reinterpret_cast<const void*>(k_dense33_bwd<F, F, NXV, XRV, GF_>),          \
                                             hipFuncAttributeMaxDynamicSharedMemorySize, D9_LDS_FLOATS * 4);             \
         if (e_ != hipSuccess) return (int)e_;                                                                          \
-        hipLaunchKernelGGL((k_dense33_bwd<F, F, NXV, XRV>), dim3(grid), dim3(NT), D9_LDS_FLOATS * 4, s, g, x, y, da, bn, w, dx, \
+        hipLaunchKernelGGL((k_dense33_bwd<F, F, NXV, XRV, GF_>), dim3(grid), dim3(NT), D9_LDS_FLOATS * 4, s, g, x, y, da, bn, w, dx, \
                            fscratch, nx, dscratch, tiles_t, nfa);                                                      \
     } while (0)
-    if (bf == 0) { if (xr) GT_D9(0, true, true, 4); else if (nxt) GT_D9(0, true, false, 0); else GT_D9(0, false, false, 1); }
-    else { if (xr) GT_D9(1, true, true, 5); else if (nxt) GT_D9(1, true, false, 2); else GT_D9(1, false, false, 3); }
+    if (bf == 0) { if (xr) GT_D9(0, true, true, 0); else if (nxt) GT_D9(0, true, false, 0); else GT_D9(0, false, false, 0); }
+    else if (gbf) { if (xr) GT_D9(1, true, true, 1); else if (nxt) GT_D9(1, true, false, 1); else GT_D9(1, false, false, 1); }
+    else { if (xr) GT_D9(1, true, true, 0); else if (nxt) GT_D9(1, true, false, 0); else GT_D9(1, false, false, 0); }
 #undef GT_D9
     const int K = 9 * 256 + 16;
     hipLaunchKernelGGL(k_wgrad_mfma_finish, dim3((K + 63) / 64), dim3(1024), 0, s, g, fscratch, grid, dw, dbias);
@@ -4174,8 +4209,9 @@ int dense33_bwd(const ConvGeom& g, const float* x, const float* y, const float* 
 int conv15_bwd(const ConvGeom& g, const float* x, const float* y, const float* da, const float* stats,
                const float* gamma, const float* beta, const float* slope, const float* w, float* dx, int dx_acc,
                float* dw, float* dbias, float* dgamma, float* dbeta, float* dslope, double* dscratch, float* fscratch,
-               hipStream_t s, int bf, int ybf, const DwUnitNext* next, int* next_parts, int have_parts) {
+               hipStream_t s, int bf, int ybf, const DwUnitNext* next, int* next_parts, int have_parts, int gbf) {
     if (next_parts) *next_parts = 0;
+    if (gbf && !bf) return (int)hipErrorInvalidValue;
     const bool dyw = g.f_mode == 1;
     if (g.nkt != 1 || g.nkf != 5 || g.t_off[0] != 0 || g.sf != 2 || g.pf != 2 || g.Cin != 16 || g.CinT != 16 || g.cin_off != 0 ||
         g.Cout != 16 || g.CoutT != 16 || g.cout_off != 0 || g.Tin != g.Tout || g.Fin != (dyw ? 33 : 65) || g.Fout != (dyw ? 65 : 33) ||
@@ -4183,7 +4219,7 @@ int conv15_bwd(const ConvGeom& g, const float* x, const float* y, const float* d
         return (int)hipErrorInvalidValue;
     const long n = (long)g.B * g.Tout * g.Fout;
     const int slot = bwd_first_pass(have_parts, s, da, y, n, 16, stats, gamma, beta, nullptr, ACT_PRELU, slope, dscratch, bf, ybf,
-                                    dgamma, dbeta, dslope);
+                                    dgamma, dbeta, dslope, gbf);
     float* red = red_slot(dscratch, slot);
     const int tiles_t = (g.Tout + C15_TF - 1) / C15_TF;
     const long ntiles = (long)g.B * tiles_t;
@@ -4193,12 +4229,12 @@ int conv15_bwd(const ConvGeom& g, const float* x, const float* y, const float* d
     const bool nxt = next && next->slope && !next->res;
     if (nxt) nx = NextRedArgs{next->y, next->stats, next->gamma, next->beta, next->slope, nullptr, 0, ybf};
     const FinArgs nfa = next_fin(nxt, next, dscratch, slot);
-#define GT_C15(DW_, F, NXV)                                                                                             \
-    hipLaunchKernelGGL((k_conv15_bwd<DW_, F, F, NXV>), dim3(grid), dim3(NT), 0, s, g, x, y, da, bn, w, dx, dx_acc, fscratch, nx, \
+#define GT_C15(DW_, F, NXV, GF_)                                                                                        \
+    hipLaunchKernelGGL((k_conv15_bwd<DW_, F, F, NXV, GF_>), dim3(grid), dim3(NT), 0, s, g, x, y, da, bn, w, dx, dx_acc, fscratch, nx, \
                        dscratch, tiles_t, nfa)
-    if (dyw) { if (bf == 0) GT_C15(true, 0, 0); else GT_C15(true, 1, 0); }
-    else if (nxt) { if (bf == 0) GT_C15(false, 0, 1); else GT_C15(false, 1, 2); }
-    else { if (bf == 0) GT_C15(false, 0, 0); else GT_C15(false, 1, 0); }
+    if (dyw) { if (bf == 0) GT_C15(true, 0, 0, 0); else if (gbf) GT_C15(true, 1, 0, 1); else GT_C15(true, 1, 0, 0); }
+    else if (nxt) { if (bf == 0) GT_C15(false, 0, 1, 0); else if (gbf) GT_C15(false, 1, 2, 1); else GT_C15(false, 1, 2, 0); }
+    else { if (bf == 0) GT_C15(false, 0, 0, 0); else if (gbf) GT_C15(false, 1, 0, 1); else GT_C15(false, 1, 0, 0); }
 #undef GT_C15
     const int K = 5 * 256 + 16;
     hipLaunchKernelGGL(k_wgrad_mfma_finish, dim3((K + 63) / 64), dim3(1024), 0, s, g, fscratch, grid, dw, dbias);
@@ -4210,14 +4246,14 @@ int unit1x1_bwd(const ConvGeom& g, const float* x, const float* y, const float* 
                 const float* stats, const float* gamma, const float* beta, int act, const float* slope,
                 const float* w, float* dx, int dx_acc, float* dres, int dres_acc, float* dw, float* dbias,
                 float* dgamma, float* dbeta, float* dslope, double* dscratch, float* fscratch, hipStream_t s, int bf,
-                int ybf, int have_parts, const DwUnitNext* next, int* next_parts) {
+                int ybf, int have_parts, const DwUnitNext* next, int* next_parts, int gbf) {
     if (next_parts) *next_parts = 0;
     const long n = (long)g.B * g.Tout * g.Fout;
     if (g.nkt != 1 || g.nkf != 1 || g.sf != 1 || g.pf != 0 || g.Cout != g.CoutT || g.cout_off != 0 || (g.Cout % 4) ||
-        (g.Cin % 4) || (g.CinT % 4) || (g.cin_off % 4))
+        (g.Cin % 4) || (g.CinT % 4) || (g.cin_off % 4) || (gbf && !(bf == 1 && ybf == 1)))
         return (int)hipErrorInvalidValue;
     const int slot = bwd_first_pass(have_parts, s, da, y, n, g.Cout, stats, gamma, beta, res, act, slope, dscratch, bf, ybf,
-                                    dgamma, dbeta, dslope);
+                                    dgamma, dbeta, dslope, gbf);
     float* red = red_slot(dscratch, slot);
     const long ntiles = (n + 15) / 16;
     // the unit in front takes this dx as its gradient input: its reduction rides along (its partial sums replace this
@@ -4235,19 +4271,17 @@ int unit1x1_bwd(const ConvGeom& g, const float* x, const float* y, const float* 
     if (!x && !xr) return (int)hipErrorInvalidValue;
     if (nxt) nx = NextRedArgs{next->y, next->stats, next->gamma, next->beta, next->slope, next->res, next->recompute_x == 2};
     const FinArgs nfa = next_fin(nxt, next, dscratch, slot);
-#define GT_U1(F, Y)                                                                                                     \
+#define GT_U1(F, Y, GF_)                                                                                                \
     do {                                                                                                               \
-        if (xr) hipLaunchKernelGGL((k_unit1x1_bwd<F, Y, true, true>), dim3(grid), dim3(NT), 0, s, g, x, y, da, res, bn, w, dx, dx_acc, \
+        if (xr) hipLaunchKernelGGL((k_unit1x1_bwd<F, Y, true, true, GF_>), dim3(grid), dim3(NT), 0, s, g, x, y, da, res, bn, w, dx, dx_acc, \
                                    dres, dres_acc, fscratch, tpw, nx, dscratch, nfa);                                   \
-        else if (nxt) hipLaunchKernelGGL((k_unit1x1_bwd<F, Y, true>), dim3(grid), dim3(NT), 0, s, g, x, y, da, res, bn, w, dx, dx_acc, \
+        else if (nxt) hipLaunchKernelGGL((k_unit1x1_bwd<F, Y, true, false, GF_>), dim3(grid), dim3(NT), 0, s, g, x, y, da, res, bn, w, dx, dx_acc, \
                                     dres, dres_acc, fscratch, tpw, nx, dscratch, nfa);                                  \
-        else hipLaunchKernelGGL((k_unit1x1_bwd<F, Y, false>), dim3(grid), dim3(NT), 0, s, g, x, y, da, res, bn, w, dx, dx_acc, \
+        else hipLaunchKernelGGL((k_unit1x1_bwd<F, Y, false, false, GF_>), dim3(grid), dim3(NT), 0, s, g, x, y, da, res, bn, w, dx, dx_acc, \
                                 dres, dres_acc, fscratch, tpw, nx, dscratch, nfa);                                      \
     } while (0)
-    if (bf == 0 && ybf == 0) GT_U1(0, 0);
-    else if (bf == 1 && ybf == 1) GT_U1(1, 1);
-    else if (bf == 1 && ybf == 0) GT_U1(1, 0);
-    else if (bf == 1 && ybf == 2) GT_U1(1, 2);
+    if (bf == 0 && ybf == 0) GT_U1(0, 0, 0);
+    else if (bf == 1 && ybf == 1) { if (gbf) GT_U1(1, 1, 1); else GT_U1(1, 1, 0); }
     else return (int)hipErrorInvalidValue;
 #undef GT_U1
     if (nxt && next_parts) *next_parts = next_parts_value(nfa, slot, grid);
@@ -4321,14 +4355,14 @@ int gate_shuffle_fwd(const float* v, const float* g, const float* x, int B, int 
 int tra_gate_shuffle_bwd(const float* dout, const float* v, const float* g, const float* e, const float* y, int B,
                          int T, int Tt, const float* dw_w, const float* pw_w, float* dv, float* dx, float* d_dw_w,
                          float* d_dw_b, float* d_pw_w, float* d_pw_b, float* tmp, float* scratch, hipStream_t s,
-                         int bf, int dx_acc, const TraBn* tb) {
+                         int bf, int dx_acc, const TraBn* tb, int gbf) {
     const long rows = (long)B * Tt;
     float* dzg = tmp;
     float* dy = tmp + rows * 8;
-    hipLaunchKernelGGL(k_tra_dgate, dim3(grid_for(rows * 64, 8192)), dim3(NT), 0, s, dout, v, g, B, T, Tt, dzg, bf, bn_load(tb));
+    hipLaunchKernelGGL(k_tra_dgate, dim3(grid_for(rows * 64, 8192)), dim3(NT), 0, s, dout, v, g, B, T, Tt, dzg, bf, bn_load(tb), gbf);
     hipLaunchKernelGGL(k_tra_dy, dim3(grid_for(rows * 8)), dim3(NT), 0, s, dzg, rows, pw_w, dy);
     hipLaunchKernelGGL(k_gate_shuffle_bwd, dim3(grid_for(rows * 33 * 2)), dim3(NT), 0, s, dout, g, dy, v, dw_w, B, T, Tt, dv,
-                       dx, bf, dx_acc, bn_load(tb));
+                       dx, bf, dx_acc, bn_load(tb), gbf);
     const int parts = (int)(rows < MAX_PARTIALS ? rows : MAX_PARTIALS);
     hipLaunchKernelGGL(k_tra_pgrad, dim3(parts), dim3(1024), 0, s, dzg, y, dy, e, B, Tt, scratch);
     // the four gradients are contiguous in the blob in exactly the partials' order (d_dw_w is the first)

@@ -304,9 +304,11 @@ class GTCRNMicro(nn.Module):
         """Train mode only: keep the saved activations in "f32" (default, the reference's precision), "bf16"
         (BASELINE configs[3]: halves the HBM traffic and the workspace of the layer-at-a-time train step; arithmetic,
         BatchNorm statistics, gradients, Adam and the weights stay fp32 -- but the forward then IS the bf16-activation
-        network) or "bf16_saves" (bf16 copies for the backward only: the forward chain stays fp32, so the output equals
+        network), "bf16_saves" (bf16 copies for the backward only: the forward chain stays fp32, so the output equals
         the "f32" mode's bit for bit and the gradient differs from it only by the rounding of the saved tensors, at the
-        bf16 mode's workspace).  Takes effect at the next forward."""
+        bf16 mode's workspace) or "bf16_grads" ("bf16" with the gradients handed from one layer's backward to the next
+        stored in bf16 as well -- what bf16 autocast keeps; same forward as "bf16", the fastest step).  Takes effect at
+        the next forward."""
         if storage not in _lib.Trainer.STORAGE:
             raise _lib.GtcrnError(f"storage must be one of {sorted(_lib.Trainer.STORAGE)}, got {storage!r}")
         self._act_storage = storage

@@ -243,8 +243,11 @@ long gtcrn_train_workspace_bytes(int B, int T);   /* saved activations + gradien
  * values); 4 = bf16 SAVES with an exact forward chain: every forward tensor is written twice -- the fp32 value the next
  * layer reads and the bf16 copy the backward re-reads -- so the output equals mode 0's bit for bit and the gradient
  * differs from mode 0's only by the rounding of the saved tensors, at mode 1's workspace (the fp32 buffers of the chain
- * are short-lived and share the backward's scratch region).  Arithmetic, BatchNorm statistics, gradients, the gradient
- * all-reduce, Adam and the master weights stay fp32 in all modes.  Takes effect at the next forward. */
+ * are short-lived and share the backward's scratch region); 5 = mode 1 with the gradient tensors handed from one
+ * unit's backward to the next stored in bf16 as well (what bf16 autocast training keeps: the forward is mode 1's bit for
+ * bit; a unit rounds the gradient it hands on where it stores it).  Arithmetic, BatchNorm statistics and reductions,
+ * every PARAMETER gradient, the gradient all-reduce, Adam and the master weights stay fp32 in all modes.  Takes effect
+ * at the next forward. */
 int gtcrn_trainer_set_storage(gtcrn_trainer *t, int storage);
 /* Workspace of a (B, T) problem in `storage` with the DEFAULT fusion mask (every pass fusion on).  A trainer whose mask
  * was changed with gtcrn_trainer_set_fusions stores more tensors (about 6 GiB more at B = 512 with mask 7):
