@@ -53,10 +53,11 @@ if [ "$WHAT" = all ] || [ "$WHAT" = train ]; then
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/train_f32" -- python3 "$R/bench.py" --mode train --steps 3 --warmup 1 > "$OUT/train_f32.log" 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/train_bf16" -- python3 "$R/bench.py" --mode train --train-storage bf16 --steps 3 --warmup 1 > "$OUT/train_bf16.log" 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/train_bf16_saves" -- python3 "$R/bench.py" --mode train --train-storage bf16_saves --steps 3 --warmup 1 > "$OUT/train_bf16_saves.log" 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/train_bf16_grads" -- python3 "$R/bench.py" --mode train --train-storage bf16_grads --steps 3 --warmup 1 > "$OUT/train_bf16_grads.log" 2>&1
 # HBM counters of the train step, every storage mode (tools/profile_summary.py -> profiles/<tag>_train_hbm_traffic.json)
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$OUT/train_pmc_fetch" -- python3 "$R/bench.py" --mode train --steps 2 --warmup 1 > "$OUT/train_pmc_fetch.log" 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$OUT/train_pmc_write" -- python3 "$R/bench.py" --mode train --steps 2 --warmup 1 > "$OUT/train_pmc_write.log" 2>&1
-for M in bf16 bf16_saves; do
+for M in bf16 bf16_saves bf16_grads; do
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$OUT/train_${M}_pmc_fetch" -- python3 "$R/bench.py" --mode train --train-storage $M --steps 2 --warmup 1 > "$OUT/train_${M}_pmc_fetch.log" 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$OUT/train_${M}_pmc_write" -- python3 "$R/bench.py" --mode train --train-storage $M --steps 2 --warmup 1 > "$OUT/train_${M}_pmc_write.log" 2>&1
 done

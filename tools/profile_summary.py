@@ -141,7 +141,8 @@ def main():
         # factor -- both readings are reported, the truth for the 16-bit modes lies between them.
         modes = {}
         for mode, fsub, wsub in (("f32", "train_pmc_fetch", "train_pmc_write"), ("bf16", "train_bf16_pmc_fetch", "train_bf16_pmc_write"),
-                                 ("bf16_saves", "train_bf16_saves_pmc_fetch", "train_bf16_saves_pmc_write")):
+                                 ("bf16_saves", "train_bf16_saves_pmc_fetch", "train_bf16_saves_pmc_write"),
+                                 ("bf16_grads", "train_bf16_grads_pmc_fetch", "train_bf16_grads_pmc_write")):
             tot_f = tot_w = 0.0
             for sub, name in ((fsub, "FETCH_SIZE"), (wsub, "WRITE_SIZE")):
                 for f in newest(sub, "*counter_collection.csv"):
@@ -233,7 +234,7 @@ def main():
             open(os.path.join(dst, f"{tag}_ubench_mfma_valu.txt"), "w").write(open(plain).read())
     # --- streaming / training traces
     for sub, pats in (("stream", ("k_stream_ms", "k_encoder", "k_gtcn_ms", "k_decoder")), ("train_f32", None), ("train_bf16", None),
-                      ("train_bf16_saves", None)):
+                      ("train_bf16_saves", None), ("train_bf16_grads", None)):
         f = newest(sub, "*kernel_stats.csv")
         if not f:
             continue
