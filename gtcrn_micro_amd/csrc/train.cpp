@@ -131,7 +131,7 @@ struct gtcrn_trainer {
                                       // 512 the backward of en_convs.1 / de_convs.3 from LDS tiles,
                                       // 1024 the second stage of every BatchNorm reduction in the last workgroup of the
                                       // kernel that produces its partial sums (no finish launches),
-                                      // 2048 (fp32 storage) the decoder's sums x + skip written by the layer that produces x,
+                                      // 2048 (not the exact chain) the decoder's sums x + skip written by the layer that produces x,
                                       // 4096 point_bn2 applied on load by TRALite / gate-shuffle (forward and backward)
     const void* red_unit = nullptr;   // backward: the unit whose BatchNorm reduction already sits in dscratch ...
     int red_parts = 0;                // ... as this many per-workgroup partial sums (see unit_bwd)
@@ -285,10 +285,11 @@ size_t plan(gtcrn_trainer* t, int B, int T, float* base) {
     // conditions under which unit_bwd takes those fused forms with a riding reduction)
     const bool lean = fuse && t->bf == t->ybf && (t->fusions & 4) && (t->fusions & 8);
     const bool lean_c1 = lean && (t->fusions & 2);
-    // fusion bit 11 (fp32 storage: every sum x + skip of the decoder is saved anyway): a sum is written by the layer that
+    // fusion bit 11 (16-bit storage: the sums then get buffers of their own instead of ONE shared buffer that the
+    // backward refills by recomputing each sum -- the same memory, the block outputs' buffers go): a sum is written by the layer that
     // PRODUCES x -- the last TCN block's bn_act, the decoder blocks' gate/shuffle, de_convs.3's bn_act -- instead of a pass
     // that reads x and the skip and writes the sum; x itself (an output nobody else reads) is not stored
-    t->fuse_sums = (t->fusions & 2048) && t->bf == 0 && !t->exact;
+    t->fuse_sums = (t->fusions & 2048) && !t->exact;
     t->taps.clear();
     t->tap_minus.clear();
     {   // (the fp32 twins of the exact chain are assigned at the end; a unit that has none must not keep an old one)
@@ -413,7 +414,7 @@ size_t plan(gtcrn_trainer* t, int B, int T, float* base) {
     // bf16 storage (the memory-lean variant): the decoder's sums x + skip (three block inputs, s3, s4) are not saved --
     // one shared buffer holds the current one, the backward recomputes each from its two (saved) addends right before
     // it is needed (five extra streaming adds).  fp32 storage keeps them all, as before.
-    t->share_sums = t->bf != 0;
+    t->share_sums = t->bf != 0 && !t->fuse_sums;
     t->s_tmp = t->share_sums ? b.take_saved(n65 * 16) : nullptr;
     t->de3.post = nullptr;
     for (int i = 0; i < 3; ++i) {

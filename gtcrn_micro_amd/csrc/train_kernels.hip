@@ -1573,7 +1573,7 @@ __global__ __launch_bounds__(NT) void k_bn_act(const float* __restrict__ y, long
             o[e] = act_fwd(z, act, sl);
             // post: the decoder's skip is added AFTER the activation and the sum is what gets stored (the next layer's
             // input x + skip; the activation itself has no other reader) -- the same fp32 add the separate pass made
-            if (post) o[e] += pa[e];
+            if (post) o[e] = round16(o[e], bf) + pa[e];      // (16-bit storage: the activation rounded as the stored one was)
             if (y2) yt[e] = ycopy_value(x[e], z, mean[e], istd[e], gm[e], bt[e], res != nullptr, res ? r[e] : 0.f, y2_bf,
                                         act == ACT_PRELU);
         }
@@ -3255,8 +3255,9 @@ __global__ __launch_bounds__(NT) void k_gate_shuffle(const float* __restrict__ v
         const f32x4 p = vv * gg;
         if (skip) {
             const f32x4 k0 = sld4<kNt>(skip, pos * 16 + 8 * h, bf), k1 = sld4<kNt>(skip, pos * 16 + 8 * h + 4, bf);
-            sst4<kNtSt>(out, pos * 16 + 8 * h, bf, f32x4{p[0], xx[0], p[1], xx[1]} + k0);
-            sst4<kNtSt>(out, pos * 16 + 8 * h + 4, bf, f32x4{p[2], xx[2], p[3], xx[3]} + k1);
+            // (16-bit storage: the block output rounded as the stored one was, then the same add as the separate pass)
+            sst4<kNtSt>(out, pos * 16 + 8 * h, bf, round_bf4(f32x4{p[0], xx[0], p[1], xx[1]}, bf) + k0);
+            sst4<kNtSt>(out, pos * 16 + 8 * h + 4, bf, round_bf4(f32x4{p[2], xx[2], p[3], xx[3]}, bf) + k1);
             continue;
         }
         sst4<kNtSt>(out, pos * 16 + 8 * h, bf, f32x4{p[0], xx[0], p[1], xx[1]});

@@ -269,10 +269,11 @@ long gtcrn_trainer_workspace_bytes(gtcrn_trainer *t, int B, int T);
  * backward of the two 16 -> 16 (1,5) stride-2 units (en_convs.1, de_convs.3) from LDS tiles.  bit 10: the second
  * stage of every BatchNorm reduction (forward statistics + running estimates; backward means, dgamma, dbeta, dslope) runs
  * in the LAST workgroup of the kernel that produces the per-workgroup sums (two-level last-arriver reduction, agent-scope
- * write-through hand-off, fixed summation order) instead of 92 one-workgroup finish launches per step.  bit 11 (fp32
- * storage): each of the decoder's five sums x + en_outs[..] (models/gtcrn_micro.py:463-469) is written by the layer
+ * write-through hand-off, fixed summation order) instead of 92 one-workgroup finish launches per step.  bit 11 (not
+ * in storage mode 4): each of the decoder's five sums x + en_outs[..] (models/gtcrn_micro.py:463-469) is written by the layer
  * that produces x (the last TCN block's normalise pass, the decoder blocks' gate/shuffle, de_convs.3's normalise pass)
- * instead of an add pass; x itself is not stored (its test tap is sum - skip).  bit 12 (needs bit 0; not in storage
+ * instead of an add pass; x itself is not stored (its test tap is sum - skip); in the 16-bit modes x is rounded to
+ * the storage format before the add, as the stored x was, and the backward no longer recomputes the sums.  bit 12 (needs bit 0; not in storage
  * mode 4): point_bn2 -- the one BatchNorm with no activation behind it -- is applied on load by its four readers
  * (TRALite's energy, the gate/shuffle, their two backward passes): six normalise passes per step and the tensor they
  * wrote are gone, the values are the same bit for bit.  Default 8191.
