@@ -871,6 +871,125 @@ __global__ __launch_bounds__(NT) void k_conv_mfma(ConvGeom g, const float* __res
     }
 }
 
+// ------------------------------------------------------------ the pointwise (1x1) forward convs, dedicated form
+// 28 launches of a step (21 of them normalise-on-load) ran through k_conv_mfma<1, 1>, whose loop carries everything a
+// strided, padded, multi-tap conv needs -- a (b, t, f) position per tile, 64-bit row arithmetic per tap, run-time format /
+// residual / accumulate switches: ~250 vector instructions per 16-position tile, which is what bounded it (114 us on
+// 272 MB of bf16 tensors, 148 us on 544 MB of fp32 ones: the same 4 waves per SIMD issue-bound either way).  A pointwise
+// conv needs none of that: position p reads element p * CinT + cin_off and writes element p * Cout; per tile the lane
+// advances two 32-bit offsets.  Formats, residual and normalise-on-load are compile-time; the A fragment of the one 16 x 16
+// weight matrix stays in registers.  Same expressions in the same order as k_conv_mfma (pre_apply, bias first, four
+// k-ordered MFMAs, statistics in double from the value the tensor holds): bit-identical outputs and statistics.
+// (exact-chain storage and accumulating launches keep the general kernel.)
+template <int FIN, int OUTF, bool PRE, bool RES>
+__global__ __launch_bounds__(NT) void k_pw_fwd(long npos, int Cin, int CinT, int cin_off, int Cout, int w_co, int w_ci,
+                                              const float* __restrict__ in, const float* __restrict__ w,
+                                              const float* __restrict__ bias, float* __restrict__ out, long tiles_per_wave,
+                                              double* __restrict__ stat_partial, const float* __restrict__ shift, BnPre pre,
+                                              FinArgs fa) {
+    static_assert(PRE || !RES, "the residual belongs to the deferred unit");
+    __shared__ __attribute__((aligned(16))) float sW[256];   // [co][ci], zero padded
+    __shared__ double sStat[NT / 64][32];
+    const int tid = threadIdx.x;
+    {
+        const int co = tid >> 4, ci = tid & 15;
+        sW[tid] = (co < Cout && ci < Cin) ? w[co * w_co + ci * w_ci] : 0.f;
+    }
+    __syncthreads();
+    const int lane = tid & 63, n = lane & 15, q = lane >> 4;
+    const long ntiles = (npos + 15) >> 4;
+    const long wave = (long)blockIdx.x * (NT / 64) + (tid >> 6);
+    long tile = wave * tiles_per_wave;
+    const long tend = tile + tiles_per_wave < ntiles ? tile + tiles_per_wave : ntiles;
+    const bool cin_ok = 4 * q < Cin, cout_ok = 4 * q < Cout;
+    double s1[4] = {0.0, 0.0, 0.0, 0.0}, s2[4] = {0.0, 0.0, 0.0, 0.0};
+    f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+    if (bias && cout_ok) bv = *reinterpret_cast<const f32x4*>(bias + 4 * q);
+    if (shift && cout_ok) bv -= *reinterpret_cast<const f32x4*>(shift + 4 * q);
+    PreConst pk{};
+    float sl = 1.f;
+    if constexpr (PRE) {
+        pk = pre_const(pre, q, CinT);
+        sl = pk.act ? pk.sl : 1.f;           // (no activation: z > 0 ? z : 1 * z is z)
+    }
+    const f32x4 A = *reinterpret_cast<const f32x4*>(sW + n * 16 + 4 * q);
+    if (tile >= tend) goto finish;           // (a wave past the last tile still takes part in the reductions below)
+    {
+        // wave-uniform bases (scalar registers) + 32-bit lane offsets, both advanced per tile
+        const long p0 = tile * 16;
+        const float* inb = in;
+        const float* resb = pre.res;
+        float* aob = pre.a_out;
+        float* outb = out;
+        unsigned ioff = (unsigned)((p0 + n) * CinT + cin_off + 4 * q);      // elements; the tensors have < 2^31 of them
+        unsigned ooff = (unsigned)((p0 + n) * Cout + 4 * q);
+        const unsigned istep = 16u * (unsigned)CinT, ostep = 16u * (unsigned)Cout;
+        long p = p0 + n;
+        auto ld_in = [&](unsigned off) {
+            if constexpr (FIN == 0) return *reinterpret_cast<const f32x4*>(inb + off);
+            else {
+                const u32x2 u = *reinterpret_cast<const u32x2*>(reinterpret_cast<const unsigned short*>(inb) + off);
+                return uint2{u.x, u.y};
+            }
+        };
+        typename Raw4<FIN>::t cur = ld_in((p < npos && cin_ok) ? ioff : 0u), nxt = cur;
+        f32x4 rcur = {0.f, 0.f, 0.f, 0.f}, rnxt = rcur;
+        if constexpr (RES) rcur = sld4(resb, (p < npos) ? (long)ioff : 0L, FIN);
+        for (; tile < tend; ++tile) {
+            const bool pv = p < npos;
+            if (tile + 1 < tend) {           // (wave-uniform) the next tile's loads in flight while this one is computed
+                const bool pn = p + 16 < npos;
+                nxt = ld_in((pn && cin_ok) ? ioff + istep : 0u);
+                if constexpr (RES) rnxt = sld4(resb, pn ? (long)(ioff + istep) : 0L, FIN);
+            }
+            f32x4 d = dec4<FIN>(cur);
+            if constexpr (PRE) {
+                f32x4 a;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float z = pk.gm[e] * ((d[e] - pk.mean[e]) * pk.istd[e]) + pk.bt[e];
+                    if constexpr (RES) z += rcur[e];
+                    a[e] = z > 0.f ? z : sl * z;
+                }
+                d = round_bf4(a, FIN);
+                if (pv && aob) sst4<kNtSt>(aob, (long)ioff, FIN, d);
+            }
+            const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+            const f32x4 xv = (pv && cin_ok) ? d : zero;
+            f32x4 acc = bv;
+#pragma unroll
+            for (int s4 = 0; s4 < 4; ++s4) acc = mfma4(A[s4], xv[s4], acc);
+            if (pv && cout_ok) {
+                acc = round_bf4(acc, OUTF);  // the statistics are those of the STORED tensor (the backward re-reads it)
+                sst4<kNtSt>(outb, (long)ooff, OUTF, acc);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { const double a = (double)acc[e]; s1[e] += a; s2[e] = fma(a, a, s2[e]); }
+            }
+            cur = nxt;
+            rcur = rnxt;
+            ioff += istep;
+            ooff += ostep;
+            p += 16;
+        }
+    }
+finish:
+    if (stat_partial) {          // as k_conv_mfma: lanes -> LDS -> one thread per (sum, channel), fixed order
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { s1[e] = wave_sum_xor(s1[e], 1, 8); s2[e] = wave_sum_xor(s2[e], 1, 8); }
+        if (n == 0)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { sStat[tid >> 6][4 * q + e] = s1[e]; sStat[tid >> 6][16 + 4 * q + e] = s2[e]; }
+        __syncthreads();
+        if (tid < 2 * Cout) {
+            const int which = tid / Cout, ch = tid - which * Cout;
+            double t = 0.0;
+            for (int w2 = 0; w2 < NT / 64; ++w2) t += sStat[w2][which * 16 + ch];
+            st_part(stat_partial + (long)blockIdx.x * 2 * Cout + tid, t, fa);
+        }
+        if (fa.kind) fin_reduce(stat_partial, 2 * Cout, blockIdx.x, gridDim.x, fa);
+    }
+}
+
 // The window form on the VALU, for the FORWARD of encoder.en_convs.0: thread (position, channel quad), the window as
 // four unaligned 16-byte loads (the four lanes of a position read the same addresses), then the multiply-adds of
 // k_conv<3, 16> in ITS order (tap, input channel: one fp32 fmaf chain per output channel; a tap outside the row enters
@@ -3665,6 +3784,9 @@ inline int parts_slot(int have_parts) { return have_parts < 0 ? -have_parts - 1 
 }  // namespace
 
 void set_fin_context(bool on, double* gpart, unsigned* ctr) { g_fin.on = on; g_fin.gpart = gpart; g_fin.ctr = ctr; }
+// fusion bit 13: the pointwise forward convs through k_pw_fwd instead of the general k_conv_mfma<1, 1> (thread local, like g_fin)
+static thread_local bool g_pw_form = true;
+void set_pointwise_form(bool on) { g_pw_form = on; }
 
 // ====================================================================================== launchers
 // grid of a streaming reduction: a stride that is a multiple of C (NT is), at most MAX_PARTIALS workgroups
@@ -3829,6 +3951,25 @@ int conv_fwd(const ConvGeom& g, const float* in, const float* w, const float* bi
         else if (g.in_bf == 1) hipLaunchKernelGGL((k_conv_mfma<KT, KF, 1>), dim3(grid), dim3(NT), 0, s, g, in, w, bias, out, tpw, sp, shift, nopre, nonx, fm); \
         else hipLaunchKernelGGL((k_conv_mfma<KT, KF, 2>), dim3(grid), dim3(NT), 0, s, g, in, w, bias, out, tpw, sp, shift, nopre, nonx, fm); \
     } while (0)
+        // the dedicated pointwise form (see k_pw_fwd): a pure 1x1 conv over flat positions, whole output tensor, 0 / bf16 formats
+        const bool pw = !win && g.nkt == 1 && g.nkf == 1 && g.t_off[0] == 0 && g.Tin == g.Tout && g.Fin == g.Fout && g.sf == 1 &&
+                        g.pf == 0 && g.f_mode == 0 && !g.accumulate && g.cout_off == 0 && g.Cout == g.CoutT && g.in_bf <= 1 && g.out_bf <= 1 &&
+                        (long)g.B * g.Tout * g.Fout * 16 < (1L << 31) && (!pre || (!pre->exact && pre->bf == g.in_bf)) &&
+                        g_pw_form;
+        if (pw) {
+            const long npos = (long)g.B * g.Tout * g.Fout;
+#define GT_PW(FI, FO, PR, RS) hipLaunchKernelGGL((k_pw_fwd<FI, FO, PR, RS>), dim3(grid), dim3(NT), 0, s, npos, g.Cin, g.CinT, g.cin_off, \
+                                                 g.Cout, g.w_co, g.w_ci, in, w, bias, out, tpw, sp, shift, pre ? *pre : nopre, fm)
+#define GT_PW2(PR, RS) do { if (g.in_bf == 0 && g.out_bf == 0) GT_PW(0, 0, PR, RS); else if (g.in_bf == 1 && g.out_bf == 1) GT_PW(1, 1, PR, RS); \
+                            else if (g.in_bf == 0) GT_PW(0, 1, PR, RS); else GT_PW(1, 0, PR, RS); } while (0)
+            if (pre && pre->res) GT_PW2(true, true);
+            else if (pre) GT_PW2(true, false);
+            else GT_PW2(false, false);
+#undef GT_PW2
+#undef GT_PW
+            if (sp) *stat_parts = fm.kind ? -grid : grid;
+            return check();
+        }
         if (pre) {
             if (g.in_bf == 0) hipLaunchKernelGGL((k_conv_mfma<1, 1, 0, false, true>), dim3(grid), dim3(NT), 0, s, g, in, w, bias, out, tpw, sp, shift, *pre, nonx, fm);
             else if (g.in_bf == 1) hipLaunchKernelGGL((k_conv_mfma<1, 1, 1, false, true>), dim3(grid), dim3(NT), 0, s, g, in, w, bias, out, tpw, sp, shift, *pre, nonx, fm);
