@@ -216,6 +216,13 @@ __device__ __forceinline__ unsigned f2bf(float x) {
 }
 __device__ __forceinline__ float dec16(unsigned h, int fmt) { (void)fmt; return bf2f(h); }
 __device__ __forceinline__ unsigned enc16(float x, int fmt) { (void)fmt; return f2bf(x); }
+// two elements in ONE v_cvt_pk_bf16_f32 (a in the low half): the element-wise form above spends one conversion plus the
+// masking / merging of its half on every element -- ~5 vector instructions per stored pair instead of 1
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned enc16x2(float a, float b) {
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2_t{a, b}, bf16x2_t));
+}
 // one element.  NOTE for callers with unrolled load loops (the weight-gradient kernels): make `fmt` a COMPILE-TIME
 // constant there (template parameter).  A run-time `if (fmt)` around each load splits the loop into one basic block
 // per load, so the 36 loads of an iteration are no longer issued together (measured 1.8x longer with bf16 storage
@@ -267,8 +274,8 @@ template <bool NTS = false>
 __device__ __forceinline__ void sst4(float* base, long idx, int fmt, const f32x4 v) {
     if (fmt) {
         u32x2 u;
-        u.x = enc16(v[0], fmt) | (enc16(v[1], fmt) << 16);
-        u.y = enc16(v[2], fmt) | (enc16(v[3], fmt) << 16);
+        u.x = enc16x2(v[0], v[1]);
+        u.y = enc16x2(v[2], v[3]);
         u32x2* p = reinterpret_cast<u32x2*>(reinterpret_cast<unsigned short*>(base) + idx);
         if (NTS) __builtin_nontemporal_store(u, p); else *p = u;
     } else {
@@ -278,7 +285,9 @@ __device__ __forceinline__ void sst4(float* base, long idx, int fmt, const f32x4
 }
 __device__ __forceinline__ float round16(float x, int fmt) { return fmt ? dec16(enc16(x, fmt), fmt) : x; }
 __device__ __forceinline__ f32x4 round_bf4(const f32x4 v, int fmt) {
-    return fmt ? f32x4{round16(v[0], fmt), round16(v[1], fmt), round16(v[2], fmt), round16(v[3], fmt)} : v;
+    if (!fmt) return v;
+    const unsigned a = enc16x2(v[0], v[1]), b = enc16x2(v[2], v[3]);       // (same round-to-nearest-even as enc16)
+    return f32x4{__uint_as_float(a << 16), __uint_as_float(a & 0xFFFF0000u), __uint_as_float(b << 16), __uint_as_float(b & 0xFFFF0000u)};
 }
 template <int C, bool NTL = false>
 __device__ __forceinline__ void load_vec_s(const float* base, long idx, int bf, float (&v)[C]) {
@@ -626,10 +635,9 @@ __device__ __forceinline__ f32x4 next_act(const NextConst& k, const f32x4 y, int
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
         const float z = k.gm[e] * ((y[e] - k.mean[e]) * k.istd[e]) + k.bt[e];
-        const float v = z > 0.f ? z : k.sl * z;
-        a[e] = xround ? round16(v, 1) : v;
+        a[e] = z > 0.f ? z : k.sl * z;
     }
-    return a;
+    return xround ? round_bf4(a, 1) : a;
 }
 __device__ __forceinline__ void next_accum(const NextConst& k, const f32x4 y, const f32x4 g, float (&vr)[3][4]) {
 #pragma unroll
@@ -881,6 +889,7 @@ __global__ __launch_bounds__(NT) void k_conv_mfma(ConvGeom g, const float* __res
 // weight matrix stays in registers.  Same expressions in the same order as k_conv_mfma (pre_apply, bias first, four
 // k-ordered MFMAs, statistics in double from the value the tensor holds): bit-identical outputs and statistics.
 // (exact-chain storage and accumulating launches keep the general kernel.)
+constexpr int PW_U = 2;
 template <int FIN, int OUTF, bool PRE, bool RES>
 __global__ __launch_bounds__(NT) void k_pw_fwd(long npos, int Cin, int CinT, int cin_off, int Cout, int w_co, int w_ci,
                                               const float* __restrict__ in, const float* __restrict__ w,
@@ -932,44 +941,65 @@ __global__ __launch_bounds__(NT) void k_pw_fwd(long npos, int Cin, int CinT, int
                 return uint2{u.x, u.y};
             }
         };
-        typename Raw4<FIN>::t cur = ld_in((p < npos && cin_ok) ? ioff : 0u), nxt = cur;
-        f32x4 rcur = {0.f, 0.f, 0.f, 0.f}, rnxt = rcur;
-        if constexpr (RES) rcur = sld4(resb, (p < npos) ? (long)ioff : 0L, FIN);
-        for (; tile < tend; ++tile) {
-            const bool pv = p < npos;
-            if (tile + 1 < tend) {           // (wave-uniform) the next tile's loads in flight while this one is computed
-                const bool pn = p + 16 < npos;
-                nxt = ld_in((pn && cin_ok) ? ioff + istep : 0u);
-                if constexpr (RES) rnxt = sld4(resb, pn ? (long)(ioff + istep) : 0L, FIN);
-            }
-            f32x4 d = dec4<FIN>(cur);
-            if constexpr (PRE) {
-                f32x4 a;
+        // PW_U tiles per iteration, the NEXT PW_U already requested: 2 x PW_U tiles of input in flight per wave (one tile per
+        // wave at a time left the kernel at ~3.4 TB/s: 16 waves per CU x 0.5-1 KB is a third of what the latency asks for)
+        typename Raw4<FIN>::t cur[PW_U], nxt[PW_U];
+        f32x4 rcur[PW_U], rnxt[PW_U];
+        auto fetch = [&](long tl, long pp, unsigned off, typename Raw4<FIN>::t (&r)[PW_U], f32x4 (&rr)[PW_U]) {
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    float z = pk.gm[e] * ((d[e] - pk.mean[e]) * pk.istd[e]) + pk.bt[e];
-                    if constexpr (RES) z += rcur[e];
-                    a[e] = z > 0.f ? z : sl * z;
+            for (int u = 0; u < PW_U; ++u) {
+                const bool ok = tl + u < tend && pp + 16 * u < npos;
+                r[u] = ld_in((ok && cin_ok) ? off + (unsigned)u * istep : 0u);
+                rr[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+                if constexpr (RES) rr[u] = sld4(resb, ok ? (long)(off + (unsigned)u * istep) : 0L, FIN);
+            }
+        };
+        fetch(tile, p, ioff, cur, rcur);
+        for (; tile < tend; tile += PW_U) {
+            if (tile + PW_U < tend) fetch(tile + PW_U, p + 16 * PW_U, ioff + PW_U * istep, nxt, rnxt);     // (wave-uniform)
+            f32x4 xv[PW_U], acc[PW_U];
+#pragma unroll
+            for (int u = 0; u < PW_U; ++u) {
+                const bool pv = tile + u < tend && p + 16 * u < npos;
+                f32x4 d = dec4<FIN>(cur[u]);
+                if constexpr (PRE) {
+                    f32x4 a;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        float z = pk.gm[e] * ((d[e] - pk.mean[e]) * pk.istd[e]) + pk.bt[e];
+                        if constexpr (RES) z += rcur[u][e];
+                        a[e] = z > 0.f ? z : sl * z;
+                    }
+                    d = round_bf4(a, FIN);
+                    if (pv && aob) sst4<kNtSt>(aob, (long)(ioff + (unsigned)u * istep), FIN, d);
                 }
-                d = round_bf4(a, FIN);
-                if (pv && aob) sst4<kNtSt>(aob, (long)ioff, FIN, d);
+                // (a lane past the last position computes on element 0's data and stores nothing: no select needed; the
+                // channel quads past Cin -- point_conv1 reads 8 of 16 channels -- meet zero weight rows but must not bring
+                // another tensor region's Inf / NaN to them)
+                const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+                if constexpr (PRE) xv[u] = d;
+                else xv[u] = cin_ok ? d : zero;
+                acc[u] = bv;
             }
-            const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
-            const f32x4 xv = (pv && cin_ok) ? d : zero;
-            f32x4 acc = bv;
 #pragma unroll
-            for (int s4 = 0; s4 < 4; ++s4) acc = mfma4(A[s4], xv[s4], acc);
-            if (pv && cout_ok) {
-                acc = round_bf4(acc, OUTF);  // the statistics are those of the STORED tensor (the backward re-reads it)
-                sst4<kNtSt>(outb, (long)ooff, OUTF, acc);
+            for (int s4 = 0; s4 < 4; ++s4)           // the tiles' k-ordered chains interleaved
 #pragma unroll
-                for (int e = 0; e < 4; ++e) { const double a = (double)acc[e]; s1[e] += a; s2[e] = fma(a, a, s2[e]); }
+                for (int u = 0; u < PW_U; ++u) acc[u] = mfma4(A[s4], xv[u][s4], acc[u]);
+#pragma unroll
+            for (int u = 0; u < PW_U; ++u) {
+                const bool pv = tile + u < tend && p + 16 * u < npos;
+                if (pv && cout_ok) {
+                    acc[u] = round_bf4(acc[u], OUTF);  // the statistics are those of the STORED tensor (the backward re-reads it)
+                    sst4<kNtSt>(outb, (long)(ooff + (unsigned)u * ostep), OUTF, acc[u]);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { const double a = (double)acc[u][e]; s1[e] += a; s2[e] = fma(a, a, s2[e]); }
+                }
             }
-            cur = nxt;
-            rcur = rnxt;
-            ioff += istep;
-            ooff += ostep;
-            p += 16;
+#pragma unroll
+            for (int u = 0; u < PW_U; ++u) { cur[u] = nxt[u]; rcur[u] = rnxt[u]; }
+            ioff += PW_U * istep;
+            ooff += PW_U * ostep;
+            p += 16 * PW_U;
         }
     }
 finish:
@@ -2032,11 +2062,10 @@ __global__ __launch_bounds__(NT) void k_unit1x1_bwd(ConvGeom g, const float* __r
             if constexpr (XR) {    // x = PReLU(z), the expressions of pre_apply / k_bn_act
                 f32x4 xa;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const float a = nz[e] > 0.f ? nz[e] : nsl * nz[e];
-                    xa[e] = pv ? (nx.xround ? round16(a, 1) : a) : 0.f;
-                }
-                *reinterpret_cast<f32x4*>(&sX[wv][n * 16 + 4 * q]) = xa;
+                for (int e = 0; e < 4; ++e) xa[e] = nz[e] > 0.f ? nz[e] : nsl * nz[e];
+                if (nx.xround) xa = round_bf4(xa, 1);
+                const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+                *reinterpret_cast<f32x4*>(&sX[wv][n * 16 + 4 * q]) = pv ? xa : zero4;
             }
         }
         if constexpr (!XR) {
