@@ -2040,94 +2040,96 @@ __global__ __launch_bounds__(NT) void k_unit1x1_bwd(ConvGeom g, const float* __r
     const f32x4 At = *reinterpret_cast<const f32x4*>(sWt + n * 16 + 4 * q);   // row ci = n of W^T
     f32x4 accW = {0.f, 0.f, 0.f, 0.f};
     float bsum = 0.f;
+    // Round 5 (late): the loop below is issue-bound once the tensors are 16-bit (180 us on 0.8 GB), so it is written for
+    // instruction count -- quad-wide expressions (packed fp32 instructions), 32-bit lane offsets from wave-uniform bases
+    // advanced per tile, the activation derivative as one select (PReLU, or "none" as slope 1: the pointwise units have
+    // no other activation, the launcher checks).
+    const float slw = bn.act == ACT_PRELU ? sl : 1.f;
+    const f32x4 gi = gm * istd;
+    f32x4 vrv[3] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+    const int np32 = (int)npos;                                       // (positions and element offsets fit in 31 bits: the launcher checks)
+    int p = (int)(tile * 16) + n;
+    unsigned yoff = (unsigned)p * (unsigned)g.Cout + 4u * q;          // y, da, res, dres: [pos][Cout]
+    unsigned xoff = (unsigned)p * (unsigned)g.CinT + (unsigned)g.cin_off + 4u * q;   // x, dx (and, NEXT: that unit's y / res)
+    const unsigned ystep = 16u * (unsigned)g.Cout, xstep = 16u * (unsigned)g.CinT;
+    struct TileIn {
+        typename Raw4<YF>::t y, ny;
+        typename Raw4<GF>::t da;
+        typename Raw4<FMT>::t x, r, nr;
+    };
+    auto fetch = [&](int pp, unsigned yo, unsigned xo, TileIn& ti) {
+        const bool pvv = pp < np32;
+        const unsigned yq = (pvv && co_ok4) ? yo : 0u, xq = (pvv && ci_ok4) ? xo : 0u;
+        ti.y = sld4_raw<YF, kNt>(y, (long)yq);
+        ti.da = sld4_raw<GF, kNt>(da, (long)yq);
+        if (res) ti.r = sld4_raw<FMT, kNt>(res, (long)yq);
+        if constexpr (!XR) ti.x = sld4_raw<FMT, true>(x, (long)xq);
+        if constexpr (NEXT) {
+            ti.ny = sld4_raw<YF, kNt>(nx.y, (long)(pvv ? xo : 0u));
+            if (nx.res) ti.nr = sld4_raw<FMT, kNt>(nx.res, (long)(pvv ? xo : 0u));
+        }
+    };
+    // (requesting tile i + 1's loads before tile i is computed -- what pays in k_pw_fwd -- made this kernel SLOWER: the bf16
+    // step 22.27 ms with it against 21.79 without, same box; its registers also cost the fp32 form a wave per SIMD)
+    TileIn cur{};
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
     for (; tile < tend; ++tile) {
-        const long p = tile * 16 + n;
-        const bool pv = p < npos;
-        // weight-gradient operand x: ONE 16-byte load per lane in the (position, channel quad) layout, issued first; it
-        // reaches the (channel, position) layout the MFMA wants through a wave-private LDS tile like dy (four 4-byte
-        // loads per lane in that layout directly cost four requests per tile: the Cin = 8 units ran at 3.2 TB/s)
-        typename Raw4<FMT>::t xraw{};
-        if constexpr (!XR) xraw = sld4_raw<FMT, true>(x, (pv && ci_ok4) ? p * g.CinT + g.cin_off + 4 * q : 0L);
-        f32x4 ynx = {0.f, 0.f, 0.f, 0.f}, rnx = ynx;
-        f32x4 nxh = ynx, nz = ynx;                                // the NEXT unit's xhat and pre-activation z of this lane's quad
+        const bool pv = p < np32;
+        fetch(p, yoff, xoff, cur);
+        f32x4 nxh = zero4, nz = zero4;                             // the NEXT unit's xhat and pre-activation z of this lane's quad
         if constexpr (NEXT) {      // (Cin == CinT == 16 with NEXT: the launcher checks)
-            ynx = sld4<kNt>(nx.y, (pv ? p : 0) * 16 + 4 * q, ybf);
-            if (nx.res) rnx = sld4<kNt>(nx.res, (pv ? p : 0) * 16 + 4 * q, bf);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                nxh[e] = (ynx[e] - nmean[e]) * nistd[e];
-                nz[e] = ngm[e] * nxh[e] + nbt[e];
-                if (nx.res) nz[e] += rnx[e];
-            }
+            nxh = (dec4<YF>(cur.ny) - nmean) * nistd;
+            nz = ngm * nxh + nbt;
+            if (nx.res) nz += dec4<FMT>(cur.nr);
             if constexpr (XR) {    // x = PReLU(z), the expressions of pre_apply / k_bn_act
                 f32x4 xa;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) xa[e] = nz[e] > 0.f ? nz[e] : nsl * nz[e];
                 if (nx.xround) xa = round_bf4(xa, 1);
-                const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
                 *reinterpret_cast<f32x4*>(&sX[wv][n * 16 + 4 * q]) = pv ? xa : zero4;
             }
         }
-        if constexpr (!XR) {
-            const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
-            *reinterpret_cast<f32x4*>(&sX[wv][n * 16 + 4 * q]) = (pv && ci_ok4) ? dec4<FMT>(xraw) : zero4;
-        }
-        f32x4 dy = {0.f, 0.f, 0.f, 0.f};
-        if (pv && co_ok4) {
-            const f32x4 yv = sld4<kNt>(y, p * g.Cout + 4 * q, ybf);
-            const f32x4 gv = sld4<kNt>(da, p * g.Cout + 4 * q, GF);
-            f32x4 rv = {0.f, 0.f, 0.f, 0.f};
-            if (res) rv = sld4<kNt>(res, p * g.Cout + 4 * q, bf);
+        if constexpr (!XR) *reinterpret_cast<f32x4*>(&sX[wv][n * 16 + 4 * q]) = (pv && ci_ok4) ? dec4<FMT>(cur.x) : zero4;
+        f32x4 dy = zero4;
+        {
+            const f32x4 xh = (dec4<YF>(cur.y) - mean) * istd;
+            f32x4 z = gm * xh + bt;
+            if (res) z += dec4<FMT>(cur.r);
+            const f32x4 gv = dec4<GF>(cur.da), gs = slw * gv;
             f32x4 dzv;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const float xh = (yv[e] - mean[e]) * istd[e];
-                float z = gm[e] * xh + bt[e];
-                if (res) z += rv[e];
-                float dsl;
-                const float dz = act_bwd(z, gv[e], bn.act, sl, dsl);
-                dzv[e] = dz;
-                dy[e] = gm[e] * istd[e] * (dz - m1[e] - xh * m2[e]);
-            }
-            if (dres) {
-                if constexpr (GF == 0) {
-                    f32x4* dr = reinterpret_cast<f32x4*>(dres + p * g.Cout + 4 * q);
-                    if (dres_acc) *dr = *dr + dzv;
-                    else sst4<kNtSt>(dres, p * g.Cout + 4 * q, 0, dzv);
-                } else {
-                    if (dres_acc) sst4(dres, p * g.Cout + 4 * q, GF, sld4(dres, p * g.Cout + 4 * q, GF) + dzv);
-                    else sst4<kNtSt>(dres, p * g.Cout + 4 * q, GF, dzv);
+            for (int e = 0; e < 4; ++e) dzv[e] = z[e] > 0.f ? gv[e] : gs[e];
+            const f32x4 dyv = gi * (dzv - m1 - xh * m2);
+            if (pv && co_ok4) {
+                dy = dyv;
+                if (dres) {
+                    if (dres_acc) sst4(dres, (long)yoff, GF, sld4(dres, (long)yoff, GF) + dzv);
+                    else sst4<kNtSt>(dres, (long)yoff, GF, dzv);
                 }
             }
         }
         // data gradient: dx[pos][ci] = sum_co W[co][ci] dy[pos][co]
         if (dx) {
-            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+            f32x4 acc = zero4;
 #pragma unroll
             for (int e = 0; e < 4; ++e) acc = mfma4(At[e], dy[e], acc);
             if (pv && ci_ok4) {
-                if constexpr (GF == 0) {
-                    f32x4* o = reinterpret_cast<f32x4*>(dx + p * g.CinT + g.cin_off + 4 * q);
-                    if (dx_acc) {
-                        acc = *o + acc;
-                        *o = acc;
-                    }
-                    else sst4<kNtSt>(dx, p * g.CinT + g.cin_off + 4 * q, 0, acc);
-                } else {
-                    if (dx_acc) acc = sld4(dx, p * g.CinT + g.cin_off + 4 * q, GF) + acc;
-                    acc = round_bf4(acc, GF);          // (the riding reduction below sees the value the tensor now holds)
-                    if (dx_acc) sst4(dx, p * g.CinT + g.cin_off + 4 * q, GF, acc);
-                    else sst4<kNtSt>(dx, p * g.CinT + g.cin_off + 4 * q, GF, acc);
-                }
+                if (dx_acc) acc = sld4(dx, (long)xoff, GF) + acc;
+                acc = round_bf4(acc, GF);          // (the riding reduction below sees the value the tensor now holds)
+                if (dx_acc) sst4(dx, (long)xoff, GF, acc);
+                else sst4<kNtSt>(dx, (long)xoff, GF, acc);
                 if constexpr (NEXT) {
+                    const f32x4 as = nsl * acc, az = acc * nz;
+                    f32x4 dz2, ds2;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        float dsl;
-                        const float dz = act_bwd(nz[e], acc[e], ACT_PRELU, nsl, dsl);
-                        vr[0][e] += dz;
-                        vr[1][e] = fmaf(dz, nxh[e], vr[1][e]);
-                        vr[2][e] += dsl;
+                        const bool pos = nz[e] > 0.f;
+                        dz2[e] = pos ? acc[e] : as[e];
+                        ds2[e] = pos ? 0.f : az[e];
                     }
+                    vrv[0] += dz2;
+                    vrv[1] += dz2 * nxh;
+                    vrv[2] += ds2;
                 }
             }
         }
@@ -2145,7 +2147,12 @@ __global__ __launch_bounds__(NT) void k_unit1x1_bwd(ConvGeom g, const float* __r
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        p += 16;
+        yoff += ystep;
+        xoff += xstep;
     }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { vr[0][e] = vrv[0][e]; vr[1][e] = vrv[1][e]; vr[2][e] = vrv[2][e]; }
     (void)co_ok; (void)ci_ok;
     // per-workgroup partial dW / db, same layout as k_conv_wgrad_mfma<1,1>: [co*16 + ci] then 16 bias sums
 #pragma unroll
@@ -4421,7 +4428,9 @@ int unit1x1_bwd(const ConvGeom& g, const float* x, const float* y, const float* 
     if (next_parts) *next_parts = 0;
     const long n = (long)g.B * g.Tout * g.Fout;
     if (g.nkt != 1 || g.nkf != 1 || g.sf != 1 || g.pf != 0 || g.Cout != g.CoutT || g.cout_off != 0 || (g.Cout % 4) ||
-        (g.Cin % 4) || (g.CinT % 4) || (g.cin_off % 4) || (gbf && !(bf == 1 && ybf == 1)))
+        (g.Cin % 4) || (g.CinT % 4) || (g.cin_off % 4) || (gbf && !(bf == 1 && ybf == 1)) ||
+        act == ACT_TANH ||                    // (the pointwise units are PReLU or linear: the kernel's derivative is one select)
+        n * 16 >= (1L << 31))                 // (32-bit element offsets)
         return (int)hipErrorInvalidValue;
     const int slot = bwd_first_pass(have_parts, s, da, y, n, g.Cout, stats, gamma, beta, res, act, slope, dscratch, bf, ybf,
                                     dgamma, dbeta, dslope, gbf);
