@@ -122,7 +122,7 @@ struct gtcrn_trainer {
     double* dscratch = nullptr;   // BatchNorm partial sums
     double* fin_gpart = nullptr;  // in-launch finish of the BatchNorm reductions (fusion bit 10): group sums and
     unsigned* fin_ctr = nullptr;  // arrival counters (zero between launches), see train_kernels.h
-    int fusions = 16383;                // gtcrn_trainer_set_fusions: 1 normalise-on-load, 2 depthwise backward, 4 riding reductions,
+    int fusions = 32767;                // gtcrn_trainer_set_fusions: 1 normalise-on-load, 2 depthwise backward, 4 riding reductions,
                                       // 8 single-reader activations recomputed in the backward instead of stored,
                                       // 16 skip gradients accumulated in place (no add passes in the backward),
                                       // 32 reductions riding in the adjoint convs of the 3x3 units and of en_convs.1,
@@ -133,7 +133,8 @@ struct gtcrn_trainer {
                                       // kernel that produces its partial sums (no finish launches),
                                       // 2048 (not the exact chain) the decoder's sums x + skip written by the layer that produces x,
                                       // 4096 point_bn2 applied on load by TRALite / gate-shuffle (forward and backward),
-                                      // 8192 the pointwise forward convs in their dedicated kernel (k_pw_fwd)
+                                      // 8192 the pointwise forward convs in their dedicated kernel (k_pw_fwd),
+                                      // 16384 the TCN's dilated depthwise forward in its column form (k_dw31_col)
     const void* red_unit = nullptr;   // backward: the unit whose BatchNorm reduction already sits in dscratch ...
     int red_parts = 0;                // ... as this many per-workgroup partial sums (see unit_bwd)
     std::map<std::string, long> off;   // parameter name -> blob offset
@@ -934,7 +935,7 @@ int gtcrn_trainer_set_storage(gtcrn_trainer* t, int storage) {
 }
 
 int gtcrn_trainer_set_fusions(gtcrn_trainer* t, int mask) {
-    if (!t || mask < 0 || mask > 16383) return tfail(GTCRN_ERR_ARG, "gtcrn_trainer_set_fusions: mask must be 0..16383");
+    if (!t || mask < 0 || mask > 32767) return tfail(GTCRN_ERR_ARG, "gtcrn_trainer_set_fusions: mask must be 0..32767");
     if (t->fusions != mask) {
         t->fusions = mask;
         t->planned = false;      // the unit links are laid out again on the next forward
@@ -955,6 +956,7 @@ int gtcrn_train_forward(gtcrn_trainer* t, float* d_params, const float* d_spec, 
     // failed or interrupted call may have left in them
     gtt::set_fin_context((t->fusions & 1024) != 0, t->fin_gpart, t->fin_ctr);
     gtt::set_pointwise_form((t->fusions & 8192) != 0);
+    gtt::set_column_form((t->fusions & 16384) != 0);
     T_HIP(hipMemsetAsync(t->fin_ctr, 0, sizeof(unsigned) * gtt::FIN_CTR_WORDS, s));
     float* prm = d_params;
     const bool ex = t->exact != 0;
@@ -1029,6 +1031,7 @@ int gtcrn_train_backward(gtcrn_trainer* t, const float* d_params, const float* d
     T_HIP(hipMemsetAsync(G, 0, sizeof(float) * GTCRN_NPARAM_FLOATS, s));
     gtt::set_fin_context((t->fusions & 1024) != 0, t->fin_gpart, t->fin_ctr);
     gtt::set_pointwise_form((t->fusions & 8192) != 0);
+    gtt::set_column_form((t->fusions & 16384) != 0);
     T_HIP(hipMemsetAsync(t->fin_ctr, 0, sizeof(unsigned) * gtt::FIN_CTR_WORDS, s));
     t->red_unit = nullptr;
     const long n33 = (long)B * T * 33 * 16, n65 = (long)B * T * 65 * 16;

@@ -1598,6 +1598,94 @@ __global__ __launch_bounds__(NT) void k_dw16(DwGeom g, const float* __restrict__
     }
 }
 
+// ------------------------------------------- the TCN's dilated depthwise (3,1) conv behind a deferred unit, column form
+// k_dw16<3, 1, FIN, PRE> gives a thread one (position, channel quad): it loads the taps t - 2d, t - d, t and applies the
+// previous unit's BatchNorm + PReLU + rounding to ALL THREE -- every element of the input is normalised three times, by
+// three different threads -- with three 8-byte loads in flight per thread: 141 us on 272 MB of bf16 tensors (1.9 TB/s).
+// Here a thread owns a (b, f, channel quad) COLUMN and walks the frames of ONE residue class modulo the dilation,
+// t = r + j d: the two older taps of output j are the thread's own values j - 2 and j - 1, so every input element is
+// loaded and normalised once (a chunk of DC_J outputs re-reads the two values in front of it), and all DC_J + 2 loads of a
+// chunk are requested before the first is used.  Same expressions in the same order per output as k_dw16 (bias - shift
+// first, taps oldest first, a tap in front of the utterance skipped, statistics in double from the stored value): the
+// conv outputs are bit-identical; the BatchNorm partial sums are taken in another order (double sums, the statistics round
+// to the same floats: test_pass_fusions_... compares the masks bit for bit).
+template <int FIN> struct DcChunk { static constexpr int J = FIN ? 16 : 8; };   // (fp32 raws are twice the registers: 4 waves per SIMD either way)
+template <int FIN, int OUTF>
+__global__ __launch_bounds__(NT) void k_dw31_col(int B, int T, int F, int d, int w_c, int w_kt, const float* __restrict__ in,
+                                                const float* __restrict__ w, const float* __restrict__ bias,
+                                                float* __restrict__ out, double* __restrict__ stat_partial,
+                                                const float* __restrict__ shift, BnPre pre, FinArgs fa) {
+    constexpr int DC_J = DcChunk<FIN>::J;
+    __shared__ double sStat[NT / 64][32];
+    const int tid = threadIdx.x, q = tid & 3;
+    double s1[4] = {0.0, 0.0, 0.0, 0.0}, s2[4] = {0.0, 0.0, 0.0, 0.0};
+    const PreConst pk = pre_const(pre, q, 16);
+    f32x4 wt[3];
+#pragma unroll
+    for (int kt = 0; kt < 3; ++kt)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) wt[kt][e] = w[(4 * q + e) * w_c + kt * w_kt];
+    f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+    if (bias) bv = *reinterpret_cast<const f32x4*>(bias + 4 * q);
+    if (shift) bv -= *reinterpret_cast<const f32x4*>(shift + 4 * q);
+    const int F4 = F * 4, S = ((T + d - 1) / d + DC_J - 1) / DC_J;     // chunks of a residue class
+    const long items = (long)B * d * S * F4;
+    const unsigned rowstep = (unsigned)d * (unsigned)F * 16u;          // elements between consecutive frames of a chain
+    for (long item = (long)blockIdx.x * NT + tid; item < items; item += (long)gridDim.x * NT) {
+        const int fq = (int)(item % F4);
+        long rest = item / F4;
+        const int sc = (int)(rest % S);
+        rest /= S;
+        const int r = (int)(rest % d), b = (int)(rest / d);
+        const int j0 = sc * DC_J, t0 = r + j0 * d;
+        if (t0 >= T) continue;
+        // element offset of (b, t0, f, 4q); < 2^31 (the launcher checks)
+        const unsigned off0 = (unsigned)(((long)b * T + t0) * F * 16 + fq * 4);
+        typename Raw4<FIN>::t raw[DC_J + 2];
+#pragma unroll
+        for (int k = 0; k < DC_J + 2; ++k) {
+            const int t = t0 + (k - 2) * d;
+            const bool ok = t >= 0 && t < T;
+            raw[k] = sld4_raw<FIN>(in, (long)(ok ? off0 + (unsigned)(k - 2) * rowstep : off0));
+        }
+        f32x4 x2 = pre_apply(pk, dec4<FIN>(raw[0]), FIN), x1 = pre_apply(pk, dec4<FIN>(raw[1]), FIN);
+#pragma unroll
+        for (int k = 0; k < DC_J; ++k) {
+            const int t = t0 + k * d;
+            const f32x4 x0 = pre_apply(pk, dec4<FIN>(raw[k + 2]), FIN);
+            if (t < T) {
+                const unsigned off = off0 + (unsigned)k * rowstep;
+                if (pre.a_out) sst4<kNtSt>(pre.a_out, (long)off, FIN, x0);
+                f32x4 acc = bv;
+                const f32x4 n2 = acc + wt[0] * x2;
+                acc = t - 2 * d >= 0 ? n2 : acc;
+                const f32x4 n1 = acc + wt[1] * x1;
+                acc = t - d >= 0 ? n1 : acc;
+                acc = acc + wt[2] * x0;
+                acc = round_bf4(acc, OUTF);
+                sst4<kNtSt>(out, (long)off, OUTF, acc);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { const double a = (double)acc[e]; s1[e] += a; s2[e] = fma(a, a, s2[e]); }
+            }
+            x2 = x1;
+            x1 = x0;
+        }
+    }
+    // per-workgroup BatchNorm partial sums; a thread's channel quad is tid & 3 (as k_dw16)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { s1[e] = wave_sum_xor(s1[e], 4, 32); s2[e] = wave_sum_xor(s2[e], 4, 32); }
+    if ((tid & 63) < 4)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { sStat[tid >> 6][4 * q + e] = s1[e]; sStat[tid >> 6][16 + 4 * q + e] = s2[e]; }
+    __syncthreads();
+    if (tid < 32) {
+        double t = 0.0;
+        for (int w2 = 0; w2 < NT / 64; ++w2) t += sStat[w2][tid];
+        st_part(stat_partial + (long)blockIdx.x * 32 + tid, t, fa);
+    }
+    if (fa.kind) fin_reduce(stat_partial, 32, (int)blockIdx.x, gridDim.x, fa);
+}
+
 // ------------------------------------------------------------------------------ BatchNorm
 // nn.BatchNorm2d in train mode (ConvBlock :159, GTConvBlock :190/:218/:222, TCN :269/:282/:286):
 // biased batch variance for the normalisation, unbiased for the running estimate, momentum 0.1, eps 1e-5.
@@ -3823,6 +3911,9 @@ void set_fin_context(bool on, double* gpart, unsigned* ctr) { g_fin.on = on; g_f
 // fusion bit 13: the pointwise forward convs through k_pw_fwd instead of the general k_conv_mfma<1, 1> (thread local, like g_fin)
 static thread_local bool g_pw_form = true;
 void set_pointwise_form(bool on) { g_pw_form = on; }
+// fusion bit 14: the TCN's dilated depthwise forward in its column form (k_dw31_col)
+static thread_local bool g_col_form = true;
+void set_column_form(bool on) { g_col_form = on; }
 
 // ====================================================================================== launchers
 // grid of a streaming reduction: a stride that is a multiple of C (NT is), at most MAX_PARTIALS workgroups
@@ -4143,6 +4234,23 @@ int dw_fwd(const DwGeom& g, const float* in, const float* w, const float* bias, 
         else if (g.in_bf == 1) hipLaunchKernelGGL((k_dw16<KT, KF, 1>), dim3(g16), dim3(NT), 0, s, g, in, w, bias, out, sp, it, shift, nopre, nonx, fd); \
         else hipLaunchKernelGGL((k_dw16<KT, KF, -1>), dim3(g16), dim3(NT), 0, s, g, in, w, bias, out, sp, it, shift, nopre, nonx, fd); \
     } while (0)
+        // the column form (see k_dw31_col): the TCN's dilated (3,1) conv behind its deferred unit, fusion bit 14
+        const int dil = -g.t_off[1];
+        if (pre && g_col_form && sp && dil >= 1 && g.t_off[0] == -2 * dil && g.w_kf == 1 && !pre->exact && pre->bf == g.in_bf &&
+            g.out_bf <= 1 && !g.out2 && (long)g.B * g.Tout * g.F * 16 < (1L << 31)) {
+            const int cj = g.in_bf ? DcChunk<1>::J : DcChunk<0>::J;
+            const long items = (long)g.B * dil * (((g.Tout + dil - 1) / dil + cj - 1) / cj) * g.F * 4;
+            const int gc = grid_for(items, MAX_PARTIALS);
+#define GT_DC(FI, FO) hipLaunchKernelGGL((k_dw31_col<FI, FO>), dim3(gc), dim3(NT), 0, s, g.B, g.Tout, g.F, dil, g.w_c, g.w_kt, in, w, bias, \
+                                         out, sp, shift, *pre, fd)
+            if (g.in_bf == 0 && g.out_bf == 0) GT_DC(0, 0);
+            else if (g.in_bf == 1 && g.out_bf == 1) GT_DC(1, 1);
+            else if (g.in_bf == 0) GT_DC(0, 1);
+            else GT_DC(1, 0);
+#undef GT_DC
+            *stat_parts = fd.kind ? -gc : gc;
+            return check();
+        }
         if (pre) {
             if (g.in_bf == 0) hipLaunchKernelGGL((k_dw16<3, 1, 0, true>), dim3(g16), dim3(NT), 0, s, g, in, w, bias, out, sp, it, shift, *pre, nonx, fd);
             else hipLaunchKernelGGL((k_dw16<3, 1, 1, true>), dim3(g16), dim3(NT), 0, s, g, in, w, bias, out, sp, it, shift, *pre, nonx, fd);
