@@ -2410,6 +2410,142 @@ __global__ __launch_bounds__(NT) void k_dwunit31_bwd(DwGeom g, const float* __re
     }
 }
 
+// The same unit's backward in the COLUMN form of k_dw31_col (fusion bit 14): k_dwunit31_bwd gives a thread one position and
+// has it form dy at t, t + d, t + 2d and -- recomputing form -- the input activation at t - 2d, t - d, t: every dy and
+// every activation of the tensor is computed three times, from nine to ten loads per thread.  A thread that walks ONE
+// residue class of frames modulo the dilation computes each once and keeps three-deep windows: at step k it has dy_k
+// and x_k and emits, for the element two steps back, the weight-gradient products dy_m (x_m-2, x_m-1, x_m), the data
+// gradient dx_m = w0 dy_m+2 + w1 dy_m+1 + w2 dy_m (the adjoint taps in k_dw16's order) and the riding reduction of
+// the unit in front.  A chunk of J outputs re-reads two elements on either side; all 3 (J + 2) loads of a chunk are
+// requested before the first is used.  Same per-element expressions as k_dwunit31_bwd; sums in another order.
+template <int F, int GF> struct DcBwdChunk { static constexpr int J = (F && GF) ? 8 : 4; };
+template <int F, int GF, bool XR>      // F: storage format of x / y / the front unit's y; GF: of da / dx; XR: x recomputed
+__global__ __launch_bounds__(NT) void k_dwunit31_col(int B, int T, int Fb, int d, int w_c, int w_kt, const float* __restrict__ x,
+                                                    const float* __restrict__ y, const float* __restrict__ da, BnBwdArgs bn,
+                                                    const float* __restrict__ w, float* __restrict__ dx,
+                                                    double* __restrict__ wpartial, NextRedArgs nx,
+                                                    double* __restrict__ rpartial, FinArgs fa) {
+    constexpr int J = DcBwdChunk<F, GF>::J;
+    __shared__ double sh[NT];
+    const int tid = threadIdx.x, q = tid & 3;
+    const f32x4 mean = *reinterpret_cast<const f32x4*>(bn.stats + 4 * q), istd = *reinterpret_cast<const f32x4*>(bn.stats + 16 + 4 * q);
+    const f32x4 gm = *reinterpret_cast<const f32x4*>(bn.gamma + 4 * q), bt = *reinterpret_cast<const f32x4*>(bn.beta + 4 * q);
+    const f32x4 m1 = *reinterpret_cast<const f32x4*>(bn.red + 4 * q), m2 = *reinterpret_cast<const f32x4*>(bn.red + 16 + 4 * q);
+    const f32x4 gi = gm * istd;
+    const float sl = bn.slope[0];
+    f32x4 wk[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) wk[k][e] = w[(4 * q + e) * w_c + k * w_kt];
+    const f32x4 nmean = *reinterpret_cast<const f32x4*>(nx.stats + 4 * q), nistd = *reinterpret_cast<const f32x4*>(nx.stats + 16 + 4 * q);
+    const f32x4 ngm = *reinterpret_cast<const f32x4*>(nx.gamma + 4 * q), nbt = *reinterpret_cast<const f32x4*>(nx.beta + 4 * q);
+    const float nsl = nx.slope[0];
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+    f32x4 vwv[4] = {zero, zero, zero, zero}, vrv[3] = {zero, zero, zero};
+    const int F4 = Fb * 4, S = ((T + d - 1) / d + J - 1) / J;
+    const long items = (long)B * d * S * F4;
+    const unsigned rowstep = (unsigned)d * (unsigned)Fb * 16u;
+    for (long item = (long)blockIdx.x * NT + tid; item < items; item += (long)gridDim.x * NT) {
+        const int fq = (int)(item % F4);
+        long rest = item / F4;
+        const int sc = (int)(rest % S);
+        rest /= S;
+        const int r = (int)(rest % d), b = (int)(rest / d);
+        const int t0 = r + sc * J * d;
+        if (t0 >= T) continue;
+        const unsigned off0 = (unsigned)(((long)b * T + t0) * Fb * 16 + fq * 4);     // element (b, t0, f, 4q); < 2^31
+        // step k: forward element j0 + k (da, y: frame t0 + k d) and backward element j0 - 2 + k (the front unit's y,
+        // or x: frame t0 + (k - 2) d)
+        typename Raw4<GF>::t gr[J + 2];
+        typename Raw4<F>::t yr[J + 2], br[J + 2];
+#pragma unroll
+        for (int k = 0; k < J + 2; ++k) {
+            const int tf = t0 + k * d, tb = t0 + (k - 2) * d;
+            const unsigned of = tf < T ? off0 + (unsigned)k * rowstep : off0;
+            const unsigned ob = (tb >= 0 && tb < T) ? off0 + (unsigned)(k - 2) * rowstep : off0;
+            gr[k] = sld4_raw<GF, kNt>(da, (long)of);
+            yr[k] = sld4_raw<F>(y, (long)of);
+            br[k] = sld4_raw<F>(XR ? nx.y : x, (long)ob);
+        }
+        typename Raw4<F>::t nr[J];          // (!XR: the front unit's y of the chunk's own elements, for its reduction)
+        if constexpr (!XR) {
+#pragma unroll
+            for (int m = 0; m < J; ++m) nr[m] = sld4_raw<F>(nx.y, (long)(t0 + m * d < T ? off0 + (unsigned)m * rowstep : off0));
+        }
+        f32x4 dy2 = zero, dy1 = zero, xa2 = zero, xa1 = zero;      // windows: elements k - 2, k - 1
+#pragma unroll
+        for (int k = 0; k < J + 2; ++k) {
+            const int tf = t0 + k * d, tb = t0 + (k - 2) * d;
+            // dy of forward element k (zero past the utterance)
+            f32x4 dy0;
+            {
+                const f32x4 xh = (dec4<F>(yr[k]) - mean) * istd, z = gm * xh + bt;
+                const f32x4 gv = dec4<GF>(gr[k]), gs = sl * gv;
+                f32x4 dz;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) dz[e] = z[e] > 0.f ? gv[e] : gs[e];
+                dy0 = gi * (dz - m1 - xh * m2);
+                dy0 = tf < T ? dy0 : zero;
+            }
+            // the unit's input x of backward element k - 2 (zero outside the utterance), and the front unit's z / xhat there
+            f32x4 xa0, nz = zero, nxh = zero;
+            if constexpr (XR) {
+                nxh = (dec4<F>(br[k]) - nmean) * nistd;
+                nz = ngm * nxh + nbt;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) xa0[e] = nz[e] > 0.f ? nz[e] : nsl * nz[e];
+                if (nx.xround) xa0 = round_bf4(xa0, 1);
+            } else {
+                xa0 = dec4<F>(br[k]);
+            }
+            xa0 = (tb >= 0 && tb < T) ? xa0 : zero;
+            if (k >= 2) {
+                // output element m = k - 2 (frame tb): dy window (dy2, dy1, dy0) = elements m, m + 1, m + 2; x window
+                // (xa2, xa1, xa0) = elements m - 2, m - 1, m
+                vwv[0] += dy2 * xa2;
+                vwv[1] += dy2 * xa1;
+                vwv[2] += dy2 * xa0;
+                vwv[3] += dy2;
+                if (tb < T) {
+                    f32x4 acc = zero;
+                    acc = acc + wk[0] * dy0;
+                    acc = acc + wk[1] * dy1;
+                    acc = acc + wk[2] * dy2;
+                    acc = round_bf4(acc, GF);
+                    sst4<kNtSt>(dx, (long)(off0 + (unsigned)(k - 2) * rowstep), GF, acc);
+                    if constexpr (!XR) {
+                        nxh = (dec4<F>(nr[k - 2 < J ? k - 2 : 0]) - nmean) * nistd;
+                        nz = ngm * nxh + nbt;
+                    }
+                    const f32x4 as = nsl * acc, az = acc * nz;
+                    f32x4 dz2, ds2;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const bool pos = nz[e] > 0.f;
+                        dz2[e] = pos ? acc[e] : as[e];
+                        ds2[e] = pos ? 0.f : az[e];
+                    }
+                    vrv[0] += dz2;
+                    vrv[1] += dz2 * nxh;
+                    vrv[2] += ds2;
+                }
+            }
+            dy2 = dy1; dy1 = dy0;
+            xa2 = xa1; xa1 = xa0;
+        }
+    }
+    float vw[4][4], vr[3][4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        vw[0][e] = vwv[0][e]; vw[1][e] = vwv[1][e]; vw[2][e] = vwv[2][e]; vw[3][e] = vwv[3][e];
+        vr[0][e] = vrv[0][e]; vr[1][e] = vrv[1][e]; vr[2][e] = vrv[2][e];
+    }
+    block_reduce_store<4, 4>(vw, 16, sh, wpartial + (long)blockIdx.x * 64);
+    block_reduce_store<3, 4>(vr, 16, sh, rpartial + (long)blockIdx.x * 48, fa.kind != 0);
+    if (fa.kind) fin_reduce(rpartial, 48, (int)blockIdx.x, gridDim.x, fa);
+}
+
 // ---------------------------------------------- depth_conv FORWARD with point_conv1's BatchNorm + PReLU applied while staging
 // point_conv1 -> depth_conv could not use the normalise-on-load forms above: nine taps would each re-apply the BatchNorm +
 // PReLU (measured: slower than the separate k_bn_act pass).  With an LDS tile the activation is formed ONCE per element
@@ -4366,6 +4502,7 @@ int bn_act_bwd(const float* da, const float* y, long n, int C, const float* stat
     return check();
 }
 
+constexpr int DC_BWD_GRID = 512;  // workgroups of k_dwunit31_col (see the register counts in its launcher)
 constexpr int NEXT_GRID = 768;    // workgroups of k_unit1x1_bwd<.., NEXT>: 126-138 VGPRs = 3 per CU, all resident
 int dwunit_bwd(const DwGeom& g, const float* x, const float* y, const float* da, const float* stats,
                const float* gamma, const float* beta, const float* slope, const float* w, float* dx, float* dw,
@@ -4391,6 +4528,21 @@ int dwunit_bwd(const DwGeom& g, const float* x, const float* y, const float* da,
     if (!x && !xr) return (int)hipErrorInvalidValue;
     if (nxt) nx = NextRedArgs{next->y, next->stats, next->gamma, next->beta, next->slope, nullptr, next->recompute_x == 2};
     const FinArgs nfa = next_fin(nxt, next, dscratch, slot);
+    if (g_col_form && nxt && total < (1L << 31)) {       // the column form (see k_dwunit31_col), fusion bit 14
+        const int dil = -g.t_off[1];
+        const int cj = (bf && gbf) ? DcBwdChunk<1, 1>::J : DcBwdChunk<0, 0>::J;
+        const long items = (long)g.B * dil * (((g.Tout + dil - 1) / dil + cj - 1) / cj) * g.F * 4;
+        const int gc = (int)((items + NT - 1) / NT < DC_BWD_GRID ? (items + NT - 1) / NT : DC_BWD_GRID);
+#define GT_DCB(FX_, GF_, XR_) hipLaunchKernelGGL((k_dwunit31_col<FX_, GF_, XR_>), dim3(gc), dim3(NT), 0, s, g.B, g.Tout, g.F, dil, g.w_c, g.w_kt, \
+                                               x, y, da, bn, w, dx, wpart, nx, dscratch, nfa)
+        if (bf == 0) { if (xr) GT_DCB(0, 0, true); else GT_DCB(0, 0, false); }
+        else if (gbf) { if (xr) GT_DCB(1, 1, true); else GT_DCB(1, 1, false); }
+        else { if (xr) GT_DCB(1, 0, true); else GT_DCB(1, 0, false); }
+#undef GT_DCB
+        hipLaunchKernelGGL(k_dw_wgrad_finish2, dim3(1), dim3(1024), 0, s, g, wpart, gc, dw, dbias);
+        if (next_parts) *next_parts = next_parts_value(nfa, slot, gc);
+        return check();
+    }
 #define GT_DU(F, GF_)                                                                                                   \
     do {                                                                                                               \
         if (xr) hipLaunchKernelGGL((k_dwunit31_bwd<F, F, true, true, GF_>), dim3(grid), dim3(NT), 0, s, g, x, y, da, bn, w, dx, wpart, nx, dscratch, it, nfa); \

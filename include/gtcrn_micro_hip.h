@@ -276,7 +276,12 @@ long gtcrn_trainer_workspace_bytes(gtcrn_trainer *t, int B, int T);
  * the storage format before the add, as the stored x was, and the backward no longer recomputes the sums.  bit 12 (needs bit 0; not in storage
  * mode 4): point_bn2 -- the one BatchNorm with no activation behind it -- is applied on load by its four readers
  * (TRALite's energy, the gate/shuffle, their two backward passes): six normalise passes per step and the tensor they
- * wrote are gone, the values are the same bit for bit.  Default 8191.
+ * wrote are gone, the values are the same bit for bit.  bit 13: the 28 pointwise forward convs of a step run in a
+ * dedicated kernel (flat positions, compile-time formats, two tiles per iteration with the next two requested) instead of
+ * the general strided / padded conv kernel.  bit 14: the TCN's dilated depthwise (3,1) forward in a column form -- a
+ * thread walks one residue class of frames modulo the dilation, so every input is normalised once instead of three
+ * times and a chunk's loads are issued together.  Both are bit-identical to the kernels they replace (conv outputs;
+ * the BatchNorm statistics to the float).  Default 32767.
  * 0 runs the layer-at-a-time passes (tests/test_gpu_train.py compares them).  Takes effect at the next forward; not
  * part of the reference's interface. */
 int gtcrn_trainer_set_fusions(gtcrn_trainer *t, int mask);
