@@ -637,7 +637,11 @@ __device__ __forceinline__ f32x4 next_act(const NextConst& k, const f32x4 y, int
         const float z = k.gm[e] * ((y[e] - k.mean[e]) * k.istd[e]) + k.bt[e];
         a[e] = z > 0.f ? z : k.sl * z;
     }
-    return xround ? round_bf4(a, 1) : a;
+    // (a select per element, not a branch around the rounding: the branch cost k_dense33_bwd's fp32 form 30 registers)
+    const f32x4 r = round_bf4(a, 1);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) a[e] = xround ? r[e] : a[e];
+    return a;
 }
 __device__ __forceinline__ void next_accum(const NextConst& k, const f32x4 y, const f32x4 g, float (&vr)[3][4]) {
 #pragma unroll
@@ -2874,7 +2878,9 @@ constexpr int D9_LDS_FLOATS = 2 * D9_IMG + 9 * 256;
 static_assert(D9_LDS_FLOATS * 4 * 2 <= 160 * 1024, "two workgroups per CU");
 static_assert((NT / 64) * (9 * 256 + 64) <= 2 * D9_IMG, "the accumulator tiles reuse the images");
 template <int FX, int FY, bool NEXT, bool XR = false, int GF = 0>      // XR, GF: see k_dwunit33_bwd
-__global__ __launch_bounds__(NT) void k_dense33_bwd(ConvGeom g, const float* __restrict__ x, const float* __restrict__ y,
+// (two workgroups per CU by LDS: keep the register file at two waves per SIMD -- left alone the compiler gave the fp32
+// recomputing form 234 + 40 registers, one wave per SIMD, and the kernel took 770 us instead of 580)
+__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2))) void k_dense33_bwd(ConvGeom g, const float* __restrict__ x, const float* __restrict__ y,
                                                    const float* __restrict__ da, BnBwdArgs bn,
                                                    const float* __restrict__ w, float* __restrict__ dx,
                                                    float* __restrict__ wpartial, NextRedArgs nx,
