@@ -621,7 +621,7 @@ class Trainer:
         return int(_check(lib().gtcrn_trainer_workspace_bytes(self._h, int(B), int(T))))
 
     def set_fusions(self, mask):
-        """Diagnostic (gtcrn_trainer_set_fusions): 32767 = all pass fusions (default), 16383 = the TCN's dilated depthwise forward through the general kernel, 8191 = the pointwise forward convs through the general conv kernel too, 4095 = without point_bn2 on load, 2047 =
+        """Diagnostic (gtcrn_trainer_set_fusions): 65535 = all pass fusions (default), 32767 = the weight-gradient finishes launched one by one, 16383 = the TCN's dilated depthwise forward through the general kernel, 8191 = the pointwise forward convs through the general conv kernel too, 4095 = without point_bn2 on load, 2047 =
         also without the producer-written decoder sums, 1023 = also without the in-launch finish of the BatchNorm reductions (round 4's), 7 = round 3's (every activation stored, separate skip-gradient adds),
         0 = the layer-at-a-time passes."""
         _check(lib().gtcrn_trainer_set_fusions(self._h, int(mask)))

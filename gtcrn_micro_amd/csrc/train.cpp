@@ -38,6 +38,9 @@ int tfail(int code, const std::string& m) {
         hipError_t e_ = (expr);                                                                      \
         if (e_ != hipSuccess) return tfail(GTCRN_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_)); \
     } while (0)
+// pool of the deferred weight-gradient partials (fusion bit 15): 28 pointwise units x 1024 x 272 floats + the 3x3 / 1x5 /
+// depthwise units = 14.3 M floats at B = 512; a unit that does not fit finishes right away as before
+constexpr size_t WFIN_POOL_FLOATS = (size_t)16 << 20;
 #define T_RUN(expr)                                                                                  \
     do {                                                                                             \
         int e_ = (expr);                                                                             \
@@ -119,10 +122,11 @@ struct gtcrn_trainer {
     float* arena = nullptr;
     size_t arena_floats = 0;
     float* fscratch = nullptr;    // wgrad / TRA partial sums
+    float* wfin_pool = nullptr;   // fusion bit 15: every unit's weight-gradient partials until the batched finish (WFIN_POOL_FLOATS)
     double* dscratch = nullptr;   // BatchNorm partial sums
     double* fin_gpart = nullptr;  // in-launch finish of the BatchNorm reductions (fusion bit 10): group sums and
     unsigned* fin_ctr = nullptr;  // arrival counters (zero between launches), see train_kernels.h
-    int fusions = 32767;                // gtcrn_trainer_set_fusions: 1 normalise-on-load, 2 depthwise backward, 4 riding reductions,
+    int fusions = 65535;                // gtcrn_trainer_set_fusions: 1 normalise-on-load, 2 depthwise backward, 4 riding reductions,
                                       // 8 single-reader activations recomputed in the backward instead of stored,
                                       // 16 skip gradients accumulated in place (no add passes in the backward),
                                       // 32 reductions riding in the adjoint convs of the 3x3 units and of en_convs.1,
@@ -134,7 +138,8 @@ struct gtcrn_trainer {
                                       // 2048 (not the exact chain) the decoder's sums x + skip written by the layer that produces x,
                                       // 4096 point_bn2 applied on load by TRALite / gate-shuffle (forward and backward),
                                       // 8192 the pointwise forward convs in their dedicated kernel (k_pw_fwd),
-                                      // 16384 the TCN's dilated depthwise forward in its column form (k_dw31_col)
+                                      // 16384 the TCN's dilated depthwise unit (forward and backward) in the column form,
+                                      // 32768 the weight-gradient finishes of a backward pass recorded and run as a batch
     const void* red_unit = nullptr;   // backward: the unit whose BatchNorm reduction already sits in dscratch ...
     int red_parts = 0;                // ... as this many per-workgroup partial sums (see unit_bwd)
     std::map<std::string, long> off;   // parameter name -> blob offset
@@ -857,6 +862,7 @@ int gtcrn_trainer_create(gtcrn_trainer** out, int device) {
     for (const auto& p : gtcrn::param_table()) t->off[p.name] = p.offset;
     hipError_t e = hipMalloc(&t->fscratch, sizeof(float) * gtt::MAX_PARTIALS * (9 * 256 + 16));
     if (e == hipSuccess) e = hipMalloc(&t->dscratch, sizeof(double) * gtt::MAX_PARTIALS * 3 * 16 + 256);
+    if (e == hipSuccess) e = hipMalloc(&t->wfin_pool, sizeof(float) * WFIN_POOL_FLOATS);
     if (e == hipSuccess) e = hipMalloc(&t->fin_gpart, sizeof(double) * gtt::FIN_GPART_DOUBLES);
     if (e == hipSuccess) e = hipMalloc(&t->fin_ctr, sizeof(unsigned) * gtt::FIN_CTR_WORDS);
     if (e == hipSuccess) e = hipMemset(t->fin_ctr, 0, sizeof(unsigned) * gtt::FIN_CTR_WORDS);
@@ -873,6 +879,7 @@ void gtcrn_trainer_destroy(gtcrn_trainer* t) {
     (void)hipSetDevice(t->device);
     if (t->arena) (void)hipFree(t->arena);
     if (t->fscratch) (void)hipFree(t->fscratch);
+    if (t->wfin_pool) (void)hipFree(t->wfin_pool);
     if (t->dscratch) (void)hipFree(t->dscratch);
     if (t->fin_gpart) (void)hipFree(t->fin_gpart);
     if (t->fin_ctr) (void)hipFree(t->fin_ctr);
@@ -935,7 +942,7 @@ int gtcrn_trainer_set_storage(gtcrn_trainer* t, int storage) {
 }
 
 int gtcrn_trainer_set_fusions(gtcrn_trainer* t, int mask) {
-    if (!t || mask < 0 || mask > 32767) return tfail(GTCRN_ERR_ARG, "gtcrn_trainer_set_fusions: mask must be 0..32767");
+    if (!t || mask < 0 || mask > 65535) return tfail(GTCRN_ERR_ARG, "gtcrn_trainer_set_fusions: mask must be 0..65535");
     if (t->fusions != mask) {
         t->fusions = mask;
         t->planned = false;      // the unit links are laid out again on the next forward
@@ -1033,6 +1040,7 @@ int gtcrn_train_backward(gtcrn_trainer* t, const float* d_params, const float* d
     gtt::set_pointwise_form((t->fusions & 8192) != 0);
     gtt::set_column_form((t->fusions & 16384) != 0);
     T_HIP(hipMemsetAsync(t->fin_ctr, 0, sizeof(unsigned) * gtt::FIN_CTR_WORDS, s));
+    gtt::set_wgrad_defer((t->fusions & 32768) != 0, t->wfin_pool, WFIN_POOL_FLOATS);
     t->red_unit = nullptr;
     const long n33 = (long)B * T * 33 * 16, n65 = (long)B * T * 65 * 16;
     T_RUN(gtt::bs_mask_bwd(d_grad_out, gb, gf, gt, d_spec, sb, sf, st, B, T, prm + P(t, "erb.ierb_fc.weight"), t->dm, s));
@@ -1098,6 +1106,8 @@ int gtcrn_train_backward(gtcrn_trainer* t, const float* d_params, const float* d
         g.in_bf = t->bf; g.out_bf = 0;
         T_RUN(gtt::dw_wgrad(g, t->eb, t->df0, G + P(t, "sfe.depth_conv.weight"), nullptr, t->fscratch, s));
     }
+    T_RUN(gtt::flush_wgrad_finishes(s));      // (fusion bit 15: the recorded weight-gradient finishes, two launches)
+    gtt::set_wgrad_defer(false, nullptr, 0);
     return 0;
 }
 

@@ -75,6 +75,10 @@ constexpr int MAX_PARTIALS = 1024;   // workgroups of a two-stage reduction
 constexpr int FIN_GPART_DOUBLES = 32 * 64;
 constexpr int FIN_CTR_WORDS = 64;
 void set_fin_context(bool on, double* gpart, unsigned* ctr);      // thread local; on = false: finish kernels as before
+// fusion bit 15: the fused backward launchers record their weight-gradient finishes (partials in a region of `pool`) instead of
+// launching them; flush_wgrad_finishes runs them in batches (thread local; on = false or pool exhausted: as before)
+void set_wgrad_defer(bool on, float* pool, size_t cap_floats);
+int flush_wgrad_finishes(hipStream_t s);
 void set_column_form(bool on);        // thread local; fusion bit 14: dw_fwd sends the TCN's dilated (3,1) conv through k_dw31_col
 void set_pointwise_form(bool on);     // thread local; fusion bit 13: conv_fwd sends pure 1x1 convs through k_pw_fwd
 // what the statistics finish of a forward unit needs; given to conv_fwd / dw_fwd (sf), they run it in the producing

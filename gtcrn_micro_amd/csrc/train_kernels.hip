@@ -2022,6 +2022,58 @@ __global__ __launch_bounds__(1024) void k_dw_wgrad_finish2(DwGeom g, const doubl
         dw[c * g.w_c + kt * g.w_kt + kf * g.w_kf] = (float)s;
     }
 }
+
+// The weight-gradient finishes of a backward pass, BATCHED (fusion bit 15): the fused backward kernels leave per-workgroup
+// partial sums, and 44 one-to-five-workgroup launches of k_wgrad_mfma_finish / k_dw_wgrad_finish2 per step (6-7 us each,
+// ~0.3 ms, each behind a kernel boundary of the main stream) added them up.  With the bit on every unit's partials go to
+// a region of their own in a pool and the launcher only RECORDS the finish; gtcrn_train_backward runs them all in two
+// launches at its end.  Same sums in the same order (sum_strided over the workgroups, 16 slices): bit-identical gradients.
+struct WFin {
+    const void* partial;       // float [nparts][K] (type 0) or double [nparts][K] (type 1)
+    float* dw;
+    float* dbias;
+    int nparts, K, type;       // type 0: conv, K = ntap * 256 + 16; type 1: depthwise, K = (ntap + 1) * 16
+    int ntap, nkf, Cout, Cin;
+    int s0, s1, s2, s3;        // conv: w_co, w_ci, w_kt, w_kf; depthwise: w_c, w_kt, w_kf
+};
+constexpr int WFIN_BATCH = 24;
+struct WFinBatch {
+    int n;
+    WFin e[WFIN_BATCH];
+};
+__global__ __launch_bounds__(1024) void k_wgrad_finish_batch(WFinBatch b) {
+    __shared__ double sh[16][64];
+    const WFin& f = b.e[blockIdx.y];
+    const int K = f.K;
+    if ((int)blockIdx.x * 64 >= K) return;                         // (uniform: this entry has fewer columns)
+    const int j = threadIdx.x & 63, slice = threadIdx.x >> 6, k = blockIdx.x * 64 + j;
+    double s = 0.0;
+    if (k < K) {
+        if (f.type == 0) s = sum_strided(reinterpret_cast<const float*>(f.partial) + k, slice, f.nparts, 16, K);
+        else s = sum_strided(reinterpret_cast<const double*>(f.partial) + k, slice, f.nparts, 16, K);
+    }
+    sh[slice][j] = s;
+    __syncthreads();
+    if (slice != 0 || k >= K) return;
+    for (int q = 1; q < 16; ++q) s += sh[q][j];
+    if (f.type == 0) {
+        if (k >= f.ntap * 256) {
+            const int co = k - f.ntap * 256;
+            if (f.dbias && co < f.Cout) f.dbias[co] = (float)s;
+        } else {
+            const int tap = k >> 8, co = (k >> 4) & 15, ci = k & 15, kt = tap / f.nkf, kf = tap - kt * f.nkf;
+            if (co < f.Cout && ci < f.Cin) f.dw[co * f.s0 + ci * f.s1 + kt * f.s2 + kf * f.s3] = (float)s;
+        }
+    } else {
+        const int tap = k >> 4, c = k & 15;
+        if (tap == f.ntap) {
+            if (f.dbias) f.dbias[c] = (float)s;
+        } else {
+            const int kt = tap / f.nkf, kf = tap - kt * f.nkf;
+            f.dw[c * f.s0 + kt * f.s1 + kf * f.s2] = (float)s;
+        }
+    }
+}
 // SFE_Lite weight gradient (3 channels, (1,3) taps, no bias): one thread per position, all 3 channels
 __global__ __launch_bounds__(NT) void k_sfe_wgrad(const float* __restrict__ in, const float* __restrict__ dout, long rows,
                                                  int F, double* __restrict__ partial, int bf) {
@@ -3769,13 +3821,34 @@ __global__ __launch_bounds__(1024) void k_tra_pgrad(const float* __restrict__ dz
     const long r0 = (long)blockIdx.x * per, r1 = r0 + per < rows ? r0 + per : rows;
     float s = 0.f;
     if (tid < 104) {
-        for (long r = r0 + slice; r < r1; r += 8) {
-            if (tid < 24) {
-                const int c = tid / 3, k = tid % 3, t = (int)(r % Tt);
-                if (t - 2 + k >= 0) s = fmaf(dy[r * 8 + c], e[(r - 2 + k) * 8 + c], s);
-            } else if (tid < 32) s += dy[r * 8 + tid - 24];
-            else if (tid < 96) s = fmaf(dzg[r * 8 + ((tid - 32) >> 3)], y[r * 8 + ((tid - 32) & 7)], s);
-            else s += dzg[r * 8 + tid - 96];
+        // a thread's role is fixed: operand pointers and the frame offset of the second one once, then the rows FOUR at a
+        // time -- all eight loads requested before the first multiply-add (one row per trip was a chain of ~16 dependent
+        // load latencies per thread: 47 us for 17 MB of input); same order of additions as the row-by-row loop
+        const float* pa;
+        const float* pb = nullptr;
+        int back = 0;                       // rows the second operand lies behind (the conv1d taps), 0 otherwise
+        if (tid < 24) { const int c = tid / 3, k = tid % 3; pa = dy + c; pb = e + c; back = 2 - k; }
+        else if (tid < 32) pa = dy + (tid - 24);
+        else if (tid < 96) { pa = dzg + ((tid - 32) >> 3); pb = y + ((tid - 32) & 7); }
+        else pa = dzg + (tid - 96);
+        long r = r0 + slice;
+        for (; r + 24 < r1; r += 32) {
+            float a[4], b[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const long ru = r + 8 * u;
+                const bool ok = (int)(ru % Tt) - back >= 0;
+                a[u] = pa[ru * 8];
+                b[u] = pb ? (ok ? pb[(ru - back) * 8] : 0.f) : 1.f;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) s = pb ? fmaf(a[u], b[u], s) : s + a[u];
+        }
+        for (; r < r1; r += 8) {
+            const bool ok = (int)(r % Tt) - back >= 0;
+            const float a = pa[r * 8];
+            if (pb) { if (ok) s = fmaf(a, pb[(r - back) * 8], s); }
+            else s += a;
         }
         sh[slice][tid] = s;
     }
@@ -4053,6 +4126,46 @@ void set_fin_context(bool on, double* gpart, unsigned* ctr) { g_fin.on = on; g_f
 // fusion bit 13: the pointwise forward convs through k_pw_fwd instead of the general k_conv_mfma<1, 1> (thread local, like g_fin)
 static thread_local bool g_pw_form = true;
 void set_pointwise_form(bool on) { g_pw_form = on; }
+// fusion bit 15: the weight-gradient finishes of a backward pass recorded and run as a batch (see k_wgrad_finish_batch)
+struct WDefer {
+    bool on = false;
+    float* pool = nullptr;
+    size_t cap = 0, used = 0;         // floats
+    int n = 0;
+    WFin list[64];
+};
+static thread_local WDefer g_wdefer;
+void set_wgrad_defer(bool on, float* pool, size_t cap_floats) {
+    g_wdefer.on = on && pool; g_wdefer.pool = pool; g_wdefer.cap = cap_floats; g_wdefer.used = 0; g_wdefer.n = 0;
+}
+// a region of the pool for one unit's partial sums, or nullptr (deferral off, pool or list full: finish right away)
+static float* wdefer_take(size_t nfloats) {
+    nfloats = (nfloats + 63) & ~(size_t)63;
+    if (!g_wdefer.on || g_wdefer.n >= 64 || g_wdefer.used + nfloats > g_wdefer.cap) return nullptr;
+    float* p = g_wdefer.pool + g_wdefer.used;
+    g_wdefer.used += nfloats;
+    return p;
+}
+static void wdefer_conv(const ConvGeom& g, const float* partial, int nparts, float* dw, float* dbias) {
+    const int ntap = g.nkt * g.nkf;
+    g_wdefer.list[g_wdefer.n++] = WFin{partial, dw, dbias, nparts, ntap * 256 + 16, 0, ntap, g.nkf, g.Cout, g.Cin, g.w_co, g.w_ci, g.w_kt, g.w_kf};
+}
+static void wdefer_dw(const DwGeom& g, const double* partial, int nparts, float* dw, float* dbias) {
+    const int ntap = g.nkt * g.nkf;
+    g_wdefer.list[g_wdefer.n++] = WFin{partial, dw, dbias, nparts, (ntap + 1) * 16, 1, ntap, g.nkf, 16, 16, g.w_c, g.w_kt, g.w_kf, 0};
+}
+int flush_wgrad_finishes(hipStream_t s) {
+    for (int i0 = 0; i0 < g_wdefer.n; i0 += WFIN_BATCH) {
+        WFinBatch b{};
+        b.n = g_wdefer.n - i0 < WFIN_BATCH ? g_wdefer.n - i0 : WFIN_BATCH;
+        int kmax = 0;
+        for (int i = 0; i < b.n; ++i) { b.e[i] = g_wdefer.list[i0 + i]; kmax = b.e[i].K > kmax ? b.e[i].K : kmax; }
+        hipLaunchKernelGGL(k_wgrad_finish_batch, dim3((kmax + 63) / 64, b.n), dim3(1024), 0, s, b);
+    }
+    g_wdefer.n = 0;
+    g_wdefer.used = 0;
+    return check();
+}
 // fusion bit 14: the TCN's dilated depthwise forward in its column form (k_dw31_col)
 static thread_local bool g_col_form = true;
 void set_column_form(bool on) { g_col_form = on; }
@@ -4526,6 +4639,8 @@ int dwunit_bwd(const DwGeom& g, const float* x, const float* y, const float* da,
     // would run alone at a third of the occupancy)
     const int grid = red_grid(total / 4) > 768 ? 768 : red_grid(total / 4);
     const StrideIter it = stride_iter((long)grid * NT / 4, g.F, g.Tout);
+    float* const dpool = wdefer_take((size_t)MAX_PARTIALS * 64 * 2);     // (both forms' grids fit)
+    if (dpool) fscratch = dpool;
     double* wpart = reinterpret_cast<double*>(fscratch);      // [grid][64]
     BnBwdArgs bn{stats, gamma, beta, slope, red, ACT_PRELU};
     NextRedArgs nx{};
@@ -4545,7 +4660,8 @@ int dwunit_bwd(const DwGeom& g, const float* x, const float* y, const float* da,
         else if (gbf) { if (xr) GT_DCB(1, 1, true); else GT_DCB(1, 1, false); }
         else { if (xr) GT_DCB(1, 0, true); else GT_DCB(1, 0, false); }
 #undef GT_DCB
-        hipLaunchKernelGGL(k_dw_wgrad_finish2, dim3(1), dim3(1024), 0, s, g, wpart, gc, dw, dbias);
+        if (dpool) wdefer_dw(g, wpart, gc, dw, dbias);
+        else hipLaunchKernelGGL(k_dw_wgrad_finish2, dim3(1), dim3(1024), 0, s, g, wpart, gc, dw, dbias);
         if (next_parts) *next_parts = next_parts_value(nfa, slot, gc);
         return check();
     }
@@ -4559,7 +4675,8 @@ int dwunit_bwd(const DwGeom& g, const float* x, const float* y, const float* da,
     else if (gbf) GT_DU(1, 1);
     else GT_DU(1, 0);
 #undef GT_DU
-    hipLaunchKernelGGL(k_dw_wgrad_finish2, dim3(1), dim3(1024), 0, s, g, wpart, grid, dw, dbias);
+    if (dpool) wdefer_dw(g, wpart, grid, dw, dbias);
+    else hipLaunchKernelGGL(k_dw_wgrad_finish2, dim3(1), dim3(1024), 0, s, g, wpart, grid, dw, dbias);
     if (nxt && next_parts) *next_parts = next_parts_value(nfa, slot, grid);
     return check();
 }
@@ -4582,6 +4699,8 @@ int dwunit33_bwd(const DwGeom& g, const float* x, const float* y, const float* d
     const long ntiles = (long)g.B * tiles_t;
     // 64 KB of LDS: two workgroups per CU, 512 resident -- whole rounds of them
     const int grid = (int)(ntiles < 512 ? ntiles : 512);
+    float* const dpool = wdefer_take((size_t)grid * 160 * 2);
+    if (dpool) fscratch = dpool;
     double* wpart = reinterpret_cast<double*>(fscratch);      // [grid][160]
     BnBwdArgs bn{stats, gamma, beta, slope, red, ACT_PRELU};
     NextRedArgs nx{};
@@ -4600,7 +4719,8 @@ int dwunit33_bwd(const DwGeom& g, const float* x, const float* y, const float* d
     else if (gbf) GT_D33(1, 1);
     else GT_D33(1, 0);
 #undef GT_D33
-    hipLaunchKernelGGL(k_dw_wgrad_finish2, dim3((160 + 63) / 64), dim3(1024), 0, s, g, wpart, grid, dw, dbias);
+    if (dpool) wdefer_dw(g, wpart, grid, dw, dbias);
+    else hipLaunchKernelGGL(k_dw_wgrad_finish2, dim3((160 + 63) / 64), dim3(1024), 0, s, g, wpart, grid, dw, dbias);
     if (nxt && next_parts) *next_parts = next_parts_value(nfa, slot, grid);
     return check();
 }
@@ -4630,6 +4750,8 @@ int dense33_bwd(const ConvGeom& g, const float* x, const float* y, const float* 
     if (!x && !xr) return (int)hipErrorInvalidValue;
     if (nxt) nx = NextRedArgs{next->y, next->stats, next->gamma, next->beta, next->slope, nullptr, next->recompute_x == 2, ybf};
     const FinArgs nfa = next_fin(nxt, next, dscratch, slot);
+    float* const dpool = wdefer_take((size_t)grid * (9 * 256 + 16));
+    if (dpool) fscratch = dpool;
     // (the attribute belongs to the current device's copy of the kernel: set on every launch -- a host-side table lookup --
     // rather than remembered per process, which would miss a second device)
 #define GT_D9(F, NXV, XRV, GF_)                                                                                         \
@@ -4645,7 +4767,8 @@ int dense33_bwd(const ConvGeom& g, const float* x, const float* y, const float* 
     else { if (xr) GT_D9(1, true, true, 0); else if (nxt) GT_D9(1, true, false, 0); else GT_D9(1, false, false, 0); }
 #undef GT_D9
     const int K = 9 * 256 + 16;
-    hipLaunchKernelGGL(k_wgrad_mfma_finish, dim3((K + 63) / 64), dim3(1024), 0, s, g, fscratch, grid, dw, dbias);
+    if (dpool) wdefer_conv(g, fscratch, grid, dw, dbias);
+    else hipLaunchKernelGGL(k_wgrad_mfma_finish, dim3((K + 63) / 64), dim3(1024), 0, s, g, fscratch, grid, dw, dbias);
     if (nxt && next_parts) *next_parts = next_parts_value(nfa, slot, grid);
     return check();
 }
@@ -4673,6 +4796,8 @@ int conv15_bwd(const ConvGeom& g, const float* x, const float* y, const float* d
     const bool nxt = next && next->slope && !next->res;
     if (nxt) nx = NextRedArgs{next->y, next->stats, next->gamma, next->beta, next->slope, nullptr, 0, ybf};
     const FinArgs nfa = next_fin(nxt, next, dscratch, slot);
+    float* const dpool = wdefer_take((size_t)grid * (5 * 256 + 16));
+    if (dpool) fscratch = dpool;
 #define GT_C15(DW_, F, NXV, GF_)                                                                                        \
     hipLaunchKernelGGL((k_conv15_bwd<DW_, F, F, NXV, GF_>), dim3(grid), dim3(NT), 0, s, g, x, y, da, bn, w, dx, dx_acc, fscratch, nx, \
                        dscratch, tiles_t, nfa)
@@ -4681,7 +4806,8 @@ int conv15_bwd(const ConvGeom& g, const float* x, const float* y, const float* d
     else { if (bf == 0) GT_C15(false, 0, 0, 0); else if (gbf) GT_C15(false, 1, 0, 1); else GT_C15(false, 1, 0, 0); }
 #undef GT_C15
     const int K = 5 * 256 + 16;
-    hipLaunchKernelGGL(k_wgrad_mfma_finish, dim3((K + 63) / 64), dim3(1024), 0, s, g, fscratch, grid, dw, dbias);
+    if (dpool) wdefer_conv(g, fscratch, grid, dw, dbias);
+    else hipLaunchKernelGGL(k_wgrad_mfma_finish, dim3((K + 63) / 64), dim3(1024), 0, s, g, fscratch, grid, dw, dbias);
     if (nxt && next_parts) *next_parts = next_parts_value(nfa, slot, grid);
     return check();
 }
@@ -4717,6 +4843,8 @@ int unit1x1_bwd(const ConvGeom& g, const float* x, const float* y, const float* 
     if (!x && !xr) return (int)hipErrorInvalidValue;
     if (nxt) nx = NextRedArgs{next->y, next->stats, next->gamma, next->beta, next->slope, next->res, next->recompute_x == 2};
     const FinArgs nfa = next_fin(nxt, next, dscratch, slot);
+    float* const dpool = wdefer_take((size_t)grid * (256 + 16));      // (fusion bit 15: the finish is recorded, not launched)
+    if (dpool) fscratch = dpool;
 #define GT_U1(F, Y, GF_)                                                                                                \
     do {                                                                                                               \
         if (xr) hipLaunchKernelGGL((k_unit1x1_bwd<F, Y, true, true, GF_>), dim3(grid), dim3(NT), 0, s, g, x, y, da, res, bn, w, dx, dx_acc, \
@@ -4731,7 +4859,8 @@ int unit1x1_bwd(const ConvGeom& g, const float* x, const float* y, const float* 
     else return (int)hipErrorInvalidValue;
 #undef GT_U1
     if (nxt && next_parts) *next_parts = next_parts_value(nfa, slot, grid);
-    hipLaunchKernelGGL(k_wgrad_mfma_finish, dim3((256 + 16 + 63) / 64), dim3(1024), 0, s, g, fscratch, grid, dw, dbias);
+    if (dpool) wdefer_conv(g, fscratch, grid, dw, dbias);
+    else hipLaunchKernelGGL(k_wgrad_mfma_finish, dim3((256 + 16 + 63) / 64), dim3(1024), 0, s, g, fscratch, grid, dw, dbias);
     return check();
 }
 

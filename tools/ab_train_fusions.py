@@ -2,7 +2,7 @@
 """Same-box A/B of the train step's pass fusions: full steps (forward, HybridLoss, backward, clip, Adam) at B = 512 x 4 s
 for each fusion mask given, interleaved, a few rounds.
 
-    python tools/ab_train_fusions.py [--masks 7,15,31,63,127,255,511,1023,2047,4095,8191,16383,32767] [--storage f32] [--steps 6] [--rounds 3]
+    python tools/ab_train_fusions.py [--masks 7,15,31,63,127,255,511,1023,2047,4095,8191,16383,32767,65535] [--storage f32] [--steps 6] [--rounds 3]
 """
 import argparse
 import os
@@ -15,7 +15,7 @@ sys.path.insert(0, ROOT)
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--masks", default="7,15,31,63,127,255,511,1023,2047,4095,8191,16383,32767")
+    ap.add_argument("--masks", default="7,15,31,63,127,255,511,1023,2047,4095,8191,16383,32767,65535")
     ap.add_argument("--storage", default="f32")
     ap.add_argument("--batch", type=int, default=512)
     ap.add_argument("--steps", type=int, default=6)
