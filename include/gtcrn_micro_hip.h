@@ -281,7 +281,10 @@ long gtcrn_trainer_workspace_bytes(gtcrn_trainer *t, int B, int T);
  * the general strided / padded conv kernel.  bit 14: the TCN's dilated depthwise (3,1) forward in a column form -- a
  * thread walks one residue class of frames modulo the dilation, so every input is normalised once instead of three
  * times and a chunk's loads are issued together.  Both are bit-identical to the kernels they replace (conv outputs;
- * the BatchNorm statistics to the float).  Default 32767.
+ * the BatchNorm statistics to the float); bit 14 also runs that unit's fused backward in the column form (dy and the
+ * recomputed activation once per element; sums in another order).  bit 15: the weight-gradient finishes of a backward
+ * pass (44 small launches) are recorded and run as two batched launches at its end, partial sums in a pool (same sums,
+ * same order: bit-identical gradients).  Default 65535.
  * 0 runs the layer-at-a-time passes (tests/test_gpu_train.py compares them).  Takes effect at the next forward; not
  * part of the reference's interface. */
 int gtcrn_trainer_set_fusions(gtcrn_trainer *t, int mask);
