@@ -3434,6 +3434,123 @@ __global__ __launch_bounds__(NT) void k_bs_mask_bwd(const float* __restrict__ do
     }
 }
 
+// ---- the same three kernels for DENSE FRAME-MAJOR spectrograms ((B,T,257,2) contiguous: what k_stft writes and the train
+// step passes).  One thread per (b,t,j) cost a 64-bit division by the run-time T per item, strided 4-byte accesses with
+// 64-bit address arithmetic, and a long tail -- 65 of a frame's 129 items copy one bin, 64 walk a band of up to 12
+// (k_feat 288 us at 1.6 TB/s, k_bs_mask 340 us, k_bs_mask_bwd 456 us at 1.8 TB/s).  Here a workgroup stages FM_NF frames
+// in LDS with coalesced 8-byte loads and the band sums read LDS.  Per-element arithmetic and its order are unchanged.
+constexpr int FM_NF = 4;
+__global__ __launch_bounds__(NT) void k_feat_fm(const float* __restrict__ spec, long nframes, const float* __restrict__ erb_w,
+                                               float* __restrict__ eb, int bf, float* __restrict__ eb2, int eb2_bf) {
+    __shared__ int lo[64], hi[64];
+    __shared__ float2 sX[FM_NF][257];
+    nz_ranges(erb_w, 64, 192, 192, 1, lo, hi);
+    const long groups = (nframes + FM_NF - 1) / FM_NF;
+    for (long grp = blockIdx.x; grp < groups; grp += gridDim.x) {
+        const long bt0 = grp * FM_NF;
+        const int nf = (int)(nframes - bt0 < FM_NF ? nframes - bt0 : FM_NF);
+        const float2* src = reinterpret_cast<const float2*>(spec + bt0 * 514);
+        for (int i = threadIdx.x; i < nf * 257; i += NT) (&sX[0][0])[i] = src[i];
+        __syncthreads();
+        for (int i = threadIdx.x; i < nf * 129; i += NT) {
+            const int fr = i / 129, j = i - fr * 129;
+            const float2* x = sX[fr];
+            float m = 0.f, re = 0.f, im = 0.f;
+            if (j < 65) {
+                re = x[j].x; im = x[j].y;
+                m = sqrtf(re * re + im * im + 1e-12f);
+            } else {
+                const float* w = erb_w + (long)(j - 65) * 192;
+                const int l0 = lo[j - 65], h0 = hi[j - 65];
+                for (int k = l0; k < h0; ++k) {
+                    const float wi = w[k];
+                    const float r = x[65 + k].x, q = x[65 + k].y;
+                    m = fmaf(wi, sqrtf(r * r + q * q + 1e-12f), m);
+                    re = fmaf(wi, r, re);
+                    im = fmaf(wi, q, im);
+                }
+            }
+            const long p = bt0 * 129 + i;
+            sst1(eb, p * 3, bf, m); sst1(eb, p * 3 + 1, bf, re); sst1(eb, p * 3 + 2, bf, im);
+            if (eb2) { sst1(eb2, p * 3, eb2_bf, m); sst1(eb2, p * 3 + 1, eb2_bf, re); sst1(eb2, p * 3 + 2, eb2_bf, im); }
+        }
+        __syncthreads();
+    }
+}
+__global__ __launch_bounds__(NT) void k_bs_mask_fm(const float* __restrict__ m, const float* __restrict__ spec, long nframes,
+                                                  const float* __restrict__ ierb_w, float* __restrict__ out, int bf) {
+    __shared__ int lo[192], hi[192];
+    __shared__ float2 sM[FM_NF][129];
+    nz_ranges(ierb_w, 192, 64, 64, 1, lo, hi);
+    const long groups = (nframes + FM_NF - 1) / FM_NF;
+    for (long grp = blockIdx.x; grp < groups; grp += gridDim.x) {
+        const long bt0 = grp * FM_NF;
+        const int nf = (int)(nframes - bt0 < FM_NF ? nframes - bt0 : FM_NF);
+        for (int i = threadIdx.x; i < nf * 129; i += NT) {
+            const long e = (bt0 * 129 + i) * 2;
+            (&sM[0][0])[i] = make_float2(sld1(m, e, bf), sld1(m, e + 1, bf));
+        }
+        __syncthreads();
+        const float2* xs = reinterpret_cast<const float2*>(spec + bt0 * 514);
+        float2* os = reinterpret_cast<float2*>(out + bt0 * 514);
+        for (int i = threadIdx.x; i < nf * 257; i += NT) {
+            const int fr = i / 257, f = i - fr * 257;
+            float m0 = 0.f, m1 = 0.f;
+            if (f < 65) {
+                m0 = sM[fr][f].x; m1 = sM[fr][f].y;
+            } else {
+                const float* w = ierb_w + (long)(f - 65) * 64;
+                for (int j = lo[f - 65]; j < hi[f - 65]; ++j) {
+                    const float wj = w[j];
+                    if (wj != 0.f) {
+                        m0 = fmaf(wj, sM[fr][65 + j].x, m0);
+                        m1 = fmaf(wj, sM[fr][65 + j].y, m1);
+                    }
+                }
+            }
+            const float2 x = xs[i];
+            os[i] = make_float2(x.x * m0 - x.y * m1, x.y * m0 + x.x * m1);
+        }
+        __syncthreads();
+    }
+}
+__global__ __launch_bounds__(NT) void k_bs_mask_bwd_fm(const float* __restrict__ dout, const float* __restrict__ spec,
+                                                      long nframes, const float* __restrict__ ierb_w, float* __restrict__ dm) {
+    __shared__ int lo[64], hi[64];
+    __shared__ float2 sG[FM_NF][257];          // per bin: (dr re + di im, di re - dr im)
+    nz_ranges(ierb_w, 64, 192, 1, 64, lo, hi);        // columns of the (192, 64) matrix
+    const long groups = (nframes + FM_NF - 1) / FM_NF;
+    for (long grp = blockIdx.x; grp < groups; grp += gridDim.x) {
+        const long bt0 = grp * FM_NF;
+        const int nf = (int)(nframes - bt0 < FM_NF ? nframes - bt0 : FM_NF);
+        const float2* xs = reinterpret_cast<const float2*>(spec + bt0 * 514);
+        const float2* ds = reinterpret_cast<const float2*>(dout + bt0 * 514);
+        for (int i = threadIdx.x; i < nf * 257; i += NT) {
+            const float2 x = xs[i], d = ds[i];
+            const float re = x.x, im = x.y, dr = d.x, di = d.y;
+            (&sG[0][0])[i] = make_float2(dr * re + di * im, di * re - dr * im);
+        }
+        __syncthreads();
+        for (int i = threadIdx.x; i < nf * 129; i += NT) {
+            const int fr = i / 129, j = i - fr * 129;
+            float g0 = 0.f, g1 = 0.f;
+            if (j < 65) {
+                g0 = sG[fr][j].x; g1 = sG[fr][j].y;
+            } else {
+                for (int k = lo[j - 65]; k < hi[j - 65]; ++k) {
+                    const float wi = ierb_w[(long)k * 64 + (j - 65)];
+                    if (wi != 0.f) {
+                        g0 = fmaf(wi, sG[fr][65 + k].x, g0);
+                        g1 = fmaf(wi, sG[fr][65 + k].y, g1);
+                    }
+                }
+            }
+            reinterpret_cast<float2*>(dm)[bt0 * 129 + i] = make_float2(g0, g1);
+        }
+        __syncthreads();
+    }
+}
+
 // ---- the same three kernels for the layout the callers actually pass: (B,257,T,2) with the FRAME axis fastest
 // (torch.stft's, st < sf).  One thread per (b,t,f) with f fastest then reads / writes the 0.5 GB spectrograms 8 bytes
 // at a time with a stride of 2 T floats (k_bs_mask_bwd ran at 0.7 TB/s).  Here a workgroup takes a tile of TT frames of
@@ -4871,7 +4988,10 @@ int feat_fwd(const float* spec, long sb, long sf, long st, int B, int T, const f
     auto pair_ok = [](const float* p, long a, long b2, long c) {
         return ((a | b2 | c) & 1) == 0 && (reinterpret_cast<uintptr_t>(p) & 7) == 0;
     };
-    if ((st < 0 ? -st : st) < (sf < 0 ? -sf : sf) && pair_ok(spec, sb, sf, st))
+    if (sf == 2 && st == 514 && sb == (long)T * 514 && pair_ok(spec, sb, sf, st))      // dense frame-major: LDS-staged frames
+        hipLaunchKernelGGL(k_feat_fm, dim3(grid_for(((long)B * T + FM_NF - 1) / FM_NF * NT, 2048)), dim3(NT), 0, s, spec, (long)B * T,
+                           erb_w, eb, bf, eb2, eb2_bf);
+    else if ((st < 0 ? -st : st) < (sf < 0 ? -sf : sf) && pair_ok(spec, sb, sf, st))
         hipLaunchKernelGGL(k_feat_t, dim3(B * ((T + TT - 1) / TT)), dim3(NT), 0, s, spec, sb, sf, st, B, T, erb_w, eb, bf,
                            eb2, eb2_bf);
     else
@@ -4885,7 +5005,11 @@ int bs_mask_fwd(const float* m, const float* spec, long sb, long sf, long st, in
     auto pair_ok = [](const float* p, long a, long b2, long c) {
         return ((a | b2 | c) & 1) == 0 && (reinterpret_cast<uintptr_t>(p) & 7) == 0;
     };
-    if (ab(st) < ab(sf) && ab(ot) < ab(of) && pair_ok(spec, sb, sf, st) && pair_ok(out, ob, of, ot))
+    if (sf == 2 && st == 514 && sb == (long)T * 514 && of == 2 && ot == 514 && ob == (long)T * 514 && pair_ok(spec, sb, sf, st) &&
+        pair_ok(out, ob, of, ot))
+        hipLaunchKernelGGL(k_bs_mask_fm, dim3(grid_for(((long)B * T + FM_NF - 1) / FM_NF * NT, 2048)), dim3(NT), 0, s, m, spec,
+                           (long)B * T, ierb_w, out, bf);
+    else if (ab(st) < ab(sf) && ab(ot) < ab(of) && pair_ok(spec, sb, sf, st) && pair_ok(out, ob, of, ot))
         hipLaunchKernelGGL(k_bs_mask_t, dim3(B * ((T + TT - 1) / TT)), dim3(NT), 0, s, m, spec, sb, sf, st, B, T, ierb_w,
                            out, ob, of, ot, bf);
     else
@@ -4899,7 +5023,11 @@ int bs_mask_bwd(const float* dout, long ob, long of, long ot, const float* spec,
     auto pair_ok = [](const float* p, long a, long b2, long c) {
         return ((a | b2 | c) & 1) == 0 && (reinterpret_cast<uintptr_t>(p) & 7) == 0;
     };
-    if (ab(st) < ab(sf) && ab(ot) < ab(of) && pair_ok(spec, sb, sf, st) && pair_ok(dout, ob, of, ot))
+    if (sf == 2 && st == 514 && sb == (long)T * 514 && of == 2 && ot == 514 && ob == (long)T * 514 && pair_ok(spec, sb, sf, st) &&
+        pair_ok(dout, ob, of, ot))
+        hipLaunchKernelGGL(k_bs_mask_bwd_fm, dim3(grid_for(((long)B * T + FM_NF - 1) / FM_NF * NT, 2048)), dim3(NT), 0, s, dout, spec,
+                           (long)B * T, ierb_w, dm);
+    else if (ab(st) < ab(sf) && ab(ot) < ab(of) && pair_ok(spec, sb, sf, st) && pair_ok(dout, ob, of, ot))
         hipLaunchKernelGGL(k_bs_mask_bwd_t, dim3(B * ((T + TT - 1) / TT)), dim3(NT), 0, s, dout, ob, of, ot, spec, sb, sf,
                            st, B, T, ierb_w, dm);
     else
