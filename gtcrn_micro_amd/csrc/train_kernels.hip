@@ -339,10 +339,14 @@ __global__ __launch_bounds__(NT) void k_conv(ConvGeom g, const float* __restrict
     }
     __syncthreads();
     const long npos = (long)g.B * g.Tout * g.Fout;
+    // (positions fit in 31 bits -- the launcher checks: 32-bit divisions; the 64-bit ones by the run-time Fout / Tout were a
+    // third of this kernel's instructions)
+    const unsigned uF = (unsigned)g.Fout, uT = (unsigned)g.Tout;
     for (long p = (long)blockIdx.x * NT + tid; p < npos; p += (long)gridDim.x * NT) {
-        const int fo = (int)(p % g.Fout);
-        const long bt = p / g.Fout;
-        const int to = (int)(bt % g.Tout), b = (int)(bt / g.Tout);
+        const unsigned pu = (unsigned)p, ubt = pu / uF, ub = ubt / uT;
+        const int fo = (int)(pu - ubt * uF);
+        const long bt = ubt;
+        const int to = (int)(ubt - ub * uT), b = (int)ub;
         float acc[COUT];
 #pragma unroll
         for (int co = 0; co < COUT; ++co) acc[co] = (bias ? bias[co] : 0.f) - (shift ? shift[co] : 0.f);
@@ -3996,14 +4000,15 @@ __global__ __launch_bounds__(NT) void k_hloss_spec(const float* __restrict__ pre
     double sri = 0.0, smag = 0.0;
     for (long i = (long)blockIdx.x * NT + threadIdx.x; i < N; i += (long)gridDim.x * NT) {
         int t, f, b;
+        const unsigned iu = (unsigned)i;                 // (N < 2^31: the launcher checks)
         if constexpr (FMAJ) {
-            f = (int)(i % 257);
-            const long bt = i / 257;
-            t = (int)(bt % T); b = (int)(bt / T);
+            const unsigned bt = iu / 257u, ub = bt / (unsigned)T;
+            f = (int)(iu - bt * 257u);
+            t = (int)(bt - ub * (unsigned)T); b = (int)ub;
         } else {
-            t = (int)(i % T);
-            const long bf = i / T;
-            f = (int)(bf % 257); b = (int)(bf / 257);
+            const unsigned bf = iu / (unsigned)T, ub = bf / 257u;
+            t = (int)(iu - bf * (unsigned)T);
+            f = (int)(bf - ub * 257u); b = (int)ub;
         }
         const float2 p = *reinterpret_cast<const float2*>(pred + (long)b * pb + (long)f * pf + (long)t * pt);
         const float2 q = *reinterpret_cast<const float2*>(tru + (long)b * tb + (long)f * tf + (long)t * tt);
@@ -4487,6 +4492,7 @@ int conv_fwd(const ConvGeom& g, const float* in, const float* w, const float* bi
         return check();
     }
     const int grid = grid_for((long)g.B * g.Tout * g.Fout);
+    if ((long)g.B * g.Tout * g.Fout >= (1L << 31)) return (int)hipErrorInvalidValue;      // (k_conv divides in 32 bits)
 #define GT_CONV_CASE(CI, CO)                                                                      \
     if (g.Cin == CI && g.Cout == CO) {                                                            \
         hipLaunchKernelGGL((k_conv<CI, CO>), dim3(grid), dim3(NT), 0, s, g, in, w, bias, out, shift); \
@@ -5077,6 +5083,7 @@ int tra_gate_shuffle_bwd(const float* dout, const float* v, const float* g, cons
 int hybrid_loss_spec(const float* pred, long pb, long pf, long pt, const float* tru, long tb, long tf, long tt, int B,
                      int T, float* grad, long gb, long gf, long gt, double* partial, int* parts, hipStream_t s) {
     const int grid = red_grid((long)B * 257 * T);
+    if ((long)B * 257 * T >= (1L << 31)) return (int)hipErrorInvalidValue;       // (k_hloss_spec divides in 32 bits)
     if ((pt < 0 ? -pt : pt) > (pf < 0 ? -pf : pf))
         hipLaunchKernelGGL(k_hloss_spec<true>, dim3(grid), dim3(NT), 0, s, pred, pb, pf, pt, tru, tb, tf, tt, B, T, grad, gb, gf, gt,
                            partial);
