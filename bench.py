@@ -496,6 +496,13 @@ def io_leg(eng, wave, win, out, world, sync_all, max_over_ranks, steps=20):
     ev_cmp = [torch.cuda.Event() for _ in range(2)]
     ev_out = [torch.cuda.Event() for _ in range(2)]
 
+    # copy-out on a DMA engine (tensor.copy_) -- the served pipeline -- or, for comparison, by a kernel (gtcrn_link_copy: 32
+    # workgroups write the pinned buffer over the link).  On an otherwise idle GPU, DMA in + kernel out holds 43-45 GB/s each
+    # way where two DMA copies run at 28-48 from run to run (tools/link_copy_probe.py); inside the pipeline the copy kernel
+    # has to share the CUs with model kernels that fill the register file (3 x 168 VGPRs per SIMD), and loses
+    from gtcrn_micro_amd import link_copy
+    use_kernel_out = [False]
+
     def served(n):
         for i in range(n):
             k = i & 1
@@ -510,24 +517,37 @@ def io_leg(eng, wave, win, out, world, sync_all, max_over_ranks, steps=20):
                 ev_cmp[k].record()
             with torch.cuda.stream(s_out):
                 s_out.wait_event(ev_cmp[k])
-                hout[k].copy_(dout[k], non_blocking=True)
+                if use_kernel_out[0]:
+                    link_copy(hout[k], dout[k], workgroups=32, stream=s_out)
+                else:
+                    hout[k].copy_(dout[k], non_blocking=True)
                 ev_out[k].record()
-    served(4)
-    sync_all()
-    t0 = time.perf_counter()
-    served(steps)
-    sync_all()
-    cold_el = time.perf_counter() - t0                # the first region after the pipeline starts (transient)
-    served(3 * steps)
-    regions = []
-    for _ in range(3):
+
+    def steady():
+        served(4)
         sync_all()
         t0 = time.perf_counter()
         served(steps)
         sync_all()
-        regions.append(time.perf_counter() - t0)
-    el = max_over_ranks(sorted(regions)[1], "cuda")   # steady state: the median of three regions of `steps` steps
+        cold = time.perf_counter() - t0               # the first region after the pipeline starts (transient)
+        served(3 * steps)
+        regions = []
+        for _ in range(3):
+            sync_all()
+            t0 = time.perf_counter()
+            served(steps)
+            sync_all()
+            regions.append(time.perf_counter() - t0)
+        # steady state: the median of three regions of `steps` steps
+        return cold, max_over_ranks(sorted(regions)[1], "cuda")
+    cold_el, el = steady()
     same = bool(torch.equal(hout[(steps - 1) & 1], out.cpu()))     # the served output is the resident path's, bit for bit
+    use_kernel_out[0] = True
+    for h in hout:
+        h.zero_()
+    _, el_kern = steady()
+    same = same and bool(torch.equal(hout[(steps - 1) & 1], out.cpu()))
+    use_kernel_out[0] = False
     T = 1 + L // 256
     res = {
         "workload": f"the headline batch handed over as HOST buffers: {nbytes / 1e6:.1f} MB in + "
@@ -538,7 +558,9 @@ def io_leg(eng, wave, win, out, world, sync_all, max_over_ranks, steps=20):
         "pinned": True,
         "served_frames_per_s": round(world * B * T * steps / el, 1),
         "served_ms_per_step": round(el / steps * 1e3, 4),
-        "served_pipeline": "3 HIP streams, 2 pinned staging slots: copy-in || 6 kernels || copy-out",
+        "served_pipeline": "3 HIP streams, 2 pinned staging slots: copy-in || 6 kernels || copy-out (both copies on DMA engines)",
+        "served_kernel_copy_out_frames_per_s": round(world * B * T * steps / el_kern, 1),
+        "served_kernel_copy_out_ms_per_step": round(el_kern / steps * 1e3, 4),
         "served_equals_resident": same,
         "serial_pageable_frames_per_s": round(B * T / serial_s, 1),
         "serial_pageable_ms_per_step": round(serial_s * 1e3, 3),
@@ -548,7 +570,8 @@ def io_leg(eng, wave, win, out, world, sync_all, max_over_ranks, steps=20):
                 "link (link_bound_frames_per_s = the slowest of h2d, d2h and the per-direction rate with both "
                 "directions busy / bytes per clip x frames per clip), not by the kernels; the first few dozen steps of a "
                 "pipeline run at about half the duplex rate (the *_first_* fields)",
-        "_rate_keys": ["served_frames_per_s"], "_time_keys": ["served_ms_per_step"],
+        "_rate_keys": ["served_frames_per_s", "served_kernel_copy_out_frames_per_s"],
+        "_time_keys": ["served_ms_per_step", "served_kernel_copy_out_ms_per_step"],
     }
     del hin, hout, din, dout
     torch.cuda.empty_cache()

@@ -87,6 +87,7 @@ def lib():
     L.gtcrn_debug_stamps.restype = cl
     L.gtcrn_debug_stamps.argtypes = [_vp, ci, ctypes.POINTER(ctypes.c_ulonglong), cl]
     L.gtcrn_selftest_mfma.argtypes = [ci]
+    L.gtcrn_link_copy.argtypes = [ci, _vp, _vp, cl, ci, _vp]
     L.gtcrn_selftest_split3.argtypes = [ci, _c_f32p, cl, _c_f32p, _c_f32p, _c_f32p, _c_f32p, _c_f32p]
     L.gtcrn_timing_enable.argtypes = [_vp, ci]
     L.gtcrn_timing_read.argtypes = [_vp, ci, ctypes.c_char_p, ci, _c_f32p, ctypes.POINTER(ci)]
@@ -551,6 +552,27 @@ class Engine:
             if n.value:
                 out[buf.value.decode()] = (float(ms.value), int(n.value))
         return out
+
+
+def link_copy(dst, src, workgroups=64, stream=None):
+    """dst.copy_(src) over the host link by a kernel (gtcrn_link_copy) instead of the DMA engines: one side a CUDA tensor,
+    the other a PINNED host tensor (or both device tensors); contiguous, same byte size, a multiple of 16 bytes.  Runs on
+    the current (or given) stream of the device tensor's device; asynchronous like copy_(non_blocking=True)."""
+    import torch
+    if not (dst.is_contiguous() and src.is_contiguous()):
+        raise GtcrnError("link_copy: contiguous tensors only")
+    nbytes = src.numel() * src.element_size()
+    if nbytes != dst.numel() * dst.element_size():
+        raise GtcrnError("link_copy: sizes differ")
+    for t in (dst, src):
+        if not t.is_cuda and not t.is_pinned():
+            raise GtcrnError("link_copy: a host tensor must be pinned (its address is then valid on the device)")
+    devs = [t.device.index for t in (dst, src) if t.is_cuda]
+    if not devs:
+        raise GtcrnError("link_copy: one side must be a device tensor")
+    _check(lib().gtcrn_link_copy(int(devs[0]), ctypes.c_void_p(dst.data_ptr()), ctypes.c_void_p(src.data_ptr()), int(nbytes),
+                                 int(workgroups), _stream_ptr(stream)))
+    return dst
 
 
 def selftest_mfma(device=0):

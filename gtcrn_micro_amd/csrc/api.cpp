@@ -125,9 +125,9 @@ int ensure_workspace(gtcrn_model* m, int B, int T, hipStream_t s) {
         HIP_TRY(hipMalloc(&m->d_dbg, sizeof(float) * bt * (3 * 528 + 65 * 16 + 2 * 129)));
         m->dbg_cap_bt = bt;
     }
-    if (m->debug && B > m->stamps_cap_b) {
+    if (m->debug && B + 2048 > m->stamps_cap_b) {
         // one row per WORKGROUP: launches in time spans run up to 2048 of them whatever the batch
-        const int rows = B > 2048 ? B : 2048;
+        const int rows = B + 2048;        // (a split plan: nA <= B one-per-utterance rows, then up to 2048 share rows behind them)
         if (m->d_stamps) (void)hipFree(m->d_stamps);
         m->d_stamps = nullptr;
         HIP_TRY(hipMalloc(&m->d_stamps, sizeof(unsigned long long) * 4 * rows * 16));
@@ -721,6 +721,16 @@ struct DeviceScope {
     ~DeviceScope() { if (prev >= 0) (void)hipSetDevice(prev); }
 };
 }  // namespace
+
+int gtcrn_link_copy(int device, void* dst, const void* src, long bytes, int workgroups, void* stream) {
+    if (!dst || !src) return fail(GTCRN_ERR_ARG, "gtcrn_link_copy: null pointer");
+    if (bytes <= 0 || (bytes & 15) || ((reinterpret_cast<uintptr_t>(dst) | reinterpret_cast<uintptr_t>(src)) & 15) ||
+        workgroups < 1 || workgroups > 4096)
+        return fail(GTCRN_ERR_ARG, "gtcrn_link_copy: 16-byte aligned pointers, a multiple of 16 bytes, 1..4096 workgroups");
+    HIP_TRY(hipSetDevice(device));
+    LAUNCH_TRY(gtk::launch_link_copy(dst, src, bytes, workgroups, static_cast<hipStream_t>(stream)));
+    return 0;
+}
 
 int gtcrn_selftest_mfma(int device) {
     int ndev = 0;

@@ -3881,6 +3881,33 @@ int launch_len_prefix(const int* lens, int B, int T, int* pref, hipStream_t s) {
     return 0;
 }
 
+// A copy over the host link done by the COMPUTE units instead of the DMA engines: `src` / `dst` may be pinned host memory
+// (hipHostMalloc / torch pin_memory: the same virtual address is valid on the device).  The served pipeline moves 65.5 MB
+// each way per step; with both directions on the DMA engines each runs at about half its solo rate on this platform
+// (bench.py io.duplex_each_GBps), so one direction is given to a few workgroups here (posted writes over PCIe for the
+// device-to-host direction; four 16-byte loads in flight per lane for host-to-device).
+__global__ __launch_bounds__(256) void k_link_copy(const f32x4* __restrict__ src, f32x4* __restrict__ dst, long n16) {
+    const long stride = (long)gridDim.x * 256;
+    long i = (long)blockIdx.x * 256 + threadIdx.x;
+    for (; i + 3 * stride < n16; i += 4 * stride) {
+        const f32x4 a = __builtin_nontemporal_load(src + i), b = __builtin_nontemporal_load(src + i + stride);
+        const f32x4 c = __builtin_nontemporal_load(src + i + 2 * stride), d = __builtin_nontemporal_load(src + i + 3 * stride);
+        __builtin_nontemporal_store(a, dst + i);
+        __builtin_nontemporal_store(b, dst + i + stride);
+        __builtin_nontemporal_store(c, dst + i + 2 * stride);
+        __builtin_nontemporal_store(d, dst + i + 3 * stride);
+    }
+    for (; i < n16; i += stride) __builtin_nontemporal_store(__builtin_nontemporal_load(src + i), dst + i);
+}
+int launch_link_copy(void* dst, const void* src, long bytes, int workgroups, hipStream_t s) {
+    if (bytes <= 0 || (bytes & 15) || ((reinterpret_cast<uintptr_t>(dst) | reinterpret_cast<uintptr_t>(src)) & 15) || workgroups < 1)
+        return (int)hipErrorInvalidValue;
+    hipLaunchKernelGGL(k_link_copy, dim3(workgroups), dim3(256), 0, s, reinterpret_cast<const f32x4*>(src),
+                       reinterpret_cast<f32x4*>(dst), bytes / 16);
+    GT_LAUNCH_CHECK();
+    return 0;
+}
+
 int launch_stft(const float* wave, int B, long L, int T, const int* lens, const float* win, const float* twid,
                 float* spec, long sb, long sf, long st, float* frames, hipStream_t s) {
     const long nframes = (long)B * T;
@@ -4053,7 +4080,7 @@ int launch_encoder(const float* spec, long sb, long sf, long st, int B, int T, c
         const long o = (long)pl.nA * T * 528;
         hipLaunchKernelGGL((k_encoder<TPW, false, false, false, true>), dim3(pl.nwgB), dim3(NTHR), ENC_GT_LDS_FLOATS * 4, s,
                            spec, sb, sf, st, T, lens, B - pl.nA, 0.f, PF, PI, en0, en1 + o, en2 + o, en3 + o, en4 + o, state,
-                           stamps);
+                           stamps ? stamps + (long)pl.nA * 16 : nullptr);     // (its stamp rows behind the first launch's)
     } else if (front_done) {
         if (T <= SHORT_T) GT_ENC(1, false, false);
         else if (T <= SHORT_T2) GT_ENC(2, false, false);
@@ -4174,11 +4201,11 @@ int launch_decoder(const float* xg, const float* en0, const float* en1, const fl
         if (dbg)
             hipLaunchKernelGGL((k_decoder<true, TPW, false, false, true>), dim3(pl.nwgB), dim3(NTHR), DEC_LDS_FLOATS * 4, s,
                                xg + o, en0 + o0, en1 + o, en2 + o, en3 + o, en4 + o, specB, sb, sf, st, outB, osb, osf, ost, T,
-                               lens, B - pl.nA, 0.f, 0.f, PF, PI, state, dbg, stamps);
+                               lens, B - pl.nA, 0.f, 0.f, PF, PI, state, dbg, stamps ? stamps + (long)pl.nA * 16 : nullptr);
         else
             hipLaunchKernelGGL((k_decoder<false, TPW, false, false, true>), dim3(pl.nwgB), dim3(NTHR), DEC_LDS_FLOATS * 4, s,
                                xg + o, en0 + o0, en1 + o, en2 + o, en3 + o, en4 + o, specB, sb, sf, st, outB, osb, osf, ost, T,
-                               lens, B - pl.nA, 0.f, 0.f, PF, PI, state, dbg, stamps);
+                               lens, B - pl.nA, 0.f, 0.f, PF, PI, state, dbg, stamps ? stamps + (long)pl.nA * 16 : nullptr);
     } else if (T <= SHORT_T) {
         if (dbg) GT_DEC(true, 1); else GT_DEC(false, 1);
     } else if (T <= SHORT_T2) {

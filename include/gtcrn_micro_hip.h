@@ -198,6 +198,12 @@ long gtcrn_debug_tap(gtcrn_model *m, const char *name, int b, float *h_dst, long
 long gtcrn_debug_stamps(gtcrn_model *m, int kernel, unsigned long long *h_dst, long cap);
 /* Checks the MFMA f32 16x16x4 lane maps the kernels rely on (exact integer
  * data, asymmetric operands).  0 = as assumed. */
+/* A copy over the host link by a kernel instead of the DMA engines (no reference counterpart: the reference's callers use
+ * tensor.to(device) / .cpu(), infer.py:60-76, train.py:246,255).  dst / src: device memory or PINNED host memory (its
+ * address is valid on the device), 16-byte aligned, bytes a multiple of 16; `workgroups` x 256 threads do the copy on
+ * `stream`.  Used by the served pipeline (bench.py io, gtcrn_micro_amd/infer.py) for ONE of the two directions: with both
+ * on the DMA engines each direction runs at about half its solo rate on this platform. */
+int gtcrn_link_copy(int device, void *dst, const void *src, long bytes, int workgroups, void *stream);
 int gtcrn_selftest_mfma(int device);
 /* The exact three-way bf16 split the dense 3x3 runs on (kernels.hip split3 / join3 / split_mm6), on caller-chosen
  * values: h_x[n] (n a multiple of 4) -> h_planes[3][n] (hi, mid, lo as floats) and h_joined[n] (= h_x bit for bit

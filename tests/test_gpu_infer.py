@@ -234,3 +234,28 @@ def test_pipelined_folder_driver_writes_the_serial_drivers_bytes(tmp_path):
         I.read_wav_f32 = real
     import threading
     assert not [t for t in threading.enumerate() if t.name.startswith("gtcrn-folder-")]
+
+
+@pytest.mark.gpu
+def test_link_copy_kernel_moves_pinned_host_buffers_both_ways():
+    """gtcrn_link_copy: a copy over the host link by a kernel (pinned host memory is addressable from the device) --
+    device -> pinned host, pinned host -> device and device -> device, odd workgroup counts, a size that is not a multiple
+    of the kernel's unrolled stride; unpinned or misaligned arguments are refused."""
+    import torch
+    import gtcrn_micro_amd as G
+    n = 4 * 12345
+    src = torch.randn(n, device="cuda")
+    host = torch.empty(n).pin_memory()
+    back = torch.empty(n, device="cuda")
+    G.link_copy(host, src, workgroups=7)
+    torch.cuda.synchronize()
+    assert torch.equal(host, src.cpu())
+    G.link_copy(back, host, workgroups=33)
+    dd = torch.empty(n, device="cuda")
+    G.link_copy(dd, back, workgroups=1)
+    torch.cuda.synchronize()
+    assert torch.equal(back, src) and torch.equal(dd, src)
+    with pytest.raises(G.GtcrnError):
+        G.link_copy(torch.empty(n), src)                       # pageable host memory
+    with pytest.raises(G.GtcrnError):
+        G.link_copy(host[1:5], src[1:5])                       # 4-byte aligned, 16 bytes
