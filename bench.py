@@ -1170,6 +1170,12 @@ def main(argv=None):
         for name, (fn, timeout_s) in shim.secondary_legs(rank, world).items():
             put(name, run_leg(name, fn, rank, world, get_line, timeout_s))
     if not shim and not args.no_secondary:
+        # the host-link leg FIRST: it is what a serving process does from its start, and the duplex DMA rate depends on what
+        # the process did before -- after the streaming-capacity leg (40 GB of state allocated and freed) both directions
+        # at once run at 28 GB/s each and the served step takes 2.0-2.6 ms; in a fresh process 48 GB/s each and 1.47 ms
+        # (tools/io_overlap_probe.py; gpurun_out/r05p: the same io_leg behind each of the other legs)
+        put("io", run_leg("io", lambda sync_local, record: io_leg(eng, wave, win, out, world, sync_local, record,
+                                                                  steps=args.steps), rank, world, get_line))
         put("stream", run_leg("stream", lambda sync_local, record: stream_leg(eng, world, sync_local, record),
                               rank, world, get_line))
         put("stream_capacity", run_leg("stream_capacity", lambda sync_local, record: stream_capacity_leg(
@@ -1178,8 +1184,6 @@ def main(argv=None):
             eng, win, world, sync_local, record), rank, world, get_line))
         eng.reserve(B, T)
         eng.forward_wave(wave, win, out=out)
-        put("io", run_leg("io", lambda sync_local, record: io_leg(eng, wave, win, out, world, sync_local, record,
-                                                                  steps=args.steps), rank, world, get_line))
 
         def folder(sync_local, record):
             r = folder_leg(rank, world, local_rank)
