@@ -21,7 +21,7 @@ def main():
     ap.add_argument("--steps", type=int, default=300)
     ap.add_argument("--batch", type=int, default=64)
     ap.add_argument("--seconds", type=float, default=2.0)
-    ap.add_argument("--storage", choices=["f32", "bf16", "bf16_saves"], default="f32")
+    ap.add_argument("--storage", choices=["f32", "bf16", "bf16_saves", "bf16_grads"], default="f32")
     a = ap.parse_args()
     import torch
     from gtcrn_micro_amd.train import make_training, synthetic_mix, train_step
