@@ -1028,6 +1028,91 @@ finish:
     }
 }
 
+// ------------------------------------------------ the two 16 -> 16 (1,5) stride-2 forward convs, dedicated form
+// encoder.en_convs.1 (Conv2d, 65 -> 33 bins) and decoder.de_convs.3 (ConvTranspose2d, 33 -> 65 bins) ran through
+// k_conv_mfma<1, 5>: 314 us each on 0.8 GB (2.6 TB/s), most of it the general kernel's per-tap bookkeeping (run-time
+// stride / mode / parity logic, 64-bit row arithmetic, a (b, t, f) position carried per tile).  Same structure as
+// k_pw_fwd: the bin counts are compile-time (row = p / FO is a multiply), offsets are 32-bit, the five A fragments
+// stay in registers, all five tap loads of a tile are issued before the first MFMA.  Same taps in the same order
+// (kf = 0 .. 4, a tap outside the row enters as zero), bias first, statistics in double: bit-identical outputs.
+template <int FIN, int OUTF, bool TR>      // TR: the transposed conv (decoder)
+__global__ __launch_bounds__(NT) void k_c15_fwd(long npos, int w_co, int w_ci, const float* __restrict__ in,
+                                               const float* __restrict__ w, const float* __restrict__ bias,
+                                               float* __restrict__ out, long tiles_per_wave, double* __restrict__ stat_partial,
+                                               const float* __restrict__ shift, FinArgs fa) {
+    constexpr unsigned FI = TR ? 33 : 65, FO = TR ? 65 : 33;
+    __shared__ __attribute__((aligned(16))) float sW[5 * 256];   // [tap][co][ci]
+    __shared__ double sStat[NT / 64][32];
+    const int tid = threadIdx.x;
+    for (int i = tid; i < 5 * 256; i += NT) {
+        const int k = i >> 8, co = (i >> 4) & 15, ci = i & 15;
+        sW[i] = w[co * w_co + ci * w_ci + k];
+    }
+    __syncthreads();
+    const int lane = tid & 63, n = lane & 15, q = lane >> 4;
+    const long ntiles = (npos + 15) >> 4;
+    const long wave = (long)blockIdx.x * (NT / 64) + (tid >> 6);
+    long tile = wave * tiles_per_wave;
+    const long tend = tile + tiles_per_wave < ntiles ? tile + tiles_per_wave : ntiles;
+    double s1[4] = {0.0, 0.0, 0.0, 0.0}, s2[4] = {0.0, 0.0, 0.0, 0.0};
+    f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+    if (bias) bv = *reinterpret_cast<const f32x4*>(bias + 4 * q);
+    if (shift) bv -= *reinterpret_cast<const f32x4*>(shift + 4 * q);
+    f32x4 A[5];
+#pragma unroll
+    for (int k = 0; k < 5; ++k) A[k] = *reinterpret_cast<const f32x4*>(sW + k * 256 + n * 16 + 4 * q);
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+    unsigned p = (unsigned)(tile * 16) + n;          // (positions and element offsets fit in 31 bits: the launcher checks)
+    const unsigned np32 = (unsigned)npos;
+    for (; tile < tend; ++tile, p += 16) {
+        const bool pv = p < np32;
+        const unsigned row = p / FO, f = p - row * FO, base = row * (FI * 16u) + 4u * q;
+        typename Raw4<FIN>::t raw[5];
+        bool ok[5];
+#pragma unroll
+        for (int k = 0; k < 5; ++k) {
+            int fi;
+            if constexpr (TR) {
+                const int n1 = (int)f + 2 - k;
+                fi = n1 >> 1;
+                ok[k] = pv && n1 >= 0 && (n1 & 1) == 0 && fi < (int)FI;
+            } else {
+                fi = 2 * (int)f - 2 + k;
+                ok[k] = pv && fi >= 0 && fi < (int)FI;
+            }
+            raw[k] = sld4_raw<FIN>(in, (long)(ok[k] ? base + (unsigned)fi * 16u : 0u));
+        }
+        f32x4 acc = bv;
+#pragma unroll
+        for (int k = 0; k < 5; ++k) {
+            const f32x4 d = dec4<FIN>(raw[k]);
+            const f32x4 xv = ok[k] ? d : zero;
+#pragma unroll
+            for (int s4 = 0; s4 < 4; ++s4) acc = mfma4(A[k][s4], xv[s4], acc);
+        }
+        if (pv) {
+            acc = round_bf4(acc, OUTF);      // the statistics are those of the STORED tensor (the backward re-reads it)
+            sst4<kNtSt>(out, (long)(p * 16u + 4u * q), OUTF, acc);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { const double a = (double)acc[e]; s1[e] += a; s2[e] = fma(a, a, s2[e]); }
+        }
+    }
+    if (stat_partial) {          // as k_conv_mfma
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { s1[e] = wave_sum_xor(s1[e], 1, 8); s2[e] = wave_sum_xor(s2[e], 1, 8); }
+        if (n == 0)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { sStat[tid >> 6][4 * q + e] = s1[e]; sStat[tid >> 6][16 + 4 * q + e] = s2[e]; }
+        __syncthreads();
+        if (tid < 32) {
+            double t = 0.0;
+            for (int w2 = 0; w2 < NT / 64; ++w2) t += sStat[w2][tid];
+            st_part(stat_partial + (long)blockIdx.x * 32 + tid, t, fa);
+        }
+        if (fa.kind) fin_reduce(stat_partial, 32, blockIdx.x, gridDim.x, fa);
+    }
+}
+
 // The window form on the VALU, for the FORWARD of encoder.en_convs.0: thread (position, channel quad), the window as
 // four unaligned 16-byte loads (the four lanes of a position read the same addresses), then the multiply-adds of
 // k_conv<3, 16> in ITS order (tap, input channel: one fp32 fmaf chain per output channel; a tap outside the row enters
@@ -4460,6 +4545,24 @@ int conv_fwd(const ConvGeom& g, const float* in, const float* w, const float* bi
                         g.pf == 0 && g.f_mode == 0 && !g.accumulate && g.cout_off == 0 && g.Cout == g.CoutT && g.in_bf <= 1 && g.out_bf <= 1 &&
                         (long)g.B * g.Tout * g.Fout * 16 < (1L << 31) && (!pre || (!pre->exact && pre->bf == g.in_bf)) &&
                         g_pw_form;
+        // ... and the two 16 -> 16 (1,5) stride-2 layers (see k_c15_fwd)
+        const bool c15 = !win && !pre && g_pw_form && g.nkt == 1 && g.nkf == 5 && g.t_off[0] == 0 && g.Tin == g.Tout && g.sf == 2 &&
+                         g.pf == 2 && g.w_kf == 1 && g.Cin == 16 && g.CinT == 16 && g.cin_off == 0 && g.Cout == 16 && g.CoutT == 16 &&
+                         g.cout_off == 0 && !g.accumulate && g.in_bf <= 1 && g.out_bf <= 1 &&
+                         ((g.f_mode == 0 && g.Fin == 65 && g.Fout == 33) || (g.f_mode == 1 && g.Fin == 33 && g.Fout == 65)) &&
+                         (long)g.B * g.Tout * 65 * 16 < (1L << 31);
+        if (c15) {
+            const long npos = (long)g.B * g.Tout * g.Fout;
+#define GT_C5(FI_, FO_, TR_) hipLaunchKernelGGL((k_c15_fwd<FI_, FO_, TR_>), dim3(grid), dim3(NT), 0, s, npos, g.w_co, g.w_ci, in, w, bias, out, \
+                                                tpw, sp, shift, fm)
+#define GT_C52(TR_) do { if (g.in_bf == 0 && g.out_bf == 0) GT_C5(0, 0, TR_); else if (g.in_bf == 1 && g.out_bf == 1) GT_C5(1, 1, TR_); \
+                         else if (g.in_bf == 0) GT_C5(0, 1, TR_); else GT_C5(1, 0, TR_); } while (0)
+            if (g.f_mode) GT_C52(true); else GT_C52(false);
+#undef GT_C52
+#undef GT_C5
+            if (sp) *stat_parts = fm.kind ? -grid : grid;
+            return check();
+        }
         if (pw) {
             const long npos = (long)g.B * g.Tout * g.Fout;
 #define GT_PW(FI, FO, PR, RS) hipLaunchKernelGGL((k_pw_fwd<FI, FO, PR, RS>), dim3(grid), dim3(NT), 0, s, npos, g.Cin, g.CinT, g.cin_off, \
