@@ -284,7 +284,7 @@ long gtcrn_trainer_workspace_bytes(gtcrn_trainer *t, int B, int T);
  * (TRALite's energy, the gate/shuffle, their two backward passes): six normalise passes per step and the tensor they
  * wrote are gone, the values are the same bit for bit.  bit 13: the 28 pointwise forward convs of a step run in a
  * dedicated kernel (flat positions, compile-time formats, two tiles per iteration with the next two requested) instead of
- * the general strided / padded conv kernel.  bit 14: the TCN's dilated depthwise (3,1) forward in a column form -- a
+ * the general strided / padded conv kernel (and the two 16 -> 16 (1,5) stride-2 layers in one of their own, k_c15_fwd).  bit 14: the TCN's dilated depthwise (3,1) forward in a column form -- a
  * thread walks one residue class of frames modulo the dilation, so every input is normalised once instead of three
  * times and a chunk's loads are issued together.  Both are bit-identical to the kernels they replace (conv outputs;
  * the BatchNorm statistics to the float); bit 14 also runs that unit's fused backward in the column form (dy and the
