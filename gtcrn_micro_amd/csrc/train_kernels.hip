@@ -1062,39 +1062,94 @@ __global__ __launch_bounds__(NT) void k_c15_fwd(long npos, int w_co, int w_ci, c
 #pragma unroll
     for (int k = 0; k < 5; ++k) A[k] = *reinterpret_cast<const f32x4*>(sW + k * 256 + n * 16 + 4 * q);
     const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
-    unsigned p = (unsigned)(tile * 16) + n;          // (positions and element offsets fit in 31 bits: the launcher checks)
-    const unsigned np32 = (unsigned)npos;
-    for (; tile < tend; ++tile, p += 16) {
-        const bool pv = p < np32;
-        const unsigned row = p / FO, f = p - row * FO, base = row * (FI * 16u) + 4u * q;
-        typename Raw4<FIN>::t raw[5];
-        bool ok[5];
+    if constexpr (TR) {
+        // The transposed layer's outputs see only the taps of their own parity -- even bins kf = 0, 2, 4, odd bins kf = 1, 3:
+        // with 16 consecutive bins per tile half of the 20 MFMAs and of the loads multiplied zeros (346 us).  Here a tile is
+        // 16 outputs of ONE parity (all rows' even bins first, then all odd bins): 12 / 8 MFMAs, 3 / 2 loads, and the input
+        // bins of a tile are consecutive.  Skipping a zero tap leaves the accumulator as it was: the same values.
+        const unsigned rows = (unsigned)(npos / FO);
+        const unsigned nE = rows * 33u, nO = rows * 32u, tE = (nE + 15u) >> 4, tO = (nO + 15u) >> 4;
+        const unsigned ntl = tE + tO;
+        const unsigned per = (ntl + (unsigned)gridDim.x * (NT / 64) - 1) / ((unsigned)gridDim.x * (NT / 64));
+        unsigned tl = (unsigned)wave * per;
+        const unsigned tl1 = tl + per < ntl ? tl + per : ntl;
+        // (the next tile's loads are requested before this tile is computed: with one tile's three loads per wave in flight
+        // the kernel waited a memory latency per tile -- 353 us for 0.8 GB)
+        struct TIn { typename Raw4<FIN>::t raw[3]; bool ok[3]; bool pv, odd; unsigned oidx; };
+        auto fetch = [&](unsigned t_, TIn& ti) {
+            ti.odd = t_ >= tE;
+            const unsigned idx = (ti.odd ? t_ - tE : t_) * 16u + n, cnt = ti.odd ? nO : nE, per_row = ti.odd ? 32u : 33u;
+            ti.pv = idx < cnt;
+            const unsigned row = idx / per_row, j = idx - row * per_row, f = 2u * j + (ti.odd ? 1u : 0u);
+            const unsigned base = row * (FI * 16u) + 4u * q;
+            ti.oidx = (row * FO + f) * 16u + 4u * q;
+            // even: taps 0, 2, 4 read bins j + 1, j, j - 1; odd: taps 1, 3 read bins j + 1, j
 #pragma unroll
-        for (int k = 0; k < 5; ++k) {
-            int fi;
-            if constexpr (TR) {
-                const int n1 = (int)f + 2 - k;
-                fi = n1 >> 1;
-                ok[k] = pv && n1 >= 0 && (n1 & 1) == 0 && fi < (int)FI;
-            } else {
-                fi = 2 * (int)f - 2 + k;
-                ok[k] = pv && fi >= 0 && fi < (int)FI;
+            for (int u = 0; u < 3; ++u) {
+                const int fi = (int)j + 1 - u;
+                ti.ok[u] = ti.pv && fi >= 0 && fi < (int)FI && (u < 2 || !ti.odd);
+                ti.raw[u] = sld4_raw<FIN>(in, (long)(ti.ok[u] ? base + (unsigned)fi * 16u : 0u));
             }
-            raw[k] = sld4_raw<FIN>(in, (long)(ok[k] ? base + (unsigned)fi * 16u : 0u));
+        };
+        TIn cur{}, nxt{};
+        if (tl < tl1) fetch(tl, cur);
+        for (; tl < tl1; ++tl) {
+            nxt = cur;
+            if (tl + 1 < tl1) fetch(tl + 1, nxt);
+            f32x4 acc = bv;
+#pragma unroll
+            for (int u = 0; u < 3; ++u) {
+                const f32x4 d = dec4<FIN>(cur.raw[u]);
+                const f32x4 xv = cur.ok[u] ? d : zero;
+                const f32x4 Ae = A[2 * u], Ao = A[u < 2 ? 2 * u + 1 : 0];
+                if (u < 2 || !cur.odd) {         // (wave-uniform: a tile has one parity)
+#pragma unroll
+                    for (int s4 = 0; s4 < 4; ++s4) acc = mfma4(cur.odd ? Ao[s4] : Ae[s4], xv[s4], acc);
+                }
+            }
+            if (cur.pv) {
+                acc = round_bf4(acc, OUTF);
+                sst4<kNtSt>(out, (long)cur.oidx, OUTF, acc);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { const double a = (double)acc[e]; s1[e] += a; s2[e] = fma(a, a, s2[e]); }
+            }
+            cur = nxt;
         }
-        f32x4 acc = bv;
+    }
+    if constexpr (!TR) {
+        unsigned p = (unsigned)(tile * 16) + n;          // (positions and element offsets fit in 31 bits: the launcher checks)
+        const unsigned np32 = (unsigned)npos;
+        struct EIn { typename Raw4<FIN>::t raw[5]; bool ok[5]; };
+        auto fetch = [&](unsigned pp, EIn& ti) {
+            const bool pv = pp < np32;
+            const unsigned row = pp / FO, f = pp - row * FO, base = row * (FI * 16u) + 4u * q;
 #pragma unroll
-        for (int k = 0; k < 5; ++k) {
-            const f32x4 d = dec4<FIN>(raw[k]);
-            const f32x4 xv = ok[k] ? d : zero;
+            for (int k = 0; k < 5; ++k) {
+                const int fi = 2 * (int)f - 2 + k;
+                ti.ok[k] = pv && fi >= 0 && fi < (int)FI;
+                ti.raw[k] = sld4_raw<FIN>(in, (long)(ti.ok[k] ? base + (unsigned)fi * 16u : 0u));
+            }
+        };
+        EIn cur{}, nxt{};
+        if (tile < tend) fetch(p, cur);
+        for (; tile < tend; ++tile, p += 16) {
+            nxt = cur;
+            if (tile + 1 < tend) fetch(p + 16, nxt);       // (the next tile's five loads in flight while this one is computed)
+            f32x4 acc = bv;
 #pragma unroll
-            for (int s4 = 0; s4 < 4; ++s4) acc = mfma4(A[k][s4], xv[s4], acc);
-        }
-        if (pv) {
-            acc = round_bf4(acc, OUTF);      // the statistics are those of the STORED tensor (the backward re-reads it)
-            sst4<kNtSt>(out, (long)(p * 16u + 4u * q), OUTF, acc);
+            for (int k = 0; k < 5; ++k) {
+                const f32x4 d = dec4<FIN>(cur.raw[k]);
+                const f32x4 xv = cur.ok[k] ? d : zero;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) { const double a = (double)acc[e]; s1[e] += a; s2[e] = fma(a, a, s2[e]); }
+                for (int s4 = 0; s4 < 4; ++s4) acc = mfma4(A[k][s4], xv[s4], acc);
+            }
+            if (p < np32) {
+                acc = round_bf4(acc, OUTF);      // the statistics are those of the STORED tensor (the backward re-reads it)
+                sst4<kNtSt>(out, (long)(p * 16u + 4u * q), OUTF, acc);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { const double a = (double)acc[e]; s1[e] += a; s2[e] = fma(a, a, s2[e]); }
+            }
+            cur = nxt;
         }
     }
     if (stat_partial) {          // as k_conv_mfma
@@ -3529,11 +3584,18 @@ __global__ __launch_bounds__(NT) void k_bs_mask_bwd(const float* __restrict__ do
 // (k_feat 288 us at 1.6 TB/s, k_bs_mask 340 us, k_bs_mask_bwd 456 us at 1.8 TB/s).  Here a workgroup stages FM_NF frames
 // in LDS with coalesced 8-byte loads and the band sums read LDS.  Per-element arithmetic and its order are unchanged.
 constexpr int FM_NF = 4;
+constexpr int FM_BW = 12;       // band weights kept in LDS per row / column of the filterbank (the ERB bands are at most 12 bins wide)
 __global__ __launch_bounds__(NT) void k_feat_fm(const float* __restrict__ spec, long nframes, const float* __restrict__ erb_w,
                                                float* __restrict__ eb, int bf, float* __restrict__ eb2, int eb2_bf) {
     __shared__ int lo[64], hi[64];
     __shared__ float2 sX[FM_NF][257];
+    __shared__ float sWt[64 * FM_BW];           // the bands' weights from their first non-zero bin on (a band wider than FM_BW: global)
     nz_ranges(erb_w, 64, 192, 192, 1, lo, hi);
+    for (int i = threadIdx.x; i < 64 * FM_BW; i += NT) {
+        const int j = i / FM_BW, u = i - j * FM_BW, k = lo[j] + u;
+        sWt[i] = k < hi[j] ? erb_w[(long)j * 192 + k] : 0.f;
+    }
+    __syncthreads();
     const long groups = (nframes + FM_NF - 1) / FM_NF;
     for (long grp = blockIdx.x; grp < groups; grp += gridDim.x) {
         const long bt0 = grp * FM_NF;
@@ -3552,7 +3614,7 @@ __global__ __launch_bounds__(NT) void k_feat_fm(const float* __restrict__ spec, 
                 const float* w = erb_w + (long)(j - 65) * 192;
                 const int l0 = lo[j - 65], h0 = hi[j - 65];
                 for (int k = l0; k < h0; ++k) {
-                    const float wi = w[k];
+                    const float wi = k - l0 < FM_BW ? sWt[(j - 65) * FM_BW + k - l0] : w[k];
                     const float r = x[65 + k].x, q = x[65 + k].y;
                     m = fmaf(wi, sqrtf(r * r + q * q + 1e-12f), m);
                     re = fmaf(wi, r, re);
@@ -3570,7 +3632,13 @@ __global__ __launch_bounds__(NT) void k_bs_mask_fm(const float* __restrict__ m, 
                                                   const float* __restrict__ ierb_w, float* __restrict__ out, int bf) {
     __shared__ int lo[192], hi[192];
     __shared__ float2 sM[FM_NF][129];
+    __shared__ float sWt[192 * 4];              // a bin's band weights from its first non-zero band on (more than 4: global)
     nz_ranges(ierb_w, 192, 64, 64, 1, lo, hi);
+    for (int i = threadIdx.x; i < 192 * 4; i += NT) {
+        const int f = i >> 2, u = i & 3, j = lo[f] + u;
+        sWt[i] = j < hi[f] ? ierb_w[(long)f * 64 + j] : 0.f;
+    }
+    __syncthreads();
     const long groups = (nframes + FM_NF - 1) / FM_NF;
     for (long grp = blockIdx.x; grp < groups; grp += gridDim.x) {
         const long bt0 = grp * FM_NF;
@@ -3589,8 +3657,9 @@ __global__ __launch_bounds__(NT) void k_bs_mask_fm(const float* __restrict__ m, 
                 m0 = sM[fr][f].x; m1 = sM[fr][f].y;
             } else {
                 const float* w = ierb_w + (long)(f - 65) * 64;
-                for (int j = lo[f - 65]; j < hi[f - 65]; ++j) {
-                    const float wj = w[j];
+                const int l0 = lo[f - 65];
+                for (int j = l0; j < hi[f - 65]; ++j) {
+                    const float wj = j - l0 < 4 ? sWt[(f - 65) * 4 + j - l0] : w[j];
                     if (wj != 0.f) {
                         m0 = fmaf(wj, sM[fr][65 + j].x, m0);
                         m1 = fmaf(wj, sM[fr][65 + j].y, m1);
@@ -3607,7 +3676,13 @@ __global__ __launch_bounds__(NT) void k_bs_mask_bwd_fm(const float* __restrict__
                                                       long nframes, const float* __restrict__ ierb_w, float* __restrict__ dm) {
     __shared__ int lo[64], hi[64];
     __shared__ float2 sG[FM_NF][257];          // per bin: (dr re + di im, di re - dr im)
+    __shared__ float sWt[64 * FM_BW];           // a band's column of the (192, 64) matrix from its first non-zero bin on
     nz_ranges(ierb_w, 64, 192, 1, 64, lo, hi);        // columns of the (192, 64) matrix
+    for (int i = threadIdx.x; i < 64 * FM_BW; i += NT) {
+        const int j = i / FM_BW, u = i - j * FM_BW, k = lo[j] + u;
+        sWt[i] = k < hi[j] ? ierb_w[(long)k * 64 + j] : 0.f;
+    }
+    __syncthreads();
     const long groups = (nframes + FM_NF - 1) / FM_NF;
     for (long grp = blockIdx.x; grp < groups; grp += gridDim.x) {
         const long bt0 = grp * FM_NF;
@@ -3626,8 +3701,9 @@ __global__ __launch_bounds__(NT) void k_bs_mask_bwd_fm(const float* __restrict__
             if (j < 65) {
                 g0 = sG[fr][j].x; g1 = sG[fr][j].y;
             } else {
-                for (int k = lo[j - 65]; k < hi[j - 65]; ++k) {
-                    const float wi = ierb_w[(long)k * 64 + (j - 65)];
+                const int l0 = lo[j - 65];
+                for (int k = l0; k < hi[j - 65]; ++k) {
+                    const float wi = k - l0 < FM_BW ? sWt[(j - 65) * FM_BW + k - l0] : ierb_w[(long)k * 64 + (j - 65)];
                     if (wi != 0.f) {
                         g0 = fmaf(wi, sG[fr][65 + k].x, g0);
                         g1 = fmaf(wi, sG[fr][65 + k].y, g1);
