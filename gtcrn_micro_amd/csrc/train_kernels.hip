@@ -3716,6 +3716,69 @@ __global__ __launch_bounds__(NT) void k_bs_mask_bwd_fm(const float* __restrict__
     }
 }
 
+// ---- the two thin transposed (1,5) stride-2 convs at the network's edges, 16 -> CO channels, 65 -> 129 bins: decoder.de_convs.4
+// forward (CO = 2) and the data gradient of encoder.en_convs.0 (CO = 3).  k_conv<16, CO> gives a thread one output position:
+// 64-byte loads at a 64-byte lane stride, and -- the expensive part -- neighbouring lanes have opposite output parity, so a
+// wave walks all five taps with half its lanes masked (even bins see kf = 0, 2, 4, odd bins kf = 1, 3): 305 / 314 us.
+// Here a workgroup stages four input rows in LDS with coalesced 16-byte loads (records 20 floats apart) and its threads take
+// the rows' EVEN bins first, then the odd ones: a wave has one parity, runs only its own taps, and reads the records and the
+// tap's weights as 16-byte LDS quads.  Same fmaf chain per output as k_conv (bias - shift first, taps kf ascending, input
+// channels ascending): bit-identical outputs.
+template <int CO, int FIN, int OUTF>
+__global__ __launch_bounds__(NT) void k_thin_tr_fm(long nrows, int w_co, int w_ci, const float* __restrict__ in,
+                                                  const float* __restrict__ w, const float* __restrict__ bias,
+                                                  const float* __restrict__ shift, float* __restrict__ out) {
+    constexpr int NF = 4, PITCH = 20;
+    __shared__ __attribute__((aligned(16))) float sX[NF * 65 * PITCH];
+    __shared__ __attribute__((aligned(16))) float sWt[5 * 16 * CO];          // [kf][ci][co]
+    for (int i = threadIdx.x; i < 5 * 16 * CO; i += NT) {
+        const int k = i / (16 * CO), r = i - k * 16 * CO, ci = r / CO, co = r - ci * CO;
+        sWt[i] = w[co * w_co + ci * w_ci + k];
+    }
+    float bv[CO];
+#pragma unroll
+    for (int co = 0; co < CO; ++co) bv[co] = (bias ? bias[co] : 0.f) - (shift ? shift[co] : 0.f);
+    const long groups = (nrows + NF - 1) / NF;
+    for (long grp = blockIdx.x; grp < groups; grp += gridDim.x) {
+        const long r0 = grp * NF;
+        const int nf = (int)(nrows - r0 < NF ? nrows - r0 : NF);
+        __syncthreads();                                         // (the previous group's reads of sX / the weight table)
+        for (int i = threadIdx.x; i < nf * 65 * 4; i += NT) {
+            const int pos = i >> 2, q = i & 3;
+            *reinterpret_cast<f32x4*>(sX + pos * PITCH + 4 * q) = sld4<kNt>(in, (r0 * 65 + pos) * 16 + 4 * q, FIN);
+        }
+        __syncthreads();
+        const int nE = nf * 65;                                  // even bins 0, 2 .. 128 of the rows, then the odd ones
+        for (int i = threadIdx.x; i < nf * 129; i += NT) {
+            const bool odd = i >= nE;
+            const int ii = odd ? i - nE : i, per = odd ? 64 : 65, fr = ii / per, j = ii - fr * per, fo = 2 * j + (odd ? 1 : 0);
+            float acc[CO];
+#pragma unroll
+            for (int co = 0; co < CO; ++co) acc[co] = bv[co];
+            // even: taps 0, 2, 4 read bins j + 1, j, j - 1; odd: taps 1, 3 read bins j + 1, j
+#pragma unroll
+            for (int u = 0; u < 3; ++u) {
+                const int fi = j + 1 - u, k = odd ? 2 * u + 1 : 2 * u;
+                if (fi < 0 || fi >= 65 || (odd && u == 2)) continue;
+                const f32x4* xq = reinterpret_cast<const f32x4*>(sX + (fr * 65 + fi) * PITCH);
+                const f32x4* wq = reinterpret_cast<const f32x4*>(sWt + k * 16 * CO);
+                float xv[16], wv[16 * CO];
+#pragma unroll
+                for (int v = 0; v < 4; ++v) { const f32x4 t = xq[v]; xv[4 * v] = t[0]; xv[4 * v + 1] = t[1]; xv[4 * v + 2] = t[2]; xv[4 * v + 3] = t[3]; }
+#pragma unroll
+                for (int v = 0; v < 4 * CO; ++v) { const f32x4 t = wq[v]; wv[4 * v] = t[0]; wv[4 * v + 1] = t[1]; wv[4 * v + 2] = t[2]; wv[4 * v + 3] = t[3]; }
+#pragma unroll
+                for (int ci = 0; ci < 16; ++ci)
+#pragma unroll
+                    for (int co = 0; co < CO; ++co) acc[co] = fmaf(wv[ci * CO + co], xv[ci], acc[co]);
+            }
+            const long o = ((r0 + fr) * 129 + fo) * CO;
+#pragma unroll
+            for (int co = 0; co < CO; ++co) sst1(out, o + co, OUTF, acc[co]);
+        }
+    }
+}
+
 // ---- the same three kernels for the layout the callers actually pass: (B,257,T,2) with the FRAME axis fastest
 // (torch.stft's, st < sf).  One thread per (b,t,f) with f fastest then reads / writes the 0.5 GB spectrograms 8 bytes
 // at a time with a stride of 2 T floats (k_bs_mask_bwd ran at 0.7 TB/s).  Here a workgroup takes a tile of TT frames of
@@ -4672,6 +4735,21 @@ int conv_fwd(const ConvGeom& g, const float* in, const float* w, const float* bi
     }
     const int grid = grid_for((long)g.B * g.Tout * g.Fout);
     if ((long)g.B * g.Tout * g.Fout >= (1L << 31)) return (int)hipErrorInvalidValue;      // (k_conv divides in 32 bits)
+    // de_convs.4 forward / en_convs.0's data gradient: the LDS-staged, parity-sorted form (see k_thin_tr_fm)
+    if (g.nkt == 1 && g.nkf == 5 && g.f_mode == 1 && g.sf == 2 && g.pf == 2 && g.Fin == 65 && g.Fout == 129 && g.Cin == 16 &&
+        g.CinT == 16 && g.cin_off == 0 && (g.Cout == 2 || g.Cout == 3) && g.CoutT == g.Cout && g.cout_off == 0 && !g.accumulate &&
+        g.w_kf == 1 && g.Tin == g.Tout && g.t_off[0] == 0 && g.in_bf <= 1 && g.out_bf <= 1) {
+        const long nrows = (long)g.B * g.Tout;
+        const int gt = grid_for((nrows + 3) / 4 * NT, 2048);
+#define GT_TT(CO_, FI_, FO_) hipLaunchKernelGGL((k_thin_tr_fm<CO_, FI_, FO_>), dim3(gt), dim3(NT), 0, s, nrows, g.w_co, g.w_ci, in, w, bias, \
+                                                shift, out)
+#define GT_TT2(CO_) do { if (g.in_bf == 0 && g.out_bf == 0) GT_TT(CO_, 0, 0); else if (g.in_bf == 1 && g.out_bf == 1) GT_TT(CO_, 1, 1); \
+                         else if (g.in_bf == 0) GT_TT(CO_, 0, 1); else GT_TT(CO_, 1, 0); } while (0)
+        if (g.Cout == 2) GT_TT2(2); else GT_TT2(3);
+#undef GT_TT2
+#undef GT_TT
+        return check();
+    }
 #define GT_CONV_CASE(CI, CO)                                                                      \
     if (g.Cin == CI && g.Cout == CO) {                                                            \
         hipLaunchKernelGGL((k_conv<CI, CO>), dim3(grid), dim3(NT), 0, s, g, in, w, bias, out, shift); \
