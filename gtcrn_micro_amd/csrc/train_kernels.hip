@@ -1074,47 +1074,52 @@ __global__ __launch_bounds__(NT) void k_c15_fwd(long npos, int w_co, int w_ci, c
         unsigned tl = (unsigned)wave * per;
         const unsigned tl1 = tl + per < ntl ? tl + per : ntl;
         // (the next tile's loads are requested before this tile is computed: with one tile's three loads per wave in flight
-        // the kernel waited a memory latency per tile -- 353 us for 0.8 GB)
-        struct TIn { typename Raw4<FIN>::t raw[3]; bool ok[3]; bool pv, odd; unsigned oidx; };
-        auto fetch = [&](unsigned t_, TIn& ti) {
-            ti.odd = t_ >= tE;
-            const unsigned idx = (ti.odd ? t_ - tE : t_) * 16u + n, cnt = ti.odd ? nO : nE, per_row = ti.odd ? 32u : 33u;
-            ti.pv = idx < cnt;
-            const unsigned row = idx / per_row, j = idx - row * per_row, f = 2u * j + (ti.odd ? 1u : 0u);
-            const unsigned base = row * (FI * 16u) + 4u * q;
-            ti.oidx = (row * FO + f) * 16u + 4u * q;
-            // even: taps 0, 2, 4 read bins j + 1, j, j - 1; odd: taps 1, 3 read bins j + 1, j
+        // the kernel waited a memory latency per tile -- 353 us for 0.8 GB; the two parities are two loops, so that the bins
+        // per row and the tap count are compile-time inside each)
+        auto run = [&](auto oddc, unsigned t0, unsigned t1, unsigned tbase, unsigned cnt) {
+            constexpr bool ODD = decltype(oddc)::value;
+            constexpr unsigned PER = ODD ? 32u : 33u;
+            constexpr int NTAP = ODD ? 2 : 3;
+            struct TIn { typename Raw4<FIN>::t raw[NTAP]; bool ok[NTAP]; bool pv; unsigned oidx; };
+            auto fetch = [&](unsigned t_, TIn& ti) {
+                const unsigned idx = (t_ - tbase) * 16u + n;
+                ti.pv = idx < cnt;
+                const unsigned row = idx / PER, j = idx - row * PER, f = 2u * j + (ODD ? 1u : 0u);
+                const unsigned base = row * (FI * 16u) + 4u * q;
+                ti.oidx = (row * FO + f) * 16u + 4u * q;
+                // even: taps 0, 2, 4 read bins j + 1, j, j - 1; odd: taps 1, 3 read bins j + 1, j
 #pragma unroll
-            for (int u = 0; u < 3; ++u) {
-                const int fi = (int)j + 1 - u;
-                ti.ok[u] = ti.pv && fi >= 0 && fi < (int)FI && (u < 2 || !ti.odd);
-                ti.raw[u] = sld4_raw<FIN>(in, (long)(ti.ok[u] ? base + (unsigned)fi * 16u : 0u));
+                for (int u = 0; u < NTAP; ++u) {
+                    const int fi = (int)j + 1 - u;
+                    ti.ok[u] = ti.pv && fi >= 0 && fi < (int)FI;
+                    ti.raw[u] = sld4_raw<FIN>(in, (long)(ti.ok[u] ? base + (unsigned)fi * 16u : 0u));
+                }
+            };
+            TIn cur{}, nxt{};
+            if (t0 < t1) fetch(t0, cur);
+            for (unsigned t_ = t0; t_ < t1; ++t_) {
+                nxt = cur;
+                if (t_ + 1 < t1) fetch(t_ + 1, nxt);
+                f32x4 acc = bv;
+#pragma unroll
+                for (int u = 0; u < NTAP; ++u) {
+                    const f32x4 d = dec4<FIN>(cur.raw[u]);
+                    const f32x4 xv = cur.ok[u] ? d : zero;
+                    const f32x4 Ak = A[ODD ? 2 * u + 1 : 2 * u];
+#pragma unroll
+                    for (int s4 = 0; s4 < 4; ++s4) acc = mfma4(Ak[s4], xv[s4], acc);
+                }
+                if (cur.pv) {
+                    acc = round_bf4(acc, OUTF);
+                    sst4<kNtSt>(out, (long)cur.oidx, OUTF, acc);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { const double a = (double)acc[e]; s1[e] += a; s2[e] = fma(a, a, s2[e]); }
+                }
+                cur = nxt;
             }
         };
-        TIn cur{}, nxt{};
-        if (tl < tl1) fetch(tl, cur);
-        for (; tl < tl1; ++tl) {
-            nxt = cur;
-            if (tl + 1 < tl1) fetch(tl + 1, nxt);
-            f32x4 acc = bv;
-#pragma unroll
-            for (int u = 0; u < 3; ++u) {
-                const f32x4 d = dec4<FIN>(cur.raw[u]);
-                const f32x4 xv = cur.ok[u] ? d : zero;
-                const f32x4 Ae = A[2 * u], Ao = A[u < 2 ? 2 * u + 1 : 0];
-                if (u < 2 || !cur.odd) {         // (wave-uniform: a tile has one parity)
-#pragma unroll
-                    for (int s4 = 0; s4 < 4; ++s4) acc = mfma4(cur.odd ? Ao[s4] : Ae[s4], xv[s4], acc);
-                }
-            }
-            if (cur.pv) {
-                acc = round_bf4(acc, OUTF);
-                sst4<kNtSt>(out, (long)cur.oidx, OUTF, acc);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) { const double a = (double)acc[e]; s1[e] += a; s2[e] = fma(a, a, s2[e]); }
-            }
-            cur = nxt;
-        }
+        run(std::false_type{}, tl < tE ? tl : tE, tl1 < tE ? tl1 : tE, 0u, nE);
+        run(std::true_type{}, tl > tE ? tl : tE, tl1 > tE ? tl1 : tE, tE, nO);
     }
     if constexpr (!TR) {
         unsigned p = (unsigned)(tile * 16) + n;          // (positions and element offsets fit in 31 bits: the launcher checks)
