@@ -501,8 +501,9 @@ class Engine:
         _check(lib().gtcrn_var_spans_enable(self._h, int(bool(on))))
 
     def stream_form(self, form=0):
-        """Single-frame streaming steps: 0 = one launch per step (default), 1 = the three-launch form (A/B switch;
-        bit-identical results)."""
+        """Single-frame streaming steps: 0 = one launch per step, four or seven streams per workgroup by the stream count
+        (default); 1 = the three-launch form; 2 / 3 = one launch pinned to four / seven streams per workgroup (A/B
+        switches; bit-identical results)."""
         _check(lib().gtcrn_stream_form(self._h, int(form)))
 
     def tap(self, name, b, T):

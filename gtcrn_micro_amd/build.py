@@ -42,6 +42,7 @@ def build_native(force=False, verbose=False, stamps=False, exp=False):
     lib = LIB
     if stamps:
         common.append("-DGT_STAMPS")
+        per_file = {k: v + os.environ.get("GT_STAMPS_FLAGS", "").split() for k, v in per_file.items()}
         suffix = ".stamps"
         lib = LIB.replace(".so", "_stamps.so")
     elif exp:

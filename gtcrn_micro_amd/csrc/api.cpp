@@ -46,9 +46,10 @@ struct Timing {
     hipEvent_t a = nullptr, b = nullptr;
 };
 // every timed launch records WHICH kernel it was (mixed offline / streaming calls keep their own rows)
-enum KernelId { K_STFT, K_ENCODER, K_GTCN1, K_GTCN2, K_DECODER, K_ISTFT, K_FRONT, K_ENCODER_GT, K_GTCN_MS, K_STREAM_MS, K_COUNT };
+enum KernelId { K_STFT, K_ENCODER, K_GTCN1, K_GTCN2, K_DECODER, K_ISTFT, K_FRONT, K_ENCODER_GT, K_GTCN_MS, K_STREAM_MS, K_STREAM_WIDE, K_COUNT };
 const char* const kKernelNames[K_COUNT] = {"k_stft",  "k_encoder",    "k_gtcn1",   "k_gtcn2",    "k_decoder",
-                                           "k_istft", "k_front",      "k_encoder_gt", "k_gtcn_ms", "k_stream_ms"};
+                                           "k_istft", "k_front",      "k_encoder_gt", "k_gtcn_ms", "k_stream_ms",
+                                           "k_stream_wide"};
 constexpr int kNumKernels = K_COUNT;
 
 }  // namespace
@@ -64,8 +65,10 @@ struct gtcrn_model {
     float* d_twid = nullptr; // 512 complex twiddles
     int* d_pref = nullptr;   // prefix table of a variable-length batch (1025 ints, see gtk::launch_len_prefix)
     bool var_spans = true;   // variable-length batches run in time spans (off: one workgroup per utterance, the A/B switch)
-    int stream_form = 0;     // single-frame streaming steps: 0 = ONE launch (k_stream_ms), 1 = the three-launch form
-                             // (encoder / both GTCN stacks / decoder, hand-offs through HBM): the A/B switch
+    int stream_form = 0;     // single-frame streaming steps: 0 = ONE launch, the form picked by the stream count (four
+                             // streams per workgroup, k_stream_ms, or seven, k_stream_wide: stream_wide_pays); 1 = the
+                             // three-launch form (encoder / both GTCN stacks / decoder, hand-offs through HBM); 2 / 3 =
+                             // ONE launch, k_stream_ms / k_stream_wide whatever the count: the A/B switches
     std::vector<int> h_pi;   // host copy of the int tables (slot permutations for the debug taps)
     // workspace for B x T
     long cap_bt = 0;         // capacity in (batch * frames)
@@ -163,6 +166,16 @@ struct Timer {
     }
 };
 
+// Single-frame steps of B streams: k_stream_ms serves four streams per workgroup, k_stream_wide seven in a workgroup that
+// takes WIDE_COST times as long (measured: profiles/r06_ab_stream_wide.txt).  Both run one workgroup per CU, so a step
+// costs rounds-of-256-workgroups x the form's time: the wide form pays once the narrow one needs more rounds than it.
+static bool stream_wide_pays(int B) {
+    constexpr double WIDE_COST = 1.25;
+    const int ws = gtk::stream_wide_streams();
+    const long r4 = ((B + 3) / 4 + 255) / 256, r7 = ((B + ws - 1) / ws + 255) / 256;
+    return (double)r7 * WIDE_COST < (double)r4;
+}
+
 // the five model kernels on one stream; state == nullptr for offline
 int run_model(gtcrn_model* m, const float* spec_in, long isb, long isf, long ist, float* spec_out, long osb, long osf,
               long ost, int B, int T, float* state, hipStream_t s, const int* lens = nullptr,
@@ -174,10 +187,12 @@ int run_model(gtcrn_model* m, const float* spec_in, long isb, long isf, long ist
     m->last_fused_stream = false;
     // single-frame streaming step: ONE launch, nothing handed over through HBM (the three-launch form below remains
     // for the stage taps of the parity tests, which read the hand-off tensors)
-    if (state && T == 1 && !q && (!m->debug || m->debug_keep_fused) && m->stream_form == 0 && gtk::stream_ms_usable(isb, osb)) {
-        tm.begin(K_STREAM_MS);
-        LAUNCH_TRY(gtk::launch_stream_ms(spec_in, isb, isf, spec_out, osb, osf, B, pf, m->d_pi, state,
-                                         (m->debug && m->d_stamps) ? m->d_stamps : nullptr, s));
+    if (state && T == 1 && !q && (!m->debug || m->debug_keep_fused) && m->stream_form != 1 && gtk::stream_ms_usable(isb, osb)) {
+        const bool wide = m->stream_form == 3 || (m->stream_form == 0 && stream_wide_pays(B));
+        unsigned long long* stamps = (m->debug && m->d_stamps) ? m->d_stamps : nullptr;
+        tm.begin(wide ? K_STREAM_WIDE : K_STREAM_MS);
+        if (wide) LAUNCH_TRY(gtk::launch_stream_wide(spec_in, isb, isf, spec_out, osb, osf, B, pf, m->d_pi, state, stamps, s));
+        else LAUNCH_TRY(gtk::launch_stream_ms(spec_in, isb, isf, spec_out, osb, osf, B, pf, m->d_pi, state, stamps, s));
         tm.end();
         m->last_fused_stream = true;
         m->last_B = B;
@@ -632,7 +647,9 @@ int gtcrn_var_spans_enable(gtcrn_model* m, int on) {
 int gtcrn_stream_form(gtcrn_model* m, int form) {
     int rc = check_model(m);
     if (rc) return rc;
-    if (form < 0 || form > 1) return fail(GTCRN_ERR_ARG, "gtcrn_stream_form: 0 (one launch) or 1 (three launches)");
+    if (form < 0 || form > 3)
+        return fail(GTCRN_ERR_ARG, "gtcrn_stream_form: 0 (one launch, form by stream count), 1 (three launches), 2 / 3 (one launch: "
+                                   "four / seven streams per workgroup)");
     m->stream_form = form;
     return 0;
 }

@@ -77,6 +77,11 @@ int launch_len_prefix(const int* lens, int B, int T, int* pref, hipStream_t s);
 // single-frame streaming step of B streams as ONE launch (encoder -> both GTCN stacks -> decoder, nothing through HBM)
 int launch_stream_ms(const float* spec, long sb, long sf, float* out, long osb, long osf, int B, const float* PF,
                      const int* PI, float* state, unsigned long long* stamps, hipStream_t s);
+// the same step with stream_wide_streams() streams per workgroup (eight waves x two tiles, streamed parameters): the form
+// for stream counts that fill the chip more than once
+int launch_stream_wide(const float* spec, long sb, long sf, float* out, long osb, long osf, int B, const float* PF,
+                       const int* PI, float* state, unsigned long long* stamps, hipStream_t s);
+int stream_wide_streams();
 bool stream_ms_usable(long sb, long osb);
 int launch_state_convert(float* state, int N, float* conv, float* tra, float* const* tcn8, const int* PI, int dir,
                          hipStream_t s);

@@ -756,12 +756,14 @@ struct BlockCtx {
     int tabs;            // absolute frame index of the chunk's first frame
     // multi-stream mode (MS): image row r holds the ONE new frame of stream r, so every temporal tap comes from that
     // stream's own ring and nothing is shared between rows
-    int ms_roff;         // per lane: float offset from sW to this block's h ring of the lane's stream
-    int ms_tb;           // per lane: frame counter of the lane's stream
+    // (per TILE of the wave: the wide single-launch step runs two tiles per wave, whose positions belong to different
+    // streams; every other multi-stream form uses entry 0)
+    int ms_roff[2];      // per lane: float offset from sW to this block's h ring of the lane's stream
+    int ms_tb[2];        // per lane: frame counter of the lane's stream
     const int* sTB;      // LDS: frame counter per row
     // fused single-launch streaming step (k_stream_ms): the h history is a per-block LDS image filled from the stream
     // state; the ONE new row goes straight from the registers to the state (nullptr elsewhere: the rings live in LDS)
-    float* g_hist;       // per lane: its 16 bytes of the new history row in the stream state, or nullptr
+    float* g_hist[2];    // per lane: its 16 bytes of the new history row in the stream state, or nullptr
 };
 
 // multi-stream geometry of the single-frame streaming step: MS_STREAMS streams per workgroup = rows 0..3 of the
@@ -791,17 +793,22 @@ __device__ __forceinline__ void ring_to_image(float* sW, const float* ring, int 
 // NWV: waves of the workgroup (the pair form of the offline encoder runs six); PMAX > 0: the image holds PMAX positions and
 // the wave's LAST tile may run past them (its other tiles never do): those lanes compute on whatever they read and store
 // nothing into the image
+// VMC >= 0: the block's CLOSING barrier also waits for the wave's vector-memory operations down to VMC outstanding
+// (the wide streaming step: an LDS-DMA issued a block or more ago becomes visible to every wave there)
 template <bool DENSE, int TPW, bool MS, bool Q, int RS, int RSS, bool WIDE_TRA, int PT, int VMK = 0, int VMK1 = -1, int NWV = NW,
-          int PMAX = 0, class Hook, class Hook3>
+          int PMAX = 0, int VMC = -1, class Hook, class Hook3>
 __device__ __forceinline__ void gtconv_block(f32x4 (&x)[TPW], const Tiles<TPW>& tin, const BlockCtx& c,
                                              const Lane& L, Hook&& hook, Hook3&& hook3 STAMP_PARAM) {
-    static_assert(!MS || TPW == 1, "multi-stream mode runs one tile per wave");
+    static_assert(!MS || TPW <= 2, "multi-stream mode runs one tile per wave (two in the wide single-launch step)");
     // SPLIT: the dense 3x3 on the 16-bit matrix pipe; the image W then holds h as three bf16 planes per position
     constexpr bool SPLIT = DENSE && !Q && kSplitDense;
     constexpr bool HALF = DENSE && Q && !MS;              // the fp16 variant: h as fp16 records, K = 32 chunks
     constexpr int FMT = SPLIT ? IMG_SPLIT3 : (HALF ? IMG_HALF : IMG_F32);
     static_assert(!(SPLIT || HALF) || RS == RS_WIDE, "the split / half image has 96-byte records");
-    static_assert(PMAX == 0 || (!DENSE && !MS && NWV * 16 * (TPW - 1) <= PMAX), "partial last tile: depthwise offline form");
+    static_assert(PMAX == 0 || (((!DENSE && !MS) || (MS && !Q)) && NWV * 16 * (TPW - 1) <= PMAX),
+                  "partial last tile: depthwise offline form, or the wide single-launch streaming step");
+    // (only the wave's LAST tile can run past PMAX)
+    auto in_image = [&](int i) -> bool { return PMAX == 0 || i < TPW - 1 || tin.pp(i) < PMAX; };
     constexpr int NT = NWV * 64;
     const int n = L.n, g = L.g;
     // Image rows (not MS): rows 0, 1 hold the two frames BEFORE the chunk -- copied from the block's history ring at
@@ -819,7 +826,7 @@ __device__ __forceinline__ void gtconv_block(f32x4 (&x)[TPW], const Tiles<TPW>& 
     for (int i = 0; i < TPW; ++i) b0s[i] = o35<RS, R0, PT>(tt, i, g);
     // float offset (from sW) of the record `back` frames before tile i's own position b0
     auto tap_base = [&](int i, int back, int b0) -> int {
-        if constexpr (MS) return back == 0 ? b0 : c.ms_roff + (((c.ms_tb + back) & 1) * 35 + 1 + tt.ff[i]) * RS + 4 * g;
+        if constexpr (MS) return back == 0 ? b0 : c.ms_roff[i] + (((c.ms_tb[i] + back) & 1) * 35 + 1 + tt.ff[i]) * RS + 4 * g;
         else return b0 - back * PT * RS;
     };
     if constexpr (!MS) {
@@ -837,11 +844,11 @@ __device__ __forceinline__ void gtconv_block(f32x4 (&x)[TPW], const Tiles<TPW>& 
 #pragma unroll
         for (int i = 0; i < TPW; ++i) {
             const f32x4 hv = rq<Q>(prelu4(h[i], a1));
-            if constexpr (SPLIT) st_split(c.sW, b0s[i] - 4 * g, g, hv);
+            if constexpr (SPLIT) { if (in_image(i)) st_split(c.sW, b0s[i] - 4 * g, g, hv); }
             else if constexpr (HALF) st_half(c.sW, b0s[i] - 4 * g, g, hv);
-            else if (PMAX == 0 || i < TPW - 1 || tt.pp(i) < PMAX) st4(c.sW + b0s[i], hv);
+            else if (in_image(i)) st4(c.sW + b0s[i], hv);
             if constexpr (MS) {
-                if (c.g_hist && tt.tl[i] < c.nfr) st4(c.g_hist, hv);     // the stream's new history row (replaces frame t-2)
+                if (c.g_hist[i] && tt.tl[i] < c.nfr) st4(c.g_hist[i], hv);     // the stream's new history row (replaces frame t-2)
             }
         }
     }
@@ -890,7 +897,7 @@ __device__ __forceinline__ void gtconv_block(f32x4 (&x)[TPW], const Tiles<TPW>& 
 #pragma unroll
             for (int i = 0; i < TPW; ++i) {
                 x[i] = rq<Q>(x[i]);
-                st4(c.sS + tt.pp(i) * RSS + 4 * g, x[i] * x[i]);   // energies are reduced cooperatively after the barrier
+                if (!MS || in_image(i)) st4(c.sS + tt.pp(i) * RSS + 4 * g, x[i] * x[i]);   // energies are reduced cooperatively after the barrier
             }
         } else if constexpr (SPLIT) {
             // dense transposed 3x3 on v_mfma_f32_16x16x32_bf16: K-chunk cc = taps 2cc and 2cc+1 (k = tap half * 16 + hidden
@@ -908,7 +915,7 @@ __device__ __forceinline__ void gtconv_block(f32x4 (&x)[TPW], const Tiles<TPW>& 
             const int q16 = 4 * (gq & 1);                    // channels 0..7 / 8..15 of the plane
             // float offset of the record `back` frames before tile i's own one (MS: in that stream's ring)
             auto rec_back = [&](int i, int back) -> int {
-                if constexpr (MS) return back == 0 ? rec0[i] : c.ms_roff + (((c.ms_tb + back) & 1) * 35 + 1 + tt.ff[i]) * RS;
+                if constexpr (MS) return back == 0 ? rec0[i] : c.ms_roff[i] + (((c.ms_tb[i] + back) & 1) * 35 + 1 + tt.ff[i]) * RS;
                 else return rec0[i] - back * PT * RS;
             };
 #pragma unroll
@@ -942,7 +949,8 @@ __device__ __forceinline__ void gtconv_block(f32x4 (&x)[TPW], const Tiles<TPW>& 
             }
             mm16<TPW, Q>(A2, acc, x);                         // point_conv2: the tiles' chains interleaved
 #pragma unroll
-            for (int i = 0; i < TPW; ++i) st4(c.sS + tt.pp(i) * RSS + 4 * g, x[i] * x[i]);
+            for (int i = 0; i < TPW; ++i)
+                if (!MS || in_image(i)) st4(c.sS + tt.pp(i) * RSS + 4 * g, x[i] * x[i]);
         } else if constexpr (HALF) {
             // the fp16 variant: same K-chunks, one plane: per chunk one weight read per wave, one h read and ONE
             // v_mfma_f32_16x16x32_f16 per tile
@@ -1026,8 +1034,8 @@ __device__ __forceinline__ void gtconv_block(f32x4 (&x)[TPW], const Tiles<TPW>& 
         // 8 bytes, which sit at float offsets 2g, 8 + 2g, 16 + 2g of the 96-byte record)
 #pragma unroll
         for (int i = 0; i < TPW; ++i)
-            if (tt.tl[i] < c.nfr && !c.g_hist) {
-                const int dst = c.ms_roff + ((c.ms_tb & 1) * 35 + 1 + tt.ff[i]) * RS;
+            if (tt.tl[i] < c.nfr && !c.g_hist[i]) {
+                const int dst = c.ms_roff[i] + ((c.ms_tb[i] & 1) * 35 + 1 + tt.ff[i]) * RS;
                 if constexpr (SPLIT) {
 #pragma unroll
                     for (int p = 0; p < 3; ++p)
@@ -1161,7 +1169,8 @@ __device__ __forceinline__ void gtconv_block(f32x4 (&x)[TPW], const Tiles<TPW>& 
     }
     // the decoder's hook started the next block's weight DMA two barriers ago; the VMK loads it issued behind the DMA
     // (en_outs[0] for the tail) stay in flight
-    if constexpr (DENSE && VMK1 < 0) wg_barrier_vm<VMK>();
+    if constexpr (VMC >= 0) wg_barrier_vm<VMC>();
+    else if constexpr (DENSE && VMK1 < 0) wg_barrier_vm<VMK>();
     else wg_barrier();               // (VMK1 >= 0: the DMA is waited for at the next block's first barrier)
     STAMP(SS, 7)
 #pragma unroll
@@ -1686,12 +1695,12 @@ segment_top:
             c.sTB = sTB;
             if constexpr (MS) {
                 const int sidx = min(tt.tl[0], NS - 1);
-                c.ms_roff = (int)(sH - sW) + sidx * RING_SET + k * (2 * 35 * 16);
-                c.ms_tb = sTB[sidx];
+                c.ms_roff[0] = (int)(sH - sW) + sidx * RING_SET + k * (2 * 35 * 16);
+                c.ms_tb[0] = sTB[sidx];
             } else {
-                c.ms_roff = 0; c.ms_tb = 0;
+                c.ms_roff[0] = 0; c.ms_tb[0] = 0;
             }
-            c.g_hist = nullptr;
+            c.g_hist[0] = nullptr;
             gtconv_block<false, TPW, MS, Q, RS, RS, !(FRONT && TPW == 3), LD::PT>(x, tt, c, L, [] {}, [] {} STAMP_ARG);
             if (k < 2) {
                 ht* dst = k == 0 ? en2h : en3h;
@@ -1864,7 +1873,7 @@ segment_top:
             c.sE = smem + LD::E;
             c.sY = sG + RW * 16;
             c.nfr = nfr; c.tabs = t0;
-            c.sTB = nullptr; c.ms_roff = 0; c.ms_tb = 0; c.g_hist = nullptr;
+            c.sTB = nullptr; c.ms_roff[0] = 0; c.ms_tb[0] = 0; c.g_hist[0] = nullptr;
             gtconv_block<false, TPWV, false, false, RS, LD::RSS, true, LD::PT, 0, -1, EP_NW, EP_RW * 33>(x, tt, c, L, [] {}, [] {} STAMP_ARG);
             if (k < 2) {
                 float* dst = k == 0 ? en2h : en3h;
@@ -2860,15 +2869,15 @@ segment_top:
             if constexpr (MS) {
                 const int sidx = min(tt.tl[0], NS - 1);
                 constexpr int RSM = SPLIT ? RS_WIDE : 16;      // record pitch of the LDS rings (rings_load_ms)
-                c.ms_roff = (int)(sH - sW) + sidx * (3 * 2 * 35 * RSM) + j * (2 * 35 * RSM);
-                c.ms_tb = sTB[sidx];
+                c.ms_roff[0] = (int)(sH - sW) + sidx * (3 * 2 * 35 * RSM) + j * (2 * 35 * RSM);
+                c.ms_tb[0] = sTB[sidx];
             } else {
-                c.ms_roff = 0; c.ms_tb = 0;
+                c.ms_roff[0] = 0; c.ms_tb[0] = 0;
             }
             // the next block's dense 3x3 (block 0 of the next chunk after the last one): the DMA starts once this block's
             // dense phase is over (the hook runs behind its closing barrier) and is waited for two barrier intervals
             // later, one barrier (the next block's point_conv1) before its first reader
-            c.g_hist = nullptr;
+            c.g_hist[0] = nullptr;
             gtconv_block<true, TPW, MS, Q, RS, LD::RSS, true, LD::PT, decltype(vmk)::value>(
                 x, tt, c, L, [&] { dense_fetch(j == 2 ? 0 : j + 1); hook(); }, [] {} STAMP_ARG);
             if (DBG)
@@ -3178,7 +3187,11 @@ __global__ __launch_bounds__(NTHR) void k_stream_ms(const float* __restrict__ sp
     const Lane L = lane_info();
     const int tid = L.tid, n = L.n, g = L.g;
     const int b = blockIdx.x;
+#ifdef GT_EXP_SAMESTATE   // timing experiment only (results are wrong): every workgroup works on the state of one of eight -- all
+    float* stb = state + (long)(b & 7) * NS * ST_FLOATS;       // state traffic hits in L2: what the step costs without HBM latency
+#else
     float* stb = state + (long)b * NS * ST_FLOATS;             // first stream of this workgroup
+#endif
     const int nlive = min(NS, NB - b * NS), nfr = nlive;
     const Tiles<1> tt = make_tiles<1>(L);
     const int row = min(tt.tl[0], NS - 1);                      // the lane's stream (tail lanes of the tile geometry: clamped)
@@ -3440,9 +3453,9 @@ __global__ __launch_bounds__(NTHR) void k_stream_ms(const float* __restrict__ sp
         c.sY = sG + RW * 16;
         c.nfr = nfr; c.tabs = 0;
         c.sTB = sTB;
-        c.ms_roff = (int)(smem + LD::HE - sWe) + row * (2 * 35 * 16);
-        c.ms_tb = tbl;
-        c.g_hist = stl + ST_ENC_H + ((k * 2 + (tbl & 1)) * 33 + ffl) * 16 + 4 * g;
+        c.ms_roff[0] = (int)(smem + LD::HE - sWe) + row * (2 * 35 * 16);
+        c.ms_tb[0] = tbl;
+        c.g_hist[0] = stl + ST_ENC_H + ((k * 2 + (tbl & 1)) * 33 + ffl) * 16 + 4 * g;
         if (k < 2) hist_fetch(ST_ENC_H + (k + 1) * 2 * 33 * 16, hv);
         else fetch_rows(stl + ST_G1_H);
         // the next block's history image is written once this block's taps are read (behind its third barrier); every
@@ -3515,9 +3528,9 @@ __global__ __launch_bounds__(NTHR) void k_stream_ms(const float* __restrict__ sp
         c.sY = sG + RW * 16;
         c.nfr = nfr; c.tabs = 0;
         c.sTB = sTB;
-        c.ms_roff = (int)(sHd - sW) + row * (2 * 35 * RS);
-        c.ms_tb = tbl;
-        c.g_hist = stl + ST_DEC_H + ((j * 2 + (tbl & 1)) * 33 + ffl) * 16 + 4 * g;
+        c.ms_roff[0] = (int)(sHd - sW) + row * (2 * 35 * RS);
+        c.ms_tb[0] = tbl;
+        c.g_hist[0] = stl + ST_DEC_H + ((j * 2 + (tbl & 1)) * 33 + ffl) * 16 + 4 * g;
         gtconv_block<true, 1, true, false, RS, 16, true, 35, 0, decltype(vmk1)::value>(
             x, tt, c, L, [&] { if (j < 2) dense_fetch(j + 1); hook(); }, hook3 STAMP_ARG);
         x[0] = x[0] + skv;
@@ -3631,6 +3644,651 @@ __global__ __launch_bounds__(NTHR) void k_stream_ms(const float* __restrict__ sp
     }
     // ------------------------------------------------------------------------------------------------- epilogue
     // energy rings and frame counters (the h rows and the TCN rows went out where they were produced)
+    if (tid < nlive * 48) {
+        const int sidx = tid / 48, e = tid - sidx * 48;
+        stb[(long)sidx * ST_FLOATS + ST_ENC_E + e] = sEHe[tid];
+        stb[(long)sidx * ST_FLOATS + ST_DEC_E + e] = sEHd[tid];
+    }
+    if (tid < nlive) reinterpret_cast<int*>(stb + (long)tid * ST_FLOATS)[0] = (sTB[tid] + 1) & 0xFFFF;
+    STAMP(SS, 15)
+    STAMP_OUT(SS, stamps)
+}
+
+// =============================================================================== streaming step, ONE launch, WIDE form
+// The same step as k_stream_ms for SEVEN streams per workgroup.  k_stream_ms is a chain of ~35 barrier-delimited phases
+// whose length hardly depends on the number of streams (65 k cycles for one stream, 75 k for four: profiles/
+// r04_phase_profile_stream.txt), so the lever for capacity (N >> 1024 streams per GPU) is more streams per workgroup;
+// what stood in the way was LDS: 86 KB of resident parameters.  Here:
+//   * eight waves x TWO tiles: 16 tiles = 256 positions for 7 x 33 = 231 (90 % of the lanes live; the 11 x 1 form: 75 %),
+//     two independent MFMA chains per wave, 256 VGPRs per wave;
+//   * the parameters are STREAMED, each segment by LDS-DMA a phase or more before its first reader:
+//       P1   encoder front end + blocks (19 KB)  -> after the encoder: decoder blocks, de_convs.3/4 (20 KB, same slot)
+//       GP   both GTCN stacks (19.6 KB)          -> into the dead EB / F0 region of the encoder front end, during the blocks
+//       DN   one decoder block's dense planes (15 KB), as in k_stream_ms;   BS  the ERB.bs table (4 KB)
+//     40 KB instead of 86 KB, which is what lets seven streams' images (en0, history, W / S / Z / M) fit in 160 KB;
+//   * images carry exactly NS rows; the nine lanes past position 231 (and the whole last tile) compute on whatever they
+//     read and store nothing (gtconv_block PMAX).
+// Same helper code and source expressions as k_stream_ms and the three-launch form: bit-identical outputs and state
+// (tests/test_gpu_stream.py).  Chosen by launch_stream_step for stream counts that fill the chip more than once.
+struct SwCfg {
+    static constexpr int NWV = 8, NT = NWV * 64, TPW = 2, NS = 7, RW = 7, RWG = 8, PMAX = NS * 33;
+    static_assert(NWV * TPW * 16 >= PMAX && RWG * 33 >= NWV * TPW * 16, "tiles cover the streams; gate rows cover the tiles");
+};
+template <class CF>
+struct SwLds {
+    static constexpr int RW = CF::RW, NS = CF::NS;
+    static constexpr bool SPLIT = kSplitDense;
+    static constexpr int P1SZ = ((ENC_SIZE > DL_DN ? ENC_SIZE : DL_DN) + 3) & ~3;
+    static constexpr int P1 = 0;                                  // encoder segment, later the decoder's DL_* layout up to DL_DN
+    static constexpr int DN = P1 + P1SZ;                          // dense stage buffer
+    static constexpr int BS = DN + (SPLIT ? DN16_SIZE : 9 * 256);
+    static constexpr int I = BS + NBINS * 4;
+    static constexpr int EHE = I + ((P_INTS - ENC_I_SKIP + 3) & ~3);
+    static constexpr int EHD = EHE + NS * 48;
+    static constexpr int TB = EHD + NS * 48;
+    static constexpr int G = TB + 8;
+    static constexpr int E = G + CF::RWG * 16 + CF::RWG * 8;
+    static constexpr int EN0 = E + ((NS * 24 + 3) & ~3);
+    static constexpr int X = EN0 + NS * F1 * 16;                  // ---- region shared by the encoder, GTCN and decoder phases
+    static constexpr int HE = X;                                  // encoder: history image [NS][2][35][16]
+    static constexpr int A = HE + NS * 2 * 35 * 16;               //          staged spectrogram, then E0, then W + S (both inside A)
+    static constexpr int SE = A + RW * 35 * 16;
+    static constexpr int B = A + RW * ENC_E0_ROW * 16;            //          EB + F0; from the first block on: the GTCN parameters
+    static constexpr int BSZ = (3 * RW * EB_ROW + 3 * RW * F0_ROW + 3) & ~3;
+    static constexpr int GP = B;
+    static constexpr int ENC_END = B + BSZ;
+    static constexpr int RSD = RS_WIDE;                           // decoder: 96-byte records (split planes)
+    static constexpr int HD = X;                                  //          history image [NS][2][35][24]
+    static constexpr int W = HD + NS * 2 * 35 * RSD;
+    static constexpr int SD = W + RW * 35 * RSD;
+    static constexpr int ZSZ = RW * DEC_Z_ROW * DEC_ZS;
+    static constexpr int M = W + ZSZ;
+    static constexpr int MSZ = (2 * RW * F0 + 4 + 3) & ~3;
+    static constexpr int DEC_END = (SD + RW * 33 * 16) > (M + MSZ) ? (SD + RW * 33 * 16) : (M + MSZ);
+    static constexpr int FLOATS = ENC_END > DEC_END ? ENC_END : DEC_END;
+    static_assert(FLOATS * 4 <= 160 * 1024, "wide streaming step: LDS budget");
+    static_assert(SE + RW * 33 * 16 <= B && 3 * RW * NBINS <= RW * ENC_E0_ROW * 16, "encoder overlay: W + S inside the E0 region");
+    static_assert(2 * GTCN_SIZE <= BSZ, "the GTCN parameters fit the EB / F0 region");
+    static_assert(CF::NWV * 320 <= RW * 33 * 16 && CF::NWV * 320 <= BSZ, "wave-private permutation scratch");
+    static_assert(DN % 4 == 0 && BS % 4 == 0 && I % 4 == 0 && EHE % 4 == 0 && G % 4 == 0 && E % 4 == 0 && EN0 % 4 == 0 &&
+                  X % 4 == 0 && A % 4 == 0 && B % 4 == 0 && SE % 4 == 0 && W % 4 == 0 && SD % 4 == 0 && M % 4 == 0, "16B carve");
+};
+constexpr int SW_LDS_FLOATS = SwLds<SwCfg>::FLOATS;
+
+template <int D, int N>
+__device__ __forceinline__ void tcn_block_msn(f32x4 (&x)[N], const float* pk, const f32x4 (&t1)[N], const f32x4 (&t2)[N],
+                                              float* const (&ring_r2)[N], const bool (&live)[N], int n, int g) {
+    // (tcn_block_ms for N tiles of a wave: the same expressions per tile, the tiles' MFMA chains interleaved)
+    const float a1 = pk[TCN_SLOPE] - 1.0f, a2 = pk[TCN_SLOPE + 1] - 1.0f, a3 = pk[TCN_SLOPE + 2] - 1.0f;
+    f32x4 y1[N], acc[N];
+    {
+        const f32x4 A = ld4(pk + TCN_A1 + arow(n, g)), Bv = ld4(pk + TCN_B1 + 4 * g);
+#pragma unroll
+        for (int i = 0; i < N; ++i) acc[i] = Bv;
+        mm16<N>(A, x, acc);
+#pragma unroll
+        for (int i = 0; i < N; ++i) y1[i] = prelu4(acc[i], a1);
+    }
+    {
+        const f32x4 w0 = ld4(pk + TCN_DW + 4 * g), w1 = ld4(pk + TCN_DW + 16 + 4 * g),
+                    w2 = ld4(pk + TCN_DW + 32 + 4 * g), B2 = ld4(pk + TCN_B2 + 4 * g);
+        const f32x4 A = ld4(pk + TCN_A3 + arow(n, g)), B3 = ld4(pk + TCN_B3 + 4 * g);
+        f32x4 y2[N];
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            y2[i] = prelu4(B2 + w0 * t2[i] + w1 * t1[i] + w2 * y1[i], a2);
+            acc[i] = B3 + x[i];
+        }
+        mm16<N>(A, y2, acc);
+#pragma unroll
+        for (int i = 0; i < N; ++i) x[i] = prelu4(acc[i], a3);
+    }
+#pragma unroll
+    for (int i = 0; i < N; ++i)
+        if (live[i]) st4(ring_r2[i], y1[i]);
+}
+
+template <class CF>
+__global__ __launch_bounds__(CF::NT) void k_stream_wide(const float* __restrict__ spec, long sb, long sf,
+                                                       float* __restrict__ out, long osb, long osf, int NB,
+                                                       const float* __restrict__ PF, const int* __restrict__ PI,
+                                                       float* __restrict__ state, unsigned long long* __restrict__ stamps) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    STAMP_INIT(SS)
+    using LD = SwLds<CF>;
+    constexpr int RW = CF::RW, NS = CF::NS, NWV = CF::NWV, NT = CF::NT, TPW = CF::TPW, PMAX = CF::PMAX;
+    constexpr bool SPLIT = kSplitDense;
+    constexpr bool SPLIT3 = SPLIT && kSplitDe3;
+    float* sP1 = smem + LD::P1;
+    float* sPE = sP1;                                              // P1 while the encoder runs ...
+    float* sPD = sP1;                                              // ... and from the GTCN on (DL_* offsets below DL_DN)
+    float* sDN = smem + LD::DN;
+    float* sPG = smem + LD::GP;
+    int* sI = reinterpret_cast<int*>(smem + LD::I);
+    float* sBS = smem + LD::BS;
+    float* sEHe = smem + LD::EHE;
+    float* sEHd = smem + LD::EHD;
+    int* sTB = reinterpret_cast<int*>(smem + LD::TB);
+    float* sG = smem + LD::G;
+    float* sEN0 = smem + LD::EN0;
+    const Lane L = lane_info();
+    const int tid = L.tid, n = L.n, g = L.g;
+    const int b = blockIdx.x;
+#ifdef GT_EXP_SAMESTATE   // timing experiment only (results are wrong): every workgroup works on the state of one of eight -- all
+    float* stb = state + (long)(b & 7) * NS * ST_FLOATS;       // state traffic hits in L2: what the step costs without HBM latency
+#else
+    float* stb = state + (long)b * NS * ST_FLOATS;             // first stream of this workgroup
+#endif
+    const int nlive = min(NS, NB - b * NS), nfr = nlive;
+    const Tiles<TPW> tt = make_tiles<TPW, NWV>(L);
+    int row[TPW], ffl[TPW];
+    bool lane_live[TPW];
+    float* stl[TPW];
+#pragma unroll
+    for (int i = 0; i < TPW; ++i) {
+        row[i] = min(tt.tl[i], NS - 1);                         // the lane's stream (lanes past the last stream: clamped)
+        lane_live[i] = tt.tl[i] < nlive;
+        stl[i] = stb + (long)(lane_live[i] ? tt.tl[i] : 0) * ST_FLOATS;
+        ffl[i] = lane_live[i] ? tt.ff[i] : 0;
+    }
+
+    constexpr int DN_PIECES = (SPLIT ? DN16_SIZE : 9 * 256) / 256;
+    auto dense_fetch = [&](int j) {                                 // decoder block j's dense 3x3 -> stage buffer (see k_decoder)
+        const float* src = PF + P_DEC + (SPLIT ? D_DN16 + j * DN16_SIZE : D_BLK + j * GBD_SIZE + GB_DN_A);
+        int lz = L.lane;
+        asm volatile("" : "+v"(lz));
+        for (int pi = L.wave; pi < DN_PIECES; pi += NWV) lds_dma_1k(src + pi * 256 + 4 * lz, sDN + pi * 256);
+    };
+    // history rows of one block, all streams of the workgroup (k_stream_ms: hist_fetch / hist_store), HI items per thread
+    constexpr int HI = (NS * 264 + NT - 1) / NT;
+    auto hist_fetch = [&](int st_off, f32x4 (&v)[HI]) {
+#pragma unroll
+        for (int q = 0; q < HI; ++q) {
+            const int i = tid + q * NT, sidx = i / 264, r = i - sidx * 264;
+            const bool ok = i < NS * 264 && sidx < nlive;
+            v[q] = ld4(stb + (ok ? (long)sidx * ST_FLOATS + st_off + r * 4 : (long)ST_ENC_H));   // clamped: a valid record
+        }
+    };
+    auto hist_store = [&](float* img, auto split, const f32x4 (&v)[HI]) {
+        constexpr bool SP = decltype(split)::value;
+        constexpr int RS = SP ? RS_WIDE : 16;
+#pragma unroll
+        for (int q = 0; q < HI; ++q) {
+            const int i = tid + q * NT, sidx = i / 264, r = i - sidx * 264;
+            if (i < NS * 264) {
+                const int rw = r >= 132 ? 1 : 0, rr = r - rw * 132;
+                const f32x4 val = sidx < nlive ? v[q] : splat(0.f);
+                const int rec = (sidx * 2 * 35 + rw * 35 + 1 + (rr >> 2)) * RS;
+                if constexpr (SP) st_split(img, rec, rr & 3, val);
+                else st4(img + rec + 4 * (rr & 3), val);
+            }
+        }
+    };
+    auto hist_zero_pads = [&](float* img, int rs) {               // columns 0 and 34 of the NS * 2 image rows
+        static_assert(NS * 2 * 2 * 8 <= NT, "one thread per 16-byte piece");
+        if (tid < NS * 2 * 2 * 8) {
+            const int rw = tid >> 4, side = (tid >> 3) & 1, gg = tid & 7;
+            if (gg < rs / 4) st4(img + (rw * 35 + side * 34) * rs + 4 * gg, splat(0.f));
+        }
+    };
+    // spectrogram items of a thread: element idx = tid + q * NT of the [stream][bin] step, bin fastest
+    constexpr int SPEC_ITEMS = (NS * NBINS + NT - 1) / NT;
+    auto spec_item = [&](int tz, int q, int& tq, int& f) {
+        const int idx = tz + q * NT;
+        tq = idx / NBINS;
+        f = idx - tq * NBINS;
+    };
+
+    // ------------------------------------------------------------------------------------------------- prologue
+    // group A  encoder front end (ERB bands, SFE, en_convs.0/1) -> P1, waited for at the first barrier
+    // group B  the three encoder blocks -> P1, counted wait at the barrier behind en_conv1
+    // group D0 the ERB.bs table and decoder block 0's dense planes -> their own buffers (first read in the decoder)
+    // B and D0 are issued BEHIND the consumption of this phase's register loads (see lds_dma_1k)
+    constexpr int DMA_A = ((E_BLK + 255) / 256 + NWV - 1) / NWV;
+    constexpr int DMA_B = ((ENC_SIZE - E_BLK + 255) / 256 + NWV - 1) / NWV;
+    constexpr int DMA_D0 = ((NBINS * 4 + 255) / 256 + DN_PIECES + NWV - 1) / NWV;   // (issued behind the GTCN, see there)
+    {
+        const DmaSeg ga[1] = {{P_ENC, LD::P1, E_BLK}};
+        lds_dma_group<1, DMA_A, NWV>(ga, PF, smem, L.wave, L.lane);
+    }
+    for (int i = tid; i < P_INTS - ENC_I_SKIP; i += NT) sI[i] = PI[i < I_BS_LO ? i : i + ENC_I_SKIP];
+    if (tid < NS * 48) {
+        const int sidx = tid / 48, e = tid - sidx * 48;
+        sEHe[tid] = sidx < nlive ? stb[(long)sidx * ST_FLOATS + ST_ENC_E + e] : 0.f;
+        sEHd[tid] = sidx < nlive ? stb[(long)sidx * ST_FLOATS + ST_DEC_E + e] : 0.f;
+    }
+    if (tid < 8) sTB[tid] = tid < nlive ? reinterpret_cast<const int*>(stb + (long)tid * ST_FLOATS)[0] : 0;
+    f32x4 hv[HI];
+    hist_fetch(ST_ENC_H, hv);
+    hist_zero_pads(smem + LD::HE, 16);
+
+    // ------------------------------------------------------------------------------------------------- encoder
+    float* sSpec = smem + LD::A;
+    float* sE0 = smem + LD::A;
+    float* sWe = smem + LD::A;
+    float* sSe = smem + LD::SE;
+    float* sEB = smem + LD::B;
+    float* sF0 = sEB + 3 * RW * EB_ROW;
+    const int sf32 = (int)sf, st32 = (int)sb;
+    float2 spn[SPEC_ITEMS];                                        // kept for the mask at the end of the step
+    {
+        const float* base = spec + (long)b * NS * sb;
+#pragma unroll
+        for (int q = 0; q < SPEC_ITEMS; ++q) {
+            int tl, f;
+            spec_item(tid, q, tl, f);
+            const bool ok = tl < nfr;                              // (f < NBINS by construction)
+            spn[q] = *reinterpret_cast<const float2*>(base + (ok ? f * sf32 + tl * st32 : 0));
+        }
+    }
+    hist_store(smem + LD::HE, std::false_type{}, hv);
+    if (tid < 3 * RW * 9) {                                        // zero pad entries of EB / F0
+        const int rw = tid / 9, e = tid - rw * 9;
+        if (e < 2) sEB[rw * EB_ROW + e * 130] = 0.f;
+        else sF0[rw * F0_ROW + (e < 4 ? e - 2 : 127 + e)] = 0.f;
+    }
+    {   // A0: [mag, re, im] of the new frames
+#pragma unroll
+        for (int q = 0; q < SPEC_ITEMS; ++q) {
+            int tl, f;
+            spec_item(tid, q, tl, f);
+            if (tl < nfr) {
+                const float2 v = spn[q];
+                const bool low = f < ERB_LOW;
+                float* d = low ? sEB + tl * EB_ROW + 1 + f : sSpec + tl * NBINS + f;
+                const int cs = low ? RW * EB_ROW : RW * NBINS;
+                d[0] = __builtin_amdgcn_sqrtf(v.x * v.x + v.y * v.y + 1e-12f);
+                d[cs] = v.x;
+                d[2 * cs] = v.y;
+            }
+        }
+    }
+    // the spectrogram items wait for the mask phase in LDS until the decoder starts (lane-private pieces in the dense stage
+    // buffer and the ERB.bs table's place, both first needed by the decoder): eight registers less through the encoder
+    // and the GTCN, the kernel's register peak
+    float* sParkS = smem + LD::DN + 4 * tid;
+    static_assert(SPEC_ITEMS % 2 == 0 && SPEC_ITEMS / 2 * NT * 4 <= LD::I - LD::DN, "parked spectrogram items fit DN + BS");
+#pragma unroll
+    for (int q = 0; q < SPEC_ITEMS; q += 2) {
+        const f32x4 pk = {spn[q].x, spn[q].y, spn[q + 1].x, spn[q + 1].y};
+        st4(sParkS + (q / 2) * NT * 4, pk);
+    }
+    {
+        const DmaSeg gb[1] = {{P_ENC + E_BLK, LD::P1 + E_BLK, ENC_SIZE - E_BLK}};
+        lds_dma_group<1, DMA_B, NWV>(gb, PF, smem, L.wave, L.lane);
+    }
+    wg_barrier_vm<DMA_B>();                                        // group A has landed; B stays in flight
+    STAMP(SS, 0)
+    {   // A: ERB.bm bands
+        const int band = tid & (ERB_BANDS - 1);
+        const int lo = sI[I_ERB_LO + band], cnt = sI[I_ERB_N + band];
+        float w[ERB_MAXBW];
+#pragma unroll
+        for (int i = 0; i < ERB_MAXBW; i += 4) {
+            const f32x4 t = ld4(sPE + E_ERB_W + band * ERB_MAXBW + i);
+            w[i] = t[0]; w[i + 1] = t[1]; w[i + 2] = t[2]; w[i + 3] = t[3];
+        }
+        for (int ct = tid >> 6; ct < 3 * RW; ct += NWV) {
+            if ((ct % RW) >= nfr) continue;
+            const float* sp = sSpec + ct * NBINS + ERB_LOW + lo;
+            float a0 = 0.f, a1 = 0.f;
+#pragma unroll
+            for (int i = 0; i < ERB_MAXBW; i += 2) {
+                a0 += w[i] * (i < cnt ? sp[i] : 0.f);
+                a1 += w[i + 1] * (i + 1 < cnt ? sp[i + 1] : 0.f);
+            }
+            sEB[ct * EB_ROW + 1 + ERB_LOW + band] = a0 + a1;
+        }
+    }
+    wg_barrier();
+    STAMP(SS, 1)
+    // B: SFE_Lite
+    for (int rw = L.wave; rw < 3 * RW; rw += NWV) {
+        const int tl = rw % RW, c = rw / RW;
+        if (tl >= nfr) continue;
+        const float w0 = sPE[E_SFE_W + c * 3], w1 = sPE[E_SFE_W + c * 3 + 1], w2 = sPE[E_SFE_W + c * 3 + 2];
+        const float* e = sEB + rw * EB_ROW;
+        float* d = sF0 + rw * F0_ROW + 2;
+        const int f = tid & 63;
+        d[f] = w0 * e[f] + w1 * e[f + 1] + w2 * e[f + 2];
+        d[f + 64] = w0 * e[f + 64] + w1 * e[f + 65] + w2 * e[f + 66];
+        if (f == 0) d[128] = w0 * e[128] + w1 * e[129] + w2 * e[130];
+    }
+    if (tid < RW * 4 * 4) {                                        // pad positions of E0
+        const int r = tid >> 4, cc = (tid >> 2) & 3, gg = tid & 3;
+        st4(sE0 + pl(r * ENC_E0_ROW + (cc < 2 ? cc : 65 + cc), gg), splat(0.f));
+    }
+    wg_barrier();
+    STAMP(SS, 2)
+    {   // C: en_convs.0; en0 stays in LDS for the decoder tail
+        const f32x4 A = ld4(sPE + E_EN0_A + arow(n, g)), Bv = ld4(sPE + E_EN0_B + 4 * g);
+        const float a = sPE[E_EN0_S] - 1.0f;
+        int off[4];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const int e = 4 * g + s, c = e < 15 ? e / 5 : 0, k = e < 15 ? e % 5 : 0;
+            off[s] = c * RW * F0_ROW + k;
+        }
+        const int nt0 = (nfr * F1 + 15) >> 4;
+        for (int tile = L.wave; tile < nt0; tile += NWV) {
+            const int q = tile * 16 + n;
+            int tl = q / F1;
+            const int fo = q - tl * F1;
+            if (tl >= RW) tl = RW - 1;
+            f32x4 bv;
+#pragma unroll
+            for (int s = 0; s < 4; ++s) bv[s] = sF0[off[s] + tl * F0_ROW + 2 * fo];
+            f32x4 acc = mm1<false>(A, bv, Bv);
+            acc = prelu4(acc, a);
+            if (q < RW * F1) st4(sE0 + pl(tl * ENC_E0_ROW + 2 + fo, g), acc);
+            if (q < nfr * F1) st4(sEN0 + q * 16 + 4 * g, acc);
+        }
+    }
+    wg_barrier();
+    STAMP(SS, 3)
+    f32x4 x[TPW], en1p[TPW], en2p[TPW], en3p[TPW];
+    {   // D: en_convs.1; en1 is kept in the slot order of its decoder consumer
+        const f32x4 Bv = ld4(sPE + E_EN1_B + 4 * g);
+        const float a = sPE[E_EN1_S] - 1.0f;
+        const int* ix = sI + I_ENST - ENC_I_SKIP + 0 * 16 + 4 * g;
+#pragma unroll
+        for (int i = 0; i < TPW; ++i) x[i] = Bv;
+#pragma unroll
+        for (int k = 0; k < 5; ++k) {
+            const f32x4 A = ld4(sPE + E_EN1_A + k * 256 + arow(n, g));
+#pragma unroll
+            for (int i = 0; i < TPW; ++i) {
+                const f32x4 tap = ld4(sE0 + pl(row[i] * ENC_E0_ROW + 2 * tt.ff[i], g) + k * 16);
+                x[i] = mm1<false>(A, tap, x[i]);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < TPW; ++i) {
+            x[i] = prelu4(x[i], a);
+            en1p[i] = permute_via_lds(sEB + (L.wave * 16 + n) * PERM_RS, ix, g, x[i]);
+        }
+    }
+    wg_barrier_vm<0>();                                            // E0, EB, F0 are dead; group B (block parameters) has landed
+    STAMP(SS, 4)
+    // group C: both GTCN stacks -> the EB / F0 region; first read behind the last encoder block's closing barrier
+    {
+        constexpr int DMA_C = ((2 * GTCN_SIZE + 255) / 256 + NWV - 1) / NWV;
+        const DmaSeg gc[1] = {{P_GTCN, LD::GP, 2 * GTCN_SIZE}};
+        lds_dma_group<1, DMA_C, NWV>(gc, PF, smem, L.wave, L.lane);
+    }
+    zero_row_pads<RW, 16, 35>(sWe, tid);
+    // GTCN history rows of the lane's positions (k_gtcn_ms): requested during the last encoder block
+    int tbl[TPW];
+#pragma unroll
+    for (int i = 0; i < TPW; ++i) tbl[i] = sTB[row[i]];
+    f32x4 t1[4][TPW], t2[4][TPW];
+    int r2[4][TPW];
+    auto fetch_rows = [&](int st_off) {
+#pragma unroll
+        for (int i = 0; i < TPW; ++i) {
+            const float* ring = stl[i] + st_off;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int d = 1 << k, m2d = 2 * d - 1, row0 = 2 * (d - 1);
+                const int r1 = ((row0 + ((tbl[i] + d) & m2d)) * 33 + ffl[i]) * 16 + 4 * g;
+                r2[k][i] = ((row0 + (tbl[i] & m2d)) * 33 + ffl[i]) * 16 + 4 * g;
+                t1[k][i] = ld4(ring + r1);
+                t2[k][i] = ld4(ring + r2[k][i]);
+            }
+        }
+    };
+    auto fill_ctx = [&](BlockCtx& c, const float* pb, const float* gA, const int* ib, float* sW, float* sS, float* sEHk,
+                        int roff0, int hrs, int st_h, int blk) {
+        c.pb = pb; c.gA = gA; c.ib = ib;
+        c.sW = sW; c.sHk = nullptr; c.sS = sS; c.sG = sG; c.sEHk = sEHk;
+        c.sHtop = nullptr; c.sHnext = nullptr;
+        c.sE = smem + LD::E;
+        c.sY = sG + CF::RWG * 16;
+        c.nfr = nfr; c.tabs = 0;
+        c.sTB = sTB;
+#pragma unroll
+        for (int i = 0; i < TPW; ++i) {
+            c.ms_roff[i] = roff0 + row[i] * (2 * 35 * hrs);
+            c.ms_tb[i] = tbl[i];
+            c.g_hist[i] = stl[i] + st_h + ((blk * 2 + (tbl[i] & 1)) * 33 + ffl[i]) * 16 + 4 * g;
+        }
+    };
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        BlockCtx c;
+        fill_ctx(c, sPE + E_BLK + k * GB_SIZE, nullptr, sI + I_ENC_BLK - ENC_I_SKIP + k * 16, sWe, sSe, sEHe + k * 16,
+                 (int)(smem + LD::HE - sWe), 16, ST_ENC_H, k);
+        if (k < 2) hist_fetch(ST_ENC_H + (k + 1) * 2 * 33 * 16, hv);
+        else fetch_rows(ST_G1_H);
+        // (k == 2: the closing barrier also waits for the wave's vector memory: the GTCN parameters -- issued two blocks
+        // ago -- are then visible to every wave; the row loads above are a block old by then)
+        if (k < 2)
+            gtconv_block<false, TPW, true, false, 16, 16, true, 35, 0, -1, NWV, PMAX, -1>(
+                x, tt, c, L, [] {}, [&] { hist_store(smem + LD::HE, std::false_type{}, hv); } STAMP_ARG);
+        else
+            gtconv_block<false, TPW, true, false, 16, 16, true, 35, 0, -1, NWV, PMAX, 0>(x, tt, c, L, [] {}, [] {} STAMP_ARG);
+        if (k < 2) {
+            const int* ix = sI + I_ENST - ENC_I_SKIP + (k + 1) * 16 + 4 * g;
+#pragma unroll
+            for (int i = 0; i < TPW; ++i) {
+                // (wave-private scratch inside S: free from the block's closing barrier to the next block's second phase)
+                const f32x4 y = permute_via_lds(sSe + (L.wave * 16 + n) * PERM_RS, ix, g, x[i]);
+                if (k == 0) en2p[i] = y; else en3p[i] = y;
+            }
+        }
+        STAMP(SS, 8)
+    }
+#ifdef GT_STAMPS
+    SS.acc[10] = SS.acc[5]; SS.acc[11] = SS.acc[6]; SS.acc[12] = SS.acc[7];
+    SS.acc[5] = SS.acc[6] = SS.acc[7] = 0;
+#endif
+    // ------------------------------------------------------------------------------------------------- GTCN x 2
+    // every wave is behind the encoder's last barrier: the encoder parameters are dead, P1 takes the decoder's blocks
+    // (without their dense matrices) and the de_convs.3/4 segment -- group D1, first read behind the barrier after the GTCN
+    {
+        constexpr int D1_PIECES = 3 * ((GB_SIZE + 255) / 256) + (SPLIT3 ? DE3_16_MATS : 5) + (D_BS_W - D_DE3_B + 255) / 256;
+        constexpr int DMA_D1 = (D1_PIECES + NWV - 1) / NWV;
+        const DmaSeg gd[5] = {{P_DEC + D_BLK + 0 * GBD_SIZE, LD::P1 + 0 * GB_SIZE, GB_SIZE},
+                              {P_DEC + D_BLK + 1 * GBD_SIZE, LD::P1 + 1 * GB_SIZE, GB_SIZE},
+                              {P_DEC + D_BLK + 2 * GBD_SIZE, LD::P1 + 2 * GB_SIZE, GB_SIZE},
+                              {P_DEC + (SPLIT3 ? D_DE3_16 : D_DE3_AE), LD::P1 + DL_DE3M, SPLIT3 ? DE3_16_MATS * 256 : 5 * 256},
+                              {P_DEC + D_DE3_B, LD::P1 + DL_DE, D_BS_W - D_DE3_B}};
+        lds_dma_group<5, DMA_D1, NWV>(gd, PF, smem, L.wave, L.lane);
+    }
+    // The three skips wait out the GTCN in LDS (lane-private 16-byte pieces in the dead encoder images, no barrier: a lane
+    // reads back what it wrote): with the rows of four TCN blocks x two tiles in registers the GTCN is the kernel's
+    // register peak, and the skips -- live from the encoder to the decoder -- would otherwise go to scratch.
+    float* sPark = smem + LD::X + 4 * tid;
+    static_assert(3 * TPW * NT * 4 <= LD::GP - LD::X, "parked skips fit the dead encoder images");
+#pragma unroll
+    for (int i = 0; i < TPW; ++i) {
+        st4(sPark + (0 * TPW + i) * NT * 4, en1p[i]);
+        st4(sPark + (1 * TPW + i) * NT * 4, en2p[i]);
+        st4(sPark + (2 * TPW + i) * NT * 4, en3p[i]);
+    }
+    {
+        f32x4 x0[TPW];
+#pragma unroll
+        for (int i = 0; i < TPW; ++i) x0[i] = x[i];
+#pragma unroll
+        for (int stack = 0; stack < 2; ++stack) {
+            const int st_off = stack == 0 ? ST_G1_H : ST_G2_H;
+            const float* pk = sPG + stack * GTCN_SIZE;
+            // (the second stack's rows of block k are requested as soon as the first stack's block k has used its own: the
+            // same registers, four blocks of lead time -- holding both stacks' rows at once does not fit 256 VGPRs)
+            auto blk = [&](auto kc, auto dc) {
+                constexpr int k = decltype(kc)::value, D = decltype(dc)::value;
+                float* q2[TPW];
+#pragma unroll
+                for (int i = 0; i < TPW; ++i) q2[i] = stl[i] + st_off + r2[k][i];
+                tcn_block_msn<D, TPW>(x, pk + k * TCN_SIZE, t1[k], t2[k], q2, lane_live, n, g);
+                // (one TCN block's parameter reads in flight at a time: hoisted across blocks they push the long-lived skips
+                // and the spectrogram into scratch)
+                __builtin_amdgcn_sched_barrier(0);
+                if (stack == 0) {
+#pragma unroll
+                    for (int i = 0; i < TPW; ++i) {
+                        const float* ring = stl[i] + ST_G2_H;
+                        constexpr int m2d = 2 * D - 1, row0 = 2 * (D - 1);
+                        t1[k][i] = ld4(ring + ((row0 + ((tbl[i] + D) & m2d)) * 33 + ffl[i]) * 16 + 4 * g);
+                        t2[k][i] = ld4(ring + r2[k][i]);
+                    }
+                }
+            };
+            blk(std::integral_constant<int, 0>{}, std::integral_constant<int, 1>{});
+            blk(std::integral_constant<int, 1>{}, std::integral_constant<int, 2>{});
+            // the decoder's first history image: requested where the second stack has released half of its row registers
+            if (stack == 1) hist_fetch(ST_DEC_H, hv);
+            blk(std::integral_constant<int, 2>{}, std::integral_constant<int, 4>{});
+            blk(std::integral_constant<int, 3>{}, std::integral_constant<int, 8>{});
+        }
+#pragma unroll
+        for (int i = 0; i < TPW; ++i) x[i] = x[i] + x0[i];         // gtcn2(gtcn1(x)) + en_outs[4] (Decoder.forward :467)
+    }
+#pragma unroll
+    for (int i = 0; i < TPW; ++i) {                                // the skips come back before the decoder's images take the region
+        en1p[i] = ld4(sPark + (0 * TPW + i) * NT * 4);
+        en2p[i] = ld4(sPark + (1 * TPW + i) * NT * 4);
+        en3p[i] = ld4(sPark + (2 * TPW + i) * NT * 4);
+    }
+#pragma unroll
+    for (int q = 0; q < SPEC_ITEMS; q += 2) {
+        const f32x4 pk = ld4(sParkS + (q / 2) * NT * 4);
+        spn[q] = make_float2(pk[0], pk[1]);
+        spn[q + 1] = make_float2(pk[2], pk[3]);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    STAMP(SS, 9)
+    // ------------------------------------------------------------------------------------------------- decoder
+    constexpr int RS = LD::RSD;
+    float* sHd = smem + LD::HD;
+    float* sW = smem + LD::W;
+    float* sS = smem + LD::SD;
+    float* sZ = smem + LD::W;
+    float* sM = smem + LD::M;
+    constexpr int ZS = DEC_ZS;
+    // Behind this barrier every wave has left the GTCN: its parameters and the parked skips are dead, the region takes the
+    // decoder's images (block 0 reads them behind its first barrier); group D1 has landed.
+    wg_barrier_vm<0>();
+    {   // group D0: the ERB.bs table and block 0's dense planes take the place of the parked spectrogram items; every wave
+        // issues the HI history loads of block 1 behind it, so block 0's first barrier (VMK1 = HI) retires it
+        const DmaSeg gd[2] = {{P_DEC + D_BS_TAB, LD::BS, NBINS * 4},
+                              {P_DEC + (SPLIT ? D_DN16 : D_BLK + GB_DN_A), LD::DN, DN_PIECES * 256}};
+        lds_dma_group<2, DMA_D0, NWV>(gd, PF, smem, L.wave, L.lane);
+    }
+    hist_zero_pads(sHd, RS);
+    if constexpr (SPLIT) hist_store(sHd, std::true_type{}, hv);
+    else hist_store(sHd, std::false_type{}, hv);
+    zero_row_pads<RW, RS>(sW, tid);
+    STAMP(SS, 13)
+    const int npos = nfr * 33;
+    f32x4 s0e[TPW], s0o[TPW];
+    auto run_block = [&](int j, const f32x4 (&skv)[TPW], auto&& hook, auto&& hook3, auto vmk1) {
+        BlockCtx c;
+        fill_ctx(c, sPD + j * GB_SIZE, sDN, sI + I_DEC_BLK - ENC_I_SKIP + j * 16, sW, sS, sEHd + j * 16, (int)(sHd - sW), RS,
+                 ST_DEC_H, j);
+        gtconv_block<true, TPW, true, false, RS, 16, true, 35, 0, decltype(vmk1)::value, NWV, PMAX>(
+            x, tt, c, L, [&] { if (j < 2) dense_fetch(j + 1); hook(); }, hook3 STAMP_ARG);
+#pragma unroll
+        for (int i = 0; i < TPW; ++i) x[i] = x[i] + skv[i];
+        STAMP(SS, 8)
+    };
+    // (first-barrier wait of a block = the vector-memory operations EVERY wave issues behind the DMA of its planes: blocks
+    // 0 and 1 the HI history loads of the next block; block 2 none)
+    hist_fetch(ST_DEC_H + 1 * 2 * 33 * 16, hv);
+    run_block(0, en3p, [] {},
+              [&] { if constexpr (SPLIT) hist_store(sHd, std::true_type{}, hv); else hist_store(sHd, std::false_type{}, hv); },
+              std::integral_constant<int, HI>{});
+    hist_fetch(ST_DEC_H + 2 * 2 * 33 * 16, hv);
+    run_block(1, en2p, [] {},
+              [&] { if constexpr (SPLIT) hist_store(sHd, std::true_type{}, hv); else hist_store(sHd, std::false_type{}, hv); },
+              std::integral_constant<int, HI>{});
+    run_block(2, en1p, [&] {
+        // en_outs[0] for the even / odd output bins of the lane's positions, from LDS
+#pragma unroll
+        for (int i = 0; i < TPW; ++i) {
+            const int o0 = (tt.pp(i) < npos ? tt.tl[i] * F1 + 2 * tt.ff[i] : 0) * 16 + 4 * g;
+            s0e[i] = ld4(sEN0 + o0);
+            s0o[i] = ld4(sEN0 + o0 + (tt.ff[i] < 32 ? 16 : 0));
+        }
+    }, [] {}, std::integral_constant<int, 0>{});
+    // ---- de_convs.3 (gather form) + de_convs.4 (scatter form)
+    int rec3[TPW];
+#pragma unroll
+    for (int i = 0; i < TPW; ++i) {
+        rec3[i] = o35<RS, 0>(tt, i, 0);
+        if (i < TPW - 1 || tt.pp(i) < PMAX) {
+            if constexpr (SPLIT3) st_split(sW, rec3[i], g, x[i]);
+            else st4(sW + rec3[i] + 4 * g, x[i]);
+        }
+    }
+    wg_barrier();
+    f32x4 ze[TPW], zo[TPW];
+    {
+        const f32x4 Bv = ld4(sPD + dl(D_DE3_B) + 4 * g);
+        const float a = sPD[dl(D_DE3_S)] - 1.0f;
+        f32x4 ae[TPW], ao[TPW];
+        de_conv3_tiles<TPW, SPLIT3, false, RS>(sW, rec3, x, sPD + DL_DE3M, Bv, n, g, ae, ao);
+        const f32x4 A4 = ld4(sPD + dl(D_DE4_A) + arow(n, g));
+#pragma unroll
+        for (int i = 0; i < TPW; ++i) {
+            f32x4 e2 = prelu4(ae[i], a), o2 = prelu4(ao[i], a);
+            e2 = e2 + s0e[i];
+            o2 = o2 + s0o[i];
+            ze[i] = mm1<false>(A4, e2, splat(0.f));
+            zo[i] = mm1<false>(A4, o2, splat(0.f));
+        }
+    }
+    wg_barrier();                                                  // region W becomes Z
+    if (g < 3) {
+#pragma unroll
+        for (int i = 0; i < TPW; ++i)
+            if (i < TPW - 1 || tt.pp(i) < PMAX) {
+                st4(sZ + (tt.tl[i] * DEC_Z_ROW + 1 + 2 * tt.ff[i]) * ZS + 4 * g, ze[i]);
+                if (tt.ff[i] < 32) st4(sZ + (tt.tl[i] * DEC_Z_ROW + 2 + 2 * tt.ff[i]) * ZS + 4 * g, zo[i]);
+            }
+    }
+    if (tid < RW * 2 * 4 && (tid & 3) < 3)
+        st4(sZ + ((tid >> 3) * DEC_Z_ROW + ((tid >> 2) & 1) * (DEC_Z_ROW - 1)) * ZS + 4 * (tid & 3), splat(0.f));
+    wg_barrier();
+    {   // de_convs.4 gather + BN + Tanh: item = (stream row, output channel o, bin f'')
+        for (int idx = tid; idx < RW * 2 * F0; idx += NT) {
+            const int h = idx / (2 * F0), c = idx - h * (2 * F0), o = c >= F0 ? 1 : 0, fq = c - o * F0;
+            const int par = fq & 1, m = fq >> 1;
+            const float* zr = sZ + (h * DEC_Z_ROW + 1 + m) * ZS;
+            const float* r1 = zr + ZS + o * 5 + par;
+            const float* r2p = zr + o * 5 + 2 + par;
+            const float* r3 = zr - ZS + (par ? 10 : o * 5 + 4);
+            const float bias = sPD[dl(D_DE4_B) + o];
+            const float sum = bias + r1[0] + r2p[0] + r3[0];
+            sM[(o * RW + h) * F0 + fq] = fast_tanh(sum);
+        }
+    }
+    wg_barrier();
+    STAMP(SS, 14)
+    {   // ERB.bs + complex ratio mask + output layout
+        float* obase = out + (long)b * NS * osb;
+        const int osf32 = (int)osf, ost32 = (int)osb;
+        int tz = tid;                                              // (opaque: the items' (stream, bin) are recomputed here,
+        asm volatile("" : "+v"(tz));                               //  not kept live -- in scratch -- since the prologue)
+#pragma unroll
+        for (int q = 0; q < SPEC_ITEMS; ++q) {
+            int tq, f;
+            spec_item(tz, q, tq, f);
+            const bool ok = tq < nfr;
+            const int tc = ok ? tq : 0;
+            const f32x4 tb = ld4(sBS + f * 4);
+            const float* mp = sM + tc * F0 + __float_as_int(tb[0]);
+            const float a0 = mp[0], a1 = mp[1], b0 = mp[RW * F0], b1 = mp[RW * F0 + 1];
+            const bool two = tb[2] != 0.f;
+            const float mr = tb[1] * a0 + (two ? tb[2] * a1 : 0.f);
+            const float mi = tb[1] * b0 + (two ? tb[2] * b1 : 0.f);
+            const float re = spn[q].x, im = spn[q].y;
+            const float yr = re * mr - im * mi, yi = im * mr + re * mi;
+            if (ok) *reinterpret_cast<float2*>(obase + f * osf32 + tq * ost32) = make_float2(yr, yi);
+        }
+    }
+    // ------------------------------------------------------------------------------------------------- epilogue
     if (tid < nlive * 48) {
         const int sidx = tid / 48, e = tid - sidx * 48;
         stb[(long)sidx * ST_FLOATS + ST_ENC_E + e] = sEHe[tid];
@@ -3969,6 +4627,9 @@ int configure_kernels() {
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_stream_ms), hipFuncAttributeMaxDynamicSharedMemorySize,
                             SM_LDS_FLOATS * 4);
     if (e != hipSuccess) return (int)e;
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_stream_wide<SwCfg>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            SW_LDS_FLOATS * 4);
+    if (e != hipSuccess) return (int)e;
 #ifdef GT_EXP
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_encoder_pair<EncPair>), hipFuncAttributeMaxDynamicSharedMemorySize,
                             EncPairLds<EncPair>::FLOATS * 4);
@@ -4227,9 +4888,19 @@ int launch_stream_ms(const float* spec, long sb, long sf, float* out, long osb, 
     GT_LAUNCH_CHECK();
     return 0;
 }
+// the wide form of the same step: SwCfg::NS streams per workgroup (see k_stream_wide)
+int launch_stream_wide(const float* spec, long sb, long sf, float* out, long osb, long osf, int B, const float* PF,
+                       const int* PI, float* state, unsigned long long* stamps, hipStream_t s) {
+    const int grid = (B + SwCfg::NS - 1) / SwCfg::NS;
+    hipLaunchKernelGGL(k_stream_wide<SwCfg>, dim3(grid), dim3(SwCfg::NT), SW_LDS_FLOATS * 4, s, spec, sb, sf, out, osb, osf, B,
+                       PF, PI, state, stamps);
+    GT_LAUNCH_CHECK();
+    return 0;
+}
+int stream_wide_streams() { return SwCfg::NS; }
 bool stream_ms_usable(long sb, long osb) {
     const long a = sb < 0 ? -sb : sb, o = osb < 0 ? -osb : osb;
-    return (MS_ROWS - 1) * a < (1L << 31) && (MS_ROWS - 1) * o < (1L << 31);
+    return 8 * a < (1L << 31) && 8 * o < (1L << 31);     // (row offsets of either form in 32 bits)
 }
 
 int launch_state_convert(float* state, int N, float* conv, float* tra, float* const* tcn8, const int* PI, int dir,

@@ -187,8 +187,11 @@ int gtcrn_debug_enable(gtcrn_model *m, int on);
  * switch of tests and measurements).  Default on. */
 int gtcrn_var_spans_enable(gtcrn_model *m, int on);
 /* Single-frame streaming steps (gtcrn_stream_step with nframes == 1): form 0 (default) runs the whole step as ONE
- * kernel per four streams, nothing handed over through HBM; form 1 runs the three-launch form (encoder, both GTCN
- * stacks, decoder; hand-off tensors in HBM) that the stage taps use.  Bit-identical outputs and ring state
+ * kernel, nothing handed over through HBM -- four streams per workgroup (k_stream_ms) while one round of workgroups
+ * covers the streams, seven per workgroup (k_stream_wide: eight waves x two tiles, parameters streamed through LDS)
+ * once the stream count fills the chip more than once; form 1 runs the three-launch form (encoder, both GTCN stacks,
+ * decoder; hand-off tensors in HBM) that the stage taps use; forms 2 and 3 pin the one-launch step to four / seven
+ * streams per workgroup whatever the count.  Bit-identical outputs and ring state in every form
  * (tests/test_gpu_stream.py); the A/B switch of the capacity measurements. */
 int gtcrn_stream_form(gtcrn_model *m, int form);
 long gtcrn_debug_tap(gtcrn_model *m, const char *name, int b, float *h_dst, long cap);

@@ -492,21 +492,60 @@ def test_65536_streams_past_the_infinity_cache_equal_small_batches(dev):
 
 
 def test_stream_form_switch_gives_the_same_bits(dev):
-    """gtcrn_stream_form: the one-launch step (default) against the three-launch form without the stage taps (the A/B of
-    bench.py's stream_capacity leg): 70 streams (17 full workgroups of four + one of two), five frames -- outputs and
-    the whole ring state bit-equal; a wrong form is refused."""
+    """gtcrn_stream_form: the one-launch step (default: form by stream count) against the three-launch form without the
+    stage taps and against the one-launch step pinned to four (k_stream_ms) / seven (k_stream_wide) streams per workgroup
+    -- the A/Bs of bench.py's stream_capacity leg: 70 streams (17 full workgroups of four + one of two; ten of seven), five
+    frames -- outputs and the whole ring state bit-equal in every form; a wrong form is refused."""
     from gtcrn_micro_amd import Engine, GtcrnError
     eng = Engine(load_params("dns3"), 0)
     N, T = 70, 5
     gen = torch.Generator(device="cuda").manual_seed(70)
     spec = (torch.randn(N, T, 257, 2, device="cuda", generator=gen) * 0.3).permute(0, 2, 1, 3)
-    st0, st1 = eng.new_state(N), eng.new_state(N)
+    st0 = eng.new_state(N)
     a = torch.cat([eng.stream_step(st0, spec[:, :, t:t + 1]) for t in range(T)], 2)
-    eng.stream_form(1)
-    try:
-        b = torch.cat([eng.stream_step(st1, spec[:, :, t:t + 1]) for t in range(T)], 2)
-    finally:
-        eng.stream_form(0)
-    assert torch.equal(a, b) and torch.equal(st0, st1)
+    for form in (1, 2, 3):
+        st1 = eng.new_state(N)
+        eng.stream_form(form)
+        try:
+            b = torch.cat([eng.stream_step(st1, spec[:, :, t:t + 1]) for t in range(T)], 2)
+        finally:
+            eng.stream_form(0)
+        assert torch.equal(a, b) and torch.equal(st0, st1), form
     with pytest.raises(GtcrnError):
-        eng.stream_form(2)
+        eng.stream_form(4)
+
+
+@pytest.mark.parametrize("which", ["dns3", "rand"])
+def test_wide_single_launch_step_equals_the_narrow_one_and_offline(dev, which):
+    """k_stream_wide (seven streams per workgroup, eight waves x two tiles, parameters streamed through LDS by DMA) against
+    k_stream_ms (four per workgroup, parameters resident): 40 frames -- every TCN ring wraps, the dilation-8 ring more than
+    twice -- at stream counts that leave the last workgroup with 1 .. 7 live streams; outputs and the whole ring state
+    bit-equal, the wide form's name in the timing table, the streamed output == the offline forward of the same
+    spectrogram bit for bit.  Then the form the library picks by itself: narrow at 1024 streams (one round of four-stream
+    workgroups), wide at 1792 (two rounds of four-stream workgroups against one round of seven-stream ones)."""
+    from gtcrn_micro_amd import Engine
+    eng = Engine(load_params(which), 0)
+    T = 40
+    for N in (1, 6, 7, 8, 13, 30, 100):
+        gen = torch.Generator(device="cuda").manual_seed(1000 + N)
+        spec = (torch.randn(N, T, 257, 2, device="cuda", generator=gen) * 0.3).permute(0, 2, 1, 3)
+        outs, states = [], []
+        for form in (2, 3):
+            st = eng.new_state(N)
+            eng.stream_form(form)
+            try:
+                outs.append(torch.cat([eng.stream_step(st, spec[:, :, t:t + 1]) for t in range(T)], 2))
+            finally:
+                eng.stream_form(0)
+            states.append(st)
+        assert torch.equal(outs[0], outs[1]), N
+        assert torch.equal(states[0], states[1]), N
+        assert torch.equal(outs[1], eng.forward_spec(spec.contiguous())), N
+    for N, name in ((1024, "k_stream_ms"), (1792, "k_stream_wide")):
+        eng.timing_enable(True)
+        st = eng.new_state(N)
+        spec = torch.zeros(N, 257, 1, 2, device="cuda")
+        eng.stream_step(st, spec)
+        torch.cuda.synchronize()
+        assert list(eng.timing_read()) == [name], (N, eng.timing_read())
+    eng.timing_enable(False)

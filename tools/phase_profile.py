@@ -45,6 +45,7 @@ def main():
     ap.add_argument("--json", default=None)
     ap.add_argument("--exp", action="store_true", help="profile the -DGT_EXP build instead of the default one")
     ap.add_argument("--stream", type=int, default=0, help="profile single-frame streaming steps of this many streams")
+    ap.add_argument("--form", type=int, default=2, help="with --stream: 2 = k_stream_ms (four streams per workgroup), 3 = k_stream_wide (seven)")
     a = ap.parse_args()
     import numpy as np
     import torch
@@ -58,6 +59,8 @@ def main():
         torch.manual_seed(44)
         spec = (torch.randn(N, 40, 257, 2, device="cuda") * 0.3).permute(0, 2, 1, 3)
         st = eng.new_state(N)
+        eng.stream_form(a.form)
+        per_wg, kname = (7, "k_stream_wide") if a.form == 3 else (4, "k_stream_ms")
         for t in range(20):
             eng.stream_step(st, spec[:, :, t:t + 1])
         eng.debug_enable(2)                       # stamps only: the step stays ONE launch
@@ -66,11 +69,11 @@ def main():
             eng.stream_step(st, spec[:, :, t:t + 1])
         torch.cuda.synchronize()
         kern = eng.timing_read()
-        stp = eng.stamps(0, N).astype(np.float64)[: (N + 3) // 4]          # the LAST step's stamps, one row per workgroup
+        stp = eng.stamps(0, N).astype(np.float64)[: (N + per_wg - 1) // per_wg]   # the LAST step's stamps, one row per workgroup
         avg = stp.mean(axis=0)
         tot = avg.sum()
-        us = kern.get("k_stream_ms", (0, 0))[0] * 1e3
-        print(f"\nk_stream_ms, {N} streams: {tot:,.0f} cycles per workgroup (launch {us:.1f} us -> {tot / max(us, 1e-9):.0f} cycles/us)")
+        us = kern.get(kname, (0, 0))[0] * 1e3
+        print(f"\n{kname}, {N} streams: {tot:,.0f} cycles per workgroup (launch {us:.1f} us -> {tot / max(us, 1e-9):.0f} cycles/us)")
         out = {"streams": N, "launch_us": us, "cycles": tot, "phases": {}}
         for i, nm in STREAM_PHASES.items():
             print(f"   {nm:<62} {avg[i]:>10,.0f}  {100 * avg[i] / tot:5.1f} %")
