@@ -7,6 +7,6 @@ Layout mirrors the reference package for the path it replaces:
 The arithmetic lives in csrc/ (HIP, built into libgtcrn_micro_hip.so) behind the C ABI of
 include/gtcrn_micro_hip.h; nothing here falls back to the CPU.
 """
-from ._lib import Engine, GtcrnError, Trainer, istft, link_copy, make_window, num_frames, selftest_mfma, selftest_split3, stft, stft_frames  # noqa: F401
+from ._lib import f32_to_pcm16, pcm16_to_f32, Engine, GtcrnError, Trainer, istft, make_window, num_frames, selftest_mfma, selftest_split3, stft, stft_frames  # noqa: F401
 
-__all__ = ["Engine", "GtcrnError", "Trainer", "stft", "istft", "stft_frames", "make_window", "num_frames", "selftest_mfma", "selftest_split3", "link_copy"]
+__all__ = ["pcm16_to_f32", "f32_to_pcm16", "Engine", "GtcrnError", "Trainer", "stft", "istft", "stft_frames", "make_window", "num_frames", "selftest_mfma", "selftest_split3"]

@@ -87,7 +87,8 @@ def lib():
     L.gtcrn_debug_stamps.restype = cl
     L.gtcrn_debug_stamps.argtypes = [_vp, ci, ctypes.POINTER(ctypes.c_ulonglong), cl]
     L.gtcrn_selftest_mfma.argtypes = [ci]
-    L.gtcrn_link_copy.argtypes = [ci, _vp, _vp, cl, ci, _vp]
+    L.gtcrn_pcm16_to_f32.argtypes = [ci, _vp, _vp, cl, _vp]
+    L.gtcrn_f32_to_pcm16.argtypes = [ci, _vp, _vp, cl, _vp]
     L.gtcrn_selftest_split3.argtypes = [ci, _c_f32p, cl, _c_f32p, _c_f32p, _c_f32p, _c_f32p, _c_f32p]
     L.gtcrn_timing_enable.argtypes = [_vp, ci]
     L.gtcrn_timing_read.argtypes = [_vp, ci, ctypes.c_char_p, ci, _c_f32p, ctypes.POINTER(ci)]
@@ -555,25 +556,42 @@ class Engine:
         return out
 
 
-def link_copy(dst, src, workgroups=64, stream=None):
-    """dst.copy_(src) over the host link by a kernel (gtcrn_link_copy) instead of the DMA engines: one side a CUDA tensor,
-    the other a PINNED host tensor (or both device tensors); contiguous, same byte size, a multiple of 16 bytes.  Runs on
-    the current (or given) stream of the device tensor's device; asynchronous like copy_(non_blocking=True)."""
+def _pcm_pair(pcm, wave, who):
     import torch
-    if not (dst.is_contiguous() and src.is_contiguous()):
-        raise GtcrnError("link_copy: contiguous tensors only")
-    nbytes = src.numel() * src.element_size()
-    if nbytes != dst.numel() * dst.element_size():
-        raise GtcrnError("link_copy: sizes differ")
-    for t in (dst, src):
-        if not t.is_cuda and not t.is_pinned():
-            raise GtcrnError("link_copy: a host tensor must be pinned (its address is then valid on the device)")
-    devs = [t.device.index for t in (dst, src) if t.is_cuda]
-    if not devs:
-        raise GtcrnError("link_copy: one side must be a device tensor")
-    _check(lib().gtcrn_link_copy(int(devs[0]), ctypes.c_void_p(dst.data_ptr()), ctypes.c_void_p(src.data_ptr()), int(nbytes),
-                                 int(workgroups), _stream_ptr(stream)))
-    return dst
+    for t, dt, what in ((pcm, torch.int16, "int16"), (wave, torch.float32, "float32")):
+        if not (t.is_cuda and t.dtype == dt and t.is_contiguous()):
+            raise GtcrnError(f"{who}: a contiguous {what} CUDA tensor is required")
+    if pcm.numel() != wave.numel() or pcm.device != wave.device:
+        raise GtcrnError(f"{who}: the two tensors must hold the same number of samples on one device")
+    if pcm.numel() % 8 or pcm.data_ptr() % 16 or wave.data_ptr() % 16:
+        raise GtcrnError(f"{who}: 16-byte aligned tensors, a sample count that is a multiple of 8")
+
+
+def pcm16_to_f32(pcm, out=None):
+    """int16 samples -> float32 waveform on the device (x = s / 32768, exact: what soundfile.read returns, infer.py:54);
+    asynchronous on the current stream of the tensor's device (gtcrn_pcm16_to_f32)."""
+    import torch
+    if out is None:
+        out = torch.empty(pcm.shape, dtype=torch.float32, device=pcm.device)
+    _pcm_pair(pcm, out, "pcm16_to_f32")
+    with torch.cuda.device(pcm.device):
+        _check(lib().gtcrn_pcm16_to_f32(pcm.device.index, ctypes.c_void_p(pcm.data_ptr()), ctypes.c_void_p(out.data_ptr()),
+                                        int(pcm.numel()), _stream_ptr()))
+    return out
+
+
+def f32_to_pcm16(wave, out=None):
+    """float32 waveform -> int16 samples on the device: clip(rint(y * 32768), -32768, 32767), round half to even (the
+    16-bit PCM sf.write / scipy.io.wavfile.write of np.rint produce, infer.py:113); asynchronous on the current stream of
+    the tensor's device (gtcrn_f32_to_pcm16)."""
+    import torch
+    if out is None:
+        out = torch.empty(wave.shape, dtype=torch.int16, device=wave.device)
+    _pcm_pair(out, wave, "f32_to_pcm16")
+    with torch.cuda.device(wave.device):
+        _check(lib().gtcrn_f32_to_pcm16(wave.device.index, ctypes.c_void_p(wave.data_ptr()), ctypes.c_void_p(out.data_ptr()),
+                                        int(wave.numel()), _stream_ptr()))
+    return out
 
 
 def selftest_mfma(device=0):
@@ -729,10 +747,20 @@ class Trainer:
 _adam_ws = {}
 
 
+def clip_adam_workspace(device, n=None):
+    """A zeroed workspace for clip_adam_step (ticket + partial sums; every call leaves the ticket at zero again).  One per
+    caller that may step concurrently with another on the same device (FlatAdam owns one per instance)."""
+    import torch
+    n = NPARAM_FLOATS if n is None else n
+    return torch.zeros((int(lib().gtcrn_clip_adam_workspace_bytes(n)) + 7) // 8, dtype=torch.float64, device=device)
+
+
 def clip_adam_step(params, grads, exp_avg, exp_avg_sq, mask, step, lr, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0,
-                   max_norm=0.0, norm_out=None):
+                   max_norm=0.0, norm_out=None, ws=None):
     """clip_grad_norm_(max_norm) + torch.optim.Adam.step() over flat fp32 device blobs in two launches
-    (gtcrn_clip_adam_step).  norm_out: optional 2-float device tensor (total norm, clip coefficient)."""
+    (gtcrn_clip_adam_step).  norm_out: optional 2-float device tensor (total norm, clip coefficient).  ws: the caller's own
+    workspace (clip_adam_workspace); without one a per-(device, size) workspace shared by such callers is used -- fine for
+    one stream per device."""
     import torch
     n = params.numel()
     for t, what in ((params, "params"), (grads, "grads"), (exp_avg, "exp_avg"), (exp_avg_sq, "exp_avg_sq"), (mask, "mask")):
@@ -743,11 +771,13 @@ def clip_adam_step(params, grads, exp_avg, exp_avg_sq, mask, step, lr, betas=(0.
         _require_cuda_f32(norm_out, "norm_out")
         if norm_out.numel() < 2 or not norm_out.is_contiguous():
             raise GtcrnError("norm_out must hold 2 contiguous floats")
-    key = (params.device.index, n)
-    ws = _adam_ws.get(key)
-    if ws is None:      # zeroed once: every call leaves the ticket at zero again
-        ws = _adam_ws[key] = torch.zeros((int(lib().gtcrn_clip_adam_workspace_bytes(n)) + 7) // 8, dtype=torch.float64,
-                                         device=params.device)
+    if ws is None:
+        key = (params.device.index, n)
+        ws = _adam_ws.get(key)
+        if ws is None:      # zeroed once: every call leaves the ticket at zero again
+            ws = _adam_ws[key] = clip_adam_workspace(params.device, n)
+    elif ws.device != params.device or ws.numel() * ws.element_size() < int(lib().gtcrn_clip_adam_workspace_bytes(n)):
+        raise GtcrnError("clip_adam_step: the workspace is on another device or too small")
     with torch.cuda.device(params.device):
         _check(lib().gtcrn_clip_adam_step(params.device.index, params.data_ptr(), grads.data_ptr(), exp_avg.data_ptr(),
                                           exp_avg_sq.data_ptr(), mask.data_ptr(), n, float(max_norm), float(lr),

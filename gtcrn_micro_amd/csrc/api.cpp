@@ -170,7 +170,7 @@ struct Timer {
 // takes WIDE_COST times as long (measured: profiles/r06_ab_stream_wide.txt).  Both run one workgroup per CU, so a step
 // costs rounds-of-256-workgroups x the form's time: the wide form pays once the narrow one needs more rounds than it.
 static bool stream_wide_pays(int B) {
-    constexpr double WIDE_COST = 1.25;
+    constexpr double WIDE_COST = 1.5;      // 49.3 us against 32.9 us per round of 256 workgroups at 65 536 streams
     const int ws = gtk::stream_wide_streams();
     const long r4 = ((B + 3) / 4 + 255) / 256, r7 = ((B + ws - 1) / ws + 255) / 256;
     return (double)r7 * WIDE_COST < (double)r4;
@@ -739,14 +739,20 @@ struct DeviceScope {
 };
 }  // namespace
 
-int gtcrn_link_copy(int device, void* dst, const void* src, long bytes, int workgroups, void* stream) {
-    if (!dst || !src) return fail(GTCRN_ERR_ARG, "gtcrn_link_copy: null pointer");
-    if (bytes <= 0 || (bytes & 15) || ((reinterpret_cast<uintptr_t>(dst) | reinterpret_cast<uintptr_t>(src)) & 15) ||
-        workgroups < 1 || workgroups > 4096)
-        return fail(GTCRN_ERR_ARG, "gtcrn_link_copy: 16-byte aligned pointers, a multiple of 16 bytes, 1..4096 workgroups");
+static int pcm16_convert(int device, const void* src, void* dst, long n, int dir, void* stream, const char* who) {
+    if (!dst || !src) return fail(GTCRN_ERR_ARG, std::string(who) + ": null pointer");
+    if (n <= 0 || (n & 7) || ((reinterpret_cast<uintptr_t>(dst) | reinterpret_cast<uintptr_t>(src)) & 15))
+        return fail(GTCRN_ERR_ARG, std::string(who) + ": 16-byte aligned device pointers and a sample count that is a multiple of 8");
+    DeviceScope scope;              // (a C caller's current device is put back)
     HIP_TRY(hipSetDevice(device));
-    LAUNCH_TRY(gtk::launch_link_copy(dst, src, bytes, workgroups, static_cast<hipStream_t>(stream)));
+    LAUNCH_TRY(gtk::launch_pcm16_convert(src, dst, n, dir, static_cast<hipStream_t>(stream)));
     return 0;
+}
+int gtcrn_pcm16_to_f32(int device, const short* d_pcm, float* d_wave, long n, void* stream) {
+    return pcm16_convert(device, d_pcm, d_wave, n, 0, stream, "gtcrn_pcm16_to_f32");
+}
+int gtcrn_f32_to_pcm16(int device, const float* d_wave, short* d_pcm, long n, void* stream) {
+    return pcm16_convert(device, d_wave, d_pcm, n, 1, stream, "gtcrn_f32_to_pcm16");
 }
 
 int gtcrn_selftest_mfma(int device) {

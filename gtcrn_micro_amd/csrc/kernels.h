@@ -45,7 +45,8 @@ int configure_kernels();
 // L, i.e. 1 + lens[b]/256 <= T frames; L and T stay the row strides of every tensor.  nullptr: all rows are full.
 int launch_stft(const float* wave, int B, long L, int T, const int* lens, const float* win, const float* twid,
                 float* spec, long sb, long sf, long st, float* frames, hipStream_t s);
-int launch_link_copy(void* dst, const void* src, long bytes, int workgroups, hipStream_t s);
+// 16-bit PCM <-> float32 at the host boundary (n samples, a multiple of 8; dir 0: int16 / 32768, 1: clip(rint(y * 32768)))
+int launch_pcm16_convert(const void* src, void* dst, long n, int dir, hipStream_t s);
 int launch_istft(const float* spec, long sb, long sf, long st, int B, int T, const int* lens, const float* win,
                  const float* twid, float* wave, hipStream_t s);
 // gspec += adjoint(iSTFT)(gwave): gwave (B, 256 (T-1)) is the gradient w.r.t. the iSTFT output ALREADY divided by

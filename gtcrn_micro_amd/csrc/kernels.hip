@@ -4023,18 +4023,18 @@ __global__ __launch_bounds__(CF::NT) void k_stream_wide(const float* __restrict_
     for (int i = 0; i < TPW; ++i) tbl[i] = sTB[row[i]];
     f32x4 t1[4][TPW], t2[4][TPW];
     int r2[4][TPW];
-    auto fetch_rows = [&](int st_off) {
+    // (all sixteen loads per thread at the top of the last encoder block; spreading them over the block's phases or over
+    // two blocks was tried: the longer live ranges push 19 .. 45 registers into scratch)
+    auto fetch_rows = [&](int st_off, auto kc) {
+        constexpr int k = decltype(kc)::value;
 #pragma unroll
         for (int i = 0; i < TPW; ++i) {
             const float* ring = stl[i] + st_off;
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const int d = 1 << k, m2d = 2 * d - 1, row0 = 2 * (d - 1);
-                const int r1 = ((row0 + ((tbl[i] + d) & m2d)) * 33 + ffl[i]) * 16 + 4 * g;
-                r2[k][i] = ((row0 + (tbl[i] & m2d)) * 33 + ffl[i]) * 16 + 4 * g;
-                t1[k][i] = ld4(ring + r1);
-                t2[k][i] = ld4(ring + r2[k][i]);
-            }
+            constexpr int d = 1 << k, m2d = 2 * d - 1, row0 = 2 * (d - 1);
+            const int r1 = ((row0 + ((tbl[i] + d) & m2d)) * 33 + ffl[i]) * 16 + 4 * g;
+            r2[k][i] = ((row0 + (tbl[i] & m2d)) * 33 + ffl[i]) * 16 + 4 * g;
+            t1[k][i] = ld4(ring + r1);
+            t2[k][i] = ld4(ring + r2[k][i]);
         }
     };
     auto fill_ctx = [&](BlockCtx& c, const float* pb, const float* gA, const int* ib, float* sW, float* sS, float* sEHk,
@@ -4059,14 +4059,20 @@ __global__ __launch_bounds__(CF::NT) void k_stream_wide(const float* __restrict_
         fill_ctx(c, sPE + E_BLK + k * GB_SIZE, nullptr, sI + I_ENC_BLK - ENC_I_SKIP + k * 16, sWe, sSe, sEHe + k * 16,
                  (int)(smem + LD::HE - sWe), 16, ST_ENC_H, k);
         if (k < 2) hist_fetch(ST_ENC_H + (k + 1) * 2 * 33 * 16, hv);
-        else fetch_rows(ST_G1_H);
+        if (k == 2) {
+            fetch_rows(ST_G1_H, std::integral_constant<int, 0>{});
+            fetch_rows(ST_G1_H, std::integral_constant<int, 1>{});
+            fetch_rows(ST_G1_H, std::integral_constant<int, 2>{});
+            fetch_rows(ST_G1_H, std::integral_constant<int, 3>{});
+        }
         // (k == 2: the closing barrier also waits for the wave's vector memory: the GTCN parameters -- issued two blocks
         // ago -- are then visible to every wave; the row loads above are a block old by then)
         if (k < 2)
             gtconv_block<false, TPW, true, false, 16, 16, true, 35, 0, -1, NWV, PMAX, -1>(
                 x, tt, c, L, [] {}, [&] { hist_store(smem + LD::HE, std::false_type{}, hv); } STAMP_ARG);
         else
-            gtconv_block<false, TPW, true, false, 16, 16, true, 35, 0, -1, NWV, PMAX, 0>(x, tt, c, L, [] {}, [] {} STAMP_ARG);
+            gtconv_block<false, TPW, true, false, 16, 16, true, 35, 0, -1, NWV, PMAX, 0>(
+                x, tt, c, L, [] {}, [] {} STAMP_ARG);
         if (k < 2) {
             const int* ix = sI + I_ENST - ENC_I_SKIP + (k + 1) * 16 + 4 * g;
 #pragma unroll
@@ -4168,8 +4174,10 @@ __global__ __launch_bounds__(CF::NT) void k_stream_wide(const float* __restrict_
     float* sM = smem + LD::M;
     constexpr int ZS = DEC_ZS;
     // Behind this barrier every wave has left the GTCN: its parameters and the parked skips are dead, the region takes the
-    // decoder's images (block 0 reads them behind its first barrier); group D1 has landed.
-    wg_barrier_vm<0>();
+    // decoder's images (block 0 reads them behind its first barrier); group D1 has landed: every wave has issued twenty
+    // loads behind it (the second stack's rows, the history image), so "at most four outstanding" retires it and leaves
+    // only the last two TCN blocks' ring stores in flight.
+    wg_barrier_vm<2 * TPW>();
     {   // group D0: the ERB.bs table and block 0's dense planes take the place of the parked spectrogram items; every wave
         // issues the HI history loads of block 1 behind it, so block 0's first barrier (VMK1 = HI) retires it
         const DmaSeg gd[2] = {{P_DEC + D_BS_TAB, LD::BS, NBINS * 4},
@@ -4539,29 +4547,43 @@ int launch_len_prefix(const int* lens, int B, int T, int* pref, hipStream_t s) {
     return 0;
 }
 
-// A copy over the host link done by the COMPUTE units instead of the DMA engines: `src` / `dst` may be pinned host memory
-// (hipHostMalloc / torch pin_memory: the same virtual address is valid on the device).  The served pipeline moves 65.5 MB
-// each way per step; with both directions on the DMA engines each runs at about half its solo rate on this platform
-// (bench.py io.duplex_each_GBps), so one direction is given to a few workgroups here (posted writes over PCIe for the
-// device-to-host direction; four 16-byte loads in flight per lane for host-to-device).
-__global__ __launch_bounds__(256) void k_link_copy(const f32x4* __restrict__ src, f32x4* __restrict__ dst, long n16) {
+// 16-bit PCM at the host boundary.  The reference's data are mono 16-bit WAV files (infer.py:54, examples/*.wav) and its
+// callers widen them on the host (soundfile / librosa); a caller that hands the SAMPLES over as int16 moves half the bytes
+// over the host link, which is what bounds the served rate (bench.py io).  In: x = s / 32768 (exact in fp32: what
+// soundfile.read returns).  Out: s = clip(rint(y * 32768), -32768, 32767), round half to even -- scipy.io.wavfile.write
+// of np.rint(...), torch.round, and write_wav_pcm16 of gtcrn_micro_amd/infer.py all agree.  8 samples per lane and step.
+typedef short i16x8 __attribute__((ext_vector_type(8)));
+__global__ __launch_bounds__(256) void k_pcm16_to_f32(const i16x8* __restrict__ src, f32x4* __restrict__ dst, long n8) {
     const long stride = (long)gridDim.x * 256;
-    long i = (long)blockIdx.x * 256 + threadIdx.x;
-    for (; i + 3 * stride < n16; i += 4 * stride) {
-        const f32x4 a = __builtin_nontemporal_load(src + i), b = __builtin_nontemporal_load(src + i + stride);
-        const f32x4 c = __builtin_nontemporal_load(src + i + 2 * stride), d = __builtin_nontemporal_load(src + i + 3 * stride);
-        __builtin_nontemporal_store(a, dst + i);
-        __builtin_nontemporal_store(b, dst + i + stride);
-        __builtin_nontemporal_store(c, dst + i + 2 * stride);
-        __builtin_nontemporal_store(d, dst + i + 3 * stride);
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n8; i += stride) {
+        const i16x8 v = __builtin_nontemporal_load(src + i);
+        f32x4 a, b;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { a[k] = (float)v[k] * (1.0f / 32768.0f); b[k] = (float)v[4 + k] * (1.0f / 32768.0f); }
+        dst[2 * i] = a;
+        dst[2 * i + 1] = b;
     }
-    for (; i < n16; i += stride) __builtin_nontemporal_store(__builtin_nontemporal_load(src + i), dst + i);
 }
-int launch_link_copy(void* dst, const void* src, long bytes, int workgroups, hipStream_t s) {
-    if (bytes <= 0 || (bytes & 15) || ((reinterpret_cast<uintptr_t>(dst) | reinterpret_cast<uintptr_t>(src)) & 15) || workgroups < 1)
-        return (int)hipErrorInvalidValue;
-    hipLaunchKernelGGL(k_link_copy, dim3(workgroups), dim3(256), 0, s, reinterpret_cast<const f32x4*>(src),
-                       reinterpret_cast<f32x4*>(dst), bytes / 16);
+__global__ __launch_bounds__(256) void k_f32_to_pcm16(const f32x4* __restrict__ src, i16x8* __restrict__ dst, long n8) {
+    const long stride = (long)gridDim.x * 256;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n8; i += stride) {
+        const f32x4 a = __builtin_nontemporal_load(src + 2 * i), b = __builtin_nontemporal_load(src + 2 * i + 1);
+        i16x8 v;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            v[k] = (short)(int)fminf(fmaxf(__builtin_rintf(a[k] * 32768.0f), -32768.0f), 32767.0f);
+            v[4 + k] = (short)(int)fminf(fmaxf(__builtin_rintf(b[k] * 32768.0f), -32768.0f), 32767.0f);
+        }
+        dst[i] = v;
+    }
+}
+// n samples (a multiple of 8), both pointers 16-byte aligned; dir 0: int16 -> float32, 1: float32 -> int16
+int launch_pcm16_convert(const void* src, void* dst, long n, int dir, hipStream_t s) {
+    if (n <= 0 || (n & 7) || ((reinterpret_cast<uintptr_t>(dst) | reinterpret_cast<uintptr_t>(src)) & 15)) return (int)hipErrorInvalidValue;
+    const long n8 = n / 8;
+    const int grid = (int)std::min<long>((n8 + 255) / 256, 256 * 16);
+    if (dir == 0) hipLaunchKernelGGL(k_pcm16_to_f32, dim3(grid), dim3(256), 0, s, reinterpret_cast<const i16x8*>(src), reinterpret_cast<f32x4*>(dst), n8);
+    else hipLaunchKernelGGL(k_f32_to_pcm16, dim3(grid), dim3(256), 0, s, reinterpret_cast<const f32x4*>(src), reinterpret_cast<i16x8*>(dst), n8);
     GT_LAUNCH_CHECK();
     return 0;
 }

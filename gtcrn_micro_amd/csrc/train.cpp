@@ -862,7 +862,8 @@ int gtcrn_trainer_create(gtcrn_trainer** out, int device) {
     for (const auto& p : gtcrn::param_table()) t->off[p.name] = p.offset;
     hipError_t e = hipMalloc(&t->fscratch, sizeof(float) * gtt::MAX_PARTIALS * (9 * 256 + 16));
     if (e == hipSuccess) e = hipMalloc(&t->dscratch, sizeof(double) * gtt::MAX_PARTIALS * 3 * 16 + 256);
-    if (e == hipSuccess) e = hipMalloc(&t->wfin_pool, sizeof(float) * WFIN_POOL_FLOATS);
+    // (the 64 MiB pool of the batched weight-gradient finishes, fusion bit 15, is allocated by the first backward that
+    // uses it -- ensure_wfin_pool -- and counted by the workspace queries)
     if (e == hipSuccess) e = hipMalloc(&t->fin_gpart, sizeof(double) * gtt::FIN_GPART_DOUBLES);
     if (e == hipSuccess) e = hipMalloc(&t->fin_ctr, sizeof(unsigned) * gtt::FIN_CTR_WORDS);
     if (e == hipSuccess) e = hipMemset(t->fin_ctr, 0, sizeof(unsigned) * gtt::FIN_CTR_WORDS);
@@ -902,13 +903,26 @@ static int storage_formats(int storage, int* bf, int* ybf) {
     return 0;
 }
 
+// what a trainer holds besides the planned arena: the partial-sum scratch of the weight-gradient kernels and, with fusion
+// bit 15, the pool their partials wait in for the two batched finish launches
+static size_t fixed_workspace_bytes(int fusions) {
+    return sizeof(float) * gtt::MAX_PARTIALS * (9 * 256 + 16) + sizeof(double) * gtt::MAX_PARTIALS * 3 * 16 + 256 +
+           sizeof(double) * gtt::FIN_GPART_DOUBLES + sizeof(unsigned) * gtt::FIN_CTR_WORDS +
+           ((fusions & 32768) ? sizeof(float) * WFIN_POOL_FLOATS : 0);
+}
+static int ensure_wfin_pool(gtcrn_trainer* t) {
+    if (!(t->fusions & 32768) || t->wfin_pool) return 0;
+    T_HIP(hipMalloc(&t->wfin_pool, sizeof(float) * WFIN_POOL_FLOATS));
+    return 0;
+}
+
 long gtcrn_train_workspace_bytes2(int B, int T, int storage) {
     gtcrn_trainer tmp;
     if (storage_formats(storage, &tmp.bf, &tmp.ybf)) return -1;
     tmp.exact = storage == 4;
     tmp.gbf = storage == 5;
     for (const auto& p : gtcrn::param_table()) tmp.off[p.name] = p.offset;
-    return (long)(plan(&tmp, B, T, nullptr) * sizeof(float));
+    return (long)(plan(&tmp, B, T, nullptr) * sizeof(float) + fixed_workspace_bytes(tmp.fusions));
 }
 long gtcrn_train_workspace_bytes(int B, int T) { return gtcrn_train_workspace_bytes2(B, T, 0); }
 
@@ -921,7 +935,7 @@ long gtcrn_trainer_workspace_bytes(gtcrn_trainer* t, int B, int T) {
     tmp.gbf = t->gbf;
     tmp.fusions = t->fusions;
     tmp.off = t->off;
-    return (long)(plan(&tmp, B, T, nullptr) * sizeof(float));
+    return (long)(plan(&tmp, B, T, nullptr) * sizeof(float) + fixed_workspace_bytes(t->fusions));
 }
 
 int gtcrn_trainer_set_storage(gtcrn_trainer* t, int storage) {
@@ -1029,26 +1043,33 @@ int gtcrn_train_backward(gtcrn_trainer* t, const float* d_params, const float* d
     if (!t || !d_params || !d_spec || !d_grad_out || !d_grads)
         return tfail(GTCRN_ERR_ARG, "gtcrn_train_backward: bad argument");
     if (!t->have_fwd) return tfail(GTCRN_ERR_STATE, "gtcrn_train_backward: no forward pass to differentiate");
+    // (checked before anything is enqueued: a refusal leaves the gradient blob and the deferral state untouched)
+    if (t->gbf && !(t->fusions & 16))
+        return tfail(GTCRN_ERR_STATE, "gtcrn_train_backward: bf16 gradient hand-offs (storage 5) need fusion bit 4 (skip "
+                                      "gradients accumulated in place: the separate add passes are fp32)");
     T_HIP(hipSetDevice(t->device));
     hipStream_t s = (hipStream_t)stream;
     const int B = t->B, T = t->T;
     const float* prm = d_params;
     float* G = d_grads;
     int rc;
+    if ((rc = ensure_wfin_pool(t))) return rc;
     T_HIP(hipMemsetAsync(G, 0, sizeof(float) * GTCRN_NPARAM_FLOATS, s));
     gtt::set_fin_context((t->fusions & 1024) != 0, t->fin_gpart, t->fin_ctr);
     gtt::set_pointwise_form((t->fusions & 8192) != 0);
     gtt::set_column_form((t->fusions & 16384) != 0);
     T_HIP(hipMemsetAsync(t->fin_ctr, 0, sizeof(unsigned) * gtt::FIN_CTR_WORDS, s));
+    // the weight-gradient deferral is thread-local state of the launch layer: switched off again on EVERY way out of
+    // this function (an early error return used to leave it on, pointing at this trainer's pool)
+    struct DeferGuard {
+        ~DeferGuard() { gtt::set_wgrad_defer(false, nullptr, 0); }
+    } defer_guard;
     gtt::set_wgrad_defer((t->fusions & 32768) != 0, t->wfin_pool, WFIN_POOL_FLOATS);
     t->red_unit = nullptr;
     const long n33 = (long)B * T * 33 * 16, n65 = (long)B * T * 65 * 16;
     T_RUN(gtt::bs_mask_bwd(d_grad_out, gb, gf, gt, d_spec, sb, sf, st, B, T, prm + P(t, "erb.ierb_fc.weight"), t->dm, s));
     // de_convs.4 <- s4 = de3.a + en0.a : gs0 is the gradient of both addends (the sums are recomputed, see plan())
     if (t->share_sums) T_RUN(gtt::add_saved(t->de3.a, t->en0.a, t->s4, n65, s, t->bf));
-    if (t->gbf && !(t->fusions & 16))
-        return tfail(GTCRN_ERR_STATE, "gtcrn_train_backward: bf16 gradient hand-offs (storage 5) need fusion bit 4 (skip "
-                                      "gradients accumulated in place: the separate add passes are fp32)");
     if ((rc = unit_bwd(t, t->de4, prm, G, t->dm, t->gs0, 0, nullptr, 0, s, 0, -1))) return rc;      // (dm: fp32)
     if (t->share_sums) T_RUN(gtt::add_saved(t->dec[2].out, t->en1.a, t->s3, n33, s, t->bf));
     if ((rc = unit_bwd(t, t->de3, prm, G, t->gs0, t->gs[1], 0, nullptr, 0, s))) return rc;   // gs[1]: d s3
@@ -1107,7 +1128,6 @@ int gtcrn_train_backward(gtcrn_trainer* t, const float* d_params, const float* d
         T_RUN(gtt::dw_wgrad(g, t->eb, t->df0, G + P(t, "sfe.depth_conv.weight"), nullptr, t->fscratch, s));
     }
     T_RUN(gtt::flush_wgrad_finishes(s));      // (fusion bit 15: the recorded weight-gradient finishes, two launches)
-    gtt::set_wgrad_defer(false, nullptr, 0);
     return 0;
 }
 
@@ -1190,6 +1210,11 @@ int gtcrn_clip_adam_step(int device, float* d_params, float* d_grads, float* d_e
         (reinterpret_cast<uintptr_t>(d_workspace) & 7))
         return tfail(GTCRN_ERR_ARG, "gtcrn_clip_adam_step: bad argument (needs device pointers, an 8-byte aligned "
                                     "workspace, 1 <= n, step >= 1, 0 <= beta < 1, eps >= 0, lr >= 0)");
+    struct DeviceScope {            // a C caller's current device is put back on every way out
+        int prev = -1;
+        DeviceScope() { if (hipGetDevice(&prev) != hipSuccess) prev = -1; }
+        ~DeviceScope() { if (prev >= 0) (void)hipSetDevice(prev); }
+    } device_scope;
     T_HIP(hipSetDevice(device));
     // workspace: [0] the last-workgroup ticket (0 between calls), [8..16) norm / coefficient when the caller wants
     // neither, [64..) one double per workgroup of the norm

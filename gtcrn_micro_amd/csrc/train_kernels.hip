@@ -5024,14 +5024,14 @@ int dwunit_bwd(const DwGeom& g, const float* x, const float* y, const float* da,
     // would run alone at a third of the occupancy)
     const int grid = red_grid(total / 4) > 768 ? 768 : red_grid(total / 4);
     const StrideIter it = stride_iter((long)grid * NT / 4, g.F, g.Tout);
+    const bool nxt = next && next->slope;
+    const bool xr = nxt && next->recompute_x;
+    if (!x && !xr) return (int)hipErrorInvalidValue;          // (before a region of the deferral pool is taken)
     float* const dpool = wdefer_take((size_t)MAX_PARTIALS * 64 * 2);     // (both forms' grids fit)
     if (dpool) fscratch = dpool;
     double* wpart = reinterpret_cast<double*>(fscratch);      // [grid][64]
     BnBwdArgs bn{stats, gamma, beta, slope, red, ACT_PRELU};
     NextRedArgs nx{};
-    const bool nxt = next && next->slope;
-    const bool xr = nxt && next->recompute_x;
-    if (!x && !xr) return (int)hipErrorInvalidValue;
     if (nxt) nx = NextRedArgs{next->y, next->stats, next->gamma, next->beta, next->slope, nullptr, next->recompute_x == 2};
     const FinArgs nfa = next_fin(nxt, next, dscratch, slot);
     if (g_col_form && nxt && total < (1L << 31)) {       // the column form (see k_dwunit31_col), fusion bit 14
@@ -5084,14 +5084,14 @@ int dwunit33_bwd(const DwGeom& g, const float* x, const float* y, const float* d
     const long ntiles = (long)g.B * tiles_t;
     // 64 KB of LDS: two workgroups per CU, 512 resident -- whole rounds of them
     const int grid = (int)(ntiles < 512 ? ntiles : 512);
+    const bool nxt = next && next->slope && !next->res;
+    const bool xr = nxt && next->recompute_x;
+    if (!x && !xr) return (int)hipErrorInvalidValue;          // (before a region of the deferral pool is taken)
     float* const dpool = wdefer_take((size_t)grid * 160 * 2);
     if (dpool) fscratch = dpool;
     double* wpart = reinterpret_cast<double*>(fscratch);      // [grid][160]
     BnBwdArgs bn{stats, gamma, beta, slope, red, ACT_PRELU};
     NextRedArgs nx{};
-    const bool nxt = next && next->slope && !next->res;
-    const bool xr = nxt && next->recompute_x;
-    if (!x && !xr) return (int)hipErrorInvalidValue;
     if (nxt) nx = NextRedArgs{next->y, next->stats, next->gamma, next->beta, next->slope, nullptr, next->recompute_x == 2, ybf};
     const FinArgs nfa = next_fin(nxt, next, dscratch, slot);
 #define GT_D33(F, GF_)                                                                                                  \

@@ -138,7 +138,7 @@ def _enhance_shard(noisy_dir, clean_dir, enh_dir, checkpoint, device=0, max_batc
     import warnings
 
     import torch
-    from . import Engine
+    from . import Engine, _lib
     from .sharding import shard_range
 
     os.makedirs(enh_dir, exist_ok=True)
@@ -197,6 +197,7 @@ def _enhance_shard(noisy_dir, clean_dir, enh_dir, checkpoint, device=0, max_batc
         # bytes it receives).  Half the link traffic, and no per-sample work on the host at all; a batch with any other kind
         # of file goes through the generic reader into float32 staging.
         cap = max(len(sel) * max(items[i][4] for i in sel) for sel in batches)
+        cap = (cap + 7) & ~7                          # (the conversion kernels move 8 samples per lane)
         nslot = max(1, min(int(stages), len(batches)))
         with torch.cuda.device(device):
             slots = [{"hin": torch.empty(cap * 4, dtype=torch.uint8, pin_memory=True),
@@ -317,17 +318,19 @@ def _enhance_shard(noisy_dir, clean_dir, enh_dir, checkpoint, device=0, max_batc
                         ev_a, ev_b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                         ev_a.record()
                         if pcm:
-                            x.copy_(sl["din"][:nb].view(torch.int16).view(n, Lmax))     # int16 -> float32, exact
-                            x.mul_(1.0 / 32768.0)
+                            # int16 -> float32 (s / 32768, exact), one pass (gtcrn_pcm16_to_f32); the count rounded up to the
+                            # kernel's 8 samples per lane: the slack lies inside both buffers and nothing reads it
+                            n8 = (n * Lmax + 7) & ~7
+                            _lib.pcm16_to_f32(sl["din"][:2 * n8].view(torch.int16), out=xf[:n8])
                         else:
                             x.copy_(sl["din"][:nb].view(torch.float32).view(n, Lmax))
                         if min(lens) == Lmax:
                             eng.forward_wave(x, win, out=y)
                         else:
                             eng.forward_wave_var(x, lens, win, out=y)
-                        # write_wav_pcm16's conversion on the device: rint(y * 32768) clipped to the int16 range
-                        y.mul_(32768.0).round_().clamp_(-32768.0, 32767.0)
-                        sl["dout"][:n * Lout].view(n, Lout).copy_(y)
+                        # write_wav_pcm16's conversion on the device: rint(y * 32768) clipped to the int16 range, one pass
+                        # (gtcrn_f32_to_pcm16; n * Lout is a multiple of 256)
+                        _lib.f32_to_pcm16(yf[:n * Lout], out=sl["dout"][:n * Lout])
                         ev_b.record()
                     with torch.cuda.stream(s_out):
                         s_out.wait_event(ev_b)

@@ -112,16 +112,21 @@ def gpu_numa_nodes(sysfs_root="/"):
 
 
 def _visible_index(local_rank):
-    """The physical GPU index behind `local_rank` when HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES / CUDA_VISIBLE_DEVICES
-    hold a numeric list (the launcher's usual form); otherwise local_rank itself."""
-    for var in ("HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES"):
-        v = os.environ.get(var)
-        if v:
-            items = [x.strip() for x in v.split(",") if x.strip()]
-            if all(x.isdigit() for x in items) and local_rank < len(items):
-                return int(items[local_rank])
-            return local_rank
-    return local_rank
+    """The physical GPU index behind `local_rank`, or None when it cannot be told.  The visibility lists COMPOSE:
+    HIP_VISIBLE_DEVICES (CUDA_VISIBLE_DEVICES is its alias on ROCm) indexes INTO the devices ROCR_VISIBLE_DEVICES leaves
+    visible, so local_rank is mapped through the HIP / CUDA list first and the result through the ROCR list.  A list in
+    another form (UUIDs "GPU-...") or an index past a list's end gives None: the caller then leaves the CPU mask alone
+    instead of pinning the rank to a guessed -- possibly the other -- socket."""
+    idx = local_rank
+    for names in (("HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"), ("ROCR_VISIBLE_DEVICES",)):
+        v = next((os.environ[n] for n in names if os.environ.get(n)), None)
+        if not v:
+            continue
+        items = [x.strip() for x in v.split(",") if x.strip()]
+        if not all(x.isdigit() for x in items) or idx >= len(items):
+            return None
+        idx = int(items[idx])
+    return idx
 
 
 def bind_rank_to_gpu_numa(local_rank, sysfs_root="/", apply=True):
@@ -129,10 +134,11 @@ def bind_rank_to_gpu_numa(local_rank, sysfs_root="/", apply=True):
     allowed to use now).  Returns a dict describing what was done -- {"numa_node", "cpus", "bound"} -- so the bench line
     can say so; a node without topology files, a GPU that reports no node (-1: single-socket box) or an empty
     intersection leave the mask alone ("bound": False).  Call it first thing in a rank's process."""
-    info = {"numa_node": None, "cpus": None, "bound": False}
+    info = {"numa_node": None, "cpus": None, "bound": False, "physical_gpu": None}
     numas = gpu_numa_nodes(sysfs_root)
     idx = _visible_index(local_rank)
-    if not numas or idx >= len(numas) or numas[idx] < 0:
+    info["physical_gpu"] = idx if idx is not None else "unknown"
+    if idx is None or not numas or idx >= len(numas) or numas[idx] < 0:
         return info
     node = numas[idx]
     info["numa_node"] = node

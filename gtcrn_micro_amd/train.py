@@ -191,12 +191,27 @@ def validate_step(model, loss_func, noisy, clean, window=None):
     weights.  Returns the loss."""
     m = model.module if hasattr(model, "module") else model
     win = window if window is not None else torch.hann_window(512, device=noisy.device)
-    saved = [b.detach().clone() for b in m.buffers()]
+    # every parameter and buffer of the mirror is a view of ONE device blob once it has run (GTCRNMicro._flatten): the
+    # statistics are saved and put back as two copies, not as 2 x 139 (which showed up as ~280 copyBuffer launches per
+    # prepared train leg in the kernel statistics)
+    flat = None
+    if noisy.is_cuda and hasattr(m, "_flatten"):
+        if not m._flat_ok(noisy.device):
+            m._flatten(noisy.device)
+        flat = (m._flat.detach().clone(), m._nbt_flat.detach().clone())
+    else:
+        saved = [b.detach().clone() for b in m.buffers()]
     loss = loss_func(model(_lib.stft(noisy, win)), _lib.stft(clean, win))
     loss.backward()
     with torch.no_grad():
-        for b, v in zip(m.buffers(), saved):
-            b.copy_(v)
+        if flat is not None and m._flat_ok(noisy.device):
+            m._flat.copy_(flat[0])          # (the weights in it are untouched: no optimizer step ran)
+            m._nbt_flat.copy_(flat[1])
+        elif flat is not None:
+            raise _lib.GtcrnError("validate_step: the model's tensors stopped being views of its flat blob during the step")
+        else:
+            for b, v in zip(m.buffers(), saved):
+                b.copy_(v)
     for p in m.parameters():
         p.grad = None
     return loss.detach()

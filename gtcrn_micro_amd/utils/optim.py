@@ -40,6 +40,9 @@ class FlatAdam(torch.optim.Optimizer):
         super().__init__(list(m.parameters()), defaults)
         self._model = m
         self._m = self._v = self._mask = None
+        self._uniform = True      # every state entry carries the same step count (the normal case: no per-step check)
+        self._wsbuf = None        # the launch pair's own workspace (ticket + partial sums): two optimizers stepping on
+                                  # different streams of one device must not share one
         self._nstep = 0
         self._steps = []          # one 0-d CPU tensor per parameter, like torch.optim.Adam's state["step"] (a tensor shared
                                   # by all entries would be incremented 248 times per step by an Adam that loaded this state)
@@ -54,23 +57,36 @@ class FlatAdam(torch.optim.Optimizer):
         fv = torch.zeros(n, device=device, dtype=torch.float32)
         mask = torch.zeros(n, device=device, dtype=torch.float32)
         step = None
+        own = []                  # the step count each entry brings along (None: no entry)
         for p, (off, numel, shape) in zip(m._train_params, m._train_slices):
             st = self.state[p]
             if "exp_avg" in st:
                 fm[off:off + numel].copy_(st["exp_avg"].reshape(-1))
                 fv[off:off + numel].copy_(st["exp_avg_sq"].reshape(-1))
-                step = int(float(st["step"])) if step is None else step
+                own.append(int(float(st["step"])))
+                step = own[-1] if step is None else step
+            else:
+                own.append(None)
             mask[off:off + numel] = 1.0
-        if step is not None:
-            self._nstep = step
+        # (a loaded state without entries starts from step 0, like a fresh torch.optim.Adam: keeping an older count would
+        # bias-correct zeroed moments with the wrong power)
+        self._nstep = step if step is not None else 0
         self._steps = []
-        for p, (off, numel, shape) in zip(m._train_params, m._train_slices):
+        # (entries of one torch.optim.Adam run carry one count; a state with several -- a parameter was frozen for a while --
+        # keeps them, and step_clipped then checks that the parameters it steps agree)
+        self._uniform = all(o is None or o == self._nstep for o in own)
+        for (p, (off, numel, shape)), o in zip(zip(m._train_params, m._train_slices), own):
             st = self.state[p]
-            st["step"] = torch.tensor(float(self._nstep))
+            st["step"] = torch.tensor(float(self._nstep if o is None else o))
             st["exp_avg"] = fm[off:off + numel].view(shape)
             st["exp_avg_sq"] = fv[off:off + numel].view(shape)
             self._steps.append(st["step"])
         self._m, self._v, self._mask = fm, fv, mask
+
+    def _ws(self, device):
+        if self._wsbuf is None or self._wsbuf.device != device:
+            self._wsbuf = _lib.clip_adam_workspace(device)
+        return self._wsbuf
 
     def load_state_dict(self, state_dict):
         super().load_state_dict(state_dict)
@@ -92,17 +108,35 @@ class FlatAdam(torch.optim.Optimizer):
             self._adopt(flat.device)
         g = _grad_blob(m)
         packed = g is None
+        mask = self._mask
+        live = self._steps
         if packed:                                  # gradients from elsewhere (hand-set, accumulated): pack, run, unpack
             g = torch.zeros_like(flat)
+            frozen = [i for i, p in enumerate(m._train_params) if p.grad is None]
+            if frozen:
+                # torch.optim.Adam and clip_grad_norm_ skip a parameter without a gradient: neither its weight (weight
+                # decay included), nor its moments, nor its step count move.  The kernel updates where the mask is set.
+                mask = mask.clone()
+                for i in frozen:
+                    off, numel, _ = m._train_slices[i]
+                    mask[off:off + numel] = 0.0
+                fz = set(frozen)
+                live = [st for i, st in enumerate(self._steps) if i not in fz]
+                self._uniform = False
             for p, (off, numel, _) in zip(m._train_params, m._train_slices):
                 if p.grad is not None:
                     g[off:off + numel].copy_(p.grad.reshape(-1))
         grp = self.param_groups[0]
-        self._nstep += 1
-        torch._foreach_add_(self._steps, 1)         # (host tensors: what a state_dict carries)
+        if not self._uniform and live and any(float(st) != float(live[0]) for st in live):
+            raise _lib.GtcrnError("FlatAdam: the parameters being stepped have different step counts (one was frozen for a "
+                                  "while): the one-launch step bias-corrects with ONE count -- use torch.optim.Adam")
+        if not live:
+            return torch.zeros((), device=flat.device)
+        self._nstep = int(float(live[0])) + 1
+        torch._foreach_add_(live, 1)                # (host tensors: what a state_dict carries)
         norm = torch.empty(2, device=flat.device, dtype=torch.float32)
-        _lib.clip_adam_step(flat, g, self._m, self._v, self._mask, self._nstep, grp["lr"], grp["betas"], grp["eps"],
-                            grp["weight_decay"], max_norm, norm)
+        _lib.clip_adam_step(flat, g, self._m, self._v, mask, self._nstep, grp["lr"], grp["betas"], grp["eps"],
+                            grp["weight_decay"], max_norm, norm, ws=self._ws(flat.device))
         if packed and max_norm > 0:
             for p, (off, numel, _) in zip(m._train_params, m._train_slices):
                 if p.grad is not None:

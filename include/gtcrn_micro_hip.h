@@ -201,12 +201,14 @@ long gtcrn_debug_tap(gtcrn_model *m, const char *name, int b, float *h_dst, long
 long gtcrn_debug_stamps(gtcrn_model *m, int kernel, unsigned long long *h_dst, long cap);
 /* Checks the MFMA f32 16x16x4 lane maps the kernels rely on (exact integer
  * data, asymmetric operands).  0 = as assumed. */
-/* A copy over the host link by a kernel instead of the DMA engines (no reference counterpart: the reference's callers use
- * tensor.to(device) / .cpu(), infer.py:60-76, train.py:246,255).  dst / src: device memory or PINNED host memory (its
- * address is valid on the device), 16-byte aligned, bytes a multiple of 16; `workgroups` x 256 threads do the copy on
- * `stream`.  Used by the served pipeline (bench.py io, gtcrn_micro_amd/infer.py) for ONE of the two directions: with both
- * on the DMA engines each direction runs at about half its solo rate on this platform. */
-int gtcrn_link_copy(int device, void *dst, const void *src, long bytes, int workgroups, void *stream);
+/* 16-bit PCM at the host boundary: the reference's callers read mono 16-bit WAV files with soundfile (infer.py:54: the
+ * samples arrive as int16 / 32768) and write the enhanced waveform back as 16-bit PCM (infer.py:113, sf.write).  A caller
+ * that hands the int16 SAMPLES over moves half the bytes across the host link, which is what bounds a served pipeline
+ * (bench.py io.served_pcm16_*).  gtcrn_pcm16_to_f32: x = s / 32768 (exact); gtcrn_f32_to_pcm16: s = clip(rint(y * 32768),
+ * -32768, 32767), round half to even.  Device pointers, 16-byte aligned; n samples, a multiple of 8; asynchronous on
+ * `stream`.  The bulk offline driver (gtcrn_micro_amd/infer.py) uses both. */
+int gtcrn_pcm16_to_f32(int device, const short *d_pcm, float *d_wave, long n, void *stream);
+int gtcrn_f32_to_pcm16(int device, const float *d_wave, short *d_pcm, long n, void *stream);
 int gtcrn_selftest_mfma(int device);
 /* The exact three-way bf16 split the dense 3x3 runs on (kernels.hip split3 / join3 / split_mm6), on caller-chosen
  * values: h_x[n] (n a multiple of 4) -> h_planes[3][n] (hi, mid, lo as floats) and h_joined[n] (= h_x bit for bit

@@ -237,25 +237,28 @@ def test_pipelined_folder_driver_writes_the_serial_drivers_bytes(tmp_path):
 
 
 @pytest.mark.gpu
-def test_link_copy_kernel_moves_pinned_host_buffers_both_ways():
-    """gtcrn_link_copy: a copy over the host link by a kernel (pinned host memory is addressable from the device) --
-    device -> pinned host, pinned host -> device and device -> device, odd workgroup counts, a size that is not a multiple
-    of the kernel's unrolled stride; unpinned or misaligned arguments are refused."""
+def test_pcm16_boundary_conversions_are_soundfiles_and_wavfile_writes():
+    """gtcrn_pcm16_to_f32 / gtcrn_f32_to_pcm16, the 16-bit PCM boundary of the served pipeline and the folder driver: in,
+    every int16 value / 32768 exactly (what soundfile.read hands infer.py:54); out, clip(rint(y * 32768)) with round half
+    to even -- np.rint's and write_wav_pcm16's bytes --, including ties (k + 0.5), both clipping ends, -0.0 and a size that
+    is several grid strides; int16 -> float -> int16 is the identity; misaligned or odd-sized arguments are refused."""
     import torch
     import gtcrn_micro_amd as G
-    n = 4 * 12345
-    src = torch.randn(n, device="cuda")
-    host = torch.empty(n).pin_memory()
-    back = torch.empty(n, device="cuda")
-    G.link_copy(host, src, workgroups=7)
+    allv = torch.arange(-32768, 32768, dtype=torch.int32).to(torch.int16).cuda()
+    x = G.pcm16_to_f32(allv)
+    assert torch.equal(x.cpu(), allv.cpu().to(torch.float32) / 32768.0)
+    assert torch.equal(G.f32_to_pcm16(x), allv)
+    rng = np.random.default_rng(5)
+    y = np.concatenate([rng.standard_normal(8 * 300001).astype(np.float32) * 0.5,
+                        ((np.arange(-40, 40, dtype=np.float32) + 0.5) / 32768.0),             # ties: half to even
+                        np.array([1.0, -1.0, 0.99999, -1.00002, 3.5, -7.0, -0.0, 1e-9], np.float32)])
+    want = np.clip(np.rint(y * np.float32(32768.0)), -32768, 32767).astype(np.int16)
+    got = G.f32_to_pcm16(torch.from_numpy(y).cuda())
     torch.cuda.synchronize()
-    assert torch.equal(host, src.cpu())
-    G.link_copy(back, host, workgroups=33)
-    dd = torch.empty(n, device="cuda")
-    G.link_copy(dd, back, workgroups=1)
-    torch.cuda.synchronize()
-    assert torch.equal(back, src) and torch.equal(dd, src)
+    assert np.array_equal(got.cpu().numpy(), want)
     with pytest.raises(G.GtcrnError):
-        G.link_copy(torch.empty(n), src)                       # pageable host memory
+        G.f32_to_pcm16(torch.zeros(12, device="cuda"))                       # not a multiple of 8
     with pytest.raises(G.GtcrnError):
-        G.link_copy(host[1:5], src[1:5])                       # 4-byte aligned, 16 bytes
+        G.pcm16_to_f32(torch.zeros(24, dtype=torch.int16, device="cuda")[4:20])  # 8-byte aligned
+    with pytest.raises(G.GtcrnError):
+        G.pcm16_to_f32(torch.zeros(16, dtype=torch.int16))                   # host tensor

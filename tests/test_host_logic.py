@@ -617,11 +617,26 @@ def test_rank_is_bound_to_the_numa_node_of_its_gpu(tmp_path, monkeypatch):
         monkeypatch.delenv(v, raising=False)
     i0 = S.bind_rank_to_gpu_numa(1, root, apply=False)
     i1 = S.bind_rank_to_gpu_numa(6, root, apply=False)
-    assert i0 == {"numa_node": 0, "cpus": len(lo), "bound": True} and i1 == {"numa_node": 1, "cpus": len(hi), "bound": True}
+    assert i0 == {"numa_node": 0, "cpus": len(lo), "bound": True, "physical_gpu": 1}
+    assert i1 == {"numa_node": 1, "cpus": len(hi), "bound": True, "physical_gpu": 6}
     # a launcher that remaps the devices: local rank 0 is physical GPU 5 -> node 1
     monkeypatch.setenv("HIP_VISIBLE_DEVICES", "5,6")
     assert S.bind_rank_to_gpu_numa(0, root, apply=False)["numa_node"] == 1
+    # the lists compose: HIP_VISIBLE_DEVICES indexes INTO what ROCR_VISIBLE_DEVICES leaves visible -- local rank 1 ->
+    # HIP entry "0" -> ROCR entry "2" -> physical GPU 2 (node 0); local rank 0 -> "1" -> "7" (node 1)
+    monkeypatch.setenv("ROCR_VISIBLE_DEVICES", "2,7")
+    monkeypatch.setenv("HIP_VISIBLE_DEVICES", "1,0")
+    got = S.bind_rank_to_gpu_numa(1, root, apply=False)
+    assert (got["physical_gpu"], got["numa_node"]) == (2, 0)
+    got = S.bind_rank_to_gpu_numa(0, root, apply=False)
+    assert (got["physical_gpu"], got["numa_node"]) == (7, 1)
+    # a list that cannot be resolved (UUID form, an index past its end): no guess, no binding
+    monkeypatch.setenv("ROCR_VISIBLE_DEVICES", "GPU-6f5e4d3c2b1a0000,GPU-0000a1b2c3d4e5f6")
+    assert S.bind_rank_to_gpu_numa(0, root, apply=False) == {"numa_node": None, "cpus": None, "bound": False, "physical_gpu": "unknown"}
+    monkeypatch.setenv("ROCR_VISIBLE_DEVICES", "3")
+    assert S.bind_rank_to_gpu_numa(0, root, apply=False)["bound"] is False          # HIP entry "1" of a one-entry ROCR list
     monkeypatch.delenv("HIP_VISIBLE_DEVICES")
+    monkeypatch.delenv("ROCR_VISIBLE_DEVICES")
     # really applied (and restored): the process mask becomes the node's CPUs
     try:
         got = S.bind_rank_to_gpu_numa(2, root, apply=True)
@@ -629,13 +644,13 @@ def test_rank_is_bound_to_the_numa_node_of_its_gpu(tmp_path, monkeypatch):
     finally:
         os.sched_setaffinity(0, allowed)
     # nothing to go by: no topology, a GPU without a node, CPUs we may not use -> the mask is left alone
-    assert S.bind_rank_to_gpu_numa(0, str(tmp_path / "nowhere")) == {"numa_node": None, "cpus": None, "bound": False}
+    assert S.bind_rank_to_gpu_numa(0, str(tmp_path / "nowhere")) == {"numa_node": None, "cpus": None, "bound": False, "physical_gpu": 0}
     root2 = str(tmp_path / "single")
     _fake_sysfs(root2, [(128, -1)], {})
     assert S.bind_rank_to_gpu_numa(0, root2)["bound"] is False
     root3 = str(tmp_path / "foreign")
     _fake_sysfs(root3, [(128, 0)], {0: "100000-100003"})
-    assert S.bind_rank_to_gpu_numa(0, root3) == {"numa_node": 0, "cpus": None, "bound": False}
+    assert S.bind_rank_to_gpu_numa(0, root3) == {"numa_node": 0, "cpus": None, "bound": False, "physical_gpu": 0}
     assert sorted(os.sched_getaffinity(0)) == allowed
 
 
