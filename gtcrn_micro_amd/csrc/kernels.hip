@@ -1754,156 +1754,10 @@ segment_top:
     STAMP_OUT(SS, stamps)
 }
 
-#ifdef GT_EXP
-// =============================================================================== encoder blocks, pair form (experiment)
-// MEASURED AND NOT ADOPTED (round 5, profiles/r05_ab_encoder_pair.txt): 0.268 ms against 0.214 ms for the 11-wave form at
-// B = 256 x 4 s, outputs bit-identical.  Compiled only into the -DGT_EXP library (tools/ab_bench.py, tools/ab_check.py).
-// The three causal GTConv blocks of an offline call (what k_encoder<TPW, false, false, false, SPANS = true> does) for TWO
-// workgroups per CU: six waves on 8-frame chunks (264 positions = 16.5 tiles on 18 tile slots, three per wave), 79 KB
-// of LDS each, so that a CU hosts two independent barrier domains at the same 12 waves.  Same gtconv_block, same
-// expressions, same order: bit-identical outputs.  Two six-wave workgroups share a CU only at <= 128 VGPRs and
-// <= 81 920 B of LDS (tools/ubench_coresidency.hip: the six waves go 2 / 2 / 1 / 1 over the SIMDs and the second
-// workgroup lands on the same pattern, so SIMD 0 and 1 carry four waves) -- hence amdgpu_waves_per_eu(4, 4) below, which
-// costs this kernel five spilled registers; at its natural 141 VGPRs the 512 workgroups run in two rounds (0.368 ms).
-// What the form pays: the (utterance, frame) axis has to be cut into 512 shares at B = 256 (12 frames of warm-up in front
-// of every share that starts inside an utterance), every block's fixed phases run per 8 frames instead of 16, and the
-// images drop to a 35-record row pitch (the 41-record pitch of the 11-wave form does not fit).
-// A SECOND experiment on the same kernel body (EncWide: sixteen waves, two tiles per wave, 15-frame chunks = 495 positions on
-// 32 tile slots, one workgroup per CU): four waves on every SIMD instead of 3 / 3 / 3 / 2 and two thirds of the work per wave.
-struct EncPair { static constexpr int NWV = 6, RWV = 8, TPWV = 3, PT = 35, RSS = PERM_RS, WAVES_EU = 4, PER_CU = 2; };
-struct EncWide { static constexpr int NWV = 16, RWV = 15, TPWV = 2, PT = 41, RSS = RS_WIDE, WAVES_EU = 4, PER_CU = 1; };
-template <class CF>
-struct EncPairLds {
-    static constexpr int EP_NW = CF::NWV, EP_RW = CF::RWV;
-    static constexpr int RS = RS_WIDE, PT = CF::PT, RSS = CF::RSS;
-    static constexpr int P = 0;                                   // the three blocks' parameters (E_BLK ..)
-    static constexpr int I = P + 3 * GB_SIZE;                     // ints: I_ENC_BLK[3][16], then I_ENST[4][16]
-    static constexpr int H = I + 48 + 64;
-    static constexpr int EH = H + 3 * RING_DENSE;
-    static constexpr int G = EH + 48;
-    static constexpr int E = G + EP_RW * 16 + EP_RW * 8;
-    static constexpr int A = E + (EP_RW + 2) * 8;                 // W: two history rows + the chunk's rows
-    static constexpr int S = A + (EP_RW + IMG_R0) * PT * RS;      // v^2 / permute scratch: one record per tile-slot position
-    static constexpr int FLOATS = S + EP_NW * CF::TPWV * 16 * RSS;
-    static_assert(I % 4 == 0 && H % 4 == 0 && EH % 4 == 0 && G % 4 == 0 && E % 4 == 0 && A % 4 == 0 && S % 4 == 0, "16B carve");
-    static_assert(FLOATS * 4 * CF::PER_CU <= 160 * 1024, "workgroups per CU");
-    // lanes of the last tile that lie past the image read (never write) up to one row behind it: inside S
-    static_assert(PT * RS <= EP_NW * CF::TPWV * 16 * RSS, "reads past the image stay inside the allocation");
-};
-
-template <class CF>
-__global__ __launch_bounds__(CF::NWV * 64) __attribute__((amdgpu_waves_per_eu(CF::WAVES_EU, CF::WAVES_EU))) void k_encoder_pair(int T, const int* __restrict__ pref, int NB,
-                                                           const float* __restrict__ PF, const int* __restrict__ PI,
-                                                           const float* __restrict__ en1, float* __restrict__ en2,
-                                                           float* __restrict__ en3, float* __restrict__ en4) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    STAMP_INIT(SS)
-    using LD = EncPairLds<CF>;
-    constexpr int EP_NW = CF::NWV, EP_RW = CF::RWV, EP_NT = EP_NW * 64;
-    constexpr int RS = LD::RS, RW = EP_RW, TPWV = CF::TPWV;
-    float* sP = smem + LD::P;
-    int* sI = reinterpret_cast<int*>(smem + LD::I);
-    float* sH = smem + LD::H;
-    float* sEH = smem + LD::EH;
-    float* sG = smem + LD::G;
-    float* sW = smem + LD::A;
-    float* sS = smem + LD::S;
-    const Lane L = lane_info();
-    const int tid = L.tid, g = L.g;
-    const int Tstride = T;
-    SpanIter sit;
-    int s_b = 0, s_fb = 0, s_wlo = 0, s_nT = 0;
-    if (!span_begin(sit, blockIdx.x, gridDim.x, NB, T, pref)) return;
-    span_next(sit, NB, Tstride, pref, HALO_BLOCKS, s_b, s_fb, s_wlo, s_nT);
-
-    copy_params(sP, PF + P_ENC + E_BLK, 3 * GB_SIZE, tid, EP_NT);
-    if (tid < 48 + 64) sI[tid] = PI[tid < 48 ? I_ENC_BLK + tid : I_ENST + tid - 48];
-    auto zero_rings = [&]() {
-        for (int i = tid; i < 3 * RING_DENSE / 4; i += EP_NT) st4(sH + 4 * i, splat(0.f));
-        if (tid < 48) sEH[tid] = 0.f;
-    };
-    zero_rings();
-    const Tiles<TPWV> tt = make_tiles<TPWV, EP_NW>(L);
-    wg_barrier();
-    ring_to_image<RS, LD::PT>(sW, sH, tid);
-
-    const float* x1h;
-    float *en2h, *en3h, *en4h;
-    int wlo;
-    auto seg_setup = [&](int sb_, int sfb, int swlo, int snT) {
-        const long ob = ((long)sb_ * Tstride + sfb) * 528;
-        x1h = en1 + ob; en2h = en2 + ob; en3h = en3 + ob; en4h = en4 + ob;
-        T = snT;
-        wlo = swlo;
-    };
-    seg_setup(s_b, s_fb, s_wlo, s_nT);
-    f32x4 xn[TPWV];
-segment_top:
-    {
-        const int np0 = min(RW, T) * 33;
-#pragma unroll
-        for (int i = 0; i < TPWV; ++i) xn[i] = ld4(x1h + (unsigned)((tt.pp(i) < np0 ? tt.pp(i) : 0) * 16 + 4 * g));
-    }
-    for (int t0 = 0; t0 < T; t0 += RW) {
-        const int nfr = min(RW, T - t0);
-        f32x4 x[TPWV];
-        {   // en1 arrives in the slot order of its decoder consumer (see k_encoder)
-            const int* ix = sI + 48 + 0 * 16 + 4 * g;
-            int po[TPWV];
-#pragma unroll
-            for (int i = 0; i < TPWV; ++i) po[i] = tt.pp(i) * PERM_RS;
-            unpermute_tiles_via_lds<TPWV>(sS, po, ix, g, xn, x);
-        }
-        if (t0 + RW < T) {
-            const int npn = min(RW, T - t0 - RW) * 33;
-            const float* xc = x1h + (long)(t0 + RW) * 528;
-#pragma unroll
-            for (int i = 0; i < TPWV; ++i) xn[i] = ld4(xc + (unsigned)((tt.pp(i) < npn ? tt.pp(i) : 0) * 16 + 4 * g));
-        }
-        zero_row_pads<RW + IMG_R0, RS, LD::PT>(sW, tid);
-#pragma unroll 1
-        for (int k = 0; k < 3; ++k) {
-            BlockCtx c;
-            c.pb = sP + k * GB_SIZE;
-            c.gA = nullptr;
-            c.ib = sI + k * 16;
-            c.sW = sW; c.sHk = sH + k * RING_DENSE; c.sS = sS; c.sG = sG; c.sEHk = sEH + k * 16;
-            c.sHtop = nullptr;
-            c.sHnext = k < 2 ? sH + (k + 1) * RING_DENSE : sH;
-            c.sE = smem + LD::E;
-            c.sY = sG + RW * 16;
-            c.nfr = nfr; c.tabs = t0;
-            c.sTB = nullptr; c.ms_roff[0] = 0; c.ms_tb[0] = 0; c.g_hist[0] = nullptr;
-            gtconv_block<false, TPWV, false, false, RS, LD::RSS, true, LD::PT, 0, -1, EP_NW, EP_RW * 33>(x, tt, c, L, [] {}, [] {} STAMP_ARG);
-            if (k < 2) {
-                float* dst = k == 0 ? en2h : en3h;
-                const int* ix = sI + 48 + (k + 1) * 16 + 4 * g;
-                int po[TPWV];
-                f32x4 y[TPWV];
-#pragma unroll
-                for (int i = 0; i < TPWV; ++i) po[i] = tt.pp(i) * PERM_RS;
-                permute_tiles_via_lds<TPWV>(sS, po, ix, g, x, y);
-#pragma unroll
-                for (int i = 0; i < TPWV; ++i)
-                    if (tt.pp(i) < nfr * 33 && t0 + tt.tl[i] >= wlo) st4(dst + (long)t0 * 528 + (unsigned)(tt.pp(i) * 16 + 4 * g), y[i]);
-            } else {
-#pragma unroll
-                for (int i = 0; i < TPWV; ++i)
-                    if (tt.pp(i) < nfr * 33 && t0 + tt.tl[i] >= wlo) st4(en4h + (long)t0 * 528 + (unsigned)(tt.pp(i) * 16 + 4 * g), x[i]);
-            }
-        }
-        wg_barrier();
-    }
-    if (span_next(sit, NB, Tstride, pref, HALO_BLOCKS, s_b, s_fb, s_wlo, s_nT)) {
-        zero_rings();
-        wg_barrier();
-        ring_to_image<RS, LD::PT>(sW, sH, tid);
-        seg_setup(s_b, s_fb, s_wlo, s_nT);
-        goto segment_top;
-    }
-}
-
-#endif   // GT_EXP
+// (Two other workgroup shapes of these three blocks were built on the same gtconv_block in round 5 -- two six-wave
+// workgroups per CU over 512 shares, and sixteen waves with two tiles each -- measured same-box, bit-identical, not faster
+// (0.268 / 0.2068 ms against 0.214 / 0.2063 ms), and removed from the source in round 6: profiles/r05_ab_encoder_forms.txt.
+// gtconv_block keeps the NWV / PMAX template arguments they introduced: the wide streaming step uses them.)
 
 // =============================================================================== front end (offline form)
 // Everything in front of the first GTConv block has NO dependence across frames: reflect-pad framing, window, FFT
@@ -4652,14 +4506,6 @@ int configure_kernels() {
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_stream_wide<SwCfg>), hipFuncAttributeMaxDynamicSharedMemorySize,
                             SW_LDS_FLOATS * 4);
     if (e != hipSuccess) return (int)e;
-#ifdef GT_EXP
-    e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_encoder_pair<EncPair>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            EncPairLds<EncPair>::FLOATS * 4);
-    if (e != hipSuccess) return (int)e;
-    e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_encoder_pair<EncWide>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            EncPairLds<EncWide>::FLOATS * 4);
-    if (e != hipSuccess) return (int)e;
-#endif
     const void* gt[] = {reinterpret_cast<const void*>(k_gtcn<TPW, false>), reinterpret_cast<const void*>(k_gtcn<1, false>),
                         reinterpret_cast<const void*>(k_gtcn<1, true>),
                         reinterpret_cast<const void*>(k_gtcn<2, true>), reinterpret_cast<const void*>(k_gtcn<2, false>)};
@@ -4729,20 +4575,6 @@ int launch_encoder(const float* spec, long sb, long sf, long st, int B, int T, c
         GT_LAUNCH_CHECK();
         return 0;
     }
-#ifdef GT_EXP      // experiments (tools/ab_bench.py): GT_EXP_PAIR: two six-wave workgroups per CU over 512 shares; default:
-                   // the sixteen-wave form, one workgroup per utterance
-    if (front_done && !state && !q && lens == nullptr && B <= 512 && (long)B * T >= 512L * 2 * HALO_BLOCKS) {
-#ifdef GT_EXP_PAIR
-        hipLaunchKernelGGL(k_encoder_pair<EncPair>, dim3(512), dim3(EncPair::NWV * 64), EncPairLds<EncPair>::FLOATS * 4, s, T,
-                           (const int*)nullptr, B, PF, PI, en1, en2, en3, en4);
-#else
-        hipLaunchKernelGGL(k_encoder_pair<EncWide>, dim3(B <= 256 ? B : 512), dim3(EncWide::NWV * 64),
-                           EncPairLds<EncWide>::FLOATS * 4, s, T, (const int*)nullptr, B, PF, PI, en1, en2, en3, en4);
-#endif
-        GT_LAUNCH_CHECK();
-        return 0;
-    }
-#endif
 #define GT_ENC(TPWV, QV, FRV)                                                                                       \
     hipLaunchKernelGGL((k_encoder<TPWV, false, QV, FRV>), dim3(B), dim3(NTHR),                                      \
                        (FRV ? ENC_LDS_FLOATS : ENC_GT_LDS_FLOATS) * 4, s, spec, sb, sf, st,                         \
