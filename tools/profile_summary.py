@@ -17,7 +17,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def short(name):
-    for k in ("k_stream_ms", "k_front", "k_stft", "k_istft", "k_encoder", "k_gtcn_ms", "k_gtcn", "k_decoder", "k_state_convert"):
+    for k in ("k_stream_wide", "k_stream_ms", "k_front", "k_stft", "k_istft", "k_encoder", "k_gtcn_ms", "k_gtcn", "k_decoder", "k_state_convert"):
         if k in name:
             return k
     return None
@@ -62,7 +62,7 @@ def main():
     # Round 5 calibrated the other widths (tools/ubench_fetch_size.hip -> profiles/r05_fetch_calibration.json): a fully
     # coalesced streaming read is tallied at HALF its bytes at 4, 8 and 16 bytes per lane alike, plain or nontemporal
     # (factor 2.000 +- 1e-4 on 1 GiB); WRITE_SIZE is exact at every width.  One multiplier for every kernel.
-    WIDE = {"k_decoder", "k_gtcn", "k_encoder", "k_front", "k_istft", "k_stft", "k_stream_ms", "k_gtcn_ms", "k_state_convert"}
+    WIDE = {"k_decoder", "k_gtcn", "k_encoder", "k_front", "k_istft", "k_stft", "k_stream_ms", "k_stream_wide", "k_gtcn_ms", "k_state_convert"}
     traffic = {}
     for k in sorted(set(fetch) | set(write)):
         fs = fetch.get(k, {}).get("FETCH_SIZE", [])
@@ -163,8 +163,8 @@ def main():
     # Infinity Cache): bytes per frame-step against SURVEY 8d's 94 KB state-traffic figure
     sres = {}
     for N in (1024, 16384, 65536):
-        fs = [v for k, c in pmc(f"stream_pmc_{N}_fetch").items() if k == "k_stream_ms" for v in c.get("FETCH_SIZE", [])]
-        ws = [v for k, c in pmc(f"stream_pmc_{N}_write").items() if k == "k_stream_ms" for v in c.get("WRITE_SIZE", [])]
+        fs = [v for k, c in pmc(f"stream_pmc_{N}_fetch").items() if k in ("k_stream_ms", "k_stream_wide") for v in c.get("FETCH_SIZE", [])]
+        ws = [v for k, c in pmc(f"stream_pmc_{N}_write").items() if k in ("k_stream_ms", "k_stream_wide") for v in c.get("WRITE_SIZE", [])]
         if not fs and not ws:
             continue
         fkb = sum(fs) / len(fs) if fs else 0.0
@@ -175,7 +175,7 @@ def main():
                         "bytes_per_frame_step": round(byt / N, 1), "of_94KB_state_figure": round(byt / N / (94 * 1024), 3),
                         "state_MiB": round(N * 152464 / 2 ** 20, 1)}
     if sres:
-        sres["note"] = ("k_stream_ms, one launch per single-frame step of N streams; FETCH_SIZE x 2 + WRITE_SIZE per launch "
+        sres["note"] = ("k_stream_ms (N <= 4 096 here) / k_stream_wide (seven streams per workgroup, picked by the library at N = 16 384 and 65 536), one launch per single-frame step of N streams; FETCH_SIZE x 2 + WRITE_SIZE per launch "
                         "(the counters sit on the L2's memory side: Infinity-Cache hits are counted, MI355X_MICROARCH.md)")
         json.dump(sres, open(os.path.join(dst, f"{tag}_stream_hbm_traffic.json"), "w"), indent=1)
         print(json.dumps(sres, indent=1))
@@ -233,7 +233,7 @@ def main():
         if os.path.exists(plain):
             open(os.path.join(dst, f"{tag}_ubench_mfma_valu.txt"), "w").write(open(plain).read())
     # --- streaming / training traces
-    for sub, pats in (("stream", ("k_stream_ms", "k_encoder", "k_gtcn_ms", "k_decoder")), ("train_f32", None), ("train_bf16", None),
+    for sub, pats in (("stream", ("k_stream_ms", "k_stream_wide", "k_encoder", "k_gtcn_ms", "k_decoder")), ("train_f32", None), ("train_bf16", None),
                       ("train_bf16_saves", None), ("train_bf16_grads", None)):
         f = newest(sub, "*kernel_stats.csv")
         if not f:
