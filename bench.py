@@ -255,6 +255,58 @@ def cpu_model_name():
     return platform.processor() or platform.machine() or "unknown"
 
 
+_CPU_HOST_WORKER = r"""
+import os, sys, time
+import numpy as np
+import torch
+sys.path.insert(0, sys.argv[1])
+from oracle.torch_port import TorchPort
+threads, seconds = int(sys.argv[2]), float(sys.argv[3])
+torch.set_num_threads(threads)
+port = TorchPort(np.fromfile(os.path.join(sys.argv[1], "tests", "golden", "params_dns3.f32"), dtype=np.float32))
+win = torch.hann_window(512).pow(0.5)
+x = torch.randn(16, 64000, generator=torch.Generator().manual_seed(43 + os.getpid() % 97)) * 0.1
+port.enhance(x, win)
+n, t0 = 0, time.perf_counter()
+while True:
+    port.enhance(x, win)
+    n += 1
+    el = time.perf_counter() - t0
+    if el >= seconds:
+        break
+print("RATE", n * 16 * 251 / el)
+"""
+
+
+def cpu_host_wide(threads_each, seconds=5.0, max_procs=16, limit_s=180.0):
+    """The same CPU port as several concurrent processes (each `threads_each` threads, its own B = 16 batches): what the
+    HOST -- not one PyTorch process, which stops scaling at 16-32 threads on this 19 k-parameter model -- gets through.
+    Plain child processes running a few lines of Python (no GPU context, nothing shared with this process), ~5 s each,
+    all at once, under a time limit."""
+    import subprocess
+    ncpu = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    procs = max(1, min(max_procs, ncpu // max(1, threads_each)))
+    if procs < 2:
+        return None
+    env = dict(os.environ, OMP_NUM_THREADS=str(threads_each), MKL_NUM_THREADS=str(threads_each))
+    kids = [subprocess.Popen([sys.executable, "-c", _CPU_HOST_WORKER, ROOT, str(threads_each), str(seconds)],
+                             stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True, env=env) for _ in range(procs)]
+    rates, t_end = [], time.time() + limit_s
+    for k in kids:
+        try:
+            out, _ = k.communicate(timeout=max(1.0, t_end - time.time()))
+            rates += [float(l.split()[1]) for l in out.splitlines() if l.startswith("RATE")]
+        except subprocess.TimeoutExpired:
+            k.kill()
+            k.communicate()
+    if len(rates) < procs:
+        return {"error": f"{procs - len(rates)} of {procs} CPU processes did not finish within {limit_s:g} s"}
+    return {"value": round(sum(rates), 1), "unit": "frames/s", "processes": procs, "threads_each": int(threads_each),
+            "cores": int(procs * threads_each),
+            "sample": f"{procs} concurrent processes x {threads_each} threads, each passing B=16 four-second clips through "
+                      f"oracle/torch_port.py for {seconds:g} s; the sum of their rates"}
+
+
 def cpu_baseline(params, seconds_per_candidate=3.0):
     """The reference's CPU arithmetic (ATen) on a bounded sample of the same workload.
 
@@ -290,7 +342,13 @@ def cpu_baseline(params, seconds_per_candidate=3.0):
     best16 = max(sweep16, key=sweep16.get)
     best1 = max(sweep1, key=sweep1.get)
     n, el = passes[best16]
+    # one process stops scaling at 16-32 threads; the host has more cores: the same port as concurrent processes
+    try:
+        host = cpu_host_wide(min(best16, 16))
+    except Exception as e:                                    # (a host that cannot spawn: the single-process figure stands)
+        host = {"error": repr(e)}
     return {
+        "host_wide": host,
         "value": round(sweep16[best16], 1), "unit": "frames/s", "cores": int(best16), "kind": "port",
         "sample": f"{n} passes of 16 four-second clips (B=16, {el:.1f} s) through oracle/torch_port.py "
                   f"(PyTorch {torch.__version__} CPU, the reference's ATen op sequence) at {best16} threads, the "
@@ -1264,6 +1322,9 @@ def main(argv=None):
             # a reported baseline, not the target: the CPU leg moves 2x from host to host on the pool, so the ratio says
             # no more than ">> 100x" (north_star's bar) -- it lives inside the object, not at the top of the line
             line["cpu_baseline"]["gpu_over_cpu"] = round(line["value"] / line["cpu_baseline"]["value"], 1)
+            hw = line["cpu_baseline"].get("host_wide") or {}
+            if hw.get("value"):
+                line["cpu_baseline"]["gpu_over_cpu_host_wide"] = round(line["value"] / hw["value"], 1)
         print(json.dumps(line), flush=True)
     if world > 1:
         line = None                                            # printed: a late watchdog must not print it again

@@ -83,7 +83,7 @@ def _check_bench_line(stdout, steps, warmup, world=2):
     assert len(pr["all"]) == world and pr["min"] <= pr["max"] and abs(pr["max"] - d["ms_per_step"]) < 1e-3
     # host-side cost of a step per rank (what N processes on one host contend with) and where each rank was bound
     assert len(d["host_us_per_step_per_rank"]) == world and d["host_us_per_step"] == max(d["host_us_per_step_per_rank"])
-    assert len(d["numa_binding"]) == world and all(set(b) == {"numa_node", "cpus", "bound"} for b in d["numa_binding"])
+    assert len(d["numa_binding"]) == world and all(set(b) == {"numa_node", "cpus", "bound", "physical_gpu"} for b in d["numa_binding"])
     return d
 
 
