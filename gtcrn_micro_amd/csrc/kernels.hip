@@ -15,6 +15,8 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
+#include <cstdio>
+#include <cstdlib>
 #include <type_traits>
 
 #include "kernels.h"
@@ -2981,6 +2983,22 @@ segment_top:
 //     decoder history during the GTCN, dense planes by LDS-DMA during the previous block).
 // Same helper code (gtconv_block, tcn_block_ms, the front-end expressions) as the three-launch form, same rounding:
 // streamed == offline bit for bit (tests/test_gpu_stream.py).  The three-launch form remains for the stage taps.
+// Launches of many rounds of workgroups: every workgroup walks the same phases, all 256 CUs start together, and the phases
+// that request the GTCN history rows (a third of the step's state traffic within a fifth of its time) then ask for more
+// than the HBM delivers -- the per-block stamps of the GTCN phase show the LATER blocks of the first stack waiting for rows
+// that were requested with the first block's (profiles/r06_ab_stream_wide.txt).  The first round's workgroups therefore
+// start one of 32 phase shifts late (a sleep, once per launch); every CU runs its workgroups back to back, so the
+// shift persists and the chip-wide demand is spread over the step.  `unit` = 0: no stagger (launches of a few rounds).
+__device__ __forceinline__ void stagger_start(int unit) {
+#ifndef GT_EXP_NOSTAGGER
+    // unit: low byte = sleeps of 8 x 64 clocks per phase shift, the bits above = number of phase shifts (a power of two <= 256)
+    if (unit > 0 && blockIdx.x < 256) {
+        // (consecutive workgroups go to consecutive XCDs: the shifts are spread inside every XCD first)
+        const int ph = ((blockIdx.x >> 3) + 32 * (blockIdx.x & 7)) & ((unit >> 8) - 1);
+        for (int i = 0; i < ph * (unit & 255); ++i) __builtin_amdgcn_s_sleep(8);
+    }
+#endif
+}
 struct SmLds {
     static constexpr int RW = MS_ROWS, NS = MS_STREAMS;
     static constexpr int PE = 0;                                  // encoder segment, then both GTCN stacks (contiguous in PF too)
@@ -3022,8 +3040,10 @@ constexpr int SM_LDS_FLOATS = SmLds::FLOATS;
 __global__ __launch_bounds__(NTHR) void k_stream_ms(const float* __restrict__ spec, long sb, long sf,
                                                    float* __restrict__ out, long osb, long osf, int NB,
                                                    const float* __restrict__ PF, const int* __restrict__ PI,
-                                                   float* __restrict__ state, unsigned long long* __restrict__ stamps) {
+                                                   float* __restrict__ state, unsigned long long* __restrict__ stamps,
+                                                   int stagger) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
+    stagger_start(stagger);
     STAMP_INIT(SS)
     using LD = SmLds;
     constexpr int RW = LD::RW, NS = LD::NS;
@@ -3606,8 +3626,10 @@ template <class CF>
 __global__ __launch_bounds__(CF::NT) void k_stream_wide(const float* __restrict__ spec, long sb, long sf,
                                                        float* __restrict__ out, long osb, long osf, int NB,
                                                        const float* __restrict__ PF, const int* __restrict__ PI,
-                                                       float* __restrict__ state, unsigned long long* __restrict__ stamps) {
+                                                       float* __restrict__ state, unsigned long long* __restrict__ stamps,
+                                                       int stagger) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
+    stagger_start(stagger);
     STAMP_INIT(SS)
     using LD = SwLds<CF>;
     constexpr int RW = CF::RW, NS = CF::NS, NWV = CF::NWV, NT = CF::NT, TPW = CF::TPW, PMAX = CF::PMAX;
@@ -3997,12 +4019,27 @@ __global__ __launch_bounds__(CF::NT) void k_stream_wide(const float* __restrict_
                     }
                 }
             };
+#ifdef GT_STAMPS_GTCN      // (diagnostic: the eight TCN blocks of the step in stamp slots 0 .. 7 instead of the phase sums)
+#define GTCN_STAMP(i) if (stack == 0) STAMP(SS, i) else STAMP(SS, 4 + i)
+            if (stack == 0) {
+#pragma unroll
+                for (int k_ = 0; k_ < 16; ++k_) SS.acc[k_] = 0;
+                SS.t = __builtin_amdgcn_s_memtime();
+            }
+#else
+#define GTCN_STAMP(i)
+#endif
             blk(std::integral_constant<int, 0>{}, std::integral_constant<int, 1>{});
+            GTCN_STAMP(0)
             blk(std::integral_constant<int, 1>{}, std::integral_constant<int, 2>{});
+            GTCN_STAMP(1)
             // the decoder's first history image: requested where the second stack has released half of its row registers
             if (stack == 1) hist_fetch(ST_DEC_H, hv);
             blk(std::integral_constant<int, 2>{}, std::integral_constant<int, 4>{});
+            GTCN_STAMP(2)
             blk(std::integral_constant<int, 3>{}, std::integral_constant<int, 8>{});
+            GTCN_STAMP(3)
+#undef GTCN_STAMP
         }
 #pragma unroll
         for (int i = 0; i < TPW; ++i) x[i] = x[i] + x0[i];         // gtcn2(gtcn1(x)) + en_outs[4] (Decoder.forward :467)
@@ -4020,6 +4057,10 @@ __global__ __launch_bounds__(CF::NT) void k_stream_wide(const float* __restrict_
         spn[q + 1] = make_float2(pk[2], pk[3]);
     }
     __builtin_amdgcn_sched_barrier(0);
+#ifdef GT_STAMPS_GTCN
+    STAMP_OUT(SS, stamps)
+    stamps = nullptr;
+#endif
     STAMP(SS, 9)
     // ------------------------------------------------------------------------------------------------- decoder
     constexpr int RS = LD::RSD;
@@ -4739,21 +4780,36 @@ int launch_decoder(const float* xg, const float* en0, const float* en1, const fl
 int launch_stream_ms(const float* spec, long sb, long sf, float* out, long osb, long osf, int B, const float* PF,
                      const int* PI, float* state, unsigned long long* stamps, hipStream_t s) {
     const int grid = (B + MS_STREAMS - 1) / MS_STREAMS;
+    // eight phase shifts over a ~33 us workgroup: ~10 k cycles each = 2 sleeps of 100 x 64 clocks; from four rounds on
     hipLaunchKernelGGL(k_stream_ms, dim3(grid), dim3(NTHR), SM_LDS_FLOATS * 4, s, spec, sb, sf, out, osb, osf, B, PF, PI,
-                       state, stamps);
+                       state, stamps, 0);     // (measured: no gain for this form, and the first round's sleeps cost 20 % at four rounds)
     GT_LAUNCH_CHECK();
     return 0;
+}
+// (GTCRN_STAGGER = "phases,unit" overrides the default for measurements: tools/stream_form_ab.py)
+static int stagger_setting() {
+    static const int v = [] {
+        int ph = 32, unit = 5;
+        if (const char* e = getenv("GTCRN_STAGGER")) {
+            if (sscanf(e, "%d,%d", &ph, &unit) != 2 || ph < 1 || ph > 256 || (ph & (ph - 1)) || unit < 0 || unit > 255) { ph = 32; unit = 5; }
+        }
+        return unit == 0 ? 0 : (ph << 8) | unit;
+    }();
+    return v;
 }
 // the wide form of the same step: SwCfg::NS streams per workgroup (see k_stream_wide)
 int launch_stream_wide(const float* spec, long sb, long sf, float* out, long osb, long osf, int B, const float* PF,
                        const int* PI, float* state, unsigned long long* stamps, hipStream_t s) {
     const int grid = (B + SwCfg::NS - 1) / SwCfg::NS;
+    // from three rounds of workgroups on: 32 start shifts of 5 x 512 clocks (two thirds of a ~118 k-cycle workgroup in all;
+    // swept on the GPU, tools/stagger_sweep.sh -> profiles/r06_ab_stream_wide.txt)
     hipLaunchKernelGGL(k_stream_wide<SwCfg>, dim3(grid), dim3(SwCfg::NT), SW_LDS_FLOATS * 4, s, spec, sb, sf, out, osb, osf, B,
-                       PF, PI, state, stamps);
+                       PF, PI, state, stamps, grid >= 3 * 256 ? stagger_setting() : 0);
     GT_LAUNCH_CHECK();
     return 0;
 }
 int stream_wide_streams() { return SwCfg::NS; }
+
 bool stream_ms_usable(long sb, long osb) {
     const long a = sb < 0 ? -sb : sb, o = osb < 0 ? -osb : osb;
     return 8 * a < (1L << 31) && 8 * o < (1L << 31);     // (row offsets of either form in 32 bits)
