@@ -1411,7 +1411,11 @@ __global__ __launch_bounds__(NTHR) void k_encoder(const float* __restrict__ spec
     const int Tstride = T;
     static_assert(!SPANS || (!MS && !FRONT), "time spans: offline blocks-only form");
     SpanIter sit;
+    #ifdef GT_EXP_SAMEUTT    // timing experiment only (wrong results): every workgroup works on one of eight utterances, so all
+    int s_b = blockIdx.x & 7, s_fb = 0, s_wlo = 0, s_nT = T;   // hand-off traffic hits in L2: the kernels without HBM latency
+#else
     int s_b = blockIdx.x, s_fb = 0, s_wlo = 0, s_nT = T;
+#endif
     if constexpr (SPANS) {     // (`lens` is the PREFIX table of a variable-length batch here, see span_begin)
         if (!span_begin(sit, blockIdx.x, gridDim.x, NB, T, lens)) return;
         span_next(sit, NB, Tstride, lens, HALO_BLOCKS, s_b, s_fb, s_wlo, s_nT);
@@ -2126,7 +2130,11 @@ __global__ __launch_bounds__(NTHR) void k_gtcn(const float* __restrict__ xin, fl
     float* sW = smem + GT_LDS_W;
     const Lane L = lane_info();
     const int tid = L.tid, n = L.n, g = L.g;
+#ifdef GT_EXP_SAMEUTT
+    const int b = blockIdx.x & 7;
+#else
     const int b = blockIdx.x;
+#endif
     copy_params(sP, P, GTCN_SIZE, tid, NTHR);
     float* stb = state ? state + (long)b * ST_FLOATS : nullptr;
     const int tbase = stb ? reinterpret_cast<const int*>(stb)[0] : 0;
@@ -2355,7 +2363,11 @@ __global__ __launch_bounds__(NTHR) void k_gtcn_band(const float* __restrict__ xi
     const Lane L = lane_info();
     const int tid = L.tid, n = L.n, g = L.g;
     SpanIter sit;
+    #ifdef GT_EXP_SAMEUTT    // timing experiment only (wrong results): every workgroup works on one of eight utterances, so all
+    int s_b = blockIdx.x & 7, s_fb = 0, s_wlo = 0, s_nT = T;   // hand-off traffic hits in L2: the kernels without HBM latency
+#else
     int s_b = blockIdx.x, s_fb = 0, s_wlo = 0, s_nT = T;
+#endif
     if constexpr (SPANS) {       // (`lens` is the PREFIX table of a variable-length batch here, see span_begin)
         if (!span_begin(sit, blockIdx.x, gridDim.x, B, T, lens)) return;
     } else {                     // one workgroup per utterance (lens: a variable-length batch, this utterance's frames)
@@ -2595,7 +2607,11 @@ __global__ __launch_bounds__(NTHR) void k_decoder(const float* __restrict__ xg, 
     const int Tstride = T;
     static_assert(!SPANS || (!MS && !Q), "time spans: offline fp32 form");
     SpanIter sit;
+    #ifdef GT_EXP_SAMEUTT    // timing experiment only (wrong results): every workgroup works on one of eight utterances, so all
+    int s_b = blockIdx.x & 7, s_fb = 0, s_wlo = 0, s_nT = T;   // hand-off traffic hits in L2: the kernels without HBM latency
+#else
     int s_b = blockIdx.x, s_fb = 0, s_wlo = 0, s_nT = T;
+#endif
     if constexpr (SPANS) {     // (`lens` is the PREFIX table of a variable-length batch here, see span_begin)
         if (!span_begin(sit, blockIdx.x, gridDim.x, NB, T, lens)) return;
         span_next(sit, NB, Tstride, lens, HALO_BLOCKS, s_b, s_fb, s_wlo, s_nT);
