@@ -515,6 +515,33 @@ def test_stream_form_switch_gives_the_same_bits(dev):
         eng.stream_form(4)
 
 
+def test_staggered_many_round_launch_of_the_wide_step_changes_no_bit(dev):
+    """From three rounds of workgroups on, the first round of a k_stream_wide launch starts phase-staggered (s_sleep before
+    the first instruction: the CUs then do not all ask the HBM for their GTCN rows at once).  5 600 streams = 800 workgroups
+    of seven: outputs and the whole ring state after six frames equal the four-streams-per-workgroup form's (no stagger there)
+    bit for bit."""
+    from gtcrn_micro_amd import Engine
+    eng = Engine(load_params("dns3"), 0)
+    N, T = 5600, 6
+    gen = torch.Generator(device="cuda").manual_seed(56)
+    spec = (torch.randn(N, T, 257, 2, device="cuda", generator=gen) * 0.3).permute(0, 2, 1, 3)
+    res = []
+    for form in (2, 3):
+        st = eng.new_state(N)
+        eng.stream_form(form)
+        try:
+            eng.timing_enable(True)
+            out = torch.cat([eng.stream_step(st, spec[:, :, t:t + 1]) for t in range(T)], 2)
+            torch.cuda.synchronize()
+            names = list(eng.timing_read())
+            eng.timing_enable(False)
+        finally:
+            eng.stream_form(0)
+        res.append((out, st, names))
+    assert res[0][2] == ["k_stream_ms"] and res[1][2] == ["k_stream_wide"]
+    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
+
+
 @pytest.mark.parametrize("which", ["dns3", "rand"])
 def test_wide_single_launch_step_equals_the_narrow_one_and_offline(dev, which):
     """k_stream_wide (seven streams per workgroup, eight waves x two tiles, parameters streamed through LDS by DMA) against

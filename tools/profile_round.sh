@@ -36,6 +36,8 @@ fi
 # configs[2] (1024 streams, single-frame calls) and configs[3] (train step, fp32 and bf16 storage)
 if [ "$WHAT" = all ] || [ "$WHAT" = stream ]; then
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stream" -- python3 "$R/tools/stream_bench.py" > "$OUT/stream.log" 2>&1
+# the seven-streams-per-workgroup form (picked by the library at this count): kernel trace + stats of 65 536 streams
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stream_wide" -- python3 "$R/tools/stream_bench.py" --streams 65536 --frames 24 > "$OUT/stream_wide.log" 2>&1
 # HBM counters of the single-launch streaming step inside and past the Infinity Cache (state 0.16 / 2.5 / 10 GB)
 for N in 1024 16384 65536; do
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$OUT/stream_pmc_${N}_fetch" -- python3 "$R/tools/stream_bench.py" --streams $N --frames 16 > "$OUT/stream_pmc_${N}_fetch.log" 2>&1

@@ -233,7 +233,8 @@ def main():
         if os.path.exists(plain):
             open(os.path.join(dst, f"{tag}_ubench_mfma_valu.txt"), "w").write(open(plain).read())
     # --- streaming / training traces
-    for sub, pats in (("stream", ("k_stream_ms", "k_stream_wide", "k_encoder", "k_gtcn_ms", "k_decoder")), ("train_f32", None), ("train_bf16", None),
+    for sub, pats in (("stream", ("k_stream_ms", "k_stream_wide", "k_encoder", "k_gtcn_ms", "k_decoder")),
+                      ("stream_wide", ("k_stream_ms", "k_stream_wide")), ("train_f32", None), ("train_bf16", None),
                       ("train_bf16_saves", None), ("train_bf16_grads", None)):
         f = newest(sub, "*kernel_stats.csv")
         if not f:
