@@ -220,7 +220,7 @@ int gtcrn_selftest_split3(int device, const float *h_x, long n, float *h_planes,
  * synchronisation inside the timed region).  gtcrn_timing_enable(m,1) clears the record;
  * gtcrn_timing_read returns, for kernel idx in [0, gtcrn_timing_kernels()) -- every timed launch records which
  * kernel it was, so offline and streaming calls keep their own rows (k_front, k_encoder_gt, k_gtcn1, k_gtcn2,
- * k_decoder, k_istft offline; k_stream_ms for single-frame streaming steps; ...) -- its name, the average device time
+ * k_decoder, k_istft offline; k_stream_ms / k_stream_wide for single-frame streaming steps; ...) -- its name, the average device time
  * in ms over the launches recorded since and their count.  idx = -1 - k only returns the name of kernel k (m may be
  * NULL).  on = 2 + idx records events around kernel idx ONLY: every event pair costs a few microseconds of dispatch
  * gap, so the timed region of bench.py keeps just the dominant kernel's.  Used for the roofline line. */
