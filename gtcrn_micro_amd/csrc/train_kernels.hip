@@ -345,7 +345,6 @@ __global__ __launch_bounds__(NT) void k_conv(ConvGeom g, const float* __restrict
     for (long p = (long)blockIdx.x * NT + tid; p < npos; p += (long)gridDim.x * NT) {
         const unsigned pu = (unsigned)p, ubt = pu / uF, ub = ubt / uT;
         const int fo = (int)(pu - ubt * uF);
-        const long bt = ubt;
         const int to = (int)(ubt - ub * uT), b = (int)ub;
         float acc[COUT];
 #pragma unroll
@@ -2290,7 +2289,6 @@ __global__ __launch_bounds__(NT) void k_unit1x1_bwd(ConvGeom g, const float* __r
                                                    float* __restrict__ dx, int dx_acc, float* __restrict__ dres,
                                                    int dres_acc, float* __restrict__ partial, long tiles_per_wave,
                                                    NextRedArgs nx, double* __restrict__ rpartial, FinArgs fa) {
-    constexpr int bf = FMT, ybf = YF;
     __shared__ double sRed[NEXT ? NT / 64 : 1][48];
     f32x4 nmean = {0, 0, 0, 0}, nistd = nmean, ngm = nmean, nbt = nmean;
     float nsl = 0.f, vr[3][4];
