@@ -885,6 +885,8 @@ __device__ __forceinline__ void gtconv_block(f32x4 (&x)[TPW], const Tiles<TPW>& 
                     const int b0 = b0s[i];
                     const int rb = tap_base(i, back, b0);
                     // three fused multiply-adds per component (a sum of products added afterwards costs a fourth op)
+                    // (the side taps from the centre record by DPP row shifts -- 9 instead of 27 reads per wave and block --
+                    // measured SLOWER even without the edge lanes' extra reads: profiles/r06_ab_encoder_dpp.txt)
                     acc[i] += w0 * ld4(c.sW + rb - RS);
                     acc[i] += w1 * ld4(c.sW + rb);
                     acc[i] += w2 * ld4(c.sW + rb + RS);
