@@ -82,6 +82,7 @@ def lib():
     L.gtcrn_debug_enable.argtypes = [_vp, ci]
     L.gtcrn_var_spans_enable.argtypes = [_vp, ci]
     L.gtcrn_stream_form.argtypes = [_vp, ci]
+    L.gtcrn_stream_streams_per_workgroup.argtypes = [ci]
     L.gtcrn_debug_tap.restype = cl
     L.gtcrn_debug_tap.argtypes = [_vp, ctypes.c_char_p, ci, _c_f32p, cl]
     L.gtcrn_debug_stamps.restype = cl
@@ -592,6 +593,12 @@ def f32_to_pcm16(wave, out=None):
         _check(lib().gtcrn_f32_to_pcm16(wave.device.index, ctypes.c_void_p(wave.data_ptr()), ctypes.c_void_p(out.data_ptr()),
                                         int(wave.numel()), _stream_ptr()))
     return out
+
+
+def stream_streams_per_workgroup(nstreams):
+    """Streams per workgroup (4: k_stream_ms, 7: k_stream_wide) of the one-launch step the library picks for `nstreams`
+    single-frame steps (host logic only)."""
+    return _check(lib().gtcrn_stream_streams_per_workgroup(int(nstreams)))
 
 
 def selftest_mfma(device=0):

@@ -644,6 +644,11 @@ int gtcrn_var_spans_enable(gtcrn_model* m, int on) {
     return 0;
 }
 
+int gtcrn_stream_streams_per_workgroup(int nstreams) {
+    if (nstreams < 1) return fail(GTCRN_ERR_ARG, "gtcrn_stream_streams_per_workgroup: nstreams >= 1");
+    return stream_wide_pays(nstreams) ? gtk::stream_wide_streams() : 4;
+}
+
 int gtcrn_stream_form(gtcrn_model* m, int form) {
     int rc = check_model(m);
     if (rc) return rc;

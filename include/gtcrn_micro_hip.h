@@ -194,6 +194,11 @@ int gtcrn_var_spans_enable(gtcrn_model *m, int on);
  * streams per workgroup whatever the count.  Bit-identical outputs and ring state in every form
  * (tests/test_gpu_stream.py); the A/B switch of the capacity measurements. */
 int gtcrn_stream_form(gtcrn_model *m, int form);
+/* Which one-launch form the default (form 0) runs for `nstreams` single-frame steps: the streams per workgroup, 4
+ * (k_stream_ms) or 7 (k_stream_wide).  Pure host logic (no device is touched): both forms run one workgroup per CU, so a
+ * step costs rounds-of-256-workgroups x the form's time per round (32.9 us against ~1.5 x that); the wide form is taken
+ * once the narrow one needs more rounds than it. */
+int gtcrn_stream_streams_per_workgroup(int nstreams);
 long gtcrn_debug_tap(gtcrn_model *m, const char *name, int b, float *h_dst, long cap);
 /* Diagnostic build only (libgtcrn_micro_hip_stamps.so, -DGT_STAMPS): per-workgroup sums of shader
  * cycles spent in each barrier-delimited phase of kernel 0 encoder, 1 gtcn1, 2 gtcn2, 3 decoder,

@@ -29,6 +29,25 @@ def test_abi_exports_every_declared_symbol():
     assert not missing, missing
 
 
+def test_one_launch_streaming_form_is_picked_by_rounds_of_workgroups():
+    """gtcrn_stream_streams_per_workgroup (host logic, no device): both one-launch forms of a single-frame step run one
+    workgroup per CU, so a step costs rounds-of-256-workgroups x the form's time per round; four streams per workgroup
+    (k_stream_ms) while that needs no more rounds than seven (k_stream_wide, 1.5 x the time per round) would, seven from
+    there on.  BASELINE configs[2]'s own 1 024 streams stay one round of the narrow form."""
+    from gtcrn_micro_amd import _lib, GtcrnError
+    f = _lib.stream_streams_per_workgroup
+    assert [f(n) for n in (1, 4, 1000, 1024)] == [4, 4, 4, 4]               # one round either way: the faster round
+    assert f(1025) == 7 and f(1792) == 7                                    # two rounds of four against ONE of seven
+    assert f(2048) == 4                                                     # 512 workgroups of four = 2 rounds; 293 of seven = 2
+    assert f(4096) == 4                                                     # 4 rounds against 3 x 1.5
+    assert all(f(n) == 7 for n in (5376, 8192, 16384, 65536, 262144))
+    for n in range(1, 20000, 37):                                           # the rule itself
+        r4, r7 = -(-(-(-n // 4)) // 256), -(-(-(-n // 7)) // 256)
+        assert f(n) == (7 if r7 * 1.5 < r4 else 4), n
+    with pytest.raises(GtcrnError):
+        f(0)
+
+
 def test_param_table_matches_reference_state_dict():
     from gtcrn_micro_amd import _lib
     man = json.load(open(os.path.join(GOLDEN, "params_manifest.json")))
