@@ -75,7 +75,7 @@ STREAM_STATE_BYTES_PER_FRAME = 94 * 1024        # ring-state traff
 # (round 4: every storage mode, dispatch by dispatch.  The x2 on FETCH_SIZE is calibrated for 16-byte-per-lane reads; the
 # 16-bit tensors are read 8 bytes per lane, for which the guide gives no factor: for the two 16-bit modes the figure
 # below is the UPPER reading, `traffic_lower` the raw one -- the truth lies between)
-ROUND_TAG = "r05"
+ROUND_TAG = "r06"
 
 
 def train_hbm_bytes():
@@ -83,7 +83,7 @@ def train_hbm_bytes():
     (tools/profile_summary.py -> profiles/<tag>_train_hbm_traffic.json; FETCH_SIZE x 2 + WRITE_SIZE: the x 2 holds at 4, 8
     and 16 bytes per lane, profiles/r05_fetch_calibration.json -- ONE figure per mode since round 5).  A constant of the
     profiled build, not of the run that prints it: the source file is named in the line."""
-    for tag in (ROUND_TAG, "r04"):
+    for tag in (ROUND_TAG, "r05", "r04"):
         fn = os.path.join(ROOT, "profiles", f"{tag}_train_hbm_traffic.json")
         try:
             modes = json.load(open(fn)).get("per_storage_mode", {})
@@ -1197,7 +1197,7 @@ def main(argv=None):
         flops_launch = 2.0 * MAC_PER_FRAME[dom] * frames_per_step
         achieved = flops_launch / (dom_ms * 1e-3) / 1e12
         traffic, traffic_source = None, None
-        for tag in (ROUND_TAG, "r04", "r03", "r02", "r01"):
+        for tag in (ROUND_TAG, "r05", "r04", "r03", "r02", "r01"):
             tf = os.path.join(ROOT, "profiles", f"{tag}_hbm_traffic.json")
             if os.path.exists(tf):
                 try:
